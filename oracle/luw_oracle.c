@@ -1,0 +1,472 @@
+/*
+ * luw_oracle.c -- CPU restatement of the reference's D3Q19 hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build/load this file; the
+ * product (latticeurbanwind_amd/csrc) never links, loads or falls back to it.
+ *
+ * What it restates (all citations: /root/reference/core/cfd_core/FluidX3D/src/, "FX/"):
+ *   FP16C codec            FX/kernel.cpp:864-875
+ *   SoA DDF index          FX/kernel.cpp:877-879
+ *   c_i / w_i tables       FX/kernel.cpp:880-919, FX/lbm.cpp:674-676
+ *   neighbours (periodic)  FX/kernel.cpp:920-974
+ *   f_eq                   FX/kernel.cpp:1016-1055
+ *   rho,u moments          FX/kernel.cpp:1075-1100
+ *   Guo forcing            FX/kernel.cpp:1103-1113
+ *   Esoteric-Pull ld/st    FX/kernel.cpp:1338-1351
+ *   initialize             FX/kernel.cpp:1370-1452
+ *   stream_collide         FX/kernel.cpp:1475-1780 (SRT + SUBGRID + VOLUME_FORCE + FORCE_FIELD +
+ *                          EQUILIBRIUM_BOUNDARIES + UPDATE_FIELDS + Coriolis + BUFFER_NUDGING + TOP_SPONGE)
+ *   halo extract/insert    FX/kernel.cpp:2188-2270
+ *   constants baked into the kernel source as 9-digit decimal text: FX/lbm.cpp:626-782,
+ *   FX/utilities.hpp:2603-2634,2741-2750
+ *
+ * Arithmetic contract: FP32 throughout, fmaf() exactly where the reference writes fma(), every other
+ * operation a separately rounded IEEE op (build with -ffp-contract=off), correctly rounded / and sqrtf.
+ * The reference itself is compiled by the OpenCL driver with -cl-mad-enable (FX/opencl.hpp:305), i.e. it
+ * is not bit-defined across compilers; this file fixes one legal evaluation.
+ *
+ * PINNING STATUS: the reference's own tests hold no golden vectors for this path.  The
+ * oracle is pinned instead by (1) known-answer tests in tests/test_oracle_*.py and (2) fields produced by
+ * the REAL reference binary (oracle/_ref/FluidX3D, built by oracle/build_ref.sh) run on an MI355X through
+ * the AMD OpenCL runtime, committed under tests/golden/ref_*; see DESIGN.md "Oracle".
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TYPE_S 0x01
+#define TYPE_E 0x02
+#define TYPE_T 0x04
+#define TYPE_BO 0x03
+#define TYPE_SU 0x38
+#define TYPE_G 0x20
+
+typedef struct LuwOracleCfg {
+	uint32_t Nx, Ny, Nz;          /* local lattice (incl. halo layers when D>1), FX/lbm.cpp:627-629 */
+	uint32_t Dx, Dy, Dz;          /* number of domains per axis, FX/lbm.cpp:633-635 */
+	int32_t Ox, Oy, Oz;           /* global offset of local (0,0,0), FX/lbm.cpp:637-639 */
+	float w;                      /* def_w = 1/tau after the decimal-text round trip, FX/lbm.cpp:664 */
+	float fx, fy, fz;             /* global volume force, FX/lbm.cpp:345 */
+	float omega_x, omega_y, omega_z; /* Coriolis rotation, FX/kernel.cpp:1517-1519 */
+	int32_t fp16c;                /* 0: FP32 DDFs, 1: FP16C DDFs (FX/defines.hpp:13-14) */
+	int32_t subgrid;              /* SUBGRID (always 1 in the shipped build) */
+	int32_t buffer_active;        /* BUFFER_NUDGING, FX/lbm.cpp:771-776 */
+	uint32_t buffer_N;
+	float buffer_inv_tau;
+	int32_t buffer_nudge_vertical;
+	int32_t downstream_face;      /* 0 none, 1 west, 2 east, 3 south, 4 north; FX/setup.cpp:3749-3755 */
+	int32_t sponge_active;        /* TOP_SPONGE with def_sponge_ref_mode==0, FX/lbm.cpp:777-782 */
+	uint32_t sponge_N;
+	float sponge_inv_tau;
+} LuwOracleCfg;
+
+/* ------------------------------------------------------------------ helpers */
+static inline float sq(const float x) { return x*x; }
+static inline uint32_t as_uint(const float x) { uint32_t r; memcpy(&r, &x, 4); return r; }
+static inline float as_float(const uint32_t x) { float r; memcpy(&r, &x, 4); return r; }
+static inline float clampf(const float x, const float a, const float b) { return fminf(fmaxf(x, a), b); } /* OpenCL clamp = min(max(x,a),b) */
+
+/* FX/kernel.cpp:864-869 */
+float luwo_half_to_float_custom(const uint16_t x) {
+	const uint32_t e = ((uint32_t)x&0x7800u)>>11;
+	const uint32_t m = ((uint32_t)x&0x07FFu)<<12;
+	const uint32_t v = as_uint((float)m)>>23;
+	return as_float(((uint32_t)x&0x8000u)<<16 | (uint32_t)(e!=0u)*((e+112u)<<23|m) | (uint32_t)((e==0u)&(m!=0u))*((v-37u)<<23|((m<<(150u-v))&0x007FF000u)));
+}
+/* FX/kernel.cpp:870-875 */
+uint16_t luwo_float_to_half_custom(const float x) {
+	const uint32_t b = as_uint(x)+0x00000800u;
+	const uint32_t e = (b&0x7F800000u)>>23;
+	const uint32_t m = b&0x007FFFFFu;
+	/* note: for e<113 the shift 124-e is evaluated only under the mask (e<113)&(e>100) in effect; keep it in range like the GPU does (shift amount mod 32) */
+	const uint32_t sh = (124u-e)&31u;
+	return (uint16_t)((b&0x80000000u)>>16 | (uint32_t)(e>112u)*((((e-112u)<<11)&0x7800u)|m>>12) | (uint32_t)((e<113u)&(e>100u))*((((0x007FF800u+m)>>sh)+1u)>>1));
+}
+
+/* FX/utilities.hpp:2603-2634 + 2741-2750: to_string(float) as used by device_defines(), then the float
+ * literal is parsed back by the OpenCL compiler.  Returns the float the kernel actually sees. */
+float luwo_literal_roundtrip(float x) {
+	int neg = 0;
+	if(x<0.0f) { neg = 1; x = -x; }
+	if(isnan(x)||isinf(x)) return neg ? -x : x;
+	int exponent = 0;
+	if(x>=10.0f) {
+		if(x>=1E32f) { x *= 1E-32f; exponent += 32; }
+		if(x>=1E16f) { x *= 1E-16f; exponent += 16; }
+		if(x>= 1E8f) { x *=  1E-8f; exponent +=  8; }
+		if(x>= 1E4f) { x *=  1E-4f; exponent +=  4; }
+		if(x>= 1E2f) { x *=  1E-2f; exponent +=  2; }
+		if(x>= 1E1f) { x *=  1E-1f; exponent +=  1; }
+	}
+	if(x>0.0f && x<=1.0f) {
+		if(x<1E-31f) { x *=  1E32f; exponent -= 32; }
+		if(x<1E-15f) { x *=  1E16f; exponent -= 16; }
+		if(x< 1E-7f) { x *=   1E8f; exponent -=  8; }
+		if(x< 1E-3f) { x *=   1E4f; exponent -=  4; }
+		if(x< 1E-1f) { x *=   1E2f; exponent -=  2; }
+		if(x<  1E0f) { x *=   1E1f; exponent -=  1; }
+	}
+	uint32_t integral = (uint32_t)x;
+	const float remainder = (x-(float)integral)*1E8f;
+	uint32_t decimal = (uint32_t)remainder;
+	if(remainder-(float)decimal>=0.5f) {
+		decimal++;
+		if(decimal>=100000000u) {
+			decimal = 0u;
+			integral++;
+			if(integral>=10u) { integral = 1u; exponent++; }
+		}
+	}
+	char text[64];
+	if(exponent!=0) snprintf(text, sizeof(text), "%s%u.%08uE%d", neg?"-":"", integral, decimal, exponent);
+	else snprintf(text, sizeof(text), "%s%u.%08u", neg?"-":"", integral, decimal);
+	return strtof(text, NULL);
+}
+
+/* D3Q19 tables, FX/kernel.cpp:890-893 */
+static const float CX[19] = {0, 1,-1, 0, 0, 0, 0, 1,-1, 1,-1, 0, 0, 1,-1, 1,-1, 0, 0};
+static const float CY[19] = {0, 0, 0, 1,-1, 0, 0, 1,-1, 0, 0, 1,-1,-1, 1, 0, 0, 1,-1};
+static const float CZ[19] = {0, 0, 0, 0, 0, 1,-1, 0, 0, 1,-1, 1,-1, 0, 0,-1, 1,-1, 1};
+#define DEF_W0 (1.0f/3.0f)
+#define DEF_WS (1.0f/18.0f)
+#define DEF_WE (1.0f/36.0f)
+#define DEF_C 0.57735027f
+static inline float wi(const uint32_t i) { return i==0u ? DEF_W0 : (i<7u ? DEF_WS : DEF_WE); }
+
+typedef struct { const LuwOracleCfg* c; uint64_t N; } Ctx;
+
+static inline void coordinates(const LuwOracleCfg* c, const uint64_t n, uint32_t* x, uint32_t* y, uint32_t* z) { /* FX/kernel.cpp:833-836 */
+	const uint64_t NxNy = (uint64_t)c->Nx*(uint64_t)c->Ny;
+	const uint32_t t = (uint32_t)(n%NxNy);
+	*x = t%c->Nx; *y = t/c->Nx; *z = (uint32_t)(n/NxNy);
+}
+static inline uint64_t index3(const LuwOracleCfg* c, const uint32_t x, const uint32_t y, const uint32_t z) { /* FX/kernel.cpp:837-839 */
+	return (uint64_t)x+(uint64_t)(y+z*c->Ny)*(uint64_t)c->Nx;
+}
+static inline int is_halo(const LuwOracleCfg* c, const uint64_t n) { /* FX/kernel.cpp:856-859 */
+	uint32_t x, y, z; coordinates(c, n, &x, &y, &z);
+	return ((c->Dx>1u)&(x==0u||x>=c->Nx-1u))||((c->Dy>1u)&(y==0u||y>=c->Ny-1u))||((c->Dz>1u)&(z==0u||z>=c->Nz-1u));
+}
+static void neighbors(const LuwOracleCfg* c, const uint64_t n, uint64_t* j) { /* FX/kernel.cpp:920-958 */
+	uint32_t x, y, z; coordinates(c, n, &x, &y, &z);
+	const uint64_t Nx = c->Nx, NxNy = (uint64_t)c->Nx*(uint64_t)c->Ny;
+	const uint64_t x0 = x, xp = (x+1u)%c->Nx, xm = (x+c->Nx-1u)%c->Nx;
+	const uint64_t y0 = (uint64_t)y*Nx, yp = (uint64_t)((y+1u)%c->Ny)*Nx, ym = (uint64_t)((y+c->Ny-1u)%c->Ny)*Nx;
+	const uint64_t z0 = (uint64_t)z*NxNy, zp = (uint64_t)((z+1u)%c->Nz)*NxNy, zm = (uint64_t)((z+c->Nz-1u)%c->Nz)*NxNy;
+	j[0] = n;
+	j[ 1] = xp+y0+z0; j[ 2] = xm+y0+z0;
+	j[ 3] = x0+yp+z0; j[ 4] = x0+ym+z0;
+	j[ 5] = x0+y0+zp; j[ 6] = x0+y0+zm;
+	j[ 7] = xp+yp+z0; j[ 8] = xm+ym+z0;
+	j[ 9] = xp+y0+zp; j[10] = xm+y0+zm;
+	j[11] = x0+yp+zp; j[12] = x0+ym+zm;
+	j[13] = xp+ym+z0; j[14] = xm+yp+z0;
+	j[15] = xp+y0+zm; j[16] = xm+y0+zp;
+	j[17] = x0+yp+zm; j[18] = x0+ym+zp;
+}
+
+static inline float load_fi(const LuwOracleCfg* c, const void* fi, const uint64_t idx) { /* FX/lbm.cpp:706-721 */
+	return c->fp16c ? luwo_half_to_float_custom(((const uint16_t*)fi)[idx]) : ((const float*)fi)[idx];
+}
+static inline void store_fi(const LuwOracleCfg* c, void* fi, const uint64_t idx, const float v) {
+	if(c->fp16c) ((uint16_t*)fi)[idx] = luwo_float_to_half_custom(v); else ((float*)fi)[idx] = v;
+}
+static void load_f(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, float* fhn, const void* fi, const uint64_t* j, const uint64_t t) { /* FX/kernel.cpp:1338-1344 */
+	fhn[0] = load_fi(c, fi, n);
+	for(uint32_t i=1u; i<19u; i+=2u) {
+		fhn[i   ] = load_fi(c, fi, (uint64_t)(t%2ull ? i    : i+1u)*N+n);
+		fhn[i+1u] = load_fi(c, fi, (uint64_t)(t%2ull ? i+1u : i   )*N+j[i]);
+	}
+}
+static void store_f(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, const float* fhn, void* fi, const uint64_t* j, const uint64_t t) { /* FX/kernel.cpp:1345-1351 */
+	store_fi(c, fi, n, fhn[0]);
+	for(uint32_t i=1u; i<19u; i+=2u) {
+		store_fi(c, fi, (uint64_t)(t%2ull ? i+1u : i   )*N+j[i], fhn[i   ]);
+		store_fi(c, fi, (uint64_t)(t%2ull ? i    : i+1u)*N+n   , fhn[i+1u]);
+	}
+}
+
+void luwo_calculate_f_eq(const float rho, float ux, float uy, float uz, float* feq) { /* FX/kernel.cpp:1016-1055 */
+	const float rhom1 = rho-1.0f;
+	const float c3 = -3.0f*(sq(ux)+sq(uy)+sq(uz));
+	uz *= 3.0f;
+	ux *= 3.0f;
+	uy *= 3.0f;
+	feq[ 0] = DEF_W0*fmaf(rho, 0.5f*c3, rhom1);
+	const float u0=ux+uy, u1=ux+uz, u2=uy+uz, u3=ux-uy, u4=ux-uz, u5=uy-uz;
+	const float rhos=DEF_WS*rho, rhoe=DEF_WE*rho, rhom1s=DEF_WS*rhom1, rhom1e=DEF_WE*rhom1;
+	feq[ 1] = fmaf(rhos, fmaf(0.5f, fmaf(ux, ux, c3), ux), rhom1s); feq[ 2] = fmaf(rhos, fmaf(0.5f, fmaf(ux, ux, c3), -ux), rhom1s);
+	feq[ 3] = fmaf(rhos, fmaf(0.5f, fmaf(uy, uy, c3), uy), rhom1s); feq[ 4] = fmaf(rhos, fmaf(0.5f, fmaf(uy, uy, c3), -uy), rhom1s);
+	feq[ 5] = fmaf(rhos, fmaf(0.5f, fmaf(uz, uz, c3), uz), rhom1s); feq[ 6] = fmaf(rhos, fmaf(0.5f, fmaf(uz, uz, c3), -uz), rhom1s);
+	feq[ 7] = fmaf(rhoe, fmaf(0.5f, fmaf(u0, u0, c3), u0), rhom1e); feq[ 8] = fmaf(rhoe, fmaf(0.5f, fmaf(u0, u0, c3), -u0), rhom1e);
+	feq[ 9] = fmaf(rhoe, fmaf(0.5f, fmaf(u1, u1, c3), u1), rhom1e); feq[10] = fmaf(rhoe, fmaf(0.5f, fmaf(u1, u1, c3), -u1), rhom1e);
+	feq[11] = fmaf(rhoe, fmaf(0.5f, fmaf(u2, u2, c3), u2), rhom1e); feq[12] = fmaf(rhoe, fmaf(0.5f, fmaf(u2, u2, c3), -u2), rhom1e);
+	feq[13] = fmaf(rhoe, fmaf(0.5f, fmaf(u3, u3, c3), u3), rhom1e); feq[14] = fmaf(rhoe, fmaf(0.5f, fmaf(u3, u3, c3), -u3), rhom1e);
+	feq[15] = fmaf(rhoe, fmaf(0.5f, fmaf(u4, u4, c3), u4), rhom1e); feq[16] = fmaf(rhoe, fmaf(0.5f, fmaf(u4, u4, c3), -u4), rhom1e);
+	feq[17] = fmaf(rhoe, fmaf(0.5f, fmaf(u5, u5, c3), u5), rhom1e); feq[18] = fmaf(rhoe, fmaf(0.5f, fmaf(u5, u5, c3), -u5), rhom1e);
+}
+
+void luwo_calculate_rho_u(const float* f, float* rhon, float* uxn, float* uyn, float* uzn) { /* FX/kernel.cpp:1075-1100 */
+	float rho=f[0], ux, uy, uz;
+	for(uint32_t i=1u; i<19u; i++) rho += f[i];
+	rho += 1.0f;
+	ux = f[ 1]-f[ 2]+f[ 7]-f[ 8]+f[ 9]-f[10]+f[13]-f[14]+f[15]-f[16];
+	uy = f[ 3]-f[ 4]+f[ 7]-f[ 8]+f[11]-f[12]+f[14]-f[13]+f[17]-f[18];
+	uz = f[ 5]-f[ 6]+f[ 9]-f[10]+f[11]-f[12]+f[16]-f[15]+f[18]-f[17];
+	*rhon = rho;
+	*uxn = ux/rho;
+	*uyn = uy/rho;
+	*uzn = uz/rho;
+}
+
+static void calculate_forcing_terms(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, float* Fin) { /* FX/kernel.cpp:1103-1113 */
+	const float uF = -0.33333334f*fmaf(ux, fx, fmaf(uy, fy, uz*fz));
+	Fin[0] = 9.0f*DEF_W0*uF;
+	for(uint32_t i=1u; i<19u; i++) {
+		Fin[i] = 9.0f*wi(i)*fmaf(CX[i]*fx+CY[i]*fy+CZ[i]*fz, CX[i]*ux+CY[i]*uy+CZ[i]*uz+0.33333334f, uF);
+	}
+}
+
+/* FX/kernel.cpp:1370-1452 (no SURFACE / MOVING_BOUNDARIES / TEMPERATURE part) */
+void luwo_initialize(const LuwOracleCfg* c, void* fi, const float* rho, float* u, const uint8_t* flags) {
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	#pragma omp parallel for schedule(static)
+	for(int64_t nn=0; nn<(int64_t)N; nn++) {
+		const uint64_t n = (uint64_t)nn;
+		if(is_halo(c, n)) continue;
+		const uint8_t flagsn_bo = flags[n]&TYPE_BO;
+		uint64_t j[19];
+		neighbors(c, n, j);
+		if(flagsn_bo==TYPE_S) { /* both branches of FX/kernel.cpp:1386-1399 end with u=0 on solid cells */
+			u[n] = 0.0f; u[N+n] = 0.0f; u[2ull*N+n] = 0.0f;
+		}
+		float feq[19];
+		luwo_calculate_f_eq(rho[n], u[n], u[N+n], u[2ull*N+n], feq);
+		store_f(c, N, n, feq, fi, j, 1ull);
+	}
+}
+
+/* FX/kernel.cpp:1475-1780 for one cell */
+static void stream_collide_cell(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t) {
+	if(is_halo(c, n)) return;
+	const uint8_t flagsn = flags[n];
+	const uint8_t flagsn_bo = flagsn&TYPE_BO, flagsn_su = flagsn&TYPE_SU;
+	if(flagsn_bo==TYPE_S||flagsn_su==TYPE_G) return;
+
+	uint64_t j[19];
+	neighbors(c, n, j);
+	float fhn[19];
+	load_f(c, N, n, fhn, fi, j, t);
+
+	float rhon, uxn, uyn, uzn;
+	if(flagsn_bo==TYPE_E) {
+		rhon = rho[n];
+		uxn = u[n];
+		uyn = u[N+n];
+		uzn = u[2ull*N+n];
+	} else {
+		luwo_calculate_rho_u(fhn, &rhon, &uxn, &uyn, &uzn);
+	}
+	float fxn = c->fx, fyn = c->fy, fzn = c->fz;
+	const float cor_x = -2.0f*rhon*(c->omega_y*uzn-c->omega_z*uyn);
+	const float cor_y = -2.0f*rhon*(c->omega_z*uxn-c->omega_x*uzn);
+	const float cor_z = -2.0f*rhon*(c->omega_x*uyn-c->omega_y*uxn);
+	fxn += cor_x;
+	fyn += cor_y;
+	fzn += cor_z;
+
+	/* derived face constants, FX/lbm.cpp:613-625 */
+	const uint32_t Nx_global = (c->Nx-2u*(c->Dx>1u))*c->Dx;
+	const uint32_t Ny_global = (c->Ny-2u*(c->Dy>1u))*c->Dy;
+	const uint32_t Nz_global = (c->Nz-2u*(c->Dz>1u))*c->Dz;
+	const int west_local_x = -c->Ox;
+	const int east_local_x = (int)Nx_global-1-c->Ox;
+	const int south_local_y = -c->Oy;
+	const int north_local_y = (int)Ny_global-1-c->Oy;
+	const int top_local_z = (int)Nz_global-1-c->Oz;
+	const int has_west_face = west_local_x>=0&&west_local_x<(int)c->Nx ? 1 : 0;
+	const int has_east_face = east_local_x>=0&&east_local_x<(int)c->Nx ? 1 : 0;
+	const int has_south_face = south_local_y>=0&&south_local_y<(int)c->Ny ? 1 : 0;
+	const int has_north_face = north_local_y>=0&&north_local_y<(int)c->Ny ? 1 : 0;
+	const int has_top_face = top_local_z>=0&&top_local_z<(int)c->Nz ? 1 : 0;
+
+	if(c->buffer_active) { /* FX/kernel.cpp:1523-1595 */
+		if(flagsn_bo!=TYPE_E) {
+			uint32_t x, y, z; coordinates(c, n, &x, &y, &z);
+			const int xg = (int)x+c->Ox;
+			const int yg = (int)y+c->Oy;
+			const int zg = (int)z+c->Oz;
+			const int Nbuf_i = (int)c->buffer_N;
+			const int d_w_i = xg;
+			const int d_e_i = (int)(Nx_global-1u)-xg;
+			const int d_s_i = yg;
+			const int d_n_i = (int)(Ny_global-1u)-yg;
+			const int d_t_i = (int)(Nz_global-1u)-zg;
+			const int in_w = c->downstream_face!=1&&has_west_face==1&&d_w_i>=0&&d_w_i<=Nbuf_i;
+			const int in_e = c->downstream_face!=2&&has_east_face==1&&d_e_i>=0&&d_e_i<=Nbuf_i;
+			const int in_s = c->downstream_face!=3&&has_south_face==1&&d_s_i>=0&&d_s_i<=Nbuf_i;
+			const int in_n = c->downstream_face!=4&&has_north_face==1&&d_n_i>=0&&d_n_i<=Nbuf_i;
+			const int in_t = has_top_face==1&&d_t_i>=0&&d_t_i<=Nbuf_i;
+			if(in_w||in_e||in_s||in_n||in_t) {
+				uint32_t d_min = c->buffer_N+1u;
+				uint64_t n_ref = n;
+				if(in_w) { const uint32_t d = (uint32_t)d_w_i; if(d<d_min) { d_min = d; n_ref = index3(c, (uint32_t)west_local_x, y, z); } }
+				if(in_e) { const uint32_t d = (uint32_t)d_e_i; if(d<d_min) { d_min = d; n_ref = index3(c, (uint32_t)east_local_x, y, z); } }
+				if(in_s) { const uint32_t d = (uint32_t)d_s_i; if(d<d_min) { d_min = d; n_ref = index3(c, x, (uint32_t)south_local_y, z); } }
+				if(in_n) { const uint32_t d = (uint32_t)d_n_i; if(d<d_min) { d_min = d; n_ref = index3(c, x, (uint32_t)north_local_y, z); } }
+				if(in_t) { const uint32_t d = (uint32_t)d_t_i; if(d<d_min) { d_min = d; n_ref = index3(c, x, y, (uint32_t)top_local_z); } }
+				const float xi = 1.0f-(float)d_min/(float)c->buffer_N;
+				float w_buf = sinf(1.5707963267948966f*xi);
+				w_buf *= w_buf;
+				const float u_target_x = u[n_ref];
+				const float u_target_y = u[N+n_ref];
+				const float u_target_z = u[2ull*N+n_ref];
+				const float a_x = w_buf*c->buffer_inv_tau*(u_target_x-uxn);
+				const float a_y = w_buf*c->buffer_inv_tau*(u_target_y-uyn);
+				const float a_z = c->buffer_nudge_vertical==1 ? w_buf*c->buffer_inv_tau*(u_target_z-uzn) : 0.0f;
+				fxn += rhon*a_x;
+				fyn += rhon*a_y;
+				fzn += rhon*a_z;
+			}
+		}
+	}
+	if(c->sponge_active) { /* FX/kernel.cpp:1596-1614 */
+		if(flagsn_bo!=TYPE_E&&has_top_face==1) {
+			uint32_t x, y, z; coordinates(c, n, &x, &y, &z);
+			const int d_t_i = (int)(Nz_global-2u)-((int)z+c->Oz);
+			const int Nsponge_i = (int)c->sponge_N;
+			if(d_t_i>=0&&d_t_i<Nsponge_i) {
+				const float xi = Nsponge_i>1 ? 1.0f-(float)d_t_i/(float)(Nsponge_i-1) : 1.0f;
+				float sigma = sinf(1.5707963267948966f*xi);
+				sigma = c->sponge_inv_tau*sigma*sigma;
+				const uint64_t n_ref = index3(c, x, y, (uint32_t)top_local_z);
+				fxn += rhon*sigma*(u[n_ref]-uxn);
+				fyn += rhon*sigma*(u[N+n_ref]-uyn);
+				fzn += rhon*sigma*(u[2ull*N+n_ref]-uzn);
+			}
+		}
+	}
+
+	float Fin[19];
+	if(F) { /* FORCE_FIELD, FX/kernel.cpp:1617-1623 */
+		fxn += F[n];
+		fyn += F[N+n];
+		fzn += F[2ull*N+n];
+	}
+	{ /* VOLUME_FORCE, FX/kernel.cpp:1686-1692 */
+		const float rho2 = 0.5f/rhon;
+		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
+		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
+		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
+		calculate_forcing_terms(uxn, uyn, uzn, fxn, fyn, fzn, Fin);
+	}
+	if(flagsn_bo!=TYPE_E) { /* UPDATE_FIELDS, FX/kernel.cpp:1709-1716 */
+		rho[n] = rhon;
+		u[n] = uxn;
+		u[N+n] = uyn;
+		u[2ull*N+n] = uzn;
+	}
+	float feq[19];
+	luwo_calculate_f_eq(rhon, uxn, uyn, uzn, feq);
+	float w = c->w;
+	if(c->subgrid) { /* FX/kernel.cpp:1723-1737 */
+		const float tau0 = 1.0f/w;
+		float Hxx=0.0f, Hyy=0.0f, Hzz=0.0f, Hxy=0.0f, Hxz=0.0f, Hyz=0.0f;
+		for(uint32_t i=1u; i<19u; i++) {
+			const float fneqi = fhn[i]-feq[i];
+			const float cxi=CX[i], cyi=CY[i], czi=CZ[i];
+			Hxx += cxi*cxi*fneqi;
+			Hxy += cxi*cyi*fneqi; Hyy += cyi*cyi*fneqi;
+			Hxz += cxi*czi*fneqi; Hyz += cyi*czi*fneqi; Hzz += czi*czi*fneqi;
+		}
+		const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
+		w = 2.0f/(tau0+sqrtf(sq(tau0)+0.76421222f*sqrtf(Q)/rhon));
+	}
+	const float c_tau = fmaf(w, -0.5f, 1.0f); /* FX/kernel.cpp:1741-1742 */
+	for(uint32_t i=0u; i<19u; i++) Fin[i] *= c_tau;
+	for(uint32_t i=0u; i<19u; i++) fhn[i] = flagsn_bo==TYPE_E ? feq[i] : fmaf(1.0f-w, fhn[i], fmaf(w, feq[i], Fin[i])); /* FX/kernel.cpp:1747 */
+	store_f(c, N, n, fhn, fi, j, t);
+}
+
+void luwo_stream_collide(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t) {
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	#pragma omp parallel for schedule(static)
+	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t);
+}
+
+/* LBM::run for a single domain: FX/lbm.cpp:1262-1312 (t increments after each stream_collide) */
+void luwo_run(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t0, const uint64_t steps) {
+	for(uint64_t t=t0; t<t0+steps; t++) luwo_stream_collide(c, fi, rho, u, flags, F, t);
+}
+
+/* ------------------------------------------------------------------ halo transfer, FX/kernel.cpp:2188-2270 */
+static const uint8_t INDEX_TRANSFER[30] = { /* FX/kernel.cpp:2223-2229 */
+	1,  7, 13,  9, 15,
+	2,  8, 14, 10, 16,
+	3,  7, 14, 11, 17,
+	4,  8, 13, 12, 18,
+	5,  9, 16, 11, 18,
+	6, 10, 15, 12, 17
+};
+uint64_t luwo_get_area(const LuwOracleCfg* c, const uint32_t direction) {
+	const uint64_t A[3] = { (uint64_t)c->Ny*c->Nz, (uint64_t)c->Nz*c->Nx, (uint64_t)c->Nx*c->Ny };
+	return A[direction];
+}
+static uint64_t index_face(const LuwOracleCfg* c, const uint32_t a, const uint32_t direction, const uint32_t fixed) { /* FX/kernel.cpp:2192-2207 */
+	if(direction==0u) return index3(c, fixed, a%c->Ny, a/c->Ny);
+	if(direction==1u) return index3(c, a/c->Nz, fixed, a%c->Nz);
+	return index3(c, a%c->Nx, a/c->Nx, fixed);
+}
+static inline uint32_t Ndir(const LuwOracleCfg* c, const uint32_t direction) { return direction==0u ? c->Nx : direction==1u ? c->Ny : c->Nz; }
+
+static void copy_ddf(const LuwOracleCfg* c, void* dst, const uint64_t di, const void* src, const uint64_t si) { /* fpxx_copy: raw bits */
+	if(c->fp16c) ((uint16_t*)dst)[di] = ((const uint16_t*)src)[si]; else ((float*)dst)[di] = ((const float*)src)[si];
+}
+void luwo_transfer_extract_fi(const LuwOracleCfg* c, const uint32_t direction, const uint64_t t, void* buf_p, void* buf_m, const void* fi) { /* FX/kernel.cpp:2241-2249,2259-2264 */
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	const uint64_t A = luwo_get_area(c, direction);
+	for(uint64_t a=0; a<A; a++) {
+		for(uint32_t pm=0u; pm<2u; pm++) {
+			const uint64_t n = index_face(c, (uint32_t)a, direction, pm==0u ? Ndir(c, direction)-2u : 1u);
+			const uint32_t side = 2u*direction+pm;
+			uint64_t j[19]; neighbors(c, n, j);
+			for(uint32_t b=0u; b<5u; b++) {
+				const uint32_t i = INDEX_TRANSFER[side*5u+b];
+				const uint64_t idx = (uint64_t)(t%2ull ? (i%2u ? i+1u : i-1u) : i)*N+(i%2u ? j[i] : n);
+				copy_ddf(c, pm==0u ? buf_p : buf_m, b*A+a, fi, idx);
+			}
+		}
+	}
+}
+void luwo_transfer_insert_fi(const LuwOracleCfg* c, const uint32_t direction, const uint64_t t, const void* buf_p, const void* buf_m, void* fi) { /* FX/kernel.cpp:2250-2258,2265-2270 */
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	const uint64_t A = luwo_get_area(c, direction);
+	for(uint64_t a=0; a<A; a++) {
+		for(uint32_t pm=0u; pm<2u; pm++) {
+			const uint64_t n = index_face(c, (uint32_t)a, direction, pm==0u ? Ndir(c, direction)-1u : 0u);
+			const uint32_t side = 2u*direction+pm;
+			uint64_t j[19]; neighbors(c, n, j);
+			for(uint32_t b=0u; b<5u; b++) {
+				const uint32_t i = INDEX_TRANSFER[side*5u+b];
+				const uint64_t idx = (uint64_t)(t%2ull ? i : (i%2u ? i+1u : i-1u))*N+(i%2u ? n : j[i-1u]);
+				copy_ddf(c, fi, idx, pm==0u ? buf_p : buf_m, b*A+a);
+			}
+		}
+	}
+}
+
+/* update_fields equivalent for checks: rho,u of a cell straight from the stored DDFs at time t, no forcing.
+ * (used by tests for conservation checks; mirrors load_f + calculate_rho_u) */
+void luwo_moments(const LuwOracleCfg* c, const void* fi, const uint64_t t, float* rho_out, float* u_out) {
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	#pragma omp parallel for schedule(static)
+	for(int64_t nn=0; nn<(int64_t)N; nn++) {
+		const uint64_t n = (uint64_t)nn;
+		uint64_t j[19]; neighbors(c, n, j);
+		float fhn[19]; load_f(c, N, n, fhn, fi, j, t);
+		float r, ux, uy, uz; luwo_calculate_rho_u(fhn, &r, &ux, &uy, &uz);
+		rho_out[n] = r; u_out[n] = ux; u_out[N+n] = uy; u_out[2ull*N+n] = uz;
+	}
+}
