@@ -1,0 +1,149 @@
+/*
+ * luw_core.h -- C-ABI of the MI355X-native D3Q19 lattice-Boltzmann core that replaces the reference's
+ * in-process solver API (class LBM / LBM_Domain of the LUW-modified FluidX3D).
+ *
+ * The reference has no FFI: its driver (FX/setup.cpp main_setup) talks to the solver through the C++ class
+ * `LBM` (FX/lbm.hpp:223-633).  Every entry point below names the reference member it replaces; a
+ * maintainer swaps `LBM` for the thin C++ mirror in latticeurbanwind_amd/host/lbm.hpp (same member names)
+ * which forwards to this ABI -- see INTEGRATION.md.   ("FX/" = core/cfd_core/FluidX3D/src/ of the reference.)
+ *
+ * Conventions: plain C, no torch / HIP types in signatures (streams travel as void*), every function
+ * returns LUW_OK (0) or a negative error code and records a message readable with luw_last_error().
+ * A solver handle is not re-entrant; different handles may be driven from different host threads.
+ * All arrays use the reference's global cell index n = x + (y + z*Ny)*Nx (FX/lbm.hpp:512-514) and its
+ * SoA field layout: rho[N], u[3N] = ux[N] uy[N] uz[N], flags[N], F[3N] (FX/lbm.cpp:283-294).
+ */
+#ifndef LUW_CORE_H
+#define LUW_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUW_ABI_VERSION 1
+
+/* error codes */
+#define LUW_OK 0
+#define LUW_ERR_INVALID (-1)     /* bad argument / configuration (reference: print_error + exit(1)) */
+#define LUW_ERR_DEVICE (-2)      /* HIP runtime error */
+#define LUW_ERR_STATE (-3)       /* call order violated (e.g. run before initialize) */
+#define LUW_ERR_NOMEM (-4)
+
+/* cell flags, FX/defines.hpp:50-57 */
+#define LUW_TYPE_S 0x01
+#define LUW_TYPE_E 0x02
+#define LUW_TYPE_T 0x04
+#define LUW_TYPE_X 0x40
+#define LUW_TYPE_Y 0x80
+
+/* fields (luw_host_ptr / luw_device_ptr) and field masks (luw_upload / luw_download) */
+#define LUW_FIELD_RHO 0
+#define LUW_FIELD_U 1
+#define LUW_FIELD_FLAGS 2
+#define LUW_FIELD_F 3
+#define LUW_FIELD_FI 4           /* device only: DDFs, 19 planes */
+#define LUW_MASK_RHO (1u<<LUW_FIELD_RHO)
+#define LUW_MASK_U (1u<<LUW_FIELD_U)
+#define LUW_MASK_FLAGS (1u<<LUW_FIELD_FLAGS)
+#define LUW_MASK_F (1u<<LUW_FIELD_F)
+
+/* DDF storage formats: compile-time `#define FP16C` in the reference (FX/defines.hpp:13-14), a run-time
+ * choice here */
+#define LUW_DDF_FP32 0
+#define LUW_DDF_FP16C 1
+
+/* option bits */
+#define LUW_OPT_FORCE_FIELD 0x1u        /* allocate + read the per-cell force F (FORCE_FIELD, FX/kernel.cpp:1617-1623) */
+#define LUW_OPT_UPDATE_FIELDS_EVERY_STEP 0x2u /* write rho,u in every step exactly like UPDATE_FIELDS (FX/kernel.cpp:1709-1716);
+                                           without it rho,u are written by the last step of each luw_run() call and on
+                                           luw_download(), which yields identical values whenever they are observed */
+#define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
+
+/* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
+#define LUW_KERNEL_AUTO 0
+#define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, dword accesses */
+#define LUW_KERNEL_VEC4 2               /* 4 cells / lane, 16-byte accesses, wave64 lane shifts for x+1 populations */
+
+typedef struct luw_config {
+	uint32_t struct_size;            /* = sizeof(luw_config), ABI check */
+	uint32_t Nx, Ny, Nz;             /* LOCAL lattice of this domain incl. halo layers on split axes; LBM_Domain ctor FX/lbm.cpp:246-249 */
+	uint32_t Dx, Dy, Dz;             /* domains per axis (n_gpu deck key), FX/lbm.hpp:444 */
+	int32_t Ox, Oy, Oz;              /* global offset of local cell (0,0,0), FX/lbm.cpp:1072 */
+	float nu;                        /* kinematic viscosity in lattice units; w = 1/(3 nu + 1/2) is derived exactly as FX/lbm.cpp:664 */
+	float fx, fy, fz;                /* global volume force, LBM ctor / set_f(), FX/lbm.hpp:492-495 */
+	float omega_x, omega_y, omega_z; /* LBM::set_coriolis, FX/lbm.hpp:496-498 */
+	uint32_t ddf_format;             /* LUW_DDF_* */
+	uint32_t options;                /* LUW_OPT_* */
+	/* process-global solver configuration the reference bakes into the kernel source, FX/lbm.cpp:770-782 */
+	int32_t buffer_nudging_active;   /* buffer_nudging_active */
+	uint32_t buffer_n_cells;         /* buffer_n_cells */
+	float buffer_inv_tau_lbmu;       /* buffer_inv_tau_lbmu */
+	int32_t buffer_nudge_vertical;   /* buffer_nudge_vertical */
+	int32_t buffer_downstream_face_id; /* 0 none, 1 west, 2 east, 3 south, 4 north */
+	int32_t top_sponge_active;       /* top_sponge_active (sponge_ref_mode 0 only) */
+	uint32_t sponge_n_cells;         /* sponge_n_cells */
+	float sponge_inv_tau_lbmu;       /* sponge_inv_tau_lbmu */
+	int32_t device;                  /* HIP device ordinal */
+	uint32_t kernel;                 /* LUW_KERNEL_* */
+} luw_config;
+
+typedef struct luw_solver luw_solver;
+
+/* library */
+int luw_abi_version(void);
+const char* luw_last_error(void);
+int luw_device_count(int* count);            /* smart_device_selection's enumeration, FX/lbm.cpp:947-979 */
+
+/* life cycle: LBM::LBM (FX/lbm.cpp:1057-1112) / LBM::~LBM */
+int luw_create(const luw_config* cfg, luw_solver** out);
+void luw_destroy(luw_solver* s);
+
+/* host mirrors owned by the solver: lbm.rho[n], lbm.u.x/y/z[n], lbm.flags[n], lbm.F (FX/lbm.hpp:428-433).
+ * Returns NULL for fields that do not exist.  rho is pre-filled with 1.0f (FX/lbm.cpp:286). */
+void* luw_host_ptr(luw_solver* s, int field);
+uint64_t luw_get_N(const luw_solver* s);     /* LBM_Domain::get_N */
+
+/* Memory_Container::write_to_device / read_from_device, FX/lbm.hpp:406-416 */
+int luw_upload(luw_solver* s, uint32_t field_mask);
+int luw_download(luw_solver* s, uint32_t field_mask);
+
+/* LBM::run(0): upload rho,u,flags,F + initialize kernel, t = 0 (FX/lbm.cpp:1221-1260, FX/kernel.cpp:1370-1452) */
+int luw_initialize(luw_solver* s);
+/* LBM::run(steps): `steps` x { stream_collide; t++ } (FX/lbm.cpp:1262-1312), returns after the device finished */
+int luw_run(luw_solver* s, uint64_t steps);
+uint64_t luw_get_t(const luw_solver* s);     /* LBM::get_t */
+
+/* run-time setters the reference allows between steps at no cost (kernel arguments, FX/lbm.cpp:345) */
+int luw_set_f(luw_solver* s, float fx, float fy, float fz);               /* LBM::set_f */
+int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz);        /* LBM::set_coriolis */
+
+/* ---- device-level interface for callers that own streams (multi-GPU driver, on-device inlet updaters) ---- */
+/* device buffer handles, the analogue of lbm_domain[d]->u etc. (FX/setup.cpp:1085).  Device layout: x-pitch
+ * luw_get_pitch() (>= Nx), index x + (y + z*Ny)*pitch, plane stride luw_get_plane_stride(). */
+void* luw_device_ptr(luw_solver* s, int field);
+uint32_t luw_get_pitch(const luw_solver* s);
+uint64_t luw_get_plane_stride(const luw_solver* s);
+int luw_set_stream(luw_solver* s, void* hip_stream);                      /* stream used by all enqueue calls; NULL = solver's own */
+/* enqueue ONE stream_collide over the box [x0,x1) x [y0,y1) x [z0,z1) of local cells at the current t, without
+ * incrementing t and without host synchronisation (interior / boundary-shell split of the multi-GPU driver).
+ * write_fields != 0 also stores rho,u. */
+int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, int write_fields);
+int luw_increment_time_step(luw_solver* s, uint64_t steps);               /* LBM_Domain::increment_time_step */
+/* halo transfer of the 5 outgoing DDFs per face cell: transfer_extract_fi / transfer__insert_fi
+ * (FX/kernel.cpp:2241-2270).  direction 0/1/2 = x/y/z.  Buffers are DEVICE pointers holding 5*A elements of
+ * the DDF storage type, A = luw_get_area(direction), element (b*A + a) as in the reference. */
+uint64_t luw_get_area(const luw_solver* s, uint32_t direction);           /* LBM_Domain::get_area */
+int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p, void* dev_buffer_m);
+int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* dev_buffer_p, const void* dev_buffer_m);
+int luw_finish(luw_solver* s);                                            /* LBM_Domain::finish_queue */
+
+/* measurement helper for bench.py: runs `steps` steps like luw_run and returns the mean duration of the
+ * stream_collide kernel in milliseconds, taken with HIP events on the launch stream. */
+int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUW_CORE_H */

@@ -1,0 +1,247 @@
+// luw_device.hpp -- device-side building blocks of the D3Q19 collide-stream step for gfx950 (wave64).
+//
+// What is computed follows the reference kernel `stream_collide` (FX/kernel.cpp:1475-1780, with the
+// device functions it calls: f_eq :1016-1055, moments :1075-1100, Guo forcing :1103-1113, FP16C codec
+// :864-875).  HOW it is computed is ours: coordinates come from the launch geometry (no div/mod per cell),
+// the sin^2 ramps of the nudging/sponge terms come from host-built tables, DDFs are addressed as per-plane
+// base pointer + 32-bit cell offset, and the vector kernels move 4 cells per lane.
+//
+// Arithmetic contract (shared with the CPU oracle used by the tests): FP32, fmaf() exactly where the
+// reference writes fma(), every other operation individually rounded (this translation unit is compiled with
+// -ffp-contract=off), IEEE-correct division and square root (hipcc default).  Zero-valued terms of the
+// c_i-weighted sums are dropped: adding (+-0) never changes a value, so results are value-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace luw {
+
+constexpr float DEF_W0 = 1.0f/3.0f;   // FX/lbm.cpp:674-676
+constexpr float DEF_WS = 1.0f/18.0f;
+constexpr float DEF_WE = 1.0f/36.0f;
+constexpr float DEF_C = 0.57735027f;  // FX/lbm.cpp:663
+
+constexpr uint8_t TYPE_S = 0x01, TYPE_E = 0x02, TYPE_BO = 0x03, TYPE_SU = 0x38, TYPE_G = 0x20;
+
+// Everything the kernels need besides the big arrays; passed by value (lands in SGPRs).
+struct KParams {
+	uint32_t Nx, Ny, Nz;      // local lattice
+	uint32_t Px;              // x pitch of every device array (multiple of 4, >= Nx)
+	uint32_t Np;              // plane stride = Px*Ny*Nz (< 2^32, checked on the host)
+	uint32_t halo_x, halo_y, halo_z; // 1 if that axis is split over domains (cells 0 and N-1 are halo: FX/kernel.cpp:856-859)
+	int32_t Ox, Oy, Oz;
+	float w;                  // def_w
+	float fx, fy, fz;
+	float omx, omy, omz;
+	uint32_t subgrid;
+	// BUFFER_NUDGING / TOP_SPONGE, FX/lbm.cpp:613-625,770-782
+	uint32_t buffer_active, buffer_N, nudge_vertical, downstream_face;
+	float buffer_inv_tau;
+	uint32_t sponge_active, sponge_N;
+	uint32_t Nxg, Nyg, Nzg;   // global extents
+	int32_t west_x, east_x, south_y, north_y, top_z;   // local coordinates of the global outer faces
+	uint32_t has_w, has_e, has_s, has_n, has_t;
+	const float* wbuf;        // wbuf[d] = sin^2(pi/2 (1 - d/Nbuf)),           d = 0..Nbuf   (FX/kernel.cpp:1581-1583)
+	const float* sigma;       // sigma[d] = inv_tau sin^2(pi/2 (1 - d/(Ns-1))), d = 0..Ns-1  (FX/kernel.cpp:1604-1606)
+	uint32_t has_F;
+};
+
+// ---------------------------------------------------------------- FP16C codec, FX/kernel.cpp:864-875
+__device__ __forceinline__ float half_to_float_custom(const uint32_t x) {
+	const uint32_t e = (x&0x7800u)>>11;
+	const uint32_t m = (x&0x07FFu)<<12;
+	const uint32_t v = __float_as_uint((float)m)>>23;
+	return __uint_as_float((x&0x8000u)<<16 | (uint32_t)(e!=0u)*((e+112u)<<23|m) | (uint32_t)((e==0u)&(m!=0u))*((v-37u)<<23|((m<<((150u-v)&31u))&0x007FF000u)));
+}
+__device__ __forceinline__ uint32_t float_to_half_custom(const float x) {
+	const uint32_t b = __float_as_uint(x)+0x00000800u;
+	const uint32_t e = (b&0x7F800000u)>>23;
+	const uint32_t m = b&0x007FFFFFu;
+	return (b&0x80000000u)>>16 | (uint32_t)(e>112u)*((((e-112u)<<11)&0x7800u)|m>>12) | (uint32_t)((e<113u)&(e>100u))*((((0x007FF800u+m)>>((124u-e)&31u))+1u)>>1);
+}
+template<typename T> __device__ __forceinline__ float ddf_decode(const T v);
+template<> __device__ __forceinline__ float ddf_decode<float>(const float v) { return v; }
+template<> __device__ __forceinline__ float ddf_decode<uint16_t>(const uint16_t v) { return half_to_float_custom((uint32_t)v); }
+template<typename T> __device__ __forceinline__ T ddf_encode(const float v);
+template<> __device__ __forceinline__ float ddf_encode<float>(const float v) { return v; }
+template<> __device__ __forceinline__ uint16_t ddf_encode<uint16_t>(const float v) { return (uint16_t)float_to_half_custom(v); }
+
+__device__ __forceinline__ float sq(const float x) { return x*x; }
+__device__ __forceinline__ float clampf(const float x, const float a, const float b) { return fminf(fmaxf(x, a), b); }
+
+// ---------------------------------------------------------------- f_eq, FX/kernel.cpp:1016-1055
+__device__ __forceinline__ void calculate_f_eq(const float rho, float ux, float uy, float uz, float* feq) {
+	const float rhom1 = rho-1.0f;
+	const float c3 = -3.0f*(sq(ux)+sq(uy)+sq(uz));
+	uz *= 3.0f;
+	ux *= 3.0f;
+	uy *= 3.0f;
+	feq[ 0] = DEF_W0*fmaf(rho, 0.5f*c3, rhom1);
+	const float u0=ux+uy, u1=ux+uz, u2=uy+uz, u3=ux-uy, u4=ux-uz, u5=uy-uz;
+	const float rhos=DEF_WS*rho, rhoe=DEF_WE*rho, rhom1s=DEF_WS*rhom1, rhom1e=DEF_WE*rhom1;
+	feq[ 1] = fmaf(rhos, fmaf(0.5f, fmaf(ux, ux, c3), ux), rhom1s); feq[ 2] = fmaf(rhos, fmaf(0.5f, fmaf(ux, ux, c3), -ux), rhom1s);
+	feq[ 3] = fmaf(rhos, fmaf(0.5f, fmaf(uy, uy, c3), uy), rhom1s); feq[ 4] = fmaf(rhos, fmaf(0.5f, fmaf(uy, uy, c3), -uy), rhom1s);
+	feq[ 5] = fmaf(rhos, fmaf(0.5f, fmaf(uz, uz, c3), uz), rhom1s); feq[ 6] = fmaf(rhos, fmaf(0.5f, fmaf(uz, uz, c3), -uz), rhom1s);
+	feq[ 7] = fmaf(rhoe, fmaf(0.5f, fmaf(u0, u0, c3), u0), rhom1e); feq[ 8] = fmaf(rhoe, fmaf(0.5f, fmaf(u0, u0, c3), -u0), rhom1e);
+	feq[ 9] = fmaf(rhoe, fmaf(0.5f, fmaf(u1, u1, c3), u1), rhom1e); feq[10] = fmaf(rhoe, fmaf(0.5f, fmaf(u1, u1, c3), -u1), rhom1e);
+	feq[11] = fmaf(rhoe, fmaf(0.5f, fmaf(u2, u2, c3), u2), rhom1e); feq[12] = fmaf(rhoe, fmaf(0.5f, fmaf(u2, u2, c3), -u2), rhom1e);
+	feq[13] = fmaf(rhoe, fmaf(0.5f, fmaf(u3, u3, c3), u3), rhom1e); feq[14] = fmaf(rhoe, fmaf(0.5f, fmaf(u3, u3, c3), -u3), rhom1e);
+	feq[15] = fmaf(rhoe, fmaf(0.5f, fmaf(u4, u4, c3), u4), rhom1e); feq[16] = fmaf(rhoe, fmaf(0.5f, fmaf(u4, u4, c3), -u4), rhom1e);
+	feq[17] = fmaf(rhoe, fmaf(0.5f, fmaf(u5, u5, c3), u5), rhom1e); feq[18] = fmaf(rhoe, fmaf(0.5f, fmaf(u5, u5, c3), -u5), rhom1e);
+}
+
+// ---------------------------------------------------------------- moments, FX/kernel.cpp:1075-1100
+__device__ __forceinline__ void calculate_rho_u(const float* f, float& rhon, float& uxn, float& uyn, float& uzn) {
+	float rho = f[0];
+	#pragma unroll
+	for(int i=1; i<19; i++) rho += f[i];
+	rho += 1.0f;
+	const float ux = f[ 1]-f[ 2]+f[ 7]-f[ 8]+f[ 9]-f[10]+f[13]-f[14]+f[15]-f[16];
+	const float uy = f[ 3]-f[ 4]+f[ 7]-f[ 8]+f[11]-f[12]+f[14]-f[13]+f[17]-f[18];
+	const float uz = f[ 5]-f[ 6]+f[ 9]-f[10]+f[11]-f[12]+f[16]-f[15]+f[18]-f[17];
+	rhon = rho;
+	uxn = ux/rho;
+	uyn = uy/rho;
+	uzn = uz/rho;
+}
+
+// c_i . (a,b,c) with the zero terms dropped, evaluated left to right like c(i)*a+c(19+i)*b+c(38+i)*c
+// (FX/kernel.cpp:1111).  D3Q19 order: FX/kernel.cpp:890-893.
+template<int I> __device__ __forceinline__ float cdot(const float a, const float b, const float c) {
+	if constexpr(I== 1) return  a; else if constexpr(I== 2) return -a;
+	else if constexpr(I== 3) return  b; else if constexpr(I== 4) return -b;
+	else if constexpr(I== 5) return  c; else if constexpr(I== 6) return -c;
+	else if constexpr(I== 7) return  a+b; else if constexpr(I== 8) return -a-b;
+	else if constexpr(I== 9) return  a+c; else if constexpr(I==10) return -a-c;
+	else if constexpr(I==11) return  b+c; else if constexpr(I==12) return -b-c;
+	else if constexpr(I==13) return  a-b; else if constexpr(I==14) return -a+b;
+	else if constexpr(I==15) return  a-c; else if constexpr(I==16) return -a+c;
+	else if constexpr(I==17) return  b-c; else return -b+c; // 18
+}
+template<int I> __device__ __forceinline__ void forcing_term(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, const float uF, float* Fin) {
+	constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
+	Fin[I] = w9*fmaf(cdot<I>(fx, fy, fz), cdot<I>(ux, uy, uz)+0.33333334f, uF);
+	if constexpr(I<18) forcing_term<I+1>(ux, uy, uz, fx, fy, fz, uF, Fin);
+}
+// Guo forcing, FX/kernel.cpp:1103-1113
+__device__ __forceinline__ void calculate_forcing_terms(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, float* Fin) {
+	const float uF = -0.33333334f*fmaf(ux, fx, fmaf(uy, fy, uz*fz));
+	Fin[0] = 9.0f*DEF_W0*uF;
+	forcing_term<1>(ux, uy, uz, fx, fy, fz, uF, Fin);
+}
+
+// ---------------------------------------------------------------- LUW force assembly, FX/kernel.cpp:1516-1623
+// Adds Coriolis, buffer nudging, top sponge and the per-cell force to (fxn,fyn,fzn).  n is the device index of
+// the cell, (x,y,z) its local coordinates.  u is the device velocity field (3 planes of stride Np).
+__device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E,
+		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn, float& fzn) {
+	fxn = p.fx; fyn = p.fy; fzn = p.fz;
+	const float cor_x = -2.0f*rhon*(p.omy*uzn-p.omz*uyn);
+	const float cor_y = -2.0f*rhon*(p.omz*uxn-p.omx*uzn);
+	const float cor_z = -2.0f*rhon*(p.omx*uyn-p.omy*uxn);
+	fxn += cor_x;
+	fyn += cor_y;
+	fzn += cor_z;
+	if(p.buffer_active && !is_E) {
+		const int Nbuf_i = (int)p.buffer_N;
+		const int d_w_i = (int)x+p.Ox;
+		const int d_e_i = (int)(p.Nxg-1u)-((int)x+p.Ox);
+		const int d_s_i = (int)y+p.Oy;
+		const int d_n_i = (int)(p.Nyg-1u)-((int)y+p.Oy);
+		const int d_t_i = (int)(p.Nzg-1u)-((int)z+p.Oz);
+		const bool in_w = p.downstream_face!=1u&&p.has_w&&d_w_i>=0&&d_w_i<=Nbuf_i;
+		const bool in_e = p.downstream_face!=2u&&p.has_e&&d_e_i>=0&&d_e_i<=Nbuf_i;
+		const bool in_s = p.downstream_face!=3u&&p.has_s&&d_s_i>=0&&d_s_i<=Nbuf_i;
+		const bool in_n = p.downstream_face!=4u&&p.has_n&&d_n_i>=0&&d_n_i<=Nbuf_i;
+		const bool in_t = p.has_t&&d_t_i>=0&&d_t_i<=Nbuf_i;
+		if(in_w||in_e||in_s||in_n||in_t) {
+			uint32_t d_min = p.buffer_N+1u;
+			uint32_t n_ref = n;
+			const uint32_t rowyz = (y+z*p.Ny)*p.Px;
+			if(in_w) { const uint32_t d = (uint32_t)d_w_i; if(d<d_min) { d_min = d; n_ref = (uint32_t)p.west_x+rowyz; } }
+			if(in_e) { const uint32_t d = (uint32_t)d_e_i; if(d<d_min) { d_min = d; n_ref = (uint32_t)p.east_x+rowyz; } }
+			if(in_s) { const uint32_t d = (uint32_t)d_s_i; if(d<d_min) { d_min = d; n_ref = x+((uint32_t)p.south_y+z*p.Ny)*p.Px; } }
+			if(in_n) { const uint32_t d = (uint32_t)d_n_i; if(d<d_min) { d_min = d; n_ref = x+((uint32_t)p.north_y+z*p.Ny)*p.Px; } }
+			if(in_t) { const uint32_t d = (uint32_t)d_t_i; if(d<d_min) { d_min = d; n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px; } }
+			const float w_buf = p.wbuf[d_min];
+			const float u_target_x = u[n_ref];
+			const float u_target_y = u[(size_t)p.Np+n_ref];
+			const float u_target_z = u[2ull*p.Np+n_ref];
+			const float a_x = w_buf*p.buffer_inv_tau*(u_target_x-uxn);
+			const float a_y = w_buf*p.buffer_inv_tau*(u_target_y-uyn);
+			const float a_z = p.nudge_vertical==1u ? w_buf*p.buffer_inv_tau*(u_target_z-uzn) : 0.0f;
+			fxn += rhon*a_x;
+			fyn += rhon*a_y;
+			fzn += rhon*a_z;
+		}
+	}
+	if(p.sponge_active && !is_E && p.has_t) {
+		const int d_t_i = (int)(p.Nzg-2u)-((int)z+p.Oz);
+		if(d_t_i>=0&&d_t_i<(int)p.sponge_N) {
+			const float sigma = p.sigma[d_t_i];
+			const uint32_t n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px;
+			fxn += rhon*sigma*(u[n_ref]-uxn);
+			fyn += rhon*sigma*(u[(size_t)p.Np+n_ref]-uyn);
+			fzn += rhon*sigma*(u[2ull*p.Np+n_ref]-uzn);
+		}
+	}
+	if(p.has_F) {
+		fxn += F[n];
+		fyn += F[(size_t)p.Np+n];
+		fzn += F[2ull*p.Np+n];
+	}
+}
+
+// ---------------------------------------------------------------- collision of one cell, FX/kernel.cpp:1502-1515,1686-1748
+// in: streamed-in DDFs f[19], flags byte.  out: post-collision DDFs in f[19]; rho/u (after the half-force
+// shift and the +-c clamp) in rhon,uxn,uyn,uzn.  Returns false when the cell must not touch memory at all
+// (solid / gas, FX/kernel.cpp:1490).
+__device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
+	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+	if(is_E) {
+		rhon = rho[n];
+		uxn = u[n];
+		uyn = u[(size_t)p.Np+n];
+		uzn = u[2ull*p.Np+n];
+	} else {
+		calculate_rho_u(f, rhon, uxn, uyn, uzn);
+	}
+	float fxn, fyn, fzn;
+	assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
+	float Fin[19];
+	{
+		const float rho2 = 0.5f/rhon;
+		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
+		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
+		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
+		calculate_forcing_terms(uxn, uyn, uzn, fxn, fyn, fzn, Fin);
+	}
+	float feq[19];
+	calculate_f_eq(rhon, uxn, uyn, uzn, feq);
+	float w = p.w;
+	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped
+		const float tau0 = 1.0f/w;
+		float n_[19];
+		#pragma unroll
+		for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
+		float Hxx = 0.0f, Hyy = 0.0f, Hzz = 0.0f, Hxy = 0.0f, Hxz = 0.0f, Hyz = 0.0f;
+		Hxx += n_[ 1]; Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
+		Hyy += n_[ 3]; Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
+		Hzz += n_[ 5]; Hzz += n_[ 6]; Hzz += n_[ 9]; Hzz += n_[10]; Hzz += n_[11]; Hzz += n_[12]; Hzz += n_[15]; Hzz += n_[16]; Hzz += n_[17]; Hzz += n_[18];
+		Hxy += n_[ 7]; Hxy += n_[ 8]; Hxy += -n_[13]; Hxy += -n_[14];
+		Hxz += n_[ 9]; Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
+		Hyz += n_[11]; Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
+		const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
+		w = 2.0f/(tau0+sqrtf(sq(tau0)+0.76421222f*sqrtf(Q)/rhon));
+	}
+	const float c_tau = fmaf(w, -0.5f, 1.0f);
+	const float omw = 1.0f-w;
+	#pragma unroll
+	for(int i=0; i<19; i++) {
+		const float Fi = Fin[i]*c_tau;
+		f[i] = is_E ? feq[i] : fmaf(omw, f[i], fmaf(w, feq[i], Fi));
+	}
+}
+
+} // namespace luw

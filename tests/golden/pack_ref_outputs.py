@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Packs outputs of the REAL reference binary (runs made on the MI355X box with oracle/run_ref_case.sh, see
+tests/golden/README.md) into small .npz fixtures:  u (SI units, as written by the reference) at t=8 and t=64,
+rho at t=64, the TYPE_S mask recovered from the `fluid` field of the _avg VTK, plus the console log.
+usage: pack_ref_outputs.py <run_dir> <out_prefix>   e.g.  gpurun_out/ref1/fp32_CaseA tests/golden/ref_fp32_CaseA
+"""
+import glob, os, re, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from vtkio import read_vtk
+
+run_dir, out = sys.argv[1], sys.argv[2]
+g = lambda pat: glob.glob(os.path.join(run_dir, pat))[0]
+d = {}
+for t in (8, 64):
+    h, f = read_vtk(g("*_raw_u-%09d.vtk" % t)); d["u%d" % t] = f["data"].astype(np.float32)
+h, f = read_vtk(g("*_raw_rho-*.vtk")); d["rho64"] = f["data"][..., 0].astype(np.float32)
+h, f = read_vtk(g("*_avg-*.vtk")); d["solid"] = (f["fluid"][..., 0] == 0)
+d["u_avg"] = f["u_avg"].astype(np.float32)   # mean of u over the last purge_avg=4 steps, SI units
+d["dims"] = np.array(h["dims"]); d["origin"] = np.array(h["origin"]); d["spacing"] = np.array(h["spacing"])
+np.savez_compressed(out + ".npz", **d)
+log = open(os.path.join(run_dir, "console.log"), errors="replace").read()
+keep = [l for l in log.splitlines() if l.strip() and not re.match(r"^\|\s+\d+\s+\|", l) and "MLUPs" not in l]
+open(out + ".console.txt", "w").write("\n".join(keep) + "\n")
+print(out, os.path.getsize(out + ".npz"))
