@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- MLUPS of the D3Q19 collide-stream hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 512^3 D3Q19 channel per GPU, FP32 DDFs, Smagorinsky LES on,
+z=0 plane solid, the other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the
+same profile, rho=1.  N>1 runs the weak-scaled tile (512^3 per GPU; 8 GPUs = BASELINE configs[3] 2048x1024x512 with
+n_gpu=[4,2,1]) with one-cell halos exchanged over RCCL.  A "step" is one stream_collide pass over the whole lattice;
+rho/u are written by the last step only (153 B/LUP mode); data is synthetic and resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_LUP = {"f32": 153.0, "fp16c": 77.0}   # 19 DDF reads + 19 DDF writes + 1 flag byte (FX/lbm.cpp:122)
+
+
+def loglaw_profile(nz, u_max=0.1):
+    """lattice-unit inflow speed per z level: log law over the cell centres above the solid z=0 plane"""
+    z = (np.arange(nz, dtype=np.float64) - 0.5) * 2.0          # metres above ground, cell = 2 m
+    z0 = 0.3
+    u = np.log(np.maximum(z, 0.0) / z0 + 1.0)
+    u[0] = 0.0
+    return (u_max * u / u.max()).astype(np.float32)
+
+
+def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None):
+    """flags/u/rho of the (sub)box [gx0,gx0+Nx) x ... of the global channel GNx x GNy x GNz (wind along +x)"""
+    GNx, GNy, GNz = GNx or Nx, GNy or Ny, GNz or Nz
+    prof = loglaw_profile(GNz)
+    zs = (np.arange(Nz) + gz0) % GNz; ys = (np.arange(Ny) + gy0) % GNy; xs = (np.arange(Nx) + gx0) % GNx
+    flags = np.zeros((Nz, Ny, Nx), np.uint8)
+    bz = (zs == GNz - 1); by = (ys == 0) | (ys == GNy - 1); bx = (xs == 0) | (xs == GNx - 1)
+    flags[bz, :, :] = 2; flags[:, by, :] = 2; flags[:, :, bx] = 2
+    flags[zs == 0, :, :] = 1
+    u = np.zeros((3, Nz, Ny, Nx), np.float32)
+    u[0] = prof[zs][:, None, None]
+    u[0][flags == 1] = 0.0
+    rho = np.ones((Nz, Ny, Nx), np.float32)
+    return flags.ravel(), u.ravel(), rho.ravel()
+
+
+def cpu_baseline(max_seconds=20.0):
+    """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port") timed on this box's host
+    cores on a bounded sample of the same workload recipe: 128^3 channel, FP32 DDFs, as many steps as fit."""
+    from oracle import oracle
+    N = 128
+    o = oracle.OracleLBM(N, N, N, 1.48e-7)
+    fl, u, rho = channel_state(N, N, N)
+    o.flags[:] = fl; o.u[:] = u; o.rho[:] = rho
+    o.run(2)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        o.run(4); steps += 4
+        dt = time.perf_counter() - t0
+        if dt > max_seconds or steps >= 400:
+            break
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(N ** 3 * steps / dt / 1e6, 1), "unit": "MLUPS", "cores": cores, "kind": "port",
+            "sample": "%d steps of a 128^3 FP32 channel (same recipe as the GPU workload) in %.1f s" % (steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU lattice (default 512 512 512)")
+    ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
+    ap.add_argument("--kernel", choices=["auto", "scalar", "vec4"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
+    args = ap.parse_args()
+
+    import torch
+    import latticeurbanwind_amd as luw
+    from latticeurbanwind_amd import capi
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    luw.load()
+    Nx, Ny, Nz = args.size or (512, 512, 512)
+    kern = {"auto": capi.KERNEL_AUTO, "scalar": capi.KERNEL_SCALAR, "vec4": capi.KERNEL_VEC4}[args.kernel]
+    fp16c = args.dtype == "fp16c"
+    nu = 1.48e-7                                     # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
+
+    if world == 1:
+        lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields)
+        fl, u, rho = channel_state(Nx, Ny, Nz)
+        lbm.flags.data[:] = fl; lbm.u.data[:] = u; lbm.rho.data[:] = rho
+        lbm.run(0)
+        lbm.run(args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms = lbm.run_timed(args.steps)        # K steps, HIP events around each launch on the launch stream
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cells = Nx * Ny * Nz
+        D = (1, 1, 1)
+    else:
+        import torch.distributed as dist
+        from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        D = choose_decomposition(world)
+        sim = DomainDecomposedLBM((Nx * D[0], Ny * D[1], Nz * D[2]), D, nu, fp16c=fp16c, kernel=kern, device=local_rank)
+        ox, oy, oz = sim.global_offset
+        fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, Nx * D[0], Ny * D[1], Nz * D[2])
+        sim.set_fields(fl, u, rho)
+        sim.initialize()
+        sim.run(args.warmup)
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms = sim.run(args.steps, timed=True)
+        torch.cuda.synchronize(); dist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        cells = Nx * Ny * Nz * world
+
+    if rank == 0:
+        mlups = cells * args.steps / dt / 1e6
+        bpl = BYTES_PER_LUP[args.dtype] + (16.0 if args.every_step_fields else 0.0)
+        per_gpu_cells = Nx * Ny * Nz
+        achieved = per_gpu_cells * bpl / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+        out = {
+            "metric": "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref",
+            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
+            "config": {"workload": "%dx%dx%d D3Q19 channel per GPU (BASELINE configs[1]), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky, %s DDFs, rho/u written %s"
+                       % (Nx, Ny, Nz, "FP16C" if fp16c else "FP32", "every step" if args.every_step_fields else "by the last step only"),
+                       "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "kernel": args.kernel,
+                       "bytes_per_lup": bpl},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
+                         "kernel_ms": round(kernel_ms, 4) if kernel_ms else None,
+                         "note": "achieved = %g B/LUP x %d cells / mean stream_collide duration (HIP events on the launch stream)" % (bpl, per_gpu_cells)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,6 +139,11 @@ int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* dev_buffer_p, const void* dev_buffer_m);
 int luw_finish(luw_solver* s);                                            /* LBM_Domain::finish_queue */
 
+/* debugging / test access to the DDFs: copies the 19 planes to / from host memory in the reference's layout
+ * fi[i*N + n] (FX/kernel.cpp:877-879), raw storage type (float or uint16_t FP16C codes). */
+int luw_download_fi(luw_solver* s, void* host_dst);
+int luw_upload_fi(luw_solver* s, const void* host_src);
+
 /* measurement helper for bench.py: runs `steps` steps like luw_run and returns the mean duration of the
  * stream_collide kernel in milliseconds, taken with HIP events on the launch stream. */
 int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms);

@@ -1,0 +1,10 @@
+"""latticeurbanwind_amd -- MI355X-native D3Q19 lattice-Boltzmann core for LatticeUrbanWind.
+
+Layout: csrc/ (HIP kernels + C-ABI, builds libluw_core.so), capi.py (ctypes binding of include/luw_core.h),
+lbm.py (host-side mirror of the reference's `LBM` class over the C-ABI), distributed.py (one-process-per-GPU
+domain decomposition driver over torch.distributed).
+"""
+from .capi import build, load, LuwError  # noqa: F401
+from .lbm import LBM  # noqa: F401
+
+__all__ = ["build", "load", "LuwError", "LBM"]

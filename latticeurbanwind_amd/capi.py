@@ -1,0 +1,104 @@
+"""ctypes binding of the C-ABI declared in include/luw_core.h (product library csrc/libluw_core.so).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no GPU is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libluw_core.so")
+_LIB = None
+
+LUW_OK = 0
+FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F, FIELD_FI = 0, 1, 2, 3, 4
+MASK_RHO, MASK_U, MASK_FLAGS, MASK_F = 1, 2, 4, 8
+DDF_FP32, DDF_FP16C = 0, 1
+OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID = 1, 2, 4
+KERNEL_AUTO, KERNEL_SCALAR, KERNEL_VEC4 = 0, 1, 2
+TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
+
+SYMBOLS = [
+    "luw_abi_version", "luw_last_error", "luw_device_count", "luw_create", "luw_destroy", "luw_host_ptr",
+    "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
+    "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
+    "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_get_area", "luw_enqueue_extract_fi",
+    "luw_enqueue_insert_fi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_upload_fi",
+]
+
+
+class LuwError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("Nx", C.c_uint32), ("Ny", C.c_uint32), ("Nz", C.c_uint32),
+        ("Dx", C.c_uint32), ("Dy", C.c_uint32), ("Dz", C.c_uint32),
+        ("Ox", C.c_int32), ("Oy", C.c_int32), ("Oz", C.c_int32),
+        ("nu", C.c_float),
+        ("fx", C.c_float), ("fy", C.c_float), ("fz", C.c_float),
+        ("omega_x", C.c_float), ("omega_y", C.c_float), ("omega_z", C.c_float),
+        ("ddf_format", C.c_uint32), ("options", C.c_uint32),
+        ("buffer_nudging_active", C.c_int32), ("buffer_n_cells", C.c_uint32), ("buffer_inv_tau_lbmu", C.c_float),
+        ("buffer_nudge_vertical", C.c_int32), ("buffer_downstream_face_id", C.c_int32),
+        ("top_sponge_active", C.c_int32), ("sponge_n_cells", C.c_uint32), ("sponge_inv_tau_lbmu", C.c_float),
+        ("device", C.c_int32), ("kernel", C.c_uint32),
+    ]
+
+
+def build(force=False):
+    """Compile csrc/luw_core.hip for gfx950 with hipcc (in-tree, so the .so travels with the repo snapshot)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("luw_core.hip", "luw_device.hpp")] + [os.path.join(_HERE, "..", "include", "luw_core.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in srcs):
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return _SO
+
+
+def load():
+    """dlopen the product library and declare the prototypes.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise LuwError("HIP library %s is missing: run latticeurbanwind_amd.build() (needs hipcc); there is no CPU fallback" % _SO)
+    L = C.CDLL(_SO)
+    vp, u64, u32, i32, f32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float
+    L.luw_abi_version.restype = i32
+    L.luw_last_error.restype = C.c_char_p
+    L.luw_device_count.argtypes = [C.POINTER(i32)]
+    L.luw_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.luw_destroy.argtypes = [vp]; L.luw_destroy.restype = None
+    L.luw_host_ptr.argtypes = [vp, i32]; L.luw_host_ptr.restype = vp
+    L.luw_device_ptr.argtypes = [vp, i32]; L.luw_device_ptr.restype = vp
+    L.luw_get_N.argtypes = [vp]; L.luw_get_N.restype = u64
+    L.luw_get_t.argtypes = [vp]; L.luw_get_t.restype = u64
+    L.luw_get_pitch.argtypes = [vp]; L.luw_get_pitch.restype = u32
+    L.luw_get_plane_stride.argtypes = [vp]; L.luw_get_plane_stride.restype = u64
+    L.luw_get_area.argtypes = [vp, u32]; L.luw_get_area.restype = u64
+    L.luw_upload.argtypes = [vp, u32]
+    L.luw_download.argtypes = [vp, u32]
+    L.luw_initialize.argtypes = [vp]
+    L.luw_run.argtypes = [vp, u64]
+    L.luw_run_timed.argtypes = [vp, u64, C.POINTER(C.c_double)]
+    L.luw_set_f.argtypes = [vp, f32, f32, f32]
+    L.luw_set_coriolis.argtypes = [vp, f32, f32, f32]
+    L.luw_set_stream.argtypes = [vp, vp]
+    L.luw_enqueue_stream_collide.argtypes = [vp, u32, u32, u32, u32, u32, u32, i32]
+    L.luw_increment_time_step.argtypes = [vp, u64]
+    L.luw_enqueue_extract_fi.argtypes = [vp, u32, vp, vp]
+    L.luw_enqueue_insert_fi.argtypes = [vp, u32, vp, vp]
+    L.luw_finish.argtypes = [vp]
+    L.luw_download_fi.argtypes = [vp, vp]
+    L.luw_upload_fi.argtypes = [vp, vp]
+    if L.luw_abi_version() != 1:
+        raise LuwError("libluw_core.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != LUW_OK:
+        raise LuwError("luw_core error %d: %s" % (rc, load().luw_last_error().decode("utf-8", "replace")))

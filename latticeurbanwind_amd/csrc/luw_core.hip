@@ -1,0 +1,766 @@
+// luw_core.hip -- HIP kernels (gfx950) + C-ABI of the MI355X-native D3Q19 core.  See include/luw_core.h.
+//
+// Kernels
+//   k_initialize          one-off: f_eq(rho,u) -> Esoteric-Pull store with t=1      (FX/kernel.cpp:1370-1452)
+//   k_stream_collide_s    1 cell per lane, dword accesses, direct neighbour addressing (reference-style access
+//                         pattern; the correctness baseline and the A/B partner of the vector kernel)
+//   k_stream_collide_v    V=4 (FP32) cells per lane: every population moves as one aligned 16-byte access per
+//                         lane; the five x+1 populations are aligned loads shifted across lanes with wave64
+//                         cross-lane ops, so a wave touches whole 1-KiB row segments only.  Solid cells
+//                         pass their populations through unchanged (each DDF slot is owned by exactly one cell
+//                         per step, so this is value-identical to "do not touch memory", FX/kernel.cpp:1490).
+//   k_extract_fi/k_insert_fi  halo pack/unpack of the 5 outgoing DDFs per face cell   (FX/kernel.cpp:2241-2270)
+//
+// Memory layout in HBM: SoA planes fi[q][z][y][x] with x-pitch Px (multiple of 4) and plane stride Np=Px*Ny*Nz;
+// rho[Np], u[3][Np], flags[Np], F[3][Np] share the pitch.  Host mirrors keep the reference layout (pitch Nx).
+#include "luw_device.hpp"
+#include "../../include/luw_core.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace luw;
+
+// =====================================================================================================
+// kernels
+// =====================================================================================================
+
+// Esoteric-Pull slots (FX/kernel.cpp:1338-1351): for odd i, A(i) is the plane read/written at the cell itself
+// (carries f[i] in, f[i+1] out), B(i) the plane read/written at the +c_i neighbour (f[i+1] in, f[i] out).
+template<int PARITY> __device__ __forceinline__ constexpr int slotA(const int i) { return PARITY ? i : i+1; }
+template<int PARITY> __device__ __forceinline__ constexpr int slotB(const int i) { return PARITY ? i+1 : i; }
+
+__device__ __forceinline__ bool cell_is_halo(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
+	return (p.halo_x&&(x==0u||x>=p.Nx-1u))||(p.halo_y&&(y==0u||y>=p.Ny-1u))||(p.halo_z&&(z==0u||z>=p.Nz-1u));
+}
+
+struct Box { uint32_t x0, x1, y0, y1, z0, z1; };
+
+// neighbour offsets of one cell (periodic wrap, FX/kernel.cpp:920-958), as 32-bit device offsets
+struct Nbr { uint32_t j[19]; };
+__device__ __forceinline__ void neighbors(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, uint32_t* j) {
+	const uint32_t xp = x+1u==p.Nx ? 0u : x+1u, xm = x==0u ? p.Nx-1u : x-1u;
+	const uint32_t y0 = y*p.Px, yp = (y+1u==p.Ny ? 0u : y+1u)*p.Px, ym = (y==0u ? p.Ny-1u : y-1u)*p.Px;
+	const uint32_t A = p.Px*p.Ny;
+	const uint32_t z0 = z*A, zp = (z+1u==p.Nz ? 0u : z+1u)*A, zm = (z==0u ? p.Nz-1u : z-1u)*A;
+	j[ 0] = x+y0+z0;
+	j[ 1] = xp+y0+z0; j[ 2] = xm+y0+z0;
+	j[ 3] = x +yp+z0; j[ 4] = x +ym+z0;
+	j[ 5] = x +y0+zp; j[ 6] = x +y0+zm;
+	j[ 7] = xp+yp+z0; j[ 8] = xm+ym+z0;
+	j[ 9] = xp+y0+zp; j[10] = xm+y0+zm;
+	j[11] = x +yp+zp; j[12] = x +ym+zm;
+	j[13] = xp+ym+z0; j[14] = xm+yp+z0;
+	j[15] = xp+y0+zm; j[16] = xm+y0+zp;
+	j[17] = x +yp+zm; j[18] = x +ym+zp;
+}
+
+template<typename T> __global__ __launch_bounds__(256) void k_initialize(const KParams p, T* __restrict__ fi, const float* __restrict__ rho, float* __restrict__ u, const uint8_t* __restrict__ flags) {
+	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+	if(x>=p.Nx) return;
+	if(cell_is_halo(p, x, y, z)) return;
+	uint32_t j[19];
+	neighbors(p, x, y, z, j);
+	const uint32_t n = j[0];
+	if((flags[n]&TYPE_BO)==TYPE_S) { // FX/kernel.cpp:1386-1399: u = 0 on every solid cell
+		u[n] = 0.0f; u[(size_t)p.Np+n] = 0.0f; u[2ull*p.Np+n] = 0.0f;
+	}
+	float feq[19];
+	calculate_f_eq(rho[n], u[n], u[(size_t)p.Np+n], u[2ull*p.Np+n], feq);
+	// store_f with t = 1 (odd), FX/kernel.cpp:1451
+	fi[n] = ddf_encode<T>(feq[0]);
+	#pragma unroll
+	for(int i=1; i<19; i+=2) {
+		fi[(size_t)slotB<1>(i)*p.Np+j[i]] = ddf_encode<T>(feq[i]);
+		fi[(size_t)slotA<1>(i)*p.Np+n] = ddf_encode<T>(feq[i+1]);
+	}
+}
+
+// ---------------------------------------------------------------- scalar kernel: 1 cell per lane
+template<typename T, int PARITY> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
+	const uint32_t x = b.x0+blockIdx.x*blockDim.x+threadIdx.x, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
+	if(x>=b.x1) return;
+	if(cell_is_halo(p, x, y, z)) return;
+	uint32_t j[19];
+	neighbors(p, x, y, z, j);
+	const uint32_t n = j[0];
+	const uint8_t flagsn = flags[n];
+	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
+	float f[19];
+	f[0] = ddf_decode<T>(fi[n]);
+	#pragma unroll
+	for(int i=1; i<19; i+=2) {
+		f[i  ] = ddf_decode<T>(fi[(size_t)slotA<PARITY>(i)*p.Np+n]);
+		f[i+1] = ddf_decode<T>(fi[(size_t)slotB<PARITY>(i)*p.Np+j[i]]);
+	}
+	float rhon, uxn, uyn, uzn;
+	collide_cell(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
+	if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
+		rho[n] = rhon;
+		u[n] = uxn;
+		u[(size_t)p.Np+n] = uyn;
+		u[2ull*p.Np+n] = uzn;
+	}
+	fi[n] = ddf_encode<T>(f[0]);
+	#pragma unroll
+	for(int i=1; i<19; i+=2) {
+		fi[(size_t)slotB<PARITY>(i)*p.Np+j[i]] = ddf_encode<T>(f[i]);
+		fi[(size_t)slotA<PARITY>(i)*p.Np+n] = ddf_encode<T>(f[i+1]);
+	}
+}
+
+// ---------------------------------------------------------------- vector kernel: V cells per lane
+template<typename T, int V> struct VecT;
+template<> struct VecT<float, 4> { typedef float4 type; };
+template<> struct VecT<uint16_t, 4> { typedef ushort4 type; };
+template<> struct VecT<float, 2> { typedef float2 type; };
+template<> struct VecT<uint16_t, 2> { typedef ushort2 type; };
+
+template<typename T, int V> struct Pack { T v[V]; };
+template<typename T, int V> __device__ __forceinline__ Pack<T, V> vload(const T* ptr) {
+	typedef typename VecT<T, V>::type VT;
+	const VT t = *reinterpret_cast<const VT*>(ptr);
+	Pack<T, V> r;
+	if constexpr(V==4) { r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; } else { r.v[0] = t.x; r.v[1] = t.y; }
+	return r;
+}
+template<typename T, int V> __device__ __forceinline__ void vstore(T* ptr, const Pack<T, V>& r) {
+	typedef typename VecT<T, V>::type VT;
+	VT t;
+	if constexpr(V==4) { t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3]; } else { t.x = r.v[0]; t.y = r.v[1]; }
+	*reinterpret_cast<VT*>(ptr) = t;
+}
+template<typename T> __device__ __forceinline__ T lane_down(const T v) { // value held by lane+1
+	return (T)__shfl_down((int)v, 1, 64);
+}
+template<> __device__ __forceinline__ float lane_down<float>(const float v) { return __shfl_down(v, 1, 64); }
+template<typename T> __device__ __forceinline__ T lane_up(const T v) { // value held by lane-1
+	return (T)__shfl_up((int)v, 1, 64);
+}
+template<> __device__ __forceinline__ float lane_up<float>(const float v) { return __shfl_up(v, 1, 64); }
+
+// Launch geometry: blockDim = (VX, RY), VX a power of two <= 256, VX*RY = 256.  blockIdx.x = rowblock*nchunk + chunk.
+// A lane owns the V cells X..X+V-1 (X = V*k) of row (y,z); rows are enumerated r = (z-z0)*(y1-y0) + (y-y0); k runs
+// over the vectors that overlap [b.x0,b.x1).  Lanes whose V cells all lie inside the box ("full") move whole
+// vectors; lanes on the box edge (or holding row padding) store element-wise and only what in-box cells own, so a
+// launch never writes a DDF slot owned by a cell outside its box (required when halo unpack / shell passes of the
+// multi-GPU driver run concurrently on another stream).
+template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k_stream_collide_v(const KParams p, const Box b, const uint32_t nchunk, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
+	const uint32_t kfirst = b.x0/V, klast = (b.x1-1u)/V;
+	const uint32_t chunk = blockIdx.x%nchunk, rowblock = blockIdx.x/nchunk;
+	const uint32_t k = kfirst+chunk*blockDim.x+threadIdx.x;
+	const uint32_t ny = b.y1-b.y0;
+	const uint32_t r = rowblock*blockDim.y+threadIdx.y;
+	const bool row_ok = r<ny*(b.z1-b.z0);
+	const uint32_t y = b.y0+(row_ok ? r%ny : 0u), z = b.z0+(row_ok ? r/ny : 0u);
+	const bool active = row_ok && k<=klast;
+	const uint32_t X = V*(active ? k : kfirst);
+	const uint32_t lane = (threadIdx.y*blockDim.x+threadIdx.x)&63u;
+	auto is_full = [&](const uint32_t kk) { return V*kk>=b.x0 && V*kk+V<=b.x1; };
+	const bool full = active && is_full(k);
+	// lane+1 / lane-1 hold the neighbouring vectors k+1 / k-1 of the same row?
+	const bool nb_next = lane<63u && threadIdx.x+1u<blockDim.x && k+1u<=klast;
+	const bool nb_prev = lane>0u && threadIdx.x>0u;
+	const bool next_full = nb_next && is_full(k+1u);
+	const bool prev_full = nb_prev && is_full(k-1u);
+
+	const uint32_t Arow = p.Px*p.Ny;
+	const uint32_t yp = (y+1u==p.Ny ? 0u : y+1u), ym = (y==0u ? p.Ny-1u : y-1u);
+	const uint32_t zp = (z+1u==p.Nz ? 0u : z+1u), zm = (z==0u ? p.Nz-1u : z-1u);
+	const uint32_t r00 = y*p.Px+z*Arow;     // own row
+	const uint32_t rp0 = yp*p.Px+z*Arow, rm0 = ym*p.Px+z*Arow;
+	const uint32_t r0p = y*p.Px+zp*Arow, r0m = y*p.Px+zm*Arow;
+	const uint32_t rpp = yp*p.Px+zp*Arow, rpm = yp*p.Px+zm*Arow;
+	const uint32_t n0 = r00+X;
+
+	// the lane that holds cell x = Nx-1 wraps to x = 0 of the same row for its x+1 neighbour
+	const uint32_t kw = (p.Nx-1u)/V, cw = (p.Nx-1u)%V;
+	const bool is_wrap = active && k==kw;
+
+	float f[19][V];
+	uint8_t fl[V];
+	if(active) {
+		if constexpr(V==4) { const uchar4 t = *reinterpret_cast<const uchar4*>(flags+n0); fl[0] = t.x; fl[1] = t.y; fl[2] = t.z; fl[3] = t.w; }
+		else { const uchar2 t = *reinterpret_cast<const uchar2*>(flags+n0); fl[0] = t.x; fl[1] = t.y; }
+	} else {
+		#pragma unroll
+		for(int c=0; c<V; c++) fl[c] = TYPE_S;
+	}
+	bool proc[V]; // cell is processed by this launch (in box, not halo, not solid/gas)
+	#pragma unroll
+	for(int c=0; c<V; c++) {
+		const uint32_t x = X+c;
+		proc[c] = active && x>=b.x0 && x<b.x1 && !cell_is_halo(p, x, y, z) && (fl[c]&TYPE_BO)!=TYPE_S && (fl[c]&TYPE_SU)!=TYPE_G;
+	}
+
+	// ---- load: straight (aligned) populations
+	auto load_straight = [&](const int q, const int plane, const uint32_t row) {
+		Pack<T, V> t;
+		if(active) t = vload<T, V>(fi+(size_t)plane*p.Np+row+X);
+		else { for(int c=0; c<V; c++) t.v[c] = (T)0; }
+		#pragma unroll
+		for(int c=0; c<V; c++) f[q][c] = ddf_decode<T>(t.v[c]);
+	};
+	// ---- load: populations living at x+1 (aligned vector + first element of the next lane, wrap at the row end)
+	auto load_shifted = [&](const int q, const int plane, const uint32_t row) {
+		const T* S = fi+(size_t)plane*p.Np+row;
+		Pack<T, V> t;
+		if(active) t = vload<T, V>(S+X);
+		else { for(int c=0; c<V; c++) t.v[c] = (T)0; }
+		T e = lane_down<T>(t.v[0]);
+		if(active && !nb_next && X+V<p.Px) e = S[X+V];
+		T in[V];
+		#pragma unroll
+		for(int c=0; c<V-1; c++) in[c] = t.v[c+1];
+		in[V-1] = e;
+		if(is_wrap) {
+			const T wv = S[0];
+			#pragma unroll
+			for(int c=0; c<V; c++) if((uint32_t)c==cw) in[c] = wv;
+		}
+		#pragma unroll
+		for(int c=0; c<V; c++) f[q][c] = ddf_decode<T>(in[c]);
+	};
+	load_straight(0, 0, r00);
+	load_straight( 1, slotA<PARITY>( 1), r00); load_shifted ( 2, slotB<PARITY>( 1), r00); // +00
+	load_straight( 3, slotA<PARITY>( 3), r00); load_straight( 4, slotB<PARITY>( 3), rp0); // 0+0
+	load_straight( 5, slotA<PARITY>( 5), r00); load_straight( 6, slotB<PARITY>( 5), r0p); // 00+
+	load_straight( 7, slotA<PARITY>( 7), r00); load_shifted ( 8, slotB<PARITY>( 7), rp0); // ++0
+	load_straight( 9, slotA<PARITY>( 9), r00); load_shifted (10, slotB<PARITY>( 9), r0p); // +0+
+	load_straight(11, slotA<PARITY>(11), r00); load_straight(12, slotB<PARITY>(11), rpp); // 0++
+	load_straight(13, slotA<PARITY>(13), r00); load_shifted (14, slotB<PARITY>(13), rm0); // +-0
+	load_straight(15, slotA<PARITY>(15), r00); load_shifted (16, slotB<PARITY>(15), r0m); // +0-
+	load_straight(17, slotA<PARITY>(17), r00); load_straight(18, slotB<PARITY>(17), rpm); // 0+-
+
+	// ---- collide the V cells; everything else passes through
+	#pragma unroll
+	for(int c=0; c<V; c++) {
+		if(proc[c]) {
+			const uint8_t flagsn = fl[c];
+			float fc[19];
+			#pragma unroll
+			for(int q=0; q<19; q++) fc[q] = f[q][c];
+			float rhon, uxn, uyn, uzn;
+			collide_cell(p, n0+c, X+c, y, z, flagsn, fc, rho, u, F, rhon, uxn, uyn, uzn);
+			if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
+				rho[n0+c] = rhon;
+				u[n0+c] = uxn;
+				u[(size_t)p.Np+n0+c] = uyn;
+				u[2ull*p.Np+n0+c] = uzn;
+			}
+			#pragma unroll
+			for(int q=0; q<19; q++) f[q][c] = fc[q];
+		}
+	}
+
+	// ---- store (Esoteric-Pull swap: what came in as f[i] leaves through B(i), f[i+1] through A(i))
+	auto store_straight = [&](const int q, const int plane, const uint32_t row) {
+		if(!active) return;
+		T* S = fi+(size_t)plane*p.Np+row;
+		if(full) {
+			Pack<T, V> t;
+			#pragma unroll
+			for(int c=0; c<V; c++) t.v[c] = ddf_encode<T>(f[q][c]);
+			vstore<T, V>(S+X, t);
+		} else {
+			#pragma unroll
+			for(int c=0; c<V; c++) if(proc[c]) S[X+c] = ddf_encode<T>(f[q][c]);
+		}
+	};
+	auto store_shifted = [&](const int q, const int plane, const uint32_t row) {
+		T* S = fi+(size_t)plane*p.Np+row;
+		T o[V];
+		#pragma unroll
+		for(int c=0; c<V; c++) o[c] = ddf_encode<T>(f[q][c]);
+		const T pv = lane_up<T>(o[V-1]); // out value of cell X-1 (meaningful when prev_full)
+		if(!active) return;
+		if(full) {
+			if(prev_full) {
+				Pack<T, V> t;
+				t.v[0] = pv;
+				#pragma unroll
+				for(int c=1; c<V; c++) t.v[c] = o[c-1];
+				vstore<T, V>(S+X, t);
+			} else {
+				// S[X] is owned by cell X-1, which another wave / an edge lane / nobody in this launch handles
+				#pragma unroll
+				for(int c=1; c<V; c++) S[X+c] = o[c-1];
+			}
+			if(!next_full && X+V<p.Nx) S[X+V] = o[V-1]; // the element the next vector will not write for us
+			if(is_wrap) {
+				#pragma unroll
+				for(int c=0; c<V; c++) if((uint32_t)c==cw) S[0] = o[c];
+			}
+		} else {
+			#pragma unroll
+			for(int c=0; c<V; c++) if(proc[c]) S[X+c+1u==p.Nx ? 0u : X+c+1u] = o[c];
+		}
+	};
+	store_straight(0, 0, r00);
+	store_shifted ( 1, slotB<PARITY>( 1), r00); store_straight( 2, slotA<PARITY>( 1), r00);
+	store_straight( 3, slotB<PARITY>( 3), rp0); store_straight( 4, slotA<PARITY>( 3), r00);
+	store_straight( 5, slotB<PARITY>( 5), r0p); store_straight( 6, slotA<PARITY>( 5), r00);
+	store_shifted ( 7, slotB<PARITY>( 7), rp0); store_straight( 8, slotA<PARITY>( 7), r00);
+	store_shifted ( 9, slotB<PARITY>( 9), r0p); store_straight(10, slotA<PARITY>( 9), r00);
+	store_straight(11, slotB<PARITY>(11), rpp); store_straight(12, slotA<PARITY>(11), r00);
+	store_shifted (13, slotB<PARITY>(13), rm0); store_straight(14, slotA<PARITY>(13), r00);
+	store_shifted (15, slotB<PARITY>(15), r0m); store_straight(16, slotA<PARITY>(15), r00);
+	store_straight(17, slotB<PARITY>(17), rpm); store_straight(18, slotA<PARITY>(17), r00);
+}
+
+// ---------------------------------------------------------------- halo pack / unpack, FX/kernel.cpp:2188-2270
+__device__ __constant__ uint8_t c_index_transfer[30] = {
+	1,  7, 13,  9, 15,
+	2,  8, 14, 10, 16,
+	3,  7, 14, 11, 17,
+	4,  8, 13, 12, 18,
+	5,  9, 16, 11, 18,
+	6, 10, 15, 12, 17
+};
+__device__ __forceinline__ void face_cell(const KParams& p, const uint32_t a, const uint32_t direction, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z) {
+	if(direction==0u) { x = fixed; y = a%p.Ny; z = a/p.Ny; }
+	else if(direction==1u) { x = a/p.Nz; y = fixed; z = a%p.Nz; }
+	else { x = a%p.Nx; y = a/p.Nx; z = fixed; }
+}
+template<typename T> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
+	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
+	if(a>=A) return;
+	const uint32_t Nd = direction==0u ? p.Nx : direction==1u ? p.Ny : p.Nz;
+	#pragma unroll
+	for(uint32_t pm=0u; pm<2u; pm++) {
+		uint32_t x, y, z;
+		face_cell(p, a, direction, pm==0u ? Nd-2u : 1u, x, y, z);
+		uint32_t j[19];
+		neighbors(p, x, y, z, j);
+		T* buf = pm==0u ? buf_p : buf_m;
+		for(uint32_t bb=0u; bb<5u; bb++) {
+			const uint32_t i = c_index_transfer[(2u*direction+pm)*5u+bb];
+			const uint32_t plane = t_odd ? ((i&1u) ? i+1u : i-1u) : i;
+			buf[(size_t)bb*A+a] = fi[(size_t)plane*p.Np+((i&1u) ? j[i] : j[0])];
+		}
+	}
+}
+template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
+	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
+	if(a>=A) return;
+	const uint32_t Nd = direction==0u ? p.Nx : direction==1u ? p.Ny : p.Nz;
+	#pragma unroll
+	for(uint32_t pm=0u; pm<2u; pm++) {
+		uint32_t x, y, z;
+		face_cell(p, a, direction, pm==0u ? Nd-1u : 0u, x, y, z);
+		uint32_t j[19];
+		neighbors(p, x, y, z, j);
+		const T* buf = pm==0u ? buf_p : buf_m;
+		for(uint32_t bb=0u; bb<5u; bb++) {
+			const uint32_t i = c_index_transfer[(2u*direction+pm)*5u+bb];
+			const uint32_t plane = t_odd ? i : ((i&1u) ? i+1u : i-1u);
+			fi[(size_t)plane*p.Np+((i&1u) ? j[0] : j[i-1u])] = buf[(size_t)bb*A+a];
+		}
+	}
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static thread_local std::string g_last_error;
+static int fail(const int code, const std::string& msg) { g_last_error = msg; return code; }
+#define HIP_TRY(expr) do { const hipError_t e_ = (expr); if(e_!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string(#expr)+": "+hipGetErrorString(e_)); } while(0)
+
+// FX/utilities.hpp:2603-2634,2741-2750 + strtof: the float the reference kernel sees after device_defines()
+// printed it as 9-digit decimal text (FX/lbm.cpp:664,774,780).
+static float literal_roundtrip(float x) {
+	bool neg = false;
+	if(x<0.0f) { neg = true; x = -x; }
+	if(std::isnan(x)||std::isinf(x)) return neg ? -x : x;
+	int exponent = 0;
+	if(x>=10.0f) {
+		if(x>=1E32f) { x *= 1E-32f; exponent += 32; }
+		if(x>=1E16f) { x *= 1E-16f; exponent += 16; }
+		if(x>= 1E8f) { x *=  1E-8f; exponent +=  8; }
+		if(x>= 1E4f) { x *=  1E-4f; exponent +=  4; }
+		if(x>= 1E2f) { x *=  1E-2f; exponent +=  2; }
+		if(x>= 1E1f) { x *=  1E-1f; exponent +=  1; }
+	}
+	if(x>0.0f&&x<=1.0f) {
+		if(x<1E-31f) { x *=  1E32f; exponent -= 32; }
+		if(x<1E-15f) { x *=  1E16f; exponent -= 16; }
+		if(x< 1E-7f) { x *=   1E8f; exponent -=  8; }
+		if(x< 1E-3f) { x *=   1E4f; exponent -=  4; }
+		if(x< 1E-1f) { x *=   1E2f; exponent -=  2; }
+		if(x<  1E0f) { x *=   1E1f; exponent -=  1; }
+	}
+	uint32_t integral = (uint32_t)x;
+	const float remainder = (x-(float)integral)*1E8f;
+	uint32_t decimal = (uint32_t)remainder;
+	if(remainder-(float)decimal>=0.5f) {
+		decimal++;
+		if(decimal>=100000000u) { decimal = 0u; integral++; if(integral>=10u) { integral = 1u; exponent++; } }
+	}
+	char text[64];
+	if(exponent!=0) snprintf(text, sizeof(text), "%s%u.%08uE%d", neg ? "-" : "", integral, decimal, exponent);
+	else snprintf(text, sizeof(text), "%s%u.%08u", neg ? "-" : "", integral, decimal);
+	return strtof(text, nullptr);
+}
+
+struct luw_solver {
+	luw_config cfg;
+	KParams kp;
+	uint64_t N = 0;          // Nx*Ny*Nz
+	uint64_t t = 0;
+	bool initialized = false;
+	bool fields_current = true; // device rho,u reflect the state after the last executed step
+	size_t ddf_bytes = 4;
+	void* d_fi = nullptr;
+	float* d_rho = nullptr; float* d_u = nullptr; uint8_t* d_flags = nullptr; float* d_F = nullptr;
+	float* d_wbuf = nullptr; float* d_sigma = nullptr;
+	float* h_rho = nullptr; float* h_u = nullptr; uint8_t* h_flags = nullptr; float* h_F = nullptr;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	uint32_t kernel = LUW_KERNEL_AUTO;
+};
+
+static int set_device(const luw_solver* s) { HIP_TRY(hipSetDevice(s->cfg.device)); return LUW_OK; }
+
+static int copy_pitched(void* dst, const void* src, const size_t elem, const luw_solver* s, const uint32_t planes, const bool to_device, hipStream_t st) {
+	const size_t rows = (size_t)s->cfg.Ny*s->cfg.Nz;
+	for(uint32_t c=0u; c<planes; c++) {
+		if(to_device) HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (const char*)src+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyHostToDevice, st));
+		else HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (const char*)src+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyDeviceToHost, st));
+	}
+	return LUW_OK;
+}
+
+template<typename T> static void launch_typed(luw_solver* s, const Box& b, const int write_fields, const bool vec) {
+	T* fi = (T*)s->d_fi;
+	const bool odd = (s->t&1ull)!=0ull;
+	if(vec) {
+		constexpr int V = 4;
+		const uint32_t nvec = (b.x1-1u)/V-b.x0/V+1u;          // vectors overlapping [x0,x1)
+		uint32_t vx = 1u; while(vx<nvec&&vx<256u) vx <<= 1;   // power of two
+		const uint32_t ry = 256u/vx;
+		const uint32_t nchunk = (nvec+vx-1u)/vx;
+		const uint32_t rows = (b.y1-b.y0)*(b.z1-b.z0);
+		const dim3 grid(((rows+ry-1u)/ry)*nchunk), block(vx, ry);
+		if(odd) hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+		else hipLaunchKernelGGL((k_stream_collide_v<T, V, 0>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+	} else {
+		const uint32_t nx = b.x1-b.x0;
+		const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
+		const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+		if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+		else hipLaunchKernelGGL((k_stream_collide_s<T, 0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+	}
+}
+
+static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields) {
+	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
+	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
+	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
+	const bool vec = s->kernel==LUW_KERNEL_VEC4 || s->kernel==LUW_KERNEL_AUTO;
+	if(s->ddf_bytes==2u) launch_typed<uint16_t>(s, b, write_fields, vec); else launch_typed<float>(s, b, write_fields, vec);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+
+extern "C" {
+
+int luw_abi_version(void) { return LUW_ABI_VERSION; }
+const char* luw_last_error(void) { return g_last_error.c_str(); }
+int luw_device_count(int* count) {
+	if(!count) return fail(LUW_ERR_INVALID, "luw_device_count: null argument");
+	HIP_TRY(hipGetDeviceCount(count));
+	return LUW_OK;
+}
+
+void luw_destroy(luw_solver* s) {
+	if(!s) return;
+	(void)hipSetDevice(s->cfg.device);
+	if(s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+	(void)hipFree(s->d_fi); (void)hipFree(s->d_rho); (void)hipFree(s->d_u); (void)hipFree(s->d_flags); (void)hipFree(s->d_F);
+	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
+	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F);
+	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
+	delete s;
+}
+
+int luw_create(const luw_config* cfg, luw_solver** out) {
+	if(!cfg||!out) return fail(LUW_ERR_INVALID, "luw_create: null argument");
+	*out = nullptr;
+	if(cfg->struct_size!=sizeof(luw_config)) return fail(LUW_ERR_INVALID, "luw_create: luw_config size mismatch (ABI)");
+	if((uint64_t)cfg->Nx*cfg->Ny*cfg->Nz==0ull) return fail(LUW_ERR_INVALID, "Grid point number is 0."); // FX/lbm.cpp:1123
+	if(cfg->Dx*cfg->Dy*cfg->Dz==0u) return fail(LUW_ERR_INVALID, "You specified 0 LBM grid domains."); // FX/lbm.cpp:1124
+	if(cfg->nu==0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be 0."); // FX/lbm.cpp:1141
+	if(cfg->nu<0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be negative."); // FX/lbm.cpp:1142
+	if(cfg->ddf_format!=LUW_DDF_FP32&&cfg->ddf_format!=LUW_DDF_FP16C) return fail(LUW_ERR_INVALID, "luw_create: unknown ddf_format");
+	if((cfg->Dx>1u&&cfg->Nx<3u)||(cfg->Dy>1u&&cfg->Ny<3u)||(cfg->Dz>1u&&cfg->Nz<3u)) return fail(LUW_ERR_INVALID, "luw_create: split axes need at least one interior cell between the halo layers");
+	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
+	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
+	const uint32_t Px = (cfg->Nx+3u)&~3u;
+	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz;
+	if(Np>=(1ull<<32)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^32 cells per domain are not supported");
+	int ndev = 0;
+	HIP_TRY(hipGetDeviceCount(&ndev));
+	if(cfg->device<0||cfg->device>=ndev) return fail(LUW_ERR_INVALID, "luw_create: no such HIP device"); // FX/lbm.cpp:961-979
+	HIP_TRY(hipSetDevice(cfg->device));
+
+	luw_solver* s = new luw_solver();
+	s->cfg = *cfg;
+	s->N = (uint64_t)cfg->Nx*cfg->Ny*cfg->Nz;
+	s->ddf_bytes = cfg->ddf_format==LUW_DDF_FP16C ? 2u : 4u;
+	s->kernel = cfg->kernel;
+	KParams& k = s->kp;
+	memset(&k, 0, sizeof(k));
+	k.Nx = cfg->Nx; k.Ny = cfg->Ny; k.Nz = cfg->Nz; k.Px = Px; k.Np = (uint32_t)Np;
+	k.halo_x = cfg->Dx>1u; k.halo_y = cfg->Dy>1u; k.halo_z = cfg->Dz>1u;
+	k.Ox = cfg->Ox; k.Oy = cfg->Oy; k.Oz = cfg->Oz;
+	k.w = literal_roundtrip(1.0f/(3.0f*cfg->nu+0.5f)); // FX/lbm.hpp:140, FX/lbm.cpp:664
+	k.fx = cfg->fx; k.fy = cfg->fy; k.fz = cfg->fz;
+	k.omx = cfg->omega_x; k.omy = cfg->omega_y; k.omz = cfg->omega_z;
+	k.subgrid = (cfg->options&LUW_OPT_NO_SUBGRID) ? 0u : 1u;
+	k.buffer_active = cfg->buffer_nudging_active ? 1u : 0u;
+	k.buffer_N = cfg->buffer_n_cells; k.nudge_vertical = (uint32_t)cfg->buffer_nudge_vertical; k.downstream_face = (uint32_t)cfg->buffer_downstream_face_id;
+	k.buffer_inv_tau = literal_roundtrip(cfg->buffer_inv_tau_lbmu);
+	k.sponge_active = cfg->top_sponge_active ? 1u : 0u;
+	k.sponge_N = cfg->sponge_n_cells;
+	// FX/lbm.cpp:613-625
+	k.Nxg = (cfg->Nx-2u*k.halo_x)*cfg->Dx; k.Nyg = (cfg->Ny-2u*k.halo_y)*cfg->Dy; k.Nzg = (cfg->Nz-2u*k.halo_z)*cfg->Dz;
+	k.west_x = -cfg->Ox; k.east_x = (int)k.Nxg-1-cfg->Ox; k.south_y = -cfg->Oy; k.north_y = (int)k.Nyg-1-cfg->Oy; k.top_z = (int)k.Nzg-1-cfg->Oz;
+	k.has_w = k.west_x>=0&&k.west_x<(int)cfg->Nx; k.has_e = k.east_x>=0&&k.east_x<(int)cfg->Nx;
+	k.has_s = k.south_y>=0&&k.south_y<(int)cfg->Ny; k.has_n = k.north_y>=0&&k.north_y<(int)cfg->Ny;
+	k.has_t = k.top_z>=0&&k.top_z<(int)cfg->Nz;
+	k.has_F = (cfg->options&LUW_OPT_FORCE_FIELD) ? 1u : 0u;
+
+	auto oom = [&](const char* what) { luw_destroy(s); return fail(LUW_ERR_NOMEM, std::string("luw_create: allocation failed: ")+what); };
+	if(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking)!=hipSuccess) return oom("stream");
+	s->stream = s->own_stream;
+	if(hipMalloc(&s->d_fi, 19ull*Np*s->ddf_bytes)!=hipSuccess) return oom("fi");
+	if(hipMalloc((void**)&s->d_rho, Np*4ull)!=hipSuccess) return oom("rho");
+	if(hipMalloc((void**)&s->d_u, 3ull*Np*4ull)!=hipSuccess) return oom("u");
+	if(hipMalloc((void**)&s->d_flags, Np)!=hipSuccess) return oom("flags");
+	if(k.has_F&&hipMalloc((void**)&s->d_F, 3ull*Np*4ull)!=hipSuccess) return oom("F");
+	if(hipHostMalloc((void**)&s->h_rho, s->N*4ull)!=hipSuccess) return oom("host rho");
+	if(hipHostMalloc((void**)&s->h_u, 3ull*s->N*4ull)!=hipSuccess) return oom("host u");
+	if(hipHostMalloc((void**)&s->h_flags, s->N)!=hipSuccess) return oom("host flags");
+	if(k.has_F&&hipHostMalloc((void**)&s->h_F, 3ull*s->N*4ull)!=hipSuccess) return oom("host F");
+	for(uint64_t n=0ull; n<s->N; n++) s->h_rho[n] = 1.0f; // Memory<float>(device, N, 1u, true, true, 1.0f), FX/lbm.cpp:286
+	memset(s->h_u, 0, 3ull*s->N*4ull);
+	memset(s->h_flags, 0, s->N);
+	if(s->h_F) memset(s->h_F, 0, 3ull*s->N*4ull);
+	// padding / not-yet-uploaded device memory must hold defined values (pass-through of padding cells)
+	if(hipMemset(s->d_fi, 0, 19ull*Np*s->ddf_bytes)!=hipSuccess||hipMemset(s->d_rho, 0, Np*4ull)!=hipSuccess||hipMemset(s->d_u, 0, 3ull*Np*4ull)!=hipSuccess||hipMemset(s->d_flags, 0, Np)!=hipSuccess) return oom("memset");
+	if(s->d_F&&hipMemset(s->d_F, 0, 3ull*Np*4ull)!=hipSuccess) return oom("memset F");
+	// ramps of the nudging / sponge terms, evaluated on the host exactly like FX/kernel.cpp:1581-1583,1604-1606
+	if(k.buffer_active) {
+		std::vector<float> wb(k.buffer_N+2u);
+		for(uint32_t d=0u; d<=k.buffer_N+1u; d++) {
+			const float xi = 1.0f-(float)d/(float)k.buffer_N;
+			float w_buf = sinf(1.5707963267948966f*xi);
+			w_buf *= w_buf;
+			wb[d] = w_buf;
+		}
+		if(hipMalloc((void**)&s->d_wbuf, wb.size()*4u)!=hipSuccess||hipMemcpy(s->d_wbuf, wb.data(), wb.size()*4u, hipMemcpyHostToDevice)!=hipSuccess) return oom("wbuf");
+		k.wbuf = s->d_wbuf;
+	}
+	if(k.sponge_active) {
+		const float inv_tau = literal_roundtrip(cfg->sponge_inv_tau_lbmu);
+		const int Ns = (int)k.sponge_N;
+		std::vector<float> sg(k.sponge_N);
+		for(int d=0; d<Ns; d++) {
+			const float xi = Ns>1 ? 1.0f-(float)d/(float)(Ns-1) : 1.0f;
+			float sigma = sinf(1.5707963267948966f*xi);
+			sigma = inv_tau*sigma*sigma;
+			sg[d] = sigma;
+		}
+		if(hipMalloc((void**)&s->d_sigma, sg.size()*4u)!=hipSuccess||hipMemcpy(s->d_sigma, sg.data(), sg.size()*4u, hipMemcpyHostToDevice)!=hipSuccess) return oom("sigma");
+		k.sigma = s->d_sigma;
+	}
+	*out = s;
+	return LUW_OK;
+}
+
+void* luw_host_ptr(luw_solver* s, int field) {
+	if(!s) return nullptr;
+	switch(field) {
+		case LUW_FIELD_RHO: return s->h_rho;
+		case LUW_FIELD_U: return s->h_u;
+		case LUW_FIELD_FLAGS: return s->h_flags;
+		case LUW_FIELD_F: return s->h_F;
+		default: return nullptr;
+	}
+}
+void* luw_device_ptr(luw_solver* s, int field) {
+	if(!s) return nullptr;
+	switch(field) {
+		case LUW_FIELD_RHO: return s->d_rho;
+		case LUW_FIELD_U: return s->d_u;
+		case LUW_FIELD_FLAGS: return s->d_flags;
+		case LUW_FIELD_F: return s->d_F;
+		case LUW_FIELD_FI: return s->d_fi;
+		default: return nullptr;
+	}
+}
+uint64_t luw_get_N(const luw_solver* s) { return s ? s->N : 0ull; }
+uint64_t luw_get_t(const luw_solver* s) { return s ? s->t : 0ull; }
+uint32_t luw_get_pitch(const luw_solver* s) { return s ? s->kp.Px : 0u; }
+uint64_t luw_get_plane_stride(const luw_solver* s) { return s ? s->kp.Np : 0ull; }
+uint64_t luw_get_area(const luw_solver* s, uint32_t direction) {
+	if(!s||direction>2u) return 0ull;
+	const uint64_t A[3] = { (uint64_t)s->cfg.Ny*s->cfg.Nz, (uint64_t)s->cfg.Nz*s->cfg.Nx, (uint64_t)s->cfg.Nx*s->cfg.Ny };
+	return A[direction];
+}
+
+int luw_set_stream(luw_solver* s, void* hip_stream) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_set_stream: null solver");
+	s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+	return LUW_OK;
+}
+int luw_finish(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_finish: null solver");
+	if(int e = set_device(s)) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+
+int luw_upload(luw_solver* s, uint32_t mask) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_upload: null solver");
+	if(int e = set_device(s)) return e;
+	int e = LUW_OK;
+	if(mask&LUW_MASK_RHO) if((e = copy_pitched(s->d_rho, s->h_rho, 4u, s, 1u, true, s->stream))) return e;
+	if(mask&LUW_MASK_U) if((e = copy_pitched(s->d_u, s->h_u, 4u, s, 3u, true, s->stream))) return e;
+	if(mask&LUW_MASK_FLAGS) if((e = copy_pitched(s->d_flags, s->h_flags, 1u, s, 1u, true, s->stream))) return e;
+	if((mask&LUW_MASK_F)&&s->d_F) if((e = copy_pitched(s->d_F, s->h_F, 4u, s, 3u, true, s->stream))) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+
+int luw_download(luw_solver* s, uint32_t mask) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_download: null solver");
+	if(int e = set_device(s)) return e;
+	int e = LUW_OK;
+	if(mask&LUW_MASK_RHO) if((e = copy_pitched(s->h_rho, s->d_rho, 4u, s, 1u, false, s->stream))) return e;
+	if(mask&LUW_MASK_U) if((e = copy_pitched(s->h_u, s->d_u, 4u, s, 3u, false, s->stream))) return e;
+	if(mask&LUW_MASK_FLAGS) if((e = copy_pitched(s->h_flags, s->d_flags, 1u, s, 1u, false, s->stream))) return e;
+	if((mask&LUW_MASK_F)&&s->d_F) if((e = copy_pitched(s->h_F, s->d_F, 4u, s, 3u, false, s->stream))) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+
+int luw_download_fi(luw_solver* s, void* host_dst) {
+	if(!s||!host_dst) return fail(LUW_ERR_INVALID, "luw_download_fi: bad argument");
+	if(int e = set_device(s)) return e;
+	if(int e = copy_pitched(host_dst, s->d_fi, s->ddf_bytes, s, 19u, false, s->stream)) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+int luw_upload_fi(luw_solver* s, const void* host_src) {
+	if(!s||!host_src) return fail(LUW_ERR_INVALID, "luw_upload_fi: bad argument");
+	if(int e = set_device(s)) return e;
+	if(int e = copy_pitched(s->d_fi, host_src, s->ddf_bytes, s, 19u, true, s->stream)) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+
+int luw_set_f(luw_solver* s, float fx, float fy, float fz) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_set_f: null solver");
+	s->cfg.fx = s->kp.fx = fx; s->cfg.fy = s->kp.fy = fy; s->cfg.fz = s->kp.fz = fz;
+	return LUW_OK;
+}
+int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_set_coriolis: null solver");
+	s->cfg.omega_x = s->kp.omx = ox; s->cfg.omega_y = s->kp.omy = oy; s->cfg.omega_z = s->kp.omz = oz;
+	return LUW_OK;
+}
+
+int luw_initialize(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_initialize: null solver");
+	if(int e = luw_upload(s, LUW_MASK_RHO|LUW_MASK_U|LUW_MASK_FLAGS|LUW_MASK_F)) return e;
+	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
+	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_initialize<uint16_t>), grid, block, 0, s->stream, s->kp, (uint16_t*)s->d_fi, s->d_rho, s->d_u, s->d_flags);
+	else hipLaunchKernelGGL((k_initialize<float>), grid, block, 0, s->stream, s->kp, (float*)s->d_fi, s->d_rho, s->d_u, s->d_flags);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->t = 0ull;
+	s->initialized = true;
+	s->fields_current = true;
+	return LUW_OK;
+}
+
+int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, int write_fields) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_enqueue_stream_collide: null solver");
+	if(!s->initialized) return fail(LUW_ERR_STATE, "luw_enqueue_stream_collide: call luw_initialize first");
+	if(int e = set_device(s)) return e;
+	const Box b = { x0, x1, y0, y1, z0, z1 };
+	if(!write_fields) s->fields_current = false;
+	return launch_stream_collide(s, b, write_fields);
+}
+int luw_increment_time_step(luw_solver* s, uint64_t steps) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_increment_time_step: null solver");
+	s->t += steps;
+	return LUW_OK;
+}
+
+static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_run: null solver");
+	if(int e = set_device(s)) return e;
+	if(!s->initialized) { if(int e = luw_initialize(s)) return e; } // LBM::run initialises on first use, FX/lbm.cpp:1294-1296
+	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
+	const bool every = (s->cfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
+	std::vector<hipEvent_t> ev;
+	if(mean_kernel_ms) {
+		ev.resize(2u*steps);
+		for(auto& e : ev) HIP_TRY(hipEventCreate(&e));
+	}
+	for(uint64_t i=0ull; i<steps; i++) {
+		const int wf = (every||i+1ull==steps) ? 1 : 0;
+		if(mean_kernel_ms) HIP_TRY(hipEventRecord(ev[2u*i], s->stream));
+		if(int e = launch_stream_collide(s, whole, wf)) return e;
+		if(mean_kernel_ms) HIP_TRY(hipEventRecord(ev[2u*i+1u], s->stream));
+		s->t++;
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if(steps>0ull) s->fields_current = true;
+	if(mean_kernel_ms) {
+		double sum = 0.0;
+		for(uint64_t i=0ull; i<steps; i++) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, ev[2u*i], ev[2u*i+1u])); sum += (double)ms; }
+		for(auto& e : ev) (void)hipEventDestroy(e);
+		*mean_kernel_ms = steps ? sum/(double)steps : 0.0;
+	}
+	return LUW_OK;
+}
+int luw_run(luw_solver* s, uint64_t steps) { return run_steps(s, steps, nullptr); }
+int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
+	if(!mean_kernel_ms) return fail(LUW_ERR_INVALID, "luw_run_timed: null output");
+	return run_steps(s, steps, mean_kernel_ms);
+}
+
+int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
+	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_fi: bad argument");
+	if(int e = set_device(s)) return e;
+	const uint32_t A = (uint32_t)luw_get_area(s, direction);
+	const dim3 grid((A+255u)/256u), block(256);
+	const uint32_t odd = (uint32_t)(s->t&1ull);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_extract_fi<uint16_t>), grid, block, 0, s->stream, s->kp, direction, A, odd, (uint16_t*)buf_p, (uint16_t*)buf_m, (const uint16_t*)s->d_fi);
+	else hipLaunchKernelGGL((k_extract_fi<float>), grid, block, 0, s->stream, s->kp, direction, A, odd, (float*)buf_p, (float*)buf_m, (const float*)s->d_fi);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m) {
+	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_insert_fi: bad argument");
+	if(int e = set_device(s)) return e;
+	const uint32_t A = (uint32_t)luw_get_area(s, direction);
+	const dim3 grid((A+255u)/256u), block(256);
+	const uint32_t odd = (uint32_t)(s->t&1ull);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const uint16_t*)buf_p, (const uint16_t*)buf_m, (uint16_t*)s->d_fi);
+	else hipLaunchKernelGGL((k_insert_fi<float>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_fi);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+
+} // extern "C"

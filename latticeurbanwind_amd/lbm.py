@@ -1,0 +1,153 @@
+"""Host-side mirror of the reference's `LBM` class (FX/lbm.hpp:223-633) over the C-ABI.
+
+Same member names and argument meaning as the reference so that set-up code and tests read like the reference's
+own driver code (FX/setup.cpp:6018-6078): construct, fill `flags`, `u.x/y/z`, `rho` through the global index
+n = x + (y + z*Ny)*Nx, `run(0)` to upload + initialise, `run(steps)`, `u.read_from_device()`.
+Single domain per object (one process per GPU); multi-GPU runs compose these through distributed.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class _Vec3View:
+    """lbm.u.x[n] / lbm.u.y[n] / lbm.u.z[n] (FX/lbm.hpp:359-372)"""
+
+    def __init__(self, arr, N):
+        self.x, self.y, self.z = arr[0:N], arr[N:2 * N], arr[2 * N:3 * N]
+
+
+class _Field:
+    def __init__(self, lbm, field, mask, arr, dims):
+        self._lbm, self._field, self._mask, self.data = lbm, field, mask, arr
+        if dims == 3:
+            v = _Vec3View(arr, lbm.get_N())
+            self.x, self.y, self.z = v.x, v.y, v.z
+
+    def __getitem__(self, n): return self.data[n]
+    def __setitem__(self, n, v): self.data[n] = v
+    def __len__(self): return len(self.data)
+
+    def read_from_device(self):  # Memory_Container::read_from_device, FX/lbm.hpp:406-412
+        capi.check(self._lbm._L.luw_download(self._lbm._h, self._mask))
+
+    def write_to_device(self):  # FX/lbm.hpp:413-416
+        capi.check(self._lbm._L.luw_upload(self._lbm._h, self._mask))
+
+
+class LBM:
+    """LBM(Nx, Ny, Nz, nu, fx, fy, fz) -- FX/lbm.hpp:444-451 (sigma/alpha/beta of the SURFACE / TEMPERATURE
+    extensions are not part of this path).  Keyword-only extras carry what the reference keeps in process
+    globals or compile-time defines: DDF format, domain placement, nudging / sponge constants."""
+
+    def __init__(self, Nx, Ny, Nz, nu, fx=0.0, fy=0.0, fz=0.0, *, fp16c=False, D=(1, 1, 1), O=(0, 0, 0),
+                 force_field=False, update_fields_every_step=False, subgrid=True, device=0, kernel=capi.KERNEL_AUTO,
+                 buffer_nudging=None, top_sponge=None):
+        self._L = capi.load()
+        cfg = capi.Config()
+        cfg.struct_size = C.sizeof(capi.Config)
+        cfg.Nx, cfg.Ny, cfg.Nz = int(Nx), int(Ny), int(Nz)
+        cfg.Dx, cfg.Dy, cfg.Dz = D
+        cfg.Ox, cfg.Oy, cfg.Oz = O
+        cfg.nu = float(nu)
+        cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
+        cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
+        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid else capi.OPT_NO_SUBGRID)
+        if buffer_nudging is not None:  # dict(n_cells, inv_tau, downstream_face, nudge_vertical): FX/setup.cpp:3844-3866
+            cfg.buffer_nudging_active = 1
+            cfg.buffer_n_cells = int(buffer_nudging["n_cells"])
+            cfg.buffer_inv_tau_lbmu = float(buffer_nudging["inv_tau"])
+            cfg.buffer_downstream_face_id = int(buffer_nudging.get("downstream_face", 0))
+            cfg.buffer_nudge_vertical = int(buffer_nudging.get("nudge_vertical", 0))
+        if top_sponge is not None:  # dict(n_cells, inv_tau): FX/setup.cpp:3867-3903
+            cfg.top_sponge_active = 1
+            cfg.sponge_n_cells = int(top_sponge["n_cells"])
+            cfg.sponge_inv_tau_lbmu = float(top_sponge["inv_tau"])
+        cfg.device = int(device)
+        cfg.kernel = int(kernel)
+        self.cfg = cfg
+        h = C.c_void_p()
+        capi.check(self._L.luw_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.Nx, self.Ny, self.Nz = int(Nx), int(Ny), int(Nz)
+        N = self.get_N()
+
+        def view(field, ctype, count):
+            ptr = self._L.luw_host_ptr(self._h, field)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)) if ptr else None
+        self.rho = _Field(self, capi.FIELD_RHO, capi.MASK_RHO, view(capi.FIELD_RHO, C.c_float, N), 1)
+        self.u = _Field(self, capi.FIELD_U, capi.MASK_U, view(capi.FIELD_U, C.c_float, 3 * N), 3)
+        self.flags = _Field(self, capi.FIELD_FLAGS, capi.MASK_FLAGS, view(capi.FIELD_FLAGS, C.c_uint8, N), 1)
+        Fv = view(capi.FIELD_F, C.c_float, 3 * N)
+        self.F = _Field(self, capi.FIELD_F, capi.MASK_F, Fv, 3) if Fv is not None else None
+        self._initialized = False
+
+    # ---- life cycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.luw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API
+    def get_Nx(self): return self.Nx
+    def get_Ny(self): return self.Ny
+    def get_Nz(self): return self.Nz
+    def get_N(self): return self.Nx * self.Ny * self.Nz
+    def get_t(self): return int(self._L.luw_get_t(self._h))
+    def index(self, x, y, z): return x + (y + z * self.Ny) * self.Nx  # FX/lbm.hpp:512-514
+    def position(self, x, y, z):  # FX/lbm.hpp:523-525
+        f = np.float32
+        return (f(x) - f(0.5) * f(self.Nx) + f(0.5), f(y) - f(0.5) * f(self.Ny) + f(0.5), f(z) - f(0.5) * f(self.Nz) + f(0.5))
+
+    def set_f(self, fx, fy, fz): capi.check(self._L.luw_set_f(self._h, fx, fy, fz))
+    def set_coriolis(self, ox, oy, oz): capi.check(self._L.luw_set_coriolis(self._h, ox, oy, oz))
+
+    def run(self, steps=0):
+        """LBM::run (FX/lbm.cpp:1292-1312): first call uploads the host fields and runs `initialize`."""
+        if not self._initialized:
+            capi.check(self._L.luw_initialize(self._h))
+            self._initialized = True
+        if steps:
+            capi.check(self._L.luw_run(self._h, int(steps)))
+
+    def run_timed(self, steps):
+        """like run(); returns the mean stream_collide kernel time in ms (HIP events on the launch stream)"""
+        if not self._initialized:
+            self.run(0)
+        ms = C.c_double()
+        capi.check(self._L.luw_run_timed(self._h, int(steps), C.byref(ms)))
+        return ms.value
+
+    # ---- device-level interface (multi-GPU driver)
+    def area(self, direction): return int(self._L.luw_get_area(self._h, direction))
+    def set_stream(self, stream_ptr): capi.check(self._L.luw_set_stream(self._h, stream_ptr))
+    def enqueue_stream_collide(self, box, write_fields=False):
+        x0, x1, y0, y1, z0, z1 = box
+        capi.check(self._L.luw_enqueue_stream_collide(self._h, x0, x1, y0, y1, z0, z1, int(write_fields)))
+    def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
+    def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
+    def increment_time_step(self, steps=1): capi.check(self._L.luw_increment_time_step(self._h, steps))
+    def finish(self): capi.check(self._L.luw_finish(self._h))
+    def device_ptr(self, field): return self._L.luw_device_ptr(self._h, field)
+    def pitch(self): return int(self._L.luw_get_pitch(self._h))
+    def plane_stride(self): return int(self._L.luw_get_plane_stride(self._h))
+    def download_fi(self):
+        """DDFs as stored (float32 values or uint16 FP16C codes), reference layout fi[i*N+n]"""
+        out = np.zeros(19 * self.get_N(), np.uint16 if self.cfg.ddf_format == capi.DDF_FP16C else np.float32)
+        capi.check(self._L.luw_download_fi(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def upload_fi(self, fi):
+        fi = np.ascontiguousarray(fi, np.uint16 if self.cfg.ddf_format == capi.DDF_FP16C else np.float32)
+        assert fi.size == 19 * self.get_N()
+        capi.check(self._L.luw_upload_fi(self._h, fi.ctypes.data_as(C.c_void_p)))
+
+    def ddf_itemsize(self): return 2 if self.cfg.ddf_format == capi.DDF_FP16C else 4

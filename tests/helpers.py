@@ -1,0 +1,56 @@
+"""Shared test helpers: synthetic states applied identically to the oracle (oracle.OracleLBM) and to the product
+(latticeurbanwind_amd.LBM), which expose the same host arrays (rho, u, flags, F) in the reference's layout."""
+import numpy as np
+
+TYPE_S, TYPE_E = 0x01, 0x02
+
+
+def synthetic_state(Nx, Ny, Nz, seed=1, solids=True, shell="E", u0=0.05):
+    """Deterministic 'urban' state: smooth shear flow + seeded perturbation, optional box solids, outer shell of
+    TYPE_E ("E"), solid ground + TYPE_E elsewhere ("luw", like FX/setup.cpp:5945-5985) or fully periodic (None)."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(np.arange(Nz), np.arange(Ny), np.arange(Nx), indexing="ij")
+    flags = np.zeros((Nz, Ny, Nx), np.uint8)
+    if solids:
+        bx0, bx1 = Nx // 3, max(Nx // 3 + 1, Nx // 2)
+        by0, by1 = Ny // 4, max(Ny // 4 + 1, Ny // 2)
+        flags[: max(1, Nz // 2), by0:by1, bx0:bx1] = TYPE_S
+        if Nx > 8 and Ny > 8:
+            flags[: max(1, Nz // 3), Ny - 4:Ny - 2, 2:5] = TYPE_S
+    ux = (u0 * (0.3 + 0.7 * (z + 0.5) / Nz) + 0.01 * rng.standard_normal((Nz, Ny, Nx))).astype(np.float32)
+    uy = (0.02 * np.sin(2 * np.pi * x / max(Nx, 2)) + 0.01 * rng.standard_normal((Nz, Ny, Nx))).astype(np.float32)
+    uz = (0.01 * rng.standard_normal((Nz, Ny, Nx))).astype(np.float32)
+    rho = (1.0 + 0.01 * rng.standard_normal((Nz, Ny, Nx))).astype(np.float32)
+    if shell in ("E", "luw"):
+        b = np.zeros((Nz, Ny, Nx), bool)
+        b[0], b[-1], b[:, 0], b[:, -1], b[:, :, 0], b[:, :, -1] = True, True, True, True, True, True
+        if shell == "luw":
+            flags[0] = TYPE_S
+            b[0] = False
+        m = b & (flags != TYPE_S)
+        flags[m] |= TYPE_E
+        rho[m] = 1.0
+    s = (flags & TYPE_S) != 0
+    ux[s] = 0; uy[s] = 0; uz[s] = 0
+    return flags.ravel(), np.concatenate([ux.ravel(), uy.ravel(), uz.ravel()]), rho.ravel()
+
+
+def apply_state(lbm, flags, u, rho, F=None):
+    lbm.flags.data[:] = flags if hasattr(lbm.flags, "data") else 0
+    lbm.u.data[:] = u
+    lbm.rho.data[:] = rho
+    if F is not None:
+        lbm.F.data[:] = F
+
+
+def apply_state_oracle(o, flags, u, rho, F=None):
+    o.flags[:] = flags
+    o.u[:] = u
+    o.rho[:] = rho
+    if F is not None:
+        o.F[:] = F
+
+
+def rmse_u(ua, ub, fluid_mask):
+    d = (ua.reshape(3, -1) - ub.reshape(3, -1))[:, fluid_mask]
+    return float(np.sqrt((d.astype(np.float64) ** 2).sum(0).mean()))

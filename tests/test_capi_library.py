@@ -1,0 +1,60 @@
+"""CPU checks of the product's C-ABI: the library builds for gfx950, loads, exports every symbol that
+include/luw_core.h declares, and fails loudly (no fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "luw_core.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(luw_[a-z_A-Z0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(luw):
+    from latticeurbanwind_amd import capi
+    L = capi.load()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "missing export " + n
+    assert sorted(capi.SYMBOLS) == names
+    assert L.luw_abi_version() == 1
+
+
+def test_config_struct_layout_matches_header(luw):
+    from latticeurbanwind_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "luw_core.h")).read()
+    body = hdr[hdr.index("typedef struct luw_config {") + len("typedef struct luw_config {"):hdr.index("} luw_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(uint32_t|int32_t|float)\s+(.*)", decl.strip(), flags=re.S)
+        if m:
+            fields += [(n.strip(), m.group(1)) for n in m.group(2).split(",")]
+    ctype = {"uint32_t": C.c_uint32, "int32_t": C.c_int32, "float": C.c_float}
+    assert [(n, ctype[t]) for n, t in fields] == list(capi.Config._fields_)
+
+
+def test_no_cpu_fallback_without_gpu(luw):
+    from latticeurbanwind_amd import capi
+    L = capi.load()
+    n = C.c_int(0)
+    rc = L.luw_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.LuwError):
+        luw.LBM(8, 8, 8, 0.01)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "latticeurbanwind_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "luw_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

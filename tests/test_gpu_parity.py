@@ -1,0 +1,209 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on identical inputs.  GPU only.
+
+Bar: value-exact.  The kernels and the oracle implement one arithmetic contract (FP32, fmaf where the reference
+writes fma, every other op rounded separately, IEEE / and sqrt), so rho, u and all 19 DDF planes must compare equal
+element for element (np.array_equal; +0 == -0) -- for FP32 and for FP16C storage, for both kernels."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import synthetic_state, TYPE_S, TYPE_E
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0), coriolis=None, nudging=None, sponge=None,
+              use_F=False, every_step=False, subgrid=True):
+    from latticeurbanwind_amd import capi
+    flags, u, rho = state
+    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4}[kernel],
+                force_field=use_F, update_fields_every_step=every_step, subgrid=subgrid,
+                buffer_nudging=nudging, top_sponge=sponge)
+    o = oracle.OracleLBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, use_F=use_F, subgrid=subgrid)
+    for l in (g, o):
+        fl = l.flags.data if hasattr(l.flags, "data") else l.flags
+        fl[:] = flags
+        (l.u.data if hasattr(l.u, "data") else l.u)[:] = u
+        (l.rho.data if hasattr(l.rho, "data") else l.rho)[:] = rho
+    if use_F:
+        rng = np.random.default_rng(7)
+        F = (1e-5 * rng.standard_normal(3 * Nx * Ny * Nz)).astype(np.float32)
+        g.F.data[:] = F; o.F[:] = F
+    if coriolis:
+        g.set_coriolis(*coriolis); o.set_coriolis(*coriolis)
+    if nudging:
+        o.set_buffer_nudging(nudging["n_cells"], nudging["inv_tau"], nudging.get("downstream_face", 0), nudging.get("nudge_vertical", 0))
+    if sponge:
+        o.set_top_sponge(sponge["n_cells"], sponge["inv_tau"])
+    return g, o
+
+
+def assert_same(g, o, what=""):
+    g.u.read_from_device(); g.rho.read_from_device()
+    fi = g.download_fi()
+    assert np.array_equal(fi, o.fi) or np.array_equal(fi.astype(np.float32) if fi.dtype != np.uint16 else fi, o.fi), "DDF mismatch " + what + " (%d differ)" % int((fi != o.fi).sum())
+    assert np.array_equal(g.rho.data, o.rho), "rho mismatch " + what
+    assert np.array_equal(g.u.data, o.u), "u mismatch " + what
+
+
+def ddf_equal(fi, ref):
+    """value equality; FP16C codes 0x0000/0x8000 are both zero"""
+    if fi.dtype == np.uint16:
+        a = fi.copy(); b = ref.copy()
+        a[a == 0x8000] = 0; b[b == 0x8000] = 0
+        return np.array_equal(a, b)
+    return np.array_equal(fi, ref)
+
+
+def check(g, o, what):
+    g.u.read_from_device(); g.rho.read_from_device()
+    fi = g.download_fi()
+    nbad = int((fi != o.fi).sum())
+    assert ddf_equal(fi, o.fi), "%s: %d DDF values differ" % (what, nbad)
+    assert np.array_equal(g.rho.data, o.rho), what + ": rho differs"
+    assert np.array_equal(g.u.data, o.u), what + ": u differs"
+
+
+SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4)]
+
+
+@pytest.mark.parametrize("kernel", ["s", "v"])
+@pytest.mark.parametrize("fp16c", [False, True])
+@pytest.mark.parametrize("size", SIZES)
+def test_stream_collide_matches_oracle(luw, kernel, fp16c, size):
+    from oracle import oracle
+    Nx, Ny, Nz = size
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-4, fp16c, kernel, synthetic_state(Nx, Ny, Nz, seed=3, shell="luw"), every_step=True)
+    g.run(0); o.initialize()
+    check(g, o, "after initialize")
+    for _ in range(4):
+        g.run(3); o.run(3)          # odd count: exercises both parities across calls
+        check(g, o, "t=%d" % o.t)
+
+
+@pytest.mark.parametrize("kernel", ["s", "v"])
+def test_periodic_box_without_boundaries(luw, kernel):
+    # "all box sides where no boundary type is set remain periodic" (DOCUMENTATION.md:195-256): wrap in x,y,z
+    from oracle import oracle
+    Nx, Ny, Nz = 22, 9, 7
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 0.02, False, kernel, synthetic_state(Nx, Ny, Nz, seed=5, solids=True, shell=None), every_step=True)
+    g.run(9); o.run(9)
+    check(g, o, "periodic")
+
+
+@pytest.mark.parametrize("kernel", ["s", "v"])
+@pytest.mark.parametrize("fp16c", [False, True])
+def test_all_force_terms(luw, kernel, fp16c):
+    # volume force + Coriolis + per-cell force field + buffer nudging (west/south/north/top, east = downstream) + top sponge
+    from oracle import oracle
+    Nx, Ny, Nz = 40, 36, 30
+    nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1)
+    spg = dict(n_cells=6, inv_tau=0.02)
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, fp16c, kernel, synthetic_state(Nx, Ny, Nz, seed=11, shell="luw"),
+                     force=(1e-5, -2e-5, 3e-6), coriolis=(0.0, 3e-5, 4e-5), nudging=nud, sponge=spg, use_F=True, every_step=True)
+    for _ in range(3):
+        g.run(5); o.run(5)
+        check(g, o, "forces t=%d" % o.t)
+
+
+@pytest.mark.parametrize("kernel", ["s", "v"])
+def test_deferred_field_update_equals_every_step(luw, kernel):
+    # default mode writes rho,u only in the last step of a run() call; observed values must equal UPDATE_FIELDS
+    from oracle import oracle
+    Nx, Ny, Nz = 24, 20, 16
+    st = synthetic_state(Nx, Ny, Nz, seed=2, shell="luw")
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-4, False, kernel, st, every_step=False)
+    g.run(7); o.run(7)
+    check(g, o, "deferred 7")
+    g.run(6); o.run(6)
+    check(g, o, "deferred 13")
+
+
+def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
+    # size-independent property at a bench-class size (the oracle would take minutes): both kernels, same bits
+    from latticeurbanwind_amd import capi
+    N = 256
+    st = synthetic_state(N, N, N, seed=9, shell="luw")
+    res = []
+    for k in (capi.KERNEL_SCALAR, capi.KERNEL_VEC4):
+        g = luw.LBM(N, N, N, 1e-5, kernel=k)
+        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+        g.run(10)
+        g.u.read_from_device(); g.rho.read_from_device()
+        res.append((g.u.data.copy(), g.rho.data.copy()))
+        g.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    fluid = (st[0] & TYPE_S) == 0
+    m0 = st[2][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum()
+    assert np.isfinite(res[0][0]).all() and abs(res[0][1][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum() / m0 - 1) < 1e-3
+
+
+def test_rest_state_and_mass_conservation_at_512cubed(luw):
+    # BASELINE config C2 size (512^3 FP32): rest state is an exact fixed point; a periodic box conserves mass
+    N = 512
+    g = luw.LBM(N, N, N, 1e-5)
+    g.run(4)
+    g.rho.read_from_device(); g.u.read_from_device()
+    assert np.all(g.rho.data == 1.0) and not g.u.data.any()
+    g.close()
+    g = luw.LBM(N, N, N, 0.01)
+    x = np.arange(N, dtype=np.float32)
+    wave = (0.02 * np.sin(2 * np.pi * x / N)).astype(np.float32)
+    g.u.data.reshape(3, N, N, N)[0] = wave[None, :, None]       # u_x varies along y: shear wave, divergence free
+    g.run(20)
+    g.rho.read_from_device()
+    assert abs(g.rho.data.astype(np.float64).mean() - 1.0) < 1e-7
+    g.close()
+
+
+@pytest.mark.parametrize("case,fp16c,npz", [("CaseA", False, "ref_fp32_CaseA.npz"), ("CaseB", False, "ref_fp32_CaseB.npz"),
+                                            ("CaseL", False, "ref_fp32_CaseL.npz"), ("CaseA", True, "ref_shipped_CaseA.npz")])
+def test_hip_path_vs_real_reference_fields(luw, case, fp16c, npz):
+    # the committed fields of the REAL reference solver (FluidX3D via OpenCL on MI355X): same gates as the oracle
+    from oracle import setup_profile
+    from test_oracle_vs_reference import compare
+    gold = np.load(os.path.join(GOLD, npz))
+    s = setup_profile.setup_profile_case(os.path.join(GOLD, "refcases", case, "conf.luwpf"), solid_mask=gold["solid"])
+    nud = dict(n_cells=s["buffer_N"], inv_tau=float(s["buffer_inv_tau"]), downstream_face=s["buffer_face"], nudge_vertical=s["buffer_nudge_vertical"]) if s["buffer_active"] else None
+    spg = dict(n_cells=s["sponge_N"], inv_tau=float(s["sponge_inv_tau"])) if s["sponge_active"] else None
+    g = luw.LBM(s["Nx"], s["Ny"], s["Nz"], float(s["nu"]), fp16c=fp16c, buffer_nudging=nud, top_sponge=spg)
+    g.flags.data[:] = s["flags"]; g.u.data[:] = s["u"]; g.rho.data[:] = s["rho"]
+    g.run(8); g.u.read_from_device()
+    compare(gold, s, g.u.data, None, 8, 2e-6 if fp16c else 2e-7)
+    g.run(56); g.u.read_from_device(); g.rho.read_from_device()
+    compare(gold, s, g.u.data, g.rho.data, 64, 1e-4 if fp16c else 1e-6)
+
+
+def test_halo_extract_insert_match_oracle(luw):
+    # transfer_extract_fi / transfer__insert_fi (FX/kernel.cpp:2241-2270) on a domain that is split in all 3 axes
+    import ctypes as C
+    import torch
+    from oracle import oracle
+    Nx, Ny, Nz = 14, 10, 9
+    st = synthetic_state(Nx, Ny, Nz, seed=4, shell=None)
+    for fp16c in (False, True):
+        g = luw.LBM(Nx, Ny, Nz, 0.01, fp16c=fp16c, D=(2, 2, 2), O=(-1, -1, -1), update_fields_every_step=True)
+        o = oracle.OracleLBM(Nx, Ny, Nz, 0.01, fp16c=fp16c, D=(2, 2, 2), O=(-1, -1, -1))
+        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+        o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+        g.run(0); o.initialize()
+        for step in range(3):
+            g.enqueue_stream_collide((0, Nx, 0, Ny, 0, Nz), True); g.finish()
+            o.stream_collide()
+            tdt = torch.int16 if fp16c else torch.float32
+            for d in range(3):
+                A = g.area(d)
+                bp = torch.zeros(5 * A, dtype=tdt, device="cuda"); bm = torch.zeros(5 * A, dtype=tdt, device="cuda")
+                torch.cuda.synchronize()
+                g.enqueue_extract_fi(d, bp.data_ptr(), bm.data_ptr()); g.finish()
+                obp, obm = o.extract_fi(d)
+                assert np.array_equal(bp.cpu().numpy().view(obp.dtype), obp) and np.array_equal(bm.cpu().numpy().view(obm.dtype), obm)
+                # swap p/m (periodic self-neighbour) and insert
+                g.enqueue_insert_fi(d, bm.data_ptr(), bp.data_ptr()); g.finish()
+                o.insert_fi(d, obm, obp)
+            g.increment_time_step(1); o.t += 1
+            assert ddf_equal(g.download_fi(), o.fi)
+        g.close()
