@@ -131,6 +131,7 @@ int luw_set_stream(luw_solver* s, void* hip_stream);                      /* str
  * write_fields != 0 also stores rho,u. */
 int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, int write_fields);
 int luw_increment_time_step(luw_solver* s, uint64_t steps);               /* LBM_Domain::increment_time_step */
+int luw_reset_time_step(luw_solver* s);                                   /* LBM_Domain::reset_time_step */
 /* halo transfer of the 5 outgoing DDFs per face cell: transfer_extract_fi / transfer__insert_fi
  * (FX/kernel.cpp:2241-2270).  direction 0/1/2 = x/y/z.  Buffers are DEVICE pointers holding 5*A elements of
  * the DDF storage type, A = luw_get_area(direction), element (b*A + a) as in the reference. */

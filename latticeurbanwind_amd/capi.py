@@ -22,7 +22,7 @@ SYMBOLS = [
     "luw_abi_version", "luw_last_error", "luw_device_count", "luw_create", "luw_destroy", "luw_host_ptr",
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
-    "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_get_area", "luw_enqueue_extract_fi",
+    "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
     "luw_enqueue_insert_fi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_upload_fi",
 ]
 
@@ -64,6 +64,13 @@ def load():
         return _LIB
     if not os.path.exists(_SO):
         raise LuwError("HIP library %s is missing: run latticeurbanwind_amd.build() (needs hipcc); there is no CPU fallback" % _SO)
+    try:
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64 under the same SONAMEs as /opt/rocm; whichever is
+        # loaded first serves the whole process.  Load torch's first so that torch tensors, streams and RCCL share
+        # ONE HIP runtime with this library (loading ours first leaves torch without devices).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     vp, u64, u32, i32, f32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float
     L.luw_abi_version.restype = i32
@@ -88,6 +95,7 @@ def load():
     L.luw_set_stream.argtypes = [vp, vp]
     L.luw_enqueue_stream_collide.argtypes = [vp, u32, u32, u32, u32, u32, u32, i32]
     L.luw_increment_time_step.argtypes = [vp, u64]
+    L.luw_reset_time_step.argtypes = [vp]
     L.luw_enqueue_extract_fi.argtypes = [vp, u32, vp, vp]
     L.luw_enqueue_insert_fi.argtypes = [vp, u32, vp, vp]
     L.luw_finish.argtypes = [vp]

@@ -256,6 +256,11 @@ template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k
 			}
 			#pragma unroll
 			for(int q=0; q<19; q++) f[q][c] = fc[q];
+		} else {
+			// pass-through: the store phase swaps the slots of each pair (f[i] leaves through B(i), f[i+1] through
+			// A(i)); pre-swap so that every value returns to the slot it was loaded from
+			#pragma unroll
+			for(int i=1; i<19; i+=2) { const float t = f[i][c]; f[i][c] = f[i+1][c]; f[i+1][c] = t; }
 		}
 	}
 
@@ -553,8 +558,10 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	memset(s->h_flags, 0, s->N);
 	if(s->h_F) memset(s->h_F, 0, 3ull*s->N*4ull);
 	// padding / not-yet-uploaded device memory must hold defined values (pass-through of padding cells)
-	if(hipMemset(s->d_fi, 0, 19ull*Np*s->ddf_bytes)!=hipSuccess||hipMemset(s->d_rho, 0, Np*4ull)!=hipSuccess||hipMemset(s->d_u, 0, 3ull*Np*4ull)!=hipSuccess||hipMemset(s->d_flags, 0, Np)!=hipSuccess) return oom("memset");
-	if(s->d_F&&hipMemset(s->d_F, 0, 3ull*Np*4ull)!=hipSuccess) return oom("memset F");
+	// (on the solver's own non-blocking stream: the legacy NULL stream does not order against it)
+	if(hipMemsetAsync(s->d_fi, 0, 19ull*Np*s->ddf_bytes, s->stream)!=hipSuccess||hipMemsetAsync(s->d_rho, 0, Np*4ull, s->stream)!=hipSuccess||hipMemsetAsync(s->d_u, 0, 3ull*Np*4ull, s->stream)!=hipSuccess||hipMemsetAsync(s->d_flags, 0, Np, s->stream)!=hipSuccess) return oom("memset");
+	if(s->d_F&&hipMemsetAsync(s->d_F, 0, 3ull*Np*4ull, s->stream)!=hipSuccess) return oom("memset F");
+	if(hipStreamSynchronize(s->stream)!=hipSuccess) return oom("memset sync");
 	// ramps of the nudging / sponge terms, evaluated on the host exactly like FX/kernel.cpp:1581-1583,1604-1606
 	if(k.buffer_active) {
 		std::vector<float> wb(k.buffer_N+2u);
@@ -703,6 +710,12 @@ int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t
 int luw_increment_time_step(luw_solver* s, uint64_t steps) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_increment_time_step: null solver");
 	s->t += steps;
+	return LUW_OK;
+}
+
+int luw_reset_time_step(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_reset_time_step: null solver");
+	s->t = 0ull;
 	return LUW_OK;
 }
 

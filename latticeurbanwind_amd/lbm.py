@@ -135,6 +135,7 @@ class LBM:
     def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def increment_time_step(self, steps=1): capi.check(self._L.luw_increment_time_step(self._h, steps))
+    def reset_time_step(self): capi.check(self._L.luw_reset_time_step(self._h))
     def finish(self): capi.check(self._L.luw_finish(self._h))
     def device_ptr(self, field): return self._L.luw_device_ptr(self._h, field)
     def pitch(self): return int(self._L.luw_get_pitch(self._h))

@@ -1,0 +1,41 @@
+"""CPU test double for latticeurbanwind_amd.distributed: one domain backed by the oracle, halo buffers as torch CPU
+tensors (so the real DomainDecomposedLBM / TorchDistTransport code runs under gloo).  tests/ only."""
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+class OracleDomain:
+    def __init__(self, layout, nu, fp16c=False):
+        self.layout = layout
+        self.o = oracle.OracleLBM(*layout.lN, nu, fp16c=fp16c, D=layout.D, O=layout.O)
+        self.np_dtype = np.uint16 if fp16c else np.float32
+        self.t_dtype = torch.int16 if fp16c else torch.float32
+        self.buf = {a: [torch.zeros(5 * self.o.area(a), dtype=self.t_dtype) for _ in range(4)] for a in layout.split_axes()}
+
+    def set_fields(self, flags, u, rho):
+        self.o.flags[:] = flags; self.o.u[:] = u; self.o.rho[:] = rho
+
+    def initialize(self): self.o.initialize()
+    def get_t(self): return self.o.t
+    def increment_time_step(self, n=1): self.o.t += n
+    def reset_time_step(self): self.o.t = 0
+
+    def stream_collide(self, box, write_fields, stream):
+        assert tuple(box) == tuple(self.layout.whole_box())      # the test double always does the whole domain at once
+        self.o.stream_collide()
+
+    def extract(self, axis, stream):
+        bp, bm = self.o.extract_fi(axis)
+        self.buf[axis][0].copy_(torch.from_numpy(bp.view(np.int16) if self.np_dtype == np.uint16 else bp))
+        self.buf[axis][1].copy_(torch.from_numpy(bm.view(np.int16) if self.np_dtype == np.uint16 else bm))
+        return self.buf[axis][0], self.buf[axis][1]
+
+    def recv_buffers(self, axis): return self.buf[axis][2], self.buf[axis][3]
+
+    def insert(self, axis, stream):
+        rp = self.buf[axis][2].numpy().view(self.np_dtype); rm = self.buf[axis][3].numpy().view(self.np_dtype)
+        self.o.insert_fi(axis, np.ascontiguousarray(rp), np.ascontiguousarray(rm))
+
+    def download(self): return self.o.u, self.o.rho

@@ -1,0 +1,56 @@
+"""N>1 path on CPU: the product's decomposition + halo-exchange driver (latticeurbanwind_amd/distributed.py) runs in
+world_size 2 and 4 gloo groups over the oracle test double and must reproduce the single-domain run of the global
+lattice bit for bit (reference semantics: FX/lbm.cpp:1907-1935, FX/kernel.cpp:2241-2270)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import synthetic_state
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def single_domain(gN, steps, fp16c):
+    flags, u, rho = synthetic_state(*gN, seed=21, shell=None)
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
+    o.flags[:] = flags; o.u[:] = u; o.rho[:] = rho
+    o.run(steps)
+    return o.u.copy(), o.rho.copy()
+
+
+@pytest.mark.parametrize("gN,D,fp16c", [((16, 10, 6), (2, 1, 1), False), ((12, 12, 8), (2, 2, 1), False), ((12, 8, 8), (1, 2, 2), True)])
+def test_gloo_multi_domain_equals_single_domain(tmp_path, gN, D, fp16c):
+    world = D[0] * D[1] * D[2]
+    steps = 5
+    out = str(tmp_path / "result.npz")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), *map(str, gN), *map(str, D), str(steps), str(int(fp16c)), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    u_ref, rho_ref = single_domain(gN, steps, fp16c)
+    assert np.array_equal(got["u"], u_ref) and np.array_equal(got["rho"], rho_ref)
+
+
+def test_layout_matches_reference_rules():
+    from latticeurbanwind_amd.distributed import DomainLayout, choose_decomposition
+    assert choose_decomposition(8) == (4, 2, 1) and choose_decomposition(2) == (2, 1, 1) and choose_decomposition(1) == (1, 1, 1)
+    lay = DomainLayout((2048, 1024, 512), (4, 2, 1), 6)          # d = x + (y + z*Dy)*Dx -> x=2, y=1, z=0 (FX/lbm.cpp:1071)
+    assert lay.coord == (2, 1, 0)
+    assert lay.lN == (514, 514, 512) and lay.O == (1023, 511, 0)  # N/D + 2 on split axes, O = coord*N/D - 1 (FX/lbm.cpp:1072)
+    assert lay.neighbor(0, +1) == 7 and lay.neighbor(0, -1) == 5 and lay.neighbor(1, +1) == 2 and lay.neighbor(2, +1) == 6
+    assert lay.neighbor(0, +1) == lay.rank_of(((2 + 1) % 4, 1, 0))
+    # shell + interior tile the non-halo cells exactly once
+    cover = np.zeros((lay.lN[2], lay.lN[1], lay.lN[0]), np.int32)
+    for b in lay.shell_boxes() + [lay.interior_box()]:
+        cover[b[4]:b[5], b[2]:b[3], b[0]:b[1]] += 1
+    w = lay.whole_box()
+    assert cover[w[4]:w[5], w[2]:w[3], w[0]:w[1]].min() == 1 and cover.max() == 1 and cover.sum() == 512 * 512 * 512
+    with pytest.raises(ValueError):
+        DomainLayout((10, 10, 10), (3, 1, 1), 0)

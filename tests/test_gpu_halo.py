@@ -1,0 +1,56 @@
+"""The whole multi-domain machinery on ONE GPU: 2..8 HipDomain objects (real pack/unpack kernels, shell/interior split
+on two streams, box launches of the vector kernel) driven in lock-step must equal the single-domain HIP run and the
+oracle bit for bit.  GPU only (what cannot run here -- RCCL between processes -- is covered by the gloo test of the
+same driver code)."""
+import numpy as np
+import pytest
+
+from helpers import synthetic_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("gN,D", [((24, 20, 16), (2, 1, 1)), ((24, 20, 16), (2, 2, 2)), ((32, 24, 12), (4, 2, 1)), ((26, 18, 16), (1, 3, 2))])
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("fp16c", [False, True])
+def test_local_group_equals_single_domain(luw, gN, D, overlap, fp16c):
+    from latticeurbanwind_amd.distributed import LocalGroup, HipDomain
+    from oracle import oracle
+    flags, u, rho = synthetic_state(*gN, seed=31, shell=None)
+    steps = 5
+    grp = LocalGroup(gN, D, 0.01, lambda lay: HipDomain(lay, 0.01, fp16c=fp16c), overlap=overlap)
+    assert all(s.overlap == overlap for s in grp.sims)
+    for s in grp.sims:
+        s.set_fields_from_global(flags, u, rho)
+    grp.run(steps)
+    gu, grho = grp.gather_u_rho()
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
+    o.flags[:] = flags; o.u[:] = u; o.rho[:] = rho
+    o.run(steps)
+    assert np.array_equal(gu, o.u) and np.array_equal(grho, o.rho)
+    for s in grp.sims:
+        s.backend.lbm.close()
+
+
+def test_box_launches_tile_the_domain(luw):
+    # any partition of the lattice into boxes gives the same result as one whole-domain launch (both kernels)
+    from latticeurbanwind_amd import capi
+    Nx, Ny, Nz = 45, 14, 9
+    st = synthetic_state(Nx, Ny, Nz, seed=8, shell="luw")
+    res = {}
+    for name, kern, boxes in (("whole_v", capi.KERNEL_VEC4, [(0, Nx, 0, Ny, 0, Nz)]),
+                              ("split_v", capi.KERNEL_VEC4, [(0, 1, 0, Ny, 0, Nz), (1, 7, 0, Ny, 0, Nz), (7, 30, 0, 5, 0, Nz), (7, 30, 5, Ny, 0, 4), (7, 30, 5, Ny, 4, Nz), (30, 44, 0, Ny, 0, Nz), (44, 45, 0, Ny, 0, Nz)]),
+                              ("split_s", capi.KERNEL_SCALAR, [(0, 20, 0, Ny, 0, Nz), (20, Nx, 0, 6, 0, Nz), (20, Nx, 6, Ny, 0, Nz)])):
+        g = luw.LBM(Nx, Ny, Nz, 1e-3, kernel=kern)
+        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+        g.run(0)
+        for step in range(4):
+            for b in boxes:
+                g.enqueue_stream_collide(b, True)
+            g.finish(); g.increment_time_step(1)
+        g.u.read_from_device(); g.rho.read_from_device()
+        res[name] = (g.u.data.copy(), g.rho.data.copy(), g.download_fi())
+        g.close()
+    for k in ("split_v", "split_s"):
+        for a, b in zip(res["whole_v"], res[k]):
+            assert np.array_equal(a, b), k

@@ -41,14 +41,6 @@ def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0)
     return g, o
 
 
-def assert_same(g, o, what=""):
-    g.u.read_from_device(); g.rho.read_from_device()
-    fi = g.download_fi()
-    assert np.array_equal(fi, o.fi) or np.array_equal(fi.astype(np.float32) if fi.dtype != np.uint16 else fi, o.fi), "DDF mismatch " + what + " (%d differ)" % int((fi != o.fi).sum())
-    assert np.array_equal(g.rho.data, o.rho), "rho mismatch " + what
-    assert np.array_equal(g.u.data, o.u), "u mismatch " + what
-
-
 def ddf_equal(fi, ref):
     """value equality; FP16C codes 0x0000/0x8000 are both zero"""
     if fi.dtype == np.uint16:
