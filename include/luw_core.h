@@ -65,6 +65,8 @@ extern "C" {
 #define LUW_KERNEL_AUTO 0
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, dword accesses */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, 16-byte accesses, wave64 lane shifts for x+1 populations */
+#define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
+#define LUW_KERNEL_EXP_NOSHIFT 101      /* measurement only: scalar kernel with the x+1 neighbours replaced by x (no physics) */
 
 typedef struct luw_config {
 	uint32_t struct_size;            /* = sizeof(luw_config), ABI check */

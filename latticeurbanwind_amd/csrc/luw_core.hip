@@ -81,13 +81,16 @@ template<typename T> __global__ __launch_bounds__(256) void k_initialize(const K
 }
 
 // ---------------------------------------------------------------- scalar kernel: 1 cell per lane
-template<typename T, int PARITY> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
+// measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
+template<typename T, int PARITY, int MODE=0> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t x = b.x0+blockIdx.x*blockDim.x+threadIdx.x, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	if(cell_is_halo(p, x, y, z)) return;
 	uint32_t j[19];
 	neighbors(p, x, y, z, j);
+	if constexpr(MODE==2) { j[1] = j[0]; j[7] = j[3]; j[9] = j[5]; j[13] = j[4]; j[15] = j[6]; }
 	const uint32_t n = j[0];
 	const uint8_t flagsn = flags[n];
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
@@ -98,13 +101,15 @@ template<typename T, int PARITY> __global__ __launch_bounds__(256) void k_stream
 		f[i  ] = ddf_decode<T>(fi[(size_t)slotA<PARITY>(i)*p.Np+n]);
 		f[i+1] = ddf_decode<T>(fi[(size_t)slotB<PARITY>(i)*p.Np+j[i]]);
 	}
-	float rhon, uxn, uyn, uzn;
-	collide_cell(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
-	if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
-		rho[n] = rhon;
-		u[n] = uxn;
-		u[(size_t)p.Np+n] = uyn;
-		u[2ull*p.Np+n] = uzn;
+	if constexpr(MODE!=1) {
+		float rhon, uxn, uyn, uzn;
+		collide_cell(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
+		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
+			rho[n] = rhon;
+			u[n] = uxn;
+			u[(size_t)p.Np+n] = uyn;
+			u[2ull*p.Np+n] = uzn;
+		}
 	}
 	fi[n] = ddf_encode<T>(f[0]);
 	#pragma unroll
@@ -458,8 +463,12 @@ template<typename T> static void launch_typed(luw_solver* s, const Box& b, const
 		const uint32_t nx = b.x1-b.x0;
 		const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
 		const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-		if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
-		else hipLaunchKernelGGL((k_stream_collide_s<T, 0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+		const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : 0;
+		#define LUW_LAUNCH_S(PAR, MODE) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
+		if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0); else LUW_LAUNCH_S(0, 0); }
+		else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1); else LUW_LAUNCH_S(0, 1); }
+		else { if(odd) LUW_LAUNCH_S(1, 2); else LUW_LAUNCH_S(0, 2); }
+		#undef LUW_LAUNCH_S
 	}
 }
 
@@ -467,7 +476,7 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
-	const bool vec = s->kernel==LUW_KERNEL_VEC4 || s->kernel==LUW_KERNEL_AUTO;
+	const bool vec = s->kernel==LUW_KERNEL_VEC4; // LUW_KERNEL_AUTO: the scalar kernel is the faster one on MI355X today (profiles/)
 	if(s->ddf_bytes==2u) launch_typed<uint16_t>(s, b, write_fields, vec); else launch_typed<float>(s, b, write_fields, vec);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
