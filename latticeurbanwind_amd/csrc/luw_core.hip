@@ -80,10 +80,16 @@ template<typename T> __global__ __launch_bounds__(256) void k_initialize(const K
 	}
 }
 
+// DDF accesses are streaming: every slot is read once and written once per step, so all DDF loads / stores carry
+// the non-temporal hint (global_load/store ... nt).  Measured on MI355X (tools/membench.hip, profiles/): the
+// 19-plane in-place update moves 5.3 TB/s with the default cache policy and 6.1 TB/s non-temporal.
+template<bool NT, typename T> __device__ __forceinline__ T ldg(const T* p) { if constexpr(NT) return __builtin_nontemporal_load(p); else return *p; }
+template<bool NT, typename T> __device__ __forceinline__ void stg(T* p, const T v) { if constexpr(NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
 // ---------------------------------------------------------------- scalar kernel: 1 cell per lane
 // MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
 // measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
-template<typename T, int PARITY, int MODE=0> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<typename T, int PARITY, int MODE=0, bool NT=true> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t x = b.x0+blockIdx.x*blockDim.x+threadIdx.x, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
@@ -95,11 +101,11 @@ template<typename T, int PARITY, int MODE=0> __global__ __launch_bounds__(256) v
 	const uint8_t flagsn = flags[n];
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
 	float f[19];
-	f[0] = ddf_decode<T>(fi[n]);
+	f[0] = ddf_decode<T>(ldg<NT>(fi+n));
 	#pragma unroll
 	for(int i=1; i<19; i+=2) {
-		f[i  ] = ddf_decode<T>(fi[(size_t)slotA<PARITY>(i)*p.Np+n]);
-		f[i+1] = ddf_decode<T>(fi[(size_t)slotB<PARITY>(i)*p.Np+j[i]]);
+		f[i  ] = ddf_decode<T>(ldg<NT>(fi+(size_t)slotA<PARITY>(i)*p.Np+n));
+		f[i+1] = ddf_decode<T>(ldg<NT>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i]));
 	}
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
@@ -111,34 +117,34 @@ template<typename T, int PARITY, int MODE=0> __global__ __launch_bounds__(256) v
 			u[2ull*p.Np+n] = uzn;
 		}
 	}
-	fi[n] = ddf_encode<T>(f[0]);
+	stg<NT>(fi+n, ddf_encode<T>(f[0]));
 	#pragma unroll
 	for(int i=1; i<19; i+=2) {
-		fi[(size_t)slotB<PARITY>(i)*p.Np+j[i]] = ddf_encode<T>(f[i]);
-		fi[(size_t)slotA<PARITY>(i)*p.Np+n] = ddf_encode<T>(f[i+1]);
+		stg<NT>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i], ddf_encode<T>(f[i]));
+		stg<NT>(fi+(size_t)slotA<PARITY>(i)*p.Np+n, ddf_encode<T>(f[i+1]));
 	}
 }
 
 // ---------------------------------------------------------------- vector kernel: V cells per lane
-template<typename T, int V> struct VecT;
-template<> struct VecT<float, 4> { typedef float4 type; };
-template<> struct VecT<uint16_t, 4> { typedef ushort4 type; };
-template<> struct VecT<float, 2> { typedef float2 type; };
-template<> struct VecT<uint16_t, 2> { typedef ushort2 type; };
-
 template<typename T, int V> struct Pack { T v[V]; };
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template<int BYTES> struct RawT;
+template<> struct RawT<4> { typedef uint32_t type; };
+template<> struct RawT<8> { typedef u32x2 type; };
+template<> struct RawT<16> { typedef u32x4 type; };
+// one aligned V*sizeof(T)-byte access per lane (4, 8 or 16 bytes), non-temporal
 template<typename T, int V> __device__ __forceinline__ Pack<T, V> vload(const T* ptr) {
-	typedef typename VecT<T, V>::type VT;
-	const VT t = *reinterpret_cast<const VT*>(ptr);
-	Pack<T, V> r;
-	if constexpr(V==4) { r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; } else { r.v[0] = t.x; r.v[1] = t.y; }
-	return r;
+	typedef typename RawT<V*sizeof(T)>::type R;
+	union { R r; Pack<T, V> p; } c;
+	c.r = __builtin_nontemporal_load(reinterpret_cast<const R*>(ptr));
+	return c.p;
 }
-template<typename T, int V> __device__ __forceinline__ void vstore(T* ptr, const Pack<T, V>& r) {
-	typedef typename VecT<T, V>::type VT;
-	VT t;
-	if constexpr(V==4) { t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3]; } else { t.x = r.v[0]; t.y = r.v[1]; }
-	*reinterpret_cast<VT*>(ptr) = t;
+template<typename T, int V> __device__ __forceinline__ void vstore(T* ptr, const Pack<T, V>& v) {
+	typedef typename RawT<V*sizeof(T)>::type R;
+	union { R r; Pack<T, V> p; } c;
+	c.p = v;
+	__builtin_nontemporal_store(c.r, reinterpret_cast<R*>(ptr));
 }
 template<typename T> __device__ __forceinline__ T lane_down(const T v) { // value held by lane+1
 	return (T)__shfl_down((int)v, 1, 64);
@@ -192,7 +198,8 @@ template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k
 	uint8_t fl[V];
 	if(active) {
 		if constexpr(V==4) { const uchar4 t = *reinterpret_cast<const uchar4*>(flags+n0); fl[0] = t.x; fl[1] = t.y; fl[2] = t.z; fl[3] = t.w; }
-		else { const uchar2 t = *reinterpret_cast<const uchar2*>(flags+n0); fl[0] = t.x; fl[1] = t.y; }
+		else if constexpr(V==2) { const uchar2 t = *reinterpret_cast<const uchar2*>(flags+n0); fl[0] = t.x; fl[1] = t.y; }
+		else fl[0] = flags[n0];
 	} else {
 		#pragma unroll
 		for(int c=0; c<V; c++) fl[c] = TYPE_S;
@@ -219,13 +226,13 @@ template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k
 		if(active) t = vload<T, V>(S+X);
 		else { for(int c=0; c<V; c++) t.v[c] = (T)0; }
 		T e = lane_down<T>(t.v[0]);
-		if(active && !nb_next && X+V<p.Px) e = S[X+V];
+		if(active && !nb_next && X+V<p.Px) e = ldg<true>(S+X+V);
 		T in[V];
 		#pragma unroll
 		for(int c=0; c<V-1; c++) in[c] = t.v[c+1];
 		in[V-1] = e;
 		if(is_wrap) {
-			const T wv = S[0];
+			const T wv = ldg<true>(S);
 			#pragma unroll
 			for(int c=0; c<V; c++) if((uint32_t)c==cw) in[c] = wv;
 		}
@@ -280,7 +287,7 @@ template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k
 			vstore<T, V>(S+X, t);
 		} else {
 			#pragma unroll
-			for(int c=0; c<V; c++) if(proc[c]) S[X+c] = ddf_encode<T>(f[q][c]);
+			for(int c=0; c<V; c++) if(proc[c]) stg<true>(S+X+c, ddf_encode<T>(f[q][c]));
 		}
 	};
 	auto store_shifted = [&](const int q, const int plane, const uint32_t row) {
@@ -300,16 +307,16 @@ template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k
 			} else {
 				// S[X] is owned by cell X-1, which another wave / an edge lane / nobody in this launch handles
 				#pragma unroll
-				for(int c=1; c<V; c++) S[X+c] = o[c-1];
+				for(int c=1; c<V; c++) stg<true>(S+X+c, o[c-1]);
 			}
-			if(!next_full && X+V<p.Nx) S[X+V] = o[V-1]; // the element the next vector will not write for us
+			if(!next_full && X+V<p.Nx) stg<true>(S+X+V, o[V-1]); // the element the next vector will not write for us
 			if(is_wrap) {
 				#pragma unroll
-				for(int c=0; c<V; c++) if((uint32_t)c==cw) S[0] = o[c];
+				for(int c=0; c<V; c++) if((uint32_t)c==cw) stg<true>(S, o[c]);
 			}
 		} else {
 			#pragma unroll
-			for(int c=0; c<V; c++) if(proc[c]) S[X+c+1u==p.Nx ? 0u : X+c+1u] = o[c];
+			for(int c=0; c<V; c++) if(proc[c]) stg<true>(S+(X+c+1u==p.Nx ? 0u : X+c+1u), o[c]);
 		}
 	};
 	store_straight(0, 0, r00);
@@ -446,38 +453,45 @@ static int copy_pitched(void* dst, const void* src, const size_t elem, const luw
 	return LUW_OK;
 }
 
-template<typename T> static void launch_typed(luw_solver* s, const Box& b, const int write_fields, const bool vec) {
+template<typename T, int V> static void launch_vec(luw_solver* s, const Box& b, const int write_fields) {
 	T* fi = (T*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
-	if(vec) {
-		constexpr int V = 4;
-		const uint32_t nvec = (b.x1-1u)/V-b.x0/V+1u;          // vectors overlapping [x0,x1)
-		uint32_t vx = 1u; while(vx<nvec&&vx<256u) vx <<= 1;   // power of two
-		const uint32_t ry = 256u/vx;
-		const uint32_t nchunk = (nvec+vx-1u)/vx;
-		const uint32_t rows = (b.y1-b.y0)*(b.z1-b.z0);
-		const dim3 grid(((rows+ry-1u)/ry)*nchunk), block(vx, ry);
-		if(odd) hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
-		else hipLaunchKernelGGL((k_stream_collide_v<T, V, 0>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
-	} else {
-		const uint32_t nx = b.x1-b.x0;
-		const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
-		const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-		const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : 0;
-		#define LUW_LAUNCH_S(PAR, MODE) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
-		if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0); else LUW_LAUNCH_S(0, 0); }
-		else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1); else LUW_LAUNCH_S(0, 1); }
-		else { if(odd) LUW_LAUNCH_S(1, 2); else LUW_LAUNCH_S(0, 2); }
-		#undef LUW_LAUNCH_S
-	}
+	const uint32_t nvec = (b.x1-1u)/V-b.x0/V+1u;          // vectors overlapping [x0,x1)
+	uint32_t vx = 1u; while(vx<nvec&&vx<256u) vx <<= 1;   // power of two
+	const uint32_t ry = 256u/vx;
+	const uint32_t nchunk = (nvec+vx-1u)/vx;
+	const uint32_t rows = (b.y1-b.y0)*(b.z1-b.z0);
+	const dim3 grid(((rows+ry-1u)/ry)*nchunk), block(vx, ry);
+	if(odd) hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+	else hipLaunchKernelGGL((k_stream_collide_v<T, V, 0>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+}
+template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields) {
+	T* fi = (T*)s->d_fi;
+	const bool odd = (s->t&1ull)!=0ull;
+	const uint32_t nx = b.x1-b.x0;
+	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
+	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : 0;
+	#define LUW_LAUNCH_S(PAR, MODE, NT) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
+	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, true); else LUW_LAUNCH_S(0, 0, true); }
+	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, true); else LUW_LAUNCH_S(0, 1, true); }
+	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, true); else LUW_LAUNCH_S(0, 2, true); }
+	else { if(odd) LUW_LAUNCH_S(1, 0, false); else LUW_LAUNCH_S(0, 0, false); }
+	#undef LUW_LAUNCH_S
 }
 
+// Kernel choice.  LUW_KERNEL_AUTO: FP32 DDFs -> scalar kernel (one dword per lane and plane); FP16C DDFs -> 2 cells per
+// lane (again one dword per lane and plane).  Both measured fastest on MI355X, see profiles/ and DESIGN.md.
 static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields) {
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
-	const bool vec = s->kernel==LUW_KERNEL_VEC4; // LUW_KERNEL_AUTO: the scalar kernel is the faster one on MI355X today (profiles/)
-	if(s->ddf_bytes==2u) launch_typed<uint16_t>(s, b, write_fields, vec); else launch_typed<float>(s, b, write_fields, vec);
+	const bool fp16 = s->ddf_bytes==2u;
+	uint32_t k = s->kernel;
+	if(k==LUW_KERNEL_AUTO) k = fp16 ? LUW_KERNEL_VEC2 : LUW_KERNEL_SCALAR;
+	if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
+	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
+	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }

@@ -19,7 +19,7 @@ def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0)
               use_F=False, every_step=False, subgrid=True):
     from latticeurbanwind_amd import capi
     flags, u, rho = state
-    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4}[kernel],
+    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED}[kernel],
                 force_field=use_F, update_fields_every_step=every_step, subgrid=subgrid,
                 buffer_nudging=nudging, top_sponge=sponge)
     o = oracle.OracleLBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, use_F=use_F, subgrid=subgrid)
@@ -62,7 +62,7 @@ def check(g, o, what):
 SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4)]
 
 
-@pytest.mark.parametrize("kernel", ["s", "v"])
+@pytest.mark.parametrize("kernel", ["s", "v", "v2", "sc"])
 @pytest.mark.parametrize("fp16c", [False, True])
 @pytest.mark.parametrize("size", SIZES)
 def test_stream_collide_matches_oracle(luw, kernel, fp16c, size):
@@ -86,7 +86,7 @@ def test_periodic_box_without_boundaries(luw, kernel):
     check(g, o, "periodic")
 
 
-@pytest.mark.parametrize("kernel", ["s", "v"])
+@pytest.mark.parametrize("kernel", ["s", "v", "v2"])
 @pytest.mark.parametrize("fp16c", [False, True])
 def test_all_force_terms(luw, kernel, fp16c):
     # volume force + Coriolis + per-cell force field + buffer nudging (west/south/north/top, east = downstream) + top sponge
@@ -120,7 +120,7 @@ def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
     N = 256
     st = synthetic_state(N, N, N, seed=9, shell="luw")
     res = []
-    for k in (capi.KERNEL_SCALAR, capi.KERNEL_VEC4):
+    for k in (capi.KERNEL_SCALAR, capi.KERNEL_VEC4, capi.KERNEL_VEC2):
         g = luw.LBM(N, N, N, 1e-5, kernel=k)
         g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
         g.run(10)
@@ -128,6 +128,7 @@ def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
         res.append((g.u.data.copy(), g.rho.data.copy()))
         g.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
     fluid = (st[0] & TYPE_S) == 0
     m0 = st[2][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum()
     assert np.isfinite(res[0][0]).all() and abs(res[0][1][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum() / m0 - 1) < 1e-3

@@ -1,0 +1,131 @@
+// membench.hip -- HBM microbenchmarks that bound what the collide-stream access pattern can reach on MI355X.
+// Not part of the product; run through gpurun:  hipcc --offload-arch=gfx950 -O3 -o membench tools/membench.hip && ./membench
+// Every test moves the bytes of one D3Q19 step on N = 512^3 cells (19 x 4 B read + 19 x 4 B written per cell) and
+// reports GB/s = 152 B x N / time.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if(e!=hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while(0)
+
+// S planes, W floats per lane (1,2,4); LAYOUT 0: plane-major out[s*P + n]; LAYOUT 1: row-interleaved out[(row*S + s)*NX + x]
+template<int S, int W, int LAYOUT, bool INPLACE> __global__ __launch_bounds__(256) void k_update(const float* __restrict__ in, float* __restrict__ out, const size_t P, const unsigned NX) {
+	const size_t e = ((size_t)blockIdx.x*blockDim.x+threadIdx.x)*W; // element index within a plane
+	if(e>=P) return;
+	float v[S][W];
+	#pragma unroll
+	for(int s=0; s<S; s++) {
+		size_t idx;
+		if(LAYOUT==0) idx = (size_t)s*P+e; else { const size_t row = e/NX, x = e%NX; idx = (row*S+s)*NX+x; }
+		if constexpr(W==4) { const float4 t = *reinterpret_cast<const float4*>(in+idx); v[s][0]=t.x; v[s][1]=t.y; v[s][2]=t.z; v[s][3]=t.w; }
+		else if constexpr(W==2) { const float2 t = *reinterpret_cast<const float2*>(in+idx); v[s][0]=t.x; v[s][1]=t.y; }
+		else v[s][0] = in[idx];
+	}
+	float* o = INPLACE ? const_cast<float*>(in) : out;
+	#pragma unroll
+	for(int s=0; s<S; s++) {
+		size_t idx;
+		if(LAYOUT==0) idx = (size_t)s*P+e; else { const size_t row = e/NX, x = e%NX; idx = (row*S+s)*NX+x; }
+		if constexpr(W==4) { *reinterpret_cast<float4*>(o+idx) = make_float4(v[s][0]+1.0f, v[s][1]+1.0f, v[s][2]+1.0f, v[s][3]+1.0f); }
+		else if constexpr(W==2) { *reinterpret_cast<float2*>(o+idx) = make_float2(v[s][0]+1.0f, v[s][1]+1.0f); }
+		else o[idx] = v[s][0]+1.0f;
+	}
+}
+// 19-plane in-place dword/float4 update with (a) occupancy limited through a dynamic LDS request and (b) optional
+// non-temporal loads / stores
+template<int S, int W, bool NT> __global__ __launch_bounds__(256) void k_update_occ(float* __restrict__ io, const size_t P) {
+	extern __shared__ float lds[];
+	const size_t e = ((size_t)blockIdx.x*blockDim.x+threadIdx.x)*W;
+	if(e>=P) return;
+	float v[S][W];
+	#pragma unroll
+	for(int s=0; s<S; s++) {
+		const float* p = io+(size_t)s*P+e;
+		#pragma unroll
+		for(int c=0; c<W; c++) v[s][c] = NT ? __builtin_nontemporal_load(p+c) : p[c];
+	}
+	if(v[0][0]==-123.0f) lds[threadIdx.x] = v[0][0];
+	#pragma unroll
+	for(int s=0; s<S; s++) {
+		float* p = io+(size_t)s*P+e;
+		#pragma unroll
+		for(int c=0; c<W; c++) { if(NT) __builtin_nontemporal_store(v[s][c]+1.0f, p+c); else p[c] = v[s][c]+1.0f; }
+	}
+}
+// read-only / write-only of S planes (dword)
+template<int S, int W> __global__ __launch_bounds__(256) void k_read(const float* __restrict__ in, float* __restrict__ sink, const size_t P) {
+	const size_t e = ((size_t)blockIdx.x*blockDim.x+threadIdx.x)*W;
+	if(e>=P) return;
+	float acc = 0.0f;
+	#pragma unroll
+	for(int s=0; s<S; s++) {
+		if constexpr(W==4) { const float4 t = *reinterpret_cast<const float4*>(in+(size_t)s*P+e); acc += t.x+t.y+t.z+t.w; }
+		else acc += in[(size_t)s*P+e];
+	}
+	if(acc==123.456f) sink[0] = acc;
+}
+template<int S, int W> __global__ __launch_bounds__(256) void k_write(float* __restrict__ out, const size_t P) {
+	const size_t e = ((size_t)blockIdx.x*blockDim.x+threadIdx.x)*W;
+	if(e>=P) return;
+	#pragma unroll
+	for(int s=0; s<S; s++) {
+		if constexpr(W==4) *reinterpret_cast<float4*>(out+(size_t)s*P+e) = make_float4(1.0f, 2.0f, 3.0f, (float)s);
+		else out[(size_t)s*P+e] = (float)s;
+	}
+}
+
+template<typename F> static double time_ms(F launch, int reps=20) {
+	hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+	for(int i=0; i<3; i++) launch();
+	CHECK(hipDeviceSynchronize());
+	CHECK(hipEventRecord(a));
+	for(int i=0; i<reps; i++) launch();
+	CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+	float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+	return ms/reps;
+}
+
+int main() {
+	const size_t N = 512ull*512ull*512ull; const unsigned NX = 512;
+	float *A, *B; CHECK(hipMalloc(&A, 19*N*4)); CHECK(hipMalloc(&B, 19*N*4));
+	CHECK(hipMemset(A, 0, 19*N*4)); CHECK(hipMemset(B, 0, 19*N*4));
+	const double bytes = 152.0*N;
+	auto rep = [&](const char* name, double ms, double b) { printf("%-58s %8.3f ms  %8.1f GB/s\n", name, ms, b/ms/1e6); fflush(stdout); };
+	#define RUN(name, S, W, L, IP, total) { const size_t P = (total)/(S); rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update<S, W, L, IP>), dim3((unsigned)((P/W+255)/256)), dim3(256), 0, 0, A, B, P, NX); }), bytes); }
+	RUN("copy A->B  1 plane-pair  float4", 1, 4, 0, false, 19*N)
+	RUN("copy A->B  1 plane-pair  dword", 1, 1, 0, false, 19*N)
+	RUN("in-place   1 plane       float4", 1, 4, 0, true, 19*N)
+	RUN("in-place   1 plane       dword", 1, 1, 0, true, 19*N)
+	RUN("copy A->B  19 planes     float4", 19, 4, 0, false, 19*N)
+	RUN("copy A->B  19 planes     dword", 19, 1, 0, false, 19*N)
+	RUN("in-place   19 planes     float4", 19, 4, 0, true, 19*N)
+	RUN("in-place   19 planes     float2", 19, 2, 0, true, 19*N)
+	RUN("in-place   19 planes     dword", 19, 1, 0, true, 19*N)
+	RUN("in-place   19 row-interleaved planes float4", 19, 4, 1, true, 19*N)
+	RUN("in-place   19 row-interleaved planes dword", 19, 1, 1, true, 19*N)
+	RUN("in-place   4 planes      dword", 4, 1, 0, true, 19*N)
+	RUN("in-place   8 planes      dword", 8, 1, 0, true, 19*N)
+	for(int blocks_per_cu : {8, 4, 3, 2, 1}) {
+		const size_t lds_bytes = blocks_per_cu>=8 ? 0 : (size_t)(160*1024/blocks_per_cu-2048);
+		char name[128];
+		const size_t P = N;
+		CHECK(hipFuncSetAttribute((const void*)k_update_occ<19, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		CHECK(hipFuncSetAttribute((const void*)k_update_occ<19, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		CHECK(hipFuncSetAttribute((const void*)k_update_occ<19, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		CHECK(hipFuncSetAttribute((const void*)k_update_occ<19, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		snprintf(name, sizeof(name), "in-place 19 planes dword   %d blocks/CU", blocks_per_cu);
+		rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_occ<19, 1, false>), dim3((unsigned)((P+255)/256)), dim3(256), lds_bytes, 0, A, P); }), bytes);
+		snprintf(name, sizeof(name), "in-place 19 planes dword   %d blocks/CU nontemporal", blocks_per_cu);
+		rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_occ<19, 1, true>), dim3((unsigned)((P+255)/256)), dim3(256), lds_bytes, 0, A, P); }), bytes);
+		snprintf(name, sizeof(name), "in-place 19 planes float4  %d blocks/CU", blocks_per_cu);
+		rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_occ<19, 4, false>), dim3((unsigned)((P/4+255)/256)), dim3(256), lds_bytes, 0, A, P); }), bytes);
+		snprintf(name, sizeof(name), "in-place 19 planes float4  %d blocks/CU nontemporal", blocks_per_cu);
+		rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_occ<19, 4, true>), dim3((unsigned)((P/4+255)/256)), dim3(256), lds_bytes, 0, A, P); }), bytes);
+	}
+	{ const size_t P = N; rep("read only  19 planes dword", time_ms([&]{ hipLaunchKernelGGL((k_read<19, 1>), dim3((unsigned)((P+255)/256)), dim3(256), 0, 0, A, B, P); }), 76.0*N); }
+	{ const size_t P = N; rep("read only  19 planes float4", time_ms([&]{ hipLaunchKernelGGL((k_read<19, 4>), dim3((unsigned)((P/4+255)/256)), dim3(256), 0, 0, A, B, P); }), 76.0*N); }
+	{ const size_t P = N; rep("write only 19 planes dword", time_ms([&]{ hipLaunchKernelGGL((k_write<19, 1>), dim3((unsigned)((P+255)/256)), dim3(256), 0, 0, B, P); }), 76.0*N); }
+	{ const size_t P = N; rep("write only 19 planes float4", time_ms([&]{ hipLaunchKernelGGL((k_write<19, 4>), dim3((unsigned)((P/4+255)/256)), dim3(256), 0, 0, B, P); }), 76.0*N); }
+	return 0;
+}
