@@ -83,13 +83,17 @@ template<typename T> __global__ __launch_bounds__(256) void k_initialize(const K
 // DDF accesses are streaming: every slot is read once and written once per step, so all DDF loads / stores carry
 // the non-temporal hint (global_load/store ... nt).  Measured on MI355X (tools/membench.hip, profiles/): the
 // 19-plane in-place update moves 5.3 TB/s with the default cache policy and 6.1 TB/s non-temporal.
+template<int I> struct IC { static constexpr int value = I; };
+template<typename Fn> __device__ __forceinline__ void static_for_pairs(Fn&& fn) { // i = 1,3,...,17 as compile-time constants
+	fn(IC<1>{}); fn(IC<3>{}); fn(IC<5>{}); fn(IC<7>{}); fn(IC<9>{}); fn(IC<11>{}); fn(IC<13>{}); fn(IC<15>{}); fn(IC<17>{});
+}
 template<bool NT, typename T> __device__ __forceinline__ T ldg(const T* p) { if constexpr(NT) return __builtin_nontemporal_load(p); else return *p; }
 template<bool NT, typename T> __device__ __forceinline__ void stg(T* p, const T v) { if constexpr(NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
 // ---------------------------------------------------------------- scalar kernel: 1 cell per lane
 // MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
 // measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
-template<typename T, int PARITY, int MODE=0, bool NT=true> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<typename T, int PARITY, int MODE=0, int NT=1> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t x = b.x0+blockIdx.x*blockDim.x+threadIdx.x, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
@@ -101,12 +105,12 @@ template<typename T, int PARITY, int MODE=0, bool NT=true> __global__ __launch_b
 	const uint8_t flagsn = flags[n];
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
 	float f[19];
-	f[0] = ddf_decode<T>(ldg<NT>(fi+n));
-	#pragma unroll
-	for(int i=1; i<19; i+=2) {
-		f[i  ] = ddf_decode<T>(ldg<NT>(fi+(size_t)slotA<PARITY>(i)*p.Np+n));
-		f[i+1] = ddf_decode<T>(ldg<NT>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i]));
-	}
+	f[0] = ddf_decode<T>(ldg<(NT!=0)>(fi+n));
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		f[i  ] = ddf_decode<T>(ldg<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*p.Np+n));
+		{ constexpr bool shifted = i==1||i==7||i==9||i==13||i==15; f[i+1] = ddf_decode<T>(ldg<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i])); }
+	});
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
 		collide_cell(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
@@ -117,12 +121,12 @@ template<typename T, int PARITY, int MODE=0, bool NT=true> __global__ __launch_b
 			u[2ull*p.Np+n] = uzn;
 		}
 	}
-	stg<NT>(fi+n, ddf_encode<T>(f[0]));
-	#pragma unroll
-	for(int i=1; i<19; i+=2) {
-		stg<NT>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i], ddf_encode<T>(f[i]));
-		stg<NT>(fi+(size_t)slotA<PARITY>(i)*p.Np+n, ddf_encode<T>(f[i+1]));
-	}
+	stg<(NT!=0)>(fi+n, ddf_encode<T>(f[0]));
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		{ constexpr bool shifted = i==1||i==7||i==9||i==13||i==15; stg<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i], ddf_encode<T>(f[i])); }
+		stg<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*p.Np+n, ddf_encode<T>(f[i+1]));
+	});
 }
 
 // ---------------------------------------------------------------- vector kernel: V cells per lane
@@ -130,6 +134,7 @@ template<typename T, int V> struct Pack { T v[V]; };
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template<int BYTES> struct RawT;
+template<> struct RawT<2> { typedef uint16_t type; };
 template<> struct RawT<4> { typedef uint32_t type; };
 template<> struct RawT<8> { typedef u32x2 type; };
 template<> struct RawT<16> { typedef u32x4 type; };
@@ -471,12 +476,13 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const uint32_t nx = b.x1-b.x0;
 	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : 0;
+	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALIGNED ? 4 : 0;
 	#define LUW_LAUNCH_S(PAR, MODE, NT) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
-	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, true); else LUW_LAUNCH_S(0, 0, true); }
-	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, true); else LUW_LAUNCH_S(0, 1, true); }
-	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, true); else LUW_LAUNCH_S(0, 2, true); }
-	else { if(odd) LUW_LAUNCH_S(1, 0, false); else LUW_LAUNCH_S(0, 0, false); }
+	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
+	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
+	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
+	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
+	else { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
 	#undef LUW_LAUNCH_S
 }
 
@@ -491,6 +497,7 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	if(k==LUW_KERNEL_AUTO) k = fp16 ? LUW_KERNEL_VEC2 : LUW_KERNEL_SCALAR;
 	if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
+	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
 	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
