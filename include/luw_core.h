@@ -151,6 +151,10 @@ int luw_finish(luw_solver* s);                                            /* LBM
 int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_upload_fi(luw_solver* s, const void* host_src);
 
+/* device self-check: number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C
+ * codec differs from the literal formulas of FX/kernel.cpp:864-875; must be 0 */
+int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches);
+
 /* measurement helper for bench.py: runs `steps` steps like luw_run and returns the mean duration of the
  * stream_collide kernel in milliseconds, taken with HIP events on the launch stream. */
 int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms);

@@ -387,6 +387,17 @@ template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KP
 	}
 }
 
+// ---------------------------------------------------------------- self-check of the fast FP16C codec
+// counts inputs for which the fast codec differs from the literal restatement of FX/kernel.cpp:864-875:
+// all 2^16 codes (decode, compared as bit patterns) and all 2^32 float bit patterns (encode)
+__global__ __launch_bounds__(256) void k_codec_check(unsigned long long* __restrict__ mismatches) {
+	const uint32_t tid = blockIdx.x*blockDim.x+threadIdx.x, nth = gridDim.x*blockDim.x;
+	unsigned long long bad = 0ull;
+	for(uint32_t c=tid; c<65536u; c+=nth) bad += __float_as_uint(half_to_float_custom(c))!=__float_as_uint(half_to_float_custom_ref(c));
+	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) { const float x = __uint_as_float((uint32_t)v); bad += float_to_half_custom(x)!=float_to_half_custom_ref(x); }
+	if(bad) atomicAdd(mismatches, bad);
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -700,6 +711,21 @@ int luw_upload_fi(luw_solver* s, const void* host_src) {
 	if(int e = set_device(s)) return e;
 	if(int e = copy_pitched(s->d_fi, host_src, s->ddf_bytes, s, 19u, true, s->stream)) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+
+int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches) {
+	if(!mismatches) return fail(LUW_ERR_INVALID, "luw_selfcheck_fp16c_codec: null argument");
+	HIP_TRY(hipSetDevice(device));
+	unsigned long long* d = nullptr;
+	HIP_TRY(hipMalloc((void**)&d, 8));
+	HIP_TRY(hipMemset(d, 0, 8));
+	hipLaunchKernelGGL(k_codec_check, dim3(4096), dim3(256), 0, 0, d);
+	HIP_TRY(hipGetLastError());
+	unsigned long long h = 0ull;
+	HIP_TRY(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+	(void)hipFree(d);
+	*mismatches = h;
 	return LUW_OK;
 }
 

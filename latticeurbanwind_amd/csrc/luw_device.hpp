@@ -47,17 +47,42 @@ struct KParams {
 };
 
 // ---------------------------------------------------------------- FP16C codec, FX/kernel.cpp:864-875
-__device__ __forceinline__ float half_to_float_custom(const uint32_t x) {
+// Bit-identical to the reference's branch-free formulas for every input (checked exhaustively on the GPU by
+// tests/test_gpu_parity.py::test_fp16c_codec_exhaustive: all 2^16 codes, all 2^32 floats), but the common case --
+// normalised numbers -- takes a 4-instruction path and the rare denormal path sits behind a branch.
+__device__ __forceinline__ float half_to_float_custom_ref(const uint32_t x) { // literal restatement, FX/kernel.cpp:864-869
 	const uint32_t e = (x&0x7800u)>>11;
 	const uint32_t m = (x&0x07FFu)<<12;
 	const uint32_t v = __float_as_uint((float)m)>>23;
 	return __uint_as_float((x&0x8000u)<<16 | (uint32_t)(e!=0u)*((e+112u)<<23|m) | (uint32_t)((e==0u)&(m!=0u))*((v-37u)<<23|((m<<((150u-v)&31u))&0x007FF000u)));
 }
-__device__ __forceinline__ uint32_t float_to_half_custom(const float x) {
+__device__ __forceinline__ uint32_t float_to_half_custom_ref(const float x) { // literal restatement, FX/kernel.cpp:870-875
 	const uint32_t b = __float_as_uint(x)+0x00000800u;
 	const uint32_t e = (b&0x7F800000u)>>23;
 	const uint32_t m = b&0x007FFFFFu;
 	return (b&0x80000000u)>>16 | (uint32_t)(e>112u)*((((e-112u)<<11)&0x7800u)|m>>12) | (uint32_t)((e<113u)&(e>100u))*((((0x007FF800u+m)>>((124u-e)&31u))+1u)>>1);
+}
+__device__ __forceinline__ float half_to_float_custom(const uint32_t x) {
+	const uint32_t sign = (x&0x8000u)<<16;
+	uint32_t r = (x&0x7FFFu)<<12;                 // exponent at bits 23..26, mantissa at bits 12..22
+	if(r>=0x00800000u) r += 112u<<23;             // e != 0: rebias 15 -> 127
+	else if(r!=0u) {                              // e == 0, m != 0: denormal (rare)
+		const uint32_t v = __float_as_uint((float)r)>>23;
+		r = (v-37u)<<23|((r<<((150u-v)&31u))&0x007FF000u);
+	}
+	return __uint_as_float(sign|r);
+}
+__device__ __forceinline__ uint32_t float_to_half_custom(const float x) {
+	const uint32_t b = __float_as_uint(x)+0x00000800u;
+	const uint32_t sign = (b&0x80000000u)>>16;
+	const uint32_t a = b&0x7FFFFFFFu;
+	uint32_t r = 0u;
+	if(a>=(113u<<23)) r = ((a>>12)-(112u<<11))&0x7FFFu;                // e > 112: normalised
+	else if(a>=(101u<<23)) {                                             // 100 < e < 113: denormal (rare)
+		const uint32_t e = a>>23, m = a&0x007FFFFFu;
+		r = (((0x007FF800u+m)>>(124u-e))+1u)>>1;
+	}
+	return sign|r;
 }
 template<typename T> __device__ __forceinline__ float ddf_decode(const T v);
 template<> __device__ __forceinline__ float ddf_decode<float>(const float v) { return v; }
@@ -210,12 +235,22 @@ __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n,
 	float fxn, fyn, fzn;
 	assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
 	float Fin[19];
-	{
+	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
+	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
+	// (fma(w, feq, +-0) == w*feq) as long as rho != 0.
+	const bool forced = fxn!=0.0f||fyn!=0.0f||fzn!=0.0f;
+	if(forced) {
 		const float rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
 		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
 		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
 		calculate_forcing_terms(uxn, uyn, uzn, fxn, fyn, fzn, Fin);
+	} else {
+		uxn = clampf(uxn, -DEF_C, DEF_C);
+		uyn = clampf(uyn, -DEF_C, DEF_C);
+		uzn = clampf(uzn, -DEF_C, DEF_C);
+		#pragma unroll
+		for(int i=0; i<19; i++) Fin[i] = 0.0f;
 	}
 	float feq[19];
 	calculate_f_eq(rhon, uxn, uyn, uzn, feq);

@@ -59,6 +59,15 @@ def check(g, o, what):
     assert np.array_equal(g.u.data, o.u), what + ": u differs"
 
 
+def test_fp16c_codec_exhaustive(luw):
+    # the kernels' fast FP16C codec vs the literal FX/kernel.cpp:864-875 formulas: all 2^16 codes, all 2^32 floats
+    import ctypes as C
+    from latticeurbanwind_amd import capi
+    n = C.c_uint64(123)
+    capi.check(capi.load().luw_selfcheck_fp16c_codec(0, C.byref(n)))
+    assert n.value == 0
+
+
 SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4)]
 
 
