@@ -63,11 +63,11 @@ extern "C" {
 
 /* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
 #define LUW_KERNEL_AUTO 0
-#define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, dword accesses */
+#define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
 #define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */
 #define LUW_KERNEL_SCALAR_CACHED 4      /* scalar kernel with the default cache policy instead of non-temporal DDF accesses (A/B) */
-#define LUW_KERNEL_SCALAR_NT_ALIGNED 5  /* scalar kernel, non-temporal on the 14 aligned planes, default policy on the 5 x+1 planes (A/B) */
+#define LUW_KERNEL_SCALAR_NT_ALL 5      /* scalar kernel with non-temporal accesses on all 19 planes (A/B; the product uses nt on the 14 aligned planes) */
 #define LUW_KERNEL_VEC1 6               /* 1 cell / lane with aligned accesses + wave64 lane shifts for the x+1 populations (A/B) */
 #define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
 #define LUW_KERNEL_EXP_NOSHIFT 101      /* measurement only: scalar kernel with the x+1 neighbours replaced by x (no physics) */

@@ -91,25 +91,58 @@ template<bool NT, typename T> __device__ __forceinline__ T ldg(const T* p) { if 
 template<bool NT, typename T> __device__ __forceinline__ void stg(T* p, const T v) { if constexpr(NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
 // ---------------------------------------------------------------- scalar kernel: 1 cell per lane
+// Addressing: every DDF access is (uniform plane base in SGPRs) + (32-bit byte offset in one VGPR), the
+// global_load/store "saddr" form; the 10 byte offsets (own cell + 9 neighbours) stay live from the loads to the
+// stores instead of 38 64-bit addresses.  Byte offsets fit 32 bits because Np*sizeof(T) <= 2^32 (checked on the host).
+template<bool NT, typename T> __device__ __forceinline__ T ldo(const T* plane, const uint32_t byte_off) {
+	return ldg<NT>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(plane)+byte_off));
+}
+template<bool NT, typename T> __device__ __forceinline__ void sto(T* plane, const uint32_t byte_off, const T v) {
+	stg<NT>(reinterpret_cast<T*>(reinterpret_cast<char*>(plane)+byte_off), v);
+}
+// byte offset of the +c_i neighbour for odd i (periodic wrap, FX/kernel.cpp:920-958)
+struct NbrOff { uint32_t n, j1, j3, j5, j7, j9, j11, j13, j15, j17; };
+template<typename T> __device__ __forceinline__ NbrOff neighbor_offsets(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
+	const uint32_t xp = x+1u==p.Nx ? 0u : x+1u;
+	const uint32_t y0 = y*p.Px, yp = (y+1u==p.Ny ? 0u : y+1u)*p.Px, ym = (y==0u ? p.Ny-1u : y-1u)*p.Px;
+	const uint32_t A = p.Px*p.Ny;
+	const uint32_t z0 = z*A, zp = (z+1u==p.Nz ? 0u : z+1u)*A, zm = (z==0u ? p.Nz-1u : z-1u)*A;
+	constexpr uint32_t B = (uint32_t)sizeof(T);
+	NbrOff o;
+	o.n = (x+y0+z0)*B;
+	o.j1 = (xp+y0+z0)*B; o.j3 = (x+yp+z0)*B; o.j5 = (x+y0+zp)*B;
+	o.j7 = (xp+yp+z0)*B; o.j9 = (xp+y0+zp)*B; o.j11 = (x+yp+zp)*B;
+	o.j13 = (xp+ym+z0)*B; o.j15 = (xp+y0+zm)*B; o.j17 = (x+yp+zm)*B;
+	return o;
+}
+template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
+	if constexpr(I==1) return o.j1; else if constexpr(I==3) return o.j3; else if constexpr(I==5) return o.j5;
+	else if constexpr(I==7) return o.j7; else if constexpr(I==9) return o.j9; else if constexpr(I==11) return o.j11;
+	else if constexpr(I==13) return o.j13; else if constexpr(I==15) return o.j15; else return o.j17;
+}
+
 // MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
 // measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
-template<typename T, int PARITY, int MODE=0, int NT=1> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// NT: 0 default cache policy, 1 non-temporal everywhere, 2 non-temporal on the 14 aligned planes and default policy on
+// the five x+1 planes, whose wave-edge lines are shared between neighbouring waves (product setting, measured best).
+template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t x = b.x0+blockIdx.x*blockDim.x+threadIdx.x, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	if(cell_is_halo(p, x, y, z)) return;
-	uint32_t j[19];
-	neighbors(p, x, y, z, j);
-	if constexpr(MODE==2) { j[1] = j[0]; j[7] = j[3]; j[9] = j[5]; j[13] = j[4]; j[15] = j[6]; }
-	const uint32_t n = j[0];
+	NbrOff o = neighbor_offsets<T>(p, x, y, z);
+	if constexpr(MODE==2) { o.j1 = o.n; o.j7 = o.j3; o.j9 = o.j5; o.j13 = (x+(y==0u ? p.Ny-1u : y-1u)*p.Px+z*p.Px*p.Ny)*(uint32_t)sizeof(T); o.j15 = (x+y*p.Px+(z==0u ? p.Nz-1u : z-1u)*p.Px*p.Ny)*(uint32_t)sizeof(T); }
+	const uint32_t n = o.n/(uint32_t)sizeof(T);
 	const uint8_t flagsn = flags[n];
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
+	const size_t Np = p.Np;
 	float f[19];
-	f[0] = ddf_decode<T>(ldg<(NT!=0)>(fi+n));
+	f[0] = ddf_decode<T>(ldo<(NT!=0)>(fi, o.n));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
-		f[i  ] = ddf_decode<T>(ldg<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*p.Np+n));
-		{ constexpr bool shifted = i==1||i==7||i==9||i==13||i==15; f[i+1] = ddf_decode<T>(ldg<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i])); }
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n));
+		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o)));
 	});
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
@@ -117,15 +150,16 @@ template<typename T, int PARITY, int MODE=0, int NT=1> __global__ __launch_bound
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
 			u[n] = uxn;
-			u[(size_t)p.Np+n] = uyn;
-			u[2ull*p.Np+n] = uzn;
+			u[Np+n] = uyn;
+			u[2ull*Np+n] = uzn;
 		}
 	}
-	stg<(NT!=0)>(fi+n, ddf_encode<T>(f[0]));
+	sto<(NT!=0)>(fi, o.n, ddf_encode<T>(f[0]));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
-		{ constexpr bool shifted = i==1||i==7||i==9||i==13||i==15; stg<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*p.Np+j[i], ddf_encode<T>(f[i])); }
-		stg<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*p.Np+n, ddf_encode<T>(f[i+1]));
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), ddf_encode<T>(f[i]));
+		sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n, ddf_encode<T>(f[i+1]));
 	});
 }
 
@@ -487,13 +521,13 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const uint32_t nx = b.x1-b.x0;
 	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALIGNED ? 4 : 0;
+	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : 0;
 	#define LUW_LAUNCH_S(PAR, MODE, NT) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
-	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
+	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
 	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
 	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
 	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
-	else { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
+	else { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
 	#undef LUW_LAUNCH_S
 }
 
@@ -549,7 +583,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
 	const uint32_t Px = (cfg->Nx+3u)&~3u;
 	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz;
-	if(Np>=(1ull<<32)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^32 cells per domain are not supported");
+	if(Np>(1ull<<30)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^30 (padded) cells per domain are not supported (32-bit byte offsets)");
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
 	if(cfg->device<0||cfg->device>=ndev) return fail(LUW_ERR_INVALID, "luw_create: no such HIP device"); // FX/lbm.cpp:961-979

@@ -47,9 +47,9 @@ struct KParams {
 };
 
 // ---------------------------------------------------------------- FP16C codec, FX/kernel.cpp:864-875
-// Bit-identical to the reference's branch-free formulas for every input (checked exhaustively on the GPU by
-// tests/test_gpu_parity.py::test_fp16c_codec_exhaustive: all 2^16 codes, all 2^32 floats), but the common case --
-// normalised numbers -- takes a 4-instruction path and the rare denormal path sits behind a branch.
+// The kernels' codec is bit-identical to the reference's formulas for every input: checked exhaustively on the GPU
+// (tests/test_gpu_parity.py::test_fp16c_codec_exhaustive: all 2^16 codes, all 2^32 floats) against the literal
+// restatements *_ref below.
 __device__ __forceinline__ float half_to_float_custom_ref(const uint32_t x) { // literal restatement, FX/kernel.cpp:864-869
 	const uint32_t e = (x&0x7800u)>>11;
 	const uint32_t m = (x&0x07FFu)<<12;
@@ -62,27 +62,25 @@ __device__ __forceinline__ uint32_t float_to_half_custom_ref(const float x) { //
 	const uint32_t m = b&0x007FFFFFu;
 	return (b&0x80000000u)>>16 | (uint32_t)(e>112u)*((((e-112u)<<11)&0x7800u)|m>>12) | (uint32_t)((e<113u)&(e>100u))*((((0x007FF800u+m)>>((124u-e)&31u))+1u)>>1);
 }
+// Decode: the 15 exponent+mantissa bits placed at float bits 12..26 form a tiny float 2^(e-127)(1+m/2048) (or, for
+// e = 0, the float DENORMAL m 2^-137); one exact multiplication by 2^112 turns both into the FP16C value
+// 2^(e-15)(1+m/2048) resp. m 2^-25 -- the same numbers the reference builds with its integer formula
+// (FX/kernel.cpp:864-869).  Needs FP32 denormals enabled (hipcc default).  5 instructions, no branches: DDF values
+// are small deviations from equilibrium, so FP16C denormals (|f| < 6.1e-5) are common and branching on them costs
+// more than it saves (measured).
 __device__ __forceinline__ float half_to_float_custom(const uint32_t x) {
-	const uint32_t sign = (x&0x8000u)<<16;
-	uint32_t r = (x&0x7FFFu)<<12;                 // exponent at bits 23..26, mantissa at bits 12..22
-	if(r>=0x00800000u) r += 112u<<23;             // e != 0: rebias 15 -> 127
-	else if(r!=0u) {                              // e == 0, m != 0: denormal (rare)
-		const uint32_t v = __float_as_uint((float)r)>>23;
-		r = (v-37u)<<23|((r<<((150u-v)&31u))&0x007FF000u);
-	}
-	return __uint_as_float(sign|r);
+	return __uint_as_float(((x<<16)&0x80000000u)|((x<<12)&0x07FFF000u))*0x1p+112f;
 }
+// Encode: the reference's integer formula, branch-free (its carry behaviour in the denormal range is not a plain
+// rounding of x, so it is kept literally; the shift is clamped so that e <= 100 yields 0 through the same expression).
 __device__ __forceinline__ uint32_t float_to_half_custom(const float x) {
 	const uint32_t b = __float_as_uint(x)+0x00000800u;
-	const uint32_t sign = (b&0x80000000u)>>16;
 	const uint32_t a = b&0x7FFFFFFFu;
-	uint32_t r = 0u;
-	if(a>=(113u<<23)) r = ((a>>12)-(112u<<11))&0x7FFFu;                // e > 112: normalised
-	else if(a>=(101u<<23)) {                                             // 100 < e < 113: denormal (rare)
-		const uint32_t e = a>>23, m = a&0x007FFFFFu;
-		r = (((0x007FF800u+m)>>(124u-e))+1u)>>1;
-	}
-	return sign|r;
+	const uint32_t e = a>>23;
+	const uint32_t rn = ((a>>12)-(112u<<11))&0x7FFFu;                                  // e > 112
+	const uint32_t sh = min(124u-e, 31u);                                             // e < 113 (wraps harmlessly above: rd unused)
+	const uint32_t rd = (((0x007FF800u+(a&0x007FFFFFu))>>sh)+1u)>>1;                   // 100 < e < 113, and 0 for e <= 100
+	return ((b>>16)&0x8000u)|(e>112u ? rn : rd);
 }
 template<typename T> __device__ __forceinline__ float ddf_decode(const T v);
 template<> __device__ __forceinline__ float ddf_decode<float>(const float v) { return v; }

@@ -19,7 +19,7 @@ def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0)
               use_F=False, every_step=False, subgrid=True):
     from latticeurbanwind_amd import capi
     flags, u, rho = state
-    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALIGNED, "v1": capi.KERNEL_VEC1}[kernel],
+    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALL, "v1": capi.KERNEL_VEC1}[kernel],
                 force_field=use_F, update_fields_every_step=every_step, subgrid=subgrid,
                 buffer_nudging=nudging, top_sponge=sponge)
     o = oracle.OracleLBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, use_F=use_F, subgrid=subgrid)
