@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU lattice (default 512 512 512)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
-    ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
+    ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
     args = ap.parse_args()
@@ -94,7 +94,7 @@ def main():
     torch.cuda.set_device(local_rank)
     luw.load()
     Nx, Ny, Nz = args.size or (512, 512, 512)
-    kern = {"auto": capi.KERNEL_AUTO, "scalar": capi.KERNEL_SCALAR, "scalar_cached": capi.KERNEL_SCALAR_CACHED, "vec4": capi.KERNEL_VEC4, "vec2": capi.KERNEL_VEC2, "vec1": capi.KERNEL_VEC1, "scalar_nt_all": capi.KERNEL_SCALAR_NT_ALL, "exp_copy": capi.KERNEL_EXP_COPY, "exp_noshift": capi.KERNEL_EXP_NOSHIFT}[args.kernel]
+    kern = {"auto": capi.KERNEL_AUTO, "scalar": capi.KERNEL_SCALAR, "scalar_cached": capi.KERNEL_SCALAR_CACHED, "vec4": capi.KERNEL_VEC4, "vec2": capi.KERNEL_VEC2, "vec1": capi.KERNEL_VEC1, "pair": capi.KERNEL_PAIR, "scalar_nt_all": capi.KERNEL_SCALAR_NT_ALL, "exp_copy": capi.KERNEL_EXP_COPY, "exp_noshift": capi.KERNEL_EXP_NOSHIFT}[args.kernel]
     fp16c = args.dtype == "fp16c"
     nu = 1.48e-7                                     # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
 

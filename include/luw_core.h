@@ -68,6 +68,7 @@ extern "C" {
 #define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */
 #define LUW_KERNEL_SCALAR_CACHED 4      /* scalar kernel with the default cache policy instead of non-temporal DDF accesses (A/B) */
 #define LUW_KERNEL_SCALAR_NT_ALL 5      /* scalar kernel with non-temporal accesses on all 19 planes (A/B; the product uses nt on the 14 aligned planes) */
+#define LUW_KERNEL_PAIR 7               /* FP16C only: 2 cells / lane, direct neighbour addressing, one dword per lane and plane */
 #define LUW_KERNEL_VEC1 6               /* 1 cell / lane with aligned accesses + wave64 lane shifts for the x+1 populations (A/B) */
 #define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
 #define LUW_KERNEL_EXP_NOSHIFT 101      /* measurement only: scalar kernel with the x+1 neighbours replaced by x (no physics) */

@@ -15,7 +15,7 @@ FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F, FIELD_FI = 0, 1, 2, 3, 4
 MASK_RHO, MASK_U, MASK_FLAGS, MASK_F = 1, 2, 4, 8
 DDF_FP32, DDF_FP16C = 0, 1
 OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID = 1, 2, 4
-KERNEL_AUTO, KERNEL_SCALAR, KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERNEL_SCALAR_NT_ALL, KERNEL_VEC1 = 0, 1, 2, 3, 4, 5, 6
+KERNEL_AUTO, KERNEL_SCALAR, KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERNEL_SCALAR_NT_ALL, KERNEL_VEC1, KERNEL_PAIR = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_EXP_COPY, KERNEL_EXP_NOSHIFT = 100, 101   # measurement-only variants, never used by the product path
 TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
 

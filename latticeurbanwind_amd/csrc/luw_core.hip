@@ -163,6 +163,100 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 	});
 }
 
+// ---------------------------------------------------------------- pair kernel: 2 cells per lane (FP16C DDFs)
+// With 2-byte DDFs the scalar kernel moves only 128 B per wave instruction.  Here a lane owns the cells (x, x+1), x even,
+// and moves both FP16C codes of a plane with ONE dword access -- the same bytes per instruction as the FP32 scalar
+// kernel.  Straight planes are 4-byte aligned; the x+1 planes are read/written at a 2-byte offset (dword access on a
+// 2-byte boundary, expressed with memcpy so the compiler may split it where the target demands), except for the
+// lane at the row end whose second neighbour wraps to x = 0.  A cell that must not be processed (solid / halo) passes
+// its populations through; its values are pre-swapped so the Esoteric-Pull store puts them back where they came from.
+// Requires even b.x0 and even b.x1 (the host falls back to the scalar kernel otherwise).
+__device__ __forceinline__ uint32_t ld_pair(const uint16_t* plane, const uint32_t byte_off, const bool nt) {
+	uint32_t v;
+	const char* ptr = reinterpret_cast<const char*>(plane)+byte_off;
+	if(nt) v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ptr)); else __builtin_memcpy(&v, ptr, 4);
+	return v;
+}
+__device__ __forceinline__ void st_pair(uint16_t* plane, const uint32_t byte_off, const uint32_t v, const bool nt) {
+	char* ptr = reinterpret_cast<char*>(plane)+byte_off;
+	if(nt) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(ptr)); else __builtin_memcpy(ptr, &v, 4);
+}
+template<int PARITY> __global__ __launch_bounds__(256, 3) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
+	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
+	if(x>=b.x1) return;
+	const NbrOff o = neighbor_offsets<uint16_t>(p, x, y, z);      // offsets of cell x; cell x+1 sits 2 bytes further
+	const bool wrap = x+2u==p.Nx;                                  // cell x+1 is the last of the row: its x+1 neighbour is x = 0
+	const uint32_t n = o.n>>1;
+	const size_t Np = p.Np;
+	const uint32_t fl2 = *reinterpret_cast<const uint16_t*>(flags+n);
+	uint8_t fl[2] = { (uint8_t)(fl2&0xFFu), (uint8_t)(fl2>>8) };
+	bool proc[2];
+	#pragma unroll
+	for(int c=0; c<2; c++) proc[c] = !cell_is_halo(p, x+c, y, z) && (fl[c]&TYPE_BO)!=TYPE_S && (fl[c]&TYPE_SU)!=TYPE_G;
+	if(!proc[0]&&!proc[1]) return;
+	float f[19][2];
+	auto unpack = [&](const int q, const uint32_t v) { f[q][0] = half_to_float_custom(v&0xFFFFu); f[q][1] = half_to_float_custom(v>>16); };
+	auto pack = [&](const int q) { return float_to_half_custom(f[q][0])|(float_to_half_custom(f[q][1])<<16); };
+	unpack(0, ld_pair(fi, o.n, true));
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		unpack(i, ld_pair(fi+(size_t)slotA<PARITY>(i)*Np, o.n, true));
+		const uint16_t* B = fi+(size_t)slotB<PARITY>(i)*Np;
+		if constexpr(!shifted) unpack(i+1, ld_pair(B, nbr<i>(o), true));
+		else {
+			uint32_t v;
+			if(!wrap) v = ld_pair(B, nbr<i>(o), false);
+			else { // (row, Nx-1) and (row, 0): nbr<i>(o) addresses x+1 = Nx-1 of the neighbour row
+				const uint32_t off = nbr<i>(o);
+				const uint32_t lo = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(B)+off);
+				const uint32_t hi = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(B)+(off-2u*(p.Nx-1u)));
+				v = lo|(hi<<16);
+			}
+			unpack(i+1, v);
+		}
+	});
+	#pragma unroll
+	for(int c=0; c<2; c++) {
+		if(proc[c]) {
+			float fc[19];
+			#pragma unroll
+			for(int q=0; q<19; q++) fc[q] = f[q][c];
+			float rhon, uxn, uyn, uzn;
+			collide_cell(p, n+c, x+c, y, z, fl[c], fc, rho, u, F, rhon, uxn, uyn, uzn);
+			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
+				rho[n+c] = rhon;
+				u[n+c] = uxn;
+				u[Np+n+c] = uyn;
+				u[2ull*Np+n+c] = uzn;
+			}
+			#pragma unroll
+			for(int q=0; q<19; q++) f[q][c] = fc[q];
+		} else {
+			#pragma unroll
+			for(int i=1; i<19; i+=2) { const float t = f[i][c]; f[i][c] = f[i+1][c]; f[i+1][c] = t; }
+		}
+	}
+	st_pair(fi, o.n, pack(0), true);
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		uint16_t* B = fi+(size_t)slotB<PARITY>(i)*Np;
+		const uint32_t v = pack(i);
+		if constexpr(!shifted) st_pair(B, nbr<i>(o), v, true);
+		else {
+			if(!wrap) st_pair(B, nbr<i>(o), v, false);
+			else {
+				const uint32_t off = nbr<i>(o);
+				*reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(B)+off) = (uint16_t)(v&0xFFFFu);
+				*reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(B)+(off-2u*(p.Nx-1u))) = (uint16_t)(v>>16);
+			}
+		}
+		st_pair(fi+(size_t)slotA<PARITY>(i)*Np, o.n, pack(i+1), true);
+	});
+}
+
 // ---------------------------------------------------------------- vector kernel: V cells per lane
 template<typename T, int V> struct Pack { T v[V]; };
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -531,16 +625,28 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	#undef LUW_LAUNCH_S
 }
 
+static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
+	uint16_t* fi = (uint16_t*)s->d_fi;
+	const bool odd = (s->t&1ull)!=0ull;
+	const uint32_t nx = (b.x1-b.x0)/2u;
+	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
+	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+	if(odd) hipLaunchKernelGGL((k_stream_collide_p<1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+}
+
 // Kernel choice.  LUW_KERNEL_AUTO: FP32 DDFs -> scalar kernel (one dword per lane and plane); FP16C DDFs -> 2 cells per
-// lane (again one dword per lane and plane).  Both measured fastest on MI355X, see profiles/ and DESIGN.md.
+// lane, direct addressing (again one dword per lane and plane).  Both measured fastest on MI355X, see profiles/ and DESIGN.md.
 static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields) {
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
 	const bool fp16 = s->ddf_bytes==2u;
 	uint32_t k = s->kernel;
-	if(k==LUW_KERNEL_AUTO) k = fp16 ? LUW_KERNEL_VEC2 : LUW_KERNEL_SCALAR;
-	if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
+	if(k==LUW_KERNEL_AUTO) k = fp16 ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
+	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || (b.x1&1u))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, even x range
+	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields);
+	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
 	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }

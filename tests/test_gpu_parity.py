@@ -19,7 +19,7 @@ def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0)
               use_F=False, every_step=False, subgrid=True):
     from latticeurbanwind_amd import capi
     flags, u, rho = state
-    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALL, "v1": capi.KERNEL_VEC1}[kernel],
+    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALL, "v1": capi.KERNEL_VEC1, "p": capi.KERNEL_PAIR}[kernel],
                 force_field=use_F, update_fields_every_step=every_step, subgrid=subgrid,
                 buffer_nudging=nudging, top_sponge=sponge)
     o = oracle.OracleLBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, use_F=use_F, subgrid=subgrid)
@@ -68,10 +68,10 @@ def test_fp16c_codec_exhaustive(luw):
     assert n.value == 0
 
 
-SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4)]
+SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4), (2, 3, 3), (514, 4, 3)]
 
 
-@pytest.mark.parametrize("kernel", ["s", "v", "v2", "sc", "sa", "v1"])
+@pytest.mark.parametrize("kernel", ["s", "v", "v2", "sc", "sa", "v1", "p"])
 @pytest.mark.parametrize("fp16c", [False, True])
 @pytest.mark.parametrize("size", SIZES)
 def test_stream_collide_matches_oracle(luw, kernel, fp16c, size):
@@ -95,7 +95,7 @@ def test_periodic_box_without_boundaries(luw, kernel):
     check(g, o, "periodic")
 
 
-@pytest.mark.parametrize("kernel", ["s", "v", "v2"])
+@pytest.mark.parametrize("kernel", ["s", "v", "v2", "p"])
 @pytest.mark.parametrize("fp16c", [False, True])
 def test_all_force_terms(luw, kernel, fp16c):
     # volume force + Coriolis + per-cell force field + buffer nudging (west/south/north/top, east = downstream) + top sponge
