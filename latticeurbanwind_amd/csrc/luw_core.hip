@@ -635,15 +635,16 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
 	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
 
-// Kernel choice.  LUW_KERNEL_AUTO: FP32 DDFs -> scalar kernel (one dword per lane and plane); FP16C DDFs -> 2 cells per
-// lane, direct addressing (again one dword per lane and plane).  Both measured fastest on MI355X, see profiles/ and DESIGN.md.
+// Kernel choice.  LUW_KERNEL_AUTO = the scalar kernel for both DDF formats: measured fastest on MI355X (FP32 36.0k MLUPS,
+// FP16C 45.7k MLUPS at 512^3; pair kernel 37.8k, vector kernels 20-29k; profiles/r01_kernel_ab.md).  The other kernels
+// stay selectable for A/B runs.
 static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields) {
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
 	const bool fp16 = s->ddf_bytes==2u;
 	uint32_t k = s->kernel;
-	if(k==LUW_KERNEL_AUTO) k = fp16 ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
+	if(k==LUW_KERNEL_AUTO) k = LUW_KERNEL_SCALAR;
 	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || (b.x1&1u))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, even x range
 	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields);
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
