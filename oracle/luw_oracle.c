@@ -457,6 +457,16 @@ void luwo_transfer_insert_fi(const LuwOracleCfg* c, const uint32_t direction, co
 	}
 }
 
+/* OpenMP thread control for the cpu_baseline leg of bench.py (no-ops when built without OpenMP) */
+#ifdef _OPENMP
+#include <omp.h>
+void luwo_set_threads(const int n) { if(n>0) omp_set_num_threads(n); }
+int luwo_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void luwo_set_threads(const int n) { (void)n; }
+int luwo_get_max_threads(void) { return 1; }
+#endif
+
 /* update_fields equivalent for checks: rho,u of a cell straight from the stored DDFs at time t, no forcing.
  * (used by tests for conservation checks; mirrors load_f + calculate_rho_u) */
 void luwo_moments(const LuwOracleCfg* c, const void* fi, const uint64_t t, float* rho_out, float* u_out) {

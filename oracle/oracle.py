@@ -56,6 +56,8 @@ def lib():
         L.luwo_transfer_extract_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_extract_fi.restype = None
         L.luwo_transfer_insert_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_insert_fi.restype = None
         L.luwo_moments.argtypes = [cfgp, vp, u64, vp, vp]; L.luwo_moments.restype = None
+        L.luwo_set_threads.argtypes = [C.c_int]; L.luwo_set_threads.restype = None
+        L.luwo_get_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -146,6 +148,14 @@ class OracleLBM:
         rho = np.zeros(self.N, np.float32); u = np.zeros(3 * self.N, np.float32)
         lib().luwo_moments(C.byref(self.cfg), _p(self.fi), self.t, _p(rho), _p(u))
         return rho, u
+
+
+def set_threads(n):
+    lib().luwo_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().luwo_get_max_threads())
 
 
 def feq(rho, ux, uy, uz):
