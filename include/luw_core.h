@@ -152,6 +152,16 @@ int luw_finish(luw_solver* s);                                            /* LBM
 int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_upload_fi(luw_solver* s, const void* host_src);
 
+/* on-device time averaging, replaces the per-sample device->host copy + host Welford update of the reference
+ * (process_post_step_samples / accumulate_from_buffers, FX/setup.cpp:4441-4542): running mean of u (3 comp.) and rho,
+ * M2 of the three velocity components, identical arithmetic and operation order.
+ * luw_stats_accumulate samples the device rho,u as they stand (they must have been written by the last step: every
+ * luw_run() call ends with such a step).  luw_stats_download returns host arrays in the layout write_avg_vtk consumes
+ * (FX/setup.cpp:2513-2683): avg_u AoS [3n+c], the others [n]; any pointer may be NULL. */
+int luw_stats_reset(luw_solver* s);
+int luw_stats_accumulate(luw_solver* s);
+int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, uint64_t* count);
+
 /* device self-check: number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C
  * codec differs from the literal formulas of FX/kernel.cpp:864-875; must be 0 */
 int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches);

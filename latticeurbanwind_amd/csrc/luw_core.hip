@@ -515,6 +515,31 @@ template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KP
 	}
 }
 
+// ---------------------------------------------------------------- on-device time averaging
+// The reference downloads u,rho at every sampled step and runs Welford's update on the host
+// (accumulate_from_buffers, FX/setup.cpp:4441-4488).  Same arithmetic, same operation order, on the device: mean and M2 of
+// the three velocity components, mean of rho.  One lane per cell, x fastest.
+__global__ __launch_bounds__(256) void k_stats_accumulate(const KParams p, const float inv_n, const float* __restrict__ rho, const float* __restrict__ u,
+		float* __restrict__ avg_u, float* __restrict__ avg_rho, float* __restrict__ m2) {
+	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+	if(x>=p.Nx) return;
+	const uint32_t n = x+(y+z*p.Ny)*p.Px;
+	const size_t Np = p.Np;
+	#pragma unroll
+	for(int c=0; c<3; c++) {
+		const float v = u[c*Np+n];
+		float mean = avg_u[c*Np+n];
+		const float delta = v-mean;
+		mean += delta*inv_n;
+		const float delta2 = v-mean;
+		m2[c*Np+n] += delta*delta2;
+		avg_u[c*Np+n] = mean;
+	}
+	const float r = rho[n];
+	const float ra = avg_rho[n];
+	avg_rho[n] = ra+(r-ra)*inv_n;
+}
+
 // ---------------------------------------------------------------- self-check of the fast FP16C codec
 // counts inputs for which the fast codec differs from the literal restatement of FX/kernel.cpp:864-875:
 // all 2^16 codes (decode, compared as bit patterns) and all 2^32 float bit patterns (encode)
@@ -580,6 +605,7 @@ struct luw_solver {
 	void* d_fi = nullptr;
 	float* d_rho = nullptr; float* d_u = nullptr; uint8_t* d_flags = nullptr; float* d_F = nullptr;
 	float* d_wbuf = nullptr; float* d_sigma = nullptr;
+	float* d_avg_u = nullptr; float* d_avg_rho = nullptr; float* d_m2 = nullptr; uint64_t avg_count = 0ull;
 	float* h_rho = nullptr; float* h_u = nullptr; uint8_t* h_flags = nullptr; float* h_F = nullptr;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
@@ -671,6 +697,7 @@ void luw_destroy(luw_solver* s) {
 	if(s->own_stream) (void)hipStreamSynchronize(s->own_stream);
 	(void)hipFree(s->d_fi); (void)hipFree(s->d_rho); (void)hipFree(s->d_u); (void)hipFree(s->d_flags); (void)hipFree(s->d_F);
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
+	(void)hipFree(s->d_avg_u); (void)hipFree(s->d_avg_rho); (void)hipFree(s->d_m2);
 	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F);
 	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
 	delete s;
@@ -855,6 +882,57 @@ int luw_upload_fi(luw_solver* s, const void* host_src) {
 	return LUW_OK;
 }
 
+int luw_run(luw_solver* s, uint64_t steps);
+int luw_stats_reset(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_stats_reset: null solver");
+	if(int e = set_device(s)) return e;
+	const size_t Np = s->kp.Np;
+	if(!s->d_avg_u) {
+		if(hipMalloc((void**)&s->d_avg_u, 3ull*Np*4ull)!=hipSuccess||hipMalloc((void**)&s->d_avg_rho, Np*4ull)!=hipSuccess||hipMalloc((void**)&s->d_m2, 3ull*Np*4ull)!=hipSuccess)
+			return fail(LUW_ERR_NOMEM, "luw_stats_reset: allocation failed");
+	}
+	HIP_TRY(hipMemsetAsync(s->d_avg_u, 0, 3ull*Np*4ull, s->stream));
+	HIP_TRY(hipMemsetAsync(s->d_avg_rho, 0, Np*4ull, s->stream));
+	HIP_TRY(hipMemsetAsync(s->d_m2, 0, 3ull*Np*4ull, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->avg_count = 0ull;
+	return LUW_OK;
+}
+int luw_stats_accumulate(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_stats_accumulate: null solver");
+	if(!s->d_avg_u) return fail(LUW_ERR_STATE, "luw_stats_accumulate: call luw_stats_reset first");
+	if(!s->fields_current) return fail(LUW_ERR_STATE, "luw_stats_accumulate: rho,u on the device are stale (the last step did not write fields)");
+	if(int e = set_device(s)) return e;
+	s->avg_count++;
+	const float inv_n = 1.0f/(float)s->avg_count; // FX/setup.cpp:4442-4443
+	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
+	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
+	hipLaunchKernelGGL(k_stats_accumulate, grid, block, 0, s->stream, s->kp, inv_n, s->d_rho, s->d_u, s->d_avg_u, s->d_avg_rho, s->d_m2);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, uint64_t* count) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_stats_download: null solver");
+	if(!s->d_avg_u) return fail(LUW_ERR_STATE, "luw_stats_download: no statistics have been accumulated");
+	if(int e = set_device(s)) return e;
+	const uint64_t N = s->N;
+	int e = LUW_OK;
+	if(avg_u) { // the reference keeps u_avg as AoS [3n+c] (FX/setup.cpp:4453-4477): interleave on the host
+		std::vector<float> tmp(3ull*N);
+		if((e = copy_pitched(tmp.data(), s->d_avg_u, 4u, s, 3u, false, s->stream))) return e;
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		for(uint64_t n=0ull; n<N; n++) { avg_u[3ull*n] = tmp[n]; avg_u[3ull*n+1ull] = tmp[N+n]; avg_u[3ull*n+2ull] = tmp[2ull*N+n]; }
+	}
+	if(avg_rho) if((e = copy_pitched(avg_rho, s->d_avg_rho, 4u, s, 1u, false, s->stream))) return e;
+	float* m2h[3] = { m2_u, m2_v, m2_w };
+	for(int c=0; c<3; c++) if(m2h[c]) {
+		const size_t rows = (size_t)s->cfg.Ny*s->cfg.Nz;
+		HIP_TRY(hipMemcpy2DAsync(m2h[c], (size_t)s->cfg.Nx*4u, s->d_m2+(size_t)c*s->kp.Np, (size_t)s->kp.Px*4u, (size_t)s->cfg.Nx*4u, rows, hipMemcpyDeviceToHost, s->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if(count) *count = s->avg_count;
+	return LUW_OK;
+}
 int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches) {
 	if(!mismatches) return fail(LUW_ERR_INVALID, "luw_selfcheck_fp16c_codec: null argument");
 	HIP_TRY(hipSetDevice(device));

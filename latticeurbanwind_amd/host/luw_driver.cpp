@@ -1,0 +1,831 @@
+// luw_driver.cpp -- process-level drop-in for the reference's solver executable `FluidX3D <deck>`
+// (argv contract FX/setup.cpp:2768-2773; project dir = the deck's parent, FX/setup.cpp:3391), host side in C++ over
+// the C-ABI (lbm.hpp mirror).  Re-states just enough of main_setup (FX/setup.cpp:2726-6154) to consume the same
+// deck / proj_temp / wind_bc files and to write the same RESULTS/vtk files:
+//   deck grammar FX/setup.cpp:40-178, key handlers :2918-3305, mesh_control :3364-3390 (gpu_memory bisection :335-407
+//   with the shipped build's memory model FX/lbm.cpp:188-228), grid sizing :3552-3568, profile samples :3660-3729,
+//   Units FX/units.hpp:21-67, Coriolis / buffer / sponge constants FX/setup.cpp:3800-3903, STL FX/utilities.hpp:4835-4888
+//   + transform FX/setup.cpp:4070-4087, profile table :5777-5912, flags/u fill :5914-5995 (profile mode) and :5655-5688
+//   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
+// Modes: *.luwpf (profile) and *.luwdg (dataset).  Not in this build (announced on the console, never silently):
+//   *.luw NWP boundary builders, von-Karman inlet (8f-2), DEM ground plane, probes, PNG frames.
+// Differences by design: time averaging runs on the device (luw_stats_*), the voxeliser runs on the host.
+// Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
+//   --device N, --dry-run (host stage only, no GPU), --sizing-only (stop after grid / unit / buffer / sponge numbers),
+//   --dump-setup FILE (raw initial state of the first case).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <ctime>
+#include <filesystem>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "lbm.hpp"
+
+using namespace luw_host;
+using std::string;
+
+// ------------------------------------------------------------------------------------------------ console / text
+static std::ofstream g_log;
+static void println(const string& s = "") { std::cout << s << "\n"; std::cout.flush(); if(g_log.is_open()) { g_log << s << "\n"; g_log.flush(); } }
+static const uint CONSOLE_WIDTH = 94u; // FX/utilities.hpp:9
+static string alignr(const uint n, const string& x) { string s(n, ' '); s += x; return s.substr((uint)std::min((int)s.length()-(int)n, (int)n)); }
+static string alignl(const uint n, const string& x) { string s = x+string(n, ' '); return s.substr(0, std::max(n, (uint)x.length())); }
+static string alignc(const uint n, const string& x) { if((uint)x.length()>=n) return x.substr(0u, n); const uint l = (n-(uint)x.length())/2u; return string(l, ' ')+x+string(n-(uint)x.length()-l, ' '); }
+static string hr_plain() { return "|"+string(CONSOLE_WIDTH-2u, '-')+"|"; }
+static void print_section_title(const string& t) { println(hr_plain()); println("|"+alignc(CONSOLE_WIDTH-2u, t)+"|"); println(hr_plain()); }
+static void print_kv_row(const string& k, const string& v) { println("| "+k+" | "+v+" |"); }
+static string to_string_u(ulong x) { string r; do { r = (char)(x%10ull+48ull)+r; x /= 10ull; } while(x); return r; }
+static string decimal_to_string(uint x, int digits) { string r; while((digits--)>0) { r = (char)(x%10u+48u)+r; x /= 10u; } return r; }
+static string to_string_f(float x) { // FX/utilities.hpp:2603-2634,2741-2750
+	string s;
+	if(x<0.0f) { s += "-"; x = -x; }
+	if(std::isnan(x)) return s+"NaN";
+	if(std::isinf(x)) return s+"Inf";
+	int exponent = 0;
+	if(x>=10.0f) {
+		if(x>=1E32f) { x *= 1E-32f; exponent += 32; } if(x>=1E16f) { x *= 1E-16f; exponent += 16; } if(x>=1E8f) { x *= 1E-8f; exponent += 8; }
+		if(x>=1E4f) { x *= 1E-4f; exponent += 4; } if(x>=1E2f) { x *= 1E-2f; exponent += 2; } if(x>=1E1f) { x *= 1E-1f; exponent += 1; }
+	}
+	if(x>0.0f&&x<=1.0f) {
+		if(x<1E-31f) { x *= 1E32f; exponent -= 32; } if(x<1E-15f) { x *= 1E16f; exponent -= 16; } if(x<1E-7f) { x *= 1E8f; exponent -= 8; }
+		if(x<1E-3f) { x *= 1E4f; exponent -= 4; } if(x<1E-1f) { x *= 1E2f; exponent -= 2; } if(x<1E0f) { x *= 1E1f; exponent -= 1; }
+	}
+	uint integral = (uint)x;
+	const float remainder = (x-(float)integral)*1E8f;
+	uint decimal = (uint)remainder;
+	if(remainder-(float)decimal>=0.5f) { decimal++; if(decimal>=100000000u) { decimal = 0u; integral++; if(integral>=10u) { integral = 1u; exponent++; } } }
+	return s+to_string_u(integral)+"."+decimal_to_string(decimal, 8)+(exponent!=0 ? "E"+std::to_string(exponent) : "");
+}
+static string to_string_fd(float x, const uint decimals) { // FX/utilities.hpp:2762-2772
+	string s;
+	if(x<0.0f) { s += "-"; x = -x; }
+	if(std::isnan(x)) return s+"NaN";
+	if(std::isinf(x)) return s+"Inf";
+	const float power = std::pow(10.0f, (float)std::min(decimals, 8u));
+	x += 0.5f/power;
+	const ulong integral = (ulong)x;
+	const uint decimal = (uint)((x-(float)integral)*power);
+	return s+to_string_u(integral)+(decimals==0u ? "" : "."+decimal_to_string(decimal, (int)std::min(decimals, 8u)));
+}
+static string fmtf(float v, int prec = 4) { std::ostringstream os; os << std::fixed; os.precision(prec); os << v; return os.str(); }
+static string format_tag(float v) { string s = to_string_fd(v, 3u); if(s.find('.')!=string::npos) { while(!s.empty()&&s.back()=='0') s.pop_back(); if(!s.empty()&&s.back()=='.') s.pop_back(); } return s.empty() ? "0" : s; }
+static string now_str(const char* fmt = "%Y%m%d %H:%M:%S") { std::time_t tt = std::time(nullptr); std::tm tm{}; localtime_r(&tt, &tm); char b[64]; std::strftime(b, sizeof(b), fmt, &tm); return b; }
+[[noreturn]] static void fatal(const string& msg, const int code = -1) { println(msg); println(hr_plain()); std::exit(code); }
+
+template<typename Fn> static void parallel_for(const ulong N, Fn fn) { // FX/utilities.hpp:64-97
+	const uint threads = std::max(1u, std::min((uint)std::thread::hardware_concurrency(), 64u));
+	std::vector<std::thread> pool;
+	for(uint t=0u; t<threads; t++) pool.emplace_back([=]() { for(ulong n=N*(ulong)t/threads; n<N*(ulong)(t+1u)/threads; n++) fn(n); });
+	for(auto& th : pool) th.join();
+}
+static inline float reverse_bytes(const float v) { uint32_t u; std::memcpy(&u, &v, 4); u = __builtin_bswap32(u); float r; std::memcpy(&r, &u, 4); return r; }
+
+// ------------------------------------------------------------------------------------------------ deck (FX/setup.cpp:40-178)
+static string deck_trim(const string& s) { const char* ws = " \t\r\n"; const size_t b = s.find_first_not_of(ws); if(b==string::npos) return ""; return s.substr(b, s.find_last_not_of(ws)-b+1u); }
+static string deck_unquote(string s) { s = deck_trim(s); if(s.size()>=2u) { const char q = s.front(); if((q=='"'||q=='\'')&&s.back()==q) s = deck_trim(s.substr(1u, s.size()-2u)); } return s; }
+static size_t deck_comment_index(const string& line) {
+	bool sq = false, dq = false;
+	for(size_t i=0u; i+1u<line.size(); ++i) {
+		const char ch = line[i], nx = line[i+1u];
+		if(ch=='\''&&!dq) { sq = !sq; continue; }
+		if(ch=='"'&&!sq) { dq = !dq; continue; }
+		if(!sq&&!dq&&ch=='/'&&nx=='/') return i;
+	}
+	return string::npos;
+}
+static string deck_normalize_key(string key) {
+	key = deck_trim(key);
+	string n; bool last_sep = false;
+	for(unsigned char ch : key) {
+		if(ch=='-'||std::isspace(ch)) { if(!n.empty()&&!last_sep) n.push_back('_'); last_sep = true; continue; }
+		n.push_back((char)std::tolower(ch)); last_sep = false;
+	}
+	while(!n.empty()&&n.front()=='_') n.erase(n.begin());
+	while(!n.empty()&&n.back()=='_') n.pop_back();
+	static const std::unordered_map<string, string> aliases = { {"vk_inlet_enable", "turb_inflow_enable"}, {"vk_inlet_anisotropy_scale", "vk_inlet_anisotropy"}, {"vk_inlet_aniso_scale", "vk_inlet_anisotropy"} };
+	const auto it = aliases.find(n);
+	return it!=aliases.end() ? it->second : n;
+}
+static bool deck_try_parse_bool(const string& raw, bool& out) {
+	string n = deck_unquote(raw);
+	std::transform(n.begin(), n.end(), n.begin(), ::tolower);
+	if(n.empty()) return false;
+	static const std::unordered_map<string, bool> tok = { {"1", true}, {"true", true}, {"t", true}, {"yes", true}, {"y", true}, {"on", true}, {"enable", true}, {"enabled", true},
+		{"0", false}, {"false", false}, {"f", false}, {"no", false}, {"n", false}, {"off", false}, {"disable", false}, {"disabled", false} };
+	const auto it = tok.find(n);
+	if(it!=tok.end()) { out = it->second; return true; }
+	char* end = nullptr;
+	const double v = std::strtod(n.c_str(), &end);
+	if(end==n.c_str()||*end!='\0'||!std::isfinite(v)) return false;
+	out = v!=0.0;
+	return true;
+}
+static std::unordered_map<string, string> read_deck_entries(std::istream& in) {
+	std::unordered_map<string, string> values;
+	string line;
+	while(std::getline(in, line)) {
+		const size_t c = deck_comment_index(line);
+		if(c!=string::npos) line.erase(c);
+		const size_t eq = line.find('=');
+		if(eq==string::npos) continue;
+		const string key = deck_normalize_key(line.substr(0u, eq));
+		if(key.empty()) continue;
+		values[key] = deck_trim(line.substr(eq+1u));
+	}
+	return values;
+}
+
+// ------------------------------------------------------------------------------------------------ units (FX/units.hpp)
+struct Units {
+	float unit_m = 1.0f, unit_kg = 1.0f, unit_s = 1.0f, unit_K = 1.0f;
+	void set_m_kg_s_K(const float x, const float u, const float rho, const float T, const float si_x, const float si_u, const float si_rho, const float si_T) {
+		unit_m = si_x/x; unit_kg = si_rho/rho*(unit_m*unit_m*unit_m); unit_s = u/si_u*unit_m; unit_K = si_T/T;
+	}
+	float x(const float si_x) const { return si_x/unit_m; }
+	float si_x(const float x) const { return x*unit_m; }
+	float nu(const float si_nu) const { return si_nu*unit_s/(unit_m*unit_m); }
+	float si_u(const float u) const { return u*unit_m/unit_s; }
+	float si_rho(const float rho) const { return rho*unit_kg/(unit_m*unit_m*unit_m); }
+	ulong t(const float si_t) const { return (ulong)std::fmax(si_t/unit_s+0.5f, 0.5f); }
+};
+
+// ------------------------------------------------------------------------------------------------ configuration (defaults FX/setup.cpp:183-220)
+struct Config {
+	string caseName = "example", datetime = "20990101120000", parent, deck_path;
+	bool profile_mode = false, dataset_mode = false;
+	float z_si_offset = 50.0f;
+	bool downstream_open_face = false;
+	uint memory = 20000u; float cell_m = 20.0f;
+	float si_x = 0.0f, si_y = 0.0f, si_z = 0.0f;
+	uint Dx = 1u, Dy = 1u, Dz = 1u;
+	uint research_output_steps = 0u, unsteady_output_interval = 0u, purge_avg_steps = 0u, purge_avg_stride = 1u;
+	ulong run_nstep_override = 0ull;
+	bool out_tke = true, out_ti = true, out_tls = true;
+	bool enable_coriolis = false; float cut_lon[2] = {0, 0}, cut_lat[2] = {0, 0}; bool has_cut_lon = false, has_cut_lat = false;
+	bool enable_buffer_nudging = true; float buffer_thickness_m = 160.0f, buffer_tau_s = 300.0f; int buffer_nudge_vertical = 0;
+	bool enable_top_sponge = true; float sponge_thickness_m = 200.0f, sponge_tau_s = 120.0f; int sponge_ref_mode = 0;
+	bool vk_enable = true; int vk_nmodes = 256;
+	std::vector<float> inflow_list, angle_list;
+	// command line
+	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup;
+};
+
+// memory model of the SHIPPED reference build (D3Q19 FP16C + FORCE_FIELD + TEMPERATURE + GRAPHICS), FX/lbm.cpp:188-228:
+// gpu_memory decks were sized against it, so the same deck must give the same grid here
+static uint vram_required_mb_per_device(const uint Nx, const uint Ny, const uint Nz, const uint Dx, const uint Dy, const uint Dz) {
+	const uint Hx = Dx>1u, Hy = Dy>1u, Hz = Dz>1u;
+	const ulong lx = (ulong)(Nx/Dx+2u*Hx), ly = (ulong)(Ny/Dy+2u*Hy), lz = (ulong)(Nz/Dz+2u*Hz), N = lx*ly*lz;
+	auto mb = [](const ulong bytes) { return (uint)(bytes/1048576ull); };
+	uint m = 0u;
+	m += mb(N*19ull*2ull); m += mb(N*4ull); m += mb(N*12ull); m += mb(N);           // fi, rho, u, flags
+	m += mb(N*12ull); m += mb(16ull);                                              // F, object_sum
+	m += mb(N*7ull*2ull); m += mb(N*4ull);                                          // gi, T
+	const ulong pixels = 1920ull*1080ull; m += mb(pixels*4ull); m += mb(pixels*4ull); m += mb(60ull); // bitmap, zbuffer, camera
+	if(Dx*Dy*Dz>1u) {
+		ulong Amax = 0ull;
+		if(Dx>1u) Amax = std::max(Amax, ly*lz); if(Dy>1u) Amax = std::max(Amax, lz*lx); if(Dz>1u) Amax = std::max(Amax, lx*ly);
+		m += 2u*mb(Amax*(ulong)std::max(5u*2u, 17u));
+	}
+	return m;
+}
+static uint vk_extra_mb(const Config& c, const uint Nx, const uint Ny, const uint Nz) { // FX/setup.cpp:312-333
+	if(!c.vk_enable||Nx<2u||Ny<2u||Nz<2u) return 0u;
+	const ulong nz_side = Nz>2u ? (ulong)(Nz-2u) : 0ull, nx_inner = Nx>2u ? (ulong)(Nx-2u) : 0ull;
+	const ulong pts = 2ull*(ulong)Ny*nz_side+2ull*nx_inner*nz_side+(ulong)Nx*(ulong)Ny;
+	const ulong mode_stride = 5ull*(ulong)std::max(1, c.vk_nmodes);
+	auto mb = [](const ulong bytes) { return (uint)(bytes/1048576ull); };
+	return mb(pts*8ull)+mb(pts)+mb(pts*28ull)+mb(mode_stride*40ull);
+}
+struct GridEstimate { uint Nx, Ny, Nz, core_mb, extra_mb, total_mb; };
+static GridEstimate estimate_from_cell_size(const Config& c, const float cell) { // FX/setup.cpp:345-369
+	const float safe = std::fmax(cell, 1.0e-6f);
+	GridEstimate e{};
+	e.Nx = (uint)std::max(1, (int)(c.si_x/safe+0.5f)); e.Ny = (uint)std::max(1, (int)(c.si_y/safe+0.5f));
+	const uint core = (uint)std::max(1, (int)(c.si_z/safe+0.5f));
+	const bool ext = c.enable_top_sponge&&c.sponge_tau_s>0.0f&&c.sponge_ref_mode==0&&core>2u;
+	e.Nz = core+(ext ? (uint)std::max(1, (int)std::lround(c.sponge_thickness_m/safe)) : 0u);
+	e.core_mb = vram_required_mb_per_device(e.Nx, e.Ny, e.Nz, c.Dx, c.Dy, c.Dz);
+	e.extra_mb = vk_extra_mb(c, e.Nx, e.Ny, e.Nz);
+	e.total_mb = e.core_mb+e.extra_mb;
+	return e;
+}
+static float fit_cell_size_to_gpu_memory_request(const Config& c, const uint target_mb) { // FX/setup.cpp:371-407
+	if(target_mb==0u) return 20.0f;
+	float fit = std::fmax(std::fmax(c.si_x, c.si_y), c.si_z+std::fmax(c.sponge_thickness_m, 0.0f));
+	fit = std::fmax(fit, 1.0f);
+	GridEstimate fe = estimate_from_cell_size(c, fit);
+	for(int i=0; i<32&&fe.total_mb>target_mb; ++i) { fit *= 2.0f; fe = estimate_from_cell_size(c, fit); }
+	float over = fit*0.5f;
+	GridEstimate oe = estimate_from_cell_size(c, over);
+	for(int i=0; i<64&&over>1.0e-6f&&oe.total_mb<=target_mb; ++i) { fit = over; fe = oe; over *= 0.5f; oe = estimate_from_cell_size(c, over); }
+	for(int i=0; i<48; ++i) {
+		const float mid = 0.5f*(over+fit);
+		const GridEstimate me = estimate_from_cell_size(c, mid);
+		if(me.total_mb<=target_mb) { fit = mid; fe = me; } else { over = mid; oe = me; }
+	}
+	return fit;
+}
+
+// ------------------------------------------------------------------------------------------------ profile (FX/setup.cpp:2122-2150,2243-2280)
+static std::vector<std::pair<float, float>> read_profile_dat(const string& path) {
+	std::vector<std::pair<float, float>> out;
+	std::ifstream fin(path);
+	if(!fin.is_open()) { println("ERROR: could not open profile file "+path); return out; }
+	string line;
+	while(std::getline(fin, line)) {
+		size_t c = line.find("//"); if(c!=string::npos) line.erase(c);
+		c = line.find('#'); if(c!=string::npos) line.erase(c);
+		line = deck_trim(line);
+		if(line.empty()) continue;
+		for(char& ch : line) if(ch==','||ch==';') ch = ' ';
+		std::stringstream ss(line);
+		float z = 0.0f, u = 0.0f;
+		if(!(ss >> z >> u)) continue;
+		if(!std::isfinite(z)||!std::isfinite(u)) continue;
+		out.push_back({z, u});
+	}
+	return out;
+}
+static float hermite_spline(const float a, const float b, const float va, const float vb, const float t) { // FX/utilities.hpp:2374-2377
+	const float cbt = t*t*t, sqt = t*t;
+	return (2.0f*cbt-3.0f*sqt+1.0f)*a+(-2.0f*cbt+3.0f*sqt)*b+(cbt-2.0f*sqt+t)*va+(cbt-sqt)*vb;
+}
+static float interpolate_profile_cubic(const std::vector<float>& z, const std::vector<float>& u, const float zq) {
+	const size_t n = z.size();
+	if(n==0u) return 0.0f;
+	if(n==1u) return u[0];
+	if(zq<=z.front()) return u.front();
+	if(zq>=z.back()) return u.back();
+	auto it = std::upper_bound(z.begin(), z.end(), zq);
+	const size_t i1 = it==z.begin() ? 0u : (size_t)(it-z.begin()-1), i2 = std::min(i1+1u, n-1u);
+	const float z0 = z[i1], z1 = z[i2], denom = z1-z0;
+	if(denom<=0.0f) return u[i1];
+	const float t = (zq-z0)/denom;
+	auto slope_at = [&](const size_t i) -> float {
+		if(i==0u) { const float dz = z[1]-z[0]; return dz!=0.0f ? (u[1]-u[0])/dz : 0.0f; }
+		if(i+1u>=n) { const float dz = z[n-1u]-z[n-2u]; return dz!=0.0f ? (u[n-1u]-u[n-2u])/dz : 0.0f; }
+		const float dz = z[i+1u]-z[i-1u]; return dz!=0.0f ? (u[i+1u]-u[i-1u])/dz : 0.0f;
+	};
+	const float m0 = slope_at(i1), m1 = slope_at(i2);
+	return hermite_spline(u[i1], u[i2], m0*denom, m1*denom, t);
+}
+
+// ------------------------------------------------------------------------------------------------ mesh + host voxeliser
+struct Mesh { std::vector<float> p0, p1, p2; uint n = 0u; float pmin[3], pmax[3]; };
+static void mesh_find_bounds(Mesh& m) { // FX/utilities.hpp:4774-4785: seeded with p0[0] only
+	for(int c=0; c<3; c++) m.pmin[c] = m.pmax[c] = m.p0[c];
+	for(uint i=1u; i<m.n; i++) for(int c=0; c<3; c++) {
+		m.pmin[c] = std::fmin(std::fmin(std::fmin(m.p0[3u*i+c], m.p1[3u*i+c]), m.p2[3u*i+c]), m.pmin[c]);
+		m.pmax[c] = std::fmax(std::fmax(std::fmax(m.p0[3u*i+c], m.p1[3u*i+c]), m.p2[3u*i+c]), m.pmax[c]);
+	}
+}
+static bool read_stl(const string& path, Mesh& m) { // binary STL only, FX/utilities.hpp:4835-4866
+	std::ifstream f(path, std::ios::in|std::ios::binary);
+	if(f.fail()) return false;
+	std::vector<char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	if(data.size()<84u) return false;
+	uint tn; std::memcpy(&tn, data.data()+80, 4);
+	if(tn==0u||data.size()!=84u+50ull*tn) fatal("| Error: File \""+path+"\" is corrupt or unsupported! Only binary .stl files are supported.", 1);
+	m.n = tn; m.p0.resize(3u*tn); m.p1.resize(3u*tn); m.p2.resize(3u*tn);
+	for(uint i=0u; i<tn; i++) { const char* t = data.data()+84u+50ull*i; std::memcpy(&m.p0[3u*i], t+12, 12); std::memcpy(&m.p1[3u*i], t+24, 12); std::memcpy(&m.p2[3u*i], t+36, 12); }
+	mesh_find_bounds(m);
+	return true;
+}
+static void mesh_scale_translate(Mesh& m, const float scale) { // scale about center 0, then pmin -> (1,1,1): FX/setup.cpp:4086-4087
+	for(auto* v : {&m.p0, &m.p1, &m.p2}) for(float& f : *v) f = scale*f;
+	for(int c=0; c<3; c++) { m.pmin[c] = scale*m.pmin[c]; m.pmax[c] = scale*m.pmax[c]; }
+	float tr[3]; for(int c=0; c<3; c++) tr[c] = 1.0f-m.pmin[c];
+	for(auto* v : {&m.p0, &m.p1, &m.p2}) for(size_t i=0u; i<v->size(); i++) (*v)[i] += tr[i%3u];
+	for(int c=0; c<3; c++) { m.pmin[c] += tr[c]; m.pmax[c] += tr[c]; }
+}
+// voxelize_mesh with direction 2 and flag TYPE_S on one domain (FX/kernel.cpp:2381-2471, FX/lbm.cpp:498), on the host.
+// IEEE 1/g here vs the device reciprocal of the OpenCL build: faces exactly on lattice planes may land one cell off
+// (DESIGN.md section 3).
+static ulong voxelize_z(const Mesh& m, const uint Nx, const uint Ny, const uint Nz, std::vector<uchar>& flags) {
+	const float x0 = m.pmin[0]-2.0f, y0 = m.pmin[1]-2.0f, z0 = m.pmin[2]-2.0f, x1 = m.pmax[0]+2.0f, y1 = m.pmax[1]+2.0f, z1 = m.pmax[2]+2.0f;
+	auto clampi = [](const int v, const int lo, const int hi) { return std::max(lo, std::min(hi, v)); };
+	const uint zstart = (uint)clampi((int)z0, 0, (int)Nz-1), hmax = (uint)clampi((int)z1, 0, (int)Nz);
+	std::atomic<ulong> solid{0ull};
+	parallel_for((ulong)Nx*(ulong)Ny, [&](const ulong a) {
+		const uint x = (uint)(a%Nx), y = (uint)(a/Nx);
+		const float rx = (float)x, ry = (float)y, rz = (float)zstart;
+		if(rx<x0||ry<y0||rx>=x1||ry>=y1) return;
+		uint intersections = 0u, check = 0u;
+		unsigned short dist[64];
+		for(uint i=0u; i<m.n; i++) {
+			const float* a0 = &m.p0[3u*i]; const float* a1 = &m.p1[3u*i]; const float* a2 = &m.p2[3u*i];
+			const float u[3] = {a1[0]-a0[0], a1[1]-a0[1], a1[2]-a0[2]}, v[3] = {a2[0]-a0[0], a2[1]-a0[1], a2[2]-a0[2]}, w[3] = {rx-a0[0], ry-a0[1], rz-a0[2]};
+			const float h[3] = {0.0f*v[2]-1.0f*v[1], 1.0f*v[0]-0.0f*v[2], 0.0f*v[1]-0.0f*v[0]};             // cross(r_direction, v)
+			const float q[3] = {w[1]*u[2]-w[2]*u[1], w[2]*u[0]-w[0]*u[2], w[0]*u[1]-w[1]*u[0]};               // cross(w, u)
+			const float g = u[0]*h[0]+u[1]*h[1]+u[2]*h[2], f = 1.0f/g, s = f*(w[0]*h[0]+w[1]*h[1]+w[2]*h[2]), t = f*(0.0f*q[0]+0.0f*q[1]+1.0f*q[2]), d = f*(v[0]*q[0]+v[1]*q[1]+v[2]*q[2]);
+			if(g!=0.0f&&s>=0.0f&&s<1.0f&&t>=0.0f&&s+t<1.0f) {
+				if(d>0.0f) { if(intersections<64u&&d<65536.0f) dist[intersections] = (unsigned short)d; intersections++; } else check++;
+			}
+		}
+		const uint ns = std::min(intersections, 64u);
+		std::sort(dist, dist+ns);
+		bool inside = (intersections%2u)&&(check%2u);
+		uint k = (intersections%2u)!=(check%2u);
+		const uint h0 = zstart;
+		const uint hmesh = h0+(ns>0u ? (uint)dist[std::min(intersections-1u, 63u)] : 0u);
+		ulong cnt = 0ull;
+		for(uint h=h0; h<hmax; h++) {
+			while(k<intersections&&h>h0+(uint)dist[std::min(k, 63u)]) { inside = !inside; k++; }
+			inside = inside&&(k<intersections&&h<hmesh);
+			if(inside) { const ulong n = (ulong)x+((ulong)y+(ulong)h*Ny)*Nx; flags[n] = (uchar)((flags[n]&~0x03)|TYPE_S); cnt++; }
+		}
+		solid += cnt;
+	});
+	return solid.load();
+}
+
+// ------------------------------------------------------------------------------------------------ VTK writers
+static string default_filename(const string& path, const string& name, const ulong t) { // FX/lbm.cpp:235-239
+	string time = "00000000"+to_string_u(t);
+	time = time.substr(time.length()-9u, 9u);
+	return path+name+"-"+time+".vtk";
+}
+struct VtkGeom { uint Nx, Ny, Nz, Nz_out; float spacing; float origin[3]; };
+static string vtk_header(const string& filename, const VtkGeom& g) {
+	const string base = filename.substr(filename.find_last_of("/\\")+1u);
+	const ulong points = (ulong)g.Nx*(ulong)g.Ny*(ulong)g.Nz_out;
+	return "# vtk DataFile Version 3.0\nFluidX3D "+base+"\nBINARY\nDATASET STRUCTURED_POINTS\n"
+		"DIMENSIONS "+to_string_u(g.Nx)+" "+to_string_u(g.Ny)+" "+to_string_u(g.Nz_out)+"\n"
+		"ORIGIN "+to_string_f(g.origin[0])+" "+to_string_f(g.origin[1])+" "+to_string_f(g.origin[2])+"\n"
+		"SPACING "+to_string_f(g.spacing)+" "+to_string_f(g.spacing)+" "+to_string_f(g.spacing)+"\n"
+		"POINT_DATA "+to_string_u(points)+"\n";
+}
+// Memory_Container::write_vtk (FX/lbm.hpp:307-356): SoA host field -> AoS big-endian floats in SI units
+static void write_field_vtk(const string& filename, const VtkGeom& g, const float* data, const uint comps, const float factor) {
+	std::filesystem::create_directories(std::filesystem::path(filename).parent_path());
+	std::ofstream file(filename, std::ios::out|std::ios::binary);
+	const string header = vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n";
+	file.write(header.c_str(), (std::streamsize)header.length());
+	const ulong N = (ulong)g.Nx*g.Ny*g.Nz, points = (ulong)g.Nx*g.Ny*g.Nz_out;
+	std::vector<float> buf(points*comps);
+	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(factor*data[(ulong)d*N+i]); });
+	file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
+}
+
+// ------------------------------------------------------------------------------------------------ main
+int main(int argc, char** argv) {
+	Config c;
+	if(argc<2) { std::fprintf(stderr, "usage: %s <deck.luwpf|.luwdg> [--ddf fp32|fp16c] [--device N] [--dry-run] [--dump-setup FILE]\n", argv[0]); return -1; }
+	c.deck_path = argv[1];
+	for(int i=2; i<argc; i++) {
+		const string a = argv[i];
+		if(a=="--ddf"&&i+1<argc) { const string v = argv[++i]; c.fp16c = v!="fp32"; }
+		else if(a=="--device"&&i+1<argc) c.device = std::atoi(argv[++i]);
+		else if(a=="--dry-run") c.dry_run = true;
+		else if(a=="--sizing-only") { c.dry_run = true; c.sizing_only = true; } // stop after the derived numbers (no lattice-sized host arrays)
+		else if(a=="--dump-setup"&&i+1<argc) c.dump_setup = argv[++i];
+		else println("| WARNING: extra CLI arg ignored: "+a);
+	}
+	println(hr_plain());
+	println("|"+alignc(CONSOLE_WIDTH-2u, "LatticeUrbanWind LUW core for AMD Instinct MI355X (HIP, D3Q19 SRT + Smagorinsky)")+"|");
+	println(hr_plain());
+	{ // mode from the suffix, FX/setup.cpp:2792-2810
+		string ext = std::filesystem::path(c.deck_path).extension().string();
+		std::transform(ext.begin(), ext.end(), ext.begin(), ::tolower);
+		if(ext==".luwdg") { c.dataset_mode = true; println("| Dataset generation mode enabled (*.luwdg).                                  |"); }
+		else if(ext==".luwpf") { c.profile_mode = true; println("| Profile forcing mode enabled (*.luwpf).                                     |"); }
+		else fatal("ERROR: NWP mode (*.luw: SurfData CSV boundary builders, SURVEY 8f-3) is not part of this build yet; use the reference solver for *.luw decks.");
+	}
+	std::ifstream fin(c.deck_path);
+	if(!fin.is_open()) fatal("ERROR: config not found. Please provide a valid *.luw, *.luwdg, or *.luwpf and rerun.");
+	const auto deck = read_deck_entries(fin);
+	string mesh_control, gpu_memory_val, cell_size_val;
+	auto second_val = [](const string& r) { const size_t cpos = r.find(','), rpos = r.find(']', cpos); return (float)atof(r.substr(cpos+1u, rpos-cpos-1u).c_str()); };
+	auto parse_float_list = [](const string& r, std::vector<float>& out) {
+		out.clear(); string s = deck_trim(r); const size_t lb = s.find('['), rb = s.find(']', lb);
+		const string inside = (lb!=string::npos&&rb!=string::npos&&rb>lb) ? s.substr(lb+1u, rb-lb-1u) : s;
+		std::stringstream ss(inside); string tok;
+		while(std::getline(ss, tok, ',')) { const string t = deck_trim(tok); if(!t.empty()) out.push_back((float)atof(t.c_str())); }
+	};
+	auto parse_pair = [](const string& r, float& a, float& b) { const size_t lb = r.find('['), rb = r.find(']', lb); if(lb==string::npos||rb==string::npos) return; std::stringstream ss(r.substr(lb+1u, rb-lb-1u)); string tok; int i = 0; while(std::getline(ss, tok, ',')) { const float v = (float)atof(deck_trim(tok).c_str()); if(i==0) a = v; else if(i==1) b = v; i++; } };
+	for(const auto& e : deck) { // FX/setup.cpp:2911-3308 (solver-consumed keys of the supported modes)
+		const string& key = e.first; const string& val = e.second; const string uq = deck_unquote(val); bool pb = false;
+		if(key=="casename") c.caseName = uq;
+		else if(key=="datetime") c.datetime = uq;
+		else if(key=="downstream_open_face") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.downstream_open_face = pb; }
+		else if(key=="base_height") { if(!uq.empty()) c.z_si_offset = (float)atof(val.c_str()); }
+		else if(key=="memory_lbm") { if(!uq.empty()) c.memory = (uint)atoi(val.c_str()); }
+		else if(key=="si_x_cfd") { if(!uq.empty()) c.si_x = second_val(val); }
+		else if(key=="si_y_cfd") { if(!uq.empty()) c.si_y = second_val(val); }
+		else if(key=="si_z_cfd") { if(!uq.empty()) c.si_z = second_val(val); }
+		else if(key=="enable_buffer_nudging") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.enable_buffer_nudging = pb; }
+		else if(key=="buffer_thickness_m") { if(!uq.empty()) c.buffer_thickness_m = (float)atof(uq.c_str()); }
+		else if(key=="buffer_tau_s") { if(!uq.empty()) c.buffer_tau_s = (float)atof(uq.c_str()); }
+		else if(key=="buffer_nudge_vertical") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.buffer_nudge_vertical = pb ? 1 : 0; }
+		else if(key=="enable_top_sponge") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.enable_top_sponge = pb; }
+		else if(key=="sponge_thickness_m") { if(!uq.empty()) c.sponge_thickness_m = (float)atof(uq.c_str()); }
+		else if(key=="sponge_tau_s") { if(!uq.empty()) c.sponge_tau_s = (float)atof(uq.c_str()); }
+		else if(key=="sponge_ref_mode") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::tolower); c.sponge_ref_mode = (v=="0"||v=="mode0"||v=="mode_0") ? 0 : (v=="1"||v=="mode1"||v=="mode_1"||v=="geostrophic") ? 1 : atoi(v.c_str()); }
+		else if(key=="mesh_control") mesh_control = uq;
+		else if(key=="gpu_memory") gpu_memory_val = uq;
+		else if(key=="cell_size") cell_size_val = uq;
+		else if(key=="n_gpu") { if(!uq.empty()) { const size_t lb = val.find('['), rb = val.find(']', lb); if(lb!=string::npos&&rb!=string::npos) { std::stringstream ss(val.substr(lb+1u, rb-lb-1u)); string tok; uint v[3] = {c.Dx, c.Dy, c.Dz}; int i = 0; while(std::getline(ss, tok, ',')&&i<3) v[i++] = (uint)atoi(deck_trim(tok).c_str()); if(i==3) { c.Dx = v[0]; c.Dy = v[1]; c.Dz = v[2]; } } } }
+		else if(key=="research_output") { if(!uq.empty()) c.research_output_steps = (uint)atoi(val.c_str()); }
+		else if(key=="unsteady_output") { if(!uq.empty()) { const int v = atoi(uq.c_str()); c.unsteady_output_interval = v>0 ? (uint)v : 0u; } }
+		else if(key=="run_nstep") { if(!uq.empty()) { const long long v = atoll(uq.c_str()); c.run_nstep_override = v>0ll ? (ulong)v : 0ull; } }
+		else if(key=="purge_avg") { if(!uq.empty()) { const int v = atoi(val.c_str()); c.purge_avg_steps = v>0 ? (uint)v : 0u; } }
+		else if(key=="purge_avg_stride") { if(!uq.empty()) { const int v = atoi(uq.c_str()); c.purge_avg_stride = v>0 ? (uint)v : 1u; } }
+		else if(key=="output_tke_ti_tls") { const string lt = deck_trim(uq); const size_t lb = lt.find('['), rb = lt.find(']', lb); if(!lt.empty()&&lb!=string::npos&&rb!=string::npos&&rb>lb) { c.out_tke = c.out_ti = c.out_tls = false; std::stringstream ss(lt.substr(lb+1u, rb-lb-1u)); string tok; while(std::getline(ss, tok, ',')) { string it = deck_trim(tok); std::transform(it.begin(), it.end(), it.begin(), ::tolower); if(it=="tke") c.out_tke = true; else if(it=="ti") c.out_ti = true; else if(it=="tls") c.out_tls = true; } } }
+		else if(key=="coriolis_term") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::tolower); if(!v.empty()&&deck_try_parse_bool(v, pb)) c.enable_coriolis = pb; }
+		else if(key=="turb_inflow_enable") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_enable = pb; }
+		else if(key=="vk_inlet_nmodes") { if(!uq.empty()) c.vk_nmodes = atoi(uq.c_str()); }
+		else if(key=="cut_lon_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lon[0], c.cut_lon[1]); c.has_cut_lon = true; } }
+		else if(key=="cut_lat_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lat[0], c.cut_lat[1]); c.has_cut_lat = true; } }
+		else if(key=="inflow") { if(!uq.empty()) parse_float_list(val, c.inflow_list); }
+		else if(key=="angle") { if(!uq.empty()) parse_float_list(val, c.angle_list); }
+	}
+	if(!c.memory) c.memory = 6000u;
+	if(c.Dx==0u) c.Dx = 1u; if(c.Dy==0u) c.Dy = 1u; if(c.Dz==0u) c.Dz = 1u;
+	if(c.vk_nmodes<=0) c.vk_nmodes = 256; if(c.vk_nmodes>512) c.vk_nmodes = 512;
+	{ // mesh_control, FX/setup.cpp:3364-3390
+		bool applied = false;
+		if(mesh_control=="gpu_memory") { if(!deck_trim(gpu_memory_val).empty()) { const uint mm = (uint)atoi(deck_trim(gpu_memory_val).c_str()); if(mm>0u) { c.memory = mm; c.cell_m = fit_cell_size_to_gpu_memory_request(c, c.memory); applied = true; } } }
+		else if(mesh_control=="cell_size") { if(!deck_trim(cell_size_val).empty()) { const float cs = (float)atof(deck_trim(cell_size_val).c_str()); if(cs>0.0f&&std::isfinite(cs)) { c.cell_m = cs; applied = true; } } }
+		if(!applied) c.cell_m = 20.0f;
+	}
+	c.parent = std::filesystem::path(c.deck_path).parent_path().string();
+	if(c.parent.empty()) c.parent = ".";
+	if(c.profile_mode&&c.enable_coriolis&&!(c.has_cut_lon&&c.has_cut_lat)) { println("| WARNING: coriolis_term=true but cut_lon_manual/cut_lat_manual is missing in *.luwpf. |"); println("| WARNING: Coriolis is auto-disabled for Profile mode.                         |"); c.enable_coriolis = false; }
+	{ // console log tee, FX/setup.cpp:2502-2511
+		std::error_code ec; std::filesystem::create_directories(std::filesystem::path(c.parent)/"proj_temp", ec);
+		const string lp = (std::filesystem::path(c.parent)/"proj_temp"/(now_str("%Y%m%d%H%M%S")+"_lbm.log")).string();
+		if(!ec&&!c.dry_run) { g_log.open(lp); if(g_log.is_open()) println("| Console log     | "+lp+" |"); }
+	}
+	if(c.vk_enable) { println("| WARNING: turb_inflow_enable is on, but the von-Karman inlet (SURVEY 8f-2) is not part of this build: running WITHOUT synthetic inflow turbulence. |"); }
+	if(c.Dx*c.Dy*c.Dz>1u) println("| NOTE: n_gpu>1: this executable drives one GPU; multi-GPU runs use the torch.distributed launcher (latticeurbanwind_amd.distributed). Grid sizing still honours n_gpu. |");
+
+	println("|"+string(CONSOLE_WIDTH-2u, ' ')+"|");
+	print_section_title("PARAMETER INFORMATION");
+	println("| Configure deck  | "+alignr(57u, c.deck_path)+" |");
+	println("| Casename / Time | "+alignr(40u, c.caseName)+alignr(17u, c.datetime)+" |");
+	println("| Basement Height | "+alignr(55u, fmtf(c.z_si_offset))+" m |");
+	println("| SI Size (m)     | "+alignr(12u, " X:")+alignl(11u, fmtf(c.si_x))+"   Y: "+alignl(11u, fmtf(c.si_y))+"   Z: "+alignl(11u, fmtf(c.si_z))+" | ");
+	println("| GPU Decompose   | "+alignr(49u, to_string_u(c.Dx))+", "+alignr(2u, to_string_u(c.Dy))+", "+alignr(2u, to_string_u(c.Dz))+" |");
+	println("| Run Steps       | "+alignr(57u, c.run_nstep_override>0ull ? to_string_u(c.run_nstep_override)+" (run_nstep)" : string("20001 (default)"))+" |");
+	println("| DDF storage     | "+alignr(57u, c.fp16c ? string("FP16C (as the shipped reference build)") : string("FP32"))+" |");
+
+	const float lbm_ref_u = 0.10f; float si_ref_u = 10.0f; const float si_nu = 1.48E-5f, si_rho = 1.225f;
+	const uint Nx = (uint)std::max(1, (int)(c.si_x/c.cell_m+0.5f)), Ny = (uint)std::max(1, (int)(c.si_y/c.cell_m+0.5f));
+	const int sponge_cells_cfg = std::max(1, (int)std::lround(c.sponge_thickness_m/c.cell_m));
+	const uint Nz_core = (uint)std::max(1, (int)(c.si_z/c.cell_m+0.5f));
+	const bool top_sponge_grid_extend = c.enable_top_sponge&&c.sponge_tau_s>0.0f&&c.sponge_ref_mode==0&&Nz_core>2u;
+	const uint Nz = Nz_core+(top_sponge_grid_extend ? (uint)sponge_cells_cfg : 0u);
+	const int side_ref_z_cap = top_sponge_grid_extend ? (int)Nz_core-1 : -1;
+	print_section_title("DOMAIN AND TRANSFORMATION");
+	println("| Grid Resolution | "+alignr(45u, to_string_u(Nx))+","+alignr(5u, to_string_u(Ny))+","+alignr(5u, to_string_u(Nz))+" (nCell = "+to_string_u((ulong)Nx*Ny*Nz)+") |");
+	if(top_sponge_grid_extend) println("| Top sponge grid | "+alignr(57u, "core Nz="+to_string_u(Nz_core)+", ext="+to_string_u((ulong)sponge_cells_cfg)+", total Nz="+to_string_u(Nz))+" |");
+	{
+		const uint core = vram_required_mb_per_device(Nx, Ny, Nz, c.Dx, c.Dy, c.Dz), extra = vk_extra_mb(c, Nx, Ny, Nz);
+		if(extra>0u) println("| GPU Estimate    | "+alignr(57u, to_string_u(c.Dx*c.Dy*c.Dz)+"x "+to_string_u(core+extra)+" MB (core "+to_string_u(core)+" + extra "+to_string_u(extra)+")")+" |");
+		else println("| GPU Estimate    | "+alignr(57u, to_string_u(c.Dx*c.Dy*c.Dz)+"x "+to_string_u(core)+" MB")+" |");
+	}
+	std::vector<float> prof_z, prof_u;
+	if(c.dataset_mode) {
+		if(c.inflow_list.empty()) fatal("| ERROR: dataset generation requires inflow list (inflow=[...]).              |");
+		if(c.angle_list.empty()) fatal("| ERROR: dataset generation requires angle list (angle=[...]).                |");
+		si_ref_u = *std::max_element(c.inflow_list.begin(), c.inflow_list.end());
+	} else { // FX/setup.cpp:3660-3729
+		if(c.angle_list.empty()) fatal("| ERROR: profile forcing requires angle list (angle=[...]).                   |");
+		const float agl = c.si_z-c.z_si_offset;
+		if(agl<=0.0f) fatal("| ERROR: invalid profile domain height. Check si_z_cfd/base_height.           |");
+		auto smp = read_profile_dat(c.parent+"/wind_bc/profile.dat");
+		if(smp.empty()) fatal("| ERROR: no profile samples found. Aborting...                                |");
+		std::sort(smp.begin(), smp.end(), [](const auto& a, const auto& b) { return a.first<b.first; });
+		for(const auto& s : smp) { if(!prof_z.empty()&&std::fabs(s.first-prof_z.back())<1e-6f) { prof_u.back() = s.second; continue; } prof_z.push_back(s.first); prof_u.push_back(s.second); }
+		if(prof_z.size()<2u) fatal("| ERROR: profile.dat needs at least two valid samples. Aborting...            |");
+		if(agl>1.0f&&prof_z.back()<=1.5f) { for(float& z : prof_z) z *= agl; println("| Profile z unit  | normalized -> scaled by domain AGL height                 |"); }
+		float max_u = 0.0f; for(const float v : prof_u) if(v>max_u) max_u = v;
+		if(max_u<=0.0f) fatal("| ERROR: profile.dat has non-positive max U. Aborting...                      |");
+		si_ref_u = max_u;
+		println("| Profile samples | "+alignr(57u, to_string_u(prof_z.size()))+" |");
+		println("| Profile z range | "+alignr(24u, fmtf(prof_z.front()))+" to "+alignl(16u, fmtf(prof_z.back()))+" m |");
+		println("| Profile domain  | "+alignr(57u, fmtf(agl))+" m AGL |");
+	}
+	Units units;
+	units.set_m_kg_s_K((float)Ny, lbm_ref_u, 1.0f, 1.0f, c.si_y, si_ref_u, si_rho, 293.15f);
+	println("| Info: Unit Conversion: 1 cell = "+to_string_fd(1000.0f*units.si_x(1.0f), 3u)+" mm, 1 s = "+to_string_u(units.t(1.0f))+" time steps");
+	float u_scale = lbm_ref_u/si_ref_u;
+	float lbm_nu = units.nu(si_nu);
+	float omega[3] = {0.0f, 0.0f, 0.0f};
+	auto update_coriolis = [&]() { // FX/setup.cpp:3800-3823
+		if(!c.enable_coriolis) return;
+		const float lat = 0.5f*(c.cut_lat[0]+c.cut_lat[1]);
+		const float Om = 7.292115e-5f, deg2rad = 3.14159265358979323846f/180.0f, lat_rad = lat*deg2rad;
+		const float dt_si = c.cell_m*(lbm_ref_u/si_ref_u);
+		omega[0] = 0.0f*dt_si; omega[1] = Om*cosf(lat_rad)*dt_si; omega[2] = Om*sinf(lat_rad)*dt_si;
+	};
+	SolverGlobals& G = solver_globals();
+	G.fp16c = c.fp16c; G.device = c.device;
+	auto buffer_face_id_from_bc = [](const string& bc) { return bc=="-x" ? 1 : bc=="+x" ? 2 : bc=="-y" ? 3 : bc=="+y" ? 4 : 0; };
+	auto bc_from_dir = [](const float dx, const float dy) -> string { if(fabsf(dx)>=fabsf(dy)) return dx>=0.0f ? "+x" : "-x"; return dy>=0.0f ? "+y" : "-y"; };
+	auto update_buffer_nudging = [&](const string& bc) { // FX/setup.cpp:3844-3856
+		G.buffer_downstream_face_id = buffer_face_id_from_bc(bc);
+		const uint min_dim = std::min(Nx, std::min(Ny, Nz)), max_nbuf = std::max(1u, min_dim/4u);
+		int nbuf = (int)std::lround(c.buffer_thickness_m/c.cell_m);
+		if(nbuf<1) nbuf = 1; if((uint)nbuf>max_nbuf) nbuf = (int)max_nbuf;
+		G.buffer_n_cells = nbuf;
+		const float dt_si = c.cell_m*(lbm_ref_u/si_ref_u);
+		G.buffer_inv_tau_lbmu = c.buffer_tau_s>0.0f ? dt_si/c.buffer_tau_s : 0.0f;
+		G.buffer_nudging_active = c.enable_buffer_nudging&&c.buffer_tau_s>0.0f;
+		G.buffer_nudge_vertical = c.buffer_nudge_vertical;
+	};
+	auto update_top_sponge = [&]() { // FX/setup.cpp:3867-3881
+		int ns = std::max(sponge_cells_cfg, 1);
+		if(Nz>2u) ns = std::min(ns, (int)Nz-2);
+		G.sponge_n_cells = ns;
+		const float dt_si = c.cell_m*(lbm_ref_u/si_ref_u);
+		G.sponge_inv_tau_lbmu = c.sponge_tau_s>0.0f ? dt_si/c.sponge_tau_s : 0.0f;
+		G.top_sponge_active = top_sponge_grid_extend&&c.sponge_tau_s>0.0f&&c.sponge_ref_mode==0&&Nz_core>2u;
+	};
+	update_coriolis(); update_buffer_nudging("+y"); update_top_sponge();
+	print_kv_row("Buffer nudging", G.buffer_nudging_active ? "enabled (downstream face auto by angle)" : "disabled");
+	print_kv_row("", "Nbuf="+to_string_u((ulong)G.buffer_n_cells)+" cells, tau_s="+to_string_fd(c.buffer_tau_s, 6u)+" s");
+	print_kv_row("", "inv_tau_lbmu="+to_string_fd(G.buffer_inv_tau_lbmu, 8u)+", downstream_face_id=auto, nudge_vertical="+to_string_u((ulong)G.buffer_nudge_vertical));
+	print_kv_row("Top sponge", G.top_sponge_active ? "enabled" : "disabled");
+	print_kv_row("", "Nsponge="+to_string_u((ulong)G.sponge_n_cells)+" cells, tau_s="+to_string_fd(c.sponge_tau_s, 6u)+" s");
+	print_kv_row("", "inv_tau_lbmu="+to_string_fd(G.sponge_inv_tau_lbmu, 8u)+", ref_mode="+std::to_string(c.sponge_ref_mode));
+	if(G.top_sponge_active) print_kv_row("", "core_top_z="+to_string_u(Nz_core-1u)+", side_ref_cap_z="+std::to_string(side_ref_z_cap));
+
+	if(c.sizing_only) { println(hr_plain()); return 0; }
+	// ---- geometry, FX/setup.cpp:4001-4093
+	print_section_title("LOADING GEOMETRY AND VOXELIZE");
+	string stl_path;
+	{
+		const std::filesystem::path dir = std::filesystem::path(c.parent)/"proj_temp";
+		if(!std::filesystem::exists(dir)) fatal("ERROR: directory not found: "+dir.string());
+		std::vector<string> names;
+		for(const auto& e : std::filesystem::directory_iterator(dir)) if(e.is_regular_file()) names.push_back(e.path().filename().string());
+		std::sort(names.begin(), names.end());
+		auto ends = [](const string& s, const string& suf) { return s.size()>=suf.size()&&s.substr(s.size()-suf.size())==suf; };
+		const string a = c.caseName+"_DEM_PF.stl", b = c.caseName+"_DG.stl";
+		if(c.profile_mode&&std::filesystem::is_regular_file(dir/a)) stl_path = (dir/a).string();
+		else if(std::filesystem::is_regular_file(dir/b)) stl_path = (dir/b).string();
+		else {
+			std::vector<string> order; if(c.profile_mode) order.push_back("_DEM_PF.stl"); order.push_back("_DG.stl"); order.push_back(".stl");
+			for(const string& suf : order) { for(const string& n : names) if(ends(n, suf)) { stl_path = (dir/n).string(); break; } if(!stl_path.empty()) break; }
+		}
+		if(stl_path.empty()) fatal("ERROR: no STL file under "+dir.string());
+	}
+	Mesh mesh;
+	if(!read_stl(stl_path, mesh)) fatal("ERROR: failed to load STL");
+	println("| Info: Loading \""+stl_path+"\" with "+to_string_u(mesh.n)+" triangles.");
+	const float stl_min[3] = {mesh.pmin[0], mesh.pmin[1], mesh.pmin[2]}, stl_max[3] = {mesh.pmax[0], mesh.pmax[1], mesh.pmax[2]};
+	float vtk_origin_shift[3];
+	{ const uint NN[3] = {Nx, Ny, Nz}; for(int k=0; k<3; k++) vtk_origin_shift[k] = stl_min[k]-units.si_x(0.5f-0.5f*(float)NN[k]); }
+	const float scale_geom = units.x(c.si_x)/(stl_max[0]-stl_min[0]);
+	mesh_scale_translate(mesh, scale_geom);
+	print_kv_row("Geometry STL", stl_path);
+	print_kv_row("STL bounds SI", "x=["+to_string_fd(stl_min[0], 3u)+", "+to_string_fd(stl_max[0], 3u)+"], y=["+to_string_fd(stl_min[1], 3u)+", "+to_string_fd(stl_max[1], 3u)+"], z=["+to_string_fd(stl_min[2], 3u)+", "+to_string_fd(stl_max[2], 3u)+"]");
+	print_kv_row("Geometry", "scaled by "+to_string_fd(scale_geom, 4u)+", ready for voxelization");
+	if(c.profile_mode&&std::filesystem::exists(c.parent+"/proj_temp/interpolated_dem.csv")) println("| WARNING: interpolated_dem.csv found, but the DEM ground plane is not part of this build: flat ground at base_height is used. |");
+	else if(c.profile_mode) print_kv_row("Terrain DEM", "interpolated_dem.csv not found or empty, fallback to flat ground");
+
+	// ---- profile table, FX/setup.cpp:5777-5912
+	const float origin_z = 0.5f-0.5f*(float)Nz;
+	const float flat_ground = origin_z+units.x(c.z_si_offset);
+	std::vector<float> prof_lbmu;
+	const float profile_dz = 0.1f;
+	if(c.profile_mode) {
+		const float solver_top_si = units.si_x((float)(Nz-1u));
+		const float core_top_si = side_ref_z_cap>=0 ? units.si_x((float)side_ref_z_cap) : solver_top_si;
+		float ground_min_si = units.si_x(flat_ground-origin_z);
+		if(!std::isfinite(ground_min_si)) ground_min_si = c.z_si_offset;
+		float table_top = solver_top_si-ground_min_si;
+		if(!std::isfinite(table_top)||table_top<=0.0f) table_top = std::max(profile_dz, c.si_z-ground_min_si);
+		table_top = std::max(table_top, profile_dz);
+		const uint steps = (uint)std::ceil(table_top/profile_dz);
+		float umin = 0.0f, umax = 0.0f;
+		prof_lbmu.assign(steps+1u, 0.0f);
+		for(uint i=0u; i<=steps; ++i) {
+			const float zq = std::min(table_top, (float)i*profile_dz);
+			float v = interpolate_profile_cubic(prof_z, prof_u, zq);
+			if(v<0.0f) v = 0.0f;
+			if(i==0u) umin = umax = v; umin = std::min(umin, v); umax = std::max(umax, v);
+			prof_lbmu[i] = v*u_scale;
+		}
+		println("| Profile table   | local-terrain AGL top="+to_string_fd(table_top, 3u)+" m, core_top="+to_string_fd(core_top_si, 3u)+" m, solver_top="+to_string_fd(solver_top_si, 3u)+" m |");
+		println("| Profile ground  | z(SI) min/max="+to_string_fd(ground_min_si, 3u)+" / "+to_string_fd(ground_min_si, 3u)+" m |");
+		println("| Profile U range | "+alignr(24u, fmtf(umin))+" to "+alignl(16u, fmtf(umax))+" m/s |");
+	}
+	auto profile_speed = [&](const float pos_z, const float ground_z) -> float { // FX/setup.cpp:5901-5912
+		if(pos_z<=ground_z) return 0.0f;
+		const float inv_dz = 1.0f/profile_dz;
+		const uint last = (uint)(prof_lbmu.size()-1u);
+		float z_agl = units.si_x(pos_z-ground_z);
+		if(z_agl<0.0f) z_agl = 0.0f;
+		long idx = std::lround(z_agl*inv_dz);
+		if(idx<0l) idx = 0l;
+		return prof_lbmu[std::min((uint)idx, last)];
+	};
+	auto pos_z_of = [&](const uint z) { return (float)z-0.5f*(float)Nz+0.5f; };
+
+	// ---- cases
+	struct Case { float inflow_si, angle_deg; };
+	std::vector<Case> cases;
+	if(c.dataset_mode) { for(const float in : c.inflow_list) for(const float an : c.angle_list) cases.push_back({in, an}); }
+	else for(const float an : c.angle_list) cases.push_back({0.0f, an});
+	const ulong N = (ulong)Nx*Ny*Nz;
+	uint case_index = 0u;
+	for(const Case& cs : cases) {
+		++case_index;
+		const float deg2rad = 3.14159265358979323846f/180.0f, angle_rad = cs.angle_deg*deg2rad;
+		float dir_x = -sinf(angle_rad), dir_y = -cosf(angle_rad);
+		float uin[3] = {0.0f, 0.0f, 0.0f};
+		string vtk_prefix;
+		if(c.dataset_mode) { // FX/setup.cpp:5690-5740
+			si_ref_u = cs.inflow_si; u_scale = lbm_ref_u/si_ref_u;
+			units.set_m_kg_s_K((float)Ny, lbm_ref_u, 1.0f, 1.0f, c.si_y, si_ref_u, si_rho, 293.15f);
+			lbm_nu = units.nu(si_nu);
+			update_coriolis();
+			const float speed = cs.inflow_si*u_scale;
+			uin[0] = -sinf(angle_rad)*speed; uin[1] = -cosf(angle_rad)*speed;
+			dir_x = uin[0]; dir_y = uin[1];
+			vtk_prefix = "DG_"+format_tag(cs.inflow_si)+"_"+format_tag(cs.angle_deg)+"_";
+			println("|-----------------------------------------------------------------------------|");
+			println("| Dataset case    | "+alignr(57u, to_string_u(case_index)+"/"+to_string_u(cases.size()))+" |");
+			println("| Inflow / Angle  | "+alignr(57u, format_tag(cs.inflow_si)+" m/s, "+format_tag(cs.angle_deg)+" deg")+" |");
+		} else {
+			vtk_prefix = cases.size()==1u ? string("") : "ANG_"+format_tag(cs.angle_deg)+"_";
+			println("|-----------------------------------------------------------------------------|");
+			println("| Profile case    | "+alignr(57u, to_string_u(case_index)+"/"+to_string_u(cases.size())+" (remaining "+to_string_u(cases.size()-case_index)+")")+" |");
+			println("| Angle           | "+alignr(57u, format_tag(cs.angle_deg)+" deg")+" |");
+		}
+		println("| SI Reference U  | "+alignr(57u, format_tag(si_ref_u)+" m/s")+" |");
+		const string case_bc = bc_from_dir(dir_x, dir_y);
+		print_section_title("DEVICE INFORMATION");
+		print_kv_row("Downstream BC", case_bc+(c.dataset_mode ? " (auto from batch angle)" : " (auto from profile angle)"));
+		update_buffer_nudging(case_bc); update_top_sponge();
+
+		// host state of this case
+		std::vector<uchar> flags(N, 0u); std::vector<float> u(3ull*N, 0.0f);
+		const ulong nvox = voxelize_z(mesh, Nx, Ny, Nz, flags);
+		println("| Info: Voxelized cells (whole domain global, no halos): solid = "+to_string_u(nvox)+", fluid = "+to_string_u(N-nvox)+", total = "+to_string_u(N)+".");
+		println("| Voxelization done.                                                          |");
+		print_section_title("BUILD BOUNDARY CONDITIONS");
+		auto is_downstream = [&](const uint x, const uint y) { return case_bc=="+y" ? y==Ny-1u : case_bc=="-y" ? y==0u : case_bc=="+x" ? x==Nx-1u : case_bc=="-x" ? x==0u : false; };
+		std::atomic<ulong> mapped{0ull}, terrain_solid{0ull}, outlet{0ull};
+		if(c.profile_mode) { // FX/setup.cpp:5914-5995
+			parallel_for(N, [&](const ulong n) {
+				const uint z = (uint)(n/((ulong)Nx*Ny));
+				if((flags[n]&TYPE_S)!=0u) return;
+				const float um = profile_speed(pos_z_of(z), flat_ground);
+				u[n] = dir_x*um; u[N+n] = dir_y*um; u[2ull*N+n] = 0.0f;
+			});
+			parallel_for(N, [&](const ulong n) {
+				const ulong t = n%((ulong)Nx*Ny); const uint x = (uint)(t%Nx), y = (uint)(t/Nx), z = (uint)(n/((ulong)Nx*Ny));
+				if(z==0u) { flags[n] = TYPE_S; u[n] = u[N+n] = u[2ull*N+n] = 0.0f; return; }
+				if(!(x==0u||x==Nx-1u||y==0u||y==Ny-1u||z==Nz-1u)) return;
+				if((flags[n]&TYPE_S)!=0u) return;
+				const float pz = pos_z_of(z);
+				if(pz<=flat_ground) { flags[n] = TYPE_S; u[n] = u[N+n] = u[2ull*N+n] = 0.0f; terrain_solid++; return; }
+				flags[n] = (uchar)(flags[n]|TYPE_E);
+				if(c.downstream_open_face&&is_downstream(x, y)) { outlet++; return; }
+				float pze = pz;
+				const bool side = x==0u||x==Nx-1u||y==0u||y==Ny-1u;
+				if(side&&side_ref_z_cap>=0&&(int)z>side_ref_z_cap) pze = pos_z_of((uint)side_ref_z_cap);
+				const float um = profile_speed(pze, flat_ground);
+				u[n] = dir_x*um; u[N+n] = dir_y*um; u[2ull*N+n] = 0.0f;
+				mapped++;
+			});
+			println("| Velocity BC     | profile boundaries mapped: "+to_string_u(mapped.load())+" cells                |");
+			if(outlet.load()>0ull) println("|                 | downstream outlet cells: "+to_string_u(outlet.load())+" (no fixed velocity)        |");
+			if(terrain_solid.load()>0ull) println("|                 | boundary cells below local terrain -> solid: "+to_string_u(terrain_solid.load())+"                     |");
+		} else { // FX/setup.cpp:5655-5688
+			for(ulong n=0ull; n<N; n++) { u[n] = uin[0]; u[N+n] = uin[1]; u[2ull*N+n] = uin[2]; }
+			const bool has_ground = Nz>1u;
+			for(ulong n=0ull; n<N; n++) {
+				const ulong t = n%((ulong)Nx*Ny); const uint x = (uint)(t%Nx), y = (uint)(t/Nx), z = (uint)(n/((ulong)Nx*Ny));
+				if(has_ground&&z==0u) { flags[n] = TYPE_S; continue; }
+				if(x==0u||x==Nx-1u||y==0u||y==Ny-1u||(has_ground&&z==Nz-1u)) {
+					flags[n] = TYPE_E;
+					if(c.downstream_open_face&&is_downstream(x, y)) continue;
+					u[n] = uin[0]; u[N+n] = uin[1]; u[2ull*N+n] = uin[2];
+				}
+			}
+		}
+		print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
+		if(!c.dump_setup.empty()&&case_index==1u) { // raw initial state for tests: header (Nx,Ny,Nz,Nz_core as u32; nu, si_u_factor, si_rho_factor as f32) + flags + u + rho(=1)
+			std::ofstream df(c.dump_setup, std::ios::binary);
+			const uint hdr[4] = {Nx, Ny, Nz, Nz_core}; const float fh[8] = {lbm_nu, units.si_u(1.0f), units.si_rho(1.0f), G.buffer_inv_tau_lbmu, G.sponge_inv_tau_lbmu, scale_geom, omega[1], omega[2]};
+			const int ih[8] = {G.buffer_nudging_active, G.buffer_n_cells, G.buffer_downstream_face_id, G.buffer_nudge_vertical, G.top_sponge_active, G.sponge_n_cells, (int)nvox, (int)mapped.load()};
+			df.write((const char*)hdr, 16); df.write((const char*)fh, 32); df.write((const char*)ih, 32);
+			df.write((const char*)flags.data(), (std::streamsize)N); df.write((const char*)u.data(), (std::streamsize)(12ull*N));
+		}
+		if(c.dry_run) continue;
+
+		// ---- run_lbm, FX/setup.cpp:4117-4911
+		LBM lbm(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f);
+		lbm.set_coriolis(omega[0], omega[1], omega[2]);
+		std::memcpy(lbm.flags.host, flags.data(), N); std::memcpy(lbm.u.host, u.data(), 12ull*N); // rho mirror is pre-filled with 1.0f
+		print_section_title("LBM SOLVER INFORMATION");
+		const ulong total_steps = (c.run_nstep_override>0ull ? c.run_nstep_override : 20001ull)+(ulong)c.research_output_steps;
+		const ulong unsteady = (ulong)c.unsteady_output_interval;
+		const string results_vtk_dir = c.parent+"/RESULTS/vtk/";
+		const string vtk_dir = results_vtk_dir+vtk_prefix+c.datetime+"_raw_";
+		const uint Nz_out = (top_sponge_grid_extend&&Nz_core<Nz) ? Nz_core : Nz;
+		VtkGeom geom{Nx, Ny, Nz, Nz_out, units.si_x(1.0f), {0, 0, 0}};
+		{ const uint NN[3] = {Nx, Ny, Nz}; for(int k=0; k<3; k++) geom.origin[k] = geom.spacing*(0.5f-0.5f*(float)NN[k])+vtk_origin_shift[k]; }
+		if(Nz_out<Nz) print_kv_row("VTK z output", "core Nz="+to_string_u(Nz_out)+" of solver Nz="+to_string_u(Nz)+" (top sponge omitted)");
+		print_kv_row("Run steps", to_string_u(total_steps)+(c.run_nstep_override>0ull ? " (run_nstep override)" : " (default)"));
+		const ulong avg_window = c.purge_avg_steps>0u ? std::min((ulong)c.purge_avg_steps, total_steps) : 0ull;
+		const ulong avg_stride = std::max((ulong)1u, (ulong)c.purge_avg_stride);
+		const ulong avg_start_t = avg_window>0ull ? total_steps-avg_window+1ull : ~0ull;
+		if(avg_window>0ull) { print_kv_row("Avg stride", "sample every "+to_string_u(avg_stride)+" step(s) in purge_avg window (on-device accumulation)"); luw_check(luw_stats_reset(lbm.handle())); }
+		lbm.run(0u, total_steps);
+		print_section_title("SOLVER START");
+		const auto t_start = std::chrono::steady_clock::now();
+		ulong last_u_vtk_t = ~0ull;
+		while(lbm.get_t()<total_steps) {
+			// advance to the next step at which something must be observed (sample / unsteady output / end); fields are
+			// written by the last step of each run() call
+			ulong next = total_steps;
+			if(unsteady>0ull) next = std::min(next, (ulong)((lbm.get_t()/unsteady+1ull)*unsteady));
+			if(avg_window>0ull) { const ulong t1 = lbm.get_t()+1ull; ulong s = std::max(t1, avg_start_t); const ulong off = (s-avg_start_t)%avg_stride; if(off!=0ull) s += avg_stride-off; if(s<=total_steps) next = std::min(next, s); }
+			lbm.run(next-lbm.get_t(), total_steps);
+			const ulong t = lbm.get_t();
+			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); last_u_vtk_t = t; }
+			if(avg_window>0ull&&t>=avg_start_t&&(t-avg_start_t)%avg_stride==0ull) luw_check(luw_stats_accumulate(lbm.handle()));
+		}
+		luw_check(luw_finish(lbm.handle()));
+		const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
+		print_kv_row("Solver", to_string_u(total_steps)+" steps in "+to_string_fd((float)secs, 3u)+" s = "+to_string_fd((float)((double)N*(double)total_steps/secs*1e-6), 1u)+" MLUPs");
+		{ // write_final_transient, FX/setup.cpp:4762-4776
+			const ulong t = lbm.get_t();
+			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); }
+			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); print_kv_row("", fr+" saved");
+		}
+		if(avg_window>0ull) { // finalize_avg + write_avg_vtk, FX/setup.cpp:4693-4717,2513-2683
+			std::vector<float> avg_u(3ull*N), avg_rho(N), m2u(N), m2v(N), m2w(N); uint64_t avg_count = 0ull;
+			luw_check(luw_stats_download(lbm.handle(), avg_u.data(), avg_rho.data(), m2u.data(), m2v.data(), m2w.data(), &avg_count));
+			if(avg_count>0ull) {
+				const string fn = default_filename(results_vtk_dir, vtk_prefix+c.datetime+"_avg", lbm.get_t());
+				std::filesystem::create_directories(std::filesystem::path(fn).parent_path());
+				std::ofstream file(fn, std::ios::out|std::ios::binary);
+				const string header = vtk_header(fn, geom); file.write(header.c_str(), (std::streamsize)header.length());
+				const ulong points = (ulong)Nx*Ny*Nz_out;
+				const float u_factor = units.si_u(1.0f), rho_factor = units.si_rho(1.0f), spacing = geom.spacing;
+				auto write_field = [&](const string& name, const float* data, const uint comps, const float factor) {
+					const string fh = "SCALARS "+name+" float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n"; file.write(fh.c_str(), (std::streamsize)fh.length());
+					std::vector<float> buf(points*comps);
+					parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(data[i*comps+d]*factor+0.0f); });
+					file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
+				};
+				write_field("u_avg", avg_u.data(), 3u, u_factor);
+				write_field("rho_avg", avg_rho.data(), 1u, rho_factor);
+				std::vector<float> fluid(points, 1.0f), tke, ti, tls;
+				if(c.out_tke) tke.assign(points, 0.0f); if(c.out_ti) ti.assign(points, 0.0f); if(c.out_tls) tls.assign(points, 0.0f);
+				const bool has_m2 = avg_count>1ull; const float inv_n = has_m2 ? 1.0f/(float)avg_count : 0.0f;
+				const float grid_dx = fmaxf(spacing, 1.0e-12f); const ulong plane = (ulong)Nx*Ny;
+				const float tls_cap = (float)std::max(std::max(Nx, Ny), Nz_out)*grid_dx;
+				const uchar* fl = lbm.flags.data<uchar>();
+				auto su = [&](const ulong idx, const uint comp) { return avg_u[3ull*idx+comp]*u_factor; };
+				parallel_for(points, [&](const ulong n) {
+					const bool solid = (fl[n]&TYPE_S)!=0u;
+					fluid[n] = solid ? 0.0f : 1.0f;
+					if(!has_m2||solid) return;
+					if(!(c.out_tke||c.out_ti||c.out_tls)) return;
+					const float var_u = fmaxf(m2u[n]*inv_n, 0.0f), var_v = fmaxf(m2v[n]*inv_n, 0.0f), var_w = fmaxf(m2w[n]*inv_n, 0.0f), var_sum = var_u+var_v+var_w;
+					if(c.out_tke) tke[n] = 0.5f*var_sum;
+					if(c.out_ti) { const ulong i3 = 3ull*n; const float umag = sqrtf(avg_u[i3]*avg_u[i3]+avg_u[i3+1ull]*avg_u[i3+1ull]+avg_u[i3+2ull]*avg_u[i3+2ull]); if(umag>1.0e-9f&&var_sum>0.0f) ti[n] = sqrtf(var_sum*(1.0f/3.0f))/umag; }
+					if(!c.out_tls) return;
+					const ulong z = n/plane, rem = n-z*plane, y = rem/Nx, x = rem-y*Nx;
+					const ulong xm = x>0ull ? x-1ull : x, xp = x+1ull<Nx ? x+1ull : x, ym = y>0ull ? y-1ull : y, yp = y+1ull<Ny ? y+1ull : y, zm = z>0ull ? z-1ull : z, zp = z+1ull<Nz_out ? z+1ull : z;
+					const ulong ixm = xm+(y+z*Ny)*Nx, ixp = xp+(y+z*Ny)*Nx, iym = x+(ym+z*Ny)*Nx, iyp = x+(yp+z*Ny)*Nx, izm = x+(y+zm*Ny)*Nx, izp = x+(y+zp*Ny)*Nx;
+					const float idx_ = xp>xm ? 1.0f/((float)(xp-xm)*grid_dx) : 0.0f, idy = yp>ym ? 1.0f/((float)(yp-ym)*grid_dx) : 0.0f, idz = zp>zm ? 1.0f/((float)(zp-zm)*grid_dx) : 0.0f;
+					const float duxdx = (su(ixp, 0u)-su(ixm, 0u))*idx_, duydx = (su(ixp, 1u)-su(ixm, 1u))*idx_, duzdx = (su(ixp, 2u)-su(ixm, 2u))*idx_;
+					const float duxdy = (su(iyp, 0u)-su(iym, 0u))*idy, duydy = (su(iyp, 1u)-su(iym, 1u))*idy, duzdy = (su(iyp, 2u)-su(iym, 2u))*idy;
+					const float duxdz = (su(izp, 0u)-su(izm, 0u))*idz, duydz = (su(izp, 1u)-su(izm, 1u))*idz, duzdz = (su(izp, 2u)-su(izm, 2u))*idz;
+					const float Sxy = 0.5f*(duxdy+duydx), Sxz = 0.5f*(duxdz+duzdx), Syz = 0.5f*(duydz+duzdy);
+					const float S_mag = sqrtf(fmaxf(0.0f, 2.0f*(duxdx*duxdx+duydy*duydy+duzdz*duzdz+2.0f*(Sxy*Sxy+Sxz*Sxz+Syz*Syz))));
+					const float k_local = 0.5f*var_sum*(u_factor*u_factor);
+					const float tls_local = (S_mag>1.0e-10f&&k_local>0.0f) ? sqrtf(k_local)/S_mag : 0.0f;
+					tls[n] = fminf(fmaxf(tls_local, 0.0f), tls_cap);
+				});
+				write_field("fluid", fluid.data(), 1u, 1.0f);
+				if(c.out_tke) write_field("tke", tke.data(), 1u, u_factor*u_factor);
+				if(c.out_ti) write_field("TI", ti.data(), 1u, 1.0f);
+				if(c.out_tls) write_field("TLS", tls.data(), 1u, 1.0f);
+				print_kv_row("VTK file", fn+" saved");
+				print_kv_row("Avg samples", to_string_u(avg_count));
+			}
+		}
+		print_kv_row("Task finished", "["+now_str()+"]");
+	}
+	println(hr_plain());
+	return 0;
+}

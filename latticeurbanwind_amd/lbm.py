@@ -126,6 +126,19 @@ class LBM:
         capi.check(self._L.luw_run_timed(self._h, int(steps), C.byref(ms)))
         return ms.value
 
+    # ---- on-device time averaging (replaces FX/setup.cpp:4441-4542)
+    def stats_reset(self): capi.check(self._L.luw_stats_reset(self._h))
+    def stats_accumulate(self): capi.check(self._L.luw_stats_accumulate(self._h))
+    def stats_download(self):
+        N = self.get_N()
+        out = dict(avg_u=np.zeros(3 * N, np.float32), avg_rho=np.zeros(N, np.float32), m2_u=np.zeros(N, np.float32),
+                   m2_v=np.zeros(N, np.float32), m2_w=np.zeros(N, np.float32))
+        cnt = C.c_uint64(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        capi.check(self._L.luw_stats_download(self._h, p(out["avg_u"]), p(out["avg_rho"]), p(out["m2_u"]), p(out["m2_v"]), p(out["m2_w"]), C.byref(cnt)))
+        out["count"] = cnt.value
+        return out
+
     # ---- device-level interface (multi-GPU driver)
     def area(self, direction): return int(self._L.luw_get_area(self._h, direction))
     def set_stream(self, stream_ptr): capi.check(self._L.luw_set_stream(self._h, stream_ptr))

@@ -457,6 +457,35 @@ void luwo_transfer_insert_fi(const LuwOracleCfg* c, const uint32_t direction, co
 	}
 }
 
+/* accumulate_from_buffers, FX/setup.cpp:4441-4488: Welford mean / M2 of u (avg_u is AoS [3n+c]), running mean of rho.
+ * count is the sample number AFTER the increment (avg_count), inv_n = 1/count. */
+void luwo_accumulate_stats(const uint64_t N, const uint64_t count, const float* rho, const float* u, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w) {
+	const float inv_n = 1.0f/(float)count;
+	#pragma omp parallel for schedule(static)
+	for(int64_t nn=0; nn<(int64_t)N; nn++) {
+		const uint64_t n = (uint64_t)nn, i3 = 3ull*n;
+		const float ux = u[n], uy = u[N+n], uz = u[2ull*N+n];
+		float mean_u = avg_u[i3], mean_v = avg_u[i3+1ull], mean_w = avg_u[i3+2ull];
+		const float delta_u = ux-mean_u;
+		mean_u += delta_u*inv_n;
+		const float delta2_u = ux-mean_u;
+		m2_u[n] += delta_u*delta2_u;
+		avg_u[i3] = mean_u;
+		const float delta_v = uy-mean_v;
+		mean_v += delta_v*inv_n;
+		const float delta2_v = uy-mean_v;
+		m2_v[n] += delta_v*delta2_v;
+		avg_u[i3+1ull] = mean_v;
+		const float delta_w = uz-mean_w;
+		mean_w += delta_w*inv_n;
+		const float delta2_w = uz-mean_w;
+		m2_w[n] += delta_w*delta2_w;
+		avg_u[i3+2ull] = mean_w;
+		const float r = rho[n];
+		avg_rho[n] += (r-avg_rho[n])*inv_n;
+	}
+}
+
 /* OpenMP thread control for the cpu_baseline leg of bench.py (no-ops when built without OpenMP) */
 #ifdef _OPENMP
 #include <omp.h>

@@ -56,6 +56,7 @@ def lib():
         L.luwo_transfer_extract_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_extract_fi.restype = None
         L.luwo_transfer_insert_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_insert_fi.restype = None
         L.luwo_moments.argtypes = [cfgp, vp, u64, vp, vp]; L.luwo_moments.restype = None
+        L.luwo_accumulate_stats.argtypes = [u64, u64] + [vp] * 7; L.luwo_accumulate_stats.restype = None
         L.luwo_set_threads.argtypes = [C.c_int]; L.luwo_set_threads.restype = None
         L.luwo_get_max_threads.restype = C.c_int
         _LIB = L
@@ -148,6 +149,20 @@ class OracleLBM:
         rho = np.zeros(self.N, np.float32); u = np.zeros(3 * self.N, np.float32)
         lib().luwo_moments(C.byref(self.cfg), _p(self.fi), self.t, _p(rho), _p(u))
         return rho, u
+
+
+class OracleStats:
+    """host time averaging of the reference's run loop (FX/setup.cpp:4252-4268,4441-4488)"""
+
+    def __init__(self, N):
+        self.N = N
+        self.avg_u = np.zeros(3 * N, np.float32); self.avg_rho = np.zeros(N, np.float32)
+        self.m2_u = np.zeros(N, np.float32); self.m2_v = np.zeros(N, np.float32); self.m2_w = np.zeros(N, np.float32)
+        self.count = 0
+
+    def accumulate(self, o):
+        self.count += 1
+        lib().luwo_accumulate_stats(self.N, self.count, _p(o.rho), _p(o.u), _p(self.avg_u), _p(self.avg_rho), _p(self.m2_u), _p(self.m2_v), _p(self.m2_w))
 
 
 def set_threads(n):

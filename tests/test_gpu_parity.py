@@ -123,6 +123,29 @@ def test_deferred_field_update_equals_every_step(luw, kernel):
     check(g, o, "deferred 13")
 
 
+@pytest.mark.parametrize("size", [(24, 20, 16), (37, 9, 5)])
+def test_on_device_time_averaging_matches_host_welford(luw, size):
+    # device Welford == the reference's host accumulate_from_buffers (FX/setup.cpp:4441-4488), bit for bit
+    from oracle import oracle
+    Nx, Ny, Nz = size
+    st = synthetic_state(Nx, Ny, Nz, seed=12, shell="luw")
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-3, False, "s", st)
+    stats = oracle.OracleStats(o.N)
+    g.run(5); o.run(5)
+    g.stats_reset()
+    for _ in range(6):
+        g.run(1); o.run(1)                  # sampled steps: one step per call writes rho,u
+        g.stats_accumulate(); stats.accumulate(o)
+    d = g.stats_download()
+    assert d["count"] == 6
+    for k in ("avg_u", "avg_rho", "m2_u", "m2_v", "m2_w"):
+        assert np.array_equal(d[k], getattr(stats, k)), k
+    # sampling after a multi-step run() is allowed (its last step wrote the fields); stale fields are refused
+    g.enqueue_stream_collide((0, Nx, 0, Ny, 0, Nz), False); g.finish()
+    with pytest.raises(luw.LuwError):
+        g.stats_accumulate()
+
+
 def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
     # size-independent property at a bench-class size (the oracle would take minutes): both kernels, same bits
     from latticeurbanwind_amd import capi
