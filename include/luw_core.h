@@ -152,6 +152,18 @@ int luw_finish(luw_solver* s);                                            /* LBM
 int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_upload_fi(luw_solver* s, const void* host_src);
 
+/* von-Karman synthetic-turbulence inlet: the device half of the reference's VonKarmanInletUpdater (FX/setup.cpp:413-1149,
+ * kernel vk_inlet_apply FX/kernel.cpp:2495-2571).  The caller builds the tables like build_gpu_runtime_ does
+ * (latticeurbanwind_amd/host/vk_inlet.hpp): point_cell[P] = cell index n in the reference layout, point_face[P] = 0 west /
+ * 1 east / 2 south / 3 north / 4 top, point_data[7*P] SoA (px, py, pz, base_u.xyz, sigma), mode_data[10*5*M] SoA over the five
+ * faces (kx, ky, kz, omega, Ax, Ay, Az, phix, phiy, phiz).  Once attached, luw_run() rewrites u on those cells before every
+ * step (the run loop's pre_step_update, FX/setup.cpp:4872) with update_stride / stride_interpolation as in
+ * compute_time_params_ (FX/setup.cpp:1118-1140); callers that enqueue steps themselves call luw_vk_inlet_apply(). */
+int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face,
+                        const float* point_data, const float* mode_data, int update_stride, int stride_interpolation);
+int luw_vk_inlet_apply(luw_solver* s);
+int luw_vk_inlet_detach(luw_solver* s);
+
 /* on-device time averaging, replaces the per-sample device->host copy + host Welford update of the reference
  * (process_post_step_samples / accumulate_from_buffers, FX/setup.cpp:4441-4542): running mean of u (3 comp.) and rho,
  * M2 of the three velocity components, identical arithmetic and operation order.

@@ -515,6 +515,41 @@ template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KP
 	}
 }
 
+// ---------------------------------------------------------------- von-Karman synthetic-turbulence inlet
+// vk_inlet_apply, FX/kernel.cpp:2495-2571: u[cell] = u_base + sigma * sum_m A_m cos(k_m.p + omega_m t + phi_m) on the inlet
+// cells (TYPE_E: the collide step then relaxes them to f_eq(rho, u)).  One lane per inlet point; cosf is the same device
+// library function (ocml) the reference's OpenCL build calls.
+__global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint32_t P, const uint32_t M, const uint32_t V,
+		const uint32_t* __restrict__ point_cell, const uint8_t* __restrict__ point_face, const float* __restrict__ point_data, const float* __restrict__ mode_data, float* __restrict__ u, const size_t Np) {
+	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
+	if(i>=P) return;
+	const uint32_t n = point_cell[i];
+	const uint32_t fid = (uint32_t)(point_face[i]&0x07u);
+	const float px = point_data[i], py = point_data[(size_t)P+i], pz = point_data[2ull*P+i];
+	const float ubx = point_data[3ull*P+i], uby = point_data[4ull*P+i], ubz = point_data[5ull*P+i];
+	const float sigma = point_data[6ull*P+i];
+	if(fid>=5u||!(sigma>0.0f)) { u[n] = ubx; u[Np+n] = uby; u[2ull*Np+n] = ubz; return; }
+	const uint32_t fbase = fid*M;
+	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+	for(uint32_t m=0u; m<M; ++m) {
+		const uint32_t idx = fbase+m;
+		const float kx = mode_data[idx], ky = mode_data[(size_t)V+idx], kz = mode_data[2ull*V+idx], omega = mode_data[3ull*V+idx];
+		const float Ax = mode_data[4ull*V+idx], Ay = mode_data[5ull*V+idx], Az = mode_data[6ull*V+idx];
+		const float phix = mode_data[7ull*V+idx], phiy = mode_data[8ull*V+idx], phiz = mode_data[9ull*V+idx];
+		const float phase0 = fmaf(kx, px, fmaf(ky, py, fmaf(kz, pz, omega*t0)));
+		float vx = Ax*cosf(phase0+phix), vy = Ay*cosf(phase0+phiy), vz = Az*cosf(phase0+phiz);
+		if(use_interp!=0u) {
+			const float phase1 = fmaf(kx, px, fmaf(ky, py, fmaf(kz, pz, omega*t1)));
+			const float vx1 = Ax*cosf(phase1+phix), vy1 = Ay*cosf(phase1+phiy), vz1 = Az*cosf(phase1+phiz);
+			vx = fmaf(alpha, vx1-vx, vx); vy = fmaf(alpha, vy1-vy, vy); vz = fmaf(alpha, vz1-vz, vz);
+		}
+		qx += vx; qy += vy; qz += vz;
+	}
+	u[n] = fmaf(sigma, qx, ubx);
+	u[Np+n] = fmaf(sigma, qy, uby);
+	u[2ull*Np+n] = fmaf(sigma, qz, ubz);
+}
+
 // ---------------------------------------------------------------- on-device time averaging
 // The reference downloads u,rho at every sampled step and runs Welford's update on the host
 // (accumulate_from_buffers, FX/setup.cpp:4441-4488).  Same arithmetic, same operation order, on the device: mean and M2 of
@@ -606,6 +641,8 @@ struct luw_solver {
 	float* d_rho = nullptr; float* d_u = nullptr; uint8_t* d_flags = nullptr; float* d_F = nullptr;
 	float* d_wbuf = nullptr; float* d_sigma = nullptr;
 	float* d_avg_u = nullptr; float* d_avg_rho = nullptr; float* d_m2 = nullptr; uint64_t avg_count = 0ull;
+	uint32_t vk_P = 0u, vk_M = 0u; int vk_stride = 1; bool vk_interp = false, vk_active = false; uint64_t vk_last_t = ~0ull;
+	uint32_t* d_vk_cell = nullptr; uint8_t* d_vk_face = nullptr; float* d_vk_point = nullptr; float* d_vk_mode = nullptr;
 	float* h_rho = nullptr; float* h_u = nullptr; uint8_t* h_flags = nullptr; float* h_F = nullptr;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
@@ -698,6 +735,7 @@ void luw_destroy(luw_solver* s) {
 	(void)hipFree(s->d_fi); (void)hipFree(s->d_rho); (void)hipFree(s->d_u); (void)hipFree(s->d_flags); (void)hipFree(s->d_F);
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
 	(void)hipFree(s->d_avg_u); (void)hipFree(s->d_avg_rho); (void)hipFree(s->d_m2);
+	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
 	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F);
 	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
 	delete s;
@@ -883,6 +921,45 @@ int luw_upload_fi(luw_solver* s, const void* host_src) {
 }
 
 int luw_run(luw_solver* s, uint64_t steps);
+static int vk_apply(luw_solver* s);
+int luw_vk_inlet_detach(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_vk_inlet_detach: null solver");
+	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
+	s->d_vk_cell = nullptr; s->d_vk_face = nullptr; s->d_vk_point = nullptr; s->d_vk_mode = nullptr;
+	s->vk_active = false; s->vk_P = s->vk_M = 0u;
+	return LUW_OK;
+}
+int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, int update_stride, int stride_interpolation) {
+	if(!s||!point_cell||!point_face||!point_data||!mode_data) return fail(LUW_ERR_INVALID, "luw_vk_inlet_attach: null argument");
+	if(point_count==0ull||mode_count==0ull||point_count>=(1ull<<31)||mode_count>65536ull) return fail(LUW_ERR_INVALID, "luw_vk_inlet_attach: bad table sizes");
+	if(int e = set_device(s)) return e;
+	(void)luw_vk_inlet_detach(s);
+	std::vector<uint32_t> cell(point_count); // reference-layout cell index -> pitched device index
+	const uint64_t NxNy = (uint64_t)s->cfg.Nx*s->cfg.Ny;
+	for(uint64_t i=0ull; i<point_count; i++) {
+		const uint64_t n = point_cell[i];
+		if(n>=s->N) return fail(LUW_ERR_INVALID, "luw_vk_inlet_attach: point cell outside the lattice");
+		const uint64_t t = n%NxNy; const uint32_t x = (uint32_t)(t%s->cfg.Nx), y = (uint32_t)(t/s->cfg.Nx), z = (uint32_t)(n/NxNy);
+		cell[i] = x+(y+z*s->cfg.Ny)*s->kp.Px;
+	}
+	const size_t P = point_count, V = 5ull*mode_count;
+	if(hipMalloc((void**)&s->d_vk_cell, P*4u)!=hipSuccess||hipMalloc((void**)&s->d_vk_face, P)!=hipSuccess||hipMalloc((void**)&s->d_vk_point, 7ull*P*4u)!=hipSuccess||hipMalloc((void**)&s->d_vk_mode, 10ull*V*4u)!=hipSuccess)
+		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocation failed");
+	HIP_TRY(hipMemcpy(s->d_vk_cell, cell.data(), P*4u, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(s->d_vk_face, point_face, P, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(s->d_vk_point, point_data, 7ull*P*4u, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(s->d_vk_mode, mode_data, 10ull*V*4u, hipMemcpyHostToDevice));
+	s->vk_P = (uint32_t)P; s->vk_M = (uint32_t)mode_count; s->vk_stride = update_stride>1 ? update_stride : 1; s->vk_interp = stride_interpolation!=0;
+	s->vk_active = true; s->vk_last_t = ~0ull;
+	return LUW_OK;
+}
+int luw_vk_inlet_apply(luw_solver* s) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_vk_inlet_apply: null solver");
+	if(!s->vk_active) return fail(LUW_ERR_STATE, "luw_vk_inlet_apply: no inlet attached");
+	if(int e = set_device(s)) return e;
+	return vk_apply(s);
+}
+
 int luw_stats_reset(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_stats_reset: null solver");
 	if(int e = set_device(s)) return e;
@@ -994,6 +1071,22 @@ int luw_reset_time_step(luw_solver* s) {
 	return LUW_OK;
 }
 
+// VonKarmanInletUpdater::update + compute_time_params_ (FX/setup.cpp:538-558,1118-1140): at most once per time step
+static int vk_apply(luw_solver* s) {
+	if(!s->vk_active||s->vk_last_t==s->t) return LUW_OK;
+	s->vk_last_t = s->t;
+	const uint64_t t = s->t, stride = s->vk_stride>1 ? (uint64_t)s->vk_stride : 1ull;
+	uint32_t use_interp = 0u; float t0 = (float)t, t1 = (float)t, alpha = 0.0f;
+	if(stride>1ull) {
+		const uint64_t anchor = (t/stride)*stride;
+		if(s->vk_interp) { use_interp = 1u; t0 = (float)anchor; t1 = (float)(anchor+stride); alpha = (float)(t-anchor)/(float)stride; }
+		else { t0 = (float)anchor; t1 = t0; }
+	}
+	hipLaunchKernelGGL(k_vk_inlet_apply, dim3((s->vk_P+255u)/256u), dim3(256), 0, s->stream, use_interp, t0, t1, alpha, s->vk_P, s->vk_M, 5u*s->vk_M, s->d_vk_cell, s->d_vk_face, s->d_vk_point, s->d_vk_mode, s->d_u, (size_t)s->kp.Np);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+
 static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_run: null solver");
 	if(int e = set_device(s)) return e;
@@ -1007,6 +1100,7 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 	}
 	for(uint64_t i=0ull; i<steps; i++) {
 		const int wf = (every||i+1ull==steps) ? 1 : 0;
+		if(int e = vk_apply(s)) return e; // pre_step_update of the reference's run loop, FX/setup.cpp:4872
 		if(mean_kernel_ms) HIP_TRY(hipEventRecord(ev[2u*i], s->stream));
 		if(int e = launch_stream_collide(s, whole, wf)) return e;
 		if(mean_kernel_ms) HIP_TRY(hipEventRecord(ev[2u*i+1u], s->stream));

@@ -8,8 +8,9 @@
 //   + transform FX/setup.cpp:4070-4087, profile table :5777-5912, flags/u fill :5914-5995 (profile mode) and :5655-5688
 //   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
 // Modes: *.luwpf (profile) and *.luwdg (dataset).  Not in this build (announced on the console, never silently):
-//   *.luw NWP boundary builders, von-Karman inlet (8f-2), DEM ground plane, probes, PNG frames.
-// Differences by design: time averaging runs on the device (luw_stats_*), the voxeliser runs on the host.
+//   *.luw NWP boundary builders, DEM ground plane, probes, PNG frames.
+// Differences by design: time averaging runs on the device (luw_stats_*), the voxeliser runs on the host; the von-Karman
+// inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
 // Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
 //   --device N, --dry-run (host stage only, no GPU), --sizing-only (stop after grid / unit / buffer / sponge numbers),
 //   --dump-setup FILE (raw initial state of the first case).
@@ -30,6 +31,7 @@
 #include <vector>
 
 #include "lbm.hpp"
+#include "vk_inlet.hpp"
 
 using namespace luw_host;
 using std::string;
@@ -174,10 +176,11 @@ struct Config {
 	bool enable_coriolis = false; float cut_lon[2] = {0, 0}, cut_lat[2] = {0, 0}; bool has_cut_lon = false, has_cut_lat = false;
 	bool enable_buffer_nudging = true; float buffer_thickness_m = 160.0f, buffer_tau_s = 300.0f; int buffer_nudge_vertical = 0;
 	bool enable_top_sponge = true; float sponge_thickness_m = 200.0f, sponge_tau_s = 120.0f; int sponge_ref_mode = 0;
-	bool vk_enable = true; int vk_nmodes = 256;
+	bool vk_enable = true; int vk_nmodes = 256; float vk_ti = 0.05f, vk_sigma_si = 0.0f, vk_L_si = 100.0f; uint64_t vk_seed = 100ull; int vk_stride = 1;
+	VkUcMode vk_uc = VkUcMode::NORM_MEAN; bool vk_same = true, vk_interp = false, vk_inflow_only = false; VkFaceMode vk_face_mode = VkFaceMode::AUTO_SIDES; float vk_aniso[3] = {1.0f, 1.0f, 1.0f};
 	std::vector<float> inflow_list, angle_list;
 	// command line
-	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup;
+	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
 };
 
 // memory model of the SHIPPED reference build (D3Q19 FP16C + FORCE_FIELD + TEMPERATURE + GRAPHICS), FX/lbm.cpp:188-228:
@@ -389,6 +392,7 @@ int main(int argc, char** argv) {
 		else if(a=="--dry-run") c.dry_run = true;
 		else if(a=="--sizing-only") { c.dry_run = true; c.sizing_only = true; } // stop after the derived numbers (no lattice-sized host arrays)
 		else if(a=="--dump-setup"&&i+1<argc) c.dump_setup = argv[++i];
+		else if(a=="--dump-vk"&&i+1<argc) c.dump_vk = argv[++i];
 		else println("| WARNING: extra CLI arg ignored: "+a);
 	}
 	println(hr_plain());
@@ -444,6 +448,23 @@ int main(int argc, char** argv) {
 		else if(key=="coriolis_term") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::tolower); if(!v.empty()&&deck_try_parse_bool(v, pb)) c.enable_coriolis = pb; }
 		else if(key=="turb_inflow_enable") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_enable = pb; }
 		else if(key=="vk_inlet_nmodes") { if(!uq.empty()) c.vk_nmodes = atoi(uq.c_str()); }
+		else if(key=="vk_inlet_ti") { if(!uq.empty()) c.vk_ti = (float)atof(uq.c_str()); }
+		else if(key=="vk_inlet_sigma") { if(!uq.empty()) c.vk_sigma_si = (float)atof(uq.c_str()); }
+		else if(key=="vk_inlet_l") { if(!uq.empty()) c.vk_L_si = (float)atof(uq.c_str()); }
+		else if(key=="vk_inlet_seed") { if(!uq.empty()) { char* end = nullptr; const unsigned long long v = std::strtoull(uq.c_str(), &end, 10); if(end!=uq.c_str()) c.vk_seed = (uint64_t)v; } }
+		else if(key=="vk_inlet_update_stride") { if(!uq.empty()) c.vk_stride = atoi(uq.c_str()); }
+		else if(key=="vk_inlet_uc_mode") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::toupper); if(v=="NORM_MEAN") c.vk_uc = VkUcMode::NORM_MEAN; else if(v=="NORMAL_COMPONENT") c.vk_uc = VkUcMode::NORMAL_COMPONENT; }
+		else if(key=="vk_inlet_same_realization_all_faces") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_same = pb; }
+		else if(key=="vk_inlet_stride_interpolation") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_interp = pb; }
+		else if(key=="vk_inlet_inflow_only") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_inflow_only = pb; }
+		else if(key=="vk_inlet_face_mode") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), [](unsigned char ch) { return ch=='-' ? '_' : (char)std::toupper(ch); });
+			if(v=="AUTO"||v=="AUTO_SIDES"||v=="BY_INFLOW_ONLY"||v=="BUSINESS_DEFAULT"||v=="DEFAULT") c.vk_face_mode = VkFaceMode::AUTO_SIDES;
+			else if(v=="TARGET_INFLOW"||v=="INFLOW"||v=="TARGET"||v=="UPSTREAM_ONLY") c.vk_face_mode = VkFaceMode::TARGET_INFLOW;
+			else if(v=="EXCLUDE_DOWNSTREAM"||v=="EXCEPT_DOWNSTREAM"||v=="ALL_EXCEPT_DOWNSTREAM"||v=="NON_DOWNSTREAM") c.vk_face_mode = VkFaceMode::EXCLUDE_DOWNSTREAM;
+			else if(v=="EXCLUDE_DOWNSTREAM_SIDES"||v=="EXCEPT_DOWNSTREAM_SIDES"||v=="SIDE_EXCEPT_DOWNSTREAM"||v=="SIDES_EXCEPT_DOWNSTREAM"||v=="NON_DOWNSTREAM_SIDES"||v=="SIDE_FACES_EXCEPT_DOWNSTREAM") c.vk_face_mode = VkFaceMode::EXCLUDE_DOWNSTREAM_SIDES;
+			else if(v=="ALL_SIDES"||v=="SIDE_FACES"||v=="ALL_SIDE_FACES"||v=="SIDES_ONLY"||v=="ALL_SIDES_NO_TOP") c.vk_face_mode = VkFaceMode::ALL_SIDES;
+			else if(v=="ALL"||v=="ALL_SELECTED"||v=="ALL_FACES") c.vk_face_mode = VkFaceMode::ALL_SELECTED; }
+		else if(key=="vk_inlet_anisotropy") { if(!uq.empty()) { const size_t lb = uq.find('['), rb = uq.find(']', lb); const string in = (lb!=string::npos&&rb!=string::npos&&rb>lb) ? uq.substr(lb+1u, rb-lb-1u) : uq; std::stringstream ss(in); string tok; float v[3]; int i = 0; bool ok = true; while(std::getline(ss, tok, ',')&&i<3) { const string t = deck_trim(tok); char* end = nullptr; const float f = std::strtof(t.c_str(), &end); if(t.empty()||end==t.c_str()) { ok = false; break; } v[i++] = f; } if(ok&&i==3) for(int k=0; k<3; k++) c.vk_aniso[k] = (std::isfinite(v[k])&&v[k]>=0.0f) ? v[k] : 1.0f; } }
 		else if(key=="cut_lon_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lon[0], c.cut_lon[1]); c.has_cut_lon = true; } }
 		else if(key=="cut_lat_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lat[0], c.cut_lat[1]); c.has_cut_lat = true; } }
 		else if(key=="inflow") { if(!uq.empty()) parse_float_list(val, c.inflow_list); }
@@ -451,7 +472,12 @@ int main(int argc, char** argv) {
 	}
 	if(!c.memory) c.memory = 6000u;
 	if(c.Dx==0u) c.Dx = 1u; if(c.Dy==0u) c.Dy = 1u; if(c.Dz==0u) c.Dz = 1u;
+	if(c.vk_ti<0.0f) c.vk_ti = 0.0f; if(c.vk_ti>1.0f&&c.vk_ti<=100.0f) c.vk_ti *= 0.01f; // FX/setup.cpp:3315-3362
+	if(c.vk_sigma_si<0.0f) c.vk_sigma_si = 0.0f; if(c.vk_L_si<0.0f) c.vk_L_si = 0.0f;
 	if(c.vk_nmodes<=0) c.vk_nmodes = 256; if(c.vk_nmodes>512) c.vk_nmodes = 512;
+	if(c.vk_stride<=0) c.vk_stride = 1;
+	if(c.vk_enable&&!(c.vk_L_si>0.0f)) { println("| WARNING: turb_inflow_enable=true but L is invalid. VK inlet disabled.         |"); c.vk_enable = false; }
+	if(c.vk_enable&&!(c.vk_ti>0.0f||c.vk_sigma_si>0.0f)) { println("| WARNING: turb_inflow_enable=true but TI/sigma is invalid. VK inlet disabled.  |"); c.vk_enable = false; }
 	{ // mesh_control, FX/setup.cpp:3364-3390
 		bool applied = false;
 		if(mesh_control=="gpu_memory") { if(!deck_trim(gpu_memory_val).empty()) { const uint mm = (uint)atoi(deck_trim(gpu_memory_val).c_str()); if(mm>0u) { c.memory = mm; c.cell_m = fit_cell_size_to_gpu_memory_request(c, c.memory); applied = true; } } }
@@ -466,7 +492,6 @@ int main(int argc, char** argv) {
 		const string lp = (std::filesystem::path(c.parent)/"proj_temp"/(now_str("%Y%m%d%H%M%S")+"_lbm.log")).string();
 		if(!ec&&!c.dry_run) { g_log.open(lp); if(g_log.is_open()) println("| Console log     | "+lp+" |"); }
 	}
-	if(c.vk_enable) { println("| WARNING: turb_inflow_enable is on, but the von-Karman inlet (SURVEY 8f-2) is not part of this build: running WITHOUT synthetic inflow turbulence. |"); }
 	if(c.Dx*c.Dy*c.Dz>1u) println("| NOTE: n_gpu>1: this executable drives one GPU; multi-GPU runs use the torch.distributed launcher (latticeurbanwind_amd.distributed). Grid sizing still honours n_gpu. |");
 
 	println("|"+string(CONSOLE_WIDTH-2u, ' ')+"|");
@@ -719,6 +744,24 @@ int main(int argc, char** argv) {
 			}
 		}
 		print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
+		VkTables vk; bool vk_on = false;
+		if(c.vk_enable) { // make_vk_runtime_config + VonKarmanInletUpdater::initialize, FX/setup.cpp:3762-3799,417-534
+			VkRuntimeConfig vc;
+			vc.ti = c.vk_ti; vc.sigma_lbm = c.vk_sigma_si*units.unit_s/units.unit_m; vc.L_lbm = units.x(c.vk_L_si);
+			vc.nmodes = c.vk_nmodes; vc.seed = c.vk_seed; vc.update_stride = c.vk_stride; vc.uc_mode = c.vk_uc;
+			vc.same_realization_all_faces = c.vk_same; vc.stride_interpolation = c.vk_interp; vc.inflow_only = c.vk_inflow_only;
+			vc.face_mode = vk_resolve_face_mode(c.vk_face_mode, c.vk_inflow_only);
+			for(int k=0; k<3; k++) vc.aniso[k] = c.vk_aniso[k];
+			vc.downstream_face_id = case_bc=="-x" ? 0 : case_bc=="+x" ? 1 : case_bc=="-y" ? 2 : case_bc=="+y" ? 3 : -1;
+			if(!(vc.L_lbm>0.0f)) println("| WARNING: vk_inlet_l converts to non-positive LBM value. Disabled.            |");
+			else vk_on = vk_build_tables(vc, Nx, Ny, Nz, flags.data(), u.data(), vk, [](const string& l) { println(l); });
+			if(!vk_on) println(c.profile_mode ? "| VK inlet        | profile case: no valid inflow faces.                       |" : "| VK inlet        | dataset case: no valid inflow faces.                       |");
+			if(vk_on&&!c.dump_vk.empty()&&case_index==1u) {
+				std::ofstream vf(c.dump_vk, std::ios::binary); const uint64_t hdr[2] = {vk.point_count, vk.mode_count};
+				vf.write((const char*)hdr, 16); vf.write((const char*)vk.point_cell.data(), (std::streamsize)(8ull*vk.point_count)); vf.write((const char*)vk.point_face.data(), (std::streamsize)vk.point_count);
+				vf.write((const char*)vk.point_data.data(), (std::streamsize)(28ull*vk.point_count)); vf.write((const char*)vk.mode_data.data(), (std::streamsize)(200ull*vk.mode_count));
+			}
+		}
 		if(!c.dump_setup.empty()&&case_index==1u) { // raw initial state for tests: header (Nx,Ny,Nz,Nz_core as u32; nu, si_u_factor, si_rho_factor as f32) + flags + u + rho(=1)
 			std::ofstream df(c.dump_setup, std::ios::binary);
 			const uint hdr[4] = {Nx, Ny, Nz, Nz_core}; const float fh[8] = {lbm_nu, units.si_u(1.0f), units.si_rho(1.0f), G.buffer_inv_tau_lbmu, G.sponge_inv_tau_lbmu, scale_geom, omega[1], omega[2]};
@@ -732,6 +775,7 @@ int main(int argc, char** argv) {
 		LBM lbm(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f);
 		lbm.set_coriolis(omega[0], omega[1], omega[2]);
 		std::memcpy(lbm.flags.host, flags.data(), N); std::memcpy(lbm.u.host, u.data(), 12ull*N); // rho mirror is pre-filled with 1.0f
+		if(vk_on) luw_check(luw_vk_inlet_attach(lbm.handle(), vk.point_count, vk.mode_count, vk.point_cell.data(), vk.point_face.data(), vk.point_data.data(), vk.mode_data.data(), c.vk_stride, c.vk_interp ? 1 : 0));
 		print_section_title("LBM SOLVER INFORMATION");
 		const ulong total_steps = (c.run_nstep_override>0ull ? c.run_nstep_override : 20001ull)+(ulong)c.research_output_steps;
 		const ulong unsteady = (ulong)c.unsteady_output_interval;

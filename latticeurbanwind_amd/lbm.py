@@ -126,6 +126,17 @@ class LBM:
         capi.check(self._L.luw_run_timed(self._h, int(steps), C.byref(ms)))
         return ms.value
 
+    # ---- von-Karman inlet (tables built like FX/setup.cpp:886-1057; see host/vk_inlet.hpp)
+    def vk_inlet_attach(self, point_cell, point_face, point_data, mode_data, mode_count, update_stride=1, stride_interpolation=False):
+        pc = np.ascontiguousarray(point_cell, np.uint64); pf = np.ascontiguousarray(point_face, np.uint8)
+        pd = np.ascontiguousarray(point_data, np.float32); md = np.ascontiguousarray(mode_data, np.float32)
+        assert pd.size == 7 * pc.size and md.size == 50 * int(mode_count)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        capi.check(self._L.luw_vk_inlet_attach(self._h, pc.size, int(mode_count), p(pc), p(pf), p(pd), p(md), int(update_stride), int(bool(stride_interpolation))))
+
+    def vk_inlet_apply(self): capi.check(self._L.luw_vk_inlet_apply(self._h))
+    def vk_inlet_detach(self): capi.check(self._L.luw_vk_inlet_detach(self._h))
+
     # ---- on-device time averaging (replaces FX/setup.cpp:4441-4542)
     def stats_reset(self): capi.check(self._L.luw_stats_reset(self._h))
     def stats_accumulate(self): capi.check(self._L.luw_stats_accumulate(self._h))

@@ -457,6 +457,39 @@ void luwo_transfer_insert_fi(const LuwOracleCfg* c, const uint32_t direction, co
 	}
 }
 
+/* vk_inlet_apply, FX/kernel.cpp:2495-2571 (u in the reference layout, plane stride N) */
+void luwo_vk_inlet_apply(const uint64_t N, const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint64_t P, const uint64_t M,
+		const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, float* u) {
+	const uint64_t V = 5ull*M;
+	#pragma omp parallel for schedule(static)
+	for(int64_t ii=0; ii<(int64_t)P; ii++) {
+		const uint64_t i = (uint64_t)ii, n = point_cell[i];
+		const uint64_t fid = (uint64_t)(point_face[i]&0x07u);
+		const float px = point_data[i], py = point_data[P+i], pz = point_data[2ull*P+i];
+		const float ubx = point_data[3ull*P+i], uby = point_data[4ull*P+i], ubz = point_data[5ull*P+i], sigma = point_data[6ull*P+i];
+		if(fid>=5ull||!(sigma>0.0f)) { u[n] = ubx; u[N+n] = uby; u[2ull*N+n] = ubz; continue; }
+		const uint64_t fbase = fid*M;
+		float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+		for(uint64_t m=0ull; m<M; ++m) {
+			const uint64_t idx = fbase+m;
+			const float kx = mode_data[idx], ky = mode_data[V+idx], kz = mode_data[2ull*V+idx], omega = mode_data[3ull*V+idx];
+			const float Ax = mode_data[4ull*V+idx], Ay = mode_data[5ull*V+idx], Az = mode_data[6ull*V+idx];
+			const float phix = mode_data[7ull*V+idx], phiy = mode_data[8ull*V+idx], phiz = mode_data[9ull*V+idx];
+			const float phase0 = fmaf(kx, px, fmaf(ky, py, fmaf(kz, pz, omega*t0)));
+			float vx = Ax*cosf(phase0+phix), vy = Ay*cosf(phase0+phiy), vz = Az*cosf(phase0+phiz);
+			if(use_interp!=0u) {
+				const float phase1 = fmaf(kx, px, fmaf(ky, py, fmaf(kz, pz, omega*t1)));
+				const float vx1 = Ax*cosf(phase1+phix), vy1 = Ay*cosf(phase1+phiy), vz1 = Az*cosf(phase1+phiz);
+				vx = fmaf(alpha, vx1-vx, vx); vy = fmaf(alpha, vy1-vy, vy); vz = fmaf(alpha, vz1-vz, vz);
+			}
+			qx += vx; qy += vy; qz += vz;
+		}
+		u[n] = fmaf(sigma, qx, ubx);
+		u[N+n] = fmaf(sigma, qy, uby);
+		u[2ull*N+n] = fmaf(sigma, qz, ubz);
+	}
+}
+
 /* accumulate_from_buffers, FX/setup.cpp:4441-4488: Welford mean / M2 of u (avg_u is AoS [3n+c]), running mean of rho.
  * count is the sample number AFTER the increment (avg_count), inv_n = 1/count. */
 void luwo_accumulate_stats(const uint64_t N, const uint64_t count, const float* rho, const float* u, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w) {

@@ -56,6 +56,7 @@ def lib():
         L.luwo_transfer_extract_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_extract_fi.restype = None
         L.luwo_transfer_insert_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_insert_fi.restype = None
         L.luwo_moments.argtypes = [cfgp, vp, u64, vp, vp]; L.luwo_moments.restype = None
+        L.luwo_vk_inlet_apply.argtypes = [u64, u32, C.c_float, C.c_float, C.c_float, u64, u64, vp, vp, vp, vp, vp]; L.luwo_vk_inlet_apply.restype = None
         L.luwo_accumulate_stats.argtypes = [u64, u64] + [vp] * 7; L.luwo_accumulate_stats.restype = None
         L.luwo_set_threads.argtypes = [C.c_int]; L.luwo_set_threads.restype = None
         L.luwo_get_max_threads.restype = C.c_int
@@ -149,6 +150,12 @@ class OracleLBM:
         rho = np.zeros(self.N, np.float32); u = np.zeros(3 * self.N, np.float32)
         lib().luwo_moments(C.byref(self.cfg), _p(self.fi), self.t, _p(rho), _p(u))
         return rho, u
+
+
+def vk_inlet_apply(o, tables, use_interp, t0, t1, alpha):
+    """kernel vk_inlet_apply (FX/kernel.cpp:2495-2571) on an OracleLBM's u field"""
+    lib().luwo_vk_inlet_apply(o.N, int(use_interp), float(t0), float(t1), float(alpha), tables["point_count"], tables["mode_count"],
+                              _p(tables["point_cell"]), _p(tables["point_face"]), _p(tables["point_data"]), _p(tables["mode_data"]), _p(o.u))
 
 
 class OracleStats:
