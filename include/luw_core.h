@@ -152,6 +152,13 @@ int luw_finish(luw_solver* s);                                            /* LBM
 int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_upload_fi(luw_solver* s, const void* host_src);
 
+/* LBM::voxelize_mesh_on_device(mesh, TYPE_S) for a static mesh (FX/lbm.cpp:1411-1645, kernel voxelize_mesh FX/kernel.cpp:2381-2471,
+ * rays along z): p0/p1/p2 are the triangle corners (xyz triples, lattice index coordinates of the GLOBAL lattice, i.e. after the
+ * driver's scale + translate, FX/setup.cpp:4084-4087); bounds = Mesh::pmin xyz, Mesh::pmax xyz, or NULL to run Mesh::find_bounds
+ * (FX/utilities.hpp:4774-4785) on the corners.  Uploads the host flags/u mirrors, works on the device flags and leaves the
+ * result in the host flags mirror. */
+int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag);
+
 /* von-Karman synthetic-turbulence inlet: the device half of the reference's VonKarmanInletUpdater (FX/setup.cpp:413-1149,
  * kernel vk_inlet_apply FX/kernel.cpp:2495-2571).  The caller builds the tables like build_gpu_runtime_ does
  * (latticeurbanwind_amd/host/vk_inlet.hpp): point_cell[P] = cell index n in the reference layout, point_face[P] = 0 west /

@@ -515,6 +515,66 @@ template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KP
 	}
 }
 
+// ---------------------------------------------------------------- mesh voxeliser
+// voxelize_mesh with direction 2 (z rays; LUW always voxelises TYPE_S along z, FX/lbm.cpp:1427-1430) for a static mesh:
+// one lane per (x,y) column casts a ray from the bottom of the padded bounding box through ALL triangles
+// (Moeller-Trumbore), sorts up to 64 hit distances and fills the cells between odd/even crossings
+// (FX/kernel.cpp:2381-2471).  Arithmetic mirrors what the reference's OpenCL build executes on this hardware: 1/g is the
+// hardware reciprocal v_rcp_f32 (OpenCL's 2.5-ulp 1.0f/g) and dot / cross are the fma chains of the OpenCL device library
+// (dot = mad(z,z', mad(y,y', x*x')), cross.x = mad(a.y, b.z, -(a.z*b.y)) ...).  Faces of LUW geometry sit on exact lattice
+// planes by construction (ground slab pmin -> 1), where the (ushort)d truncation depends on exactly these roundings.
+__device__ __forceinline__ float vdot(const float ax, const float ay, const float az, const float bx, const float by, const float bz) {
+	return fmaf(az, bz, fmaf(ay, by, ax*bx)); // dot(float3) of the OpenCL device library: mad(z, z', mad(y, y', x*x'))
+}
+__global__ __launch_bounds__(256) void k_voxelize_z(const KParams p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t triangle_number,
+		const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2, const float x0, const float y0, const float z0, const float x1, const float y1, const float z1) {
+	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
+	if(a>=p.Nx*p.Ny) return;
+	const uint32_t x = a%p.Nx, y = a/p.Nx;
+	const int zs = min(max((int)z0-p.Oz, 0), (int)p.Nz-1);
+	const float rx = (float)((int)x+p.Ox), ry = (float)((int)y+p.Oy), rz = (float)(zs+p.Oz); // position(xyz)+offset = global index coordinates
+	if(rx<x0||ry<y0||rx>=x1||ry>=y1) return;
+	uint32_t intersections = 0u, intersections_check = 0u;
+	uint16_t distances[64];
+	for(uint32_t i=0u; i<triangle_number; i++) {
+		const float ax = p0[3u*i], ay = p0[3u*i+1u], az = p0[3u*i+2u];
+		const float ux = p1[3u*i]-ax, uy = p1[3u*i+1u]-ay, uz = p1[3u*i+2u]-az;
+		const float vx = p2[3u*i]-ax, vy = p2[3u*i+1u]-ay, vz = p2[3u*i+2u]-az;
+		const float wx = rx-ax, wy = ry-ay, wz = rz-az;
+		// h = cross(r_direction, v) with r_direction = (0,0,1); q = cross(w, u)
+		const float hx = fmaf(0.0f, vz, -(1.0f*vy)), hy = fmaf(1.0f, vx, -(0.0f*vz)), hz = fmaf(0.0f, vy, -(0.0f*vx));
+		const float qx = fmaf(wy, uz, -(wz*uy)), qy = fmaf(wz, ux, -(wx*uz)), qz = fmaf(wx, uy, -(wy*ux));
+		const float g = vdot(ux, uy, uz, hx, hy, hz);
+		const float f = __builtin_amdgcn_rcpf(g);
+		const float sv = f*vdot(wx, wy, wz, hx, hy, hz), tv = f*vdot(0.0f, 0.0f, 1.0f, qx, qy, qz), d = f*vdot(vx, vy, vz, qx, qy, qz);
+		if(g!=0.0f&&sv>=0.0f&&sv<1.0f&&tv>=0.0f&&sv+tv<1.0f) {
+			if(d>0.0f) { if(intersections<64u&&d<65536.0f) distances[intersections] = (uint16_t)d; intersections++; }
+			else intersections_check++;
+		}
+	}
+	const uint32_t ns = min(intersections, 64u);
+	for(uint32_t i=1u; i<ns; i++) { // insertion sort
+		const uint16_t t = distances[i];
+		int j = (int)i-1;
+		while(j>=0&&distances[j]>t) { distances[j+1] = distances[j]; j--; }
+		distances[j+1] = t;
+	}
+	bool inside = (intersections%2u)&&(intersections_check%2u);
+	uint32_t k = (intersections%2u)!=(intersections_check%2u);
+	const uint32_t h0 = (uint32_t)zs;
+	const uint32_t hmax = (uint32_t)min(max((int)z1-p.Oz, 0), (int)p.Nz);
+	const uint32_t hmesh = h0+(ns>0u ? (uint32_t)distances[min(intersections-1u, 63u)] : 0u);
+	for(uint32_t h=h0; h<hmax; h++) {
+		while(k<intersections&&h>h0+(uint32_t)distances[min(k, 63u)]) { inside = !inside; k++; }
+		inside = inside&&(k<intersections&&h<hmesh);
+		const uint32_t n = x+(y+h*p.Ny)*p.Px;
+		uint8_t fl = flags[n];
+		if(inside) fl = (uint8_t)((fl&~TYPE_BO)|flag);
+		else if((fl&TYPE_BO)==TYPE_S&&u[n]==0.0f&&u[p.Np+(uint64_t)n]==0.0f&&u[2ull*p.Np+(uint64_t)n]==0.0f) fl = (uint8_t)(fl&~flag); // was solid with the mesh's velocity (static: 0), FX/kernel.cpp:2451-2462
+		flags[n] = fl;
+	}
+}
+
 // ---------------------------------------------------------------- von-Karman synthetic-turbulence inlet
 // vk_inlet_apply, FX/kernel.cpp:2495-2571: u[cell] = u_base + sigma * sum_m A_m cos(k_m.p + omega_m t + phi_m) on the inlet
 // cells (TYPE_E: the collide step then relaxes them to f_eq(rho, u)).  One lane per inlet point; cosf is the same device
@@ -921,7 +981,34 @@ int luw_upload_fi(luw_solver* s, const void* host_src) {
 }
 
 int luw_run(luw_solver* s, uint64_t steps);
+int luw_upload(luw_solver* s, uint32_t mask);
+int luw_download(luw_solver* s, uint32_t mask);
 static int vk_apply(luw_solver* s);
+int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag) {
+	if(!s||!p0||!p1||!p2||triangle_number==0u) return fail(LUW_ERR_INVALID, "luw_voxelize_mesh: bad argument");
+	if(int e = set_device(s)) return e;
+	float pmin[3], pmax[3]; // Mesh::find_bounds seeds with p0[0] only, FX/utilities.hpp:4774-4785
+	if(bounds) for(int c=0; c<3; c++) { pmin[c] = bounds[c]; pmax[c] = bounds[3+c]; }
+	else {
+		for(int c=0; c<3; c++) pmin[c] = pmax[c] = p0[c];
+		for(uint32_t i=1u; i<triangle_number; i++) for(int c=0; c<3; c++) {
+			pmin[c] = fminf(fminf(fminf(p0[3u*i+c], p1[3u*i+c]), p2[3u*i+c]), pmin[c]);
+			pmax[c] = fmaxf(fmaxf(fmaxf(p0[3u*i+c], p1[3u*i+c]), p2[3u*i+c]), pmax[c]);
+		}
+	}
+	float* d[3] = { nullptr, nullptr, nullptr };
+	const float* h[3] = { p0, p1, p2 };
+	for(int k=0; k<3; k++) { if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess) { for(int q=0; q<3; q++) (void)hipFree(d[q]); return fail(LUW_ERR_NOMEM, "luw_voxelize_mesh: allocation failed"); } HIP_TRY(hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)); }
+	if(int e = luw_upload(s, LUW_MASK_FLAGS|LUW_MASK_U)) return e; // the host mirror is authoritative before the first run
+	const uint32_t A = s->cfg.Nx*s->cfg.Ny;
+	hipLaunchKernelGGL(k_voxelize_z, dim3((A+255u)/256u), dim3(256), 0, s->stream, s->kp, s->d_flags, s->d_u, flag, triangle_number, d[0], d[1], d[2],
+		pmin[0]-2.0f, pmin[1]-2.0f, pmin[2]-2.0f, pmax[0]+2.0f, pmax[1]+2.0f, pmax[2]+2.0f); // bounding box + 2 cells, FX/lbm.cpp:498
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	for(int k=0; k<3; k++) (void)hipFree(d[k]);
+	return luw_download(s, LUW_MASK_FLAGS); // LBM::voxelize_mesh_on_device leaves the result in lbm.flags
+}
+
 int luw_vk_inlet_detach(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_vk_inlet_detach: null solver");
 	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);

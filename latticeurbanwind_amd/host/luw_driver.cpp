@@ -9,13 +9,14 @@
 //   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
 // Modes: *.luwpf (profile) and *.luwdg (dataset).  Not in this build (announced on the console, never silently):
 //   *.luw NWP boundary builders, DEM ground plane, probes, PNG frames.
-// Differences by design: time averaging runs on the device (luw_stats_*), the voxeliser runs on the host; the von-Karman
+// Differences by design: time averaging runs on the device (luw_stats_*); --dry-run voxelises on the host; the von-Karman
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
 // Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
 //   --device N, --dry-run (host stage only, no GPU), --sizing-only (stop after grid / unit / buffer / sponge numbers),
 //   --dump-setup FILE (raw initial state of the first case).
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -698,7 +699,16 @@ int main(int argc, char** argv) {
 
 		// host state of this case
 		std::vector<uchar> flags(N, 0u); std::vector<float> u(3ull*N, 0.0f);
-		const ulong nvox = voxelize_z(mesh, Nx, Ny, Nz, flags);
+		std::unique_ptr<LBM> lbm_p;
+		ulong nvox = 0ull;
+		if(c.dry_run) nvox = voxelize_z(mesh, Nx, Ny, Nz, flags); // no GPU: host restatement of the kernel
+		else { // lbm.voxelize_mesh_on_device(mesh), FX/setup.cpp:4089
+			lbm_p.reset(new LBM(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f));
+			const float bounds[6] = {mesh.pmin[0], mesh.pmin[1], mesh.pmin[2], mesh.pmax[0], mesh.pmax[1], mesh.pmax[2]};
+			luw_check(luw_voxelize_mesh(lbm_p->handle(), mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), bounds, TYPE_S));
+			std::memcpy(flags.data(), lbm_p->flags.host, N);
+			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
+		}
 		println("| Info: Voxelized cells (whole domain global, no halos): solid = "+to_string_u(nvox)+", fluid = "+to_string_u(N-nvox)+", total = "+to_string_u(N)+".");
 		println("| Voxelization done.                                                          |");
 		print_section_title("BUILD BOUNDARY CONDITIONS");
@@ -772,7 +782,7 @@ int main(int argc, char** argv) {
 		if(c.dry_run) continue;
 
 		// ---- run_lbm, FX/setup.cpp:4117-4911
-		LBM lbm(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f);
+		LBM& lbm = *lbm_p;
 		lbm.set_coriolis(omega[0], omega[1], omega[2]);
 		std::memcpy(lbm.flags.host, flags.data(), N); std::memcpy(lbm.u.host, u.data(), 12ull*N); // rho mirror is pre-filled with 1.0f
 		if(vk_on) luw_check(luw_vk_inlet_attach(lbm.handle(), vk.point_count, vk.mode_count, vk.point_cell.data(), vk.point_face.data(), vk.point_data.data(), vk.mode_data.data(), c.vk_stride, c.vk_interp ? 1 : 0));

@@ -126,6 +126,15 @@ class LBM:
         capi.check(self._L.luw_run_timed(self._h, int(steps), C.byref(ms)))
         return ms.value
 
+    def voxelize_mesh_on_device(self, tri, flag=capi.TYPE_S, bounds=None):
+        """LBM::voxelize_mesh_on_device (FX/lbm.hpp:560): tri = float32 array (T,3,3) of triangle corners in lattice index
+        coordinates; marks cells inside the mesh in self.flags (host mirror updated)"""
+        tri = np.ascontiguousarray(tri, np.float32)
+        p0, p1, p2 = (np.ascontiguousarray(tri[:, k, :]) for k in range(3))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        b = None if bounds is None else np.ascontiguousarray(bounds, np.float32).reshape(6)
+        capi.check(self._L.luw_voxelize_mesh(self._h, tri.shape[0], p(p0), p(p1), p(p2), None if b is None else p(b), int(flag)))
+
     # ---- von-Karman inlet (tables built like FX/setup.cpp:886-1057; see host/vk_inlet.hpp)
     def vk_inlet_attach(self, point_cell, point_face, point_data, mode_data, mode_count, update_stride=1, stride_interpolation=False):
         pc = np.ascontiguousarray(point_cell, np.uint64); pf = np.ascontiguousarray(point_face, np.uint8)

@@ -419,7 +419,7 @@ def setup_profile_case(deck_path, angle_index=0, solid_mask=None):
         val = np.where(side, s_cap, s_here).astype(f32)
         u3[0, z][m] = (dir_x * val)[m]; u3[1, z][m] = (dir_y * val)[m]; u3[2, z][m] = 0
         mapped += int(m.sum())
-    return dict(case=case, Nx=Nx, Ny=Ny, Nz=Nz, Nz_core=Nz_core, D=D, nu=lbm_nu, units=units, cell_m=cell_m,
+    return dict(case=case, tri_lattice=tri, Nx=Nx, Ny=Ny, Nz=Nz, Nz_core=Nz_core, D=D, nu=lbm_nu, units=units, cell_m=cell_m,
                 si_ref_u=si_ref_u, u_scale=u_scale, flags=flags, u=u, rho=rho,
                 buffer_active=buffer_active, buffer_N=nbuf, buffer_inv_tau=buffer_inv_tau,
                 buffer_nudge_vertical=buffer_nudge_vertical, buffer_face=buffer_face,

@@ -11,6 +11,8 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   B  nudging + sponge OFF                                      (Nz = 24)
   L  "laminar" micro-domain (cell 1e-5 m -> nu_lbm ~ 0.03), nudging + sponge OFF, uniform inflow
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
+  G,H case B with a 'city' STL (aligned / off-grid / rotated boxes, roofs, pyramid, floating tetrahedron, overlapping
+     boxes) at cell 2 m and 2.5 m: voxeliser goldens
 """
 import os, struct, sys
 
@@ -32,13 +34,53 @@ def write_stl(path, tris):
             l = (n[0]**2+n[1]**2+n[2]**2)**0.5 or 1.0
             f.write(struct.pack("<12fH", n[0]/l,n[1]/l,n[2]/l, *p0, *p1, *p2, 0))
 
-def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False):
+def rot_box_tris(cx, cy, lx, ly, z0, z1, deg):
+    """box rotated about the vertical axis through (cx, cy)"""
+    import math
+    c, sn = math.cos(math.radians(deg)), math.sin(math.radians(deg))
+    out = []
+    for tri in box_tris(-lx/2, lx/2, -ly/2, ly/2, z0, z1):
+        out.append(tuple((cx + c*x - sn*y, cy + sn*x + c*y, z) for x, y, z in tri))
+    return out
+
+def hull_tris(base, apexes):
+    """closed solid over a convex base polygon (counter-clockwise, z = base z) with a roof: apexes = 1 point (pyramid)
+    or 2 points (ridge of a pitched roof over a 4-corner base)"""
+    t = []
+    n = len(base)
+    for i in range(1, n-1): t.append((base[0], base[i+1], base[i]))          # floor, facing down
+    if len(apexes) == 1:
+        for i in range(n): t.append((base[i], base[(i+1) % n], apexes[0]))
+    else:
+        a, b = apexes                                                        # ridge a (near base[0],base[3]) .. b (near base[1],base[2])
+        t += [(base[0], base[1], b), (base[0], b, a), (base[2], base[3], a), (base[2], a, b), (base[1], base[2], b), (base[3], base[0], a)]
+    return t
+
+def city_tris(s):
+    """a small 'city' exercising the voxeliser: off-grid box, box with faces exactly ON lattice planes, box on half-cell
+    planes, rotated box, pitched-roof house, pyramid, floating tetrahedron, two overlapping boxes"""
+    t  = box_tris(10.3*s, 22.7*s, 8.6*s, 21.4*s, 0.0, 13.3*s)
+    t += box_tris(30*s, 40*s, 10*s, 20*s, 0.0, 12*s)
+    t += box_tris(47*s, 55*s, 9*s, 17*s, 0.0, 9*s)
+    t += rot_box_tris(70*s, 18*s, 14.2*s, 9.1*s, 0.0, 17.7*s, 31.0)
+    hb = [(12*s, 40*s, 0.0), (30*s, 40*s, 0.0), (30*s, 52*s, 0.0), (12*s, 52*s, 0.0)]
+    t += box_tris(12*s, 30*s, 40*s, 52*s, 0.0, 8*s)
+    t += hull_tris([(x, y, 8*s) for x, y, _ in hb], [(12*s, 46*s, 15.5*s), (30*s, 46*s, 15.5*s)])
+    t += hull_tris([(42.2*s, 40.4*s, 0.0), (58.9*s, 41.1*s, 0.0), (57.3*s, 58.2*s, 0.0), (41.0*s, 56.6*s, 0.0)], [(50.1*s, 49.3*s, 21.4*s)])
+    t += hull_tris([(68.3*s, 44.1*s, 22.2*s), (80.6*s, 46.3*s, 24.1*s), (73.4*s, 57.7*s, 23.3*s)], [(74.2*s, 49.9*s, 33.8*s)])
+    t += box_tris(66.5*s, 78.5*s, 60.2*s, 70.9*s, 0.0, 11.1*s)
+    t += box_tris(74.1*s, 86.3*s, 64.8*s, 75.6*s, 0.0, 15.2*s)
+    return t
+
+def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0):
     """s = length scale (metres per 'unit'); the box geometry is dims units (default 96 x 80 x 48), base slab 4 units."""
     d = os.path.join(root, name)
     os.makedirs(os.path.join(d, "proj_temp"), exist_ok=True)
     os.makedirs(os.path.join(d, "wind_bc"), exist_ok=True)
     tris  = box_tris(0, dims[0]*s, 0, dims[1]*s, -4*s, 0.0)          # ground slab (full footprint)
-    if building:
+    if building == "city":
+        tris += city_tris(s)
+    elif building:
         tris += box_tris(30.3*s, 46.7*s, 28.6*s, 51.4*s, 0.0, 19.3*s)    # one building, off-grid faces
     write_stl(os.path.join(d, "proj_temp", name + "_PF.stl"), tris)
     with open(os.path.join(d, "wind_bc", "profile.dat"), "w") as f:
@@ -55,7 +97,7 @@ def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64,
         "base_height = %.9g" % (4*s),
         "n_gpu = [1, 1, 1]",
         'mesh_control = "cell_size"',
-        "cell_size = %.9g" % (2*s),
+        "cell_size = %.9g" % (cell*s),
         "validation = pass",
         "high_order = false",
         "flux_correction = false",
@@ -77,6 +119,9 @@ if __name__ == "__main__":
     # V: case B with the von-Karman synthetic-turbulence inlet on (defaults TI = 5 %, seed 100; L = 20 m, 64 modes)
     write_case(root, "CaseV", 1.0, ["enable_buffer_nudging = false", "enable_top_sponge = false", "vk_inlet_l = 20", "vk_inlet_nmodes = 64"], vk=True)
     off = ["enable_buffer_nudging = false", "enable_top_sponge = false"]
+    # G, H: voxeliser cases ("city" geometry) at cell 2 m (mesh scale 0.5, exact) and cell 2.5 m (scale 0.4, inexact)
+    write_case(root, "CaseG", 1.0, off, building="city", nstep=16)
+    write_case(root, "CaseH", 1.0, off, building="city", nstep=16, cell=2.5)
     # performance decks for timing the reference itself on the GPU box (not fixtures: generated on demand)
     if "--perf" in sys.argv:
         write_case(root, "Perf512", 1.0, off, dims=(1024, 1024, 1024), building=False, nstep=300, unsteady=0, purge=0)

@@ -12,9 +12,10 @@ from vtkio import read_vtk
 run_dir, out = sys.argv[1], sys.argv[2]
 g = lambda pat: glob.glob(os.path.join(run_dir, pat))[0]
 d = {}
-for t in (8, 64):
+times = sorted(int(re.search(r"_raw_u-(\d+)\.vtk$", p).group(1)) for p in glob.glob(os.path.join(run_dir, "*_raw_u-*.vtk")))
+for t in (times[0], times[-1]):   # first unsteady output and the final step (8 and 64 for the 64-step cases)
     h, f = read_vtk(g("*_raw_u-%09d.vtk" % t)); d["u%d" % t] = f["data"].astype(np.float32)
-h, f = read_vtk(g("*_raw_rho-*.vtk")); d["rho64"] = f["data"][..., 0].astype(np.float32)
+h, f = read_vtk(g("*_raw_rho-*.vtk")); d["rho%d" % times[-1]] = f["data"][..., 0].astype(np.float32)
 h, f = read_vtk(g("*_avg-*.vtk")); d["solid"] = (f["fluid"][..., 0] == 0)
 d["u_avg"] = f["u_avg"].astype(np.float32)   # mean of u over the last purge_avg=4 steps, SI units
 d["dims"] = np.array(h["dims"]); d["origin"] = np.array(h["origin"]); d["spacing"] = np.array(h["spacing"])

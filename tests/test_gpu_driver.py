@@ -26,7 +26,10 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
     deck = os.path.join(proj, "conf.luwpf")
     r = subprocess.run([DRIVER, deck, "--ddf", ddf], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    s = setup_profile.setup_profile_case(deck)
+    # the driver voxelises on the device (bit-identical to the reference's masks, tests/test_gpu_voxelize.py); the python
+    # set-up restatement takes the reference's mask instead of its IEEE-division host voxeliser
+    gold = np.load(os.path.join(GOLD, "ref_fp32_%s.npz" % case))
+    s = setup_profile.setup_profile_case(deck, solid_mask=gold["solid"])
     Nx, Ny, Nz, Nzc = s["Nx"], s["Ny"], s["Nz"], s["Nz_core"]
     o = oracle.OracleLBM(Nx, Ny, Nz, s["nu"], fp16c=(ddf == "fp16c"))
     o.flags[:] = s["flags"]; o.u[:] = s["u"]; o.rho[:] = s["rho"]
@@ -65,5 +68,51 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
     assert np.allclose(f["TI"][..., 0], ti, rtol=2e-7, atol=0)
     assert np.isfinite(f["TLS"]).all() and (f["TLS"][..., 0][solid] == 0).all() and f["TLS"].max() <= max(Nx, Ny, Nzc) * h["spacing"][0]
     # the same deck through the real reference: identical header grammar (FX/lbm.hpp:322-329)
-    gold = np.load(os.path.join(GOLD, "ref_fp32_%s.npz" % case))
     assert tuple(gold["dims"]) == h["dims"] and np.allclose(gold["origin"], h["origin"]) and np.allclose(gold["spacing"], h["spacing"])
+
+
+@pytest.mark.parametrize("case,ddf,fixture", [
+    ("CaseA", "fp32", "ref_fp32_CaseA"), ("CaseB", "fp32", "ref_fp32_CaseB"), ("CaseL", "fp32", "ref_fp32_CaseL"),
+    ("CaseV", "fp32", "ref_fp32_CaseV"), ("CaseG", "fp32", "ref_fp32_CaseG"), ("CaseH", "fp32", "ref_fp32_CaseH"),
+    ("CaseA", "fp16c", "ref_shipped_CaseA"), ("CaseV", "fp16c", "ref_shipped_CaseV"),
+    ("CaseG", "fp16c", "ref_shipped_CaseG"), ("CaseH", "fp16c", "ref_shipped_CaseH")])
+def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture):
+    """deck in, VTK out, nothing injected: the driver's files against the files the REAL reference wrote for the same deck on
+    an MI355X (geometry voxelised on the device, BC fill, VK inlet, run loop, averaging, writers).  Gates as in
+    test_gpu_parity.test_hip_path_vs_real_reference_fields (lattice units): first output 2e-7 (FP32) / 2e-6 (FP16C) u RMSE,
+    final step 1e-6 / 1e-4; masks and headers exact."""
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
+    proj = str(tmp_path / case)
+    shutil.copytree(os.path.join(GOLD, "refcases", case), proj)
+    r = subprocess.run([DRIVER, os.path.join(proj, "conf.luwpf"), "--ddf", ddf], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    gold = np.load(os.path.join(GOLD, fixture + ".npz"))
+    vt = os.path.join(proj, "RESULTS", "vtk")
+    times = sorted(int(k[1:]) for k in gold.files if k[0] == "u" and k[1:].isdigit())
+    fp16c = ddf == "fp16c"
+    h, f = read_vtk(glob.glob(os.path.join(vt, "*_avg-%09d.vtk" % times[-1]))[0])
+    assert tuple(gold["dims"]) == h["dims"] and np.array_equal(gold["origin"], np.array(h["origin"])) and np.array_equal(gold["spacing"], np.array(h["spacing"]))
+    solid = f["fluid"][..., 0] == 0
+    assert np.array_equal(solid, gold["solid"]), "TYPE_S mask differs from the reference in %d cells" % int((solid != gold["solid"]).sum())
+    fluid = ~solid
+    import re
+    # SI <-> lattice factors exactly as the set-up restatement computes them (units.si_u(1), units.si_rho(1))
+    s = setup_profile.setup_profile_case(os.path.join(proj, "conf.luwpf"), solid_mask=gold["solid"])
+    fac = s["si_u_factor"]
+
+    def rmse(a, b):
+        d = ((a - b) / fac)[fluid].astype(np.float64)
+        return float(np.sqrt((d ** 2).sum(-1).mean()))
+    for t, gate in ((times[0], 2e-6 if fp16c else 2e-7), (times[-1], 1e-4 if fp16c else 1e-6)):
+        hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_u-%09d.vtk" % t))[0])
+        e = rmse(ff["data"], gold["u%d" % t])
+        assert e < gate, "u RMSE %.3e at t=%d" % (e, t)
+    e = rmse(f["u_avg"], gold["u_avg"])
+    assert e < (1e-4 if fp16c else 1e-6), "u_avg RMSE %.3e" % e
+    hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_rho-%09d.vtk" % times[-1]))[0])
+    dr = np.abs((ff["data"][..., 0] - gold["rho%d" % times[-1]]) / s["si_rho_factor"])[fluid].max()
+    assert dr < (1e-2 if fp16c else 1e-4), "rho max diff %.3e" % dr
+    # voxel count line of the console, as the reference prints it
+    want = re.search(r"solid = (\d+), fluid = (\d+)", open(os.path.join(GOLD, fixture + ".console.txt")).read())
+    got = re.search(r"solid = (\d+), fluid = (\d+)", r.stdout)
+    assert got and got.groups() == want.groups()
