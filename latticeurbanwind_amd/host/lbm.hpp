@@ -94,6 +94,12 @@ public:
 	void position(const uint x, const uint y, const uint z, float& px, float& py, float& pz) const { // FX/lbm.hpp:523-525
 		px = (float)x-0.5f*(float)Nx+0.5f; py = (float)y-0.5f*(float)Ny+0.5f; pz = (float)z-0.5f*(float)Nz+0.5f;
 	}
+	// lbm.voxelize_mesh_on_device(mesh, TYPE_S) for a static mesh, FX/lbm.hpp:560 / FX/lbm.cpp:1411: corners are float3
+	// arrays (xyz triples) in lattice index coordinates, pmin/pmax the Mesh's bounds; result lands in flags[] (host mirror)
+	void voxelize_mesh_on_device(const uint triangle_number, const float* p0, const float* p1, const float* p2, const float* pmin, const float* pmax, const uchar flag = 0x01) {
+		const float bounds[6] = { pmin[0], pmin[1], pmin[2], pmax[0], pmax[1], pmax[2] };
+		luw_check(luw_voxelize_mesh(s, triangle_number, p0, p1, p2, bounds, flag));
+	}
 	luw_solver* handle() { return s; }
 };
 

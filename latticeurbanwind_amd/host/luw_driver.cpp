@@ -704,8 +704,7 @@ int main(int argc, char** argv) {
 		if(c.dry_run) nvox = voxelize_z(mesh, Nx, Ny, Nz, flags); // no GPU: host restatement of the kernel
 		else { // lbm.voxelize_mesh_on_device(mesh), FX/setup.cpp:4089
 			lbm_p.reset(new LBM(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f));
-			const float bounds[6] = {mesh.pmin[0], mesh.pmin[1], mesh.pmin[2], mesh.pmax[0], mesh.pmax[1], mesh.pmax[2]};
-			luw_check(luw_voxelize_mesh(lbm_p->handle(), mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), bounds, TYPE_S));
+			lbm_p->voxelize_mesh_on_device(mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), mesh.pmin, mesh.pmax, TYPE_S);
 			std::memcpy(flags.data(), lbm_p->flags.host, N);
 			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
 		}
