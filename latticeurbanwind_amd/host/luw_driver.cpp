@@ -33,6 +33,7 @@
 
 #include "lbm.hpp"
 #include "vk_inlet.hpp"
+#include "bc_builders.hpp"
 
 using namespace luw_host;
 using std::string;
@@ -79,6 +80,18 @@ static string to_string_fd(float x, const uint decimals) { // FX/utilities.hpp:2
 	const ulong integral = (ulong)x;
 	const uint decimal = (uint)((x-(float)integral)*power);
 	return s+to_string_u(integral)+(decimals==0u ? "" : "."+decimal_to_string(decimal, (int)std::min(decimals, 8u)));
+}
+static string to_string_dd(double x, const uint decimals) { // FX/utilities.hpp:2773-2783
+	string s;
+	if(x<0.0) { s += "-"; x = -x; }
+	if(std::isnan(x)) return s+"NaN";
+	if(std::isinf(x)) return s+"Inf";
+	const double power = std::pow(10.0, (double)std::min(decimals, 16u));
+	x += 0.5/power;
+	const ulong integral = (ulong)x;
+	ulong decimal = (ulong)((x-(double)integral)*power);
+	string r; for(int d=(int)std::min(decimals, 16u); d>0; d--) { r = (char)(decimal%10ull+48ull)+r; decimal /= 10ull; }
+	return s+to_string_u(integral)+(decimals==0u ? "" : "."+r);
 }
 static string fmtf(float v, int prec = 4) { std::ostringstream os; os << std::fixed; os.precision(prec); os << v; return os.str(); }
 static string format_tag(float v) { string s = to_string_fd(v, 3u); if(s.find('.')!=string::npos) { while(!s.empty()&&s.back()=='0') s.pop_back(); if(!s.empty()&&s.back()=='.') s.pop_back(); } return s.empty() ? "0" : s; }
@@ -181,6 +194,7 @@ struct Config {
 	VkUcMode vk_uc = VkUcMode::NORM_MEAN; bool vk_same = true, vk_interp = false, vk_inflow_only = false; VkFaceMode vk_face_mode = VkFaceMode::AUTO_SIDES; float vk_aniso[3] = {1.0f, 1.0f, 1.0f};
 	std::vector<float> inflow_list, angle_list;
 	// command line
+	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
 	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
 };
 
@@ -404,7 +418,7 @@ int main(int argc, char** argv) {
 		std::transform(ext.begin(), ext.end(), ext.begin(), ::tolower);
 		if(ext==".luwdg") { c.dataset_mode = true; println("| Dataset generation mode enabled (*.luwdg).                                  |"); }
 		else if(ext==".luwpf") { c.profile_mode = true; println("| Profile forcing mode enabled (*.luwpf).                                     |"); }
-		else fatal("ERROR: NWP mode (*.luw: SurfData CSV boundary builders, SURVEY 8f-3) is not part of this build yet; use the reference solver for *.luw decks.");
+		else c.nwp_mode = true; // *.luw: boundaries from proj_temp/SurfData_<datetime>.csv
 	}
 	std::ifstream fin(c.deck_path);
 	if(!fin.is_open()) fatal("ERROR: config not found. Please provide a valid *.luw, *.luwdg, or *.luwpf and rerun.");
@@ -422,6 +436,11 @@ int main(int argc, char** argv) {
 		const string& key = e.first; const string& val = e.second; const string uq = deck_unquote(val); bool pb = false;
 		if(key=="casename") c.caseName = uq;
 		else if(key=="datetime") c.datetime = uq;
+		else if(key=="downstream_bc") c.downstream_bc = uq;
+		else if(key=="downstream_bc_yaw") c.downstream_bc_yaw = uq;
+		else if(key=="high_order") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.use_high_order = pb; }
+		else if(key=="flux_correction") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.flux_correction = pb; }
+		else if(key=="validation") c.validation = uq;
 		else if(key=="downstream_open_face") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.downstream_open_face = pb; }
 		else if(key=="base_height") { if(!uq.empty()) c.z_si_offset = (float)atof(val.c_str()); }
 		else if(key=="memory_lbm") { if(!uq.empty()) c.memory = (uint)atoi(val.c_str()); }
@@ -493,6 +512,10 @@ int main(int argc, char** argv) {
 		const string lp = (std::filesystem::path(c.parent)/"proj_temp"/(now_str("%Y%m%d%H%M%S")+"_lbm.log")).string();
 		if(!ec&&!c.dry_run) { g_log.open(lp); if(g_log.is_open()) println("| Console log     | "+lp+" |"); }
 	}
+	if(c.nwp_mode) { // FX/setup.cpp:3446-3475: the reference asks on stdin; with no terminal attached an empty answer means "continue"
+		string v = c.validation; std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+		if(v!="pass"&&v!="true"&&v!="1") { println("|-----------------------------------------------------------------------------|"); println("| WARNING: Validation status is '"+c.validation+"'. Pre-processing may be incomplete or invalid. |"); println("| Proceeding (non-interactive).                                               |"); }
+	}
 	if(c.Dx*c.Dy*c.Dz>1u) println("| NOTE: n_gpu>1: this executable drives one GPU; multi-GPU runs use the torch.distributed launcher (latticeurbanwind_amd.distributed). Grid sizing still honours n_gpu. |");
 
 	println("|"+string(CONSOLE_WIDTH-2u, ' ')+"|");
@@ -501,6 +524,9 @@ int main(int argc, char** argv) {
 	println("| Casename / Time | "+alignr(40u, c.caseName)+alignr(17u, c.datetime)+" |");
 	println("| Basement Height | "+alignr(55u, fmtf(c.z_si_offset))+" m |");
 	println("| SI Size (m)     | "+alignr(12u, " X:")+alignl(11u, fmtf(c.si_x))+"   Y: "+alignl(11u, fmtf(c.si_y))+"   Z: "+alignl(11u, fmtf(c.si_z))+" | ");
+	if(c.nwp_mode) { println("| Downstream BC   | "+alignr(57u, c.downstream_bc)+" |"); println("| Normal Yaw      | "+alignr(53u, c.downstream_bc_yaw)+" deg |"); }
+	else { println("| Downstream BC   | "+alignr(57u, "auto by angle (dominant axis)")+" |"); println("| Normal Yaw      | "+alignr(57u, "auto by angle list")+" |"); }
+	println("| Downstream Open | "+alignr(57u, c.downstream_open_face ? string("true") : string("false"))+" |");
 	println("| GPU Decompose   | "+alignr(49u, to_string_u(c.Dx))+", "+alignr(2u, to_string_u(c.Dy))+", "+alignr(2u, to_string_u(c.Dz))+" |");
 	println("| Run Steps       | "+alignr(57u, c.run_nstep_override>0ull ? to_string_u(c.run_nstep_override)+" (run_nstep)" : string("20001 (default)"))+" |");
 	println("| DDF storage     | "+alignr(57u, c.fp16c ? string("FP16C (as the shipped reference build)") : string("FP32"))+" |");
@@ -521,7 +547,16 @@ int main(int argc, char** argv) {
 		else println("| GPU Estimate    | "+alignr(57u, to_string_u(c.Dx*c.Dy*c.Dz)+"x "+to_string_u(core)+" MB")+" |");
 	}
 	std::vector<float> prof_z, prof_u;
-	if(c.dataset_mode) {
+	SurfData surf;
+	if(c.nwp_mode) { // FX/setup.cpp:3600-3650
+		const string csv = c.parent+"/proj_temp/SurfData_"+c.datetime+".csv";
+		if(!read_surfdata_csv(csv, surf)) println("ERROR: could not open CSV "+csv);
+		for(const string& w : surf.warnings) println(w);
+		if(surf.rows.empty()) fatal("| ERROR: no inlet samples when computing si_ref_u. Aborting...                |");
+		float max_u = 0.0f;
+		for(const SurfSample& sm : surf.rows) { const float speed = std::sqrt(sm.u.x*sm.u.x+sm.u.y*sm.u.y+sm.u.z*sm.u.z); if(speed>max_u) max_u = speed; }
+		si_ref_u = max_u;
+	} else if(c.dataset_mode) {
 		if(c.inflow_list.empty()) fatal("| ERROR: dataset generation requires inflow list (inflow=[...]).              |");
 		if(c.angle_list.empty()) fatal("| ERROR: dataset generation requires angle list (angle=[...]).                |");
 		si_ref_u = *std::max_element(c.inflow_list.begin(), c.inflow_list.end());
@@ -578,10 +613,17 @@ int main(int argc, char** argv) {
 		G.sponge_inv_tau_lbmu = c.sponge_tau_s>0.0f ? dt_si/c.sponge_tau_s : 0.0f;
 		G.top_sponge_active = top_sponge_grid_extend&&c.sponge_tau_s>0.0f&&c.sponge_ref_mode==0&&Nz_core>2u;
 	};
-	update_coriolis(); update_buffer_nudging("+y"); update_top_sponge();
-	print_kv_row("Buffer nudging", G.buffer_nudging_active ? "enabled (downstream face auto by angle)" : "disabled");
+	if(c.nwp_mode) {
+		println("| SI Reference U  | "+alignl(7u, fmtf(si_ref_u))+alignl(50u, "m/s")+" |");
+		println("| LBM Reference U | "+alignl(7u, fmtf(lbm_ref_u))+alignl(50u, "(Nondimensionalized)")+" |");
+		if(surf.has_T) println("| Temperature BC  | T column present: ignored (thermal lattice is outside this build)  |");
+	}
+	update_coriolis(); update_buffer_nudging(c.nwp_mode ? c.downstream_bc : string("+y")); update_top_sponge();
+	if(c.nwp_mode&&c.enable_coriolis) { print_kv_row("Coriolis", "enabled. center(lon,lat)=("+to_string_fd(0.5f*(c.cut_lon[0]+c.cut_lon[1]), 6u)+", "+to_string_fd(0.5f*(c.cut_lat[0]+c.cut_lat[1]), 6u)+") deg"); print_kv_row("", "Omega(lbmu)=("+to_string_fd(omega[0], 8u)+", "+to_string_fd(omega[1], 8u)+", "+to_string_fd(omega[2], 8u)+") per step"); }
+	else if(c.nwp_mode) print_kv_row("Coriolis", "disabled by 'coriolis_term' setting in .luw");
+	print_kv_row("Buffer nudging", G.buffer_nudging_active ? (c.nwp_mode ? "enabled" : "enabled (downstream face auto by angle)") : "disabled");
 	print_kv_row("", "Nbuf="+to_string_u((ulong)G.buffer_n_cells)+" cells, tau_s="+to_string_fd(c.buffer_tau_s, 6u)+" s");
-	print_kv_row("", "inv_tau_lbmu="+to_string_fd(G.buffer_inv_tau_lbmu, 8u)+", downstream_face_id=auto, nudge_vertical="+to_string_u((ulong)G.buffer_nudge_vertical));
+	print_kv_row("", "inv_tau_lbmu="+to_string_fd(G.buffer_inv_tau_lbmu, 8u)+", downstream_face_id="+(c.nwp_mode ? to_string_u((ulong)G.buffer_downstream_face_id) : string("auto"))+", nudge_vertical="+to_string_u((ulong)G.buffer_nudge_vertical));
 	print_kv_row("Top sponge", G.top_sponge_active ? "enabled" : "disabled");
 	print_kv_row("", "Nsponge="+to_string_u((ulong)G.sponge_n_cells)+" cells, tau_s="+to_string_fd(c.sponge_tau_s, 6u)+" s");
 	print_kv_row("", "inv_tau_lbmu="+to_string_fd(G.sponge_inv_tau_lbmu, 8u)+", ref_mode="+std::to_string(c.sponge_ref_mode));
@@ -663,7 +705,8 @@ int main(int argc, char** argv) {
 	// ---- cases
 	struct Case { float inflow_si, angle_deg; };
 	std::vector<Case> cases;
-	if(c.dataset_mode) { for(const float in : c.inflow_list) for(const float an : c.angle_list) cases.push_back({in, an}); }
+	if(c.nwp_mode) cases.push_back({0.0f, 0.0f});
+	else if(c.dataset_mode) { for(const float in : c.inflow_list) for(const float an : c.angle_list) cases.push_back({in, an}); }
 	else for(const float an : c.angle_list) cases.push_back({0.0f, an});
 	const ulong N = (ulong)Nx*Ny*Nz;
 	uint case_index = 0u;
@@ -673,7 +716,8 @@ int main(int argc, char** argv) {
 		float dir_x = -sinf(angle_rad), dir_y = -cosf(angle_rad);
 		float uin[3] = {0.0f, 0.0f, 0.0f};
 		string vtk_prefix;
-		if(c.dataset_mode) { // FX/setup.cpp:5690-5740
+		if(c.nwp_mode) vtk_prefix = "";
+		else if(c.dataset_mode) { // FX/setup.cpp:5690-5740
 			si_ref_u = cs.inflow_si; u_scale = lbm_ref_u/si_ref_u;
 			units.set_m_kg_s_K((float)Ny, lbm_ref_u, 1.0f, 1.0f, c.si_y, si_ref_u, si_rho, 293.15f);
 			lbm_nu = units.nu(si_nu);
@@ -691,10 +735,10 @@ int main(int argc, char** argv) {
 			println("| Profile case    | "+alignr(57u, to_string_u(case_index)+"/"+to_string_u(cases.size())+" (remaining "+to_string_u(cases.size()-case_index)+")")+" |");
 			println("| Angle           | "+alignr(57u, format_tag(cs.angle_deg)+" deg")+" |");
 		}
-		println("| SI Reference U  | "+alignr(57u, format_tag(si_ref_u)+" m/s")+" |");
-		const string case_bc = bc_from_dir(dir_x, dir_y);
+		if(!c.nwp_mode) println("| SI Reference U  | "+alignr(57u, format_tag(si_ref_u)+" m/s")+" |");
+		const string case_bc = c.nwp_mode ? c.downstream_bc : bc_from_dir(dir_x, dir_y);
 		print_section_title("DEVICE INFORMATION");
-		print_kv_row("Downstream BC", case_bc+(c.dataset_mode ? " (auto from batch angle)" : " (auto from profile angle)"));
+		if(!c.nwp_mode) print_kv_row("Downstream BC", case_bc+(c.dataset_mode ? " (auto from batch angle)" : " (auto from profile angle)"));
 		update_buffer_nudging(case_bc); update_top_sponge();
 
 		// host state of this case
@@ -713,7 +757,76 @@ int main(int argc, char** argv) {
 		print_section_title("BUILD BOUNDARY CONDITIONS");
 		auto is_downstream = [&](const uint x, const uint y) { return case_bc=="+y" ? y==Ny-1u : case_bc=="-y" ? y==0u : case_bc=="+x" ? x==Nx-1u : case_bc=="-x" ? x==0u : false; };
 		std::atomic<ulong> mapped{0ull}, terrain_solid{0ull}, outlet{0ull};
-		if(c.profile_mode) { // FX/setup.cpp:5914-5995
+		HostLattice HL; HL.Nx = Nx; HL.Ny = Ny; HL.Nz = Nz; HL.flags = flags.data(); HL.u = u.data();
+		auto report_flux = [&](const FluxReport& fr) { // FX/fluxcorrection.cpp:180-192
+			println("| Flux correction | S_in="+to_string_dd(fr.S_in, 3u)+", S_out="+to_string_dd(fr.S_out, 3u)+", net_before="+to_string_dd(fr.net_before, 3u)+" |");
+			println("| Flux correction | avg_dU="+to_string_dd(fr.delta, 3u)+" m/s, corrected="+to_string_u(fr.corrected)+", net_after="+to_string_dd(fr.net_after, 3u)+" |");
+			println("| Flux correction | per-face dU: Xn="+to_string_dd(fr.face_avg[0], 3u)+", Xp="+to_string_dd(fr.face_avg[1], 3u)+", Yn="+to_string_dd(fr.face_avg[2], 3u)+", Yp="+to_string_dd(fr.face_avg[3], 3u)+", Zp="+to_string_dd(fr.face_avg[4], 3u)+" m/s |");
+		};
+		if(c.nwp_mode) { // FX/setup.cpp:4931-5632
+			const V3 org = HL.position(0u, 0u, 0u);
+			std::vector<SurfSample> smp; smp.reserve(surf.rows.size()); // SI -> lattice units (:3963-3979), then shifted to cell-centre coordinates (:4940-4946)
+			for(const SurfSample& r : surf.rows) {
+				SurfSample q; q.patch = r.patch; q.T = 1.0f;
+				q.p.x = units.x(r.p.x); q.p.y = units.x(r.p.y); q.p.z = units.x(r.p.z);
+				q.u.x = r.u.x*u_scale; q.u.y = r.u.y*u_scale; q.u.z = r.u.z*u_scale;
+				q.p.x += org.x; q.p.y += org.y; q.p.z += org.z;
+				smp.push_back(q);
+			}
+			const float z0_lbmu = org.z;
+			println("| CDF data loaded | "+alignl(57u, to_string_u(surf.rows.size()))+" |");
+			std::function<V3(uint, uint, uint)> downstream_fill;
+			SampleCloud cloud; std::unique_ptr<KnnSurfaceInterpolator> knn;
+			std::vector<PatchField2D> face_fields(6);
+			if(surf.has_patch) { // patch-driven 2-D mapping, :5120-5267
+				ulong counts[6] = {0, 0, 0, 0, 0, 0};
+				for(const SurfSample& q : smp) if(q.patch>=0&&q.patch<=5) counts[q.patch]++;
+				println("| Patch samples   | "+alignr(8u, string(patch_name(PATCH_BOTTOM)))+" = "+alignl(47u, to_string_u(counts[PATCH_BOTTOM]))+" |");
+				for(int pt=PATCH_TOP; pt<=PATCH_EAST; ++pt) {
+					face_fields[(size_t)pt].build(smp, pt, [](const SurfSample& q) { return q.u; }, V3{});
+					println("|                 | "+alignr(8u, string(patch_name(pt)))+" = "+alignl(47u, to_string_u(counts[pt]))+" |");
+				}
+				PatchField2D ground; V3 gdef; gdef.x = z0_lbmu;
+				ground.build(smp, PATCH_BOTTOM, [](const SurfSample& q) { V3 v; v.x = q.p.z; return v; }, gdef);
+				const PatchBcCounts pc = apply_patch_boundaries(HL, face_fields, ground, case_bc, c.downstream_open_face, side_ref_z_cap);
+				if(pc.terrain_clipped>0ull) println("| Terrain clip    | below-terrain cells forced to solid: "+to_string_u(pc.terrain_clipped)+"                    |");
+				println("| Velocity BC     | patch-driven 2D mapping: "+to_string_u(pc.mapped)+" cells                 |");
+				if(pc.grounded>0ull) println("|                 | underground no-slip cells: "+to_string_u(pc.grounded)+"                     |");
+				if(pc.below_support>0ull) println("|                 | side cells below terrain support -> solid: "+to_string_u(pc.below_support)+"     |");
+				if(pc.outlet>0ull) println("|                 | downstream outlet cells: "+to_string_u(pc.outlet)+" (no fixed velocity)        |");
+				if(pc.missing>0ull) println("|                 | WARNING: missing patch samples for "+to_string_u(pc.missing)+" cells         |");
+				mapped = pc.mapped; outlet = pc.outlet; terrain_solid = pc.grounded+pc.below_support+pc.terrain_clipped;
+				const int dp = downstream_to_patch(case_bc);
+				downstream_fill = [&face_fields, HL, dp](const uint x, const uint y, const uint z) -> V3 {
+					if(dp<PATCH_TOP||dp>PATCH_EAST||!face_fields[(size_t)dp].has_samples()) return V3{};
+					float a, b; if(!patch_plane_coords(dp, HL.position(x, y, z), a, b)) return V3{};
+					return face_fields[(size_t)dp].eval(a, b);
+				};
+			} else {
+				cloud.P.reserve(smp.size()); cloud.U.reserve(smp.size());
+				for(const SurfSample& q : smp) { cloud.P.push_back(q.p); cloud.U.push_back(q.u); }
+				std::function<V3(const V3&)> inlet;
+				if(c.use_high_order) { // :5354-5359, FX/interpolation_hd.cpp
+					knn.reset(new KnnSurfaceInterpolator(cloud));
+					const float z_base = units.x(c.z_si_offset)+z0_lbmu;
+					const KnnSurfaceInterpolator* k = knn.get();
+					inlet = [k, z_base](const V3& p) -> V3 { return p.z<z_base ? V3{} : k->eval(p); };
+					println("| using high order surface based inlet interpolator (HD)");
+				} else { // :5555-5558, FX/interpolation.cpp
+					const float z_off = units.x(c.z_si_offset);
+					const SampleCloud* cl = &cloud;
+					inlet = [cl, z0_lbmu, z_off](const V3& p) -> V3 { return p.z<z0_lbmu+z_off ? V3{} : nearest_sample_velocity(*cl, p); };
+				}
+				println("| Threads used for BC connection: "+to_string_u(bc_worker_threads())+"                                 |");
+				mapped = apply_cloud_boundaries(HL, case_bc, c.downstream_open_face, side_ref_z_cap, inlet);
+				downstream_fill = [inlet, HL](const uint x, const uint y, const uint z) -> V3 { return inlet(HL.position(x, y, z)); };
+			}
+			print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
+			if(c.flux_correction) {
+				print_kv_row("Flux correction", "starting. Time: ["+now_str()+"]");
+				report_flux(apply_flux_correction(HL, case_bc, downstream_fill));
+			} else print_kv_row("Flux correction", "skipped. Set flux_correction=true to enable");
+		} else if(c.profile_mode) { // FX/setup.cpp:5914-5995
 			parallel_for(N, [&](const ulong n) {
 				const uint z = (uint)(n/((ulong)Nx*Ny));
 				if((flags[n]&TYPE_S)!=0u) return;
@@ -752,7 +865,18 @@ int main(int argc, char** argv) {
 				}
 			}
 		}
-		print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
+		if(!c.nwp_mode) print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
+		if(c.profile_mode) { // FX/setup.cpp:6087-6119
+			if(c.flux_correction) {
+				print_kv_row("Flux correction", "starting. Time: ["+now_str()+"]");
+				report_flux(apply_flux_correction(HL, case_bc, [&](const uint x, const uint y, const uint z) -> V3 {
+					float pze = pos_z_of(z);
+					if((x==0u||x==Nx-1u||y==0u||y==Ny-1u)&&side_ref_z_cap>=0&&(int)z>side_ref_z_cap) pze = pos_z_of((uint)side_ref_z_cap);
+					const float um = profile_speed(pze, flat_ground);
+					V3 v; v.x = dir_x*um; v.y = dir_y*um; v.z = 0.0f; return v;
+				}));
+			} else print_kv_row("Flux correction", "skipped. Set flux_correction=true to enable");
+		}
 		VkTables vk; bool vk_on = false;
 		if(c.vk_enable) { // make_vk_runtime_config + VonKarmanInletUpdater::initialize, FX/setup.cpp:3762-3799,417-534
 			VkRuntimeConfig vc;

@@ -11,6 +11,9 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   B  nudging + sponge OFF                                      (Nz = 24)
   L  "laminar" micro-domain (cell 1e-5 m -> nu_lbm ~ 0.03), nudging + sponge OFF, uniform inflow
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
+  N1..N4  *.luw (NWP) decks on the case-B geometry with synthetic SurfData CSVs: N1 patch-driven 2-D mapping + flux
+     correction + Coriolis; N2 KNN-HD (high_order) + flux correction; N3 nearest-sample + nudging + sponge + open
+     downstream face; N4 patch mapping with an open downstream face
   G,H case B with a 'city' STL (aligned / off-grid / rotated boxes, roofs, pyramid, floating tetrahedron, overlapping
      boxes) at cell 2 m and 2.5 m: voxeliser goldens
 """
@@ -110,6 +113,70 @@ def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64,
     with open(os.path.join(d, "conf.luwpf"), "w") as f:
         f.write("\n".join(deck) + "\n")
 
+def wind(x, y, z):
+    """smooth synthetic NWP-like field (SI): veering log-ish profile with horizontal variation and a weak vertical component"""
+    import math
+    zz = max(z - 4.0, 0.05)
+    speed = 1.2 * math.log(1.0 + zz / 0.5) * (1.0 + 0.06 * math.sin(0.05 * x) + 0.04 * math.cos(0.07 * y))
+    th = math.radians(12.0 + 0.25 * z + 2.0 * math.sin(0.03 * y))
+    return speed * math.cos(th), speed * math.sin(th), 0.03 * math.sin(0.04 * x + 0.06 * y) * min(zz / 20.0, 1.0)
+
+def write_luw_case(root, name, kind, extra, nstep=16, unsteady=8, purge=4):
+    """*.luw (NWP) case on the CaseB geometry: boundaries from proj_temp/SurfData_<datetime>.csv.
+    kind = "patch" (X,Y,Z,u,v,w,patch: patch-driven 2-D mapping incl. a bottom patch with gentle terrain),
+           "cloud" (X,Y,Z,u,v,w: nearest-sample or, with high_order = true, KNN-HD interpolation)"""
+    import math
+    d = os.path.join(root, name)
+    os.makedirs(os.path.join(d, "proj_temp"), exist_ok=True)
+    dims = (96, 80, 48); cell = 2.0
+    tris = box_tris(0, dims[0], 0, dims[1], -4.0, 0.0) + box_tris(30.3, 46.7, 28.6, 51.4, 0.0, 19.3)
+    write_stl(os.path.join(d, "proj_temp", name + "_DG.stl"), tris)
+    Lx, Ly, Lz = (dims[0] - cell), (dims[1] - cell), (dims[2] - cell)     # cell centres span [0, (N-1)*cell] in SI sample coordinates
+    def frange(a, b, h):
+        n = int(round((b - a) / h)); return [a + (b - a) * i / n for i in range(n + 1)]
+    rows = []
+    xs, ys = frange(0.0, Lx, 3.1), frange(0.0, Ly, 2.9)
+    def terrain(x, y): return 4.4 + 0.9 * math.exp(-((x - 20.0) ** 2 + (y - 60.0) ** 2) / 300.0)
+    zs_side = lambda zg: [zg + (Lz - zg) * (i / 17.0) ** 1.3 for i in range(18)]    # stretched, starts at the terrain
+    if kind == "patch":
+        for x in xs:
+            for y in ys: rows.append((x, y, terrain(x, y), 0.0, 0.0, 0.0, 0))
+        for x in xs:
+            for y in ys: rows.append((x, y, Lz) + wind(x, y, Lz) + (1,))
+        for x in xs:
+            for yy, pid in ((0.0, 2), (Ly, 3)):
+                for z in zs_side(terrain(x, yy)): rows.append((x, yy, z) + wind(x, yy, z) + (pid,))
+        for y in ys:
+            for xx, pid in ((0.0, 4), (Lx, 5)):
+                for z in zs_side(terrain(xx, y)): rows.append((xx, y, z) + wind(xx, y, z) + (pid,))
+        header = "X,Y,Z,u,v,w,patch"
+    else:
+        zs = frange(0.0, Lz, 2.7)
+        for x in xs:
+            for y in ys: rows.append((x, y, Lz) + wind(x, y, Lz))
+        for x in xs:
+            for yy in (0.0, Ly):
+                for z in zs: rows.append((x, yy, z) + wind(x, yy, z))
+        for y in ys:
+            for xx in (0.0, Lx):
+                for z in zs: rows.append((xx, y, z) + wind(xx, y, z))
+        header = "X,Y,Z,u,v,w"
+    with open(os.path.join(d, "proj_temp", "SurfData_20260101120000.csv"), "w") as f:
+        f.write(header + "\n")
+        for r in rows:
+            f.write(",".join(("%d" % v) if (i == 6) else ("%.6f" % v) for i, v in enumerate(r)) + "\n")
+    deck = [
+        "// LUW deck (synthetic NWP-mode case, generated by tests/golden/make_refcases.py)",
+        "casename = %s" % name, "datetime = 20260101120000",
+        "cut_lon_manual = [121.30, 121.60]", "cut_lat_manual = [31.10, 31.40]",
+        "si_x_cfd = [0.000000, %.9g]" % dims[0], "si_y_cfd = [0.000000, %.9g]" % dims[1], "si_z_cfd = [0.000000, %.9g]" % dims[2],
+        "base_height = 4", "n_gpu = [1, 1, 1]", 'mesh_control = "cell_size"', "cell_size = %.9g" % cell,
+        "validation = pass", 'downstream_bc = "+x"', "downstream_bc_yaw = 0", "turb_inflow_enable = false",
+        "run_nstep = %d" % nstep, "unsteady_output = %d" % unsteady, "purge_avg = %d" % purge,
+    ] + extra
+    with open(os.path.join(d, "conf.luw"), "w") as f:
+        f.write("\n".join(deck) + "\n")
+
 if __name__ == "__main__":
     root = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(os.path.dirname(os.path.abspath(__file__)), "refcases")
     write_case(root, "CaseA", 1.0, ["enable_buffer_nudging = true", "buffer_thickness_m = 8", "buffer_tau_s = 3",
@@ -122,6 +189,13 @@ if __name__ == "__main__":
     # G, H: voxeliser cases ("city" geometry) at cell 2 m (mesh scale 0.5, exact) and cell 2.5 m (scale 0.4, inexact)
     write_case(root, "CaseG", 1.0, off, building="city", nstep=16)
     write_case(root, "CaseH", 1.0, off, building="city", nstep=16, cell=2.5)
+    # N1..N4: *.luw (NWP) mode, boundaries from a synthetic SurfData CSV
+    write_luw_case(root, "CaseN1", "patch", off + ["high_order = false", "flux_correction = true", "coriolis_term = true"])
+    write_luw_case(root, "CaseN2", "cloud", off + ["high_order = true", "flux_correction = true", "coriolis_term = false"])
+    write_luw_case(root, "CaseN3", "cloud", ["enable_buffer_nudging = true", "buffer_thickness_m = 8", "buffer_tau_s = 3", "enable_top_sponge = true",
+                                             "sponge_thickness_m = 8", "sponge_tau_s = 2", "high_order = false", "flux_correction = false",
+                                             "coriolis_term = false", "downstream_open_face = true"])
+    write_luw_case(root, "CaseN4", "patch", off + ["high_order = true", "flux_correction = false", "coriolis_term = false", "downstream_open_face = true"])
     # performance decks for timing the reference itself on the GPU box (not fixtures: generated on demand)
     if "--perf" in sys.argv:
         write_case(root, "Perf512", 1.0, off, dims=(1024, 1024, 1024), building=False, nstep=300, unsteady=0, purge=0)

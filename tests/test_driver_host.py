@@ -115,7 +115,37 @@ def test_deck_grammar(driver, tmp_path):
     assert "126, 125, 17" in out and "Top sponge | disabled" in out and "Buffer nudging | disabled" in out and "von-Karman" not in out
 
 
-def test_unsupported_mode_is_announced(driver, tmp_path):
-    deck = str(tmp_path / "x.luw"); open(deck, "w").write("casename = x\n")
-    r = subprocess.run([driver, deck], capture_output=True, text=True)
-    assert r.returncode != 0 and "not part of this build" in r.stdout
+def test_luw_deck_without_surfdata_fails_loudly(driver, tmp_path):
+    deck = str(tmp_path / "x.luw"); open(deck, "w").write("casename = x\ndatetime = 20260101120000\nsi_x_cfd = [0, 96]\nsi_y_cfd = [0, 80]\nsi_z_cfd = [0, 48]\n")
+    r = subprocess.run([driver, deck, "--dry-run"], capture_output=True, text=True)
+    assert r.returncode != 0 and "could not open CSV" in r.stdout and "no inlet samples" in r.stdout
+
+
+@pytest.mark.parametrize("case", ["CaseN1", "CaseN2", "CaseN3", "CaseN4"])
+def test_nwp_boundary_builders_against_real_reference_fields(driver, tmp_path, case):
+    """*.luw host stage on CPU (SurfData reader, patch-driven 2-D mapping / KNN-HD / nearest-sample fill, terrain clip, flux
+    correction): TYPE_E cells keep the velocity the builders wrote, so the first u output of the REAL reference shows their
+    result; the driver's initial state must equal it bit for bit on the side faces.  (--dry-run voxelises with the IEEE host
+    restatement, whose mask can differ from the device's on lattice-plane faces: cells solid in either mask are skipped.)"""
+    deck = os.path.join(GOLD, "refcases", case, "conf.luw")
+    dump = str(tmp_path / "setup.bin")
+    out = run(driver, deck, "--dry-run", "--dump-setup", dump)
+    d = read_dump(dump)
+    gold = np.load(os.path.join(GOLD, "ref_fp32_%s.npz" % case))
+    Nx, Ny, Nz, Nzc = d["Nx"], d["Ny"], d["Nz"], d["Nz_core"]
+    assert tuple(gold["dims"]) == (Nx, Ny, Nzc)
+    u = (d["u"].reshape(3, Nz, Ny, Nx)[:, :Nzc] * np.float32(d["si_u"])).astype(np.float32).transpose(1, 2, 3, 0)
+    fl = d["flags"].reshape(Nz, Ny, Nx)[:Nzc]
+    side = np.zeros(fl.shape, bool); side[:, 0, :] = side[:, -1, :] = side[:, :, 0] = side[:, :, -1] = True
+    if Nzc == Nz: side[-1] = True                                     # the top face too when it is part of the output
+    m = side & ((fl & 1) == 0) & ~gold["solid"]
+    assert m.sum() > 3000 and np.array_equal((fl[m] & 2), np.full(int(m.sum()), 2, np.uint8))
+    assert np.array_equal(u[m], gold["u8"][m]), "%d boundary cells differ" % int((u[m] != gold["u8"][m]).any(-1).sum())
+    # console numbers of the reference's host stage
+    ref = open(os.path.join(GOLD, "ref_fp32_%s.console.txt" % case)).read()
+    norm = lambda txt: [" ".join(l.strip().strip("|").split()) for l in txt.splitlines()]
+    mine_all, theirs_all = norm(out), norm(ref)
+    for frag in ("Unit Conversion: 1 cell =", "CDF data loaded", "S_in=", "corrected=", "per-face dU", "patch-driven 2D mapping", "bottom =", "top =", "south =", "north =", "west =", "east ="):
+        mine = sorted(l for l in mine_all if frag in l)
+        theirs = sorted(l for l in theirs_all if frag in l)
+        assert mine == theirs, (frag, mine, theirs)

@@ -75,7 +75,12 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
     ("CaseA", "fp32", "ref_fp32_CaseA"), ("CaseB", "fp32", "ref_fp32_CaseB"), ("CaseL", "fp32", "ref_fp32_CaseL"),
     ("CaseV", "fp32", "ref_fp32_CaseV"), ("CaseG", "fp32", "ref_fp32_CaseG"), ("CaseH", "fp32", "ref_fp32_CaseH"),
     ("CaseA", "fp16c", "ref_shipped_CaseA"), ("CaseV", "fp16c", "ref_shipped_CaseV"),
-    ("CaseG", "fp16c", "ref_shipped_CaseG"), ("CaseH", "fp16c", "ref_shipped_CaseH")])
+    ("CaseG", "fp16c", "ref_shipped_CaseG"), ("CaseH", "fp16c", "ref_shipped_CaseH"),
+    # *.luw (NWP) decks: SurfData CSV -> patch-driven 2-D mapping / KNN-HD / nearest-sample boundaries, flux correction,
+    # terrain clip, Coriolis, open downstream face
+    ("CaseN1", "fp32", "ref_fp32_CaseN1"), ("CaseN2", "fp32", "ref_fp32_CaseN2"), ("CaseN3", "fp32", "ref_fp32_CaseN3"),
+    ("CaseN4", "fp32", "ref_fp32_CaseN4"), ("CaseN1", "fp16c", "ref_shipped_CaseN1"), ("CaseN2", "fp16c", "ref_shipped_CaseN2"),
+    ("CaseN3", "fp16c", "ref_shipped_CaseN3"), ("CaseN4", "fp16c", "ref_shipped_CaseN4")])
 def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture):
     """deck in, VTK out, nothing injected: the driver's files against the files the REAL reference wrote for the same deck on
     an MI355X (geometry voxelised on the device, BC fill, VK inlet, run loop, averaging, writers).  Gates as in
@@ -84,7 +89,8 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
     proj = str(tmp_path / case)
     shutil.copytree(os.path.join(GOLD, "refcases", case), proj)
-    r = subprocess.run([DRIVER, os.path.join(proj, "conf.luwpf"), "--ddf", ddf], capture_output=True, text=True, timeout=600)
+    deck = glob.glob(os.path.join(proj, "conf.luw*"))[0]
+    r = subprocess.run([DRIVER, deck, "--ddf", ddf], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     gold = np.load(os.path.join(GOLD, fixture + ".npz"))
     vt = os.path.join(proj, "RESULTS", "vtk")
@@ -97,8 +103,15 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     fluid = ~solid
     import re
     # SI <-> lattice factors exactly as the set-up restatement computes them (units.si_u(1), units.si_rho(1))
-    s = setup_profile.setup_profile_case(os.path.join(proj, "conf.luwpf"), solid_mask=gold["solid"])
-    fac = s["si_u_factor"]
+    if deck.endswith(".luwpf"):
+        s = setup_profile.setup_profile_case(deck, solid_mask=gold["solid"])
+        fac, rho_fac = s["si_u_factor"], s["si_rho_factor"]
+    else:   # *.luw: si_ref_u = max |u| of the CSV (FX/setup.cpp:3617-3650); u_lbm = 0.1, rho_si = 1.225, unit_m = si_y / Ny
+        rows = np.loadtxt(glob.glob(os.path.join(proj, "proj_temp", "SurfData_*.csv"))[0], delimiter=",", skiprows=1, dtype=np.float32)
+        f32 = np.float32
+        si_ref_u = np.sqrt(rows[:, 3] * rows[:, 3] + rows[:, 4] * rows[:, 4] + rows[:, 5] * rows[:, 5]).max()
+        fac = f32(si_ref_u) / f32(0.1)
+        rho_fac = f32(1.225)
 
     def rmse(a, b):
         d = ((a - b) / fac)[fluid].astype(np.float64)
@@ -107,10 +120,14 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
         hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_u-%09d.vtk" % t))[0])
         e = rmse(ff["data"], gold["u%d" % t])
         assert e < gate, "u RMSE %.3e at t=%d" % (e, t)
+    if case != "CaseV":   # without the VK inlet, TYPE_E cells keep what the boundary builders wrote: bit-exact on the side faces
+        hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_u-%09d.vtk" % times[0]))[0])
+        side = np.zeros(solid.shape, bool); side[:, 0, :] = side[:, -1, :] = side[:, :, 0] = side[:, :, -1] = True
+        assert np.array_equal(ff["data"][side & fluid], gold["u%d" % times[0]][side & fluid]), "boundary velocities differ from the reference's"
     e = rmse(f["u_avg"], gold["u_avg"])
     assert e < (1e-4 if fp16c else 1e-6), "u_avg RMSE %.3e" % e
     hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_rho-%09d.vtk" % times[-1]))[0])
-    dr = np.abs((ff["data"][..., 0] - gold["rho%d" % times[-1]]) / s["si_rho_factor"])[fluid].max()
+    dr = np.abs((ff["data"][..., 0] - gold["rho%d" % times[-1]]) / rho_fac)[fluid].max()
     assert dr < (1e-2 if fp16c else 1e-4), "rho max diff %.3e" % dr
     # voxel count line of the console, as the reference prints it
     want = re.search(r"solid = (\d+), fluid = (\d+)", open(os.path.join(GOLD, fixture + ".console.txt")).read())
