@@ -99,10 +99,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU lattice (default 512 512 512)")
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU lattice (default 512 512 512; with N > 1 the default global lattice is the BASELINE tile, 2048x1024x512 on 8 GPUs)")
+    ap.add_argument("--n-gpu", type=int, nargs=3, default=None, help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 2 4 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
     args = ap.parse_args()
 
@@ -121,7 +123,7 @@ def main():
     fp16c = args.dtype == "fp16c"
     nu = 1.48e-7                                     # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
 
-    if world == 1:
+    if world == 1 and not args.force_distributed:
         lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields)
         fl, u, rho = channel_state(Nx, Ny, Nz)
         lbm.flags.data[:] = fl; lbm.u.data[:] = u; lbm.rho.data[:] = rho
@@ -136,12 +138,19 @@ def main():
         D = (1, 1, 1)
     else:
         import torch.distributed as dist
-        from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition
+        from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        D = choose_decomposition(world)
-        sim = DomainDecomposedLBM((Nx * D[0], Ny * D[1], Nz * D[2]), D, nu, fp16c=fp16c, kernel=kern, device=local_rank)
+        D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
+        if D[0] * D[1] * D[2] != world:
+            raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
+        # weak scaling: 512^3 cells per GPU.  Default global lattice = the BASELINE tile for this GPU count (8: 2048x1024x512)
+        gN = (Nx * D[0], Ny * D[1], Nz * D[2]) if args.size else tile_lattice(world)
+        if any(g % d for g, d in zip(gN, D)):
+            raise SystemExit("bench.py: lattice %s is not divisible by n_gpu %s" % (gN, D))
+        Nx, Ny, Nz = (g // d for g, d in zip(gN, D))          # per-GPU block (without halos)
+        sim = DomainDecomposedLBM(gN, D, nu, fp16c=fp16c, kernel=kern, device=local_rank)
         ox, oy, oz = sim.global_offset
-        fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, Nx * D[0], Ny * D[1], Nz * D[2])
+        fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN)
         sim.set_fields(fl, u, rho)
         sim.initialize()
         sim.run(args.warmup)
@@ -165,9 +174,11 @@ def main():
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d D3Q19 channel per GPU (BASELINE configs[1]), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky, %s DDFs, rho/u written %s"
-                       % (Nx, Ny, Nz, "FP16C" if fp16c else "FP32", "every step" if args.every_step_fields else "by the last step only"),
-                       "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "kernel": args.kernel,
+            "config": {"workload": "%s, log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky, %s DDFs, rho/u written %s"
+                       % (("%dx%dx%d D3Q19 channel (BASELINE configs[1])" % (Nx, Ny, Nz)) if world == 1 else
+                          ("%dx%dx%d D3Q19 channel tile (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU" % (Nx * D[0], Ny * D[1], Nz * D[2], Nx, Ny, Nz)),
+                          "FP16C" if fp16c else "FP32", "every step" if args.every_step_fields else "by the last step only"),
+                       "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "halo_exchange": (None if D == (1, 1, 1) else ("RCCL p2p, overlapped with the interior (x rows kept whole)" if sim.overlap else "RCCL p2p after the whole-box kernel (x split)")), "kernel": args.kernel,
                        "bytes_per_lup": bpl},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
@@ -182,10 +193,10 @@ def main():
             pr = json.load(open(prof))
             out["roofline"]["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_distributed:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_distributed:
         import torch.distributed as dist
         dist.destroy_process_group()
 

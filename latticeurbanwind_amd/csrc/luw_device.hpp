@@ -26,7 +26,7 @@ constexpr uint8_t TYPE_S = 0x01, TYPE_E = 0x02, TYPE_BO = 0x03, TYPE_SU = 0x38, 
 // Everything the kernels need besides the big arrays; passed by value (lands in SGPRs).
 struct KParams {
 	uint32_t Nx, Ny, Nz;      // local lattice
-	uint32_t Px;              // x pitch of every device array (multiple of 4, >= Nx)
+	uint32_t Px;              // x pitch of every device array (multiple of 64, >= Nx)
 	uint32_t Np;              // plane stride = Px*Ny*Nz (< 2^32, checked on the host)
 	uint32_t halo_x, halo_y, halo_z; // 1 if that axis is split over domains (cells 0 and N-1 are halo: FX/kernel.cpp:856-859)
 	int32_t Ox, Oy, Oz;

@@ -17,23 +17,46 @@ tests/test_gpu_halo.py).
 import numpy as np
 
 
-def choose_decomposition(world):
-    """n_gpu for a weak-scaled tile: 8 -> [4,2,1] (BASELINE configs[3]), 4 -> [2,2,1], 2 -> [2,1,1]"""
-    table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1), 16: (4, 4, 1)}
+def choose_decomposition(world, split_x=False):
+    """n_gpu and per-GPU lattice shape factors for a weak-scaled tile of 512^3 cells per GPU.
+
+    split_x=False (default): the memory-fastest axis is kept whole -- rows stay complete memory lines, the y/z boundary
+    shells are whole rows and the halo traffic hides behind the interior: 8 GPUs cover the 2048x1024x512 tile of
+    BASELINE configs[3] as n_gpu=[1,2,4] (local 2048x512x128).  split_x=True reproduces the deck's literal
+    n_gpu=[4,2,1] (local 512^3); with x split the step runs the whole box first and exchanges afterwards (measured on
+    MI355X, one rank with loopback halos: 3.76 ms sequential vs 4.20 ms with an x shell, vs 3.60 ms undivided).
+    Returns (D, global_lattice)."""
+    if split_x:
+        table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1), 16: (4, 4, 1)}
+    else:
+        table = {1: (1, 1, 1), 2: (1, 2, 1), 4: (1, 2, 2), 8: (1, 2, 4), 16: (1, 4, 4)}
     if world in table:
         return table[world]
     d = [1, 1, 1]
     n, ax = world, 0
     for p in (2, 3, 5, 7):
         while n % p == 0:
-            d[ax % 3] *= p; ax += 1; n //= p
+            d[(ax % 2) + 1 if not split_x else ax % 3] *= p; ax += 1; n //= p
     if n != 1:
-        d[0] *= n
+        d[1 if not split_x else 0] *= n
     return tuple(d)
+
+
+def tile_lattice(world):
+    """global lattice of the weak-scaled benchmark tile: 512^3 cells per GPU, growing x, then y, then x again
+    (1: 512^3 = BASELINE configs[1]; 2: 1024x512x512; 4: 1024x1024x512; 8: 2048x1024x512 = configs[3])"""
+    g = [512, 512, 512]
+    n, ax = world, 0
+    while n > 1 and n % 2 == 0:
+        g[(0, 1)[ax % 2]] *= 2; ax += 1; n //= 2
+    g[2] *= n
+    return tuple(g)
 
 
 class DomainLayout:
     """Pure host logic: where a rank sits, what it owns, whom it talks to (FX/lbm.cpp:1066-1073,1912-1931)."""
+
+    X_SHELL = 64   # thickness of the x boundary slabs: one memory line of cells (see shell_boxes)
 
     def __init__(self, global_N, D, rank):
         self.gN = tuple(int(v) for v in global_N)
@@ -65,8 +88,22 @@ class DomainLayout:
     def nonhalo_range(self, a):
         return (1, self.lN[a] - 1) if self.H[a] else (0, self.lN[a])
 
+    def shell_ranges(self, a):
+        """(low slab, high slab) of the boundary shell along a split axis.  y, z: the one cell layer next to the halo.
+        x: whole 64-cell blocks starting at the first owned cell -- a one-cell-wide x face would run one lane per wave and
+        touch a full memory line per value; a line-wide slab costs the same traffic per cell as the interior."""
+        lo, hi = self.nonhalo_range(a)
+        if a != 0:
+            return (lo, lo + 1), (hi - 1, hi)
+        first_end = min(lo + self.X_SHELL, hi)
+        last_start = max(lo + ((hi - 1 - lo) // self.X_SHELL) * self.X_SHELL, first_end)
+        return (lo, first_end), (last_start, hi)
+
     def interior_range(self, a):
-        return (2, self.lN[a] - 2) if self.H[a] else (0, self.lN[a])
+        if not self.H[a]:
+            return (0, self.lN[a])
+        low, high = self.shell_ranges(a)
+        return (low[1], high[0])
 
     def whole_box(self):
         r = [self.nonhalo_range(a) for a in range(3)]
@@ -81,8 +118,7 @@ class DomainLayout:
         boxes = []
         rng = [self.nonhalo_range(a) for a in range(3)]
         for a in self.split_axes():
-            lo, hi = self.nonhalo_range(a)
-            for s0, s1 in ((lo, lo + 1), (hi - 1, hi)):
+            for s0, s1 in self.shell_ranges(a):
                 r = list(rng)
                 r[a] = (s0, s1)
                 if all(e > s for s, e in r):
@@ -175,7 +211,7 @@ class HipDomain:
 class DomainDecomposedLBM:
     """The multi-domain `LBM` of the reference (FX/lbm.cpp:1057-1112,1221-1312) for THIS rank's domain."""
 
-    def __init__(self, global_N, D, nu, rank=None, backend=None, transport=None, overlap=True, **backend_kw):
+    def __init__(self, global_N, D, nu, rank=None, backend=None, transport=None, overlap=None, **backend_kw):
         if rank is None:
             import torch.distributed as dist
             rank = dist.get_rank()
@@ -184,6 +220,8 @@ class DomainDecomposedLBM:
         self.global_offset = self.layout.O
         self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
         self.transport = transport if transport is not None else TorchDistTransport(self.layout)
+        if overlap is None:      # shell/interior overlap pays when the shells are whole rows, i.e. x is not split (see choose_decomposition)
+            overlap = self.layout.D[0] == 1
         self.overlap = bool(overlap) and self.layout.can_overlap() and hasattr(self.backend, "comm")
         self.initialized = False
 
