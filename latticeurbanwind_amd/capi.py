@@ -8,6 +8,10 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "csrc", "libluw_core.so")
+if os.environ.get("LUW_CORE_LIB"):      # A/B builds of the same source (tools/ab_libs.sh): never a different implementation
+    _SO = os.environ["LUW_CORE_LIB"]
+if os.environ.get("LUW_CORE_LIB"):      # A/B builds of the same source (tools/): never a different implementation
+    _SO = os.environ["LUW_CORE_LIB"]
 _LIB = None
 
 LUW_OK = 0

@@ -71,16 +71,17 @@ __device__ __forceinline__ uint32_t float_to_half_custom_ref(const float x) { //
 __device__ __forceinline__ float half_to_float_custom(const uint32_t x) {
 	return __uint_as_float(((x<<16)&0x80000000u)|((x<<12)&0x07FFF000u))*0x1p+112f;
 }
-// Encode: the reference's integer formula, branch-free (its carry behaviour in the denormal range is not a plain
-// rounding of x, so it is kept literally; the shift is clamped so that e <= 100 yields 0 through the same expression).
+// Encode: the reference formula (FX/kernel.cpp:870-875) rounds |x| half away from zero onto the FP16C grid.  Above 2^-14
+// that is its integer expression: add 0x800, drop 12 mantissa bits, rebias the exponent (the carry runs into the exponent
+// field by itself).  Below, the code is the integer m = round_half_up(|x| 2^25): |x| 2^26 is a pure exponent shift (exact),
+// the conversion truncates, and (floor(2v)+1)>>1 = floor(v+1/2).  Equal to the literal formula for all 2^32 inputs (checked
+// exhaustively on the host and on the device, luw_selfcheck_fp16c_codec), including the carry cases next to 2^-14, the sign
+// of NaN payloads that carry into bit 31, and out-of-range exponents (4-bit wrap).
 __device__ __forceinline__ uint32_t float_to_half_custom(const float x) {
 	const uint32_t b = __float_as_uint(x)+0x00000800u;
-	const uint32_t a = b&0x7FFFFFFFu;
-	const uint32_t e = a>>23;
-	const uint32_t rn = ((a>>12)-(112u<<11))&0x7FFFu;                                  // e > 112
-	const uint32_t sh = min(124u-e, 31u);                                             // e < 113 (wraps harmlessly above: rd unused)
-	const uint32_t rd = (((0x007FF800u+(a&0x007FFFFFu))>>sh)+1u)>>1;                   // 100 < e < 113, and 0 for e <= 100
-	return ((b>>16)&0x8000u)|(e>112u ? rn : rd);
+	const uint32_t rn = (b>>12)-(112u<<11);
+	const uint32_t rd = ((uint32_t)(fabsf(x)*0x1p+26f)+1u)>>1;
+	return ((b>>16)&0x8000u)|((!(fabsf(x)<0x1p-14f) ? rn : rd)&0x7FFFu);
 }
 template<typename T> __device__ __forceinline__ float ddf_decode(const T v);
 template<> __device__ __forceinline__ float ddf_decode<float>(const float v) { return v; }
