@@ -1161,7 +1161,7 @@ int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t
 	if(!s->initialized) return fail(LUW_ERR_STATE, "luw_enqueue_stream_collide: call luw_initialize first");
 	if(int e = set_device(s)) return e;
 	const Box b = { x0, x1, y0, y1, z0, z1 };
-	if(!write_fields) s->fields_current = false;
+	s->fields_current = write_fields!=0; // callers cover the lattice with boxes of one step using the same flag
 	return launch_stream_collide(s, b, write_fields);
 }
 int luw_increment_time_step(luw_solver* s, uint64_t steps) {

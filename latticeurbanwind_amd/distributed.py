@@ -155,6 +155,18 @@ class TorchDistTransport:
             req.wait()
 
 
+class HostStagedTransport(TorchDistTransport):
+    """the same swap staged through host memory, for process groups that cannot move device memory (gloo): lets several
+    ranks share ONE GPU in tests; never the production path"""
+
+    def exchange(self, axis, send_p, send_m, recv_p, recv_m):
+        import torch
+        sp, sm = send_p.cpu(), send_m.cpu()                     # ordered after the pack kernel on the current stream
+        rp, rm = torch.empty_like(sp), torch.empty_like(sm)
+        super().exchange(axis, sp, sm, rp, rm)
+        recv_p.copy_(rp); recv_m.copy_(rm)
+
+
 class HipDomain:
     """One LBM domain on one GPU through the C-ABI; buffers are torch CUDA tensors, work is enqueued on torch streams."""
 
@@ -207,6 +219,31 @@ class HipDomain:
         self.lbm.u.read_from_device(); self.lbm.rho.read_from_device()
         return self.lbm.u.data, self.lbm.rho.data
 
+    # ---- what the deck run loop needs besides the step (latticeurbanwind_amd/run_deck.py)
+    def set_coriolis(self, ox, oy, oz): self.lbm.set_coriolis(ox, oy, oz)
+
+    def vk_attach(self, cell, face, point_data, mode_data, mode_count, stride, interp):
+        self.lbm.vk_inlet_attach(cell, face, point_data, mode_data, mode_count, stride, interp)
+
+    def vk_apply(self, stream):
+        self.lbm.set_stream(stream.cuda_stream)
+        self.lbm.vk_inlet_apply()
+
+    def stats_reset(self): self.lbm.stats_reset()
+
+    def stats_accumulate(self):
+        self.lbm.set_stream(self.compute.cuda_stream)
+        self.lbm.stats_accumulate()
+        self.compute.synchronize()
+
+    def stats_download(self):
+        self.lbm.set_stream(self.compute.cuda_stream)
+        return self.lbm.stats_download()
+
+    def close(self):
+        self.torch.cuda.synchronize(self.device)
+        self.lbm.close()
+
 
 class DomainDecomposedLBM:
     """The multi-domain `LBM` of the reference (FX/lbm.cpp:1057-1112,1221-1312) for THIS rank's domain."""
@@ -219,22 +256,27 @@ class DomainDecomposedLBM:
         self.lNx, self.lNy, self.lNz = self.layout.lN
         self.global_offset = self.layout.O
         self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
-        self.transport = transport if transport is not None else TorchDistTransport(self.layout)
+        if transport is None:
+            import torch.distributed as dist
+            staged = isinstance(self.backend, HipDomain) and dist.is_initialized() and dist.get_backend() == "gloo"
+            transport = HostStagedTransport(self.layout) if staged else TorchDistTransport(self.layout)
+        self.transport = transport
         if overlap is None:      # shell/interior overlap pays when the shells are whole rows, i.e. x is not split (see choose_decomposition)
             overlap = self.layout.D[0] == 1
         self.overlap = bool(overlap) and self.layout.can_overlap() and hasattr(self.backend, "comm")
         self.initialized = False
+        self.pre_step = None     # callable(stream) enqueued before every step's kernels (von-Karman inlet update)
 
     def set_fields(self, flags, u, rho):
         self.backend.set_fields(flags, u, rho)
 
-    def set_fields_from_global(self, gflags, gu, grho):
-        """cut this rank's box (incl. periodic halos) out of global (z,y,x) arrays"""
+    def set_fields_from_global(self, gflags, gu, grho=None):
+        """cut this rank's box (incl. periodic halos) out of global (z,y,x) arrays; grho=None means rho = 1"""
         ix, iy, iz = self.layout.local_slices()
         sel = np.ix_(iz, iy, ix)
         gN = self.layout.gN
         f = gflags.reshape(gN[2], gN[1], gN[0])[sel]
-        r = grho.reshape(gN[2], gN[1], gN[0])[sel]
+        r = grho.reshape(gN[2], gN[1], gN[0])[sel] if grho is not None else np.ones(f.shape, np.float32)
         u = np.stack([gu.reshape(3, gN[2], gN[1], gN[0])[c][sel] for c in range(3)])
         self.backend.set_fields(f.ravel(), u.ravel(), r.ravel())
 
@@ -279,7 +321,10 @@ class DomainDecomposedLBM:
             wf = (i + 1 == steps)
             if self.overlap:
                 comm, comp = b.comm, b.compute
-                comm.wait_stream(comp); comp.wait_stream(comm)         # step t needs all of step t-1
+                comp.wait_stream(comm)                                 # step t needs all of step t-1
+                if self.pre_step is not None:
+                    self.pre_step(comp)
+                comm.wait_stream(comp)
                 for box in lay.shell_boxes():
                     b.stream_collide(box, wf, comm)                    # boundary shell first ...
                 if timed:
@@ -292,6 +337,8 @@ class DomainDecomposedLBM:
                 self.communicate_fi(comm)
             else:
                 st = getattr(b, "compute", None)
+                if self.pre_step is not None:
+                    self.pre_step(st)
                 b.stream_collide(lay.whole_box(), wf, st)
                 self.communicate_fi(st)
             b.increment_time_step(1)

@@ -195,7 +195,7 @@ struct Config {
 	std::vector<float> inflow_list, angle_list;
 	// command line
 	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
-	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
+	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk, export_setup;
 };
 
 // memory model of the SHIPPED reference build (D3Q19 FP16C + FORCE_FIELD + TEMPERATURE + GRAPHICS), FX/lbm.cpp:188-228:
@@ -408,6 +408,7 @@ int main(int argc, char** argv) {
 		else if(a=="--sizing-only") { c.dry_run = true; c.sizing_only = true; } // stop after the derived numbers (no lattice-sized host arrays)
 		else if(a=="--dump-setup"&&i+1<argc) c.dump_setup = argv[++i];
 		else if(a=="--dump-vk"&&i+1<argc) c.dump_vk = argv[++i];
+		else if(a=="--export-setup"&&i+1<argc) c.export_setup = argv[++i]; // host stage only (voxelised on the GPU unless --dry-run), state + manifest per case for run_deck.py
 		else println("| WARNING: extra CLI arg ignored: "+a);
 	}
 	println(hr_plain());
@@ -516,7 +517,7 @@ int main(int argc, char** argv) {
 		string v = c.validation; std::transform(v.begin(), v.end(), v.begin(), ::tolower);
 		if(v!="pass"&&v!="true"&&v!="1") { println("|-----------------------------------------------------------------------------|"); println("| WARNING: Validation status is '"+c.validation+"'. Pre-processing may be incomplete or invalid. |"); println("| Proceeding (non-interactive).                                               |"); }
 	}
-	if(c.Dx*c.Dy*c.Dz>1u) println("| NOTE: n_gpu>1: this executable drives one GPU; multi-GPU runs use the torch.distributed launcher (latticeurbanwind_amd.distributed). Grid sizing still honours n_gpu. |");
+	if(c.Dx*c.Dy*c.Dz>1u&&c.export_setup.empty()&&!c.dry_run) println("| NOTE: n_gpu>1: this executable drives one GPU; launch `python -m torch.distributed.run --nproc-per-node "+to_string_u(c.Dx*c.Dy*c.Dz)+" -m latticeurbanwind_amd.run_deck <deck>` for the decomposed run (same host stage, one process per GPU, RCCL halos). |");
 
 	println("|"+string(CONSOLE_WIDTH-2u, ' ')+"|");
 	print_section_title("PARAMETER INFORMATION");
@@ -902,6 +903,40 @@ int main(int argc, char** argv) {
 			df.write((const char*)hdr, 16); df.write((const char*)fh, 32); df.write((const char*)ih, 32);
 			df.write((const char*)flags.data(), (std::streamsize)N); df.write((const char*)u.data(), (std::streamsize)(12ull*N));
 		}
+		const ulong total_steps = (c.run_nstep_override>0ull ? c.run_nstep_override : 20001ull)+(ulong)c.research_output_steps;
+		const ulong unsteady = (ulong)c.unsteady_output_interval;
+		const string results_vtk_dir = c.parent+"/RESULTS/vtk/";
+		const string vtk_dir = results_vtk_dir+vtk_prefix+c.datetime+"_raw_";
+		const uint Nz_out = (top_sponge_grid_extend&&Nz_core<Nz) ? Nz_core : Nz;
+		VtkGeom geom{Nx, Ny, Nz, Nz_out, units.si_x(1.0f), {0, 0, 0}};
+		{ const uint NN[3] = {Nx, Ny, Nz}; for(int k=0; k<3; k++) geom.origin[k] = geom.spacing*(0.5f-0.5f*(float)NN[k])+vtk_origin_shift[k]; }
+		const ulong avg_window = c.purge_avg_steps>0u ? std::min((ulong)c.purge_avg_steps, total_steps) : 0ull;
+		const ulong avg_stride = std::max((ulong)1u, (ulong)c.purge_avg_stride);
+		const ulong avg_start_t = avg_window>0ull ? total_steps-avg_window+1ull : ~0ull;
+		if(!c.export_setup.empty()) { // hand-over to the multi-GPU launcher (latticeurbanwind_amd/run_deck.py): everything the run loop needs, per case
+			std::filesystem::create_directories(c.export_setup);
+			const string base = c.export_setup+"/case"+to_string_u(case_index);
+			{ std::ofstream sf(base+".state", std::ios::binary); sf.write((const char*)flags.data(), (std::streamsize)N); sf.write((const char*)u.data(), (std::streamsize)(12ull*N)); }
+			if(vk_on) { std::ofstream vf(base+".vk", std::ios::binary); const uint64_t hdr[2] = {vk.point_count, vk.mode_count};
+				vf.write((const char*)hdr, 16); vf.write((const char*)vk.point_cell.data(), (std::streamsize)(8ull*vk.point_count)); vf.write((const char*)vk.point_face.data(), (std::streamsize)vk.point_count);
+				vf.write((const char*)vk.point_data.data(), (std::streamsize)(28ull*vk.point_count)); vf.write((const char*)vk.mode_data.data(), (std::streamsize)(200ull*vk.mode_count)); }
+			auto fbits = [](const float f) { uint32_t b; std::memcpy(&b, &f, 4); return to_string_u(b); }; // floats travel as bit patterns
+			auto jstr = [](const string& v) { string o = "\""; for(const char ch : v) { if(ch=='\\'||ch=='"') o += '\\'; o += ch; } return o+"\""; };
+			std::ofstream jf(base+".json");
+			jf << "{\n \"case_index\": " << case_index << ", \"case_count\": " << cases.size() << ",\n"
+			   << " \"N\": [" << Nx << ", " << Ny << ", " << Nz << "], \"Nz_out\": " << Nz_out << ", \"n_gpu\": [" << c.Dx << ", " << c.Dy << ", " << c.Dz << "], \"fp16c\": " << (c.fp16c ? 1 : 0) << ",\n"
+			   << " \"nu_bits\": " << fbits(lbm_nu) << ", \"omega_bits\": [" << fbits(omega[0]) << ", " << fbits(omega[1]) << ", " << fbits(omega[2]) << "],\n"
+			   << " \"si_u_bits\": " << fbits(units.si_u(1.0f)) << ", \"si_rho_bits\": " << fbits(units.si_rho(1.0f)) << ", \"spacing_bits\": " << fbits(geom.spacing) << ",\n"
+			   << " \"buffer\": {\"active\": " << G.buffer_nudging_active << ", \"n_cells\": " << G.buffer_n_cells << ", \"inv_tau_bits\": " << fbits(G.buffer_inv_tau_lbmu) << ", \"nudge_vertical\": " << G.buffer_nudge_vertical << ", \"downstream_face\": " << G.buffer_downstream_face_id << "},\n"
+			   << " \"sponge\": {\"active\": " << G.top_sponge_active << ", \"n_cells\": " << G.sponge_n_cells << ", \"inv_tau_bits\": " << fbits(G.sponge_inv_tau_lbmu) << "},\n"
+			   << " \"steps\": {\"total\": " << total_steps << ", \"unsteady\": " << unsteady << ", \"avg_window\": " << avg_window << ", \"avg_stride\": " << avg_stride << "},\n"
+			   << " \"output\": {\"tke\": " << (c.out_tke ? 1 : 0) << ", \"ti\": " << (c.out_ti ? 1 : 0) << ", \"tls\": " << (c.out_tls ? 1 : 0) << ", \"results_vtk_dir\": " << jstr(results_vtk_dir) << ", \"raw_prefix\": " << jstr(vtk_prefix+c.datetime+"_raw_") << ", \"avg_name\": " << jstr(vtk_prefix+c.datetime+"_avg") << ",\n"
+			   << "   \"vtk_origin\": " << jstr(to_string_f(geom.origin[0])+" "+to_string_f(geom.origin[1])+" "+to_string_f(geom.origin[2])) << ", \"vtk_spacing\": " << jstr(to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)) << "},\n"
+			   << " \"vk\": {\"on\": " << (vk_on ? 1 : 0) << ", \"stride\": " << c.vk_stride << ", \"interp\": " << (c.vk_interp ? 1 : 0) << "},\n"
+			   << " \"state\": " << jstr(base+".state") << ", \"vk_tables\": " << jstr(vk_on ? base+".vk" : string("")) << "\n}\n";
+			print_kv_row("Setup exported", base+".json");
+			continue;
+		}
 		if(c.dry_run) continue;
 
 		// ---- run_lbm, FX/setup.cpp:4117-4911
@@ -910,18 +945,8 @@ int main(int argc, char** argv) {
 		std::memcpy(lbm.flags.host, flags.data(), N); std::memcpy(lbm.u.host, u.data(), 12ull*N); // rho mirror is pre-filled with 1.0f
 		if(vk_on) luw_check(luw_vk_inlet_attach(lbm.handle(), vk.point_count, vk.mode_count, vk.point_cell.data(), vk.point_face.data(), vk.point_data.data(), vk.mode_data.data(), c.vk_stride, c.vk_interp ? 1 : 0));
 		print_section_title("LBM SOLVER INFORMATION");
-		const ulong total_steps = (c.run_nstep_override>0ull ? c.run_nstep_override : 20001ull)+(ulong)c.research_output_steps;
-		const ulong unsteady = (ulong)c.unsteady_output_interval;
-		const string results_vtk_dir = c.parent+"/RESULTS/vtk/";
-		const string vtk_dir = results_vtk_dir+vtk_prefix+c.datetime+"_raw_";
-		const uint Nz_out = (top_sponge_grid_extend&&Nz_core<Nz) ? Nz_core : Nz;
-		VtkGeom geom{Nx, Ny, Nz, Nz_out, units.si_x(1.0f), {0, 0, 0}};
-		{ const uint NN[3] = {Nx, Ny, Nz}; for(int k=0; k<3; k++) geom.origin[k] = geom.spacing*(0.5f-0.5f*(float)NN[k])+vtk_origin_shift[k]; }
 		if(Nz_out<Nz) print_kv_row("VTK z output", "core Nz="+to_string_u(Nz_out)+" of solver Nz="+to_string_u(Nz)+" (top sponge omitted)");
 		print_kv_row("Run steps", to_string_u(total_steps)+(c.run_nstep_override>0ull ? " (run_nstep override)" : " (default)"));
-		const ulong avg_window = c.purge_avg_steps>0u ? std::min((ulong)c.purge_avg_steps, total_steps) : 0ull;
-		const ulong avg_stride = std::max((ulong)1u, (ulong)c.purge_avg_stride);
-		const ulong avg_start_t = avg_window>0ull ? total_steps-avg_window+1ull : ~0ull;
 		if(avg_window>0ull) { print_kv_row("Avg stride", "sample every "+to_string_u(avg_stride)+" step(s) in purge_avg window (on-device accumulation)"); luw_check(luw_stats_reset(lbm.handle())); }
 		lbm.run(0u, total_steps);
 		print_section_title("SOLVER START");

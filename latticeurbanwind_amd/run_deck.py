@@ -1,0 +1,278 @@
+"""Decomposed deck run: `n_gpu = [Dx, Dy, Dz]` decks on Dx*Dy*Dz GPUs of one node, one process per GPU.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m latticeurbanwind_amd.run_deck case/conf.luw
+
+The host stage is the C++ driver's (latticeurbanwind_amd/host/luw_driver --export-setup: deck, sizing, units, STL + device
+voxeliser, boundary builders, VK tables), run once by rank 0; every rank then cuts its block out of the exported state, and
+the run loop of the reference (FX/setup.cpp:4117-4911: unsteady u outputs, purge_avg window on the device, final u / rho,
+_avg VTK with tke / TI / TLS) is driven here over DomainDecomposedLBM (RCCL halos).  Blocks are assembled through files in
+the project's proj_temp (ranks share the node's file system), rank 0 writes the same VTK files as the single-GPU driver.
+With one rank it reproduces the C++ driver's files (tests/test_gpu_run_deck.py).
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+from . import capi
+from .distributed import DomainDecomposedLBM, DomainLayout
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DRIVER = os.path.join(HERE, "host", "luw_driver")
+f32 = np.float32
+
+
+def _f(bits):
+    return np.array([bits], np.uint32).view(np.float32)[0]
+
+
+class _Single:
+    """stand-in for torch.distributed when the module is started without a launcher (one GPU)"""
+    rank, world = 0, 1
+    def barrier(self): pass
+
+
+class _Dist:
+    def __init__(self, dist):
+        self.d = dist; self.rank = dist.get_rank(); self.world = dist.get_world_size()
+    def barrier(self): self.d.barrier()
+
+
+# ----------------------------------------------------------------------------- VTK (FX/lbm.hpp:307-356, FX/setup.cpp:2513-2683)
+def vtk_header(filename, m, Nz_out):
+    Nx, Ny, _ = m["N"]
+    return ("# vtk DataFile Version 3.0\nFluidX3D %s\nBINARY\nDATASET STRUCTURED_POINTS\nDIMENSIONS %d %d %d\nORIGIN %s\nSPACING %s\nPOINT_DATA %d\n"
+            % (os.path.basename(filename), Nx, Ny, Nz_out, m["output"]["vtk_origin"], m["output"]["vtk_spacing"], Nx * Ny * Nz_out)).encode()
+
+
+def write_field_vtk(filename, m, soa, comps, factor):
+    """soa: (comps, Nz, Ny, Nx) float32 in lattice units -> AoS big-endian floats in SI units, first Nz_out layers"""
+    os.makedirs(os.path.dirname(filename), exist_ok=True)
+    Nz_out = m["Nz_out"]
+    with open(filename, "wb") as f:
+        f.write(vtk_header(filename, m, Nz_out))
+        f.write(("SCALARS data float %d\nLOOKUP_TABLE default\n" % comps).encode())
+        for z in range(Nz_out):      # layer by layer: bounded memory on billion-cell lattices
+            lay = (f32(factor) * np.asarray(soa[:, z])).astype(np.float32)
+            f.write(np.ascontiguousarray(np.moveaxis(lay, 0, -1)).astype(">f4").tobytes())
+
+
+def write_avg_vtk(filename, m, avg_u, avg_rho, m2, count, solid, si_u, si_rho, spacing):
+    """avg_u (Nz,Ny,Nx,3), avg_rho / m2[k] (Nz,Ny,Nx), all lattice units, already cut to Nz_out layers"""
+    os.makedirs(os.path.dirname(filename), exist_ok=True)
+    Nzo, Ny, Nx = avg_rho.shape
+    uf, rf = f32(si_u), f32(si_rho)
+    out = m["output"]
+    with open(filename, "wb") as f:
+        f.write(vtk_header(filename, m, Nzo))
+        def field(name, a, comps, factor):
+            f.write(("SCALARS %s float %d\nLOOKUP_TABLE default\n" % (name, comps)).encode())
+            f.write(((a * f32(factor)) + f32(0.0)).astype(">f4").tobytes())
+        field("u_avg", avg_u, 3, uf)
+        field("rho_avg", avg_rho, 1, rf)
+        fluid = np.where(solid, f32(0), f32(1)).astype(np.float32)
+        zero = np.zeros(avg_rho.shape, np.float32)
+        tke, ti, tls = zero.copy(), zero.copy(), zero.copy()
+        if count > 1 and (out["tke"] or out["ti"] or out["tls"]):
+            inv_n = f32(1.0) / f32(count)
+            var = [np.maximum(m2[k] * inv_n, f32(0)) for k in range(3)]
+            var_sum = (var[0] + var[1]) + var[2]
+            live = ~solid
+            if out["tke"]:
+                tke = np.where(live, f32(0.5) * var_sum, f32(0)).astype(np.float32)
+            if out["ti"]:
+                ax, ay, az = avg_u[..., 0], avg_u[..., 1], avg_u[..., 2]
+                umag = np.sqrt((ax * ax + ay * ay) + az * az)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    ti = np.where(live & (umag > f32(1.0e-9)) & (var_sum > 0), np.sqrt(var_sum * (f32(1.0) / f32(3.0))) / umag, f32(0)).astype(np.float32)
+            if out["tls"]:
+                dx = np.maximum(f32(spacing), f32(1.0e-12))
+                su = (avg_u * uf).astype(np.float32)
+                def grad(axis, n):        # one-sided at the ends, central inside; axis: 0 z, 1 y, 2 x of the (z,y,x,3) array
+                    ip = np.minimum(np.arange(n) + 1, n - 1); im = np.maximum(np.arange(n) - 1, 0)
+                    inv = np.where(ip > im, f32(1.0) / ((ip - im).astype(np.float32) * dx), f32(0)).astype(np.float32)
+                    shape = [1, 1, 1, 1]; shape[axis] = n
+                    return ((np.take(su, ip, axis) - np.take(su, im, axis)) * inv.reshape(shape)).astype(np.float32)
+                gx, gy, gz = grad(2, Nx), grad(1, Ny), grad(0, Nzo)
+                duxdx, duydx, duzdx = gx[..., 0], gx[..., 1], gx[..., 2]
+                duxdy, duydy, duzdy = gy[..., 0], gy[..., 1], gy[..., 2]
+                duxdz, duydz, duzdz = gz[..., 0], gz[..., 1], gz[..., 2]
+                Sxy = f32(0.5) * (duxdy + duydx); Sxz = f32(0.5) * (duxdz + duzdx); Syz = f32(0.5) * (duydz + duzdy)
+                S_mag = np.sqrt(np.maximum(f32(0), f32(2.0) * (((duxdx * duxdx + duydy * duydy) + duzdz * duzdz) + f32(2.0) * ((Sxy * Sxy + Sxz * Sxz) + Syz * Syz))))
+                k_loc = (f32(0.5) * var_sum) * (uf * uf)
+                cap = f32(max(Nx, Ny, Nzo)) * dx
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = np.where((S_mag > f32(1.0e-10)) & (k_loc > 0), np.sqrt(k_loc) / S_mag, f32(0))
+                tls = np.where(live, np.minimum(np.maximum(t, f32(0)), cap), f32(0)).astype(np.float32)
+        field("fluid", fluid, 1, 1.0)
+        if out["tke"]: field("tke", tke, 1, uf * uf)
+        if out["ti"]: field("TI", ti, 1, 1.0)
+        if out["tls"]: field("TLS", tls, 1, 1.0)
+
+
+# ----------------------------------------------------------------------------- one case
+def _default_name(prefix, name, t):
+    return "%s%s-%09d.vtk" % (prefix, name, t)
+
+
+def run_case(m, G, device, log, make_sim=None):
+    Nx, Ny, Nz = m["N"]; D = tuple(m["n_gpu"]); Ncells = Nx * Ny * Nz
+    if D[0] * D[1] * D[2] != G.world:
+        raise SystemExit("run_deck: the deck asks for n_gpu=%s = %d domains but %d ranks were launched" % (list(D), D[0] * D[1] * D[2], G.world))
+    nu = float(_f(m["nu_bits"])); si_u = _f(m["si_u_bits"]); si_rho = _f(m["si_rho_bits"]); spacing = _f(m["spacing_bits"])
+    nud = m["buffer"]; spg = m["sponge"]
+    kw = dict(fp16c=bool(m["fp16c"]),
+              buffer_nudging=dict(n_cells=nud["n_cells"], inv_tau=float(_f(nud["inv_tau_bits"])), downstream_face=nud["downstream_face"], nudge_vertical=nud["nudge_vertical"]) if nud["active"] else None,
+              top_sponge=dict(n_cells=spg["n_cells"], inv_tau=float(_f(spg["inv_tau_bits"]))) if spg["active"] else None)
+    sim = make_sim((Nx, Ny, Nz), D, nu, G.rank, kw) if make_sim else DomainDecomposedLBM((Nx, Ny, Nz), D, nu, rank=G.rank, device=device, **kw)
+    lay = sim.layout
+    state = np.memmap(m["state"], np.uint8, "r")
+    gflags = state[:Ncells]; gu = state[Ncells:Ncells + 12 * Ncells].view(np.float32)
+    sim.set_fields_from_global(gflags, gu, None)
+    om = [float(_f(b)) for b in m["omega_bits"]]
+    if any(om):
+        sim.backend.set_coriolis(*om)
+    if m["vk"]["on"]:            # von-Karman tables are global; keep the points that sit on cells this rank owns
+        raw = np.fromfile(m["vk_tables"], np.uint8)
+        P, M = (int(v) for v in raw[:16].view(np.uint64))
+        o = 16; cell = raw[o:o + 8 * P].view(np.uint64); o += 8 * P
+        face = raw[o:o + P]; o += P
+        pdat = raw[o:o + 28 * P].view(np.float32).reshape(7, P); o += 28 * P       # SoA: x, y, z, ubx, uby, ubz, sigma
+        mdat = raw[o:o + 200 * M].view(np.float32)
+        x = (cell % Nx).astype(np.int64); y = ((cell // Nx) % Ny).astype(np.int64); z = (cell // (Nx * Ny)).astype(np.int64)
+        lx, ly, lz = x - lay.O[0], y - lay.O[1], z - lay.O[2]
+        own = np.ones(P, bool)
+        for l, a in ((lx, 0), (ly, 1), (lz, 2)):
+            lo, hi = lay.nonhalo_range(a); own &= (l >= lo) & (l < hi)
+        lcell = (lx + (ly + lz * lay.lN[1]) * lay.lN[0])[own].astype(np.uint64)
+        if own.any():
+            sim.backend.vk_attach(lcell, face[own], np.ascontiguousarray(pdat[:, own]).ravel(), mdat, M, m["vk"]["stride"], bool(m["vk"]["interp"]))
+            sim.pre_step = sim.backend.vk_apply
+    st = m["steps"]; total, unsteady, avg_window, avg_stride = st["total"], st["unsteady"], st["avg_window"], max(1, st["avg_stride"])
+    avg_start = total - avg_window + 1 if avg_window > 0 else None
+    if avg_window > 0:
+        sim.backend.stats_reset()
+    out = m["output"]; raw_prefix = os.path.join(out["results_vtk_dir"], out["raw_prefix"])
+    scratch = os.path.dirname(m["state"])
+    sim.initialize()
+    log("| Decomposed run  | n_gpu=%s, local %s, %s, %d steps" % (list(D), list(lay.lN), "shell/interior overlap" if sim.overlap else "whole box + exchange", total))
+    t0 = time.perf_counter()
+
+    def gather(name, comps, local, t):
+        """every rank drops its owned block into one file; returns the (comps,Nz,Ny,Nx) memmap on rank 0"""
+        path = os.path.join(scratch, "%s_%d.gather" % (name, t))
+        if G.rank == 0:
+            np.memmap(path, np.float32, "w+", shape=(comps, Nz, Ny, Nx)).flush()
+        G.barrier()
+        mm = np.memmap(path, np.float32, "r+", shape=(comps, Nz, Ny, Nx))
+        blk, (x0, y0, z0) = sim.interior_to_global(local, comps)
+        mm[:, z0:z0 + blk.shape[1], y0:y0 + blk.shape[2], x0:x0 + blk.shape[3]] = blk
+        mm.flush(); del mm
+        G.barrier()
+        return np.memmap(path, np.float32, "r", shape=(comps, Nz, Ny, Nx)) if G.rank == 0 else None, path
+
+    def write_u(t):
+        u, _ = sim.fields()
+        g, path = gather("u", 3, u, t)
+        if G.rank == 0:
+            fn = _default_name(raw_prefix, "u", t); write_field_vtk(fn, m, g, 3, si_u); log("| VTK file        | %s saved" % fn); del g; os.remove(path)
+        G.barrier()
+
+    t = 0; last_u = None
+    while t < total:
+        nxt = total
+        if unsteady > 0:
+            nxt = min(nxt, (t // unsteady + 1) * unsteady)
+        if avg_window > 0:
+            s = max(t + 1, avg_start); off = (s - avg_start) % avg_stride
+            if off: s += avg_stride - off
+            if s <= total: nxt = min(nxt, s)
+        sim.run(nxt - t); t = nxt
+        if unsteady > 0 and t % unsteady == 0:
+            write_u(t); last_u = t
+        if avg_window > 0 and t >= avg_start and (t - avg_start) % avg_stride == 0:
+            sim.backend.stats_accumulate()
+    secs = time.perf_counter() - t0
+    log("| Solver          | %d steps in %.3f s = %.1f MLUPs" % (total, secs, Ncells * total / secs * 1e-6))
+    if last_u != t:
+        write_u(t)
+    u, rho = sim.fields()
+    g, path = gather("rho", 1, rho, t)
+    if G.rank == 0:
+        fn = _default_name(raw_prefix, "rho", t); write_field_vtk(fn, m, g, 1, si_rho); log("|                 | %s saved" % fn); del g; os.remove(path)
+    G.barrier()
+    if avg_window > 0:
+        sd = sim.backend.stats_download()
+        lN = lay.lN
+        au = sd["avg_u"].reshape(lN[2], lN[1], lN[0], 3).transpose(3, 0, 1, 2)          # AoS -> (3,z,y,x) like a field
+        parts = {}
+        for name, comps, arr in (("avg_u", 3, au), ("avg_rho", 1, sd["avg_rho"]), ("m2u", 1, sd["m2_u"]), ("m2v", 1, sd["m2_v"]), ("m2w", 1, sd["m2_w"])):
+            parts[name] = gather(name, comps, np.ascontiguousarray(arr), t)
+        if G.rank == 0 and sd["count"] > 0:
+            Nzo = m["Nz_out"]
+            A = lambda k: np.asarray(parts[k][0][:, :Nzo])
+            solid = (np.asarray(gflags).reshape(Nz, Ny, Nx)[:Nzo] & 1) != 0
+            fn = _default_name(os.path.join(out["results_vtk_dir"], out["avg_name"]), "", t)
+            write_avg_vtk(fn, m, np.ascontiguousarray(np.moveaxis(A("avg_u"), 0, -1)), A("avg_rho")[0], [A("m2u")[0], A("m2v")[0], A("m2w")[0]], sd["count"], solid, si_u, si_rho, spacing)
+            log("| VTK file        | %s saved" % fn); log("| Avg samples     | %d" % sd["count"])
+        G.barrier()
+        if G.rank == 0:
+            for g, path in parts.values():
+                del g
+                os.remove(path)
+    sim.backend.close()
+    G.barrier()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m latticeurbanwind_amd.run_deck")
+    ap.add_argument("deck"); ap.add_argument("--ddf", choices=["fp32", "fp16c"], default="fp16c")
+    ap.add_argument("--host-voxeliser", action="store_true", help="export the set-up with --dry-run (no GPU in the host stage)")
+    ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU and exchange halos through gloo + host staging")
+    a = ap.parse_args(argv)
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        if a.share_device is not None:
+            local_rank = a.share_device
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            raise SystemExit("run_deck: no GPU visible; the solver has no CPU fallback")
+        G = _Dist(dist)
+    else:
+        G = _Single()
+    capi.load()
+    parent = os.path.dirname(os.path.abspath(a.deck)) or "."
+    scratch = os.path.join(parent, "proj_temp", "run_deck_setup")
+    log = (lambda s: print(s, flush=True)) if G.rank == 0 else (lambda s: None)
+    if G.rank == 0:
+        shutil.rmtree(scratch, ignore_errors=True)
+        cmd = [DRIVER, a.deck, "--ddf", a.ddf, "--device", str(local_rank), "--export-setup", scratch] + (["--dry-run"] if a.host_voxeliser else [])
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        sys.stdout.write(r.stdout); sys.stdout.flush()
+        if r.returncode != 0:
+            raise SystemExit("run_deck: host stage failed (exit %d)" % r.returncode)
+    G.barrier()
+    k = 1
+    while os.path.exists(os.path.join(scratch, "case%d.json" % k)):
+        run_case(json.load(open(os.path.join(scratch, "case%d.json" % k))), G, local_rank, log)
+        k += 1
+    G.barrier()
+    if G.rank == 0:
+        shutil.rmtree(scratch, ignore_errors=True)
+    if world > 1:
+        G.d.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
