@@ -210,6 +210,105 @@ public:
 	}
 };
 
+// Terrain height over (x, y) from scattered or gridded points: coordinates are clustered into sorted unique x / y lines
+// (tolerance 1e-6 of the extent), each point is binned to its nearest grid node (mean of what lands there, empty nodes
+// take the overall mean), evaluation is bilinear with clamping; with fewer than 2 lines in a direction it falls back to the
+// nearest raw point (GroundTemperaturePlane2D used as the profile-mode DEM ground plane, FX/setup.cpp:1617-1795,5805-5830).
+class GroundPlane2D {
+	std::vector<float> xr_, yr_, vr_, xs_, ys_, grid_;
+	bool structured_ = false; float default_ = 0.0f;
+	static std::vector<float> cluster(std::vector<float> v, const float tol) {
+		std::vector<float> out;
+		if(v.empty()) return out;
+		std::sort(v.begin(), v.end());
+		float last = v[0]; out.push_back(last);
+		for(size_t i=1u; i<v.size(); i++) {
+			if(fabsf(v[i]-last)>tol) { out.push_back(v[i]); last = v[i]; }
+			else { out.back() = 0.5f*(out.back()+v[i]); last = out.back(); } // representative stays centred in its cluster
+		}
+		return out;
+	}
+	static size_t nearest(const std::vector<float>& a, const float v) {
+		auto it = std::lower_bound(a.begin(), a.end(), v);
+		if(it==a.begin()) return 0u;
+		if(it==a.end()) return a.size()-1u;
+		const size_t i1 = (size_t)(it-a.begin()), i0 = i1-1u;
+		return fabsf(v-a[i1])<fabsf(v-a[i0]) ? i1 : i0;
+	}
+	static size_t upper(const std::vector<float>& a, const float v) { auto it = std::upper_bound(a.begin(), a.end(), v); return it==a.end() ? a.size()-1u : (size_t)(it-a.begin()); }
+	float nearest_raw(const float xq, const float yq) const {
+		float best = FLT_MAX, val = default_;
+		for(size_t i=0u; i<vr_.size(); i++) { const float dx = xq-xr_[i], dy = yq-yr_[i], d2 = dx*dx+dy*dy; if(d2<best) { best = d2; val = vr_[i]; } }
+		return val;
+	}
+public:
+	void build(const std::vector<float>& x, const std::vector<float>& y, const std::vector<float>& v, const float default_value) {
+		xr_ = x; yr_ = y; vr_ = v; xs_.clear(); ys_.clear(); grid_.clear(); structured_ = false; default_ = default_value;
+		if(vr_.empty()) return;
+		double sum = 0.0; for(const float t : vr_) sum += (double)t;
+		default_ = (float)(sum/(double)vr_.size());
+		float xmin = xr_[0], xmax = xr_[0], ymin = yr_[0], ymax = yr_[0];
+		for(size_t i=1u; i<xr_.size(); i++) { xmin = fminf(xmin, xr_[i]); xmax = fmaxf(xmax, xr_[i]); ymin = fminf(ymin, yr_[i]); ymax = fmaxf(ymax, yr_[i]); }
+		xs_ = cluster(xr_, std::max(1e-6f, 1e-6f*fmaxf(1.0f, xmax-xmin)));
+		ys_ = cluster(yr_, std::max(1e-6f, 1e-6f*fmaxf(1.0f, ymax-ymin)));
+		const size_t nx = xs_.size(), ny = ys_.size();
+		if(nx==0u||ny==0u) return;
+		std::vector<double> acc(nx*ny, 0.0); std::vector<uint32_t> cnt(nx*ny, 0u);
+		for(size_t i=0u; i<vr_.size(); i++) { const size_t id = nearest(ys_, yr_[i])*nx+nearest(xs_, xr_[i]); acc[id] += (double)vr_[i]; cnt[id]++; }
+		grid_.assign(nx*ny, default_);
+		for(size_t id=0u; id<grid_.size(); id++) if(cnt[id]>0u) grid_[id] = (float)(acc[id]/(double)cnt[id]);
+		structured_ = nx>=2u&&ny>=2u;
+	}
+	bool has_samples() const { return !vr_.empty(); }
+	bool structured() const { return structured_; }
+	size_t nx() const { return xs_.size(); } size_t ny() const { return ys_.size(); }
+	float eval(const float xq, const float yq) const {
+		if(vr_.empty()) return default_;
+		const size_t nx = xs_.size(), ny = ys_.size();
+		if(!structured_||nx<2u||ny<2u) return nearest_raw(xq, yq);
+		const float x = fminf(fmaxf(xq, xs_.front()), xs_.back()), y = fminf(fmaxf(yq, ys_.front()), ys_.back());
+		const size_t ix1 = upper(xs_, x), iy1 = upper(ys_, y);
+		const size_t ix0 = ix1==0u ? 0u : ix1-1u, iy0 = iy1==0u ? 0u : iy1-1u;
+		const size_t ia = ix0>=nx-1u ? nx-2u : ix0, ja = iy0>=ny-1u ? ny-2u : iy0, ib = ia+1u, jb = ja+1u;
+		const float xa = xs_[ia], xb = xs_[ib], ya = ys_[ja], yb = ys_[jb];
+		const float tx = fabsf(xb-xa)>1e-12f ? (x-xa)/(xb-xa) : 0.0f, ty = fabsf(yb-ya)>1e-12f ? (y-ya)/(yb-ya) : 0.0f;
+		const float t00 = grid_[ja*nx+ia], t10 = grid_[ja*nx+ib], t01 = grid_[jb*nx+ia], t11 = grid_[jb*nx+ib];
+		const float t0 = t00+tx*(t10-t00), t1 = t01+tx*(t11-t01);
+		return t0+ty*(t1-t0);
+	}
+};
+
+struct DemPoints { std::vector<float> x, y, e; float xmin = 0, xmax = 0, ymin = 0, ymax = 0, emin = 0, emax = 0; };
+// proj_temp/interpolated_dem.csv: header x,y,elevation (or z), or three positional columns; `;` and tabs count as commas
+inline DemPoints read_dem_csv(const std::string& path) { // FX/setup.cpp:2153-2241
+	DemPoints d;
+	std::ifstream fin(path);
+	if(!fin.is_open()) return d;
+	auto split = [](const std::string& s) { std::vector<std::string> c; std::stringstream ss(s); std::string t; while(std::getline(ss, t, ',')) c.push_back(bc_trim(t)); return c; };
+	auto lower = [](std::string s) { for(char& ch : s) ch = (char)std::tolower((unsigned char)ch); return s; };
+	std::string header;
+	if(!std::getline(fin, header)) return d;
+	const std::vector<std::string> hc = split(header);
+	auto col = [&](const char* key) { for(size_t i=0u; i<hc.size(); i++) if(lower(hc[i])==key) return (int)i; return -1; };
+	const int ix = col("x"), iy = col("y"); int ie = col("elevation"); if(ie<0) ie = col("z");
+	const bool named = ix>=0&&iy>=0&&ie>=0;
+	float xmin = +FLT_MAX, xmax = -FLT_MAX, ymin = +FLT_MAX, ymax = -FLT_MAX, emin = +FLT_MAX, emax = -FLT_MAX;
+	std::string line;
+	while(std::getline(fin, line)) {
+		if(line.empty()) continue;
+		for(char& ch : line) if(ch==';'||ch=='\t') ch = ',';
+		const std::vector<std::string> c = split(line);
+		float x, y, e;
+		if(named) { if((int)c.size()<=std::max(ix, std::max(iy, ie))) continue; x = (float)atof(c[ix].c_str()); y = (float)atof(c[iy].c_str()); e = (float)atof(c[ie].c_str()); }
+		else { if(c.size()<3u) continue; x = (float)atof(c[0].c_str()); y = (float)atof(c[1].c_str()); e = (float)atof(c[2].c_str()); }
+		if(!std::isfinite(x)||!std::isfinite(y)||!std::isfinite(e)) continue;
+		d.x.push_back(x); d.y.push_back(y); d.e.push_back(e);
+		xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); ymin = fminf(ymin, y); ymax = fmaxf(ymax, y); emin = fminf(emin, e); emax = fmaxf(emax, e);
+	}
+	if(!d.x.empty()) { d.xmin = xmin; d.xmax = xmax; d.ymin = ymin; d.ymax = ymax; d.emin = emin; d.emax = emax; }
+	return d;
+}
+
 // view of the solver's host mirrors
 struct HostLattice {
 	uint32_t Nx = 1u, Ny = 1u, Nz = 1u; uint8_t* flags = nullptr; float* u = nullptr; // u SoA: x[N], y[N], z[N]

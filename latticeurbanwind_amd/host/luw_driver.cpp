@@ -7,8 +7,8 @@
 //   Units FX/units.hpp:21-67, Coriolis / buffer / sponge constants FX/setup.cpp:3800-3903, STL FX/utilities.hpp:4835-4888
 //   + transform FX/setup.cpp:4070-4087, profile table :5777-5912, flags/u fill :5914-5995 (profile mode) and :5655-5688
 //   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
-// Modes: *.luwpf (profile) and *.luwdg (dataset).  Not in this build (announced on the console, never silently):
-//   *.luw NWP boundary builders, DEM ground plane, probes, PNG frames.
+// Modes: *.luw (NWP: SurfData CSV boundaries), *.luwpf (profile, with optional DEM ground plane) and *.luwdg (dataset).
+// Not in this build (announced on the console, never silently): probes, PNG frames, temperature boundaries.
 // Differences by design: time averaging runs on the device (luw_stats_*); --dry-run voxelises on the host; the von-Karman
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
 // Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
@@ -661,19 +661,50 @@ int main(int argc, char** argv) {
 	print_kv_row("Geometry STL", stl_path);
 	print_kv_row("STL bounds SI", "x=["+to_string_fd(stl_min[0], 3u)+", "+to_string_fd(stl_max[0], 3u)+"], y=["+to_string_fd(stl_min[1], 3u)+", "+to_string_fd(stl_max[1], 3u)+"], z=["+to_string_fd(stl_min[2], 3u)+", "+to_string_fd(stl_max[2], 3u)+"]");
 	print_kv_row("Geometry", "scaled by "+to_string_fd(scale_geom, 4u)+", ready for voxelization");
-	if(c.profile_mode&&std::filesystem::exists(c.parent+"/proj_temp/interpolated_dem.csv")) println("| WARNING: interpolated_dem.csv found, but the DEM ground plane is not part of this build: flat ground at base_height is used. |");
-	else if(c.profile_mode) print_kv_row("Terrain DEM", "interpolated_dem.csv not found or empty, fallback to flat ground");
+	DemPoints dem;
+	if(c.profile_mode) { // FX/setup.cpp:4095-4113
+		dem = read_dem_csv(c.parent+"/proj_temp/interpolated_dem.csv");
+		if(!dem.x.empty()) {
+			print_kv_row("Terrain DEM", "Loaded "+to_string_u(dem.x.size())+" points from interpolated_dem.csv");
+			print_kv_row("DEM bounds SI", "x=["+to_string_fd(dem.xmin, 3u)+", "+to_string_fd(dem.xmax, 3u)+"], y=["+to_string_fd(dem.ymin, 3u)+", "+to_string_fd(dem.ymax, 3u)+"], elev=["+to_string_fd(dem.emin, 3u)+", "+to_string_fd(dem.emax, 3u)+"]");
+		} else print_kv_row("Terrain DEM", "interpolated_dem.csv not found or empty, fallback to flat ground");
+	}
 
 	// ---- profile table, FX/setup.cpp:5777-5912
 	const float origin_z = 0.5f-0.5f*(float)Nz;
 	const float flat_ground = origin_z+units.x(c.z_si_offset);
 	std::vector<float> prof_lbmu;
 	const float profile_dz = 0.1f;
+	GroundPlane2D ground_plane; bool use_dem_ground = false; float ground_z_min = flat_ground, ground_z_max = flat_ground;
+	if(c.profile_mode&&!dem.x.empty()) { // DEM points -> STL frame -> lattice units, FX/setup.cpp:5790-5847
+		const float origin_x = 0.5f-0.5f*(float)Nx, origin_y = 0.5f-0.5f*(float)Ny;
+		const float dem_rx = dem.xmax-dem.xmin, dem_ry = dem.ymax-dem.ymin, stl_rx = stl_max[0]-stl_min[0], stl_ry = stl_max[1]-stl_min[1];
+		if(dem_rx>1.0e-6f&&dem_ry>1.0e-6f&&stl_rx>1.0e-6f&&stl_ry>1.0e-6f) {
+			const float sx = stl_rx/dem_rx, sy = stl_ry/dem_ry;
+			if(fmaxf(fabsf(sx-1.0f), fabsf(sy-1.0f))>0.02f||fabsf(dem.xmin-stl_min[0])/stl_rx>0.02f||fabsf(dem.ymin-stl_min[1])/stl_ry>0.02f) {
+				println("| Terrain DEM     | WARNING: DEM/STL XY bounds mismatch. Apply affine bounds alignment. |");
+				println("|                 | DEM->STL scale x="+to_string_fd(sx, 6u)+", y="+to_string_fd(sy, 6u)+"                             |");
+			}
+			std::vector<float> gx, gy, gz;
+			ground_z_min = +FLT_MAX; ground_z_max = -FLT_MAX;
+			for(size_t i=0u; i<dem.x.size(); i++) {
+				const float xs = stl_min[0]+(dem.x[i]-dem.xmin)*sx, ys = stl_min[1]+(dem.y[i]-dem.ymin)*sy, zs = c.z_si_offset+dem.e[i];
+				const float xl = origin_x+(xs-stl_min[0])*scale_geom, yl = origin_y+(ys-stl_min[1])*scale_geom, zl = origin_z+(zs-stl_min[2])*scale_geom;
+				if(!std::isfinite(xl)||!std::isfinite(yl)||!std::isfinite(zl)) continue;
+				gx.push_back(xl); gy.push_back(yl); gz.push_back(zl);
+				ground_z_min = fminf(ground_z_min, zl); ground_z_max = fmaxf(ground_z_max, zl);
+			}
+			if(!gz.empty()) { ground_plane.build(gx, gy, gz, flat_ground); use_dem_ground = ground_plane.has_samples(); }
+			if(use_dem_ground) println("| Terrain DEM     | profile ground enabled. z(SI) range "+to_string_fd(units.si_x(ground_z_min-origin_z), 3u)+" .. "+to_string_fd(units.si_x(ground_z_max-origin_z), 3u)+" m |");
+			else { println("| Terrain DEM     | no valid points after mapping, fallback to flat ground     |"); ground_z_min = ground_z_max = flat_ground; }
+		} else println("| Terrain DEM     | invalid DEM or STL XY range, fallback to flat ground       |");
+	}
 	if(c.profile_mode) {
 		const float solver_top_si = units.si_x((float)(Nz-1u));
 		const float core_top_si = side_ref_z_cap>=0 ? units.si_x((float)side_ref_z_cap) : solver_top_si;
-		float ground_min_si = units.si_x(flat_ground-origin_z);
+		float ground_min_si = units.si_x(ground_z_min-origin_z), ground_max_si = units.si_x(ground_z_max-origin_z);
 		if(!std::isfinite(ground_min_si)) ground_min_si = c.z_si_offset;
+		if(!std::isfinite(ground_max_si)) ground_max_si = ground_min_si;
 		float table_top = solver_top_si-ground_min_si;
 		if(!std::isfinite(table_top)||table_top<=0.0f) table_top = std::max(profile_dz, c.si_z-ground_min_si);
 		table_top = std::max(table_top, profile_dz);
@@ -688,7 +719,7 @@ int main(int argc, char** argv) {
 			prof_lbmu[i] = v*u_scale;
 		}
 		println("| Profile table   | local-terrain AGL top="+to_string_fd(table_top, 3u)+" m, core_top="+to_string_fd(core_top_si, 3u)+" m, solver_top="+to_string_fd(solver_top_si, 3u)+" m |");
-		println("| Profile ground  | z(SI) min/max="+to_string_fd(ground_min_si, 3u)+" / "+to_string_fd(ground_min_si, 3u)+" m |");
+		println("| Profile ground  | z(SI) min/max="+to_string_fd(ground_min_si, 3u)+" / "+to_string_fd(ground_max_si, 3u)+" m |");
 		println("| Profile U range | "+alignr(24u, fmtf(umin))+" to "+alignl(16u, fmtf(umax))+" m/s |");
 	}
 	auto profile_speed = [&](const float pos_z, const float ground_z) -> float { // FX/setup.cpp:5901-5912
@@ -758,6 +789,8 @@ int main(int argc, char** argv) {
 		print_section_title("BUILD BOUNDARY CONDITIONS");
 		auto is_downstream = [&](const uint x, const uint y) { return case_bc=="+y" ? y==Ny-1u : case_bc=="-y" ? y==0u : case_bc=="+x" ? x==Nx-1u : case_bc=="-x" ? x==0u : false; };
 		std::atomic<ulong> mapped{0ull}, terrain_solid{0ull}, outlet{0ull};
+		std::vector<float> ground_xy; // terrain height per column (profile mode with a DEM), else flat
+		auto ground_at = [&](const ulong id) { return ground_xy.empty() ? flat_ground : ground_xy[id]; };
 		HostLattice HL; HL.Nx = Nx; HL.Ny = Ny; HL.Nz = Nz; HL.flags = flags.data(); HL.u = u.data();
 		auto report_flux = [&](const FluxReport& fr) { // FX/fluxcorrection.cpp:180-192
 			println("| Flux correction | S_in="+to_string_dd(fr.S_in, 3u)+", S_out="+to_string_dd(fr.S_out, 3u)+", net_before="+to_string_dd(fr.net_before, 3u)+" |");
@@ -827,11 +860,31 @@ int main(int argc, char** argv) {
 				print_kv_row("Flux correction", "starting. Time: ["+now_str()+"]");
 				report_flux(apply_flux_correction(HL, case_bc, downstream_fill));
 			} else print_kv_row("Flux correction", "skipped. Set flux_correction=true to enable");
-		} else if(c.profile_mode) { // FX/setup.cpp:5914-5995
+		} else if(c.profile_mode) { // FX/setup.cpp:5914-5995,6043-6078
+			if(use_dem_ground) { // per-column terrain height, cells under it become solid
+				const float zmin = pos_z_of(0u), zmax = pos_z_of(Nz-1u);
+				ground_xy.assign((size_t)Nx*Ny, flat_ground);
+				parallel_for((ulong)Nx*Ny, [&](const ulong id) {
+					const uint x = (uint)(id%Nx), y = (uint)(id/Nx);
+					float zg = ground_plane.eval((float)x-0.5f*(float)Nx+0.5f, (float)y-0.5f*(float)Ny+0.5f);
+					if(!std::isfinite(zg)) zg = flat_ground;
+					ground_xy[id] = fminf(fmaxf(zg, zmin), zmax);
+				});
+				float gmin = +FLT_MAX, gmax = -FLT_MAX;
+				for(const float zg : ground_xy) { gmin = fminf(gmin, zg); gmax = fmaxf(gmax, zg); }
+				println("| Terrain ground  | mapped z(SI) range "+to_string_fd(units.si_x(gmin-origin_z), 3u)+" .. "+to_string_fd(units.si_x(gmax-origin_z), 3u)+" m                     |");
+				std::atomic<ulong> clipped{0ull};
+				parallel_for(N, [&](const ulong n) {
+					if((flags[n]&TYPE_S)!=0u) return;
+					const ulong t = n%((ulong)Nx*Ny); const uint z = (uint)(n/((ulong)Nx*Ny));
+					if(pos_z_of(z)<ground_xy[t]) { flags[n] = TYPE_S; u[n] = u[N+n] = u[2ull*N+n] = 0.0f; clipped++; }
+				});
+				if(clipped.load()>0ull) println("| Terrain clip    | below-terrain cells forced to solid: "+to_string_u(clipped.load())+"                    |");
+			}
 			parallel_for(N, [&](const ulong n) {
 				const uint z = (uint)(n/((ulong)Nx*Ny));
-				if((flags[n]&TYPE_S)!=0u) return;
-				const float um = profile_speed(pos_z_of(z), flat_ground);
+				if((flags[n]&TYPE_S)!=0u) { u[n] = u[N+n] = u[2ull*N+n] = 0.0f; return; }
+				const float um = profile_speed(pos_z_of(z), ground_at(n%((ulong)Nx*Ny)));
 				u[n] = dir_x*um; u[N+n] = dir_y*um; u[2ull*N+n] = 0.0f;
 			});
 			parallel_for(N, [&](const ulong n) {
@@ -840,13 +893,14 @@ int main(int argc, char** argv) {
 				if(!(x==0u||x==Nx-1u||y==0u||y==Ny-1u||z==Nz-1u)) return;
 				if((flags[n]&TYPE_S)!=0u) return;
 				const float pz = pos_z_of(z);
-				if(pz<=flat_ground) { flags[n] = TYPE_S; u[n] = u[N+n] = u[2ull*N+n] = 0.0f; terrain_solid++; return; }
+				const float ground_z = ground_at(t);
+				if(pz<=ground_z) { flags[n] = TYPE_S; u[n] = u[N+n] = u[2ull*N+n] = 0.0f; terrain_solid++; return; }
 				flags[n] = (uchar)(flags[n]|TYPE_E);
 				if(c.downstream_open_face&&is_downstream(x, y)) { outlet++; return; }
 				float pze = pz;
 				const bool side = x==0u||x==Nx-1u||y==0u||y==Ny-1u;
 				if(side&&side_ref_z_cap>=0&&(int)z>side_ref_z_cap) pze = pos_z_of((uint)side_ref_z_cap);
-				const float um = profile_speed(pze, flat_ground);
+				const float um = profile_speed(pze, ground_z);
 				u[n] = dir_x*um; u[N+n] = dir_y*um; u[2ull*N+n] = 0.0f;
 				mapped++;
 			});
@@ -873,7 +927,7 @@ int main(int argc, char** argv) {
 				report_flux(apply_flux_correction(HL, case_bc, [&](const uint x, const uint y, const uint z) -> V3 {
 					float pze = pos_z_of(z);
 					if((x==0u||x==Nx-1u||y==0u||y==Ny-1u)&&side_ref_z_cap>=0&&(int)z>side_ref_z_cap) pze = pos_z_of((uint)side_ref_z_cap);
-					const float um = profile_speed(pze, flat_ground);
+					const float um = profile_speed(pze, ground_at((ulong)y*Nx+x));
 					V3 v; v.x = dir_x*um; v.y = dir_y*um; v.z = 0.0f; return v;
 				}));
 			} else print_kv_row("Flux correction", "skipped. Set flux_correction=true to enable");

@@ -11,6 +11,8 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   B  nudging + sponge OFF                                      (Nz = 24)
   L  "laminar" micro-domain (cell 1e-5 m -> nu_lbm ~ 0.03), nudging + sponge OFF, uniform inflow
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
+  D  case B on a base slab at z = 0..4 m with proj_temp/interpolated_dem.csv (terrain hill): DEM ground plane, terrain clip,
+     profile above local terrain, flux correction in profile mode
   N1..N4  *.luw (NWP) decks on the case-B geometry with synthetic SurfData CSVs: N1 patch-driven 2-D mapping + flux
      correction + Coriolis; N2 KNN-HD (high_order) + flux correction; N3 nearest-sample + nudging + sponge + open
      downstream face; N4 patch mapping with an open downstream face
@@ -75,16 +77,25 @@ def city_tris(s):
     t += box_tris(74.1*s, 86.3*s, 64.8*s, 75.6*s, 0.0, 15.2*s)
     return t
 
-def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0):
+def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0, z0=0.0, dem=False):
     """s = length scale (metres per 'unit'); the box geometry is dims units (default 96 x 80 x 48), base slab 4 units."""
     d = os.path.join(root, name)
     os.makedirs(os.path.join(d, "proj_temp"), exist_ok=True)
     os.makedirs(os.path.join(d, "wind_bc"), exist_ok=True)
-    tris  = box_tris(0, dims[0]*s, 0, dims[1]*s, -4*s, 0.0)          # ground slab (full footprint)
+    tris  = box_tris(0, dims[0]*s, 0, dims[1]*s, z0-4*s, z0)         # ground slab (full footprint)
     if building == "city":
         tris += city_tris(s)
     elif building:
-        tris += box_tris(30.3*s, 46.7*s, 28.6*s, 51.4*s, 0.0, 19.3*s)    # one building, off-grid faces
+        tris += box_tris(30.3*s, 46.7*s, 28.6*s, 51.4*s, z0, z0+19.3*s)  # one building, off-grid faces
+    if dem:   # proj_temp/interpolated_dem.csv: terrain elevation above the base slab, a smooth hill off-centre (own DEM frame: shifted + scaled xy)
+        import math
+        with open(os.path.join(d, "proj_temp", "interpolated_dem.csv"), "w") as f:
+            f.write("x,y,elevation\n")
+            for j in range(17):
+                for i in range(21):
+                    x, y = dims[0]*s*i/20.0, dims[1]*s*j/16.0
+                    e = 5.2*s*math.exp(-((x-22.0*s)**2+(y-52.0*s)**2)/(260.0*s*s)) + 0.8*s*math.sin(0.05*x/s)**2
+                    f.write("%.4f,%.4f,%.5f\n" % (1000.0+x, 500.0+y, e))
     write_stl(os.path.join(d, "proj_temp", name + "_PF.stl"), tris)
     with open(os.path.join(d, "wind_bc", "profile.dat"), "w") as f:
         f.write("z,U\n")
@@ -189,6 +200,8 @@ if __name__ == "__main__":
     # G, H: voxeliser cases ("city" geometry) at cell 2 m (mesh scale 0.5, exact) and cell 2.5 m (scale 0.4, inexact)
     write_case(root, "CaseG", 1.0, off, building="city", nstep=16)
     write_case(root, "CaseH", 1.0, off, building="city", nstep=16, cell=2.5)
+    # D: profile mode with a DEM ground plane (interpolated_dem.csv), STL base slab on z = 0..4 as luwvox writes it
+    write_case(root, "CaseD", 1.0, off + ["flux_correction = true"], nstep=16, z0=4.0, dem=True)
     # N1..N4: *.luw (NWP) mode, boundaries from a synthetic SurfData CSV
     write_luw_case(root, "CaseN1", "patch", off + ["high_order = false", "flux_correction = true", "coriolis_term = true"])
     write_luw_case(root, "CaseN2", "cloud", off + ["high_order = true", "flux_correction = true", "coriolis_term = false"])
