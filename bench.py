@@ -35,8 +35,10 @@ def loglaw_profile(nz, u_max=0.1):
     return (u_max * u / u.max()).astype(np.float32)
 
 
-def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None):
-    """flags/u/rho of the (sub)box [gx0,gx0+Nx) x ... of the global channel GNx x GNy x GNz (wind along +x)"""
+def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None, buildings=False):
+    """flags/u/rho of the (sub)box [gx0,gx0+Nx) x ... of the global channel GNx x GNy x GNz (wind along +x).
+    buildings=True adds BASELINE configs[2]'s solid mask: an array of axis-aligned boxes, footprint 24x24 cells on a 64-cell
+    pitch, heights 8+((7i+13j) mod 48) cells (closed form)"""
     GNx, GNy, GNz = GNx or Nx, GNy or Ny, GNz or Nz
     prof = loglaw_profile(GNz)
     zs = (np.arange(Nz) + gz0) % GNz; ys = (np.arange(Ny) + gy0) % GNy; xs = (np.arange(Nx) + gx0) % GNx
@@ -44,6 +46,12 @@ def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None)
     bz = (zs == GNz - 1); by = (ys == 0) | (ys == GNy - 1); bx = (xs == 0) | (xs == GNx - 1)
     flags[bz, :, :] = 2; flags[:, by, :] = 2; flags[:, :, bx] = 2
     flags[zs == 0, :, :] = 1
+    if buildings:
+        i, j = xs // 64, ys // 64
+        inx = (xs % 64 >= 20) & (xs % 64 < 44) & (xs > 0) & (xs < GNx - 1); iny = (ys % 64 >= 20) & (ys % 64 < 44) & (ys > 0) & (ys < GNy - 1)
+        h = 8 + ((7 * i[None, :] + 13 * j[:, None]) % 48)                       # (Ny, Nx) building height in cells
+        solid = (inx[None, :] & iny[:, None])[None, :, :] & (zs[:, None, None] >= 1) & (zs[:, None, None] < 1 + h[None, :, :])
+        flags[solid] = 1
     u = np.zeros((3, Nz, Ny, Nx), np.float32)
     u[0] = prof[zs][:, None, None]
     u[0][flags == 1] = 0.0
@@ -103,6 +111,7 @@ def main():
     ap.add_argument("--n-gpu", type=int, nargs=3, default=None, help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 2 4 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
+    ap.add_argument("--buildings", action="store_true", help="BASELINE configs[2] solid mask (box array); use with --size 1024 1024 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
@@ -125,7 +134,7 @@ def main():
 
     if world == 1 and not args.force_distributed:
         lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields)
-        fl, u, rho = channel_state(Nx, Ny, Nz)
+        fl, u, rho = channel_state(Nx, Ny, Nz, buildings=args.buildings)
         lbm.flags.data[:] = fl; lbm.u.data[:] = u; lbm.rho.data[:] = rho
         lbm.run(0)
         lbm.run(args.warmup)
@@ -150,7 +159,7 @@ def main():
         Nx, Ny, Nz = (g // d for g, d in zip(gN, D))          # per-GPU block (without halos)
         sim = DomainDecomposedLBM(gN, D, nu, fp16c=fp16c, kernel=kern, device=local_rank)
         ox, oy, oz = sim.global_offset
-        fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN)
+        fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN, buildings=args.buildings)
         sim.set_fields(fl, u, rho)
         sim.initialize()
         sim.run(args.warmup)
@@ -175,7 +184,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
             "config": {"workload": "%s, log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky, %s DDFs, rho/u written %s"
-                       % (("%dx%dx%d D3Q19 channel (BASELINE configs[1])" % (Nx, Ny, Nz)) if world == 1 else
+                       % (("%dx%dx%d D3Q19 channel%s" % (Nx, Ny, Nz, " with the configs[2] building array (solid fraction %.3f)" % float((fl == 1).mean()) if args.buildings else " (BASELINE configs[1])")) if world == 1 else
                           ("%dx%dx%d D3Q19 channel tile (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU" % (Nx * D[0], Ny * D[1], Nz * D[2], Nx, Ny, Nz)),
                           "FP16C" if fp16c else "FP32", "every step" if args.every_step_fields else "by the last step only"),
                        "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "halo_exchange": (None if D == (1, 1, 1) else ("RCCL p2p, overlapped with the interior (x rows kept whole)" if sim.overlap else "RCCL p2p after the whole-box kernel (x split)")), "kernel": args.kernel,

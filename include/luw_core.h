@@ -159,6 +159,11 @@ int luw_upload_fi(luw_solver* s, const void* host_src);
  * result in the host flags mirror. */
 int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag);
 
+/* The same voxelisation on a bare lattice, without a solver object: flags is a host array u8[Nx*Ny*Nz] (reference layout,
+ * in/out); bounds = pmin xyz, pmax xyz.  Used by the set-up export of decomposed runs, where the GLOBAL lattice is voxelised
+ * once (the reference voxelises per domain with the triangles that overlap it, FX/lbm.cpp:1455-1587: same cells). */
+int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag, uint8_t* flags);
+
 /* von-Karman synthetic-turbulence inlet: the device half of the reference's VonKarmanInletUpdater (FX/setup.cpp:413-1149,
  * kernel vk_inlet_apply FX/kernel.cpp:2495-2571).  The caller builds the tables like build_gpu_runtime_ does
  * (latticeurbanwind_amd/host/vk_inlet.hpp): point_cell[P] = cell index n in the reference layout, point_face[P] = 0 west /

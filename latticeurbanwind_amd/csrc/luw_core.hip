@@ -530,7 +530,8 @@ template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KP
 __device__ __forceinline__ float vdot(const float ax, const float ay, const float az, const float bx, const float by, const float bz) {
 	return fmaf(az, bz, fmaf(ay, by, ax*bx)); // dot(float3) of the OpenCL device library: mad(z, z', mad(y, y', x*x'))
 }
-__global__ __launch_bounds__(256) void k_voxelize_z(const KParams p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t triangle_number,
+struct VoxGrid { uint32_t Nx, Ny, Nz, Px; int Ox, Oy, Oz; uint64_t Np; }; // lattice of the pass: a solver domain, or a bare global lattice (luw_voxelize_lattice)
+__global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t triangle_number,
 		const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2, const float x0, const float y0, const float z0, const float x1, const float y1, const float z1) {
 	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
 	if(a>=p.Nx*p.Ny) return;
@@ -571,10 +572,10 @@ __global__ __launch_bounds__(256) void k_voxelize_z(const KParams p, uint8_t* __
 	for(uint32_t h=h0; h<hmax; h++) {
 		while(k<intersections&&h>h0+(uint32_t)distances[min(k, 63u)]) { inside = !inside; k++; }
 		inside = inside&&(k<intersections&&h<hmesh);
-		const uint32_t n = x+(y+h*p.Ny)*p.Px;
+		const uint64_t n = (uint64_t)x+((uint64_t)y+(uint64_t)h*p.Ny)*p.Px;
 		uint8_t fl = flags[n];
 		if(inside) fl = (uint8_t)((fl&~TYPE_BO)|flag);
-		else if((fl&TYPE_BO)==TYPE_S&&u[n]==0.0f&&u[p.Np+(uint64_t)n]==0.0f&&u[2ull*p.Np+(uint64_t)n]==0.0f) fl = (uint8_t)(fl&~flag); // was solid with the mesh's velocity (static: 0), FX/kernel.cpp:2451-2462
+		else if((fl&TYPE_BO)==TYPE_S&&(!u||(u[n]==0.0f&&u[p.Np+n]==0.0f&&u[2ull*p.Np+n]==0.0f))) fl = (uint8_t)(fl&~flag); // was solid with the mesh's velocity (static: 0), FX/kernel.cpp:2451-2462
 		flags[n] = fl;
 	}
 }
@@ -1019,12 +1020,35 @@ int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, 
 	for(int k=0; k<3; k++) { if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess) { for(int q=0; q<3; q++) (void)hipFree(d[q]); return fail(LUW_ERR_NOMEM, "luw_voxelize_mesh: allocation failed"); } HIP_TRY(hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)); }
 	if(int e = luw_upload(s, LUW_MASK_FLAGS|LUW_MASK_U)) return e; // the host mirror is authoritative before the first run
 	const uint32_t A = s->cfg.Nx*s->cfg.Ny;
-	hipLaunchKernelGGL(k_voxelize_z, dim3((A+255u)/256u), dim3(256), 0, s->stream, s->kp, s->d_flags, s->d_u, flag, triangle_number, d[0], d[1], d[2],
+	const VoxGrid vg = { s->kp.Nx, s->kp.Ny, s->kp.Nz, s->kp.Px, s->kp.Ox, s->kp.Oy, s->kp.Oz, (uint64_t)s->kp.Np };
+	hipLaunchKernelGGL(k_voxelize_z, dim3((A+255u)/256u), dim3(256), 0, s->stream, vg, s->d_flags, s->d_u, flag, triangle_number, d[0], d[1], d[2],
 		pmin[0]-2.0f, pmin[1]-2.0f, pmin[2]-2.0f, pmax[0]+2.0f, pmax[1]+2.0f, pmax[2]+2.0f); // bounding box + 2 cells, FX/lbm.cpp:498
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	for(int k=0; k<3; k++) (void)hipFree(d[k]);
 	return luw_download(s, LUW_MASK_FLAGS); // LBM::voxelize_mesh_on_device leaves the result in lbm.flags
+}
+
+int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag, uint8_t* flags) {
+	if(!p0||!p1||!p2||!bounds||!flags||triangle_number==0u||(uint64_t)Nx*Ny*Nz==0ull||(uint64_t)Nx*Ny>0xFFFFFF00ull) return fail(LUW_ERR_INVALID, "luw_voxelize_lattice: bad argument");
+	HIP_TRY(hipSetDevice(device));
+	const uint64_t N = (uint64_t)Nx*Ny*Nz;
+	uint8_t* d_flags = nullptr; float* d[3] = { nullptr, nullptr, nullptr };
+	auto cleanup = [&]() { (void)hipFree(d_flags); for(int k=0; k<3; k++) (void)hipFree(d[k]); };
+	if(hipMalloc((void**)&d_flags, N)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_voxelize_lattice: allocation failed");
+	const float* h[3] = { p0, p1, p2 };
+	for(int k=0; k<3; k++) if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess||hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)!=hipSuccess) { cleanup(); return fail(LUW_ERR_NOMEM, "luw_voxelize_lattice: allocation failed"); }
+	if(hipMemcpy(d_flags, flags, N, hipMemcpyHostToDevice)!=hipSuccess) { cleanup(); return fail(LUW_ERR_DEVICE, "luw_voxelize_lattice: upload failed"); }
+	const VoxGrid vg = { Nx, Ny, Nz, Nx, 0, 0, 0, N };
+	const uint32_t A = Nx*Ny;
+	hipLaunchKernelGGL(k_voxelize_z, dim3((A+255u)/256u), dim3(256), 0, 0, vg, d_flags, (const float*)nullptr, flag, triangle_number, d[0], d[1], d[2],
+		bounds[0]-2.0f, bounds[1]-2.0f, bounds[2]-2.0f, bounds[3]+2.0f, bounds[4]+2.0f, bounds[5]+2.0f);
+	hipError_t e = hipGetLastError();
+	if(e==hipSuccess) e = hipDeviceSynchronize();
+	if(e==hipSuccess) e = hipMemcpy(flags, d_flags, N, hipMemcpyDeviceToHost);
+	cleanup();
+	if(e!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string("luw_voxelize_lattice: ")+hipGetErrorString(e));
+	return LUW_OK;
 }
 
 int luw_vk_inlet_detach(luw_solver* s) {

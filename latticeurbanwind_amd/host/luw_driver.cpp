@@ -778,6 +778,11 @@ int main(int argc, char** argv) {
 		std::unique_ptr<LBM> lbm_p;
 		ulong nvox = 0ull;
 		if(c.dry_run) nvox = voxelize_z(mesh, Nx, Ny, Nz, flags); // no GPU: host restatement of the kernel
+		else if(!c.export_setup.empty()) { // decomposed run: no solver object for the global lattice, voxelise it bare
+			const float bounds[6] = {mesh.pmin[0], mesh.pmin[1], mesh.pmin[2], mesh.pmax[0], mesh.pmax[1], mesh.pmax[2]};
+			luw_check(luw_voxelize_lattice(c.device, Nx, Ny, Nz, mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), bounds, TYPE_S, flags.data()));
+			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
+		}
 		else { // lbm.voxelize_mesh_on_device(mesh), FX/setup.cpp:4089
 			lbm_p.reset(new LBM(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f));
 			lbm_p->voxelize_mesh_on_device(mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), mesh.pmin, mesh.pmax, TYPE_S);
