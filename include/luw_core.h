@@ -159,6 +159,13 @@ int luw_upload_fi(luw_solver* s, const void* host_src);
  * result in the host flags mirror. */
 int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag);
 
+/* Probe columns (FX/setup.cpp:4495-4506 reads lbm.u at the probe cells after a full-field download every step): attach a
+ * list of cells (reference-layout indices n = x+(y+z*Ny)*Nx) once, then luw_gather_u copies u at those cells, packed
+ * [i][3], to the host -- a few hundred bytes per step instead of 12 bytes per lattice cell.  The last executed step must
+ * have written the fields (luw_run does at the end of each call). */
+int luw_gather_attach(luw_solver* s, uint32_t count, const uint64_t* cells);
+int luw_gather_u(luw_solver* s, float* out);
+
 /* The same voxelisation on a bare lattice, without a solver object: flags is a host array u8[Nx*Ny*Nz] (reference layout,
  * in/out); bounds = pmin xyz, pmax xyz.  Used by the set-up export of decomposed runs, where the GLOBAL lattice is voxelised
  * once (the reference voxelises per domain with the triangles that overlap it, FX/lbm.cpp:1455-1587: same cells). */

@@ -580,6 +580,14 @@ __global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __
 	}
 }
 
+// ---------------------------------------------------------------- probe gather: u at a short list of cells -> packed [i][3]
+__global__ void k_gather_u(const uint32_t count, const uint32_t* __restrict__ cell, const float* __restrict__ u, const size_t Np, float* __restrict__ out) {
+	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
+	if(i>=count) return;
+	const uint32_t n = cell[i];
+	out[3u*i] = u[n]; out[3u*i+1u] = u[Np+n]; out[3u*i+2u] = u[2ull*Np+n];
+}
+
 // ---------------------------------------------------------------- von-Karman synthetic-turbulence inlet
 // vk_inlet_apply, FX/kernel.cpp:2495-2571: u[cell] = u_base + sigma * sum_m A_m cos(k_m.p + omega_m t + phi_m) on the inlet
 // cells (TYPE_E: the collide step then relaxes them to f_eq(rho, u)).  One lane per inlet point; cosf is the same device
@@ -713,6 +721,7 @@ struct luw_solver {
 	hipStream_t stream = nullptr;
 	uint32_t kernel = LUW_KERNEL_AUTO;
 	std::vector<void*> raw; // hipMalloc'ed blocks behind the lattice-sized arrays (lead_alloc)
+	uint32_t gather_count = 0u; uint32_t* d_gather_cell = nullptr; float* d_gather_out = nullptr; // probe columns
 };
 
 // Lattice-sized device arrays start LEAD elements into their allocation, LEAD = 64 - halo_x: with the x pitch a multiple of
@@ -817,6 +826,7 @@ void luw_destroy(luw_solver* s) {
 	if(s->own_stream) (void)hipStreamSynchronize(s->own_stream);
 	for(void* r : s->raw) (void)hipFree(r); // fi, rho, u, flags, F, statistics
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
+	(void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out);
 	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
 	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F);
 	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1027,6 +1037,35 @@ int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, 
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	for(int k=0; k<3; k++) (void)hipFree(d[k]);
 	return luw_download(s, LUW_MASK_FLAGS); // LBM::voxelize_mesh_on_device leaves the result in lbm.flags
+}
+
+int luw_gather_attach(luw_solver* s, uint32_t count, const uint64_t* cells) {
+	if(!s||(count>0u&&!cells)) return fail(LUW_ERR_INVALID, "luw_gather_attach: bad argument");
+	if(int e = set_device(s)) return e;
+	(void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out); s->d_gather_cell = nullptr; s->d_gather_out = nullptr; s->gather_count = 0u;
+	if(count==0u) return LUW_OK;
+	std::vector<uint32_t> c(count);
+	const uint64_t A = (uint64_t)s->cfg.Nx*s->cfg.Ny;
+	for(uint32_t i=0u; i<count; i++) {
+		if(cells[i]>=s->N) return fail(LUW_ERR_INVALID, "luw_gather_attach: cell index outside the lattice");
+		const uint32_t z = (uint32_t)(cells[i]/A), y = (uint32_t)((cells[i]%A)/s->cfg.Nx), x = (uint32_t)(cells[i]%s->cfg.Nx);
+		c[i] = x+(y+z*s->cfg.Ny)*s->kp.Px;
+	}
+	if(hipMalloc((void**)&s->d_gather_cell, 4ull*count)!=hipSuccess||hipMalloc((void**)&s->d_gather_out, 12ull*count)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed");
+	HIP_TRY(hipMemcpy(s->d_gather_cell, c.data(), 4ull*count, hipMemcpyHostToDevice));
+	s->gather_count = count;
+	return LUW_OK;
+}
+int luw_gather_u(luw_solver* s, float* out) {
+	if(!s||!out) return fail(LUW_ERR_INVALID, "luw_gather_u: bad argument");
+	if(s->gather_count==0u) return LUW_OK;
+	if(!s->fields_current) return fail(LUW_ERR_STATE, "luw_gather_u: rho,u on the device are stale (the last step did not write fields)");
+	if(int e = set_device(s)) return e;
+	hipLaunchKernelGGL(k_gather_u, dim3((s->gather_count+255u)/256u), dim3(256), 0, s->stream, s->gather_count, s->d_gather_cell, s->d_u, (size_t)s->kp.Np, s->d_gather_out);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out, s->d_gather_out, 12ull*s->gather_count, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
 }
 
 int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag, uint8_t* flags) {

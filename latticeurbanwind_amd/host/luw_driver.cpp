@@ -8,7 +8,7 @@
 //   + transform FX/setup.cpp:4070-4087, profile table :5777-5912, flags/u fill :5914-5995 (profile mode) and :5655-5688
 //   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
 // Modes: *.luw (NWP: SurfData CSV boundaries), *.luwpf (profile, with optional DEM ground plane) and *.luwdg (dataset).
-// Not in this build (announced on the console, never silently): probes, PNG frames, temperature boundaries.
+// Not in this build (announced on the console, never silently): PNG frames, temperature boundaries.
 // Differences by design: time averaging runs on the device (luw_stats_*); --dry-run voxelises on the host; the von-Karman
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
 // Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
@@ -34,6 +34,7 @@
 #include "lbm.hpp"
 #include "vk_inlet.hpp"
 #include "bc_builders.hpp"
+#include "probes.hpp"
 
 using namespace luw_host;
 using std::string;
@@ -194,6 +195,7 @@ struct Config {
 	VkUcMode vk_uc = VkUcMode::NORM_MEAN; bool vk_same = true, vk_interp = false, vk_inflow_only = false; VkFaceMode vk_face_mode = VkFaceMode::AUTO_SIDES; float vk_aniso[3] = {1.0f, 1.0f, 1.0f};
 	std::vector<float> inflow_list, angle_list;
 	// command line
+	string probes_raw, utm_crs; bool probes_output_defined = false; uint probes_output_steps = 0u; bool has_rotate_deg = false; double rotate_deg = 0.0;
 	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
 	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk, export_setup;
 };
@@ -488,6 +490,10 @@ int main(int argc, char** argv) {
 		else if(key=="vk_inlet_anisotropy") { if(!uq.empty()) { const size_t lb = uq.find('['), rb = uq.find(']', lb); const string in = (lb!=string::npos&&rb!=string::npos&&rb>lb) ? uq.substr(lb+1u, rb-lb-1u) : uq; std::stringstream ss(in); string tok; float v[3]; int i = 0; bool ok = true; while(std::getline(ss, tok, ',')&&i<3) { const string t = deck_trim(tok); char* end = nullptr; const float f = std::strtof(t.c_str(), &end); if(t.empty()||end==t.c_str()) { ok = false; break; } v[i++] = f; } if(ok&&i==3) for(int k=0; k<3; k++) c.vk_aniso[k] = (std::isfinite(v[k])&&v[k]>=0.0f) ? v[k] : 1.0f; } }
 		else if(key=="cut_lon_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lon[0], c.cut_lon[1]); c.has_cut_lon = true; } }
 		else if(key=="cut_lat_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lat[0], c.cut_lat[1]); c.has_cut_lat = true; } }
+		else if(key=="probes") c.probes_raw = deck_trim(val);
+		else if(key=="probes_output") { if(!uq.empty()) { const int v = atoi(uq.c_str()); c.probes_output_defined = true; if(v>0) c.probes_output_steps = (uint)v; else { c.probes_output_steps = 0u; println("| WARNING: probes_output must be > 0 to take effect. Fallback to legacy window. |"); } } }
+		else if(key=="utm_crs") { if(!uq.empty()) c.utm_crs = uq; }
+		else if(key=="rotate_deg") { if(!uq.empty()) { char* end = nullptr; const double v = std::strtod(uq.c_str(), &end); if(end!=uq.c_str()&&std::isfinite(v)) { c.rotate_deg = v; c.has_rotate_deg = true; } } }
 		else if(key=="inflow") { if(!uq.empty()) parse_float_list(val, c.inflow_list); }
 		else if(key=="angle") { if(!uq.empty()) parse_float_list(val, c.angle_list); }
 	}
@@ -513,6 +519,17 @@ int main(int argc, char** argv) {
 		const string lp = (std::filesystem::path(c.parent)/"proj_temp"/(now_str("%Y%m%d%H%M%S")+"_lbm.log")).string();
 		if(!ec&&!c.dry_run) { g_log.open(lp); if(g_log.is_open()) println("| Console log     | "+lp+" |"); }
 	}
+	std::vector<ProbeRequest> probe_requests; GeoFrame probe_geo; // FX/setup.cpp:3396-3426
+	if(!c.probes_raw.empty()) {
+		for(const string& tok : split_probe_list(c.probes_raw)) {
+			ProbeRequest rq; string err;
+			if(!parse_probe(tok, rq, err)) { println("| WARNING: ignore probe token '"+tok+"': "+err+"                        |"); continue; }
+			probe_requests.push_back(rq);
+		}
+		if(probe_requests.empty()) println("| WARNING: probes is defined but no valid probe token was parsed.                |");
+		else if(!(c.has_cut_lon&&c.has_cut_lat)) println("| WARNING: probes requires cut_lon_manual/cut_lat_manual for lon-lat mapping.    |");
+		else { probe_geo = make_geo_frame(c.cut_lon[0], c.cut_lon[1], c.cut_lat[0], c.cut_lat[1], c.utm_crs, c.has_rotate_deg, c.rotate_deg); if(!probe_geo.valid) println("| WARNING: failed to build probes geographic mapping. Probes are disabled.       |"); }
+	}
 	if(c.nwp_mode) { // FX/setup.cpp:3446-3475: the reference asks on stdin; with no terminal attached an empty answer means "continue"
 		string v = c.validation; std::transform(v.begin(), v.end(), v.begin(), ::tolower);
 		if(v!="pass"&&v!="true"&&v!="1") { println("|-----------------------------------------------------------------------------|"); println("| WARNING: Validation status is '"+c.validation+"'. Pre-processing may be incomplete or invalid. |"); println("| Proceeding (non-interactive).                                               |"); }
@@ -530,6 +547,13 @@ int main(int argc, char** argv) {
 	println("| Downstream Open | "+alignr(57u, c.downstream_open_face ? string("true") : string("false"))+" |");
 	println("| GPU Decompose   | "+alignr(49u, to_string_u(c.Dx))+", "+alignr(2u, to_string_u(c.Dy))+", "+alignr(2u, to_string_u(c.Dz))+" |");
 	println("| Run Steps       | "+alignr(57u, c.run_nstep_override>0ull ? to_string_u(c.run_nstep_override)+" (run_nstep)" : string("20001 (default)"))+" |");
+	{ // FX/setup.cpp:3507-3527
+		string d = "off"; if(!probe_requests.empty()) { d = to_string_u(probe_requests.size())+" request(s)"; if(!probe_geo.valid) d += " (mapping unavailable)"; }
+		println("| Probes         | "+alignr(57u, d)+" |");
+		string w = "n/a";
+		if(!probe_requests.empty()) w = (c.probes_output_defined&&c.probes_output_steps>0u) ? "last "+to_string_u(c.probes_output_steps)+" step(s) via probes_output" : (c.purge_avg_steps>0u||c.research_output_steps>0u) ? "fallback last "+to_string_u(std::max(c.purge_avg_steps, c.research_output_steps))+" step(s)" : string("entire simulation");
+		println("| Probes Window  | "+alignr(57u, w)+" |");
+	}
 	println("| DDF storage     | "+alignr(57u, c.fp16c ? string("FP16C (as the shipped reference build)") : string("FP32"))+" |");
 
 	const float lbm_ref_u = 0.10f; float si_ref_u = 10.0f; const float si_nu = 1.48E-5f, si_rho = 1.225f;
@@ -972,6 +996,35 @@ int main(int argc, char** argv) {
 		const ulong avg_window = c.purge_avg_steps>0u ? std::min((ulong)c.purge_avg_steps, total_steps) : 0ull;
 		const ulong avg_stride = std::max((ulong)1u, (ulong)c.purge_avg_stride);
 		const ulong avg_start_t = avg_window>0ull ? total_steps-avg_window+1ull : ~0ull;
+		// probes, FX/setup.cpp:4269-4395
+		const double dt_si_d = (double)c.cell_m*((double)lbm_ref_u/(double)si_ref_u);
+		const ulong probe_window = probe_requests.empty() ? 0ull : (c.probes_output_defined&&c.probes_output_steps>0u) ? std::min((ulong)c.probes_output_steps, total_steps)
+			: (c.purge_avg_steps>0u||c.research_output_steps>0u) ? std::min((ulong)std::max(c.purge_avg_steps, c.research_output_steps), total_steps) : total_steps;
+		const ulong probe_start_t = probe_window>0ull ? total_steps-probe_window+1ull : ~0ull;
+		std::vector<ProbeColumn> probes; std::vector<uint64_t> probe_cells;
+		if(!probe_requests.empty()) {
+			if(!probe_geo.valid) print_kv_row("Probes", "disabled: geographic mapping is unavailable");
+			else {
+				std::vector<string> used;
+				for(const ProbeRequest& rq : probe_requests) {
+					ProbeColumn pc; pc.req = rq; string why;
+					bool ok = resolve_probe_xy(rq, probe_geo, Nx, Ny, c.cell_m, c.si_x, c.si_y, pc.x, pc.y, why);
+					if(ok) { for(uint z=0u; z<Nz; ++z) if((flags[(ulong)pc.x+((ulong)pc.y+(ulong)z*Ny)*Nx]&TYPE_S)==0u) pc.z.push_back(z); if(pc.z.empty()) { ok = false; why = "resolved column has no fluid cell"; } }
+					if(!ok) { println("| WARNING: probe '"+rq.raw+"' ignored: "+why+"                |"); continue; }
+					for(const uint z : pc.z) pc.height_si.push_back((float)(((double)z-(double)pc.z.front()+0.5)*(double)c.cell_m));
+					string stem = probe_stem(rq, probe_geo, vtk_prefix);
+					if(std::find(used.begin(), used.end(), stem)!=used.end()) { uint k = 2u; string u2 = stem; while(std::find(used.begin(), used.end(), u2)!=used.end()) u2 = stem+"_"+to_string_u(k++); stem = u2; }
+					used.push_back(stem); pc.stem = stem;
+					probes.push_back(std::move(pc));
+				}
+				if(probes.empty()) print_kv_row("Probes", "0 valid probe column after geometry/domain checks");
+				else {
+					print_kv_row("Probes", to_string_u(probes.size())+" active, "+(probe_window>=total_steps ? string("entire run") : "last "+to_string_u(probe_window)+" step(s)"));
+					bool first = true;
+					for(const ProbeColumn& pc : probes) { print_kv_row(first ? "Probe cell" : "", pc.stem+" -> ("+to_string_u(pc.x)+","+to_string_u(pc.y)+"), levels="+to_string_u(pc.z.size())); first = false; for(const uint z : pc.z) probe_cells.push_back((uint64_t)pc.x+((uint64_t)pc.y+(uint64_t)z*Ny)*Nx); }
+				}
+			}
+		}
 		if(!c.export_setup.empty()) { // hand-over to the multi-GPU launcher (latticeurbanwind_amd/run_deck.py): everything the run loop needs, per case
 			std::filesystem::create_directories(c.export_setup);
 			const string base = c.export_setup+"/case"+to_string_u(case_index);
@@ -1007,6 +1060,8 @@ int main(int argc, char** argv) {
 		if(Nz_out<Nz) print_kv_row("VTK z output", "core Nz="+to_string_u(Nz_out)+" of solver Nz="+to_string_u(Nz)+" (top sponge omitted)");
 		print_kv_row("Run steps", to_string_u(total_steps)+(c.run_nstep_override>0ull ? " (run_nstep override)" : " (default)"));
 		if(avg_window>0ull) { print_kv_row("Avg stride", "sample every "+to_string_u(avg_stride)+" step(s) in purge_avg window (on-device accumulation)"); luw_check(luw_stats_reset(lbm.handle())); }
+		if(!probe_cells.empty()) luw_check(luw_gather_attach(lbm.handle(), (uint32_t)probe_cells.size(), probe_cells.data()));
+		std::vector<float> probe_buf(3u*probe_cells.size());
 		lbm.run(0u, total_steps);
 		print_section_title("SOLVER START");
 		const auto t_start = std::chrono::steady_clock::now();
@@ -1017,10 +1072,16 @@ int main(int argc, char** argv) {
 			ulong next = total_steps;
 			if(unsteady>0ull) next = std::min(next, (ulong)((lbm.get_t()/unsteady+1ull)*unsteady));
 			if(avg_window>0ull) { const ulong t1 = lbm.get_t()+1ull; ulong s = std::max(t1, avg_start_t); const ulong off = (s-avg_start_t)%avg_stride; if(off!=0ull) s += avg_stride-off; if(s<=total_steps) next = std::min(next, s); }
+			if(!probes.empty()) next = std::min(next, std::max((ulong)(lbm.get_t()+1ull), probe_start_t)); // every step of the probe window is observed
 			lbm.run(next-lbm.get_t(), total_steps);
 			const ulong t = lbm.get_t();
 			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); last_u_vtk_t = t; }
 			if(avg_window>0ull&&t>=avg_start_t&&(t-avg_start_t)%avg_stride==0ull) luw_check(luw_stats_accumulate(lbm.handle()));
+			if(!probes.empty()&&t>=probe_start_t) { // FX/setup.cpp:4498-4509
+				luw_check(luw_gather_u(lbm.handle(), probe_buf.data()));
+				size_t k = 0u;
+				for(ProbeColumn& pc : probes) { pc.time_si.push_back((double)t*dt_si_d); for(size_t l=0u; l<pc.z.size(); l++, k++) for(int d=0; d<3; d++) pc.uvw_si.push_back(units.si_u(probe_buf[3u*k+(size_t)d])); }
+			}
 		}
 		luw_check(luw_finish(lbm.handle()));
 		const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
@@ -1084,6 +1145,12 @@ int main(int argc, char** argv) {
 				print_kv_row("VTK file", fn+" saved");
 				print_kv_row("Avg samples", to_string_u(avg_count));
 			}
+		}
+		if(!probes.empty()) { // FX/setup.cpp:4718-4760
+			std::filesystem::create_directories(c.parent+"/RESULTS");
+			ulong written = 0ull;
+			for(const ProbeColumn& pc : probes) { const string path = c.parent+"/RESULTS/"+pc.stem+".csv"; if(write_probe_csv(path, pc)) written++; else print_kv_row("Probe output", "failed to open "+path); }
+			print_kv_row("Probe files", to_string_u(written)+" CSV saved to RESULTS");
 		}
 		print_kv_row("Task finished", "["+now_str()+"]");
 	}

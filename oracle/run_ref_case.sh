@@ -10,6 +10,6 @@ cp -r "$CASE"/. "$WORK"/
 DECK="$(ls "$WORK"/*.luw* | head -1)"
 ( cd "$(dirname "$BIN")" && timeout "$TMO" "$BIN" "$DECK" </dev/null 2>&1 | sed 's/\x1b\[[0-9;]*[A-Za-z]//g' | tr '\r' '\n' > "$OUT/console.log" )
 echo "exit=${PIPESTATUS[0]}" >> "$OUT/console.log"
-if [ "${5:-}" != "novtk" ] && [ -d "$WORK/RESULTS/vtk" ]; then cp "$WORK"/RESULTS/vtk/*.vtk "$OUT"/ 2>/dev/null; fi
+if [ "${5:-}" != "novtk" ] && [ -d "$WORK/RESULTS/vtk" ]; then cp "$WORK"/RESULTS/vtk/*.vtk "$WORK"/RESULTS/*.csv "$OUT"/ 2>/dev/null; fi
 ls -la "$OUT" | tail -n +2
 rm -rf "$WORK"

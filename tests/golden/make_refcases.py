@@ -13,6 +13,7 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
   D  case B on a base slab at z = 0..4 m with proj_temp/interpolated_dem.csv (terrain hill): DEM ground plane, terrain clip,
      profile above local terrain, flux correction in profile mode
+  P  case B with probe columns (deck key probes / probes_output): RESULTS/<lon>_<lat>[_offset].csv
   N1..N4  *.luw (NWP) decks on the case-B geometry with synthetic SurfData CSVs: N1 patch-driven 2-D mapping + flux
      correction + Coriolis; N2 KNN-HD (high_order) + flux correction; N3 nearest-sample + nudging + sponge + open
      downstream face; N4 patch mapping with an open downstream face
@@ -202,6 +203,9 @@ if __name__ == "__main__":
     write_case(root, "CaseH", 1.0, off, building="city", nstep=16, cell=2.5)
     # D: profile mode with a DEM ground plane (interpolated_dem.csv), STL base slab on z = 0..4 as luwvox writes it
     write_case(root, "CaseD", 1.0, off + ["flux_correction = true"], nstep=16, z0=4.0, dem=True)
+    # P: probes (centre, grid-cell and metre offsets, lon:lat) sampled over the last 6 steps
+    write_case(root, "CaseP", 1.0, off + ["cut_lon_manual = [121.4000, 121.4010]", "cut_lat_manual = [31.2000, 31.2007]",
+                                          'probes = [center, "centre" NNE, center S10.5W20, 121.40031:31.20022, 121.40085:31.20051 E4, 125.0:31.2]', "probes_output = 6"], nstep=16)
     # N1..N4: *.luw (NWP) mode, boundaries from a synthetic SurfData CSV
     write_luw_case(root, "CaseN1", "patch", off + ["high_order = false", "flux_correction = true", "coriolis_term = true"])
     write_luw_case(root, "CaseN2", "cloud", off + ["high_order = true", "flux_correction = true", "coriolis_term = false"])

@@ -149,3 +149,17 @@ def test_nwp_boundary_builders_against_real_reference_fields(driver, tmp_path, c
         mine = sorted(l for l in mine_all if frag in l)
         theirs = sorted(l for l in theirs_all if frag in l)
         assert mine == theirs, (frag, mine, theirs)
+
+
+def test_probe_requests_resolve_like_the_reference(driver, tmp_path):
+    """deck key `probes`: token grammar (centre / quoted centre + grid offset / metre offset / lon:lat / lon:lat + offset /
+    outside the domain), WGS84 -> UTM -> rotated local frame, snapping to a lattice column, file stems: the rows the REAL
+    reference printed for the same deck (levels depend on the voxel mask: host-voxelised here, so only stems and columns
+    are compared on the CPU; tests/test_gpu_driver.py compares the CSV files)"""
+    out = run(driver, os.path.join(GOLD, "refcases", "CaseP", "conf.luwpf"), "--dry-run")
+    ref = open(os.path.join(GOLD, "ref_fp32_CaseP.console.txt")).read()
+    import re
+    pick = lambda txt: re.findall(r"(\S+) -> \((\d+),(\d+)\), levels=", txt)
+    assert pick(out) == pick(ref) and len(pick(ref)) == 5
+    norm = lambda txt: [" ".join(l.strip().strip("|").split()) for l in txt.splitlines() if "ignored:" in l or "Probes Window" in l or "request(s)" in l]
+    assert norm(out) == norm(ref)

@@ -78,6 +78,7 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
     ("CaseG", "fp16c", "ref_shipped_CaseG"), ("CaseH", "fp16c", "ref_shipped_CaseH"),
     # *.luw (NWP) decks: SurfData CSV -> patch-driven 2-D mapping / KNN-HD / nearest-sample boundaries, flux correction,
     # terrain clip, Coriolis, open downstream face
+    ("CaseP", "fp32", "ref_fp32_CaseP"), ("CaseP", "fp16c", "ref_shipped_CaseP"),     # probe columns -> RESULTS/*.csv
     ("CaseD", "fp32", "ref_fp32_CaseD"), ("CaseD", "fp16c", "ref_shipped_CaseD"),     # DEM ground plane + flux correction in profile mode
     ("CaseN1", "fp32", "ref_fp32_CaseN1"), ("CaseN2", "fp32", "ref_fp32_CaseN2"), ("CaseN3", "fp32", "ref_fp32_CaseN3"),
     ("CaseN4", "fp32", "ref_fp32_CaseN4"), ("CaseN1", "fp16c", "ref_shipped_CaseN1"), ("CaseN2", "fp16c", "ref_shipped_CaseN2"),
@@ -130,6 +131,20 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_rho-%09d.vtk" % times[-1]))[0])
     dr = np.abs((ff["data"][..., 0] - gold["rho%d" % times[-1]]) / rho_fac)[fluid].max()
     assert dr < (1e-2 if fp16c else 1e-4), "rho max diff %.3e" % dr
+    probes = os.path.join(GOLD, fixture + "_probes")
+    if os.path.isdir(probes):     # probe CSVs: same files, same levels and times, velocities within the final-step gate (SI text, 6 decimals)
+        def rd(path):
+            L = open(path).read().strip().split("\n")
+            return L[0], [l.split(",")[0] for l in L[1:]], np.array([[[float(x) for x in c.split(":")] for c in l.split(",")[1:]] for l in L[1:]])
+        want = sorted(os.listdir(probes)); got = sorted(os.path.basename(q) for q in glob.glob(os.path.join(proj, "RESULTS", "*.csv")))
+        assert want == got and len(want) == 5
+        for name in want:
+            hw, zw, vw = rd(os.path.join(probes, name)); hg, zg, vg = rd(os.path.join(proj, "RESULTS", name))
+            assert hw == hg and zw == zg and vw.shape == vg.shape, name
+            assert np.abs(vw - vg).max() / float(fac) < (1e-4 if fp16c else 1e-6), name
+        ref_rows = [" ".join(l.strip().strip("|").split()) for l in open(os.path.join(GOLD, fixture + ".console.txt")).read().splitlines() if "levels=" in l or "ignored:" in l]
+        my_rows = [" ".join(l.strip().strip("|").split()) for l in r.stdout.splitlines() if "levels=" in l or "ignored:" in l]
+        assert ref_rows == my_rows and len(ref_rows) == 6
     # voxel count line of the console, as the reference prints it
     want = re.search(r"solid = (\d+), fluid = (\d+)", open(os.path.join(GOLD, fixture + ".console.txt")).read())
     got = re.search(r"solid = (\d+), fluid = (\d+)", r.stdout)

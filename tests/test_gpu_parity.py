@@ -12,6 +12,7 @@ from helpers import synthetic_state, TYPE_S, TYPE_E
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -181,6 +182,36 @@ def test_rest_state_and_mass_conservation_at_512cubed(luw):
     g.run(20)
     g.rho.read_from_device()
     assert abs(g.rho.data.astype(np.float64).mean() - 1.0) < 1e-7
+    g.close()
+
+
+def test_building_array_at_1024x1024x256(luw):
+    """BASELINE configs[2] size and solid mask (bench.py --buildings): with solids, the rest state stays an exact fixed point
+    (bounce-back moves only zeros), a periodic box with the building array conserves the fluid mass while a shear wave
+    decays."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from bench import channel_state
+    Nx, Ny, Nz = 1024, 1024, 256
+    fl, u, rho = channel_state(Nx, Ny, Nz, buildings=True)
+    solid = (fl & TYPE_S) != 0
+    g = luw.LBM(Nx, Ny, Nz, 1e-5)
+    g.flags.data[:] = np.where(solid, TYPE_S, 0).astype(np.uint8)        # periodic box: solids only
+    g.run(6)
+    g.rho.read_from_device(); g.u.read_from_device()
+    assert np.all(g.rho.data == 1.0) and not g.u.data.any()
+    g.close()
+    g = luw.LBM(Nx, Ny, Nz, 0.01)
+    g.flags.data[:] = np.where(solid, TYPE_S, 0).astype(np.uint8)
+    wave = (0.02 * np.sin(2 * np.pi * np.arange(Nz, dtype=np.float32) / Nz)).astype(np.float32)
+    ux = g.u.data.reshape(3, Nz, Ny, Nx)[0]
+    ux[:] = wave[:, None, None]; ux[solid.reshape(Nz, Ny, Nx)] = 0.0
+    g.run(20)
+    g.rho.read_from_device(); g.u.read_from_device()
+    fluid = ~solid
+    assert np.isfinite(g.u.data).all()
+    assert abs(g.rho.data[fluid].astype(np.float64).mean() - 1.0) < 1e-6       # bounce-back conserves mass
+    assert not g.u.data.reshape(3, -1)[:, solid].any()                        # solids never receive a velocity
     g.close()
 
 

@@ -8,6 +8,6 @@ for c in "$@"; do
   for ddf in fp32 fp16c; do
     w=$(mktemp -d); cp -r tests/golden/refcases/$c/. $w/
     latticeurbanwind_amd/host/luw_driver $w/conf.luw* --ddf $ddf > $w/console.log 2>&1; echo "driver $c $ddf rc=$?"
-    mkdir -p gpurun_out/mine/${ddf}_$c; cp $w/RESULTS/vtk/*.vtk $w/console.log gpurun_out/mine/${ddf}_$c/ 2>/dev/null
+    mkdir -p gpurun_out/mine/${ddf}_$c; cp $w/RESULTS/vtk/*.vtk $w/RESULTS/*.csv $w/console.log gpurun_out/mine/${ddf}_$c/ 2>/dev/null
   done
 done
