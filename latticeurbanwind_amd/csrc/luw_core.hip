@@ -531,17 +531,23 @@ __device__ __forceinline__ float vdot(const float ax, const float ay, const floa
 	return fmaf(az, bz, fmaf(ay, by, ax*bx)); // dot(float3) of the OpenCL device library: mad(z, z', mad(y, y', x*x'))
 }
 struct VoxGrid { uint32_t Nx, Ny, Nz, Px; int Ox, Oy, Oz; uint64_t Np; }; // lattice of the pass: a solver domain, or a bare global lattice (luw_voxelize_lattice)
-__global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t triangle_number,
+// One block = one 16x16 tile of columns; it visits only the triangles binned to the tile (tile_start / tile_tri: CSR, triangle
+// ids ascending, so hits are met in the reference's order and the 64-entry cut-off falls on the same hits).  The bins hold
+// every triangle whose xy bounding box, grown by one cell, touches the tile -- the margin the reference itself uses when it
+// hands a domain its triangle subset (FX/lbm.cpp:1455-1487).
+constexpr uint32_t VOX_TILE = 16u;
+__global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_tri,
 		const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2, const float x0, const float y0, const float z0, const float x1, const float y1, const float z1) {
-	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
-	if(a>=p.Nx*p.Ny) return;
-	const uint32_t x = a%p.Nx, y = a/p.Nx;
+	const uint32_t x = blockIdx.x*VOX_TILE+threadIdx.x%VOX_TILE, y = blockIdx.y*VOX_TILE+threadIdx.x/VOX_TILE;
+	if(x>=p.Nx||y>=p.Ny) return;
+	const uint32_t tile = blockIdx.x+blockIdx.y*gridDim.x, k0 = tile_start[tile], k1 = tile_start[tile+1u];
 	const int zs = min(max((int)z0-p.Oz, 0), (int)p.Nz-1);
 	const float rx = (float)((int)x+p.Ox), ry = (float)((int)y+p.Oy), rz = (float)(zs+p.Oz); // position(xyz)+offset = global index coordinates
 	if(rx<x0||ry<y0||rx>=x1||ry>=y1) return;
 	uint32_t intersections = 0u, intersections_check = 0u;
 	uint16_t distances[64];
-	for(uint32_t i=0u; i<triangle_number; i++) {
+	for(uint32_t kk=k0; kk<k1; kk++) {
+		const uint32_t i = tile_tri[kk];
 		const float ax = p0[3u*i], ay = p0[3u*i+1u], az = p0[3u*i+2u];
 		const float ux = p1[3u*i]-ax, uy = p1[3u*i+1u]-ay, uz = p1[3u*i+2u]-az;
 		const float vx = p2[3u*i]-ax, vy = p2[3u*i+1u]-ay, vz = p2[3u*i+2u]-az;
@@ -1013,6 +1019,7 @@ int luw_run(luw_solver* s, uint64_t steps);
 int luw_upload(luw_solver* s, uint32_t mask);
 int luw_download(luw_solver* s, uint32_t mask);
 static int vk_apply(luw_solver* s);
+static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1, const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st);
 int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag) {
 	if(!s||!p0||!p1||!p2||triangle_number==0u) return fail(LUW_ERR_INVALID, "luw_voxelize_mesh: bad argument");
 	if(int e = set_device(s)) return e;
@@ -1029,14 +1036,45 @@ int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, 
 	const float* h[3] = { p0, p1, p2 };
 	for(int k=0; k<3; k++) { if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess) { for(int q=0; q<3; q++) (void)hipFree(d[q]); return fail(LUW_ERR_NOMEM, "luw_voxelize_mesh: allocation failed"); } HIP_TRY(hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)); }
 	if(int e = luw_upload(s, LUW_MASK_FLAGS|LUW_MASK_U)) return e; // the host mirror is authoritative before the first run
-	const uint32_t A = s->cfg.Nx*s->cfg.Ny;
 	const VoxGrid vg = { s->kp.Nx, s->kp.Ny, s->kp.Nz, s->kp.Px, s->kp.Ox, s->kp.Oy, s->kp.Oz, (uint64_t)s->kp.Np };
-	hipLaunchKernelGGL(k_voxelize_z, dim3((A+255u)/256u), dim3(256), 0, s->stream, vg, s->d_flags, s->d_u, flag, triangle_number, d[0], d[1], d[2],
-		pmin[0]-2.0f, pmin[1]-2.0f, pmin[2]-2.0f, pmax[0]+2.0f, pmax[1]+2.0f, pmax[2]+2.0f); // bounding box + 2 cells, FX/lbm.cpp:498
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(s->stream));
+	const int rc = voxelize_launch(vg, s->d_flags, s->d_u, flag, triangle_number, p0, p1, p2, d, pmin, pmax, s->stream);
 	for(int k=0; k<3; k++) (void)hipFree(d[k]);
+	if(rc!=LUW_OK) return rc;
 	return luw_download(s, LUW_MASK_FLAGS); // LBM::voxelize_mesh_on_device leaves the result in lbm.flags
+}
+
+// bins + launch shared by luw_voxelize_mesh (a solver's domain) and luw_voxelize_lattice (bare lattice)
+static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1, const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st) {
+	const uint32_t tx = (vg.Nx+VOX_TILE-1u)/VOX_TILE, ty = (vg.Ny+VOX_TILE-1u)/VOX_TILE;
+	const bool brute = getenv("LUW_VOXELIZE_ALL_TRIANGLES")!=nullptr; // test aid: every tile sees every triangle
+	std::vector<uint32_t> start((size_t)tx*ty+1u, 0u), tri;
+	auto range = [&](const uint32_t i, int& a0, int& a1, int& b0, int& b1) {
+		if(brute) { a0 = 0; a1 = (int)tx-1; b0 = 0; b1 = (int)ty-1; return; }
+		const float xlo = fminf(fminf(p0[3u*i], p1[3u*i]), p2[3u*i]), xhi = fmaxf(fmaxf(p0[3u*i], p1[3u*i]), p2[3u*i]);
+		const float ylo = fminf(fminf(p0[3u*i+1u], p1[3u*i+1u]), p2[3u*i+1u]), yhi = fmaxf(fmaxf(p0[3u*i+1u], p1[3u*i+1u]), p2[3u*i+1u]);
+		const float pad = 1.0f+1.0e-4f; // overlap_pad + overlap_eps of the reference's subset test
+		a0 = (int)floorf((xlo-pad-(float)vg.Ox)/(float)VOX_TILE); a1 = (int)floorf((xhi+pad-(float)vg.Ox)/(float)VOX_TILE);
+		b0 = (int)floorf((ylo-pad-(float)vg.Oy)/(float)VOX_TILE); b1 = (int)floorf((yhi+pad-(float)vg.Oy)/(float)VOX_TILE);
+		a0 = std::max(a0, 0); b0 = std::max(b0, 0); a1 = std::min(a1, (int)tx-1); b1 = std::min(b1, (int)ty-1);
+	};
+	for(uint32_t i=0u; i<ntri; i++) { int a0, a1, b0, b1; range(i, a0, a1, b0, b1); for(int b=b0; b<=b1; b++) for(int a=a0; a<=a1; a++) start[(size_t)a+(size_t)b*tx+1u]++; }
+	for(size_t t=0u; t<(size_t)tx*ty; t++) { if((uint64_t)start[t]+start[t+1u]>0xFFFFFFFFull) return fail(LUW_ERR_INVALID, "voxelize: triangle bins exceed 2^32 entries"); start[t+1u] += start[t]; }
+	tri.resize(std::max<size_t>(start.back(), 1u));
+	{ std::vector<uint32_t> fill(start.begin(), start.end()-1);
+	  for(uint32_t i=0u; i<ntri; i++) { int a0, a1, b0, b1; range(i, a0, a1, b0, b1); for(int b=b0; b<=b1; b++) for(int a=a0; a<=a1; a++) tri[fill[(size_t)a+(size_t)b*tx]++] = i; } }
+	uint32_t* d_start = nullptr; uint32_t* d_tri = nullptr;
+	if(hipMalloc((void**)&d_start, 4ull*start.size())!=hipSuccess||hipMalloc((void**)&d_tri, 4ull*tri.size())!=hipSuccess) { (void)hipFree(d_start); (void)hipFree(d_tri); return fail(LUW_ERR_NOMEM, "voxelize: allocation failed"); }
+	hipError_t e = hipMemcpy(d_start, start.data(), 4ull*start.size(), hipMemcpyHostToDevice);
+	if(e==hipSuccess) e = hipMemcpy(d_tri, tri.data(), 4ull*tri.size(), hipMemcpyHostToDevice);
+	if(e==hipSuccess) {
+		hipLaunchKernelGGL(k_voxelize_z, dim3(tx, ty), dim3(256), 0, st, vg, d_flags, d_u, flag, d_start, d_tri, d[0], d[1], d[2],
+			pmin[0]-2.0f, pmin[1]-2.0f, pmin[2]-2.0f, pmax[0]+2.0f, pmax[1]+2.0f, pmax[2]+2.0f); // bounding box + 2 cells, FX/lbm.cpp:498
+		e = hipGetLastError();
+	}
+	if(e==hipSuccess) e = hipStreamSynchronize(st);
+	(void)hipFree(d_start); (void)hipFree(d_tri);
+	if(e!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string("voxelize: ")+hipGetErrorString(e));
+	return LUW_OK;
 }
 
 int luw_gather_attach(luw_solver* s, uint32_t count, const uint64_t* cells) {
@@ -1079,13 +1117,10 @@ int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint
 	for(int k=0; k<3; k++) if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess||hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)!=hipSuccess) { cleanup(); return fail(LUW_ERR_NOMEM, "luw_voxelize_lattice: allocation failed"); }
 	if(hipMemcpy(d_flags, flags, N, hipMemcpyHostToDevice)!=hipSuccess) { cleanup(); return fail(LUW_ERR_DEVICE, "luw_voxelize_lattice: upload failed"); }
 	const VoxGrid vg = { Nx, Ny, Nz, Nx, 0, 0, 0, N };
-	const uint32_t A = Nx*Ny;
-	hipLaunchKernelGGL(k_voxelize_z, dim3((A+255u)/256u), dim3(256), 0, 0, vg, d_flags, (const float*)nullptr, flag, triangle_number, d[0], d[1], d[2],
-		bounds[0]-2.0f, bounds[1]-2.0f, bounds[2]-2.0f, bounds[3]+2.0f, bounds[4]+2.0f, bounds[5]+2.0f);
-	hipError_t e = hipGetLastError();
-	if(e==hipSuccess) e = hipDeviceSynchronize();
-	if(e==hipSuccess) e = hipMemcpy(flags, d_flags, N, hipMemcpyDeviceToHost);
+	const int rc = voxelize_launch(vg, d_flags, nullptr, flag, triangle_number, p0, p1, p2, d, bounds, bounds+3, (hipStream_t)0);
+	hipError_t e = rc==LUW_OK ? hipMemcpy(flags, d_flags, N, hipMemcpyDeviceToHost) : hipSuccess;
 	cleanup();
+	if(rc!=LUW_OK) return rc;
 	if(e!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string("luw_voxelize_lattice: ")+hipGetErrorString(e));
 	return LUW_OK;
 }

@@ -60,3 +60,39 @@ def test_voxelize_preserves_other_flags_and_clears_stale_solids(luw):
     lbm.voxelize_mesh_on_device(su["tri_lattice"])
     f = lbm.flags.data.reshape(Nz, Ny, Nx)
     assert f[13, 5, 5] == 0 and f[13, 6, 6] == 0x01 and f[13, 7, 7] == 0x02 and f[1, 8, 8] == 0x01
+
+
+def test_triangle_bins_do_not_change_the_mask(luw):
+    """the kernel visits only the triangles binned to a 16x16 column tile (bounding box grown by one cell, triangle order
+    kept); with LUW_VOXELIZE_ALL_TRIANGLES every tile sees every triangle, as the reference kernel does: same cells, on a
+    mesh of 300 rotated boxes / pyramids / tetrahedra spread over a 400x320x64 lattice"""
+    import sys, time
+    sys.path.insert(0, GOLD)
+    import make_refcases as mr
+    from latticeurbanwind_amd.lbm import LBM
+    rng = np.random.default_rng(5)
+    tris = mr.box_tris(1.0, 399.0, 1.0, 319.0, 1.0, 3.0)
+    for k in range(300):
+        cx, cy = rng.uniform(20, 380), rng.uniform(20, 300)
+        kind = k % 3
+        if kind == 0:
+            tris += mr.rot_box_tris(cx, cy, rng.uniform(4, 30), rng.uniform(4, 30), 3.0, 3.0 + rng.uniform(2, 50), rng.uniform(0, 90))
+        elif kind == 1:
+            w = rng.uniform(5, 20)
+            tris += mr.hull_tris([(cx - w, cy - w, 3.0), (cx + w, cy - w * 0.8, 3.0), (cx + w * 0.9, cy + w, 3.0), (cx - w, cy + w * 0.7, 3.0)], [(cx, cy, 3.0 + rng.uniform(5, 40))])
+        else:
+            z = rng.uniform(10, 40)
+            tris += mr.hull_tris([(cx - 6, cy - 5, z), (cx + 7, cy - 4, z + 1.5), (cx, cy + 8, z + 0.7)], [(cx + 0.5, cy, z + rng.uniform(4, 15))])
+    tri = np.array(tris, np.float32)
+    masks, secs = [], []
+    for brute in (False, True):
+        if brute: os.environ["LUW_VOXELIZE_ALL_TRIANGLES"] = "1"
+        else: os.environ.pop("LUW_VOXELIZE_ALL_TRIANGLES", None)
+        try:
+            lbm = LBM(400, 320, 64, nu=0.01)
+            t0 = time.perf_counter(); lbm.voxelize_mesh_on_device(tri); secs.append(time.perf_counter() - t0)
+            masks.append((lbm.flags.data & 1).copy()); lbm.close()
+        finally:
+            os.environ.pop("LUW_VOXELIZE_ALL_TRIANGLES", None)
+    assert masks[0].sum() > 100000 and np.array_equal(masks[0], masks[1])
+    print("voxelise %d triangles on 400x320x64: binned %.3f s, all triangles per column %.3f s" % (len(tris), secs[0], secs[1]))
