@@ -177,7 +177,9 @@ class HipDomain:
         self.layout = layout
         self.device = torch.device("cuda", device)
         self.lbm = LBM(*layout.lN, nu, fp16c=fp16c, D=layout.D, O=layout.O, device=device, kernel=kernel, **kw)
-        self.dtype = torch.int16 if fp16c else torch.float32
+        # halo buffers travel as raw values: FP32 as float32, FP16C codes as float16 bit patterns (RCCL/NCCL has no int16 type;
+        # point-to-point ops copy bytes, nothing interprets the halves)
+        self.dtype = torch.float16 if fp16c else torch.float32
         self.compute = torch.cuda.Stream(device=self.device)
         self.comm = torch.cuda.Stream(device=self.device)
         self.buf = {}

@@ -11,7 +11,7 @@ class OracleDomain:
         self.layout = layout
         self.o = oracle.OracleLBM(*layout.lN, nu, fp16c=fp16c, D=layout.D, O=layout.O)
         self.np_dtype = np.uint16 if fp16c else np.float32
-        self.t_dtype = torch.int16 if fp16c else torch.float32
+        self.t_dtype = torch.float16 if fp16c else torch.float32   # FP16C codes ride as float16 bit patterns (NCCL has no int16)
         self.buf = {a: [torch.zeros(5 * self.o.area(a), dtype=self.t_dtype) for _ in range(4)] for a in layout.split_axes()}
 
     def set_fields(self, flags, u, rho):
@@ -28,8 +28,8 @@ class OracleDomain:
 
     def extract(self, axis, stream):
         bp, bm = self.o.extract_fi(axis)
-        self.buf[axis][0].copy_(torch.from_numpy(bp.view(np.int16) if self.np_dtype == np.uint16 else bp))
-        self.buf[axis][1].copy_(torch.from_numpy(bm.view(np.int16) if self.np_dtype == np.uint16 else bm))
+        self.buf[axis][0].copy_(torch.from_numpy(bp.view(np.float16) if self.np_dtype == np.uint16 else bp))
+        self.buf[axis][1].copy_(torch.from_numpy(bm.view(np.float16) if self.np_dtype == np.uint16 else bm))
         return self.buf[axis][0], self.buf[axis][1]
 
     def recv_buffers(self, axis): return self.buf[axis][2], self.buf[axis][3]
