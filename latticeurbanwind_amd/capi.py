@@ -59,6 +59,7 @@ def build(force=False):
     srcs = [os.path.join(src_dir, f) for f in ("luw_core.hip", "luw_device.hpp")] + [os.path.join(_HERE, "..", "include", "luw_core.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "host"), "-s"])      # the deck driver (C++ host over the C-ABI)
     return _SO
 
 
