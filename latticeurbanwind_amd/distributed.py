@@ -231,6 +231,12 @@ class HipDomain:
         self.lbm.set_stream(stream.cuda_stream)
         self.lbm.vk_inlet_apply()
 
+    def gather_attach(self, cells): self.lbm.gather_attach(cells)
+
+    def gather_u(self):
+        self.lbm.set_stream(self.compute.cuda_stream)
+        return self.lbm.gather_u()
+
     def stats_reset(self): self.lbm.stats_reset()
 
     def stats_accumulate(self):

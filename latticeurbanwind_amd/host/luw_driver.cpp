@@ -24,6 +24,7 @@
 #include <filesystem>
 #include <fstream>
 #include <functional>
+#include <iomanip>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -1045,6 +1046,9 @@ int main(int argc, char** argv) {
 			   << " \"output\": {\"tke\": " << (c.out_tke ? 1 : 0) << ", \"ti\": " << (c.out_ti ? 1 : 0) << ", \"tls\": " << (c.out_tls ? 1 : 0) << ", \"results_vtk_dir\": " << jstr(results_vtk_dir) << ", \"raw_prefix\": " << jstr(vtk_prefix+c.datetime+"_raw_") << ", \"avg_name\": " << jstr(vtk_prefix+c.datetime+"_avg") << ",\n"
 			   << "   \"vtk_origin\": " << jstr(to_string_f(geom.origin[0])+" "+to_string_f(geom.origin[1])+" "+to_string_f(geom.origin[2])) << ", \"vtk_spacing\": " << jstr(to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)) << "},\n"
 			   << " \"vk\": {\"on\": " << (vk_on ? 1 : 0) << ", \"stride\": " << c.vk_stride << ", \"interp\": " << (c.vk_interp ? 1 : 0) << "},\n"
+			   << " \"unit_m_bits\": " << fbits(units.unit_m) << ", \"unit_s_bits\": " << fbits(units.unit_s) << ",\n"
+			   << " \"probes\": {\"start_t\": " << (probes.empty() ? 0ull : probe_start_t) << ", \"dt_si\": \"" << [&]() { std::ostringstream o; o << std::setprecision(17) << dt_si_d; return o.str(); }() << "\", \"results_dir\": " << jstr(c.parent+"/RESULTS") << ", \"columns\": ["
+			   << [&]() { std::ostringstream o; bool first = true; for(const ProbeColumn& pc : probes) { o << (first ? "" : ", ") << "{\"stem\": " << jstr(pc.stem) << ", \"x\": " << pc.x << ", \"y\": " << pc.y << ", \"z\": ["; for(size_t i=0u; i<pc.z.size(); i++) o << (i ? ", " : "") << pc.z[i]; o << "], \"height_bits\": ["; for(size_t i=0u; i<pc.height_si.size(); i++) o << (i ? ", " : "") << fbits(pc.height_si[i]); o << "]}"; first = false; } return o.str(); }() << "]},\n"
 			   << " \"state\": " << jstr(base+".state") << ", \"vk_tables\": " << jstr(vk_on ? base+".vk" : string("")) << "\n}\n";
 			print_kv_row("Setup exported", base+".json");
 			continue;
@@ -1090,6 +1094,13 @@ int main(int argc, char** argv) {
 			const ulong t = lbm.get_t();
 			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); }
 			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); print_kv_row("", fr+" saved");
+		}
+		if(c.research_output_steps>0u) { // maybe_write_transform_info, FX/setup.cpp:4778-4798
+			println("| Writing transform.info...                                                  |");
+			const string info_path = c.parent+"/proj_temp/transform.info";
+			std::ofstream info(info_path);
+			if(info.is_open()) { const float dt_si = c.cell_m*(lbm_ref_u/si_ref_u); info << "dt = " << std::fixed << std::setprecision(10) << dt_si << "s\n"; info.close(); println("| Successfully wrote "+info_path+" |"); }
+			else println("ERROR: Could not open "+info_path+" for writing.");
 		}
 		if(avg_window>0ull) { // finalize_avg + write_avg_vtk, FX/setup.cpp:4693-4717,2513-2683
 			std::vector<float> avg_u(3ull*N), avg_rho(N), m2u(N), m2v(N), m2w(N); uint64_t avg_count = 0ull;

@@ -159,6 +159,17 @@ class LBM:
         out["count"] = cnt.value
         return out
 
+    # ---- probe columns: u at a short list of cells per step (luw_gather_*)
+    def gather_attach(self, cells):
+        c = np.ascontiguousarray(cells, np.uint64)
+        self._gather_n = int(c.size)
+        capi.check(self._L.luw_gather_attach(self._h, c.size, c.ctypes.data_as(C.c_void_p)))
+
+    def gather_u(self):
+        out = np.zeros((getattr(self, "_gather_n", 0), 3), np.float32)
+        capi.check(self._L.luw_gather_u(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # ---- device-level interface (multi-GPU driver)
     def area(self, direction): return int(self._L.luw_get_area(self._h, direction))
     def set_stream(self, stream_ptr): capi.check(self._L.luw_set_stream(self._h, stream_ptr))

@@ -157,6 +157,18 @@ def run_case(m, G, device, log, make_sim=None):
     avg_start = total - avg_window + 1 if avg_window > 0 else None
     if avg_window > 0:
         sim.backend.stats_reset()
+    # probe columns (FX/setup.cpp:4269-4395,4495-4506): every rank samples the probe cells it owns, rank 0 writes the CSVs
+    pr = m.get("probes", {"columns": []}); cols = pr["columns"]; probe_start = pr.get("start_t", 0) if cols else None
+    my_cells, my_slots = [], []            # slot = (column index, level index)
+    for ci, col in enumerate(cols):
+        lx, ly = col["x"] - lay.O[0], col["y"] - lay.O[1]
+        for li, z in enumerate(col["z"]):
+            l = (lx, ly, z - lay.O[2])
+            if all(lay.nonhalo_range(a)[0] <= l[a] < lay.nonhalo_range(a)[1] for a in range(3)):
+                my_cells.append(l[0] + (l[1] + l[2] * lay.lN[1]) * lay.lN[0]); my_slots.append((ci, li))
+    if my_cells:
+        sim.backend.gather_attach(np.array(my_cells, np.uint64))
+    probe_times, probe_vals = [], []      # per sampled step: float32 (n_my_cells, 3) in lattice units
     out = m["output"]; raw_prefix = os.path.join(out["results_vtk_dir"], out["raw_prefix"])
     scratch = os.path.dirname(m["state"])
     sim.initialize()
@@ -192,11 +204,17 @@ def run_case(m, G, device, log, make_sim=None):
             s = max(t + 1, avg_start); off = (s - avg_start) % avg_stride
             if off: s += avg_stride - off
             if s <= total: nxt = min(nxt, s)
+        if cols:
+            nxt = min(nxt, max(t + 1, probe_start))       # every step of the probe window is observed
         sim.run(nxt - t); t = nxt
         if unsteady > 0 and t % unsteady == 0:
             write_u(t); last_u = t
         if avg_window > 0 and t >= avg_start and (t - avg_start) % avg_stride == 0:
             sim.backend.stats_accumulate()
+        if cols and t >= probe_start:
+            probe_times.append(t)
+            if my_cells:
+                probe_vals.append(sim.backend.gather_u())
     secs = time.perf_counter() - t0
     log("| Solver          | %d steps in %.3f s = %.1f MLUPs" % (total, secs, Ncells * total / secs * 1e-6))
     if last_u != t:
@@ -225,6 +243,27 @@ def run_case(m, G, device, log, make_sim=None):
             for g, path in parts.values():
                 del g
                 os.remove(path)
+    if cols:
+        part = os.path.join(scratch, "probes_rank%d.npz" % G.rank)
+        np.savez(part, slots=np.array(my_slots, np.int64).reshape(-1, 2), vals=np.array(probe_vals, np.float32).reshape(len(probe_times), len(my_cells), 3) if my_cells else np.zeros((len(probe_times), 0, 3), np.float32))
+        G.barrier()
+        if G.rank == 0:
+            unit_m, unit_s = _f(m["unit_m_bits"]), _f(m["unit_s_bits"]); dt = float(pr["dt_si"])
+            series = [np.zeros((len(probe_times), len(c["z"]), 3), np.float32) for c in cols]
+            for r in range(G.world):
+                d = np.load(os.path.join(scratch, "probes_rank%d.npz" % r))
+                for k, (ci, li) in enumerate(d["slots"]):
+                    series[ci][:, li, :] = (d["vals"][:, k, :] * unit_m) / unit_s          # Units::si_u, FP32
+            fmt = lambda v: ("%.6f" % v).rstrip("0").rstrip(".") if "." in ("%.6f" % v) else ("%.6f" % v)
+            fix = lambda v: "0" if fmt(v) in ("", "-0") and v == 0 else fmt(v)
+            os.makedirs(pr["results_dir"], exist_ok=True)
+            for c, sr in zip(cols, series):
+                with open(os.path.join(pr["results_dir"], c["stem"] + ".csv"), "w") as f:
+                    f.write("height (m)" + "".join("," + fix(tt * dt) for tt in probe_times) + "\n")
+                    for li, hb in enumerate(c["height_bits"]):
+                        f.write(fix(float(_f(hb))) + "".join(",%s:%s:%s" % tuple(fix(float(x)) for x in sr[ti, li]) for ti in range(len(probe_times))) + "\n")
+            log("| Probe files     | %d CSV saved to RESULTS" % len(cols))
+        G.barrier()
     sim.backend.close()
     G.barrier()
 

@@ -32,7 +32,7 @@ def _files(proj):
     return {os.path.basename(p): p for p in glob.glob(os.path.join(proj, "RESULTS", "vtk", "*.vtk"))}
 
 
-@pytest.mark.parametrize("case,n_gpu", [("CaseA", (1, 1, 1)), ("CaseV", (1, 1, 1)), ("CaseA", (2, 1, 1)), ("CaseV", (1, 2, 2)), ("CaseN1", (1, 2, 1))])
+@pytest.mark.parametrize("case,n_gpu", [("CaseA", (1, 1, 1)), ("CaseV", (1, 1, 1)), ("CaseA", (2, 1, 1)), ("CaseV", (1, 2, 2)), ("CaseN1", (1, 2, 1)), ("CaseP", (2, 2, 1))])
 def test_run_deck_writes_the_drivers_files(luw, tmp_path, case, n_gpu):
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
     ref_proj, ref_deck = _case(tmp_path, case, (1, 1, 1), "_ref")
@@ -50,6 +50,10 @@ def test_run_deck_writes_the_drivers_files(luw, tmp_path, case, n_gpu):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     want, got = _files(ref_proj), _files(proj)
     assert sorted(want) == sorted(got) and len(want) >= 3
+    csv_w = sorted(glob.glob(os.path.join(ref_proj, "RESULTS", "*.csv"))); csv_g = sorted(glob.glob(os.path.join(proj, "RESULTS", "*.csv")))
+    assert [os.path.basename(q) for q in csv_w] == [os.path.basename(q) for q in csv_g] and (case != "CaseP" or len(csv_w) == 5)
+    for a, b in zip(csv_w, csv_g):                                  # probe CSVs: identical text
+        assert open(a).read() == open(b).read(), os.path.basename(a)
     for name in sorted(want):
         hw, fw = read_vtk(want[name]); hg, fg = read_vtk(got[name])
         assert hw == hg, name
