@@ -1,3 +1,5 @@
+"""Runs one golden case through the single-GPU C++ driver and through latticeurbanwind_amd.run_deck on n_gpu = Dx Dy Dz ranks
+(all on GPU 0, gloo + host staging) and lists which output arrays differ.  usage: compare_run_deck.py CaseX Dx Dy Dz"""
 import glob, os, re, shutil, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
