@@ -70,6 +70,7 @@ extern "C" {
 #define LUW_KERNEL_SCALAR_NT_ALL 5      /* scalar kernel with non-temporal accesses on all 19 planes (A/B; the product uses nt on the 14 aligned planes) */
 #define LUW_KERNEL_PAIR 7               /* FP16C only: 2 cells / lane, direct neighbour addressing, one dword per lane and plane */
 #define LUW_KERNEL_VEC1 6               /* 1 cell / lane with aligned accesses + wave64 lane shifts for the x+1 populations (A/B) */
+#define LUW_KERNEL_SCALAR_GENERAL 8     /* scalar kernel without the wave-uniform "no TYPE_E, no force in this wave" fast path (A/B) */
 #define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
 #define LUW_KERNEL_EXP_NOSHIFT 101      /* measurement only: scalar kernel with the x+1 neighbours replaced by x (no physics) */
 
@@ -151,6 +152,9 @@ int luw_finish(luw_solver* s);                                            /* LBM
  * fi[i*N + n] (FX/kernel.cpp:877-879), raw storage type (float or uint16_t FP16C codes). */
 int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_upload_fi(luw_solver* s, const void* host_src);
+
+/* switch the kernel variant of an existing solver (A/B on the same memory; values are identical for all product variants) */
+int luw_set_kernel(luw_solver* s, uint32_t kernel);
 
 /* LBM::voxelize_mesh_on_device(mesh, TYPE_S) for a static mesh (FX/lbm.cpp:1411-1645, kernel voxelize_mesh FX/kernel.cpp:2381-2471,
  * rays along z): p0/p1/p2 are the triangle corners (xyz triples, lattice index coordinates of the GLOBAL lattice, i.e. after the

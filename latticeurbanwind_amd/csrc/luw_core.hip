@@ -150,7 +150,7 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 	});
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
-		collide_cell(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
+		collide_cell<(MODE!=3)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
 			u[n] = uxn;
@@ -775,12 +775,13 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const uint32_t nx = (uint32_t)((int)b.x1-xa);
 	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : 0;
+	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
 	#define LUW_LAUNCH_S(PAR, MODE, NT) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
 	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
 	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
 	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
 	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
+	else if(mode==5) { if(odd) LUW_LAUNCH_S(1, 3, 2); else LUW_LAUNCH_S(0, 3, 2); }
 	else { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
 	#undef LUW_LAUNCH_S
 }
@@ -813,6 +814,57 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
 	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }
 	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+
+// Where the driver places the DDF array physically changes the step time of this 19-stream kernel by up to 10 % on MI355X:
+// allocations of the same size at the same virtual address come out in two classes (512^3 FP32: 3.40-3.50 ms vs 3.70-3.85 ms
+// per step, persistent for the life of the allocation; tools/placement_probe.py).  Nothing in the HIP API selects the class,
+// so large solvers allocate a few candidates, time the real kernel on each (zero DDFs = rest state, flags 0 = all fluid: a
+// valid, full-cost step) and keep the fastest.  LUW_TUNE_PLACEMENT=0 disables it; skipped when memory is short.
+static int tune_ddf_placement(luw_solver* s) {
+	const size_t bytes = 19ull*s->kp.Np*s->ddf_bytes;
+	const char* env = getenv("LUW_TUNE_PLACEMENT");
+	int candidates = env ? atoi(env) : 6;
+	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
+	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
+	hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+	auto step_ms = [&](float& ms) -> int { // two steps (both parities) after one untimed
+		s->initialized = true; s->t = 0ull;
+		if(int e = launch_stream_collide(s, whole, 0)) return e;
+		s->t = 1ull;
+		HIP_TRY(hipEventRecord(e0, s->stream));
+		if(int e = launch_stream_collide(s, whole, 0)) return e;
+		s->t = 2ull;
+		if(int e = launch_stream_collide(s, whole, 0)) return e;
+		HIP_TRY(hipEventRecord(e1, s->stream));
+		HIP_TRY(hipEventSynchronize(e1));
+		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+		s->initialized = false; s->t = 0ull;
+		return LUW_OK;
+	};
+	float best_ms = 0.0f;
+	if(int e = step_ms(best_ms)) return e;
+	void* best_raw = s->raw.front(); void* best_fi = s->d_fi; // fi is the first lead_alloc of luw_create
+	std::vector<void*> losers;
+	for(int k=1; k<candidates; k++) {
+		size_t free_b = 0u, total_b = 0u;
+		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+(8ull<<30)) break; // keep headroom for the rest of the run
+		void* fi = nullptr;
+		if(lead_alloc(s, &fi, 19ull*s->kp.Np, s->ddf_bytes)!=hipSuccess) { (void)hipGetLastError(); break; }
+		void* raw = s->raw.back(); s->raw.pop_back();
+		s->d_fi = fi;
+		float ms = 0.0f;
+		if(int e = step_ms(ms)) { (void)hipFree(raw); s->d_fi = best_fi; return e; }
+		if(getenv("LUW_TUNE_VERBOSE")) fprintf(stderr, "luw: placement candidate %d: %.3f ms per 2 steps (best so far %.3f)\n", k, ms, best_ms);
+		if(ms<best_ms) { losers.push_back(best_raw); best_ms = ms; best_raw = raw; best_fi = fi; }
+		else losers.push_back(raw);
+	}
+	for(void* r : losers) (void)hipFree(r); // released only now, so that no candidate reuses the pages of another
+	s->raw.front() = best_raw; s->d_fi = best_fi;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	HIP_TRY(hipMemsetAsync(best_raw, 0, bytes+64u*s->ddf_bytes, s->stream)); // the probe steps left zeros, but be explicit
+	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
 
@@ -852,7 +904,10 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
 	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
 	const uint32_t Px = (cfg->Nx+63u)&~63u; // rows are whole 256-byte blocks (see lead_alloc)
-	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz;
+	// plane stride: the lattice plus a skew of 33 line blocks (8448 B in FP32).  With a bare power-of-two stride the 19 planes of
+	// a cell sit at the same offset of 19 equally aligned regions; the skew measured 2-4 % faster on every lattice shape tried
+	// (512^3 3.50 -> 3.40 ms, 768x768x256 3.87 -> 3.70 ms, 1024x1024x256 6.80 -> 6.69 ms; odd small multiples behave alike).
+	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz+64ull*33ull;
 	if(Np>(1ull<<30)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^30 (padded) cells per domain are not supported (32-bit byte offsets)");
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
@@ -929,6 +984,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 		if(hipMalloc((void**)&s->d_sigma, sg.size()*4u)!=hipSuccess||hipMemcpy(s->d_sigma, sg.data(), sg.size()*4u, hipMemcpyHostToDevice)!=hipSuccess) return oom("sigma");
 		k.sigma = s->d_sigma;
 	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if(int e = tune_ddf_placement(s)) { luw_destroy(s); return e; } // last: the probe steps run the complete kernel (nudging / sponge tables included)
 	*out = s;
 	return LUW_OK;
 }
@@ -1261,6 +1318,11 @@ int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t
 	const Box b = { x0, x1, y0, y1, z0, z1 };
 	s->fields_current = write_fields!=0; // callers cover the lattice with boxes of one step using the same flag
 	return launch_stream_collide(s, b, write_fields);
+}
+int luw_set_kernel(luw_solver* s, uint32_t kernel) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_set_kernel: null solver");
+	s->kernel = kernel;
+	return LUW_OK;
 }
 int luw_increment_time_step(luw_solver* s, uint64_t steps) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_increment_time_step: null solver");

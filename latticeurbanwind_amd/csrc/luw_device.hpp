@@ -220,7 +220,7 @@ __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t 
 // in: streamed-in DDFs f[19], flags byte.  out: post-collision DDFs in f[19]; rho/u (after the half-force
 // shift and the +-c clamp) in rhon,uxn,uyn,uzn.  Returns false when the cell must not touch memory at all
 // (solid / gas, FX/kernel.cpp:1490).
-__device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
 		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	if(is_E) {
@@ -233,11 +233,43 @@ __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n,
 	}
 	float fxn, fyn, fzn;
 	assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
-	float Fin[19];
 	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
 	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
 	// (fma(w, feq, +-0) == w*feq) as long as rho != 0.
 	const bool forced = fxn!=0.0f||fyn!=0.0f||fzn!=0.0f;
+	// Smagorinsky-Lilly relaxation rate, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped
+	auto relaxation_rate = [&](const float* feq) -> float {
+		if(!p.subgrid) return p.w;
+		const float tau0 = 1.0f/p.w;
+		float n_[19];
+		#pragma unroll
+		for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
+		float Hxx = 0.0f, Hyy = 0.0f, Hzz = 0.0f, Hxy = 0.0f, Hxz = 0.0f, Hyz = 0.0f;
+		Hxx += n_[ 1]; Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
+		Hyy += n_[ 3]; Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
+		Hzz += n_[ 5]; Hzz += n_[ 6]; Hzz += n_[ 9]; Hzz += n_[10]; Hzz += n_[11]; Hzz += n_[12]; Hzz += n_[15]; Hzz += n_[16]; Hzz += n_[17]; Hzz += n_[18];
+		Hxy += n_[ 7]; Hxy += n_[ 8]; Hxy += -n_[13]; Hxy += -n_[14];
+		Hxz += n_[ 9]; Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
+		Hyz += n_[11]; Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
+		const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
+		return 2.0f/(tau0+sqrtf(sq(tau0)+0.76421222f*sqrtf(Q)/rhon));
+	};
+	float feq[19];
+	// Wave-uniform fast path: when no lane of the wave is a TYPE_E cell or feels a force (interior waves of an urban case),
+	// the equilibrium override and the Guo terms drop out for the whole wave -- one scalar branch instead of 19 selects, 19
+	// products with zero and the zero-filled Fin registers per lane.  Same values (+-0 aside) as the general path below.
+	if(FAST&&__ballot(is_E||forced)==0ull) {
+		uxn = clampf(uxn, -DEF_C, DEF_C);
+		uyn = clampf(uyn, -DEF_C, DEF_C);
+		uzn = clampf(uzn, -DEF_C, DEF_C);
+		calculate_f_eq(rhon, uxn, uyn, uzn, feq);
+		const float w = relaxation_rate(feq);
+		const float omw = 1.0f-w;
+		#pragma unroll
+		for(int i=0; i<19; i++) f[i] = fmaf(omw, f[i], w*feq[i]);
+		return;
+	}
+	float Fin[19];
 	if(forced) {
 		const float rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
@@ -251,24 +283,8 @@ __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n,
 		#pragma unroll
 		for(int i=0; i<19; i++) Fin[i] = 0.0f;
 	}
-	float feq[19];
 	calculate_f_eq(rhon, uxn, uyn, uzn, feq);
-	float w = p.w;
-	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped
-		const float tau0 = 1.0f/w;
-		float n_[19];
-		#pragma unroll
-		for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
-		float Hxx = 0.0f, Hyy = 0.0f, Hzz = 0.0f, Hxy = 0.0f, Hxz = 0.0f, Hyz = 0.0f;
-		Hxx += n_[ 1]; Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
-		Hyy += n_[ 3]; Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
-		Hzz += n_[ 5]; Hzz += n_[ 6]; Hzz += n_[ 9]; Hzz += n_[10]; Hzz += n_[11]; Hzz += n_[12]; Hzz += n_[15]; Hzz += n_[16]; Hzz += n_[17]; Hzz += n_[18];
-		Hxy += n_[ 7]; Hxy += n_[ 8]; Hxy += -n_[13]; Hxy += -n_[14];
-		Hxz += n_[ 9]; Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
-		Hyz += n_[11]; Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
-		const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
-		w = 2.0f/(tau0+sqrtf(sq(tau0)+0.76421222f*sqrtf(Q)/rhon));
-	}
+	const float w = relaxation_rate(feq);
 	const float c_tau = fmaf(w, -0.5f, 1.0f);
 	const float omw = 1.0f-w;
 	#pragma unroll
