@@ -130,6 +130,9 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
+	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
+	// measured 3.5 % slower, 3.50 vs 3.39 ms at 512^3 -- no population is shared between workgroups, so there is nothing
+	// for an XCD's L2 to reuse, and eight distant fronts cost DRAM page locality)
 	const int xi = xa+(int)(blockIdx.x*blockDim.x+threadIdx.x);
 	if(xi<(int)b.x0||xi>=(int)b.x1) return;
 	const uint32_t x = (uint32_t)xi, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
