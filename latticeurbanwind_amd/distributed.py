@@ -24,7 +24,7 @@ def choose_decomposition(world, split_x=False):
     shells are whole rows and the halo traffic hides behind the interior: 8 GPUs cover the 2048x1024x512 tile of
     BASELINE configs[3] as n_gpu=[1,2,4] (local 2048x512x128).  split_x=True reproduces the deck's literal
     n_gpu=[4,2,1] (local 512^3); with x split the step runs the whole box first and exchanges afterwards (measured on
-    MI355X, one rank with loopback halos: 3.76 ms sequential vs 4.20 ms with an x shell, vs 3.60 ms undivided).
+    MI355X, one rank with loopback halos: 3.77 ms sequential vs 4.19 ms with an x shell, vs 3.38 ms undivided).
     Returns (D, global_lattice)."""
     if split_x:
         table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1), 16: (4, 4, 1)}
