@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LUW_ABI_VERSION 1
+#define LUW_ABI_VERSION 2
 
 /* error codes */
 #define LUW_OK 0
@@ -44,10 +44,13 @@ extern "C" {
 #define LUW_FIELD_FLAGS 2
 #define LUW_FIELD_F 3
 #define LUW_FIELD_FI 4           /* device only: DDFs, 19 planes */
+#define LUW_FIELD_T 5            /* temperature (LUW_OPT_TEMPERATURE), lbm.T of the reference */
+#define LUW_FIELD_GI 6           /* device only: thermal DDFs, 7 planes */
 #define LUW_MASK_RHO (1u<<LUW_FIELD_RHO)
 #define LUW_MASK_U (1u<<LUW_FIELD_U)
 #define LUW_MASK_FLAGS (1u<<LUW_FIELD_FLAGS)
 #define LUW_MASK_F (1u<<LUW_FIELD_F)
+#define LUW_MASK_T (1u<<LUW_FIELD_T)
 
 /* DDF storage formats: compile-time `#define FP16C` in the reference (FX/defines.hpp:13-14), a run-time
  * choice here */
@@ -59,6 +62,7 @@ extern "C" {
 #define LUW_OPT_UPDATE_FIELDS_EVERY_STEP 0x2u /* write rho,u in every step exactly like UPDATE_FIELDS (FX/kernel.cpp:1709-1716);
                                            without it rho,u are written by the last step of each luw_run() call and on
                                            luw_download(), which yields identical values whenever they are observed */
+#define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha; single domain */
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
 
 /* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
@@ -93,6 +97,7 @@ typedef struct luw_config {
 	int32_t top_sponge_active;       /* top_sponge_active (sponge_ref_mode 0 only) */
 	uint32_t sponge_n_cells;         /* sponge_n_cells */
 	float sponge_inv_tau_lbmu;       /* sponge_inv_tau_lbmu */
+	float alpha;                     /* thermal diffusivity in lattice units (LUW_OPT_TEMPERATURE), LBM(..., alpha, beta) FX/lbm.hpp:444 */
 	int32_t device;                  /* HIP device ordinal */
 	uint32_t kernel;                 /* LUW_KERNEL_* */
 } luw_config;
@@ -155,6 +160,7 @@ int luw_finish(luw_solver* s);                                            /* LBM
 /* debugging / test access to the DDFs: copies the 19 planes to / from host memory in the reference's layout
  * fi[i*N + n] (FX/kernel.cpp:877-879), raw storage type (float or uint16_t FP16C codes). */
 int luw_download_fi(luw_solver* s, void* host_dst);
+int luw_download_gi(luw_solver* s, void* host_dst);   /* thermal DDFs as stored, gi[i*N+n], i = 0..6 (tests) */
 int luw_upload_fi(luw_solver* s, const void* host_src);
 
 /* switch the kernel variant of an existing solver (A/B on the same memory; values are identical for all product variants) */

@@ -15,10 +15,10 @@ if os.environ.get("LUW_CORE_LIB"):      # A/B builds of the same source (tools/)
 _LIB = None
 
 LUW_OK = 0
-FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F, FIELD_FI = 0, 1, 2, 3, 4
-MASK_RHO, MASK_U, MASK_FLAGS, MASK_F = 1, 2, 4, 8
+FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F, FIELD_FI, FIELD_T, FIELD_GI = 0, 1, 2, 3, 4, 5, 6
+MASK_RHO, MASK_U, MASK_FLAGS, MASK_F, MASK_T = 1, 2, 4, 8, 32
 DDF_FP32, DDF_FP16C = 0, 1
-OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID = 1, 2, 4
+OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID, OPT_TEMPERATURE = 1, 2, 4, 8
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERNEL_SCALAR_NT_ALL, KERNEL_VEC1, KERNEL_PAIR = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_SCALAR_GENERAL = 8
 KERNEL_EXP_COPY, KERNEL_EXP_NOSHIFT = 100, 101   # measurement-only variants, never used by the product path
@@ -29,7 +29,7 @@ SYMBOLS = [
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
     "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
-    "luw_enqueue_insert_fi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_stats_download", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
+    "luw_enqueue_insert_fi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_stats_download", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
 
@@ -50,7 +50,7 @@ class Config(C.Structure):
         ("buffer_nudging_active", C.c_int32), ("buffer_n_cells", C.c_uint32), ("buffer_inv_tau_lbmu", C.c_float),
         ("buffer_nudge_vertical", C.c_int32), ("buffer_downstream_face_id", C.c_int32),
         ("top_sponge_active", C.c_int32), ("sponge_n_cells", C.c_uint32), ("sponge_inv_tau_lbmu", C.c_float),
-        ("device", C.c_int32), ("kernel", C.c_uint32),
+        ("alpha", C.c_float), ("device", C.c_int32), ("kernel", C.c_uint32),
     ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.luw_upload_fi.argtypes = [vp, vp]
     L.luw_selfcheck_fp16c_codec.argtypes = [i32, C.POINTER(u64)]
     L.luw_voxelize_mesh.argtypes = [vp, u32, vp, vp, vp, vp, C.c_uint8]
+    L.luw_download_gi.argtypes = [vp, vp]
     L.luw_set_kernel.argtypes = [vp, u32]
     L.luw_gather_attach.argtypes = [vp, u32, vp]; L.luw_gather_u.argtypes = [vp, vp]
     L.luw_voxelize_lattice.argtypes = [i32, u32, u32, u32, u32, vp, vp, vp, vp, C.c_uint8, vp]
@@ -119,7 +120,7 @@ def load():
     L.luw_stats_reset.argtypes = [vp]
     L.luw_stats_accumulate.argtypes = [vp]
     L.luw_stats_download.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
-    if L.luw_abi_version() != 1:
+    if L.luw_abi_version() != 2:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
     return L

@@ -60,7 +60,7 @@ __device__ __forceinline__ void neighbors(const KParams& p, const uint32_t x, co
 	j[17] = x +yp+zm; j[18] = x +ym+zp;
 }
 
-template<typename T> __global__ __launch_bounds__(256) void k_initialize(const KParams p, T* __restrict__ fi, const float* __restrict__ rho, float* __restrict__ u, const uint8_t* __restrict__ flags) {
+template<typename T> __global__ __launch_bounds__(256) void k_initialize(const KParams p, T* __restrict__ fi, const float* __restrict__ rho, float* __restrict__ u, const uint8_t* __restrict__ flags, T* __restrict__ gi, const float* __restrict__ Tf) {
 	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
 	if(x>=p.Nx) return;
 	if(cell_is_halo(p, x, y, z)) return;
@@ -78,6 +78,16 @@ template<typename T> __global__ __launch_bounds__(256) void k_initialize(const K
 	for(int i=1; i<19; i+=2) {
 		fi[(size_t)slotB<1>(i)*p.Np+j[i]] = ddf_encode<T>(feq[i]);
 		fi[(size_t)slotA<1>(i)*p.Np+n] = ddf_encode<T>(feq[i+1]);
+	}
+	if(gi) { // TEMPERATURE: store_g(geq(T, u), t = 1), FX/kernel.cpp:1442-1449
+		float geq[7];
+		calculate_g_eq(Tf[n], u[n], u[(size_t)p.Np+n], u[2ull*p.Np+n], geq);
+		gi[n] = ddf_encode<T>(geq[0]);
+		#pragma unroll
+		for(int i=1; i<7; i+=2) {
+			gi[(size_t)(i+1)*p.Np+j[i]] = ddf_encode<T>(geq[i]);
+			gi[(size_t)i*p.Np+n] = ddf_encode<T>(geq[i+1]);
+		}
 	}
 }
 
@@ -127,7 +137,7 @@ template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
 // NT: 0 default cache policy, 1 non-temporal everywhere, 2 non-temporal on the 14 aligned planes and default policy on
 // the five x+1 planes, whose wave-edge lines are shared between neighbouring waves (product setting, measured best).
 template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
-		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
 	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
@@ -153,6 +163,12 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 	});
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
+		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
+			float u0[3];
+			collide_cell<true>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
+			constexpr uint32_t es = (uint32_t)sizeof(T);
+			thermal_cell<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf);
+		} else
 		collide_cell<(MODE!=3)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
@@ -726,6 +742,7 @@ struct luw_solver {
 	uint32_t vk_P = 0u, vk_M = 0u; int vk_stride = 1; bool vk_interp = false, vk_active = false; uint64_t vk_last_t = ~0ull;
 	uint32_t* d_vk_cell = nullptr; uint8_t* d_vk_face = nullptr; float* d_vk_point = nullptr; float* d_vk_mode = nullptr;
 	float* h_rho = nullptr; float* h_u = nullptr; uint8_t* h_flags = nullptr; float* h_F = nullptr;
+	void* d_gi = nullptr; float* d_T = nullptr; float* h_T = nullptr; float* d_avg_T = nullptr; // TEMPERATURE
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
 	uint32_t kernel = LUW_KERNEL_AUTO;
@@ -780,7 +797,11 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
 	#define LUW_LAUNCH_S(PAR, MODE, NT) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
-	if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
+	if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
+		if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1, 4, 2>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T);
+		else hipLaunchKernelGGL((k_stream_collide_s<T, 0, 4, 2>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T);
+	}
+	else if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
 	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
 	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
 	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
@@ -809,6 +830,7 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	const bool fp16 = s->ddf_bytes==2u;
 	uint32_t k = s->kernel;
 	if(k==LUW_KERNEL_AUTO) k = LUW_KERNEL_SCALAR;
+	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
 	if(s->kp.halo_x&&(k==LUW_KERNEL_PAIR||k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the A/B kernels assume rows that start on a 16-byte boundary at x = 0
 	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || (b.x1&1u))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, even x range
 	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields);
@@ -889,7 +911,7 @@ void luw_destroy(luw_solver* s) {
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
 	(void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out);
 	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
-	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F);
+	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F); (void)hipHostFree(s->h_T);
 	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
 	delete s;
 }
@@ -904,6 +926,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->nu<0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be negative."); // FX/lbm.cpp:1142
 	if(cfg->ddf_format!=LUW_DDF_FP32&&cfg->ddf_format!=LUW_DDF_FP16C) return fail(LUW_ERR_INVALID, "luw_create: unknown ddf_format");
 	if((cfg->Dx>1u&&cfg->Nx<3u)||(cfg->Dy>1u&&cfg->Ny<3u)||(cfg->Dz>1u&&cfg->Nz<3u)) return fail(LUW_ERR_INVALID, "luw_create: split axes need at least one interior cell between the halo layers");
+	if((cfg->options&LUW_OPT_TEMPERATURE)&&cfg->Dx*cfg->Dy*cfg->Dz>1u) return fail(LUW_ERR_INVALID, "luw_create: the thermal lattice is single-domain in this build (no gi / T halo exchange)");
+	if((cfg->options&LUW_OPT_TEMPERATURE)&&!(cfg->alpha>=0.0f)) return fail(LUW_ERR_INVALID, "luw_create: thermal diffusivity must not be negative");
 	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
 	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
 	const uint32_t Px = (cfg->Nx+63u)&~63u; // rows are whole 256-byte blocks (see lead_alloc)
@@ -943,6 +967,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	k.has_s = k.south_y>=0&&k.south_y<(int)cfg->Ny; k.has_n = k.north_y>=0&&k.north_y<(int)cfg->Ny;
 	k.has_t = k.top_z>=0&&k.top_z<(int)cfg->Nz;
 	k.has_F = (cfg->options&LUW_OPT_FORCE_FIELD) ? 1u : 0u;
+	k.w_T = (cfg->options&LUW_OPT_TEMPERATURE) ? literal_roundtrip(1.0f/(2.0f*cfg->alpha+0.5f)) : 0.0f; // FX/lbm.cpp:750
 
 	auto oom = [&](const char* what) { luw_destroy(s); return fail(LUW_ERR_NOMEM, std::string("luw_create: allocation failed: ")+what); };
 	if(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking)!=hipSuccess) return oom("stream");
@@ -953,6 +978,12 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(lead_alloc(s, (void**)&s->d_u, 3ull*Np, 4u)!=hipSuccess) return oom("u");
 	if(lead_alloc(s, (void**)&s->d_flags, Np, 1u)!=hipSuccess) return oom("flags");
 	if(k.has_F&&lead_alloc(s, (void**)&s->d_F, 3ull*Np, 4u)!=hipSuccess) return oom("F");
+	if(cfg->options&LUW_OPT_TEMPERATURE) {
+		if(lead_alloc(s, &s->d_gi, 7ull*Np, s->ddf_bytes)!=hipSuccess) return oom("gi");
+		if(lead_alloc(s, (void**)&s->d_T, Np, 4u)!=hipSuccess) return oom("T");
+		if(hipHostMalloc((void**)&s->h_T, s->N*4ull)!=hipSuccess) return oom("host T");
+		for(uint64_t n=0ull; n<s->N; n++) s->h_T[n] = 1.0f; // T = Memory<float>(device, N, 1u, true, true, 1.0f), FX/lbm.cpp:304
+	}
 	if(hipHostMalloc((void**)&s->h_rho, s->N*4ull)!=hipSuccess) return oom("host rho");
 	if(hipHostMalloc((void**)&s->h_u, 3ull*s->N*4ull)!=hipSuccess) return oom("host u");
 	if(hipHostMalloc((void**)&s->h_flags, s->N)!=hipSuccess) return oom("host flags");
@@ -1000,6 +1031,7 @@ void* luw_host_ptr(luw_solver* s, int field) {
 		case LUW_FIELD_U: return s->h_u;
 		case LUW_FIELD_FLAGS: return s->h_flags;
 		case LUW_FIELD_F: return s->h_F;
+		case LUW_FIELD_T: return s->h_T;
 		default: return nullptr;
 	}
 }
@@ -1011,6 +1043,8 @@ void* luw_device_ptr(luw_solver* s, int field) {
 		case LUW_FIELD_FLAGS: return s->d_flags;
 		case LUW_FIELD_F: return s->d_F;
 		case LUW_FIELD_FI: return s->d_fi;
+		case LUW_FIELD_T: return s->d_T;
+		case LUW_FIELD_GI: return s->d_gi;
 		default: return nullptr;
 	}
 }
@@ -1044,6 +1078,7 @@ int luw_upload(luw_solver* s, uint32_t mask) {
 	if(mask&LUW_MASK_U) if((e = copy_pitched(s->d_u, s->h_u, 4u, s, 3u, true, s->stream))) return e;
 	if(mask&LUW_MASK_FLAGS) if((e = copy_pitched(s->d_flags, s->h_flags, 1u, s, 1u, true, s->stream))) return e;
 	if((mask&LUW_MASK_F)&&s->d_F) if((e = copy_pitched(s->d_F, s->h_F, 4u, s, 3u, true, s->stream))) return e;
+	if((mask&LUW_MASK_T)&&s->d_T) if((e = copy_pitched(s->d_T, s->h_T, 4u, s, 1u, true, s->stream))) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
@@ -1056,6 +1091,7 @@ int luw_download(luw_solver* s, uint32_t mask) {
 	if(mask&LUW_MASK_U) if((e = copy_pitched(s->h_u, s->d_u, 4u, s, 3u, false, s->stream))) return e;
 	if(mask&LUW_MASK_FLAGS) if((e = copy_pitched(s->h_flags, s->d_flags, 1u, s, 1u, false, s->stream))) return e;
 	if((mask&LUW_MASK_F)&&s->d_F) if((e = copy_pitched(s->h_F, s->d_F, 4u, s, 3u, false, s->stream))) return e;
+	if((mask&LUW_MASK_T)&&s->d_T) if((e = copy_pitched(s->h_T, s->d_T, 4u, s, 1u, false, s->stream))) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
@@ -1064,6 +1100,14 @@ int luw_download_fi(luw_solver* s, void* host_dst) {
 	if(!s||!host_dst) return fail(LUW_ERR_INVALID, "luw_download_fi: bad argument");
 	if(int e = set_device(s)) return e;
 	if(int e = copy_pitched(host_dst, s->d_fi, s->ddf_bytes, s, 19u, false, s->stream)) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}
+int luw_download_gi(luw_solver* s, void* host_dst) {
+	if(!s||!host_dst) return fail(LUW_ERR_INVALID, "luw_download_gi: bad argument");
+	if(!s->d_gi) return fail(LUW_ERR_STATE, "luw_download_gi: the solver was created without LUW_OPT_TEMPERATURE");
+	if(int e = set_device(s)) return e;
+	if(int e = copy_pitched(host_dst, s->d_gi, s->ddf_bytes, s, 7u, false, s->stream)) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
@@ -1301,11 +1345,11 @@ int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz) {
 
 int luw_initialize(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_initialize: null solver");
-	if(int e = luw_upload(s, LUW_MASK_RHO|LUW_MASK_U|LUW_MASK_FLAGS|LUW_MASK_F)) return e;
+	if(int e = luw_upload(s, LUW_MASK_RHO|LUW_MASK_U|LUW_MASK_FLAGS|LUW_MASK_F|LUW_MASK_T)) return e;
 	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
 	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
-	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_initialize<uint16_t>), grid, block, 0, s->stream, s->kp, (uint16_t*)s->d_fi, s->d_rho, s->d_u, s->d_flags);
-	else hipLaunchKernelGGL((k_initialize<float>), grid, block, 0, s->stream, s->kp, (float*)s->d_fi, s->d_rho, s->d_u, s->d_flags);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_initialize<uint16_t>), grid, block, 0, s->stream, s->kp, (uint16_t*)s->d_fi, s->d_rho, s->d_u, s->d_flags, (uint16_t*)s->d_gi, s->d_T);
+	else hipLaunchKernelGGL((k_initialize<float>), grid, block, 0, s->stream, s->kp, (float*)s->d_fi, s->d_rho, s->d_u, s->d_flags, (float*)s->d_gi, s->d_T);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->t = 0ull;

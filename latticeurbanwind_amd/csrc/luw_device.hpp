@@ -21,7 +21,7 @@ constexpr float DEF_WS = 1.0f/18.0f;
 constexpr float DEF_WE = 1.0f/36.0f;
 constexpr float DEF_C = 0.57735027f;  // FX/lbm.cpp:663
 
-constexpr uint8_t TYPE_S = 0x01, TYPE_E = 0x02, TYPE_BO = 0x03, TYPE_SU = 0x38, TYPE_G = 0x20;
+constexpr uint8_t TYPE_S = 0x01, TYPE_E = 0x02, TYPE_BO = 0x03, TYPE_T = 0x04, TYPE_SU = 0x38, TYPE_G = 0x20;
 
 // Everything the kernels need besides the big arrays; passed by value (lands in SGPRs).
 struct KParams {
@@ -44,6 +44,7 @@ struct KParams {
 	const float* wbuf;        // wbuf[d] = sin^2(pi/2 (1 - d/Nbuf)),           d = 0..Nbuf   (FX/kernel.cpp:1581-1583)
 	const float* sigma;       // sigma[d] = inv_tau sin^2(pi/2 (1 - d/(Ns-1))), d = 0..Ns-1  (FX/kernel.cpp:1604-1606)
 	uint32_t has_F;
+	float w_T;                // TEMPERATURE: def_w_T = 1/(2 alpha + 1/2), FX/lbm.cpp:750 (0 when the thermal lattice is off)
 };
 
 // ---------------------------------------------------------------- FP16C codec, FX/kernel.cpp:864-875
@@ -221,7 +222,7 @@ __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t 
 // shift and the +-c clamp) in rhon,uxn,uyn,uzn.  Returns false when the cell must not touch memory at all
 // (solid / gas, FX/kernel.cpp:1490).
 template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
-		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
+		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	if(is_E) {
 		rhon = rho[n];
@@ -233,6 +234,7 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 	}
 	float fxn, fyn, fzn;
 	assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
+	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
 	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
 	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
 	// (fma(w, feq, +-0) == w*feq) as long as rho != 0.
@@ -291,6 +293,55 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 	for(int i=0; i<19; i++) {
 		const float Fi = Fin[i]*c_tau;
 		f[i] = is_E ? feq[i] : fmaf(omw, f[i], fmaf(w, feq[i], Fi));
+	}
+}
+
+// ---------------------------------------------------------------- thermal D3Q7 lattice (TEMPERATURE), FX/kernel.cpp:1306-1335,1639-1684
+__device__ __forceinline__ void calculate_g_eq(const float T, const float ux, const float uy, const float uz, float* geq) {
+	const float wsT4 = 0.5f*T, wsTm1 = 0.125f*(T-1.0f);
+	geq[0] = fmaf(0.25f, T, -0.25f);
+	geq[1] = fmaf(wsT4, ux, wsTm1); geq[2] = fmaf(wsT4, -ux, wsTm1);
+	geq[3] = fmaf(wsT4, uy, wsTm1); geq[4] = fmaf(wsT4, -uy, wsTm1);
+	geq[5] = fmaf(wsT4, uz, wsTm1); geq[6] = fmaf(wsT4, -uz, wsTm1);
+}
+// One cell of the temperature lattice: Esoteric-Pull stream-in, T = sum g + 1 (or the preset on TYPE_T cells), top sponge
+// on T, BGK with w_T (TYPE_T: g = g_eq), stream-out.  n, jx, jy, jz are ELEMENT indices of the cell and its +x, +y, +z
+// neighbours; (ux,uy,uz) is the velocity before the force shift.  The buoyancy term it would add to the force carries the
+// factor (fx,fy,fz), which LUW sets to zero (FX/setup.cpp:4935): T is a passive scalar here.
+template<typename T, int PARITY> __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
+		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, T* __restrict__ gi, float* __restrict__ Tf) {
+	const size_t Np = p.Np;
+	const uint32_t jn[3] = { jx, jy, jz };
+	float g[7];
+	g[0] = ddf_decode<T>(gi[n]);
+	#pragma unroll
+	for(int k=0; k<3; k++) {
+		const int i = 2*k+1;
+		g[i  ] = ddf_decode<T>(gi[(size_t)(PARITY ? i : i+1)*Np+n]);
+		g[i+1] = ddf_decode<T>(gi[(size_t)(PARITY ? i+1 : i)*Np+jn[k]]);
+	}
+	const bool preset = (flagsn&TYPE_T)!=0u;
+	float Tn;
+	if(preset) Tn = Tf[n];
+	else { Tn = 0.0f; for(int i=0; i<7; i++) Tn += g[i]; Tn += 1.0f; }
+	if(p.sponge_active && !preset && (flagsn&TYPE_BO)!=TYPE_E && p.has_t) {
+		const int d_t_i = (int)(p.Nzg-2u)-((int)z+p.Oz);
+		if(d_t_i>=0&&d_t_i<(int)p.sponge_N) Tn = fmaf(p.sigma[d_t_i], Tf[x+(y+(uint32_t)p.top_z*p.Ny)*p.Px]-Tn, Tn);
+	}
+	float geq[7];
+	calculate_g_eq(Tn, ux, uy, uz, geq);
+	if(preset) { for(int i=0; i<7; i++) g[i] = geq[i]; }
+	else {
+		Tf[n] = Tn;
+		const float omw = 1.0f-p.w_T;
+		for(int i=0; i<7; i++) g[i] = fmaf(omw, g[i], p.w_T*geq[i]);
+	}
+	gi[n] = ddf_encode<T>(g[0]);
+	#pragma unroll
+	for(int k=0; k<3; k++) {
+		const int i = 2*k+1;
+		gi[(size_t)(PARITY ? i+1 : i)*Np+jn[k]] = ddf_encode<T>(g[i]);
+		gi[(size_t)(PARITY ? i : i+1)*Np+n] = ddf_encode<T>(g[i+1]);
 	}
 }
 

@@ -44,7 +44,7 @@ class LBM:
 
     def __init__(self, Nx, Ny, Nz, nu, fx=0.0, fy=0.0, fz=0.0, *, fp16c=False, D=(1, 1, 1), O=(0, 0, 0),
                  force_field=False, update_fields_every_step=False, subgrid=True, device=0, kernel=capi.KERNEL_AUTO,
-                 buffer_nudging=None, top_sponge=None):
+                 buffer_nudging=None, top_sponge=None, alpha=None):
         self._L = capi.load()
         cfg = capi.Config()
         cfg.struct_size = C.sizeof(capi.Config)
@@ -54,7 +54,8 @@ class LBM:
         cfg.nu = float(nu)
         cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
         cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
-        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid else capi.OPT_NO_SUBGRID)
+        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
+        cfg.alpha = float(alpha) if alpha is not None else 0.0      # thermal D3Q7 lattice: LBM(..., alpha, beta), FX/lbm.hpp:444
         if buffer_nudging is not None:  # dict(n_cells, inv_tau, downstream_face, nudge_vertical): FX/setup.cpp:3844-3866
             cfg.buffer_nudging_active = 1
             cfg.buffer_n_cells = int(buffer_nudging["n_cells"])
@@ -82,6 +83,8 @@ class LBM:
         self.flags = _Field(self, capi.FIELD_FLAGS, capi.MASK_FLAGS, view(capi.FIELD_FLAGS, C.c_uint8, N), 1)
         Fv = view(capi.FIELD_F, C.c_float, 3 * N)
         self.F = _Field(self, capi.FIELD_F, capi.MASK_F, Fv, 3) if Fv is not None else None
+        Tv = view(capi.FIELD_T, C.c_float, N)
+        self.T = _Field(self, capi.FIELD_T, capi.MASK_T, Tv, 1) if Tv is not None else None
         self._initialized = False
 
     # ---- life cycle
@@ -184,6 +187,12 @@ class LBM:
     def device_ptr(self, field): return self._L.luw_device_ptr(self._h, field)
     def pitch(self): return int(self._L.luw_get_pitch(self._h))
     def plane_stride(self): return int(self._L.luw_get_plane_stride(self._h))
+    def download_gi(self):
+        """thermal DDFs as stored, reference layout gi[i*N+n], i = 0..6"""
+        out = np.zeros(7 * self.get_N(), np.uint16 if self.cfg.ddf_format == capi.DDF_FP16C else np.float32)
+        capi.check(self._L.luw_download_gi(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def download_fi(self):
         """DDFs as stored (float32 values or uint16 FP16C codes), reference layout fi[i*N+n]"""
         out = np.zeros(19 * self.get_N(), np.uint16 if self.cfg.ddf_format == capi.DDF_FP16C else np.float32)

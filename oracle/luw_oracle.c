@@ -60,7 +60,11 @@ typedef struct LuwOracleCfg {
 	int32_t sponge_active;        /* TOP_SPONGE with def_sponge_ref_mode==0, FX/lbm.cpp:777-782 */
 	uint32_t sponge_N;
 	float sponge_inv_tau;
+	float w_T;                    /* TEMPERATURE: def_w_T = 1/(2 alpha + 1/2) after the decimal-text round trip, FX/lbm.cpp:750 */
 } LuwOracleCfg;
+
+/* optional thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1442-1449,1639-1684): gi 7 planes like fi, T[N]; NULL = off */
+typedef struct { void* gi; float* T; } LuwOracleThermal;
 
 /* ------------------------------------------------------------------ helpers */
 static inline float sq(const float x) { return x*x; }
@@ -230,6 +234,44 @@ static void calculate_forcing_terms(const float ux, const float uy, const float 
 }
 
 /* FX/kernel.cpp:1370-1452 (no SURFACE / MOVING_BOUNDARIES / TEMPERATURE part) */
+/* FX/kernel.cpp:1307-1314: +x, -x, +y, -y, +z, -z neighbours (j7[1], j7[3], j7[5] are j[1], j[3], j[5] of the D3Q19 list) */
+static void calculate_g_eq(const float T, const float ux, const float uy, const float uz, float* geq) { /* FX/kernel.cpp:1315-1321 */
+	const float wsT4 = 0.5f*T, wsTm1 = 0.125f*(T-1.0f);
+	geq[0] = fmaf(0.25f, T, -0.25f);
+	geq[1] = fmaf(wsT4, ux, wsTm1); geq[2] = fmaf(wsT4, -ux, wsTm1);
+	geq[3] = fmaf(wsT4, uy, wsTm1); geq[4] = fmaf(wsT4, -uy, wsTm1);
+	geq[5] = fmaf(wsT4, uz, wsTm1); geq[6] = fmaf(wsT4, -uz, wsTm1);
+}
+static void load_g(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, float* ghn, const void* gi, const uint64_t* j, const uint64_t t) { /* FX/kernel.cpp:1322-1328 */
+	ghn[0] = load_fi(c, gi, n);
+	for(uint32_t i=1u; i<7u; i+=2u) {
+		ghn[i   ] = load_fi(c, gi, (uint64_t)(t%2ull ? i    : i+1u)*N+n);
+		ghn[i+1u] = load_fi(c, gi, (uint64_t)(t%2ull ? i+1u : i   )*N+j[i]);
+	}
+}
+static void store_g(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, const float* ghn, void* gi, const uint64_t* j, const uint64_t t) { /* FX/kernel.cpp:1329-1335 */
+	store_fi(c, gi, n, ghn[0]);
+	for(uint32_t i=1u; i<7u; i+=2u) {
+		store_fi(c, gi, (uint64_t)(t%2ull ? i+1u : i   )*N+j[i], ghn[i   ]);
+		store_fi(c, gi, (uint64_t)(t%2ull ? i    : i+1u)*N+n,    ghn[i+1u]);
+	}
+}
+
+void luwo_initialize_thermal(const LuwOracleCfg* c, void* gi, const float* T, const float* u, const uint8_t* flags) { /* FX/kernel.cpp:1442-1449; solids' u is 0 by then */
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	#pragma omp parallel for schedule(static)
+	for(int64_t nn=0; nn<(int64_t)N; nn++) {
+		const uint64_t n = (uint64_t)nn;
+		if(is_halo(c, n)) continue;
+		uint64_t j[19];
+		neighbors(c, n, j);
+		const int solid = (flags[n]&TYPE_BO)==TYPE_S;
+		float geq[7];
+		calculate_g_eq(T[n], solid ? 0.0f : u[n], solid ? 0.0f : u[N+n], solid ? 0.0f : u[2ull*N+n], geq);
+		store_g(c, N, n, geq, gi, j, 1ull);
+	}
+}
+
 void luwo_initialize(const LuwOracleCfg* c, void* fi, const float* rho, float* u, const uint8_t* flags) {
 	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
 	#pragma omp parallel for schedule(static)
@@ -249,7 +291,7 @@ void luwo_initialize(const LuwOracleCfg* c, void* fi, const float* rho, float* u
 }
 
 /* FX/kernel.cpp:1475-1780 for one cell */
-static void stream_collide_cell(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t) {
+static void stream_collide_cell(const LuwOracleCfg* c, const uint64_t N, const uint64_t n, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t, const LuwOracleThermal* th) {
 	if(is_halo(c, n)) return;
 	const uint8_t flagsn = flags[n];
 	const uint8_t flagsn_bo = flagsn&TYPE_BO, flagsn_su = flagsn&TYPE_SU;
@@ -349,6 +391,33 @@ static void stream_collide_cell(const LuwOracleCfg* c, const uint64_t N, const u
 		}
 	}
 
+	if(th&&th->gi) { /* TEMPERATURE, FX/kernel.cpp:1639-1684; uses the velocity BEFORE the force shift */
+		float ghn[7];
+		load_g(c, N, n, ghn, th->gi, j, t);
+		float Tn;
+		if(flagsn&TYPE_T) Tn = th->T[n];
+		else { Tn = 0.0f; for(uint32_t i=0u; i<7u; i++) Tn += ghn[i]; Tn += 1.0f; }
+		if(c->sponge_active&&!(flagsn&TYPE_T)&&flagsn_bo!=TYPE_E&&has_top_face==1) { /* FX/kernel.cpp:1653-1667 */
+			uint32_t x, y, z; coordinates(c, n, &x, &y, &z);
+			const int d_t_i = (int)(Nz_global-2u)-((int)z+c->Oz);
+			const int Nsponge_i = (int)c->sponge_N;
+			if(d_t_i>=0&&d_t_i<Nsponge_i) {
+				const float xi = Nsponge_i>1 ? 1.0f-(float)d_t_i/(float)(Nsponge_i-1) : 1.0f;
+				float sigma_T = sinf(1.5707963267948966f*xi);
+				sigma_T = c->sponge_inv_tau*sigma_T*sigma_T;
+				Tn = fmaf(sigma_T, th->T[index3(c, x, y, (uint32_t)top_local_z)]-Tn, Tn);
+			}
+		}
+		float geq[7];
+		calculate_g_eq(Tn, uxn, uyn, uzn, geq);
+		if(flagsn&TYPE_T) { for(uint32_t i=0u; i<7u; i++) ghn[i] = geq[i]; }
+		else {
+			th->T[n] = Tn; /* UPDATE_FIELDS */
+			for(uint32_t i=0u; i<7u; i++) ghn[i] = fmaf(1.0f-c->w_T, ghn[i], c->w_T*geq[i]);
+		}
+		store_g(c, N, n, ghn, th->gi, j, t);
+		/* buoyancy: fxn -= fx*beta*(Tn-T_avg) etc. -- LUW constructs the solver with fx=fy=fz=0 (FX/setup.cpp:4935): no-op */
+	}
 	float Fin[19];
 	if(F) { /* FORCE_FIELD, FX/kernel.cpp:1617-1623 */
 		fxn += F[n];
@@ -393,7 +462,13 @@ static void stream_collide_cell(const LuwOracleCfg* c, const uint64_t N, const u
 void luwo_stream_collide(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t) {
 	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
 	#pragma omp parallel for schedule(static)
-	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t);
+	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t, NULL);
+}
+void luwo_stream_collide_thermal(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, void* gi, float* T, const uint64_t t) {
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	const LuwOracleThermal th = { gi, T };
+	#pragma omp parallel for schedule(static)
+	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t, &th);
 }
 
 /* LBM::run for a single domain: FX/lbm.cpp:1262-1312 (t increments after each stream_collide) */

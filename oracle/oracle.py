@@ -27,6 +27,7 @@ class Cfg(C.Structure):
         ("buffer_active", C.c_int32), ("buffer_N", C.c_uint32), ("buffer_inv_tau", C.c_float),
         ("buffer_nudge_vertical", C.c_int32), ("downstream_face", C.c_int32),
         ("sponge_active", C.c_int32), ("sponge_N", C.c_uint32), ("sponge_inv_tau", C.c_float),
+        ("w_T", C.c_float),
     ]
 
 
@@ -52,6 +53,8 @@ def lib():
         L.luwo_initialize.argtypes = [cfgp, vp, vp, vp, vp]; L.luwo_initialize.restype = None
         L.luwo_stream_collide.argtypes = [cfgp, vp, vp, vp, vp, vp, u64]; L.luwo_stream_collide.restype = None
         L.luwo_run.argtypes = [cfgp, vp, vp, vp, vp, vp, u64, u64]; L.luwo_run.restype = None
+        L.luwo_initialize_thermal.argtypes = [cfgp, vp, vp, vp, vp]; L.luwo_initialize_thermal.restype = None
+        L.luwo_stream_collide_thermal.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, vp, u64]; L.luwo_stream_collide_thermal.restype = None
         L.luwo_get_area.argtypes = [cfgp, u32]; L.luwo_get_area.restype = u64
         L.luwo_transfer_extract_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_extract_fi.restype = None
         L.luwo_transfer_insert_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_insert_fi.restype = None
@@ -84,7 +87,7 @@ class OracleLBM:
     the reference's layout (rho[N], u[3N] SoA, flags[N], fi[19N] SoA), n = x+(y+z*Ny)*Nx."""
 
     def __init__(self, Nx, Ny, Nz, nu, fx=0.0, fy=0.0, fz=0.0, fp16c=False, D=(1, 1, 1), O=(0, 0, 0),
-                 subgrid=True, use_F=False):
+                 subgrid=True, use_F=False, alpha=None):
         self.cfg = Cfg()
         c = self.cfg
         c.Nx, c.Ny, c.Nz = Nx, Ny, Nz
@@ -100,6 +103,12 @@ class OracleLBM:
         self.flags = np.zeros(self.N, np.uint8)
         self.F = np.zeros(3 * self.N, np.float32) if use_F else None
         self.fi = np.zeros(19 * self.N, np.uint16 if fp16c else np.float32)
+        # TEMPERATURE extension (FX/lbm.hpp:140-141, FX/lbm.cpp:750): thermal diffusivity alpha -> def_w_T through the text round trip
+        self.thermal = alpha is not None
+        if self.thermal:
+            c.w_T = literal(np.float32(1.0) / (np.float32(2.0) * np.float32(alpha) + np.float32(0.5)))
+            self.T = np.ones(self.N, np.float32)
+            self.gi = np.zeros(7 * self.N, np.uint16 if fp16c else np.float32)
         self.t = 0
         self.initialized = False
 
@@ -118,14 +127,21 @@ class OracleLBM:
 
     def initialize(self):
         lib().luwo_initialize(C.byref(self.cfg), _p(self.fi), _p(self.rho), _p(self.u), _p(self.flags))
+        if self.thermal:
+            lib().luwo_initialize_thermal(C.byref(self.cfg), _p(self.gi), _p(self.T), _p(self.u), _p(self.flags))
         self.initialized = True
         self.t = 0
 
     def run(self, steps):
         if not self.initialized:
             self.initialize()
-        lib().luwo_run(C.byref(self.cfg), _p(self.fi), _p(self.rho), _p(self.u), _p(self.flags), _p(self.F),
-                       self.t, steps)
+        if self.thermal:
+            for k in range(steps):
+                lib().luwo_stream_collide_thermal(C.byref(self.cfg), _p(self.fi), _p(self.rho), _p(self.u), _p(self.flags), _p(self.F),
+                                                  _p(self.gi), _p(self.T), self.t + k)
+        else:
+            lib().luwo_run(C.byref(self.cfg), _p(self.fi), _p(self.rho), _p(self.u), _p(self.flags), _p(self.F),
+                           self.t, steps)
         self.t += steps
 
     def stream_collide(self):

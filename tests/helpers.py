@@ -2,7 +2,7 @@
 (latticeurbanwind_amd.LBM), which expose the same host arrays (rho, u, flags, F) in the reference's layout."""
 import numpy as np
 
-TYPE_S, TYPE_E = 0x01, 0x02
+TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
 
 
 def synthetic_state(Nx, Ny, Nz, seed=1, solids=True, shell="E", u0=0.05):

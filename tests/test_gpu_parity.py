@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import synthetic_state, TYPE_S, TYPE_E
+from helpers import synthetic_state, TYPE_S, TYPE_E, TYPE_T
 
 pytestmark = pytest.mark.gpu
 
@@ -263,3 +263,40 @@ def test_halo_extract_insert_match_oracle(luw):
             g.increment_time_step(1); o.t += 1
             assert ddf_equal(g.download_fi(), o.fi)
         g.close()
+
+
+@pytest.mark.parametrize("fp16c", [False, True])
+@pytest.mark.parametrize("sponge", [False, True])
+def test_thermal_lattice_matches_oracle(luw, fp16c, sponge):
+    """TEMPERATURE (D3Q7 advection-diffusion of T on the LBM velocity, TYPE_T presets, top sponge on T; FX/kernel.cpp:1306-1335,
+    1639-1684): T, the thermal DDFs and -- unchanged by it -- u, rho and the DDFs equal the oracle value for value"""
+    from oracle import oracle
+    Nx, Ny, Nz = 40, 28, 24
+    st = synthetic_state(Nx, Ny, Nz, seed=11, shell="luw")
+    spg = dict(n_cells=5, inv_tau=0.02) if sponge else None
+    g = luw.LBM(Nx, Ny, Nz, 1e-3, fp16c=fp16c, alpha=4e-3, top_sponge=spg)
+    o = oracle.OracleLBM(Nx, Ny, Nz, 1e-3, fp16c=fp16c, alpha=4e-3)
+    if sponge:
+        o.set_top_sponge(5, 0.02)
+    flags = st[0].copy()
+    E = (flags & 3) == 2
+    flags[E] |= TYPE_T                                          # temperature boundary on the velocity boundary
+    rng = np.random.default_rng(3)
+    extra = (rng.random(flags.size) < 0.01) & ((flags & 3) == 0)
+    flags[extra] |= TYPE_T                                       # a few interior heat sources
+    z = (np.arange(flags.size) // (Nx * Ny)).astype(np.float32)
+    Tinit = np.ones(flags.size, np.float32)
+    Tinit[(flags & TYPE_T) != 0] = (1.0 + 0.05 * np.sin(z / 4.0) + 0.02 * rng.standard_normal(flags.size).astype(np.float32))[(flags & TYPE_T) != 0]
+    for l in (g, o):
+        (l.flags.data if hasattr(l.flags, "data") else l.flags)[:] = flags
+        (l.u.data if hasattr(l.u, "data") else l.u)[:] = st[1]
+        (l.rho.data if hasattr(l.rho, "data") else l.rho)[:] = st[2]
+        (l.T.data if hasattr(l.T, "data") else l.T)[:] = Tinit
+    for steps in (1, 2, 14):
+        g.run(steps); o.run(steps)
+        g.T.read_from_device()
+        assert np.array_equal(g.T.data, o.T), "T after %d more steps: %d cells differ" % (steps, int((g.T.data != o.T).sum()))
+        assert ddf_equal(g.download_gi(), o.gi)
+        check(g, o, "flow fields with the thermal lattice on")
+    assert np.isfinite(o.T).all() and o.T[(flags & 1) == 0].std() > 1e-4
+    g.close()
