@@ -206,6 +206,7 @@ int luw_vk_inlet_detach(luw_solver* s);
 int luw_stats_reset(luw_solver* s);
 int luw_stats_accumulate(luw_solver* s);
 int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, uint64_t* count);
+int luw_stats_download_T(luw_solver* s, float* avg_T);   /* running mean of T (LUW_OPT_TEMPERATURE), T_avg of FX/setup.cpp:4481-4484 */
 
 /* device self-check: number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C
  * codec differs from the literal formulas of FX/kernel.cpp:864-875; must be 0 */

@@ -653,10 +653,11 @@ __global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_inter
 // (accumulate_from_buffers, FX/setup.cpp:4441-4488).  Same arithmetic, same operation order, on the device: mean and M2 of
 // the three velocity components, mean of rho.  One lane per cell, x fastest.
 __global__ __launch_bounds__(256) void k_stats_accumulate(const KParams p, const float inv_n, const float* __restrict__ rho, const float* __restrict__ u,
-		float* __restrict__ avg_u, float* __restrict__ avg_rho, float* __restrict__ m2) {
+		float* __restrict__ avg_u, float* __restrict__ avg_rho, float* __restrict__ m2, const float* __restrict__ Tf, float* __restrict__ avg_T) {
 	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
 	if(x>=p.Nx) return;
 	const uint32_t n = x+(y+z*p.Ny)*p.Px;
+	if(avg_T) { const float ta = avg_T[n]; avg_T[n] = ta+(Tf[n]-ta)*inv_n; } // FX/setup.cpp:4481-4484
 	const size_t Np = p.Np;
 	#pragma unroll
 	for(int c=0; c<3; c++) {
@@ -1275,6 +1276,8 @@ int luw_stats_reset(luw_solver* s) {
 		if(lead_alloc(s, (void**)&s->d_avg_u, 3ull*Np, 4u)!=hipSuccess||lead_alloc(s, (void**)&s->d_avg_rho, Np, 4u)!=hipSuccess||lead_alloc(s, (void**)&s->d_m2, 3ull*Np, 4u)!=hipSuccess)
 			return fail(LUW_ERR_NOMEM, "luw_stats_reset: allocation failed");
 	}
+	if(s->d_T&&!s->d_avg_T) { if(lead_alloc(s, (void**)&s->d_avg_T, Np, 4u)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_stats_reset: allocation failed"); }
+	if(s->d_avg_T) HIP_TRY(hipMemsetAsync(s->d_avg_T, 0, Np*4ull, s->stream));
 	HIP_TRY(hipMemsetAsync(s->d_avg_u, 0, 3ull*Np*4ull, s->stream));
 	HIP_TRY(hipMemsetAsync(s->d_avg_rho, 0, Np*4ull, s->stream));
 	HIP_TRY(hipMemsetAsync(s->d_m2, 0, 3ull*Np*4ull, s->stream));
@@ -1291,7 +1294,7 @@ int luw_stats_accumulate(luw_solver* s) {
 	const float inv_n = 1.0f/(float)s->avg_count; // FX/setup.cpp:4442-4443
 	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
 	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
-	hipLaunchKernelGGL(k_stats_accumulate, grid, block, 0, s->stream, s->kp, inv_n, s->d_rho, s->d_u, s->d_avg_u, s->d_avg_rho, s->d_m2);
+	hipLaunchKernelGGL(k_stats_accumulate, grid, block, 0, s->stream, s->kp, inv_n, s->d_rho, s->d_u, s->d_avg_u, s->d_avg_rho, s->d_m2, s->d_T, s->d_avg_T);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
@@ -1315,6 +1318,14 @@ int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u,
 	}
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if(count) *count = s->avg_count;
+	return LUW_OK;
+}
+int luw_stats_download_T(luw_solver* s, float* avg_T) {
+	if(!s||!avg_T) return fail(LUW_ERR_INVALID, "luw_stats_download_T: bad argument");
+	if(!s->d_avg_T) return fail(LUW_ERR_STATE, "luw_stats_download_T: no temperature statistics (LUW_OPT_TEMPERATURE + luw_stats_reset)");
+	if(int e = set_device(s)) return e;
+	if(int e = copy_pitched(avg_T, s->d_avg_T, 4u, s, 1u, false, s->stream)) return e;
+	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
 int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches) {

@@ -514,6 +514,77 @@ inline uint64_t apply_cloud_boundaries(HostLattice& L, const std::string& downst
 	return (uint64_t)cells.size();
 }
 
+// ---- temperature boundaries (use_temperature_bc: buoyancy on and a T column in the CSV), lattice units, T = 1 at the reference
+struct TemperatureCounts { uint64_t mapped = 0ull, missing = 0ull, ground_cells = 0ull, ground_columns = 0ull; };
+// patch-driven: every non-solid outer cell (z > 0) of a patch with samples gets T = field(a, b), clamped to the CSV's range,
+// and the TYPE_T bit; an open downstream face is left alone (FX/setup.cpp:5268-5311)
+inline void apply_patch_temperature(HostLattice& L, float* T, const std::vector<PatchField2D>& tfields, const std::string& downstream_bc, const bool downstream_open_face, const float Tmin, const float Tmax, TemperatureCounts& cnt) {
+	const int dp = downstream_to_patch(downstream_bc);
+	std::atomic<uint64_t> mapped{0ull}, missing{0ull};
+	bc_parallel_for(L.N(), [&](const uint64_t n) {
+		uint32_t x, y, z; L.coords(n, x, y, z);
+		if(z==0u) return;
+		const int patch = boundary_cell_to_patch(x, y, z, L.Nx, L.Ny, L.Nz);
+		if(patch<0||(L.flags[n]&0x01u)||(downstream_open_face&&patch==dp)) return;
+		const PatchField2D& f = tfields[(size_t)patch];
+		float a, b;
+		if(!f.has_samples()||!patch_plane_coords(patch, L.position(x, y, z), a, b)) { missing.fetch_add(1ull, std::memory_order_relaxed); return; }
+		T[n] = fminf(fmaxf(f.eval(a, b).x, Tmin), Tmax);
+		L.flags[n] = (uint8_t)(L.flags[n]|0x04u);
+		mapped.fetch_add(1ull, std::memory_order_relaxed);
+	});
+	cnt.mapped = mapped.load(); cnt.missing = missing.load();
+}
+// sample-cloud variants (FX/setup.cpp:5360-5520 high order, :5561-5590 low order): T = 1 below the base height, else the
+// interpolator's value; high order marks every outer cell (solid ones too), low order the inlet faces
+inline void apply_cloud_temperature(HostLattice& L, float* T, const std::string& downstream_bc, const bool downstream_open_face, const bool high_order, const float z_threshold, const float Tmin, const float Tmax,
+		const std::function<float(const V3&)>& interp, TemperatureCounts& cnt) {
+	const int dp = downstream_to_patch(downstream_bc);
+	std::vector<uint64_t> cells;
+	for(uint64_t n=0ull; n<L.N(); n++) {
+		uint32_t x, y, z; L.coords(n, x, y, z);
+		if(z==0u||!(x==0u||x==L.Nx-1u||y==0u||y==L.Ny-1u||z==L.Nz-1u)) continue;
+		if(downstream_open_face) {
+			if(high_order) { const int face_patch = x==0u ? PATCH_WEST : x==L.Nx-1u ? PATCH_EAST : y==0u ? PATCH_SOUTH : y==L.Ny-1u ? PATCH_NORTH : PATCH_TOP; if(face_patch==dp) continue; } // face priority x, y, z
+			else if(is_downstream_cell(x, y, L.Nx, L.Ny, downstream_bc)) continue;
+		}
+		cells.push_back(n);
+	}
+	bc_parallel_for((uint64_t)cells.size(), [&](const uint64_t i) {
+		const uint64_t n = cells[i];
+		uint32_t x, y, z; L.coords(n, x, y, z);
+		const V3 p = L.position(x, y, z);
+		T[n] = fminf(fmaxf(p.z<z_threshold ? 1.0f : interp(p), Tmin), Tmax);
+		L.flags[n] = (uint8_t)(L.flags[n]|0x04u);
+	});
+	cnt.mapped = (uint64_t)cells.size();
+}
+// solid columns take the temperature of the bottom patch (GroundTemperaturePlane2D on patch 0, FX/setup.cpp:5034-5072)
+inline void apply_ground_temperature(HostLattice& L, float* T, const GroundPlane2D& plane, const float Tmin, const float Tmax, TemperatureCounts& cnt) {
+	std::vector<float> col((size_t)L.Nx*L.Ny);
+	bc_parallel_for((uint64_t)col.size(), [&](const uint64_t id) { const V3 p = L.position((uint32_t)(id%L.Nx), (uint32_t)(id/L.Nx), 0u); col[id] = fminf(fmaxf(plane.eval(p.x, p.y), Tmin), Tmax); });
+	std::vector<uint8_t> used(col.size(), 0u);
+	uint64_t cells = 0ull;
+	for(uint64_t n=0ull; n<L.N(); n++) {
+		if(!(L.flags[n]&0x01u)) continue;
+		const uint64_t id = n%((uint64_t)L.Nx*L.Ny);
+		T[n] = col[id]; L.flags[n] = (uint8_t)(L.flags[n]|0x01u|0x04u); used[id] = 1u; cells++;
+	}
+	cnt.ground_cells = cells; cnt.ground_columns = 0ull; for(const uint8_t v : used) cnt.ground_columns += v;
+}
+struct TemperatureSummary { uint64_t total = 0ull, solid = 0ull, fluid = 0ull, invalid = 0ull; float smin = +FLT_MAX, smax = -FLT_MAX, fmin = +FLT_MAX, fmax = -FLT_MAX; };
+inline TemperatureSummary summarize_temperature(const HostLattice& L, const float* T) { // FX/setup.cpp:5075-5117
+	TemperatureSummary r;
+	for(uint64_t n=0ull; n<L.N(); n++) {
+		if(!(L.flags[n]&0x04u)) continue;
+		r.total++;
+		if(!std::isfinite(T[n])) { r.invalid++; continue; }
+		if(L.flags[n]&0x01u) { r.solid++; r.smin = fminf(r.smin, T[n]); r.smax = fmaxf(r.smax, T[n]); }
+		else { r.fluid++; r.fmin = fminf(r.fmin, T[n]); r.fmax = fmaxf(r.fmax, T[n]); }
+	}
+	return r;
+}
+
 struct FluxReport { double S_in = 0.0, S_out = 0.0, net_before = 0.0, net_after = 0.0, delta = 0.0, avg_delta = 0.0; uint64_t corrected = 0ull; double face_avg[5] = {0, 0, 0, 0, 0}; /* Xn, Xp, Yn, Yp, Zp */ };
 
 // Uniform shift of the outward-normal velocity on all non-solid outer-face cells so that the net boundary flux vanishes;

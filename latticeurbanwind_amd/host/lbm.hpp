@@ -49,12 +49,14 @@ public:
 	struct VectorField : ScalarField { // lbm.u.x[n] etc., FX/lbm.hpp:359-372
 		struct Component { float* p = nullptr; float& operator[](const ulong n) { return p[n]; } } x, y, z;
 	};
-	FloatField rho; VectorField u; FlagField flags; VectorField F;
+	FloatField rho; VectorField u; FlagField flags; VectorField F; FloatField T;
 
 	// LBM(Nx, Ny, Nz, Dx, Dy, Dz, nu, fx, fy, fz, sigma, alpha, beta), FX/lbm.hpp:444: only Dx=Dy=Dz=1 per object here
 	// (multi-GPU = one object per process, latticeurbanwind_amd/distributed.py); sigma/alpha/beta belong to
 	// extensions outside this path and must be 0 / are ignored (thermal lattice: DESIGN.md section 1)
-	LBM(const uint Nx_, const uint Ny_, const uint Nz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const bool force_field = false) {
+	// alpha >= 0 switches the thermal D3Q7 lattice on (the reference's TEMPERATURE extension with LBM(..., alpha, beta); beta acts
+	// through (fx,fy,fz), which LUW keeps at zero)
+	LBM(const uint Nx_, const uint Ny_, const uint Nz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const bool force_field = false, const float alpha = -1.0f) {
 		Nx = Nx_; Ny = Ny_; Nz = Nz_;
 		const SolverGlobals& g = solver_globals();
 		luw_config c = {};
@@ -62,7 +64,8 @@ public:
 		c.Nx = Nx; c.Ny = Ny; c.Nz = Nz; c.Dx = c.Dy = c.Dz = 1u;
 		c.nu = nu; c.fx = fx; c.fy = fy; c.fz = fz;
 		c.ddf_format = g.fp16c ? LUW_DDF_FP16C : LUW_DDF_FP32;
-		c.options = force_field ? LUW_OPT_FORCE_FIELD : 0u;
+		c.options = (force_field ? LUW_OPT_FORCE_FIELD : 0u)|(alpha>=0.0f ? LUW_OPT_TEMPERATURE : 0u);
+		c.alpha = alpha>=0.0f ? alpha : 0.0f;
 		c.buffer_nudging_active = g.buffer_nudging_active; c.buffer_n_cells = (uint32_t)g.buffer_n_cells; c.buffer_inv_tau_lbmu = g.buffer_inv_tau_lbmu;
 		c.buffer_nudge_vertical = g.buffer_nudge_vertical; c.buffer_downstream_face_id = g.buffer_downstream_face_id;
 		c.top_sponge_active = g.top_sponge_active; c.sponge_n_cells = (uint32_t)g.sponge_n_cells; c.sponge_inv_tau_lbmu = g.sponge_inv_tau_lbmu;
@@ -73,6 +76,7 @@ public:
 		flags.lbm = this; flags.host = luw_host_ptr(s, LUW_FIELD_FLAGS); flags.mask = LUW_MASK_FLAGS;
 		u.lbm = this; u.host = luw_host_ptr(s, LUW_FIELD_U); u.mask = LUW_MASK_U;
 		float* up = static_cast<float*>(u.host); u.x.p = up; u.y.p = up+N; u.z.p = up+2ull*N;
+		T.lbm = this; T.host = luw_host_ptr(s, LUW_FIELD_T); T.mask = LUW_MASK_T;
 		F.lbm = this; F.host = luw_host_ptr(s, LUW_FIELD_F); F.mask = LUW_MASK_F;
 		if(F.host) { float* fp = static_cast<float*>(F.host); F.x.p = fp; F.y.p = fp+N; F.z.p = fp+2ull*N; }
 	}

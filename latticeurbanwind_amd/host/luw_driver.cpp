@@ -8,7 +8,8 @@
 //   + transform FX/setup.cpp:4070-4087, profile table :5777-5912, flags/u fill :5914-5995 (profile mode) and :5655-5688
 //   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
 // Modes: *.luw (NWP: SurfData CSV boundaries), *.luwpf (profile, with optional DEM ground plane) and *.luwdg (dataset).
-// Not in this build (announced on the console, never silently): PNG frames, temperature boundaries.
+// Temperature (buoyancy = true and a T column in the CSV): boundary temperatures, thermal lattice, T / T_avg outputs; single GPU.
+// Not in this build (announced on the console, never silently): PNG frames.
 // Differences by design: time averaging runs on the device (luw_stats_*); --dry-run voxelises on the host; the von-Karman
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
 // Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
@@ -165,10 +166,16 @@ static std::unordered_map<string, string> read_deck_entries(std::istream& in) {
 
 // ------------------------------------------------------------------------------------------------ units (FX/units.hpp)
 struct Units {
-	float unit_m = 1.0f, unit_kg = 1.0f, unit_s = 1.0f, unit_K = 1.0f;
+	float unit_m = 1.0f, unit_kg = 1.0f, unit_s = 1.0f, unit_K = 1.0f, unit_K_offset = 0.0f; // T_SI = T*unit_K + unit_K_offset
 	void set_m_kg_s_K(const float x, const float u, const float rho, const float T, const float si_x, const float si_u, const float si_rho, const float si_T) {
-		unit_m = si_x/x; unit_kg = si_rho/rho*(unit_m*unit_m*unit_m); unit_s = u/si_u*unit_m; unit_K = si_T/T;
+		unit_m = si_x/x; unit_kg = si_rho/rho*(unit_m*unit_m*unit_m); unit_s = u/si_u*unit_m; unit_K = si_T/T; unit_K_offset = 0.0f;
 	}
+	void set_temperature_reference(const float T_ref, const float si_T_ref) { unit_K_offset = si_T_ref-T_ref*unit_K; } // FX/units.hpp:37-39
+	float T(const float si_T) const { return (si_T-unit_K_offset)/unit_K; }
+	float si_T(const float T) const { return T*unit_K+unit_K_offset; }
+	float si_dT(const float dT) const { return dT*unit_K; }
+	float alpha(const float si_alpha) const { return si_alpha*unit_s/(unit_m*unit_m); }
+	float beta(const float si_beta) const { return si_beta*unit_K; }
 	float x(const float si_x) const { return si_x/unit_m; }
 	float si_x(const float x) const { return x*unit_m; }
 	float nu(const float si_nu) const { return si_nu*unit_s/(unit_m*unit_m); }
@@ -197,6 +204,7 @@ struct Config {
 	std::vector<float> inflow_list, angle_list;
 	// command line
 	string probes_raw, utm_crs; bool probes_output_defined = false; uint probes_output_steps = 0u; bool has_rotate_deg = false; double rotate_deg = 0.0;
+	bool buoyancy = true, buoyancy_explicit = false; // default-on unless explicitly false (FX/setup.cpp:2743)
 	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
 	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk, export_setup;
 };
@@ -387,14 +395,15 @@ static string vtk_header(const string& filename, const VtkGeom& g) {
 		"POINT_DATA "+to_string_u(points)+"\n";
 }
 // Memory_Container::write_vtk (FX/lbm.hpp:307-356): SoA host field -> AoS big-endian floats in SI units
-static void write_field_vtk(const string& filename, const VtkGeom& g, const float* data, const uint comps, const float factor) {
+static void write_field_vtk(const string& filename, const VtkGeom& g, const float* data, const uint comps, const float factor, const float offset = 0.0f, const bool affine = false) {
 	std::filesystem::create_directories(std::filesystem::path(filename).parent_path());
 	std::ofstream file(filename, std::ios::out|std::ios::binary);
 	const string header = vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n";
 	file.write(header.c_str(), (std::streamsize)header.length());
 	const ulong N = (ulong)g.Nx*g.Ny*g.Nz, points = (ulong)g.Nx*g.Ny*g.Nz_out;
 	std::vector<float> buf(points*comps);
-	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(factor*data[(ulong)d*N+i]); });
+	// the field named T goes through units.si_T (value*unit_K + offset), every other one through its unit factor (FX/lbm.hpp:343)
+	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(affine ? data[(ulong)d*N+i]*factor+offset : factor*data[(ulong)d*N+i]); });
 	file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
 }
 
@@ -440,6 +449,7 @@ int main(int argc, char** argv) {
 		const string& key = e.first; const string& val = e.second; const string uq = deck_unquote(val); bool pb = false;
 		if(key=="casename") c.caseName = uq;
 		else if(key=="datetime") c.datetime = uq;
+		else if(key=="buoyancy") { string v = uq; if(!v.empty()) { std::transform(v.begin(), v.end(), v.begin(), ::tolower); c.buoyancy_explicit = true; bool parsed = true; c.buoyancy = deck_try_parse_bool(v, parsed) ? parsed : true; } }
 		else if(key=="downstream_bc") c.downstream_bc = uq;
 		else if(key=="downstream_bc_yaw") c.downstream_bc_yaw = uq;
 		else if(key=="high_order") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.use_high_order = pb; }
@@ -573,6 +583,7 @@ int main(int argc, char** argv) {
 		else println("| GPU Estimate    | "+alignr(57u, to_string_u(c.Dx*c.Dy*c.Dz)+"x "+to_string_u(core)+" MB")+" |");
 	}
 	std::vector<float> prof_z, prof_u;
+	float temperature_ref_kelvin = 293.15f, temperature_scale_kelvin = 293.15f; bool temperature_ref_adaptive = false, temperature_scale_adaptive = false;
 	SurfData surf;
 	if(c.nwp_mode) { // FX/setup.cpp:3600-3650
 		const string csv = c.parent+"/proj_temp/SurfData_"+c.datetime+".csv";
@@ -582,6 +593,15 @@ int main(int argc, char** argv) {
 		float max_u = 0.0f;
 		for(const SurfSample& sm : surf.rows) { const float speed = std::sqrt(sm.u.x*sm.u.x+sm.u.y*sm.u.y+sm.u.z*sm.u.z); if(speed>max_u) max_u = speed; }
 		si_ref_u = max_u;
+		if(surf.has_T&&surf.rows_T>0ull) { // adaptive affine temperature map, FX/setup.cpp:3627-3648
+			float tmin = surf.tmin, tmax = surf.tmax; if(tmin>tmax) std::swap(tmin, tmax);
+			if(std::isfinite(tmin)&&std::isfinite(tmax)&&tmax>0.0f) {
+				const float tref = 0.5f*(tmin+tmax);
+				if(std::isfinite(tref)&&tref>0.0f) { temperature_ref_kelvin = tref; temperature_ref_adaptive = true; }
+				const float thalf = 0.5f*(tmax-tmin);
+				temperature_scale_kelvin = (std::isfinite(thalf)&&thalf>1.0e-6f) ? thalf : 1.0f; temperature_scale_adaptive = true;
+			}
+		}
 	} else if(c.dataset_mode) {
 		if(c.inflow_list.empty()) fatal("| ERROR: dataset generation requires inflow list (inflow=[...]).              |");
 		if(c.angle_list.empty()) fatal("| ERROR: dataset generation requires angle list (angle=[...]).                |");
@@ -604,7 +624,10 @@ int main(int argc, char** argv) {
 		println("| Profile domain  | "+alignr(57u, fmtf(agl))+" m AGL |");
 	}
 	Units units;
-	units.set_m_kg_s_K((float)Ny, lbm_ref_u, 1.0f, 1.0f, c.si_y, si_ref_u, si_rho, 293.15f);
+	units.set_m_kg_s_K((float)Ny, lbm_ref_u, 1.0f, 1.0f, c.si_y, si_ref_u, si_rho, temperature_scale_kelvin);
+	units.set_temperature_reference(1.0f, temperature_ref_kelvin); // T_lbm = 1.0 maps to the (adaptive) reference temperature, FX/setup.cpp:3731-3732
+	const float lbm_alpha = units.alpha(2.10E-5f);                // thermal diffusivity of air, FX/setup.cpp:3738-3741
+	const bool use_temperature_bc = c.nwp_mode&&c.buoyancy&&surf.has_T;
 	println("| Info: Unit Conversion: 1 cell = "+to_string_fd(1000.0f*units.si_x(1.0f), 3u)+" mm, 1 s = "+to_string_u(units.t(1.0f))+" time steps");
 	float u_scale = lbm_ref_u/si_ref_u;
 	float lbm_nu = units.nu(si_nu);
@@ -642,7 +665,12 @@ int main(int argc, char** argv) {
 	if(c.nwp_mode) {
 		println("| SI Reference U  | "+alignl(7u, fmtf(si_ref_u))+alignl(50u, "m/s")+" |");
 		println("| LBM Reference U | "+alignl(7u, fmtf(lbm_ref_u))+alignl(50u, "(Nondimensionalized)")+" |");
-		if(surf.has_T) println("| Temperature BC  | T column present: ignored (thermal lattice is outside this build)  |");
+		println("| Temp Reference  | "+alignr(57u, fmtf(temperature_ref_kelvin)+(temperature_ref_adaptive ? " K (auto center of input Tmin/Tmax)" : " K (default)"))+" |");
+		println("| Temp Scale      | "+alignr(57u, fmtf(temperature_scale_kelvin)+(temperature_scale_adaptive ? " K per 1.0 T_lbm (auto from input range)" : " K per 1.0 T_lbm (default)"))+" |");
+		println("| Thermal alpha   | "+alignr(57u, to_string_fd(lbm_alpha, 8u))+" |");
+		println("| Thermal tau_T   | "+alignr(57u, to_string_fd(2.0f*lbm_alpha+0.5f, 8u))+" |");
+		println("| Thermal beta    | "+alignr(57u, c.buoyancy ? to_string_fd(units.beta(1.0f/temperature_ref_kelvin), 8u) : string("0 (disabled by buoyancy=false)"))+" |");
+		if(c.buoyancy) println("| Thermal note    | temperature is advected as a passive scalar: the solver's volume force is zero, as in the reference |");
 	}
 	update_coriolis(); update_buffer_nudging(c.nwp_mode ? c.downstream_bc : string("+y")); update_top_sponge();
 	if(c.nwp_mode&&c.enable_coriolis) { print_kv_row("Coriolis", "enabled. center(lon,lat)=("+to_string_fd(0.5f*(c.cut_lon[0]+c.cut_lon[1]), 6u)+", "+to_string_fd(0.5f*(c.cut_lat[0]+c.cut_lat[1]), 6u)+") deg"); print_kv_row("", "Omega(lbmu)=("+to_string_fd(omega[0], 8u)+", "+to_string_fd(omega[1], 8u)+", "+to_string_fd(omega[2], 8u)+") per step"); }
@@ -655,6 +683,19 @@ int main(int argc, char** argv) {
 	print_kv_row("", "inv_tau_lbmu="+to_string_fd(G.sponge_inv_tau_lbmu, 8u)+", ref_mode="+std::to_string(c.sponge_ref_mode));
 	if(G.top_sponge_active) print_kv_row("", "core_top_z="+to_string_u(Nz_core-1u)+", side_ref_cap_z="+std::to_string(side_ref_z_cap));
 
+	float T_bc_min = 1.0f, T_bc_max = 1.0f;
+	if(c.nwp_mode) { // FX/setup.cpp:3944-3987
+		if(surf.has_T) {
+			println("| T column        | detected ("+to_string_u(surf.rows_T)+" rows)                               |");
+			println("| CSV T range SI  | "+alignr(24u, fmtf(surf.tmin))+" to "+alignl(16u, fmtf(surf.tmax))+" K |");
+			println(c.buoyancy ? "| Temperature BC  | enabled from CSV T (Kelvin -> nondimensionalized)               |" : "| Temperature BC  | buoyancy=false, ignore T column                                 |");
+		} else println("| T column        | not found, keep legacy velocity-only boundary behavior           |");
+		if(use_temperature_bc) {
+			ulong out_of_range = 0ull; for(const SurfSample& r : surf.rows) if(r.T<223.15f||r.T>343.15f) out_of_range++;
+			if(out_of_range>0ull) println("| WARNING: "+to_string_u(out_of_range)+" temperature samples are outside [-50C, 70C].                |");
+			T_bc_min = units.T(surf.tmin); T_bc_max = units.T(surf.tmax); if(T_bc_min>T_bc_max) std::swap(T_bc_min, T_bc_max);
+		}
+	}
 	if(c.sizing_only) { println(hr_plain()); return 0; }
 	// ---- geometry, FX/setup.cpp:4001-4093
 	print_section_title("LOADING GEOMETRY AND VOXELIZE");
@@ -800,6 +841,7 @@ int main(int argc, char** argv) {
 
 		// host state of this case
 		std::vector<uchar> flags(N, 0u); std::vector<float> u(3ull*N, 0.0f);
+		std::vector<float> Tcell; if(use_temperature_bc) Tcell.assign(N, 1.0f); // lbm.T, FX/lbm.cpp:304
 		std::unique_ptr<LBM> lbm_p;
 		ulong nvox = 0ull;
 		if(c.dry_run) nvox = voxelize_z(mesh, Nx, Ny, Nz, flags); // no GPU: host restatement of the kernel
@@ -809,7 +851,7 @@ int main(int argc, char** argv) {
 			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
 		}
 		else { // lbm.voxelize_mesh_on_device(mesh), FX/setup.cpp:4089
-			lbm_p.reset(new LBM(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f));
+			lbm_p.reset(new LBM(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f, false, use_temperature_bc ? lbm_alpha : -1.0f));
 			lbm_p->voxelize_mesh_on_device(mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), mesh.pmin, mesh.pmax, TYPE_S);
 			std::memcpy(flags.data(), lbm_p->flags.host, N);
 			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
@@ -831,7 +873,7 @@ int main(int argc, char** argv) {
 			const V3 org = HL.position(0u, 0u, 0u);
 			std::vector<SurfSample> smp; smp.reserve(surf.rows.size()); // SI -> lattice units (:3963-3979), then shifted to cell-centre coordinates (:4940-4946)
 			for(const SurfSample& r : surf.rows) {
-				SurfSample q; q.patch = r.patch; q.T = 1.0f;
+				SurfSample q; q.patch = r.patch; q.T = use_temperature_bc ? units.T(r.T) : 1.0f;
 				q.p.x = units.x(r.p.x); q.p.y = units.x(r.p.y); q.p.z = units.x(r.p.z);
 				q.u.x = r.u.x*u_scale; q.u.y = r.u.y*u_scale; q.u.z = r.u.z*u_scale;
 				q.p.x += org.x; q.p.y += org.y; q.p.z += org.z;
@@ -885,10 +927,66 @@ int main(int argc, char** argv) {
 				mapped = apply_cloud_boundaries(HL, case_bc, c.downstream_open_face, side_ref_z_cap, inlet);
 				downstream_fill = [inlet, HL](const uint x, const uint y, const uint z) -> V3 { return inlet(HL.position(x, y, z)); };
 			}
+			auto temperature_summary = [&](const string& tag) { // FX/setup.cpp:5075-5117
+				const TemperatureSummary ts = summarize_temperature(HL, Tcell.data());
+				println("| Temperature BC  | summary ["+tag+"]: TYPE_T total="+to_string_u(ts.total)+", solid="+to_string_u(ts.solid)+", fluid="+to_string_u(ts.fluid)+"            |");
+				if(ts.solid>0ull) println("| Temperature BC  | solid TYPE_T range SI: "+fmtf(units.si_T(ts.smin))+" .. "+fmtf(units.si_T(ts.smax))+" K                      |");
+				if(ts.fluid>0ull) println("| Temperature BC  | fluid TYPE_T range SI: "+fmtf(units.si_T(ts.fmin))+" .. "+fmtf(units.si_T(ts.fmax))+" K                      |");
+				if(ts.invalid>0ull) println("| Temperature BC  | WARNING: non-finite TYPE_T cells = "+to_string_u(ts.invalid)+"                         |");
+			};
+			string t_tag;
+			if(use_temperature_bc) {
+				TemperatureCounts tc;
+				SampleCloud tcloud; std::unique_ptr<KnnSurfaceInterpolator> tknn;
+				if(surf.has_patch) { // :4986-5012, :5268-5311
+					t_tag = "patch-2d";
+					std::vector<PatchField2D> tfields(6);
+					V3 tdef; tdef.x = 1.0f;
+					for(int pt=PATCH_TOP; pt<=PATCH_EAST; ++pt) {
+						tfields[(size_t)pt].build(smp, pt, [](const SurfSample& q) { V3 v; v.x = q.T; return v; }, tdef);
+						ulong cntp = 0ull; float mn = +FLT_MAX, mx = -FLT_MAX;
+						for(const SurfSample& q : smp) if(q.patch==pt) { cntp++; mn = fminf(mn, q.T); mx = fmaxf(mx, q.T); }
+						if(cntp>0ull) println("| T patch         | "+string(patch_name(pt))+": n="+to_string_u(cntp)+", SI "+fmtf(units.si_T(mn))+" .. "+fmtf(units.si_T(mx))+" K                    |");
+						else println("| T patch         | "+string(patch_name(pt))+": n=0                                           |");
+					}
+					apply_patch_temperature(HL, Tcell.data(), tfields, case_bc, c.downstream_open_face, T_bc_min, T_bc_max, tc);
+					println("| Temperature BC  | patch-driven 2D mapping: "+to_string_u(tc.mapped)+" cells              |");
+					if(tc.missing>0ull) println("|                 | WARNING: missing patch samples for "+to_string_u(tc.missing)+" cells      |");
+				} else {
+					tcloud.P.reserve(smp.size()); tcloud.U.reserve(smp.size());
+					for(const SurfSample& q : smp) { tcloud.P.push_back(q.p); V3 v; v.x = q.T; tcloud.U.push_back(v); }
+					if(c.use_high_order) {
+						t_tag = "high-order";
+						tknn.reset(new KnnSurfaceInterpolator(tcloud));
+						const KnnSurfaceInterpolator* k = tknn.get();
+						apply_cloud_temperature(HL, Tcell.data(), case_bc, c.downstream_open_face, true, units.x(c.z_si_offset)+z0_lbmu, T_bc_min, T_bc_max, [k](const V3& p) { return k->eval(p).x; }, tc);
+						println("| Temperature BC  | per-face interpolation done on 5 boundary surfaces        |");
+						println("| Temperature BC  | mapped "+to_string_u(tc.mapped)+" cells (high-order)      |");
+					} else {
+						t_tag = "low-order";
+						const SampleCloud* cl = &tcloud;
+						apply_cloud_temperature(HL, Tcell.data(), case_bc, c.downstream_open_face, false, z0_lbmu+units.x(c.z_si_offset), T_bc_min, T_bc_max, [cl](const V3& p) { return nearest_sample_velocity(*cl, p).x; }, tc);
+						println("| Temperature BC  | mapped "+to_string_u(tc.mapped)+" cells (low-order)                     |");
+					}
+				}
+				if(surf.has_patch) { // ground temperature plane from patch 0, :5019-5072 (in every boundary mode when the CSV carries patches)
+					std::vector<float> gx, gy, gt;
+					for(const SurfSample& q : smp) if(q.patch==PATCH_BOTTOM) { gx.push_back(q.p.x); gy.push_back(q.p.y); gt.push_back(q.T); }
+					GroundPlane2D tplane; tplane.build(gx, gy, gt, 1.0f);
+					if(tplane.has_samples()) {
+						println("| Ground T plane  | enabled from patch=0 ("+to_string_u(gt.size())+" samples, grid "+to_string_u(tplane.nx())+"x"+to_string_u(tplane.ny())+", mode="+(tplane.structured() ? string("2D bilinear") : string("2D nearest"))+") |");
+						apply_ground_temperature(HL, Tcell.data(), tplane, T_bc_min, T_bc_max, tc);
+						println("| Ground T plane  | mapped "+to_string_u(tc.ground_cells)+" solid cells, unique (x,y)="+to_string_u(tc.ground_columns)+" ["+t_tag+"]                                |");
+						if(tc.ground_cells==0ull) println("| Ground T plane  | WARNING: no solid cells were found                          |");
+					} else println("| Ground T plane  | patch column detected, but no patch=0 samples found        |");
+				}
+				temperature_summary(t_tag);
+			}
 			print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
 			if(c.flux_correction) {
 				print_kv_row("Flux correction", "starting. Time: ["+now_str()+"]");
 				report_flux(apply_flux_correction(HL, case_bc, downstream_fill));
+				if(use_temperature_bc) temperature_summary(t_tag+"/post-flux");
 			} else print_kv_row("Flux correction", "skipped. Set flux_correction=true to enable");
 		} else if(c.profile_mode) { // FX/setup.cpp:5914-5995,6043-6078
 			if(use_dem_ground) { // per-column terrain height, cells under it become solid
@@ -986,6 +1084,7 @@ int main(int argc, char** argv) {
 			const int ih[8] = {G.buffer_nudging_active, G.buffer_n_cells, G.buffer_downstream_face_id, G.buffer_nudge_vertical, G.top_sponge_active, G.sponge_n_cells, (int)nvox, (int)mapped.load()};
 			df.write((const char*)hdr, 16); df.write((const char*)fh, 32); df.write((const char*)ih, 32);
 			df.write((const char*)flags.data(), (std::streamsize)N); df.write((const char*)u.data(), (std::streamsize)(12ull*N));
+			if(use_temperature_bc) { const float th[2] = {units.unit_K, units.unit_K_offset}; df.write("TEMP", 4); df.write((const char*)th, 8); df.write((const char*)Tcell.data(), (std::streamsize)(4ull*N)); } // optional trailer: T in lattice units
 		}
 		const ulong total_steps = (c.run_nstep_override>0ull ? c.run_nstep_override : 20001ull)+(ulong)c.research_output_steps;
 		const ulong unsteady = (ulong)c.unsteady_output_interval;
@@ -1026,6 +1125,7 @@ int main(int argc, char** argv) {
 				}
 			}
 		}
+		if(!c.export_setup.empty()&&use_temperature_bc) println("| WARNING: temperature boundaries are not carried into decomposed runs (the thermal lattice is single-domain in this build); T is dropped. |");
 		if(!c.export_setup.empty()) { // hand-over to the multi-GPU launcher (latticeurbanwind_amd/run_deck.py): everything the run loop needs, per case
 			std::filesystem::create_directories(c.export_setup);
 			const string base = c.export_setup+"/case"+to_string_u(case_index);
@@ -1059,8 +1159,10 @@ int main(int argc, char** argv) {
 		LBM& lbm = *lbm_p;
 		lbm.set_coriolis(omega[0], omega[1], omega[2]);
 		std::memcpy(lbm.flags.host, flags.data(), N); std::memcpy(lbm.u.host, u.data(), 12ull*N); // rho mirror is pre-filled with 1.0f
+		if(use_temperature_bc) std::memcpy(lbm.T.host, Tcell.data(), 4ull*N);
 		if(vk_on) luw_check(luw_vk_inlet_attach(lbm.handle(), vk.point_count, vk.mode_count, vk.point_cell.data(), vk.point_face.data(), vk.point_data.data(), vk.mode_data.data(), c.vk_stride, c.vk_interp ? 1 : 0));
 		print_section_title("LBM SOLVER INFORMATION");
+		if(use_temperature_bc) print_kv_row("Export mode", "include temperature T field in Kelvin");
 		if(Nz_out<Nz) print_kv_row("VTK z output", "core Nz="+to_string_u(Nz_out)+" of solver Nz="+to_string_u(Nz)+" (top sponge omitted)");
 		print_kv_row("Run steps", to_string_u(total_steps)+(c.run_nstep_override>0ull ? " (run_nstep override)" : " (default)"));
 		if(avg_window>0ull) { print_kv_row("Avg stride", "sample every "+to_string_u(avg_stride)+" step(s) in purge_avg window (on-device accumulation)"); luw_check(luw_stats_reset(lbm.handle())); }
@@ -1094,6 +1196,7 @@ int main(int argc, char** argv) {
 			const ulong t = lbm.get_t();
 			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); }
 			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); print_kv_row("", fr+" saved");
+			if(use_temperature_bc) { lbm.T.read_from_device(); const string ft = default_filename(vtk_dir, "T", t); write_field_vtk(ft, geom, lbm.T.data<float>(), 1u, units.unit_K, units.unit_K_offset, true); print_kv_row("", ft+" saved"); }
 		}
 		if(c.research_output_steps>0u) { // maybe_write_transform_info, FX/setup.cpp:4778-4798
 			println("| Writing transform.info...                                                  |");
@@ -1120,6 +1223,13 @@ int main(int argc, char** argv) {
 				};
 				write_field("u_avg", avg_u.data(), 3u, u_factor);
 				write_field("rho_avg", avg_rho.data(), 1u, rho_factor);
+				if(use_temperature_bc) { // T_avg in Kelvin: factor si_dT(1), offset si_T(0), FX/setup.cpp:2526-2528,2580-2582
+					std::vector<float> avg_T(N); luw_check(luw_stats_download_T(lbm.handle(), avg_T.data()));
+					const string fh = "SCALARS T_avg float 1\nLOOKUP_TABLE default\n"; file.write(fh.c_str(), (std::streamsize)fh.length());
+					std::vector<float> buf(points); const float tf = units.si_dT(1.0f), to = units.si_T(0.0f);
+					parallel_for(points, [&](const ulong i) { buf[i] = reverse_bytes(avg_T[i]*tf+to); });
+					file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
+				}
 				std::vector<float> fluid(points, 1.0f), tke, ti, tls;
 				if(c.out_tke) tke.assign(points, 0.0f); if(c.out_ti) ti.assign(points, 0.0f); if(c.out_tls) tls.assign(points, 0.0f);
 				const bool has_m2 = avg_count>1ull; const float inv_n = has_m2 ? 1.0f/(float)avg_count : 0.0f;

@@ -13,6 +13,7 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
   D  case B on a base slab at z = 0..4 m with proj_temp/interpolated_dem.csv (terrain hill): DEM ground plane, terrain clip,
      profile above local terrain, flux correction in profile mode
+  T1..T3  N1 / N2 / N3-like decks with a T column in the CSV (temperature boundaries + thermal lattice + T outputs)
   P  case B with probe columns (deck key probes / probes_output): RESULTS/<lon>_<lat>[_offset].csv
   N1..N4  *.luw (NWP) decks on the case-B geometry with synthetic SurfData CSVs: N1 patch-driven 2-D mapping + flux
      correction + Coriolis; N2 KNN-HD (high_order) + flux correction; N3 nearest-sample + nudging + sponge + open
@@ -133,7 +134,12 @@ def wind(x, y, z):
     th = math.radians(12.0 + 0.25 * z + 2.0 * math.sin(0.03 * y))
     return speed * math.cos(th), speed * math.sin(th), 0.03 * math.sin(0.04 * x + 0.06 * y) * min(zz / 20.0, 1.0)
 
-def write_luw_case(root, name, kind, extra, nstep=16, unsteady=8, purge=4):
+def air_temperature(x, y, z):
+    """synthetic potential-temperature-like field in Kelvin: warm near the ground, horizontal variation"""
+    import math
+    return 287.5 + 4.0 * math.exp(-max(z - 4.0, 0.0) / 25.0) + 1.2 * math.sin(0.04 * x) * math.cos(0.03 * y)
+
+def write_luw_case(root, name, kind, extra, nstep=16, unsteady=8, purge=4, with_T=False):
     """*.luw (NWP) case on the CaseB geometry: boundaries from proj_temp/SurfData_<datetime>.csv.
     kind = "patch" (X,Y,Z,u,v,w,patch: patch-driven 2-D mapping incl. a bottom patch with gentle terrain),
            "cloud" (X,Y,Z,u,v,w: nearest-sample or, with high_order = true, KNN-HD interpolation)"""
@@ -162,6 +168,9 @@ def write_luw_case(root, name, kind, extra, nstep=16, unsteady=8, purge=4):
             for xx, pid in ((0.0, 4), (Lx, 5)):
                 for z in zs_side(terrain(xx, y)): rows.append((xx, y, z) + wind(xx, y, z) + (pid,))
         header = "X,Y,Z,u,v,w,patch"
+        if with_T:   # X,Y,Z,u,v,w,T,patch: ground temperature on the bottom patch, air temperature elsewhere
+            rows = [r[:6] + ((291.0 + 2.5 * math.exp(-((r[0] - 60.0) ** 2 + (r[1] - 30.0) ** 2) / 500.0)) if r[6] == 0 else air_temperature(r[0], r[1], r[2]),) + (r[6],) for r in rows]
+            header = "X,Y,Z,u,v,w,T,patch"
     else:
         zs = frange(0.0, Lz, 2.7)
         for x in xs:
@@ -173,10 +182,14 @@ def write_luw_case(root, name, kind, extra, nstep=16, unsteady=8, purge=4):
             for xx in (0.0, Lx):
                 for z in zs: rows.append((xx, y, z) + wind(xx, y, z))
         header = "X,Y,Z,u,v,w"
+        if with_T:
+            rows = [r + (air_temperature(r[0], r[1], r[2]),) for r in rows]
+            header = "X,Y,Z,u,v,w,T"
     with open(os.path.join(d, "proj_temp", "SurfData_20260101120000.csv"), "w") as f:
         f.write(header + "\n")
         for r in rows:
-            f.write(",".join(("%d" % v) if (i == 6) else ("%.6f" % v) for i, v in enumerate(r)) + "\n")
+            last_is_patch = header.endswith("patch")
+            f.write(",".join(("%d" % v) if (last_is_patch and i == len(r) - 1) else ("%.6f" % v) for i, v in enumerate(r)) + "\n")
     deck = [
         "// LUW deck (synthetic NWP-mode case, generated by tests/golden/make_refcases.py)",
         "casename = %s" % name, "datetime = 20260101120000",
@@ -213,6 +226,11 @@ if __name__ == "__main__":
                                              "sponge_thickness_m = 8", "sponge_tau_s = 2", "high_order = false", "flux_correction = false",
                                              "coriolis_term = false", "downstream_open_face = true"])
     write_luw_case(root, "CaseN4", "patch", off + ["high_order = true", "flux_correction = false", "coriolis_term = false", "downstream_open_face = true"])
+    # T1..T3: NWP decks whose CSV carries a T column (buoyancy defaults to true): temperature boundaries, thermal lattice, T outputs
+    write_luw_case(root, "CaseT1", "patch", off + ["high_order = false", "flux_correction = true", "coriolis_term = false"], with_T=True)
+    write_luw_case(root, "CaseT2", "cloud", off + ["high_order = true", "flux_correction = false", "coriolis_term = false"], with_T=True)
+    write_luw_case(root, "CaseT3", "cloud", ["enable_buffer_nudging = false", "enable_top_sponge = true", "sponge_thickness_m = 8", "sponge_tau_s = 2", "high_order = false",
+                                             "flux_correction = false", "coriolis_term = false", "downstream_open_face = true"], with_T=True)
     # performance decks for timing the reference itself on the GPU box (not fixtures: generated on demand)
     if "--perf" in sys.argv:
         write_case(root, "Perf512", 1.0, off, dims=(1024, 1024, 1024), building=False, nstep=300, unsteady=0, purge=0)

@@ -17,6 +17,9 @@ for t in (times[0], times[-1]):   # first unsteady output and the final step (8 
     h, f = read_vtk(g("*_raw_u-%09d.vtk" % t)); d["u%d" % t] = f["data"].astype(np.float32)
 h, f = read_vtk(g("*_raw_rho-*.vtk")); d["rho%d" % times[-1]] = f["data"][..., 0].astype(np.float32)
 h, f = read_vtk(g("*_avg-*.vtk")); d["solid"] = (f["fluid"][..., 0] == 0)
+if glob.glob(os.path.join(run_dir, "*_raw_T-*.vtk")):       # temperature cases: final T in Kelvin and its window mean
+    hT, fT = read_vtk(g("*_raw_T-*.vtk")); d["T%d" % times[-1]] = fT["data"][..., 0].astype(np.float32)
+    if "T_avg" in f: d["T_avg"] = f["T_avg"][..., 0].astype(np.float32)
 d["u_avg"] = f["u_avg"].astype(np.float32)   # mean of u over the last purge_avg=4 steps, SI units
 d["dims"] = np.array(h["dims"]); d["origin"] = np.array(h["origin"]); d["spacing"] = np.array(h["spacing"])
 np.savez_compressed(out + ".npz", **d)

@@ -34,7 +34,11 @@ def read_dump(path):
     N = Nx * Ny * Nz
     flags = np.frombuffer(raw, np.uint8, N, 80)
     u = np.frombuffer(raw, np.float32, 3 * N, 80 + N)
-    return dict(Nx=Nx, Ny=Ny, Nz=Nz, Nz_core=Nzc, nu=fh[0], si_u=fh[1], si_rho=fh[2], buffer_inv_tau=fh[3], sponge_inv_tau=fh[4], scale=fh[5],
+    extra = {}
+    off = 80 + N + 12 * N
+    if raw[off:off + 4] == b"TEMP":      # temperature cases: unit_K, unit_K_offset, T[N] in lattice units
+        extra = dict(unit_K=np.frombuffer(raw, np.float32, 1, off + 4)[0], unit_K_offset=np.frombuffer(raw, np.float32, 1, off + 8)[0], T=np.frombuffer(raw, np.float32, N, off + 12))
+    return dict(extra, Nx=Nx, Ny=Ny, Nz=Nz, Nz_core=Nzc, nu=fh[0], si_u=fh[1], si_rho=fh[2], buffer_inv_tau=fh[3], sponge_inv_tau=fh[4], scale=fh[5],
                 buffer_active=ih[0], buffer_N=ih[1], buffer_face=ih[2], nudge_vertical=ih[3], sponge_active=ih[4], sponge_N=ih[5], nvox=ih[6], mapped=ih[7], flags=flags, u=u)
 
 
@@ -163,3 +167,27 @@ def test_probe_requests_resolve_like_the_reference(driver, tmp_path):
     assert pick(out) == pick(ref) and len(pick(ref)) == 5
     norm = lambda txt: [" ".join(l.strip().strip("|").split()) for l in txt.splitlines() if "ignored:" in l or "Probes Window" in l or "request(s)" in l]
     assert norm(out) == norm(ref)
+
+
+@pytest.mark.parametrize("case", ["CaseT1", "CaseT2", "CaseT3"])
+def test_temperature_boundaries_against_real_reference_fields(driver, tmp_path, case):
+    """buoyancy = true + a T column in the CSV: adaptive Kelvin <-> lattice map, patch-driven / KNN-HD / nearest-sample temperature
+    on the boundary cells, ground-temperature plane on the solids.  TYPE_T cells keep their preset, so the reference's final T
+    output shows the builders' result there: the driver's initial T must equal it bit for bit (cells whose solid state differs
+    between the host voxeliser of --dry-run and the device mask are skipped)."""
+    deck = os.path.join(GOLD, "refcases", case, "conf.luw")
+    dump = str(tmp_path / "setup.bin")
+    out = run(driver, deck, "--dry-run", "--dump-setup", dump)
+    d = read_dump(dump)
+    gold = np.load(os.path.join(GOLD, "ref_fp32_%s.npz" % case))
+    Nx, Ny, Nz, Nzc = d["Nx"], d["Ny"], d["Nz"], d["Nz_core"]
+    fl = d["flags"].reshape(Nz, Ny, Nx)[:Nzc]
+    T_si = (d["T"].reshape(Nz, Ny, Nx)[:Nzc] * d["unit_K"] + d["unit_K_offset"]).astype(np.float32)
+    preset = (fl & 4) != 0
+    same_solid = ((fl & 1) != 0) == gold["solid"]
+    m = preset & same_solid
+    assert m.sum() > 2500 and np.array_equal(T_si[m], gold["T16"][m]), "%d preset cells differ" % int((T_si[m] != gold["T16"][m]).sum())
+    ref = open(os.path.join(GOLD, "ref_fp32_%s.console.txt" % case)).read()
+    norm = lambda txt, keys: sorted(" ".join(l.strip().strip("|").split()) for l in txt.splitlines() if any(k in l for k in keys))
+    keys = ("Temp Reference", "Temp Scale", "Thermal alpha", "Thermal tau_T", "Thermal beta", "T patch", "CSV T range", "T column")
+    assert norm(out, keys) == norm(ref, keys)

@@ -82,7 +82,10 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
     ("CaseD", "fp32", "ref_fp32_CaseD"), ("CaseD", "fp16c", "ref_shipped_CaseD"),     # DEM ground plane + flux correction in profile mode
     ("CaseN1", "fp32", "ref_fp32_CaseN1"), ("CaseN2", "fp32", "ref_fp32_CaseN2"), ("CaseN3", "fp32", "ref_fp32_CaseN3"),
     ("CaseN4", "fp32", "ref_fp32_CaseN4"), ("CaseN1", "fp16c", "ref_shipped_CaseN1"), ("CaseN2", "fp16c", "ref_shipped_CaseN2"),
-    ("CaseN3", "fp16c", "ref_shipped_CaseN3"), ("CaseN4", "fp16c", "ref_shipped_CaseN4")])
+    ("CaseN3", "fp16c", "ref_shipped_CaseN3"), ("CaseN4", "fp16c", "ref_shipped_CaseN4"),
+    # temperature: T column + buoyancy -> temperature boundaries, thermal D3Q7 lattice, T / T_avg outputs in Kelvin
+    ("CaseT1", "fp32", "ref_fp32_CaseT1"), ("CaseT2", "fp32", "ref_fp32_CaseT2"), ("CaseT3", "fp32", "ref_fp32_CaseT3"),
+    ("CaseT1", "fp16c", "ref_shipped_CaseT1"), ("CaseT2", "fp16c", "ref_shipped_CaseT2"), ("CaseT3", "fp16c", "ref_shipped_CaseT3")])
 def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture):
     """deck in, VTK out, nothing injected: the driver's files against the files the REAL reference wrote for the same deck on
     an MI355X (geometry voxelised on the device, BC fill, VK inlet, run loop, averaging, writers).  Gates as in
@@ -131,6 +134,15 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_rho-%09d.vtk" % times[-1]))[0])
     dr = np.abs((ff["data"][..., 0] - gold["rho%d" % times[-1]]) / rho_fac)[fluid].max()
     assert dr < (1e-2 if fp16c else 1e-4), "rho max diff %.3e" % dr
+    tkey = "T%d" % times[-1]
+    if tkey in gold.files:     # Kelvin; one float ulp at 290 K is 3.05e-5 K
+        hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_T-%09d.vtk" % times[-1]))[0])
+        Tm, Tr = ff["data"][..., 0], gold[tkey]
+        assert np.array_equal(Tm[solid], Tr[solid]), "ground-temperature plane differs"
+        assert np.abs(Tm - Tr).max() < (2e-3 if fp16c else 1e-4) and np.sqrt(((Tm - Tr)[fluid] ** 2).mean()) < (2e-4 if fp16c else 1e-5)
+        assert np.abs(f["T_avg"][..., 0] - gold["T_avg"]).max() < (2e-3 if fp16c else 1e-4)
+    else:
+        assert not glob.glob(os.path.join(vt, "*_raw_T-*.vtk")) and "T_avg" not in f
     probes = os.path.join(GOLD, fixture + "_probes")
     if os.path.isdir(probes):     # probe CSVs: same files, same levels and times, velocities within the final-step gate (SI text, 6 decimals)
         def rd(path):
