@@ -62,7 +62,7 @@ extern "C" {
 #define LUW_OPT_UPDATE_FIELDS_EVERY_STEP 0x2u /* write rho,u in every step exactly like UPDATE_FIELDS (FX/kernel.cpp:1709-1716);
                                            without it rho,u are written by the last step of each luw_run() call and on
                                            luw_download(), which yields identical values whenever they are observed */
-#define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha; single domain */
+#define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha */
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
 
 /* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
@@ -155,6 +155,10 @@ int luw_reset_time_step(luw_solver* s);                                   /* LBM
 uint64_t luw_get_area(const luw_solver* s, uint32_t direction);           /* LBM_Domain::get_area */
 int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p, void* dev_buffer_m);
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* dev_buffer_p, const void* dev_buffer_m);
+/* the thermal lattice's halo swap: ONE population per face cell and side (buffers of get_area(direction) DDF elements),
+ * transfer_extract_gi / transfer__insert_gi, FX/kernel.cpp:2338-2363.  (The reference also swaps T itself, for rendering only.) */
+int luw_enqueue_extract_gi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m);
+int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m);
 int luw_finish(luw_solver* s);                                            /* LBM_Domain::finish_queue */
 
 /* debugging / test access to the DDFs: copies the 19 planes to / from host memory in the reference's layout

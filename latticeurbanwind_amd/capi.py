@@ -29,7 +29,7 @@ SYMBOLS = [
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
     "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
-    "luw_enqueue_insert_fi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
+    "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
     L.luw_selfcheck_fp16c_codec.argtypes = [i32, C.POINTER(u64)]
     L.luw_voxelize_mesh.argtypes = [vp, u32, vp, vp, vp, vp, C.c_uint8]
     L.luw_download_gi.argtypes = [vp, vp]
+    L.luw_enqueue_extract_gi.argtypes = [vp, u32, vp, vp]; L.luw_enqueue_insert_gi.argtypes = [vp, u32, vp, vp]
     L.luw_set_kernel.argtypes = [vp, u32]
     L.luw_gather_attach.argtypes = [vp, u32, vp]; L.luw_gather_u.argtypes = [vp, vp]
     L.luw_voxelize_lattice.argtypes = [i32, u32, u32, u32, u32, vp, vp, vp, vp, C.c_uint8, vp]

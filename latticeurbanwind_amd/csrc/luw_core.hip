@@ -501,7 +501,9 @@ __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t a, co
 	else if(direction==1u) { x = a/p.Nz; y = fixed; z = a%p.Nz; }
 	else { x = a%p.Nx; y = a/p.Nx; z = fixed; }
 }
-template<typename T> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
+// G = false: the 5 D3Q19 populations of a face (fi); G = true: the single D3Q7 population of the thermal lattice (gi, i = side+1,
+// FX/kernel.cpp:2338-2351) -- same slot algebra, the D3Q7 neighbours are the first six of the D3Q19 list
+template<typename T, bool G=false> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
 	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
 	if(a>=A) return;
 	const uint32_t Nd = direction==0u ? p.Nx : direction==1u ? p.Ny : p.Nz;
@@ -512,14 +514,14 @@ template<typename T> __global__ __launch_bounds__(256) void k_extract_fi(const K
 		uint32_t j[19];
 		neighbors(p, x, y, z, j);
 		T* buf = pm==0u ? buf_p : buf_m;
-		for(uint32_t bb=0u; bb<5u; bb++) {
-			const uint32_t i = c_index_transfer[(2u*direction+pm)*5u+bb];
+		for(uint32_t bb=0u; bb<(G ? 1u : 5u); bb++) {
+			const uint32_t i = G ? 2u*direction+pm+1u : c_index_transfer[(2u*direction+pm)*5u+bb];
 			const uint32_t plane = t_odd ? ((i&1u) ? i+1u : i-1u) : i;
 			buf[(size_t)bb*A+a] = fi[(size_t)plane*p.Np+((i&1u) ? j[i] : j[0])];
 		}
 	}
 }
-template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
+template<typename T, bool G=false> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
 	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
 	if(a>=A) return;
 	const uint32_t Nd = direction==0u ? p.Nx : direction==1u ? p.Ny : p.Nz;
@@ -530,8 +532,8 @@ template<typename T> __global__ __launch_bounds__(256) void k_insert_fi(const KP
 		uint32_t j[19];
 		neighbors(p, x, y, z, j);
 		const T* buf = pm==0u ? buf_p : buf_m;
-		for(uint32_t bb=0u; bb<5u; bb++) {
-			const uint32_t i = c_index_transfer[(2u*direction+pm)*5u+bb];
+		for(uint32_t bb=0u; bb<(G ? 1u : 5u); bb++) {
+			const uint32_t i = G ? 2u*direction+pm+1u : c_index_transfer[(2u*direction+pm)*5u+bb];
 			const uint32_t plane = t_odd ? i : ((i&1u) ? i+1u : i-1u);
 			fi[(size_t)plane*p.Np+((i&1u) ? j[0] : j[i-1u])] = buf[(size_t)bb*A+a];
 		}
@@ -927,7 +929,6 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->nu<0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be negative."); // FX/lbm.cpp:1142
 	if(cfg->ddf_format!=LUW_DDF_FP32&&cfg->ddf_format!=LUW_DDF_FP16C) return fail(LUW_ERR_INVALID, "luw_create: unknown ddf_format");
 	if((cfg->Dx>1u&&cfg->Nx<3u)||(cfg->Dy>1u&&cfg->Ny<3u)||(cfg->Dz>1u&&cfg->Nz<3u)) return fail(LUW_ERR_INVALID, "luw_create: split axes need at least one interior cell between the halo layers");
-	if((cfg->options&LUW_OPT_TEMPERATURE)&&cfg->Dx*cfg->Dy*cfg->Dz>1u) return fail(LUW_ERR_INVALID, "luw_create: the thermal lattice is single-domain in this build (no gi / T halo exchange)");
 	if((cfg->options&LUW_OPT_TEMPERATURE)&&!(cfg->alpha>=0.0f)) return fail(LUW_ERR_INVALID, "luw_create: thermal diffusivity must not be negative");
 	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
 	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
@@ -1464,6 +1465,30 @@ int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, 
 	const uint32_t odd = (uint32_t)(s->t&1ull);
 	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const uint16_t*)buf_p, (const uint16_t*)buf_m, (uint16_t*)s->d_fi);
 	else hipLaunchKernelGGL((k_insert_fi<float>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_fi);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+int luw_enqueue_extract_gi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
+	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_gi: bad argument");
+	if(!s->d_gi) return fail(LUW_ERR_STATE, "luw_enqueue_extract_gi: the solver was created without LUW_OPT_TEMPERATURE");
+	if(int e = set_device(s)) return e;
+	const uint32_t A = (uint32_t)luw_get_area(s, direction);
+	const dim3 grid((A+255u)/256u), block(256);
+	const uint32_t odd = (uint32_t)(s->t&1ull);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_extract_fi<uint16_t, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (uint16_t*)buf_p, (uint16_t*)buf_m, (const uint16_t*)s->d_gi);
+	else hipLaunchKernelGGL((k_extract_fi<float, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (float*)buf_p, (float*)buf_m, (const float*)s->d_gi);
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m) {
+	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_insert_gi: bad argument");
+	if(!s->d_gi) return fail(LUW_ERR_STATE, "luw_enqueue_insert_gi: the solver was created without LUW_OPT_TEMPERATURE");
+	if(int e = set_device(s)) return e;
+	const uint32_t A = (uint32_t)luw_get_area(s, direction);
+	const dim3 grid((A+255u)/256u), block(256);
+	const uint32_t odd = (uint32_t)(s->t&1ull);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const uint16_t*)buf_p, (const uint16_t*)buf_m, (uint16_t*)s->d_gi);
+	else hipLaunchKernelGGL((k_insert_fi<float, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_gi);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }

@@ -182,14 +182,19 @@ class HipDomain:
         self.dtype = torch.float16 if fp16c else torch.float32
         self.compute = torch.cuda.Stream(device=self.device)
         self.comm = torch.cuda.Stream(device=self.device)
-        self.buf = {}
+        self.thermal = kw.get("alpha") is not None       # thermal D3Q7 lattice: one more population per face cell travels
+        self.buf, self.gbuf = {}, {}
         for a in layout.split_axes():
             A = self.lbm.area(a)
             self.buf[a] = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(4)]  # send_p, send_m, recv_p, recv_m
+            if self.thermal:
+                self.gbuf[a] = [torch.zeros(A, dtype=self.dtype, device=self.device) for _ in range(4)]
 
     # host fields (reference layout, local box incl. halos)
-    def set_fields(self, flags, u, rho):
+    def set_fields(self, flags, u, rho, T=None):
         self.lbm.flags.data[:] = flags; self.lbm.u.data[:] = u; self.lbm.rho.data[:] = rho
+        if T is not None:
+            self.lbm.T.data[:] = T
 
     def initialize(self):
         self.lbm.run(0)
@@ -215,6 +220,25 @@ class HipDomain:
         self.lbm.set_stream(stream.cuda_stream)
         b = self.buf[axis]
         self.lbm.enqueue_insert_fi(axis, b[2].data_ptr(), b[3].data_ptr())
+
+    def extract_g(self, axis, stream):
+        self.lbm.set_stream(stream.cuda_stream)
+        b = self.gbuf[axis]
+        self.lbm.enqueue_extract_gi(axis, b[0].data_ptr(), b[1].data_ptr())
+        return b[0], b[1]
+
+    def recv_buffers_g(self, axis):
+        return self.gbuf[axis][2], self.gbuf[axis][3]
+
+    def insert_g(self, axis, stream):
+        self.lbm.set_stream(stream.cuda_stream)
+        b = self.gbuf[axis]
+        self.lbm.enqueue_insert_gi(axis, b[2].data_ptr(), b[3].data_ptr())
+
+    def download_T(self):
+        self.torch.cuda.synchronize(self.device)
+        self.lbm.T.read_from_device()
+        return self.lbm.T.data
 
     def download(self):
         self.torch.cuda.synchronize(self.device)
@@ -248,6 +272,10 @@ class HipDomain:
         self.lbm.set_stream(self.compute.cuda_stream)
         return self.lbm.stats_download()
 
+    def stats_download_T(self):
+        self.lbm.set_stream(self.compute.cuda_stream)
+        return self.lbm.stats_download_T()
+
     def close(self):
         self.torch.cuda.synchronize(self.device)
         self.lbm.close()
@@ -275,10 +303,11 @@ class DomainDecomposedLBM:
         self.initialized = False
         self.pre_step = None     # callable(stream) enqueued before every step's kernels (von-Karman inlet update)
 
-    def set_fields(self, flags, u, rho):
-        self.backend.set_fields(flags, u, rho)
+    def set_fields(self, flags, u, rho, T=None):
+        if T is not None: self.backend.set_fields(flags, u, rho, T)
+        else: self.backend.set_fields(flags, u, rho)
 
-    def set_fields_from_global(self, gflags, gu, grho=None):
+    def set_fields_from_global(self, gflags, gu, grho=None, gT=None):
         """cut this rank's box (incl. periodic halos) out of global (z,y,x) arrays; grho=None means rho = 1"""
         ix, iy, iz = self.layout.local_slices()
         sel = np.ix_(iz, iy, ix)
@@ -286,7 +315,10 @@ class DomainDecomposedLBM:
         f = gflags.reshape(gN[2], gN[1], gN[0])[sel]
         r = grho.reshape(gN[2], gN[1], gN[0])[sel] if grho is not None else np.ones(f.shape, np.float32)
         u = np.stack([gu.reshape(3, gN[2], gN[1], gN[0])[c][sel] for c in range(3)])
-        self.backend.set_fields(f.ravel(), u.ravel(), r.ravel())
+        if gT is not None:
+            self.backend.set_fields(f.ravel(), u.ravel(), r.ravel(), np.ascontiguousarray(gT.reshape(gN[2], gN[1], gN[0])[sel]).ravel())
+        else:
+            self.backend.set_fields(f.ravel(), u.ravel(), r.ravel())
 
     # ---- FX/lbm.cpp:1907-1935 for the DDF field, device to device
     def communicate_fi(self, stream=None):
@@ -296,6 +328,12 @@ class DomainDecomposedLBM:
             rp, rm = b.recv_buffers(axis)
             self._exchange(axis, sp, sm, rp, rm, stream)
             b.insert(axis, stream)
+        if getattr(b, "thermal", False):      # communicate_gi, FX/lbm.cpp:1283,1952-1954: after the DDFs, same axis order
+            for axis in self.layout.split_axes():
+                sp, sm = b.extract_g(axis, stream)
+                rp, rm = b.recv_buffers_g(axis)
+                self._exchange(axis, sp, sm, rp, rm, stream)
+                b.insert_g(axis, stream)
 
     def _exchange(self, axis, sp, sm, rp, rm, stream):
         if stream is not None:
@@ -399,6 +437,18 @@ class LocalGroup:
             for s in self.sims:
                 s.backend.insert(axis, getattr(s.backend, "comm", None))
             self._sync()
+        if getattr(self.sims[0].backend, "thermal", False):
+            for axis in lay0.split_axes():
+                sent = [s.backend.extract_g(axis, getattr(s.backend, "comm", None)) for s in self.sims]
+                self._sync()
+                for s, (sp, sm) in zip(self.sims, sent):
+                    plus, minus = self.sims[s.layout.neighbor(axis, +1)], self.sims[s.layout.neighbor(axis, -1)]
+                    plus.backend.recv_buffers_g(axis)[1].copy_(sp)
+                    minus.backend.recv_buffers_g(axis)[0].copy_(sm)
+                self._sync_all_devices()
+                for s in self.sims:
+                    s.backend.insert_g(axis, getattr(s.backend, "comm", None))
+                self._sync()
 
     def _sync_all_devices(self):
         try:

@@ -8,7 +8,7 @@
 //   + transform FX/setup.cpp:4070-4087, profile table :5777-5912, flags/u fill :5914-5995 (profile mode) and :5655-5688
 //   (dataset mode), run loop :4117-4911, VTK writers FX/lbm.hpp:307-356 and FX/setup.cpp:2513-2683.
 // Modes: *.luw (NWP: SurfData CSV boundaries), *.luwpf (profile, with optional DEM ground plane) and *.luwdg (dataset).
-// Temperature (buoyancy = true and a T column in the CSV): boundary temperatures, thermal lattice, T / T_avg outputs; single GPU.
+// Temperature (buoyancy = true and a T column in the CSV): boundary temperatures, thermal lattice, T / T_avg outputs.
 // Not in this build (announced on the console, never silently): PNG frames.
 // Differences by design: time averaging runs on the device (luw_stats_*); --dry-run voxelises on the host; the von-Karman
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
@@ -1125,11 +1125,10 @@ int main(int argc, char** argv) {
 				}
 			}
 		}
-		if(!c.export_setup.empty()&&use_temperature_bc) println("| WARNING: temperature boundaries are not carried into decomposed runs (the thermal lattice is single-domain in this build); T is dropped. |");
 		if(!c.export_setup.empty()) { // hand-over to the multi-GPU launcher (latticeurbanwind_amd/run_deck.py): everything the run loop needs, per case
 			std::filesystem::create_directories(c.export_setup);
 			const string base = c.export_setup+"/case"+to_string_u(case_index);
-			{ std::ofstream sf(base+".state", std::ios::binary); sf.write((const char*)flags.data(), (std::streamsize)N); sf.write((const char*)u.data(), (std::streamsize)(12ull*N)); }
+			{ std::ofstream sf(base+".state", std::ios::binary); sf.write((const char*)flags.data(), (std::streamsize)N); sf.write((const char*)u.data(), (std::streamsize)(12ull*N)); if(use_temperature_bc) sf.write((const char*)Tcell.data(), (std::streamsize)(4ull*N)); }
 			if(vk_on) { std::ofstream vf(base+".vk", std::ios::binary); const uint64_t hdr[2] = {vk.point_count, vk.mode_count};
 				vf.write((const char*)hdr, 16); vf.write((const char*)vk.point_cell.data(), (std::streamsize)(8ull*vk.point_count)); vf.write((const char*)vk.point_face.data(), (std::streamsize)vk.point_count);
 				vf.write((const char*)vk.point_data.data(), (std::streamsize)(28ull*vk.point_count)); vf.write((const char*)vk.mode_data.data(), (std::streamsize)(200ull*vk.mode_count)); }
@@ -1146,6 +1145,7 @@ int main(int argc, char** argv) {
 			   << " \"output\": {\"tke\": " << (c.out_tke ? 1 : 0) << ", \"ti\": " << (c.out_ti ? 1 : 0) << ", \"tls\": " << (c.out_tls ? 1 : 0) << ", \"results_vtk_dir\": " << jstr(results_vtk_dir) << ", \"raw_prefix\": " << jstr(vtk_prefix+c.datetime+"_raw_") << ", \"avg_name\": " << jstr(vtk_prefix+c.datetime+"_avg") << ",\n"
 			   << "   \"vtk_origin\": " << jstr(to_string_f(geom.origin[0])+" "+to_string_f(geom.origin[1])+" "+to_string_f(geom.origin[2])) << ", \"vtk_spacing\": " << jstr(to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)) << "},\n"
 			   << " \"vk\": {\"on\": " << (vk_on ? 1 : 0) << ", \"stride\": " << c.vk_stride << ", \"interp\": " << (c.vk_interp ? 1 : 0) << "},\n"
+			   << " \"thermal\": {\"on\": " << (use_temperature_bc ? 1 : 0) << ", \"alpha_bits\": " << fbits(lbm_alpha) << ", \"unit_K_bits\": " << fbits(units.unit_K) << ", \"unit_K_offset_bits\": " << fbits(units.unit_K_offset) << ", \"si_dT_bits\": " << fbits(units.si_dT(1.0f)) << ", \"si_T0_bits\": " << fbits(units.si_T(0.0f)) << "},\n"
 			   << " \"unit_m_bits\": " << fbits(units.unit_m) << ", \"unit_s_bits\": " << fbits(units.unit_s) << ",\n"
 			   << " \"probes\": {\"start_t\": " << (probes.empty() ? 0ull : probe_start_t) << ", \"dt_si\": \"" << [&]() { std::ostringstream o; o << std::setprecision(17) << dt_si_d; return o.str(); }() << "\", \"results_dir\": " << jstr(c.parent+"/RESULTS") << ", \"columns\": ["
 			   << [&]() { std::ostringstream o; bool first = true; for(const ProbeColumn& pc : probes) { o << (first ? "" : ", ") << "{\"stem\": " << jstr(pc.stem) << ", \"x\": " << pc.x << ", \"y\": " << pc.y << ", \"z\": ["; for(size_t i=0u; i<pc.z.size(); i++) o << (i ? ", " : "") << pc.z[i]; o << "], \"height_bits\": ["; for(size_t i=0u; i<pc.height_si.size(); i++) o << (i ? ", " : "") << fbits(pc.height_si[i]); o << "]}"; first = false; } return o.str(); }() << "]},\n"

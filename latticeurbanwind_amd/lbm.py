@@ -162,6 +162,11 @@ class LBM:
         out["count"] = cnt.value
         return out
 
+    def stats_download_T(self):
+        out = np.zeros(self.get_N(), np.float32)
+        capi.check(self._L.luw_stats_download_T(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # ---- probe columns: u at a short list of cells per step (luw_gather_*)
     def gather_attach(self, cells):
         c = np.ascontiguousarray(cells, np.uint64)
@@ -181,6 +186,8 @@ class LBM:
         capi.check(self._L.luw_enqueue_stream_collide(self._h, x0, x1, y0, y1, z0, z1, int(write_fields)))
     def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
+    def enqueue_extract_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
+    def enqueue_insert_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def increment_time_step(self, steps=1): capi.check(self._L.luw_increment_time_step(self._h, steps))
     def reset_time_step(self): capi.check(self._L.luw_reset_time_step(self._h))
     def finish(self): capi.check(self._L.luw_finish(self._h))

@@ -50,19 +50,20 @@ def vtk_header(filename, m, Nz_out):
             % (os.path.basename(filename), Nx, Ny, Nz_out, m["output"]["vtk_origin"], m["output"]["vtk_spacing"], Nx * Ny * Nz_out)).encode()
 
 
-def write_field_vtk(filename, m, soa, comps, factor):
-    """soa: (comps, Nz, Ny, Nx) float32 in lattice units -> AoS big-endian floats in SI units, first Nz_out layers"""
+def write_field_vtk(filename, m, soa, comps, factor, offset=None):
+    """soa: (comps, Nz, Ny, Nx) float32 in lattice units -> AoS big-endian floats in SI units, first Nz_out layers; with an
+    offset the value is data*factor+offset (the T field in Kelvin, FX/lbm.hpp:343), else factor*data"""
     os.makedirs(os.path.dirname(filename), exist_ok=True)
     Nz_out = m["Nz_out"]
     with open(filename, "wb") as f:
         f.write(vtk_header(filename, m, Nz_out))
         f.write(("SCALARS data float %d\nLOOKUP_TABLE default\n" % comps).encode())
         for z in range(Nz_out):      # layer by layer: bounded memory on billion-cell lattices
-            lay = (f32(factor) * np.asarray(soa[:, z])).astype(np.float32)
+            lay = (np.asarray(soa[:, z]) * f32(factor) + f32(offset)).astype(np.float32) if offset is not None else (f32(factor) * np.asarray(soa[:, z])).astype(np.float32)
             f.write(np.ascontiguousarray(np.moveaxis(lay, 0, -1)).astype(">f4").tobytes())
 
 
-def write_avg_vtk(filename, m, avg_u, avg_rho, m2, count, solid, si_u, si_rho, spacing):
+def write_avg_vtk(filename, m, avg_u, avg_rho, m2, count, solid, si_u, si_rho, spacing, avg_T=None, T_factor=1.0, T_offset=0.0):
     """avg_u (Nz,Ny,Nx,3), avg_rho / m2[k] (Nz,Ny,Nx), all lattice units, already cut to Nz_out layers"""
     os.makedirs(os.path.dirname(filename), exist_ok=True)
     Nzo, Ny, Nx = avg_rho.shape
@@ -75,6 +76,9 @@ def write_avg_vtk(filename, m, avg_u, avg_rho, m2, count, solid, si_u, si_rho, s
             f.write(((a * f32(factor)) + f32(0.0)).astype(">f4").tobytes())
         field("u_avg", avg_u, 3, uf)
         field("rho_avg", avg_rho, 1, rf)
+        if avg_T is not None:
+            f.write(b"SCALARS T_avg float 1\nLOOKUP_TABLE default\n")
+            f.write((avg_T * f32(T_factor) + f32(T_offset)).astype(">f4").tobytes())
         fluid = np.where(solid, f32(0), f32(1)).astype(np.float32)
         zero = np.zeros(avg_rho.shape, np.float32)
         tke, ti, tls = zero.copy(), zero.copy(), zero.copy()
@@ -129,11 +133,15 @@ def run_case(m, G, device, log, make_sim=None):
     kw = dict(fp16c=bool(m["fp16c"]),
               buffer_nudging=dict(n_cells=nud["n_cells"], inv_tau=float(_f(nud["inv_tau_bits"])), downstream_face=nud["downstream_face"], nudge_vertical=nud["nudge_vertical"]) if nud["active"] else None,
               top_sponge=dict(n_cells=spg["n_cells"], inv_tau=float(_f(spg["inv_tau_bits"]))) if spg["active"] else None)
+    th = m.get("thermal", {"on": 0}); thermal = bool(th["on"])
+    if thermal:
+        kw["alpha"] = float(_f(th["alpha_bits"]))
     sim = make_sim((Nx, Ny, Nz), D, nu, G.rank, kw) if make_sim else DomainDecomposedLBM((Nx, Ny, Nz), D, nu, rank=G.rank, device=device, **kw)
     lay = sim.layout
     state = np.memmap(m["state"], np.uint8, "r")
     gflags = state[:Ncells]; gu = state[Ncells:Ncells + 12 * Ncells].view(np.float32)
-    sim.set_fields_from_global(gflags, gu, None)
+    gT = state[13 * Ncells:17 * Ncells].view(np.float32) if thermal else None
+    sim.set_fields_from_global(gflags, gu, None, gT)
     om = [float(_f(b)) for b in m["omega_bits"]]
     if any(om):
         sim.backend.set_coriolis(*om)
@@ -224,19 +232,28 @@ def run_case(m, G, device, log, make_sim=None):
     if G.rank == 0:
         fn = _default_name(raw_prefix, "rho", t); write_field_vtk(fn, m, g, 1, si_rho); log("|                 | %s saved" % fn); del g; os.remove(path)
     G.barrier()
+    if thermal:      # raw_T in Kelvin, FX/setup.cpp:4771-4774
+        g, path = gather("T", 1, sim.backend.download_T(), t)
+        if G.rank == 0:
+            fn = _default_name(raw_prefix, "T", t); write_field_vtk(fn, m, g, 1, _f(th["unit_K_bits"]), _f(th["unit_K_offset_bits"])); log("|                 | %s saved" % fn); del g; os.remove(path)
+        G.barrier()
     if avg_window > 0:
         sd = sim.backend.stats_download()
         lN = lay.lN
         au = sd["avg_u"].reshape(lN[2], lN[1], lN[0], 3).transpose(3, 0, 1, 2)          # AoS -> (3,z,y,x) like a field
         parts = {}
-        for name, comps, arr in (("avg_u", 3, au), ("avg_rho", 1, sd["avg_rho"]), ("m2u", 1, sd["m2_u"]), ("m2v", 1, sd["m2_v"]), ("m2w", 1, sd["m2_w"])):
+        fields = [("avg_u", 3, au), ("avg_rho", 1, sd["avg_rho"]), ("m2u", 1, sd["m2_u"]), ("m2v", 1, sd["m2_v"]), ("m2w", 1, sd["m2_w"])]
+        if thermal:
+            fields.append(("avg_T", 1, sim.backend.stats_download_T()))
+        for name, comps, arr in fields:
             parts[name] = gather(name, comps, np.ascontiguousarray(arr), t)
         if G.rank == 0 and sd["count"] > 0:
             Nzo = m["Nz_out"]
             A = lambda k: np.asarray(parts[k][0][:, :Nzo])
             solid = (np.asarray(gflags).reshape(Nz, Ny, Nx)[:Nzo] & 1) != 0
             fn = _default_name(os.path.join(out["results_vtk_dir"], out["avg_name"]), "", t)
-            write_avg_vtk(fn, m, np.ascontiguousarray(np.moveaxis(A("avg_u"), 0, -1)), A("avg_rho")[0], [A("m2u")[0], A("m2v")[0], A("m2w")[0]], sd["count"], solid, si_u, si_rho, spacing)
+            write_avg_vtk(fn, m, np.ascontiguousarray(np.moveaxis(A("avg_u"), 0, -1)), A("avg_rho")[0], [A("m2u")[0], A("m2v")[0], A("m2w")[0]], sd["count"], solid, si_u, si_rho, spacing,
+                          A("avg_T")[0] if thermal else None, _f(th["si_dT_bits"]) if thermal else 1.0, _f(th["si_T0_bits"]) if thermal else 0.0)
             log("| VTK file        | %s saved" % fn); log("| Avg samples     | %d" % sd["count"])
         G.barrier()
         if G.rank == 0:

@@ -532,6 +532,28 @@ void luwo_transfer_insert_fi(const LuwOracleCfg* c, const uint32_t direction, co
 	}
 }
 
+/* thermal lattice: one population per face cell and side, i = side+1 (FX/kernel.cpp:2338-2363) */
+void luwo_transfer_extract_gi(const LuwOracleCfg* c, const uint32_t direction, const uint64_t t, void* buf_p, void* buf_m, const void* gi) {
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	const uint64_t A = luwo_get_area(c, direction);
+	for(uint64_t a=0; a<A; a++) for(uint32_t pm=0u; pm<2u; pm++) {
+		const uint64_t n = index_face(c, (uint32_t)a, direction, pm==0u ? Ndir(c, direction)-2u : 1u);
+		uint64_t j[19]; neighbors(c, n, j);
+		const uint32_t i = 2u*direction+pm+1u;
+		copy_ddf(c, pm==0u ? buf_p : buf_m, a, gi, (uint64_t)(t%2ull ? (i%2u ? i+1u : i-1u) : i)*N+(i%2u ? j[i] : n));
+	}
+}
+void luwo_transfer_insert_gi(const LuwOracleCfg* c, const uint32_t direction, const uint64_t t, const void* buf_p, const void* buf_m, void* gi) {
+	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
+	const uint64_t A = luwo_get_area(c, direction);
+	for(uint64_t a=0; a<A; a++) for(uint32_t pm=0u; pm<2u; pm++) {
+		const uint64_t n = index_face(c, (uint32_t)a, direction, pm==0u ? Ndir(c, direction)-1u : 0u);
+		uint64_t j[19]; neighbors(c, n, j);
+		const uint32_t i = 2u*direction+pm+1u;
+		copy_ddf(c, gi, (uint64_t)(t%2ull ? i : (i%2u ? i+1u : i-1u))*N+(i%2u ? n : j[i-1u]), pm==0u ? buf_p : buf_m, a);
+	}
+}
+
 /* vk_inlet_apply, FX/kernel.cpp:2495-2571 (u in the reference layout, plane stride N) */
 void luwo_vk_inlet_apply(const uint64_t N, const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint64_t P, const uint64_t M,
 		const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, float* u) {

@@ -58,6 +58,8 @@ def lib():
         L.luwo_get_area.argtypes = [cfgp, u32]; L.luwo_get_area.restype = u64
         L.luwo_transfer_extract_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_extract_fi.restype = None
         L.luwo_transfer_insert_fi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_insert_fi.restype = None
+        L.luwo_transfer_extract_gi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_extract_gi.restype = None
+        L.luwo_transfer_insert_gi.argtypes = [cfgp, u32, u64, vp, vp, vp]; L.luwo_transfer_insert_gi.restype = None
         L.luwo_moments.argtypes = [cfgp, vp, u64, vp, vp]; L.luwo_moments.restype = None
         L.luwo_vk_inlet_apply.argtypes = [u64, u32, C.c_float, C.c_float, C.c_float, u64, u64, vp, vp, vp, vp, vp]; L.luwo_vk_inlet_apply.restype = None
         L.luwo_accumulate_stats.argtypes = [u64, u64] + [vp] * 7; L.luwo_accumulate_stats.restype = None
@@ -161,6 +163,18 @@ class OracleLBM:
 
     def insert_fi(self, direction, bp, bm, t=None):
         lib().luwo_transfer_insert_fi(C.byref(self.cfg), direction, self.t if t is None else t, _p(bp), _p(bm), _p(self.fi))
+
+    def extract_gi(self, direction, t=None):
+        A = self.area(direction)
+        bp = np.zeros(A, self.gi.dtype); bm = np.zeros(A, self.gi.dtype)
+        lib().luwo_transfer_extract_gi(C.byref(self.cfg), direction, self.t if t is None else t, _p(bp), _p(bm), _p(self.gi))
+        return bp, bm
+
+    def insert_gi(self, direction, bp, bm, t=None):
+        lib().luwo_transfer_insert_gi(C.byref(self.cfg), direction, self.t if t is None else t, _p(bp), _p(bm), _p(self.gi))
+
+    def stream_collide_thermal(self):
+        lib().luwo_stream_collide_thermal(C.byref(self.cfg), _p(self.fi), _p(self.rho), _p(self.u), _p(self.flags), _p(self.F), _p(self.gi), _p(self.T), self.t)
 
     def moments(self):
         rho = np.zeros(self.N, np.float32); u = np.zeros(3 * self.N, np.float32)

@@ -13,6 +13,7 @@ import torch.distributed as dist
 
 def main():
     gNx, gNy, gNz, Dx, Dy, Dz, steps, fp16c, out = sys.argv[1:10]
+    thermal = len(sys.argv) > 10 and sys.argv[10] == "thermal"
     gN = (int(gNx), int(gNy), int(gNz)); D = (int(Dx), int(Dy), int(Dz)); steps = int(steps); fp16c = bool(int(fp16c))
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -21,12 +22,17 @@ def main():
     from helpers import synthetic_state
     flags, u, rho = synthetic_state(*gN, seed=21, shell=None)           # fully periodic: exercises the wrap through the halo ring
     lay = DomainLayout(gN, D, rank)
-    sim = DomainDecomposedLBM(gN, D, 0.01, rank=rank, backend=OracleDomain(lay, 0.01, fp16c=fp16c))
-    sim.set_fields_from_global(flags, u, rho)
+    sim = DomainDecomposedLBM(gN, D, 0.01, rank=rank, backend=OracleDomain(lay, 0.01, fp16c=fp16c, alpha=0.004 if thermal else None))
+    if thermal:
+        from helpers import thermal_state
+        tflags, T = thermal_state(flags, gN)
+        sim.set_fields_from_global(tflags, u, rho, T)
+    else:
+        sim.set_fields_from_global(flags, u, rho)
     sim.run(steps)
     lu, lr = sim.fields()
     ub, off = sim.interior_to_global(lu, 3)
-    rb, _ = sim.interior_to_global(lr, 1)
+    rb, _ = sim.interior_to_global(sim.backend.download_T() if thermal else lr, 1)          # thermal runs ship T in the rho slot
     gathered = [None] * dist.get_world_size()
     dist.all_gather_object(gathered, (off, ub, rb))
     if rank == 0:

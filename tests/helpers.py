@@ -54,3 +54,14 @@ def apply_state_oracle(o, flags, u, rho, F=None):
 def rmse_u(ua, ub, fluid_mask):
     d = (ua.reshape(3, -1) - ub.reshape(3, -1))[:, fluid_mask]
     return float(np.sqrt((d.astype(np.float64) ** 2).sum(0).mean()))
+
+
+def thermal_state(flags, gN, seed=5):
+    """TYPE_T presets for thermal tests: 3 % of the non-solid cells become heat sources with T in 1 +- 0.05; T = 1 elsewhere"""
+    rng = np.random.default_rng(seed)
+    f = flags.copy()
+    pick = (rng.random(f.size) < 0.03) & ((f & TYPE_S) == 0)
+    f[pick] |= TYPE_T
+    T = np.ones(f.size, np.float32)
+    T[pick] = (1.0 + 0.05 * rng.standard_normal(int(pick.sum()))).astype(np.float32)
+    return f, T

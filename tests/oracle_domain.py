@@ -7,15 +7,18 @@ from oracle import oracle
 
 
 class OracleDomain:
-    def __init__(self, layout, nu, fp16c=False):
+    def __init__(self, layout, nu, fp16c=False, alpha=None):
         self.layout = layout
-        self.o = oracle.OracleLBM(*layout.lN, nu, fp16c=fp16c, D=layout.D, O=layout.O)
+        self.thermal = alpha is not None
+        self.o = oracle.OracleLBM(*layout.lN, nu, fp16c=fp16c, D=layout.D, O=layout.O, alpha=alpha)
         self.np_dtype = np.uint16 if fp16c else np.float32
         self.t_dtype = torch.float16 if fp16c else torch.float32   # FP16C codes ride as float16 bit patterns (NCCL has no int16)
         self.buf = {a: [torch.zeros(5 * self.o.area(a), dtype=self.t_dtype) for _ in range(4)] for a in layout.split_axes()}
+        self.gbuf = {a: [torch.zeros(self.o.area(a), dtype=self.t_dtype) for _ in range(4)] for a in layout.split_axes()} if self.thermal else {}
 
-    def set_fields(self, flags, u, rho):
+    def set_fields(self, flags, u, rho, T=None):
         self.o.flags[:] = flags; self.o.u[:] = u; self.o.rho[:] = rho
+        if T is not None: self.o.T[:] = T
 
     def initialize(self): self.o.initialize()
     def get_t(self): return self.o.t
@@ -24,7 +27,8 @@ class OracleDomain:
 
     def stream_collide(self, box, write_fields, stream):
         assert tuple(box) == tuple(self.layout.whole_box())      # the test double always does the whole domain at once
-        self.o.stream_collide()
+        if self.thermal: self.o.stream_collide_thermal()
+        else: self.o.stream_collide()
 
     def extract(self, axis, stream):
         bp, bm = self.o.extract_fi(axis)
@@ -37,5 +41,20 @@ class OracleDomain:
     def insert(self, axis, stream):
         rp = self.buf[axis][2].numpy().view(self.np_dtype); rm = self.buf[axis][3].numpy().view(self.np_dtype)
         self.o.insert_fi(axis, np.ascontiguousarray(rp), np.ascontiguousarray(rm))
+
+    def _view(self, a): return a.view(np.float16) if self.np_dtype == np.uint16 else a
+
+    def extract_g(self, axis, stream):
+        bp, bm = self.o.extract_gi(axis)
+        self.gbuf[axis][0].copy_(torch.from_numpy(self._view(bp))); self.gbuf[axis][1].copy_(torch.from_numpy(self._view(bm)))
+        return self.gbuf[axis][0], self.gbuf[axis][1]
+
+    def recv_buffers_g(self, axis): return self.gbuf[axis][2], self.gbuf[axis][3]
+
+    def insert_g(self, axis, stream):
+        rp = self.gbuf[axis][2].numpy().view(self.np_dtype); rm = self.gbuf[axis][3].numpy().view(self.np_dtype)
+        self.o.insert_gi(axis, np.ascontiguousarray(rp), np.ascontiguousarray(rm))
+
+    def download_T(self): return self.o.T
 
     def download(self): return self.o.u, self.o.rho

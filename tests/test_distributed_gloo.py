@@ -38,6 +38,26 @@ def test_gloo_multi_domain_equals_single_domain(tmp_path, gN, D, fp16c):
     assert np.array_equal(got["u"], u_ref) and np.array_equal(got["rho"], rho_ref)
 
 
+def test_gloo_multi_domain_thermal_lattice(tmp_path):
+    """the thermal D3Q7 lattice across domains: its one-population halo swap (communicate_gi) keeps T identical to the
+    single-domain run"""
+    from helpers import thermal_state
+    gN, D, steps = (12, 12, 8), (2, 2, 1), 6
+    out = str(tmp_path / "result.npz")
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), *map(str, gN), *map(str, D), str(steps), "0", out, "thermal"]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    flags, u, rho = synthetic_state(*gN, seed=21, shell=None)
+    tflags, T = thermal_state(flags, gN)
+    o = oracle.OracleLBM(*gN, 0.01, alpha=0.004)
+    o.flags[:] = tflags; o.u[:] = u; o.rho[:] = rho; o.T[:] = T
+    o.run(steps)
+    assert np.array_equal(got["u"], o.u) and np.array_equal(got["rho"], o.T) and o.T.std() > 1e-4   # the worker ships T in the rho slot
+
+
 def test_layout_matches_reference_rules():
     from latticeurbanwind_amd.distributed import DomainLayout, choose_decomposition, tile_lattice
     assert choose_decomposition(8, split_x=True) == (4, 2, 1) and choose_decomposition(2, split_x=True) == (2, 1, 1) and choose_decomposition(1) == (1, 1, 1)

@@ -32,6 +32,33 @@ def test_local_group_equals_single_domain(luw, gN, D, overlap, fp16c):
         s.backend.lbm.close()
 
 
+@pytest.mark.parametrize("D,overlap,fp16c", [((2, 1, 1), False, False), ((1, 2, 2), True, False), ((2, 2, 2), True, True)])
+def test_local_group_thermal_lattice(luw, D, overlap, fp16c):
+    """thermal D3Q7 lattice across domains on the GPU (pack / unpack of the single gi population per face cell): T and u of
+    2-8 HIP domains equal the single-domain oracle"""
+    from latticeurbanwind_amd.distributed import LocalGroup, HipDomain
+    from oracle import oracle
+    from helpers import thermal_state
+    gN = (24, 20, 16)
+    flags, u, rho = synthetic_state(*gN, seed=31, shell=None)
+    tflags, T = thermal_state(flags, gN)
+    grp = LocalGroup(gN, D, 0.01, lambda lay: HipDomain(lay, 0.01, fp16c=fp16c, alpha=0.004), overlap=overlap)
+    for s in grp.sims:
+        s.set_fields_from_global(tflags, u, rho, T)
+    grp.run(6)
+    gu, _ = grp.gather_u_rho()
+    gT = np.zeros((1, gN[2], gN[1], gN[0]), np.float32)
+    for s in grp.sims:
+        tb, off = s.interior_to_global(s.backend.download_T(), 1)
+        gT[:, off[2]:off[2] + tb.shape[1], off[1]:off[1] + tb.shape[2], off[0]:off[0] + tb.shape[3]] = tb
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c, alpha=0.004)
+    o.flags[:] = tflags; o.u[:] = u; o.rho[:] = rho; o.T[:] = T
+    o.run(6)
+    assert np.array_equal(gu, o.u) and np.array_equal(gT.ravel(), o.T)
+    for s in grp.sims:
+        s.backend.lbm.close()
+
+
 def test_box_launches_tile_the_domain(luw):
     # any partition of the lattice into boxes gives the same result as one whole-domain launch (both kernels)
     from latticeurbanwind_amd import capi

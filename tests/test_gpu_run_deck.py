@@ -32,7 +32,7 @@ def _files(proj):
     return {os.path.basename(p): p for p in glob.glob(os.path.join(proj, "RESULTS", "vtk", "*.vtk"))}
 
 
-@pytest.mark.parametrize("case,n_gpu", [("CaseA", (1, 1, 1)), ("CaseV", (1, 1, 1)), ("CaseA", (2, 1, 1)), ("CaseV", (1, 2, 2)), ("CaseN1", (1, 2, 1)), ("CaseP", (2, 2, 1))])
+@pytest.mark.parametrize("case,n_gpu", [("CaseA", (1, 1, 1)), ("CaseV", (1, 1, 1)), ("CaseA", (2, 1, 1)), ("CaseV", (1, 2, 2)), ("CaseN1", (1, 2, 1)), ("CaseP", (2, 2, 1)), ("CaseT1", (1, 1, 1)), ("CaseT1", (2, 2, 1)), ("CaseT3", (1, 2, 2))])
 def test_run_deck_writes_the_drivers_files(luw, tmp_path, case, n_gpu):
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
     ref_proj, ref_deck = _case(tmp_path, case, (1, 1, 1), "_ref")
