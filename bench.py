@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
     ap.add_argument("--buildings", action="store_true", help="BASELINE configs[2] solid mask (box array); use with --size 1024 1024 256")
+    ap.add_argument("--thermal", action="store_true", help="also run the thermal D3Q7 lattice (the shipped reference build always does): +7 DDF planes and T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
@@ -133,7 +134,7 @@ def main():
     nu = 1.48e-7                                     # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
 
     if world == 1 and not args.force_distributed:
-        lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields)
+        lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields, alpha=(2.1e-7 if args.thermal else None))
         fl, u, rho = channel_state(Nx, Ny, Nz, buildings=args.buildings)
         lbm.flags.data[:] = fl; lbm.u.data[:] = u; lbm.rho.data[:] = rho
         lbm.run(0)
@@ -175,7 +176,7 @@ def main():
 
     if rank == 0:
         mlups = cells * args.steps / dt / 1e6
-        bpl = BYTES_PER_LUP[args.dtype] + (16.0 if args.every_step_fields else 0.0)
+        bpl = BYTES_PER_LUP[args.dtype] + (16.0 if args.every_step_fields else 0.0) + ((7 * 2 * (2 if fp16c else 4) + 4) if args.thermal else 0.0)   # + gi read/write + T write
         per_gpu_cells = Nx * Ny * Nz
         if D != (1, 1, 1) and sim.overlap:      # the timed launch is the interior box; the shell runs beside it on the other stream
             b = sim.layout.interior_box(); per_gpu_cells = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4])
