@@ -11,6 +11,7 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   B  nudging + sponge OFF                                      (Nz = 24)
   L  "laminar" micro-domain (cell 1e-5 m -> nu_lbm ~ 0.03), nudging + sponge OFF, uniform inflow
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
+  DG dataset mode (*.luwdg), inflow = [3, 5.5] x angle = [0, 225]: four runs with DG_<inflow>_<angle>_ prefixes
   D  case B on a base slab at z = 0..4 m with proj_temp/interpolated_dem.csv (terrain hill): DEM ground plane, terrain clip,
      profile above local terrain, flux correction in profile mode
   T1..T3  N1 / N2 / N3-like decks with a T column in the CSV (temperature boundaries + thermal lattice + T outputs)
@@ -126,6 +127,19 @@ def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64,
     with open(os.path.join(d, "conf.luwpf"), "w") as f:
         f.write("\n".join(deck) + "\n")
 
+def write_dataset_case(root, name):
+    d = os.path.join(root, name)
+    os.makedirs(os.path.join(d, "proj_temp"), exist_ok=True)
+    tris = box_tris(0, 96.0, 0, 80.0, -4.0, 0.0) + box_tris(30.3, 46.7, 28.6, 51.4, 0.0, 19.3)
+    write_stl(os.path.join(d, "proj_temp", name + "_DG.stl"), tris)
+    deck = ["// LUW dataset-generation deck (synthetic)", "casename = %s" % name, "datetime = 20260101120000",
+            "si_x_cfd = [0.000000, 96]", "si_y_cfd = [0.000000, 80]", "si_z_cfd = [0.000000, 48]", "base_height = 4", "n_gpu = [1, 1, 1]",
+            'mesh_control = "cell_size"', "cell_size = 2", "high_order = true", "flux_correction = false", "coriolis_term = false", "turb_inflow_enable = false",
+            "enable_buffer_nudging = true", "buffer_thickness_m = 8", "buffer_tau_s = 3", "enable_top_sponge = false",
+            "run_nstep = 16", "unsteady_output = 8", "purge_avg = 4", "inflow = [3, 5.5]", "angle = [0, 225]"]
+    with open(os.path.join(d, "conf.luwdg"), "w") as f:
+        f.write("\n".join(deck) + "\n")
+
 def wind(x, y, z):
     """smooth synthetic NWP-like field (SI): veering log-ish profile with horizontal variation and a weak vertical component"""
     import math
@@ -214,6 +228,8 @@ if __name__ == "__main__":
     # G, H: voxeliser cases ("city" geometry) at cell 2 m (mesh scale 0.5, exact) and cell 2.5 m (scale 0.4, inexact)
     write_case(root, "CaseG", 1.0, off, building="city", nstep=16)
     write_case(root, "CaseH", 1.0, off, building="city", nstep=16, cell=2.5)
+    # DG: dataset mode (*.luwdg): uniform inflow for every (inflow, angle) pair, DG_<u>_<angle>_ output prefixes
+    write_dataset_case(root, "CaseDG")
     # D: profile mode with a DEM ground plane (interpolated_dem.csv), STL base slab on z = 0..4 as luwvox writes it
     write_case(root, "CaseD", 1.0, off + ["flux_correction = true"], nstep=16, z0=4.0, dem=True)
     # P: probes (centre, grid-cell and metre offsets, lon:lat) sampled over the last 6 steps

@@ -161,3 +161,32 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     want = re.search(r"solid = (\d+), fluid = (\d+)", open(os.path.join(GOLD, fixture + ".console.txt")).read())
     got = re.search(r"solid = (\d+), fluid = (\d+)", r.stdout)
     assert got and got.groups() == want.groups()
+
+
+@pytest.mark.parametrize("ddf,build", [("fp32", "fp32"), ("fp16c", "shipped")])
+def test_dataset_mode_files_vs_real_reference_files(luw, tmp_path, ddf, build):
+    """*.luwdg: one run per (inflow, angle) pair with DG_<inflow>_<angle>_ prefixes, per-case unit system (si_ref_u = the case's
+    inflow), uniform inflow on TYPE_E faces, nudging towards it: every file set against the real reference's"""
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
+    proj = str(tmp_path / "CaseDG")
+    shutil.copytree(os.path.join(GOLD, "refcases", "CaseDG"), proj)
+    r = subprocess.run([DRIVER, os.path.join(proj, "conf.luwdg"), "--ddf", ddf], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    vt = os.path.join(proj, "RESULTS", "vtk")
+    fp16c = ddf == "fp16c"
+    for pre, inflow in (("DG_3_0", 3.0), ("DG_3_225", 3.0), ("DG_5.5_0", 5.5), ("DG_5.5_225", 5.5)):
+        gold = np.load(os.path.join(GOLD, "ref_%s_CaseDG_%s.npz" % (build, pre)))
+        fac = np.float32(inflow) / np.float32(0.1)
+        h, f = read_vtk(glob.glob(os.path.join(vt, pre + "_*_avg-000000016.vtk"))[0])
+        solid = f["fluid"][..., 0] == 0
+        assert tuple(gold["dims"]) == h["dims"] and np.array_equal(solid, gold["solid"])
+        fluid = ~solid
+        side = np.zeros(solid.shape, bool); side[:, 0, :] = side[:, -1, :] = side[:, :, 0] = side[:, :, -1] = True
+        for t, gate in ((8, 5e-6 if fp16c else 2e-7), (16, 1e-4 if fp16c else 1e-6)):
+            hh, ff = read_vtk(glob.glob(os.path.join(vt, pre + "_*_raw_u-%09d.vtk" % t))[0])
+            if t == 8:
+                assert np.array_equal(ff["data"][side & fluid], gold["u8"][side & fluid])
+            d = ((ff["data"] - gold["u%d" % t]) / fac)[fluid].astype(np.float64)
+            assert float(np.sqrt((d ** 2).sum(-1).mean())) < gate, (pre, t)
+        d = ((f["u_avg"] - gold["u_avg"]) / fac)[fluid].astype(np.float64)
+        assert float(np.sqrt((d ** 2).sum(-1).mean())) < (1e-4 if fp16c else 1e-6)
