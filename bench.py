@@ -59,6 +59,30 @@ def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None,
     return flags.ravel(), u.ravel(), rho.ravel()
 
 
+def reference_parity():
+    """u-field RMSE against the REAL reference, measured now: the deck driver runs the committed synthetic case B (48x40x24, one
+    building, LES, 64 steps, FP32 DDFs) on this GPU and its final velocity file is compared with the file the reference solver
+    (FluidX3D, FP32 build, run on an MI355X through OpenCL) wrote for the same deck (tests/golden/ref_fp32_CaseB.npz)."""
+    import glob, shutil, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from vtkio import read_vtk
+    drv = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ref_fp32_CaseB.npz"))
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copytree(os.path.join(ROOT, "tests", "golden", "refcases", "CaseB"), os.path.join(tmp, "CaseB"))
+        r = subprocess.run([drv, os.path.join(tmp, "CaseB", "conf.luwpf"), "--ddf", "fp32"], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "driver exit %d" % r.returncode}
+        h, f = read_vtk(glob.glob(os.path.join(tmp, "CaseB", "RESULTS", "vtk", "*_raw_u-000000064.vtk"))[0])
+        fac = np.float32(5.0) / np.float32(0.1)                      # si_ref_u = max profile U = 5 m/s, u_lbm = 0.1
+        d = ((f["data"] - gold["u64"]) / fac)[~gold["solid"]].astype(np.float64)
+        return {"u_rmse_vs_reference": float(np.sqrt((d ** 2).sum(-1).mean())), "unit": "lattice units", "steps": 64, "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)",
+                "tolerance": 1e-5}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def usable_cores():
     """cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
     whole host inside containers)"""
@@ -207,6 +231,10 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
         if world == 1 and not args.no_cpu_baseline and not args.force_distributed:
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["parity"] = reference_parity()
+            except Exception as e:      # never let the side measurement break the benchmark line
+                out["parity"] = {"error": str(e)[:200]}
         print(json.dumps(out))
     if world > 1 or args.force_distributed:
         import torch.distributed as dist
