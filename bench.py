@@ -83,6 +83,13 @@ def reference_parity():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def coriolis_omega():
+    """Omega_earth (0, cos phi, sin phi) dt in lattice units at 31.25 deg N for cell = 2 m, U_ref = 10 m/s, u_lbm = 0.1 (FX/setup.cpp:3800-3823)"""
+    import math
+    dt = 2.0 * 0.1 / 10.0
+    return 0.0, 7.292115e-5 * math.cos(math.radians(31.25)) * dt, 7.292115e-5 * math.sin(math.radians(31.25)) * dt
+
+
 def usable_cores():
     """cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
     whole host inside containers)"""
@@ -136,6 +143,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
     ap.add_argument("--buildings", action="store_true", help="BASELINE configs[2] solid mask (box array); use with --size 1024 1024 256")
+    ap.add_argument("--coriolis", action="store_true", help="Coriolis body force at 31.25 deg N (BASELINE configs[4]): every cell takes the forced path")
     ap.add_argument("--thermal", action="store_true", help="also run the thermal D3Q7 lattice (the shipped reference build always does): +7 DDF planes and T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
@@ -161,6 +169,8 @@ def main():
         lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields, alpha=(2.1e-7 if args.thermal else None))
         fl, u, rho = channel_state(Nx, Ny, Nz, buildings=args.buildings)
         lbm.flags.data[:] = fl; lbm.u.data[:] = u; lbm.rho.data[:] = rho
+        if args.coriolis:
+            lbm.set_coriolis(*coriolis_omega())
         lbm.run(0)
         lbm.run(args.warmup)
         torch.cuda.synchronize()
@@ -186,6 +196,8 @@ def main():
         ox, oy, oz = sim.global_offset
         fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN, buildings=args.buildings)
         sim.set_fields(fl, u, rho)
+        if args.coriolis:
+            sim.backend.set_coriolis(*coriolis_omega())
         sim.initialize()
         sim.run(args.warmup)
         dist.barrier(); torch.cuda.synchronize()
@@ -213,7 +225,7 @@ def main():
             "config": {"workload": "%s, log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky, %s DDFs, rho/u written %s"
                        % (("%dx%dx%d D3Q19 channel%s" % (Nx, Ny, Nz, " with the configs[2] building array (solid fraction %.3f)" % float((fl == 1).mean()) if args.buildings else " (BASELINE configs[1])")) if world == 1 else
                           ("%dx%dx%d D3Q19 channel tile (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU" % (Nx * D[0], Ny * D[1], Nz * D[2], Nx, Ny, Nz)),
-                          "FP16C" if fp16c else "FP32", "every step" if args.every_step_fields else "by the last step only"),
+                          ("FP16C" if fp16c else "FP32") + (" + Coriolis force" if args.coriolis else "") + (" + thermal D3Q7 lattice" if args.thermal else ""), "every step" if args.every_step_fields else "by the last step only"),
                        "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "halo_exchange": (None if D == (1, 1, 1) else ("RCCL p2p, overlapped with the interior (x rows kept whole)" if sim.overlap else "RCCL p2p after the whole-box kernel (x split)")), "kernel": args.kernel,
                        "bytes_per_lup": bpl},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
