@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--coriolis", action="store_true", help="Coriolis body force at 31.25 deg N (BASELINE configs[4]): every cell takes the forced path")
     ap.add_argument("--thermal", action="store_true", help="also run the thermal D3Q7 lattice (the shipped reference build always does): +7 DDF planes and T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
     args = ap.parse_args()
@@ -158,6 +159,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    if args.share_device is not None:
+        local_rank = args.share_device
     torch.cuda.set_device(local_rank)
     luw.load()
     Nx, Ny, Nz = args.size or (512, 512, 512)
@@ -183,7 +186,8 @@ def main():
     else:
         import torch.distributed as dist
         from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_device is not None: dist.init_process_group("gloo")
+        else: dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
         if D[0] * D[1] * D[2] != world:
             raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
@@ -205,7 +209,7 @@ def main():
         kernel_ms = sim.run(args.steps, timed=True)
         torch.cuda.synchronize(); dist.barrier()
         dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_device is not None else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         cells = Nx * Ny * Nz * world
