@@ -13,7 +13,7 @@ import pytest
 
 from vtkio import read_vtk
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 DRIVER = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
@@ -32,6 +32,15 @@ def _files(proj):
     return {os.path.basename(p): p for p in glob.glob(os.path.join(proj, "RESULTS", "vtk", "*.vtk"))}
 
 
+def test_runtime_decomposition_keeps_x_whole():
+    from latticeurbanwind_amd.run_deck import runtime_decomposition as rd
+    assert rd((751, 742, 174), (2, 1, 1)) == (1, 2, 1)                     # the reference's example deck
+    assert rd((2048, 1024, 512), (4, 2, 1)) == (1, 4, 2)
+    assert rd((48, 40, 24), (2, 2, 1)) == (1, 4, 1) and rd((48, 41, 23), (2, 1, 1)) == (2, 1, 1)   # least halo area; nothing divides: the deck's grid stays
+    assert rd((100, 7, 64), (2, 1, 1)) == (1, 1, 2)
+
+
+@gpu
 @pytest.mark.parametrize("case,n_gpu", [("CaseA", (1, 1, 1)), ("CaseV", (1, 1, 1)), ("CaseA", (2, 1, 1)), ("CaseV", (1, 2, 2)), ("CaseN1", (1, 2, 1)), ("CaseP", (2, 2, 1)), ("CaseT1", (1, 1, 1)), ("CaseT1", (2, 2, 1)), ("CaseT3", (1, 2, 2))])
 def test_run_deck_writes_the_drivers_files(luw, tmp_path, case, n_gpu):
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
@@ -45,7 +54,7 @@ def test_run_deck_writes_the_drivers_files(luw, tmp_path, case, n_gpu):
         cmd = [sys.executable, "-m", "latticeurbanwind_amd.run_deck", deck, "--ddf", "fp32"]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", "29533",
-               "-m", "latticeurbanwind_amd.run_deck", deck, "--ddf", "fp32", "--share-device", "0"]
+               "-m", "latticeurbanwind_amd.run_deck", deck, "--ddf", "fp32", "--share-device", "0"] + (["--literal-n-gpu"] if case in ("CaseA", "CaseP") else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     want, got = _files(ref_proj), _files(proj)
