@@ -18,6 +18,10 @@ CANDS = [  # (label, D, per-GPU size, overlap)
     ("[1,4,2] 512^3 overlap", (1, 4, 2), (512, 512, 512), True),
     ("[1,2,4] 2048x512x128 overlap", (1, 2, 4), (2048, 512, 128), True),
     ("[1,2,4] 2048x512x128 sequential", (1, 2, 4), (2048, 512, 128), False),
+    ("[1,4,2] 2048x256x256 overlap", (1, 4, 2), (2048, 256, 256), True),
+    ("[1,2,2] 1024x512x256 overlap", (1, 2, 2), (1024, 512, 256), True),
+    ("[1,4,1] 1024x256x512 overlap", (1, 4, 1), (1024, 256, 512), True),
+    ("[1,2,1] 1024x256x512 overlap", (1, 2, 1), (1024, 256, 512), True),
 ]
 if len(sys.argv) > 1:
     CANDS = [c for c in CANDS if any(k in c[0] for k in sys.argv[1:])]
