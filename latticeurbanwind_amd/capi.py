@@ -23,6 +23,7 @@ KERNEL_AUTO, KERNEL_SCALAR, KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERN
 KERNEL_SCALAR_GENERAL = 8
 KERNEL_EXP_COPY, KERNEL_EXP_NOSHIFT = 100, 101   # measurement-only variants, never used by the product path
 TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
+OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4
 
 SYMBOLS = [
     "luw_abi_version", "luw_last_error", "luw_device_count", "luw_create", "luw_destroy", "luw_host_ptr",
