@@ -11,6 +11,7 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   B  nudging + sponge OFF                                      (Nz = 24)
   L  "laminar" micro-domain (cell 1e-5 m -> nu_lbm ~ 0.03), nudging + sponge OFF, uniform inflow
   V  case B + von-Karman synthetic-turbulence inlet (turb_inflow_enable = true, L = 20 m, 64 modes)
+  M  case A-like profile deck with angle = [200, 45.5, 315]: three runs with ANG_<angle>_ prefixes
   DG dataset mode (*.luwdg), inflow = [3, 5.5] x angle = [0, 225]: four runs with DG_<inflow>_<angle>_ prefixes
   D  case B on a base slab at z = 0..4 m with proj_temp/interpolated_dem.csv (terrain hill): DEM ground plane, terrain clip,
      profile above local terrain, flux correction in profile mode
@@ -80,7 +81,7 @@ def city_tris(s):
     t += box_tris(74.1*s, 86.3*s, 64.8*s, 75.6*s, 0.0, 15.2*s)
     return t
 
-def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0, z0=0.0, dem=False):
+def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0, z0=0.0, dem=False, angles="[270]"):
     """s = length scale (metres per 'unit'); the box geometry is dims units (default 96 x 80 x 48), base slab 4 units."""
     d = os.path.join(root, name)
     os.makedirs(os.path.join(d, "proj_temp"), exist_ok=True)
@@ -122,7 +123,7 @@ def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64,
         "turb_inflow_enable = %s" % ("true" if vk else "false"),
         "run_nstep = %d" % nstep,
     ] + (["unsteady_output = %d" % unsteady] if unsteady else []) + (["purge_avg = %d" % purge] if purge else []) + [
-        "angle = [270]",
+        "angle = %s" % angles,
     ] + extra
     with open(os.path.join(d, "conf.luwpf"), "w") as f:
         f.write("\n".join(deck) + "\n")
@@ -228,6 +229,8 @@ if __name__ == "__main__":
     # G, H: voxeliser cases ("city" geometry) at cell 2 m (mesh scale 0.5, exact) and cell 2.5 m (scale 0.4, inexact)
     write_case(root, "CaseG", 1.0, off, building="city", nstep=16)
     write_case(root, "CaseH", 1.0, off, building="city", nstep=16, cell=2.5)
+    # M: profile mode with several oblique angles (ANG_<angle>_ prefixes, downstream face by dominant axis, nudging on)
+    write_case(root, "CaseM", 1.0, ["enable_buffer_nudging = true", "buffer_thickness_m = 8", "buffer_tau_s = 3", "enable_top_sponge = false"], nstep=16, angles="[200, 45.5, 315]")
     # DG: dataset mode (*.luwdg): uniform inflow for every (inflow, angle) pair, DG_<u>_<angle>_ output prefixes
     write_dataset_case(root, "CaseDG")
     # D: profile mode with a DEM ground plane (interpolated_dem.csv), STL base slab on z = 0..4 as luwvox writes it

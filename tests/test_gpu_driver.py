@@ -164,18 +164,22 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
 
 
 @pytest.mark.parametrize("ddf,build", [("fp32", "fp32"), ("fp16c", "shipped")])
-def test_dataset_mode_files_vs_real_reference_files(luw, tmp_path, ddf, build):
-    """*.luwdg: one run per (inflow, angle) pair with DG_<inflow>_<angle>_ prefixes, per-case unit system (si_ref_u = the case's
-    inflow), uniform inflow on TYPE_E faces, nudging towards it: every file set against the real reference's"""
+@pytest.mark.parametrize("case,deck,runs", [("CaseDG", "conf.luwdg", (("DG_3_0", 3.0), ("DG_3_225", 3.0), ("DG_5.5_0", 5.5), ("DG_5.5_225", 5.5))),
+                                            ("CaseM", "conf.luwpf", (("ANG_200", 5.0), ("ANG_45.5", 5.0), ("ANG_315", 5.0)))])
+def test_multi_run_decks_vs_real_reference_files(luw, tmp_path, ddf, build, case, deck, runs):
+    """decks that fan out into several runs.  *.luwdg: one run per (inflow, angle) pair with DG_<inflow>_<angle>_ prefixes and a
+    per-case unit system (si_ref_u = the case's inflow), uniform inflow on TYPE_E faces, nudging towards it.  *.luwpf with an
+    angle list: ANG_<angle>_ prefixes, oblique wind directions, downstream face by dominant axis.  Every file set against the
+    real reference's (runs = (prefix, si_ref_u))."""
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
-    proj = str(tmp_path / "CaseDG")
-    shutil.copytree(os.path.join(GOLD, "refcases", "CaseDG"), proj)
-    r = subprocess.run([DRIVER, os.path.join(proj, "conf.luwdg"), "--ddf", ddf], capture_output=True, text=True, timeout=600)
+    proj = str(tmp_path / case)
+    shutil.copytree(os.path.join(GOLD, "refcases", case), proj)
+    r = subprocess.run([DRIVER, os.path.join(proj, deck), "--ddf", ddf], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     vt = os.path.join(proj, "RESULTS", "vtk")
     fp16c = ddf == "fp16c"
-    for pre, inflow in (("DG_3_0", 3.0), ("DG_3_225", 3.0), ("DG_5.5_0", 5.5), ("DG_5.5_225", 5.5)):
-        gold = np.load(os.path.join(GOLD, "ref_%s_CaseDG_%s.npz" % (build, pre)))
+    for pre, inflow in runs:
+        gold = np.load(os.path.join(GOLD, "ref_%s_%s_%s.npz" % (build, case, pre)))
         fac = np.float32(inflow) / np.float32(0.1)
         h, f = read_vtk(glob.glob(os.path.join(vt, pre + "_*_avg-000000016.vtk"))[0])
         solid = f["fluid"][..., 0] == 0
