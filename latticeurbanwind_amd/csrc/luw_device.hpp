@@ -66,30 +66,45 @@ __device__ __forceinline__ uint32_t float_to_half_custom_ref(const float x) { //
 // Decode: the 15 exponent+mantissa bits placed at float bits 12..26 form a tiny float 2^(e-127)(1+m/2048) (or, for
 // e = 0, the float DENORMAL m 2^-137); one exact multiplication by 2^112 turns both into the FP16C value
 // 2^(e-15)(1+m/2048) resp. m 2^-25 -- the same numbers the reference builds with its integer formula
-// (FX/kernel.cpp:864-869).  Needs FP32 denormals enabled (hipcc default).  5 instructions, no branches: DDF values
-// are small deviations from equilibrium, so FP16C denormals (|f| < 6.1e-5) are common and branching on them costs
-// more than it saves (measured).
-__device__ __forceinline__ float half_to_float_custom(const uint32_t x) {
-	return __uint_as_float(((x<<16)&0x80000000u)|((x<<12)&0x07FFF000u))*0x1p+112f;
+// (FX/kernel.cpp:864-869).  Needs FP32 denormals enabled (hipcc default).  No branches: DDF values are small deviations
+// from equilibrium, so FP16C denormals (|f| < 6.1e-5) are common and branching on them costs more than it saves
+// (measured).  The code arrives SIGN-EXTENDED (global_load_sshort does that for free), so bit 31 already holds the sign
+// after the shift and one mask clears the copies of it that landed in the high exponent bits: shift, and, multiply.
+__device__ __forceinline__ float half_to_float_custom_sx(const int32_t xs) {
+	return __uint_as_float(((uint32_t)xs<<12)&0x87FFF000u)*0x1p+112f;
 }
-// Encode: the reference formula (FX/kernel.cpp:870-875) rounds |x| half away from zero onto the FP16C grid.  Above 2^-14
-// that is its integer expression: add 0x800, drop 12 mantissa bits, rebias the exponent (the carry runs into the exponent
-// field by itself).  Below, the code is the integer m = round_half_up(|x| 2^25): |x| 2^26 is a pure exponent shift (exact),
-// the conversion truncates, and (floor(2v)+1)>>1 = floor(v+1/2).  Equal to the literal formula for all 2^32 inputs (checked
-// exhaustively on the host and on the device, luw_selfcheck_fp16c_codec), including the carry cases next to 2^-14, the sign
-// of NaN payloads that carry into bit 31, and out-of-range exponents (4-bit wrap).
-__device__ __forceinline__ uint32_t float_to_half_custom(const float x) {
-	const uint32_t b = __float_as_uint(x)+0x00000800u;
-	const uint32_t rn = (b>>12)-(112u<<11);
-	const uint32_t rd = ((uint32_t)(fabsf(x)*0x1p+26f)+1u)>>1;
-	return ((b>>16)&0x8000u)|((!(fabsf(x)<0x1p-14f) ? rn : rd)&0x7FFFu);
+__device__ __forceinline__ float half_to_float_custom(const uint32_t x) { return half_to_float_custom_sx((int32_t)(int16_t)(uint16_t)x); }
+// Encode: the reference formula (FX/kernel.cpp:870-875) rounds |x| half away from zero onto the FP16C grid.  With
+// v = |x| 2^25 (an exact exponent shift):
+//   rn = (bits(v) + 0x800 - (137<<23)) >> 12 (arithmetic) is the reference's normal-range code (add 0x800, drop 12 mantissa
+//        bits, rebias by 112; the carry runs into the exponent field by itself); it is negative below 2^-15;
+//   rd = floor(v + 1/2) is its denormal-range code, the integer m = round_half_up(|x| 2^25) (V_CVT_RPI_I32_F32 rounds
+//        exactly that way, without an intermediate float sum).
+// rd grows linearly and rn logarithmically with |x|, and they coincide on the first normal binade [2^-14, 2^-13), where
+// the FP16C grid spacing equals the denormal spacing.  So rn <= rd everywhere, both are >= 2048 from 2^-14 up and rd <= 2048
+// below: the median of (rn, rd, 2048) is rn for normal and rd for denormal magnitudes -- no compare/select.
+// The result is left in the HIGH half of the register (sign already in place at bit 31, low half unspecified) for
+// global_store_short_d16_hi; float_to_half_custom() shifts it down for callers that want the code as a number.
+// Equal to the literal formula for every float with |x| < 2^103 including denormals, the carry cases next to 2^-14 and
+// the 4-bit exponent wrap from |x| >= 2 (checked exhaustively on the device, luw_selfcheck_fp16c_codec); beyond that (v
+// overflows; NaN) the codes differ -- a lattice holding such values has long since blown up.
+__device__ __forceinline__ uint32_t float_to_half_custom_hi(const float x) {
+	const float v = fabsf(x)*0x1p+25f;
+	int32_t rd, mag;
+	asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(rd) : "v"(v));
+	const int32_t rn = (int32_t)(__float_as_uint(v)+(0x00000800u-(137u<<23)))>>12;
+	asm("v_med3_i32 %0, %1, %2, %3" : "=v"(mag) : "v"(rn), "v"(rd), "s"(2048));
+	uint32_t code;   // bits 0..30 from mag<<16, bit 31 from x (spelled out because the compiler expands the or-of-ands to three instructions)
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(code) : "s"(0x7FFFFFFF), "v"((uint32_t)mag<<16), "v"(x));
+	return code;
 }
+__device__ __forceinline__ uint32_t float_to_half_custom(const float x) { return float_to_half_custom_hi(x)>>16; }
 template<typename T> __device__ __forceinline__ float ddf_decode(const T v);
 template<> __device__ __forceinline__ float ddf_decode<float>(const float v) { return v; }
-template<> __device__ __forceinline__ float ddf_decode<uint16_t>(const uint16_t v) { return half_to_float_custom((uint32_t)v); }
+template<> __device__ __forceinline__ float ddf_decode<uint16_t>(const uint16_t v) { return half_to_float_custom_sx((int32_t)(int16_t)v); }
 template<typename T> __device__ __forceinline__ T ddf_encode(const float v);
 template<> __device__ __forceinline__ float ddf_encode<float>(const float v) { return v; }
-template<> __device__ __forceinline__ uint16_t ddf_encode<uint16_t>(const float v) { return (uint16_t)float_to_half_custom(v); }
+template<> __device__ __forceinline__ uint16_t ddf_encode<uint16_t>(const float v) { return (uint16_t)(float_to_half_custom_hi(v)>>16); }
 
 __device__ __forceinline__ float sq(const float x) { return x*x; }
 __device__ __forceinline__ float clampf(const float x, const float a, const float b) { return fminf(fmaxf(x, a), b); }
