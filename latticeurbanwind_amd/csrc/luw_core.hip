@@ -136,7 +136,13 @@ template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
 // measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
 // NT: 0 default cache policy, 1 non-temporal everywhere, 2 non-temporal on the 14 aligned planes and default policy on
 // the five x+1 planes, whose wave-edge lines are shared between neighbouring waves (product setting, measured best).
-template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// Waves per SIMD: the FP32 kernel is HBM-bound and measurably better with at most 4 resident waves (3.40 vs 3.43 ms at 512^3,
+// 6.68 vs 6.98 ms at 1024x1024x256: fewer concurrent row fronts, better DRAM page locality) even though its ~95 VGPRs would
+// allow 5; the FP16C kernel is VALU-bound and takes all the waves its registers allow.
+#ifndef LUW_MAXW_F32
+#define LUW_MAXW_F32 4
+#endif
+template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
@@ -960,7 +966,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	k.Ox = cfg->Ox; k.Oy = cfg->Oy; k.Oz = cfg->Oz;
 	k.w = literal_roundtrip(1.0f/(3.0f*cfg->nu+0.5f)); // FX/lbm.hpp:140, FX/lbm.cpp:664
 	k.fx = cfg->fx; k.fy = cfg->fy; k.fz = cfg->fz;
-	k.omx = cfg->omega_x; k.omy = cfg->omega_y; k.omz = cfg->omega_z;
+	k.tau0 = 1.0f/k.w; k.tau0sq = k.tau0*k.tau0;
+	k.omx = cfg->omega_x; k.omy = cfg->omega_y; k.omz = cfg->omega_z; k.coriolis = k.omx!=0.0f||k.omy!=0.0f||k.omz!=0.0f;
 	k.subgrid = (cfg->options&LUW_OPT_NO_SUBGRID) ? 0u : 1u;
 	k.buffer_active = cfg->buffer_nudging_active ? 1u : 0u;
 	k.buffer_N = cfg->buffer_n_cells; k.nudge_vertical = (uint32_t)cfg->buffer_nudge_vertical; k.downstream_face = (uint32_t)cfg->buffer_downstream_face_id;
@@ -1357,6 +1364,7 @@ int luw_set_f(luw_solver* s, float fx, float fy, float fz) {
 int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_set_coriolis: null solver");
 	s->cfg.omega_x = s->kp.omx = ox; s->cfg.omega_y = s->kp.omy = oy; s->cfg.omega_z = s->kp.omz = oz;
+	s->kp.coriolis = ox!=0.0f||oy!=0.0f||oz!=0.0f;
 	return LUW_OK;
 }
 

@@ -31,8 +31,10 @@ struct KParams {
 	uint32_t halo_x, halo_y, halo_z; // 1 if that axis is split over domains (cells 0 and N-1 are halo: FX/kernel.cpp:856-859)
 	int32_t Ox, Oy, Oz;
 	float w;                  // def_w
+	float tau0, tau0sq;       // 1/w and its square as the kernel would compute them (IEEE division / product, done once on the host)
 	float fx, fy, fz;
 	float omx, omy, omz;
+	uint32_t coriolis;        // any component of omega nonzero
 	uint32_t subgrid;
 	// BUFFER_NUDGING / TOP_SPONGE, FX/lbm.cpp:613-625,770-782
 	uint32_t buffer_active, buffer_N, nudge_vertical, downstream_face;
@@ -176,12 +178,14 @@ __device__ __forceinline__ void calculate_forcing_terms(const float ux, const fl
 __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E,
 		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn, float& fzn) {
 	fxn = p.fx; fyn = p.fy; fzn = p.fz;
-	const float cor_x = -2.0f*rhon*(p.omy*uzn-p.omz*uyn);
-	const float cor_y = -2.0f*rhon*(p.omz*uxn-p.omx*uzn);
-	const float cor_z = -2.0f*rhon*(p.omx*uyn-p.omy*uxn);
-	fxn += cor_x;
-	fyn += cor_y;
-	fzn += cor_z;
+	if(p.coriolis) { // with omega = 0 the three terms are +-0: adding them changes no value
+		const float cor_x = -2.0f*rhon*(p.omy*uzn-p.omz*uyn);
+		const float cor_y = -2.0f*rhon*(p.omz*uxn-p.omx*uzn);
+		const float cor_z = -2.0f*rhon*(p.omx*uyn-p.omy*uxn);
+		fxn += cor_x;
+		fyn += cor_y;
+		fzn += cor_z;
+	}
 	if(p.buffer_active && !is_E) {
 		const int Nbuf_i = (int)p.buffer_N;
 		const int d_w_i = (int)x+p.Ox;
@@ -257,7 +261,7 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 	// Smagorinsky-Lilly relaxation rate, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped
 	auto relaxation_rate = [&](const float* feq) -> float {
 		if(!p.subgrid) return p.w;
-		const float tau0 = 1.0f/p.w;
+		const float tau0 = p.tau0;
 		float n_[19];
 		#pragma unroll
 		for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
@@ -269,7 +273,7 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 		Hxz += n_[ 9]; Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
 		Hyz += n_[11]; Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
 		const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
-		return 2.0f/(tau0+sqrtf(sq(tau0)+0.76421222f*sqrtf(Q)/rhon));
+		return 2.0f/(tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q)/rhon));
 	};
 	float feq[19];
 	// Wave-uniform fast path: when no lane of the wave is a TYPE_E cell or feels a force (interior waves of an urban case),
