@@ -142,7 +142,7 @@ template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
 #ifndef LUW_MAXW_F32
 #define LUW_MAXW_F32 4
 #endif
-template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
@@ -167,13 +167,14 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n));
 		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o)));
 	});
+	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
 		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
 			float u0[3];
 			collide_cell<true>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
 			constexpr uint32_t es = (uint32_t)sizeof(T);
-			thermal_cell<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf);
+			thermal_collide<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
 		} else
 		collide_cell<(MODE!=3)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
@@ -187,6 +188,27 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 	// stores: instruction selection works per basic block, and without seeing the zero-extension there it builds nineteen
 	// 64-bit addresses (v_lshl_add_u64 + a VGPR pair each) instead of the saddr form the loads use
 	asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17));
+	if constexpr(sizeof(T)==2&&MODE!=1) { // FP16C, nothing but the stores left: the 3-instruction encode under round-toward-zero
+		uint32_t c[19];
+		if constexpr(MODE==4) {
+			uint32_t cg[7];
+			fp16c_encode19_hi_rtz_final(f, c, g, cg);
+			constexpr uint32_t es = (uint32_t)sizeof(T);
+			thermal_store<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, gi, [&](const int i) { return (T)(cg[i]>>16); });
+		} else fp16c_encode19_hi_rtz_final(f, c);
+		sto<(NT!=0)>(fi, o.n, (T)(c[0]>>16));
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+			sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), (T)(c[i]>>16));
+			sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n, (T)(c[i+1]>>16));
+		});
+		return;
+	}
+	if constexpr(MODE==4) {
+		constexpr uint32_t es = (uint32_t)sizeof(T);
+		thermal_store<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, gi, [&](const int i) { return ddf_encode<T>(g[i]); });
+	}
 	sto<(NT!=0)>(fi, o.n, ddf_encode<T>(f[0]));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
@@ -695,6 +717,15 @@ __global__ __launch_bounds__(256) void k_codec_check(unsigned long long* __restr
 	unsigned long long bad = 0ull;
 	for(uint32_t c=tid; c<65536u; c+=nth) bad += __float_as_uint(half_to_float_custom(c))!=__float_as_uint(half_to_float_custom_ref(c));
 	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) { if(((uint32_t)v&0x7F800000u)>=(230u<<23)) continue; const float x = __uint_as_float((uint32_t)v); bad += float_to_half_custom(x)!=float_to_half_custom_ref(x); }
+	// the product kernel's 3-instruction encode (fp16c_encode19_hi_rtz_final): every bit pattern except NaNs, under RTZ; the
+	// reference formula it is compared with is integer-only, so the mode does not touch it
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(bad));
+	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) {
+		const uint32_t b = (uint32_t)v;
+		if((b&0x7F800000u)==0x7F800000u&&(b&0x007FFFFFu)!=0u) continue;
+		bad += (fp16c_code_hi_in_rtz_mode(__uint_as_float(b))>>16)!=float_to_half_custom_ref(__uint_as_float(b));
+	}
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(bad));
 	if(bad) atomicAdd(mismatches, bad);
 }
 

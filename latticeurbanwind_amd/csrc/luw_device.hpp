@@ -101,6 +101,36 @@ __device__ __forceinline__ uint32_t float_to_half_custom_hi(const float x) {
 	return code;
 }
 __device__ __forceinline__ uint32_t float_to_half_custom(const float x) { return float_to_half_custom_hi(x)>>16; }
+// Encode of the 19 post-collision DDFs at the very end of a kernel, 3 instructions each.  Under round-TOWARD-ZERO the
+// product v = |x| 2^-112 carries the whole reference formula in its bit pattern: for |x| >= 2^-14 it is exact and its
+// exponent field is the rebiased FP16C exponent; below, v is a float DENORMAL whose mantissa field is floor(|x| 2^37), and
+// the hardware's denormalisation is exactly the reference's variable shift.  (bits(v) + 0x800) >> 12 is then
+// round_half_up onto the FP16C grid in both ranges (floor(floor(y)/4096 + 1/2) = floor(y/4096 + 1/2)), the carry runs into the
+// exponent by itself, and a 4-bit shift to the left instead leaves the code in bits 16..30 for the d16_hi store; one
+// bit-field insert adds the sign.  With the default round-to-nearest-even the denormal range would be rounded twice
+// (ties at 2^-37 before the half-up at 2^-25), hence the mode switch: the FP32 rounding mode of THIS wave is set to RTZ
+// by s_setreg and stays so -- the caller must have nothing but integer work and stores left.  All f[] pass through the
+// two asm statements, so every floating-point instruction that produces them is ordered before the switch.
+// Same codes as the literal formula for every finite float and +-Inf (device self-check, luw_selfcheck_fp16c_codec).
+__device__ __forceinline__ uint32_t fp16c_code_hi_in_rtz_mode(const float x) { // the wave's FP32 rounding mode must be RTZ
+	uint32_t v, c, code;
+	asm volatile("v_mul_f32_e64 %0, |%1|, %2" : "=v"(v) : "v"(x), "s"(0x1p-112f));
+	asm("v_add_lshl_u32 %0, %1, %2, 4" : "=v"(c) : "v"(v), "s"(0x800));
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(code) : "s"(0x7FFFFFFF), "v"(c), "v"(x));
+	return code;
+}
+// g/cg: the 7 populations of the thermal lattice, encoded in the same region (nullptr without it)
+__device__ __forceinline__ void fp16c_encode19_hi_rtz_final(float* f, uint32_t* code, float* g = nullptr, uint32_t* cg = nullptr) {
+	asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
+	if(g) asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]));
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]), "+v"(f[16]), "+v"(f[17]), "+v"(f[18]));
+	#pragma unroll
+	for(int i=0; i<19; i++) code[i] = fp16c_code_hi_in_rtz_mode(f[i]);
+	if(g) {
+		#pragma unroll
+		for(int i=0; i<7; i++) cg[i] = fp16c_code_hi_in_rtz_mode(g[i]);
+	}
+}
 template<typename T> __device__ __forceinline__ float ddf_decode(const T v);
 template<> __device__ __forceinline__ float ddf_decode<float>(const float v) { return v; }
 template<> __device__ __forceinline__ float ddf_decode<uint16_t>(const uint16_t v) { return half_to_float_custom_sx((int32_t)(int16_t)v); }
@@ -327,11 +357,10 @@ __device__ __forceinline__ void calculate_g_eq(const float T, const float ux, co
 // on T, BGK with w_T (TYPE_T: g = g_eq), stream-out.  n, jx, jy, jz are ELEMENT indices of the cell and its +x, +y, +z
 // neighbours; (ux,uy,uz) is the velocity before the force shift.  The buoyancy term it would add to the force carries the
 // factor (fx,fy,fz), which LUW sets to zero (FX/setup.cpp:4935): T is a passive scalar here.
-template<typename T, int PARITY> __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
-		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, T* __restrict__ gi, float* __restrict__ Tf) {
+template<typename T, int PARITY> __device__ __forceinline__ void thermal_collide(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
+		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, const T* __restrict__ gi, float* __restrict__ Tf, float* g) {
 	const size_t Np = p.Np;
 	const uint32_t jn[3] = { jx, jy, jz };
-	float g[7];
 	g[0] = ddf_decode<T>(gi[n]);
 	#pragma unroll
 	for(int k=0; k<3; k++) {
@@ -355,13 +384,24 @@ template<typename T, int PARITY> __device__ __forceinline__ void thermal_cell(co
 		const float omw = 1.0f-p.w_T;
 		for(int i=0; i<7; i++) g[i] = fmaf(omw, g[i], p.w_T*geq[i]);
 	}
-	gi[n] = ddf_encode<T>(g[0]);
+}
+// stream-out of the 7 encoded populations (Esoteric-Pull slots); code_of(i) yields the storage value of population i
+template<typename T, int PARITY, typename F> __device__ __forceinline__ void thermal_store(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz, T* __restrict__ gi, F code_of) {
+	const size_t Np = p.Np;
+	const uint32_t jn[3] = { jx, jy, jz };
+	gi[n] = code_of(0);
 	#pragma unroll
 	for(int k=0; k<3; k++) {
 		const int i = 2*k+1;
-		gi[(size_t)(PARITY ? i+1 : i)*Np+jn[k]] = ddf_encode<T>(g[i]);
-		gi[(size_t)(PARITY ? i : i+1)*Np+n] = ddf_encode<T>(g[i+1]);
+		gi[(size_t)(PARITY ? i+1 : i)*Np+jn[k]] = code_of(i);
+		gi[(size_t)(PARITY ? i : i+1)*Np+n] = code_of(i+1);
 	}
+}
+template<typename T, int PARITY> __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
+		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, T* __restrict__ gi, float* __restrict__ Tf) {
+	float g[7];
+	thermal_collide<T, PARITY>(p, n, jx, jy, jz, x, y, z, flagsn, ux, uy, uz, gi, Tf, g);
+	thermal_store<T, PARITY>(p, n, jx, jy, jz, gi, [&](const int i) { return ddf_encode<T>(g[i]); });
 }
 
 } // namespace luw

@@ -3,6 +3,8 @@
 // Every test moves the bytes of one D3Q19 step on N = 512^3 cells (19 x 4 B read + 19 x 4 B written per cell) and
 // reports GB/s = 152 B x N / time.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -75,6 +77,32 @@ template<int S, int W> __global__ __launch_bounds__(256) void k_write(float* __r
 	}
 }
 
+// FP16C-shaped traffic: 19 planes of 2-byte elements updated in place, W elements per lane (W = 1: ushort accesses, 128 B per
+// wave instruction; W = 2: one dword per lane, 256 B), 5 of the 19 planes accessed one element further along the row like the
+// x+1 populations (for W = 2 that is a dword on a 2-byte boundary), occupancy limited through the LDS request
+template<int W, bool NT> __global__ __launch_bounds__(256) void k_update_half(uint16_t* __restrict__ io, const size_t P) {
+	extern __shared__ float lds[];
+	const size_t e = ((size_t)blockIdx.x*blockDim.x+threadIdx.x)*W;
+	if(e+W+1>P) return;
+	uint32_t v[19];
+	#pragma unroll
+	for(int s=0; s<19; s++) {
+		const bool shifted = s==2||s==8||s==10||s==14||s==16;
+		const uint16_t* p = io+(size_t)s*P+e+(shifted ? 1 : 0);
+		if constexpr(W==1) v[s] = (NT&&!shifted) ? __builtin_nontemporal_load(p) : *p;
+		else { if(NT&&!shifted) v[s] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)); else __builtin_memcpy(&v[s], p, 4); }
+	}
+	if(v[0]==0xDEADBEEFu) lds[threadIdx.x] = 1.0f;
+	#pragma unroll
+	for(int s=0; s<19; s++) {
+		const bool shifted = s==2||s==8||s==10||s==14||s==16;
+		uint16_t* p = io+(size_t)s*P+e+(shifted ? 1 : 0);
+		const uint32_t r = v[s]+0x00010001u;
+		if constexpr(W==1) { if(NT&&!shifted) __builtin_nontemporal_store((uint16_t)r, p); else *p = (uint16_t)r; }
+		else { if(NT&&!shifted) __builtin_nontemporal_store(r, reinterpret_cast<uint32_t*>(p)); else __builtin_memcpy(p, &r, 4); }
+	}
+}
+
 template<typename F> static double time_ms(F launch, int reps=20) {
 	hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
 	for(int i=0; i<3; i++) launch();
@@ -86,12 +114,32 @@ template<typename F> static double time_ms(F launch, int reps=20) {
 	return ms/reps;
 }
 
-int main() {
+int main(int argc, char** argv) {
 	const size_t N = 512ull*512ull*512ull; const unsigned NX = 512;
 	float *A, *B; CHECK(hipMalloc(&A, 19*N*4)); CHECK(hipMalloc(&B, 19*N*4));
 	CHECK(hipMemset(A, 0, 19*N*4)); CHECK(hipMemset(B, 0, 19*N*4));
 	const double bytes = 152.0*N;
 	auto rep = [&](const char* name, double ms, double b) { printf("%-58s %8.3f ms  %8.1f GB/s\n", name, ms, b/ms/1e6); fflush(stdout); };
+	if(argc>1&&!strcmp(argv[1], "half")) { // FP16C-shaped traffic only
+		uint16_t* H = reinterpret_cast<uint16_t*>(A);
+		CHECK(hipFuncSetAttribute((const void*)k_update_half<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		CHECK(hipFuncSetAttribute((const void*)k_update_half<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		CHECK(hipFuncSetAttribute((const void*)k_update_half<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		CHECK(hipFuncSetAttribute((const void*)k_update_half<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
+		for(int blocks_per_cu : {8, 6, 5, 4, 3, 2}) {
+			const size_t lds_bytes = blocks_per_cu>=8 ? 0 : (size_t)(160*1024/blocks_per_cu-2048);
+			char name[128];
+			snprintf(name, sizeof(name), "half in-place 19 planes ushort/lane %d blocks/CU nt", blocks_per_cu);
+			rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_half<1, true>), dim3((unsigned)((N+255)/256)), dim3(256), lds_bytes, 0, H, N); }), 76.0*N);
+			snprintf(name, sizeof(name), "half in-place 19 planes dword/lane  %d blocks/CU nt", blocks_per_cu);
+			rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_half<2, true>), dim3((unsigned)((N/2+255)/256)), dim3(256), lds_bytes, 0, H, N); }), 76.0*N);
+			snprintf(name, sizeof(name), "half in-place 19 planes ushort/lane %d blocks/CU", blocks_per_cu);
+			rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_half<1, false>), dim3((unsigned)((N+255)/256)), dim3(256), lds_bytes, 0, H, N); }), 76.0*N);
+			snprintf(name, sizeof(name), "half in-place 19 planes dword/lane  %d blocks/CU", blocks_per_cu);
+			rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update_half<2, false>), dim3((unsigned)((N/2+255)/256)), dim3(256), lds_bytes, 0, H, N); }), 76.0*N);
+		}
+		return 0;
+	}
 	#define RUN(name, S, W, L, IP, total) { const size_t P = (total)/(S); rep(name, time_ms([&]{ hipLaunchKernelGGL((k_update<S, W, L, IP>), dim3((unsigned)((P/W+255)/256)), dim3(256), 0, 0, A, B, P, NX); }), bytes); }
 	RUN("copy A->B  1 plane-pair  float4", 1, 4, 0, false, 19*N)
 	RUN("copy A->B  1 plane-pair  dword", 1, 1, 0, false, 19*N)
