@@ -219,97 +219,146 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 }
 
 // ---------------------------------------------------------------- pair kernel: 2 cells per lane (FP16C DDFs)
-// With 2-byte DDFs the scalar kernel moves only 128 B per wave instruction.  Here a lane owns the cells (x, x+1), x even,
-// and moves both FP16C codes of a plane with ONE dword access -- the same bytes per instruction as the FP32 scalar
-// kernel.  Straight planes are 4-byte aligned; the x+1 planes are read/written at a 2-byte offset (dword access on a
-// 2-byte boundary, expressed with memcpy so the compiler may split it where the target demands), except for the
-// lane at the row end whose second neighbour wraps to x = 0.  A cell that must not be processed (solid / halo) passes
-// its populations through; its values are pre-swapped so the Esoteric-Pull store puts them back where they came from.
-// Requires even b.x0 and even b.x1 (the host falls back to the scalar kernel otherwise).
-__device__ __forceinline__ uint32_t ld_pair(const uint16_t* plane, const uint32_t byte_off, const bool nt) {
-	uint32_t v;
+// With 2-byte DDFs the scalar kernel moves only 128 B per wave instruction, and that access width tops out near 5.2 TB/s
+// (tools/membench half).  Here a lane owns the cells (x, x+1), x even, and moves both FP16C codes of a plane with ONE
+// dword access -- the same bytes per instruction as the FP32 scalar kernel.  Straight planes are 4-byte aligned; the x+1
+// planes are read/written at a 2-byte offset (a dword access on a 2-byte boundary, which the hardware serves), except for
+// the lane at the row end whose second neighbour wraps to x = 0.  The two cells are collided ONE AFTER THE OTHER (an
+// asm fence between the passes keeps the compiler from interleaving them), so the register footprint is that of the
+// scalar kernel plus the 19 finished values of the first cell: 4 waves/SIMD.  Both cells are encoded at the tail under
+// round-toward-zero (fp16c_code_hi_in_rtz_mode) and merged into dwords with one byte permute per plane.
+// A cell that must not be processed (solid / halo) passes its populations through; its values are pre-swapped so that
+// the Esoteric-Pull store puts them back where they came from (every slot has exactly one writing cell per step, so this
+// rewrite races with nobody).  Requires even b.x0 and even b.x1 and rows whose x = 0 sits on a 4-byte boundary (the host
+// falls back to the scalar kernel otherwise).
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+template<bool NT> __device__ __forceinline__ uint32_t ld_pair(const uint16_t* plane, const uint32_t byte_off) {
 	const char* ptr = reinterpret_cast<const char*>(plane)+byte_off;
-	if(nt) v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ptr)); else __builtin_memcpy(&v, ptr, 4);
-	return v;
+	if constexpr(NT) return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ptr));
+	else return *reinterpret_cast<const u32_a2*>(ptr);
 }
-__device__ __forceinline__ void st_pair(uint16_t* plane, const uint32_t byte_off, const uint32_t v, const bool nt) {
+template<bool NT> __device__ __forceinline__ void st_pair(uint16_t* plane, const uint32_t byte_off, const uint32_t v) {
 	char* ptr = reinterpret_cast<char*>(plane)+byte_off;
-	if(nt) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(ptr)); else __builtin_memcpy(ptr, &v, 4);
+	if constexpr(NT) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(ptr));
+	else *reinterpret_cast<u32_a2*>(ptr) = v;
 }
-template<int PARITY> __global__ __launch_bounds__(256, 3) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// every value of v[0..N) passes through a volatile asm: what produces them is ordered before, what consumes them after
+template<int N> __device__ __forceinline__ void asm_fence(float* v) {
+	static_assert(N==19, "written for the 19 DDFs of a cell");
+	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
+	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
+}
+__device__ __forceinline__ void asm_fence9(float& f0, f32x2* v) {
+	asm volatile("" : "+v"(f0), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+}
+__device__ __forceinline__ void asm_fence_u(uint32_t* v) {
+	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
+	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
+}
+template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
-	const NbrOff o = neighbor_offsets<uint16_t>(p, x, y, z);      // offsets of cell x; cell x+1 sits 2 bytes further
+	NbrOff o = neighbor_offsets<uint16_t>(p, x, y, z);            // offsets of cell x; cell x+1 sits 2 bytes further
 	const bool wrap = x+2u==p.Nx;                                  // cell x+1 is the last of the row: its x+1 neighbour is x = 0
 	const uint32_t n = o.n>>1;
 	const size_t Np = p.Np;
 	const uint32_t fl2 = *reinterpret_cast<const uint16_t*>(flags+n);
-	uint8_t fl[2] = { (uint8_t)(fl2&0xFFu), (uint8_t)(fl2>>8) };
+	const uint8_t fl[2] = { (uint8_t)(fl2&0xFFu), (uint8_t)(fl2>>8) };
 	bool proc[2];
 	#pragma unroll
 	for(int c=0; c<2; c++) proc[c] = !cell_is_halo(p, x+c, y, z) && (fl[c]&TYPE_BO)!=TYPE_S && (fl[c]&TYPE_SU)!=TYPE_G;
 	if(!proc[0]&&!proc[1]) return;
-	float f[19][2];
-	auto unpack = [&](const int q, const uint32_t v) { f[q][0] = half_to_float_custom(v&0xFFFFu); f[q][1] = half_to_float_custom(v>>16); };
-	auto pack = [&](const int q) { return float_to_half_custom(f[q][0])|(float_to_half_custom(f[q][1])<<16); };
-	unpack(0, ld_pair(fi, o.n, true));
+	// All 19 dword loads in one straight run.  For the row-end lane (wrap) the high half of the five x+1 dwords is the element
+	// behind the row end (the next row's x = 0, or the slack behind the plane: in bounds, see lead_alloc / the plane skew):
+	// it is replaced by the wrapped neighbour in ONE divergent fix-up block behind the loads.
+	uint32_t raw[19];                                              // low half: cell x, high half: cell x+1
+	raw[0] = ld_pair<true>(fi, o.n);
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-		unpack(i, ld_pair(fi+(size_t)slotA<PARITY>(i)*Np, o.n, true));
-		const uint16_t* B = fi+(size_t)slotB<PARITY>(i)*Np;
-		if constexpr(!shifted) unpack(i+1, ld_pair(B, nbr<i>(o), true));
-		else {
-			uint32_t v;
-			if(!wrap) v = ld_pair(B, nbr<i>(o), false);
-			else { // (row, Nx-1) and (row, 0): nbr<i>(o) addresses x+1 = Nx-1 of the neighbour row
-				const uint32_t off = nbr<i>(o);
-				const uint32_t lo = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(B)+off);
-				const uint32_t hi = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(B)+(off-2u*(p.Nx-1u)));
-				v = lo|(hi<<16);
-			}
-			unpack(i+1, v);
-		}
+		raw[i] = ld_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.n);
+		raw[i+1] = ld_pair<!shifted>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o));
 	});
-	#pragma unroll
-	for(int c=0; c<2; c++) {
-		if(proc[c]) {
-			float fc[19];
-			#pragma unroll
-			for(int q=0; q<19; q++) fc[q] = f[q][c];
+	if(wrap) {
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) { // nbr<i>(o) addresses x+1 = Nx-1 of the neighbour row; x+2 wraps to its x = 0
+				const uint32_t hi = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(fi+(size_t)slotB<PARITY>(i)*Np)+(nbr<i>(o)-2u*(p.Nx-1u)));
+				raw[i+1] = (raw[i+1]&0xFFFFu)|(hi<<16);
+			}
+		});
+	}
+	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
+	const bool may_force = p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull;
+	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
+	// (or pre-swap for the pass-through)
+	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
+		auto bits = [&](const int q) { return (uint32_t)(c ? (int32_t)raw[q]>>16 : (int32_t)(raw[q]<<16)>>16)<<12&0x87FFF000u; };
+		f0 = __uint_as_float(bits(0))*0x1p+112f;
+		#pragma unroll
+		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
+		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
-			collide_cell(p, n+c, x+c, y, z, fl[c], fc, rho, u, F, rhon, uxn, uyn, uzn);
+			collide_cell_pk(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				rho[n+c] = rhon;
 				u[n+c] = uxn;
 				u[Np+n+c] = uyn;
 				u[2ull*Np+n+c] = uzn;
 			}
-			#pragma unroll
-			for(int q=0; q<19; q++) f[q][c] = fc[q];
 		} else {
 			#pragma unroll
-			for(int i=1; i<19; i+=2) { const float t = f[i][c]; f[i][c] = f[i+1][c]; f[i+1][c] = t; }
+			for(int k=0; k<9; k++) { const f32x2 t = { fp[k].y, fp[k].x }; fp[k] = t; }
 		}
+	};
+	float fa0, fb0; f32x2 fa[9], fb[9];
+	one_cell(0, fa0, fa);
+	asm_fence9(fa0, fa); asm_fence_u(raw);                         // cell x is finished before cell x+1 starts
+	one_cell(1, fb0, fb);
+	asm_fence9(fa0, fa); asm_fence9(fb0, fb);                      // all floating-point work is done ...
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3"); // ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
+	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
+	uint32_t ca[19], cb[19];
+	ca[0] = fp16c_code_hi_in_rtz_mode(fa0); cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
+	#pragma unroll
+	for(int k=0; k<9; k++) {
+		fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
+		fp16c_code2_hi_in_rtz_mode(fb[k], cb[2*k+1], cb[2*k+2]);
 	}
-	st_pair(fi, o.n, pack(0), true);
+	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };
+	uint32_t cs[5];   // the five x+1 planes, stored last (dword or, on the row-end lane, two halves)
+	#define LUW_REDEFINE_OFFSETS asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17)) /* saddr stores, see k_stream_collide_s */
+	LUW_REDEFINE_OFFSETS;
+	st_pair<true>(fi, o.n, pack(0));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-		uint16_t* B = fi+(size_t)slotB<PARITY>(i)*Np;
-		const uint32_t v = pack(i);
-		if constexpr(!shifted) st_pair(B, nbr<i>(o), v, true);
-		else {
-			if(!wrap) st_pair(B, nbr<i>(o), v, false);
-			else {
-				const uint32_t off = nbr<i>(o);
-				*reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(B)+off) = (uint16_t)(v&0xFFFFu);
-				*reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(B)+(off-2u*(p.Nx-1u))) = (uint16_t)(v>>16);
-			}
-		}
-		st_pair(fi+(size_t)slotA<PARITY>(i)*Np, o.n, pack(i+1), true);
+		constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+		if constexpr(!shifted) st_pair<true>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), pack(i));
+		else cs[k] = pack(i);
+		st_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.n, pack(i+1));
 	});
+	if(!wrap) {
+		LUW_REDEFINE_OFFSETS;
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) st_pair<false>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), cs[k]);
+		});
+	} else {
+		LUW_REDEFINE_OFFSETS;
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) {
+				constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+				char* B = reinterpret_cast<char*>(fi+(size_t)slotB<PARITY>(i)*Np);
+				*reinterpret_cast<uint16_t*>(B+nbr<i>(o)) = (uint16_t)(cs[k]&0xFFFFu);
+				*reinterpret_cast<uint16_t*>(B+(nbr<i>(o)-2u*(p.Nx-1u))) = (uint16_t)(cs[k]>>16);
+			}
+		});
+	}
+	#undef LUW_REDEFINE_OFFSETS
 }
 
 // ---------------------------------------------------------------- vector kernel: V cells per lane
@@ -861,20 +910,24 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
 	const uint32_t nx = (b.x1-b.x0)/2u;
 	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // measurement aid: the kernel's memory path alone (no physics)
+	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
 	if(odd) hipLaunchKernelGGL((k_stream_collide_p<1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
 
-// Kernel choice.  LUW_KERNEL_AUTO = the scalar kernel for both DDF formats: measured fastest on MI355X (FP32 36.0k MLUPS,
-// FP16C 45.7k MLUPS at 512^3; pair kernel 37.8k, vector kernels 20-29k; profiles/r01_kernel_ab.md).  The other kernels
-// stay selectable for A/B runs.
+// Kernel choice.  LUW_KERNEL_AUTO = the scalar kernel (FP32: 39.5k MLUPS at 512^3; vector kernels 20-29k) and, for FP16C rows
+// wide enough, the pair kernel (profiles/r01_kernel_ab.md).  The other kernels stay selectable for A/B runs.
 static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields) {
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
 	const bool fp16 = s->ddf_bytes==2u;
 	uint32_t k = s->kernel;
-	if(k==LUW_KERNEL_AUTO) k = LUW_KERNEL_SCALAR;
+	// AUTO: the scalar kernel, except FP16C rows of at least two waves of pairs, which take the pair kernel (dword accesses, packed
+	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
+	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=256u) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
 	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
 	if(s->kp.halo_x&&(k==LUW_KERNEL_PAIR||k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the A/B kernels assume rows that start on a 16-byte boundary at x = 0
 	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || (b.x1&1u))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, even x range

@@ -119,6 +119,17 @@ __device__ __forceinline__ uint32_t fp16c_code_hi_in_rtz_mode(const float x) { /
 	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(code) : "s"(0x7FFFFFFF), "v"(c), "v"(x));
 	return code;
 }
+// two values at once: one packed multiplication (the sign needs no |.|: it is shifted out and re-inserted from x)
+typedef float f32x2_codec __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fp16c_code2_hi_in_rtz_mode(const f32x2_codec x, uint32_t& c0, uint32_t& c1) {
+	f32x2_codec v; const f32x2_codec k = { 0x1p-112f, 0x1p-112f };
+	asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(x), "v"(k));
+	uint32_t t0, t1;
+	asm("v_add_lshl_u32 %0, %1, %2, 4" : "=v"(t0) : "v"(v.x), "s"(0x800));
+	asm("v_add_lshl_u32 %0, %1, %2, 4" : "=v"(t1) : "v"(v.y), "s"(0x800));
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c0) : "s"(0x7FFFFFFF), "v"(t0), "v"(x.x));
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c1) : "s"(0x7FFFFFFF), "v"(t1), "v"(x.y));
+}
 // g/cg: the 7 populations of the thermal lattice, encoded in the same region (nullptr without it)
 __device__ __forceinline__ void fp16c_encode19_hi_rtz_final(float* f, uint32_t* code, float* g = nullptr, uint32_t* cg = nullptr) {
 	asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
@@ -267,12 +278,29 @@ __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t 
 }
 
 // ---------------------------------------------------------------- collision of one cell, FX/kernel.cpp:1502-1515,1686-1748
-// in: streamed-in DDFs f[19], flags byte.  out: post-collision DDFs in f[19]; rho/u (after the half-force
-// shift and the +-c clamp) in rhon,uxn,uyn,uzn.  Returns false when the cell must not touch memory at all
-// (solid / gas, FX/kernel.cpp:1490).
-template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
-		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
-	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+// Smagorinsky-Lilly relaxation rate, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped (the
+// leading 0 + n of each sum too: it can only turn -0 into +0, and every sum is squared)
+__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_) {
+	float Hxx = n_[ 1], Hyy = n_[ 3], Hzz = n_[ 5], Hxy = n_[ 7], Hxz = n_[ 9], Hyz = n_[11];
+	Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
+	Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
+	Hzz += n_[ 6]; Hzz += n_[ 9]; Hzz += n_[10]; Hzz += n_[11]; Hzz += n_[12]; Hzz += n_[15]; Hzz += n_[16]; Hzz += n_[17]; Hzz += n_[18];
+	Hxy += n_[ 8]; Hxy += -n_[13]; Hxy += -n_[14];
+	Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
+	Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
+	const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
+	return 2.0f/(p.tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q)/rhon));
+}
+__device__ __forceinline__ float relaxation_rate(const KParams& p, const float rhon, const float* f, const float* feq) {
+	if(!p.subgrid) return p.w;
+	float n_[19];
+	#pragma unroll
+	for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
+	return smagorinsky_rate(p, rhon, n_);
+}
+// rho, u of the cell (moments, or the stored values on TYPE_E cells) and the force acting on it
+__device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const float* f,
+		const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float& fxn, float& fyn, float& fzn) {
 	if(is_E) {
 		rhon = rho[n];
 		uxn = u[n];
@@ -281,46 +309,12 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 	} else {
 		calculate_rho_u(f, rhon, uxn, uyn, uzn);
 	}
-	float fxn, fyn, fzn;
 	assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
-	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
-	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
-	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
-	// (fma(w, feq, +-0) == w*feq) as long as rho != 0.
-	const bool forced = fxn!=0.0f||fyn!=0.0f||fzn!=0.0f;
-	// Smagorinsky-Lilly relaxation rate, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped
-	auto relaxation_rate = [&](const float* feq) -> float {
-		if(!p.subgrid) return p.w;
-		const float tau0 = p.tau0;
-		float n_[19];
-		#pragma unroll
-		for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
-		float Hxx = 0.0f, Hyy = 0.0f, Hzz = 0.0f, Hxy = 0.0f, Hxz = 0.0f, Hyz = 0.0f;
-		Hxx += n_[ 1]; Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
-		Hyy += n_[ 3]; Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
-		Hzz += n_[ 5]; Hzz += n_[ 6]; Hzz += n_[ 9]; Hzz += n_[10]; Hzz += n_[11]; Hzz += n_[12]; Hzz += n_[15]; Hzz += n_[16]; Hzz += n_[17]; Hzz += n_[18];
-		Hxy += n_[ 7]; Hxy += n_[ 8]; Hxy += -n_[13]; Hxy += -n_[14];
-		Hxz += n_[ 9]; Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
-		Hyz += n_[11]; Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
-		const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
-		return 2.0f/(tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q)/rhon));
-	};
-	float feq[19];
-	// Wave-uniform fast path: when no lane of the wave is a TYPE_E cell or feels a force (interior waves of an urban case),
-	// the equilibrium override and the Guo terms drop out for the whole wave -- one scalar branch instead of 19 selects, 19
-	// products with zero and the zero-filled Fin registers per lane.  Same values (+-0 aside) as the general path below.
-	if(FAST&&__ballot(is_E||forced)==0ull) {
-		uxn = clampf(uxn, -DEF_C, DEF_C);
-		uyn = clampf(uyn, -DEF_C, DEF_C);
-		uzn = clampf(uzn, -DEF_C, DEF_C);
-		calculate_f_eq(rhon, uxn, uyn, uzn, feq);
-		const float w = relaxation_rate(feq);
-		const float omw = 1.0f-w;
-		#pragma unroll
-		for(int i=0; i<19; i++) f[i] = fmaf(omw, f[i], w*feq[i]);
-		return;
-	}
-	float Fin[19];
+}
+// the general tail: Guo forcing, equilibrium override on TYPE_E cells
+__device__ __forceinline__ void collide_tail_general(const KParams& p, const bool is_E, const bool forced, const float fxn, const float fyn, const float fzn,
+		float* f, const float rhon, float& uxn, float& uyn, float& uzn) {
+	float feq[19], Fin[19];
 	if(forced) {
 		const float rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
@@ -335,7 +329,7 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 		for(int i=0; i<19; i++) Fin[i] = 0.0f;
 	}
 	calculate_f_eq(rhon, uxn, uyn, uzn, feq);
-	const float w = relaxation_rate(feq);
+	const float w = relaxation_rate(p, rhon, f, feq);
 	const float c_tau = fmaf(w, -0.5f, 1.0f);
 	const float omw = 1.0f-w;
 	#pragma unroll
@@ -343,6 +337,150 @@ template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KPar
 		const float Fi = Fin[i]*c_tau;
 		f[i] = is_E ? feq[i] : fmaf(omw, f[i], fmaf(w, feq[i], Fi));
 	}
+}
+// in: streamed-in DDFs f[19], flags byte.  out: post-collision DDFs in f[19]; rho/u (after the half-force
+// shift and the +-c clamp) in rhon,uxn,uyn,uzn.
+template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
+	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+	float fxn, fyn, fzn;
+	collide_head(p, n, x, y, z, is_E, f, rho, u, F, rhon, uxn, uyn, uzn, fxn, fyn, fzn);
+	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
+	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
+	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
+	// (fma(w, feq, +-0) == w*feq) as long as rho != 0.
+	const bool forced = fxn!=0.0f||fyn!=0.0f||fzn!=0.0f;
+	// Wave-uniform fast path: when no lane of the wave is a TYPE_E cell or feels a force (interior waves of an urban case),
+	// the equilibrium override and the Guo terms drop out for the whole wave -- one scalar branch instead of 19 selects, 19
+	// products with zero and the zero-filled Fin registers per lane.  Same values (+-0 aside) as the general path below.
+	if(FAST&&__ballot(is_E||forced)==0ull) {
+		float feq[19];
+		uxn = clampf(uxn, -DEF_C, DEF_C);
+		uyn = clampf(uyn, -DEF_C, DEF_C);
+		uzn = clampf(uzn, -DEF_C, DEF_C);
+		calculate_f_eq(rhon, uxn, uyn, uzn, feq);
+		const float w = relaxation_rate(p, rhon, f, feq);
+		const float omw = 1.0f-w;
+		#pragma unroll
+		for(int i=0; i<19; i++) f[i] = fmaf(omw, f[i], w*feq[i]);
+		return;
+	}
+	collide_tail_general(p, is_E, forced, fxn, fyn, fzn, f, rhon, uxn, uyn, uzn);
+}
+
+// ---------------------------------------------------------------- the same collision on PACKED pairs
+// The 18 moving populations as nine pairs (f[2k+1], f[2k+2]) of opposite directions in 64-bit register pairs: the fast
+// path's equilibria, non-equilibrium parts and relaxation are v_pk_fma/mul/add_f32 on those pairs (two IEEE operations per
+// instruction, same roundings as the scalar code: value-identical).  Sums whose order is fixed (moments, stress tensor)
+// read the halves.  Used where the VALU is the limit (FP16C pair kernel).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(const float a) { f32x2 r = { a, a }; return r; }
+__device__ __forceinline__ f32x2 pm2(const float a) { f32x2 r = { a, -a }; return r; }
+__device__ __forceinline__ void calculate_f_eq_pk(const float rho, float ux, float uy, float uz, float& feq0, f32x2* feqp) {
+	const float rhom1 = rho-1.0f;
+	const float c3 = -3.0f*(sq(ux)+sq(uy)+sq(uz));
+	uz *= 3.0f;
+	ux *= 3.0f;
+	uy *= 3.0f;
+	feq0 = DEF_W0*fmaf(rho, 0.5f*c3, rhom1);
+	const float u0=ux+uy, u1=ux+uz, u2=uy+uz, u3=ux-uy, u4=ux-uz, u5=uy-uz;
+	const float rhos=DEF_WS*rho, rhoe=DEF_WE*rho, rhom1s=DEF_WS*rhom1, rhom1e=DEF_WE*rhom1;
+	const float v[9] = { ux, uy, uz, u0, u1, u2, u3, u4, u5 };
+	#pragma unroll
+	for(int k=0; k<9; k++) { // feq[2k+1] = fma(rw, fma(0.5, fma(v,v,c3), v), rm1w), feq[2k+2] the same with -v (FX/kernel.cpp:1045-1055)
+		const float A = fmaf(v[k], v[k], c3);
+		const f32x2 in = __builtin_elementwise_fma(splat2(0.5f), splat2(A), pm2(v[k]));
+		feqp[k] = __builtin_elementwise_fma(splat2(k<3 ? rhos : rhoe), in, splat2(k<3 ? rhom1s : rhom1e));
+	}
+}
+// Guo terms of the pair (2k+1, 2k+2): c_(2k+2) = -c_(2k+1), so both are w9 fma(+-cF, +-cu + 1/3, uF) (FX/kernel.cpp:1103-1113)
+template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, const float uF) {
+	constexpr int I = 2*K+1;
+	constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
+	const float cF = cdot<I>(fx, fy, fz), cu = cdot<I>(ux, uy, uz);
+	const f32x2 a = { cF, cdot<I+1>(fx, fy, fz) }, b = { cu, cdot<I+1>(ux, uy, uz) };
+	return splat2(w9)*__builtin_elementwise_fma(a, b+splat2(0.33333334f), splat2(uF));
+}
+// All cases in one: wave-uniform switches for "some lane may feel a force" and "some lane is a TYPE_E cell" select the
+// extra work; a lane for which the switch is on without need computes with F = 0 (u + 0/(2 rho) = u, Fin = +-0:
+// value-identical, +-0 aside, to the scalar code's per-lane shortcut).
+__device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
+	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+	const bool wave_has_E = __ballot(is_E)!=0ull;
+	{
+		float f[19];
+		f[0] = f0;
+		#pragma unroll
+		for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
+		calculate_rho_u(f, rhon, uxn, uyn, uzn);
+	}
+	if(wave_has_E) {
+		if(is_E) {
+			rhon = rho[n];
+			uxn = u[n];
+			uyn = u[(size_t)p.Np+n];
+			uzn = u[2ull*p.Np+n];
+		}
+	}
+	f32x2 Finp[9]; float Fin0 = 0.0f;
+	if(may_force) {
+		float fxn, fyn, fzn;
+		assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
+		const float rho2 = 0.5f/rhon;
+		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
+		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
+		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
+		const float uF = -0.33333334f*fmaf(uxn, fxn, fmaf(uyn, fyn, uzn*fzn));
+		Fin0 = 9.0f*DEF_W0*uF;
+		Finp[0] = forcing_pair<0>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[1] = forcing_pair<1>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[2] = forcing_pair<2>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[3] = forcing_pair<3>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[4] = forcing_pair<4>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[5] = forcing_pair<5>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[6] = forcing_pair<6>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[7] = forcing_pair<7>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[8] = forcing_pair<8>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+	} else {
+		uxn = clampf(uxn, -DEF_C, DEF_C);
+		uyn = clampf(uyn, -DEF_C, DEF_C);
+		uzn = clampf(uzn, -DEF_C, DEF_C);
+	}
+	float feq0; f32x2 feqp[9];
+	calculate_f_eq_pk(rhon, uxn, uyn, uzn, feq0, feqp);
+	float w = p.w;
+	if(p.subgrid) {
+		float n_[19];
+		#pragma unroll
+		for(int k=0; k<9; k++) { const f32x2 d = fp[k]-feqp[k]; n_[2*k+1] = d.x; n_[2*k+2] = d.y; }
+		w = smagorinsky_rate(p, rhon, n_);
+	}
+	const float omw = 1.0f-w;
+	float r0; f32x2 rp[9];
+	if(may_force) {
+		const float c_tau = fmaf(w, -0.5f, 1.0f);
+		r0 = fmaf(omw, f0, fmaf(w, feq0, Fin0*c_tau));
+		#pragma unroll
+		for(int k=0; k<9; k++) rp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], __builtin_elementwise_fma(splat2(w), feqp[k], Finp[k]*splat2(c_tau)));
+	} else {
+		r0 = fmaf(omw, f0, w*feq0);
+		#pragma unroll
+		for(int k=0; k<9; k++) rp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], splat2(w)*feqp[k]);
+	}
+	if(wave_has_E) {
+		r0 = is_E ? feq0 : r0;
+		#pragma unroll
+		for(int k=0; k<9; k++) { rp[k].x = is_E ? feqp[k].x : rp[k].x; rp[k].y = is_E ? feqp[k].y : rp[k].y; }
+	}
+	f0 = r0;
+	#pragma unroll
+	for(int k=0; k<9; k++) fp[k] = rp[k];
+}
+// conservative, position-only test: could buffer nudging or the top sponge act on this cell (assemble_force)?
+__device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
+	bool zone = false;
+	if(p.buffer_active) {
+		const int Nbuf_i = (int)p.buffer_N;
+		const int gx = (int)x+p.Ox, gy = (int)y+p.Oy, gz = (int)z+p.Oz;
+		zone = gx<=Nbuf_i || (int)(p.Nxg-1u)-gx<=Nbuf_i || gy<=Nbuf_i || (int)(p.Nyg-1u)-gy<=Nbuf_i || (int)(p.Nzg-1u)-gz<=Nbuf_i;
+	}
+	if(p.sponge_active) zone = zone || (int)(p.Nzg-2u)-((int)z+p.Oz)<(int)p.sponge_N;
+	return zone;
 }
 
 // ---------------------------------------------------------------- thermal D3Q7 lattice (TEMPERATURE), FX/kernel.cpp:1306-1335,1639-1684
