@@ -32,6 +32,28 @@ def test_local_group_equals_single_domain(luw, gN, D, overlap, fp16c):
         s.backend.lbm.close()
 
 
+@pytest.mark.parametrize("gN,D,overlap", [((24, 20, 16), (1, 2, 2), True), ((26, 18, 16), (1, 3, 2), False), ((64, 12, 8), (1, 2, 1), True)])
+def test_local_group_pair_kernel(luw, gN, D, overlap):
+    """the FP16C pair kernel (two cells per lane; the automatic choice for wide FP16C rows) in x-whole decompositions: halo
+    cells in y / z pass through, shell and interior boxes tile the domain"""
+    from latticeurbanwind_amd import capi
+    from latticeurbanwind_amd.distributed import LocalGroup, HipDomain
+    from oracle import oracle
+    flags, u, rho = synthetic_state(*gN, seed=33, shell=None)
+    steps = 6
+    grp = LocalGroup(gN, D, 0.01, lambda lay: HipDomain(lay, 0.01, fp16c=True, kernel=capi.KERNEL_PAIR), overlap=overlap)
+    for s in grp.sims:
+        s.set_fields_from_global(flags, u, rho)
+    grp.run(steps)
+    gu, grho = grp.gather_u_rho()
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=True)
+    o.flags[:] = flags; o.u[:] = u; o.rho[:] = rho
+    o.run(steps)
+    assert np.array_equal(gu, o.u) and np.array_equal(grho, o.rho)
+    for s in grp.sims:
+        s.backend.lbm.close()
+
+
 @pytest.mark.parametrize("D,overlap,fp16c", [((2, 1, 1), False, False), ((1, 2, 2), True, False), ((2, 2, 2), True, True)])
 def test_local_group_thermal_lattice(luw, D, overlap, fp16c):
     """thermal D3Q7 lattice across domains on the GPU (pack / unpack of the single gi population per face cell): T and u of
