@@ -1,0 +1,69 @@
+"""Static check of the compiled gfx950 code (no GPU needed, hipcc cross-compiles): the FP16C kernels switch the wave's FP32
+rounding mode to round-toward-zero for their tail encode (luw_device.hpp, fp16c_code_hi_in_rtz_mode).  That is only valid
+if NO other floating-point instruction is scheduled behind the switch -- the C++ source orders them with asm fences; this
+test reads the generated ISA and holds the compiler to it.  Also pins the properties the performance notes in DESIGN.md
+rest on: no scratch spills in the product kernels, DDF stores in the saddr form."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "latticeurbanwind_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    flags = re.search(r"^HIPFLAGS\s*=\s*(.*)$", open(os.path.join(CSRC, "Makefile")).read(), re.M).group(1).split()
+    flags = [f for f in flags if f not in ("-fPIC",)]
+    out = str(tmp_path_factory.mktemp("isa") / "luw_core.s")
+    subprocess.check_call([hipcc, *flags, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, "luw_core.hip")],
+                          stderr=subprocess.DEVNULL)
+    kernels, name, body = {}, None, []
+    for line in open(out):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name, body = m.group(1), []
+        elif name and line.startswith(".Lfunc_end"):
+            kernels[name] = body; name = None
+        elif name:
+            t = line.strip()
+            if t and not t.startswith((";", ".")):
+                body.append(t)
+    return kernels
+
+
+FP_ARITH = re.compile(r"^v_(add|sub|subrev|fma|fmac|mad|mac|div|rcp|rsq|sqrt|min|max|med3|cvt|exp|log|sin|cos|ldexp|frexp|trunc|ceil|floor|rndne|fract|pk_fma|pk_add)_?\w*f(16|32|64)")
+
+
+def test_nothing_but_the_encode_follows_the_rounding_mode_switch(device_asm):
+    seen = 0
+    for name, body in device_asm.items():
+        idx = [i for i, t in enumerate(body) if t.startswith("s_setreg")]
+        if not idx or "k_codec_check" in name:
+            continue
+        assert len(idx) == 1, name
+        seen += 1
+        tail = body[idx[0] + 1:]
+        bad = [t for t in tail if FP_ARITH.match(t)]
+        assert not bad, "%s: floating-point work behind the RTZ switch: %s" % (name, bad[:5])
+        muls = [t for t in tail if t.startswith(("v_mul_f32", "v_pk_mul_f32"))]
+        stores = [t for t in tail if t.startswith("global_store")]
+        assert muls and len(stores) >= 19, name                      # the encode itself and the 19 DDF stores
+    assert seen >= 6, "expected the FP16C scalar (both parities, thermal) and pair kernels to use the RTZ encode, found %d" % seen
+
+
+def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
+    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2E", n) or re.search(r"k_stream_collide_pILi[01]ELi0E", n)]
+    assert len(product) == 6, product
+    for name in product:
+        body = device_asm[name]
+        assert not any(t.startswith(("scratch_", "buffer_store", "buffer_load")) for t in body), name + ": spills"
+        ddf_stores = [t for t in body if re.match(r"global_store_(dword|short)", t) and ("nt" in t.split()[-1] or "d16_hi" in t)]
+        vaddr = [t for t in ddf_stores if re.match(r"global_store_\w+ v\[", t)]
+        assert len(ddf_stores) >= 14 and not vaddr, "%s: DDF stores with 64-bit VGPR addresses: %s" % (name, vaddr[:3])
