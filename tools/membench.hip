@@ -102,6 +102,28 @@ template<int W, bool NT> __global__ __launch_bounds__(256) void k_update_half(ui
 		else { if(NT&&!shifted) __builtin_nontemporal_store(r, reinterpret_cast<uint32_t*>(p)); else __builtin_memcpy(p, &r, 4); }
 	}
 }
+// layouts for the 19 planes under the product access pattern (dword per lane, non-temporal, occupancy through LDS):
+// LAYOUT 0 plane-major [s][row][x]; 1 row-interleaved [row][s][x]; 2 slab-interleaved [z][s][y][x] (NY rows per slab)
+template<int LAYOUT, bool NT> __global__ __launch_bounds__(256) void k_update_layout(float* __restrict__ io, const size_t P, const unsigned NX, const unsigned NY) {
+	extern __shared__ float lds[];
+	const size_t e = (size_t)blockIdx.x*blockDim.x+threadIdx.x;
+	if(e>=P) return;
+	const size_t row = e/NX, x = e%NX;
+	float v[19];
+	#pragma unroll
+	for(int s=0; s<19; s++) {
+		size_t idx;
+		if(LAYOUT==0) idx = (size_t)s*P+e; else if(LAYOUT==1) idx = (row*19+s)*NX+x; else { const size_t z = row/NY, y = row%NY; idx = ((z*19+s)*NY+y)*NX+x; }
+		v[s] = NT ? __builtin_nontemporal_load(io+idx) : io[idx];
+	}
+	if(v[0]==-123.0f) lds[threadIdx.x] = v[0];
+	#pragma unroll
+	for(int s=0; s<19; s++) {
+		size_t idx;
+		if(LAYOUT==0) idx = (size_t)s*P+e; else if(LAYOUT==1) idx = (row*19+s)*NX+x; else { const size_t z = row/NY, y = row%NY; idx = ((z*19+s)*NY+y)*NX+x; }
+		if(NT) __builtin_nontemporal_store(v[s]+1.0f, io+idx); else io[idx] = v[s]+1.0f;
+	}
+}
 
 template<typename F> static double time_ms(F launch, int reps=20) {
 	hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -120,6 +142,14 @@ int main(int argc, char** argv) {
 	CHECK(hipMemset(A, 0, 19*N*4)); CHECK(hipMemset(B, 0, 19*N*4));
 	const double bytes = 152.0*N;
 	auto rep = [&](const char* name, double ms, double b) { printf("%-58s %8.3f ms  %8.1f GB/s\n", name, ms, b/ms/1e6); fflush(stdout); };
+	if(argc>1&&!strcmp(argv[1], "layout")) { // memory layouts of the 19 planes
+		#define LAY(L, NTV, name) { CHECK(hipFuncSetAttribute((const void*)k_update_layout<L, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048)); \
+			for(int blocks_per_cu : {8, 4, 3, 2}) { const size_t lds_bytes = blocks_per_cu>=8 ? 0 : (size_t)(160*1024/blocks_per_cu-2048); char nm[128]; snprintf(nm, sizeof(nm), "%s %d blocks/CU", name, blocks_per_cu); \
+			rep(nm, time_ms([&]{ hipLaunchKernelGGL((k_update_layout<L, NTV>), dim3((unsigned)((N+255)/256)), dim3(256), lds_bytes, 0, A, N, NX, 512u); }), bytes); } }
+		LAY(0, true, "plane-major      nt") LAY(1, true, "row-interleaved  nt") LAY(2, true, "slab-interleaved nt")
+		LAY(0, false, "plane-major        ") LAY(1, false, "row-interleaved    ") LAY(2, false, "slab-interleaved   ")
+		return 0;
+	}
 	if(argc>1&&!strcmp(argv[1], "half")) { // FP16C-shaped traffic only
 		uint16_t* H = reinterpret_cast<uint16_t*>(A);
 		CHECK(hipFuncSetAttribute((const void*)k_update_half<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024-2048));
