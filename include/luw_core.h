@@ -66,13 +66,13 @@ extern "C" {
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
 
 /* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
-#define LUW_KERNEL_AUTO 0
+#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 256 cells wide in x (even range, x not split, no thermal lattice), else SCALAR */
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
 #define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */
 #define LUW_KERNEL_SCALAR_CACHED 4      /* scalar kernel with the default cache policy instead of non-temporal DDF accesses (A/B) */
 #define LUW_KERNEL_SCALAR_NT_ALL 5      /* scalar kernel with non-temporal accesses on all 19 planes (A/B; the product uses nt on the 14 aligned planes) */
-#define LUW_KERNEL_PAIR 7               /* FP16C only: 2 cells / lane, direct neighbour addressing, one dword per lane and plane */
+#define LUW_KERNEL_PAIR 7               /* FP16C only: 2 cells / lane collided one after the other on packed FP32 pairs, one dword per lane and plane; falls back to SCALAR where it does not apply */
 #define LUW_KERNEL_VEC1 6               /* 1 cell / lane with aligned accesses + wave64 lane shifts for the x+1 populations (A/B) */
 #define LUW_KERNEL_SCALAR_GENERAL 8     /* scalar kernel without the wave-uniform "no TYPE_E, no force in this wave" fast path (A/B) */
 #define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
