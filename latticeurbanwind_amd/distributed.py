@@ -181,7 +181,10 @@ class HipDomain:
         # point-to-point ops copy bytes, nothing interprets the halves)
         self.dtype = torch.float16 if fp16c else torch.float32
         self.compute = torch.cuda.Stream(device=self.device)
-        self.comm = torch.cuda.Stream(device=self.device)
+        # the boundary shell, the halo pack/unpack kernels and the exchange run on a high-priority queue so that they are not
+        # stuck behind the interior kernel's workgroups (LUW_COMM_PRIORITY=0 turns that off for A/B runs)
+        import os
+        self.comm = torch.cuda.Stream(device=self.device, priority=(-1 if os.environ.get("LUW_COMM_PRIORITY", "1") != "0" else 0))
         self.thermal = kw.get("alpha") is not None       # thermal D3Q7 lattice: one more population per face cell travels
         self.buf, self.gbuf = {}, {}
         for a in layout.split_axes():
