@@ -569,58 +569,68 @@ template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k
 }
 
 // ---------------------------------------------------------------- halo pack / unpack, FX/kernel.cpp:2188-2270
-__device__ __constant__ uint8_t c_index_transfer[30] = {
-	1,  7, 13,  9, 15,
-	2,  8, 14, 10, 16,
-	3,  7, 14, 11, 17,
-	4,  8, 13, 12, 18,
-	5,  9, 16, 11, 18,
-	6, 10, 15, 12, 17
+// Face cell of thread t and its index a in the transfer buffers.  The buffers keep the reference's order (direction 0:
+// a = y + z Ny; 1: a = z + x Nz; 2: a = x + y Nx, FX/kernel.cpp:2188-2221), but the THREADS walk along x wherever x lies in the
+// face, so that the lattice side of the copy is coalesced (for direction 1 the small buffer side is strided instead).
+template<int DIR> __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t t, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& a) {
+	if constexpr(DIR==0) { x = fixed; y = t%p.Ny; z = t/p.Ny; a = t; }
+	else if constexpr(DIR==1) { x = t%p.Nx; y = fixed; z = t/p.Nx; a = x*p.Nz+z; }
+	else { x = t%p.Nx; y = t/p.Nx; z = fixed; a = t; }
+}
+// device index of the neighbour of (x,y,z) in direction c_I (periodic wrap), I compile-time: three selects, no table
+template<int I> __device__ __forceinline__ uint32_t neighbor_index(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
+	constexpr int cx = (I==1||I==7||I==9||I==13||I==15) ? 1 : (I==2||I==8||I==10||I==14||I==16) ? -1 : 0;
+	constexpr int cy = (I==3||I==7||I==11||I==14||I==17) ? 1 : (I==4||I==8||I==12||I==13||I==18) ? -1 : 0;
+	constexpr int cz = (I==5||I==9||I==11||I==16||I==18) ? 1 : (I==6||I==10||I==12||I==15||I==17) ? -1 : 0;
+	const uint32_t xs = cx>0 ? (x+1u==p.Nx ? 0u : x+1u) : cx<0 ? (x==0u ? p.Nx-1u : x-1u) : x;
+	const uint32_t ys = cy>0 ? (y+1u==p.Ny ? 0u : y+1u) : cy<0 ? (y==0u ? p.Ny-1u : y-1u) : y;
+	const uint32_t zs = cz>0 ? (z+1u==p.Nz ? 0u : z+1u) : cz<0 ? (z==0u ? p.Nz-1u : z-1u) : z;
+	return xs+(ys+zs*p.Ny)*p.Px;
+}
+// the 5 D3Q19 populations that leave through face (DIR, side), FX/kernel.cpp:2223-2229 
+template<int DIR, int PM, int BB> struct TransferIndex {
+	static constexpr int table[30] = { 1, 7, 13, 9, 15,  2, 8, 14, 10, 16,  3, 7, 14, 11, 17,  4, 8, 13, 12, 18,  5, 9, 16, 11, 18,  6, 10, 15, 12, 17 };
+	static constexpr int value = table[(2*DIR+PM)*5+BB];
 };
-__device__ __forceinline__ void face_cell(const KParams& p, const uint32_t a, const uint32_t direction, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z) {
-	if(direction==0u) { x = fixed; y = a%p.Ny; z = a/p.Ny; }
-	else if(direction==1u) { x = a/p.Nz; y = fixed; z = a%p.Nz; }
-	else { x = a%p.Nx; y = a/p.Nx; z = fixed; }
-}
 // G = false: the 5 D3Q19 populations of a face (fi); G = true: the single D3Q7 population of the thermal lattice (gi, i = side+1,
-// FX/kernel.cpp:2338-2351) -- same slot algebra, the D3Q7 neighbours are the first six of the D3Q19 list
-template<typename T, bool G=false> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
-	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
-	if(a>=A) return;
-	const uint32_t Nd = direction==0u ? p.Nx : direction==1u ? p.Ny : p.Nz;
-	#pragma unroll
-	for(uint32_t pm=0u; pm<2u; pm++) {
-		uint32_t x, y, z;
-		face_cell(p, a, direction, pm==0u ? Nd-2u : 1u, x, y, z);
-		uint32_t j[19];
-		neighbors(p, x, y, z, j);
-		T* buf = pm==0u ? buf_p : buf_m;
-		for(uint32_t bb=0u; bb<(G ? 1u : 5u); bb++) {
-			const uint32_t i = G ? 2u*direction+pm+1u : c_index_transfer[(2u*direction+pm)*5u+bb];
-			const uint32_t plane = t_odd ? ((i&1u) ? i+1u : i-1u) : i;
-			buf[(size_t)bb*A+a] = fi[(size_t)plane*p.Np+((i&1u) ? j[i] : j[0])];
-		}
-	}
+// FX/kernel.cpp:2338-2351) -- same slot algebra, the D3Q7 neighbours are the first six of the D3Q19 list.
+// Everything about a population is compile-time (direction is a template parameter), so no per-thread index table exists.
+template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void extract_one(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf, const T* __restrict__ fi) {
+	constexpr int i = G ? 2*DIR+PM+1 : TransferIndex<DIR, PM, BB>::value;
+	const uint32_t plane = t_odd ? ((i&1) ? i+1 : i-1) : i;
+	const uint32_t n = (i&1) ? neighbor_index<i>(p, x, y, z) : x+(y+z*p.Ny)*p.Px;
+	buf[(size_t)BB*A+a] = fi[(size_t)plane*p.Np+n];
 }
-template<typename T, bool G=false> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t direction, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
-	const uint32_t a = blockIdx.x*blockDim.x+threadIdx.x;
-	if(a>=A) return;
-	const uint32_t Nd = direction==0u ? p.Nx : direction==1u ? p.Ny : p.Nz;
-	#pragma unroll
-	for(uint32_t pm=0u; pm<2u; pm++) {
-		uint32_t x, y, z;
-		face_cell(p, a, direction, pm==0u ? Nd-1u : 0u, x, y, z);
-		uint32_t j[19];
-		neighbors(p, x, y, z, j);
-		const T* buf = pm==0u ? buf_p : buf_m;
-		for(uint32_t bb=0u; bb<(G ? 1u : 5u); bb++) {
-			const uint32_t i = G ? 2u*direction+pm+1u : c_index_transfer[(2u*direction+pm)*5u+bb];
-			const uint32_t plane = t_odd ? i : ((i&1u) ? i+1u : i-1u);
-			fi[(size_t)plane*p.Np+((i&1u) ? j[0] : j[i-1u])] = buf[(size_t)bb*A+a];
-		}
-	}
+template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void insert_one(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf, T* __restrict__ fi) {
+	constexpr int i = G ? 2*DIR+PM+1 : TransferIndex<DIR, PM, BB>::value;
+	const uint32_t plane = t_odd ? i : ((i&1) ? i+1 : i-1);
+	const uint32_t n = (i&1) ? x+(y+z*p.Ny)*p.Px : neighbor_index<i-1>(p, x, y, z);
+	fi[(size_t)plane*p.Np+n] = buf[(size_t)BB*A+a];
 }
-
+template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
+	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
+	if(t>=A) return;
+	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
+	uint32_t x, y, z, a;
+	face_cell<DIR>(p, t, Nd-2u, x, y, z, a);
+	extract_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	if constexpr(!G) { extract_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi); }
+	face_cell<DIR>(p, t, 1u, x, y, z, a);
+	extract_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	if constexpr(!G) { extract_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi); }
+}
+template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
+	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
+	if(t>=A) return;
+	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
+	uint32_t x, y, z, a;
+	face_cell<DIR>(p, t, Nd-1u, x, y, z, a);
+	insert_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	if constexpr(!G) { insert_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi); }
+	face_cell<DIR>(p, t, 0u, x, y, z, a);
+	insert_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	if constexpr(!G) { insert_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi); }
+}
 // ---------------------------------------------------------------- mesh voxeliser
 // voxelize_mesh with direction 2 (z rays; LUW always voxelises TYPE_S along z, FX/lbm.cpp:1427-1430) for a static mesh:
 // one lane per (x,y) column casts a ray from the bottom of the padded bounding box through ALL triangles
@@ -938,6 +948,19 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
+}
+
+// launch helper: picks the template instance for (storage type, lattice, direction)
+template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const uint32_t direction, void* buf_p, void* buf_m) {
+	const uint32_t A = (uint32_t)luw_get_area(s, direction);
+	const dim3 grid((A+255u)/256u), block(256);
+	const uint32_t odd = (uint32_t)(s->t&1ull);
+	void* lat = G ? s->d_gi : s->d_fi;
+	#define LUW_TR(TT, DD) do { if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat); \
+		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat); } while(0)
+	if(s->ddf_bytes==2u) { if(direction==0u) LUW_TR(uint16_t, 0); else if(direction==1u) LUW_TR(uint16_t, 1); else LUW_TR(uint16_t, 2); }
+	else { if(direction==0u) LUW_TR(float, 0); else if(direction==1u) LUW_TR(float, 1); else LUW_TR(float, 2); }
+	#undef LUW_TR
 }
 
 // Where the driver places the DDF array physically changes the step time of this 19-stream kernel by up to 10 % on MI355X:
@@ -1552,22 +1575,14 @@ int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_fi: bad argument");
 	if(int e = set_device(s)) return e;
-	const uint32_t A = (uint32_t)luw_get_area(s, direction);
-	const dim3 grid((A+255u)/256u), block(256);
-	const uint32_t odd = (uint32_t)(s->t&1ull);
-	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_extract_fi<uint16_t>), grid, block, 0, s->stream, s->kp, direction, A, odd, (uint16_t*)buf_p, (uint16_t*)buf_m, (const uint16_t*)s->d_fi);
-	else hipLaunchKernelGGL((k_extract_fi<float>), grid, block, 0, s->stream, s->kp, direction, A, odd, (float*)buf_p, (float*)buf_m, (const float*)s->d_fi);
+	launch_transfer<false, false>(s, direction, buf_p, buf_m);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_insert_fi: bad argument");
 	if(int e = set_device(s)) return e;
-	const uint32_t A = (uint32_t)luw_get_area(s, direction);
-	const dim3 grid((A+255u)/256u), block(256);
-	const uint32_t odd = (uint32_t)(s->t&1ull);
-	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const uint16_t*)buf_p, (const uint16_t*)buf_m, (uint16_t*)s->d_fi);
-	else hipLaunchKernelGGL((k_insert_fi<float>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_fi);
+	launch_transfer<false, true>(s, direction, const_cast<void*>(buf_p), const_cast<void*>(buf_m));
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
@@ -1575,11 +1590,7 @@ int luw_enqueue_extract_gi(luw_solver* s, uint32_t direction, void* buf_p, void*
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_gi: bad argument");
 	if(!s->d_gi) return fail(LUW_ERR_STATE, "luw_enqueue_extract_gi: the solver was created without LUW_OPT_TEMPERATURE");
 	if(int e = set_device(s)) return e;
-	const uint32_t A = (uint32_t)luw_get_area(s, direction);
-	const dim3 grid((A+255u)/256u), block(256);
-	const uint32_t odd = (uint32_t)(s->t&1ull);
-	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_extract_fi<uint16_t, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (uint16_t*)buf_p, (uint16_t*)buf_m, (const uint16_t*)s->d_gi);
-	else hipLaunchKernelGGL((k_extract_fi<float, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (float*)buf_p, (float*)buf_m, (const float*)s->d_gi);
+	launch_transfer<true, false>(s, direction, buf_p, buf_m);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
@@ -1587,11 +1598,7 @@ int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, 
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_insert_gi: bad argument");
 	if(!s->d_gi) return fail(LUW_ERR_STATE, "luw_enqueue_insert_gi: the solver was created without LUW_OPT_TEMPERATURE");
 	if(int e = set_device(s)) return e;
-	const uint32_t A = (uint32_t)luw_get_area(s, direction);
-	const dim3 grid((A+255u)/256u), block(256);
-	const uint32_t odd = (uint32_t)(s->t&1ull);
-	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const uint16_t*)buf_p, (const uint16_t*)buf_m, (uint16_t*)s->d_gi);
-	else hipLaunchKernelGGL((k_insert_fi<float, true>), grid, block, 0, s->stream, s->kp, direction, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_gi);
+	launch_transfer<true, true>(s, direction, const_cast<void*>(buf_p), const_cast<void*>(buf_m));
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
