@@ -6,8 +6,8 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 512^3 D3Q19 channel per GPU, FP32 DDFs, Smagorinsky LES on,
 z=0 plane solid, the other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the
-same profile, rho=1.  N>1 runs the weak-scaled tile (512^3 per GPU; 8 GPUs = BASELINE configs[3] 2048x1024x512 with
-n_gpu=[4,2,1]) with one-cell halos exchanged over RCCL.  A "step" is one stream_collide pass over the whole lattice;
+same profile, rho=1.  N>1 runs the weak-scaled tile (512^3 cells per GPU; 8 GPUs = BASELINE configs[3] 2048x1024x512, cut as
+n_gpu=[1,4,2] by default, --n-gpu 4 2 1 for the deck's literal grid) with one-cell halos exchanged over RCCL.  A "step" is one stream_collide pass over the whole lattice;
 rho/u are written by the last step only (153 B/LUP mode); data is synthetic and resident in HBM
 before the timed region.  Prints ONE JSON line on rank 0.
 """
@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU lattice (default 512 512 512; with N > 1 the default global lattice is the BASELINE tile, 2048x1024x512 on 8 GPUs)")
-    ap.add_argument("--n-gpu", type=int, nargs=3, default=None, help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 2 4 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
+    ap.add_argument("--n-gpu", type=int, nargs=3, default=None, help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 4 2 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
     ap.add_argument("--buildings", action="store_true", help="BASELINE configs[2] solid mask (box array); use with --size 1024 1024 256")

@@ -22,14 +22,15 @@ def choose_decomposition(world, split_x=False):
 
     split_x=False (default): the memory-fastest axis is kept whole -- rows stay complete memory lines, the y/z boundary
     shells are whole rows and the halo traffic hides behind the interior: 8 GPUs cover the 2048x1024x512 tile of
-    BASELINE configs[3] as n_gpu=[1,2,4] (local 2048x512x128).  split_x=True reproduces the deck's literal
+    BASELINE configs[3] as n_gpu=[1,4,2] (local 2048x256x256: the least halo area among the x-whole grids, and the fastest
+    rank step measured, 3.42 ms vs 3.55 ms for [1,2,4]; tools/bench_layouts.py).  split_x=True reproduces the deck's literal
     n_gpu=[4,2,1] (local 512^3); with x split the step runs the whole box first and exchanges afterwards (measured on
-    MI355X, one rank with loopback halos: 3.77 ms sequential vs 4.19 ms with an x shell, vs 3.38 ms undivided).
+    MI355X, one rank with loopback halos: 3.77 ms sequential vs 4.2-5.2 ms with an x shell, vs 3.37 ms undivided).
     Returns (D, global_lattice)."""
     if split_x:
         table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1), 16: (4, 4, 1)}
     else:
-        table = {1: (1, 1, 1), 2: (1, 2, 1), 4: (1, 2, 2), 8: (1, 2, 4), 16: (1, 4, 4)}
+        table = {1: (1, 1, 1), 2: (1, 2, 1), 4: (1, 2, 2), 8: (1, 4, 2), 16: (1, 4, 4)}
     if world in table:
         return table[world]
     d = [1, 1, 1]

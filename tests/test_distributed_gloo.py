@@ -61,7 +61,7 @@ def test_gloo_multi_domain_thermal_lattice(tmp_path):
 def test_layout_matches_reference_rules():
     from latticeurbanwind_amd.distributed import DomainLayout, choose_decomposition, tile_lattice
     assert choose_decomposition(8, split_x=True) == (4, 2, 1) and choose_decomposition(2, split_x=True) == (2, 1, 1) and choose_decomposition(1) == (1, 1, 1)
-    assert choose_decomposition(8) == (1, 2, 4) and choose_decomposition(4) == (1, 2, 2) and choose_decomposition(2) == (1, 2, 1) and choose_decomposition(6)[0] == 1
+    assert choose_decomposition(8) == (1, 4, 2) and choose_decomposition(4) == (1, 2, 2) and choose_decomposition(2) == (1, 2, 1) and choose_decomposition(6)[0] == 1
     assert tile_lattice(1) == (512, 512, 512) and tile_lattice(2) == (1024, 512, 512) and tile_lattice(4) == (1024, 1024, 512) and tile_lattice(8) == (2048, 1024, 512)
     for w in (1, 2, 4, 8):
         assert all(g % d == 0 for g, d in zip(tile_lattice(w), choose_decomposition(w))) and all(g % d == 0 for g, d in zip(tile_lattice(w), choose_decomposition(w, True)))
