@@ -294,7 +294,12 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
 	// (or pre-swap for the pass-through)
 	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
-		auto bits = [&](const int q) { return (uint32_t)(c ? (int32_t)raw[q]>>16 : (int32_t)(raw[q]<<16)>>16)<<12&0x87FFF000u; };
+		auto bits = [&](const int q) { // (sign-extended half) << 12 in one SDWA shift, then the mask of half_to_float_custom_sx
+			uint32_t t;
+			if(c) asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(raw[q]));
+			else asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(raw[q]));
+			return t&0x87FFF000u;
+		};
 		f0 = __uint_as_float(bits(0))*0x1p+112f;
 		#pragma unroll
 		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
