@@ -755,21 +755,22 @@ __global__ __launch_bounds__(256) void k_stats_accumulate(const KParams p, const
 	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
 	if(x>=p.Nx) return;
 	const uint32_t n = x+(y+z*p.Ny)*p.Px;
-	if(avg_T) { const float ta = avg_T[n]; avg_T[n] = ta+(Tf[n]-ta)*inv_n; } // FX/setup.cpp:4481-4484
+	// every array is streamed exactly once per sample: non-temporal accesses keep them out of the way of the step kernel's lines
+	if(avg_T) { const float ta = ldg<true>(avg_T+n); stg<true>(avg_T+n, ta+(ldg<true>(Tf+n)-ta)*inv_n); } // FX/setup.cpp:4481-4484
 	const size_t Np = p.Np;
 	#pragma unroll
 	for(int c=0; c<3; c++) {
-		const float v = u[c*Np+n];
-		float mean = avg_u[c*Np+n];
+		const float v = ldg<true>(u+c*Np+n);
+		float mean = ldg<true>(avg_u+c*Np+n);
 		const float delta = v-mean;
 		mean += delta*inv_n;
 		const float delta2 = v-mean;
-		m2[c*Np+n] += delta*delta2;
-		avg_u[c*Np+n] = mean;
+		stg<true>(m2+c*Np+n, ldg<true>(m2+c*Np+n)+delta*delta2);
+		stg<true>(avg_u+c*Np+n, mean);
 	}
-	const float r = rho[n];
-	const float ra = avg_rho[n];
-	avg_rho[n] = ra+(r-ra)*inv_n;
+	const float r = ldg<true>(rho+n);
+	const float ra = ldg<true>(avg_rho+n);
+	stg<true>(avg_rho+n, ra+(r-ra)*inv_n);
 }
 
 // ---------------------------------------------------------------- self-check of the fast FP16C codec
