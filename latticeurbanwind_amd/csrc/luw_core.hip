@@ -111,7 +111,43 @@ template<bool NT, typename T> __device__ __forceinline__ T ldo(const T* plane, c
 template<bool NT, typename T> __device__ __forceinline__ void sto(T* plane, const uint32_t byte_off, const T v) {
 	stg<NT>(reinterpret_cast<T*>(reinterpret_cast<char*>(plane)+byte_off), v);
 }
-// byte offset of the +c_i neighbour for odd i (periodic wrap, FX/kernel.cpp:920-958)
+// Addressing.  y and z of a block are uniform (they come from blockIdx), so the start of every row a cell touches -- its own
+// and those of its y/z neighbours (periodic wrap, FX/kernel.cpp:920-958) -- is a uniform 64-bit ELEMENT offset that the scalar
+// unit adds to the plane base; the only per-lane parts are the byte offsets of x and of x+1 within a row.  Two offset VGPRs
+// instead of ten, and no limit on the plane size (a per-plane 32-bit byte offset would stop at 2^30 FP32 cells).
+struct RowOff { size_t r00; int64_t p0, _0p, pp, m0, _0m, pm; };   // own row (y,z); steps to the rows (y+1,z), (y,z+1), (y+1,z+1), (y-1,z), (y,z-1), (y+1,z-1)
+struct LaneOff { uint32_t x, xp; };                            // byte offsets of x and of x+1 (wrapped) within a row
+__device__ __forceinline__ RowOff row_offsets(const KParams& p, const uint32_t y, const uint32_t z) {
+	// the neighbour rows as the own row plus a step that is +-(one row / one z plane) or, at the periodic wrap, the way back
+	// across the lattice: selects and additions on the scalar unit, a single 64-bit product for the own row
+	const uint32_t A = p.Px*p.Ny;                                  // cells of a z plane (< 2^32: it divides Np)
+	const int64_t sy = (int64_t)p.Px, wy = (int64_t)(p.Px*(p.Ny-1u)), sz = (int64_t)A, wz = (int64_t)((uint64_t)A*(p.Nz-1u));
+	const int64_t dyp = y+1u==p.Ny ? -wy : sy, dym = y==0u ? wy : -sy;
+	const int64_t dzp = z+1u==p.Nz ? -wz : sz, dzm = z==0u ? wz : -sz;
+	RowOff r;
+	r.r00 = (size_t)z*A+(size_t)(y*p.Px);
+	r.p0 = dyp; r._0p = dzp; r.pp = dyp+dzp; r.m0 = dym; r._0m = dzm; r.pm = dyp+dzm;
+	return r;
+}
+template<typename T> __device__ __forceinline__ LaneOff lane_offsets(const KParams& p, const uint32_t x) {
+	LaneOff o;
+	o.x = x*(uint32_t)sizeof(T); o.xp = (x+1u==p.Nx ? 0u : x+1u)*(uint32_t)sizeof(T);
+	return o;
+}
+// the +c_I neighbour (I odd) lives nrow<I>() cells after the own row's start, at lane offset nlane<I>()
+template<int I> __device__ __forceinline__ int64_t nrow(const RowOff& r) {
+	if constexpr(I==1) return 0; else if constexpr(I==3) return r.p0; else if constexpr(I==5) return r._0p;
+	else if constexpr(I==7) return r.p0; else if constexpr(I==9) return r._0p; else if constexpr(I==11) return r.pp;
+	else if constexpr(I==13) return r.m0; else if constexpr(I==15) return r._0m; else return r.pm;
+}
+template<int I> __device__ __forceinline__ uint32_t nlane(const LaneOff& o) {
+	if constexpr(I==1||I==7||I==9||I==13||I==15) return o.xp; else return o.x;
+}
+
+// The same addresses as ONE 32-bit byte offset per neighbour within a plane (own cell + 9 neighbours in VGPRs, plane bases
+// without the row): needs Np*sizeof(T) <= 2^32, and is what the FP32 kernel uses when that holds -- its shorter scalar
+// prologue lets a wave issue its loads earlier, worth 1 % at 512^3 on the HBM-bound kernel; the VALU-bound FP16C kernels and
+// larger lattices take the row form above.
 struct NbrOff { uint32_t n, j1, j3, j5, j7, j9, j11, j13, j15, j17; };
 template<typename T> __device__ __forceinline__ NbrOff neighbor_offsets(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
 	const uint32_t xp = x+1u==p.Nx ? 0u : x+1u;
@@ -131,6 +167,41 @@ template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
 	else if constexpr(I==7) return o.j7; else if constexpr(I==9) return o.j9; else if constexpr(I==11) return o.j11;
 	else if constexpr(I==13) return o.j13; else if constexpr(I==15) return o.j15; else return o.j17;
 }
+// one interface over both forms: plane pointer adjustment (uniform) + lane byte offset of the own cell / the +c_I neighbour
+template<typename T, bool FLAT> struct CellAddr;
+template<typename T> struct CellAddr<T, false> {
+	RowOff rb; LaneOff o; uint32_t n;
+	// returns what the caller adds to its lattice pointer: from then on it points at the own row (uniform)
+	__device__ __forceinline__ size_t init(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const bool noshift) {
+		rb = row_offsets(p, y, z); o = lane_offsets<T>(p, x);
+		if(noshift) o.xp = o.x;
+		n = x+(uint32_t)rb.r00;
+		return rb.r00;
+	}
+	template<int I> __device__ __forceinline__ int64_t row() const { return nrow<I>(rb); }
+	template<int I> __device__ __forceinline__ uint32_t lane() const { return nlane<I>(o); }
+	__device__ __forceinline__ uint32_t own() const { return o.x; }
+	__device__ __forceinline__ uint32_t jx() const { return o.xp/(uint32_t)sizeof(T)+(uint32_t)rb.r00; }
+	__device__ __forceinline__ uint32_t jy() const { return n+(uint32_t)rb.p0; }
+	__device__ __forceinline__ uint32_t jz() const { return n+(uint32_t)rb._0p; }
+	__device__ __forceinline__ void redefine() { asm volatile("" : "+v"(o.x), "+v"(o.xp)); }
+};
+template<typename T> struct CellAddr<T, true> {
+	NbrOff o; uint32_t n;
+	__device__ __forceinline__ size_t init(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const bool noshift) {
+		o = neighbor_offsets<T>(p, x, y, z);
+		if(noshift) { o.j1 = o.n; o.j7 = o.j3; o.j9 = o.j5; o.j13 = (x+(y==0u ? p.Ny-1u : y-1u)*p.Px+z*p.Px*p.Ny)*(uint32_t)sizeof(T); o.j15 = (x+y*p.Px+(z==0u ? p.Nz-1u : z-1u)*p.Px*p.Ny)*(uint32_t)sizeof(T); }
+		n = o.n/(uint32_t)sizeof(T);
+		return 0u;
+	}
+	template<int I> __device__ __forceinline__ int64_t row() const { return 0; }
+	template<int I> __device__ __forceinline__ uint32_t lane() const { return nbr<I>(o); }
+	__device__ __forceinline__ uint32_t own() const { return o.n; }
+	__device__ __forceinline__ uint32_t jx() const { return o.j1/(uint32_t)sizeof(T); }
+	__device__ __forceinline__ uint32_t jy() const { return o.j3/(uint32_t)sizeof(T); }
+	__device__ __forceinline__ uint32_t jz() const { return o.j5/(uint32_t)sizeof(T); }
+	__device__ __forceinline__ void redefine() { asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17)); }
+};
 
 // MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
 // measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
@@ -142,7 +213,7 @@ template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
 #ifndef LUW_MAXW_F32
 #define LUW_MAXW_F32 4
 #endif
-template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
@@ -153,19 +224,19 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 	if(xi<(int)b.x0||xi>=(int)b.x1) return;
 	const uint32_t x = (uint32_t)xi, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(cell_is_halo(p, x, y, z)) return;
-	NbrOff o = neighbor_offsets<T>(p, x, y, z);
-	if constexpr(MODE==2) { o.j1 = o.n; o.j7 = o.j3; o.j9 = o.j5; o.j13 = (x+(y==0u ? p.Ny-1u : y-1u)*p.Px+z*p.Px*p.Ny)*(uint32_t)sizeof(T); o.j15 = (x+y*p.Px+(z==0u ? p.Nz-1u : z-1u)*p.Px*p.Ny)*(uint32_t)sizeof(T); }
-	const uint32_t n = o.n/(uint32_t)sizeof(T);
+	CellAddr<T, FLAT> a;
+	fi += a.init(p, x, y, z, MODE==2);
+	const uint32_t n = a.n;
 	const uint8_t flagsn = flags[n];
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
 	const size_t Np = p.Np;
 	float f[19];
-	f[0] = ddf_decode<T>(ldo<(NT!=0)>(fi, o.n));
+	f[0] = ddf_decode<T>(ldo<(NT!=0)>(fi, a.own()));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n));
-		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o)));
+		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
+		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
 	});
 	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
@@ -173,8 +244,7 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
 			float u0[3];
 			collide_cell<true>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
-			constexpr uint32_t es = (uint32_t)sizeof(T);
-			thermal_collide<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
+			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
 		} else
 		collide_cell<(MODE!=3)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
@@ -187,34 +257,32 @@ template<typename T, int PARITY, int MODE=0, int NT=2> __global__ __launch_bound
 	// the ten offsets pass through an empty asm so that they are (re)defined as 32-bit values in the block that holds the
 	// stores: instruction selection works per basic block, and without seeing the zero-extension there it builds nineteen
 	// 64-bit addresses (v_lshl_add_u64 + a VGPR pair each) instead of the saddr form the loads use
-	asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17));
+	a.redefine();
 	if constexpr(sizeof(T)==2&&MODE!=1) { // FP16C, nothing but the stores left: the 3-instruction encode under round-toward-zero
 		uint32_t c[19];
 		if constexpr(MODE==4) {
 			uint32_t cg[7];
 			fp16c_encode19_hi_rtz_final(f, c, g, cg);
-			constexpr uint32_t es = (uint32_t)sizeof(T);
-			thermal_store<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, gi, [&](const int i) { return (T)(cg[i]>>16); });
+			thermal_store<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), gi, [&](const int i) { return (T)(cg[i]>>16); });
 		} else fp16c_encode19_hi_rtz_final(f, c);
-		sto<(NT!=0)>(fi, o.n, (T)(c[0]>>16));
+		sto<(NT!=0)>(fi, a.own(), (T)(c[0]>>16));
 		static_for_pairs([&](auto ic) {
 			constexpr int i = decltype(ic)::value;
 			constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-			sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), (T)(c[i]>>16));
-			sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n, (T)(c[i+1]>>16));
+			sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), (T)(c[i]>>16));
+			sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), (T)(c[i+1]>>16));
 		});
 		return;
 	}
 	if constexpr(MODE==4) {
-		constexpr uint32_t es = (uint32_t)sizeof(T);
-		thermal_store<T, PARITY>(p, n, o.j1/es, o.j3/es, o.j5/es, gi, [&](const int i) { return ddf_encode<T>(g[i]); });
+		thermal_store<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), gi, [&](const int i) { return ddf_encode<T>(g[i]); });
 	}
-	sto<(NT!=0)>(fi, o.n, ddf_encode<T>(f[0]));
+	sto<(NT!=0)>(fi, a.own(), ddf_encode<T>(f[0]));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-		sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), ddf_encode<T>(f[i]));
-		sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, o.n, ddf_encode<T>(f[i+1]));
+		sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), ddf_encode<T>(f[i]));
+		sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), ddf_encode<T>(f[i+1]));
 	});
 }
 
@@ -259,9 +327,11 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
-	NbrOff o = neighbor_offsets<uint16_t>(p, x, y, z);            // offsets of cell x; cell x+1 sits 2 bytes further
+	const RowOff rb = row_offsets(p, y, z);
+	LaneOff o = lane_offsets<uint16_t>(p, x);                      // offsets of cell x; cell x+1 sits 2 bytes further
 	const bool wrap = x+2u==p.Nx;                                  // cell x+1 is the last of the row: its x+1 neighbour is x = 0
-	const uint32_t n = o.n>>1;
+	const uint32_t n = x+(uint32_t)rb.r00;
+	fi += rb.r00;                                                  // own row (uniform)
 	const size_t Np = p.Np;
 	const uint32_t fl2 = *reinterpret_cast<const uint16_t*>(flags+n);
 	const uint8_t fl[2] = { (uint8_t)(fl2&0xFFu), (uint8_t)(fl2>>8) };
@@ -273,18 +343,18 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 	// behind the row end (the next row's x = 0, or the slack behind the plane: in bounds, see lead_alloc / the plane skew):
 	// it is replaced by the wrapped neighbour in ONE divergent fix-up block behind the loads.
 	uint32_t raw[19];                                              // low half: cell x, high half: cell x+1
-	raw[0] = ld_pair<true>(fi, o.n);
+	raw[0] = ld_pair<true>(fi, o.x);
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-		raw[i] = ld_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.n);
-		raw[i+1] = ld_pair<!shifted>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o));
+		raw[i] = ld_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x);
+		raw[i+1] = ld_pair<!shifted>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o));
 	});
 	if(wrap) {
 		static_for_pairs([&](auto ic) {
 			constexpr int i = decltype(ic)::value;
-			if constexpr(i==1||i==7||i==9||i==13||i==15) { // nbr<i>(o) addresses x+1 = Nx-1 of the neighbour row; x+2 wraps to its x = 0
-				const uint32_t hi = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(fi+(size_t)slotB<PARITY>(i)*Np)+(nbr<i>(o)-2u*(p.Nx-1u)));
+			if constexpr(i==1||i==7||i==9||i==13||i==15) { // the dword started at x+1 = Nx-1 of the neighbour row; x+2 wraps to that row's x = 0
+				const uint32_t hi = *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb));
 				raw[i+1] = (raw[i+1]&0xFFFFu)|(hi<<16);
 			}
 		});
@@ -333,23 +403,23 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 	}
 	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };
 	uint32_t cs[5];   // the five x+1 planes, stored last (dword or, on the row-end lane, two halves)
-	#define LUW_REDEFINE_OFFSETS asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17)) /* saddr stores, see k_stream_collide_s */
+	#define LUW_REDEFINE_OFFSETS asm volatile("" : "+v"(o.x), "+v"(o.xp)) /* saddr stores, see k_stream_collide_s */
 	LUW_REDEFINE_OFFSETS;
-	st_pair<true>(fi, o.n, pack(0));
+	st_pair<true>(fi, o.x, pack(0));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
 		constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
-		if constexpr(!shifted) st_pair<true>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), pack(i));
+		if constexpr(!shifted) st_pair<true>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o), pack(i));
 		else cs[k] = pack(i);
-		st_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.n, pack(i+1));
+		st_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x, pack(i+1));
 	});
 	if(!wrap) {
 		LUW_REDEFINE_OFFSETS;
 		static_for_pairs([&](auto ic) {
 			constexpr int i = decltype(ic)::value;
 			constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
-			if constexpr(i==1||i==7||i==9||i==13||i==15) st_pair<false>(fi+(size_t)slotB<PARITY>(i)*Np, nbr<i>(o), cs[k]);
+			if constexpr(i==1||i==7||i==9||i==13||i==15) st_pair<false>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o), cs[k]);
 		});
 	} else {
 		LUW_REDEFINE_OFFSETS;
@@ -357,9 +427,9 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 			constexpr int i = decltype(ic)::value;
 			if constexpr(i==1||i==7||i==9||i==13||i==15) {
 				constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
-				char* B = reinterpret_cast<char*>(fi+(size_t)slotB<PARITY>(i)*Np);
-				*reinterpret_cast<uint16_t*>(B+nbr<i>(o)) = (uint16_t)(cs[k]&0xFFFFu);
-				*reinterpret_cast<uint16_t*>(B+(nbr<i>(o)-2u*(p.Nx-1u))) = (uint16_t)(cs[k]>>16);
+				uint16_t* B = fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb);   // row of the neighbours: x+1 = Nx-1 is its last cell, x+2 its first
+				B[p.Nx-1u] = (uint16_t)(cs[k]&0xFFFFu);
+				B[0] = (uint16_t)(cs[k]>>16);
 			}
 		});
 	}
@@ -906,10 +976,15 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
-	#define LUW_LAUNCH_S(PAR, MODE, NT) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
+	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
+	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Np*sizeof(T)<=(1ull<<32);
+	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
+	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
 	if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
-		if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1, 4, 2>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T);
-		else hipLaunchKernelGGL((k_stream_collide_s<T, 0, 4, 2>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T);
+		#define LUW_LAUNCH_T(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 4, 2, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T)
+		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_T(1, true); else LUW_LAUNCH_T(0, true); } else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); } }
+		else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); }
+		#undef LUW_LAUNCH_T
 	}
 	else if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
 	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
@@ -917,6 +992,7 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
 	else if(mode==5) { if(odd) LUW_LAUNCH_S(1, 3, 2); else LUW_LAUNCH_S(0, 3, 2); }
 	else { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
+	#undef LUW_LAUNCH_SF
 	#undef LUW_LAUNCH_S
 }
 
@@ -1066,7 +1142,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	// a cell sit at the same offset of 19 equally aligned regions; the skew measured 2-4 % faster on every lattice shape tried
 	// (512^3 3.50 -> 3.40 ms, 768x768x256 3.87 -> 3.70 ms, 1024x1024x256 6.80 -> 6.69 ms; odd small multiples behave alike).
 	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz+64ull*33ull;
-	if(Np>(1ull<<30)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^30 (padded) cells per domain are not supported (32-bit byte offsets)");
+	if(Np>=(1ull<<32)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^32 (padded) cells per domain are not supported (32-bit cell indices)");
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
 	if(cfg->device<0||cfg->device>=ndev) return fail(LUW_ERR_INVALID, "luw_create: no such HIP device"); // FX/lbm.cpp:961-979

@@ -59,8 +59,10 @@ def test_nothing_but_the_encode_follows_the_rounding_mode_switch(device_asm):
 
 
 def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
-    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2E", n) or re.search(r"k_stream_collide_pILi[01]ELi0E", n)]
-    assert len(product) == 6, product
+    # scalar kernel: FP32 in both addressing forms (FLAT for planes within 32-bit byte offsets, row form beyond), FP16C in the row form;
+    # pair kernel; both time parities each
+    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]E", n) or re.search(r"k_stream_collide_pILi[01]ELi0E", n)]
+    assert len(product) == 8, product
     for name in product:
         body = device_asm[name]
         assert not any(t.startswith(("scratch_", "buffer_store", "buffer_load")) for t in body), name + ": spills"

@@ -3,7 +3,7 @@
 # prints, per kernel symbol matching $1 (default: the product kernels), VALU / SALU / memory instruction counts, 64-bit
 # address adds, VGPRs and occupancy.  usage: tools/isa_stats.sh [symbol-regex] [extra hipcc flags...]
 set -euo pipefail
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"; PAT="${1:-k_stream_collide_sI[tf]Li1ELi[04]ELi2E}"; shift || true
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"; PAT="${1:-k_stream_collide_sI[tf]Li1ELi[04]ELi2ELb[01]E|k_stream_collide_pILi1ELi0E}"; shift || true
 mkdir -p /tmp/isa && cd /tmp/isa
 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -I"$ROOT/include" --save-temps -c -o luw.o "$ROOT/latticeurbanwind_amd/csrc/luw_core.hip" "$@" 2>/dev/null
 S=luw_core-hip-amdgcn-amd-amdhsa-gfx950.s
