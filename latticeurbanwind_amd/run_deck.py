@@ -19,6 +19,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks' processes (normally already exported)
+
 from . import capi
 from .distributed import DomainDecomposedLBM, DomainLayout
 
