@@ -153,6 +153,12 @@ def main():
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON, rank 0): everything libraries print on file descriptor 1 while the run is set up
+    # (RCCL's "Librccl path", Gloo's connection notes) is sent to stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import latticeurbanwind_amd as luw
     from latticeurbanwind_amd import capi
@@ -198,13 +204,32 @@ def main():
         if any(g % d for g, d in zip(gN, D)):
             raise SystemExit("bench.py: lattice %s is not divisible by n_gpu %s" % (gN, D))
         Nx, Ny, Nz = (g // d for g, d in zip(gN, D))          # per-GPU block (without halos)
-        sim = DomainDecomposedLBM(gN, D, nu, fp16c=fp16c, kernel=kern, device=local_rank)
-        ox, oy, oz = sim.global_offset
-        fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN, buildings=args.buildings)
-        sim.set_fields(fl, u, rho)
-        if args.coriolis:
-            sim.backend.set_coriolis(*coriolis_omega())
-        sim.initialize()
+        exchange_note = None
+        gloo_group = dist.new_group(backend="gloo") if args.share_device is None else None   # only used if RCCL point-to-point fails below
+
+        def make_sim(transport=None):
+            sim = DomainDecomposedLBM(gN, D, nu, fp16c=fp16c, kernel=kern, device=local_rank, transport=transport)
+            ox, oy, oz = sim.global_offset
+            fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN, buildings=args.buildings)
+            sim.set_fields(fl, u, rho)
+            if args.coriolis:
+                sim.backend.set_coriolis(*coriolis_omega())
+            return sim, fl
+        sim, fl = make_sim()
+        try:
+            sim.initialize()
+            ok = torch.ones(1)
+        except Exception as e:      # RCCL p2p refused on this node: say so and fall back to host-staged halos rather than report nothing
+            sys.stderr.write("bench.py rank %d: halo exchange over RCCL failed (%s); falling back to host-staged gloo\n" % (rank, str(e)[:300]))
+            ok = torch.zeros(1)
+        if gloo_group is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
+            if ok.item() == 0:
+                from latticeurbanwind_amd.distributed import DomainLayout, HostStagedTransport
+                sim.backend.close()
+                sim, fl = make_sim(HostStagedTransport(DomainLayout(gN, D, rank), group=gloo_group))
+                sim.initialize()
+                exchange_note = "host-staged gloo (RCCL point-to-point failed on this node)"
         sim.run(args.warmup)
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -232,7 +257,7 @@ def main():
                        % (("%dx%dx%d D3Q19 channel%s" % (Nx, Ny, Nz, " with the configs[2] building array (solid fraction %.3f)" % float((fl == 1).mean()) if args.buildings else " (BASELINE configs[1])")) if world == 1 else
                           ("%dx%dx%d D3Q19 channel tile (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU" % (Nx * D[0], Ny * D[1], Nz * D[2], Nx, Ny, Nz)),
                           ("FP16C" if fp16c else "FP32") + (" + Coriolis force" if args.coriolis else "") + (" + thermal D3Q7 lattice" if args.thermal else ""), "every step" if args.every_step_fields else "by the last step only"),
-                       "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "halo_exchange": (None if D == (1, 1, 1) else ("RCCL p2p, overlapped with the interior (x rows kept whole)" if sim.overlap else "RCCL p2p after the whole-box kernel (x split)")), "kernel": args.kernel,
+                       "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "halo_exchange": (None if D == (1, 1, 1) else (exchange_note or ("gloo + host staging (--share-device test aid)" if args.share_device is not None else "RCCL p2p")) + (", overlapped with the interior (x rows kept whole)" if sim.overlap else " after the whole-box kernel (x split)")), "kernel": args.kernel,
                        "bytes_per_lup": bpl},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
@@ -253,7 +278,9 @@ def main():
                 out["parity"] = reference_parity()
             except Exception as e:      # never let the side measurement break the benchmark line
                 out["parity"] = {"error": str(e)[:200]}
-        print(json.dumps(out))
+        sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(out)); sys.stdout.flush()
+        os.dup2(2, 1)
     if world > 1 or args.force_distributed:
         import torch.distributed as dist
         dist.destroy_process_group()
