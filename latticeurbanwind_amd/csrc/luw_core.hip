@@ -977,7 +977,8 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
-	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Np*sizeof(T)<=(1ull<<32);
+	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid
+	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Np*sizeof(T)<=(1ull<<32) && !force_row;
 	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
 	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
 	if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
