@@ -399,6 +399,7 @@ inline V3 nearest_sample_velocity(const SampleCloud& c, const V3& pos) {
 class KnnSurfaceInterpolator {
 	const SampleCloud& c_;
 	float xmin_ = 0, xmax_ = 0, ymin_ = 0, ymax_ = 0, zmin_ = 0, zmax_ = 0, plane_tol_ = 0;
+	std::vector<int> on_plane_[5];
 	static bool solve6(double A[6][6], double bx[6], double by[6], double bz[6], double ax[6], double ay[6], double az[6]) { // Gaussian elimination, partial pivoting, 3 right-hand sides
 		for(int k=0; k<6; k++) {
 			int piv = k; double big = std::fabs(A[k][k]);
@@ -432,6 +433,12 @@ public:
 		for(const V3& p : c.P) { if(p.x<xmin_) xmin_ = p.x; if(p.x>xmax_) xmax_ = p.x; if(p.y<ymin_) ymin_ = p.y; if(p.y>ymax_) ymax_ = p.y; if(p.z<zmin_) zmin_ = p.z; if(p.z>zmax_) zmax_ = p.z; }
 		float ext = xmax_-xmin_; if(ymax_-ymin_>ext) ext = ymax_-ymin_; if(zmax_-zmin_>ext) ext = zmax_-zmin_;
 		plane_tol_ = 1e-5f*ext+1e-6f;
+		// samples of each outer plane, in file order (what the per-query plane filter of the reference keeps; built once)
+		for(int i=0; i<(int)c.P.size(); i++) {
+			const V3& p = c.P[i];
+			const float off[5] = {p.x-xmin_, p.x-xmax_, p.y-ymin_, p.y-ymax_, p.z-zmax_};
+			for(int k=0; k<5; k++) if(std::fabs(off[k])<=plane_tol_) on_plane_[k].push_back(i);
+		}
 	}
 	V3 eval(const V3& pos) const {
 		constexpr int K = 64; constexpr float eps2 = 1e-16f;
@@ -442,10 +449,8 @@ public:
 		int plane = 0; float dmin = d[0];
 		for(int k=1; k<5; k++) if(d[k]<dmin) { dmin = d[k]; plane = k; }
 		float best_r2[K]; int best_i[K]; int filled = 0; float kept_max = 0.0f;
-		for(int i=0; i<Pn; i++) {
+		for(const int i : on_plane_[plane]) {
 			const V3& p = c_.P[i];
-			const float off = plane==0 ? p.x-xmin_ : plane==1 ? p.x-xmax_ : plane==2 ? p.y-ymin_ : plane==3 ? p.y-ymax_ : p.z-zmax_;
-			if(!(std::fabs(off)<=plane_tol_)) continue;
 			float s1, s2; local(plane, p, pos, s1, s2);
 			const float r2 = s1*s1+s2*s2;
 			if(r2<=eps2) return c_.U[i]; // sample at the query point
