@@ -535,11 +535,4 @@ template<typename T, int PARITY, typename F> __device__ __forceinline__ void the
 		gi[(size_t)(PARITY ? i : i+1)*Np+n] = code_of(i+1);
 	}
 }
-template<typename T, int PARITY> __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
-		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, T* __restrict__ gi, float* __restrict__ Tf) {
-	float g[7];
-	thermal_collide<T, PARITY>(p, n, jx, jy, jz, x, y, z, flagsn, ux, uy, uz, gi, Tf, g);
-	thermal_store<T, PARITY>(p, n, jx, jy, jz, gi, [&](const int i) { return ddf_encode<T>(g[i]); });
-}
-
 } // namespace luw
