@@ -968,12 +968,20 @@ template<typename T, int V> static void launch_vec(luw_solver* s, const Box& b, 
 	if(odd) hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_v<T, V, 0>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
+// threads per block for a row of nx lanes: whole waves, at most 256, chosen so that the blocks of a row carry the fewest idle
+// lanes (a 375-lane row of the pair kernel: 3 x 128 instead of 2 x 256; ties go to the larger block)
+static uint32_t row_block(const uint32_t nx) {
+	if(nx<=256u) return ((nx+63u)/64u)*64u;
+	uint32_t best = 256u, best_lanes = ((nx+255u)/256u)*256u;
+	for(uint32_t bx : {192u, 128u, 64u}) { const uint32_t lanes = ((nx+bx-1u)/bx)*bx; if(lanes<best_lanes) { best = bx; best_lanes = lanes; } }
+	return best;
+}
 template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields) {
 	T* fi = (T*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
 	const int xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
 	const uint32_t nx = (uint32_t)((int)b.x1-xa);
-	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
+	const uint32_t bx = row_block(nx);
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
@@ -1001,7 +1009,7 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
 	uint16_t* fi = (uint16_t*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
 	const uint32_t nx = (b.x1-b.x0)/2u;
-	const uint32_t bx = nx>=256u ? 256u : ((nx+63u)/64u)*64u;
+	const uint32_t bx = row_block(nx);
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
