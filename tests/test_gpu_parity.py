@@ -20,7 +20,7 @@ def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0)
               use_F=False, every_step=False, subgrid=True):
     from latticeurbanwind_amd import capi
     flags, u, rho = state
-    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALL, "v1": capi.KERNEL_VEC1, "p": capi.KERNEL_PAIR}[kernel],
+    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"auto": capi.KERNEL_AUTO, "s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALL, "v1": capi.KERNEL_VEC1, "p": capi.KERNEL_PAIR}[kernel],
                 force_field=use_F, update_fields_every_step=every_step, subgrid=subgrid,
                 buffer_nudging=nudging, top_sponge=sponge)
     o = oracle.OracleLBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, use_F=use_F, subgrid=subgrid)
@@ -166,6 +166,39 @@ def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
     fluid = (st[0] & TYPE_S) == 0
     m0 = st[2][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum()
     assert np.isfinite(res[0][0]).all() and abs(res[0][1][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum() / m0 - 1) < 1e-3
+
+
+def test_fp16c_kernels_agree_at_bench_class_size(luw):
+    """FP16C at 512x256x256 with the LUW shell: the pair kernel (the automatic choice at this width), the scalar kernel and the
+    4-cells-per-lane vector kernel leave the same bits in u, rho and every DDF plane"""
+    from latticeurbanwind_amd import capi
+    N = (512, 256, 256)
+    st = synthetic_state(*N, seed=10, shell="luw")
+    res = []
+    for k in (capi.KERNEL_AUTO, capi.KERNEL_SCALAR, capi.KERNEL_VEC4):
+        g = luw.LBM(*N, 1e-5, fp16c=True, kernel=k)
+        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+        g.run(11)
+        g.u.read_from_device(); g.rho.read_from_device()
+        res.append((g.u.data.copy(), g.rho.data.copy(), np.asarray(g.download_fi()).copy()))
+        g.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    assert np.isfinite(res[0][0]).all()
+
+
+@pytest.mark.parametrize("fp16c", [False, True])
+def test_wide_lattice_matches_oracle(luw, fp16c):
+    """384x96x64 (2.4 M cells, rows wide enough for the pair kernel and for three 128-lane blocks per row), 12 steps, forces on:
+    the product kernels of both formats against the oracle, value for value"""
+    from oracle import oracle
+    Nx, Ny, Nz = 384, 96, 64
+    nud = dict(n_cells=6, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1)
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, fp16c, "auto", synthetic_state(Nx, Ny, Nz, seed=13, shell="luw"),
+                     coriolis=(0.0, 3e-5, 4e-5), nudging=nud, every_step=False)
+    g.run(12); o.run(12)
+    check(g, o, "wide lattice t=12")
 
 
 def test_rest_state_and_mass_conservation_at_512cubed(luw):
