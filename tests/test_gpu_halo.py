@@ -103,3 +103,15 @@ def test_box_launches_tile_the_domain(luw):
     for k in ("split_v", "split_s"):
         for a, b in zip(res["whole_v"], res[k]):
             assert np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("dt", ["f32", "fp16c"])
+def test_rccl_transport_through_self_send_recv(dt):
+    """the production transport (RCCL batch_isend_irecv on the communication stream; FP16C codes as float16) on the test box's
+    single GPU: a one-rank world whose neighbours are the rank itself -- tools/check_nccl_self.py asserts that the fields equal
+    those of the in-process loopback run bit for bit"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200 + (1 if dt == "f32" else 0)), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_nccl_self.py"), dt], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "fields identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
