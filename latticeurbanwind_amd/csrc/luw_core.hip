@@ -297,7 +297,8 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false> __global
 // round-toward-zero (fp16c_code_hi_in_rtz_mode) and merged into dwords with one byte permute per plane.
 // A cell that must not be processed (solid / halo) passes its populations through; its values are pre-swapped so that
 // the Esoteric-Pull store puts them back where they came from (every slot has exactly one writing cell per step, so this
-// rewrite races with nobody).  Requires even b.x0 and even b.x1 and rows whose x = 0 sits on a 4-byte boundary (the host
+// rewrite races with nobody).  Requires an even b.x0, an even b.x1 (or b.x1 = an odd Nx: the row's last cell then pairs with the row padding and is the only
+// one processed by its lane) and rows whose x = 0 sits on a 4-byte boundary (the host
 // falls back to the scalar kernel otherwise).
 typedef uint32_t u32_a2 __attribute__((aligned(2)));
 template<bool NT> __device__ __forceinline__ uint32_t ld_pair(const uint16_t* plane, const uint32_t byte_off) {
@@ -330,6 +331,7 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 	const RowOff rb = row_offsets(p, y, z);
 	LaneOff o = lane_offsets<uint16_t>(p, x);                      // offsets of cell x; cell x+1 sits 2 bytes further
 	const bool wrap = x+2u==p.Nx;                                  // cell x+1 is the last of the row: its x+1 neighbour is x = 0
+	const bool tail = x+1u==p.Nx;                                  // odd Nx: cell x is the last of the row, "cell x+1" is the row's padding
 	const uint32_t n = x+(uint32_t)rb.r00;
 	fi += rb.r00;                                                  // own row (uniform)
 	const size_t Np = p.Np;
@@ -338,6 +340,7 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 	bool proc[2];
 	#pragma unroll
 	for(int c=0; c<2; c++) proc[c] = !cell_is_halo(p, x+c, y, z) && (fl[c]&TYPE_BO)!=TYPE_S && (fl[c]&TYPE_SU)!=TYPE_G;
+	if(tail) proc[1] = false;                                      // passes through: reads and rewrites padding, except on the x+1 planes (below)
 	if(!proc[0]&&!proc[1]) return;
 	// All 19 dword loads in one straight run.  For the row-end lane (wrap) the high half of the five x+1 dwords is the element
 	// behind the row end (the next row's x = 0, or the slack behind the plane: in bounds, see lead_alloc / the plane skew):
@@ -414,12 +417,21 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 		else cs[k] = pack(i);
 		st_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x, pack(i+1));
 	});
-	if(!wrap) {
+	if(!wrap&&!tail) {
 		LUW_REDEFINE_OFFSETS;
 		static_for_pairs([&](auto ic) {
 			constexpr int i = decltype(ic)::value;
 			constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
 			if constexpr(i==1||i==7||i==9||i==13||i==15) st_pair<false>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o), cs[k]);
+		});
+	} else if(tail) { // the only real cell is x = Nx-1: its x+1 neighbour is the row's x = 0 (the dword load above already started there);
+		// x = 1 belongs to another lane's stores, so only the low half goes out
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) {
+				constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+				*(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)) = (uint16_t)(cs[k]&0xFFFFu);
+			}
 		});
 	} else {
 		LUW_REDEFINE_OFFSETS;
@@ -1008,7 +1020,7 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
 	uint16_t* fi = (uint16_t*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
-	const uint32_t nx = (b.x1-b.x0)/2u;
+	const uint32_t nx = (b.x1-b.x0+1u)/2u;                         // an odd count only when the box ends at an odd Nx: the last lane owns one cell
 	const uint32_t bx = row_block(nx);
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // measurement aid: the kernel's memory path alone (no physics)
@@ -1031,7 +1043,7 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=256u) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
 	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
 	if(s->kp.halo_x&&(k==LUW_KERNEL_PAIR||k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the A/B kernels assume rows that start on a 16-byte boundary at x = 0
-	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || (b.x1&1u))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, even x range
+	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || ((b.x1&1u) && b.x1!=s->cfg.Nx))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, pairs start at even x; an odd end only at the row end (the last cell pairs with the row padding)
 	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields);
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }

@@ -86,12 +86,13 @@ def test_stream_collide_matches_oracle(luw, kernel, fp16c, size):
         check(g, o, "t=%d" % o.t)
 
 
-@pytest.mark.parametrize("kernel,fp16c", [("s", False), ("v", False), ("s", True), ("p", True)])
-def test_periodic_box_without_boundaries(luw, kernel, fp16c):
+@pytest.mark.parametrize("kernel,fp16c,Nx", [("s", False, 22), ("v", False, 22), ("s", True, 22), ("p", True, 22), ("p", True, 23), ("s", True, 23)])
+def test_periodic_box_without_boundaries(luw, kernel, fp16c, Nx):
     # "all box sides where no boundary type is set remain periodic" (DOCUMENTATION.md:195-256): wrap in x,y,z
-    # (pair kernel: the row-end lane reads and writes its wrapped x+1 neighbours in two halves)
+    # (pair kernel: the row-end lane reads and writes its wrapped x+1 neighbours in two halves; with an odd Nx the last cell
+    # of a row shares its lane with the row padding)
     from oracle import oracle
-    Nx, Ny, Nz = 22, 9, 7
+    Ny, Nz = 9, 7
     g, o = make_pair(luw, oracle, Nx, Ny, Nz, 0.02, fp16c, kernel, synthetic_state(Nx, Ny, Nz, seed=5, solids=True, shell=None), every_step=True)
     g.run(9); o.run(9)
     check(g, o, "periodic")
