@@ -66,7 +66,7 @@ extern "C" {
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
 
 /* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
-#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 256 cells wide in x (starting at an even x, x not split, no thermal lattice), else SCALAR */
+#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 256 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
 #define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */

@@ -1042,8 +1042,15 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
 	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=256u) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
 	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
-	if(s->kp.halo_x&&(k==LUW_KERNEL_PAIR||k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the A/B kernels assume rows that start on a 16-byte boundary at x = 0
-	if(k==LUW_KERNEL_PAIR && (!fp16 || (b.x0&1u) || ((b.x1&1u) && b.x1!=s->cfg.Nx))) k = LUW_KERNEL_SCALAR; // pair kernel: FP16C, pairs start at even x; an odd end only at the row end (the last cell pairs with the row padding)
+	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the vector kernels assume rows that start on a 16-byte boundary at x = 0
+	// pair kernel: FP16C; pairs start on a 4-byte boundary -- at even x, or at odd x when x is split (the row's lead pad then puts
+	// x = 1 on a line start, lead_alloc); the range holds whole pairs, except that it may end at an odd Nx of an unsplit row (the
+	// last cell then pairs with the row padding)
+	if(k==LUW_KERNEL_PAIR) {
+		const bool starts_aligned = ((b.x0+s->kp.halo_x)&1u)==0u;
+		const bool whole_pairs = ((b.x1-b.x0)&1u)==0u || (!s->kp.halo_x && b.x1==s->cfg.Nx);
+		if(!fp16||!starts_aligned||!whole_pairs) k = LUW_KERNEL_SCALAR;
+	}
 	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields);
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }

@@ -32,10 +32,12 @@ def test_local_group_equals_single_domain(luw, gN, D, overlap, fp16c):
         s.backend.lbm.close()
 
 
-@pytest.mark.parametrize("gN,D,overlap", [((24, 20, 16), (1, 2, 2), True), ((26, 18, 16), (1, 3, 2), False), ((64, 12, 8), (1, 2, 1), True)])
+@pytest.mark.parametrize("gN,D,overlap", [((24, 20, 16), (1, 2, 2), True), ((26, 18, 16), (1, 3, 2), False), ((64, 12, 8), (1, 2, 1), True),
+                                          ((24, 20, 16), (2, 1, 1), False), ((32, 24, 12), (4, 2, 1), False), ((27, 18, 16), (1, 3, 2), True)])
 def test_local_group_pair_kernel(luw, gN, D, overlap):
-    """the FP16C pair kernel (two cells per lane; the automatic choice for wide FP16C rows) in x-whole decompositions: halo
-    cells in y / z pass through, shell and interior boxes tile the domain"""
+    """the FP16C pair kernel (two cells per lane; the automatic choice for wide FP16C rows) in decomposed runs: halo cells pass
+    through, shell and interior boxes tile the domain; x whole (also with an odd row length) and x split (pairs then start at the
+    first owned cell, x = 1)"""
     from latticeurbanwind_amd import capi
     from latticeurbanwind_amd.distributed import LocalGroup, HipDomain
     from oracle import oracle
