@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); normally already exported
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: gloo (side channel / test aid) over loopback, no hostname lookup
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_LUP = {"f32": 153.0, "fp16c": 77.0}   # 19 DDF reads + 19 DDF writes + 1 flag byte (FX/lbm.cpp:122)
@@ -205,7 +206,12 @@ def main():
             raise SystemExit("bench.py: lattice %s is not divisible by n_gpu %s" % (gN, D))
         Nx, Ny, Nz = (g // d for g, d in zip(gN, D))          # per-GPU block (without halos)
         exchange_note = None
-        gloo_group = dist.new_group(backend="gloo") if args.share_device is None else None   # only used if RCCL point-to-point fails below
+        gloo_group = None                                   # only used if RCCL point-to-point fails below
+        if args.share_device is None:
+            try:
+                gloo_group = dist.new_group(backend="gloo")
+            except Exception as e:                          # no fallback then; the RCCL path is unaffected
+                sys.stderr.write("bench.py rank %d: no gloo side channel (%s)\n" % (rank, str(e)[:200]))
 
         def make_sim(transport=None):
             sim = DomainDecomposedLBM(gN, D, nu, fp16c=fp16c, kernel=kern, device=local_rank, transport=transport)
@@ -222,6 +228,8 @@ def main():
         except Exception as e:      # RCCL p2p refused on this node: say so and fall back to host-staged halos rather than report nothing
             sys.stderr.write("bench.py rank %d: halo exchange over RCCL failed (%s); falling back to host-staged gloo\n" % (rank, str(e)[:300]))
             ok = torch.zeros(1)
+        if gloo_group is None and ok.item() == 0:
+            raise SystemExit("bench.py: halo exchange over RCCL failed and no fallback channel exists")
         if gloo_group is not None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
             if ok.item() == 0:
