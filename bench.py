@@ -270,6 +270,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
                          "kernel_ms": round(kernel_ms, 4) if kernel_ms else None,
+                         "whole_job_frac": round(mlups * 1e6 * bpl / 1e9 / (HBM_PEAK_GBPS * world), 4),   # wall-clock MLUPS of all GPUs x B/LUP over N x peak
                          "note": "achieved = %g B/LUP x %d cells / mean stream_collide duration (HIP events on the launch stream%s)" % (bpl, per_gpu_cells, "; interior box of rank 0, its boundary shell and the halo exchange run concurrently" if (D != (1, 1, 1) and sim.overlap) else "")},
         }
         # HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same
