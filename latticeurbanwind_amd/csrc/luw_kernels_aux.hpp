@@ -1,0 +1,225 @@
+// luw_kernels_aux.hpp -- halo pack/unpack, mesh voxeliser, probe gather, von-Karman inlet, on-device statistics, FP16C codec self-check
+// Device code of libluw_core.so; included by luw_core.hip only (after luw_device.hpp, inside `using namespace luw`).
+#pragma once
+
+// ---------------------------------------------------------------- halo pack / unpack, FX/kernel.cpp:2188-2270
+// Face cell of thread t and its index a in the transfer buffers.  The buffers keep the reference's order (direction 0:
+// a = y + z Ny; 1: a = z + x Nz; 2: a = x + y Nx, FX/kernel.cpp:2188-2221), but the THREADS walk along x wherever x lies in the
+// face, so that the lattice side of the copy is coalesced (for direction 1 the small buffer side is strided instead).
+template<int DIR> __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t t, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& a) {
+	if constexpr(DIR==0) { x = fixed; y = t%p.Ny; z = t/p.Ny; a = t; }
+	else if constexpr(DIR==1) { x = t%p.Nx; y = fixed; z = t/p.Nx; a = x*p.Nz+z; }
+	else { x = t%p.Nx; y = t/p.Nx; z = fixed; a = t; }
+}
+// device index of the neighbour of (x,y,z) in direction c_I (periodic wrap), I compile-time: three selects, no table
+template<int I> __device__ __forceinline__ uint32_t neighbor_index(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
+	constexpr int cx = (I==1||I==7||I==9||I==13||I==15) ? 1 : (I==2||I==8||I==10||I==14||I==16) ? -1 : 0;
+	constexpr int cy = (I==3||I==7||I==11||I==14||I==17) ? 1 : (I==4||I==8||I==12||I==13||I==18) ? -1 : 0;
+	constexpr int cz = (I==5||I==9||I==11||I==16||I==18) ? 1 : (I==6||I==10||I==12||I==15||I==17) ? -1 : 0;
+	const uint32_t xs = cx>0 ? (x+1u==p.Nx ? 0u : x+1u) : cx<0 ? (x==0u ? p.Nx-1u : x-1u) : x;
+	const uint32_t ys = cy>0 ? (y+1u==p.Ny ? 0u : y+1u) : cy<0 ? (y==0u ? p.Ny-1u : y-1u) : y;
+	const uint32_t zs = cz>0 ? (z+1u==p.Nz ? 0u : z+1u) : cz<0 ? (z==0u ? p.Nz-1u : z-1u) : z;
+	return xs+(ys+zs*p.Ny)*p.Px;
+}
+// the 5 D3Q19 populations that leave through face (DIR, side), FX/kernel.cpp:2223-2229 
+template<int DIR, int PM, int BB> struct TransferIndex {
+	static constexpr int table[30] = { 1, 7, 13, 9, 15,  2, 8, 14, 10, 16,  3, 7, 14, 11, 17,  4, 8, 13, 12, 18,  5, 9, 16, 11, 18,  6, 10, 15, 12, 17 };
+	static constexpr int value = table[(2*DIR+PM)*5+BB];
+};
+// G = false: the 5 D3Q19 populations of a face (fi); G = true: the single D3Q7 population of the thermal lattice (gi, i = side+1,
+// FX/kernel.cpp:2338-2351) -- same slot algebra, the D3Q7 neighbours are the first six of the D3Q19 list.
+// Everything about a population is compile-time (direction is a template parameter), so no per-thread index table exists.
+template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void extract_one(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf, const T* __restrict__ fi) {
+	constexpr int i = G ? 2*DIR+PM+1 : TransferIndex<DIR, PM, BB>::value;
+	const uint32_t plane = t_odd ? ((i&1) ? i+1 : i-1) : i;
+	const uint32_t n = (i&1) ? neighbor_index<i>(p, x, y, z) : x+(y+z*p.Ny)*p.Px;
+	buf[(size_t)BB*A+a] = fi[(size_t)plane*p.Np+n];
+}
+template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void insert_one(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf, T* __restrict__ fi) {
+	constexpr int i = G ? 2*DIR+PM+1 : TransferIndex<DIR, PM, BB>::value;
+	const uint32_t plane = t_odd ? i : ((i&1) ? i+1 : i-1);
+	const uint32_t n = (i&1) ? x+(y+z*p.Ny)*p.Px : neighbor_index<i-1>(p, x, y, z);
+	fi[(size_t)plane*p.Np+n] = buf[(size_t)BB*A+a];
+}
+template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
+	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
+	if(t>=A) return;
+	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
+	uint32_t x, y, z, a;
+	face_cell<DIR>(p, t, Nd-2u, x, y, z, a);
+	extract_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	if constexpr(!G) { extract_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi); }
+	face_cell<DIR>(p, t, 1u, x, y, z, a);
+	extract_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	if constexpr(!G) { extract_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi); }
+}
+template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
+	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
+	if(t>=A) return;
+	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
+	uint32_t x, y, z, a;
+	face_cell<DIR>(p, t, Nd-1u, x, y, z, a);
+	insert_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	if constexpr(!G) { insert_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi); }
+	face_cell<DIR>(p, t, 0u, x, y, z, a);
+	insert_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	if constexpr(!G) { insert_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi); }
+}
+// ---------------------------------------------------------------- mesh voxeliser
+// voxelize_mesh with direction 2 (z rays; LUW always voxelises TYPE_S along z, FX/lbm.cpp:1427-1430) for a static mesh:
+// one lane per (x,y) column casts a ray from the bottom of the padded bounding box through ALL triangles
+// (Moeller-Trumbore), sorts up to 64 hit distances and fills the cells between odd/even crossings
+// (FX/kernel.cpp:2381-2471).  Arithmetic mirrors what the reference's OpenCL build executes on this hardware: 1/g is the
+// hardware reciprocal v_rcp_f32 (OpenCL's 2.5-ulp 1.0f/g) and dot / cross are the fma chains of the OpenCL device library
+// (dot = mad(z,z', mad(y,y', x*x')), cross.x = mad(a.y, b.z, -(a.z*b.y)) ...).  Faces of LUW geometry sit on exact lattice
+// planes by construction (ground slab pmin -> 1), where the (ushort)d truncation depends on exactly these roundings.
+__device__ __forceinline__ float vdot(const float ax, const float ay, const float az, const float bx, const float by, const float bz) {
+	return fmaf(az, bz, fmaf(ay, by, ax*bx)); // dot(float3) of the OpenCL device library: mad(z, z', mad(y, y', x*x'))
+}
+struct VoxGrid { uint32_t Nx, Ny, Nz, Px; int Ox, Oy, Oz; uint64_t Np; }; // lattice of the pass: a solver domain, or a bare global lattice (luw_voxelize_lattice)
+// One block = one 16x16 tile of columns; it visits only the triangles binned to the tile (tile_start / tile_tri: CSR, triangle
+// ids ascending, so hits are met in the reference's order and the 64-entry cut-off falls on the same hits).  The bins hold
+// every triangle whose xy bounding box, grown by one cell, touches the tile -- the margin the reference itself uses when it
+// hands a domain its triangle subset (FX/lbm.cpp:1455-1487).
+constexpr uint32_t VOX_TILE = 16u;
+__global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_tri,
+		const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2, const float x0, const float y0, const float z0, const float x1, const float y1, const float z1) {
+	const uint32_t x = blockIdx.x*VOX_TILE+threadIdx.x%VOX_TILE, y = blockIdx.y*VOX_TILE+threadIdx.x/VOX_TILE;
+	if(x>=p.Nx||y>=p.Ny) return;
+	const uint32_t tile = blockIdx.x+blockIdx.y*gridDim.x, k0 = tile_start[tile], k1 = tile_start[tile+1u];
+	const int zs = min(max((int)z0-p.Oz, 0), (int)p.Nz-1);
+	const float rx = (float)((int)x+p.Ox), ry = (float)((int)y+p.Oy), rz = (float)(zs+p.Oz); // position(xyz)+offset = global index coordinates
+	if(rx<x0||ry<y0||rx>=x1||ry>=y1) return;
+	uint32_t intersections = 0u, intersections_check = 0u;
+	uint16_t distances[64];
+	for(uint32_t kk=k0; kk<k1; kk++) {
+		const uint32_t i = tile_tri[kk];
+		const float ax = p0[3u*i], ay = p0[3u*i+1u], az = p0[3u*i+2u];
+		const float ux = p1[3u*i]-ax, uy = p1[3u*i+1u]-ay, uz = p1[3u*i+2u]-az;
+		const float vx = p2[3u*i]-ax, vy = p2[3u*i+1u]-ay, vz = p2[3u*i+2u]-az;
+		const float wx = rx-ax, wy = ry-ay, wz = rz-az;
+		// h = cross(r_direction, v) with r_direction = (0,0,1); q = cross(w, u)
+		const float hx = fmaf(0.0f, vz, -(1.0f*vy)), hy = fmaf(1.0f, vx, -(0.0f*vz)), hz = fmaf(0.0f, vy, -(0.0f*vx));
+		const float qx = fmaf(wy, uz, -(wz*uy)), qy = fmaf(wz, ux, -(wx*uz)), qz = fmaf(wx, uy, -(wy*ux));
+		const float g = vdot(ux, uy, uz, hx, hy, hz);
+		const float f = __builtin_amdgcn_rcpf(g);
+		const float sv = f*vdot(wx, wy, wz, hx, hy, hz), tv = f*vdot(0.0f, 0.0f, 1.0f, qx, qy, qz), d = f*vdot(vx, vy, vz, qx, qy, qz);
+		if(g!=0.0f&&sv>=0.0f&&sv<1.0f&&tv>=0.0f&&sv+tv<1.0f) {
+			if(d>0.0f) { if(intersections<64u&&d<65536.0f) distances[intersections] = (uint16_t)d; intersections++; }
+			else intersections_check++;
+		}
+	}
+	const uint32_t ns = min(intersections, 64u);
+	for(uint32_t i=1u; i<ns; i++) { // insertion sort
+		const uint16_t t = distances[i];
+		int j = (int)i-1;
+		while(j>=0&&distances[j]>t) { distances[j+1] = distances[j]; j--; }
+		distances[j+1] = t;
+	}
+	bool inside = (intersections%2u)&&(intersections_check%2u);
+	uint32_t k = (intersections%2u)!=(intersections_check%2u);
+	const uint32_t h0 = (uint32_t)zs;
+	const uint32_t hmax = (uint32_t)min(max((int)z1-p.Oz, 0), (int)p.Nz);
+	const uint32_t hmesh = h0+(ns>0u ? (uint32_t)distances[min(intersections-1u, 63u)] : 0u);
+	for(uint32_t h=h0; h<hmax; h++) {
+		while(k<intersections&&h>h0+(uint32_t)distances[min(k, 63u)]) { inside = !inside; k++; }
+		inside = inside&&(k<intersections&&h<hmesh);
+		const uint64_t n = (uint64_t)x+((uint64_t)y+(uint64_t)h*p.Ny)*p.Px;
+		uint8_t fl = flags[n];
+		if(inside) fl = (uint8_t)((fl&~TYPE_BO)|flag);
+		else if((fl&TYPE_BO)==TYPE_S&&(!u||(u[n]==0.0f&&u[p.Np+n]==0.0f&&u[2ull*p.Np+n]==0.0f))) fl = (uint8_t)(fl&~flag); // was solid with the mesh's velocity (static: 0), FX/kernel.cpp:2451-2462
+		flags[n] = fl;
+	}
+}
+
+// ---------------------------------------------------------------- probe gather: u at a short list of cells -> packed [i][3]
+__global__ void k_gather_u(const uint32_t count, const uint32_t* __restrict__ cell, const float* __restrict__ u, const size_t Np, float* __restrict__ out) {
+	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
+	if(i>=count) return;
+	const uint32_t n = cell[i];
+	out[3u*i] = u[n]; out[3u*i+1u] = u[Np+n]; out[3u*i+2u] = u[2ull*Np+n];
+}
+
+// ---------------------------------------------------------------- von-Karman synthetic-turbulence inlet
+// vk_inlet_apply, FX/kernel.cpp:2495-2571: u[cell] = u_base + sigma * sum_m A_m cos(k_m.p + omega_m t + phi_m) on the inlet
+// cells (TYPE_E: the collide step then relaxes them to f_eq(rho, u)).  One lane per inlet point; cosf is the same device
+// library function (ocml) the reference's OpenCL build calls.
+__global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint32_t P, const uint32_t M, const uint32_t V,
+		const uint32_t* __restrict__ point_cell, const uint8_t* __restrict__ point_face, const float* __restrict__ point_data, const float* __restrict__ mode_data, float* __restrict__ u, const size_t Np) {
+	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
+	if(i>=P) return;
+	const uint32_t n = point_cell[i];
+	const uint32_t fid = (uint32_t)(point_face[i]&0x07u);
+	const float px = point_data[i], py = point_data[(size_t)P+i], pz = point_data[2ull*P+i];
+	const float ubx = point_data[3ull*P+i], uby = point_data[4ull*P+i], ubz = point_data[5ull*P+i];
+	const float sigma = point_data[6ull*P+i];
+	if(fid>=5u||!(sigma>0.0f)) { u[n] = ubx; u[Np+n] = uby; u[2ull*Np+n] = ubz; return; }
+	const uint32_t fbase = fid*M;
+	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+	for(uint32_t m=0u; m<M; ++m) {
+		const uint32_t idx = fbase+m;
+		const float kx = mode_data[idx], ky = mode_data[(size_t)V+idx], kz = mode_data[2ull*V+idx], omega = mode_data[3ull*V+idx];
+		const float Ax = mode_data[4ull*V+idx], Ay = mode_data[5ull*V+idx], Az = mode_data[6ull*V+idx];
+		const float phix = mode_data[7ull*V+idx], phiy = mode_data[8ull*V+idx], phiz = mode_data[9ull*V+idx];
+		const float phase0 = fmaf(kx, px, fmaf(ky, py, fmaf(kz, pz, omega*t0)));
+		float vx = Ax*cosf(phase0+phix), vy = Ay*cosf(phase0+phiy), vz = Az*cosf(phase0+phiz);
+		if(use_interp!=0u) {
+			const float phase1 = fmaf(kx, px, fmaf(ky, py, fmaf(kz, pz, omega*t1)));
+			const float vx1 = Ax*cosf(phase1+phix), vy1 = Ay*cosf(phase1+phiy), vz1 = Az*cosf(phase1+phiz);
+			vx = fmaf(alpha, vx1-vx, vx); vy = fmaf(alpha, vy1-vy, vy); vz = fmaf(alpha, vz1-vz, vz);
+		}
+		qx += vx; qy += vy; qz += vz;
+	}
+	u[n] = fmaf(sigma, qx, ubx);
+	u[Np+n] = fmaf(sigma, qy, uby);
+	u[2ull*Np+n] = fmaf(sigma, qz, ubz);
+}
+
+// ---------------------------------------------------------------- on-device time averaging
+// The reference downloads u,rho at every sampled step and runs Welford's update on the host
+// (accumulate_from_buffers, FX/setup.cpp:4441-4488).  Same arithmetic, same operation order, on the device: mean and M2 of
+// the three velocity components, mean of rho.  One lane per cell, x fastest.
+__global__ __launch_bounds__(256) void k_stats_accumulate(const KParams p, const float inv_n, const float* __restrict__ rho, const float* __restrict__ u,
+		float* __restrict__ avg_u, float* __restrict__ avg_rho, float* __restrict__ m2, const float* __restrict__ Tf, float* __restrict__ avg_T) {
+	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+	if(x>=p.Nx) return;
+	const uint32_t n = x+(y+z*p.Ny)*p.Px;
+	// every array is streamed exactly once per sample: non-temporal accesses keep them out of the way of the step kernel's lines
+	if(avg_T) { const float ta = ldg<true>(avg_T+n); stg<true>(avg_T+n, ta+(ldg<true>(Tf+n)-ta)*inv_n); } // FX/setup.cpp:4481-4484
+	const size_t Np = p.Np;
+	#pragma unroll
+	for(int c=0; c<3; c++) {
+		const float v = ldg<true>(u+c*Np+n);
+		float mean = ldg<true>(avg_u+c*Np+n);
+		const float delta = v-mean;
+		mean += delta*inv_n;
+		const float delta2 = v-mean;
+		stg<true>(m2+c*Np+n, ldg<true>(m2+c*Np+n)+delta*delta2);
+		stg<true>(avg_u+c*Np+n, mean);
+	}
+	const float r = ldg<true>(rho+n);
+	const float ra = ldg<true>(avg_rho+n);
+	stg<true>(avg_rho+n, ra+(r-ra)*inv_n);
+}
+
+// ---------------------------------------------------------------- self-check of the fast FP16C codec
+// counts inputs for which the fast codec differs from the literal restatement of FX/kernel.cpp:864-875:
+// all 2^16 codes (decode, compared as bit patterns) and every float bit pattern with |x| < 2^103 (encode; exponent field
+// < 230 -- the codec's stated domain, luw_device.hpp)
+__global__ __launch_bounds__(256) void k_codec_check(unsigned long long* __restrict__ mismatches) {
+	const uint32_t tid = blockIdx.x*blockDim.x+threadIdx.x, nth = gridDim.x*blockDim.x;
+	unsigned long long bad = 0ull;
+	for(uint32_t c=tid; c<65536u; c+=nth) bad += __float_as_uint(half_to_float_custom(c))!=__float_as_uint(half_to_float_custom_ref(c));
+	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) { if(((uint32_t)v&0x7F800000u)>=(230u<<23)) continue; const float x = __uint_as_float((uint32_t)v); bad += float_to_half_custom(x)!=float_to_half_custom_ref(x); }
+	// the product kernel's 3-instruction encode (fp16c_encode19_hi_rtz_final): every bit pattern except NaNs, under RTZ; the
+	// reference formula it is compared with is integer-only, so the mode does not touch it
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(bad));
+	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) {
+		const uint32_t b = (uint32_t)v;
+		if((b&0x7F800000u)==0x7F800000u&&(b&0x007FFFFFu)!=0u) continue;
+		bad += (fp16c_code_hi_in_rtz_mode(__uint_as_float(b))>>16)!=float_to_half_custom_ref(__uint_as_float(b));
+	}
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(bad));
+	if(bad) atomicAdd(mismatches, bad);
+}
+

@@ -1,0 +1,351 @@
+// luw_kernels_step.hpp -- the product collide-stream kernels: k_stream_collide_s (1 cell per lane) and k_stream_collide_p (FP16C, 2 cells per lane), with their addressing
+// Device code of libluw_core.so; included by luw_core.hip only (after luw_device.hpp, inside `using namespace luw`).
+#pragma once
+
+// ---------------------------------------------------------------- scalar kernel: 1 cell per lane
+// Addressing: every DDF access is (uniform plane base in SGPRs) + (32-bit byte offset in one VGPR), the
+// global_load/store "saddr" form; the 10 byte offsets (own cell + 9 neighbours) stay live from the loads to the
+// stores instead of 38 64-bit addresses.  Byte offsets fit 32 bits because Np*sizeof(T) <= 2^32 (checked on the host).
+template<bool NT, typename T> __device__ __forceinline__ T ldo(const T* plane, const uint32_t byte_off) {
+	return ldg<NT>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(plane)+byte_off));
+}
+template<bool NT, typename T> __device__ __forceinline__ void sto(T* plane, const uint32_t byte_off, const T v) {
+	stg<NT>(reinterpret_cast<T*>(reinterpret_cast<char*>(plane)+byte_off), v);
+}
+// Addressing.  y and z of a block are uniform (they come from blockIdx), so the start of every row a cell touches -- its own
+// and those of its y/z neighbours (periodic wrap, FX/kernel.cpp:920-958) -- is a uniform 64-bit ELEMENT offset that the scalar
+// unit adds to the plane base; the only per-lane parts are the byte offsets of x and of x+1 within a row.  Two offset VGPRs
+// instead of ten, and no limit on the plane size (a per-plane 32-bit byte offset would stop at 2^30 FP32 cells).
+struct RowOff { size_t r00; int64_t p0, _0p, pp, m0, _0m, pm; };   // own row (y,z); steps to the rows (y+1,z), (y,z+1), (y+1,z+1), (y-1,z), (y,z-1), (y+1,z-1)
+struct LaneOff { uint32_t x, xp; };                            // byte offsets of x and of x+1 (wrapped) within a row
+__device__ __forceinline__ RowOff row_offsets(const KParams& p, const uint32_t y, const uint32_t z) {
+	// the neighbour rows as the own row plus a step that is +-(one row / one z plane) or, at the periodic wrap, the way back
+	// across the lattice: selects and additions on the scalar unit, a single 64-bit product for the own row
+	const uint32_t A = p.Px*p.Ny;                                  // cells of a z plane (< 2^32: it divides Np)
+	const int64_t sy = (int64_t)p.Px, wy = (int64_t)(p.Px*(p.Ny-1u)), sz = (int64_t)A, wz = (int64_t)((uint64_t)A*(p.Nz-1u));
+	const int64_t dyp = y+1u==p.Ny ? -wy : sy, dym = y==0u ? wy : -sy;
+	const int64_t dzp = z+1u==p.Nz ? -wz : sz, dzm = z==0u ? wz : -sz;
+	RowOff r;
+	r.r00 = (size_t)z*A+(size_t)(y*p.Px);
+	r.p0 = dyp; r._0p = dzp; r.pp = dyp+dzp; r.m0 = dym; r._0m = dzm; r.pm = dyp+dzm;
+	return r;
+}
+template<typename T> __device__ __forceinline__ LaneOff lane_offsets(const KParams& p, const uint32_t x) {
+	LaneOff o;
+	o.x = x*(uint32_t)sizeof(T); o.xp = (x+1u==p.Nx ? 0u : x+1u)*(uint32_t)sizeof(T);
+	return o;
+}
+// the +c_I neighbour (I odd) lives nrow<I>() cells after the own row's start, at lane offset nlane<I>()
+template<int I> __device__ __forceinline__ int64_t nrow(const RowOff& r) {
+	if constexpr(I==1) return 0; else if constexpr(I==3) return r.p0; else if constexpr(I==5) return r._0p;
+	else if constexpr(I==7) return r.p0; else if constexpr(I==9) return r._0p; else if constexpr(I==11) return r.pp;
+	else if constexpr(I==13) return r.m0; else if constexpr(I==15) return r._0m; else return r.pm;
+}
+template<int I> __device__ __forceinline__ uint32_t nlane(const LaneOff& o) {
+	if constexpr(I==1||I==7||I==9||I==13||I==15) return o.xp; else return o.x;
+}
+
+// The same addresses as ONE 32-bit byte offset per neighbour within a plane (own cell + 9 neighbours in VGPRs, plane bases
+// without the row): needs Np*sizeof(T) <= 2^32, and is what the FP32 kernel uses when that holds -- its shorter scalar
+// prologue lets a wave issue its loads earlier, worth 1 % at 512^3 on the HBM-bound kernel; the VALU-bound FP16C kernels and
+// larger lattices take the row form above.
+struct NbrOff { uint32_t n, j1, j3, j5, j7, j9, j11, j13, j15, j17; };
+template<typename T> __device__ __forceinline__ NbrOff neighbor_offsets(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
+	const uint32_t xp = x+1u==p.Nx ? 0u : x+1u;
+	const uint32_t y0 = y*p.Px, yp = (y+1u==p.Ny ? 0u : y+1u)*p.Px, ym = (y==0u ? p.Ny-1u : y-1u)*p.Px;
+	const uint32_t A = p.Px*p.Ny;
+	const uint32_t z0 = z*A, zp = (z+1u==p.Nz ? 0u : z+1u)*A, zm = (z==0u ? p.Nz-1u : z-1u)*A;
+	constexpr uint32_t B = (uint32_t)sizeof(T);
+	NbrOff o;
+	o.n = (x+y0+z0)*B;
+	o.j1 = (xp+y0+z0)*B; o.j3 = (x+yp+z0)*B; o.j5 = (x+y0+zp)*B;
+	o.j7 = (xp+yp+z0)*B; o.j9 = (xp+y0+zp)*B; o.j11 = (x+yp+zp)*B;
+	o.j13 = (xp+ym+z0)*B; o.j15 = (xp+y0+zm)*B; o.j17 = (x+yp+zm)*B;
+	return o;
+}
+template<int I> __device__ __forceinline__ uint32_t nbr(const NbrOff& o) {
+	if constexpr(I==1) return o.j1; else if constexpr(I==3) return o.j3; else if constexpr(I==5) return o.j5;
+	else if constexpr(I==7) return o.j7; else if constexpr(I==9) return o.j9; else if constexpr(I==11) return o.j11;
+	else if constexpr(I==13) return o.j13; else if constexpr(I==15) return o.j15; else return o.j17;
+}
+// one interface over both forms: plane pointer adjustment (uniform) + lane byte offset of the own cell / the +c_I neighbour
+template<typename T, bool FLAT> struct CellAddr;
+template<typename T> struct CellAddr<T, false> {
+	RowOff rb; LaneOff o; uint32_t n;
+	// returns what the caller adds to its lattice pointer: from then on it points at the own row (uniform)
+	__device__ __forceinline__ size_t init(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const bool noshift) {
+		rb = row_offsets(p, y, z); o = lane_offsets<T>(p, x);
+		if(noshift) o.xp = o.x;
+		n = x+(uint32_t)rb.r00;
+		return rb.r00;
+	}
+	template<int I> __device__ __forceinline__ int64_t row() const { return nrow<I>(rb); }
+	template<int I> __device__ __forceinline__ uint32_t lane() const { return nlane<I>(o); }
+	__device__ __forceinline__ uint32_t own() const { return o.x; }
+	__device__ __forceinline__ uint32_t jx() const { return o.xp/(uint32_t)sizeof(T)+(uint32_t)rb.r00; }
+	__device__ __forceinline__ uint32_t jy() const { return n+(uint32_t)rb.p0; }
+	__device__ __forceinline__ uint32_t jz() const { return n+(uint32_t)rb._0p; }
+	__device__ __forceinline__ void redefine() { asm volatile("" : "+v"(o.x), "+v"(o.xp)); }
+};
+template<typename T> struct CellAddr<T, true> {
+	NbrOff o; uint32_t n;
+	__device__ __forceinline__ size_t init(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const bool noshift) {
+		o = neighbor_offsets<T>(p, x, y, z);
+		if(noshift) { o.j1 = o.n; o.j7 = o.j3; o.j9 = o.j5; o.j13 = (x+(y==0u ? p.Ny-1u : y-1u)*p.Px+z*p.Px*p.Ny)*(uint32_t)sizeof(T); o.j15 = (x+y*p.Px+(z==0u ? p.Nz-1u : z-1u)*p.Px*p.Ny)*(uint32_t)sizeof(T); }
+		n = o.n/(uint32_t)sizeof(T);
+		return 0u;
+	}
+	template<int I> __device__ __forceinline__ int64_t row() const { return 0; }
+	template<int I> __device__ __forceinline__ uint32_t lane() const { return nbr<I>(o); }
+	__device__ __forceinline__ uint32_t own() const { return o.n; }
+	__device__ __forceinline__ uint32_t jx() const { return o.j1/(uint32_t)sizeof(T); }
+	__device__ __forceinline__ uint32_t jy() const { return o.j3/(uint32_t)sizeof(T); }
+	__device__ __forceinline__ uint32_t jz() const { return o.j5/(uint32_t)sizeof(T); }
+	__device__ __forceinline__ void redefine() { asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17)); }
+};
+
+// MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
+// measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
+// NT: 0 default cache policy, 1 non-temporal everywhere, 2 non-temporal on the 14 aligned planes and default policy on
+// the five x+1 planes, whose wave-edge lines are shared between neighbouring waves (product setting, measured best).
+// Waves per SIMD: the FP32 kernel is HBM-bound and measurably better with at most 4 resident waves (3.40 vs 3.43 ms at 512^3,
+// 6.68 vs 6.98 ms at 1024x1024x256: fewer concurrent row fronts, better DRAM page locality) even though its ~95 VGPRs would
+// allow 5; the FP16C kernel is VALU-bound and takes all the waves its registers allow.
+#ifndef LUW_MAXW_F32
+#define LUW_MAXW_F32 4
+#endif
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
+	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
+	// start), whatever the box: lanes left of b.x0 idle
+	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
+	// measured 3.5 % slower, 3.50 vs 3.39 ms at 512^3 -- no population is shared between workgroups, so there is nothing
+	// for an XCD's L2 to reuse, and eight distant fronts cost DRAM page locality)
+	const int xi = xa+(int)(blockIdx.x*blockDim.x+threadIdx.x);
+	if(xi<(int)b.x0||xi>=(int)b.x1) return;
+	const uint32_t x = (uint32_t)xi, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
+	if(cell_is_halo(p, x, y, z)) return;
+	CellAddr<T, FLAT> a;
+	fi += a.init(p, x, y, z, MODE==2);
+	const uint32_t n = a.n;
+	const uint8_t flagsn = flags[n];
+	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
+	const size_t Np = p.Np;
+	float f[19];
+	f[0] = ddf_decode<T>(ldo<(NT!=0)>(fi, a.own()));
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
+		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
+	});
+	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
+	if constexpr(MODE!=1) {
+		float rhon, uxn, uyn, uzn;
+		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
+			float u0[3];
+			collide_cell<true>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
+			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
+		} else
+		collide_cell<(MODE!=3)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
+		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
+			rho[n] = rhon;
+			u[n] = uxn;
+			u[Np+n] = uyn;
+			u[2ull*Np+n] = uzn;
+		}
+	}
+	// the ten offsets pass through an empty asm so that they are (re)defined as 32-bit values in the block that holds the
+	// stores: instruction selection works per basic block, and without seeing the zero-extension there it builds nineteen
+	// 64-bit addresses (v_lshl_add_u64 + a VGPR pair each) instead of the saddr form the loads use
+	a.redefine();
+	if constexpr(sizeof(T)==2&&MODE!=1) { // FP16C, nothing but the stores left: the 3-instruction encode under round-toward-zero
+		uint32_t c[19];
+		if constexpr(MODE==4) {
+			uint32_t cg[7];
+			fp16c_encode19_hi_rtz_final(f, c, g, cg);
+			thermal_store<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), gi, [&](const int i) { return (T)(cg[i]>>16); });
+		} else fp16c_encode19_hi_rtz_final(f, c);
+		sto<(NT!=0)>(fi, a.own(), (T)(c[0]>>16));
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+			sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), (T)(c[i]>>16));
+			sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), (T)(c[i+1]>>16));
+		});
+		return;
+	}
+	if constexpr(MODE==4) {
+		thermal_store<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), gi, [&](const int i) { return ddf_encode<T>(g[i]); });
+	}
+	sto<(NT!=0)>(fi, a.own(), ddf_encode<T>(f[0]));
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), ddf_encode<T>(f[i]));
+		sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), ddf_encode<T>(f[i+1]));
+	});
+}
+
+// ---------------------------------------------------------------- pair kernel: 2 cells per lane (FP16C DDFs)
+// With 2-byte DDFs the scalar kernel moves only 128 B per wave instruction, and that access width tops out near 5.2 TB/s
+// (tools/membench half).  Here a lane owns the cells (x, x+1), x even, and moves both FP16C codes of a plane with ONE
+// dword access -- the same bytes per instruction as the FP32 scalar kernel.  Straight planes are 4-byte aligned; the x+1
+// planes are read/written at a 2-byte offset (a dword access on a 2-byte boundary, which the hardware serves), except for
+// the lane at the row end whose second neighbour wraps to x = 0.  The two cells are collided ONE AFTER THE OTHER (an
+// asm fence between the passes keeps the compiler from interleaving them), so the register footprint is that of the
+// scalar kernel plus the 19 finished values of the first cell: 4 waves/SIMD.  Both cells are encoded at the tail under
+// round-toward-zero (fp16c_code_hi_in_rtz_mode) and merged into dwords with one byte permute per plane.
+// A cell that must not be processed (solid / halo) passes its populations through; its values are pre-swapped so that
+// the Esoteric-Pull store puts them back where they came from (every slot has exactly one writing cell per step, so this
+// rewrite races with nobody).  Requires an even b.x0, an even b.x1 (or b.x1 = an odd Nx: the row's last cell then pairs with the row padding and is the only
+// one processed by its lane) and rows whose x = 0 sits on a 4-byte boundary (the host
+// falls back to the scalar kernel otherwise).
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+template<bool NT> __device__ __forceinline__ uint32_t ld_pair(const uint16_t* plane, const uint32_t byte_off) {
+	const char* ptr = reinterpret_cast<const char*>(plane)+byte_off;
+	if constexpr(NT) return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ptr));
+	else return *reinterpret_cast<const u32_a2*>(ptr);
+}
+template<bool NT> __device__ __forceinline__ void st_pair(uint16_t* plane, const uint32_t byte_off, const uint32_t v) {
+	char* ptr = reinterpret_cast<char*>(plane)+byte_off;
+	if constexpr(NT) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(ptr));
+	else *reinterpret_cast<u32_a2*>(ptr) = v;
+}
+// every value of v[0..N) passes through a volatile asm: what produces them is ordered before, what consumes them after
+template<int N> __device__ __forceinline__ void asm_fence(float* v) {
+	static_assert(N==19, "written for the 19 DDFs of a cell");
+	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
+	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
+}
+__device__ __forceinline__ void asm_fence9(float& f0, f32x2* v) {
+	asm volatile("" : "+v"(f0), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+}
+__device__ __forceinline__ void asm_fence_u(uint32_t* v) {
+	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
+	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
+}
+template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
+	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
+	if(x>=b.x1) return;
+	const RowOff rb = row_offsets(p, y, z);
+	LaneOff o = lane_offsets<uint16_t>(p, x);                      // offsets of cell x; cell x+1 sits 2 bytes further
+	const bool wrap = x+2u==p.Nx;                                  // cell x+1 is the last of the row: its x+1 neighbour is x = 0
+	const bool tail = x+1u==p.Nx;                                  // odd Nx: cell x is the last of the row, "cell x+1" is the row's padding
+	const uint32_t n = x+(uint32_t)rb.r00;
+	fi += rb.r00;                                                  // own row (uniform)
+	const size_t Np = p.Np;
+	const uint32_t fl2 = *reinterpret_cast<const uint16_t*>(flags+n);
+	const uint8_t fl[2] = { (uint8_t)(fl2&0xFFu), (uint8_t)(fl2>>8) };
+	bool proc[2];
+	#pragma unroll
+	for(int c=0; c<2; c++) proc[c] = !cell_is_halo(p, x+c, y, z) && (fl[c]&TYPE_BO)!=TYPE_S && (fl[c]&TYPE_SU)!=TYPE_G;
+	if(tail) proc[1] = false;                                      // passes through: reads and rewrites padding, except on the x+1 planes (below)
+	if(!proc[0]&&!proc[1]) return;
+	// All 19 dword loads in one straight run.  For the row-end lane (wrap) the high half of the five x+1 dwords is the element
+	// behind the row end (the next row's x = 0, or the slack behind the plane: in bounds, see lead_alloc / the plane skew):
+	// it is replaced by the wrapped neighbour in ONE divergent fix-up block behind the loads.
+	uint32_t raw[19];                                              // low half: cell x, high half: cell x+1
+	raw[0] = ld_pair<true>(fi, o.x);
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		raw[i] = ld_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x);
+		raw[i+1] = ld_pair<!shifted>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o));
+	});
+	if(wrap) {
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) { // the dword started at x+1 = Nx-1 of the neighbour row; x+2 wraps to that row's x = 0
+				const uint32_t hi = *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb));
+				raw[i+1] = (raw[i+1]&0xFFFFu)|(hi<<16);
+			}
+		});
+	}
+	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
+	const bool may_force = p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull;
+	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
+	// (or pre-swap for the pass-through)
+	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
+		auto bits = [&](const int q) { // (sign-extended half) << 12 in one SDWA shift, then the mask of half_to_float_custom_sx
+			uint32_t t;
+			if(c) asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(raw[q]));
+			else asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(raw[q]));
+			return t&0x87FFF000u;
+		};
+		f0 = __uint_as_float(bits(0))*0x1p+112f;
+		#pragma unroll
+		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
+		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
+			float rhon, uxn, uyn, uzn;
+			collide_cell_pk(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn);
+			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
+				rho[n+c] = rhon;
+				u[n+c] = uxn;
+				u[Np+n+c] = uyn;
+				u[2ull*Np+n+c] = uzn;
+			}
+		} else {
+			#pragma unroll
+			for(int k=0; k<9; k++) { const f32x2 t = { fp[k].y, fp[k].x }; fp[k] = t; }
+		}
+	};
+	float fa0, fb0; f32x2 fa[9], fb[9];
+	one_cell(0, fa0, fa);
+	asm_fence9(fa0, fa); asm_fence_u(raw);                         // cell x is finished before cell x+1 starts
+	one_cell(1, fb0, fb);
+	asm_fence9(fa0, fa); asm_fence9(fb0, fb);                      // all floating-point work is done ...
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3"); // ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
+	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
+	uint32_t ca[19], cb[19];
+	ca[0] = fp16c_code_hi_in_rtz_mode(fa0); cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
+	#pragma unroll
+	for(int k=0; k<9; k++) {
+		fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
+		fp16c_code2_hi_in_rtz_mode(fb[k], cb[2*k+1], cb[2*k+2]);
+	}
+	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };
+	uint32_t cs[5];   // the five x+1 planes, stored last (dword or, on the row-end lane, two halves)
+	#define LUW_REDEFINE_OFFSETS asm volatile("" : "+v"(o.x), "+v"(o.xp)) /* saddr stores, see k_stream_collide_s */
+	LUW_REDEFINE_OFFSETS;
+	st_pair<true>(fi, o.x, pack(0));
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+		if constexpr(!shifted) st_pair<true>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o), pack(i));
+		else cs[k] = pack(i);
+		st_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x, pack(i+1));
+	});
+	if(!wrap&&!tail) {
+		LUW_REDEFINE_OFFSETS;
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) st_pair<false>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o), cs[k]);
+		});
+	} else if(tail) { // the only real cell is x = Nx-1: its x+1 neighbour is the row's x = 0 (the dword load above already started there);
+		// x = 1 belongs to another lane's stores, so only the low half goes out
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) {
+				constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+				*(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)) = (uint16_t)(cs[k]&0xFFFFu);
+			}
+		});
+	} else {
+		LUW_REDEFINE_OFFSETS;
+		static_for_pairs([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if constexpr(i==1||i==7||i==9||i==13||i==15) {
+				constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
+				uint16_t* B = fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb);   // row of the neighbours: x+1 = Nx-1 is its last cell, x+2 its first
+				B[p.Nx-1u] = (uint16_t)(cs[k]&0xFFFFu);
+				B[0] = (uint16_t)(cs[k]>>16);
+			}
+		});
+	}
+	#undef LUW_REDEFINE_OFFSETS
+}
+
