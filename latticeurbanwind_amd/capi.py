@@ -58,9 +58,9 @@ class Config(C.Structure):
 def build(force=False):
     """Compile csrc/luw_core.hip for gfx950 with hipcc (in-tree, so the .so travels with the repo snapshot)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("luw_core.hip", "luw_device.hpp")] + [os.path.join(_HERE, "..", "include", "luw_core.h")]
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in srcs):
-        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    if force and os.path.exists(_SO):
+        os.remove(_SO)
+    subprocess.check_call(["make", "-C", src_dir, "-s"])                          # make knows the sources (luw_core.hip + the kernel headers)
     subprocess.check_call(["make", "-C", os.path.join(_HERE, "host"), "-s"])      # the deck driver (C++ host over the C-ABI)
     return _SO
 
