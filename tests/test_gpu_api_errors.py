@@ -23,7 +23,8 @@ def _create(L, cfg):
 @pytest.mark.parametrize("kw,msg", [
     (dict(Nx=0), "Grid point number is 0"), (dict(Dx=0), "0 LBM grid domains"), (dict(nu=0.0), "Viscosity cannot be 0"), (dict(nu=-1.0), "Viscosity cannot be negative"),
     (dict(ddf_format=7), "unknown ddf_format"), (dict(struct_size=12), "size mismatch"), (dict(Dx=2, Nx=2), "split axes need"), (dict(device=99), "no such HIP device"),
-    (dict(buffer_nudging_active=1, buffer_n_cells=0), "buffer_n_cells"), (dict(options=8, alpha=-0.5), "thermal diffusivity")])
+    (dict(buffer_nudging_active=1, buffer_n_cells=0), "buffer_n_cells"), (dict(options=8, alpha=-0.5), "thermal diffusivity"),
+    (dict(Nx=2048, Ny=2048, Nz=1024), "2^32")])      # 4.3 G cells: beyond the 32-bit cell index (refused before anything is allocated)
 def test_create_rejects_bad_configurations(luw, kw, msg):
     from latticeurbanwind_amd import capi
     L = capi.load()
