@@ -349,3 +349,12 @@ def test_fp32_row_form_addressing_matches_oracle():
                        env=dict(os.environ, LUW_ADDR_ROW="1"), capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
+
+
+def test_1024_cubed_on_one_gpu_properties():
+    """the north-star grid on ONE GPU, FP32: 82 GB of DDFs, planes beyond 32-bit byte offsets (row-form addressing at its real
+    size).  No oracle at 1.07 G cells: the rest state must be an exact fixed point and a periodic shear wave must conserve mass
+    (tools/check_huge.py, in a child process so that its 35 GB of host arrays are gone afterwards)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
