@@ -1,18 +1,18 @@
 #!/usr/bin/env bash
 # Deck in -> VTK out, wall clock: the real reference (shipped build: FP16C DDFs + thermal lattice, and its FP32 build) against this
 # repo's driver on the SAME deck on the GPU box.  The deck is a 512x512x128 profile case with one building, nudging and sponge on,
-# NSTEP steps of which the last PURGE are time-averaged (the reference's "mean-field stage": a device->host copy and a host loop
-# per sample).  usage (via gpurun): tools/e2e_wall.sh [NSTEP] [PURGE]      prints one line per run
+# NSTEP steps (optionally with the VK inlet) of which the last PURGE are time-averaged (the reference's "mean-field stage": a device->host copy and a host loop
+# per sample).  usage (via gpurun): tools/e2e_wall.sh [NSTEP] [PURGE] [vk]      prints one line per run
 set -u
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"; cd "$R"
-NSTEP="${1:-1500}"; PURGE="${2:-500}"
+NSTEP="${1:-1500}"; PURGE="${2:-500}"; VK="${3:-novk}"      # third argument "vk": von-Karman synthetic-turbulence inlet on (the decks' default)
 W=$(mktemp -d)
-python3 - "$W" "$NSTEP" "$PURGE" <<'PY'
+python3 - "$W" "$NSTEP" "$PURGE" "$VK" <<'PY'
 import sys, os
 sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
 import make_refcases as mr
 mr.write_case(sys.argv[1], "E2E", 1.0, ["enable_buffer_nudging = true", "enable_top_sponge = true", "sponge_thickness_m = 64"], dims=(1024, 1024, 192), building=True,
-              nstep=int(sys.argv[2]), unsteady=0, purge=int(sys.argv[3]))
+              nstep=int(sys.argv[2]), unsteady=0, purge=int(sys.argv[3]), vk=(sys.argv[4] == "vk"))
 PY
 grep -n "n_steps\|purge\|cell_size\|si_x_cfd\|si_y_cfd\|si_z_cfd" "$W/E2E/conf.luwpf" | tr '\n' ' '; echo
 run() { # label, binary, options that follow the deck path...
