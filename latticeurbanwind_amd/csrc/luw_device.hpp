@@ -471,15 +471,16 @@ __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t
 	#pragma unroll
 	for(int k=0; k<9; k++) fp[k] = rp[k];
 }
-// conservative, position-only test: could buffer nudging or the top sponge act on this cell (assemble_force)?
+// position-only test: can buffer nudging or the top sponge act on this cell (the zones of assemble_force)?
 __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
 	bool zone = false;
-	if(p.buffer_active) {
+	if(p.buffer_active) { // the same face tests as assemble_force (the downstream face and faces this domain does not own have no zone)
 		const int Nbuf_i = (int)p.buffer_N;
-		const int gx = (int)x+p.Ox, gy = (int)y+p.Oy, gz = (int)z+p.Oz;
-		zone = gx<=Nbuf_i || (int)(p.Nxg-1u)-gx<=Nbuf_i || gy<=Nbuf_i || (int)(p.Nyg-1u)-gy<=Nbuf_i || (int)(p.Nzg-1u)-gz<=Nbuf_i;
+		const int d_w = (int)x+p.Ox, d_e = (int)(p.Nxg-1u)-((int)x+p.Ox), d_s = (int)y+p.Oy, d_n = (int)(p.Nyg-1u)-((int)y+p.Oy), d_t = (int)(p.Nzg-1u)-((int)z+p.Oz);
+		zone = (p.downstream_face!=1u&&p.has_w&&d_w>=0&&d_w<=Nbuf_i) || (p.downstream_face!=2u&&p.has_e&&d_e>=0&&d_e<=Nbuf_i)
+		    || (p.downstream_face!=3u&&p.has_s&&d_s>=0&&d_s<=Nbuf_i) || (p.downstream_face!=4u&&p.has_n&&d_n>=0&&d_n<=Nbuf_i) || (p.has_t&&d_t>=0&&d_t<=Nbuf_i);
 	}
-	if(p.sponge_active) zone = zone || (int)(p.Nzg-2u)-((int)z+p.Oz)<(int)p.sponge_N;
+	if(p.sponge_active&&p.has_t) { const int d = (int)(p.Nzg-2u)-((int)z+p.Oz); zone = zone || (d>=0&&d<(int)p.sponge_N); }
 	return zone;
 }
 
