@@ -194,9 +194,9 @@ def main():
         D = (1, 1, 1)
     else:
         import torch.distributed as dist
-        from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice
+        from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice, init_rccl_process_group
         if args.share_device is not None: dist.init_process_group("gloo")
-        else: dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else: init_rccl_process_group(local_rank)
         D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
         if D[0] * D[1] * D[2] != world:
             raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
@@ -221,8 +221,9 @@ def main():
             if args.coriolis:
                 sim.backend.set_coriolis(*coriolis_omega())
             return sim, fl
-        sim, fl = make_sim()
+        sim = None
         try:
+            sim, fl = make_sim()        # builds the RCCL connections to the neighbours, then allocates the lattice
             sim.initialize()
             ok = torch.ones(1)
         except Exception as e:      # RCCL p2p refused on this node: say so and fall back to host-staged halos rather than report nothing
@@ -234,7 +235,7 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
             if ok.item() == 0:
                 from latticeurbanwind_amd.distributed import DomainLayout, HostStagedTransport
-                sim.backend.close()
+                if sim is not None: sim.backend.close()
                 sim, fl = make_sim(HostStagedTransport(DomainLayout(gN, D, rank), group=gloo_group))
                 sim.initialize()
                 exchange_note = "host-staged gloo (RCCL point-to-point failed on this node)"

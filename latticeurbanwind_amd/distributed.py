@@ -155,6 +155,41 @@ class TorchDistTransport:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
+    def warm_up(self, device, dtype=None):
+        """One full-size exchange per split axis on scratch buffers, BEFORE the lattice is allocated: RCCL builds its
+        point-to-point connections (channels, staging buffers) at the first send/recv to a peer.  Measured on MI355X
+        (tools/check_nccl_self.py, LUW_SELF_EARLY): when that set-up happens in a process that has already allocated and freed
+        lattice-sized arrays, the interior kernel that follows runs 24 % slower for the life of the solver (2048x258x258 FP32:
+        4.44 instead of 3.55 ms); with the connections built first it does not.  Full-size messages, so that every channel the
+        real faces will use is connected now; the scratch buffers go back to torch's caching allocator, from which the domain's
+        halo buffers of the same sizes are then served."""
+        import torch
+        lN = self.layout.lN
+        for a in self.layout.split_axes():
+            A = lN[(a + 1) % 3] * lN[(a + 2) % 3]
+            bufs = [torch.zeros(5 * A, dtype=dtype or torch.float32, device=device) for _ in range(4)]
+            self.exchange(a, *bufs)
+        torch.cuda.synchronize(device)
+
+
+def init_rccl_process_group(local_rank):
+    """`torch.distributed` over RCCL for one process per GPU.  RCCL's point-to-point kernels are launched while the interior
+    collide-stream kernel fills every CU, so the process group's internal stream is asked to be a high-priority one (like the
+    communication stream of `HipDomain`): the halo copies are dispatched ahead of the interior's remaining workgroups instead
+    of behind them (LUW_COMM_PRIORITY=0 turns both off for A/B runs, LUW_NCCL_PRIORITY=0 this one alone)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    kw = {}
+    if os.environ.get("LUW_NCCL_PRIORITY", os.environ.get("LUW_COMM_PRIORITY", "1")) != "0":
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw["pg_options"] = opts
+        except Exception:           # a torch build without the option: default stream priority
+            pass
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
+
 
 class HostStagedTransport(TorchDistTransport):
     """the same swap staged through host memory, for process groups that cannot move device memory (gloo): lets several
@@ -295,15 +330,20 @@ class DomainDecomposedLBM:
         self.layout = DomainLayout(global_N, D, rank)
         self.lNx, self.lNy, self.lNz = self.layout.lN
         self.global_offset = self.layout.O
-        self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
         if transport is None:
             import torch.distributed as dist
-            staged = isinstance(self.backend, HipDomain) and dist.is_initialized() and dist.get_backend() == "gloo"
+            staged = (backend is None or isinstance(backend, HipDomain)) and dist.is_initialized() and dist.get_backend() == "gloo"
             transport = HostStagedTransport(self.layout) if staged else TorchDistTransport(self.layout)
+            if backend is None and not staged and dist.is_initialized() and dist.get_backend() == "nccl":
+                import torch      # connections to the neighbours first, the lattice second (see TorchDistTransport.warm_up)
+                transport.warm_up(torch.device("cuda", backend_kw.get("device", 0)), torch.float16 if backend_kw.get("fp16c") else torch.float32)
         self.transport = transport
+        self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
         if overlap is None:      # shell/interior overlap pays when the shells are whole rows, i.e. x is not split (see choose_decomposition)
             overlap = self.layout.D[0] == 1
         self.overlap = bool(overlap) and self.layout.can_overlap() and hasattr(self.backend, "comm")
+        import os
+        self.pipeline = os.environ.get("LUW_PIPELINE", "1") != "0"     # A/B switch: 0 = join both streams after every step
         self.initialized = False
         self.pre_step = None     # callable(stream) enqueued before every step's kernels (von-Karman inlet update)
 
@@ -367,16 +407,39 @@ class DomainDecomposedLBM:
         b = self.backend
         lay = self.layout
         ev = []
+        pipelined = self.overlap and self.pipeline
+        if pipelined:
+            import torch
+            shell_done, interior_done = torch.cuda.Event(), torch.cuda.Event()
+            self._join()
         for i in range(steps):
             wf = (i + 1 == steps)
             if self.overlap:
                 comm, comp = b.comm, b.compute
-                comp.wait_stream(comm)                                 # step t needs all of step t-1
-                if self.pre_step is not None:
-                    self.pre_step(comp)
-                comm.wait_stream(comp)
+                if pipelined:
+                    # Who needs what (slot algebra of extract_one/insert_one, luw_kernels_aux.hpp, against load_f/store_f):
+                    # interior cells lie two layers inside the halo, they touch slots of interior and shell cells only, and
+                    # never the planes the pack/unpack kernels use there (pack reads, in a shell cell next to a -y face,
+                    # planes 3/4 7/8 11/12 17/18, the interior writes 13/14 into it; mirrored on the other faces).  So
+                    #   interior(t) needs interior(t-1) [stream order] and shell(t-1);
+                    #   shell(t)    needs interior(t-1), shell(t-1) and the unpack of step t-1 [stream order].
+                    # The interior of the next step therefore starts as soon as the previous one ends, while the exchange of
+                    # the previous step may still be on the wire: no bubble between steps on the compute stream.
+                    if i > 0:
+                        comp.wait_event(shell_done)
+                        comm.wait_event(interior_done)
+                    if self.pre_step is not None:
+                        self.pre_step(comp)
+                        pre = torch.cuda.Event(); pre.record(comp); comm.wait_event(pre)
+                else:
+                    comp.wait_stream(comm)                             # step t needs all of step t-1
+                    if self.pre_step is not None:
+                        self.pre_step(comp)
+                    comm.wait_stream(comp)
                 for box in lay.shell_boxes():
                     b.stream_collide(box, wf, comm)                    # boundary shell first ...
+                if pipelined:
+                    shell_done = torch.cuda.Event(); shell_done.record(comm)
                 if timed:
                     import torch
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,6 +447,8 @@ class DomainDecomposedLBM:
                 b.stream_collide(lay.interior_box(), wf, comp)         # ... interior overlaps the halo traffic
                 if timed:
                     e1.record(comp); ev.append((e0, e1))
+                if pipelined:
+                    interior_done = torch.cuda.Event(); interior_done.record(comp)
                 self.communicate_fi(comm)
             else:
                 st = getattr(b, "compute", None)

@@ -22,7 +22,7 @@ import numpy as np
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks' processes (normally already exported)
 
 from . import capi
-from .distributed import DomainDecomposedLBM, DomainLayout
+from .distributed import DomainDecomposedLBM, DomainLayout, init_rccl_process_group
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DRIVER = os.path.join(HERE, "host", "luw_driver")
@@ -324,7 +324,7 @@ def main(argv=None):
             dist.init_process_group("gloo")
         elif torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            init_rccl_process_group(local_rank)
         else:
             raise SystemExit("run_deck: no GPU visible; the solver has no CPU fallback")
         G = _Dist(dist)
