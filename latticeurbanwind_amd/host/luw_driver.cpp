@@ -45,6 +45,15 @@ using std::string;
 static std::ofstream g_log;
 static void println(const string& s = "") { std::cout << s << "\n"; std::cout.flush(); if(g_log.is_open()) { g_log << s << "\n"; g_log.flush(); } }
 static const uint CONSOLE_WIDTH = 94u; // FX/utilities.hpp:9
+// LUW_DRIVER_TIMING=1: wall time of each phase of the run on stderr (profiling aid; console and log stay as the reference's)
+static void phase_mark(const char* name) {
+	static const bool on = [] { const char* e = std::getenv("LUW_DRIVER_TIMING"); return e&&e[0]=='1'; }();
+	static auto last = std::chrono::steady_clock::now();
+	if(!on) return;
+	const auto now = std::chrono::steady_clock::now();
+	std::fprintf(stderr, "[timing] %-28s %8.3f s\n", name, std::chrono::duration<double>(now-last).count());
+	last = now;
+}
 static string alignr(const uint n, const string& x) { string s(n, ' '); s += x; return s.substr((uint)std::min((int)s.length()-(int)n, (int)n)); }
 static string alignl(const uint n, const string& x) { string s = x+string(n, ' '); return s.substr(0, std::max(n, (uint)x.length())); }
 static string alignc(const uint n, const string& x) { if((uint)x.length()>=n) return x.substr(0u, n); const uint l = (n-(uint)x.length())/2u; return string(l, ' ')+x+string(n-(uint)x.length()-l, ' '); }
@@ -839,6 +848,7 @@ int main(int argc, char** argv) {
 		if(!c.nwp_mode) print_kv_row("Downstream BC", case_bc+(c.dataset_mode ? " (auto from batch angle)" : " (auto from profile angle)"));
 		update_buffer_nudging(case_bc); update_top_sponge();
 
+		phase_mark("deck, sizing, mesh, profile");
 		// host state of this case
 		std::vector<uchar> flags(N, 0u); std::vector<float> u(3ull*N, 0.0f);
 		std::vector<float> Tcell; if(use_temperature_bc) Tcell.assign(N, 1.0f); // lbm.T, FX/lbm.cpp:304
@@ -856,6 +866,7 @@ int main(int argc, char** argv) {
 			std::memcpy(flags.data(), lbm_p->flags.host, N);
 			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
 		}
+		phase_mark("solver create + voxelise");
 		println("| Info: Voxelized cells (whole domain global, no halos): solid = "+to_string_u(nvox)+", fluid = "+to_string_u(N-nvox)+", total = "+to_string_u(N)+".");
 		println("| Voxelization done.                                                          |");
 		print_section_title("BUILD BOUNDARY CONDITIONS");
@@ -1155,6 +1166,7 @@ int main(int argc, char** argv) {
 		}
 		if(c.dry_run) continue;
 
+		phase_mark("boundary conditions");
 		// ---- run_lbm, FX/setup.cpp:4117-4911
 		LBM& lbm = *lbm_p;
 		lbm.set_coriolis(omega[0], omega[1], omega[2]);
@@ -1169,6 +1181,7 @@ int main(int argc, char** argv) {
 		if(!probe_cells.empty()) luw_check(luw_gather_attach(lbm.handle(), (uint32_t)probe_cells.size(), probe_cells.data()));
 		std::vector<float> probe_buf(3u*probe_cells.size());
 		lbm.run(0u, total_steps);
+		phase_mark("upload + initialise");
 		print_section_title("SOLVER START");
 		const auto t_start = std::chrono::steady_clock::now();
 		ulong last_u_vtk_t = ~0ull;
@@ -1192,12 +1205,14 @@ int main(int argc, char** argv) {
 		luw_check(luw_finish(lbm.handle()));
 		const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
 		print_kv_row("Solver", to_string_u(total_steps)+" steps in "+to_string_fd((float)secs, 3u)+" s = "+to_string_fd((float)((double)N*(double)total_steps/secs*1e-6), 1u)+" MLUPs");
+		phase_mark("solver loop");
 		{ // write_final_transient, FX/setup.cpp:4762-4776
 			const ulong t = lbm.get_t();
 			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); }
 			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); print_kv_row("", fr+" saved");
 			if(use_temperature_bc) { lbm.T.read_from_device(); const string ft = default_filename(vtk_dir, "T", t); write_field_vtk(ft, geom, lbm.T.data<float>(), 1u, units.unit_K, units.unit_K_offset, true); print_kv_row("", ft+" saved"); }
 		}
+		phase_mark("final raw VTKs");
 		if(c.research_output_steps>0u) { // maybe_write_transform_info, FX/setup.cpp:4778-4798
 			println("| Writing transform.info...                                                  |");
 			const string info_path = c.parent+"/proj_temp/transform.info";
@@ -1267,6 +1282,7 @@ int main(int argc, char** argv) {
 				print_kv_row("Avg samples", to_string_u(avg_count));
 			}
 		}
+		phase_mark("statistics download + avg VTK");
 		if(!probes.empty()) { // FX/setup.cpp:4718-4760
 			std::filesystem::create_directories(c.parent+"/RESULTS");
 			ulong written = 0ull;
