@@ -210,6 +210,13 @@ int luw_vk_inlet_detach(luw_solver* s);
 int luw_stats_reset(luw_solver* s);
 int luw_stats_accumulate(luw_solver* s);
 int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, uint64_t* count);
+/* The sampling window of run_lbm in one call (FX/setup.cpp:4252-4268: after every step of the purge_avg window with
+ * (t - avg_start) % purge_avg_stride == 0 the reference copies rho,u to the host and updates the statistics): runs `steps` steps
+ * like luw_run; step number first_sample (counted from 1 within this call) and every stride-th step after it are samples.
+ * Equivalent, value for value, to { luw_run(1); luw_stats_accumulate(); } at those steps, but nothing waits on the host in
+ * between and, with the product kernels, a sampled step carries the Welford update in its own epilogue (the rho,u it would
+ * have written and read back never travel: 56 instead of 88 B per cell and sample).  Needs luw_stats_reset first. */
+int luw_run_sampled(luw_solver* s, uint64_t steps, uint64_t first_sample, uint64_t stride);
 int luw_stats_download_T(luw_solver* s, float* avg_T);   /* running mean of T (LUW_OPT_TEMPERATURE), T_avg of FX/setup.cpp:4481-4484 */
 
 /* device self-check: number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C

@@ -142,7 +142,7 @@ static uint32_t row_block(const uint32_t nx) {
 	for(uint32_t bx : {192u, 128u, 64u}) { const uint32_t lanes = ((nx+bx-1u)/bx)*bx; if(lanes<best_lanes) { best = bx; best_lanes = lanes; } }
 	return best;
 }
-template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields) {
+template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	T* fi = (T*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
 	const int xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
@@ -155,7 +155,13 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Np*sizeof(T)<=(1ull<<32) && !force_row;
 	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
 	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
-	if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
+	if(st) { // a sampled step of the product kernel (can_fuse_stats): the Welford update rides on the cell update
+		#define LUW_LAUNCH_ST(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 0, 2, FL, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, *st)
+		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_ST(1, true); else LUW_LAUNCH_ST(0, true); } else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); } }
+		else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); }
+		#undef LUW_LAUNCH_ST
+	}
+	else if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
 		#define LUW_LAUNCH_T(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 4, 2, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T)
 		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_T(1, true); else LUW_LAUNCH_T(0, true); } else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); } }
 		else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); }
@@ -171,12 +177,14 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	#undef LUW_LAUNCH_S
 }
 
-static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
+static void launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	uint16_t* fi = (uint16_t*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
 	const uint32_t nx = (b.x1-b.x0+1u)/2u;                         // an odd count only when the box ends at an odd Nx: the last lane owns one cell
 	const uint32_t bx = row_block(nx);
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+	if(st) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 0, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, *st);
+		else hipLaunchKernelGGL((k_stream_collide_p<0, 0, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, *st); return; }
 	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
@@ -186,7 +194,13 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields) {
 
 // Kernel choice.  LUW_KERNEL_AUTO = the scalar kernel (FP32: 39.5k MLUPS at 512^3; vector kernels 20-29k) and, for FP16C rows
 // wide enough, the pair kernel (profiles/r01_kernel_ab.md).  The other kernels stay selectable for A/B runs.
-static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields) {
+// can a sampled step carry the Welford update itself?  Product kernels only (scalar / pair, no thermal lattice: its T statistics
+// stay with k_stats_accumulate); LUW_FUSE_STATS=0 keeps the separate kernel (A/B and test aid)
+static bool can_fuse_stats(const luw_solver* s) {
+	static const bool off = getenv("LUW_FUSE_STATS")!=nullptr && getenv("LUW_FUSE_STATS")[0]=='0';
+	return !off && !s->d_gi && (s->kernel==LUW_KERNEL_AUTO||s->kernel==LUW_KERNEL_SCALAR||s->kernel==LUW_KERNEL_PAIR);
+}
+static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
@@ -205,7 +219,9 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 		const bool whole_pairs = ((b.x1-b.x0)&1u)==0u || (!s->kp.halo_x && b.x1==s->cfg.Nx);
 		if(!fp16||!starts_aligned||!whole_pairs) k = LUW_KERNEL_SCALAR;
 	}
-	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields);
+	if(st&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) return fail(LUW_ERR_STATE, "stream_collide: this kernel has no fused statistics");
+	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields, st);
+	else if(st) { if(fp16) launch_scalar<uint16_t>(s, b, write_fields, st); else launch_scalar<float>(s, b, write_fields, st); }
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
@@ -801,7 +817,7 @@ static int vk_apply(luw_solver* s) {
 	return LUW_OK;
 }
 
-static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
+static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms, const uint64_t first_sample = 0ull, const uint64_t stride = 0ull) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_run: null solver");
 	if(int e = set_device(s)) return e;
 	if(!s->initialized) { if(int e = luw_initialize(s)) return e; } // LBM::run initialises on first use, FX/lbm.cpp:1294-1296
@@ -813,12 +829,19 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 		for(auto& e : ev) HIP_TRY(hipEventCreate(&e));
 	}
 	for(uint64_t i=0ull; i<steps; i++) {
-		const int wf = (every||i+1ull==steps) ? 1 : 0;
+		int wf = (every||i+1ull==steps) ? 1 : 0;
+		// luw_run_sampled: step i+1 of this call is a statistics sample
+		const bool sampled = stride>0ull && i+1ull>=first_sample && (i+1ull-first_sample)%stride==0ull;
+		const bool fused = sampled && can_fuse_stats(s);
+		StatsArgs st{};
+		if(fused) { s->avg_count++; st = StatsArgs{ s->d_avg_u, s->d_avg_rho, s->d_m2, 1.0f/(float)s->avg_count }; } // FX/setup.cpp:4442-4443
+		if(sampled&&!fused) wf = 1;
 		if(int e = vk_apply(s)) return e; // pre_step_update of the reference's run loop, FX/setup.cpp:4872
 		if(mean_kernel_ms) HIP_TRY(hipEventRecord(ev[2u*i], s->stream));
-		if(int e = launch_stream_collide(s, whole, wf)) return e;
+		if(int e = launch_stream_collide(s, whole, wf, fused ? &st : nullptr)) return e;
 		if(mean_kernel_ms) HIP_TRY(hipEventRecord(ev[2u*i+1u], s->stream));
 		s->t++;
+		if(sampled&&!fused) { s->fields_current = true; if(int e = luw_stats_accumulate(s)) return e; s->fields_current = false; }
 	}
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if(steps>0ull) s->fields_current = true;
@@ -831,6 +854,12 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 	return LUW_OK;
 }
 int luw_run(luw_solver* s, uint64_t steps) { return run_steps(s, steps, nullptr); }
+int luw_run_sampled(luw_solver* s, uint64_t steps, uint64_t first_sample, uint64_t stride) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_run_sampled: null solver");
+	if(first_sample==0ull||stride==0ull) return fail(LUW_ERR_INVALID, "luw_run_sampled: first_sample and stride count from 1");
+	if(!s->d_avg_u) return fail(LUW_ERR_STATE, "luw_run_sampled: call luw_stats_reset first");
+	return run_steps(s, steps, nullptr, first_sample, stride);
+}
 int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 	if(!mean_kernel_ms) return fail(LUW_ERR_INVALID, "luw_run_timed: null output");
 	return run_steps(s, steps, mean_kernel_ms);

@@ -77,3 +77,62 @@ template<typename Fn> __device__ __forceinline__ void static_for_pairs(Fn&& fn) 
 template<bool NT, typename T> __device__ __forceinline__ T ldg(const T* p) { if constexpr(NT) return __builtin_nontemporal_load(p); else return *p; }
 template<bool NT, typename T> __device__ __forceinline__ void stg(T* p, const T v) { if constexpr(NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
+// ---------------------------------------------------------------- statistics fused into the step ("fused epilogue")
+// A sampled step updates Welford's mean / M2 (accumulate_from_buffers, FX/setup.cpp:4441-4488) with the rho,u this step shows,
+// straight from the registers of the cell update: the 16 B/cell round trip through rho,u (written by the step, read back by
+// k_stats_accumulate) disappears.  Same operations in the same order as k_stats_accumulate, hence the same bits.  The seven
+// new values pass through an empty volatile asm before they are stored: volatile asms keep their order, so the arithmetic
+// cannot sink behind the FP16C kernels' switch to round-toward-zero at the tail.
+struct StatsArgs { float* avg_u; float* avg_rho; float* m2; float inv_n; };
+__device__ __forceinline__ void stats_welford(const size_t Np, const StatsArgs& S, const uint32_t n, const float r, const float ux, const float uy, const float uz) {
+	const float v[3] = { ux, uy, uz };
+	float mean[3], m2n[3];
+	#pragma unroll
+	for(int c=0; c<3; c++) {
+		mean[c] = ldg<true>(S.avg_u+c*Np+n);
+		const float delta = v[c]-mean[c];
+		mean[c] += delta*S.inv_n;
+		const float delta2 = v[c]-mean[c];
+		m2n[c] = ldg<true>(S.m2+c*Np+n)+delta*delta2;
+	}
+	const float ra = ldg<true>(S.avg_rho+n);
+	float rn = ra+(r-ra)*S.inv_n;
+	asm volatile("" : "+v"(mean[0]), "+v"(mean[1]), "+v"(mean[2]), "+v"(m2n[0]), "+v"(m2n[1]), "+v"(m2n[2]), "+v"(rn));
+	#pragma unroll
+	for(int c=0; c<3; c++) { stg<true>(S.m2+c*Np+n, m2n[c]); stg<true>(S.avg_u+c*Np+n, mean[c]); }
+	stg<true>(S.avg_rho+n, rn);
+}
+// pair kernel: the cells (n, n+1) of one lane together, 8-byte accesses (n is even there).  A cell without a sample (halo, row
+// padding) gets its old values written back.  Separate 4-byte passes per cell would fetch every line twice (measured: slower
+// than the separate statistics kernel).
+struct PairSample { float r[2], ux[2], uy[2], uz[2]; bool has[2]; };
+__device__ __forceinline__ void stats_welford_pair(const size_t Np, const StatsArgs& S, const uint32_t n, const PairSample& q) {
+	f32x2 mean[3], m2n[3];
+	#pragma unroll
+	for(int c=0; c<3; c++) {
+		const float* v = c==0 ? q.ux : c==1 ? q.uy : q.uz;
+		const f32x2 m0 = ldg<true>(reinterpret_cast<const f32x2*>(S.avg_u+c*Np+n)), s0 = ldg<true>(reinterpret_cast<const f32x2*>(S.m2+c*Np+n));
+		const float mo[2] = { m0.x, m0.y }, so[2] = { s0.x, s0.y };
+		float mn[2], sn[2];
+		#pragma unroll
+		for(int h=0; h<2; h++) {
+			const float delta = v[h]-mo[h];
+			const float mm = mo[h]+delta*S.inv_n;
+			const float delta2 = v[h]-mm;
+			mn[h] = q.has[h] ? mm : mo[h];
+			sn[h] = q.has[h] ? so[h]+delta*delta2 : so[h];
+		}
+		mean[c] = f32x2{ mn[0], mn[1] }; m2n[c] = f32x2{ sn[0], sn[1] };
+	}
+	const f32x2 ra = ldg<true>(reinterpret_cast<const f32x2*>(S.avg_rho+n));
+	f32x2 rn = { q.has[0] ? ra.x+(q.r[0]-ra.x)*S.inv_n : ra.x, q.has[1] ? ra.y+(q.r[1]-ra.y)*S.inv_n : ra.y };
+	asm volatile("" : "+v"(mean[0]), "+v"(mean[1]), "+v"(mean[2]), "+v"(rn), "+v"(m2n[0]), "+v"(m2n[1]), "+v"(m2n[2]));
+	#pragma unroll
+	for(int c=0; c<3; c++) { stg<true>(reinterpret_cast<f32x2*>(S.m2+c*Np+n), m2n[c]); stg<true>(reinterpret_cast<f32x2*>(S.avg_u+c*Np+n), mean[c]); }
+	stg<true>(reinterpret_cast<f32x2*>(S.avg_rho+n), rn);
+}
+// a cell the step does not update (solid) or whose fields are inputs (TYPE_E): the sample is what rho,u hold
+__device__ __forceinline__ void stats_welford_from_fields(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho, const float* __restrict__ u) {
+	stats_welford(Np, S, n, rho[n], u[n], u[Np+n], u[2ull*Np+n]);
+}
+

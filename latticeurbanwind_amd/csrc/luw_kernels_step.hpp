@@ -114,8 +114,9 @@ template<typename T> struct CellAddr<T, true> {
 #ifndef LUW_MAXW_F32
 #define LUW_MAXW_F32 4
 #endif
-template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
-		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
+// STATS: this step is a statistics sample (stats_welford, luw_kernels_common.hpp); product MODE 0 only.
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, const StatsArgs S = StatsArgs{}) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
 	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
@@ -129,8 +130,11 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false> __global
 	fi += a.init(p, x, y, z, MODE==2);
 	const uint32_t n = a.n;
 	const uint8_t flagsn = flags[n];
-	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) return;
 	const size_t Np = p.Np;
+	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) {
+		if constexpr(STATS) stats_welford_from_fields(Np, S, n, rho, u);
+		return;
+	}
 	float f[19];
 	f[0] = ddf_decode<T>(ldo<(NT!=0)>(fi, a.own()));
 	static_for_pairs([&](auto ic) {
@@ -153,6 +157,10 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false> __global
 			u[n] = uxn;
 			u[Np+n] = uyn;
 			u[2ull*Np+n] = uzn;
+		}
+		if constexpr(STATS) {
+			if((flagsn&TYPE_BO)==TYPE_E) stats_welford_from_fields(Np, S, n, rho, u); // TYPE_E keeps its input fields (UPDATE_FIELDS skips it)
+			else stats_welford(Np, S, n, rhon, uxn, uyn, uzn);
 		}
 	}
 	// the ten offsets pass through an empty asm so that they are (re)defined as 32-bit values in the block that holds the
@@ -225,8 +233,8 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
 	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
 }
-template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
-		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
+template<int PARITY, int MODE=0, bool STATS=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	const RowOff rb = row_offsets(p, y, z);
@@ -242,7 +250,14 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 	#pragma unroll
 	for(int c=0; c<2; c++) proc[c] = !cell_is_halo(p, x+c, y, z) && (fl[c]&TYPE_BO)!=TYPE_S && (fl[c]&TYPE_SU)!=TYPE_G;
 	if(tail) proc[1] = false;                                      // passes through: reads and rewrites padding, except on the x+1 planes (below)
-	if(!proc[0]&&!proc[1]) return;
+	// STATS: a cell that is not updated but belongs to the lattice (solid) samples the fields it holds
+	[[maybe_unused]] PairSample smp;
+	[[maybe_unused]] auto sample_from_fields = [&](const int c) { smp.r[c] = rho[n+c]; smp.ux[c] = u[n+c]; smp.uy[c] = u[Np+n+c]; smp.uz[c] = u[2ull*Np+n+c]; smp.has[c] = true; };
+	[[maybe_unused]] auto sample_idle_cell = [&](const int c) { smp.r[c] = smp.ux[c] = smp.uy[c] = smp.uz[c] = 0.0f; smp.has[c] = false; if(!(c==1&&tail) && !cell_is_halo(p, x+c, y, z)) sample_from_fields(c); };
+	if(!proc[0]&&!proc[1]) {
+		if constexpr(STATS) { sample_idle_cell(0); sample_idle_cell(1); stats_welford_pair(Np, S, n, smp); }
+		return;
+	}
 	// All 19 dword loads in one straight run.  For the row-end lane (wrap) the high half of the five x+1 dwords is the element
 	// behind the row end (the next row's x = 0, or the slack behind the plane: in bounds, see lead_alloc / the plane skew):
 	// it is replaced by the wrapped neighbour in ONE divergent fix-up block behind the loads.
@@ -286,15 +301,21 @@ template<int PARITY, int MODE=0> __global__ __launch_bounds__(256) __attribute__
 				u[Np+n+c] = uyn;
 				u[2ull*Np+n+c] = uzn;
 			}
+			if constexpr(STATS) {
+				if((fl[c]&TYPE_BO)==TYPE_E) sample_from_fields(c);
+				else { smp.r[c] = rhon; smp.ux[c] = uxn; smp.uy[c] = uyn; smp.uz[c] = uzn; smp.has[c] = true; }
+			}
 		} else {
 			#pragma unroll
 			for(int k=0; k<9; k++) { const f32x2 t = { fp[k].y, fp[k].x }; fp[k] = t; }
+			if constexpr(STATS) sample_idle_cell(c);
 		}
 	};
 	float fa0, fb0; f32x2 fa[9], fb[9];
 	one_cell(0, fa0, fa);
 	asm_fence9(fa0, fa); asm_fence_u(raw);                         // cell x is finished before cell x+1 starts
 	one_cell(1, fb0, fb);
+	if constexpr(STATS) stats_welford_pair(Np, S, n, smp);        // both cells' samples, one 8-byte access per array
 	asm_fence9(fa0, fa); asm_fence9(fb0, fb);                      // all floating-point work is done ...
 	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3"); // ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
 	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h

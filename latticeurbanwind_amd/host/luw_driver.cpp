@@ -1190,12 +1190,14 @@ int main(int argc, char** argv) {
 			// written by the last step of each run() call
 			ulong next = total_steps;
 			if(unsteady>0ull) next = std::min(next, (ulong)((lbm.get_t()/unsteady+1ull)*unsteady));
-			if(avg_window>0ull) { const ulong t1 = lbm.get_t()+1ull; ulong s = std::max(t1, avg_start_t); const ulong off = (s-avg_start_t)%avg_stride; if(off!=0ull) s += avg_stride-off; if(s<=total_steps) next = std::min(next, s); }
 			if(!probes.empty()) next = std::min(next, std::max((ulong)(lbm.get_t()+1ull), probe_start_t)); // every step of the probe window is observed
-			lbm.run(next-lbm.get_t(), total_steps);
+			// statistics samples that fall into (t, next] ride along (luw_run_sampled): first sample s, then every avg_stride-th step
+			ulong first_sample = 0ull;
+			if(avg_window>0ull) { const ulong t1 = lbm.get_t()+1ull; ulong s = std::max(t1, avg_start_t); const ulong off = (s-avg_start_t)%avg_stride; if(off!=0ull) s += avg_stride-off; if(s<=next) first_sample = s; }
+			if(first_sample>0ull) luw_check(luw_run_sampled(lbm.handle(), next-lbm.get_t(), first_sample-lbm.get_t(), avg_stride));
+			else lbm.run(next-lbm.get_t(), total_steps);
 			const ulong t = lbm.get_t();
 			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); last_u_vtk_t = t; }
-			if(avg_window>0ull&&t>=avg_start_t&&(t-avg_start_t)%avg_stride==0ull) luw_check(luw_stats_accumulate(lbm.handle()));
 			if(!probes.empty()&&t>=probe_start_t) { // FX/setup.cpp:4498-4509
 				luw_check(luw_gather_u(lbm.handle(), probe_buf.data()));
 				size_t k = 0u;

@@ -152,6 +152,10 @@ class LBM:
     # ---- on-device time averaging (replaces FX/setup.cpp:4441-4542)
     def stats_reset(self): capi.check(self._L.luw_stats_reset(self._h))
     def stats_accumulate(self): capi.check(self._L.luw_stats_accumulate(self._h))
+    def run_sampled(self, steps, first_sample=1, stride=1):
+        """`steps` steps of which number first_sample (from 1) and every stride-th after it are statistics samples
+        (the purge_avg window of run_lbm, FX/setup.cpp:4252-4268)"""
+        capi.check(self._L.luw_run_sampled(self._h, int(steps), int(first_sample), int(stride)))
     def stats_download(self):
         N = self.get_N()
         out = dict(avg_u=np.zeros(3 * N, np.float32), avg_rho=np.zeros(N, np.float32), m2_u=np.zeros(N, np.float32),

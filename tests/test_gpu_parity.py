@@ -149,6 +149,37 @@ def test_on_device_time_averaging_matches_host_welford(luw, size):
         g.stats_accumulate()
 
 
+@pytest.mark.parametrize("size,fp16c,kernel", [((24, 20, 16), False, "s"), ((37, 9, 5), False, "s"), ((40, 12, 6), True, "s"),
+                                               ((512, 6, 5), True, "p"), ((259, 5, 4), True, "p")])
+@pytest.mark.parametrize("first,stride", [(1, 1), (3, 2)])
+def test_sampled_run_with_fused_statistics_matches_host_welford(luw, size, fp16c, kernel, first, stride):
+    # luw_run_sampled: sampled steps carry the Welford update in the step kernel's epilogue (scalar and pair kernels, solids,
+    # TYPE_E cells, odd row widths).  Must equal the reference's host loop (FX/setup.cpp:4441-4488) on the oracle's fields bit
+    # for bit, leave the same rho,u as a plain run, and equal the separate-kernel path (LUW_FUSE_STATS=0 is process-wide, so
+    # that path is compared through { run(1); stats_accumulate() }).
+    from oracle import oracle
+    Nx, Ny, Nz = size
+    st = synthetic_state(Nx, Ny, Nz, seed=21, shell="luw")
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-3, fp16c, kernel, st)
+    g2, _ = make_pair(luw, oracle, Nx, Ny, Nz, 1e-3, fp16c, kernel, st)
+    stats = oracle.OracleStats(o.N)
+    g.run(4); o.run(4); g2.run(4)
+    g.stats_reset(); g2.stats_reset()
+    steps = 9
+    g.run_sampled(steps, first, stride)
+    n = 0
+    for i in range(1, steps + 1):
+        o.run(1); g2.run(1)
+        if i >= first and (i - first) % stride == 0:
+            stats.accumulate(o); g2.stats_accumulate(); n += 1
+    check(g, o, "fields after the sampled run")
+    d, d2 = g.stats_download(), g2.stats_download()
+    assert d["count"] == n == d2["count"]
+    for k in ("avg_u", "avg_rho", "m2_u", "m2_v", "m2_w"):
+        assert np.array_equal(d[k], getattr(stats, k)), k
+        assert np.array_equal(d[k], d2[k]), k
+
+
 def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
     # size-independent property at a bench-class size (the oracle would take minutes): both kernels, same bits
     from latticeurbanwind_amd import capi
