@@ -307,6 +307,11 @@ class HipDomain:
         self.lbm.stats_accumulate()
         self.compute.synchronize()
 
+    def stats_enqueue(self, stream):
+        """the Welford update on `stream`, no host synchronisation (sampled steps inside DomainDecomposedLBM.run)"""
+        self.lbm.set_stream(stream.cuda_stream)
+        self.lbm.stats_accumulate()
+
     def stats_download(self):
         self.lbm.set_stream(self.compute.cuda_stream)
         return self.lbm.stats_download()
@@ -401,21 +406,28 @@ class DomainDecomposedLBM:
         if hasattr(b, "comm"):
             b.comm.synchronize(); b.compute.synchronize()
 
-    def run(self, steps, timed=False):
+    def run(self, steps, timed=False, sample=None):
+        """`steps` steps.  sample = (first, stride): step number `first` of this call (from 1) and every stride-th after it are
+        statistics samples (the purge_avg window, FX/setup.cpp:4252-4268): those steps write rho,u and the Welford kernel follows
+        on the compute stream -- no host synchronisation, the overlap of exchange and interior continues through the window."""
         if not self.initialized:
             self.initialize()
         b = self.backend
         lay = self.layout
         ev = []
+        stats_done = None
         pipelined = self.overlap and self.pipeline
         if pipelined:
             import torch
             shell_done, interior_done = torch.cuda.Event(), torch.cuda.Event()
             self._join()
         for i in range(steps):
-            wf = (i + 1 == steps)
+            sampled = sample is not None and i + 1 >= sample[0] and (i + 1 - sample[0]) % sample[1] == 0
+            wf = (i + 1 == steps) or sampled
             if self.overlap:
                 comm, comp = b.comm, b.compute
+                if wf and stats_done is not None:
+                    comm.wait_event(stats_done); stats_done = None     # this step's shell rewrites the rho,u the last sample reads
                 if pipelined:
                     # Who needs what (slot algebra of extract_one/insert_one, luw_kernels_aux.hpp, against load_f/store_f):
                     # interior cells lie two layers inside the halo, they touch slots of interior and shell cells only, and
@@ -450,12 +462,23 @@ class DomainDecomposedLBM:
                 if pipelined:
                     interior_done = torch.cuda.Event(); interior_done.record(comp)
                 self.communicate_fi(comm)
+                if sampled:
+                    import torch
+                    if pipelined:
+                        comp.wait_event(shell_done)                    # the sample reads rho,u of shell and interior cells
+                    else:
+                        comp.wait_stream(comm)
+                    b.stats_enqueue(comp)
+                    stats_done = torch.cuda.Event(); stats_done.record(comp)
             else:
                 st = getattr(b, "compute", None)
                 if self.pre_step is not None:
                     self.pre_step(st)
                 b.stream_collide(lay.whole_box(), wf, st)
                 self.communicate_fi(st)
+                if sampled:
+                    if hasattr(b, "stats_enqueue") and st is not None: b.stats_enqueue(st)
+                    else: b.stats_accumulate()
             b.increment_time_step(1)
         self._join()
         if timed and ev:

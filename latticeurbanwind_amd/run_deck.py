@@ -230,17 +230,16 @@ def run_case(m, G, device, log, make_sim=None, literal_n_gpu=False):
         nxt = total
         if unsteady > 0:
             nxt = min(nxt, (t // unsteady + 1) * unsteady)
+        if cols:
+            nxt = min(nxt, max(t + 1, probe_start))       # every step of the probe window is observed
+        sample = None                                     # statistics samples inside (t, nxt] ride along, no host round trip
         if avg_window > 0:
             s = max(t + 1, avg_start); off = (s - avg_start) % avg_stride
             if off: s += avg_stride - off
-            if s <= total: nxt = min(nxt, s)
-        if cols:
-            nxt = min(nxt, max(t + 1, probe_start))       # every step of the probe window is observed
-        sim.run(nxt - t); t = nxt
+            if s <= nxt: sample = (s - t, avg_stride)
+        sim.run(nxt - t, sample=sample); t = nxt
         if unsteady > 0 and t % unsteady == 0:
             write_u(t); last_u = t
-        if avg_window > 0 and t >= avg_start and (t - avg_start) % avg_stride == 0:
-            sim.backend.stats_accumulate()
         if cols and t >= probe_start:
             probe_times.append(t)
             if my_cells:
