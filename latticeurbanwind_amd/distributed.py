@@ -344,8 +344,13 @@ class DomainDecomposedLBM:
                 transport.warm_up(torch.device("cuda", backend_kw.get("device", 0)), torch.float16 if backend_kw.get("fp16c") else torch.float32)
         self.transport = transport
         self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
-        if overlap is None:      # shell/interior overlap pays when the shells are whole rows, i.e. x is not split (see choose_decomposition)
-            overlap = self.layout.D[0] == 1
+        if overlap is None:
+            # Shell/interior overlap.  x kept whole (whole-row shells): always.  x split: the 64-cell x slabs cost the step 4 %
+            # (512^3 rank of n_gpu=[4,2,1] with pipelined steps: 3.94-3.98 ms against 3.78-3.89 for whole box + exchange when the
+            # exchange is a device-local copy), which any real wire time (>= 0.3 ms for its four faces) outweighs; LUW_X_OVERLAP=0
+            # restores whole box + exchange there.
+            import os
+            overlap = self.layout.D[0] == 1 or os.environ.get("LUW_X_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and self.layout.can_overlap() and hasattr(self.backend, "comm")
         import os
         self.pipeline = os.environ.get("LUW_PIPELINE", "1") != "0"     # A/B switch: 0 = join both streams after every step

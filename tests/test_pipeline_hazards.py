@@ -82,6 +82,23 @@ def test_interior_of_next_step_is_disjoint_from_the_exchange(D, gN, thermal):
         assert shell & touched_by_exchange
 
 
+@pytest.mark.parametrize("x_shell", [1, 2])
+@pytest.mark.parametrize("D,gN", [((2, 1, 1), (16, 5, 4)), ((2, 2, 1), (20, 12, 4)), ((2, 2, 2), (16, 12, 12))])
+def test_x_split_layouts_are_disjoint_too(monkeypatch, D, gN, x_shell):
+    # x split (a deck's literal n_gpu = [4, 2, 1]): the same property with x boundary slabs of any thickness
+    monkeypatch.setattr(DomainLayout, "X_SHELL", x_shell)
+    lay = DomainLayout(gN, D, 1)
+    lN = tuple(lay.lN)
+    assert lay.interior_box()[1] > lay.interior_box()[0]
+    for t in (0, 1):
+        interior = set()
+        for cell in box_cells(lay.interior_box()):
+            interior |= step_slots(cell, t + 1, lN, 19)
+        for axis in lay.split_axes():
+            reads, writes = transfer_slots(axis, t, lN, False)
+            assert not (interior & reads) and not (interior & writes)
+
+
 def test_shell_and_interior_tile_the_owned_cells():
     lay = DomainLayout((6, 12, 10), (1, 2, 2), 3)
     cells = list(box_cells(lay.interior_box()))

@@ -38,7 +38,7 @@ class SelfNeighbour(TorchDistTransport):
 
 
 def run(transport_of):
-    sim = DomainDecomposedLBM(N, D, 1.48e-7, rank=0, transport=None if transport_of is None else Loopback(), overlap=True, fp16c=(dt == "fp16c"), device=0)
+    sim = DomainDecomposedLBM(N, D, 1.48e-7, rank=0, transport=None if transport_of is None else Loopback(), overlap=(os.environ.get("LUW_SELF_OVERLAP", "1") != "0"), fp16c=(dt == "fp16c"), device=0)
     if transport_of is not None:
         sim.transport = transport_of(sim.layout)
     fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, *sim.global_offset, *N)
