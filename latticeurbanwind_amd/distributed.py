@@ -172,7 +172,7 @@ class TorchDistTransport:
         torch.cuda.synchronize(device)
 
 
-def init_rccl_process_group(local_rank):
+def init_rccl_process_group(local_rank, timeout=None):
     """`torch.distributed` over RCCL for one process per GPU.  RCCL's point-to-point kernels are launched while the interior
     collide-stream kernel fills every CU, so the process group's internal stream is asked to be a high-priority one (like the
     communication stream of `HipDomain`): the halo copies are dispatched ahead of the interior's remaining workgroups instead
@@ -188,6 +188,8 @@ def init_rccl_process_group(local_rank):
             kw["pg_options"] = opts
         except Exception:           # a torch build without the option: default stream priority
             pass
+    if timeout is not None:
+        kw["timeout"] = timeout
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
 
 

@@ -315,31 +315,37 @@ def main(argv=None):
     a = ap.parse_args(argv)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        if a.share_device is not None:
-            local_rank = a.share_device
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo")
-        elif torch.cuda.is_available():
-            torch.cuda.set_device(local_rank)
-            init_rccl_process_group(local_rank)
-        else:
-            raise SystemExit("run_deck: no GPU visible; the solver has no CPU fallback")
-        G = _Dist(dist)
-    else:
-        G = _Single()
-    capi.load()
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and a.share_device is not None:
+        local_rank = a.share_device
+    if world > 1 and a.share_device is None and torch.cuda.device_count() == 0:
+        raise SystemExit("run_deck: no GPU visible; the solver has no CPU fallback")
     parent = os.path.dirname(os.path.abspath(a.deck)) or "."
     scratch = os.path.join(parent, "proj_temp", "run_deck_setup")
-    log = (lambda s: print(s, flush=True)) if G.rank == 0 else (lambda s: None)
-    if G.rank == 0:
+    log = (lambda s: print(s, flush=True)) if rank == 0 else (lambda s: None)
+    # The C++ host stage runs first, on rank 0, BEFORE any rank opens its GPU or joins the process group: the other ranks wait in
+    # the rendezvous of init_process_group (no GPU involved), so the host stage's own device work (voxeliser) never shares the
+    # card with more processes than the run itself (several ranks on one GPU in the tests: the box allows six).
+    if rank == 0:
         shutil.rmtree(scratch, ignore_errors=True)
         cmd = [DRIVER, a.deck, "--ddf", a.ddf, "--device", str(local_rank), "--export-setup", scratch] + (["--dry-run"] if a.host_voxeliser else [])
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         sys.stdout.write(r.stdout); sys.stdout.flush()
         if r.returncode != 0:
             raise SystemExit("run_deck: host stage failed (exit %d)" % r.returncode)
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        if a.share_device is not None:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(hours=4))
+            torch.cuda.set_device(local_rank)
+        else:
+            torch.cuda.set_device(local_rank)
+            init_rccl_process_group(local_rank, timeout=datetime.timedelta(hours=4))
+        G = _Dist(dist)
+    else:
+        G = _Single()
+    capi.load()
     G.barrier()
     k = 1
     while os.path.exists(os.path.join(scratch, "case%d.json" % k)):
