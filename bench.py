@@ -277,7 +277,7 @@ def main():
         # HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same
         # command (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), and
         # committed under profiles/; reported here only when that profile is of this workload
-        prof = os.path.join(ROOT, "profiles", "r01f_pair_fp16c_512_summary.json" if (fp16c and args.kernel == "auto") else ("r01d_scalar_fp16c_512_summary.json" if fp16c else "r01f_scalar_f32_512_summary.json"))
+        prof = os.path.join(ROOT, "profiles", "r01g_pair_fp16c_512_summary.json" if (fp16c and args.kernel == "auto") else ("r01d_scalar_fp16c_512_summary.json" if fp16c else "r01g_scalar_f32_512_summary.json"))
         if (Nx, Ny, Nz) == (512, 512, 512) and args.kernel in ("auto", "scalar") and not args.every_step_fields and os.path.exists(prof):
             pr = json.load(open(prof))
             out["roofline"]["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
