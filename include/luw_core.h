@@ -145,7 +145,11 @@ uint64_t luw_get_plane_stride(const luw_solver* s);
 int luw_set_stream(luw_solver* s, void* hip_stream);                      /* stream used by all enqueue calls; NULL = solver's own */
 /* enqueue ONE stream_collide over the box [x0,x1) x [y0,y1) x [z0,z1) of local cells at the current t, without
  * incrementing t and without host synchronisation (interior / boundary-shell split of the multi-GPU driver).
- * write_fields != 0 also stores rho,u. */
+ * write_fields bit 0: also store rho,u; bit 1 (LUW_WF_SAMPLE): this step is a statistics sample and the box carries the
+ * Welford update of its cells itself -- call luw_stats_begin_sample once per sampled step before its boxes; when it reports
+ * fused = 0 (thermal lattice, A/B kernels) write the fields instead and call luw_stats_accumulate after the step. */
+#define LUW_WF_SAMPLE 2
+int luw_stats_begin_sample(luw_solver* s, int* fused);
 int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, int write_fields);
 int luw_increment_time_step(luw_solver* s, uint64_t steps);               /* LBM_Domain::increment_time_step */
 int luw_reset_time_step(luw_solver* s);                                   /* LBM_Domain::reset_time_step */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
     "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
-    "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
+    "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
 
@@ -122,6 +122,7 @@ def load():
     L.luw_stats_reset.argtypes = [vp]
     L.luw_stats_accumulate.argtypes = [vp]
     L.luw_run_sampled.argtypes = [vp, u64, u64, u64]
+    L.luw_stats_begin_sample.argtypes = [vp, C.POINTER(i32)]
     L.luw_stats_download.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.luw_stats_download_T.argtypes = [vp, vp]
     if L.luw_abi_version() != 2:

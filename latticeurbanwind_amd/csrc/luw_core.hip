@@ -781,8 +781,21 @@ int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t
 	if(!s->initialized) return fail(LUW_ERR_STATE, "luw_enqueue_stream_collide: call luw_initialize first");
 	if(int e = set_device(s)) return e;
 	const Box b = { x0, x1, y0, y1, z0, z1 };
-	s->fields_current = write_fields!=0; // callers cover the lattice with boxes of one step using the same flag
-	return launch_stream_collide(s, b, write_fields);
+	const int wf = write_fields&1;
+	s->fields_current = wf!=0; // callers cover the lattice with boxes of one step using the same flag
+	if(write_fields&LUW_WF_SAMPLE) { // a box of a sampled step (luw_stats_begin_sample counted it)
+		if(!s->d_avg_u||!can_fuse_stats(s)||s->avg_count==0ull) return fail(LUW_ERR_STATE, "luw_enqueue_stream_collide: LUW_WF_SAMPLE needs luw_stats_begin_sample to have returned fused = 1");
+		const StatsArgs st = { s->d_avg_u, s->d_avg_rho, s->d_m2, 1.0f/(float)s->avg_count };
+		return launch_stream_collide(s, b, wf, &st);
+	}
+	return launch_stream_collide(s, b, wf);
+}
+int luw_stats_begin_sample(luw_solver* s, int* fused) {
+	if(!s||!fused) return fail(LUW_ERR_INVALID, "luw_stats_begin_sample: bad argument");
+	if(!s->d_avg_u) return fail(LUW_ERR_STATE, "luw_stats_begin_sample: call luw_stats_reset first");
+	*fused = can_fuse_stats(s) ? 1 : 0;
+	if(*fused) s->avg_count++;
+	return LUW_OK;
 }
 int luw_set_kernel(luw_solver* s, uint32_t kernel) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_set_kernel: null solver");

@@ -244,9 +244,11 @@ class HipDomain:
     def increment_time_step(self, n=1): self.lbm.increment_time_step(n)
     def reset_time_step(self): self.lbm.reset_time_step()
 
-    def stream_collide(self, box, write_fields, stream):
+    def stream_collide(self, box, write_fields, stream, sample=False):
         self.lbm.set_stream(stream.cuda_stream)
-        self.lbm.enqueue_stream_collide(box, write_fields)
+        self.lbm.enqueue_stream_collide(box, write_fields, sample)
+
+    def stats_begin_sample(self): return self.lbm.stats_begin_sample()
 
     def extract(self, axis, stream):
         self.lbm.set_stream(stream.cuda_stream)
@@ -430,6 +432,11 @@ class DomainDecomposedLBM:
             self._join()
         for i in range(steps):
             sampled = sample is not None and i + 1 >= sample[0] and (i + 1 - sample[0]) % sample[1] == 0
+            # fused: every box of the step updates the statistics of its own cells (each cell always on the same stream, so
+            # samples of a cell stay ordered); otherwise the step writes rho,u and the statistics kernel follows
+            fused = sampled and hasattr(b, "stats_begin_sample") and b.stats_begin_sample()
+            kw = {"sample": True} if fused else {}
+            if fused: sampled = False
             wf = (i + 1 == steps) or sampled
             if self.overlap:
                 comm, comp = b.comm, b.compute
@@ -456,14 +463,14 @@ class DomainDecomposedLBM:
                         self.pre_step(comp)
                     comm.wait_stream(comp)
                 for box in lay.shell_boxes():
-                    b.stream_collide(box, wf, comm)                    # boundary shell first ...
+                    b.stream_collide(box, wf, comm, **kw)              # boundary shell first ...
                 if pipelined:
                     shell_done = torch.cuda.Event(); shell_done.record(comm)
                 if timed:
                     import torch
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(comp)
-                b.stream_collide(lay.interior_box(), wf, comp)         # ... interior overlaps the halo traffic
+                b.stream_collide(lay.interior_box(), wf, comp, **kw)   # ... interior overlaps the halo traffic
                 if timed:
                     e1.record(comp); ev.append((e0, e1))
                 if pipelined:
@@ -481,7 +488,7 @@ class DomainDecomposedLBM:
                 st = getattr(b, "compute", None)
                 if self.pre_step is not None:
                     self.pre_step(st)
-                b.stream_collide(lay.whole_box(), wf, st)
+                b.stream_collide(lay.whole_box(), wf, st, **kw)
                 self.communicate_fi(st)
                 if sampled:
                     if hasattr(b, "stats_enqueue") and st is not None: b.stats_enqueue(st)

@@ -185,9 +185,15 @@ class LBM:
     # ---- device-level interface (multi-GPU driver)
     def area(self, direction): return int(self._L.luw_get_area(self._h, direction))
     def set_stream(self, stream_ptr): capi.check(self._L.luw_set_stream(self._h, stream_ptr))
-    def enqueue_stream_collide(self, box, write_fields=False):
+    def enqueue_stream_collide(self, box, write_fields=False, sample=False):
         x0, x1, y0, y1, z0, z1 = box
-        capi.check(self._L.luw_enqueue_stream_collide(self._h, x0, x1, y0, y1, z0, z1, int(write_fields)))
+        capi.check(self._L.luw_enqueue_stream_collide(self._h, x0, x1, y0, y1, z0, z1, int(bool(write_fields)) | (2 if sample else 0)))
+
+    def stats_begin_sample(self):
+        """counts a sampled step; True when its boxes can carry the statistics themselves (enqueue_stream_collide(..., sample=True))"""
+        fused = C.c_int32(0)
+        capi.check(self._L.luw_stats_begin_sample(self._h, C.byref(fused)))
+        return bool(fused.value)
     def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_extract_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_gi(self._h, direction, buf_p_ptr, buf_m_ptr))

@@ -41,7 +41,18 @@ def test_call_order_and_argument_checks(luw):
     assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 0) == capi.ERR_STATE and "luw_initialize first" in L.luw_last_error().decode()
     assert L.luw_download_gi(h, buf.ctypes.data_as(C.c_void_p)) == capi.ERR_STATE and "LUW_OPT_TEMPERATURE" in L.luw_last_error().decode()
     assert L.luw_stats_accumulate(h) == capi.ERR_STATE and "luw_stats_reset first" in L.luw_last_error().decode()
+    assert L.luw_run_sampled(h, 4, 1, 1) == capi.ERR_STATE and "luw_stats_reset first" in L.luw_last_error().decode()
+    fused = C.c_int32(7)
+    assert L.luw_stats_begin_sample(h, C.byref(fused)) == capi.ERR_STATE and "luw_stats_reset first" in L.luw_last_error().decode()
     assert L.luw_run(h, 3) == 0 and L.luw_get_t(h) == 3                                   # run() initialises on first use, FX/lbm.cpp:1294-1296
+    assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 2) == capi.ERR_STATE and "luw_stats_begin_sample" in L.luw_last_error().decode()   # LUW_WF_SAMPLE without statistics
+    assert L.luw_stats_reset(h) == 0
+    assert L.luw_run_sampled(h, 4, 0, 1) == capi.ERR_INVALID and "count from 1" in L.luw_last_error().decode()
+    assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 2) == capi.ERR_STATE          # no sample counted yet
+    assert L.luw_stats_begin_sample(h, C.byref(fused)) == 0 and fused.value == 1
+    assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 2) == 0 and L.luw_finish(h) == 0 and L.luw_increment_time_step(h, 1) == 0
+    assert L.luw_run(h, 2) == 0 and L.luw_get_t(h) == 6
+    L.luw_reset_time_step(h); assert L.luw_run(h, 3) == 0 and L.luw_get_t(h) == 3
     assert L.luw_enqueue_stream_collide(h, 0, 9, 0, 8, 0, 8, 0) == capi.ERR_INVALID and "exceeds the local lattice" in L.luw_last_error().decode()
     assert L.luw_enqueue_stream_collide(h, 4, 4, 0, 8, 0, 8, 0) == 0                      # empty box: nothing to do
     cells = np.array([8 * 8 * 8], np.uint64)
