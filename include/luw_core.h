@@ -219,7 +219,9 @@ int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u,
  * like luw_run; step number first_sample (counted from 1 within this call) and every stride-th step after it are samples.
  * Equivalent, value for value, to { luw_run(1); luw_stats_accumulate(); } at those steps, but nothing waits on the host in
  * between and, with the product kernels, a sampled step carries the Welford update in its own epilogue (the rho,u it would
- * have written and read back never travel: 56 instead of 88 B per cell and sample).  Needs luw_stats_reset first. */
+ * have written and read back never travel: 56 instead of 88 B per cell and sample).  Cells the step never updates (TYPE_S) are
+ * taken as the constants they are: mean = field value, M2 = 0 -- what Welford's update yields for a constant, bit for bit.
+ * Needs luw_stats_reset first. */
 int luw_run_sampled(luw_solver* s, uint64_t steps, uint64_t first_sample, uint64_t stride);
 int luw_stats_download_T(luw_solver* s, float* avg_T);   /* running mean of T (LUW_OPT_TEMPERATURE), T_avg of FX/setup.cpp:4481-4484 */
 

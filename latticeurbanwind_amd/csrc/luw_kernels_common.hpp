@@ -131,7 +131,17 @@ __device__ __forceinline__ void stats_welford_pair(const size_t Np, const StatsA
 	for(int c=0; c<3; c++) { stg<true>(reinterpret_cast<f32x2*>(S.m2+c*Np+n), m2n[c]); stg<true>(reinterpret_cast<f32x2*>(S.avg_u+c*Np+n), mean[c]); }
 	stg<true>(reinterpret_cast<f32x2*>(S.avg_rho+n), rn);
 }
-// a cell the step does not update (solid) or whose fields are inputs (TYPE_E): the sample is what rho,u hold
+// A cell the step never updates (solid): its rho,u are constants, and Welford's update of a constant c from the reset state is
+// exactly mean = c, M2 = +0 after any number of samples (0 + (c-0)*1 = c; then c + (c-c)*inv_n = c; M2 = 0 + c*(c-c) = +0).
+// Stored as such, without arithmetic: a wave runs this branch AFTER its fluid lanes have gone through the kernel's tail, i.e.
+// with the FP16C kernels' round-toward-zero mode already set (the mode is per wave, not per lane) -- no floating-point
+// instruction may sit here (tests/test_isa_contract.py follows the control flow behind the switch).
+__device__ __forceinline__ void stats_hold_constant_cell(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho, const float* __restrict__ u) {
+	#pragma unroll
+	for(int c=0; c<3; c++) { stg<true>(S.avg_u+c*Np+n, u[c*Np+n]); stg<true>(S.m2+c*Np+n, 0.0f); }
+	stg<true>(S.avg_rho+n, rho[n]);
+}
+// a cell whose fields are inputs (TYPE_E): the sample is what rho,u hold
 __device__ __forceinline__ void stats_welford_from_fields(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho, const float* __restrict__ u) {
 	stats_welford(Np, S, n, rho[n], u[n], u[Np+n], u[2ull*Np+n]);
 }

@@ -132,7 +132,7 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STA
 	const uint8_t flagsn = flags[n];
 	const size_t Np = p.Np;
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) {
-		if constexpr(STATS) stats_welford_from_fields(Np, S, n, rho, u);
+		if constexpr(STATS) stats_hold_constant_cell(Np, S, n, rho, u);
 		return;
 	}
 	float f[19];
@@ -255,7 +255,10 @@ template<int PARITY, int MODE=0, bool STATS=false> __global__ __launch_bounds__(
 	[[maybe_unused]] auto sample_from_fields = [&](const int c) { smp.r[c] = rho[n+c]; smp.ux[c] = u[n+c]; smp.uy[c] = u[Np+n+c]; smp.uz[c] = u[2ull*Np+n+c]; smp.has[c] = true; };
 	[[maybe_unused]] auto sample_idle_cell = [&](const int c) { smp.r[c] = smp.ux[c] = smp.uy[c] = smp.uz[c] = 0.0f; smp.has[c] = false; if(!(c==1&&tail) && !cell_is_halo(p, x+c, y, z)) sample_from_fields(c); };
 	if(!proc[0]&&!proc[1]) {
-		if constexpr(STATS) { sample_idle_cell(0); sample_idle_cell(1); stats_welford_pair(Np, S, n, smp); }
+		if constexpr(STATS) { // two idle cells (solid / halo / padding): constants, stored without arithmetic (stats_hold_constant_cell)
+			if(!cell_is_halo(p, x, y, z)) stats_hold_constant_cell(Np, S, n, rho, u);
+			if(!tail&&!cell_is_halo(p, x+1u, y, z)) stats_hold_constant_cell(Np, S, n+1u, rho, u);
+		}
 		return;
 	}
 	// All 19 dword loads in one straight run.  For the row-end lane (wrap) the high half of the five x+1 dwords is the element

@@ -33,12 +33,36 @@ def device_asm(tmp_path_factory):
             kernels[name] = body; name = None
         elif name:
             t = line.strip()
-            if t and not t.startswith((";", ".")):
+            if re.match(r"^\.LBB\w+:", t):
+                body.append(t.split(":")[0] + ":")               # block labels stay: the RTZ test follows the control flow
+            elif t and not t.startswith((";", ".")):
                 body.append(t)
     return kernels
 
 
 FP_ARITH = re.compile(r"^v_(add|sub|subrev|fma|fmac|mad|mac|div|rcp|rsq|sqrt|min|max|med3|cvt|exp|log|sin|cos|ldexp|frexp|trunc|ceil|floor|rndne|fract|pk_fma|pk_add)_?\w*f(16|32|64)")
+
+
+def reachable_from(body, start):
+    """instructions a wave can execute from position `start` on (fall-through and branches followed; blocks that merely
+    sit behind the switch in the file but are entered from before it do not count)"""
+    label = {t[:-1]: i for i, t in enumerate(body) if t.endswith(":")}
+    seen, work = set(), [start]
+    while work:
+        i = work.pop()
+        while i < len(body) and i not in seen:
+            seen.add(i)
+            t = body[i]
+            if t.startswith("s_endpgm"):
+                break
+            m = re.match(r"^s_(c?branch\w*)\s+(\.LBB\w+)", t)
+            if m:
+                work.append(label[m.group(2)])
+                if m.group(1) == "branch":
+                    break
+            assert not t.startswith(("s_setpc", "s_swappc")), "indirect jump behind the switch"
+            i += 1
+    return [body[i] for i in sorted(seen) if not body[i].endswith(":")]
 
 
 def test_nothing_but_the_encode_follows_the_rounding_mode_switch(device_asm):
@@ -49,7 +73,7 @@ def test_nothing_but_the_encode_follows_the_rounding_mode_switch(device_asm):
             continue
         assert len(idx) == 1, name
         seen += 1
-        tail = body[idx[0] + 1:]
+        tail = reachable_from(body, idx[0] + 1)
         bad = [t for t in tail if FP_ARITH.match(t)]
         assert not bad, "%s: floating-point work behind the RTZ switch: %s" % (name, bad[:5])
         muls = [t for t in tail if t.startswith(("v_mul_f32", "v_pk_mul_f32"))]
@@ -61,8 +85,13 @@ def test_nothing_but_the_encode_follows_the_rounding_mode_switch(device_asm):
 def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
     # scalar kernel: FP32 in both addressing forms (FLAT for planes within 32-bit byte offsets, row form beyond), FP16C in the row form;
     # pair kernel; both time parities each
-    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]E", n) or re.search(r"k_stream_collide_pILi[01]ELi0E", n)]
+    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb0E", n) or re.search(r"k_stream_collide_pILi[01]ELi0ELb0E", n)]
     assert len(product) == 8, product
+    # the same kernels with the statistics epilogue (sampled steps): no spills either
+    sampled = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb1E", n) or re.search(r"k_stream_collide_pILi[01]ELi0ELb1E", n)]
+    assert len(sampled) == 8, sampled
+    for name in sampled:
+        assert not any(t.startswith(("scratch_", "buffer_store", "buffer_load")) for t in device_asm[name]), name + ": spills"
     for name in product:
         body = device_asm[name]
         assert not any(t.startswith(("scratch_", "buffer_store", "buffer_load")) for t in body), name + ": spills"
