@@ -195,6 +195,9 @@ def main():
     else:
         import torch.distributed as dist
         from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice, init_rccl_process_group
+        if world == 1:      # --force-distributed without a launcher: a one-rank world over loopback
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29537"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(k, v)
         if args.share_device is not None: dist.init_process_group("gloo")
         else: init_rccl_process_group(local_rank)
         D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
