@@ -417,8 +417,10 @@ class DomainDecomposedLBM:
 
     def run(self, steps, timed=False, sample=None):
         """`steps` steps.  sample = (first, stride): step number `first` of this call (from 1) and every stride-th after it are
-        statistics samples (the purge_avg window, FX/setup.cpp:4252-4268): those steps write rho,u and the Welford kernel follows
-        on the compute stream -- no host synchronisation, the overlap of exchange and interior continues through the window."""
+        statistics samples (the purge_avg window, FX/setup.cpp:4252-4268): the boxes of such a step carry the Welford update of
+        their cells themselves (LUW_WF_SAMPLE) or, where the kernels cannot (thermal lattice), the step writes rho,u and the
+        statistics kernel follows on the compute stream -- either way no host synchronisation, the overlap of exchange and
+        interior continues through the window."""
         if not self.initialized:
             self.initialize()
         b = self.backend
@@ -426,8 +428,9 @@ class DomainDecomposedLBM:
         ev = []
         stats_done = None
         pipelined = self.overlap and self.pipeline
-        if pipelined:
+        if self.overlap:
             import torch
+        if pipelined:
             shell_done, interior_done = torch.cuda.Event(), torch.cuda.Event()
             self._join()
         for i in range(steps):
@@ -467,7 +470,6 @@ class DomainDecomposedLBM:
                 if pipelined:
                     shell_done = torch.cuda.Event(); shell_done.record(comm)
                 if timed:
-                    import torch
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(comp)
                 b.stream_collide(lay.interior_box(), wf, comp, **kw)   # ... interior overlaps the halo traffic
@@ -477,7 +479,6 @@ class DomainDecomposedLBM:
                     interior_done = torch.cuda.Event(); interior_done.record(comp)
                 self.communicate_fi(comm)
                 if sampled:
-                    import torch
                     if pipelined:
                         comp.wait_event(shell_done)                    # the sample reads rho,u of shell and interior cells
                     else:
