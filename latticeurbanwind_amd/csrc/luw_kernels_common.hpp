@@ -84,23 +84,26 @@ template<bool NT, typename T> __device__ __forceinline__ void stg(T* p, const T 
 // new values pass through an empty volatile asm before they are stored: volatile asms keep their order, so the arithmetic
 // cannot sink behind the FP16C kernels' switch to round-toward-zero at the tail.
 struct StatsArgs { float* avg_u; float* avg_rho; float* m2; float inv_n; };
+#ifndef LUW_STATS_NT
+#define LUW_STATS_NT true   /* cache policy of the scalar kernels' statistics accesses (A/B: -DLUW_STATS_NT=false) */
+#endif
 __device__ __forceinline__ void stats_welford(const size_t Np, const StatsArgs& S, const uint32_t n, const float r, const float ux, const float uy, const float uz) {
 	const float v[3] = { ux, uy, uz };
 	float mean[3], m2n[3];
 	#pragma unroll
 	for(int c=0; c<3; c++) {
-		mean[c] = ldg<true>(S.avg_u+c*Np+n);
+		mean[c] = ldg<LUW_STATS_NT>(S.avg_u+c*Np+n);
 		const float delta = v[c]-mean[c];
 		mean[c] += delta*S.inv_n;
 		const float delta2 = v[c]-mean[c];
-		m2n[c] = ldg<true>(S.m2+c*Np+n)+delta*delta2;
+		m2n[c] = ldg<LUW_STATS_NT>(S.m2+c*Np+n)+delta*delta2;
 	}
-	const float ra = ldg<true>(S.avg_rho+n);
+	const float ra = ldg<LUW_STATS_NT>(S.avg_rho+n);
 	float rn = ra+(r-ra)*S.inv_n;
 	asm volatile("" : "+v"(mean[0]), "+v"(mean[1]), "+v"(mean[2]), "+v"(m2n[0]), "+v"(m2n[1]), "+v"(m2n[2]), "+v"(rn));
 	#pragma unroll
-	for(int c=0; c<3; c++) { stg<true>(S.m2+c*Np+n, m2n[c]); stg<true>(S.avg_u+c*Np+n, mean[c]); }
-	stg<true>(S.avg_rho+n, rn);
+	for(int c=0; c<3; c++) { stg<LUW_STATS_NT>(S.m2+c*Np+n, m2n[c]); stg<LUW_STATS_NT>(S.avg_u+c*Np+n, mean[c]); }
+	stg<LUW_STATS_NT>(S.avg_rho+n, rn);
 }
 // pair kernel: the cells (n, n+1) of one lane together, 8-byte accesses (n is even there).  A cell without a sample (halo, row
 // padding) gets its old values written back.  Separate 4-byte passes per cell would fetch every line twice (measured: slower
