@@ -1225,6 +1225,7 @@ int main(int argc, char** argv) {
 		if(avg_window>0ull) { // finalize_avg + write_avg_vtk, FX/setup.cpp:4693-4717,2513-2683
 			std::vector<float> avg_u(3ull*N), avg_rho(N), m2u(N), m2v(N), m2w(N); uint64_t avg_count = 0ull;
 			luw_check(luw_stats_download(lbm.handle(), avg_u.data(), avg_rho.data(), m2u.data(), m2v.data(), m2w.data(), &avg_count));
+			phase_mark("  statistics download");
 			if(avg_count>0ull) {
 				const string fn = default_filename(results_vtk_dir, vtk_prefix+c.datetime+"_avg", lbm.get_t());
 				std::filesystem::create_directories(std::filesystem::path(fn).parent_path());
@@ -1276,6 +1277,7 @@ int main(int argc, char** argv) {
 					const float tls_local = (S_mag>1.0e-10f&&k_local>0.0f) ? sqrtf(k_local)/S_mag : 0.0f;
 					tls[n] = fminf(fmaxf(tls_local, 0.0f), tls_cap);
 				});
+				phase_mark("  u_avg, rho_avg written; tke/TI/TLS computed");
 				write_field("fluid", fluid.data(), 1u, 1.0f);
 				if(c.out_tke) write_field("tke", tke.data(), 1u, u_factor*u_factor);
 				if(c.out_ti) write_field("TI", ti.data(), 1u, 1.0f);
