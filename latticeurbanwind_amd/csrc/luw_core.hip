@@ -22,6 +22,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <memory>
 
 using namespace luw;
 
@@ -711,10 +713,16 @@ int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u,
 	const uint64_t N = s->N;
 	int e = LUW_OK;
 	if(avg_u) { // the reference keeps u_avg as AoS [3n+c] (FX/setup.cpp:4453-4477): interleave on the host
-		std::vector<float> tmp(3ull*N);
-		if((e = copy_pitched(tmp.data(), s->d_avg_u, 4u, s, 3u, false, s->stream))) return e;
+		std::unique_ptr<float[]> tmp(new float[3ull*N]); // fully written by the copy: no value-initialisation
+		if((e = copy_pitched(tmp.get(), s->d_avg_u, 4u, s, 3u, false, s->stream))) return e;
 		HIP_TRY(hipStreamSynchronize(s->stream));
-		for(uint64_t n=0ull; n<N; n++) { avg_u[3ull*n] = tmp[n]; avg_u[3ull*n+1ull] = tmp[N+n]; avg_u[3ull*n+2ull] = tmp[2ull*N+n]; }
+		const unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+		std::vector<std::thread> th;
+		for(unsigned t=0u; t<T; t++) th.emplace_back([&, t]() {
+			const float* src = tmp.get();
+			for(uint64_t n=N*t/T; n<N*(t+1ull)/T; n++) { avg_u[3ull*n] = src[n]; avg_u[3ull*n+1ull] = src[N+n]; avg_u[3ull*n+2ull] = src[2ull*N+n]; }
+		});
+		for(auto& x : th) x.join();
 	}
 	if(avg_rho) if((e = copy_pitched(avg_rho, s->d_avg_rho, 4u, s, 1u, false, s->stream))) return e;
 	float* m2h[3] = { m2_u, m2_v, m2_w };

@@ -410,10 +410,10 @@ static void write_field_vtk(const string& filename, const VtkGeom& g, const floa
 	const string header = vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n";
 	file.write(header.c_str(), (std::streamsize)header.length());
 	const ulong N = (ulong)g.Nx*g.Ny*g.Nz, points = (ulong)g.Nx*g.Ny*g.Nz_out;
-	std::vector<float> buf(points*comps);
+	std::unique_ptr<float[]> conv(new float[points*comps]); float* const buf = conv.get(); // every element is written below: no value-initialisation
 	// the field named T goes through units.si_T (value*unit_K + offset), every other one through its unit factor (FX/lbm.hpp:343)
 	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(affine ? data[(ulong)d*N+i]*factor+offset : factor*data[(ulong)d*N+i]); });
-	file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
+	file.write((const char*)buf, (std::streamsize)(points*comps*4ull));
 }
 
 // ------------------------------------------------------------------------------------------------ main
@@ -1223,8 +1223,10 @@ int main(int argc, char** argv) {
 			else println("ERROR: Could not open "+info_path+" for writing.");
 		}
 		if(avg_window>0ull) { // finalize_avg + write_avg_vtk, FX/setup.cpp:4693-4717,2513-2683
-			std::vector<float> avg_u(3ull*N), avg_rho(N), m2u(N), m2v(N), m2w(N); uint64_t avg_count = 0ull;
-			luw_check(luw_stats_download(lbm.handle(), avg_u.data(), avg_rho.data(), m2u.data(), m2v.data(), m2w.data(), &avg_count));
+			// 7 floats per cell, every one of them overwritten by the download: no value-initialisation (a 1.4 GB memset at 50 M cells)
+			std::unique_ptr<float[]> stats_mem(new float[7ull*N]); uint64_t avg_count = 0ull;
+			float* const avg_u = stats_mem.get(); float* const avg_rho = avg_u+3ull*N; float* const m2u = avg_rho+N; float* const m2v = m2u+N; float* const m2w = m2v+N;
+			luw_check(luw_stats_download(lbm.handle(), avg_u, avg_rho, m2u, m2v, m2w, &avg_count));
 			phase_mark("  statistics download");
 			if(avg_count>0ull) {
 				const string fn = default_filename(results_vtk_dir, vtk_prefix+c.datetime+"_avg", lbm.get_t());
@@ -1233,23 +1235,24 @@ int main(int argc, char** argv) {
 				const string header = vtk_header(fn, geom); file.write(header.c_str(), (std::streamsize)header.length());
 				const ulong points = (ulong)Nx*Ny*Nz_out;
 				const float u_factor = units.si_u(1.0f), rho_factor = units.si_rho(1.0f), spacing = geom.spacing;
+				std::unique_ptr<float[]> conv(new float[3ull*points]); float* const buf = conv.get(); // one conversion buffer for all fields, fully written before each use
 				auto write_field = [&](const string& name, const float* data, const uint comps, const float factor) {
 					const string fh = "SCALARS "+name+" float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n"; file.write(fh.c_str(), (std::streamsize)fh.length());
-					std::vector<float> buf(points*comps);
 					parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(data[i*comps+d]*factor+0.0f); });
-					file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
+					file.write((const char*)buf, (std::streamsize)(points*comps*4ull));
 				};
-				write_field("u_avg", avg_u.data(), 3u, u_factor);
-				write_field("rho_avg", avg_rho.data(), 1u, rho_factor);
+				write_field("u_avg", avg_u, 3u, u_factor);
+				write_field("rho_avg", avg_rho, 1u, rho_factor);
 				if(use_temperature_bc) { // T_avg in Kelvin: factor si_dT(1), offset si_T(0), FX/setup.cpp:2526-2528,2580-2582
 					std::vector<float> avg_T(N); luw_check(luw_stats_download_T(lbm.handle(), avg_T.data()));
 					const string fh = "SCALARS T_avg float 1\nLOOKUP_TABLE default\n"; file.write(fh.c_str(), (std::streamsize)fh.length());
-					std::vector<float> buf(points); const float tf = units.si_dT(1.0f), to = units.si_T(0.0f);
+					const float tf = units.si_dT(1.0f), to = units.si_T(0.0f);
 					parallel_for(points, [&](const ulong i) { buf[i] = reverse_bytes(avg_T[i]*tf+to); });
-					file.write((const char*)buf.data(), (std::streamsize)(buf.size()*4u));
+					file.write((const char*)buf, (std::streamsize)(points*4ull));
 				}
-				std::vector<float> fluid(points, 1.0f), tke, ti, tls;
-				if(c.out_tke) tke.assign(points, 0.0f); if(c.out_ti) ti.assign(points, 0.0f); if(c.out_tls) tls.assign(points, 0.0f);
+				// derived fields: every element is set by the loop below (defaults first), so the arrays start uninitialised
+				std::unique_ptr<float[]> derived(new float[4ull*points]);
+				float* const fluid = derived.get(); float* const tke = fluid+points; float* const ti = tke+points; float* const tls = ti+points;
 				const bool has_m2 = avg_count>1ull; const float inv_n = has_m2 ? 1.0f/(float)avg_count : 0.0f;
 				const float grid_dx = fmaxf(spacing, 1.0e-12f); const ulong plane = (ulong)Nx*Ny;
 				const float tls_cap = (float)std::max(std::max(Nx, Ny), Nz_out)*grid_dx;
@@ -1258,6 +1261,7 @@ int main(int argc, char** argv) {
 				parallel_for(points, [&](const ulong n) {
 					const bool solid = (fl[n]&TYPE_S)!=0u;
 					fluid[n] = solid ? 0.0f : 1.0f;
+					tke[n] = 0.0f; ti[n] = 0.0f; tls[n] = 0.0f;
 					if(!has_m2||solid) return;
 					if(!(c.out_tke||c.out_ti||c.out_tls)) return;
 					const float var_u = fmaxf(m2u[n]*inv_n, 0.0f), var_v = fmaxf(m2v[n]*inv_n, 0.0f), var_w = fmaxf(m2w[n]*inv_n, 0.0f), var_sum = var_u+var_v+var_w;
@@ -1278,10 +1282,10 @@ int main(int argc, char** argv) {
 					tls[n] = fminf(fmaxf(tls_local, 0.0f), tls_cap);
 				});
 				phase_mark("  u_avg, rho_avg written; tke/TI/TLS computed");
-				write_field("fluid", fluid.data(), 1u, 1.0f);
-				if(c.out_tke) write_field("tke", tke.data(), 1u, u_factor*u_factor);
-				if(c.out_ti) write_field("TI", ti.data(), 1u, 1.0f);
-				if(c.out_tls) write_field("TLS", tls.data(), 1u, 1.0f);
+				write_field("fluid", fluid, 1u, 1.0f);
+				if(c.out_tke) write_field("tke", tke, 1u, u_factor*u_factor);
+				if(c.out_ti) write_field("TI", ti, 1u, 1.0f);
+				if(c.out_tls) write_field("TLS", tls, 1u, 1.0f);
 				print_kv_row("VTK file", fn+" saved");
 				print_kv_row("Avg samples", to_string_u(avg_count));
 			}
