@@ -4,12 +4,18 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 512^3 D3Q19 channel per GPU, FP32 DDFs, Smagorinsky LES on,
-z=0 plane solid, the other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the
-same profile, rho=1.  N>1 runs the weak-scaled tile (512^3 cells per GPU; 8 GPUs = BASELINE configs[3] 2048x1024x512, cut as
-n_gpu=[1,4,2] by default, --n-gpu 4 2 1 for the deck's literal grid) with one-cell halos exchanged over RCCL.  A "step" is one stream_collide pass over the whole lattice;
-rho/u are written by the last step only (153 B/LUP mode); data is synthetic and resident in HBM
-before the timed region.  Prints ONE JSON line on rank 0.
+N = 1 (the driver's BENCH line): BASELINE.json configs[2] ("C3", the largest single-GPU configuration): 1024x1024x256 D3Q19,
+voxelised building cluster (SURVEY 8d closed-form box array), bounce-back, Smagorinsky LES, FP32 DDFs, z=0 plane solid, the
+other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the same profile, rho=1.  The same JSON
+line carries `secondary` blocks measured in the same process after the headline: configs[1] ("C2", 512^3 empty channel) and the
+north star's 1024^3 grid, FP32 and FP16C each, and C3 with FP16C DDFs (--no-secondary skips them; --workload picks another
+headline).
+N > 1 (the driver's SCALE runs): the urban tile of BASELINE configs[3] weak-scaled at 512^3 cells per GPU (8 GPUs:
+2048x1024x512) -- building array, buffer nudging and top sponge with the deck defaults (160 m / 300 s, 200 m / 120 s), cut
+as n_gpu=[1,4,2] by default (--n-gpu 4 2 1 = the deck's literal grid, also measured as a secondary block), one-cell halos over
+RCCL.  There is no fallback transport: if RCCL point-to-point fails the run exits non-zero.
+A "step" is one stream_collide pass over the whole lattice; rho/u are written by the last step only (153 B/LUP mode, see
+DESIGN.md); data is synthetic and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -27,6 +33,14 @@ os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: gloo (side chann
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_LUP = {"f32": 153.0, "fp16c": 77.0}   # 19 DDF reads + 19 DDF writes + 1 flag byte (FX/lbm.cpp:122)
+NU = 1.48e-7                    # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
+CELL_M, DT_S = 2.0, 2.0 * 0.1 / 10.0            # the unit system behind NU: 2 m cells, dt = cell * u_lbm / U_ref
+
+WORKLOADS = {   # name -> (lattice, building array, BASELINE.json reference)
+    "c3": ((1024, 1024, 256), True, "BASELINE configs[2]"),
+    "c2": ((512, 512, 512), False, "BASELINE configs[1]"),
+    "cube1024": ((1024, 1024, 1024), False, "north-star 1024^3-class grid"),
+}
 
 
 def loglaw_profile(nz, u_max=0.1):
@@ -38,28 +52,51 @@ def loglaw_profile(nz, u_max=0.1):
     return (u_max * u / u.max()).astype(np.float32)
 
 
-def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None, buildings=False):
-    """flags/u/rho of the (sub)box [gx0,gx0+Nx) x ... of the global channel GNx x GNy x GNz (wind along +x).
+BUILDING_TOP = 1 + 8 + 47      # no building cell at or above this z (heights 8 + (.. mod 48), standing on the z=0 plane)
+
+
+def fill_channel(flags, u, rho, Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None, buildings=False):
+    """Writes flags/u/rho of the (sub)box [gx0,gx0+Nx) x ... of the global channel GNx x GNy x GNz (wind along +x) into the
+    given arrays (reference layout, e.g. a solver's host mirrors), in place and without lattice-sized temporaries.
     buildings=True adds BASELINE configs[2]'s solid mask: an array of axis-aligned boxes, footprint 24x24 cells on a 64-cell
     pitch, heights 8+((7i+13j) mod 48) cells (closed form)"""
     GNx, GNy, GNz = GNx or Nx, GNy or Ny, GNz or Nz
     prof = loglaw_profile(GNz)
     zs = (np.arange(Nz) + gz0) % GNz; ys = (np.arange(Ny) + gy0) % GNy; xs = (np.arange(Nx) + gx0) % GNx
-    flags = np.zeros((Nz, Ny, Nx), np.uint8)
+    fl3 = flags.reshape(Nz, Ny, Nx); u4 = u.reshape(3, Nz, Ny, Nx)
+    fl3[:] = 0
     bz = (zs == GNz - 1); by = (ys == 0) | (ys == GNy - 1); bx = (xs == 0) | (xs == GNx - 1)
-    flags[bz, :, :] = 2; flags[:, by, :] = 2; flags[:, :, bx] = 2
-    flags[zs == 0, :, :] = 1
-    if buildings:
+    fl3[bz, :, :] = 2; fl3[:, by, :] = 2; fl3[:, :, bx] = 2
+    fl3[zs == 0, :, :] = 1
+    low = np.nonzero(zs < BUILDING_TOP)[0]                                     # the only z levels that can hold solids
+    if buildings and low.size:
         i, j = xs // 64, ys // 64
         inx = (xs % 64 >= 20) & (xs % 64 < 44) & (xs > 0) & (xs < GNx - 1); iny = (ys % 64 >= 20) & (ys % 64 < 44) & (ys > 0) & (ys < GNy - 1)
         h = 8 + ((7 * i[None, :] + 13 * j[:, None]) % 48)                       # (Ny, Nx) building height in cells
-        solid = (inx[None, :] & iny[:, None])[None, :, :] & (zs[:, None, None] >= 1) & (zs[:, None, None] < 1 + h[None, :, :])
-        flags[solid] = 1
-    u = np.zeros((3, Nz, Ny, Nx), np.float32)
-    u[0] = prof[zs][:, None, None]
-    u[0][flags == 1] = 0.0
-    rho = np.ones((Nz, Ny, Nx), np.float32)
-    return flags.ravel(), u.ravel(), rho.ravel()
+        zl = zs[low]
+        solid = (inx[None, :] & iny[:, None])[None, :, :] & (zl[:, None, None] >= 1) & (zl[:, None, None] < 1 + h[None, :, :])
+        sub = fl3[low]; sub[solid] = 1; fl3[low] = sub
+    u4[0] = prof[zs][:, None, None]; u4[1] = 0.0; u4[2] = 0.0
+    if low.size:
+        sub = u4[0][low]; sub[fl3[low] == 1] = 0.0; u4[0][low] = sub
+    rho[:] = 1.0
+
+
+def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None, buildings=False):
+    """fill_channel into fresh arrays: (flags, u, rho), flat, reference layout"""
+    n = Nx * Ny * Nz
+    flags, u, rho = np.empty(n, np.uint8), np.empty(3 * n, np.float32), np.empty(n, np.float32)
+    fill_channel(flags, u, rho, Nx, Ny, Nz, gx0, gy0, gz0, GNx, GNy, GNz, buildings)
+    return flags, u, rho
+
+
+def tile_forcing():
+    """buffer nudging + top sponge of the urban tile (BASELINE configs[3]/[4]) with the deck defaults of
+    project_template/conf.luw:49-56 in the benchmark's unit system: Nbuf = round(160 m / cell), inv_tau = dt / 300 s
+    (FX/setup.cpp:3844-3856), Nsponge = round(200 m / cell), inv_tau = dt / 120 s (:3867-3881); wind along +x, so the east face
+    is the downstream one (:3756-3761)"""
+    return (dict(n_cells=int(round(160.0 / CELL_M)), inv_tau=DT_S / 300.0, downstream_face=2, nudge_vertical=0),
+            dict(n_cells=int(round(200.0 / CELL_M)), inv_tau=DT_S / 120.0))
 
 
 def reference_parity():
@@ -89,8 +126,7 @@ def reference_parity():
 def coriolis_omega():
     """Omega_earth (0, cos phi, sin phi) dt in lattice units at 31.25 deg N for cell = 2 m, U_ref = 10 m/s, u_lbm = 0.1 (FX/setup.cpp:3800-3823)"""
     import math
-    dt = 2.0 * 0.1 / 10.0
-    return 0.0, 7.292115e-5 * math.cos(math.radians(31.25)) * dt, 7.292115e-5 * math.sin(math.radians(31.25)) * dt
+    return 0.0, 7.292115e-5 * math.cos(math.radians(31.25)) * DT_S, 7.292115e-5 * math.sin(math.radians(31.25)) * DT_S
 
 
 def usable_cores():
@@ -106,34 +142,108 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(max_seconds=20.0):
-    """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port") timed on this box's host
-    cores on a bounded sample of the same workload recipe: 128^3 channel, FP32 DDFs, as many steps as fit.  The
-    thread count is the fastest of a short sweep (over-subscription inside a CPU-limited container is disastrous)."""
+    """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port") timed on this box's host cores on a bounded
+    sample of the benchmark recipe: 256^3 channel, FP32 DDFs, as many steps as fit into max_seconds.  The thread
+    count is the fastest of a short sweep (over-subscription inside a CPU-limited container is disastrous).  Reported with the
+    CPU model and the DRAM bandwidth it amounts to: the restatement moves 169 B per lattice update like the reference's
+    UPDATE_FIELDS kernel (153 + 16 for rho,u every step), set against a copy-kernel bandwidth measured with the same threads."""
     from oracle import oracle
-    N = 128
-    o = oracle.OracleLBM(N, N, N, 1.48e-7)
-    fl, u, rho = channel_state(N, N, N)
-    o.flags[:] = fl; o.u[:] = u; o.rho[:] = rho
-    o.run(2)
+    N = 256
+    o = oracle.OracleLBM(N, N, N, NU)
+    fill_channel(o.flags, o.u, o.rho, N, N, N)
+    o.run(1)
     cores = usable_cores()
     cands = sorted({max(1, c) for c in (cores, cores // 2, cores // 4, 64, 32, 16, 8) if c <= cores}, reverse=True)
     best_t, best_rate = cands[-1], 0.0
     for t in cands:
         oracle.set_threads(t)
-        o.run(1)
         t0 = time.perf_counter(); o.run(2); dt = time.perf_counter() - t0
         if 2 * N ** 3 / dt > best_rate:
             best_rate, best_t = 2 * N ** 3 / dt, t
     oracle.set_threads(best_t)
     steps, t0 = 0, time.perf_counter()
     while True:
-        o.run(4); steps += 4
+        o.run(2); steps += 2
         dt = time.perf_counter() - t0
         if dt > max_seconds or steps >= 2000:
             break
-    return {"value": round(N ** 3 * steps / dt / 1e6, 1), "unit": "MLUPS", "cores": best_t, "kind": "port",
-            "sample": "%d steps of a 128^3 FP32 channel (same recipe as the GPU workload) in %.1f s, OpenMP threads swept over %s of %d usable cores" % (steps, dt, cands, cores)}
+    mlups = N ** 3 * steps / dt / 1e6
+    copy_gbps = oracle.copy_bandwidth_gbps(1 << 30)          # read 1 GiB + write 1 GiB with the same OpenMP threads
+    return {"value": round(mlups, 1), "unit": "MLUPS", "cores": best_t, "kind": "port", "cpu_model": cpu_model(),
+            "dram_GBps": round(mlups * 169.0 / 1e3, 1), "copy_bandwidth_GBps": round(copy_gbps, 1), "dram_frac_of_copy": round(mlups * 169.0 / 1e3 / copy_gbps, 3) if copy_gbps else None,
+            "sample": "%d steps of a 256^3 FP32 channel (same recipe as the GPU workloads, 169 B per update incl. rho,u every step) in %.1f s, OpenMP threads swept over %s of %d usable cores" % (steps, dt, cands, cores)}
+
+
+def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False):
+    return "%s_%dx%dx%d%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_cor" if coriolis else "", "_th" if thermal else "", "_uf" if every_step else "")
+
+
+def attach_traffic(roof, key, kernel):
+    """HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same workload
+    (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
+    and keyed on the full configuration; null when no profile of exactly this workload exists"""
+    prof = os.path.join(ROOT, "profiles", "r02_%s_summary.json" % key)
+    if kernel == "auto" and os.path.exists(prof):
+        pr = json.load(open(prof))
+        roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
+        roof["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
+
+
+def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, coriolis=False, thermal=False, every_step=False, kernel_name="auto", keep=None):
+    """one single-GPU workload: create, fill the host mirrors in place, upload + initialise, W warm-up steps, K timed steps.
+    Returns the measurement block (MLUPS, ms/step, roofline of the stream_collide kernel)."""
+    import torch
+    Nx, Ny, Nz = size
+    fp16c = dtype == "fp16c"
+    lbm = luw.LBM(Nx, Ny, Nz, NU, fp16c=fp16c, kernel=kern, device=device, update_fields_every_step=every_step, alpha=(2.1e-7 if thermal else None))
+    try:
+        fill_channel(lbm.flags.data, lbm.u.data, lbm.rho.data, Nx, Ny, Nz, buildings=buildings)
+        solid = int(np.count_nonzero((lbm.flags.data & 3) == 1))
+        if coriolis:
+            lbm.set_coriolis(*coriolis_omega())
+        lbm.run(0)
+        lbm.run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms = lbm.run_timed(steps)             # K steps, HIP events around each launch on the launch stream
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        lbm.close()
+    cells = Nx * Ny * Nz
+    bpl = BYTES_PER_LUP[dtype] + (16.0 if every_step else 0.0) + ((7 * 2 * (2 if fp16c else 4) + 4) if thermal else 0.0)   # + gi read/write + T write
+    # algorithmic bytes of one launch: every cell's flag byte is read; only non-solid cells (fluid and TYPE_E) move their DDFs
+    launch_bytes = (bpl - 1.0) * (cells - solid) + 1.0 * cells
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(launch_bytes),
+            "note": "achieved = (%g B x %d non-solid cells + 1 flag byte x %d solid cells) / mean stream_collide duration (HIP events on the launch stream)" % (bpl, cells - solid, solid)}
+    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step), kernel_name)
+    mlups = cells * steps / dt / 1e6
+    return {"value": round(mlups, 1), "unit": "MLUPS", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+            "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5), "bytes_per_lup": bpl,
+            "options": ("building array" if buildings else "no solids above the ground plane") + (" + Coriolis force" if coriolis else "") + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
+            "roofline": roof}
+
+
+def describe(name, size, buildings, dtype, coriolis, thermal, every_step):
+    Nx, Ny, Nz = size
+    what = "voxelised building cluster (closed-form box array, SURVEY 8d), bounce-back" if buildings else "empty channel"
+    ref = WORKLOADS[name][2] if name in WORKLOADS and tuple(WORKLOADS[name][0]) == tuple(size) and WORKLOADS[name][1] == buildings else "custom size"
+    return "%dx%dx%d D3Q19 %s (%s), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s%s, rho/u written %s" % (
+        Nx, Ny, Nz, what, ref, "FP16C" if dtype == "fp16c" else "FP32", " + Coriolis force" if coriolis else "", " + thermal D3Q7 lattice" if thermal else "",
+        "every step" if every_step else "by the last step only")
 
 
 def main():
@@ -141,15 +251,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU lattice (default 512 512 512; with N > 1 the default global lattice is the BASELINE tile, 2048x1024x512 on 8 GPUs)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="N = 1 headline workload (default c3 = BASELINE configs[2], the largest single-GPU configuration)")
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="N = 1: lattice instead of the workload's; N > 1: per-GPU block (default 512 512 512, 8 GPUs = the 2048x1024x512 tile)")
     ap.add_argument("--n-gpu", type=int, nargs=3, default=None, help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 4 2 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
-    ap.add_argument("--kernel", choices=["auto", "scalar", "scalar_cached", "scalar_nt_all", "vec4", "vec2", "vec1", "pair", "exp_copy", "exp_noshift"], default="auto", help="exp_* are measurement-only variants (no physics)")
-    ap.add_argument("--buildings", action="store_true", help="BASELINE configs[2] solid mask (box array); use with --size 1024 1024 256")
+    ap.add_argument("--kernel", choices=["auto", "scalar", "pair"], default="auto")
+    ap.add_argument("--buildings", action="store_true", help="add the configs[2] solid mask to a workload that has none (c3 and the N > 1 tile always carry it)")
+    ap.add_argument("--no-buildings", action="store_true", help="N > 1: plain channel tile without the building array / nudging / sponge")
     ap.add_argument("--coriolis", action="store_true", help="Coriolis body force at 31.25 deg N (BASELINE configs[4]): every cell takes the forced path")
     ap.add_argument("--thermal", action="store_true", help="also run the thermal D3Q7 lattice (the shipped reference build always does): +7 DDF planes and T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--no-secondary", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
     args = ap.parse_args()
@@ -172,120 +285,40 @@ def main():
         local_rank = args.share_device
     torch.cuda.set_device(local_rank)
     luw.load()
-    Nx, Ny, Nz = args.size or (512, 512, 512)
-    kern = {"auto": capi.KERNEL_AUTO, "scalar": capi.KERNEL_SCALAR, "scalar_cached": capi.KERNEL_SCALAR_CACHED, "vec4": capi.KERNEL_VEC4, "vec2": capi.KERNEL_VEC2, "vec1": capi.KERNEL_VEC1, "pair": capi.KERNEL_PAIR, "scalar_nt_all": capi.KERNEL_SCALAR_NT_ALL, "exp_copy": capi.KERNEL_EXP_COPY, "exp_noshift": capi.KERNEL_EXP_NOSHIFT}[args.kernel]
+    kern = {"auto": capi.KERNEL_AUTO, "scalar": capi.KERNEL_SCALAR, "pair": capi.KERNEL_PAIR}[args.kernel]
     fp16c = args.dtype == "fp16c"
-    nu = 1.48e-7                                     # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
+    METRIC = "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref"
 
     if world == 1 and not args.force_distributed:
-        lbm = luw.LBM(Nx, Ny, Nz, nu, fp16c=fp16c, kernel=kern, device=local_rank, update_fields_every_step=args.every_step_fields, alpha=(2.1e-7 if args.thermal else None))
-        fl, u, rho = channel_state(Nx, Ny, Nz, buildings=args.buildings)
-        lbm.flags.data[:] = fl; lbm.u.data[:] = u; lbm.rho.data[:] = rho
-        if args.coriolis:
-            lbm.set_coriolis(*coriolis_omega())
-        lbm.run(0)
-        lbm.run(args.warmup)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        kernel_ms = lbm.run_timed(args.steps)        # K steps, HIP events around each launch on the launch stream
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        cells = Nx * Ny * Nz
-        D = (1, 1, 1)
-    else:
-        import torch.distributed as dist
-        from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice, init_rccl_process_group
-        if world == 1:      # --force-distributed without a launcher: a one-rank world over loopback
-            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29537"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
-                os.environ.setdefault(k, v)
-        if args.share_device is not None: dist.init_process_group("gloo")
-        else: init_rccl_process_group(local_rank)
-        D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
-        if D[0] * D[1] * D[2] != world:
-            raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
-        # weak scaling: 512^3 cells per GPU.  Default global lattice = the BASELINE tile for this GPU count (8: 2048x1024x512)
-        gN = (Nx * D[0], Ny * D[1], Nz * D[2]) if args.size else tile_lattice(world)
-        if any(g % d for g, d in zip(gN, D)):
-            raise SystemExit("bench.py: lattice %s is not divisible by n_gpu %s" % (gN, D))
-        Nx, Ny, Nz = (g // d for g, d in zip(gN, D))          # per-GPU block (without halos)
-        exchange_note = None
-        gloo_group = None                                   # only used if RCCL point-to-point fails below
-        if args.share_device is None:
-            try:
-                gloo_group = dist.new_group(backend="gloo")
-            except Exception as e:                          # no fallback then; the RCCL path is unaffected
-                sys.stderr.write("bench.py rank %d: no gloo side channel (%s)\n" % (rank, str(e)[:200]))
-
-        def make_sim(transport=None):
-            sim = DomainDecomposedLBM(gN, D, nu, fp16c=fp16c, kernel=kern, device=local_rank, transport=transport)
-            ox, oy, oz = sim.global_offset
-            fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN, buildings=args.buildings)
-            sim.set_fields(fl, u, rho)
-            if args.coriolis:
-                sim.backend.set_coriolis(*coriolis_omega())
-            return sim, fl
-        sim = None
-        try:
-            sim, fl = make_sim()        # builds the RCCL connections to the neighbours, then allocates the lattice
-            sim.initialize()
-            ok = torch.ones(1)
-        except Exception as e:      # RCCL p2p refused on this node: say so and fall back to host-staged halos rather than report nothing
-            sys.stderr.write("bench.py rank %d: halo exchange over RCCL failed (%s); falling back to host-staged gloo\n" % (rank, str(e)[:300]))
-            ok = torch.zeros(1)
-        if gloo_group is None and ok.item() == 0:
-            raise SystemExit("bench.py: halo exchange over RCCL failed and no fallback channel exists")
-        if gloo_group is not None:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
-            if ok.item() == 0:
-                from latticeurbanwind_amd.distributed import DomainLayout, HostStagedTransport
-                if sim is not None: sim.backend.close()
-                sim, fl = make_sim(HostStagedTransport(DomainLayout(gN, D, rank), group=gloo_group))
-                sim.initialize()
-                exchange_note = "host-staged gloo (RCCL point-to-point failed on this node)"
-        sim.run(args.warmup)
-        dist.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        kernel_ms = sim.run(args.steps, timed=True)
-        torch.cuda.synchronize(); dist.barrier()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_device is not None else "cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        cells = Nx * Ny * Nz * world
-
-    if rank == 0:
-        mlups = cells * args.steps / dt / 1e6
-        bpl = BYTES_PER_LUP[args.dtype] + (16.0 if args.every_step_fields else 0.0) + ((7 * 2 * (2 if fp16c else 4) + 4) if args.thermal else 0.0)   # + gi read/write + T write
-        per_gpu_cells = Nx * Ny * Nz
-        if D != (1, 1, 1) and sim.overlap:      # the timed launch is the interior box; the shell runs beside it on the other stream
-            b = sim.layout.interior_box(); per_gpu_cells = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4])
-        achieved = per_gpu_cells * bpl / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+        size, buildings, _ = WORKLOADS[args.workload]
+        if args.size: size = tuple(args.size)
+        buildings = buildings or args.buildings
+        head = run_single(luw, kern, local_rank, size, args.dtype, buildings, args.steps, args.warmup, args.coriolis, args.thermal, args.every_step_fields, args.kernel)
         out = {
-            "metric": "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref",
-            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
-            "config": {"workload": "%s, log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky, %s DDFs, rho/u written %s"
-                       % (("%dx%dx%d D3Q19 channel%s" % (Nx, Ny, Nz, " with the configs[2] building array (solid fraction %.3f)" % float((fl == 1).mean()) if args.buildings else " (BASELINE configs[1])")) if world == 1 else
-                          ("%dx%dx%d D3Q19 channel tile (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU" % (Nx * D[0], Ny * D[1], Nz * D[2], Nx, Ny, Nz)),
-                          ("FP16C" if fp16c else "FP32") + (" + Coriolis force" if args.coriolis else "") + (" + thermal D3Q7 lattice" if args.thermal else ""), "every step" if args.every_step_fields else "by the last step only"),
-                       "global_lattice": [Nx * D[0], Ny * D[1], Nz * D[2]], "n_gpu": list(D), "halo_exchange": (None if D == (1, 1, 1) else (exchange_note or ("gloo + host staging (--share-device test aid)" if args.share_device is not None else "RCCL p2p")) + (", overlapped with the interior (x rows kept whole)" if sim.overlap else " after the whole-box kernel (x split)")), "kernel": args.kernel,
-                       "bytes_per_lup": bpl},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
-                         "kernel_ms": round(kernel_ms, 4) if kernel_ms else None,
-                         "whole_job_frac": round(mlups * 1e6 * bpl / 1e9 / (HBM_PEAK_GBPS * world), 4),   # wall-clock MLUPS of all GPUs x B/LUP over N x peak
-                         "note": "achieved = %g B/LUP x %d cells / mean stream_collide duration (HIP events on the launch stream%s)" % (bpl, per_gpu_cells, "; interior box of rank 0, its boundary shell and the halo exchange run concurrently" if (D != (1, 1, 1) and sim.overlap) else "")},
+            "metric": METRIC, "value": head["value"], "unit": "MLUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": {"workload": describe(args.workload, size, buildings, args.dtype, args.coriolis, args.thermal, args.every_step_fields),
+                       "global_lattice": list(size), "n_gpu": [1, 1, 1], "halo_exchange": None, "kernel": args.kernel, "bytes_per_lup": head["bytes_per_lup"], "solid_fraction": head["solid_fraction"]},
+            "roofline": dict(head["roofline"], whole_job_frac=round(head["roofline"]["algorithmic_bytes_per_launch"] / (head["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)),
         }
-        # HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same
-        # command (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), and
-        # committed under profiles/; reported here only when that profile is of this workload
-        prof = os.path.join(ROOT, "profiles", "r01g_pair_fp16c_512_summary.json" if (fp16c and args.kernel == "auto") else ("r01d_scalar_fp16c_512_summary.json" if fp16c else "r01g_scalar_f32_512_summary.json"))
-        if (Nx, Ny, Nz) == (512, 512, 512) and args.kernel in ("auto", "scalar") and not args.every_step_fields and os.path.exists(prof):
-            pr = json.load(open(prof))
-            out["roofline"]["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
-        if world == 1 and not args.no_cpu_baseline and not args.force_distributed:
+        if not args.no_secondary:
+            # the other single-GPU configurations, same process, same code path, fewer steps (each is its own create / fill / run)
+            sec = {}
+            plan = [("c2_f32", "c2", "f32", False), ("c2_fp16c", "c2", "fp16c", False), ("c3_fp16c", "c3", "fp16c", False), ("c3_fp16c_coriolis", "c3", "fp16c", True),
+                    ("cube1024_f32", "cube1024", "f32", False), ("cube1024_fp16c", "cube1024", "fp16c", False)]
+            for key, wl, dt_, cor in plan:
+                sz, bld, _ = WORKLOADS[wl]
+                if (wl, dt_, cor) == (args.workload, args.dtype, args.coriolis) and not args.size:
+                    continue
+                try:
+                    big = sz[0] * sz[1] * sz[2] >= (1 << 30)
+                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, 30 if big else 60, 5 if big else 10, coriolis=cor)
+                    r["workload"] = describe(wl, sz, bld, dt_, cor, False, False)
+                    sec[key] = r
+                except Exception as e:      # a secondary block never takes the headline down; its absence is visible
+                    sec[key] = {"error": str(e)[:300]}
+            out["secondary"] = sec
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             try:
                 out["parity"] = reference_parity()
@@ -294,9 +327,104 @@ def main():
         sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()
         os.dup2(2, 1)
-    if world > 1 or args.force_distributed:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- N > 1: one process per GPU, halos over RCCL
+    import torch.distributed as dist
+    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice, init_rccl_process_group
+    if world == 1:      # --force-distributed without a launcher: a one-rank world over loopback
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29537"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
+    if args.share_device is not None: dist.init_process_group("gloo")
+    else: init_rccl_process_group(local_rank)
+    urban = not args.no_buildings
+    nud, spg = tile_forcing() if urban else (None, None)
+
+    def run_tile(D):
+        """the tile cut as n_gpu = D: returns this rank's timing block; every failure (RCCL p2p included) propagates"""
+        Bx, By, Bz = args.size or (512, 512, 512)
+        gN = (Bx * D[0], By * D[1], Bz * D[2]) if args.size else tile_lattice(world)
+        if any(g % d for g, d in zip(gN, D)):
+            raise SystemExit("bench.py: lattice %s is not divisible by n_gpu %s" % (gN, D))
+        kw = dict(buffer_nudging=nud, top_sponge=spg) if urban else {}
+        sim = DomainDecomposedLBM(gN, D, NU, fp16c=fp16c, kernel=kern, device=local_rank, **kw)   # RCCL connections to the neighbours first, then the lattice
+        try:
+            ox, oy, oz = sim.global_offset
+            lb = sim.backend.lbm
+            fill_channel(lb.flags.data, lb.u.data, lb.rho.data, sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *gN, buildings=urban)
+            if args.coriolis:
+                sim.backend.set_coriolis(*coriolis_omega())
+            sim.initialize()
+            sim.run(args.warmup)
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tm = sim.run(args.steps, timed=True)
+            torch.cuda.synchronize(); dist.barrier()
+            dt = time.perf_counter() - t0
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_device is not None else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            b = sim.layout.interior_box() if sim.overlap else sim.layout.whole_box()
+            mine = {"rank": rank, "device": local_rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "wall_ms_per_step": round(dt / args.steps * 1e3, 4),
+                    "kernel_ms": round(tm["kernel_ms"], 4), "kernel_cells": (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]),
+                    "shell_ms": None if tm.get("shell_ms") is None else round(tm["shell_ms"], 4), "exchange_ms": None if tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4)}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
+        finally:
+            sim.backend.close()
+
+    D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
+    if D[0] * D[1] * D[2] != world:
+        raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
+    res = run_tile(D)
+    alt = None
+    if not args.n_gpu and not args.no_secondary and world > 1:
+        Dl = choose_decomposition(world, split_x=True)            # the deck's literal grid (8 GPUs: [4,2,1]) as a secondary block
+        if Dl != D:
+            alt = run_tile(Dl)
+
+    if rank == 0:
+        def block(r):
+            cells = r["gN"][0] * r["gN"][1] * r["gN"][2]
+            mlups = cells * args.steps / r["dt"] / 1e6
+            bpl = BYTES_PER_LUP[args.dtype]
+            k0 = r["per_rank"][0]
+            achieved = k0["kernel_cells"] * bpl / (k0["kernel_ms"] * 1e-3) / 1e9 if k0["kernel_ms"] else None
+            return mlups, bpl, achieved
+        mlups, bpl, achieved = block(res)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        transport = "gloo + host staging (--share-device test aid: NOT a multi-GPU result)" if args.share_device is not None else "RCCL p2p (batch_isend_irecv)"
+        out = {
+            "metric": METRIC, "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
+            "config": {"workload": "%dx%dx%d D3Q19 %s (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU (the N = 1 line runs configs[2], 1024x1024x256 per GPU), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s, rho/u written by the last step only"
+                       % (*res["gN"], "urban tile: building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "channel tile", *res["block"],
+                          "FP16C" if fp16c else "FP32", " + Coriolis force" if args.coriolis else ""),
+                       "global_lattice": list(res["gN"]), "n_gpu": list(res["D"]),
+                       "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel"), "kernel": args.kernel, "bytes_per_lup": bpl,
+                       "rccl_version": rccl, "ranks_in_communicator": dist.get_world_size()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
+                         "kernel_ms": res["per_rank"][0]["kernel_ms"],
+                         "whole_job_frac": round(mlups * 1e6 * bpl / 1e9 / (HBM_PEAK_GBPS * world), 4),   # wall-clock MLUPS of all GPUs x B/LUP over N x peak
+                         "note": "achieved = %g B/LUP x %d cells / mean duration of rank 0's %s kernel (HIP events on its launch stream); solid cells are charged like fluid ones here (< 1 %% of the tile)"
+                                 % (bpl, res["per_rank"][0]["kernel_cells"], "interior-box (its boundary shell and the halo exchange run concurrently on the communication stream)" if res["overlap"] else "whole-box")},
+            "per_rank": res["per_rank"],
+        }
+        if alt is not None:
+            m2, _, a2 = block(alt)
+            out["secondary"] = {"literal_n_gpu": {"value": round(m2, 1), "unit": "MLUPS", "ms_per_step": round(alt["dt"] / args.steps * 1e3, 4), "n_gpu": list(alt["D"]), "global_lattice": list(alt["gN"]),
+                                                  "halo_exchange": transport + (", overlapped with the interior (64-cell x slabs)" if alt["overlap"] else " after the whole-box kernel"),
+                                                  "roofline_frac_rank0_kernel": round(a2 / HBM_PEAK_GBPS, 4) if a2 else None, "per_rank": alt["per_rank"]}}
+        sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(out)); sys.stdout.flush()
+        os.dup2(2, 1)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -425,7 +425,7 @@ class DomainDecomposedLBM:
             self.initialize()
         b = self.backend
         lay = self.layout
-        ev = []
+        ev, ev_comm = [], []
         stats_done = None
         pipelined = self.overlap and self.pipeline
         if self.overlap:
@@ -465,8 +465,13 @@ class DomainDecomposedLBM:
                     if self.pre_step is not None:
                         self.pre_step(comp)
                     comm.wait_stream(comp)
+                if timed:
+                    s0, s1, s2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    s0.record(comm)
                 for box in lay.shell_boxes():
                     b.stream_collide(box, wf, comm, **kw)              # boundary shell first ...
+                if timed:
+                    s1.record(comm)
                 if pipelined:
                     shell_done = torch.cuda.Event(); shell_done.record(comm)
                 if timed:
@@ -478,6 +483,8 @@ class DomainDecomposedLBM:
                 if pipelined:
                     interior_done = torch.cuda.Event(); interior_done.record(comp)
                 self.communicate_fi(comm)
+                if timed:
+                    s2.record(comm); ev_comm.append((s0, s1, s2))
                 if sampled:
                     if pipelined:
                         comp.wait_event(shell_done)                    # the sample reads rho,u of shell and interior cells
@@ -489,15 +496,32 @@ class DomainDecomposedLBM:
                 st = getattr(b, "compute", None)
                 if self.pre_step is not None:
                     self.pre_step(st)
+                if timed and st is not None:
+                    import torch
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    e0.record(st)
                 b.stream_collide(lay.whole_box(), wf, st, **kw)
+                if timed and st is not None:
+                    e1.record(st)
                 self.communicate_fi(st)
+                if timed and st is not None:
+                    e2.record(st); ev.append((e0, e1)); ev_comm.append((None, e1, e2))
                 if sampled:
                     if hasattr(b, "stats_enqueue") and st is not None: b.stats_enqueue(st)
                     else: b.stats_accumulate()
             b.increment_time_step(1)
         self._join()
         if timed and ev:
-            return sum(a.elapsed_time(c) for a, c in ev) / len(ev)
+            # means over the steps of this call, taken with events on the streams the work was enqueued on: the interior (or
+            # whole-box) kernel; the boundary-shell launches; pack + exchange + unpack of all split axes (time on the
+            # communication stream, which includes waiting for the neighbours)
+            mean = lambda pairs: sum(a.elapsed_time(c) for a, c in pairs) / len(pairs)
+            out = {"kernel_ms": mean(ev), "shell_ms": None, "exchange_ms": None}
+            if ev_comm:
+                out["exchange_ms"] = mean([(s1, s2) for _, s1, s2 in ev_comm])
+                if ev_comm[0][0] is not None:
+                    out["shell_ms"] = mean([(s0, s1) for s0, s1, _ in ev_comm])
+            return out
         return None
 
     def fields(self):

@@ -626,6 +626,30 @@ void luwo_set_threads(const int n) { (void)n; }
 int luwo_get_max_threads(void) { return 1; }
 #endif
 
+/* host copy bandwidth (GB/s, read + write counted) with the OpenMP threads in force: the denominator bench.py's cpu_baseline
+ * reports the restatement's DRAM traffic against.  Buffers are touched by the threads that later copy them (first touch). */
+#include <time.h>
+double luwo_copy_bandwidth_gbps(const uint64_t bytes) {
+	const uint64_t n = bytes/8u;
+	double* a = (double*)malloc(n*8u); double* b = (double*)malloc(n*8u);
+	if(!a||!b) { free(a); free(b); return 0.0; }
+	#pragma omp parallel for schedule(static)
+	for(int64_t i=0; i<(int64_t)n; i++) { a[i] = (double)i; b[i] = 0.0; }
+	double best = 0.0;
+	for(int rep=0; rep<4; rep++) {
+		struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+		#pragma omp parallel for schedule(static)
+		for(int64_t i=0; i<(int64_t)n; i++) b[i] = a[i];
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		const double dt = (double)(t1.tv_sec-t0.tv_sec)+1e-9*(double)(t1.tv_nsec-t0.tv_nsec);
+		const double gbps = 2.0*(double)(n*8u)/dt*1e-9;
+		if(gbps>best) best = gbps;
+	}
+	const double keep = b[n/2u];
+	free(a); free(b);
+	return keep<0.0 ? 0.0 : best;
+}
+
 /* update_fields equivalent for checks: rho,u of a cell straight from the stored DDFs at time t, no forcing.
  * (used by tests for conservation checks; mirrors load_f + calculate_rho_u) */
 void luwo_moments(const LuwOracleCfg* c, const void* fi, const uint64_t t, float* rho_out, float* u_out) {

@@ -65,6 +65,7 @@ def lib():
         L.luwo_accumulate_stats.argtypes = [u64, u64] + [vp] * 7; L.luwo_accumulate_stats.restype = None
         L.luwo_set_threads.argtypes = [C.c_int]; L.luwo_set_threads.restype = None
         L.luwo_get_max_threads.restype = C.c_int
+        L.luwo_copy_bandwidth_gbps.argtypes = [u64]; L.luwo_copy_bandwidth_gbps.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -204,6 +205,11 @@ class OracleStats:
 
 def set_threads(n):
     lib().luwo_set_threads(int(n))
+
+
+def copy_bandwidth_gbps(nbytes):
+    """host copy bandwidth with the current OpenMP thread count (read + write bytes per second, GB/s)"""
+    return float(lib().luwo_copy_bandwidth_gbps(int(nbytes)))
 
 
 def max_threads():

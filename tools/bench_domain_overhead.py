@@ -33,7 +33,7 @@ def main():
     fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, ox, oy, oz, *N)
     sim.set_fields(fl, u, rho)
     sim.initialize(); sim.run(10); torch.cuda.synchronize()
-    t0 = time.perf_counter(); k_ms = sim.run(a.steps, timed=True); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); k_ms = (sim.run(a.steps, timed=True) or {}).get("kernel_ms"); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     cells = a.size[0] * a.size[1] * a.size[2]
     print("D=%s local=%s overlap=%s: %.3f ms/step -> %.0f MLUPS per GPU (interior kernel %.3f ms)" % (D, (sim.lNx, sim.lNy, sim.lNz), sim.overlap, dt / a.steps * 1e3, cells * a.steps / dt / 1e6, k_ms or 0))
     if a.phases:   # serialised phases, one stream: what each piece costs on its own

@@ -43,7 +43,7 @@ def run(transport_of):
         sim.transport = transport_of(sim.layout)
     fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, *sim.global_offset, *N)
     sim.set_fields(fl, u, rho); sim.initialize(); sim.run(5)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); k_ms = sim.run(steps, timed=True); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize(); t0 = time.perf_counter(); k_ms = (sim.run(steps, timed=True) or {}).get("kernel_ms"); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
     sys.stderr.write("  %s: %.3f ms/step, interior kernel %.3f ms\n" % (type(sim.transport).__name__, ms, k_ms or 0.0))
     uu, rr = sim.fields()
     out = (uu.copy(), rr.copy(), ms)
