@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LUW_ABI_VERSION 2
+#define LUW_ABI_VERSION 3
 
 /* error codes */
 #define LUW_OK 0
@@ -65,7 +65,8 @@ extern "C" {
 #define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha */
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
 
-/* kernel selection (for A/B measurements; LUW_KERNEL_AUTO is what production uses) */
+/* kernel selection.  The product library knows AUTO, SCALAR and PAIR (luw_create rejects the others); the remaining ids name A/B and
+ * measurement-only variants that exist in the tools build only (make -C csrc ab, -DLUW_AB_KERNELS) */
 #define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 256 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
@@ -232,6 +233,49 @@ int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches);
 /* measurement helper for bench.py: runs `steps` steps like luw_run and returns the mean duration of the
  * stream_collide kernel in milliseconds, taken with HIP events on the launch stream. */
 int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms);
+
+/* ================================================================================================================
+ * Several domains in ONE process: the reference's `LBM lbm(N, Dx, Dy, Dz, nu, ...)` for Dx*Dy*Dz > 1 (FX/lbm.hpp:444-450,
+ * FX/lbm.cpp:1057-1112): it builds every LBM_Domain itself (one device each), steps them together (do_time_step,
+ * FX/lbm.cpp:1262-1290) and swaps their halos (communicate_field, FX/lbm.cpp:1907-1935).  A luw_group is that object: one HIP
+ * device and one compute + one communication stream per domain, halo faces written straight into the neighbour's receive buffer
+ * by the pack kernels (peer stores over xGMI; hipMemcpyPeerAsync where there is no peer access), boundary shell / interior
+ * overlap and pipelined steps as in the one-process-per-GPU driver.  Results equal the undivided run bit for bit.
+ * cfg describes the GLOBAL lattice: Nx,Ny,Nz without halos (each divisible by Dx,Dy,Dz: the caller shrinks the grid like
+ * FX/lbm.cpp:1058-1060 does), everything else as for luw_create.  devices[d] = HIP device of domain d = x + (y + z*Dy)*Dx, or
+ * NULL for cfg->device + d (smart_device_selection's one device per domain, FX/lbm.cpp:947-979; fewer devices than domains is an
+ * error unless an explicit list says which domains share a device). */
+typedef struct luw_group luw_group;
+int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out);       /* LBM::LBM */
+void luw_group_destroy(luw_group* g);                                                    /* LBM::~LBM */
+uint32_t luw_group_size(const luw_group* g);                                             /* LBM::get_D */
+luw_solver* luw_group_domain(luw_group* g, uint32_t d);                                  /* lbm.lbm_domain[d] (FX/setup.cpp:1085): host mirrors, device buffers, per-domain calls */
+int luw_group_domain_info(const luw_group* g, uint32_t d, uint32_t* local_N, int32_t* offset, int* device); /* LBM_Domain::get_Nx.., Ox.. (FX/lbm.cpp:1072) */
+int luw_group_overlaps(const luw_group* g);                 /* 1: shell / interior overlap in use (every split axis has >= 4 owned layers) */
+int luw_group_direct_peer_stores(const luw_group* g);       /* 1: every face travels as peer stores of the pack kernel, none through a copy */
+/* Memory_Container's global index space (FX/lbm.hpp:274-297) over the domains' host mirrors: global arrays in the reference
+ * layout n = x + (y + z*Ny)*Nx of the GLOBAL lattice, components SoA.  scatter also fills the halo layers (periodic wrap), i.e.
+ * what communicate_rho_u_flags leaves there during LBM::initialize (FX/lbm.cpp:1243-1256); gather reads owned cells. */
+int luw_group_scatter(luw_group* g, int field, const void* global_src);
+int luw_group_gather(luw_group* g, int field, void* global_dst);
+int luw_group_upload(luw_group* g, uint32_t field_mask);
+int luw_group_download(luw_group* g, uint32_t field_mask);
+int luw_group_initialize(luw_group* g);                                                  /* LBM::initialize incl. the odd-t halo exchange, FX/lbm.cpp:1221-1260 */
+int luw_group_run(luw_group* g, uint64_t steps);                                         /* LBM::run(steps): returns after all devices finished */
+int luw_group_run_sampled(luw_group* g, uint64_t steps, uint64_t first_sample, uint64_t stride); /* luw_run_sampled for every domain, no host sync inside the window */
+int luw_group_run_timed(luw_group* g, uint64_t steps, double* mean_kernel_ms);           /* mean duration of domain 0's interior (or whole-box) kernel */
+uint64_t luw_group_get_t(const luw_group* g);
+int luw_group_set_f(luw_group* g, float fx, float fy, float fz);
+int luw_group_set_coriolis(luw_group* g, float ox, float oy, float oz);
+int luw_group_voxelize_mesh(luw_group* g, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag); /* per domain, FX/lbm.cpp:1455-1587 */
+/* global cell indices in, every domain gets the inlet points / probe cells it owns (VonKarmanInletUpdater::build_gpu_runtime_ does
+ * the same per domain, FX/setup.cpp:1012-1057) */
+int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face,
+                              const float* point_data, const float* mode_data, int update_stride, int stride_interpolation);
+int luw_group_gather_attach(luw_group* g, uint32_t count, const uint64_t* cells);
+int luw_group_gather_u(luw_group* g, float* out);
+int luw_group_stats_reset(luw_group* g);
+int luw_group_stats_download(luw_group* g, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, float* avg_T, uint64_t* count);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,6 @@ lbm.py (host-side mirror of the reference's `LBM` class over the C-ABI), distrib
 domain decomposition driver over torch.distributed).
 """
 from .capi import build, load, LuwError  # noqa: F401
-from .lbm import LBM  # noqa: F401
+from .lbm import LBM, LBMGroup  # noqa: F401
 
-__all__ = ["build", "load", "LuwError", "LBM"]
+__all__ = ["build", "load", "LuwError", "LBM", "LBMGroup"]

@@ -8,10 +8,6 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "csrc", "libluw_core.so")
-if os.environ.get("LUW_CORE_LIB"):      # A/B builds of the same source (tools/ab_libs.sh): never a different implementation
-    _SO = os.environ["LUW_CORE_LIB"]
-if os.environ.get("LUW_CORE_LIB"):      # A/B builds of the same source (tools/): never a different implementation
-    _SO = os.environ["LUW_CORE_LIB"]
 _LIB = None
 
 LUW_OK = 0
@@ -19,9 +15,10 @@ FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F, FIELD_FI, FIELD_T, FIELD_GI = 0, 1, 2,
 MASK_RHO, MASK_U, MASK_FLAGS, MASK_F, MASK_T = 1, 2, 4, 8, 32
 DDF_FP32, DDF_FP16C = 0, 1
 OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID, OPT_TEMPERATURE = 1, 2, 4, 8
-KERNEL_AUTO, KERNEL_SCALAR, KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERNEL_SCALAR_NT_ALL, KERNEL_VEC1, KERNEL_PAIR = 0, 1, 2, 3, 4, 5, 6, 7
-KERNEL_SCALAR_GENERAL = 8
-KERNEL_EXP_COPY, KERNEL_EXP_NOSHIFT = 100, 101   # measurement-only variants, never used by the product path
+KERNEL_AUTO, KERNEL_SCALAR, KERNEL_PAIR = 0, 1, 7         # what the product library knows
+# ids of the A/B and measurement-only variants: only the tools build (make -C csrc ab -> tools/libluw_core_ab.so) has them
+KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERNEL_SCALAR_NT_ALL, KERNEL_VEC1, KERNEL_SCALAR_GENERAL = 2, 3, 4, 5, 6, 8
+KERNEL_EXP_COPY, KERNEL_EXP_NOSHIFT = 100, 101
 TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4
 
@@ -30,6 +27,10 @@ SYMBOLS = [
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
     "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
+    "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info", "luw_group_overlaps", "luw_group_direct_peer_stores",
+    "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download", "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_run_timed",
+    "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis", "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach", "luw_group_gather_u",
+    "luw_group_stats_reset", "luw_group_stats_download",
     "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
@@ -65,11 +66,16 @@ def build(force=False):
     return _SO
 
 
-def load():
-    """dlopen the product library and declare the prototypes.  Raises if it has not been built."""
-    global _LIB
+def load(path=None):
+    """dlopen the product library and declare the prototypes.  Raises if it has not been built.  `path` (first call only) names
+    another build of the SAME sources -- the tools' A/B library -- and is never set by the package itself."""
+    global _LIB, _SO
     if _LIB is not None:
+        if path is not None and os.path.abspath(path) != os.path.abspath(_SO):
+            raise LuwError("another libluw_core build is already loaded in this process")
         return _LIB
+    if path is not None:
+        _SO = path
     if not os.path.exists(_SO):
         raise LuwError("HIP library %s is missing: run latticeurbanwind_amd.build() (needs hipcc); there is no CPU fallback" % _SO)
     try:
@@ -125,7 +131,26 @@ def load():
     L.luw_stats_begin_sample.argtypes = [vp, C.POINTER(i32)]
     L.luw_stats_download.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.luw_stats_download_T.argtypes = [vp, vp]
-    if L.luw_abi_version() != 2:
+    i32p, u32p = C.POINTER(i32), C.POINTER(u32)
+    L.luw_group_create.argtypes = [C.POINTER(Config), i32p, C.POINTER(vp)]
+    L.luw_group_destroy.argtypes = [vp]; L.luw_group_destroy.restype = None
+    L.luw_group_size.argtypes = [vp]; L.luw_group_size.restype = u32
+    L.luw_group_domain.argtypes = [vp, u32]; L.luw_group_domain.restype = vp
+    L.luw_group_domain_info.argtypes = [vp, u32, u32p, C.POINTER(C.c_int32), i32p]
+    L.luw_group_overlaps.argtypes = [vp]; L.luw_group_direct_peer_stores.argtypes = [vp]
+    L.luw_group_scatter.argtypes = [vp, i32, vp]; L.luw_group_gather.argtypes = [vp, i32, vp]
+    L.luw_group_upload.argtypes = [vp, u32]; L.luw_group_download.argtypes = [vp, u32]
+    L.luw_group_initialize.argtypes = [vp]
+    L.luw_group_run.argtypes = [vp, u64]; L.luw_group_run_sampled.argtypes = [vp, u64, u64, u64]
+    L.luw_group_run_timed.argtypes = [vp, u64, C.POINTER(C.c_double)]
+    L.luw_group_get_t.argtypes = [vp]; L.luw_group_get_t.restype = u64
+    L.luw_group_set_f.argtypes = [vp, f32, f32, f32]; L.luw_group_set_coriolis.argtypes = [vp, f32, f32, f32]
+    L.luw_group_voxelize_mesh.argtypes = [vp, u32, vp, vp, vp, vp, C.c_uint8]
+    L.luw_group_vk_inlet_attach.argtypes = [vp, u64, u64, vp, vp, vp, vp, i32, i32]
+    L.luw_group_gather_attach.argtypes = [vp, u32, vp]; L.luw_group_gather_u.argtypes = [vp, vp]
+    L.luw_group_stats_reset.argtypes = [vp]
+    L.luw_group_stats_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
+    if L.luw_abi_version() != 3:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
     return L

@@ -23,13 +23,18 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <functional>
+#include <atomic>
+#include <algorithm>
 #include <memory>
 
 using namespace luw;
 
 #include "luw_kernels_common.hpp"
 #include "luw_kernels_step.hpp"
+#ifdef LUW_AB_KERNELS   // tools build only (make ab): A/B and measurement-only kernel variants; the product library has none of them
 #include "luw_kernels_vec.hpp"
+#endif
 #include "luw_kernels_aux.hpp"
 
 // =====================================================================================================
@@ -75,12 +80,72 @@ static float literal_roundtrip(float x) {
 	return strtof(text, nullptr);
 }
 
+// One block of device memory.  Two ways to get it: hipMalloc, or the virtual memory management API: ONE address range backed by
+// physical chunks of a chosen size (hipMemCreate / hipMemMap), which fixes the size of the physically contiguous pieces a lattice
+// array is made of instead of leaving it to the state of the driver's heap (alloc_vmm_chunk below).
+struct DevBlock {
+	void* base = nullptr; size_t bytes = 0u;
+	std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk_bytes = 0u; // VMM only
+};
+static void dev_free(DevBlock& b) {
+	if(!b.base) return;
+	if(b.chunks.empty()) (void)hipFree(b.base);
+	else {
+		(void)hipMemUnmap(b.base, b.bytes);
+		for(auto& h : b.chunks) (void)hipMemRelease(h);
+		(void)hipMemAddressFree(b.base, b.bytes);
+	}
+	b = DevBlock{};
+}
+static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, const size_t vmm_chunk) {
+	b = DevBlock{};
+	if(vmm_chunk==0u) { const hipError_t e = hipMalloc(&b.base, bytes); if(e==hipSuccess) b.bytes = bytes; else b.base = nullptr; return e; }
+	hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+	size_t gran = 0u;
+	hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+	if(e!=hipSuccess) return e;
+	const size_t chunk = ((std::max(vmm_chunk, gran)+gran-1u)/gran)*gran, total = ((bytes+chunk-1u)/chunk)*chunk;
+	if((e = hipMemAddressReserve(&b.base, total, chunk, nullptr, 0ull))!=hipSuccess) { b.base = nullptr; return e; }
+	b.bytes = total; b.chunk_bytes = chunk;
+	for(size_t off=0u; off<total; off+=chunk) {
+		hipMemGenericAllocationHandle_t h;
+		if((e = hipMemCreate(&h, chunk, &prop, 0ull))!=hipSuccess) break;
+		if((e = hipMemMap((char*)b.base+off, chunk, 0u, h, 0ull))!=hipSuccess) { (void)hipMemRelease(h); break; }
+		b.chunks.push_back(h);
+	}
+	if(e==hipSuccess) { hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite; e = hipMemSetAccess(b.base, total, &acc, 1u); }
+	if(e!=hipSuccess) { // undo what was mapped
+		if(!b.chunks.empty()) (void)hipMemUnmap(b.base, b.chunks.size()*chunk);
+		for(auto& h : b.chunks) (void)hipMemRelease(h);
+		(void)hipMemAddressFree(b.base, total);
+		b = DevBlock{};
+	}
+	return e;
+}
+// How lattice-sized arrays are allocated.  Measured on MI355X (tools/placement_study.sh, profiles/r02_placement_study.txt): the step
+// kernel on a hipMalloc'ed DDF array runs in one of two classes (512^3 FP32: 3.37 or 3.65 ms, fixed for the life of the
+// allocation), on an array mapped from 1 GiB physical chunks always in 3.26 ms; 1024x1024x256: 7.28 -> 6.69 ms.  Large
+// physically contiguous pieces let the GPU's page tables use large fragments, and the 19 + 19 streams of a step stop
+// missing in the TLBs.  So arrays of at least 64 MiB are mapped from chunks (LUW_ALLOC=vmm:<chunk MiB>, default 1024);
+// LUW_ALLOC=malloc restores plain hipMalloc (and with it the placement search of tune_ddf_placement).
+static size_t alloc_vmm_chunk() {
+	static const size_t chunk = [] {
+		const char* e = getenv("LUW_ALLOC");
+		if(e&&strncmp(e, "malloc", 6)==0) return (size_t)0u;
+		size_t mib = 1024u;
+		if(e&&strncmp(e, "vmm:", 4)==0) { const size_t v = (size_t)strtoull(e+4, nullptr, 10); if(v) mib = v; }
+		return mib<<20;
+	}();
+	return chunk;
+}
+
 struct luw_solver {
 	luw_config cfg;
 	KParams kp;
 	uint64_t N = 0;          // Nx*Ny*Nz
 	uint64_t t = 0;
 	bool initialized = false;
+	bool counted = false;    // registered in g_live_solvers
 	bool fields_current = true; // device rho,u reflect the state after the last executed step
 	size_t ddf_bytes = 4;
 	void* d_fi = nullptr;
@@ -94,8 +159,9 @@ struct luw_solver {
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
 	uint32_t kernel = LUW_KERNEL_AUTO;
-	std::vector<void*> raw; // hipMalloc'ed blocks behind the lattice-sized arrays (lead_alloc)
+	std::vector<DevBlock> raw; // device blocks behind the lattice-sized arrays (lead_alloc)
 	uint32_t gather_count = 0u; uint32_t* d_gather_cell = nullptr; float* d_gather_out = nullptr; // probe columns
+	void* d_stage = nullptr; size_t stage_bytes = 0u; // copy_pitched's staging buffer (chunk-mapped arrays)
 };
 
 // Lattice-sized device arrays start LEAD elements into their allocation, LEAD = 64 - halo_x: with the x pitch a multiple of
@@ -103,27 +169,83 @@ struct luw_solver {
 // that a wave's 64 consecutive cells are exactly the lines it touches -- in a halo'ed domain (Nx = 512 + 2) just as in a
 // single one.  Measured on MI355X before this: interior kernel of a 514x514x512 domain 7.3 ms vs 3.5 ms for 512^3.
 static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, const size_t elem_bytes) {
-	void* r = nullptr;
+	DevBlock blk;
 	const size_t lead = (size_t)(64u-s->kp.halo_x)*elem_bytes, total = elems*elem_bytes+64u*elem_bytes;
-	hipError_t e = hipMalloc(&r, total);
+	const size_t chunk = total>=(64ull<<20) ? std::min<size_t>(alloc_vmm_chunk(), (size_t)(((total+(2ull<<20)-1u)>>21)<<21)) : 0u; // small arrays: one piece of their own size, or hipMalloc
+	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk);
+	if(e!=hipSuccess&&chunk) { (void)hipGetLastError(); e = dev_alloc(blk, total, s->cfg.device, 0u); } // no VMM on this system: hipMalloc
 	if(e!=hipSuccess) return e;
-	s->raw.push_back(r);
-	e = hipMemsetAsync(r, 0, total, s->stream); // padding / not-yet-uploaded memory must hold defined values
-	*base = (char*)r+lead;
+	e = hipMemsetAsync(blk.base, 0, total, s->stream); // padding / not-yet-uploaded memory must hold defined values
+	*base = (char*)blk.base+lead;
+	s->raw.push_back(std::move(blk));
 	return e;
 }
 
 static int set_device(const luw_solver* s) { HIP_TRY(hipSetDevice(s->cfg.device)); return LUW_OK; }
 
-static int copy_pitched(void* dst, const void* src, const size_t elem, const luw_solver* s, const uint32_t planes, const bool to_device, hipStream_t st) {
+// Host mirror (reference layout, pitch Nx) <-> device array (pitch Px), `planes` components.  Arrays in one physical piece go
+// through hipMemcpy2DAsync.  Arrays mapped from several physical chunks do not: the runtime's copy routines reject ranges that
+// span chunks (hipMemcpy2DAsync: "invalid argument" at 1024^3), while kernels address them like any other memory -- so the rows
+// travel through a contiguous staging buffer (1-D copies, bounded size) and a kernel moves them between staging and lattice.
+template<typename E> __global__ __launch_bounds__(256) void k_rows_copy(E* __restrict__ lattice, const size_t lattice_pitch, E* __restrict__ staging, const uint32_t nx, const bool to_lattice) {
+	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x;
+	if(x>=nx) return;
+	const size_t row = (size_t)blockIdx.y+(size_t)blockIdx.z*gridDim.y;
+	E* l = lattice+row*lattice_pitch+x; E* t = staging+row*nx+x;
+	if(to_lattice) *l = *t; else *t = *l;
+}
+static const DevBlock* block_of(const luw_solver* s, const void* p) {
+	for(const DevBlock& b : s->raw) if((const char*)p>=(const char*)b.base&&(const char*)p<(const char*)b.base+b.bytes) return &b;
+	return nullptr;
+}
+static int copy_pitched(void* dst, const void* src, const size_t elem, luw_solver* s, const uint32_t planes, const bool to_device, hipStream_t st) {
 	const size_t rows = (size_t)s->cfg.Ny*s->cfg.Nz;
-	for(uint32_t c=0u; c<planes; c++) {
-		if(to_device) HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (const char*)src+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyHostToDevice, st));
-		else HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (const char*)src+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyDeviceToHost, st));
+	const DevBlock* blk = block_of(s, to_device ? dst : src);
+	static const bool force_staged = getenv("LUW_COPY_STAGED")!=nullptr; // test aid: the staged path also for single-piece arrays
+	if(!force_staged&&(!blk||blk->chunks.size()<=1u)) {
+		for(uint32_t c=0u; c<planes; c++) {
+			if(to_device) HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (const char*)src+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyHostToDevice, st));
+			else HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (const char*)src+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyDeviceToHost, st));
+		}
+		return LUW_OK;
+	}
+	const size_t row_bytes = (size_t)s->cfg.Nx*elem;
+	if(!s->d_stage) { // copies and kernels of successive batches are ordered by the stream, so one buffer serves them all
+		s->stage_bytes = std::max<size_t>(row_bytes, std::min<size_t>(256ull<<20, rows*row_bytes));
+		if(hipMalloc(&s->d_stage, s->stage_bytes)!=hipSuccess) { s->d_stage = nullptr; return fail(LUW_ERR_NOMEM, "copy: staging buffer"); }
+	}
+	const size_t batch_rows = std::max<size_t>(1u, s->stage_bytes/row_bytes);
+	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
+	for(uint32_t c=0u; c<planes; c++) for(size_t r0=0u; r0<rows; r0+=batch_rows) {
+		const size_t nr = std::min(batch_rows, rows-r0);
+		char* stage = (char*)s->d_stage;
+		char* lat = (char*)(to_device ? dst : const_cast<void*>(src))+((size_t)c*s->kp.Np+r0*s->kp.Px)*elem;
+		char* host = (char*)(to_device ? const_cast<void*>(src) : dst)+((size_t)c*s->N+r0*s->cfg.Nx)*elem;
+		// rows as a (y, z)-shaped grid: gridDim.y <= 65535
+		const uint32_t gy = (uint32_t)std::min<size_t>(nr, 4096u);
+		// the kernel indexes row = y + z*gy and may run past nr in the last z slab: launch the full slabs and the remainder separately
+		auto launch = [&](const size_t first, const uint32_t ny, const uint32_t nz) {
+			if(ny==0u||nz==0u) return;
+			const dim3 grid((s->cfg.Nx+bx-1u)/bx, ny, nz), block(bx);
+			char* l = lat+first*s->kp.Px*elem; char* t = stage+first*row_bytes;
+			if(elem==4u) hipLaunchKernelGGL(k_rows_copy<uint32_t>, grid, block, 0, st, (uint32_t*)l, (size_t)s->kp.Px, (uint32_t*)t, s->cfg.Nx, to_device);
+			else if(elem==2u) hipLaunchKernelGGL(k_rows_copy<uint16_t>, grid, block, 0, st, (uint16_t*)l, (size_t)s->kp.Px, (uint16_t*)t, s->cfg.Nx, to_device);
+			else hipLaunchKernelGGL(k_rows_copy<uint8_t>, grid, block, 0, st, (uint8_t*)l, (size_t)s->kp.Px, (uint8_t*)t, s->cfg.Nx, to_device);
+		};
+		const uint32_t full = (uint32_t)(nr/gy), rem = (uint32_t)(nr%gy);
+		if(to_device) {
+			HIP_TRY(hipMemcpyAsync(stage, host, nr*row_bytes, hipMemcpyHostToDevice, st));
+			launch(0u, gy, full); launch((size_t)full*gy, rem, 1u);
+		} else {
+			launch(0u, gy, full); launch((size_t)full*gy, rem, 1u);
+			HIP_TRY(hipMemcpyAsync(host, stage, nr*row_bytes, hipMemcpyDeviceToHost, st));
+		}
+		HIP_TRY(hipGetLastError());
 	}
 	return LUW_OK;
 }
 
+#ifdef LUW_AB_KERNELS
 template<typename T, int V> static void launch_vec(luw_solver* s, const Box& b, const int write_fields) {
 	T* fi = (T*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
@@ -136,6 +258,7 @@ template<typename T, int V> static void launch_vec(luw_solver* s, const Box& b, 
 	if(odd) hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_v<T, V, 0>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
+#endif
 // threads per block for a row of nx lanes: whole waves, at most 256, chosen so that the blocks of a row carry the fewest idle
 // lanes (a 375-lane row of the pair kernel: 3 x 128 instead of 2 x 256; ties go to the larger block)
 static uint32_t row_block(const uint32_t nx) {
@@ -151,9 +274,11 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	const uint32_t nx = (uint32_t)((int)b.x1-xa);
 	const uint32_t bx = row_block(nx);
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+#ifdef LUW_AB_KERNELS
 	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
+#endif
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
-	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid
+	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid (both are product code, same values)
 	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Np*sizeof(T)<=(1ull<<32) && !force_row;
 	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
 	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
@@ -169,12 +294,14 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 		else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); }
 		#undef LUW_LAUNCH_T
 	}
-	else if(mode==0) { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }
+#ifdef LUW_AB_KERNELS
 	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
 	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
 	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
 	else if(mode==5) { if(odd) LUW_LAUNCH_S(1, 3, 2); else LUW_LAUNCH_S(0, 3, 2); }
-	else { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
+	else if(mode==4) { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
+#endif
+	else { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }   // the product kernel
 	#undef LUW_LAUNCH_SF
 	#undef LUW_LAUNCH_S
 }
@@ -187,9 +314,11 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
 	if(st) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 0, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, *st);
 		else hipLaunchKernelGGL((k_stream_collide_p<0, 0, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, *st); return; }
-	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // measurement aid: the kernel's memory path alone (no physics)
+#ifdef LUW_AB_KERNELS
+	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // tools build, measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
+#endif
 	if(odd) hipLaunchKernelGGL((k_stream_collide_p<1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
@@ -212,7 +341,9 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
 	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=256u) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
 	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
+#ifdef LUW_AB_KERNELS
 	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the vector kernels assume rows that start on a 16-byte boundary at x = 0
+#endif
 	// pair kernel: FP16C; pairs start on a 4-byte boundary -- at even x, or at odd x when x is split (the row's lead pad then puts
 	// x = 1 on a line start, lead_alloc); the range holds whole pairs, except that it may end at an odd Nx of an unsplit row (the
 	// last cell then pairs with the row padding)
@@ -224,9 +355,11 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	if(st&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) return fail(LUW_ERR_STATE, "stream_collide: this kernel has no fused statistics");
 	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields, st);
 	else if(st) { if(fp16) launch_scalar<uint16_t>(s, b, write_fields, st); else launch_scalar<float>(s, b, write_fields, st); }
+#ifdef LUW_AB_KERNELS
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
+#endif
 	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
@@ -247,58 +380,69 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 
 // Where the driver places the DDF array physically changes the step time of this 19-stream kernel by up to 10 % on MI355X:
 // allocations of the same size at the same virtual address come out in two classes (512^3 FP32: 3.40-3.50 ms vs 3.70-3.85 ms
-// per step, persistent for the life of the allocation; tools/placement_probe.py).  Nothing in the HIP API selects the class,
-// so large solvers allocate a few candidates, time the real kernel on each (zero DDFs = rest state, flags 0 = all fluid: a
-// valid, full-cost step) and keep the fastest.  LUW_TUNE_PLACEMENT=0 disables it; skipped when memory is short.
+// per step, persistent for the life of the allocation; tools/placement_probe.py).  Large solvers therefore time the real kernel
+// on their DDF array (zero DDFs = rest state, flags 0 = all fluid: a valid, full-cost step) and, while it is not of the fast
+// class, try another allocation -- ONE extra array at a time: the loser of each comparison is freed before the next candidate
+// is allocated, so the search never holds more than two DDF arrays and needs no more memory than that.  LUW_TUNE_PLACEMENT=
+// <candidates> (default 6, 0/1 = off); skipped when the device is short of memory or other solvers already live on it (several
+// ranks / domains sharing one GPU: the test set-ups).
+static std::atomic<int> g_live_solvers[64];
 static int tune_ddf_placement(luw_solver* s) {
-	const size_t bytes = 19ull*s->kp.Np*s->ddf_bytes;
+	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
 	const char* env = getenv("LUW_TUNE_PLACEMENT");
-	int candidates = env ? atoi(env) : 6;
+	const int candidates = env ? atoi(env) : (s->raw.front().chunks.empty() ? 6 : 0); // chunk-mapped arrays need no search
 	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
+	if(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1) return LUW_OK; // this device is shared with other solvers of this process
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
-	hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+	struct Events { hipEvent_t e0 = nullptr, e1 = nullptr; ~Events() { if(e0) (void)hipEventDestroy(e0); if(e1) (void)hipEventDestroy(e1); } } ev;
+	HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
 	auto step_ms = [&](float& ms) -> int { // two steps (both parities) after one untimed
+		struct Restore { luw_solver* s; ~Restore() { s->initialized = false; s->t = 0ull; } } restore{ s };
 		s->initialized = true; s->t = 0ull;
 		if(int e = launch_stream_collide(s, whole, 0)) return e;
 		s->t = 1ull;
-		HIP_TRY(hipEventRecord(e0, s->stream));
+		HIP_TRY(hipEventRecord(ev.e0, s->stream));
 		if(int e = launch_stream_collide(s, whole, 0)) return e;
 		s->t = 2ull;
 		if(int e = launch_stream_collide(s, whole, 0)) return e;
-		HIP_TRY(hipEventRecord(e1, s->stream));
-		HIP_TRY(hipEventSynchronize(e1));
-		HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-		s->initialized = false; s->t = 0ull;
+		HIP_TRY(hipEventRecord(ev.e1, s->stream));
+		HIP_TRY(hipEventSynchronize(ev.e1));
+		HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
 		return LUW_OK;
 	};
+	// a placement of the fast class moves this many algorithmic bytes per second through the probe (FP32 153, FP16C 77 B per update)
+	const double probe_bytes = 2.0*(s->ddf_bytes==4u ? 153.0 : 77.0)*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
+	auto fast_class = [&](const float ms) { return probe_bytes/((double)ms*1e-3)>=(s->ddf_bytes==4u ? 6.0e12 : 5.4e12); };
 	float best_ms = 0.0f;
 	if(int e = step_ms(best_ms)) return e;
-	void* best_raw = s->raw.front(); void* best_fi = s->d_fi; // fi is the first lead_alloc of luw_create
-	std::vector<void*> losers;
-	// FP32 (HBM-bound): a placement of the fast class moves >= 6.0 TB/s of algorithmic bytes in this probe; while none has been
-	// found the search goes on past the nominal count, up to twice as many candidates (memory permitting)
-	const double probe_bytes = 2.0*153.0*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
-	auto fast_class = [&](const float ms) { return s->ddf_bytes!=4u || probe_bytes/((double)ms*1e-3)>=6.0e12; };
-	for(int k=1; k<2*candidates; k++) {
-		if(k>=candidates&&fast_class(best_ms)) break;
+	const bool verbose = getenv("LUW_TUNE_VERBOSE")!=nullptr;
+	if(verbose) fprintf(stderr, "luw: placement candidate 0: %.3f ms per 2 steps\n", best_ms);
+	for(int k=1; k<candidates&&!fast_class(best_ms); k++) {
 		size_t free_b = 0u, total_b = 0u;
-		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+(8ull<<30)) break; // keep headroom for the rest of the run
+		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+bytes/4u+(2ull<<30)) break; // room for ONE more array plus what the run still allocates
 		void* fi = nullptr;
-		if(lead_alloc(s, &fi, 19ull*s->kp.Np, s->ddf_bytes)!=hipSuccess) { (void)hipGetLastError(); break; }
-		void* raw = s->raw.back(); s->raw.pop_back();
+		if(lead_alloc(s, &fi, elems, s->ddf_bytes)!=hipSuccess) { (void)hipGetLastError(); break; }
+		DevBlock cand = std::move(s->raw.back()); s->raw.pop_back();
+		void* const old_fi = s->d_fi;
 		s->d_fi = fi;
 		float ms = 0.0f;
-		if(int e = step_ms(ms)) { (void)hipFree(raw); s->d_fi = best_fi; return e; }
-		if(getenv("LUW_TUNE_VERBOSE")) fprintf(stderr, "luw: placement candidate %d: %.3f ms per 2 steps (best so far %.3f)\n", k, ms, best_ms);
-		if(ms<best_ms) { losers.push_back(best_raw); best_ms = ms; best_raw = raw; best_fi = fi; }
-		else losers.push_back(raw);
+		if(int e = step_ms(ms)) { s->d_fi = old_fi; dev_free(cand); return e; }
+		if(verbose) fprintf(stderr, "luw: placement candidate %d: %.3f ms per 2 steps (best so far %.3f)\n", k, ms, best_ms);
+		if(ms<best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
+		else s->d_fi = old_fi;
+		dev_free(cand);
 	}
-	for(void* r : losers) (void)hipFree(r); // released only now, so that no candidate reuses the pages of another
-	s->raw.front() = best_raw; s->d_fi = best_fi;
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	HIP_TRY(hipMemsetAsync(best_raw, 0, bytes+64u*s->ddf_bytes, s->stream)); // the probe steps left zeros, but be explicit
+	HIP_TRY(hipMemsetAsync(s->raw.front().base, 0, bytes+64u*s->ddf_bytes, s->stream)); // the probe steps left zeros, but be explicit
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
+}
+
+static bool kernel_selectable(const uint32_t k) {
+#ifdef LUW_AB_KERNELS
+	return k<=LUW_KERNEL_SCALAR_GENERAL||k==LUW_KERNEL_EXP_COPY||k==LUW_KERNEL_EXP_NOSHIFT;
+#else
+	return k==LUW_KERNEL_AUTO||k==LUW_KERNEL_SCALAR||k==LUW_KERNEL_PAIR;
+#endif
 }
 
 extern "C" {
@@ -315,9 +459,11 @@ void luw_destroy(luw_solver* s) {
 	if(!s) return;
 	(void)hipSetDevice(s->cfg.device);
 	if(s->own_stream) (void)hipStreamSynchronize(s->own_stream);
-	for(void* r : s->raw) (void)hipFree(r); // fi, rho, u, flags, F, statistics
+	for(DevBlock& r : s->raw) dev_free(r); // fi, rho, u, flags, F, statistics
+	if(s->counted&&s->cfg.device>=0&&s->cfg.device<64) g_live_solvers[s->cfg.device]--;
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
 	(void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out);
+	(void)hipFree(s->d_stage);
 	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
 	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F); (void)hipHostFree(s->h_T);
 	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -333,6 +479,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->nu==0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be 0."); // FX/lbm.cpp:1141
 	if(cfg->nu<0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be negative."); // FX/lbm.cpp:1142
 	if(cfg->ddf_format!=LUW_DDF_FP32&&cfg->ddf_format!=LUW_DDF_FP16C) return fail(LUW_ERR_INVALID, "luw_create: unknown ddf_format");
+	if(!kernel_selectable(cfg->kernel)) return fail(LUW_ERR_INVALID, "luw_create: this library has no such kernel (A/B and measurement-only variants exist in the tools build only)");
 	if((cfg->Dx>1u&&cfg->Nx<3u)||(cfg->Dy>1u&&cfg->Ny<3u)||(cfg->Dz>1u&&cfg->Nz<3u)) return fail(LUW_ERR_INVALID, "luw_create: split axes need at least one interior cell between the halo layers");
 	if((cfg->options&LUW_OPT_TEMPERATURE)&&!(cfg->alpha>=0.0f)) return fail(LUW_ERR_INVALID, "luw_create: thermal diffusivity must not be negative");
 	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
@@ -350,10 +497,13 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 
 	luw_solver* s = new luw_solver();
 	s->cfg = *cfg;
+	if(cfg->device<64) { g_live_solvers[cfg->device]++; s->counted = true; }
 	s->N = (uint64_t)cfg->Nx*cfg->Ny*cfg->Nz;
 	s->ddf_bytes = cfg->ddf_format==LUW_DDF_FP16C ? 2u : 4u;
 	s->kernel = cfg->kernel;
-	if(const char* ke = getenv("LUW_KERNEL")) s->kernel = (uint32_t)atoi(ke); // test / A-B aid: overrides the kernel choice of callers that expose none (the deck driver)
+#ifdef LUW_AB_KERNELS
+	if(const char* ke = getenv("LUW_KERNEL")) s->kernel = (uint32_t)atoi(ke); // tools build: overrides the kernel choice of callers that expose none (the deck driver)
+#endif
 	KParams& k = s->kp;
 	memset(&k, 0, sizeof(k));
 	k.Nx = cfg->Nx; k.Ny = cfg->Ny; k.Nz = cfg->Nz; k.Px = Px; k.Np = (uint32_t)Np;
@@ -547,12 +697,14 @@ int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, 
 	}
 	float* d[3] = { nullptr, nullptr, nullptr };
 	const float* h[3] = { p0, p1, p2 };
-	for(int k=0; k<3; k++) { if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess) { for(int q=0; q<3; q++) (void)hipFree(d[q]); return fail(LUW_ERR_NOMEM, "luw_voxelize_mesh: allocation failed"); } HIP_TRY(hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)); }
+	struct Release { float** d; ~Release() { for(int k=0; k<3; k++) (void)hipFree(d[k]); } } release{ d }; // the triangle arrays go on every path out
+	for(int k=0; k<3; k++) {
+		if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess) { d[k] = nullptr; return fail(LUW_ERR_NOMEM, "luw_voxelize_mesh: allocation failed"); }
+		HIP_TRY(hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice));
+	}
 	if(int e = luw_upload(s, LUW_MASK_FLAGS|LUW_MASK_U)) return e; // the host mirror is authoritative before the first run
 	const VoxGrid vg = { s->kp.Nx, s->kp.Ny, s->kp.Nz, s->kp.Px, s->kp.Ox, s->kp.Oy, s->kp.Oz, (uint64_t)s->kp.Np };
-	const int rc = voxelize_launch(vg, s->d_flags, s->d_u, flag, triangle_number, p0, p1, p2, d, pmin, pmax, s->stream);
-	for(int k=0; k<3; k++) (void)hipFree(d[k]);
-	if(rc!=LUW_OK) return rc;
+	if(int rc = voxelize_launch(vg, s->d_flags, s->d_u, flag, triangle_number, p0, p1, p2, d, pmin, pmax, s->stream)) return rc;
 	return luw_download(s, LUW_MASK_FLAGS); // LBM::voxelize_mesh_on_device leaves the result in lbm.flags
 }
 
@@ -602,8 +754,10 @@ int luw_gather_attach(luw_solver* s, uint32_t count, const uint64_t* cells) {
 		const uint32_t z = (uint32_t)(cells[i]/A), y = (uint32_t)((cells[i]%A)/s->cfg.Nx), x = (uint32_t)(cells[i]%s->cfg.Nx);
 		c[i] = x+(y+z*s->cfg.Ny)*s->kp.Px;
 	}
-	if(hipMalloc((void**)&s->d_gather_cell, 4ull*count)!=hipSuccess||hipMalloc((void**)&s->d_gather_out, 12ull*count)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed");
-	HIP_TRY(hipMemcpy(s->d_gather_cell, c.data(), 4ull*count, hipMemcpyHostToDevice));
+	auto drop = [&]() { (void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out); s->d_gather_cell = nullptr; s->d_gather_out = nullptr; };
+	if(hipMalloc((void**)&s->d_gather_cell, 4ull*count)!=hipSuccess) { s->d_gather_cell = nullptr; return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed"); }
+	if(hipMalloc((void**)&s->d_gather_out, 12ull*count)!=hipSuccess) { s->d_gather_out = nullptr; drop(); return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed"); }
+	if(hipMemcpy(s->d_gather_cell, c.data(), 4ull*count, hipMemcpyHostToDevice)!=hipSuccess) { drop(); return fail(LUW_ERR_DEVICE, "luw_gather_attach: upload failed"); }
 	s->gather_count = count;
 	return LUW_OK;
 }
@@ -659,12 +813,15 @@ int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count
 		cell[i] = x+(y+z*s->cfg.Ny)*s->kp.Px;
 	}
 	const size_t P = point_count, V = 5ull*mode_count;
-	if(hipMalloc((void**)&s->d_vk_cell, P*4u)!=hipSuccess||hipMalloc((void**)&s->d_vk_face, P)!=hipSuccess||hipMalloc((void**)&s->d_vk_point, 7ull*P*4u)!=hipSuccess||hipMalloc((void**)&s->d_vk_mode, 10ull*V*4u)!=hipSuccess)
-		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocation failed");
-	HIP_TRY(hipMemcpy(s->d_vk_cell, cell.data(), P*4u, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(s->d_vk_face, point_face, P, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(s->d_vk_point, point_data, 7ull*P*4u, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(s->d_vk_mode, mode_data, 10ull*V*4u, hipMemcpyHostToDevice));
+	// all four tables or none: a failure half-way leaves the solver without an inlet (detach frees what was allocated)
+	auto table = [&](void** dst, const void* src, const size_t bytes) {
+		if(hipMalloc(dst, bytes)!=hipSuccess) { *dst = nullptr; return false; }
+		return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice)==hipSuccess;
+	};
+	if(!table((void**)&s->d_vk_cell, cell.data(), P*4u)||!table((void**)&s->d_vk_face, point_face, P)||!table((void**)&s->d_vk_point, point_data, 7ull*P*4u)||!table((void**)&s->d_vk_mode, mode_data, 10ull*V*4u)) {
+		(void)hipGetLastError(); (void)luw_vk_inlet_detach(s);
+		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocating / uploading the inlet tables failed");
+	}
 	s->vk_P = (uint32_t)P; s->vk_M = (uint32_t)mode_count; s->vk_stride = update_stride>1 ? update_stride : 1; s->vk_interp = stride_interpolation!=0;
 	s->vk_active = true; s->vk_last_t = ~0ull;
 	return LUW_OK;
@@ -726,10 +883,7 @@ int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u,
 	}
 	if(avg_rho) if((e = copy_pitched(avg_rho, s->d_avg_rho, 4u, s, 1u, false, s->stream))) return e;
 	float* m2h[3] = { m2_u, m2_v, m2_w };
-	for(int c=0; c<3; c++) if(m2h[c]) {
-		const size_t rows = (size_t)s->cfg.Ny*s->cfg.Nz;
-		HIP_TRY(hipMemcpy2DAsync(m2h[c], (size_t)s->cfg.Nx*4u, s->d_m2+(size_t)c*s->kp.Np, (size_t)s->kp.Px*4u, (size_t)s->cfg.Nx*4u, rows, hipMemcpyDeviceToHost, s->stream));
-	}
+	for(int c=0; c<3; c++) if(m2h[c]) if((e = copy_pitched(m2h[c], s->d_m2+(size_t)c*s->kp.Np, 4u, s, 1u, false, s->stream))) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if(count) *count = s->avg_count;
 	return LUW_OK;
@@ -807,6 +961,7 @@ int luw_stats_begin_sample(luw_solver* s, int* fused) {
 }
 int luw_set_kernel(luw_solver* s, uint32_t kernel) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_set_kernel: null solver");
+	if(!kernel_selectable(kernel)) return fail(LUW_ERR_INVALID, "luw_set_kernel: this library has no such kernel");
 	s->kernel = kernel;
 	return LUW_OK;
 }
@@ -918,3 +1073,5 @@ int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, 
 }
 
 } // extern "C"
+
+#include "luw_group.hpp"

@@ -1,0 +1,555 @@
+// luw_group.hpp -- the multi-domain host runtime: ONE process, D = Dx*Dy*Dz domains, one HIP device + one compute / one
+// communication stream per domain.  This is the reference's `LBM` object for D > 1 (FX/lbm.cpp:1057-1112 constructor,
+// :1221-1260 initialize, :1262-1290 do_time_step, :1907-1935 communicate_field) behind the C-ABI (luw_group_* in luw_core.h).
+// Host code of libluw_core.so; included by luw_core.hip only, after the single-domain entry points it is built on.
+//
+// What is the reference's: block decomposition, domain id d = x + (y + z*Dy)*Dx, local extents N/D + 2 on split axes, offsets,
+// periodic neighbour (x+1)%Dx, per step and per axis x, y, z: extract the 5 outgoing DDFs of both faces (faces include the halo
+// rims), swap with the two neighbours, insert; one odd-t exchange at initialisation.
+// What is ours (MI355X): nothing is staged through the host.  With peer access (xGMI between the GPUs of a node, or several
+// domains on one device) the pack kernel of a domain writes its face STRAIGHT into the neighbour's receive buffer -- a remote
+// store stream over xGMI, no copy engine, no intermediate buffer; without peer access the face goes through
+// hipMemcpyPeerAsync.  The boundary shell of a domain runs first on its communication stream, its faces travel while the
+// interior box runs on the compute stream, and steps are pipelined: interior(t+1) waits for shell(t) only (the dependency
+// analysis is the one of latticeurbanwind_amd/distributed.py, held by tests/test_pipeline_hazards.py).  All ordering is done
+// with HIP events between streams; the host thread only enqueues and synchronises once per luw_group_run call.
+#pragma once
+
+struct GroupDomain {
+	luw_solver* s = nullptr;
+	int device = 0;
+	uint32_t coord[3] = { 0u, 0u, 0u };
+	uint32_t lN[3] = { 0u, 0u, 0u };
+	int32_t O[3] = { 0, 0, 0 };
+	uint32_t nbr[3][2] = {};                  // [axis][0: + neighbour, 1: - neighbour] (domain ids, periodic)
+	hipStream_t compute = nullptr, comm = nullptr;
+	void* recv[3][2] = {};                    // [axis][0: face coming from the + neighbour (insert's buf_p), 1: from the - neighbour (buf_m)], 5*A DDF elements
+	void* send[3][2] = {};                    // staging, only for neighbours without peer access
+	void* grecv[3][2] = {}; void* gsend[3][2] = {}; // thermal lattice: one population per face cell
+	hipEvent_t shell_done = nullptr, interior_done = nullptr, pre_done = nullptr, stats_done = nullptr;
+	hipEvent_t packed[3] = {}, unpacked[3] = {}, gpacked[3] = {}, gunpacked[3] = {};
+	bool stats_pending = false;
+	Box whole{}, interior{};
+	std::vector<Box> shell;
+	std::vector<uint32_t> gather_src;         // probe gather: positions of this domain's cells in the caller's list
+};
+
+struct luw_group {
+	luw_config gcfg{};                        // the GLOBAL lattice in Nx,Ny,Nz
+	uint32_t D[3] = { 1u, 1u, 1u }, gN[3] = { 1u, 1u, 1u }, H[3] = { 0u, 0u, 0u };
+	std::vector<GroupDomain> dom;
+	std::vector<std::vector<char>> peer;      // peer[a][b]: kernels of domain a's device may write domain b's memory
+	bool overlap = false, initialized = false, thermal = false;
+	size_t ddf_bytes = 4u;
+	uint64_t t = 0ull;
+	uint32_t gather_total = 0u;
+};
+
+static const uint32_t GROUP_X_SHELL = 64u;   // thickness of the x boundary slabs: one memory line of cells (a one-cell x face would run one lane per wave)
+
+static void group_axis_ranges(const luw_group* g, const GroupDomain& d, const int a, uint32_t nonhalo[2], uint32_t lo_slab[2], uint32_t hi_slab[2], uint32_t inner[2]) {
+	nonhalo[0] = g->H[a]; nonhalo[1] = d.lN[a]-g->H[a];
+	if(!g->H[a]) { lo_slab[0] = lo_slab[1] = hi_slab[0] = hi_slab[1] = 0u; inner[0] = 0u; inner[1] = d.lN[a]; return; }
+	const uint32_t lo = nonhalo[0], hi = nonhalo[1];
+	if(a!=0) { lo_slab[0] = lo; lo_slab[1] = lo+1u; hi_slab[0] = hi-1u; hi_slab[1] = hi; }
+	else {
+		const uint32_t first_end = std::min(lo+GROUP_X_SHELL, hi);
+		const uint32_t last_start = std::max(lo+((hi-1u-lo)/GROUP_X_SHELL)*GROUP_X_SHELL, first_end);
+		lo_slab[0] = lo; lo_slab[1] = first_end; hi_slab[0] = last_start; hi_slab[1] = hi;
+	}
+	inner[0] = lo_slab[1]; inner[1] = hi_slab[0];
+}
+// whole box (non-halo cells), interior box and the disjoint shell slabs covering their difference -- DomainLayout.shell_boxes
+static void group_boxes(const luw_group* g, GroupDomain& d) {
+	uint32_t nh[3][2], lo[3][2], hi[3][2], in[3][2];
+	for(int a=0; a<3; a++) group_axis_ranges(g, d, a, nh[a], lo[a], hi[a], in[a]);
+	d.whole = Box{ nh[0][0], nh[0][1], nh[1][0], nh[1][1], nh[2][0], nh[2][1] };
+	d.interior = Box{ in[0][0], in[0][1], in[1][0], in[1][1], in[2][0], in[2][1] };
+	d.shell.clear();
+	uint32_t rng[3][2] = { { nh[0][0], nh[0][1] }, { nh[1][0], nh[1][1] }, { nh[2][0], nh[2][1] } };
+	for(int a=0; a<3; a++) {
+		if(!g->H[a]) continue;
+		const uint32_t slabs[2][2] = { { lo[a][0], lo[a][1] }, { hi[a][0], hi[a][1] } };
+		for(int k=0; k<2; k++) {
+			uint32_t r[3][2] = { { rng[0][0], rng[0][1] }, { rng[1][0], rng[1][1] }, { rng[2][0], rng[2][1] } };
+			r[a][0] = slabs[k][0]; r[a][1] = slabs[k][1];
+			if(r[0][1]>r[0][0]&&r[1][1]>r[1][0]&&r[2][1]>r[2][0]) d.shell.push_back(Box{ r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1] });
+		}
+		rng[a][0] = in[a][0]; rng[a][1] = in[a][1]; // later axes exclude what this axis already covered
+	}
+}
+
+static void group_free(luw_group* g) {
+	if(!g) return;
+	for(GroupDomain& d : g->dom) {
+		(void)hipSetDevice(d.device);
+		if(d.compute) (void)hipStreamSynchronize(d.compute);
+		if(d.comm) (void)hipStreamSynchronize(d.comm);
+	}
+	for(GroupDomain& d : g->dom) {
+		(void)hipSetDevice(d.device);
+		if(d.s) { (void)luw_set_stream(d.s, nullptr); luw_destroy(d.s); }
+		for(int a=0; a<3; a++) for(int k=0; k<2; k++) { (void)hipFree(d.recv[a][k]); (void)hipFree(d.send[a][k]); (void)hipFree(d.grecv[a][k]); (void)hipFree(d.gsend[a][k]); }
+		for(hipEvent_t e : { d.shell_done, d.interior_done, d.pre_done, d.stats_done }) if(e) (void)hipEventDestroy(e);
+		for(int a=0; a<3; a++) for(hipEvent_t e : { d.packed[a], d.unpacked[a], d.gpacked[a], d.gunpacked[a] }) if(e) (void)hipEventDestroy(e);
+		if(d.compute) (void)hipStreamDestroy(d.compute);
+		if(d.comm) (void)hipStreamDestroy(d.comm);
+	}
+	delete g;
+}
+
+#define GROUP_TRY(call) do { if(int e_ = (call)) return e_; } while(0)
+static int group_set_device(const GroupDomain& d) { HIP_TRY(hipSetDevice(d.device)); return LUW_OK; }
+
+// ---- the halo exchange of one field (G = false: 5 DDFs per face cell; true: the thermal lattice's single population), all split
+// axes in the order x, y, z, on the domains' communication streams (or the stream given by `on_compute`)
+static int group_exchange(luw_group* g, const bool thermal_pass, const bool on_compute) {
+	for(int a=0; a<3; a++) {
+		if(!g->H[a]) continue;
+		for(size_t i=0; i<g->dom.size(); i++) { // pack: into the neighbours' receive buffers (peer stores) or staged through a copy
+			GroupDomain& d = g->dom[i];
+			GROUP_TRY(group_set_device(d));
+			hipStream_t st = on_compute ? d.compute : d.comm;
+			GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
+			hipEvent_t* unp = thermal_pass ? P.gunpacked : P.unpacked; hipEvent_t* unm = thermal_pass ? M.gunpacked : M.unpacked;
+			HIP_TRY(hipStreamWaitEvent(st, unp[a], 0)); HIP_TRY(hipStreamWaitEvent(st, unm[a], 0)); // the neighbours have consumed what the previous step put there
+			// my + face lands in the + neighbour's "from the - side" buffer, my - face in the - neighbour's "from the + side" buffer
+			void* dst_p = (thermal_pass ? P.grecv : P.recv)[a][1]; void* dst_m = (thermal_pass ? M.grecv : M.recv)[a][0];
+			const bool direct = g->peer[i][d.nbr[a][0]]&&g->peer[i][d.nbr[a][1]];
+			void* out_p = direct ? dst_p : (thermal_pass ? d.gsend : d.send)[a][0]; void* out_m = direct ? dst_m : (thermal_pass ? d.gsend : d.send)[a][1];
+			GROUP_TRY(luw_set_stream(d.s, st));
+			GROUP_TRY(thermal_pass ? luw_enqueue_extract_gi(d.s, (uint32_t)a, out_p, out_m) : luw_enqueue_extract_fi(d.s, (uint32_t)a, out_p, out_m));
+			if(!direct) {
+				const size_t bytes = (size_t)luw_get_area(d.s, (uint32_t)a)*(thermal_pass ? 1u : 5u)*g->ddf_bytes;
+				HIP_TRY(hipMemcpyPeerAsync(dst_p, P.device, out_p, d.device, bytes, st));
+				HIP_TRY(hipMemcpyPeerAsync(dst_m, M.device, out_m, d.device, bytes, st));
+			}
+			HIP_TRY(hipEventRecord((thermal_pass ? d.gpacked : d.packed)[a], st));
+		}
+		for(size_t i=0; i<g->dom.size(); i++) { // unpack once both neighbours have delivered
+			GroupDomain& d = g->dom[i];
+			GROUP_TRY(group_set_device(d));
+			hipStream_t st = on_compute ? d.compute : d.comm;
+			GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
+			HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? P.gpacked : P.packed)[a], 0));
+			HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? M.gpacked : M.packed)[a], 0));
+			GROUP_TRY(luw_set_stream(d.s, st));
+			GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]) : luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
+			HIP_TRY(hipEventRecord((thermal_pass ? d.gunpacked : d.unpacked)[a], st));
+		}
+	}
+	return LUW_OK;
+}
+static int group_communicate(luw_group* g, const bool on_compute) { // communicate_fi, then communicate_gi (FX/lbm.cpp:1266-1284)
+	GROUP_TRY(group_exchange(g, false, on_compute));
+	if(g->thermal) GROUP_TRY(group_exchange(g, true, on_compute));
+	return LUW_OK;
+}
+static int group_join(luw_group* g) {
+	for(GroupDomain& d : g->dom) {
+		GROUP_TRY(group_set_device(d));
+		HIP_TRY(hipStreamSynchronize(d.comm)); HIP_TRY(hipStreamSynchronize(d.compute));
+	}
+	return LUW_OK;
+}
+
+static int group_run(luw_group* g, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, double* mean_kernel_ms) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_run: null group");
+	if(!g->initialized) GROUP_TRY(luw_group_initialize(g));
+	if(g->dom.size()==1u) { // undivided lattice: the single-domain path, no events
+		luw_solver* s = g->dom[0].s;
+		GROUP_TRY(luw_set_stream(s, nullptr));
+		int e = LUW_OK;
+		if(mean_kernel_ms) e = luw_run_timed(s, steps, mean_kernel_ms);
+		else if(stride) e = luw_run_sampled(s, steps, first_sample, stride);
+		else e = luw_run(s, steps);
+		g->t = luw_get_t(s);
+		return e;
+	}
+	const bool every = (g->gcfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
+	std::vector<hipEvent_t> tev; // timing of domain 0's interior / whole-box launch
+	struct TevFree { std::vector<hipEvent_t>& v; ~TevFree() { for(hipEvent_t e : v) (void)hipEventDestroy(e); } } tev_free{ tev };
+	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.resize(2u*steps); for(auto& e : tev) { e = nullptr; HIP_TRY(hipEventCreate(&e)); } }
+	for(uint64_t i=0ull; i<steps; i++) {
+		const bool sampled = stride>0ull && i+1ull>=first_sample && (i+1ull-first_sample)%stride==0ull;
+		bool fused = false;
+		if(sampled) { // every domain answers alike (same kernels everywhere)
+			for(GroupDomain& d : g->dom) { int f = 0; GROUP_TRY(luw_stats_begin_sample(d.s, &f)); fused = f!=0; }
+		}
+		const bool separate = sampled&&!fused;
+		const int wf = ((every||i+1ull==steps||separate) ? 1 : 0)|(fused ? LUW_WF_SAMPLE : 0);
+		for(size_t k=0; k<g->dom.size(); k++) {
+			GroupDomain& d = g->dom[k];
+			GROUP_TRY(group_set_device(d));
+			if(g->overlap) {
+				if((wf&1)&&d.stats_pending) { HIP_TRY(hipStreamWaitEvent(d.comm, d.stats_done, 0)); d.stats_pending = false; } // this step's shell rewrites the rho,u the last sample reads
+				HIP_TRY(hipStreamWaitEvent(d.compute, d.shell_done, 0));   // interior(t) needs shell(t-1) ...
+				HIP_TRY(hipStreamWaitEvent(d.comm, d.interior_done, 0));   // ... shell(t) needs interior(t-1); both no-ops before the first record
+				if(d.s->vk_active) { // pre_step_update (FX/setup.cpp:4872): rewrites u on TYPE_E inlet cells, read by shell and interior
+					GROUP_TRY(luw_set_stream(d.s, d.compute)); GROUP_TRY(luw_vk_inlet_apply(d.s));
+					HIP_TRY(hipEventRecord(d.pre_done, d.compute)); HIP_TRY(hipStreamWaitEvent(d.comm, d.pre_done, 0));
+				}
+				GROUP_TRY(luw_set_stream(d.s, d.comm));
+				for(const Box& b : d.shell) GROUP_TRY(luw_enqueue_stream_collide(d.s, b.x0, b.x1, b.y0, b.y1, b.z0, b.z1, wf)); // boundary shell first ...
+				HIP_TRY(hipEventRecord(d.shell_done, d.comm));
+				GROUP_TRY(luw_set_stream(d.s, d.compute));
+				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i], d.compute));
+				GROUP_TRY(luw_enqueue_stream_collide(d.s, d.interior.x0, d.interior.x1, d.interior.y0, d.interior.y1, d.interior.z0, d.interior.z1, wf)); // ... interior overlaps the halo traffic
+				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i+1u], d.compute));
+				HIP_TRY(hipEventRecord(d.interior_done, d.compute));
+			} else {
+				GROUP_TRY(luw_set_stream(d.s, d.compute));
+				if(d.s->vk_active) GROUP_TRY(luw_vk_inlet_apply(d.s));
+				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i], d.compute));
+				GROUP_TRY(luw_enqueue_stream_collide(d.s, d.whole.x0, d.whole.x1, d.whole.y0, d.whole.y1, d.whole.z0, d.whole.z1, wf));
+				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i+1u], d.compute));
+			}
+		}
+		GROUP_TRY(group_communicate(g, !g->overlap));
+		if(separate) { // thermal lattice / no fused statistics: the step wrote rho,u; the statistics kernel follows on the compute stream
+			for(GroupDomain& d : g->dom) {
+				GROUP_TRY(group_set_device(d));
+				if(g->overlap) HIP_TRY(hipStreamWaitEvent(d.compute, d.shell_done, 0));
+				GROUP_TRY(luw_set_stream(d.s, d.compute));
+				d.s->fields_current = true;
+				GROUP_TRY(luw_stats_accumulate(d.s));
+				HIP_TRY(hipEventRecord(d.stats_done, d.compute)); d.stats_pending = true;
+			}
+		}
+		for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull));
+		g->t++;
+	}
+	GROUP_TRY(group_join(g));
+	for(GroupDomain& d : g->dom) { d.stats_pending = false; if(steps>0ull) d.s->fields_current = true; }
+	if(mean_kernel_ms) {
+		double sum = 0.0;
+		for(uint64_t i=0ull; i<steps; i++) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, tev[2u*i], tev[2u*i+1u])); sum += (double)ms; }
+		*mean_kernel_ms = steps ? sum/(double)steps : 0.0;
+	}
+	return LUW_OK;
+}
+
+// host mirrors <-> one global array in the reference layout (n = x + (y + z*Ny)*Nx over the GLOBAL lattice, components SoA)
+struct GroupField { int comps; size_t elem; };
+static bool group_field_info(const int field, GroupField& f) {
+	switch(field) {
+		case LUW_FIELD_RHO: case LUW_FIELD_T: f = GroupField{ 1, 4u }; return true;
+		case LUW_FIELD_U: case LUW_FIELD_F: f = GroupField{ 3, 4u }; return true;
+		case LUW_FIELD_FLAGS: f = GroupField{ 1, 1u }; return true;
+		default: return false;
+	}
+}
+// rows of one domain handled by a pool of host threads (the copies are memory-bound: a few threads saturate a socket)
+template<typename Fn> static void group_parallel_rows(const uint64_t rows, Fn fn) {
+	const unsigned T = (unsigned)std::max<uint64_t>(1ull, std::min<uint64_t>(std::min<uint64_t>(16ull, std::thread::hardware_concurrency()), rows/64ull+1ull));
+	if(T<=1u) { for(uint64_t r=0ull; r<rows; r++) fn(r); return; }
+	std::vector<std::thread> th;
+	for(unsigned t=0u; t<T; t++) th.emplace_back([=]() { for(uint64_t r=rows*t/T; r<rows*(t+1ull)/T; r++) fn(r); });
+	for(auto& x : th) x.join();
+}
+
+extern "C" {
+
+int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out) {
+	if(!cfg||!out) return fail(LUW_ERR_INVALID, "luw_group_create: null argument");
+	*out = nullptr;
+	if(cfg->struct_size!=sizeof(luw_config)) return fail(LUW_ERR_INVALID, "luw_group_create: luw_config size mismatch (ABI)");
+	const uint32_t D[3] = { cfg->Dx, cfg->Dy, cfg->Dz }, gN[3] = { cfg->Nx, cfg->Ny, cfg->Nz };
+	if(D[0]*D[1]*D[2]==0u) return fail(LUW_ERR_INVALID, "You specified 0 LBM grid domains."); // FX/lbm.cpp:1124
+	if((uint64_t)gN[0]*gN[1]*gN[2]==0ull) return fail(LUW_ERR_INVALID, "Grid point number is 0."); // FX/lbm.cpp:1123
+	for(int a=0; a<3; a++) if(gN[a]%D[a]!=0u) return fail(LUW_ERR_INVALID, "LBM grid is not equally divisible in domains (the caller shrinks it to a multiple first, FX/lbm.cpp:1058-1060)");
+	const uint32_t n = D[0]*D[1]*D[2];
+	int ndev = 0;
+	HIP_TRY(hipGetDeviceCount(&ndev));
+	if(!devices&&(int)n+cfg->device>ndev&&n>1u) return fail(LUW_ERR_INVALID, "luw_group_create: fewer HIP devices than domains (pass an explicit device list to share devices)"); // FX/lbm.cpp:961-979
+	std::unique_ptr<luw_group, void(*)(luw_group*)> g(new luw_group(), group_free);
+	g->gcfg = *cfg;
+	for(int a=0; a<3; a++) { g->D[a] = D[a]; g->gN[a] = gN[a]; g->H[a] = D[a]>1u ? 1u : 0u; }
+	g->ddf_bytes = cfg->ddf_format==LUW_DDF_FP16C ? 2u : 4u;
+	g->thermal = (cfg->options&LUW_OPT_TEMPERATURE)!=0u;
+	g->dom.resize(n);
+	for(uint32_t i=0u; i<n; i++) { // FX/lbm.cpp:1066-1073
+		GroupDomain& d = g->dom[i];
+		d.device = devices ? devices[i] : (n>1u ? cfg->device+(int)i : cfg->device);
+		if(d.device<0||d.device>=ndev) return fail(LUW_ERR_INVALID, "luw_group_create: no such HIP device");
+		d.coord[0] = (i%(D[0]*D[1]))%D[0]; d.coord[1] = (i%(D[0]*D[1]))/D[0]; d.coord[2] = i/(D[0]*D[1]);
+		for(int a=0; a<3; a++) {
+			d.lN[a] = gN[a]/D[a]+2u*g->H[a];
+			d.O[a] = (int32_t)(d.coord[a]*(gN[a]/D[a]))-(int32_t)g->H[a];
+			uint32_t c[3] = { d.coord[0], d.coord[1], d.coord[2] };
+			c[a] = (d.coord[a]+1u)%D[a]; d.nbr[a][0] = c[0]+(c[1]+c[2]*D[1])*D[0];
+			c[a] = (d.coord[a]+D[a]-1u)%D[a]; d.nbr[a][1] = c[0]+(c[1]+c[2]*D[1])*D[0];
+		}
+	}
+	g->overlap = n>1u;
+	for(int a=0; a<3; a++) if(g->H[a]&&g->dom[0].lN[a]<6u) g->overlap = false; // DomainLayout.can_overlap
+	// peer access between the devices of neighbouring domains (xGMI): enables the direct remote stores of the pack kernels
+	g->peer.assign(n, std::vector<char>(n, 0));
+	for(uint32_t i=0u; i<n; i++) for(uint32_t j=0u; j<n; j++) {
+		const int di = g->dom[i].device, dj = g->dom[j].device;
+		if(di==dj) { g->peer[i][j] = 1; continue; }
+		int can = 0;
+		if(hipDeviceCanAccessPeer(&can, di, dj)==hipSuccess&&can) {
+			HIP_TRY(hipSetDevice(di));
+			const hipError_t e = hipDeviceEnablePeerAccess(dj, 0u);
+			if(e==hipSuccess||e==hipErrorPeerAccessAlreadyEnabled) g->peer[i][j] = 1;
+			(void)hipGetLastError();
+		}
+	}
+	if(getenv("LUW_GROUP_STAGED")) for(auto& row : g->peer) std::fill(row.begin(), row.end(), 0); // test aid: the copy path also where peer stores would do
+	// Streams and halo buffers BEFORE the lattices: every long-lived small allocation is in place before the large arrays and the
+	// placement search of luw_create run
+	for(uint32_t i=0u; i<n; i++) {
+		GroupDomain& d = g->dom[i];
+		HIP_TRY(hipSetDevice(d.device));
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
+		HIP_TRY(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking));
+		// shell, pack / unpack and copies on a high-priority queue: they are not to be stuck behind the interior kernel's workgroups
+		if(hipStreamCreateWithPriority(&d.comm, hipStreamNonBlocking, hi)!=hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipStreamCreateWithFlags(&d.comm, hipStreamNonBlocking)); }
+		for(hipEvent_t* e : { &d.shell_done, &d.interior_done, &d.pre_done, &d.stats_done }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+		for(int a=0; a<3; a++) {
+			for(hipEvent_t* e : { &d.packed[a], &d.unpacked[a], &d.gpacked[a], &d.gunpacked[a] }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+			if(!g->H[a]) continue;
+			const size_t A = (size_t)d.lN[(a+1)%3]*d.lN[(a+2)%3];
+			const bool staged = !(g->peer[i][d.nbr[a][0]]&&g->peer[i][d.nbr[a][1]]);
+			for(int k=0; k<2; k++) {
+				if(hipMalloc(&d.recv[a][k], 5u*A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+				HIP_TRY(hipMemset(d.recv[a][k], 0, 5u*A*g->ddf_bytes));
+				if(staged&&hipMalloc(&d.send[a][k], 5u*A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+				if(g->thermal) {
+					if(hipMalloc(&d.grecv[a][k], A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+					HIP_TRY(hipMemset(d.grecv[a][k], 0, A*g->ddf_bytes));
+					if(staged&&hipMalloc(&d.gsend[a][k], A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+				}
+			}
+		}
+	}
+	for(uint32_t i=0u; i<n; i++) {
+		GroupDomain& d = g->dom[i];
+		luw_config c = *cfg;
+		c.Nx = d.lN[0]; c.Ny = d.lN[1]; c.Nz = d.lN[2];
+		c.Ox = d.O[0]; c.Oy = d.O[1]; c.Oz = d.O[2];
+		c.device = d.device;
+		GROUP_TRY(luw_create(&c, &d.s));
+		group_boxes(g.get(), d);
+	}
+	*out = g.release();
+	return LUW_OK;
+}
+void luw_group_destroy(luw_group* g) { group_free(g); }
+uint32_t luw_group_size(const luw_group* g) { return g ? (uint32_t)g->dom.size() : 0u; }
+luw_solver* luw_group_domain(luw_group* g, uint32_t d) { return (g&&d<g->dom.size()) ? g->dom[d].s : nullptr; }
+uint64_t luw_group_get_t(const luw_group* g) { return g ? g->t : 0ull; }
+int luw_group_overlaps(const luw_group* g) { return (g&&g->overlap) ? 1 : 0; }
+int luw_group_direct_peer_stores(const luw_group* g) {
+	if(!g) return 0;
+	for(size_t i=0; i<g->dom.size(); i++) for(int a=0; a<3; a++) if(g->H[a]&&!(g->peer[i][g->dom[i].nbr[a][0]]&&g->peer[i][g->dom[i].nbr[a][1]])) return 0;
+	return 1;
+}
+int luw_group_domain_info(const luw_group* g, uint32_t d, uint32_t* local_N, int32_t* offset, int* device) {
+	if(!g||d>=g->dom.size()) return fail(LUW_ERR_INVALID, "luw_group_domain_info: bad argument");
+	for(int a=0; a<3; a++) { if(local_N) local_N[a] = g->dom[d].lN[a]; if(offset) offset[a] = g->dom[d].O[a]; }
+	if(device) *device = g->dom[d].device;
+	return LUW_OK;
+}
+
+int luw_group_set_f(luw_group* g, float fx, float fy, float fz) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_set_f: null group");
+	for(GroupDomain& d : g->dom) GROUP_TRY(luw_set_f(d.s, fx, fy, fz));
+	return LUW_OK;
+}
+int luw_group_set_coriolis(luw_group* g, float ox, float oy, float oz) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_set_coriolis: null group");
+	for(GroupDomain& d : g->dom) GROUP_TRY(luw_set_coriolis(d.s, ox, oy, oz));
+	return LUW_OK;
+}
+
+// Memory_Container's global index space over the domains' host mirrors (FX/lbm.hpp:274-297): scatter fills every domain's
+// mirror INCLUDING its halo layers (periodic wrap, what communicate_rho_u_flags leaves there at initialisation,
+// FX/lbm.cpp:1243-1256); gather reads the owned cells back.
+int luw_group_scatter(luw_group* g, int field, const void* global_src) {
+	GroupField f;
+	if(!g||!global_src||!group_field_info(field, f)) return fail(LUW_ERR_INVALID, "luw_group_scatter: bad argument");
+	const uint64_t GN = (uint64_t)g->gN[0]*g->gN[1]*g->gN[2];
+	for(GroupDomain& d : g->dom) {
+		char* dst = (char*)luw_host_ptr(d.s, field);
+		if(!dst) return fail(LUW_ERR_STATE, "luw_group_scatter: the solver has no such field");
+		const uint64_t LN = (uint64_t)d.lN[0]*d.lN[1]*d.lN[2];
+		const uint32_t gNx = g->gN[0], gNy = g->gN[1], gNz = g->gN[2];
+		for(int c=0; c<f.comps; c++) {
+			const char* src = (const char*)global_src+(size_t)c*GN*f.elem;
+			char* out = dst+(size_t)c*LN*f.elem;
+			const GroupDomain* dp = &d; const size_t elem = f.elem;
+			group_parallel_rows((uint64_t)d.lN[1]*d.lN[2], [=](const uint64_t r) {
+				const uint32_t y = (uint32_t)(r%dp->lN[1]), z = (uint32_t)(r/dp->lN[1]);
+				const uint32_t gy = (uint32_t)(((int64_t)y+dp->O[1]+(int64_t)gNy)%gNy), gz = (uint32_t)(((int64_t)z+dp->O[2]+(int64_t)gNz)%gNz);
+				const char* srow = src+((size_t)gy+(size_t)gz*gNy)*gNx*elem;
+				char* drow = out+(size_t)r*dp->lN[0]*elem;
+				if(dp->O[0]==0&&dp->lN[0]==gNx) { memcpy(drow, srow, (size_t)gNx*elem); return; }
+				for(uint32_t x=0u; x<dp->lN[0]; x++) { const uint32_t gx = (uint32_t)(((int64_t)x+dp->O[0]+(int64_t)gNx)%gNx); memcpy(drow+(size_t)x*elem, srow+(size_t)gx*elem, elem); }
+			});
+		}
+	}
+	return LUW_OK;
+}
+static int group_gather_from(luw_group* g, const GroupField f, void* global_dst, const std::function<const char*(GroupDomain&)>& source) {
+	const uint64_t GN = (uint64_t)g->gN[0]*g->gN[1]*g->gN[2];
+	for(GroupDomain& d : g->dom) {
+		const char* srcb = source(d);
+		if(!srcb) return fail(LUW_ERR_STATE, "luw_group_gather: the solver has no such field");
+		const uint64_t LN = (uint64_t)d.lN[0]*d.lN[1]*d.lN[2];
+		const uint32_t gNx = g->gN[0], gNy = g->gN[1];
+		const uint32_t H0 = g->H[0], H1 = g->H[1], H2 = g->H[2];
+		const uint32_t ox = d.lN[0]-2u*H0, oy = d.lN[1]-2u*H1, oz = d.lN[2]-2u*H2; // owned extents
+		for(int c=0; c<f.comps; c++) {
+			const char* src = srcb+(size_t)c*LN*f.elem;
+			char* out = (char*)global_dst+(size_t)c*GN*f.elem;
+			const GroupDomain* dp = &d; const size_t elem = f.elem;
+			group_parallel_rows((uint64_t)oy*oz, [=](const uint64_t r) {
+				const uint32_t y = (uint32_t)(r%oy)+H1, z = (uint32_t)(r/oy)+H2;
+				const uint32_t gy = (uint32_t)((int32_t)y+dp->O[1]), gz = (uint32_t)((int32_t)z+dp->O[2]), gx0 = (uint32_t)((int32_t)H0+dp->O[0]);
+				memcpy(out+(((size_t)gy+(size_t)gz*gNy)*gNx+gx0)*elem, src+(((size_t)y+(size_t)z*dp->lN[1])*dp->lN[0]+H0)*elem, (size_t)ox*elem);
+			});
+		}
+	}
+	return LUW_OK;
+}
+int luw_group_gather(luw_group* g, int field, void* global_dst) {
+	GroupField f;
+	if(!g||!global_dst||!group_field_info(field, f)) return fail(LUW_ERR_INVALID, "luw_group_gather: bad argument");
+	return group_gather_from(g, f, global_dst, [field](GroupDomain& d) { return (const char*)luw_host_ptr(d.s, field); });
+}
+int luw_group_upload(luw_group* g, uint32_t mask) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_upload: null group");
+	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_upload(d.s, mask)); }
+	return LUW_OK;
+}
+int luw_group_download(luw_group* g, uint32_t mask) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_download: null group");
+	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_download(d.s, mask)); }
+	return LUW_OK;
+}
+
+int luw_group_initialize(luw_group* g) { // LBM::initialize, FX/lbm.cpp:1221-1260
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_initialize: null group");
+	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_initialize(d.s)); }
+	if(g->dom.size()>1u) {
+		for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull)); // "the communicate calls at initialization need an odd time step", FX/lbm.cpp:1242
+		GROUP_TRY(group_communicate(g, false));
+		GROUP_TRY(group_join(g));
+		for(GroupDomain& d : g->dom) GROUP_TRY(luw_reset_time_step(d.s)); // FX/lbm.cpp:1258
+	}
+	g->t = 0ull; g->initialized = true;
+	return LUW_OK;
+}
+int luw_group_run(luw_group* g, uint64_t steps) { return group_run(g, steps, 0ull, 0ull, nullptr); }
+int luw_group_run_sampled(luw_group* g, uint64_t steps, uint64_t first_sample, uint64_t stride) {
+	if(first_sample==0ull||stride==0ull) return fail(LUW_ERR_INVALID, "luw_group_run_sampled: first_sample and stride count from 1");
+	return group_run(g, steps, first_sample, stride, nullptr);
+}
+int luw_group_run_timed(luw_group* g, uint64_t steps, double* mean_kernel_ms) {
+	if(!mean_kernel_ms) return fail(LUW_ERR_INVALID, "luw_group_run_timed: null output");
+	return group_run(g, steps, 0ull, 0ull, mean_kernel_ms);
+}
+
+int luw_group_voxelize_mesh(luw_group* g, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_voxelize_mesh: null group");
+	// every domain voxelises its own box (halos included) against the triangles binned to its tiles: FX/lbm.cpp:1455-1587
+	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_voxelize_mesh(d.s, triangle_number, p0, p1, p2, bounds, flag)); }
+	return LUW_OK;
+}
+
+// global cell index -> (owning domain, local reference-layout index); cells are owned by exactly one domain (halos belong to the neighbour)
+static void group_locate(const luw_group* g, const uint64_t n, uint32_t& dom, uint64_t& local) {
+	const uint64_t A = (uint64_t)g->gN[0]*g->gN[1];
+	const uint32_t z = (uint32_t)(n/A), y = (uint32_t)((n%A)/g->gN[0]), x = (uint32_t)(n%g->gN[0]);
+	const uint32_t b[3] = { g->gN[0]/g->D[0], g->gN[1]/g->D[1], g->gN[2]/g->D[2] };
+	const uint32_t c[3] = { x/b[0], y/b[1], z/b[2] };
+	dom = c[0]+(c[1]+c[2]*g->D[1])*g->D[0];
+	const GroupDomain& d = g->dom[dom];
+	const uint32_t lx = (uint32_t)((int32_t)x-d.O[0]), ly = (uint32_t)((int32_t)y-d.O[1]), lz = (uint32_t)((int32_t)z-d.O[2]);
+	local = (uint64_t)lx+((uint64_t)ly+(uint64_t)lz*d.lN[1])*d.lN[0];
+}
+int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, int update_stride, int stride_interpolation) {
+	if(!g||!point_cell||!point_face||!point_data||!mode_data) return fail(LUW_ERR_INVALID, "luw_group_vk_inlet_attach: null argument");
+	const uint64_t GN = (uint64_t)g->gN[0]*g->gN[1]*g->gN[2];
+	const size_t n = g->dom.size();
+	std::vector<std::vector<uint64_t>> cell(n), src(n);
+	for(uint64_t i=0ull; i<point_count; i++) {
+		if(point_cell[i]>=GN) return fail(LUW_ERR_INVALID, "luw_group_vk_inlet_attach: point cell outside the lattice");
+		uint32_t dm; uint64_t local; group_locate(g, point_cell[i], dm, local);
+		cell[dm].push_back(local); src[dm].push_back(i);
+	}
+	for(size_t k=0; k<n; k++) { // each domain gets the points it owns; the mode table is shared
+		GroupDomain& d = g->dom[k];
+		if(cell[k].empty()) { GROUP_TRY(luw_vk_inlet_detach(d.s)); continue; }
+		const size_t P = cell[k].size();
+		std::vector<uint8_t> face(P); std::vector<float> data(7u*P);
+		for(size_t i=0; i<P; i++) { face[i] = point_face[src[k][i]]; for(int c=0; c<7; c++) data[(size_t)c*P+i] = point_data[(size_t)c*point_count+src[k][i]]; }
+		GROUP_TRY(luw_vk_inlet_attach(d.s, P, mode_count, cell[k].data(), face.data(), data.data(), mode_data, update_stride, stride_interpolation));
+	}
+	return LUW_OK;
+}
+
+int luw_group_gather_attach(luw_group* g, uint32_t count, const uint64_t* cells) {
+	if(!g||(count>0u&&!cells)) return fail(LUW_ERR_INVALID, "luw_group_gather_attach: bad argument");
+	const uint64_t GN = (uint64_t)g->gN[0]*g->gN[1]*g->gN[2];
+	std::vector<std::vector<uint64_t>> local(g->dom.size());
+	for(GroupDomain& d : g->dom) d.gather_src.clear();
+	for(uint32_t i=0u; i<count; i++) {
+		if(cells[i]>=GN) return fail(LUW_ERR_INVALID, "luw_group_gather_attach: cell index outside the lattice");
+		uint32_t dm; uint64_t l; group_locate(g, cells[i], dm, l);
+		local[dm].push_back(l); g->dom[dm].gather_src.push_back(i);
+	}
+	for(size_t k=0; k<g->dom.size(); k++) GROUP_TRY(luw_gather_attach(g->dom[k].s, (uint32_t)local[k].size(), local[k].data()));
+	g->gather_total = count;
+	return LUW_OK;
+}
+int luw_group_gather_u(luw_group* g, float* out) {
+	if(!g||!out) return fail(LUW_ERR_INVALID, "luw_group_gather_u: bad argument");
+	std::vector<float> tmp;
+	for(GroupDomain& d : g->dom) {
+		if(d.gather_src.empty()) continue;
+		tmp.resize(3u*d.gather_src.size());
+		GROUP_TRY(luw_set_stream(d.s, nullptr));
+		GROUP_TRY(luw_gather_u(d.s, tmp.data()));
+		for(size_t i=0; i<d.gather_src.size(); i++) for(int c=0; c<3; c++) out[3u*d.gather_src[i]+c] = tmp[3u*i+c];
+	}
+	return LUW_OK;
+}
+
+int luw_group_stats_reset(luw_group* g) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_stats_reset: null group");
+	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_stats_reset(d.s)); }
+	return LUW_OK;
+}
+// global arrays in the layout write_avg_vtk consumes: avg_u AoS [3n+c], the others [n]; any pointer may be NULL
+int luw_group_stats_download(luw_group* g, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, float* avg_T, uint64_t* count) {
+	if(!g) return fail(LUW_ERR_INVALID, "luw_group_stats_download: null group");
+	const uint32_t gNx = g->gN[0], gNy = g->gN[1];
+	for(GroupDomain& d : g->dom) {
+		GROUP_TRY(luw_set_stream(d.s, nullptr));
+		const uint64_t LN = (uint64_t)d.lN[0]*d.lN[1]*d.lN[2];
+		std::unique_ptr<float[]> buf(new float[8ull*LN]); // avg_u (3, AoS), avg_rho, m2 x3, avg_T of THIS domain: bounded by its block
+		float* lu = buf.get(); float* lr = lu+3ull*LN; float* l2[3] = { lr+LN, lr+2ull*LN, lr+3ull*LN }; float* lT = lr+4ull*LN;
+		uint64_t cnt = 0ull;
+		GROUP_TRY(luw_stats_download(d.s, avg_u ? lu : nullptr, avg_rho ? lr : nullptr, m2_u ? l2[0] : nullptr, m2_v ? l2[1] : nullptr, m2_w ? l2[2] : nullptr, &cnt));
+		if(avg_T) GROUP_TRY(luw_stats_download_T(d.s, lT));
+		if(count) *count = cnt;
+		const uint32_t H0 = g->H[0], H1 = g->H[1], H2 = g->H[2];
+		const uint32_t ox = d.lN[0]-2u*H0, oy = d.lN[1]-2u*H1, oz = d.lN[2]-2u*H2;
+		const GroupDomain* dp = &d;
+		float* outs[5] = { avg_rho, m2_u, m2_v, m2_w, avg_T }; const float* ins[5] = { lr, l2[0], l2[1], l2[2], lT };
+		group_parallel_rows((uint64_t)oy*oz, [=](const uint64_t r) {
+			const uint32_t y = (uint32_t)(r%oy)+H1, z = (uint32_t)(r/oy)+H2;
+			const size_t grow = (((size_t)((int32_t)y+dp->O[1]))+(size_t)((int32_t)z+dp->O[2])*gNy)*gNx+(size_t)((int32_t)H0+dp->O[0]);
+			const size_t lrow = ((size_t)y+(size_t)z*dp->lN[1])*dp->lN[0]+H0;
+			if(avg_u) memcpy(avg_u+3u*grow, lu+3u*lrow, (size_t)ox*12u);
+			for(int k=0; k<5; k++) if(outs[k]) memcpy(outs[k]+grow, ins[k]+lrow, (size_t)ox*4u);
+		});
+	}
+	return LUW_OK;
+}
+
+} // extern "C"

@@ -12,8 +12,11 @@
 // Not in this build (announced on the console, never silently): PNG frames.
 // Differences by design: time averaging runs on the device (luw_stats_*); --dry-run voxelises on the host; the von-Karman
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
+// Decks with n_gpu = [Dx, Dy, Dz] run all Dx*Dy*Dz domains in THIS process, one HIP device each (like the reference's LBM object;
+// halos between the devices inside the library, luw_group_*).
 // Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build),
-//   --device N, --dry-run (host stage only, no GPU), --sizing-only (stop after grid / unit / buffer / sponge numbers),
+//   --device N (first device; domain d runs on N + d), --devices a,b,.. (explicit device per domain), --kernel auto|scalar|pair,
+//   --dry-run (host stage only, no GPU), --sizing-only (stop after grid / unit / buffer / sponge numbers),
 //   --dump-setup FILE (raw initial state of the first case).
 #include <algorithm>
 #include <atomic>
@@ -37,6 +40,7 @@
 #include "vk_inlet.hpp"
 #include "bc_builders.hpp"
 #include "probes.hpp"
+#include "progress.hpp"
 
 using namespace luw_host;
 using std::string;
@@ -45,6 +49,10 @@ using std::string;
 static std::ofstream g_log;
 static void println(const string& s = "") { std::cout << s << "\n"; std::cout.flush(); if(g_log.is_open()) { g_log << s << "\n"; g_log.flush(); } }
 static const uint CONSOLE_WIDTH = 94u; // FX/utilities.hpp:9
+// GUI protocol lines go to stdout only, never into the log (FX/utilities.hpp:3161-3178)
+static const ProgressChannel g_progress([](const string& line) { std::cout << line << "\n"; std::cout.flush(); });
+// the running row overwrites itself on the console (reprint, FX/info.cpp:273) and is not logged until it is final
+static void reprint_row(const string& s) { std::cout << "\r" << s; std::cout.flush(); }
 // LUW_DRIVER_TIMING=1: wall time of each phase of the run on stderr (profiling aid; console and log stay as the reference's)
 static void phase_mark(const char* name) {
 	static const bool on = [] { const char* e = std::getenv("LUW_DRIVER_TIMING"); return e&&e[0]=='1'; }();
@@ -215,7 +223,8 @@ struct Config {
 	string probes_raw, utm_crs; bool probes_output_defined = false; uint probes_output_steps = 0u; bool has_rotate_deg = false; double rotate_deg = 0.0;
 	bool buoyancy = true, buoyancy_explicit = false; // default-on unless explicitly false (FX/setup.cpp:2743)
 	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
-	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk, export_setup;
+	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
+	std::vector<int> devices; uint32_t kernel = LUW_KERNEL_AUTO;
 };
 
 // memory model of the SHIPPED reference build (D3Q19 FP16C + FORCE_FIELD + TEMPERATURE + GRAPHICS), FX/lbm.cpp:188-228:
@@ -429,7 +438,8 @@ int main(int argc, char** argv) {
 		else if(a=="--sizing-only") { c.dry_run = true; c.sizing_only = true; } // stop after the derived numbers (no lattice-sized host arrays)
 		else if(a=="--dump-setup"&&i+1<argc) c.dump_setup = argv[++i];
 		else if(a=="--dump-vk"&&i+1<argc) c.dump_vk = argv[++i];
-		else if(a=="--export-setup"&&i+1<argc) c.export_setup = argv[++i]; // host stage only (voxelised on the GPU unless --dry-run), state + manifest per case for run_deck.py
+		else if(a=="--devices"&&i+1<argc) { std::stringstream ss(argv[++i]); string tok; while(std::getline(ss, tok, ',')) if(!tok.empty()) c.devices.push_back(std::atoi(tok.c_str())); } // HIP device per domain (several domains may share one)
+		else if(a=="--kernel"&&i+1<argc) { const string v = argv[++i]; c.kernel = v=="scalar" ? LUW_KERNEL_SCALAR : v=="pair" ? LUW_KERNEL_PAIR : LUW_KERNEL_AUTO; }
 		else println("| WARNING: extra CLI arg ignored: "+a);
 	}
 	println(hr_plain());
@@ -554,7 +564,6 @@ int main(int argc, char** argv) {
 		string v = c.validation; std::transform(v.begin(), v.end(), v.begin(), ::tolower);
 		if(v!="pass"&&v!="true"&&v!="1") { println("|-----------------------------------------------------------------------------|"); println("| WARNING: Validation status is '"+c.validation+"'. Pre-processing may be incomplete or invalid. |"); println("| Proceeding (non-interactive).                                               |"); }
 	}
-	if(c.Dx*c.Dy*c.Dz>1u&&c.export_setup.empty()&&!c.dry_run) println("| NOTE: n_gpu>1: this executable drives one GPU; launch `python -m torch.distributed.run --nproc-per-node "+to_string_u(c.Dx*c.Dy*c.Dz)+" -m latticeurbanwind_amd.run_deck <deck>` for the decomposed run (same host stage, one process per GPU, RCCL halos). |");
 
 	println("|"+string(CONSOLE_WIDTH-2u, ' ')+"|");
 	print_section_title("PARAMETER INFORMATION");
@@ -649,7 +658,7 @@ int main(int argc, char** argv) {
 		omega[0] = 0.0f*dt_si; omega[1] = Om*cosf(lat_rad)*dt_si; omega[2] = Om*sinf(lat_rad)*dt_si;
 	};
 	SolverGlobals& G = solver_globals();
-	G.fp16c = c.fp16c; G.device = c.device;
+	G.fp16c = c.fp16c; G.device = c.device; G.devices = c.devices; G.kernel = c.kernel;
 	auto buffer_face_id_from_bc = [](const string& bc) { return bc=="-x" ? 1 : bc=="+x" ? 2 : bc=="-y" ? 3 : bc=="+y" ? 4 : 0; };
 	auto bc_from_dir = [](const float dx, const float dy) -> string { if(fabsf(dx)>=fabsf(dy)) return dx>=0.0f ? "+x" : "-x"; return dy>=0.0f ? "+y" : "-y"; };
 	auto update_buffer_nudging = [&](const string& bc) { // FX/setup.cpp:3844-3856
@@ -728,6 +737,8 @@ int main(int argc, char** argv) {
 	Mesh mesh;
 	if(!read_stl(stl_path, mesh)) fatal("ERROR: failed to load STL");
 	println("| Info: Loading \""+stl_path+"\" with "+to_string_u(mesh.n)+" triangles.");
+	g_progress.emit("load_stl", "Loading STL", stl_path+" ("+to_string_u(mesh.n)+" triangles)", 0ll, 1ll, false); // FX/utilities.hpp:4850-4887
+	g_progress.emit("load_stl", "Loading STL", stl_path+" loaded", 1ll, 1ll, false);
 	const float stl_min[3] = {mesh.pmin[0], mesh.pmin[1], mesh.pmin[2]}, stl_max[3] = {mesh.pmax[0], mesh.pmax[1], mesh.pmax[2]};
 	float vtk_origin_shift[3];
 	{ const uint NN[3] = {Nx, Ny, Nz}; for(int k=0; k<3; k++) vtk_origin_shift[k] = stl_min[k]-units.si_x(0.5f-0.5f*(float)NN[k]); }
@@ -807,7 +818,6 @@ int main(int argc, char** argv) {
 		if(idx<0l) idx = 0l;
 		return prof_lbmu[std::min((uint)idx, last)];
 	};
-	auto pos_z_of = [&](const uint z) { return (float)z-0.5f*(float)Nz+0.5f; };
 
 	// ---- cases
 	struct Case { float inflow_si, angle_deg; };
@@ -815,10 +825,15 @@ int main(int argc, char** argv) {
 	if(c.nwp_mode) cases.push_back({0.0f, 0.0f});
 	else if(c.dataset_mode) { for(const float in : c.inflow_list) for(const float an : c.angle_list) cases.push_back({in, an}); }
 	else for(const float an : c.angle_list) cases.push_back({0.0f, an});
-	const ulong N = (ulong)Nx*Ny*Nz;
+	// LBM::LBM makes the resolution equally divisible by the domains (FX/lbm.cpp:1058-1060): everything up to here used lbm_N
+	// (units, profile table, mesh transform, buffer / sponge sizes), everything inside a case uses the lattice of the LBM object
+	const uint lbmN[3] = {Nx, Ny, Nz};
 	uint case_index = 0u;
 	for(const Case& cs : cases) {
 		++case_index;
+		const uint Nx = (lbmN[0]/c.Dx)*c.Dx, Ny = (lbmN[1]/c.Dy)*c.Dy, Nz = (lbmN[2]/c.Dz)*c.Dz;
+		const ulong N = (ulong)Nx*Ny*Nz;
+		auto pos_z_of = [&](const uint z) { return (float)z-0.5f*(float)Nz+0.5f; }; // lbm.position(x, y, z).z
 		const float deg2rad = 3.14159265358979323846f/180.0f, angle_rad = cs.angle_deg*deg2rad;
 		float dir_x = -sinf(angle_rad), dir_y = -cosf(angle_rad);
 		float uin[3] = {0.0f, 0.0f, 0.0f};
@@ -849,21 +864,36 @@ int main(int argc, char** argv) {
 		update_buffer_nudging(case_bc); update_top_sponge();
 
 		phase_mark("deck, sizing, mesh, profile");
-		// host state of this case
-		std::vector<uchar> flags(N, 0u); std::vector<float> u(3ull*N, 0.0f);
-		std::vector<float> Tcell; if(use_temperature_bc) Tcell.assign(N, 1.0f); // lbm.T, FX/lbm.cpp:304
+		// host state of this case: the LBM object's global host arrays (lbm.flags[n], lbm.u.x[n], lbm.T[n]) or, without a GPU, plain vectors
+		G.temperature = use_temperature_bc; // the thermal lattice runs exactly when the reference writes T outputs
+		std::vector<uchar> flags_store; std::vector<float> u_store, T_store;
 		std::unique_ptr<LBM> lbm_p;
 		ulong nvox = 0ull;
-		if(c.dry_run) nvox = voxelize_z(mesh, Nx, Ny, Nz, flags); // no GPU: host restatement of the kernel
-		else if(!c.export_setup.empty()) { // decomposed run: no solver object for the global lattice, voxelise it bare
-			const float bounds[6] = {mesh.pmin[0], mesh.pmin[1], mesh.pmin[2], mesh.pmax[0], mesh.pmax[1], mesh.pmax[2]};
-			luw_check(luw_voxelize_lattice(c.device, Nx, Ny, Nz, mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), bounds, TYPE_S, flags.data()));
-			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
+		if(c.dry_run) { flags_store.assign(N, 0u); u_store.assign(3ull*N, 0.0f); if(use_temperature_bc) T_store.assign(N, 1.0f); }
+		else {
+			const uint Dn = c.Dx*c.Dy*c.Dz; // LBM_Domain's constructor reports per device (FX/lbm.cpp:265-280); here all domains are built in one call
+			g_progress.emit("gpu_memory", "Configuring GPU memory", "Allocating CFD buffers on "+to_string_u(Dn)+" device(s)", 0ll, (long long)Dn, false);
+			lbm_p.reset(new LBM(uint3(lbmN[0], lbmN[1], lbmN[2]), c.Dx, c.Dy, c.Dz, lbm_nu, 0.0f, 0.0f, 0.0f, 0.0f, lbm_alpha, 0.0f)); // FX/setup.cpp:4935,5720,6018
+			g_progress.emit("gpu_memory", "Configuring GPU memory", to_string_u(Dn)+" device(s): buffers ready", (long long)Dn, (long long)Dn, false);
 		}
-		else { // lbm.voxelize_mesh_on_device(mesh), FX/setup.cpp:4089
-			lbm_p.reset(new LBM(Nx, Ny, Nz, lbm_nu, 0.0f, 0.0f, 0.0f, false, use_temperature_bc ? lbm_alpha : -1.0f));
+		if(lbm_p&&lbm_p->get_D()>1u) {
+			string devs; for(uint d=0u; d<lbm_p->get_D(); d++) { int dv = 0; luw_check(luw_group_domain_info(lbm_p->group(), d, nullptr, nullptr, &dv)); devs += (d ? "," : "")+to_string_u((ulong)dv); }
+			print_kv_row("Domains", to_string_u(lbm_p->get_D())+" domains ("+to_string_u(c.Dx)+"x"+to_string_u(c.Dy)+"x"+to_string_u(c.Dz)+") of "+to_string_u(Nx/c.Dx)+"x"+to_string_u(Ny/c.Dy)+"x"+to_string_u(Nz/c.Dz)+" cells on HIP devices "+devs);
+			print_kv_row("", string("halo faces: ")+(luw_group_direct_peer_stores(lbm_p->group()) ? "peer stores of the pack kernels (xGMI)" : "hipMemcpyPeerAsync")+(luw_group_overlaps(lbm_p->group()) ? ", overlapped with the interior" : ", after the whole-box kernel"));
+			// like the reference, nudging / sponge act only inside domains that own the face (FX/kernel.cpp:1537-1541,1598): say so when a zone is cut
+			const uint bz = G.buffer_nudging_active ? (uint)G.buffer_n_cells : 0u, sz = G.top_sponge_active ? (uint)G.sponge_n_cells : 0u;
+			if((c.Dz>1u&&std::max(bz, sz)+1u>Nz/c.Dz)||(c.Dy>1u&&bz+1u>Ny/c.Dy)||(c.Dx>1u&&bz+1u>Nx/c.Dx))
+				println("| WARNING: a nudging / sponge zone is thicker than a domain: cells of the zone in domains that do not own the face get no forcing (as in the reference). |");
+		}
+		uchar* const flags = c.dry_run ? flags_store.data() : lbm_p->flags.data<uchar>();
+		float* const u = c.dry_run ? u_store.data() : lbm_p->u.data<float>();
+		float* const Tcell = !use_temperature_bc ? nullptr : c.dry_run ? T_store.data() : lbm_p->T.data<float>(); // lbm.T, pre-filled with 1 (FX/lbm.cpp:304)
+		if(c.dry_run) nvox = voxelize_z(mesh, Nx, Ny, Nz, flags_store); // no GPU: host restatement of the kernel
+		else { // lbm.voxelize_mesh_on_device(mesh), FX/setup.cpp:4089: every domain voxelises its own box
+			const long long Dn = (long long)lbm_p->get_D(); // FX/lbm.cpp:1413-1418,1593-1598
+			g_progress.emit("voxelization", "Voxelizing geometry", to_string_u(mesh.n)+" triangles across "+to_string_u((ulong)Dn)+" domain(s)", 0ll, Dn, false);
 			lbm_p->voxelize_mesh_on_device(mesh.n, mesh.p0.data(), mesh.p1.data(), mesh.p2.data(), mesh.pmin, mesh.pmax, TYPE_S);
-			std::memcpy(flags.data(), lbm_p->flags.host, N);
+			g_progress.emit("voxelization", "Voxelizing geometry", "Finished domain "+to_string_u((ulong)Dn)+"/"+to_string_u((ulong)Dn), Dn, Dn, false);
 			for(ulong n=0ull; n<N; n++) nvox += (flags[n]&TYPE_S)!=0u;
 		}
 		phase_mark("solver create + voxelise");
@@ -874,12 +904,14 @@ int main(int argc, char** argv) {
 		std::atomic<ulong> mapped{0ull}, terrain_solid{0ull}, outlet{0ull};
 		std::vector<float> ground_xy; // terrain height per column (profile mode with a DEM), else flat
 		auto ground_at = [&](const ulong id) { return ground_xy.empty() ? flat_ground : ground_xy[id]; };
-		HostLattice HL; HL.Nx = Nx; HL.Ny = Ny; HL.Nz = Nz; HL.flags = flags.data(); HL.u = u.data();
+		HostLattice HL; HL.Nx = Nx; HL.Ny = Ny; HL.Nz = Nz; HL.flags = flags; HL.u = u;
 		auto report_flux = [&](const FluxReport& fr) { // FX/fluxcorrection.cpp:180-192
+			g_progress.emit("flux_correction", "Flux correction", "avg dU = "+to_string_dd(fr.delta, 3u)+" m/s, net after = "+to_string_dd(fr.net_after, 3u), 1ll, 1ll, false);
 			println("| Flux correction | S_in="+to_string_dd(fr.S_in, 3u)+", S_out="+to_string_dd(fr.S_out, 3u)+", net_before="+to_string_dd(fr.net_before, 3u)+" |");
 			println("| Flux correction | avg_dU="+to_string_dd(fr.delta, 3u)+" m/s, corrected="+to_string_u(fr.corrected)+", net_after="+to_string_dd(fr.net_after, 3u)+" |");
 			println("| Flux correction | per-face dU: Xn="+to_string_dd(fr.face_avg[0], 3u)+", Xp="+to_string_dd(fr.face_avg[1], 3u)+", Yn="+to_string_dd(fr.face_avg[2], 3u)+", Yp="+to_string_dd(fr.face_avg[3], 3u)+", Zp="+to_string_dd(fr.face_avg[4], 3u)+" m/s |");
 		};
+		g_progress.emit("interface_interpolation", "Interface interpolation", c.nwp_mode ? (surf.has_patch ? "Patch-driven 2D boundary mapping" : c.use_high_order ? "High-order boundary interpolation" : "Nearest-sample boundary interpolation") : c.profile_mode ? "Applying profile boundary conditions" : "Applying uniform inflow boundary conditions", 0ll, 1ll, true);
 		if(c.nwp_mode) { // FX/setup.cpp:4931-5632
 			const V3 org = HL.position(0u, 0u, 0u);
 			std::vector<SurfSample> smp; smp.reserve(surf.rows.size()); // SI -> lattice units (:3963-3979), then shifted to cell-centre coordinates (:4940-4946)
@@ -939,7 +971,7 @@ int main(int argc, char** argv) {
 				downstream_fill = [inlet, HL](const uint x, const uint y, const uint z) -> V3 { return inlet(HL.position(x, y, z)); };
 			}
 			auto temperature_summary = [&](const string& tag) { // FX/setup.cpp:5075-5117
-				const TemperatureSummary ts = summarize_temperature(HL, Tcell.data());
+				const TemperatureSummary ts = summarize_temperature(HL, Tcell);
 				println("| Temperature BC  | summary ["+tag+"]: TYPE_T total="+to_string_u(ts.total)+", solid="+to_string_u(ts.solid)+", fluid="+to_string_u(ts.fluid)+"            |");
 				if(ts.solid>0ull) println("| Temperature BC  | solid TYPE_T range SI: "+fmtf(units.si_T(ts.smin))+" .. "+fmtf(units.si_T(ts.smax))+" K                      |");
 				if(ts.fluid>0ull) println("| Temperature BC  | fluid TYPE_T range SI: "+fmtf(units.si_T(ts.fmin))+" .. "+fmtf(units.si_T(ts.fmax))+" K                      |");
@@ -960,7 +992,7 @@ int main(int argc, char** argv) {
 						if(cntp>0ull) println("| T patch         | "+string(patch_name(pt))+": n="+to_string_u(cntp)+", SI "+fmtf(units.si_T(mn))+" .. "+fmtf(units.si_T(mx))+" K                    |");
 						else println("| T patch         | "+string(patch_name(pt))+": n=0                                           |");
 					}
-					apply_patch_temperature(HL, Tcell.data(), tfields, case_bc, c.downstream_open_face, T_bc_min, T_bc_max, tc);
+					apply_patch_temperature(HL, Tcell, tfields, case_bc, c.downstream_open_face, T_bc_min, T_bc_max, tc);
 					println("| Temperature BC  | patch-driven 2D mapping: "+to_string_u(tc.mapped)+" cells              |");
 					if(tc.missing>0ull) println("|                 | WARNING: missing patch samples for "+to_string_u(tc.missing)+" cells      |");
 				} else {
@@ -970,13 +1002,13 @@ int main(int argc, char** argv) {
 						t_tag = "high-order";
 						tknn.reset(new KnnSurfaceInterpolator(tcloud));
 						const KnnSurfaceInterpolator* k = tknn.get();
-						apply_cloud_temperature(HL, Tcell.data(), case_bc, c.downstream_open_face, true, units.x(c.z_si_offset)+z0_lbmu, T_bc_min, T_bc_max, [k](const V3& p) { return k->eval(p).x; }, tc);
+						apply_cloud_temperature(HL, Tcell, case_bc, c.downstream_open_face, true, units.x(c.z_si_offset)+z0_lbmu, T_bc_min, T_bc_max, [k](const V3& p) { return k->eval(p).x; }, tc);
 						println("| Temperature BC  | per-face interpolation done on 5 boundary surfaces        |");
 						println("| Temperature BC  | mapped "+to_string_u(tc.mapped)+" cells (high-order)      |");
 					} else {
 						t_tag = "low-order";
 						const SampleCloud* cl = &tcloud;
-						apply_cloud_temperature(HL, Tcell.data(), case_bc, c.downstream_open_face, false, z0_lbmu+units.x(c.z_si_offset), T_bc_min, T_bc_max, [cl](const V3& p) { return nearest_sample_velocity(*cl, p).x; }, tc);
+						apply_cloud_temperature(HL, Tcell, case_bc, c.downstream_open_face, false, z0_lbmu+units.x(c.z_si_offset), T_bc_min, T_bc_max, [cl](const V3& p) { return nearest_sample_velocity(*cl, p).x; }, tc);
 						println("| Temperature BC  | mapped "+to_string_u(tc.mapped)+" cells (low-order)                     |");
 					}
 				}
@@ -986,16 +1018,18 @@ int main(int argc, char** argv) {
 					GroundPlane2D tplane; tplane.build(gx, gy, gt, 1.0f);
 					if(tplane.has_samples()) {
 						println("| Ground T plane  | enabled from patch=0 ("+to_string_u(gt.size())+" samples, grid "+to_string_u(tplane.nx())+"x"+to_string_u(tplane.ny())+", mode="+(tplane.structured() ? string("2D bilinear") : string("2D nearest"))+") |");
-						apply_ground_temperature(HL, Tcell.data(), tplane, T_bc_min, T_bc_max, tc);
+						apply_ground_temperature(HL, Tcell, tplane, T_bc_min, T_bc_max, tc);
 						println("| Ground T plane  | mapped "+to_string_u(tc.ground_cells)+" solid cells, unique (x,y)="+to_string_u(tc.ground_columns)+" ["+t_tag+"]                                |");
 						if(tc.ground_cells==0ull) println("| Ground T plane  | WARNING: no solid cells were found                          |");
 					} else println("| Ground T plane  | patch column detected, but no patch=0 samples found        |");
 				}
 				temperature_summary(t_tag);
 			}
+			g_progress.emit("interface_interpolation", "Interface interpolation", "Boundary conditions completed", 1ll, 1ll, false);
 			print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
 			if(c.flux_correction) {
 				print_kv_row("Flux correction", "starting. Time: ["+now_str()+"]");
+				g_progress.emit("flux_correction", "Flux correction", "Balancing boundary mass flux", 0ll, 1ll, true);
 				report_flux(apply_flux_correction(HL, case_bc, downstream_fill));
 				if(use_temperature_bc) temperature_summary(t_tag+"/post-flux");
 			} else print_kv_row("Flux correction", "skipped. Set flux_correction=true to enable");
@@ -1059,10 +1093,11 @@ int main(int argc, char** argv) {
 				}
 			}
 		}
-		if(!c.nwp_mode) print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]");
+		if(!c.nwp_mode) { g_progress.emit("interface_interpolation", "Interface interpolation", c.profile_mode ? "Profile boundary conditions completed" : "Boundary conditions completed", 1ll, 1ll, false); print_kv_row("Boundary init", "complete. Time: ["+now_str()+"]"); }
 		if(c.profile_mode) { // FX/setup.cpp:6087-6119
 			if(c.flux_correction) {
 				print_kv_row("Flux correction", "starting. Time: ["+now_str()+"]");
+				g_progress.emit("flux_correction", "Flux correction", "Balancing boundary mass flux", 0ll, 1ll, true);
 				report_flux(apply_flux_correction(HL, case_bc, [&](const uint x, const uint y, const uint z) -> V3 {
 					float pze = pos_z_of(z);
 					if((x==0u||x==Nx-1u||y==0u||y==Ny-1u)&&side_ref_z_cap>=0&&(int)z>side_ref_z_cap) pze = pos_z_of((uint)side_ref_z_cap);
@@ -1081,7 +1116,7 @@ int main(int argc, char** argv) {
 			for(int k=0; k<3; k++) vc.aniso[k] = c.vk_aniso[k];
 			vc.downstream_face_id = case_bc=="-x" ? 0 : case_bc=="+x" ? 1 : case_bc=="-y" ? 2 : case_bc=="+y" ? 3 : -1;
 			if(!(vc.L_lbm>0.0f)) println("| WARNING: vk_inlet_l converts to non-positive LBM value. Disabled.            |");
-			else vk_on = vk_build_tables(vc, Nx, Ny, Nz, flags.data(), u.data(), vk, [](const string& l) { println(l); });
+			else vk_on = vk_build_tables(vc, Nx, Ny, Nz, flags, u, vk, [](const string& l) { println(l); });
 			if(!vk_on) println(c.profile_mode ? "| VK inlet        | profile case: no valid inflow faces.                       |" : "| VK inlet        | dataset case: no valid inflow faces.                       |");
 			if(vk_on&&!c.dump_vk.empty()&&case_index==1u) {
 				std::ofstream vf(c.dump_vk, std::ios::binary); const uint64_t hdr[2] = {vk.point_count, vk.mode_count};
@@ -1094,8 +1129,8 @@ int main(int argc, char** argv) {
 			const uint hdr[4] = {Nx, Ny, Nz, Nz_core}; const float fh[8] = {lbm_nu, units.si_u(1.0f), units.si_rho(1.0f), G.buffer_inv_tau_lbmu, G.sponge_inv_tau_lbmu, scale_geom, omega[1], omega[2]};
 			const int ih[8] = {G.buffer_nudging_active, G.buffer_n_cells, G.buffer_downstream_face_id, G.buffer_nudge_vertical, G.top_sponge_active, G.sponge_n_cells, (int)nvox, (int)mapped.load()};
 			df.write((const char*)hdr, 16); df.write((const char*)fh, 32); df.write((const char*)ih, 32);
-			df.write((const char*)flags.data(), (std::streamsize)N); df.write((const char*)u.data(), (std::streamsize)(12ull*N));
-			if(use_temperature_bc) { const float th[2] = {units.unit_K, units.unit_K_offset}; df.write("TEMP", 4); df.write((const char*)th, 8); df.write((const char*)Tcell.data(), (std::streamsize)(4ull*N)); } // optional trailer: T in lattice units
+			df.write((const char*)flags, (std::streamsize)N); df.write((const char*)u, (std::streamsize)(12ull*N));
+			if(use_temperature_bc) { const float th[2] = {units.unit_K, units.unit_K_offset}; df.write("TEMP", 4); df.write((const char*)th, 8); df.write((const char*)Tcell, (std::streamsize)(4ull*N)); } // optional trailer: T in lattice units
 		}
 		const ulong total_steps = (c.run_nstep_override>0ull ? c.run_nstep_override : 20001ull)+(ulong)c.research_output_steps;
 		const ulong unsteady = (ulong)c.unsteady_output_interval;
@@ -1136,83 +1171,89 @@ int main(int argc, char** argv) {
 				}
 			}
 		}
-		if(!c.export_setup.empty()) { // hand-over to the multi-GPU launcher (latticeurbanwind_amd/run_deck.py): everything the run loop needs, per case
-			std::filesystem::create_directories(c.export_setup);
-			const string base = c.export_setup+"/case"+to_string_u(case_index);
-			{ std::ofstream sf(base+".state", std::ios::binary); sf.write((const char*)flags.data(), (std::streamsize)N); sf.write((const char*)u.data(), (std::streamsize)(12ull*N)); if(use_temperature_bc) sf.write((const char*)Tcell.data(), (std::streamsize)(4ull*N)); }
-			if(vk_on) { std::ofstream vf(base+".vk", std::ios::binary); const uint64_t hdr[2] = {vk.point_count, vk.mode_count};
-				vf.write((const char*)hdr, 16); vf.write((const char*)vk.point_cell.data(), (std::streamsize)(8ull*vk.point_count)); vf.write((const char*)vk.point_face.data(), (std::streamsize)vk.point_count);
-				vf.write((const char*)vk.point_data.data(), (std::streamsize)(28ull*vk.point_count)); vf.write((const char*)vk.mode_data.data(), (std::streamsize)(200ull*vk.mode_count)); }
-			auto fbits = [](const float f) { uint32_t b; std::memcpy(&b, &f, 4); return to_string_u(b); }; // floats travel as bit patterns
-			auto jstr = [](const string& v) { string o = "\""; for(const char ch : v) { if(ch=='\\'||ch=='"') o += '\\'; o += ch; } return o+"\""; };
-			std::ofstream jf(base+".json");
-			jf << "{\n \"case_index\": " << case_index << ", \"case_count\": " << cases.size() << ",\n"
-			   << " \"N\": [" << Nx << ", " << Ny << ", " << Nz << "], \"Nz_out\": " << Nz_out << ", \"n_gpu\": [" << c.Dx << ", " << c.Dy << ", " << c.Dz << "], \"fp16c\": " << (c.fp16c ? 1 : 0) << ",\n"
-			   << " \"nu_bits\": " << fbits(lbm_nu) << ", \"omega_bits\": [" << fbits(omega[0]) << ", " << fbits(omega[1]) << ", " << fbits(omega[2]) << "],\n"
-			   << " \"si_u_bits\": " << fbits(units.si_u(1.0f)) << ", \"si_rho_bits\": " << fbits(units.si_rho(1.0f)) << ", \"spacing_bits\": " << fbits(geom.spacing) << ",\n"
-			   << " \"buffer\": {\"active\": " << G.buffer_nudging_active << ", \"n_cells\": " << G.buffer_n_cells << ", \"inv_tau_bits\": " << fbits(G.buffer_inv_tau_lbmu) << ", \"nudge_vertical\": " << G.buffer_nudge_vertical << ", \"downstream_face\": " << G.buffer_downstream_face_id << "},\n"
-			   << " \"sponge\": {\"active\": " << G.top_sponge_active << ", \"n_cells\": " << G.sponge_n_cells << ", \"inv_tau_bits\": " << fbits(G.sponge_inv_tau_lbmu) << "},\n"
-			   << " \"steps\": {\"total\": " << total_steps << ", \"unsteady\": " << unsteady << ", \"avg_window\": " << avg_window << ", \"avg_stride\": " << avg_stride << "},\n"
-			   << " \"output\": {\"tke\": " << (c.out_tke ? 1 : 0) << ", \"ti\": " << (c.out_ti ? 1 : 0) << ", \"tls\": " << (c.out_tls ? 1 : 0) << ", \"results_vtk_dir\": " << jstr(results_vtk_dir) << ", \"raw_prefix\": " << jstr(vtk_prefix+c.datetime+"_raw_") << ", \"avg_name\": " << jstr(vtk_prefix+c.datetime+"_avg") << ",\n"
-			   << "   \"vtk_origin\": " << jstr(to_string_f(geom.origin[0])+" "+to_string_f(geom.origin[1])+" "+to_string_f(geom.origin[2])) << ", \"vtk_spacing\": " << jstr(to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)+" "+to_string_f(geom.spacing)) << "},\n"
-			   << " \"vk\": {\"on\": " << (vk_on ? 1 : 0) << ", \"stride\": " << c.vk_stride << ", \"interp\": " << (c.vk_interp ? 1 : 0) << "},\n"
-			   << " \"thermal\": {\"on\": " << (use_temperature_bc ? 1 : 0) << ", \"alpha_bits\": " << fbits(lbm_alpha) << ", \"unit_K_bits\": " << fbits(units.unit_K) << ", \"unit_K_offset_bits\": " << fbits(units.unit_K_offset) << ", \"si_dT_bits\": " << fbits(units.si_dT(1.0f)) << ", \"si_T0_bits\": " << fbits(units.si_T(0.0f)) << "},\n"
-			   << " \"unit_m_bits\": " << fbits(units.unit_m) << ", \"unit_s_bits\": " << fbits(units.unit_s) << ",\n"
-			   << " \"probes\": {\"start_t\": " << (probes.empty() ? 0ull : probe_start_t) << ", \"dt_si\": \"" << [&]() { std::ostringstream o; o << std::setprecision(17) << dt_si_d; return o.str(); }() << "\", \"results_dir\": " << jstr(c.parent+"/RESULTS") << ", \"columns\": ["
-			   << [&]() { std::ostringstream o; bool first = true; for(const ProbeColumn& pc : probes) { o << (first ? "" : ", ") << "{\"stem\": " << jstr(pc.stem) << ", \"x\": " << pc.x << ", \"y\": " << pc.y << ", \"z\": ["; for(size_t i=0u; i<pc.z.size(); i++) o << (i ? ", " : "") << pc.z[i]; o << "], \"height_bits\": ["; for(size_t i=0u; i<pc.height_si.size(); i++) o << (i ? ", " : "") << fbits(pc.height_si[i]); o << "]}"; first = false; } return o.str(); }() << "]},\n"
-			   << " \"state\": " << jstr(base+".state") << ", \"vk_tables\": " << jstr(vk_on ? base+".vk" : string("")) << "\n}\n";
-			print_kv_row("Setup exported", base+".json");
-			continue;
-		}
 		if(c.dry_run) continue;
 
 		phase_mark("boundary conditions");
 		// ---- run_lbm, FX/setup.cpp:4117-4911
 		LBM& lbm = *lbm_p;
 		lbm.set_coriolis(omega[0], omega[1], omega[2]);
-		std::memcpy(lbm.flags.host, flags.data(), N); std::memcpy(lbm.u.host, u.data(), 12ull*N); // rho mirror is pre-filled with 1.0f
-		if(use_temperature_bc) std::memcpy(lbm.T.host, Tcell.data(), 4ull*N);
-		if(vk_on) luw_check(luw_vk_inlet_attach(lbm.handle(), vk.point_count, vk.mode_count, vk.point_cell.data(), vk.point_face.data(), vk.point_data.data(), vk.mode_data.data(), c.vk_stride, c.vk_interp ? 1 : 0));
+		if(vk_on) lbm.vk_inlet_attach(vk.point_count, vk.mode_count, vk.point_cell.data(), vk.point_face.data(), vk.point_data.data(), vk.mode_data.data(), c.vk_stride, c.vk_interp ? 1 : 0);
 		print_section_title("LBM SOLVER INFORMATION");
 		if(use_temperature_bc) print_kv_row("Export mode", "include temperature T field in Kelvin");
 		if(Nz_out<Nz) print_kv_row("VTK z output", "core Nz="+to_string_u(Nz_out)+" of solver Nz="+to_string_u(Nz)+" (top sponge omitted)");
 		print_kv_row("Run steps", to_string_u(total_steps)+(c.run_nstep_override>0ull ? " (run_nstep override)" : " (default)"));
-		if(avg_window>0ull) { print_kv_row("Avg stride", "sample every "+to_string_u(avg_stride)+" step(s) in purge_avg window (on-device accumulation)"); luw_check(luw_stats_reset(lbm.handle())); }
-		if(!probe_cells.empty()) luw_check(luw_gather_attach(lbm.handle(), (uint32_t)probe_cells.size(), probe_cells.data()));
+		if(avg_window>0ull) { print_kv_row("Avg stride", "sample every "+to_string_u(avg_stride)+" step(s) in purge_avg window (on-device accumulation)"); lbm.stats_reset(); }
+		if(!probe_cells.empty()) lbm.gather_attach((uint32_t)probe_cells.size(), probe_cells.data());
 		std::vector<float> probe_buf(3u*probe_cells.size());
 		lbm.run(0u, total_steps);
 		phase_mark("upload + initialise");
 		print_section_title("SOLVER START");
+		// ---- the time loop.  The device runs batches of steps without any host round trip inside; between batches the host looks at the
+		// clock, refreshes the running row / the GUI's progress line and handles whatever must be observed at that step (unsteady output,
+		// probe samples).  A batch ends at the next such step, and otherwise after about a quarter of a second of work.
+		const double bytes_per_cell = (c.fp16c ? 77.0 : 153.0)+(use_temperature_bc ? (c.fp16c ? 32.0 : 60.0) : 0.0); // DDFs + flags (+ thermal lattice), DESIGN.md section 5
+		StepRateMeter meter; meter.configure(total_steps, avg_window>0ull ? avg_start_t : ~0ull);
+		const bool console_row = !g_progress.gui(); // FX/info.cpp:225: the GUI gets protocol lines instead of the table
+		if(console_row) { println(ProgressTable::top()); println(ProgressTable::header()); }
+		auto last_gui = std::chrono::steady_clock::time_point{};
+		auto show_progress = [&](const bool force) {
+			const ulong t = lbm.get_t();
+			if(console_row) reprint_row(ProgressTable::row(N, bytes_per_cell, meter, t, total_steps));
+			const auto now = std::chrono::steady_clock::now();
+			if(!g_progress.gui()||(!force&&t<total_steps&&last_gui.time_since_epoch().count()!=0&&now-last_gui<std::chrono::milliseconds(120))) return; // FX/setup.cpp:4144-4164
+			last_gui = now;
+			g_progress.emit("solve", "Solving CFD", to_string_u(t)+"/"+to_string_u(total_steps)+" steps | "+to_string_fd((float)meter.steps_per_second(t), 3u)+" Steps/s | ETA "+clock_text(meter.remaining_seconds(t)), (long long)t, (long long)total_steps, false);
+		};
+		auto note_saved = [&](const std::vector<string>& files) { // flush_vtk_saved_files, FX/setup.cpp:4192-4218
+			if(files.empty()) return;
+			if(console_row) std::cout << "\r" << string(CONSOLE_WIDTH, ' ') << "\r";
+			bool first = true; for(const string& f : files) { print_kv_row(first ? "VTK file" : "", f+" saved"); first = false; }
+			g_progress.emit("save", "Saving results", files.size()==1u ? files.back() : to_string_u(files.size())+" files saved; last: "+files.back(), (long long)files.size(), (long long)files.size(), false);
+		};
 		const auto t_start = std::chrono::steady_clock::now();
 		ulong last_u_vtk_t = ~0ull;
+		ulong batch_cap = 16ull; // first batch: the reference's 16-step "Normal benchmark" (FX/setup.cpp:4799-4841) doubles as the speed sample
+		g_progress.emit("speed_estimate", "Estimating solve speed", "Benchmarking normal LBM solver", 0ll, (long long)std::min<ulong>(batch_cap, total_steps), false);
+		bool speed_reported = false;
 		while(lbm.get_t()<total_steps) {
-			// advance to the next step at which something must be observed (sample / unsteady output / end); fields are
-			// written by the last step of each run() call
-			ulong next = total_steps;
+			// the next step at which something must be observed (unsteady output / probe sample / end); fields are written by the last step of each batch
+			ulong next = std::min(total_steps, lbm.get_t()+batch_cap);
 			if(unsteady>0ull) next = std::min(next, (ulong)((lbm.get_t()/unsteady+1ull)*unsteady));
 			if(!probes.empty()) next = std::min(next, std::max((ulong)(lbm.get_t()+1ull), probe_start_t)); // every step of the probe window is observed
-			// statistics samples that fall into (t, next] ride along (luw_run_sampled): first sample s, then every avg_stride-th step
+			if(avg_window>0ull&&lbm.get_t()+1ull<avg_start_t) next = std::min<ulong>(next, avg_start_t-(ulong)1u); // a batch belongs to ONE stage of the time estimate
+			// statistics samples that fall into (t, next] ride along (run_sampled): first sample s, then every avg_stride-th step
 			ulong first_sample = 0ull;
-			if(avg_window>0ull) { const ulong t1 = lbm.get_t()+1ull; ulong s = std::max(t1, avg_start_t); const ulong off = (s-avg_start_t)%avg_stride; if(off!=0ull) s += avg_stride-off; if(s<=next) first_sample = s; }
-			if(first_sample>0ull) luw_check(luw_run_sampled(lbm.handle(), next-lbm.get_t(), first_sample-lbm.get_t(), avg_stride));
-			else lbm.run(next-lbm.get_t(), total_steps);
+			if(avg_window>0ull) { const ulong t1 = lbm.get_t()+1ull; ulong sm = std::max(t1, avg_start_t); const ulong off = (sm-avg_start_t)%avg_stride; if(off!=0ull) sm += avg_stride-off; if(sm<=next) first_sample = sm; }
+			const ulong nsteps = next-lbm.get_t();
+			const auto b0 = std::chrono::steady_clock::now();
+			if(first_sample>0ull) lbm.run_sampled(nsteps, first_sample-lbm.get_t(), avg_stride);
+			else lbm.run(nsteps, total_steps);
+			const double bsec = std::chrono::duration<double>(std::chrono::steady_clock::now()-b0).count();
 			const ulong t = lbm.get_t();
-			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); last_u_vtk_t = t; }
+			meter.add_batch(t, nsteps, bsec);
+			if(!speed_reported) { speed_reported = true; g_progress.emit("speed_estimate", "Estimating solve speed", "Benchmarking normal LBM solver step "+to_string_u(nsteps)+"/"+to_string_u(nsteps), (long long)nsteps, (long long)nsteps, false); }
+			batch_cap = std::max<ulong>((ulong)16u, std::min<ulong>((ulong)1u<<20, (ulong)(0.25*meter.steps_per_second(t)))); // about 0.25 s of work per batch
+			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); note_saved({fn}); last_u_vtk_t = t; }
 			if(!probes.empty()&&t>=probe_start_t) { // FX/setup.cpp:4498-4509
-				luw_check(luw_gather_u(lbm.handle(), probe_buf.data()));
+				lbm.gather_u(probe_buf.data());
 				size_t k = 0u;
 				for(ProbeColumn& pc : probes) { pc.time_si.push_back((double)t*dt_si_d); for(size_t l=0u; l<pc.z.size(); l++, k++) for(int d=0; d<3; d++) pc.uvw_si.push_back(units.si_u(probe_buf[3u*k+(size_t)d])); }
 			}
+			show_progress(false);
 		}
-		luw_check(luw_finish(lbm.handle()));
+		show_progress(true);
+		if(console_row) { std::cout << "\r"; println(ProgressTable::row(N, bytes_per_cell, meter, lbm.get_t(), total_steps)); println(ProgressTable::bottom()); } // the final row also goes into the log
 		const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_start).count();
 		print_kv_row("Solver", to_string_u(total_steps)+" steps in "+to_string_fd((float)secs, 3u)+" s = "+to_string_fd((float)((double)N*(double)total_steps/secs*1e-6), 1u)+" MLUPs");
 		phase_mark("solver loop");
 		{ // write_final_transient, FX/setup.cpp:4762-4776
 			const ulong t = lbm.get_t();
-			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); print_kv_row("VTK file", fn+" saved"); }
-			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); print_kv_row("", fr+" saved");
-			if(use_temperature_bc) { lbm.T.read_from_device(); const string ft = default_filename(vtk_dir, "T", t); write_field_vtk(ft, geom, lbm.T.data<float>(), 1u, units.unit_K, units.unit_K_offset, true); print_kv_row("", ft+" saved"); }
+			std::vector<string> saved;
+			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); saved.push_back(fn); }
+			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); saved.push_back(fr);
+			if(use_temperature_bc) { lbm.T.read_from_device(); const string ft = default_filename(vtk_dir, "T", t); write_field_vtk(ft, geom, lbm.T.data<float>(), 1u, units.unit_K, units.unit_K_offset, true); saved.push_back(ft); }
+			bool first = true; for(const string& f : saved) { print_kv_row((first&&last_u_vtk_t!=t) ? "VTK file" : "", f+" saved"); first = false; }
+			g_progress.emit("save", "Saving results", saved.size()==1u ? saved.back() : to_string_u(saved.size())+" files saved; last: "+saved.back(), (long long)saved.size(), (long long)saved.size(), false);
 		}
 		phase_mark("final raw VTKs");
 		if(c.research_output_steps>0u) { // maybe_write_transform_info, FX/setup.cpp:4778-4798
@@ -1226,7 +1267,8 @@ int main(int argc, char** argv) {
 			// 7 floats per cell, every one of them overwritten by the download: no value-initialisation (a 1.4 GB memset at 50 M cells)
 			std::unique_ptr<float[]> stats_mem(new float[7ull*N]); uint64_t avg_count = 0ull;
 			float* const avg_u = stats_mem.get(); float* const avg_rho = avg_u+3ull*N; float* const m2u = avg_rho+N; float* const m2v = m2u+N; float* const m2w = m2v+N;
-			luw_check(luw_stats_download(lbm.handle(), avg_u, avg_rho, m2u, m2v, m2w, &avg_count));
+			std::vector<float> avg_T; if(use_temperature_bc) avg_T.resize(N);
+			lbm.stats_download(avg_u, avg_rho, m2u, m2v, m2w, use_temperature_bc ? avg_T.data() : nullptr, &avg_count);
 			phase_mark("  statistics download");
 			if(avg_count>0ull) {
 				const string fn = default_filename(results_vtk_dir, vtk_prefix+c.datetime+"_avg", lbm.get_t());
@@ -1244,8 +1286,7 @@ int main(int argc, char** argv) {
 				write_field("u_avg", avg_u, 3u, u_factor);
 				write_field("rho_avg", avg_rho, 1u, rho_factor);
 				if(use_temperature_bc) { // T_avg in Kelvin: factor si_dT(1), offset si_T(0), FX/setup.cpp:2526-2528,2580-2582
-					std::vector<float> avg_T(N); luw_check(luw_stats_download_T(lbm.handle(), avg_T.data()));
-					const string fh = "SCALARS T_avg float 1\nLOOKUP_TABLE default\n"; file.write(fh.c_str(), (std::streamsize)fh.length());
+										const string fh = "SCALARS T_avg float 1\nLOOKUP_TABLE default\n"; file.write(fh.c_str(), (std::streamsize)fh.length());
 					const float tf = units.si_dT(1.0f), to = units.si_T(0.0f);
 					parallel_for(points, [&](const ulong i) { buf[i] = reverse_bytes(avg_T[i]*tf+to); });
 					file.write((const char*)buf, (std::streamsize)(points*4ull));
@@ -1287,6 +1328,7 @@ int main(int argc, char** argv) {
 				if(c.out_ti) write_field("TI", ti, 1u, 1.0f);
 				if(c.out_tls) write_field("TLS", tls, 1u, 1.0f);
 				print_kv_row("VTK file", fn+" saved");
+				g_progress.emit("save", "Saving results", fn, 1ll, 1ll, false);
 				print_kv_row("Avg samples", to_string_u(avg_count));
 			}
 		}
@@ -1296,6 +1338,7 @@ int main(int argc, char** argv) {
 			ulong written = 0ull;
 			for(const ProbeColumn& pc : probes) { const string path = c.parent+"/RESULTS/"+pc.stem+".csv"; if(write_probe_csv(path, pc)) written++; else print_kv_row("Probe output", "failed to open "+path); }
 			print_kv_row("Probe files", to_string_u(written)+" CSV saved to RESULTS");
+			g_progress.emit("save", "Saving results", to_string_u(written)+" probe CSV file(s) saved to RESULTS", (long long)written, (long long)written, false); // FX/setup.cpp:4754-4759
 		}
 		print_kv_row("Task finished", "["+now_str()+"]");
 	}

@@ -222,3 +222,149 @@ class LBM:
         capi.check(self._L.luw_upload_fi(self._h, fi.ctypes.data_as(C.c_void_p)))
 
     def ddf_itemsize(self): return 2 if self.cfg.ddf_format == capi.DDF_FP16C else 4
+
+
+class LBMGroup:
+    """The reference's multi-domain `LBM(N, Dx, Dy, Dz, nu, ...)` (FX/lbm.hpp:444-450) in ONE process over the luw_group_* C-ABI: all
+    D domains, their streams and the halo traffic between them live in the library; this mirror holds GLOBAL host arrays in the
+    reference layout (flags[n], u.x[n] ... with n over the whole lattice, like Memory_Container's global index space) which are
+    scattered to / gathered from the domains' mirrors.  devices: HIP device per domain (None: one device each, cfg.device + d)."""
+
+    def __init__(self, Nx, Ny, Nz, Dx, Dy, Dz, nu, fx=0.0, fy=0.0, fz=0.0, *, fp16c=False, devices=None, force_field=False, update_fields_every_step=False,
+                 subgrid=True, device=0, kernel=capi.KERNEL_AUTO, buffer_nudging=None, top_sponge=None, alpha=None):
+        self._L = capi.load()
+        cfg = capi.Config()
+        cfg.struct_size = C.sizeof(capi.Config)
+        cfg.Nx, cfg.Ny, cfg.Nz = int(Nx), int(Ny), int(Nz)
+        cfg.Dx, cfg.Dy, cfg.Dz = int(Dx), int(Dy), int(Dz)
+        cfg.nu = float(nu)
+        cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
+        cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
+        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
+        cfg.alpha = float(alpha) if alpha is not None else 0.0
+        if buffer_nudging is not None:
+            cfg.buffer_nudging_active = 1
+            cfg.buffer_n_cells = int(buffer_nudging["n_cells"]); cfg.buffer_inv_tau_lbmu = float(buffer_nudging["inv_tau"])
+            cfg.buffer_downstream_face_id = int(buffer_nudging.get("downstream_face", 0)); cfg.buffer_nudge_vertical = int(buffer_nudging.get("nudge_vertical", 0))
+        if top_sponge is not None:
+            cfg.top_sponge_active = 1
+            cfg.sponge_n_cells = int(top_sponge["n_cells"]); cfg.sponge_inv_tau_lbmu = float(top_sponge["inv_tau"])
+        cfg.device = int(device); cfg.kernel = int(kernel)
+        self.cfg = cfg
+        n = int(Dx) * int(Dy) * int(Dz)
+        dev = None
+        if devices is not None:
+            assert len(devices) == n
+            dev = (C.c_int * n)(*[int(d) for d in devices])
+        h = C.c_void_p()
+        capi.check(self._L.luw_group_create(C.byref(cfg), dev, C.byref(h)))
+        self._h = h
+        self.Nx, self.Ny, self.Nz, self.D = int(Nx), int(Ny), int(Nz), (int(Dx), int(Dy), int(Dz))
+        N = self.Nx * self.Ny * self.Nz
+        self.flags = np.zeros(N, np.uint8); self.u = np.zeros(3 * N, np.float32); self.rho = np.ones(N, np.float32)
+        self.T = np.ones(N, np.float32) if alpha is not None else None
+        self.F = np.zeros(3 * N, np.float32) if force_field else None
+        self._initialized = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.luw_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _p(self, a): return a.ctypes.data_as(C.c_void_p)
+    def get_N(self): return self.Nx * self.Ny * self.Nz
+    def get_t(self): return int(self._L.luw_group_get_t(self._h))
+    def get_D(self): return self.D[0] * self.D[1] * self.D[2]
+    def overlaps(self): return bool(self._L.luw_group_overlaps(self._h))
+    def direct_peer_stores(self): return bool(self._L.luw_group_direct_peer_stores(self._h))
+    def set_f(self, fx, fy, fz): capi.check(self._L.luw_group_set_f(self._h, fx, fy, fz))
+    def set_coriolis(self, ox, oy, oz): capi.check(self._L.luw_group_set_coriolis(self._h, ox, oy, oz))
+
+    def domain_info(self, d):
+        lN = (C.c_uint32 * 3)(); off = (C.c_int32 * 3)(); dev = C.c_int(0)
+        capi.check(self._L.luw_group_domain_info(self._h, d, lN, off, C.byref(dev)))
+        return tuple(lN), tuple(off), dev.value
+
+    def write_to_device(self):
+        """the global host arrays -> every domain's mirror (halo layers included) -> device"""
+        for field, arr in ((capi.FIELD_FLAGS, self.flags), (capi.FIELD_U, self.u), (capi.FIELD_RHO, self.rho), (capi.FIELD_T, self.T), (capi.FIELD_F, self.F)):
+            if arr is not None:
+                capi.check(self._L.luw_group_scatter(self._h, field, self._p(arr)))
+
+    def read_from_device(self, fields=("u", "rho")):
+        mask = {"u": capi.MASK_U, "rho": capi.MASK_RHO, "flags": capi.MASK_FLAGS, "T": capi.MASK_T}
+        ids = {"u": capi.FIELD_U, "rho": capi.FIELD_RHO, "flags": capi.FIELD_FLAGS, "T": capi.FIELD_T}
+        m = 0
+        for f in fields: m |= mask[f]
+        capi.check(self._L.luw_group_download(self._h, m))
+        for f in fields:
+            capi.check(self._L.luw_group_gather(self._h, ids[f], self._p(getattr(self, f))))
+
+    def run(self, steps=0):
+        if not self._initialized:
+            self.write_to_device()
+            capi.check(self._L.luw_group_initialize(self._h))
+            self._initialized = True
+        if steps:
+            capi.check(self._L.luw_group_run(self._h, int(steps)))
+
+    def run_sampled(self, steps, first_sample=1, stride=1):
+        capi.check(self._L.luw_group_run_sampled(self._h, int(steps), int(first_sample), int(stride)))
+
+    def run_timed(self, steps):
+        if not self._initialized:
+            self.run(0)
+        ms = C.c_double()
+        capi.check(self._L.luw_group_run_timed(self._h, int(steps), C.byref(ms)))
+        return ms.value
+
+    def voxelize_mesh_on_device(self, tri, flag=capi.TYPE_S, bounds=None):
+        """every domain voxelises its own box; the result is gathered into self.flags"""
+        tri = np.ascontiguousarray(tri, np.float32)
+        p0, p1, p2 = (np.ascontiguousarray(tri[:, k, :]) for k in range(3))
+        b = None if bounds is None else np.ascontiguousarray(bounds, np.float32).reshape(6)
+        capi.check(self._L.luw_group_scatter(self._h, capi.FIELD_FLAGS, self._p(self.flags)))
+        capi.check(self._L.luw_group_scatter(self._h, capi.FIELD_U, self._p(self.u)))
+        capi.check(self._L.luw_group_voxelize_mesh(self._h, tri.shape[0], self._p(p0), self._p(p1), self._p(p2), None if b is None else self._p(b), int(flag)))
+        capi.check(self._L.luw_group_gather(self._h, capi.FIELD_FLAGS, self._p(self.flags)))
+
+    def vk_inlet_attach(self, point_cell, point_face, point_data, mode_data, mode_count, update_stride=1, stride_interpolation=False):
+        pc = np.ascontiguousarray(point_cell, np.uint64); pf = np.ascontiguousarray(point_face, np.uint8)
+        pd = np.ascontiguousarray(point_data, np.float32); md = np.ascontiguousarray(mode_data, np.float32)
+        capi.check(self._L.luw_group_vk_inlet_attach(self._h, pc.size, int(mode_count), self._p(pc), self._p(pf), self._p(pd), self._p(md), int(update_stride), int(bool(stride_interpolation))))
+
+    def gather_attach(self, cells):
+        c = np.ascontiguousarray(cells, np.uint64)
+        self._gather_n = int(c.size)
+        capi.check(self._L.luw_group_gather_attach(self._h, c.size, self._p(c)))
+
+    def gather_u(self):
+        out = np.zeros((getattr(self, "_gather_n", 0), 3), np.float32)
+        capi.check(self._L.luw_group_gather_u(self._h, self._p(out)))
+        return out
+
+    def stats_reset(self): capi.check(self._L.luw_group_stats_reset(self._h))
+
+    def stats_download(self):
+        N = self.get_N()
+        out = dict(avg_u=np.zeros(3 * N, np.float32), avg_rho=np.zeros(N, np.float32), m2_u=np.zeros(N, np.float32), m2_v=np.zeros(N, np.float32), m2_w=np.zeros(N, np.float32))
+        if self.T is not None:
+            out["avg_T"] = np.zeros(N, np.float32)
+        cnt = C.c_uint64(0)
+        capi.check(self._L.luw_group_stats_download(self._h, self._p(out["avg_u"]), self._p(out["avg_rho"]), self._p(out["m2_u"]), self._p(out["m2_v"]), self._p(out["m2_w"]),
+                                                    self._p(out["avg_T"]) if self.T is not None else None, C.byref(cnt)))
+        out["count"] = cnt.value
+        return out
+
+    def download_fi_domain(self, d):
+        """DDFs of domain d as stored (local reference layout incl. halos): test access"""
+        lN, _, _ = self.domain_info(d)
+        out = np.zeros(19 * lN[0] * lN[1] * lN[2], np.uint16 if self.cfg.ddf_format == capi.DDF_FP16C else np.float32)
+        capi.check(self._L.luw_download_fi(self._L.luw_group_domain(self._h, d), self._p(out)))
+        return out

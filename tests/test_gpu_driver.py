@@ -199,18 +199,18 @@ def test_multi_run_decks_vs_real_reference_files(luw, tmp_path, ddf, build, case
 
 def test_pair_and_scalar_kernels_write_identical_files(luw, tmp_path):
     """FP16C on rows of 512 cells: the driver's automatic choice is the pair kernel (two cells per lane, packed FP32
-    collision).  With LUW_KERNEL=1 the same deck runs on the scalar kernel; every file the two runs write must be byte-identical
+    collision).  With --kernel scalar the same deck runs on the scalar kernel; every file the two runs write must be byte-identical
     ('city' buildings, VK inlet, nudging, sponge, unsteady outputs, averaging)."""
     import filecmp
     sys.path.insert(0, GOLD)
     import make_refcases as mr
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
     out = {}
-    for tag, env in (("pair", {}), ("scalar", {"LUW_KERNEL": "1"})):
+    for tag, extra in (("pair", []), ("scalar", ["--kernel", "scalar"])):
         d = str(tmp_path / tag)
         mr.write_case(d, "W", 20.0, ["enable_buffer_nudging = true", "enable_top_sponge = true", "sponge_thickness_m = 64", "vk_inlet_l = 60", "vk_inlet_nmodes = 32"],
                       dims=(51.2, 25.6, 6.4), building="city", nstep=24, unsteady=12, purge=6, vk=True, cell=0.1)
-        r = subprocess.run([DRIVER, os.path.join(d, "W", "conf.luwpf"), "--ddf", "fp16c"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        r = subprocess.run([DRIVER, os.path.join(d, "W", "conf.luwpf"), "--ddf", "fp16c"] + extra, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
         out[tag] = os.path.join(d, "W", "RESULTS", "vtk")
     files = sorted(os.listdir(out["pair"]))

@@ -1,0 +1,66 @@
+"""Decks with n_gpu > 1 through the C++ driver itself: `luw_driver <deck>` builds all Dx*Dy*Dz domains in ONE process (the
+reference's LBM object, FX/lbm.cpp:1057-1112), here all on the test box's single GPU (--devices 0,0,..).  Every file it writes
+must be byte-identical to what the same deck with n_gpu = [1,1,1] writes: per-domain voxelisation, inlet points and probe cells
+split over their owners, on-device statistics gathered from the domains, thermal lattice with its own halo swap."""
+import filecmp
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from vtkio import read_vtk
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+DRIVER = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
+
+
+def _case(tmp_path, case, n_gpu, tag):
+    proj = str(tmp_path / (case + tag))
+    shutil.copytree(os.path.join(GOLD, "refcases", case), proj)
+    deck = glob.glob(os.path.join(proj, "conf.luw*"))[0]
+    txt = re.sub(r"n_gpu = \[[^\]]*\]", "n_gpu = [%d, %d, %d]" % n_gpu, open(deck).read())
+    open(deck, "w").write(txt)
+    return proj, deck
+
+
+def _files(proj):
+    return {os.path.relpath(p, proj): p for p in glob.glob(os.path.join(proj, "RESULTS", "**", "*.*"), recursive=True)}
+
+
+@pytest.mark.parametrize("case,n_gpu,ddf", [("CaseA", (2, 1, 1), "fp32"), ("CaseV", (1, 2, 2), "fp32"), ("CaseN1", (1, 2, 1), "fp32"), ("CaseP", (2, 2, 1), "fp32"),
+                                            ("CaseT1", (2, 2, 1), "fp32"), ("CaseT3", (1, 2, 2), "fp16c"), ("CaseG", (2, 2, 2), "fp16c")])
+def test_driver_with_n_gpu_writes_the_single_domain_files(luw, tmp_path, case, n_gpu, ddf):
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
+    ref_proj, ref_deck = _case(tmp_path, case, (1, 1, 1), "_one")
+    r = subprocess.run([DRIVER, ref_deck, "--ddf", ddf], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    proj, deck = _case(tmp_path, case, n_gpu, "_dom")
+    D = n_gpu[0] * n_gpu[1] * n_gpu[2]
+    r = subprocess.run([DRIVER, deck, "--ddf", ddf, "--devices", ",".join(["0"] * D)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "domains" in r.stdout
+    want, got = _files(ref_proj), _files(proj)
+    assert sorted(want) == sorted(got) and len(want) >= 3
+    for name in sorted(want):
+        if filecmp.cmp(want[name], got[name], shallow=False):
+            continue
+        if name.endswith(".vtk"):                       # say which array differs
+            hw, fw = read_vtk(want[name]); hg, fg = read_vtk(got[name])
+            assert hw == hg, name
+            for key in fw:
+                assert np.array_equal(fg[key], fw[key]), (name, key, int((fg[key] != fw[key]).sum()))
+        assert False, name + " differs"
+
+
+def test_driver_refuses_more_domains_than_devices(luw, tmp_path):
+    """one HIP device per domain unless --devices says otherwise (smart_device_selection errors alike, FX/lbm.cpp:961-979)"""
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
+    proj, deck = _case(tmp_path, "CaseB", (2, 1, 1), "_err")
+    r = subprocess.run([DRIVER, deck, "--ddf", "fp32"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "fewer HIP devices than domains" in (r.stdout + r.stderr)

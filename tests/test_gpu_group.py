@@ -1,0 +1,168 @@
+"""The multi-domain host runtime of the C-ABI (luw_group_*: the reference's `LBM(N, Dx, Dy, Dz, ...)` in ONE process) on the test
+box's single GPU: 2..8 domains share device 0, every face travels between the domains' buffers inside the library (peer
+stores of the pack kernels, or the staged copy path), shell / interior overlap and pipelined steps included.  The global
+fields must equal the oracle's run of the undivided lattice bit for bit.  GPU only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import synthetic_state, thermal_state
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    # global lattice, n_gpu, FP16C, expect shell / interior overlap
+    ((24, 20, 16), (2, 1, 1), False, True), ((24, 20, 16), (2, 2, 2), False, True), ((32, 24, 12), (4, 2, 1), False, True), ((26, 18, 16), (1, 3, 2), True, True),
+    ((16, 12, 6), (2, 2, 2), False, False),             # 3 owned layers in z: too thin for a shell, whole box + exchange
+    ((640, 24, 16), (2, 1, 2), True, True),             # rows wide enough for the FP16C pair kernel and 64-cell x slabs
+    ((260, 12, 12), (1, 2, 2), False, True),
+]
+
+
+def run_group(luw, gN, D, fp16c, state, steps, **kw):
+    n = D[0] * D[1] * D[2]
+    g = luw.LBMGroup(*gN, *D, 0.01, fp16c=fp16c, devices=[0] * n, **kw)
+    g.flags[:] = state[0]; g.u[:] = state[1]; g.rho[:] = state[2]
+    return g
+
+
+@pytest.mark.parametrize("gN,D,fp16c,overlap", CASES)
+def test_group_equals_oracle_on_the_undivided_lattice(luw, gN, D, fp16c, overlap):
+    from oracle import oracle
+    st = synthetic_state(*gN, seed=41, shell=None)                      # fully periodic: the wrap runs through the halo ring
+    g = run_group(luw, gN, D, fp16c, st, 7)
+    assert g.overlaps() == overlap and g.direct_peer_stores()
+    g.run(0); g.run(4); g.run(3)                                        # two calls: events of the first are reused by the second
+    g.read_from_device()
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
+    o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+    o.run(7)
+    assert g.get_t() == 7
+    assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
+    g.close()
+
+
+def test_group_with_luw_shell_forces_and_statistics(luw):
+    """solid ground + TYPE_E shell, nudging + sponge + Coriolis, a sampling window: fields and Welford statistics of a
+    [2,2,1] group against the oracle (+ host Welford) on the undivided lattice"""
+    from oracle import oracle
+    gN, D = (48, 40, 24), (2, 2, 1)
+    st = synthetic_state(*gN, seed=43, shell="luw")
+    nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1); spg = dict(n_cells=6, inv_tau=0.02)
+    g = run_group(luw, gN, D, False, st, 0, buffer_nudging=nud, top_sponge=spg)
+    g.set_coriolis(0.0, 3e-5, 4e-5)
+    o = oracle.OracleLBM(*gN, 0.01)
+    o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+    o.set_coriolis(0.0, 3e-5, 4e-5); o.set_buffer_nudging(5, 0.0133333, 2, 1); o.set_top_sponge(6, 0.02)
+    g.run(5); o.run(5)
+    g.stats_reset()
+    stats = oracle.OracleStats(o.N)
+    g.run_sampled(9, 2, 3)                                             # samples at steps 2, 5, 8 of the window
+    for k in range(1, 10):
+        o.run(1)
+        if k >= 2 and (k - 2) % 3 == 0:
+            stats.accumulate(o)
+    g.read_from_device()
+    assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
+    d = g.stats_download()
+    assert d["count"] == 3 == stats.count
+    assert np.array_equal(d["avg_u"], stats.avg_u) and np.array_equal(d["avg_rho"], stats.avg_rho)     # avg_u: AoS [3n+c] on both sides
+    assert np.array_equal(d["m2_u"], stats.m2_u) and np.array_equal(d["m2_v"], stats.m2_v) and np.array_equal(d["m2_w"], stats.m2_w)
+    g.close()
+
+
+@pytest.mark.parametrize("D,fp16c", [((2, 1, 1), False), ((2, 2, 2), True)])
+def test_group_thermal_lattice(luw, D, fp16c):
+    from oracle import oracle
+    gN = (24, 20, 16)
+    st = synthetic_state(*gN, seed=45, shell=None)
+    tflags, T = thermal_state(st[0], gN)
+    g = run_group(luw, gN, D, fp16c, (tflags, st[1], st[2]), 0, alpha=0.004)
+    g.T[:] = T
+    g.stats_reset()
+    g.run(0)
+    g.run_sampled(6, 1, 2)                                             # thermal lattice: separate statistics kernel between pipelined steps
+    g.read_from_device(("u", "rho", "T"))
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c, alpha=0.004)
+    o.flags[:] = tflags; o.u[:] = st[1]; o.rho[:] = st[2]; o.T[:] = T
+    o.run(6)
+    assert np.array_equal(g.u, o.u) and np.array_equal(g.T, o.T) and o.T.std() > 1e-4
+    assert g.stats_download()["count"] == 3
+    g.close()
+
+
+def test_group_voxelise_gather_and_inlet_match_the_single_domain(luw):
+    """per-domain voxelisation, probe gather and the von-Karman inlet split over the owners: a [2,2,1] group equals ONE domain"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_refcases import box_tris
+    gN, D = (48, 40, 24), (2, 2, 1)
+    st = synthetic_state(*gN, seed=47, solids=False, shell="luw")
+    tri = np.array(box_tris(10.0, 22.0, 8.0, 19.0, 1.0, 9.0) + box_tris(21.0, 30.0, 18.0, 27.0, 1.0, 14.0), np.float32)   # (T, 3, 3); the second box straddles the domain cut
+    bounds = np.concatenate([tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0)])
+    rng = np.random.default_rng(3)
+    Nx, Ny, Nz = gN
+    zs, ys = np.meshgrid(np.arange(1, Nz - 1), np.arange(Ny), indexing="ij")
+    cells = (0 + (ys.ravel() + zs.ravel() * Ny) * Nx).astype(np.uint64)            # the west face, both y halves
+    P, M = cells.size, 8
+    pdata = np.zeros((7, P), np.float32); pdata[0] = -0.5 * Nx + 0.5; pdata[1] = ys.ravel() - 0.5 * Ny + 0.5; pdata[2] = zs.ravel() - 0.5 * Nz + 0.5
+    pdata[3] = 0.05; pdata[6] = 0.01
+    mdata = (0.3 * rng.standard_normal((10, 5 * M))).astype(np.float32)
+    probes = np.array([5 + (7 + 3 * Ny) * Nx, 40 + (30 + 5 * Ny) * Nx, 30 + (10 + 20 * Ny) * Nx], np.uint64)
+    res = []
+    for kind in ("single", "group"):
+        g = luw.LBM(*gN, 0.01) if kind == "single" else luw.LBMGroup(*gN, *D, 0.01, devices=[0] * 4)
+        fl, u, rho = (g.flags.data, g.u.data, g.rho.data) if kind == "single" else (g.flags, g.u, g.rho)
+        fl[:] = st[0]; u[:] = st[1]; rho[:] = st[2]
+        g.voxelize_mesh_on_device(tri, bounds=bounds)
+        mask = fl.copy()
+        g.vk_inlet_attach(cells, np.zeros(P, np.uint8), pdata.ravel(), mdata.ravel(), M)
+        g.gather_attach(probes)
+        g.run(6)
+        pu = g.gather_u()
+        if kind == "single":
+            g.u.read_from_device(); g.rho.read_from_device()
+            res.append((mask, g.u.data.copy(), g.rho.data.copy(), pu))
+        else:
+            g.read_from_device()
+            res.append((mask, g.u.copy(), g.rho.copy(), pu))
+        g.close()
+    assert (res[0][0] & 1).sum() > 1000
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
+def test_group_staged_copy_path(tmp_path):
+    """the path for devices without peer access (pack into a send buffer, hipMemcpyPeerAsync into the neighbour's receive
+    buffer), forced with LUW_GROUP_STAGED=1 in a child process: same bits as the oracle"""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import latticeurbanwind_amd as luw
+from helpers import synthetic_state
+from oracle import oracle
+luw.load()
+gN, D = (32, 24, 12), (2, 2, 1)
+st = synthetic_state(*gN, seed=49, shell=None)
+g = luw.LBMGroup(*gN, *D, 0.01, devices=[0] * 4)
+assert not g.direct_peer_stores()
+g.flags[:] = st[0]; g.u[:] = st[1]; g.rho[:] = st[2]
+g.run(6); g.read_from_device()
+o = oracle.OracleLBM(*gN, 0.01); o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]; o.run(6)
+assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
+print("staged ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LUW_GROUP_STAGED="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def test_group_refuses_what_the_reference_refuses(luw):
+    from latticeurbanwind_amd import capi
+    with pytest.raises(capi.LuwError):
+        luw.LBMGroup(25, 20, 16, 2, 1, 1, 0.01, devices=[0, 0])          # not divisible: the caller shrinks the grid first
+    with pytest.raises(capi.LuwError):
+        luw.LBMGroup(24, 20, 16, 2, 1, 1, 0.01)                          # one device per domain unless a device list says otherwise (FX/lbm.cpp:961-979)

