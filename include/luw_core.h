@@ -109,6 +109,9 @@ typedef struct luw_solver luw_solver;
 int luw_abi_version(void);
 const char* luw_last_error(void);
 int luw_device_count(int* count);            /* smart_device_selection's enumeration, FX/lbm.cpp:947-979 */
+/* to_string(float) of the reference (FX/utilities.hpp:2741-2750): 9 significant digits, "d.dddddddd[E<exp>]", "NaN", "Inf".  The
+ * solver's constants and the VTK headers (ORIGIN, SPACING) are defined through this text; drivers use the same routine. */
+int luw_format_float9(float x, char* text, uint64_t size);
 
 /* life cycle: LBM::LBM (FX/lbm.cpp:1057-1112) / LBM::~LBM.
  * For DDF arrays of 1 GiB and more luw_create tries a few candidate allocations and keeps the one on which the step kernel

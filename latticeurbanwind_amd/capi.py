@@ -23,7 +23,7 @@ TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4
 
 SYMBOLS = [
-    "luw_abi_version", "luw_last_error", "luw_device_count", "luw_create", "luw_destroy", "luw_host_ptr",
+    "luw_abi_version", "luw_last_error", "luw_device_count", "luw_format_float9", "luw_create", "luw_destroy", "luw_host_ptr",
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
     "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
@@ -90,6 +90,7 @@ def load(path=None):
     L.luw_abi_version.restype = i32
     L.luw_last_error.restype = C.c_char_p
     L.luw_device_count.argtypes = [C.POINTER(i32)]
+    L.luw_format_float9.argtypes = [f32, C.c_char_p, u64]
     L.luw_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.luw_destroy.argtypes = [vp]; L.luw_destroy.restype = None
     L.luw_host_ptr.argtypes = [vp, i32]; L.luw_host_ptr.restype = vp

@@ -44,39 +44,43 @@ static thread_local std::string g_last_error;
 static int fail(const int code, const std::string& msg) { g_last_error = msg; return code; }
 #define HIP_TRY(expr) do { const hipError_t e_ = (expr); if(e_!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string(#expr)+": "+hipGetErrorString(e_)); } while(0)
 
-// FX/utilities.hpp:2603-2634,2741-2750 + strtof: the float the reference kernel sees after device_defines()
-// printed it as 9-digit decimal text (FX/lbm.cpp:664,774,780).
-static float literal_roundtrip(float x) {
-	bool neg = false;
-	if(x<0.0f) { neg = true; x = -x; }
-	if(std::isnan(x)||std::isinf(x)) return neg ? -x : x;
-	int exponent = 0;
-	if(x>=10.0f) {
-		if(x>=1E32f) { x *= 1E-32f; exponent += 32; }
-		if(x>=1E16f) { x *= 1E-16f; exponent += 16; }
-		if(x>= 1E8f) { x *=  1E-8f; exponent +=  8; }
-		if(x>= 1E4f) { x *=  1E-4f; exponent +=  4; }
-		if(x>= 1E2f) { x *=  1E-2f; exponent +=  2; }
-		if(x>= 1E1f) { x *=  1E-1f; exponent +=  1; }
+// ---- floats as 9-significant-digit text.  The reference bakes its kernel constants into OpenCL source as decimal text and writes
+// VTK headers the same way (to_string(float), FX/utilities.hpp:2603-2634,2741-2750; used at FX/lbm.cpp:664,774,780): what the
+// kernel computes with is the float READ BACK from that text, so the digits have to be the reference's, one float operation at a
+// time.  Decimal exponent: a binary ladder of powers of ten, each rung applied at most once, from 10^32 down to 10^1 -- scaling
+// down while the value is >= 10, scaling up while it is below 1 (the thresholds of the upward ladder sit one decade lower, so
+// that the mantissa ends in [1, 10)).  Digits: the integer part, then eight decimals from one truncation of (x - int) * 10^8
+// and one round-half-up whose carry may run into the integer part and the exponent.
+struct Decimal9 { bool negative, special; uint32_t integral, decimals; int exponent; };
+static Decimal9 split_decimal9(float x) {
+	Decimal9 d = { x<0.0f, false, 0u, 0u, 0 };
+	if(d.negative) x = -x;
+	if(std::isnan(x)||std::isinf(x)) { d.special = true; return d; }
+	static const struct { float at_least, times; int decades; } down[6] = { { 1E32f, 1E-32f, 32 }, { 1E16f, 1E-16f, 16 }, { 1E8f, 1E-8f, 8 }, { 1E4f, 1E-4f, 4 }, { 1E2f, 1E-2f, 2 }, { 1E1f, 1E-1f, 1 } };
+	static const struct { float below, times; int decades; } up[6] = { { 1E-31f, 1E32f, 32 }, { 1E-15f, 1E16f, 16 }, { 1E-7f, 1E8f, 8 }, { 1E-3f, 1E4f, 4 }, { 1E-1f, 1E2f, 2 }, { 1E0f, 1E1f, 1 } };
+	if(x>=10.0f) for(const auto& r : down) if(x>=r.at_least) { x *= r.times; d.exponent += r.decades; }
+	if(x>0.0f&&x<=1.0f) for(const auto& r : up) if(x<r.below) { x *= r.times; d.exponent -= r.decades; }
+	d.integral = (uint32_t)x;
+	const float scaled = (x-(float)d.integral)*1E8f;
+	d.decimals = (uint32_t)scaled;
+	if(scaled-(float)d.decimals>=0.5f&&++d.decimals>=100000000u) { // half up; 0.99999999x carries
+		d.decimals = 0u;
+		if(++d.integral>=10u) { d.integral = 1u; d.exponent++; }
 	}
-	if(x>0.0f&&x<=1.0f) {
-		if(x<1E-31f) { x *=  1E32f; exponent -= 32; }
-		if(x<1E-15f) { x *=  1E16f; exponent -= 16; }
-		if(x< 1E-7f) { x *=   1E8f; exponent -=  8; }
-		if(x< 1E-3f) { x *=   1E4f; exponent -=  4; }
-		if(x< 1E-1f) { x *=   1E2f; exponent -=  2; }
-		if(x<  1E0f) { x *=   1E1f; exponent -=  1; }
-	}
-	uint32_t integral = (uint32_t)x;
-	const float remainder = (x-(float)integral)*1E8f;
-	uint32_t decimal = (uint32_t)remainder;
-	if(remainder-(float)decimal>=0.5f) {
-		decimal++;
-		if(decimal>=100000000u) { decimal = 0u; integral++; if(integral>=10u) { integral = 1u; exponent++; } }
-	}
-	char text[64];
-	if(exponent!=0) snprintf(text, sizeof(text), "%s%u.%08uE%d", neg ? "-" : "", integral, decimal, exponent);
-	else snprintf(text, sizeof(text), "%s%u.%08u", neg ? "-" : "", integral, decimal);
+	return d;
+}
+static void format_decimal9(const float x, char* text, const size_t size) {
+	const Decimal9 d = split_decimal9(x);
+	const char* sign = d.negative ? "-" : "";
+	if(d.special) snprintf(text, size, "%s%s", sign, std::isnan(x) ? "NaN" : "Inf");
+	else if(d.exponent!=0) snprintf(text, size, "%s%u.%08uE%d", sign, d.integral, d.decimals, d.exponent);
+	else snprintf(text, size, "%s%u.%08u", sign, d.integral, d.decimals);
+}
+// the float the reference kernel sees after device_defines() printed it and the OpenCL compiler parsed it
+static float literal_roundtrip(const float x) {
+	if(std::isnan(x)||std::isinf(x)) return x;
+	char text[48];
+	format_decimal9(x, text, sizeof(text));
 	return strtof(text, nullptr);
 }
 
@@ -448,6 +452,11 @@ static bool kernel_selectable(const uint32_t k) {
 extern "C" {
 
 int luw_abi_version(void) { return LUW_ABI_VERSION; }
+int luw_format_float9(float x, char* text, uint64_t size) {
+	if(!text||size<24u) return fail(LUW_ERR_INVALID, "luw_format_float9: needs a buffer of at least 24 characters");
+	format_decimal9(x, text, (size_t)size);
+	return LUW_OK;
+}
 const char* luw_last_error(void) { return g_last_error.c_str(); }
 int luw_device_count(int* count) {
 	if(!count) return fail(LUW_ERR_INVALID, "luw_device_count: null argument");

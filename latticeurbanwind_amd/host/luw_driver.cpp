@@ -41,6 +41,7 @@
 #include "bc_builders.hpp"
 #include "probes.hpp"
 #include "progress.hpp"
+#include "deck.hpp"
 
 using namespace luw_host;
 using std::string;
@@ -70,25 +71,14 @@ static void print_section_title(const string& t) { println(hr_plain()); println(
 static void print_kv_row(const string& k, const string& v) { println("| "+k+" | "+v+" |"); }
 static string to_string_u(ulong x) { string r; do { r = (char)(x%10ull+48ull)+r; x /= 10ull; } while(x); return r; }
 static string decimal_to_string(uint x, int digits) { string r; while((digits--)>0) { r = (char)(x%10u+48u)+r; x /= 10u; } return r; }
-static string to_string_f(float x) { // FX/utilities.hpp:2603-2634,2741-2750
-	string s;
-	if(x<0.0f) { s += "-"; x = -x; }
-	if(std::isnan(x)) return s+"NaN";
-	if(std::isinf(x)) return s+"Inf";
-	int exponent = 0;
-	if(x>=10.0f) {
-		if(x>=1E32f) { x *= 1E-32f; exponent += 32; } if(x>=1E16f) { x *= 1E-16f; exponent += 16; } if(x>=1E8f) { x *= 1E-8f; exponent += 8; }
-		if(x>=1E4f) { x *= 1E-4f; exponent += 4; } if(x>=1E2f) { x *= 1E-2f; exponent += 2; } if(x>=1E1f) { x *= 1E-1f; exponent += 1; }
-	}
-	if(x>0.0f&&x<=1.0f) {
-		if(x<1E-31f) { x *= 1E32f; exponent -= 32; } if(x<1E-15f) { x *= 1E16f; exponent -= 16; } if(x<1E-7f) { x *= 1E8f; exponent -= 8; }
-		if(x<1E-3f) { x *= 1E4f; exponent -= 4; } if(x<1E-1f) { x *= 1E2f; exponent -= 2; } if(x<1E0f) { x *= 1E1f; exponent -= 1; }
-	}
-	uint integral = (uint)x;
-	const float remainder = (x-(float)integral)*1E8f;
-	uint decimal = (uint)remainder;
-	if(remainder-(float)decimal>=0.5f) { decimal++; if(decimal>=100000000u) { decimal = 0u; integral++; if(integral>=10u) { integral = 1u; exponent++; } } }
-	return s+to_string_u(integral)+"."+decimal_to_string(decimal, 8)+(exponent!=0 ? "E"+std::to_string(exponent) : "");
+// The reference prints floats with 9 significant digits -- "d.dddddddd[E<exp>]" -- and kernel constants and VTK headers travel
+// through that text (FX/utilities.hpp:2603-2634,2741-2750), so the digits must be the reference's, float operation for float
+// operation.  The decimal exponent comes from a binary ladder of powers of ten (each rung at most once, largest first); the nine
+// digits from one truncation and one round-half-up.  One implementation for the whole project: luw_format_float9 in the library.
+static string to_string_f(const float x) {
+	char text[48];
+	luw_format_float9(x, text, sizeof(text));
+	return text;
 }
 static string to_string_fd(float x, const uint decimals) { // FX/utilities.hpp:2762-2772
 	string s;
@@ -125,61 +115,6 @@ template<typename Fn> static void parallel_for(const ulong N, Fn fn) { // FX/uti
 	for(auto& th : pool) th.join();
 }
 static inline float reverse_bytes(const float v) { uint32_t u; std::memcpy(&u, &v, 4); u = __builtin_bswap32(u); float r; std::memcpy(&r, &u, 4); return r; }
-
-// ------------------------------------------------------------------------------------------------ deck (FX/setup.cpp:40-178)
-static string deck_trim(const string& s) { const char* ws = " \t\r\n"; const size_t b = s.find_first_not_of(ws); if(b==string::npos) return ""; return s.substr(b, s.find_last_not_of(ws)-b+1u); }
-static string deck_unquote(string s) { s = deck_trim(s); if(s.size()>=2u) { const char q = s.front(); if((q=='"'||q=='\'')&&s.back()==q) s = deck_trim(s.substr(1u, s.size()-2u)); } return s; }
-static size_t deck_comment_index(const string& line) {
-	bool sq = false, dq = false;
-	for(size_t i=0u; i+1u<line.size(); ++i) {
-		const char ch = line[i], nx = line[i+1u];
-		if(ch=='\''&&!dq) { sq = !sq; continue; }
-		if(ch=='"'&&!sq) { dq = !dq; continue; }
-		if(!sq&&!dq&&ch=='/'&&nx=='/') return i;
-	}
-	return string::npos;
-}
-static string deck_normalize_key(string key) {
-	key = deck_trim(key);
-	string n; bool last_sep = false;
-	for(unsigned char ch : key) {
-		if(ch=='-'||std::isspace(ch)) { if(!n.empty()&&!last_sep) n.push_back('_'); last_sep = true; continue; }
-		n.push_back((char)std::tolower(ch)); last_sep = false;
-	}
-	while(!n.empty()&&n.front()=='_') n.erase(n.begin());
-	while(!n.empty()&&n.back()=='_') n.pop_back();
-	static const std::unordered_map<string, string> aliases = { {"vk_inlet_enable", "turb_inflow_enable"}, {"vk_inlet_anisotropy_scale", "vk_inlet_anisotropy"}, {"vk_inlet_aniso_scale", "vk_inlet_anisotropy"} };
-	const auto it = aliases.find(n);
-	return it!=aliases.end() ? it->second : n;
-}
-static bool deck_try_parse_bool(const string& raw, bool& out) {
-	string n = deck_unquote(raw);
-	std::transform(n.begin(), n.end(), n.begin(), ::tolower);
-	if(n.empty()) return false;
-	static const std::unordered_map<string, bool> tok = { {"1", true}, {"true", true}, {"t", true}, {"yes", true}, {"y", true}, {"on", true}, {"enable", true}, {"enabled", true},
-		{"0", false}, {"false", false}, {"f", false}, {"no", false}, {"n", false}, {"off", false}, {"disable", false}, {"disabled", false} };
-	const auto it = tok.find(n);
-	if(it!=tok.end()) { out = it->second; return true; }
-	char* end = nullptr;
-	const double v = std::strtod(n.c_str(), &end);
-	if(end==n.c_str()||*end!='\0'||!std::isfinite(v)) return false;
-	out = v!=0.0;
-	return true;
-}
-static std::unordered_map<string, string> read_deck_entries(std::istream& in) {
-	std::unordered_map<string, string> values;
-	string line;
-	while(std::getline(in, line)) {
-		const size_t c = deck_comment_index(line);
-		if(c!=string::npos) line.erase(c);
-		const size_t eq = line.find('=');
-		if(eq==string::npos) continue;
-		const string key = deck_normalize_key(line.substr(0u, eq));
-		if(key.empty()) continue;
-		values[key] = deck_trim(line.substr(eq+1u));
-	}
-	return values;
-}
 
 // ------------------------------------------------------------------------------------------------ units (FX/units.hpp)
 struct Units {
@@ -266,21 +201,22 @@ static GridEstimate estimate_from_cell_size(const Config& c, const float cell) {
 	e.total_mb = e.core_mb+e.extra_mb;
 	return e;
 }
-static float fit_cell_size_to_gpu_memory_request(const Config& c, const uint target_mb) { // FX/setup.cpp:371-407
+// mesh_control = "gpu_memory": the finest cell size whose grid still fits the requested MB per device (FX/setup.cpp:371-407).
+// Memory falls monotonically with the cell size, so this is a bracket-and-bisect search in FP32: the coarse end starts at one
+// cell per domain edge and doubles until it fits, the fine end halves until it no longer does, then 48 halvings of the bracket.
+// The grid that comes out (751x742x174 for the reference's example deck) depends on every float of this sequence.
+static float fit_cell_size_to_gpu_memory_request(const Config& c, const uint target_mb) {
 	if(target_mb==0u) return 20.0f;
-	float fit = std::fmax(std::fmax(c.si_x, c.si_y), c.si_z+std::fmax(c.sponge_thickness_m, 0.0f));
-	fit = std::fmax(fit, 1.0f);
-	GridEstimate fe = estimate_from_cell_size(c, fit);
-	for(int i=0; i<32&&fe.total_mb>target_mb; ++i) { fit *= 2.0f; fe = estimate_from_cell_size(c, fit); }
-	float over = fit*0.5f;
-	GridEstimate oe = estimate_from_cell_size(c, over);
-	for(int i=0; i<64&&over>1.0e-6f&&oe.total_mb<=target_mb; ++i) { fit = over; fe = oe; over *= 0.5f; oe = estimate_from_cell_size(c, over); }
-	for(int i=0; i<48; ++i) {
-		const float mid = 0.5f*(over+fit);
-		const GridEstimate me = estimate_from_cell_size(c, mid);
-		if(me.total_mb<=target_mb) { fit = mid; fe = me; } else { over = mid; oe = me; }
+	auto fits = [&](const float cell) { return estimate_from_cell_size(c, cell).total_mb<=target_mb; };
+	float coarse = std::fmax(std::fmax(std::fmax(c.si_x, c.si_y), c.si_z+std::fmax(c.sponge_thickness_m, 0.0f)), 1.0f); // feasible end of the bracket
+	for(int tries=32; tries>0&&!fits(coarse); tries--) coarse *= 2.0f;
+	float fine = coarse*0.5f;                                                                                          // infeasible end
+	for(int tries=64; tries>0&&fine>1.0e-6f&&fits(fine); tries--) { coarse = fine; fine *= 0.5f; }
+	for(int halvings=48; halvings>0; halvings--) {
+		const float mid = 0.5f*(fine+coarse);
+		(fits(mid) ? coarse : fine) = mid;
 	}
-	return fit;
+	return coarse;
 }
 
 // ------------------------------------------------------------------------------------------------ profile (FX/setup.cpp:2122-2150,2243-2280)
@@ -292,7 +228,7 @@ static std::vector<std::pair<float, float>> read_profile_dat(const string& path)
 	while(std::getline(fin, line)) {
 		size_t c = line.find("//"); if(c!=string::npos) line.erase(c);
 		c = line.find('#'); if(c!=string::npos) line.erase(c);
-		line = deck_trim(line);
+		line = Deck::strip(line);
 		if(line.empty()) continue;
 		for(char& ch : line) if(ch==','||ch==';') ch = ' ';
 		std::stringstream ss(line);
@@ -303,28 +239,28 @@ static std::vector<std::pair<float, float>> read_profile_dat(const string& path)
 	}
 	return out;
 }
-static float hermite_spline(const float a, const float b, const float va, const float vb, const float t) { // FX/utilities.hpp:2374-2377
-	const float cbt = t*t*t, sqt = t*t;
-	return (2.0f*cbt-3.0f*sqt+1.0f)*a+(-2.0f*cbt+3.0f*sqt)*b+(cbt-2.0f*sqt+t)*va+(cbt-sqt)*vb;
+// U(z) between the samples of profile.dat: a cubic Hermite segment through the two neighbouring samples with secant slopes
+// (one-sided at the ends of the table, centred inside), constant outside the table (FX/setup.cpp:2243-2280 with the basis of
+// FX/utilities.hpp:2374-2377; FP32, the order of the operations below is the reference's).
+static float profile_secant(const std::vector<float>& z, const std::vector<float>& u, const size_t i) {
+	const size_t n = z.size(), lo = i==0u ? 0u : (i+1u>=n ? n-2u : i-1u), hi = i==0u ? 1u : (i+1u>=n ? n-1u : i+1u);
+	const float dz = z[hi]-z[lo];
+	return dz!=0.0f ? (u[hi]-u[lo])/dz : 0.0f;
+}
+static float cubic_hermite(const float y0, const float y1, const float d0, const float d1, const float t) {
+	const float t2 = t*t, t3 = t*t*t;
+	return (2.0f*t3-3.0f*t2+1.0f)*y0+(-2.0f*t3+3.0f*t2)*y1+(t3-2.0f*t2+t)*d0+(t3-t2)*d1;
 }
 static float interpolate_profile_cubic(const std::vector<float>& z, const std::vector<float>& u, const float zq) {
-	const size_t n = z.size();
-	if(n==0u) return 0.0f;
-	if(n==1u) return u[0];
-	if(zq<=z.front()) return u.front();
+	if(z.empty()) return 0.0f;
+	if(z.size()==1u||zq<=z.front()) return u.front();
 	if(zq>=z.back()) return u.back();
-	auto it = std::upper_bound(z.begin(), z.end(), zq);
-	const size_t i1 = it==z.begin() ? 0u : (size_t)(it-z.begin()-1), i2 = std::min(i1+1u, n-1u);
-	const float z0 = z[i1], z1 = z[i2], denom = z1-z0;
-	if(denom<=0.0f) return u[i1];
-	const float t = (zq-z0)/denom;
-	auto slope_at = [&](const size_t i) -> float {
-		if(i==0u) { const float dz = z[1]-z[0]; return dz!=0.0f ? (u[1]-u[0])/dz : 0.0f; }
-		if(i+1u>=n) { const float dz = z[n-1u]-z[n-2u]; return dz!=0.0f ? (u[n-1u]-u[n-2u])/dz : 0.0f; }
-		const float dz = z[i+1u]-z[i-1u]; return dz!=0.0f ? (u[i+1u]-u[i-1u])/dz : 0.0f;
-	};
-	const float m0 = slope_at(i1), m1 = slope_at(i2);
-	return hermite_spline(u[i1], u[i2], m0*denom, m1*denom, t);
+	size_t seg = 0u; // last sample at or below zq (z ascending)
+	for(size_t lo = 0u, hi = z.size()-1u; lo<hi; ) { const size_t mid = (lo+hi+1u)/2u; if(z[mid]<=zq) { lo = mid; seg = mid; } else hi = mid-1u; }
+	const size_t nxt = std::min(seg+1u, z.size()-1u);
+	const float h = z[nxt]-z[seg];
+	if(h<=0.0f) return u[seg];
+	return cubic_hermite(u[seg], u[nxt], profile_secant(z, u, seg)*h, profile_secant(z, u, nxt)*h, (zq-z[seg])/h);
 }
 
 // ------------------------------------------------------------------------------------------------ mesh + host voxeliser
@@ -454,52 +390,53 @@ int main(int argc, char** argv) {
 	}
 	std::ifstream fin(c.deck_path);
 	if(!fin.is_open()) fatal("ERROR: config not found. Please provide a valid *.luw, *.luwdg, or *.luwpf and rerun.");
-	const auto deck = read_deck_entries(fin);
+	Deck deck_file; deck_file.load(fin);
+	const auto& deck = deck_file.entries();
 	string mesh_control, gpu_memory_val, cell_size_val;
 	auto second_val = [](const string& r) { const size_t cpos = r.find(','), rpos = r.find(']', cpos); return (float)atof(r.substr(cpos+1u, rpos-cpos-1u).c_str()); };
 	auto parse_float_list = [](const string& r, std::vector<float>& out) {
-		out.clear(); string s = deck_trim(r); const size_t lb = s.find('['), rb = s.find(']', lb);
+		out.clear(); string s = Deck::strip(r); const size_t lb = s.find('['), rb = s.find(']', lb);
 		const string inside = (lb!=string::npos&&rb!=string::npos&&rb>lb) ? s.substr(lb+1u, rb-lb-1u) : s;
 		std::stringstream ss(inside); string tok;
-		while(std::getline(ss, tok, ',')) { const string t = deck_trim(tok); if(!t.empty()) out.push_back((float)atof(t.c_str())); }
+		while(std::getline(ss, tok, ',')) { const string t = Deck::strip(tok); if(!t.empty()) out.push_back((float)atof(t.c_str())); }
 	};
-	auto parse_pair = [](const string& r, float& a, float& b) { const size_t lb = r.find('['), rb = r.find(']', lb); if(lb==string::npos||rb==string::npos) return; std::stringstream ss(r.substr(lb+1u, rb-lb-1u)); string tok; int i = 0; while(std::getline(ss, tok, ',')) { const float v = (float)atof(deck_trim(tok).c_str()); if(i==0) a = v; else if(i==1) b = v; i++; } };
+	auto parse_pair = [](const string& r, float& a, float& b) { const size_t lb = r.find('['), rb = r.find(']', lb); if(lb==string::npos||rb==string::npos) return; std::stringstream ss(r.substr(lb+1u, rb-lb-1u)); string tok; int i = 0; while(std::getline(ss, tok, ',')) { const float v = (float)atof(Deck::strip(tok).c_str()); if(i==0) a = v; else if(i==1) b = v; i++; } };
 	for(const auto& e : deck) { // FX/setup.cpp:2911-3308 (solver-consumed keys of the supported modes)
-		const string& key = e.first; const string& val = e.second; const string uq = deck_unquote(val); bool pb = false;
+		const string& key = e.first; const string& val = e.second; const string uq = Deck::text(val); bool pb = false;
 		if(key=="casename") c.caseName = uq;
 		else if(key=="datetime") c.datetime = uq;
-		else if(key=="buoyancy") { string v = uq; if(!v.empty()) { std::transform(v.begin(), v.end(), v.begin(), ::tolower); c.buoyancy_explicit = true; bool parsed = true; c.buoyancy = deck_try_parse_bool(v, parsed) ? parsed : true; } }
+		else if(key=="buoyancy") { string v = uq; if(!v.empty()) { std::transform(v.begin(), v.end(), v.begin(), ::tolower); c.buoyancy_explicit = true; bool parsed = true; c.buoyancy = Deck::flag(v, parsed) ? parsed : true; } }
 		else if(key=="downstream_bc") c.downstream_bc = uq;
 		else if(key=="downstream_bc_yaw") c.downstream_bc_yaw = uq;
-		else if(key=="high_order") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.use_high_order = pb; }
-		else if(key=="flux_correction") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.flux_correction = pb; }
+		else if(key=="high_order") { if(!uq.empty()&&Deck::flag(uq, pb)) c.use_high_order = pb; }
+		else if(key=="flux_correction") { if(!uq.empty()&&Deck::flag(uq, pb)) c.flux_correction = pb; }
 		else if(key=="validation") c.validation = uq;
-		else if(key=="downstream_open_face") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.downstream_open_face = pb; }
+		else if(key=="downstream_open_face") { if(!uq.empty()&&Deck::flag(uq, pb)) c.downstream_open_face = pb; }
 		else if(key=="base_height") { if(!uq.empty()) c.z_si_offset = (float)atof(val.c_str()); }
 		else if(key=="memory_lbm") { if(!uq.empty()) c.memory = (uint)atoi(val.c_str()); }
 		else if(key=="si_x_cfd") { if(!uq.empty()) c.si_x = second_val(val); }
 		else if(key=="si_y_cfd") { if(!uq.empty()) c.si_y = second_val(val); }
 		else if(key=="si_z_cfd") { if(!uq.empty()) c.si_z = second_val(val); }
-		else if(key=="enable_buffer_nudging") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.enable_buffer_nudging = pb; }
+		else if(key=="enable_buffer_nudging") { if(!uq.empty()&&Deck::flag(uq, pb)) c.enable_buffer_nudging = pb; }
 		else if(key=="buffer_thickness_m") { if(!uq.empty()) c.buffer_thickness_m = (float)atof(uq.c_str()); }
 		else if(key=="buffer_tau_s") { if(!uq.empty()) c.buffer_tau_s = (float)atof(uq.c_str()); }
-		else if(key=="buffer_nudge_vertical") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.buffer_nudge_vertical = pb ? 1 : 0; }
-		else if(key=="enable_top_sponge") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.enable_top_sponge = pb; }
+		else if(key=="buffer_nudge_vertical") { if(!uq.empty()&&Deck::flag(uq, pb)) c.buffer_nudge_vertical = pb ? 1 : 0; }
+		else if(key=="enable_top_sponge") { if(!uq.empty()&&Deck::flag(uq, pb)) c.enable_top_sponge = pb; }
 		else if(key=="sponge_thickness_m") { if(!uq.empty()) c.sponge_thickness_m = (float)atof(uq.c_str()); }
 		else if(key=="sponge_tau_s") { if(!uq.empty()) c.sponge_tau_s = (float)atof(uq.c_str()); }
 		else if(key=="sponge_ref_mode") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::tolower); c.sponge_ref_mode = (v=="0"||v=="mode0"||v=="mode_0") ? 0 : (v=="1"||v=="mode1"||v=="mode_1"||v=="geostrophic") ? 1 : atoi(v.c_str()); }
 		else if(key=="mesh_control") mesh_control = uq;
 		else if(key=="gpu_memory") gpu_memory_val = uq;
 		else if(key=="cell_size") cell_size_val = uq;
-		else if(key=="n_gpu") { if(!uq.empty()) { const size_t lb = val.find('['), rb = val.find(']', lb); if(lb!=string::npos&&rb!=string::npos) { std::stringstream ss(val.substr(lb+1u, rb-lb-1u)); string tok; uint v[3] = {c.Dx, c.Dy, c.Dz}; int i = 0; while(std::getline(ss, tok, ',')&&i<3) v[i++] = (uint)atoi(deck_trim(tok).c_str()); if(i==3) { c.Dx = v[0]; c.Dy = v[1]; c.Dz = v[2]; } } } }
+		else if(key=="n_gpu") { if(!uq.empty()) { const size_t lb = val.find('['), rb = val.find(']', lb); if(lb!=string::npos&&rb!=string::npos) { std::stringstream ss(val.substr(lb+1u, rb-lb-1u)); string tok; uint v[3] = {c.Dx, c.Dy, c.Dz}; int i = 0; while(std::getline(ss, tok, ',')&&i<3) v[i++] = (uint)atoi(Deck::strip(tok).c_str()); if(i==3) { c.Dx = v[0]; c.Dy = v[1]; c.Dz = v[2]; } } } }
 		else if(key=="research_output") { if(!uq.empty()) c.research_output_steps = (uint)atoi(val.c_str()); }
 		else if(key=="unsteady_output") { if(!uq.empty()) { const int v = atoi(uq.c_str()); c.unsteady_output_interval = v>0 ? (uint)v : 0u; } }
 		else if(key=="run_nstep") { if(!uq.empty()) { const long long v = atoll(uq.c_str()); c.run_nstep_override = v>0ll ? (ulong)v : 0ull; } }
 		else if(key=="purge_avg") { if(!uq.empty()) { const int v = atoi(val.c_str()); c.purge_avg_steps = v>0 ? (uint)v : 0u; } }
 		else if(key=="purge_avg_stride") { if(!uq.empty()) { const int v = atoi(uq.c_str()); c.purge_avg_stride = v>0 ? (uint)v : 1u; } }
-		else if(key=="output_tke_ti_tls") { const string lt = deck_trim(uq); const size_t lb = lt.find('['), rb = lt.find(']', lb); if(!lt.empty()&&lb!=string::npos&&rb!=string::npos&&rb>lb) { c.out_tke = c.out_ti = c.out_tls = false; std::stringstream ss(lt.substr(lb+1u, rb-lb-1u)); string tok; while(std::getline(ss, tok, ',')) { string it = deck_trim(tok); std::transform(it.begin(), it.end(), it.begin(), ::tolower); if(it=="tke") c.out_tke = true; else if(it=="ti") c.out_ti = true; else if(it=="tls") c.out_tls = true; } } }
-		else if(key=="coriolis_term") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::tolower); if(!v.empty()&&deck_try_parse_bool(v, pb)) c.enable_coriolis = pb; }
-		else if(key=="turb_inflow_enable") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_enable = pb; }
+		else if(key=="output_tke_ti_tls") { const string lt = Deck::strip(uq); const size_t lb = lt.find('['), rb = lt.find(']', lb); if(!lt.empty()&&lb!=string::npos&&rb!=string::npos&&rb>lb) { c.out_tke = c.out_ti = c.out_tls = false; std::stringstream ss(lt.substr(lb+1u, rb-lb-1u)); string tok; while(std::getline(ss, tok, ',')) { string it = Deck::strip(tok); std::transform(it.begin(), it.end(), it.begin(), ::tolower); if(it=="tke") c.out_tke = true; else if(it=="ti") c.out_ti = true; else if(it=="tls") c.out_tls = true; } } }
+		else if(key=="coriolis_term") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::tolower); if(!v.empty()&&Deck::flag(v, pb)) c.enable_coriolis = pb; }
+		else if(key=="turb_inflow_enable") { if(!uq.empty()&&Deck::flag(uq, pb)) c.vk_enable = pb; }
 		else if(key=="vk_inlet_nmodes") { if(!uq.empty()) c.vk_nmodes = atoi(uq.c_str()); }
 		else if(key=="vk_inlet_ti") { if(!uq.empty()) c.vk_ti = (float)atof(uq.c_str()); }
 		else if(key=="vk_inlet_sigma") { if(!uq.empty()) c.vk_sigma_si = (float)atof(uq.c_str()); }
@@ -507,9 +444,9 @@ int main(int argc, char** argv) {
 		else if(key=="vk_inlet_seed") { if(!uq.empty()) { char* end = nullptr; const unsigned long long v = std::strtoull(uq.c_str(), &end, 10); if(end!=uq.c_str()) c.vk_seed = (uint64_t)v; } }
 		else if(key=="vk_inlet_update_stride") { if(!uq.empty()) c.vk_stride = atoi(uq.c_str()); }
 		else if(key=="vk_inlet_uc_mode") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), ::toupper); if(v=="NORM_MEAN") c.vk_uc = VkUcMode::NORM_MEAN; else if(v=="NORMAL_COMPONENT") c.vk_uc = VkUcMode::NORMAL_COMPONENT; }
-		else if(key=="vk_inlet_same_realization_all_faces") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_same = pb; }
-		else if(key=="vk_inlet_stride_interpolation") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_interp = pb; }
-		else if(key=="vk_inlet_inflow_only") { if(!uq.empty()&&deck_try_parse_bool(uq, pb)) c.vk_inflow_only = pb; }
+		else if(key=="vk_inlet_same_realization_all_faces") { if(!uq.empty()&&Deck::flag(uq, pb)) c.vk_same = pb; }
+		else if(key=="vk_inlet_stride_interpolation") { if(!uq.empty()&&Deck::flag(uq, pb)) c.vk_interp = pb; }
+		else if(key=="vk_inlet_inflow_only") { if(!uq.empty()&&Deck::flag(uq, pb)) c.vk_inflow_only = pb; }
 		else if(key=="vk_inlet_face_mode") { string v = uq; std::transform(v.begin(), v.end(), v.begin(), [](unsigned char ch) { return ch=='-' ? '_' : (char)std::toupper(ch); });
 			if(v=="AUTO"||v=="AUTO_SIDES"||v=="BY_INFLOW_ONLY"||v=="BUSINESS_DEFAULT"||v=="DEFAULT") c.vk_face_mode = VkFaceMode::AUTO_SIDES;
 			else if(v=="TARGET_INFLOW"||v=="INFLOW"||v=="TARGET"||v=="UPSTREAM_ONLY") c.vk_face_mode = VkFaceMode::TARGET_INFLOW;
@@ -517,10 +454,10 @@ int main(int argc, char** argv) {
 			else if(v=="EXCLUDE_DOWNSTREAM_SIDES"||v=="EXCEPT_DOWNSTREAM_SIDES"||v=="SIDE_EXCEPT_DOWNSTREAM"||v=="SIDES_EXCEPT_DOWNSTREAM"||v=="NON_DOWNSTREAM_SIDES"||v=="SIDE_FACES_EXCEPT_DOWNSTREAM") c.vk_face_mode = VkFaceMode::EXCLUDE_DOWNSTREAM_SIDES;
 			else if(v=="ALL_SIDES"||v=="SIDE_FACES"||v=="ALL_SIDE_FACES"||v=="SIDES_ONLY"||v=="ALL_SIDES_NO_TOP") c.vk_face_mode = VkFaceMode::ALL_SIDES;
 			else if(v=="ALL"||v=="ALL_SELECTED"||v=="ALL_FACES") c.vk_face_mode = VkFaceMode::ALL_SELECTED; }
-		else if(key=="vk_inlet_anisotropy") { if(!uq.empty()) { const size_t lb = uq.find('['), rb = uq.find(']', lb); const string in = (lb!=string::npos&&rb!=string::npos&&rb>lb) ? uq.substr(lb+1u, rb-lb-1u) : uq; std::stringstream ss(in); string tok; float v[3]; int i = 0; bool ok = true; while(std::getline(ss, tok, ',')&&i<3) { const string t = deck_trim(tok); char* end = nullptr; const float f = std::strtof(t.c_str(), &end); if(t.empty()||end==t.c_str()) { ok = false; break; } v[i++] = f; } if(ok&&i==3) for(int k=0; k<3; k++) c.vk_aniso[k] = (std::isfinite(v[k])&&v[k]>=0.0f) ? v[k] : 1.0f; } }
+		else if(key=="vk_inlet_anisotropy") { if(!uq.empty()) { const size_t lb = uq.find('['), rb = uq.find(']', lb); const string in = (lb!=string::npos&&rb!=string::npos&&rb>lb) ? uq.substr(lb+1u, rb-lb-1u) : uq; std::stringstream ss(in); string tok; float v[3]; int i = 0; bool ok = true; while(std::getline(ss, tok, ',')&&i<3) { const string t = Deck::strip(tok); char* end = nullptr; const float f = std::strtof(t.c_str(), &end); if(t.empty()||end==t.c_str()) { ok = false; break; } v[i++] = f; } if(ok&&i==3) for(int k=0; k<3; k++) c.vk_aniso[k] = (std::isfinite(v[k])&&v[k]>=0.0f) ? v[k] : 1.0f; } }
 		else if(key=="cut_lon_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lon[0], c.cut_lon[1]); c.has_cut_lon = true; } }
 		else if(key=="cut_lat_manual") { if(!uq.empty()) { parse_pair(val, c.cut_lat[0], c.cut_lat[1]); c.has_cut_lat = true; } }
-		else if(key=="probes") c.probes_raw = deck_trim(val);
+		else if(key=="probes") c.probes_raw = Deck::strip(val);
 		else if(key=="probes_output") { if(!uq.empty()) { const int v = atoi(uq.c_str()); c.probes_output_defined = true; if(v>0) c.probes_output_steps = (uint)v; else { c.probes_output_steps = 0u; println("| WARNING: probes_output must be > 0 to take effect. Fallback to legacy window. |"); } } }
 		else if(key=="utm_crs") { if(!uq.empty()) c.utm_crs = uq; }
 		else if(key=="rotate_deg") { if(!uq.empty()) { char* end = nullptr; const double v = std::strtod(uq.c_str(), &end); if(end!=uq.c_str()&&std::isfinite(v)) { c.rotate_deg = v; c.has_rotate_deg = true; } } }
@@ -537,8 +474,8 @@ int main(int argc, char** argv) {
 	if(c.vk_enable&&!(c.vk_ti>0.0f||c.vk_sigma_si>0.0f)) { println("| WARNING: turb_inflow_enable=true but TI/sigma is invalid. VK inlet disabled.  |"); c.vk_enable = false; }
 	{ // mesh_control, FX/setup.cpp:3364-3390
 		bool applied = false;
-		if(mesh_control=="gpu_memory") { if(!deck_trim(gpu_memory_val).empty()) { const uint mm = (uint)atoi(deck_trim(gpu_memory_val).c_str()); if(mm>0u) { c.memory = mm; c.cell_m = fit_cell_size_to_gpu_memory_request(c, c.memory); applied = true; } } }
-		else if(mesh_control=="cell_size") { if(!deck_trim(cell_size_val).empty()) { const float cs = (float)atof(deck_trim(cell_size_val).c_str()); if(cs>0.0f&&std::isfinite(cs)) { c.cell_m = cs; applied = true; } } }
+		if(mesh_control=="gpu_memory") { if(!Deck::strip(gpu_memory_val).empty()) { const uint mm = (uint)atoi(Deck::strip(gpu_memory_val).c_str()); if(mm>0u) { c.memory = mm; c.cell_m = fit_cell_size_to_gpu_memory_request(c, c.memory); applied = true; } } }
+		else if(mesh_control=="cell_size") { if(!Deck::strip(cell_size_val).empty()) { const float cs = (float)atof(Deck::strip(cell_size_val).c_str()); if(cs>0.0f&&std::isfinite(cs)) { c.cell_m = cs; applied = true; } } }
 		if(!applied) c.cell_m = 20.0f;
 	}
 	c.parent = std::filesystem::path(c.deck_path).parent_path().string();

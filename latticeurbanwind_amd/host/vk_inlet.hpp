@@ -47,56 +47,68 @@ struct VkTables { // what luw_vk_inlet_attach consumes
 
 struct VkMode { float kx = 0, ky = 0, kz = 0, omega = 0, Ax = 0, Ay = 0, Az = 0, phix = 0, phiy = 0, phiz = 0; };
 
-// build_modes_for_seed_, FX/setup.cpp:777-850
+// ---- random Fourier modes of a von-Karman spectrum (the reference's build_modes_for_seed_, FX/setup.cpp:777-850).
+// Mode m of M sits in the m-th of M equal slices of log k between k_min = 2 pi / (10 L) and k_max = pi (grid cut-off), at a random
+// position inside its slice; its direction is uniform on the sphere (cos(polar) uniform in [-1,1], azimuth uniform); its amplitude
+// follows E(k) ~ k^4 / (1 + (kL)^2)^(17/6); three independent phases, one per velocity component; the frequency is that of a
+// pattern frozen into a flow of speed u_ref along conv_dir.  Amplitudes are normalised to unit variance of the summed signal
+// (0.5 sum a^2 = 1) and weighted per component by the anisotropy factors.
+// The tables must equal the reference's bit for bit (tests/test_vk_inlet.py), which fixes two things: every random number comes
+// from ONE std::mt19937_64 through std::uniform_real_distribution<float>(0, 1) in the order slice position, cos(polar), azimuth,
+// phase x, phase y, phase z -- and the FP32 expressions below keep their operand order.
+struct VkSpectrumBand { float log_k_lo = 0.0f, log_k_width = 0.0f; bool valid = false; };
+inline VkSpectrumBand vk_spectrum_band(const float L) {
+	VkSpectrumBand band;
+	const float pi = 3.1415927f, k_hi = pi/1.0f; // cut-off: wavelength of two cells
+	float k_lo = 2.0f*pi/(10.0f*L);
+	if(!(k_lo>0.0f)||!std::isfinite(k_lo)) k_lo = 1.0e-4f;
+	if(k_lo>=0.99f*k_hi) k_lo = 0.1f*k_hi;
+	band.log_k_lo = logf(k_lo);
+	band.log_k_width = fmaxf(logf(k_hi)-band.log_k_lo, 1.0e-6f);
+	band.valid = true;
+	return band;
+}
+inline float vk_spectrum_amplitude(const float k, const float L) { // sqrt of k^4 / (1 + (kL)^2)^(17/6)
+	const float kL = k*L;
+	const float damping = powf(1.0f+kL*kL, 17.0f/6.0f);
+	const float energy = damping>0.0f ? powf(k, 4.0f)/damping : 0.0f;
+	return sqrtf(fmaxf(energy, 0.0f));
+}
 inline bool vk_build_modes_for_seed(const VkRuntimeConfig& cfg, const float u_ref, const float conv_dir[3], const uint64_t seed, std::vector<VkMode>& out) {
 	out.clear();
-	const float pif = 3.1415927f;
-	const float L = cfg.L_lbm;
-	if(!(L>0.0f)||cfg.nmodes<=0) return false;
-	const float delta_min = 1.0f;
-	const float k_max = pif/delta_min;
-	float k_min = 2.0f*pif/(10.0f*L);
-	if(!(k_min>0.0f)||!std::isfinite(k_min)) k_min = 1.0e-4f;
-	if(k_min>=0.99f*k_max) k_min = 0.1f*k_max;
-	const float log_k_min = logf(k_min), log_k_max = logf(k_max), log_k_span = fmaxf(log_k_max-log_k_min, 1.0e-6f);
-	std::mt19937_64 rng((unsigned long long)seed);
-	std::uniform_real_distribution<float> uni01(0.0f, 1.0f);
-	std::vector<float> a_raw((size_t)cfg.nmodes, 0.0f);
-	out.resize((size_t)cfg.nmodes);
-	double sum_a2 = 0.0;
-	for(int m=0; m<cfg.nmodes; ++m) {
-		const float xi = ((float)m+uni01(rng))/(float)cfg.nmodes;
-		const float k = expf(log_k_min+xi*log_k_span);
-		const float zeta = 2.0f*uni01(rng)-1.0f;
-		const float az = 2.0f*pif*uni01(rng);
-		const float r = sqrtf(fmaxf(0.0f, 1.0f-zeta*zeta));
-		const float dir_x = r*cosf(az), dir_y = r*sinf(az), dir_z = zeta;
-		const float kx = k*dir_x, ky = k*dir_y, kz = k*dir_z;
-		const float kL = k*L;
-		const float denom = powf(1.0f+kL*kL, 17.0f/6.0f);
-		const float W = denom>0.0f ? powf(k, 4.0f)/denom : 0.0f;
-		const float a = sqrtf(fmaxf(W, 0.0f));
-		a_raw[(size_t)m] = a;
-		sum_a2 += (double)a*(double)a;
-		VkMode mode;
-		mode.kx = kx; mode.ky = ky; mode.kz = kz;
-		mode.omega = u_ref*(kx*conv_dir[0]+ky*conv_dir[1]+kz*conv_dir[2]);
-		mode.phix = 2.0f*pif*uni01(rng);
-		mode.phiy = 2.0f*pif*uni01(rng);
-		mode.phiz = 2.0f*pif*uni01(rng);
-		out[(size_t)m] = mode;
+	if(!(cfg.L_lbm>0.0f)||cfg.nmodes<=0) return false;
+	const float two_pi = 2.0f*3.1415927f;
+	const VkSpectrumBand band = vk_spectrum_band(cfg.L_lbm);
+	std::mt19937_64 engine((unsigned long long)seed);
+	std::uniform_real_distribution<float> unit(0.0f, 1.0f);
+	const size_t M = (size_t)cfg.nmodes;
+	out.assign(M, VkMode());
+	double energy_sum = 0.0; // sum of squared raw amplitudes (held in Ax until the normalisation pass)
+	for(size_t m=0u; m<M; m++) {
+		VkMode& md = out[m];
+		const float slice_pos = ((float)(int)m+unit(engine))/(float)cfg.nmodes;
+		const float k = expf(band.log_k_lo+slice_pos*band.log_k_width);
+		const float cos_polar = 2.0f*unit(engine)-1.0f;
+		const float azimuth = two_pi*unit(engine);
+		const float sin_polar = sqrtf(fmaxf(0.0f, 1.0f-cos_polar*cos_polar));
+		md.kx = k*(sin_polar*cosf(azimuth)); md.ky = k*(sin_polar*sinf(azimuth)); md.kz = k*cos_polar;
+		md.Ax = vk_spectrum_amplitude(k, cfg.L_lbm);
+		energy_sum += (double)md.Ax*(double)md.Ax;
+		md.omega = u_ref*(md.kx*conv_dir[0]+md.ky*conv_dir[1]+md.kz*conv_dir[2]);
+		md.phix = two_pi*unit(engine);
+		md.phiy = two_pi*unit(engine);
+		md.phiz = two_pi*unit(engine);
 	}
-	const double variance_raw = 0.5*sum_a2;
-	if(!(variance_raw>0.0)) { out.clear(); return false; }
-	const float scale = 1.0f/(float)sqrt(variance_raw);
-	for(size_t m=0u; m<out.size(); ++m) { const float A = a_raw[m]*scale; out[m].Ax = A*cfg.aniso[0]; out[m].Ay = A*cfg.aniso[1]; out[m].Az = A*cfg.aniso[2]; }
+	const double signal_variance = 0.5*energy_sum;
+	if(!(signal_variance>0.0)) { out.clear(); return false; }
+	const float to_unit_variance = 1.0f/(float)sqrt(signal_variance);
+	for(VkMode& md : out) { const float a = md.Ax*to_unit_variance; md.Ax = a*cfg.aniso[0]; md.Ay = a*cfg.aniso[1]; md.Az = a*cfg.aniso[2]; }
 	return true;
 }
-inline uint64_t vk_mix_seed(const uint64_t seed, const uint32_t face_id) { // FX/setup.cpp:767-775
-	uint64_t x = seed^(0x9E3779B97F4A7C15ull*(uint64_t)(face_id+1u));
-	x ^= (x>>33u); x *= 0xff51afd7ed558ccdull; x ^= (x>>33u); x *= 0xc4ceb9fe1a85ec53ull; x ^= (x>>33u);
-	return x;
-}
+// one stream of modes per face: the 64-bit finaliser of MurmurHash3 (fmix64) over seed xor a per-face multiple of the golden-ratio
+// constant (FX/setup.cpp:767-775)
+inline uint64_t murmur3_fmix64(uint64_t h) { h ^= h>>33; h *= 0xff51afd7ed558ccdull; h ^= h>>33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h>>33; return h; }
+inline uint64_t vk_mix_seed(const uint64_t seed, const uint32_t face_id) { return murmur3_fmix64(seed^(0x9E3779B97F4A7C15ull*(uint64_t)(face_id+1u))); }
 
 // initialize(): collect_face_points_ + build_face_modes_ + the table packing of build_gpu_runtime_ for a single domain.
 // flags/u are the host fields in the reference layout AFTER the boundary fill (u = base inflow on TYPE_E cells).

@@ -58,3 +58,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "luw_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_float_text_equals_the_restatement(luw):
+    """luw_format_float9 (the product's 9-significant-digit float text, behind def_w / inv_tau constants and VTK headers) against the
+    oracle's literal restatement of the reference's to_string(float) + strtof round trip, over edge cases and 200k random floats"""
+    import numpy as np
+    from latticeurbanwind_amd import capi
+    from oracle import oracle
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([np.float32([0.0, 1.0, 9.9999999, 0.99999999, 1e-7, 1.9999990, 0.57735027, 123456.789, 1e32, 3.4e38, 1.2e-38, 1e-45, 0.1, 0.0001, 99999999.0, 0.5000004]),
+                           rng.standard_normal(50000).astype(np.float32), (10.0 ** rng.uniform(-38, 38, 100000)).astype(np.float32), rng.integers(0, 2 ** 32, 50000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    buf = C.create_string_buffer(48)
+    for v in vals:
+        if not np.isfinite(v):
+            continue
+        assert L.luw_format_float9(float(v), buf, 48) == 0
+        got = np.float32(float(buf.value.decode()))
+        want = np.float32(oracle.literal(v))
+        assert got == want or (got == 0 and want == 0), (float(v), buf.value)
+        assert re.fullmatch(rb"-?\d\.\d{8}(E-?\d+)?", buf.value), buf.value
+    assert L.luw_format_float9(float("nan"), buf, 48) == 0 and buf.value == b"NaN"
+    assert L.luw_format_float9(-float("inf"), buf, 48) == 0 and buf.value == b"-Inf"
