@@ -1169,14 +1169,14 @@ int main(int argc, char** argv) {
 			const ulong t = lbm.get_t();
 			meter.add_batch(t, nsteps, bsec);
 			if(!speed_reported) { speed_reported = true; g_progress.emit("speed_estimate", "Estimating solve speed", "Benchmarking normal LBM solver step "+to_string_u(nsteps)+"/"+to_string_u(nsteps), (long long)nsteps, (long long)nsteps, false); }
-			batch_cap = std::max<ulong>((ulong)16u, std::min<ulong>((ulong)1u<<20, (ulong)(0.25*meter.steps_per_second(t)))); // about 0.25 s of work per batch
+			batch_cap = std::max<ulong>((ulong)16u, std::min<ulong>((ulong)1u<<20, (ulong)(0.25*meter.steps_per_second(t))));
+			show_progress(false); // about 0.25 s of work per batch
 			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); note_saved({fn}); last_u_vtk_t = t; }
 			if(!probes.empty()&&t>=probe_start_t) { // FX/setup.cpp:4498-4509
 				lbm.gather_u(probe_buf.data());
 				size_t k = 0u;
 				for(ProbeColumn& pc : probes) { pc.time_si.push_back((double)t*dt_si_d); for(size_t l=0u; l<pc.z.size(); l++, k++) for(int d=0; d<3; d++) pc.uvw_si.push_back(units.si_u(probe_buf[3u*k+(size_t)d])); }
 			}
-			show_progress(false);
 		}
 		show_progress(true);
 		if(console_row) { std::cout << "\r"; println(ProgressTable::row(N, bytes_per_cell, meter, lbm.get_t(), total_steps)); println(ProgressTable::bottom()); } // the final row also goes into the log
