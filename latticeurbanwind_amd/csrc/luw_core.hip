@@ -158,6 +158,8 @@ struct luw_solver {
 	float* d_avg_u = nullptr; float* d_avg_rho = nullptr; float* d_m2 = nullptr; uint64_t avg_count = 0ull;
 	uint32_t vk_P = 0u, vk_M = 0u; int vk_stride = 1; bool vk_interp = false, vk_active = false; uint64_t vk_last_t = ~0ull;
 	uint32_t* d_vk_cell = nullptr; uint8_t* d_vk_face = nullptr; float* d_vk_point = nullptr; float* d_vk_mode = nullptr;
+	// the inlet values of step t+1 are evaluated on a side stream while step t runs (vk_apply): two packed buffers, the step each holds
+	float* d_vk_val[2] = { nullptr, nullptr }; uint64_t vk_val_t[2] = { ~0ull, ~0ull }; hipStream_t vk_stream = nullptr; hipEvent_t vk_ready[2] = { nullptr, nullptr }, vk_taken[2] = { nullptr, nullptr };
 	float* h_rho = nullptr; float* h_u = nullptr; uint8_t* h_flags = nullptr; float* h_F = nullptr;
 	void* d_gi = nullptr; float* d_T = nullptr; float* h_T = nullptr; float* d_avg_T = nullptr; // TEMPERATURE
 	hipStream_t own_stream = nullptr;
@@ -468,6 +470,7 @@ void luw_destroy(luw_solver* s) {
 	if(!s) return;
 	(void)hipSetDevice(s->cfg.device);
 	if(s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+	if(s->vk_stream) { (void)hipStreamSynchronize(s->vk_stream); (void)hipStreamDestroy(s->vk_stream); for(int b=0; b<2; b++) { (void)hipEventDestroy(s->vk_ready[b]); (void)hipEventDestroy(s->vk_taken[b]); (void)hipFree(s->d_vk_val[b]); } }
 	for(DevBlock& r : s->raw) dev_free(r); // fi, rho, u, flags, F, statistics
 	if(s->counted&&s->cfg.device>=0&&s->cfg.device<64) g_live_solvers[s->cfg.device]--;
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
@@ -803,6 +806,9 @@ int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint
 
 int luw_vk_inlet_detach(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_vk_inlet_detach: null solver");
+	(void)hipSetDevice(s->cfg.device);
+	if(s->vk_stream) (void)hipStreamSynchronize(s->vk_stream);
+	for(int b=0; b<2; b++) { (void)hipFree(s->d_vk_val[b]); s->d_vk_val[b] = nullptr; s->vk_val_t[b] = ~0ull; }
 	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
 	s->d_vk_cell = nullptr; s->d_vk_face = nullptr; s->d_vk_point = nullptr; s->d_vk_mode = nullptr;
 	s->vk_active = false; s->vk_P = s->vk_M = 0u;
@@ -832,6 +838,15 @@ int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count
 		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocating / uploading the inlet tables failed");
 	}
 	s->vk_P = (uint32_t)P; s->vk_M = (uint32_t)mode_count; s->vk_stride = update_stride>1 ? update_stride : 1; s->vk_interp = stride_interpolation!=0;
+	static const bool ahead = !(getenv("LUW_VK_AHEAD")&&getenv("LUW_VK_AHEAD")[0]=='0'); // 0: evaluate in line before every step (A/B and test aid)
+	if(ahead) {
+		bool ok = hipMalloc((void**)&s->d_vk_val[0], 3ull*P*4u)==hipSuccess&&hipMalloc((void**)&s->d_vk_val[1], 3ull*P*4u)==hipSuccess;
+		if(ok&&!s->vk_stream) {
+			ok = hipStreamCreateWithFlags(&s->vk_stream, hipStreamNonBlocking)==hipSuccess;
+			for(int b=0; b<2&&ok; b++) ok = hipEventCreateWithFlags(&s->vk_ready[b], hipEventDisableTiming)==hipSuccess&&hipEventCreateWithFlags(&s->vk_taken[b], hipEventDisableTiming)==hipSuccess;
+		}
+		if(!ok) { (void)hipGetLastError(); (void)luw_vk_inlet_detach(s); return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: side stream / value buffers"); }
+	}
 	s->vk_active = true; s->vk_last_t = ~0ull;
 	return LUW_OK;
 }
@@ -986,20 +1001,40 @@ int luw_reset_time_step(luw_solver* s) {
 	return LUW_OK;
 }
 
-// VonKarmanInletUpdater::update + compute_time_params_ (FX/setup.cpp:538-558,1118-1140): at most once per time step
-static int vk_apply(luw_solver* s) {
-	if(!s->vk_active||s->vk_last_t==s->t) return LUW_OK;
-	s->vk_last_t = s->t;
-	const uint64_t t = s->t, stride = s->vk_stride>1 ? (uint64_t)s->vk_stride : 1ull;
+// VonKarmanInletUpdater::update + compute_time_params_ (FX/setup.cpp:538-558,1118-1140): at most once per time step.
+// The evaluation (253 k inlet points x 256 modes x 3 cosf on a 512x512x128 deck: 155 us of pure VALU work) does not sit in front of
+// the step any more: the values of step t+1 are computed on a side stream into a packed buffer while step t -- HBM-bound -- runs,
+// and the step's own stream only scatters them into u (a few us).  Same kernel arithmetic, same values.
+static int vk_launch_eval(luw_solver* s, const uint64_t t, float* dst, const size_t dstride, const uint32_t* cell, hipStream_t st) {
+	const uint64_t stride = s->vk_stride>1 ? (uint64_t)s->vk_stride : 1ull;
 	uint32_t use_interp = 0u; float t0 = (float)t, t1 = (float)t, alpha = 0.0f;
 	if(stride>1ull) {
 		const uint64_t anchor = (t/stride)*stride;
 		if(s->vk_interp) { use_interp = 1u; t0 = (float)anchor; t1 = (float)(anchor+stride); alpha = (float)(t-anchor)/(float)stride; }
 		else { t0 = (float)anchor; t1 = t0; }
 	}
-	hipLaunchKernelGGL(k_vk_inlet_apply, dim3((s->vk_P+255u)/256u), dim3(256), 0, s->stream, use_interp, t0, t1, alpha, s->vk_P, s->vk_M, 5u*s->vk_M, s->d_vk_cell, s->d_vk_face, s->d_vk_point, s->d_vk_mode, s->d_u, (size_t)s->kp.Np);
+	hipLaunchKernelGGL(k_vk_inlet_apply, dim3((s->vk_P+255u)/256u), dim3(256), 0, st, use_interp, t0, t1, alpha, s->vk_P, s->vk_M, 5u*s->vk_M, cell, s->d_vk_face, s->d_vk_point, s->d_vk_mode, dst, dstride);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
+}
+static int vk_apply(luw_solver* s) {
+	if(!s->vk_active||s->vk_last_t==s->t) return LUW_OK;
+	s->vk_last_t = s->t;
+	if(!s->d_vk_val[0]) return vk_launch_eval(s, s->t, s->d_u, (size_t)s->kp.Np, s->d_vk_cell, s->stream); // in line
+	auto eval_into = [&](const int b, const uint64_t t) -> int { // on the side stream, once the scatter that last read buffer b is done
+		HIP_TRY(hipStreamWaitEvent(s->vk_stream, s->vk_taken[b], 0));
+		if(int e = vk_launch_eval(s, t, s->d_vk_val[b], (size_t)s->vk_P, nullptr, s->vk_stream)) return e;
+		HIP_TRY(hipEventRecord(s->vk_ready[b], s->vk_stream));
+		s->vk_val_t[b] = t;
+		return LUW_OK;
+	};
+	int cur = s->vk_val_t[0]==s->t ? 0 : s->vk_val_t[1]==s->t ? 1 : -1;
+	if(cur<0) { cur = 0; if(int e = eval_into(0, s->t)) return e; } // first step, or time was set from outside
+	HIP_TRY(hipStreamWaitEvent(s->stream, s->vk_ready[cur], 0));
+	hipLaunchKernelGGL(k_vk_scatter, dim3((s->vk_P+255u)/256u), dim3(256), 0, s->stream, s->vk_P, s->d_vk_cell, s->d_vk_val[cur], s->d_u, (size_t)s->kp.Np);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(s->vk_taken[cur], s->stream));
+	return eval_into(1-cur, s->t+1ull); // next step's values, beside this step
 }
 
 static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms, const uint64_t first_sample = 0ull, const uint64_t stride = 0ull) {

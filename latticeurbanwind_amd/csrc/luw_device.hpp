@@ -471,120 +471,6 @@ __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t
 	#pragma unroll
 	for(int k=0; k<9; k++) fp[k] = rp[k];
 }
-// ---------------------------------------------------------------- the collision of TWO cells at once
-// A lane of the FP16C pair kernel owns the cells (x, x+1).  Here both are collided together: every quantity is a pair
-// (.x = cell x, .y = cell x+1) in a 64-bit register pair, and moments, equilibria, stress tensor, relaxation and Guo terms are
-// v_pk_add/mul/fma_f32 -- one instruction, two IEEE operations, the roundings of the scalar code (value-identical per half; the
-// operation ORDER of every sum is the contract's).  What has no packed form -- the IEEE divisions and square roots -- runs once
-// per half.  Per-cell decisions (TYPE_E cell, a force acts) are wave-uniform switches plus per-half selects, as in collide_cell_pk.
-// live[c]: cell c takes part (not solid / halo / row padding); a dead half computes garbage that the caller discards.
-__device__ __forceinline__ f32x2 fma2(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 clamp2(const f32x2 v) { f32x2 r = { clampf(v.x, -DEF_C, DEF_C), clampf(v.y, -DEF_C, DEF_C) }; return r; }
-// c_I . (a,b,c) on pairs, same term order as cdot<I>
-template<int I> __device__ __forceinline__ f32x2 cdot2(const f32x2 a, const f32x2 b, const f32x2 c) {
-	if constexpr(I== 1) return  a; else if constexpr(I== 2) return -a;
-	else if constexpr(I== 3) return  b; else if constexpr(I== 4) return -b;
-	else if constexpr(I== 5) return  c; else if constexpr(I== 6) return -c;
-	else if constexpr(I== 7) return  a+b; else if constexpr(I== 8) return -a-b;
-	else if constexpr(I== 9) return  a+c; else if constexpr(I==10) return -a-c;
-	else if constexpr(I==11) return  b+c; else if constexpr(I==12) return -b-c;
-	else if constexpr(I==13) return  a-b; else if constexpr(I==14) return -a+b;
-	else if constexpr(I==15) return  a-c; else if constexpr(I==16) return -a+c;
-	else if constexpr(I==17) return  b-c; else return -b+c; // 18
-}
-// Guo term of direction I (FX/kernel.cpp:1103-1113), formed where it is consumed: nineteen pairs of them held at once would not fit the register budget
-template<int I> __device__ __forceinline__ f32x2 forcing_term2(const f32x2 ux, const f32x2 uy, const f32x2 uz, const f32x2 fx, const f32x2 fy, const f32x2 fz, const f32x2 uF) {
-	if constexpr(I==0) return splat2(9.0f*DEF_W0)*uF;
-	else {
-		constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
-		return splat2(w9)*fma2(cdot2<I>(fx, fy, fz), cdot2<I>(ux, uy, uz)+splat2(0.33333334f), uF);
-	}
-}
-template<int I> __device__ __forceinline__ void relax_forced2(f32x2* f, const f32x2* feq, const f32x2 omw, const f32x2 w, const f32x2 c_tau, const f32x2 ux, const f32x2 uy, const f32x2 uz, const f32x2 fx, const f32x2 fy, const f32x2 fz, const f32x2 uF) {
-	f[I] = fma2(omw, f[I], fma2(w, feq[I], forcing_term2<I>(ux, uy, uz, fx, fy, fz, uF)*c_tau));
-	if constexpr(I<18) relax_forced2<I+1>(f, feq, omw, w, c_tau, ux, uy, uz, fx, fy, fz, uF);
-}
-__device__ __forceinline__ void calculate_f_eq2(const f32x2 rho, f32x2 ux, f32x2 uy, f32x2 uz, f32x2* feq) { // calculate_f_eq on pairs
-	const f32x2 rhom1 = rho-splat2(1.0f);
-	const f32x2 c3 = splat2(-3.0f)*(ux*ux+uy*uy+uz*uz);
-	uz *= splat2(3.0f);
-	ux *= splat2(3.0f);
-	uy *= splat2(3.0f);
-	feq[0] = splat2(DEF_W0)*fma2(rho, splat2(0.5f)*c3, rhom1);
-	const f32x2 u0 = ux+uy, u1 = ux+uz, u2 = uy+uz, u3 = ux-uy, u4 = ux-uz, u5 = uy-uz;
-	const f32x2 rhos = splat2(DEF_WS)*rho, rhoe = splat2(DEF_WE)*rho, rhom1s = splat2(DEF_WS)*rhom1, rhom1e = splat2(DEF_WE)*rhom1;
-	const f32x2 v[9] = { ux, uy, uz, u0, u1, u2, u3, u4, u5 };
-	#pragma unroll
-	for(int k=0; k<9; k++) { // feq[2k+1] = fma(rw, fma(0.5, fma(v,v,c3), v), rm1w), feq[2k+2] the same with -v (FX/kernel.cpp:1045-1055)
-		const f32x2 A = fma2(v[k], v[k], c3);
-		feq[2*k+1] = fma2(k<3 ? rhos : rhoe, fma2(splat2(0.5f), A, v[k]), k<3 ? rhom1s : rhom1e);
-		feq[2*k+2] = fma2(k<3 ? rhos : rhoe, fma2(splat2(0.5f), A, -v[k]), k<3 ? rhom1s : rhom1e);
-	}
-}
-// f[19]: streamed-in DDFs of both cells in, post-collision DDFs out.  rhon/uxn/uyn/uzn: rho,u after the half-force shift and clamp.
-__device__ __forceinline__ void collide_two_cells(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t* fl, const bool* live, const bool may_force,
-		f32x2* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, f32x2& rhon, f32x2& uxn, f32x2& uyn, f32x2& uzn) {
-	const bool is_E[2] = { live[0]&&(fl[0]&TYPE_BO)==TYPE_E, live[1]&&(fl[1]&TYPE_BO)==TYPE_E };
-	const bool wave_has_E = __ballot(is_E[0]||is_E[1])!=0ull;
-	{ // moments, FX/kernel.cpp:1075-1100: the sums in the contract's order
-		f32x2 r = f[0];
-		#pragma unroll
-		for(int i=1; i<19; i++) r += f[i];
-		r += splat2(1.0f);
-		const f32x2 sx = f[ 1]-f[ 2]+f[ 7]-f[ 8]+f[ 9]-f[10]+f[13]-f[14]+f[15]-f[16];
-		const f32x2 sy = f[ 3]-f[ 4]+f[ 7]-f[ 8]+f[11]-f[12]+f[14]-f[13]+f[17]-f[18];
-		const f32x2 sz = f[ 5]-f[ 6]+f[ 9]-f[10]+f[11]-f[12]+f[16]-f[15]+f[18]-f[17];
-		rhon = r;
-		uxn = sx/r; uyn = sy/r; uzn = sz/r; // IEEE divisions, one per half
-	}
-	if(wave_has_E) { // TYPE_E cells take rho,u from the fields
-		if(is_E[0]) { rhon.x = rho[n]; uxn.x = u[n]; uyn.x = u[(size_t)p.Np+n]; uzn.x = u[2ull*p.Np+n]; }
-		if(is_E[1]) { rhon.y = rho[n+1u]; uxn.y = u[n+1u]; uyn.y = u[(size_t)p.Np+n+1u]; uzn.y = u[2ull*p.Np+n+1u]; }
-	}
-	f32x2 fx = splat2(0.0f), fy = splat2(0.0f), fz = splat2(0.0f), uF = splat2(0.0f);
-	if(may_force) {
-		if(live[0]) { float a, b, c; assemble_force(p, n, x, y, z, is_E[0], rhon.x, uxn.x, uyn.x, uzn.x, u, F, a, b, c); fx.x = a; fy.x = b; fz.x = c; }
-		if(live[1]) { float a, b, c; assemble_force(p, n+1u, x+1u, y, z, is_E[1], rhon.y, uxn.y, uyn.y, uzn.y, u, F, a, b, c); fx.y = a; fy.y = b; fz.y = c; }
-		const f32x2 rho2 = splat2(0.5f)/rhon;
-		uxn = clamp2(fma2(fx, rho2, uxn));
-		uyn = clamp2(fma2(fy, rho2, uyn));
-		uzn = clamp2(fma2(fz, rho2, uzn));
-		uF = splat2(-0.33333334f)*fma2(uxn, fx, fma2(uyn, fy, uzn*fz));
-	} else {
-		uxn = clamp2(uxn); uyn = clamp2(uyn); uzn = clamp2(uzn);
-	}
-	f32x2 feq[19];
-	calculate_f_eq2(rhon, uxn, uyn, uzn, feq);
-	f32x2 w = splat2(p.w);
-	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737: every sum runs over i = 1..18 in ascending order (zero terms dropped)
-		f32x2 nq[19];
-		#pragma unroll
-		for(int i=1; i<19; i++) nq[i] = f[i]-feq[i];
-		f32x2 Hxx = nq[ 1], Hyy = nq[ 3], Hzz = nq[ 5], Hxy = nq[ 7], Hxz = nq[ 9], Hyz = nq[11];
-		Hxx += nq[ 2]; Hxx += nq[ 7]; Hxx += nq[ 8]; Hxx += nq[ 9]; Hxx += nq[10]; Hxx += nq[13]; Hxx += nq[14]; Hxx += nq[15]; Hxx += nq[16];
-		Hyy += nq[ 4]; Hyy += nq[ 7]; Hyy += nq[ 8]; Hyy += nq[11]; Hyy += nq[12]; Hyy += nq[13]; Hyy += nq[14]; Hyy += nq[17]; Hyy += nq[18];
-		Hzz += nq[ 6]; Hzz += nq[ 9]; Hzz += nq[10]; Hzz += nq[11]; Hzz += nq[12]; Hzz += nq[15]; Hzz += nq[16]; Hzz += nq[17]; Hzz += nq[18];
-		Hxy += nq[ 8]; Hxy += -nq[13]; Hxy += -nq[14];
-		Hxz += nq[10]; Hxz += -nq[15]; Hxz += -nq[16];
-		Hyz += nq[12]; Hyz += -nq[17]; Hyz += -nq[18];
-		const f32x2 Q = Hxx*Hxx+Hyy*Hyy+Hzz*Hzz+splat2(2.0f)*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
-		w.x = 2.0f/(p.tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q.x)/rhon.x));
-		w.y = 2.0f/(p.tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q.y)/rhon.y));
-	}
-	const f32x2 omw = splat2(1.0f)-w;
-	if(may_force) {
-		const f32x2 c_tau = fma2(w, splat2(-0.5f), splat2(1.0f));
-		relax_forced2<0>(f, feq, omw, w, c_tau, uxn, uyn, uzn, fx, fy, fz, uF);
-	} else {
-		#pragma unroll
-		for(int i=0; i<19; i++) f[i] = fma2(omw, f[i], w*feq[i]);
-	}
-	if(wave_has_E) { // equilibrium override, FX/kernel.cpp:1747
-		#pragma unroll
-		for(int i=0; i<19; i++) { f[i].x = is_E[0] ? feq[i].x : f[i].x; f[i].y = is_E[1] ? feq[i].y : f[i].y; }
-	}
-}
-
 // position-only test: can buffer nudging or the top sponge act on this cell (the zones of assemble_force)?
 __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
 	bool zone = false;

@@ -144,11 +144,14 @@ __global__ void k_gather_u(const uint32_t count, const uint32_t* __restrict__ ce
 // vk_inlet_apply, FX/kernel.cpp:2495-2571: u[cell] = u_base + sigma * sum_m A_m cos(k_m.p + omega_m t + phi_m) on the inlet
 // cells (TYPE_E: the collide step then relaxes them to f_eq(rho, u)).  One lane per inlet point; cosf is the same device
 // library function (ocml) the reference's OpenCL build calls.
+// point_cell = nullptr: the values go to a PACKED buffer (u[c*Np + i], Np = P) instead of the lattice -- the evaluation of the NEXT
+// step's inlet values then runs beside the current step on another stream (VALU-bound here, HBM-bound there) and k_vk_scatter puts
+// them into place in a few microseconds.
 __global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint32_t P, const uint32_t M, const uint32_t V,
 		const uint32_t* __restrict__ point_cell, const uint8_t* __restrict__ point_face, const float* __restrict__ point_data, const float* __restrict__ mode_data, float* __restrict__ u, const size_t Np) {
 	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
 	if(i>=P) return;
-	const uint32_t n = point_cell[i];
+	const uint32_t n = point_cell ? point_cell[i] : i;
 	const uint32_t fid = (uint32_t)(point_face[i]&0x07u);
 	const float px = point_data[i], py = point_data[(size_t)P+i], pz = point_data[2ull*P+i];
 	const float ubx = point_data[3ull*P+i], uby = point_data[4ull*P+i], ubz = point_data[5ull*P+i];
@@ -173,6 +176,13 @@ __global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_inter
 	u[n] = fmaf(sigma, qx, ubx);
 	u[Np+n] = fmaf(sigma, qy, uby);
 	u[2ull*Np+n] = fmaf(sigma, qz, ubz);
+}
+
+__global__ __launch_bounds__(256) void k_vk_scatter(const uint32_t P, const uint32_t* __restrict__ point_cell, const float* __restrict__ val, float* __restrict__ u, const size_t Np) {
+	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
+	if(i>=P) return;
+	const uint32_t n = point_cell[i];
+	u[n] = val[i]; u[Np+n] = val[(size_t)P+i]; u[2ull*Np+n] = val[2ull*P+i];
 }
 
 // ---------------------------------------------------------------- on-device time averaging

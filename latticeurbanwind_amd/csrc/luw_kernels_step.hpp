@@ -233,10 +233,7 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
 	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
 }
-#ifndef LUW_PAIR_WAVES
-#define LUW_PAIR_WAVES 4
-#endif
-template<int PARITY, int MODE=0, bool STATS=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LUW_PAIR_WAVES, LUW_PAIR_WAVES))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<int PARITY, int MODE=0, bool STATS=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
@@ -268,91 +265,69 @@ template<int PARITY, int MODE=0, bool STATS=false> __global__ __launch_bounds__(
 	// behind the row end (the next row's x = 0, or the slack behind the plane: in bounds, see lead_alloc / the plane skew):
 	// it is replaced by the wrapped neighbour in ONE divergent fix-up block behind the loads.
 	uint32_t raw[19];                                              // low half: cell x, high half: cell x+1
-	auto load_all = [&](uint32_t* r) {
-		r[0] = ld_pair<true>(fi, o.x);
+	raw[0] = ld_pair<true>(fi, o.x);
+	static_for_pairs([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
+		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
+		raw[i] = ld_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x);
+		raw[i+1] = ld_pair<!shifted>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o));
+	});
+	if(wrap) {
 		static_for_pairs([&](auto ic) {
 			constexpr int i = decltype(ic)::value;
-			constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-			r[i] = ld_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x);
-			r[i+1] = ld_pair<!shifted>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o));
+			if constexpr(i==1||i==7||i==9||i==13||i==15) { // the dword started at x+1 = Nx-1 of the neighbour row; x+2 wraps to that row's x = 0
+				const uint32_t hi = *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb));
+				raw[i+1] = (raw[i+1]&0xFFFFu)|(hi<<16);
+			}
 		});
-		if(wrap) {
-			static_for_pairs([&](auto ic) {
-				constexpr int i = decltype(ic)::value;
-				if constexpr(i==1||i==7||i==9||i==13||i==15) { // the dword started at x+1 = Nx-1 of the neighbour row; x+2 wraps to that row's x = 0
-					const uint32_t hi = *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb));
-					r[i+1] = (r[i+1]&0xFFFFu)|(hi<<16);
-				}
-			});
-		}
-	};
-	load_all(raw);
+	}
 	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
 	const bool may_force = p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull;
-	// Decode BOTH cells of every plane into one register pair (.x = cell x from the low half, .y = cell x+1 from the high half):
-	// the low half through one SDWA shift (sign-extended code << 12), the high half through an arithmetic shift of the whole dword
-	// (>> 4 leaves the sign-extended code << 12 above twelve bits of the other cell's code); one mask each clears what does not
-	// belong to the float, one packed multiplication by 2^112 finishes both (half_to_float_custom_sx, luw_device.hpp).
-	f32x2 f[19];
-	#pragma unroll
-	for(int q=0; q<19; q++) {
-		uint32_t lo;
-		asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(lo) : "v"(raw[q]));
-		const uint32_t hi = (uint32_t)((int32_t)raw[q]>>4);
-		const f32x2 t = { __uint_as_float(lo&0x87FFF000u), __uint_as_float(hi&0x87FFF000u) };
-		f[q] = t*splat2(0x1p+112f);
-	}
-	// a cell that must not be processed passes its populations through: its half of every stored dword is the code it loaded from
-	// the partner plane of the pair (i <-> i+1), so that the Esoteric-Pull stores put every value back where it came from
-	// (encode(decode(c)) = c for all codes).  The rare waves that hold such a cell fetch the dwords a second time at the tail
-	// (every slot has one owner per step, and this lane has not stored yet: the same bits, from L2) rather than keeping nineteen
-	// registers alive through the collision.
-	const bool wave_all_live = __ballot(!proc[0]||!proc[1])==0ull;
-	if(MODE!=1) { // MODE 1: measurement-only, no collision (every cell passes through)
-		f32x2 rhon, uxn, uyn, uzn;
-		collide_two_cells(p, n, x, y, z, fl, proc, may_force, f, rho, u, F, rhon, uxn, uyn, uzn);
+	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
+	// (or pre-swap for the pass-through)
+	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
+		auto bits = [&](const int q) { // (sign-extended half) << 12 in one SDWA shift, then the mask of half_to_float_custom_sx
+			uint32_t t;
+			if(c) asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(raw[q]));
+			else asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(raw[q]));
+			return t&0x87FFF000u;
+		};
+		f0 = __uint_as_float(bits(0))*0x1p+112f;
 		#pragma unroll
-		for(int c=0; c<2; c++) {
-			const float rc = c ? rhon.y : rhon.x, uxc = c ? uxn.y : uxn.x, uyc = c ? uyn.y : uyn.x, uzc = c ? uzn.y : uzn.x;
-			if(proc[c]) {
-				if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
-					rho[n+c] = rc;
-					u[n+c] = uxc;
-					u[Np+n+c] = uyc;
-					u[2ull*Np+n+c] = uzc;
-				}
-				if constexpr(STATS) {
-					if((fl[c]&TYPE_BO)==TYPE_E) sample_from_fields(c);
-					else { smp.r[c] = rc; smp.ux[c] = uxc; smp.uy[c] = uyc; smp.uz[c] = uzc; smp.has[c] = true; }
-				}
-			} else {
-				if constexpr(STATS) sample_idle_cell(c);
+		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
+		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
+			float rhon, uxn, uyn, uzn;
+			collide_cell_pk(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn);
+			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
+				rho[n+c] = rhon;
+				u[n+c] = uxn;
+				u[Np+n+c] = uyn;
+				u[2ull*Np+n+c] = uzn;
 			}
+			if constexpr(STATS) {
+				if((fl[c]&TYPE_BO)==TYPE_E) sample_from_fields(c);
+				else { smp.r[c] = rhon; smp.ux[c] = uxn; smp.uy[c] = uyn; smp.uz[c] = uzn; smp.has[c] = true; }
+			}
+		} else {
+			#pragma unroll
+			for(int k=0; k<9; k++) { const f32x2 t = { fp[k].y, fp[k].x }; fp[k] = t; }
+			if constexpr(STATS) sample_idle_cell(c);
 		}
-	} else {
-		if constexpr(STATS) { sample_idle_cell(0); sample_idle_cell(1); }
-	}
+	};
+	float fa0, fb0; f32x2 fa[9], fb[9];
+	one_cell(0, fa0, fa);
+	asm_fence9(fa0, fa); asm_fence_u(raw);                         // cell x is finished before cell x+1 starts
+	one_cell(1, fb0, fb);
 	if constexpr(STATS) stats_welford_pair(Np, S, n, smp);        // both cells' samples, one 8-byte access per array
-	{ // all floating-point work is done ...
-		asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
-		asm volatile("" : "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]), "+v"(f[16]), "+v"(f[17]), "+v"(f[18]));
-	}
+	asm_fence9(fa0, fa); asm_fence9(fb0, fb);                      // all floating-point work is done ...
 	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3"); // ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
-	// codes of both cells in the high halves (ca: cell x, cb: cell x+1), merged per plane below
+	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
 	uint32_t ca[19], cb[19];
+	ca[0] = fp16c_code_hi_in_rtz_mode(fa0); cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
 	#pragma unroll
-	for(int q=0; q<19; q++) fp16c_code2_hi_in_rtz_mode(f[q], ca[q], cb[q]);
-	if(MODE==1||!wave_all_live) { // pass-through halves: the partner plane's loaded code instead of the computed one
-		const bool keepA = MODE==1||!proc[0], keepB = MODE==1||!proc[1];
-		uint32_t again[19];
-		asm volatile("" : "+v"(o.x), "+v"(o.xp)); // offsets (re)defined in THIS block: the loads keep the saddr form instead of nineteen 64-bit addresses built (and kept alive) up front
-		load_all(again);
-		#pragma unroll
-		for(int q=0; q<19; q++) {
-			const int partner = q==0 ? 0 : ((q&1) ? q+1 : q-1);
-			ca[q] = keepA ? again[partner]<<16 : ca[q];
-			cb[q] = keepB ? again[partner] : cb[q];
-		}
+	for(int k=0; k<9; k++) {
+		fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
+		fp16c_code2_hi_in_rtz_mode(fb[k], cb[2*k+1], cb[2*k+2]);
 	}
 	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };
 	uint32_t cs[5];   // the five x+1 planes, stored last (dword or, on the row-end lane, two halves)

@@ -119,3 +119,26 @@ def test_hip_vk_inlet_vs_real_reference(luw):
     compare(g, s, lbm.u.data, None, 8, 2e-7)
     lbm.run(56); lbm.u.read_from_device(); lbm.rho.read_from_device()
     compare(g, s, lbm.u.data, lbm.rho.data, 64, 1e-6)
+
+
+@pytest.mark.gpu
+def test_values_computed_ahead_equal_values_computed_in_line(luw, tmp_path):
+    """the product evaluates the inlet values of step t+1 on a side stream while step t runs and scatters them into u before the
+    next step; LUW_VK_AHEAD=0 evaluates them in line in front of every step.  Same kernel arithmetic: the deck driver must write
+    byte-identical files either way (case V: inlet on, unsteady outputs, averaging; and with update stride 3 + interpolation)."""
+    import filecmp, glob, shutil, subprocess
+    driver = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
+    subprocess.check_call(["make", "-C", os.path.dirname(driver), "-s"])
+    for tag, extra in (("plain", ""), ("stride", "vk_inlet_update_stride = 3\nvk_inlet_stride_interpolation = true\n")):
+        out = {}
+        for mode in ("1", "0"):
+            proj = str(tmp_path / (tag + mode))
+            shutil.copytree(os.path.join(GOLD, "refcases", "CaseV"), proj)
+            deck = os.path.join(proj, "conf.luwpf")
+            open(deck, "a").write("\n" + extra)
+            r = subprocess.run([driver, deck, "--ddf", "fp32"], capture_output=True, text=True, timeout=600, env=dict(os.environ, LUW_VK_AHEAD=mode))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+            out[mode] = sorted(glob.glob(os.path.join(proj, "RESULTS", "vtk", "*.vtk")))
+        assert len(out["1"]) >= 4 and [os.path.basename(p) for p in out["1"]] == [os.path.basename(p) for p in out["0"]]
+        for a, b in zip(out["1"], out["0"]):
+            assert filecmp.cmp(a, b, shallow=False), (tag, os.path.basename(a))
