@@ -8,9 +8,9 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 TAG="$1"; shift
 OUT="$R/gpurun_out/prof/$TAG"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --no-cpu-baseline "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --no-cpu-baseline --no-secondary "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   n=$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$n" -- python3 "$R/bench.py" --no-cpu-baseline "$@" > "$OUT/bench_pmc_$n.json" 2> "$OUT/pmc_$n.err"
+  rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$n" -- python3 "$R/bench.py" --no-cpu-baseline --no-secondary "$@" > "$OUT/bench_pmc_$n.json" 2> "$OUT/pmc_$n.err"
 done
 find "$OUT" -name "*.csv" | head -30
