@@ -2,12 +2,15 @@
 """Condenses one tools/profile_bench.sh run (gpurun_out/prof/<tag>/) into profiles/<tag>_summary.json + <tag>_kernel_stats.csv.
 HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950: read requests are 128 B
 (FETCH_SIZE counts 64-byte units as KB -> x2; cross-checked with TCC_EA0_RDREQ x 128 B), WRITE_SIZE is in KB.
-usage: summarize_profile.py <tag> <kernel-name-substring> <algorithmic bytes per launch>"""
+usage: summarize_profile.py <tag> <kernel-name-substring> [algorithmic bytes per launch; default: what bench.py reported in the traced run]"""
 import csv, glob, json, os, shutil, sys
 
-tag, kname, algo = sys.argv[1], sys.argv[2], float(sys.argv[3])
+tag, kname = sys.argv[1], sys.argv[2]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "prof", tag)
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+
+bench = json.loads(open(os.path.join(root, "bench_trace.json")).read().strip().splitlines()[-1])
+algo = float(sys.argv[3]) if len(sys.argv) > 3 else float(bench["roofline"]["algorithmic_bytes_per_launch"])
 
 def one(pattern):
     return glob.glob(os.path.join(root, pattern))[0]
@@ -27,9 +30,8 @@ def counter(dirpat, name):
 fetch_kb = counter("pmc_FETCH_SIZE", "FETCH_SIZE"); write_kb = counter("pmc_WRITE_SIZE", "WRITE_SIZE")
 rd = counter("pmc_TCC_EA0_RDREQ_sum_TCC_EA0_WRREQ_sum", "TCC_EA0_RDREQ_sum"); wr = counter("pmc_TCC_EA0_RDREQ_sum_TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_sum")
 hit = counter("pmc_TCC_HIT_sum_TCC_MISS_sum", "TCC_HIT_sum"); miss = counter("pmc_TCC_HIT_sum_TCC_MISS_sum", "TCC_MISS_sum")
-bench = json.loads(open(os.path.join(root, "bench_trace.json")).read().strip().splitlines()[-1])
 traffic = rd * 128.0 + write_kb * 1024.0
-s = {"tag": tag, "kernel": kname, "launches": calls, "rocprof_avg_ms": round(tot / calls / 1e6, 4), "hip_event_avg_ms_same_run": bench["roofline"]["kernel_ms"],
+s = {"tag": tag, "workload": bench["config"]["workload"], "kernel": kname, "launches": calls, "rocprof_avg_ms": round(tot / calls / 1e6, 4), "hip_event_avg_ms_same_run": bench["roofline"]["kernel_ms"],
      "algorithmic_bytes_per_launch": algo, "FETCH_SIZE_KB": fetch_kb, "FETCH_bytes_corrected_x2": fetch_kb * 1024.0 * 2.0, "TCC_EA0_RDREQ": rd,
      "read_bytes_128B_requests": rd * 128.0, "WRITE_SIZE_KB": write_kb, "write_bytes": write_kb * 1024.0, "TCC_EA0_WRREQ": wr,
      "hbm_traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": round(traffic / algo, 3), "L2_hit_rate": round(hit / max(hit + miss, 1.0), 4),
