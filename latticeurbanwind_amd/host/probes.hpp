@@ -102,7 +102,9 @@ inline bool parse_probe(const std::string& token_in, ProbeRequest& r, std::strin
 	return parse_offset(pr_trim(rest.substr((size_t)(e2-rest.c_str()))), r.off, err);
 }
 
-// WGS84 -> UTM, forward transverse-Mercator series as the reference writes it (FX/setup.cpp:1288-1337)
+// WGS84 -> UTM: the forward transverse-Mercator series of Snyder, "Map Projections -- A Working Manual" (USGS PP 1395, 1987), eqs. 8-9, 8-10,
+// 3-21 with the WGS84 ellipsoid and k0 = 0.9996 -- the textbook form the reference uses too (FX/setup.cpp:1288-1337); the result only
+// selects a lattice column, so agreement to the last bit is not required (and is not claimed)
 inline bool utm_forward(const double lon_deg, const double lat_deg, const int zone, const bool north, double& E, double& Nn) {
 	if(zone<1||zone>60||!std::isfinite(lon_deg)||!std::isfinite(lat_deg)||lat_deg<=-90.0||lat_deg>=90.0) return false;
 	constexpr double pi = 3.1415926535897932384626433832795, a = 6378137.0, f = 1.0/298.257223563, k0 = 0.9996;
