@@ -386,8 +386,13 @@ int luw_group_scatter(luw_group* g, int field, const void* global_src) {
 				const uint32_t gy = (uint32_t)(((int64_t)y+dp->O[1]+(int64_t)gNy)%gNy), gz = (uint32_t)(((int64_t)z+dp->O[2]+(int64_t)gNz)%gNz);
 				const char* srow = src+((size_t)gy+(size_t)gz*gNy)*gNx*elem;
 				char* drow = out+(size_t)r*dp->lN[0]*elem;
-				if(dp->O[0]==0&&dp->lN[0]==gNx) { memcpy(drow, srow, (size_t)gNx*elem); return; }
-				for(uint32_t x=0u; x<dp->lN[0]; x++) { const uint32_t gx = (uint32_t)(((int64_t)x+dp->O[0]+(int64_t)gNx)%gNx); memcpy(drow+(size_t)x*elem, srow+(size_t)gx*elem, elem); }
+				// the local row is the global row from gx0 on, wrapping at the lattice edge: at most a few contiguous runs
+				for(uint32_t x=0u; x<dp->lN[0]; ) {
+					const uint32_t gx = (uint32_t)(((int64_t)x+dp->O[0]+(int64_t)gNx)%gNx);
+					const uint32_t run = std::min(dp->lN[0]-x, gNx-gx);
+					memcpy(drow+(size_t)x*elem, srow+(size_t)gx*elem, (size_t)run*elem);
+					x += run;
+				}
 			});
 		}
 	}
