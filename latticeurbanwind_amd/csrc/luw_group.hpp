@@ -533,10 +533,12 @@ int luw_group_stats_reset(luw_group* g) {
 int luw_group_stats_download(luw_group* g, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, float* avg_T, uint64_t* count) {
 	if(!g) return fail(LUW_ERR_INVALID, "luw_group_stats_download: null group");
 	const uint32_t gNx = g->gN[0], gNy = g->gN[1];
+	uint64_t LNmax = 0ull;
+	for(const GroupDomain& d : g->dom) LNmax = std::max<uint64_t>(LNmax, (uint64_t)d.lN[0]*d.lN[1]*d.lN[2]);
+	std::unique_ptr<float[]> buf(new float[8ull*LNmax]); // avg_u (3, AoS), avg_rho, m2 x3, avg_T of ONE domain at a time: bounded by a block, faulted in once
 	for(GroupDomain& d : g->dom) {
 		GROUP_TRY(luw_set_stream(d.s, nullptr));
 		const uint64_t LN = (uint64_t)d.lN[0]*d.lN[1]*d.lN[2];
-		std::unique_ptr<float[]> buf(new float[8ull*LN]); // avg_u (3, AoS), avg_rho, m2 x3, avg_T of THIS domain: bounded by its block
 		float* lu = buf.get(); float* lr = lu+3ull*LN; float* l2[3] = { lr+LN, lr+2ull*LN, lr+3ull*LN }; float* lT = lr+4ull*LN;
 		uint64_t cnt = 0ull;
 		GROUP_TRY(luw_stats_download(d.s, avg_u ? lu : nullptr, avg_rho ? lr : nullptr, m2_u ? l2[0] : nullptr, m2_v ? l2[1] : nullptr, m2_w ? l2[2] : nullptr, &cnt));
