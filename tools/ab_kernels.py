@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of kernel variants on the SAME solver object (same device memory, so placement effects cancel): alternates
 luw_set_kernel between the listed variants, 40 steps each, several rounds.
+Needs the tools build of the library (make -C latticeurbanwind_amd/csrc ab -> tools/libluw_core_ab.so): the product library has no variants.
 usage: ab_kernels.py [f32|fp16c] Nx Ny Nz kernelA kernelB ...   (names: scalar, general, cached, nt_all)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +9,7 @@ import ctypes as C
 import latticeurbanwind_amd as luw
 from latticeurbanwind_amd import capi
 from bench import channel_state
+capi.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libluw_core_ab.so"))
 
 NAMES = {"scalar": capi.KERNEL_SCALAR, "general": capi.KERNEL_SCALAR_GENERAL, "cached": capi.KERNEL_SCALAR_CACHED, "nt_all": capi.KERNEL_SCALAR_NT_ALL}
 dt = sys.argv[1]; N = tuple(int(v) for v in sys.argv[2:5]); kernels = sys.argv[5:] or ["scalar", "general"]
