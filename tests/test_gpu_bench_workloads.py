@@ -74,6 +74,32 @@ def test_c3_fp16c_coriolis_vs_oracle(luw):
     run_workload_vs_oracle(luw, (1024, 1024, 256), True, True, chunks=(3,), coriolis=True)
 
 
+def test_c3_shipped_configuration_thermal_fp16c_vs_oracle(luw):
+    """what the reference's SHIPPED build runs on configs[2]'s lattice: FP16C DDFs AND the thermal D3Q7 lattice (scalar kernel with
+    the thermal cell update), here with heat sources (TYPE_T presets on 3 % of the fluid cells): rho, u, T, all 19 + 7 planes"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from bench import fill_channel, NU
+    from helpers import thermal_state
+    from oracle import oracle
+    Nx, Ny, Nz = 1024, 1024, 256
+    g = luw.LBM(Nx, Ny, Nz, NU, fp16c=True, alpha=2.1e-7)
+    try:
+        fill_channel(g.flags.data, g.u.data, g.rho.data, Nx, Ny, Nz, buildings=True)
+        tflags, T = thermal_state(g.flags.data, (Nx, Ny, Nz))
+        g.flags.data[:] = tflags; g.T.data[:] = T
+        o = oracle.OracleLBM(Nx, Ny, Nz, NU, fp16c=True, alpha=2.1e-7)
+        o.flags[:] = tflags; o.u[:] = g.u.data; o.rho[:] = g.rho.data; o.T[:] = T
+        g.run(0); o.initialize()
+        g.run(3); o.run(3)
+        g.u.read_from_device(); g.rho.read_from_device(); g.T.read_from_device()
+        assert np.array_equal(g.rho.data, o.rho) and planes_equal(g.u.data, o.u, 3)
+        assert np.array_equal(g.T.data, o.T) and float(o.T.std()) > 1e-4
+        assert planes_equal(g.download_fi(), o.fi, 19, True) and planes_equal(g.download_gi(), o.gi, 7, True)
+    finally:
+        g.close()
+
+
 RANK_CASES = [
     # dtype, per-GPU block, n_gpu, rank, options
     ("f32", (2048, 256, 256), (1, 4, 2), 0, ("bld", "forcing")),            # configs[3], bench default cut; rank 0: ground, west/east/south faces
