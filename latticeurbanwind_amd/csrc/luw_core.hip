@@ -287,7 +287,9 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 #endif
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
 	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid (both are product code, same values)
-	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Np*sizeof(T)<=(1ull<<32) && !force_row;
+	// (in-plane offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with
+	// its 2^32-byte planes still qualifies: its largest offset is 2^32 - 4)
+	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*sizeof(T)<=(1ull<<32) && !force_row;
 	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
 	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
 	if(st) { // a sampled step of the product kernel (can_fuse_stats): the Welford update rides on the cell update

@@ -64,8 +64,8 @@ def test_c2_512cubed_fp32_vs_oracle(luw):
 
 @pytest.mark.parametrize("fp16c", [False, True])
 def test_c3_building_cluster_vs_oracle(luw, fp16c):
-    """BASELINE configs[2] = the driver's N = 1 bench line: 1024x1024x256 with the building array; FP32 (scalar kernel, row
-    addressing: planes exceed 2^32 bytes) and FP16C (pair kernel)"""
+    """BASELINE configs[2] = the driver's N = 1 bench line: 1024x1024x256 with the building array; FP32 (scalar kernel) and FP16C
+    (pair kernel)"""
     run_workload_vs_oracle(luw, (1024, 1024, 256), fp16c, True)
 
 

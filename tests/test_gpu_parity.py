@@ -385,3 +385,6 @@ def test_1024_cubed_on_one_gpu_properties():
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    # (its 2^32-byte planes are the largest the flat addressing form takes: byte offsets up to 2^32 - 4.)  The row form at the same size:
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, LUW_ADDR_ROW="1"))
+    assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
