@@ -383,8 +383,12 @@ def test_1024_cubed_on_one_gpu_properties():
     size).  No oracle at 1.07 G cells: the rest state must be an exact fixed point and a periodic shear wave must conserve mass
     (tools/check_huge.py, in a child process so that its 35 GB of host arrays are gone afterwards)."""
     import subprocess, sys
+    import re
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
-    # (its 2^32-byte planes are the largest the flat addressing form takes: byte offsets up to 2^32 - 4.)  The row form at the same size:
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, LUW_ADDR_ROW="1"))
-    assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    # (its 2^32-byte planes are the largest the flat addressing form takes: byte offsets up to 2^32 - 4.)  The row form at the same size
+    # must leave the same 4.3 G values, bit for bit (digest over rho and u):
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, LUW_ADDR_ROW="1"))
+    assert r2.returncode == 0 and "exact fixed point = True" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-1500:]
+    d1, d2 = re.search(r"digest (xor=\w+ sum=\w+)", r.stdout), re.search(r"digest (xor=\w+ sum=\w+)", r2.stdout)
+    assert d1 and d2 and d1.group(1) == d2.group(1), (d1 and d1.group(1), d2 and d2.group(1))
