@@ -32,6 +32,7 @@ struct GroupDomain {
 	Box whole{}, interior{};
 	std::vector<Box> shell;
 	std::vector<uint32_t> gather_src;         // probe gather: positions of this domain's cells in the caller's list
+	uint64_t packed_seq[2][3] = {}, unpacked_seq[2][3] = {}; // [DDFs / thermal][axis]: number of the last exchange whose pack / unpack this domain has enqueued (threaded runs)
 };
 
 struct luw_group {
@@ -42,6 +43,7 @@ struct luw_group {
 	bool overlap = false, initialized = false, thermal = false;
 	size_t ddf_bytes = 4u;
 	uint64_t t = 0ull;
+	uint64_t exchanges = 0ull;                // halo exchanges done by luw_group_run calls (threaded runs number them)
 	uint32_t gather_total = 0u;
 };
 
@@ -101,42 +103,46 @@ static void group_free(luw_group* g) {
 #define GROUP_TRY(call) do { if(int e_ = (call)) return e_; } while(0)
 static int group_set_device(const GroupDomain& d) { HIP_TRY(hipSetDevice(d.device)); return LUW_OK; }
 
-// ---- the halo exchange of one field (G = false: 5 DDFs per face cell; true: the thermal lattice's single population), all split
-// axes in the order x, y, z, on the domains' communication streams (or the stream given by `on_compute`)
+// ---- the halo exchange of one field (thermal_pass false: 5 DDFs per face cell; true: the thermal lattice's single population), per
+// domain and axis in two halves: pack (into the neighbours' receive buffers: peer stores, or staged through a copy) and unpack (once
+// both neighbours have delivered).  On the domain's communication stream, or its compute stream (on_compute).
+static int domain_pack(luw_group* g, const size_t i, const int a, const bool thermal_pass, const bool on_compute) {
+	GroupDomain& d = g->dom[i];
+	hipStream_t st = on_compute ? d.compute : d.comm;
+	GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
+	hipEvent_t* unp = thermal_pass ? P.gunpacked : P.unpacked; hipEvent_t* unm = thermal_pass ? M.gunpacked : M.unpacked;
+	HIP_TRY(hipStreamWaitEvent(st, unp[a], 0)); HIP_TRY(hipStreamWaitEvent(st, unm[a], 0)); // the neighbours have consumed what the previous step put there
+	// my + face lands in the + neighbour's "from the - side" buffer, my - face in the - neighbour's "from the + side" buffer
+	void* dst_p = (thermal_pass ? P.grecv : P.recv)[a][1]; void* dst_m = (thermal_pass ? M.grecv : M.recv)[a][0];
+	const bool direct = g->peer[i][d.nbr[a][0]]&&g->peer[i][d.nbr[a][1]];
+	void* out_p = direct ? dst_p : (thermal_pass ? d.gsend : d.send)[a][0]; void* out_m = direct ? dst_m : (thermal_pass ? d.gsend : d.send)[a][1];
+	GROUP_TRY(luw_set_stream(d.s, st));
+	GROUP_TRY(thermal_pass ? luw_enqueue_extract_gi(d.s, (uint32_t)a, out_p, out_m) : luw_enqueue_extract_fi(d.s, (uint32_t)a, out_p, out_m));
+	if(!direct) {
+		const size_t bytes = (size_t)luw_get_area(d.s, (uint32_t)a)*(thermal_pass ? 1u : 5u)*g->ddf_bytes;
+		HIP_TRY(hipMemcpyPeerAsync(dst_p, P.device, out_p, d.device, bytes, st));
+		HIP_TRY(hipMemcpyPeerAsync(dst_m, M.device, out_m, d.device, bytes, st));
+	}
+	HIP_TRY(hipEventRecord((thermal_pass ? d.gpacked : d.packed)[a], st));
+	return LUW_OK;
+}
+static int domain_unpack(luw_group* g, const size_t i, const int a, const bool thermal_pass, const bool on_compute) {
+	GroupDomain& d = g->dom[i];
+	hipStream_t st = on_compute ? d.compute : d.comm;
+	GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
+	HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? P.gpacked : P.packed)[a], 0));
+	HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? M.gpacked : M.packed)[a], 0));
+	GROUP_TRY(luw_set_stream(d.s, st));
+	GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]) : luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
+	HIP_TRY(hipEventRecord((thermal_pass ? d.gunpacked : d.unpacked)[a], st));
+	return LUW_OK;
+}
+// one host thread for all domains: every domain packs, then every domain unpacks, axis by axis
 static int group_exchange(luw_group* g, const bool thermal_pass, const bool on_compute) {
 	for(int a=0; a<3; a++) {
 		if(!g->H[a]) continue;
-		for(size_t i=0; i<g->dom.size(); i++) { // pack: into the neighbours' receive buffers (peer stores) or staged through a copy
-			GroupDomain& d = g->dom[i];
-			GROUP_TRY(group_set_device(d));
-			hipStream_t st = on_compute ? d.compute : d.comm;
-			GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
-			hipEvent_t* unp = thermal_pass ? P.gunpacked : P.unpacked; hipEvent_t* unm = thermal_pass ? M.gunpacked : M.unpacked;
-			HIP_TRY(hipStreamWaitEvent(st, unp[a], 0)); HIP_TRY(hipStreamWaitEvent(st, unm[a], 0)); // the neighbours have consumed what the previous step put there
-			// my + face lands in the + neighbour's "from the - side" buffer, my - face in the - neighbour's "from the + side" buffer
-			void* dst_p = (thermal_pass ? P.grecv : P.recv)[a][1]; void* dst_m = (thermal_pass ? M.grecv : M.recv)[a][0];
-			const bool direct = g->peer[i][d.nbr[a][0]]&&g->peer[i][d.nbr[a][1]];
-			void* out_p = direct ? dst_p : (thermal_pass ? d.gsend : d.send)[a][0]; void* out_m = direct ? dst_m : (thermal_pass ? d.gsend : d.send)[a][1];
-			GROUP_TRY(luw_set_stream(d.s, st));
-			GROUP_TRY(thermal_pass ? luw_enqueue_extract_gi(d.s, (uint32_t)a, out_p, out_m) : luw_enqueue_extract_fi(d.s, (uint32_t)a, out_p, out_m));
-			if(!direct) {
-				const size_t bytes = (size_t)luw_get_area(d.s, (uint32_t)a)*(thermal_pass ? 1u : 5u)*g->ddf_bytes;
-				HIP_TRY(hipMemcpyPeerAsync(dst_p, P.device, out_p, d.device, bytes, st));
-				HIP_TRY(hipMemcpyPeerAsync(dst_m, M.device, out_m, d.device, bytes, st));
-			}
-			HIP_TRY(hipEventRecord((thermal_pass ? d.gpacked : d.packed)[a], st));
-		}
-		for(size_t i=0; i<g->dom.size(); i++) { // unpack once both neighbours have delivered
-			GroupDomain& d = g->dom[i];
-			GROUP_TRY(group_set_device(d));
-			hipStream_t st = on_compute ? d.compute : d.comm;
-			GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
-			HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? P.gpacked : P.packed)[a], 0));
-			HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? M.gpacked : M.packed)[a], 0));
-			GROUP_TRY(luw_set_stream(d.s, st));
-			GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]) : luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
-			HIP_TRY(hipEventRecord((thermal_pass ? d.gunpacked : d.unpacked)[a], st));
-		}
+		for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_pack(g, i, a, thermal_pass, on_compute)); }
+		for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_unpack(g, i, a, thermal_pass, on_compute)); }
 	}
 	return LUW_OK;
 }
@@ -153,6 +159,104 @@ static int group_join(luw_group* g) {
 	return LUW_OK;
 }
 
+// what one step means for one domain, besides the exchange: kernels of step i of a luw_group_run call
+struct GroupStepPlan { bool sampled, fused, separate; int wf; };
+static int domain_plan_step(luw_group* g, const size_t k, const uint64_t i, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, GroupStepPlan& pl) {
+	const bool every = (g->gcfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
+	pl.sampled = stride>0ull && i+1ull>=first_sample && (i+1ull-first_sample)%stride==0ull;
+	pl.fused = false;
+	if(pl.sampled) { int f = 0; GROUP_TRY(luw_stats_begin_sample(g->dom[k].s, &f)); pl.fused = f!=0; } // every domain answers alike (same kernels everywhere)
+	pl.separate = pl.sampled&&!pl.fused;
+	pl.wf = ((every||i+1ull==steps||pl.separate) ? 1 : 0)|(pl.fused ? LUW_WF_SAMPLE : 0);
+	return LUW_OK;
+}
+static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1) {
+	GroupDomain& d = g->dom[k];
+	const int wf = pl.wf;
+	if(g->overlap) {
+		if((wf&1)&&d.stats_pending) { HIP_TRY(hipStreamWaitEvent(d.comm, d.stats_done, 0)); d.stats_pending = false; } // this step's shell rewrites the rho,u the last sample reads
+		HIP_TRY(hipStreamWaitEvent(d.compute, d.shell_done, 0));   // interior(t) needs shell(t-1) ...
+		HIP_TRY(hipStreamWaitEvent(d.comm, d.interior_done, 0));   // ... shell(t) needs interior(t-1); both no-ops before the first record
+		if(d.s->vk_active) { // pre_step_update (FX/setup.cpp:4872): rewrites u on TYPE_E inlet cells, read by shell and interior
+			GROUP_TRY(luw_set_stream(d.s, d.compute)); GROUP_TRY(luw_vk_inlet_apply(d.s));
+			HIP_TRY(hipEventRecord(d.pre_done, d.compute)); HIP_TRY(hipStreamWaitEvent(d.comm, d.pre_done, 0));
+		}
+		GROUP_TRY(luw_set_stream(d.s, d.comm));
+		for(const Box& b : d.shell) GROUP_TRY(luw_enqueue_stream_collide(d.s, b.x0, b.x1, b.y0, b.y1, b.z0, b.z1, wf)); // boundary shell first ...
+		HIP_TRY(hipEventRecord(d.shell_done, d.comm));
+		GROUP_TRY(luw_set_stream(d.s, d.compute));
+		if(t0) HIP_TRY(hipEventRecord(t0, d.compute));
+		GROUP_TRY(luw_enqueue_stream_collide(d.s, d.interior.x0, d.interior.x1, d.interior.y0, d.interior.y1, d.interior.z0, d.interior.z1, wf)); // ... interior overlaps the halo traffic
+		if(t1) HIP_TRY(hipEventRecord(t1, d.compute));
+		HIP_TRY(hipEventRecord(d.interior_done, d.compute));
+	} else {
+		GROUP_TRY(luw_set_stream(d.s, d.compute));
+		if(d.s->vk_active) GROUP_TRY(luw_vk_inlet_apply(d.s));
+		if(t0) HIP_TRY(hipEventRecord(t0, d.compute));
+		GROUP_TRY(luw_enqueue_stream_collide(d.s, d.whole.x0, d.whole.x1, d.whole.y0, d.whole.y1, d.whole.z0, d.whole.z1, wf));
+		if(t1) HIP_TRY(hipEventRecord(t1, d.compute));
+	}
+	return LUW_OK;
+}
+static int domain_separate_stats(luw_group* g, const size_t k) { // thermal lattice / no fused statistics: the step wrote rho,u; the statistics kernel follows on the compute stream
+	GroupDomain& d = g->dom[k];
+	if(g->overlap) HIP_TRY(hipStreamWaitEvent(d.compute, d.shell_done, 0));
+	GROUP_TRY(luw_set_stream(d.s, d.compute));
+	d.s->fields_current = true;
+	GROUP_TRY(luw_stats_accumulate(d.s));
+	HIP_TRY(hipEventRecord(d.stats_done, d.compute)); d.stats_pending = true;
+	return LUW_OK;
+}
+
+// ---- one host thread PER DOMAIN (opt-in, LUW_GROUP_THREADS=1; for hosts where one enqueueing thread -- ~25 runtime calls per domain and
+// step -- would not keep eight devices busy).
+// A stream can only wait for an event that has already been RECORDED (hipStreamWaitEvent on an unrecorded event is a no-op), and the
+// records now happen in other threads: each domain publishes, per axis, the number of the last exchange whose pack / unpack it has
+// enqueued (a release store behind the hipEventRecord), and a neighbour spins on that number (acquire) before it enqueues its wait.
+// The same numbers keep an event from being re-recorded before every neighbour has enqueued its wait on the previous record.
+struct GroupThreads {
+	std::atomic<int> abort{0};
+	std::vector<std::string> error;
+};
+static bool group_wait_seq(const uint64_t* seq, const uint64_t want, const std::atomic<int>& abort) {
+	for(uint64_t spins=0ull; __atomic_load_n(seq, __ATOMIC_ACQUIRE)<want; spins++) {
+		if(abort.load(std::memory_order_relaxed)) return false;
+		if(spins>64ull) std::this_thread::yield();
+	}
+	return true;
+}
+static int domain_exchange_threaded(luw_group* g, const size_t k, const bool thermal_pass, const bool on_compute, const uint64_t X, GroupThreads& T) {
+	GroupDomain& d = g->dom[k];
+	const int f = thermal_pass ? 1 : 0;
+	for(int a=0; a<3; a++) {
+		if(!g->H[a]) continue;
+		GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
+		// the neighbours have enqueued (and recorded) the unpack of the previous exchange: their buffers may be written again after it
+		if(!group_wait_seq(&P.unpacked_seq[f][a], X-1ull, T.abort)||!group_wait_seq(&M.unpacked_seq[f][a], X-1ull, T.abort)) return LUW_ERR_STATE;
+		GROUP_TRY(domain_pack(g, k, a, thermal_pass, on_compute));
+		__atomic_store_n(&d.packed_seq[f][a], X, __ATOMIC_RELEASE);
+		if(!group_wait_seq(&P.packed_seq[f][a], X, T.abort)||!group_wait_seq(&M.packed_seq[f][a], X, T.abort)) return LUW_ERR_STATE;
+		GROUP_TRY(domain_unpack(g, k, a, thermal_pass, on_compute));
+		__atomic_store_n(&d.unpacked_seq[f][a], X, __ATOMIC_RELEASE);
+	}
+	return LUW_OK;
+}
+static int domain_run_threaded(luw_group* g, const size_t k, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, std::vector<hipEvent_t>* tev, const uint64_t X0, GroupThreads& T) {
+	GroupDomain& d = g->dom[k];
+	GROUP_TRY(group_set_device(d)); // per host thread
+	for(uint64_t i=0ull; i<steps; i++) {
+		GroupStepPlan pl;
+		GROUP_TRY(domain_plan_step(g, k, i, steps, first_sample, stride, pl));
+		GROUP_TRY(domain_launch_step(g, k, pl, tev ? (*tev)[2u*i] : nullptr, tev ? (*tev)[2u*i+1u] : nullptr));
+		GROUP_TRY(domain_exchange_threaded(g, k, false, !g->overlap, X0+i+1ull, T));
+		if(g->thermal) GROUP_TRY(domain_exchange_threaded(g, k, true, !g->overlap, X0+i+1ull, T));
+		if(pl.separate) GROUP_TRY(domain_separate_stats(g, k));
+		GROUP_TRY(luw_increment_time_step(d.s, 1ull));
+	}
+	HIP_TRY(hipStreamSynchronize(d.comm)); HIP_TRY(hipStreamSynchronize(d.compute));
+	return LUW_OK;
+}
+
 static int group_run(luw_group* g, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, double* mean_kernel_ms) {
 	if(!g) return fail(LUW_ERR_INVALID, "luw_group_run: null group");
 	if(!g->initialized) GROUP_TRY(luw_group_initialize(g));
@@ -166,62 +270,46 @@ static int group_run(luw_group* g, const uint64_t steps, const uint64_t first_sa
 		g->t = luw_get_t(s);
 		return e;
 	}
-	const bool every = (g->gcfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
 	std::vector<hipEvent_t> tev; // timing of domain 0's interior / whole-box launch
-	struct TevFree { std::vector<hipEvent_t>& v; ~TevFree() { for(hipEvent_t e : v) (void)hipEventDestroy(e); } } tev_free{ tev };
-	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.resize(2u*steps); for(auto& e : tev) { e = nullptr; HIP_TRY(hipEventCreate(&e)); } }
-	for(uint64_t i=0ull; i<steps; i++) {
-		const bool sampled = stride>0ull && i+1ull>=first_sample && (i+1ull-first_sample)%stride==0ull;
-		bool fused = false;
-		if(sampled) { // every domain answers alike (same kernels everywhere)
-			for(GroupDomain& d : g->dom) { int f = 0; GROUP_TRY(luw_stats_begin_sample(d.s, &f)); fused = f!=0; }
-		}
-		const bool separate = sampled&&!fused;
-		const int wf = ((every||i+1ull==steps||separate) ? 1 : 0)|(fused ? LUW_WF_SAMPLE : 0);
-		for(size_t k=0; k<g->dom.size(); k++) {
-			GroupDomain& d = g->dom[k];
-			GROUP_TRY(group_set_device(d));
-			if(g->overlap) {
-				if((wf&1)&&d.stats_pending) { HIP_TRY(hipStreamWaitEvent(d.comm, d.stats_done, 0)); d.stats_pending = false; } // this step's shell rewrites the rho,u the last sample reads
-				HIP_TRY(hipStreamWaitEvent(d.compute, d.shell_done, 0));   // interior(t) needs shell(t-1) ...
-				HIP_TRY(hipStreamWaitEvent(d.comm, d.interior_done, 0));   // ... shell(t) needs interior(t-1); both no-ops before the first record
-				if(d.s->vk_active) { // pre_step_update (FX/setup.cpp:4872): rewrites u on TYPE_E inlet cells, read by shell and interior
-					GROUP_TRY(luw_set_stream(d.s, d.compute)); GROUP_TRY(luw_vk_inlet_apply(d.s));
-					HIP_TRY(hipEventRecord(d.pre_done, d.compute)); HIP_TRY(hipStreamWaitEvent(d.comm, d.pre_done, 0));
-				}
-				GROUP_TRY(luw_set_stream(d.s, d.comm));
-				for(const Box& b : d.shell) GROUP_TRY(luw_enqueue_stream_collide(d.s, b.x0, b.x1, b.y0, b.y1, b.z0, b.z1, wf)); // boundary shell first ...
-				HIP_TRY(hipEventRecord(d.shell_done, d.comm));
-				GROUP_TRY(luw_set_stream(d.s, d.compute));
-				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i], d.compute));
-				GROUP_TRY(luw_enqueue_stream_collide(d.s, d.interior.x0, d.interior.x1, d.interior.y0, d.interior.y1, d.interior.z0, d.interior.z1, wf)); // ... interior overlaps the halo traffic
-				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i+1u], d.compute));
-				HIP_TRY(hipEventRecord(d.interior_done, d.compute));
-			} else {
-				GROUP_TRY(luw_set_stream(d.s, d.compute));
-				if(d.s->vk_active) GROUP_TRY(luw_vk_inlet_apply(d.s));
-				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i], d.compute));
-				GROUP_TRY(luw_enqueue_stream_collide(d.s, d.whole.x0, d.whole.x1, d.whole.y0, d.whole.y1, d.whole.z0, d.whole.z1, wf));
-				if(mean_kernel_ms&&k==0u) HIP_TRY(hipEventRecord(tev[2u*i+1u], d.compute));
+	struct TevFree { std::vector<hipEvent_t>& v; ~TevFree() { for(hipEvent_t e : v) if(e) (void)hipEventDestroy(e); } } tev_free{ tev };
+	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.assign(2u*steps, nullptr); for(auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
+	// Default: ONE enqueueing thread (measured with eight domains on one device: 44 us per domain and step, i.e. 0.36 ms per step for eight --
+	// well inside a 1.9 ms FP16C step; profiles/r02_group_one_gpu.txt).  LUW_GROUP_THREADS=1 gives every domain its own host thread.
+	static const bool threaded = getenv("LUW_GROUP_THREADS")&&getenv("LUW_GROUP_THREADS")[0]=='1';
+	if(threaded&&steps>=4ull) { // a call of a step or two (probe windows) is not worth starting threads for
+		GroupThreads T; T.error.assign(g->dom.size(), std::string());
+		std::vector<int> rc(g->dom.size(), LUW_OK);
+		const uint64_t X0 = g->exchanges;
+		auto work = [&](const size_t k) {
+			rc[k] = domain_run_threaded(g, k, steps, first_sample, stride, (mean_kernel_ms&&k==0u) ? &tev : nullptr, X0, T);
+			if(rc[k]!=LUW_OK) { T.error[k] = g_last_error; T.abort.store(1); } // g_last_error is per thread: carry the message over
+		};
+		std::vector<std::thread> th;
+		for(size_t k=1; k<g->dom.size(); k++) th.emplace_back(work, k);
+		work(0u);
+		for(auto& x : th) x.join();
+		for(size_t k=0; k<g->dom.size(); k++) if(rc[k]!=LUW_OK&&!T.error[k].empty()) return fail(rc[k], T.error[k]);
+		for(size_t k=0; k<g->dom.size(); k++) if(rc[k]!=LUW_OK) return fail(rc[k], "luw_group_run: stopped because another domain failed");
+		g->exchanges = X0+steps; g->t += steps;
+		for(GroupDomain& d : g->dom) for(int f=0; f<2; f++) for(int a=0; a<3; a++) { d.packed_seq[f][a] = g->exchanges; d.unpacked_seq[f][a] = g->exchanges; } // axes / passes that never ran keep in step
+	} else {
+		for(uint64_t i=0ull; i<steps; i++) {
+			GroupStepPlan pl{};
+			for(size_t k=0; k<g->dom.size(); k++) {
+				GROUP_TRY(group_set_device(g->dom[k]));
+				GROUP_TRY(domain_plan_step(g, k, i, steps, first_sample, stride, pl));
+				GROUP_TRY(domain_launch_step(g, k, pl, (mean_kernel_ms&&k==0u) ? tev[2u*i] : nullptr, (mean_kernel_ms&&k==0u) ? tev[2u*i+1u] : nullptr));
 			}
+			GROUP_TRY(group_communicate(g, !g->overlap));
+			if(pl.separate) for(size_t k=0; k<g->dom.size(); k++) { GROUP_TRY(group_set_device(g->dom[k])); GROUP_TRY(domain_separate_stats(g, k)); }
+			for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull));
+			g->t++;
 		}
-		GROUP_TRY(group_communicate(g, !g->overlap));
-		if(separate) { // thermal lattice / no fused statistics: the step wrote rho,u; the statistics kernel follows on the compute stream
-			for(GroupDomain& d : g->dom) {
-				GROUP_TRY(group_set_device(d));
-				if(g->overlap) HIP_TRY(hipStreamWaitEvent(d.compute, d.shell_done, 0));
-				GROUP_TRY(luw_set_stream(d.s, d.compute));
-				d.s->fields_current = true;
-				GROUP_TRY(luw_stats_accumulate(d.s));
-				HIP_TRY(hipEventRecord(d.stats_done, d.compute)); d.stats_pending = true;
-			}
-		}
-		for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull));
-		g->t++;
+		GROUP_TRY(group_join(g));
 	}
-	GROUP_TRY(group_join(g));
 	for(GroupDomain& d : g->dom) { d.stats_pending = false; if(steps>0ull) d.s->fields_current = true; }
 	if(mean_kernel_ms) {
+		GROUP_TRY(group_set_device(g->dom[0]));
 		double sum = 0.0;
 		for(uint64_t i=0ull; i<steps; i++) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, tev[2u*i], tev[2u*i+1u])); sum += (double)ms; }
 		*mean_kernel_ms = steps ? sum/(double)steps : 0.0;

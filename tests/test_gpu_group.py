@@ -160,6 +160,30 @@ print("staged ok")
     assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
+def test_group_one_host_thread_per_domain(tmp_path):
+    """LUW_GROUP_THREADS=1: every domain is enqueued by its own host thread (calls of four steps and more; the default is one thread for
+    all), neighbours ordered through published exchange numbers: same bits as the oracle, sampled window and thermal lattice included"""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import latticeurbanwind_amd as luw
+from helpers import synthetic_state, thermal_state
+from oracle import oracle
+luw.load()
+gN, D = (32, 24, 12), (2, 2, 1)
+st = synthetic_state(*gN, seed=51, shell=None)
+tflags, T = thermal_state(st[0], gN)
+g = luw.LBMGroup(*gN, *D, 0.01, devices=[0] * 4, alpha=0.004)
+g.flags[:] = tflags; g.u[:] = st[1]; g.rho[:] = st[2]; g.T[:] = T
+g.stats_reset(); g.run(0); g.run_sampled(7, 2, 2); g.run(2); g.read_from_device(("u", "rho", "T"))
+o = oracle.OracleLBM(*gN, 0.01, alpha=0.004); o.flags[:] = tflags; o.u[:] = st[1]; o.rho[:] = st[2]; o.T[:] = T; o.run(9)
+assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho) and np.array_equal(g.T, o.T) and g.stats_download()["count"] == 3
+print("threads ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LUW_GROUP_THREADS="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 def test_group_refuses_what_the_reference_refuses(luw):
     from latticeurbanwind_amd import capi
     with pytest.raises(capi.LuwError):
