@@ -501,10 +501,15 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
 	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
 	const uint32_t Px = (cfg->Nx+63u)&~63u; // rows are whole 256-byte blocks (see lead_alloc)
-	// plane stride: the lattice plus a skew of 33 line blocks (8448 B in FP32).  With a bare power-of-two stride the 19 planes of
-	// a cell sit at the same offset of 19 equally aligned regions; the skew measured 2-4 % faster on every lattice shape tried
-	// (512^3 3.50 -> 3.40 ms, 768x768x256 3.87 -> 3.70 ms, 1024x1024x256 6.80 -> 6.69 ms; odd small multiples behave alike).
-	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz+64ull*33ull;
+	// plane stride: the lattice plus a skew of an odd number of 64-element blocks.  With a bare power-of-two stride the 19 planes of a
+	// cell sit at the same offset of 19 equally aligned regions (512^3 FP32: 3.84 ms against 3.29 ms).  How much skew is a matter of the
+	// DRAM address mapping and was measured (tools/skew_study.sh, profiles/r02_skew_study.md): FP16C is flat from 33 blocks (4 KiB) up and
+	// worse from 385 on some lattices; FP32 with 33 blocks (8 KiB, the round-1 value) depends on the GPU it lands on -- 512^3 3.30 / 3.45 /
+	// 3.64 ms and 1024x512x256 3.48 / 3.76 ms on three boxes -- while 513 blocks (128 KiB + 256 B) gave 3.28-3.30 and 3.31-3.37 ms on all of
+	// them (1024x1024x256: 6.61-6.75 ms either way).  LUW_PLANE_SKEW=<blocks> overrides (study aid).
+	static const uint64_t skew_env = getenv("LUW_PLANE_SKEW") ? strtoull(getenv("LUW_PLANE_SKEW"), nullptr, 10) : 0ull;
+	const uint64_t skew_blocks = skew_env ? skew_env : cfg->ddf_format==LUW_DDF_FP16C ? 33ull : 513ull;
+	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz+64ull*skew_blocks;
 	if(Np>=(1ull<<32)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^32 (padded) cells per domain are not supported (32-bit cell indices)");
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
