@@ -185,6 +185,39 @@ def cpu_baseline(max_seconds=20.0):
             "sample": "%d steps of a 256^3 FP32 channel (same recipe as the GPU workloads, 169 B per update incl. rho,u every step) in %.1f s, OpenMP threads swept over %s of %d usable cores" % (steps, dt, cands, cores)}
 
 
+def device_context(torch, device):
+    """What this particular GPU streams by itself, next to the contract's 8 TB/s: the same binary ran the HBM-bound FP32 step 12 % apart on
+    different MI355X boxes of the pool (profiles/r02_skew_study.md), so the line carries the box's own device-to-device copy rate (2 GiB
+    tensor copy, bytes read + written, best of 5) and the memory / fabric clock levels the driver reports right after it."""
+    ctx = {"name": torch.cuda.get_device_name(device)}
+    try:
+        n = 1 << 29                                               # 2 GiB of float32
+        src = torch.empty(n, dtype=torch.float32, device="cuda:%d" % device).fill_(1.0)
+        dst = torch.empty_like(src)
+        best = None
+        for _ in range(5):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); dst.copy_(src); e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        ctx["copy_GBps"] = round(2.0 * n * 4 / (best * 1e-3) / 1e9, 1)
+        ctx["copy_frac_of_peak"] = round(ctx["copy_GBps"] / HBM_PEAK_GBPS, 4)
+        del src, dst
+        torch.cuda.empty_cache()
+    except Exception as e:
+        ctx["copy_error"] = str(e)[:120]
+    import glob
+    for name in ("mclk", "fclk", "sclk"):
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_%s" % name)):
+            try:
+                cur = [l.strip() for l in open(path) if l.strip().endswith("*")]
+                if cur:
+                    ctx.setdefault(name, cur[0].rstrip("*").strip())
+            except OSError:
+                pass
+    return ctx
+
+
 def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False):
     return "%s_%dx%dx%d%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_cor" if coriolis else "", "_th" if thermal else "", "_uf" if every_step else "")
 
@@ -301,6 +334,9 @@ def main():
                        "global_lattice": list(size), "n_gpu": [1, 1, 1], "halo_exchange": None, "kernel": args.kernel, "bytes_per_lup": head["bytes_per_lup"], "solid_fraction": head["solid_fraction"]},
             "roofline": dict(head["roofline"], whole_job_frac=round(head["roofline"]["algorithmic_bytes_per_launch"] / (head["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)),
         }
+        out["device"] = device_context(torch, local_rank)
+        if out["device"].get("copy_GBps"):
+            out["roofline"]["frac_of_device_copy"] = round(head["roofline"]["achieved"] / out["device"]["copy_GBps"], 4)
         if not args.no_secondary:
             # the other single-GPU configurations, same process, same code path, fewer steps (each is its own create / fill / run)
             sec = {}
