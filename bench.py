@@ -375,6 +375,7 @@ def main():
     else: init_rccl_process_group(local_rank)
     urban = not args.no_buildings
     nud, spg = tile_forcing() if urban else (None, None)
+    box = device_context(torch, local_rank)                        # this rank's GPU by itself (before the lattice exists): the slowest box sets the pace of a step
 
     def run_tile(D):
         """the tile cut as n_gpu = D: returns this rank's timing block; every failure (RCCL p2p included) propagates"""
@@ -402,7 +403,8 @@ def main():
             b = sim.layout.interior_box() if sim.overlap else sim.layout.whole_box()
             mine = {"rank": rank, "device": local_rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "wall_ms_per_step": round(dt / args.steps * 1e3, 4),
                     "kernel_ms": round(tm["kernel_ms"], 4), "kernel_cells": (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]),
-                    "shell_ms": None if tm.get("shell_ms") is None else round(tm["shell_ms"], 4), "exchange_ms": None if tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4)}
+                    "shell_ms": None if tm.get("shell_ms") is None else round(tm["shell_ms"], 4), "exchange_ms": None if tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
+                    "device_copy_GBps": box.get("copy_GBps"), "mclk": box.get("mclk"), "fclk": box.get("fclk")}
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
             return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
