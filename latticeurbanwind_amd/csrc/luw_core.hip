@@ -108,7 +108,8 @@ static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, c
 	size_t gran = 0u;
 	hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
 	if(e!=hipSuccess) return e;
-	const size_t chunk = ((std::max(vmm_chunk, gran)+gran-1u)/gran)*gran, total = ((bytes+chunk-1u)/chunk)*chunk;
+	const size_t want = vmm_chunk==~(size_t)0u ? bytes : vmm_chunk;   // ~0: the whole block as one physical allocation
+	const size_t chunk = ((std::max(want, gran)+gran-1u)/gran)*gran, total = ((bytes+chunk-1u)/chunk)*chunk;
 	if((e = hipMemAddressReserve(&b.base, total, chunk, nullptr, 0ull))!=hipSuccess) { b.base = nullptr; return e; }
 	b.bytes = total; b.chunk_bytes = chunk;
 	for(size_t off=0u; off<total; off+=chunk) {
@@ -137,6 +138,7 @@ static size_t alloc_vmm_chunk() {
 		const char* e = getenv("LUW_ALLOC");
 		if(e&&strncmp(e, "malloc", 6)==0) return (size_t)0u;
 		size_t mib = 1024u;
+		if(e&&strncmp(e, "vmm:one", 7)==0) return ~(size_t)0u;     // one physical allocation per array (study aid)
 		if(e&&strncmp(e, "vmm:", 4)==0) { const size_t v = (size_t)strtoull(e+4, nullptr, 10); if(v) mib = v; }
 		return mib<<20;
 	}();
