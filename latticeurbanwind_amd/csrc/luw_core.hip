@@ -318,6 +318,24 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	#undef LUW_LAUNCH_S
 }
 
+// Can a force act on any cell of box b?  Position-only, the host's copy of in_force_zone (luw_device.hpp) for a whole box: Coriolis,
+// the volume force and the force field act everywhere; buffer nudging within Nbuf cells of the lateral faces this domain owns (not
+// the downstream one) and of the top; the sponge in the sponge_N layers under the top.
+static bool box_is_force_free(const luw_solver* s, const Box& b) {
+	const KParams& k = s->kp;
+	if(k.coriolis||k.has_F||k.fx!=0.0f||k.fy!=0.0f||k.fz!=0.0f) return false;
+	auto overlaps = [](const int64_t lo, const int64_t hi, const uint32_t b0, const uint32_t b1) { return lo<(int64_t)b1&&hi>=(int64_t)b0; }; // cells lo..hi (inclusive) against [b0, b1)
+	if(k.buffer_active) {
+		const int64_t nb = (int64_t)k.buffer_N;
+		if(k.downstream_face!=1u&&k.has_w&&overlaps(-(int64_t)k.Ox, nb-k.Ox, b.x0, b.x1)) return false;
+		if(k.downstream_face!=2u&&k.has_e&&overlaps((int64_t)k.Nxg-1-nb-k.Ox, (int64_t)k.Nxg-1-k.Ox, b.x0, b.x1)) return false;
+		if(k.downstream_face!=3u&&k.has_s&&overlaps(-(int64_t)k.Oy, nb-k.Oy, b.y0, b.y1)) return false;
+		if(k.downstream_face!=4u&&k.has_n&&overlaps((int64_t)k.Nyg-1-nb-k.Oy, (int64_t)k.Nyg-1-k.Oy, b.y0, b.y1)) return false;
+		if(k.has_t&&overlaps((int64_t)k.Nzg-1-nb-k.Oz, (int64_t)k.Nzg-1-k.Oz, b.z0, b.z1)) return false;
+	}
+	if(k.sponge_active&&k.has_t&&overlaps((int64_t)k.Nzg-1-(int64_t)k.sponge_N-k.Oz, (int64_t)k.Nzg-2-k.Oz, b.z0, b.z1)) return false;
+	return true;
+}
 static void launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	uint16_t* fi = (uint16_t*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
@@ -331,6 +349,12 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
 #endif
+	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where no force can act (same values)
+	if(!general_only&&box_is_force_free(s, b)) { // nothing can push these cells: the kernel without the force path, 5 waves per SIMD
+		if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 0, false, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{});
+		else hipLaunchKernelGGL((k_stream_collide_p<0, 0, false, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{});
+		return;
+	}
 	if(odd) hipLaunchKernelGGL((k_stream_collide_p<1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
