@@ -12,8 +12,8 @@ out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 bench = json.loads(open(os.path.join(root, "bench_trace.json")).read().strip().splitlines()[-1])
 algo = float(sys.argv[3]) if len(sys.argv) > 3 else float(bench["roofline"]["algorithmic_bytes_per_launch"])
 
-def one(pattern):
-    return glob.glob(os.path.join(root, pattern))[0]
+def one(pattern):   # the newest match: gpurun_out/ keeps the files of earlier runs of the same tag
+    return max(glob.glob(os.path.join(root, pattern)), key=os.path.getmtime)
 
 stats = one("trace/*/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(out, tag + "_kernel_stats.csv"))
