@@ -318,23 +318,36 @@ template<typename T> static void launch_scalar(luw_solver* s, const Box& b, cons
 	#undef LUW_LAUNCH_S
 }
 
-// Can a force act on any cell of box b?  Position-only, the host's copy of in_force_zone (luw_device.hpp) for a whole box: Coriolis,
-// the volume force and the force field act everywhere; buffer nudging within Nbuf cells of the lateral faces this domain owns (not
-// the downstream one) and of the top; the sponge in the sponge_N layers under the top.
-static bool box_is_force_free(const luw_solver* s, const Box& b) {
+// Where the position-dependent forces of this domain act, as cell ranges per face (the host's copy of in_force_zone, luw_device.hpp): buffer
+// nudging within Nbuf cells of the lateral faces the domain owns (not the downstream one) and of the top, the sponge in the sponge_N layers
+// under the top.  lo[a] / hi[a]: the first cell behind the zone at the low face of axis a / the first cell of the zone at its high face
+// (0 / N when there is none): cells of [lo, hi) on all three axes are outside every zone.
+static void force_free_core(const luw_solver* s, uint32_t lo[3], uint32_t hi[3]) {
 	const KParams& k = s->kp;
-	if(k.coriolis||k.has_F||k.fx!=0.0f||k.fy!=0.0f||k.fz!=0.0f) return false;
-	auto overlaps = [](const int64_t lo, const int64_t hi, const uint32_t b0, const uint32_t b1) { return lo<(int64_t)b1&&hi>=(int64_t)b0; }; // cells lo..hi (inclusive) against [b0, b1)
+	const int64_t N[3] = { (int64_t)k.Nx, (int64_t)k.Ny, (int64_t)k.Nz };
+	int64_t l[3] = { 0, 0, 0 }, h[3] = { N[0], N[1], N[2] };
 	if(k.buffer_active) {
 		const int64_t nb = (int64_t)k.buffer_N;
-		if(k.downstream_face!=1u&&k.has_w&&overlaps(-(int64_t)k.Ox, nb-k.Ox, b.x0, b.x1)) return false;
-		if(k.downstream_face!=2u&&k.has_e&&overlaps((int64_t)k.Nxg-1-nb-k.Ox, (int64_t)k.Nxg-1-k.Ox, b.x0, b.x1)) return false;
-		if(k.downstream_face!=3u&&k.has_s&&overlaps(-(int64_t)k.Oy, nb-k.Oy, b.y0, b.y1)) return false;
-		if(k.downstream_face!=4u&&k.has_n&&overlaps((int64_t)k.Nyg-1-nb-k.Oy, (int64_t)k.Nyg-1-k.Oy, b.y0, b.y1)) return false;
-		if(k.has_t&&overlaps((int64_t)k.Nzg-1-nb-k.Oz, (int64_t)k.Nzg-1-k.Oz, b.z0, b.z1)) return false;
+		if(k.downstream_face!=1u&&k.has_w) l[0] = std::max<int64_t>(l[0], nb-k.Ox+1);
+		if(k.downstream_face!=2u&&k.has_e) h[0] = std::min<int64_t>(h[0], (int64_t)k.Nxg-1-nb-k.Ox);
+		if(k.downstream_face!=3u&&k.has_s) l[1] = std::max<int64_t>(l[1], nb-k.Oy+1);
+		if(k.downstream_face!=4u&&k.has_n) h[1] = std::min<int64_t>(h[1], (int64_t)k.Nyg-1-nb-k.Oy);
+		if(k.has_t) h[2] = std::min<int64_t>(h[2], (int64_t)k.Nzg-1-nb-k.Oz);
 	}
-	if(k.sponge_active&&k.has_t&&overlaps((int64_t)k.Nzg-1-(int64_t)k.sponge_N-k.Oz, (int64_t)k.Nzg-2-k.Oz, b.z0, b.z1)) return false;
-	return true;
+	if(k.sponge_active&&k.has_t) h[2] = std::min<int64_t>(h[2], (int64_t)k.Nzg-1-(int64_t)k.sponge_N-k.Oz);
+	for(int a=0; a<3; a++) { lo[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(l[a], 0), N[a]); hi[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(h[a], (int64_t)lo[a]), N[a]); }
+}
+// what can push the cells of box b (collide_cell_pk): re-evaluated per launch, so luw_set_f / luw_set_coriolis take effect at once.
+// (Cutting a box that reaches into the zones along their boundaries -- specialised kernel on the zone-free core, general kernels on six slabs
+// around it -- was built and measured on the 512^3 urban tile with its 80-cell nudging zones and 100-layer sponge: 2.36-2.38 ms in one
+// launch, 2.41-2.46 ms cut; the core is a third of the cells there and the slabs cost more than it gains.  One launch per box it stays.)
+static int pair_force_mode(const luw_solver* s, const Box& b) {
+	const KParams& k = s->kp;
+	if(k.has_F) return PAIR_FORCE_ANY;
+	uint32_t lo[3], hi[3];
+	force_free_core(s, lo, hi);
+	if(b.x0<lo[0]||b.x1>hi[0]||b.y0<lo[1]||b.y1>hi[1]||b.z0<lo[2]||b.z1>hi[2]) return PAIR_FORCE_ANY;
+	return (k.coriolis||k.fx!=0.0f||k.fy!=0.0f||k.fz!=0.0f) ? PAIR_FORCE_UNIFORM : PAIR_FORCE_NONE;
 }
 static void launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	uint16_t* fi = (uint16_t*)s->d_fi;
@@ -349,12 +362,12 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
 #endif
-	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where no force can act (same values)
-	if(!general_only&&box_is_force_free(s, b)) { // nothing can push these cells: the kernel without the force path, 5 waves per SIMD
-		if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 0, false, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{});
-		else hipLaunchKernelGGL((k_stream_collide_p<0, 0, false, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{});
-		return;
-	}
+	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where a specialisation would do (same values)
+	const int mode = general_only ? PAIR_FORCE_ANY : pair_force_mode(s, b);
+	#define LUW_LAUNCH_P(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
+	if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_NONE); else LUW_LAUNCH_P(0, PAIR_FORCE_NONE); return; }       // nothing can push these cells: no force path, 5 waves per SIMD
+	if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_P(0, PAIR_FORCE_UNIFORM); return; } // volume force / Coriolis only
+	#undef LUW_LAUNCH_P
 	if(odd) hipLaunchKernelGGL((k_stream_collide_p<1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }

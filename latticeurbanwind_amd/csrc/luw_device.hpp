@@ -216,7 +216,9 @@ __device__ __forceinline__ void calculate_forcing_terms(const float ux, const fl
 // ---------------------------------------------------------------- LUW force assembly, FX/kernel.cpp:1516-1623
 // Adds Coriolis, buffer nudging, top sponge and the per-cell force to (fxn,fyn,fzn).  n is the device index of
 // the cell, (x,y,z) its local coordinates.  u is the device velocity field (3 planes of stride Np).
-__device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E,
+// ZONES = false: the caller knows that the cell lies outside the nudging / sponge zones and that there is no force field -- what is
+// left is the volume force and Coriolis (the uniform part)
+template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E,
 		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn, float& fzn) {
 	fxn = p.fx; fyn = p.fy; fzn = p.fz;
 	if(p.coriolis) { // with omega = 0 the three terms are +-0: adding them changes no value
@@ -227,6 +229,7 @@ __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t 
 		fyn += cor_y;
 		fzn += cor_z;
 	}
+	if constexpr(!ZONES) return;
 	if(p.buffer_active && !is_E) {
 		const int Nbuf_i = (int)p.buffer_N;
 		const int d_w_i = (int)x+p.Ox;
@@ -404,13 +407,19 @@ template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, co
 // All cases in one: wave-uniform switches for "some lane may feel a force" and "some lane is a TYPE_E cell" select the
 // extra work; a lane for which the switch is on without need computes with F = 0 (u + 0/(2 rho) = u, Fin = +-0:
 // value-identical, +-0 aside, to the scalar code's per-lane shortcut).
-// NOFORCE: the caller knows that no force can act on any cell of the launch (no Coriolis, volume force or force field, and the box
-// lies outside the nudging / sponge zones): the whole force assembly and the Guo terms are compiled out, which is what lets the
-// kernel fit 5 waves per SIMD (86 instead of 109 VGPRs, no scalar spills).  TYPE_E cells then take no selects either: the caller
-// decodes their populations as f = 0 and this routine relaxes them with w = 1, so that fma(1 - w, f, w f_eq) = fma(0, 0, f_eq) =
-// f_eq bit for bit (f_eq is never -0: an exact cancellation gives +0, and at rho = 1, u = 0 every term is +0), whatever the
-// Smagorinsky rate of such a lane came out as -- instead of keeping the nineteen equilibria for a select behind the relaxation.
-template<bool NOFORCE=false> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
+// FORCE says what the caller knows about the launch box (luw_core.hip, pair_force_mode):
+//   PAIR_FORCE_NONE     no force can act on any of its cells (no Coriolis, volume force or force field, box outside the nudging / sponge
+//                       zones): the force assembly and the Guo terms are compiled out, which is what lets the kernel fit 5 waves per SIMD
+//                       (86 instead of 109 VGPRs, no scalar spills).  TYPE_E cells then take no selects either: the caller decodes their
+//                       populations as f = 0 and this routine relaxes them with w = 1, so that fma(1 - w, f, w f_eq) = fma(0, 0, f_eq) =
+//                       f_eq bit for bit (f_eq is never -0: an exact cancellation gives +0, and at rho = 1, u = 0 every term is +0),
+//                       whatever the Smagorinsky rate of such a lane came out as -- instead of keeping the nineteen equilibria for a
+//                       select behind the relaxation;
+//   PAIR_FORCE_UNIFORM  volume force and / or Coriolis act on every cell, nothing position-dependent does: no zone tests, no wave-uniform
+//                       switch, no scalar spills (106 VGPRs);
+//   PAIR_FORCE_ANY      everything, switched per wave.
+enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
+template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
 		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
@@ -429,10 +438,12 @@ template<bool NOFORCE=false> __device__ __forceinline__ void collide_cell_pk(con
 			uzn = u[2ull*p.Np+n];
 		}
 	}
+	constexpr bool NOFORCE = FORCE==PAIR_FORCE_NONE;
+	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
 	f32x2 Finp[9]; float Fin0 = 0.0f;
-	if(!NOFORCE&&may_force) {
+	if(forced) {
 		float fxn, fyn, fzn;
-		assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
+		assemble_force<(FORCE==PAIR_FORCE_ANY)>(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
 		const float rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
 		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
@@ -459,7 +470,7 @@ template<bool NOFORCE=false> __device__ __forceinline__ void collide_cell_pk(con
 	if constexpr(NOFORCE) { if(wave_has_E) w = is_E ? 1.0f : w; }
 	const float omw = 1.0f-w;
 	float r0; f32x2 rp[9];
-	if(!NOFORCE&&may_force) {
+	if(forced) {
 		const float c_tau = fmaf(w, -0.5f, 1.0f);
 		r0 = fmaf(omw, f0, fmaf(w, feq0, Fin0*c_tau));
 		#pragma unroll

@@ -233,8 +233,8 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
 	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
 }
-// NOFORCE (plain steps only): no force can act on any cell of the box -- see collide_cell_pk; 5 waves per SIMD instead of 4.
-template<int PARITY, int MODE=0, bool STATS=false, bool NOFORCE=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NOFORCE ? 5 : 4, NOFORCE ? 5 : 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// FORCE (plain steps only): what can push the cells of the box -- see collide_cell_pk; PAIR_FORCE_NONE runs 5 waves per SIMD instead of 4.
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORCE==PAIR_FORCE_NONE ? 5 : 4, FORCE==PAIR_FORCE_NONE ? 5 : 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
@@ -283,7 +283,8 @@ template<int PARITY, int MODE=0, bool STATS=false, bool NOFORCE=false> __global_
 		});
 	}
 	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
-	const bool may_force = !NOFORCE && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull);
+	constexpr bool NOFORCE = FORCE==PAIR_FORCE_NONE;
+	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull);
 	// NOFORCE: TYPE_E cells decode to f = 0 (collide_cell_pk<true> relaxes them with w = 1)
 	[[maybe_unused]] const uint32_t dmask[2] = { (NOFORCE&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (NOFORCE&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
 	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
@@ -300,7 +301,7 @@ template<int PARITY, int MODE=0, bool STATS=false, bool NOFORCE=false> __global_
 		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
-			collide_cell_pk<NOFORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn);
+			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				rho[n+c] = rhon;
 				u[n+c] = uxn;

@@ -113,6 +113,22 @@ def test_all_force_terms(luw, kernel, fp16c):
         check(g, o, "forces t=%d" % o.t)
 
 
+@pytest.mark.parametrize("forces", ["zones", "zones+coriolis", "coriolis", "none"])
+def test_fp16c_pair_kernel_force_modes_match_oracle(luw, forces):
+    """FP16C, automatic kernel choice, a row wide enough for the pair kernel: the launch takes the instantiation that fits what can push
+    the cells of its box -- zones: everything, switched per wave; Coriolis only: uniform-force mode; nothing: no force path, 5 waves per
+    SIMD, TYPE_E lanes relaxed with w = 1.  Every case equals the oracle bit for bit."""
+    from oracle import oracle
+    Nx, Ny, Nz = 648, 28, 26
+    nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1) if "zones" in forces else None
+    spg = dict(n_cells=4, inv_tau=0.02) if "zones" in forces else None
+    cor = (0.0, 3e-5, 4e-5) if "coriolis" in forces else None
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, True, "auto", synthetic_state(Nx, Ny, Nz, seed=21, shell="luw"), coriolis=cor, nudging=nud, sponge=spg, every_step=False)
+    for _ in range(2):
+        g.run(5); o.run(5)
+        check(g, o, "force mode %s t=%d" % (forces, o.t))
+
+
 @pytest.mark.parametrize("kernel", ["s", "p"])
 def test_deferred_field_update_equals_every_step(luw, kernel):
     # default mode writes rho,u only in the last step of a run() call; observed values must equal UPDATE_FIELDS
