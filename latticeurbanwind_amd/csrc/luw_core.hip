@@ -277,47 +277,6 @@ static uint32_t row_block(const uint32_t nx) {
 	for(uint32_t bx : {192u, 128u, 64u}) { const uint32_t lanes = ((nx+bx-1u)/bx)*bx; if(lanes<best_lanes) { best = bx; best_lanes = lanes; } }
 	return best;
 }
-template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
-	T* fi = (T*)s->d_fi;
-	const bool odd = (s->t&1ull)!=0ull;
-	const int xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
-	const uint32_t nx = (uint32_t)((int)b.x1-xa);
-	const uint32_t bx = row_block(nx);
-	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-#ifdef LUW_AB_KERNELS
-	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
-#endif
-	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
-	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid (both are product code, same values)
-	// (in-plane offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with
-	// its 2^32-byte planes still qualifies: its largest offset is 2^32 - 4)
-	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*sizeof(T)<=(1ull<<32) && !force_row;
-	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
-	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
-	if(st) { // a sampled step of the product kernel (can_fuse_stats): the Welford update rides on the cell update
-		#define LUW_LAUNCH_ST(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 0, 2, FL, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, *st)
-		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_ST(1, true); else LUW_LAUNCH_ST(0, true); } else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); } }
-		else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); }
-		#undef LUW_LAUNCH_ST
-	}
-	else if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
-		#define LUW_LAUNCH_T(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 4, 2, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T)
-		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_T(1, true); else LUW_LAUNCH_T(0, true); } else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); } }
-		else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); }
-		#undef LUW_LAUNCH_T
-	}
-#ifdef LUW_AB_KERNELS
-	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
-	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
-	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
-	else if(mode==5) { if(odd) LUW_LAUNCH_S(1, 3, 2); else LUW_LAUNCH_S(0, 3, 2); }
-	else if(mode==4) { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
-#endif
-	else { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }   // the product kernel
-	#undef LUW_LAUNCH_SF
-	#undef LUW_LAUNCH_S
-}
-
 // Where the position-dependent forces of this domain act, as cell ranges per face (the host's copy of in_force_zone, luw_device.hpp): buffer
 // nudging within Nbuf cells of the lateral faces the domain owns (not the downstream one) and of the top, the sponge in the sponge_N layers
 // under the top.  lo[a] / hi[a]: the first cell behind the zone at the low face of axis a / the first cell of the zone at its high face
@@ -341,7 +300,7 @@ static void force_free_core(const luw_solver* s, uint32_t lo[3], uint32_t hi[3])
 // (Cutting a box that reaches into the zones along their boundaries -- specialised kernel on the zone-free core, general kernels on six slabs
 // around it -- was built and measured on the 512^3 urban tile with its 80-cell nudging zones and 100-layer sponge: 2.36-2.38 ms in one
 // launch, 2.41-2.46 ms cut; the core is a third of the cells there and the slabs cost more than it gains.  One launch per box it stays.)
-static int pair_force_mode(const luw_solver* s, const Box& b) {
+static int box_force_mode(const luw_solver* s, const Box& b) {
 	const KParams& k = s->kp;
 	if(k.has_F) return PAIR_FORCE_ANY;
 	uint32_t lo[3], hi[3];
@@ -349,6 +308,59 @@ static int pair_force_mode(const luw_solver* s, const Box& b) {
 	if(b.x0<lo[0]||b.x1>hi[0]||b.y0<lo[1]||b.y1>hi[1]||b.z0<lo[2]||b.z1>hi[2]) return PAIR_FORCE_ANY;
 	return (k.coriolis||k.fx!=0.0f||k.fy!=0.0f||k.fz!=0.0f) ? PAIR_FORCE_UNIFORM : PAIR_FORCE_NONE;
 }
+template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
+	T* fi = (T*)s->d_fi;
+	const bool odd = (s->t&1ull)!=0ull;
+	const int xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
+	const uint32_t nx = (uint32_t)((int)b.x1-xa);
+	const uint32_t bx = row_block(nx);
+	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
+#ifdef LUW_AB_KERNELS
+	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
+#endif
+	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernels also where a specialisation would do (same values)
+	[[maybe_unused]] const bool force_free = sizeof(T)==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
+	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
+	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid (both are product code, same values)
+	// (in-plane offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with
+	// its 2^32-byte planes still qualifies: its largest offset is 2^32 - 4)
+	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*sizeof(T)<=(1ull<<32) && !force_row;
+	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
+	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
+	if(st) { // a sampled step of the product kernel (can_fuse_stats): the Welford update rides on the cell update
+		#define LUW_LAUNCH_ST(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 0, 2, FL, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, *st)
+		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_ST(1, true); else LUW_LAUNCH_ST(0, true); } else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); } }
+		else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); }
+		#undef LUW_LAUNCH_ST
+	}
+	else if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
+		#define LUW_LAUNCH_T(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 4, 2, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T)
+		if constexpr(sizeof(T)==2u) { if(force_free) { // FP16C, nothing can push the cells of this box: 76 VGPRs, 6 waves per SIMD
+			if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1, 4, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T, StatsArgs{});
+			else hipLaunchKernelGGL((k_stream_collide_s<T, 0, 4, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T, StatsArgs{});
+			return; } }
+		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_T(1, true); else LUW_LAUNCH_T(0, true); } else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); } }
+		else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); }
+		#undef LUW_LAUNCH_T
+	}
+#ifdef LUW_AB_KERNELS
+	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
+	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
+	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
+	else if(mode==5) { if(odd) LUW_LAUNCH_S(1, 3, 2); else LUW_LAUNCH_S(0, 3, 2); }
+	else if(mode==4) { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
+#endif
+	else if(sizeof(T)==2u&&force_free) { // FP16C, nothing can push the cells of this box: 69 VGPRs, 7 waves per SIMD
+		if constexpr(sizeof(T)==2u) {
+			if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1, 0, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, StatsArgs{});
+			else hipLaunchKernelGGL((k_stream_collide_s<T, 0, 0, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, StatsArgs{});
+		}
+	}
+	else { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }   // the product kernel
+	#undef LUW_LAUNCH_SF
+	#undef LUW_LAUNCH_S
+}
+
 static void launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	uint16_t* fi = (uint16_t*)s->d_fi;
 	const bool odd = (s->t&1ull)!=0ull;
@@ -363,7 +375,7 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
 #endif
 	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where a specialisation would do (same values)
-	const int mode = general_only ? PAIR_FORCE_ANY : pair_force_mode(s, b);
+	const int mode = general_only ? PAIR_FORCE_ANY : box_force_mode(s, b);
 	#define LUW_LAUNCH_P(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
 	if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_NONE); else LUW_LAUNCH_P(0, PAIR_FORCE_NONE); return; }       // nothing can push these cells: no force path, 5 waves per SIMD
 	if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_P(0, PAIR_FORCE_UNIFORM); return; } // volume force / Coriolis only

@@ -302,7 +302,7 @@ __device__ __forceinline__ float relaxation_rate(const KParams& p, const float r
 	return smagorinsky_rate(p, rhon, n_);
 }
 // rho, u of the cell (moments, or the stored values on TYPE_E cells) and the force acting on it
-__device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const float* f,
+template<bool NOFORCE=false> __device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const float* f,
 		const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float& fxn, float& fyn, float& fzn) {
 	if(is_E) {
 		rhon = rho[n];
@@ -312,7 +312,8 @@ __device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n,
 	} else {
 		calculate_rho_u(f, rhon, uxn, uyn, uzn);
 	}
-	assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
+	if constexpr(NOFORCE) fxn = fyn = fzn = 0.0f;   // the caller knows that nothing can push the cells of its launch box (luw_core.hip, box_force_mode)
+	else assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
 }
 // the general tail: Guo forcing, equilibrium override on TYPE_E cells
 __device__ __forceinline__ void collide_tail_general(const KParams& p, const bool is_E, const bool forced, const float fxn, const float fyn, const float fzn,
@@ -343,11 +344,13 @@ __device__ __forceinline__ void collide_tail_general(const KParams& p, const boo
 }
 // in: streamed-in DDFs f[19], flags byte.  out: post-collision DDFs in f[19]; rho/u (after the half-force
 // shift and the +-c clamp) in rhon,uxn,uyn,uzn.
-template<bool FAST=true> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+// NOFORCE: no force can act on any cell of the launch (box_force_mode): without the force assembly the FP16C kernel needs 69 instead of 89
+// VGPRs (76 instead of 93 with the thermal lattice) and no scalar spills -- 7 resp. 6 waves per SIMD instead of 5
+template<bool FAST=true, bool NOFORCE=false> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
 		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	float fxn, fyn, fzn;
-	collide_head(p, n, x, y, z, is_E, f, rho, u, F, rhon, uxn, uyn, uzn, fxn, fyn, fzn);
+	collide_head<NOFORCE>(p, n, x, y, z, is_E, f, rho, u, F, rhon, uxn, uyn, uzn, fxn, fyn, fzn);
 	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
 	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
 	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical

@@ -115,7 +115,7 @@ template<typename T> struct CellAddr<T, true> {
 #define LUW_MAXW_F32 4
 #endif
 // STATS: this step is a statistics sample (stats_welford, luw_kernels_common.hpp); product MODE 0 only.
-template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, const StatsArgs S = StatsArgs{}) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
@@ -148,10 +148,10 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STA
 		float rhon, uxn, uyn, uzn;
 		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
 			float u0[3];
-			collide_cell<true>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
+			collide_cell<true, NOFORCE>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
 			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
 		} else
-		collide_cell<(MODE!=3)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
+		collide_cell<(MODE!=3), NOFORCE>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
 			u[n] = uxn;
