@@ -419,9 +419,11 @@ template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, co
 //                       whatever the Smagorinsky rate of such a lane came out as -- instead of keeping the nineteen equilibria for a
 //                       select behind the relaxation;
 //   PAIR_FORCE_UNIFORM  volume force and / or Coriolis act on every cell, nothing position-dependent does: no zone tests, no wave-uniform
-//                       switch, no scalar spills (106 VGPRs);
+//                       switch, no scalar spills; TYPE_E lanes as above, with the Guo term's factor c_tau = 0 on top (feq + Fi 0 = feq):
+//                       96 VGPRs, 5 waves per SIMD as well;
 //   PAIR_FORCE_ANY      everything, switched per wave.
 enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
+
 template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
 		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
@@ -441,7 +443,6 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 			uzn = u[2ull*p.Np+n];
 		}
 	}
-	constexpr bool NOFORCE = FORCE==PAIR_FORCE_NONE;
 	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
 	f32x2 Finp[9]; float Fin0 = 0.0f;
 	if(forced) {
@@ -470,11 +471,13 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 		for(int k=0; k<9; k++) { const f32x2 d = fp[k]-feqp[k]; n_[2*k+1] = d.x; n_[2*k+2] = d.y; }
 		w = smagorinsky_rate(p, rhon, n_);
 	}
-	if constexpr(NOFORCE) { if(wave_has_E) w = is_E ? 1.0f : w; }
+	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;   // TYPE_E lanes through the relaxation rate (f = 0, w = 1, no Guo term) instead of nineteen selects
+	if constexpr(E_BY_RATE) { if(wave_has_E) w = is_E ? 1.0f : w; }
 	const float omw = 1.0f-w;
 	float r0; f32x2 rp[9];
 	if(forced) {
-		const float c_tau = fmaf(w, -0.5f, 1.0f);
+		float c_tau = fmaf(w, -0.5f, 1.0f);
+		if constexpr(E_BY_RATE) { if(wave_has_E) c_tau = is_E ? 0.0f : c_tau; }
 		r0 = fmaf(omw, f0, fmaf(w, feq0, Fin0*c_tau));
 		#pragma unroll
 		for(int k=0; k<9; k++) rp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], __builtin_elementwise_fma(splat2(w), feqp[k], Finp[k]*splat2(c_tau)));
@@ -483,7 +486,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 		#pragma unroll
 		for(int k=0; k<9; k++) rp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], splat2(w)*feqp[k]);
 	}
-	if constexpr(!NOFORCE) {
+	if constexpr(!E_BY_RATE) {
 		if(wave_has_E) {
 			r0 = is_E ? feq0 : r0;
 			#pragma unroll

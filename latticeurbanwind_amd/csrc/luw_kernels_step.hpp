@@ -233,8 +233,8 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 	asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
 	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
 }
-// FORCE (plain steps only): what can push the cells of the box -- see collide_cell_pk; PAIR_FORCE_NONE runs 5 waves per SIMD instead of 4.
-template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORCE==PAIR_FORCE_NONE ? 5 : 4, FORCE==PAIR_FORCE_NONE ? 5 : 4))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// FORCE (plain steps only): what can push the cells of the box -- see collide_cell_pk; the two specialised modes run 5 waves per SIMD instead of 4.
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORCE==PAIR_FORCE_ANY ? 4 : 5, FORCE==PAIR_FORCE_ANY ? 4 : 5))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
@@ -283,10 +283,10 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __g
 		});
 	}
 	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
-	constexpr bool NOFORCE = FORCE==PAIR_FORCE_NONE;
 	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull);
-	// NOFORCE: TYPE_E cells decode to f = 0 (collide_cell_pk<true> relaxes them with w = 1)
-	[[maybe_unused]] const uint32_t dmask[2] = { (NOFORCE&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (NOFORCE&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
+	// specialised modes: TYPE_E cells decode to f = 0 (collide_cell_pk relaxes them with w = 1)
+	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;
+	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (E_BY_RATE&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
 	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
 	// (or pre-swap for the pass-through)
 	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
@@ -294,7 +294,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __g
 			uint32_t t;
 			if(c) asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(raw[q]));
 			else asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(raw[q]));
-			if constexpr(NOFORCE) return t&dmask[c]; else return t&0x87FFF000u;
+			if constexpr(E_BY_RATE) return t&dmask[c]; else return t&0x87FFF000u;
 		};
 		f0 = __uint_as_float(bits(0))*0x1p+112f;
 		#pragma unroll
