@@ -286,7 +286,8 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __g
 	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull);
 	// specialised modes: TYPE_E cells decode to f = 0 (collide_cell_pk relaxes them with w = 1)
 	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;
-	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (E_BY_RATE&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
+	// (only cells that are collided: a halo or padding cell passes what it decodes through unchanged, whatever its flag)
+	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&proc[0]&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (E_BY_RATE&&proc[1]&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
 	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
 	// (or pre-swap for the pass-through)
 	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
