@@ -3,8 +3,9 @@
 against the single-domain CPU oracle: random domain grids, lattice extents (odd and even rows), overlap on/off, FP32 / FP16C,
 scalar / pair kernel, sometimes with the thermal lattice.  usage: fuzz_domains.py [CASES] [SEED]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import latticeurbanwind_amd as luw
 from latticeurbanwind_amd import capi

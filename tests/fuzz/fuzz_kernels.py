@@ -3,8 +3,9 @@
 lengths, rows shorter and longer than a block), random solid / TYPE_E cells, random forces; FP16C on the pair kernel and FP32 in
 both addressing forms.  Any mismatch in u, rho or a DDF plane stops the run.  usage: fuzz_kernels.py [CASES] [SEED]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import latticeurbanwind_amd as luw
 from latticeurbanwind_amd import capi
