@@ -129,6 +129,37 @@ def test_fp16c_pair_kernel_force_modes_match_oracle(luw, forces):
         check(g, o, "force mode %s t=%d" % (forces, o.t))
 
 
+@pytest.mark.parametrize("grow", ["", "west", "south", "north", "top"])
+@pytest.mark.parametrize("coriolis", [False, True])
+def test_fp16c_zone_free_core_as_its_own_launch_box(luw, coriolis, grow):
+    """A step assembled from launch boxes (the way the multi-domain hosts do it), cut exactly along the force zones: the zone-free core goes out
+    as one box -- for which the library picks the instantiation without the force path (or with the uniform forces only) -- and six slabs around it
+    take the general kernels.  grow = a face: the same with the middle box reaching two layers INTO that face's zone (the outermost layer of a
+    zone carries weight 0) -- the library must then keep the general kernel for it; a wrong idea of the host about where that zone ends
+    would show as missing forces in those layers."""
+    from oracle import oracle
+    Nx, Ny, Nz = 648, 30, 28
+    nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1)       # zones: west 0..5, south 0..5, north Ny-6.., top Nz-6..; east is downstream
+    spg = dict(n_cells=4, inv_tau=0.02)                                                 # sponge: the 4 layers under the top one
+    cor = (0.0, 3e-5, 4e-5) if coriolis else None
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, True, "auto", synthetic_state(Nx, Ny, Nz, seed=22, shell="luw"), coriolis=cor, nudging=nud, sponge=spg, every_step=True)
+    x0, y0, y1, z1 = 6, 6, Ny - 6, Nz - 6                                                # first cells behind / before the zones (x stays even, pairs stay whole)
+    if grow == "west": x0 -= 2
+    if grow == "south": y0 -= 2
+    if grow == "north": y1 += 2
+    if grow == "top": z1 += 2
+    core = (x0, Nx, y0, y1, 0, z1)
+    slabs = [(0, Nx, 0, Ny, z1, Nz), (0, Nx, 0, y0, 0, z1), (0, Nx, y1, Ny, 0, z1), (0, x0, y0, y1, 0, z1)]
+    g.run(0)
+    for step in range(1, 9):
+        for b in [core] + slabs:
+            g.enqueue_stream_collide(b, write_fields=True)
+        g.increment_time_step(1)
+        if step % 4 == 0:
+            g.finish(); o.run(4)
+            check(g, o, "core box, coriolis %s, grown %s, t=%d" % (coriolis, grow or "nowhere", o.t))
+
+
 @pytest.mark.parametrize("kernel", ["s", "p"])
 def test_deferred_field_update_equals_every_step(luw, kernel):
     # default mode writes rho,u only in the last step of a run() call; observed values must equal UPDATE_FIELDS
