@@ -340,16 +340,17 @@ def main():
         if not args.no_secondary:
             # the other single-GPU configurations, same process, same code path, fewer steps (each is its own create / fill / run)
             sec = {}
-            plan = [("c2_f32", "c2", "f32", False), ("c2_fp16c", "c2", "fp16c", False), ("c3_fp16c", "c3", "fp16c", False), ("c3_fp16c_coriolis", "c3", "fp16c", True),
-                    ("cube1024_f32", "cube1024", "f32", False), ("cube1024_fp16c", "cube1024", "fp16c", False)]
-            for key, wl, dt_, cor in plan:
+            plan = [("c2_f32", "c2", "f32", False, False), ("c2_fp16c", "c2", "fp16c", False, False), ("c3_fp16c", "c3", "fp16c", False, False), ("c3_fp16c_coriolis", "c3", "fp16c", True, False),
+                    ("c3_fp16c_thermal", "c3", "fp16c", False, True),      # FP16C DDFs + the thermal D3Q7 lattice: what the shipped reference build runs
+                    ("cube1024_f32", "cube1024", "f32", False, False), ("cube1024_fp16c", "cube1024", "fp16c", False, False)]
+            for key, wl, dt_, cor, th in plan:
                 sz, bld, _ = WORKLOADS[wl]
-                if (wl, dt_, cor) == (args.workload, args.dtype, args.coriolis) and not args.size:
+                if (wl, dt_, cor, th) == (args.workload, args.dtype, args.coriolis, args.thermal) and not args.size:
                     continue
                 try:
                     big = sz[0] * sz[1] * sz[2] >= (1 << 30)
-                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, 30 if big else 60, 5 if big else 10, coriolis=cor)
-                    r["workload"] = describe(wl, sz, bld, dt_, cor, False, False)
+                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, 30 if big else 60, 5 if big else 10, coriolis=cor, thermal=th)
+                    r["workload"] = describe(wl, sz, bld, dt_, cor, th, False)
                     sec[key] = r
                 except Exception as e:      # a secondary block never takes the headline down; its absence is visible
                     sec[key] = {"error": str(e)[:300]}
