@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check against the CPU oracle (profiling runs)")
+    ap.add_argument("--no-group-host", action="store_true", help="N > 1: skip the one-process multi-domain host block")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything libraries print on file descriptor 1 while the run is set up
@@ -367,16 +369,151 @@ def main():
         return
 
     # ---------------------------------------------------------------- N > 1: one process per GPU, halos over RCCL
+    run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c, METRIC, saved_stdout)
+
+
+# ======================================================================== N > 1
+PARITY_STEPS = 8                 # both time parities, eight exchanges per split axis
+PARITY_NUDGE_CELLS, PARITY_SPONGE_CELLS = 20, 24    # zones thinner than a rank's 64-cell block: only face-owning domains feel them (FX/kernel.cpp:1537-1541,1598)
+
+
+def parity_tile(world, D):
+    """global lattice of the small urban tile of the N > 1 self-check: 64 cells per rank in y and z, in x 256 per rank where x is split
+    (two 64-cell shell slabs and an interior between them, rows wide enough for the FP16C pair kernel) and 512 where it is whole"""
+    return ((256 * D[0]) if D[0] > 1 else 512, 64 * D[1], 64 * D[2])
+
+
+def parity_forcing():
+    nud, spg = tile_forcing()
+    return dict(nud, n_cells=PARITY_NUDGE_CELLS), dict(spg, n_cells=PARITY_SPONGE_CELLS)
+
+
+def owned_digests(lay, u, rho, fi, fp16c):
+    """digests of a rank's OWNED cells: rho, u (3 components) and the 19 stored DDF planes (local arrays incl. halos, reference layout).
+    The two zeros are one value (+-0.0; FP16C codes 0x0000 / 0x8000) and hash alike."""
+    import hashlib
+    own = tuple(slice(h, n - h) for h, n in zip(lay.H, lay.lN))[::-1]                  # (z, y, x)
+    cut = lambda a, c: np.asarray(a).reshape((c,) + tuple(lay.lN[::-1]))[(slice(None),) + own]
+    out = {}
+    for name, arr, comps in (("rho", rho, 1), ("u", u, 3), ("fi", fi, 19)):
+        a = np.ascontiguousarray(cut(arr, comps))
+        a = np.where(a == 0x8000, 0, a).astype(a.dtype) if a.dtype == np.uint16 else a + np.float32(0.0)
+        out[name] = hashlib.blake2b(a.tobytes(), digest_size=16).hexdigest()
+    out["max_abs_uy"] = float(np.abs(cut(u, 3)[1]).max())
+    return out
+
+
+def oracle_tile(gN, fp16c, coriolis, steps, forcing=None):
+    """the CHECKER: the CPU oracle on the UNDIVIDED small tile (rank 0 only)"""
+    from oracle import oracle
+    nud, spg = forcing or parity_forcing()
+    o = oracle.OracleLBM(*gN, NU, fp16c=fp16c)
+    fill_channel(o.flags, o.u, o.rho, *gN, buildings=True)
+    o.set_buffer_nudging(nud["n_cells"], nud["inv_tau"], nud["downstream_face"], nud["nudge_vertical"]); o.set_top_sponge(spg["n_cells"], spg["inv_tau"])
+    if coriolis:
+        o.set_coriolis(*coriolis_omega())
+    o.run(steps)
+    return o
+
+
+def oracle_digests(o, gN, D, world, fp16c):
+    from latticeurbanwind_amd.distributed import DomainLayout
+    out = []
+    for r in range(world):
+        lay = DomainLayout(gN, D, r)
+        b = tuple(g // d for g, d in zip(gN, D)); c0 = tuple(c * bb for c, bb in zip(lay.coord, b))
+        sl = (slice(None), slice(c0[2], c0[2] + b[2]), slice(c0[1], c0[1] + b[1]), slice(c0[0], c0[0] + b[0]))
+        blk = lambda a, c: a.reshape(c, gN[2], gN[1], gN[0])[sl]
+        flat = type("L", (), {"H": (0, 0, 0), "lN": b})()                                  # the block itself, no halos
+        out.append(owned_digests(flat, blk(o.u, 3), blk(o.rho, 1), blk(o.fi, 19), fp16c))
+    return out
+
+
+def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c, METRIC, saved_stdout):
     import torch.distributed as dist
     from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice, init_rccl_process_group
     if world == 1:      # --force-distributed without a launcher: a one-rank world over loopback
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29537"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
             os.environ.setdefault(k, v)
-    if args.share_device is not None: dist.init_process_group("gloo")
+    shared = args.share_device is not None
+    if shared: dist.init_process_group("gloo")
     else: init_rccl_process_group(local_rank)
+    os.environ.setdefault("LUW_MEASURE_WIRE", "10")                # TorchDistTransport.warm_up times the bare face exchange of every split axis
     urban = not args.no_buildings
     nud, spg = tile_forcing() if urban else (None, None)
     box = device_context(torch, local_rank)                        # this rank's GPU by itself (before the lattice exists): the slowest box sets the pace of a step
+    dev_of = (lambda r: args.share_device) if shared else (lambda r: r)   # one node: rank r drives device r
+    transport = "gloo + host staging (--share-device test aid: NOT a multi-GPU result)" if shared else "RCCL p2p (batch_isend_irecv)"
+
+    def topology(lay):
+        """where this rank's GPU sits and how it reaches the GPUs of its halo neighbours (HIP runtime's view of the links)"""
+        info = capi.device_info(local_rank)
+        links = {}
+        for a in lay.split_axes():
+            for sign, name in ((+1, "+"), (-1, "-")):
+                nb = lay.neighbor(a, sign)
+                try:
+                    links["xyz"[a] + name] = dict(capi.p2p_info(local_rank, dev_of(nb)), rank=nb)
+                except Exception as e:
+                    links["xyz"[a] + name] = {"rank": nb, "error": str(e)[:80]}
+        return {"pci_bus_id": info["pci_bus_id"], "links": links}
+
+    # ---- self-check through the REAL transport before anything is timed
+    def parity_case(D, p_fp16c, p_cor):
+        gN = parity_tile(world, D)
+        pn, ps = parity_forcing()
+        sim = DomainDecomposedLBM(gN, D, NU, fp16c=p_fp16c, kernel=kern, device=local_rank, buffer_nudging=pn, top_sponge=ps)
+        try:
+            lb = sim.backend.lbm
+            fill_channel(lb.flags.data, lb.u.data, lb.rho.data, sim.lNx, sim.lNy, sim.lNz, *sim.global_offset, *gN, buildings=True)
+            if p_cor:
+                sim.backend.set_coriolis(*coriolis_omega())
+            sim.initialize(); sim.run(PARITY_STEPS)
+            u, rho = sim.fields()
+            mine = owned_digests(sim.layout, u, rho, lb.download_fi(), p_fp16c)
+            mine["overlap"] = bool(sim.overlap)
+        finally:
+            sim.backend.close()
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        case = {"dtype": "fp16c" if p_fp16c else "f32", "coriolis": bool(p_cor), "lattice": list(gN), "n_gpu": list(D), "steps": PARITY_STEPS,
+                "forcing": "building array, buffer nudging %d cells, top sponge %d layers" % (PARITY_NUDGE_CELLS, PARITY_SPONGE_CELLS),
+                "schedule": "shell / interior overlap, pipelined steps" if mine["overlap"] else "whole box, then exchange"}
+        ora = None
+        if rank == 0:
+            ora = oracle_tile(gN, p_fp16c, p_cor, PARITY_STEPS)
+            want = oracle_digests(ora, gN, D, world, p_fp16c)
+            bad = [{"rank": r, "fields": [f for f in ("rho", "u", "fi") if got[r][f] != want[r][f]]} for r in range(world)]
+            bad = [b for b in bad if b["fields"]]
+            case.update(equal=not bad, mismatches=bad, cells_compared=gN[0] * gN[1] * gN[2], max_abs_uy=max(g["max_abs_uy"] for g in got),
+                        compared="rho, u and the 19 stored DDF planes of every rank's owned cells (128-bit digests, all-gathered) against the CPU oracle on the undivided lattice")
+            case["equal"] = case["equal"] and case["max_abs_uy"] > 0.0           # a flow that never left the inflow profile proves nothing
+        return case, ora
+
+    D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world, split_x=True)    # BASELINE configs[3]: the deck's literal n_gpu (8 GPUs: [4,2,1])
+    if D[0] * D[1] * D[2] != world:
+        raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
+    Dalt = choose_decomposition(world)                              # x kept whole (8 GPUs: [1,4,2]): the same tile, the cut with whole rows
+    cuts = [D] + ([Dalt] if (not args.n_gpu and not args.no_secondary and world > 1 and Dalt != D) else [])
+    parity = {"transport": transport, "cases": []}
+    oracle_f32 = None
+    if not args.no_parity:
+        for Dc in cuts:
+            for p_fp16c, p_cor in ((False, False), (True, True)):
+                case, ora = parity_case(Dc, p_fp16c, p_cor)
+                parity["cases"].append(case)
+                if Dc == D and not p_fp16c:
+                    oracle_f32 = ora                                 # kept for the one-process host's check below (rank 0)
+        verdict = [all(c.get("equal") for c in parity["cases"])] if rank == 0 else [None]
+        dist.broadcast_object_list(verdict, src=0)
+        parity["ok"] = bool(verdict[0])
+        if not parity["ok"]:
+            if rank == 0:
+                sys.stdout.flush(); os.dup2(saved_stdout, 1)
+                print(json.dumps({"metric": METRIC, "value": None, "unit": "MLUPS", "n_gpus": world, "error": "decomposed run differs from the oracle: nothing was timed", "parity": parity}))
+                sys.stdout.flush(); os.dup2(2, 1)
+            dist.barrier(); dist.destroy_process_group()
+            raise SystemExit(3)
 
     def run_tile(D):
         """the tile cut as n_gpu = D: returns this rank's timing block; every failure (RCCL p2p included) propagates"""
@@ -399,28 +536,38 @@ def main():
             tm = sim.run(args.steps, timed=True)
             torch.cuda.synchronize(); dist.barrier()
             dt = time.perf_counter() - t0
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_device is not None else "cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             b = sim.layout.interior_box() if sim.overlap else sim.layout.whole_box()
+            elem = 2 if fp16c else 4
+            halo_out = sum(2 * 5 * lb.area(a) * elem for a in sim.layout.split_axes())      # bytes this rank sends per step (as many arrive)
             mine = {"rank": rank, "device": local_rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "wall_ms_per_step": round(dt / args.steps * 1e3, 4),
                     "kernel_ms": round(tm["kernel_ms"], 4), "kernel_cells": (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]),
                     "shell_ms": None if tm.get("shell_ms") is None else round(tm["shell_ms"], 4), "exchange_ms": None if tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
+                    "halo_bytes_out_per_step": halo_out,
+                    "exchange_GBps_out": round(halo_out / (tm["exchange_ms"] * 1e-3) / 1e9, 2) if tm.get("exchange_ms") else None,    # pack + wire + unpack + waiting for the neighbours
+                    "wire": sim.wire,                                                       # the bare face exchange per split axis, measured before the lattice existed
                     "device_copy_GBps": box.get("copy_GBps"), "mclk": box.get("mclk"), "fclk": box.get("fclk")}
+            mine.update(topology(sim.layout))
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
             return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
         finally:
             sim.backend.close()
 
-    D = tuple(args.n_gpu) if args.n_gpu else choose_decomposition(world)
-    if D[0] * D[1] * D[2] != world:
-        raise SystemExit("bench.py: --n-gpu %s does not match %d ranks" % (D, world))
     res = run_tile(D)
-    alt = None
-    if not args.n_gpu and not args.no_secondary and world > 1:
-        Dl = choose_decomposition(world, split_x=True)            # the deck's literal grid (8 GPUs: [4,2,1]) as a secondary block
-        if Dl != D:
-            alt = run_tile(Dl)
+    alt = run_tile(cuts[1]) if len(cuts) > 1 else None
+
+    # ---- the product's OTHER multi-GPU host: one process, all GPUs (luw_group_*, what luw_driver runs for decks with n_gpu > 1).  Every rank
+    # has destroyed its solver; rank 0 alone drives all devices while the others wait in the barrier below.
+    group_host = None
+    if rank == 0 and not args.no_group_host and world > 1:
+        try:
+            group_host = run_group_host(args, luw, capi, D, res["gN"], [dev_of(r) for r in range(world)], fp16c, kern, urban, nud, spg, oracle_f32)
+        except Exception as e:      # never takes the RCCL line down; its absence is visible
+            group_host = {"error": str(e)[:300]}
+    if not shared:
+        torch.cuda.synchronize()
 
     if rank == 0:
         def block(r):
@@ -435,15 +582,15 @@ def main():
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             rccl = None
-        transport = "gloo + host staging (--share-device test aid: NOT a multi-GPU result)" if args.share_device is not None else "RCCL p2p (batch_isend_irecv)"
+        per_gpu = res["block"][0] * res["block"][1] * res["block"][2]
         out = {
             "metric": METRIC, "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d D3Q19 %s (8 GPUs: BASELINE configs[3]), %dx%dx%d cells per GPU (the N = 1 line runs configs[2], 1024x1024x256 per GPU), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s, rho/u written by the last step only"
-                       % (*res["gN"], "urban tile: building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "channel tile", *res["block"],
+            "config": {"workload": "%dx%dx%d D3Q19 %s (8 GPUs: BASELINE configs[3]) cut as n_gpu=%s, %dx%dx%d = %.0f M cells per GPU (the N = 1 line runs configs[2], 1024x1024x256 = 268 M cells on its GPU; its secondary block tile512_urban is this tile's N = 1 point), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s, rho/u written by the last step only"
+                       % (*res["gN"], "urban tile: building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "channel tile", list(res["D"]), *res["block"], per_gpu / 1e6,
                           "FP16C" if fp16c else "FP32", " + Coriolis force" if args.coriolis else ""),
-                       "global_lattice": list(res["gN"]), "n_gpu": list(res["D"]),
+                       "global_lattice": list(res["gN"]), "n_gpu": list(res["D"]), "cells_per_gpu": per_gpu,
                        "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel"), "kernel": args.kernel, "bytes_per_lup": bpl,
                        "rccl_version": rccl, "ranks_in_communicator": dist.get_world_size()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -452,18 +599,87 @@ def main():
                          "whole_job_frac": round(mlups * 1e6 * bpl / 1e9 / (HBM_PEAK_GBPS * world), 4),   # wall-clock MLUPS of all GPUs x B/LUP over N x peak
                          "note": "achieved = %g B/LUP x %d cells / mean duration of rank 0's %s kernel (HIP events on its launch stream); solid cells are charged like fluid ones here (< 1 %% of the tile)"
                                  % (bpl, res["per_rank"][0]["kernel_cells"], "interior-box (its boundary shell and the halo exchange run concurrently on the communication stream)" if res["overlap"] else "whole-box")},
+            "parity": parity if not args.no_parity else {"skipped": "--no-parity"},
             "per_rank": res["per_rank"],
         }
+        sec = {}
         if alt is not None:
             m2, _, a2 = block(alt)
-            out["secondary"] = {"literal_n_gpu": {"value": round(m2, 1), "unit": "MLUPS", "ms_per_step": round(alt["dt"] / args.steps * 1e3, 4), "n_gpu": list(alt["D"]), "global_lattice": list(alt["gN"]),
-                                                  "halo_exchange": transport + (", overlapped with the interior (64-cell x slabs)" if alt["overlap"] else " after the whole-box kernel"),
-                                                  "roofline_frac_rank0_kernel": round(a2 / HBM_PEAK_GBPS, 4) if a2 else None, "per_rank": alt["per_rank"]}}
+            sec["x_whole_n_gpu"] = {"value": round(m2, 1), "unit": "MLUPS", "ms_per_step": round(alt["dt"] / args.steps * 1e3, 4), "n_gpu": list(alt["D"]), "global_lattice": list(alt["gN"]),
+                                    "what": "the same tile cut with x kept whole (rows stay complete memory lines; whole-row y/z shells)",
+                                    "halo_exchange": transport + (", overlapped with the interior" if alt["overlap"] else " after the whole-box kernel"),
+                                    "roofline_frac_rank0_kernel": round(a2 / HBM_PEAK_GBPS, 4) if a2 else None, "per_rank": alt["per_rank"]}
+        if group_host is not None:
+            sec["group_host"] = group_host
+        if sec:
+            out["secondary"] = sec
         sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()
         os.dup2(2, 1)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_group_host(args, luw, capi, D, gN, devices, fp16c, kern, urban, nud, spg, oracle_f32):
+    """The one-process multi-domain host (csrc/luw_group.hpp behind luw_group_*: the reference's `LBM lbm(N, Dx, Dy, Dz, ...)`, what luw_driver runs
+    for decks with n_gpu > 1) on the SAME tile and cut, driven by this one process over all devices, once per transport: peer stores over xGMI
+    (default) and grouped ncclSend / ncclRecv.  Each with its own self-check first: the small urban tile against the CPU oracle's undivided run."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(devices)
+    out = {"what": "one process drives all %d devices (luw_group_*, the deck driver's multi-GPU host); same tile and cut as the headline" % n, "devices": devices, "n_gpu": list(D), "global_lattice": list(gN)}
+    steps, warm = min(args.steps, 60), min(args.warmup, 5)
+    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_TRANSPORT", "LUW_GROUP_THREADS")}
+    try:
+        for label, env in (("peer", {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "0"}), ("peer_threads", {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "1"}),
+                           ("rccl", {"LUW_GROUP_TRANSPORT": "rccl", "LUW_GROUP_THREADS": "0"})):
+            os.environ.update(env)
+            blk = {}
+            try:
+                # self-check on the small tile (global arrays: it is small)
+                if oracle_f32 is not None:
+                    pg = parity_tile(n, D); pn, ps = parity_forcing()
+                    g = luw.LBMGroup(*pg, *D, NU, devices=devices, kernel=kern, buffer_nudging=pn, top_sponge=ps)
+                    try:
+                        fill_channel(g.flags, g.u, g.rho, *pg, buildings=True)
+                        g.run(0); g.run(PARITY_STEPS); g.read_from_device()
+                        blk["parity"] = {"equal": bool(np.array_equal(g.rho, oracle_f32.rho) and np.array_equal(g.u, oracle_f32.u)), "lattice": list(pg), "steps": PARITY_STEPS, "dtype": "f32",
+                                         "compared": "rho, u of every cell against the CPU oracle on the undivided lattice"}
+                        blk["transport"] = capi.TRANSPORT_NAMES.get(g.transport()); blk["overlap"] = g.overlaps()
+                    finally:
+                        g.close()
+                    if not blk["parity"]["equal"]:
+                        out[label] = blk
+                        continue                                     # a host that computes something else is not timed
+                kw = dict(buffer_nudging=nud, top_sponge=spg) if urban else {}
+                g = luw.LBMGroup(*gN, *D, NU, fp16c=fp16c, devices=devices, kernel=kern, global_arrays=False, **kw)
+                try:
+                    def fill(d):
+                        lN, off, _ = g.domain_info(d)
+                        fl, u, rho = g.domain_host(d)
+                        fill_channel(fl, u, rho, *lN, *off, *gN, buildings=urban)
+                    with ThreadPoolExecutor(max_workers=min(n, 8)) as ex:
+                        list(ex.map(fill, range(n)))
+                    if args.coriolis:
+                        g.set_coriolis(*coriolis_omega())
+                    g.initialize_from_domains()
+                    g.run(warm)
+                    t0 = time.perf_counter()
+                    kms = g.run_timed(steps)
+                    dt = time.perf_counter() - t0
+                    cells = gN[0] * gN[1] * gN[2]
+                    blk.update(value=round(cells * steps / dt / 1e6, 1), unit="MLUPS", ms_per_step=round(dt / steps * 1e3, 4), steps=steps, warmup=warm, domain0_kernel_ms=round(kms, 4),
+                               transport=capi.TRANSPORT_NAMES.get(g.transport()), direct_peer_stores=g.direct_peer_stores(), overlap=g.overlaps(),
+                               host_threads="one per domain" if env["LUW_GROUP_THREADS"] == "1" else "one")
+                finally:
+                    g.close()
+            except Exception as e:
+                blk["error"] = str(e)[:300]
+            out[label] = blk
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    return out
 
 
 if __name__ == "__main__":

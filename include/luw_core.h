@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LUW_ABI_VERSION 3
+#define LUW_ABI_VERSION 4
 
 /* error codes */
 #define LUW_OK 0
@@ -109,6 +109,13 @@ typedef struct luw_solver luw_solver;
 int luw_abi_version(void);
 const char* luw_last_error(void);
 int luw_device_count(int* count);            /* smart_device_selection's enumeration, FX/lbm.cpp:947-979 */
+/* What Device_Info prints per device (FX/opencl.hpp:25-107) plus where it sits: name, PCI bus id "dddd:bb:dd.f", memory in bytes.
+ * Any output pointer may be NULL; name_size / pci_size are the capacities of the two text buffers. */
+int luw_device_info(int device, char* name, uint64_t name_size, char* pci_bus_id, uint64_t pci_size, uint64_t* total_memory);
+/* The link between two devices of this node as the HIP runtime reports it: can kernels of `device` access `peer`'s memory, the
+ * runtime's performance rank of the link, whether atomics are native on it, the link type (HSA_AMD_LINK_INFO_TYPE_*: 4 = xGMI,
+ * 2 = PCIe) and the number of hops.  The reference has no counterpart (its domains meet in host memory, FX/lbm.cpp:1895-1935). */
+int luw_p2p_info(int device, int peer, int* can_access, int* performance_rank, int* native_atomics, uint32_t* link_type, uint32_t* hops);
 /* to_string(float) of the reference (FX/utilities.hpp:2741-2750): 9 significant digits, "d.dddddddd[E<exp>]", "NaN", "Inf".  The
  * solver's constants and the VTK headers (ORIGIN, SPACING) are defined through this text; drivers use the same routine. */
 int luw_format_float9(float x, char* text, uint64_t size);
@@ -256,6 +263,16 @@ luw_solver* luw_group_domain(luw_group* g, uint32_t d);                         
 int luw_group_domain_info(const luw_group* g, uint32_t d, uint32_t* local_N, int32_t* offset, int* device); /* LBM_Domain::get_Nx.., Ox.. (FX/lbm.cpp:1072) */
 int luw_group_overlaps(const luw_group* g);                 /* 1: shell / interior overlap in use (every split axis has >= 4 owned layers) */
 int luw_group_direct_peer_stores(const luw_group* g);       /* 1: every face travels as peer stores of the pack kernel, none through a copy */
+/* How the faces of communicate_field (FX/lbm.cpp:1907-1935) travel between the domains of this process.  Chosen at luw_group_create from
+ * the environment variable LUW_GROUP_TRANSPORT = peer (default) | staged | rccl:
+ *   PEER    the pack kernel of a domain stores straight into the neighbour's receive buffer (xGMI remote stores); pairs of devices
+ *           without peer access fall back to STAGED
+ *   STAGED  pack into a send buffer, hipMemcpyPeerAsync to the neighbour
+ *   RCCL    pack into a send buffer, grouped ncclSend / ncclRecv on the domains' communication streams (librccl is loaded on demand) */
+#define LUW_TRANSPORT_PEER 0
+#define LUW_TRANSPORT_STAGED 1
+#define LUW_TRANSPORT_RCCL 2
+int luw_group_transport(const luw_group* g);                /* the transport in effect (LUW_TRANSPORT_*) */
 /* Memory_Container's global index space (FX/lbm.hpp:274-297) over the domains' host mirrors: global arrays in the reference
  * layout n = x + (y + z*Ny)*Nx of the GLOBAL lattice, components SoA.  scatter also fills the halo layers (periodic wrap), i.e.
  * what communicate_rho_u_flags leaves there during LBM::initialize (FX/lbm.cpp:1243-1256); gather reads owned cells. */

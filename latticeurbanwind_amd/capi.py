@@ -30,7 +30,7 @@ SYMBOLS = [
     "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info", "luw_group_overlaps", "luw_group_direct_peer_stores",
     "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download", "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_run_timed",
     "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis", "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach", "luw_group_gather_u",
-    "luw_group_stats_reset", "luw_group_stats_download",
+    "luw_group_stats_reset", "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info",
     "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
@@ -151,10 +151,32 @@ def load(path=None):
     L.luw_group_gather_attach.argtypes = [vp, u32, vp]; L.luw_group_gather_u.argtypes = [vp, vp]
     L.luw_group_stats_reset.argtypes = [vp]
     L.luw_group_stats_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
-    if L.luw_abi_version() != 3:
+    L.luw_group_transport.argtypes = [vp]
+    L.luw_device_info.argtypes = [i32, C.c_char_p, u64, C.c_char_p, u64, C.POINTER(u64)]
+    L.luw_p2p_info.argtypes = [i32, i32, i32p, i32p, i32p, u32p, u32p]
+    if L.luw_abi_version() != 4:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
     return L
+
+
+TRANSPORT_NAMES = {0: "peer stores", 1: "staged (hipMemcpyPeerAsync)", 2: "rccl (grouped ncclSend/ncclRecv)"}
+LINK_TYPES = {0: "HyperTransport", 1: "QPI", 2: "PCIe", 3: "InfiniBand", 4: "xGMI"}     # hsa_amd_link_info_type_t
+
+
+def device_info(device):
+    """name, PCI bus id and memory of a HIP device (luw_device_info)"""
+    name, pci, mem = C.create_string_buffer(256), C.create_string_buffer(64), C.c_uint64(0)
+    check(load().luw_device_info(int(device), name, 256, pci, 64, C.byref(mem)))
+    return {"device": int(device), "name": name.value.decode(), "pci_bus_id": pci.value.decode(), "memory_GB": round(mem.value / 1e9, 1)}
+
+
+def p2p_info(device, peer):
+    """the link from `device` to `peer` as the HIP runtime reports it (luw_p2p_info)"""
+    acc, rank, atom, lt, hops = C.c_int(0), C.c_int(0), C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+    check(load().luw_p2p_info(int(device), int(peer), C.byref(acc), C.byref(rank), C.byref(atom), C.byref(lt), C.byref(hops)))
+    return {"peer": int(peer), "can_access": bool(acc.value), "performance_rank": rank.value, "native_atomics": atom.value,
+            "link": LINK_TYPES.get(lt.value, "type %d" % lt.value) if lt.value != 0xFFFFFFFF else None, "hops": None if hops.value == 0xFFFFFFFF else hops.value}
 
 
 def check(rc):

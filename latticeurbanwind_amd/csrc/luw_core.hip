@@ -27,6 +27,7 @@
 #include <atomic>
 #include <algorithm>
 #include <memory>
+#include <dlfcn.h>
 
 using namespace luw;
 
@@ -179,7 +180,14 @@ struct luw_solver {
 static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, const size_t elem_bytes) {
 	DevBlock blk;
 	const size_t lead = (size_t)(64u-s->kp.halo_x)*elem_bytes, total = elems*elem_bytes+64u*elem_bytes;
-	const size_t chunk = total>=(64ull<<20) ? std::min<size_t>(alloc_vmm_chunk(), (size_t)(((total+(2ull<<20)-1u)>>21)<<21)) : 0u; // small arrays: one piece of their own size, or hipMalloc
+	// arrays under 64 MiB: hipMalloc.  Larger ones: equal chunks of at most the configured size (1 GiB), sized so that the last one is full too --
+	// rounding the array up to whole 1 GiB chunks would cost up to a chunk per array (u, m2, avg_u of a 512^3 domain: 1.5 -> 2 GiB each)
+	size_t chunk = 0u;
+	if(total>=(64ull<<20)) {
+		const size_t cap = alloc_vmm_chunk(), mib2 = 2ull<<20;
+		if(cap==0u||cap==~(size_t)0u) chunk = cap;
+		else { const size_t pieces = (total+cap-1u)/cap; chunk = (((total+pieces-1u)/pieces+mib2-1u)/mib2)*mib2; }
+	}
 	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk);
 	if(e!=hipSuccess&&chunk) { (void)hipGetLastError(); e = dev_alloc(blk, total, s->cfg.device, 0u); } // no VMM on this system: hipMalloc
 	if(e!=hipSuccess) return e;
@@ -220,6 +228,9 @@ static int copy_pitched(void* dst, const void* src, const size_t elem, luw_solve
 		return LUW_OK;
 	}
 	const size_t row_bytes = (size_t)s->cfg.Nx*elem;
+	if(s->d_stage&&row_bytes>s->stage_bytes) { // sized by a narrower element type on a lattice of very few rows: too small for one row of this one
+		HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(s->d_stage); s->d_stage = nullptr;
+	}
 	if(!s->d_stage) { // copies and kernels of successive batches are ordered by the stream, so one buffer serves them all
 		s->stage_bytes = std::max<size_t>(row_bytes, std::min<size_t>(256ull<<20, rows*row_bytes));
 		if(hipMalloc(&s->d_stage, s->stage_bytes)!=hipSuccess) { s->d_stage = nullptr; return fail(LUW_ERR_NOMEM, "copy: staging buffer"); }
@@ -376,6 +387,21 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 #endif
 	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where a specialisation would do (same values)
 	const int mode = general_only ? PAIR_FORCE_ANY : box_force_mode(s, b);
+	// PARK (luw_kernels_step.hpp): the lane's second set of 19 values waits in LDS instead of in registers.  Measured interleaved on MI355X
+	// (profiles/r03_pair_park_ab.txt): it pays where the registers cost a wave of occupancy that matters -- the general kernel, 109 -> 91 VGPRs,
+	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
+	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256).  LUW_PAIR_PARK=<bit mask of force
+	// modes> overrides (bit 0 force-free, 1 uniform, 2 general; A/B and test aid).
+	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (1u<<PAIR_FORCE_ANY);
+	if(park_modes&(1u<<mode)) {
+		const uint32_t lds = (bx/64u)*PAIR_PARK_BYTES_PER_WAVE;
+		#define LUW_LAUNCH_PP(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE, true>), grid, block, lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
+		if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_NONE); else LUW_LAUNCH_PP(0, PAIR_FORCE_NONE); }
+		else if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_PP(0, PAIR_FORCE_UNIFORM); }
+		else { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_ANY); else LUW_LAUNCH_PP(0, PAIR_FORCE_ANY); }
+		#undef LUW_LAUNCH_PP
+		return;
+	}
 	#define LUW_LAUNCH_P(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
 	if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_NONE); else LUW_LAUNCH_P(0, PAIR_FORCE_NONE); return; }       // nothing can push these cells: no force path, 5 waves per SIMD
 	if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_P(0, PAIR_FORCE_UNIFORM); return; } // volume force / Coriolis only
@@ -521,17 +547,42 @@ int luw_device_count(int* count) {
 	return LUW_OK;
 }
 
+int luw_device_info(int device, char* name, uint64_t name_size, char* pci_bus_id, uint64_t pci_size, uint64_t* total_memory) {
+	int ndev = 0;
+	HIP_TRY(hipGetDeviceCount(&ndev));
+	if(device<0||device>=ndev) return fail(LUW_ERR_INVALID, "luw_device_info: no such HIP device");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if(name&&name_size) snprintf(name, (size_t)name_size, "%s", prop.name);
+	if(pci_bus_id&&pci_size) HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, (int)std::min<uint64_t>(pci_size, 64u), device));
+	if(total_memory) *total_memory = (uint64_t)prop.totalGlobalMem;
+	return LUW_OK;
+}
+int luw_p2p_info(int device, int peer, int* can_access, int* performance_rank, int* native_atomics, uint32_t* link_type, uint32_t* hops) {
+	int ndev = 0;
+	HIP_TRY(hipGetDeviceCount(&ndev));
+	if(device<0||device>=ndev||peer<0||peer>=ndev) return fail(LUW_ERR_INVALID, "luw_p2p_info: no such HIP device");
+	int v = device==peer ? 1 : 0;
+	if(can_access) { if(device!=peer) HIP_TRY(hipDeviceCanAccessPeer(&v, device, peer)); *can_access = v; }
+	if(performance_rank) { v = 0; if(device!=peer&&hipDeviceGetP2PAttribute(&v, hipDevP2PAttrPerformanceRank, device, peer)!=hipSuccess) { (void)hipGetLastError(); v = -1; } *performance_rank = v; }
+	if(native_atomics) { v = 1; if(device!=peer&&hipDeviceGetP2PAttribute(&v, hipDevP2PAttrNativeAtomicSupported, device, peer)!=hipSuccess) { (void)hipGetLastError(); v = -1; } *native_atomics = v; }
+	uint32_t lt = 0u, hc = 0u;
+	if(device!=peer&&hipExtGetLinkTypeAndHopCount(device, peer, &lt, &hc)!=hipSuccess) { (void)hipGetLastError(); lt = ~0u; hc = ~0u; }
+	if(link_type) *link_type = lt;
+	if(hops) *hops = hc;
+	return LUW_OK;
+}
+
 void luw_destroy(luw_solver* s) {
 	if(!s) return;
 	(void)hipSetDevice(s->cfg.device);
 	if(s->own_stream) (void)hipStreamSynchronize(s->own_stream);
-	if(s->vk_stream) { (void)hipStreamSynchronize(s->vk_stream); (void)hipStreamDestroy(s->vk_stream); for(int b=0; b<2; b++) { (void)hipEventDestroy(s->vk_ready[b]); (void)hipEventDestroy(s->vk_taken[b]); (void)hipFree(s->d_vk_val[b]); } }
+	(void)luw_vk_inlet_detach(s); // side stream, its events, value buffers and tables
 	for(DevBlock& r : s->raw) dev_free(r); // fi, rho, u, flags, F, statistics
 	if(s->counted&&s->cfg.device>=0&&s->cfg.device<64) g_live_solvers[s->cfg.device]--;
 	(void)hipFree(s->d_wbuf); (void)hipFree(s->d_sigma);
 	(void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out);
 	(void)hipFree(s->d_stage);
-	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
 	(void)hipHostFree(s->h_rho); (void)hipHostFree(s->h_u); (void)hipHostFree(s->h_flags); (void)hipHostFree(s->h_F); (void)hipHostFree(s->h_T);
 	if(s->own_stream) (void)hipStreamDestroy(s->own_stream);
 	delete s;
@@ -867,7 +918,11 @@ int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint
 int luw_vk_inlet_detach(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_vk_inlet_detach: null solver");
 	(void)hipSetDevice(s->cfg.device);
-	if(s->vk_stream) (void)hipStreamSynchronize(s->vk_stream);
+	if(s->vk_stream) { (void)hipStreamSynchronize(s->vk_stream); (void)hipStreamDestroy(s->vk_stream); s->vk_stream = nullptr; }
+	for(int b=0; b<2; b++) { // the side stream and its four events come and go together: a partial creation leaves nothing behind
+		if(s->vk_ready[b]) { (void)hipEventDestroy(s->vk_ready[b]); s->vk_ready[b] = nullptr; }
+		if(s->vk_taken[b]) { (void)hipEventDestroy(s->vk_taken[b]); s->vk_taken[b] = nullptr; }
+	}
 	for(int b=0; b<2; b++) { (void)hipFree(s->d_vk_val[b]); s->d_vk_val[b] = nullptr; s->vk_val_t[b] = ~0ull; }
 	(void)hipFree(s->d_vk_cell); (void)hipFree(s->d_vk_face); (void)hipFree(s->d_vk_point); (void)hipFree(s->d_vk_mode);
 	s->d_vk_cell = nullptr; s->d_vk_face = nullptr; s->d_vk_point = nullptr; s->d_vk_mode = nullptr;
@@ -1016,6 +1071,7 @@ int luw_initialize(luw_solver* s) {
 	else hipLaunchKernelGGL((k_initialize<float>), grid, block, 0, s->stream, s->kp, (float*)s->d_fi, s->d_rho, s->d_u, s->d_flags, (float*)s->d_gi, s->d_T);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	if(s->d_stage) { (void)hipFree(s->d_stage); s->d_stage = nullptr; s->stage_bytes = 0u; } // the bulk uploads are done; downloads allocate it again on demand
 	s->t = 0ull;
 	s->initialized = true;
 	s->fields_current = true;
@@ -1104,8 +1160,9 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms, cons
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
 	const bool every = (s->cfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
 	std::vector<hipEvent_t> ev;
+	struct EventsFree { std::vector<hipEvent_t>& v; ~EventsFree() { for(hipEvent_t e : v) if(e) (void)hipEventDestroy(e); } } events_free{ ev }; // on every path out
 	if(mean_kernel_ms) {
-		ev.resize(2u*steps);
+		ev.assign(2u*steps, nullptr);
 		for(auto& e : ev) HIP_TRY(hipEventCreate(&e));
 	}
 	for(uint64_t i=0ull; i<steps; i++) {
@@ -1128,7 +1185,6 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms, cons
 	if(mean_kernel_ms) {
 		double sum = 0.0;
 		for(uint64_t i=0ull; i<steps; i++) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, ev[2u*i], ev[2u*i+1u])); sum += (double)ms; }
-		for(auto& e : ev) (void)hipEventDestroy(e);
 		*mean_kernel_ms = steps ? sum/(double)steps : 0.0;
 	}
 	return LUW_OK;

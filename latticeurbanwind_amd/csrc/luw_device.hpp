@@ -152,6 +152,41 @@ template<> __device__ __forceinline__ uint16_t ddf_encode<uint16_t>(const float 
 __device__ __forceinline__ float sq(const float x) { return x*x; }
 __device__ __forceinline__ float clampf(const float x, const float a, const float b) { return fminf(fmaxf(x, a), b); }
 
+// ---------------------------------------------------------------- IEEE division and square root without the range handling
+// `a/b` and `sqrtf(x)` compile to the correctly rounded sequences of the device library: for the division two v_div_scale (operands
+// scaled out of the denormal / overflow ranges), v_rcp_f32, two Newton fmas, the quotient, two residual corrections, v_div_fmas
+// (undoes the scaling) and v_div_fixup (zeros, infinities, NaNs): 11 instructions; for the square root a 2^32 pre-scaling of inputs
+// below 2^-96, v_sqrt_f32, the two neighbours of its result, their residuals, two selects, the un-scaling and a class test: 15.
+// Where the VALU is the limit (FP16C kernels) and the operands are known to sit in the plain range, the SAME instruction sequences
+// run without the scaling and the special-case tails -- bit-identical results by construction, since those parts are identities there:
+//   division n/d, d in [1/4, 4] (a density; the callers test it per wave and take the library path otherwise), n = 0 or 2^-103 <= |n| <
+//     2^64: v_div_scale leaves both operands alone (ISA: it scales for a denormal d or 1/d or n/d, |n| < 2^-103, exponents >= 96 apart)
+//     and VCC = 0, so v_div_fmas is a plain fma; v_div_fixup only re-applies the sign, which matters for n = -0 alone (this sequence
+//     gives +0: the sign of a zero, never a value).  The reciprocal refinement depends on d only: several numerators share it.
+//   square root, x = 0 or x >= 2^-96: no pre-scaling, the class test (zero / infinity pass through) is covered by v_sqrt_f32 itself:
+//     for x = 0 both neighbour tests fail (NaN and +0 residuals) and 0 stays.
+// Checked on the device against the library forms: luw_selfcheck_arith (every float of the square root's range; 2^31 quotients).
+struct Recip { float d, r; };
+__device__ __forceinline__ Recip recip_prepare(const float d) {
+	const float r0 = __builtin_amdgcn_rcpf(d);
+	const float e = fmaf(-d, r0, 1.0f);
+	return Recip{ d, fmaf(e, r0, r0) };
+}
+__device__ __forceinline__ float div_by(const float n, const Recip R) {
+	float q = n*R.r;
+	q = fmaf(fmaf(-R.d, q, n), R.r, q);
+	return fmaf(fmaf(-R.d, q, n), R.r, q);
+}
+__device__ __forceinline__ float sqrt_in_range(const float x) {
+	const float s = __builtin_amdgcn_sqrtf(x);
+	const float down = __uint_as_float(__float_as_uint(s)-1u), up = __uint_as_float(__float_as_uint(s)+1u);
+	const float r_down = fmaf(-down, s, x), r_up = fmaf(-up, s, x);
+	const float t = r_down<=0.0f ? down : s;
+	return r_up>0.0f ? up : t;
+}
+// the densities for which div_by is the library's division (tested per lane, voted per wave by the callers)
+__device__ __forceinline__ bool density_in_plain_range(const float rho) { return rho>=0.25f&&rho<=4.0f; }
+
 // ---------------------------------------------------------------- f_eq, FX/kernel.cpp:1016-1055
 __device__ __forceinline__ void calculate_f_eq(const float rho, float ux, float uy, float uz, float* feq) {
 	const float rhom1 = rho-1.0f;
@@ -174,14 +209,19 @@ __device__ __forceinline__ void calculate_f_eq(const float rho, float ux, float 
 }
 
 // ---------------------------------------------------------------- moments, FX/kernel.cpp:1075-1100
-__device__ __forceinline__ void calculate_rho_u(const float* f, float& rhon, float& uxn, float& uyn, float& uzn) {
-	float rho = f[0];
+// the sums: density and the momentum before the division by it
+__device__ __forceinline__ void moment_sums(const float* f, float& rho, float& mx, float& my, float& mz) {
+	float r = f[0];
 	#pragma unroll
-	for(int i=1; i<19; i++) rho += f[i];
-	rho += 1.0f;
-	const float ux = f[ 1]-f[ 2]+f[ 7]-f[ 8]+f[ 9]-f[10]+f[13]-f[14]+f[15]-f[16];
-	const float uy = f[ 3]-f[ 4]+f[ 7]-f[ 8]+f[11]-f[12]+f[14]-f[13]+f[17]-f[18];
-	const float uz = f[ 5]-f[ 6]+f[ 9]-f[10]+f[11]-f[12]+f[16]-f[15]+f[18]-f[17];
+	for(int i=1; i<19; i++) r += f[i];
+	rho = r+1.0f;
+	mx = f[ 1]-f[ 2]+f[ 7]-f[ 8]+f[ 9]-f[10]+f[13]-f[14]+f[15]-f[16];
+	my = f[ 3]-f[ 4]+f[ 7]-f[ 8]+f[11]-f[12]+f[14]-f[13]+f[17]-f[18];
+	mz = f[ 5]-f[ 6]+f[ 9]-f[10]+f[11]-f[12]+f[16]-f[15]+f[18]-f[17];
+}
+__device__ __forceinline__ void calculate_rho_u(const float* f, float& rhon, float& uxn, float& uyn, float& uzn) {
+	float rho, ux, uy, uz;
+	moment_sums(f, rho, ux, uy, uz);
 	rhon = rho;
 	uxn = ux/rho;
 	uyn = uy/rho;
@@ -283,7 +323,8 @@ template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const K
 // ---------------------------------------------------------------- collision of one cell, FX/kernel.cpp:1502-1515,1686-1748
 // Smagorinsky-Lilly relaxation rate, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped (the
 // leading 0 + n of each sum too: it can only turn -0 into +0, and every sum is squared)
-__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_) {
+// plain: the prepared reciprocal of rhon when the caller has established the plain operand range (FP16C kernels), else nullptr
+__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_, const Recip* plain = nullptr) {
 	float Hxx = n_[ 1], Hyy = n_[ 3], Hzz = n_[ 5], Hxy = n_[ 7], Hxz = n_[ 9], Hyz = n_[11];
 	Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
 	Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
@@ -292,6 +333,12 @@ __device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float 
 	Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
 	Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
 	const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
+	if(plain) { // operands in the plain range (see recip_prepare): FP16C populations keep Q below ~1e4 and tau in [1, 20]; a Q under 2^-96, where
+		// sqrt_in_range may be an ulp off, adds less than 1e-14 to tau0sq >= 1/4 and changes nothing
+		const float s = 0.76421222f*sqrt_in_range(Q);
+		const float tau = p.tau0+sqrt_in_range(p.tau0sq+div_by(s, *plain));
+		return div_by(2.0f, recip_prepare(tau));
+	}
 	return 2.0f/(p.tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q)/rhon));
 }
 __device__ __forceinline__ float relaxation_rate(const KParams& p, const float rhon, const float* f, const float* feq) {
@@ -424,31 +471,29 @@ template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, co
 //   PAIR_FORCE_ANY      everything, switched per wave.
 enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
 
-template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
-		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
-	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
-	const bool wave_has_E = __ballot(is_E)!=0ull;
-	{
-		float f[19];
-		f[0] = f0;
-		#pragma unroll
-		for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
-		calculate_rho_u(f, rhon, uxn, uyn, uzn);
-	}
+// PLAIN: the densities of the whole wave lie in [1/4, 4] (voted by collide_cell_pk): divisions and square roots as the library's instruction
+// sequences minus their range handling (recip_prepare), the five divisions by the density sharing one reciprocal
+template<int FORCE, bool PLAIN> __device__ __forceinline__ void collide_cell_pk_tail(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const bool wave_has_E, const bool may_force,
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, const float rho_m, const float mx, const float my, const float mz,
+		float& rhon, float& uxn, float& uyn, float& uzn) {
+	[[maybe_unused]] Recip R{};   // of the density the divisions below use: the moment sum, or (TYPE_E lanes) the stored field
+	if constexpr(PLAIN) { R = recip_prepare(rho_m); uxn = div_by(mx, R); uyn = div_by(my, R); uzn = div_by(mz, R); }
+	else { uxn = mx/rho_m; uyn = my/rho_m; uzn = mz/rho_m; }
 	if(wave_has_E) {
 		if(is_E) {
-			rhon = rho[n];
 			uxn = u[n];
 			uyn = u[(size_t)p.Np+n];
 			uzn = u[2ull*p.Np+n];
 		}
+		if constexpr(PLAIN) R = recip_prepare(rhon); // rhon: the field value on TYPE_E lanes, the moment sum elsewhere
 	}
 	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
 	f32x2 Finp[9]; float Fin0 = 0.0f;
 	if(forced) {
 		float fxn, fyn, fzn;
 		assemble_force<(FORCE==PAIR_FORCE_ANY)>(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
-		const float rho2 = 0.5f/rhon;
+		float rho2;
+		if constexpr(PLAIN) rho2 = div_by(0.5f, R); else rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
 		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
 		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
@@ -469,7 +514,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 		float n_[19];
 		#pragma unroll
 		for(int k=0; k<9; k++) { const f32x2 d = fp[k]-feqp[k]; n_[2*k+1] = d.x; n_[2*k+2] = d.y; }
-		w = smagorinsky_rate(p, rhon, n_);
+		w = smagorinsky_rate(p, rhon, n_, PLAIN ? &R : nullptr);
 	}
 	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;   // TYPE_E lanes through the relaxation rate (f = 0, w = 1, no Guo term) instead of nineteen selects
 	if constexpr(E_BY_RATE) { if(wave_has_E) w = is_E ? 1.0f : w; }
@@ -496,6 +541,32 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	f0 = r0;
 	#pragma unroll
 	for(int k=0; k<9; k++) fp[k] = rp[k];
+}
+#ifndef LUW_PLAIN_ARITH
+#define LUW_PLAIN_ARITH 1   /* 0: the library's division / square root everywhere (A/B builds) */
+#endif
+template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
+	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+	const bool wave_has_E = __ballot(is_E)!=0ull;
+	float rho_m, mx, my, mz;
+	{
+		float f[19];
+		f[0] = f0;
+		#pragma unroll
+		for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
+		moment_sums(f, rho_m, mx, my, mz);
+	}
+	rhon = rho_m;
+	bool plain = density_in_plain_range(rho_m);
+	if(wave_has_E) {
+		if(is_E) rhon = rho[n];
+		plain = plain&&density_in_plain_range(rhon);
+	}
+	// one vote per wave: every density in [1/4, 4] (any lattice that has not blown up) -> the collision with the plain-range arithmetic;
+	// otherwise the same collision with the library's division and square root.  Same values either way inside the range.
+	if(LUW_PLAIN_ARITH&&__ballot(!plain)==0ull) collide_cell_pk_tail<FORCE, true>(p, n, x, y, z, is_E, wave_has_E, may_force, f0, fp, rho, u, F, rho_m, mx, my, mz, rhon, uxn, uyn, uzn);
+	else collide_cell_pk_tail<FORCE, false>(p, n, x, y, z, is_E, wave_has_E, may_force, f0, fp, rho, u, F, rho_m, mx, my, mz, rhon, uxn, uyn, uzn);
 }
 // position-only test: can buffer nudging or the top sponge act on this cell (the zones of assemble_force)?
 __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {

@@ -45,6 +45,10 @@ struct luw_group {
 	uint64_t t = 0ull;
 	uint64_t exchanges = 0ull;                // halo exchanges done by luw_group_run calls (threaded runs number them)
 	uint32_t gather_total = 0u;
+	int transport = LUW_TRANSPORT_PEER;       // how faces travel between domains (luw_group_transport)
+	std::vector<void*> rccl_comm;             // LUW_TRANSPORT_RCCL: one communicator per DISTINCT device ...
+	std::vector<int> rccl_rank;               // ... and every domain's rank in it (domains sharing a device share the rank)
+	bool failed = false;                      // a run stopped half-way: streams and sequence numbers are not trustworthy any more
 };
 
 static const uint32_t GROUP_X_SHELL = 64u;   // thickness of the x boundary slabs: one memory line of cells (a one-cell x face would run one lane per wave)
@@ -81,6 +85,7 @@ static void group_boxes(const luw_group* g, GroupDomain& d) {
 	}
 }
 
+static void group_rccl_teardown(luw_group* g);
 static void group_free(luw_group* g) {
 	if(!g) return;
 	for(GroupDomain& d : g->dom) {
@@ -88,6 +93,7 @@ static void group_free(luw_group* g) {
 		if(d.compute) (void)hipStreamSynchronize(d.compute);
 		if(d.comm) (void)hipStreamSynchronize(d.comm);
 	}
+	group_rccl_teardown(g);
 	for(GroupDomain& d : g->dom) {
 		(void)hipSetDevice(d.device);
 		if(d.s) { (void)luw_set_stream(d.s, nullptr); luw_destroy(d.s); }
@@ -137,10 +143,127 @@ static int domain_unpack(luw_group* g, const size_t i, const int a, const bool t
 	HIP_TRY(hipEventRecord((thermal_pass ? d.gunpacked : d.unpacked)[a], st));
 	return LUW_OK;
 }
+// ---- LUW_TRANSPORT_RCCL: the faces as RCCL point-to-point messages, the reference's communicate_field (FX/lbm.cpp:1907-1935) with
+// ncclSend / ncclRecv in place of its PCIe staging.  librccl is looked up at run time (dlopen) only when this transport is asked for, so
+// the library's link dependencies stay the HIP runtime alone.  One communicator per distinct device (ncclCommInitAll); per axis ONE group
+// call carries every domain's two sends and two receives, each on that domain's communication stream, so pack -> send / recv -> unpack
+// are ordered by the streams themselves and no event crosses a device.
+struct RcclApi {
+	void* lib = nullptr;
+	int (*CommInitAll)(void**, int, const int*) = nullptr;
+	int (*CommDestroy)(void*) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi* rccl_api() {
+	static RcclApi api;
+	static const bool ok = [] {
+		// an RCCL that is already in the process (torch brings its own) is the one to use: two copies would not share their topology state
+		const char* names[] = { "librccl.so", "librccl.so.1" };
+		for(const char* n : names) if(!api.lib) api.lib = dlopen(n, RTLD_NOW|RTLD_NOLOAD);
+		for(const char* n : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if(!api.lib) api.lib = dlopen(n, RTLD_NOW|RTLD_GLOBAL);
+		if(!api.lib) return false;
+		auto sym = [](const char* n) { return dlsym(api.lib, n); };
+		api.CommInitAll = (int(*)(void**, int, const int*))sym("ncclCommInitAll");
+		api.CommDestroy = (int(*)(void*))sym("ncclCommDestroy");
+		api.GroupStart = (int(*)())sym("ncclGroupStart");
+		api.GroupEnd = (int(*)())sym("ncclGroupEnd");
+		api.Send = (int(*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+		api.Recv = (int(*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+		api.GetErrorString = (const char*(*)(int))sym("ncclGetErrorString");
+		return api.CommInitAll&&api.CommDestroy&&api.GroupStart&&api.GroupEnd&&api.Send&&api.Recv&&api.GetErrorString;
+	}();
+	return ok ? &api : nullptr;
+}
+#define RCCL_TRY(call) do { const int r_ = (call); if(r_!=0) return fail(LUW_ERR_DEVICE, std::string(#call)+": "+rccl_api()->GetErrorString(r_)); } while(0)
+static const int RCCL_UINT8 = 1; // ncclUint8: faces travel as bytes, nothing interprets them
+
+static int group_rccl_setup(luw_group* g) {
+	RcclApi* R = rccl_api();
+	if(!R) return fail(LUW_ERR_DEVICE, "luw_group_create: LUW_GROUP_TRANSPORT=rccl but librccl could not be loaded");
+	std::vector<int> devs; // distinct devices in order of first use
+	g->rccl_rank.assign(g->dom.size(), 0);
+	for(size_t i=0; i<g->dom.size(); i++) {
+		const auto it = std::find(devs.begin(), devs.end(), g->dom[i].device);
+		g->rccl_rank[i] = (int)(it-devs.begin());
+		if(it==devs.end()) devs.push_back(g->dom[i].device);
+	}
+	std::vector<void*> comms(devs.size(), nullptr);
+	RCCL_TRY(R->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+	g->rccl_comm = comms;
+	return LUW_OK;
+}
+static void group_rccl_teardown(luw_group* g) {
+	RcclApi* R = rccl_api();
+	if(R) for(void* c : g->rccl_comm) if(c) (void)R->CommDestroy(c);
+	g->rccl_comm.clear();
+}
+// one axis: every domain packs into its send buffers; one grouped batch of sends and receives; every domain unpacks.
+// A communicator works on ONE stream per batch: the communication stream of the first domain on its device (the "leader").  Domains that
+// share a device with their leader (test set-ups; on a node every domain is its own leader and the waits below are on the stream itself)
+// hand over with events: leader waits for their pack, they wait for the leader's batch before they unpack.
+static int group_exchange_rccl_axis(luw_group* g, const int a, const bool thermal_pass, const bool on_compute) {
+	RcclApi* R = rccl_api();
+	const size_t n = g->dom.size();
+	auto stream_of = [&](GroupDomain& d) { return on_compute ? d.compute : d.comm; };
+	auto leader = [&](const size_t i) { size_t l = i; for(size_t k=0; k<i; k++) if(g->dom[k].device==g->dom[i].device) { l = k; break; } return l; };
+	for(size_t i=0; i<n; i++) {
+		GroupDomain& d = g->dom[i];
+		GROUP_TRY(group_set_device(d));
+		GROUP_TRY(luw_set_stream(d.s, stream_of(d)));
+		void** out = (thermal_pass ? d.gsend : d.send)[a];
+		GROUP_TRY(thermal_pass ? luw_enqueue_extract_gi(d.s, (uint32_t)a, out[0], out[1]) : luw_enqueue_extract_fi(d.s, (uint32_t)a, out[0], out[1]));
+		HIP_TRY(hipEventRecord((thermal_pass ? d.gpacked : d.packed)[a], stream_of(d)));
+	}
+	for(size_t i=0; i<n; i++) if(leader(i)!=i) {
+		GroupDomain& L = g->dom[leader(i)];
+		GROUP_TRY(group_set_device(L));
+		HIP_TRY(hipStreamWaitEvent(stream_of(L), (thermal_pass ? g->dom[i].gpacked : g->dom[i].packed)[a], 0));
+	}
+	// Message list in ONE global order -- (domain i, its + face), (domain i, its - face) for i = 0, 1, ... -- walked once for the sends
+	// and once for the receives: RCCL pairs the k-th send of rank s to rank r with the k-th receive of r from s, and any two
+	// messages between the same pair of ranks keep their relative order in both walks (also when + and - neighbour coincide,
+	// and when several domains live on one device and talk to themselves).
+	RCCL_TRY(R->GroupStart());
+	for(size_t i=0; i<n; i++) for(int k=0; k<2; k++) {
+		GroupDomain& d = g->dom[i];
+		const uint32_t to = d.nbr[a][k];
+		const size_t bytes = (size_t)luw_get_area(d.s, (uint32_t)a)*(thermal_pass ? 1u : 5u)*g->ddf_bytes;
+		RCCL_TRY(R->Send((thermal_pass ? d.gsend : d.send)[a][k], bytes, RCCL_UINT8, g->rccl_rank[to], g->rccl_comm[g->rccl_rank[i]], stream_of(g->dom[leader(i)])));
+	}
+	for(size_t i=0; i<n; i++) for(int k=0; k<2; k++) {
+		GroupDomain& d = g->dom[i];
+		const uint32_t to = d.nbr[a][k];
+		GroupDomain& dst = g->dom[to];
+		// my + face (k = 0) is what the + neighbour receives "from its - side" (recv[a][1]); my - face lands in the - neighbour's recv[a][0]
+		void* into = (thermal_pass ? dst.grecv : dst.recv)[a][1-k];
+		const size_t bytes = (size_t)luw_get_area(d.s, (uint32_t)a)*(thermal_pass ? 1u : 5u)*g->ddf_bytes;
+		RCCL_TRY(R->Recv(into, bytes, RCCL_UINT8, g->rccl_rank[i], g->rccl_comm[g->rccl_rank[to]], stream_of(g->dom[leader(to)])));
+	}
+	RCCL_TRY(R->GroupEnd());
+	for(size_t i=0; i<n; i++) if(leader(i)==i) {
+		GroupDomain& L = g->dom[i];
+		GROUP_TRY(group_set_device(L));
+		HIP_TRY(hipEventRecord((thermal_pass ? L.gunpacked : L.unpacked)[a], stream_of(L))); // "this device's batch is done"
+	}
+	for(size_t i=0; i<n; i++) {
+		GroupDomain& d = g->dom[i];
+		GROUP_TRY(group_set_device(d));
+		if(leader(i)!=i) HIP_TRY(hipStreamWaitEvent(stream_of(d), (thermal_pass ? g->dom[leader(i)].gunpacked : g->dom[leader(i)].unpacked)[a], 0));
+		GROUP_TRY(luw_set_stream(d.s, stream_of(d)));
+		GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]) : luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
+	}
+	return LUW_OK;
+}
+
 // one host thread for all domains: every domain packs, then every domain unpacks, axis by axis
 static int group_exchange(luw_group* g, const bool thermal_pass, const bool on_compute) {
 	for(int a=0; a<3; a++) {
 		if(!g->H[a]) continue;
+		if(g->transport==LUW_TRANSPORT_RCCL) { GROUP_TRY(group_exchange_rccl_axis(g, a, thermal_pass, on_compute)); continue; }
 		for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_pack(g, i, a, thermal_pass, on_compute)); }
 		for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_unpack(g, i, a, thermal_pass, on_compute)); }
 	}
@@ -257,8 +380,23 @@ static int domain_run_threaded(luw_group* g, const size_t k, const uint64_t step
 	return LUW_OK;
 }
 
+static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, double* mean_kernel_ms);
+// A run that stops half-way (a launch failed, a domain thread gave up) leaves work enqueued on some streams and the threaded runs' sequence
+// numbers out of step: drain what is there, then refuse further runs instead of letting the next one wait for an exchange that never comes.
 static int group_run(luw_group* g, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, double* mean_kernel_ms) {
 	if(!g) return fail(LUW_ERR_INVALID, "luw_group_run: null group");
+	if(g->failed) return fail(LUW_ERR_STATE, "luw_group_run: an earlier run of this group failed half-way; destroy it");
+	const int rc = group_run_steps(g, steps, first_sample, stride, mean_kernel_ms);
+	if(rc!=LUW_OK&&g->dom.size()>1u&&g->initialized) {
+		const std::string msg = g_last_error;
+		for(GroupDomain& d : g->dom) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.comm); (void)hipStreamSynchronize(d.compute); }
+		(void)hipGetLastError();
+		g->failed = true;
+		g_last_error = msg;
+	}
+	return rc;
+}
+static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, double* mean_kernel_ms) {
 	if(!g->initialized) GROUP_TRY(luw_group_initialize(g));
 	if(g->dom.size()==1u) { // undivided lattice: the single-domain path, no events
 		luw_solver* s = g->dom[0].s;
@@ -275,8 +413,8 @@ static int group_run(luw_group* g, const uint64_t steps, const uint64_t first_sa
 	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.assign(2u*steps, nullptr); for(auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
 	// Default: ONE enqueueing thread (measured with eight domains on one device: 44 us per domain and step, i.e. 0.36 ms per step for eight --
 	// well inside a 1.9 ms FP16C step; profiles/r02_group_one_gpu.txt).  LUW_GROUP_THREADS=1 gives every domain its own host thread.
-	static const bool threaded = getenv("LUW_GROUP_THREADS")&&getenv("LUW_GROUP_THREADS")[0]=='1';
-	if(threaded&&steps>=4ull) { // a call of a step or two (probe windows) is not worth starting threads for
+	const bool threaded = getenv("LUW_GROUP_THREADS")&&getenv("LUW_GROUP_THREADS")[0]=='1'; // read per call: one process can A/B both
+	if(threaded&&steps>=4ull&&g->transport!=LUW_TRANSPORT_RCCL) { // a call of a step or two (probe windows) is not worth starting threads for; RCCL's group calls are issued by ONE thread
 		GroupThreads T; T.error.assign(g->dom.size(), std::string());
 		std::vector<int> rc(g->dom.size(), LUW_OK);
 		const uint64_t X0 = g->exchanges;
@@ -384,7 +522,16 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 			(void)hipGetLastError();
 		}
 	}
-	if(getenv("LUW_GROUP_STAGED")) for(auto& row : g->peer) std::fill(row.begin(), row.end(), 0); // test aid: the copy path also where peer stores would do
+	// transport: peer stores where the devices allow them (default), LUW_GROUP_TRANSPORT=staged the copy path everywhere (LUW_GROUP_STAGED:
+	// the same, older spelling), LUW_GROUP_TRANSPORT=rccl grouped ncclSend / ncclRecv.  Read at every create, so one process can A/B them.
+	{
+		const char* tr = getenv("LUW_GROUP_TRANSPORT");
+		if(tr&&strcmp(tr, "rccl")==0) g->transport = LUW_TRANSPORT_RCCL;
+		else if((tr&&strcmp(tr, "staged")==0)||getenv("LUW_GROUP_STAGED")) g->transport = LUW_TRANSPORT_STAGED;
+		else if(tr&&strcmp(tr, "peer")!=0&&tr[0]) return fail(LUW_ERR_INVALID, "luw_group_create: LUW_GROUP_TRANSPORT must be peer, staged or rccl");
+	}
+	if(g->transport!=LUW_TRANSPORT_PEER) for(auto& row : g->peer) std::fill(row.begin(), row.end(), 0); // faces through send buffers
+	if(g->transport==LUW_TRANSPORT_RCCL&&n>1u) GROUP_TRY(group_rccl_setup(g.get())); // connections before the lattices (cf. TorchDistTransport.warm_up)
 	// Streams and halo buffers BEFORE the lattices: every long-lived small allocation is in place before the large arrays and the
 	// placement search of luw_create run
 	for(uint32_t i=0u; i<n; i++) {
@@ -430,6 +577,11 @@ uint32_t luw_group_size(const luw_group* g) { return g ? (uint32_t)g->dom.size()
 luw_solver* luw_group_domain(luw_group* g, uint32_t d) { return (g&&d<g->dom.size()) ? g->dom[d].s : nullptr; }
 uint64_t luw_group_get_t(const luw_group* g) { return g ? g->t : 0ull; }
 int luw_group_overlaps(const luw_group* g) { return (g&&g->overlap) ? 1 : 0; }
+int luw_group_transport(const luw_group* g) {
+	if(!g) return -1;
+	if(g->transport==LUW_TRANSPORT_PEER&&!luw_group_direct_peer_stores(g)) return LUW_TRANSPORT_STAGED; // some pair of devices has no peer access
+	return g->transport;
+}
 int luw_group_direct_peer_stores(const luw_group* g) {
 	if(!g) return 0;
 	for(size_t i=0; i<g->dom.size(); i++) for(int a=0; a<3; a++) if(g->H[a]&&!(g->peer[i][g->dom[i].nbr[a][0]]&&g->peer[i][g->dom[i].nbr[a][1]])) return 0;
@@ -595,7 +747,11 @@ int luw_group_gather_attach(luw_group* g, uint32_t count, const uint64_t* cells)
 		uint32_t dm; uint64_t l; group_locate(g, cells[i], dm, l);
 		local[dm].push_back(l); g->dom[dm].gather_src.push_back(i);
 	}
-	for(size_t k=0; k<g->dom.size(); k++) GROUP_TRY(luw_gather_attach(g->dom[k].s, (uint32_t)local[k].size(), local[k].data()));
+	for(size_t k=0; k<g->dom.size(); k++) if(int e = luw_gather_attach(g->dom[k].s, (uint32_t)local[k].size(), local[k].data())) {
+		for(GroupDomain& d : g->dom) { d.gather_src.clear(); (void)luw_gather_attach(d.s, 0u, nullptr); } // all or nothing
+		g->gather_total = 0u;
+		return e;
+	}
 	g->gather_total = count;
 	return LUW_OK;
 }

@@ -234,7 +234,24 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 	asm volatile("" : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]));
 }
 // FORCE (plain steps only): what can push the cells of the box -- see collide_cell_pk; the two specialised modes run 5 waves per SIMD instead of 4.
-template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORCE==PAIR_FORCE_ANY ? 4 : 5, FORCE==PAIR_FORCE_ANY ? 4 : 5))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+// PARK: LDS as an extension of the register file.  Each lane owns 19 dwords of LDS (slot q of a wave: 64 consecutive dwords, so every
+// access is conflict-free).  The 19 raw dwords wait there while cell x is collided (only its decoded half is in registers), then trade
+// places with the 19 finished values of cell x, which wait there while cell x+1 is collided and are encoded straight out of LDS at
+// the tail.  76 DS operations per lane, none of them VALU work; the kernel's register footprint becomes that of the one-cell kernel.
+#ifndef LUW_PARK_WAVES_NONE
+#define LUW_PARK_WAVES_NONE 7
+#endif
+#ifndef LUW_PARK_WAVES_UNIFORM
+#define LUW_PARK_WAVES_UNIFORM 6
+#endif
+#ifndef LUW_PARK_WAVES_ANY
+#define LUW_PARK_WAVES_ANY 5
+#endif
+constexpr int pair_waves(const int force, const bool park) {
+	return park ? (force==PAIR_FORCE_NONE ? LUW_PARK_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_PARK_WAVES_UNIFORM : LUW_PARK_WAVES_ANY) : (force==PAIR_FORCE_ANY ? 4 : 5);
+}
+constexpr uint32_t PAIR_PARK_BYTES_PER_WAVE = 19u*64u*4u;
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK), pair_waves(FORCE, PARK)))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}) {
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
@@ -320,19 +337,50 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY> __g
 		}
 	};
 	float fa0, fb0; f32x2 fa[9], fb[9];
+	[[maybe_unused]] uint32_t* slot = nullptr;                     // PARK: this lane's column in its wave's LDS region, slot[64*q]
+	if constexpr(PARK) {
+		extern __shared__ uint32_t pair_park[];
+		slot = pair_park+(threadIdx.x>>6)*(19u*64u)+(threadIdx.x&63u);
+		#pragma unroll
+		for(int q=0; q<19; q++) slot[64*q] = raw[q];
+		asm volatile("" ::: "memory");
+	}
 	one_cell(0, fa0, fa);
-	asm_fence9(fa0, fa); asm_fence_u(raw);                         // cell x is finished before cell x+1 starts
+	if constexpr(PARK) {
+		asm_fence9(fa0, fa);                                       // cell x is finished ...
+		asm volatile("" ::: "memory");
+		// ... and trades places with the raw dwords: one value out, one in, so that the two sets never sit in registers together
+		{ const uint32_t t = slot[0]; slot[0] = __float_as_uint(fa0); raw[0] = t; }
+		#pragma unroll
+		for(int k=0; k<9; k++) {
+			const uint32_t t0 = slot[64*(2*k+1)], t1 = slot[64*(2*k+2)];
+			slot[64*(2*k+1)] = __float_as_uint(fa[k].x); slot[64*(2*k+2)] = __float_as_uint(fa[k].y);
+			raw[2*k+1] = t0; raw[2*k+2] = t1;
+		}
+		asm volatile("" ::: "memory");
+		asm_fence_u(raw);
+	} else {
+		asm_fence9(fa0, fa); asm_fence_u(raw);                     // cell x is finished before cell x+1 starts
+	}
 	one_cell(1, fb0, fb);
 	if constexpr(STATS) stats_welford_pair(Np, S, n, smp);        // both cells' samples, one 8-byte access per array
-	asm_fence9(fa0, fa); asm_fence9(fb0, fb);                      // all floating-point work is done ...
-	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3"); // ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
+	if constexpr(!PARK) asm_fence9(fa0, fa);
+	asm_fence9(fb0, fb);                                           // all floating-point work is done ...
+	// ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
+	if constexpr(PARK) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" ::: "memory"); else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");
 	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
 	uint32_t ca[19], cb[19];
-	ca[0] = fp16c_code_hi_in_rtz_mode(fa0); cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
+	cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
 	#pragma unroll
-	for(int k=0; k<9; k++) {
-		fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
-		fp16c_code2_hi_in_rtz_mode(fb[k], cb[2*k+1], cb[2*k+2]);
+	for(int k=0; k<9; k++) fp16c_code2_hi_in_rtz_mode(fb[k], cb[2*k+1], cb[2*k+2]);
+	if constexpr(PARK) {
+		ca[0] = fp16c_code_hi_in_rtz_mode(__uint_as_float(slot[0]));
+		#pragma unroll
+		for(int k=0; k<9; k++) { const f32x2 v = { __uint_as_float(slot[64*(2*k+1)]), __uint_as_float(slot[64*(2*k+2)]) }; fp16c_code2_hi_in_rtz_mode(v, ca[2*k+1], ca[2*k+2]); }
+	} else {
+		ca[0] = fp16c_code_hi_in_rtz_mode(fa0);
+		#pragma unroll
+		for(int k=0; k<9; k++) fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
 	}
 	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };
 	uint32_t cs[5];   // the five x+1 planes, stored last (dword or, on the row-end lane, two halves)

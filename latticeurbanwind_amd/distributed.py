@@ -155,7 +155,7 @@ class TorchDistTransport:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
-    def warm_up(self, device, dtype=None):
+    def warm_up(self, device, dtype=None, measure=0):
         """One full-size exchange per split axis on scratch buffers, BEFORE the lattice is allocated: RCCL builds its
         point-to-point connections (channels, staging buffers) at the first send/recv to a peer.  Measured on MI355X
         (tools/check_nccl_self.py, LUW_SELF_EARLY): when that set-up happens in a process that has already allocated and freed
@@ -165,11 +165,25 @@ class TorchDistTransport:
         halo buffers of the same sizes are then served."""
         import torch
         lN = self.layout.lN
+        wire = {}
         for a in self.layout.split_axes():
             A = lN[(a + 1) % 3] * lN[(a + 2) % 3]
             bufs = [torch.zeros(5 * A, dtype=dtype or torch.float32, device=device) for _ in range(4)]
             self.exchange(a, *bufs)
+            if measure:
+                # the wire alone: `measure` more exchanges of the same faces, HIP events on the stream the transport enqueues on
+                torch.cuda.synchronize(device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(measure):
+                    self.exchange(a, *bufs)
+                e1.record(); e1.synchronize()
+                ms = e0.elapsed_time(e1) / measure
+                out_bytes = 2 * bufs[0].numel() * bufs[0].element_size()       # the + face and the - face leave, as many bytes arrive
+                wire["xyz"[a]] = {"bytes_out": out_bytes, "ms": round(ms, 4), "GBps_out": round(out_bytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                                  "to_ranks": [self.layout.neighbor(a, +1), self.layout.neighbor(a, -1)]}
         torch.cuda.synchronize(device)
+        return wire
 
 
 def init_rccl_process_group(local_rank, timeout=None):
@@ -288,7 +302,7 @@ class HipDomain:
         self.lbm.u.read_from_device(); self.lbm.rho.read_from_device()
         return self.lbm.u.data, self.lbm.rho.data
 
-    # ---- what the deck run loop needs besides the step (latticeurbanwind_amd/run_deck.py)
+    # ---- what a deck run loop needs besides the step (inlet, probes, statistics)
     def set_coriolis(self, ox, oy, oz): self.lbm.set_coriolis(ox, oy, oz)
 
     def vk_attach(self, cell, face, point_data, mode_data, mode_count, stride, interp):
@@ -336,7 +350,9 @@ class DomainDecomposedLBM:
         if rank is None:
             import torch.distributed as dist
             rank = dist.get_rank()
+        import os
         self.layout = DomainLayout(global_N, D, rank)
+        self.wire = {}           # standalone face-exchange rates per split axis (TorchDistTransport.warm_up with LUW_MEASURE_WIRE=<repetitions>)
         self.lNx, self.lNy, self.lNz = self.layout.lN
         self.global_offset = self.layout.O
         if transport is None:
@@ -345,7 +361,8 @@ class DomainDecomposedLBM:
             transport = HostStagedTransport(self.layout) if staged else TorchDistTransport(self.layout)
             if backend is None and not staged and dist.is_initialized() and dist.get_backend() == "nccl":
                 import torch      # connections to the neighbours first, the lattice second (see TorchDistTransport.warm_up)
-                transport.warm_up(torch.device("cuda", backend_kw.get("device", 0)), torch.float16 if backend_kw.get("fp16c") else torch.float32)
+                self.wire = transport.warm_up(torch.device("cuda", backend_kw.get("device", 0)), torch.float16 if backend_kw.get("fp16c") else torch.float32,
+                                              measure=int(os.environ.get("LUW_MEASURE_WIRE", "0")))
         self.transport = transport
         self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
         if overlap is None:

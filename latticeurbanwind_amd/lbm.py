@@ -231,7 +231,7 @@ class LBMGroup:
     scattered to / gathered from the domains' mirrors.  devices: HIP device per domain (None: one device each, cfg.device + d)."""
 
     def __init__(self, Nx, Ny, Nz, Dx, Dy, Dz, nu, fx=0.0, fy=0.0, fz=0.0, *, fp16c=False, devices=None, force_field=False, update_fields_every_step=False,
-                 subgrid=True, device=0, kernel=capi.KERNEL_AUTO, buffer_nudging=None, top_sponge=None, alpha=None):
+                 subgrid=True, device=0, kernel=capi.KERNEL_AUTO, buffer_nudging=None, top_sponge=None, alpha=None, global_arrays=True):
         self._L = capi.load()
         cfg = capi.Config()
         cfg.struct_size = C.sizeof(capi.Config)
@@ -261,9 +261,12 @@ class LBMGroup:
         self._h = h
         self.Nx, self.Ny, self.Nz, self.D = int(Nx), int(Ny), int(Nz), (int(Dx), int(Dy), int(Dz))
         N = self.Nx * self.Ny * self.Nz
-        self.flags = np.zeros(N, np.uint8); self.u = np.zeros(3 * N, np.float32); self.rho = np.ones(N, np.float32)
-        self.T = np.ones(N, np.float32) if alpha is not None else None
-        self.F = np.zeros(3 * N, np.float32) if force_field else None
+        if global_arrays:
+            self.flags = np.zeros(N, np.uint8); self.u = np.zeros(3 * N, np.float32); self.rho = np.ones(N, np.float32)
+            self.T = np.ones(N, np.float32) if alpha is not None else None
+            self.F = np.zeros(3 * N, np.float32) if force_field else None
+        else:               # the caller works on the domains' own mirrors (domain_host / initialize_from_domains)
+            self.flags = self.u = self.rho = self.T = self.F = None
         self._initialized = False
 
     def close(self):
@@ -283,6 +286,7 @@ class LBMGroup:
     def get_D(self): return self.D[0] * self.D[1] * self.D[2]
     def overlaps(self): return bool(self._L.luw_group_overlaps(self._h))
     def direct_peer_stores(self): return bool(self._L.luw_group_direct_peer_stores(self._h))
+    def transport(self): return int(self._L.luw_group_transport(self._h))   # capi.TRANSPORT_NAMES
     def set_f(self, fx, fy, fz): capi.check(self._L.luw_group_set_f(self._h, fx, fy, fz))
     def set_coriolis(self, ox, oy, oz): capi.check(self._L.luw_group_set_coriolis(self._h, ox, oy, oz))
 
@@ -290,6 +294,20 @@ class LBMGroup:
         lN = (C.c_uint32 * 3)(); off = (C.c_int32 * 3)(); dev = C.c_int(0)
         capi.check(self._L.luw_group_domain_info(self._h, d, lN, off, C.byref(dev)))
         return tuple(lN), tuple(off), dev.value
+
+    def domain_host(self, d):
+        """(flags, u, rho) host mirrors of domain d -- local box incl. halo layers, reference layout -- for callers that fill the domains
+        directly (lbm.lbm_domain[d]->flags ... of the reference) instead of going through the global arrays"""
+        lN, _, _ = self.domain_info(d)
+        n = lN[0] * lN[1] * lN[2]
+        s = self._L.luw_group_domain(self._h, d)
+        view = lambda field, ct, count: np.ctypeslib.as_array(C.cast(self._L.luw_host_ptr(s, field), C.POINTER(ct)), shape=(count,))
+        return view(capi.FIELD_FLAGS, C.c_uint8, n), view(capi.FIELD_U, C.c_float, 3 * n), view(capi.FIELD_RHO, C.c_float, n)
+
+    def initialize_from_domains(self):
+        """upload + initialise from the domains' own host mirrors (filled through domain_host): no global arrays, no scatter"""
+        capi.check(self._L.luw_group_initialize(self._h))
+        self._initialized = True
 
     def write_to_device(self):
         """the global host arrays -> every domain's mirror (halo layers included) -> device"""

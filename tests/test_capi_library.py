@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(luw):
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.SYMBOLS) == names
-    assert L.luw_abi_version() == 3
+    assert L.luw_abi_version() == 4
 
 
 def test_config_struct_layout_matches_header(luw):

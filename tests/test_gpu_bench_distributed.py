@@ -1,0 +1,48 @@
+"""`bench.py --gpus N` on the one-GPU test box: the N > 1 code path end to end -- process group, self-check of a decomposed urban tile
+against the CPU oracle (must pass, and the line must say what was compared), timing blocks, per-rank topology, the one-process
+multi-domain host measured by rank 0 -- with all ranks on GPU 0 and the faces staged through gloo (--share-device).  What a node adds
+is the RCCL wire; the code above it is this."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bench(world, *extra):
+    port = 29500 + ((os.getpid() + 97 + world) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--share-device", "0", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_self_check_and_blocks(luw):
+    out = bench(2, "--size", "256", "64", "64")
+    assert out["n_gpus"] == 2 and out["config"]["n_gpu"] == [2, 1, 1] and out["value"] > 0
+    par = out["parity"]
+    assert par["ok"] and len(par["cases"]) == 4                         # literal cut and x-whole cut, FP32 and FP16C + Coriolis
+    for c in par["cases"]:
+        assert c["equal"] and c["mismatches"] == [] and c["steps"] == 8 and c["max_abs_uy"] > 0 and c["cells_compared"] == c["lattice"][0] * c["lattice"][1] * c["lattice"][2]
+    assert {tuple(c["n_gpu"]) for c in par["cases"]} == {(2, 1, 1), (1, 2, 1)}
+    for r in out["per_rank"]:
+        assert r["pci_bus_id"] and r["halo_bytes_out_per_step"] == 2 * 5 * 64 * 64 * 4 and set(r["links"]) == {"x+", "x-"}
+    sec = out["secondary"]
+    assert sec["x_whole_n_gpu"]["n_gpu"] == [1, 2, 1] and sec["x_whole_n_gpu"]["value"] > 0
+    gh = sec["group_host"]
+    for label in ("peer", "peer_threads", "rccl"):
+        assert gh[label]["parity"]["equal"] and gh[label]["value"] > 0, gh[label]
+    assert gh["peer"]["direct_peer_stores"] and not gh["rccl"]["direct_peer_stores"]
+
+
+def test_four_ranks_fp16c_coriolis(luw):
+    out = bench(4, "--size", "256", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host")
+    assert out["config"]["n_gpu"] == [2, 2, 1] and out["parity"]["ok"] and out["value"] > 0

@@ -160,6 +160,70 @@ print("staged ok")
     assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
+def test_group_rccl_transport_self(luw):
+    """LUW_GROUP_TRANSPORT=rccl (grouped ncclSend / ncclRecv, librccl loaded on demand): with all domains on the box's one GPU the
+    communicator has one rank and every face is a self send / receive -- message pairing, buffer roles and stream ordering of the
+    transport are the ones a node uses; same bits as the oracle, thermal lattice (second message pass) included"""
+    from latticeurbanwind_amd import capi
+    from oracle import oracle
+    saved = os.environ.get("LUW_GROUP_TRANSPORT")
+    os.environ["LUW_GROUP_TRANSPORT"] = "rccl"                          # read at every luw_group_create
+    try:
+        for gN, D, fp16c, alpha in (((32, 24, 12), (2, 2, 1), False, None), ((640, 24, 16), (2, 1, 2), True, None), ((24, 20, 16), (2, 2, 2), False, 0.004)):
+            st = synthetic_state(*gN, seed=53, shell=None)
+            tflags, T = thermal_state(st[0], gN) if alpha else (st[0], None)
+            g = run_group(luw, gN, D, fp16c, (tflags, st[1], st[2]), 0, **({"alpha": alpha} if alpha else {}))
+            assert g.transport() == 2 and not g.direct_peer_stores(), capi.TRANSPORT_NAMES[g.transport()]
+            if alpha: g.T[:] = T
+            g.run(0); g.run(4); g.run(3)
+            g.read_from_device(("u", "rho", "T") if alpha else ("u", "rho"))
+            o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c, alpha=alpha)
+            o.flags[:] = tflags; o.u[:] = st[1]; o.rho[:] = st[2]
+            if alpha: o.T[:] = T
+            o.run(7)
+            assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho) and (not alpha or np.array_equal(g.T, o.T))
+            g.close()
+    finally:
+        if saved is None: os.environ.pop("LUW_GROUP_TRANSPORT", None)
+        else: os.environ["LUW_GROUP_TRANSPORT"] = saved
+
+
+@pytest.mark.parametrize("transport", ["peer", "staged", "rccl"])
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_group_on_distinct_devices(luw, transport, threads):
+    """the wire: domains on DIFFERENT GPUs (default device list: one device per domain) -- peer access, remote stores of the pack kernel
+    into another GPU's receive buffer, cross-device stream waits, hipMemcpyPeerAsync, multi-rank RCCL.  Skipped on the one-GPU test box;
+    the same check runs inside `bench.py --gpus N` (secondary.group_host) whenever a node is available."""
+    import torch
+    from oracle import oracle
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs")
+    if transport == "rccl" and threads == "1":
+        pytest.skip("RCCL's grouped calls are issued by one thread")
+    D = (2, 2, 1) if ndev >= 4 else (2, 1, 1)
+    gN = (640, 48, 24)
+    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_TRANSPORT", "LUW_GROUP_THREADS")}
+    os.environ.update(LUW_GROUP_TRANSPORT=transport, LUW_GROUP_THREADS=threads)
+    try:
+        for fp16c in (False, True):
+            st = synthetic_state(*gN, seed=55, shell="luw")
+            g = luw.LBMGroup(*gN, *D, 0.01, fp16c=fp16c)                 # devices=None: domain d on device d
+            assert len({g.domain_info(d)[2] for d in range(g.get_D())}) == g.get_D()
+            g.flags[:] = st[0]; g.u[:] = st[1]; g.rho[:] = st[2]
+            g.run(0); g.run(6); g.run(5)
+            g.read_from_device()
+            o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
+            o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+            o.run(11)
+            assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho), (transport, threads, fp16c)
+            g.close()
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
 def test_group_one_host_thread_per_domain(tmp_path):
     """LUW_GROUP_THREADS=1: every domain is enqueued by its own host thread (calls of four steps and more; the default is one thread for
     all), neighbours ordered through published exchange numbers: same bits as the oracle, sampled window and thermal lattice included"""
