@@ -118,7 +118,10 @@ def reference_parity():
         fac = np.float32(5.0) / np.float32(0.1)                      # si_ref_u = max profile U = 5 m/s, u_lbm = 0.1
         d = ((f["data"] - gold["u64"]) / fac)[~gold["solid"]].astype(np.float64)
         return {"u_rmse_vs_reference": float(np.sqrt((d ** 2).sum(-1).mean())), "unit": "lattice units", "steps": 64, "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)",
-                "tolerance": 1e-5}
+                "lattice": [48, 40, 24], "cells": 48 * 40 * 24, "tolerance": 1e-5,
+                "horizon": "K = 64 steps on 46 k cells is the ONLY horizon pinned by outputs of the real reference (17 committed cases, FP32 and shipped FP16C builds, "
+                           "tests/golden/ref_*.npz); beyond it the chain is HIP path == CPU oracle bit for bit (literal 128^3 configs[0] at K = 100 turbulent and K = 1000 laminar, "
+                           "tests/test_gpu_c1.py; the bench workloads at full size, tests/test_gpu_bench_workloads.py) and oracle vs reference 0.5-1.3e-7 (FP32) at K = 64"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -226,8 +229,8 @@ def attach_traffic(roof, key, kernel):
     """HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same workload
     (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
     and keyed on the full configuration; null when no profile of exactly this workload exists"""
-    prof = os.path.join(ROOT, "profiles", "r02_%s_summary.json" % key)
-    if kernel == "auto" and os.path.exists(prof):
+    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (3, 2)) if os.path.exists(q)), None)   # newest round first
+    if kernel == "auto" and prof:
         pr = json.load(open(prof))
         roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
         roof["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
@@ -268,6 +271,56 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
             "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5), "bytes_per_lup": bpl,
             "options": ("building array" if buildings else "no solids above the ground plane") + (" + Coriolis force" if coriolis else "") + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
             "roofline": roof}
+
+
+SECONDARY_STEPS, SECONDARY_WARMUP = 200, 20
+
+
+def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, warmup):
+    """One rank of the 2048x1024x512 urban tile (BASELINE configs[3]; configs[4] with FP16C + Coriolis) cut as n_gpu = D, in its real local shape and
+    with its real share of the nudging / sponge zones, stepped through the production schedule of a multi-GPU run -- boundary shell on the
+    communication stream, pack / exchange / unpack, interior on the compute stream, pipelined steps -- with every face going through the real
+    transport to the rank itself (RCCL self send / receive).  D = (1,1,1): the 512^3 tile undivided, the N = 1 point of the scaling curve."""
+    import torch.distributed as dist
+    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, SelfExchangeTransport, init_rccl_process_group
+    if not dist.is_initialized():
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29539"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", str(device))):
+            os.environ.setdefault(k, v)
+        init_rccl_process_group(device)
+    world = D[0] * D[1] * D[2]
+    gN = (512 * D[0], 512 * D[1], 512 * D[2]) if world > 1 else (512, 512, 512)
+    nud, spg = tile_forcing()
+    lay = DomainLayout(gN, D, rank)
+    tr = SelfExchangeTransport(lay)
+    if world > 1:
+        tr.warm_up(torch.device("cuda", device), torch.float16 if fp16c else torch.float32)     # connections first, lattice second (as in a real run)
+    sim = DomainDecomposedLBM(gN, D, NU, rank=rank, transport=tr, fp16c=fp16c, kernel=kern, device=device, buffer_nudging=nud, top_sponge=spg)
+    try:
+        lb = sim.backend.lbm
+        fill_channel(lb.flags.data, lb.u.data, lb.rho.data, *sim.layout.lN, *sim.layout.O, *gN, buildings=True)
+        if coriolis:
+            sim.backend.set_coriolis(*coriolis_omega())
+        sim.initialize(); sim.run(warmup)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tm = sim.run(steps, timed=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        b = sim.layout.interior_box() if sim.overlap else sim.layout.whole_box()
+        kcells = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4])
+    finally:
+        sim.backend.close()
+    owned = (gN[0] // D[0]) * (gN[1] // D[1]) * (gN[2] // D[2])
+    bpl = BYTES_PER_LUP["fp16c" if fp16c else "f32"]
+    ms = dt / steps * 1e3
+    return {"value": round(owned / (ms * 1e-3) / 1e6, 1), "unit": "MLUPS (this rank's owned cells per wall second)", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
+            "n_gpu": list(D), "rank": rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "dtype": "fp16c-storage/f32-arithmetic" if fp16c else "f32",
+            "workload": "rank %d of the 2048x1024x512 urban tile as n_gpu=%s" % (rank, list(D)) if world > 1 else "512^3 urban tile, undivided (the N = 1 point of the N > 1 lines)",
+            "options": "building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" + (" + Coriolis force" if coriolis else ""),
+            "halo_exchange": "RCCL self send / receive of every face (no wire to another device)" if world > 1 else None, "overlap": bool(sim.overlap),
+            "kernel_ms": round(tm["kernel_ms"], 4) if tm else None, "shell_ms": None if not tm or tm.get("shell_ms") is None else round(tm["shell_ms"], 4),
+            "exchange_ms": None if not tm or tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": round(bpl * owned / (ms * 1e-3) / 1e9, 1), "frac": round(bpl * owned / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "kernel_frac": round(bpl * kcells / (tm["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tm and tm.get("kernel_ms") else None, "traffic": None,
+                         "note": "frac = %g B/LUP x %d owned cells / wall time of a whole step (shell + exchange + interior); kernel_frac = the %s kernel alone over its %d cells" % (bpl, owned, "interior-box" if sim.overlap else "whole-box", kcells)}}
 
 
 def describe(name, size, buildings, dtype, coriolis, thermal, every_step):
@@ -350,11 +403,21 @@ def main():
                 if (wl, dt_, cor, th) == (args.workload, args.dtype, args.coriolis, args.thermal) and not args.size:
                     continue
                 try:
-                    big = sz[0] * sz[1] * sz[2] >= (1 << 30)
-                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, 30 if big else 60, 5 if big else 10, coriolis=cor, thermal=th)
+                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, thermal=th)     # >= 200 timed after >= 20 warm-up steps
                     r["workload"] = describe(wl, sz, bld, dt_, cor, th, False)
                     sec[key] = r
                 except Exception as e:      # a secondary block never takes the headline down; its absence is visible
+                    sec[key] = {"error": str(e)[:300]}
+            # the 8-GPU tile of BASELINE configs[3] / configs[4] seen from ONE GPU: its N = 1 point (512^3 urban tile, undivided) and single ranks of
+            # both cuts in their real local shapes, every face through the real transport's self send / receive (no wire to another device)
+            for key, kw in (("tile512_urban_f32", dict(fp16c=False, coriolis=False, D=(1, 1, 1), rank=0)),
+                            ("tile512_urban_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(1, 1, 1), rank=0)),
+                            ("c4_rank_4x2x1_f32", dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0)),
+                            ("c5_rank_4x2x1_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0)),
+                            ("c5_rank_1x4x2_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7))):
+                try:
+                    sec[key] = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=SECONDARY_STEPS, warmup=SECONDARY_WARMUP, **kw)
+                except Exception as e:
                     sec[key] = {"error": str(e)[:300]}
             out["secondary"] = sec
         if not args.no_cpu_baseline:
@@ -366,6 +429,9 @@ def main():
         sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()
         os.dup2(2, 1)
+        import torch.distributed as dist
+        if dist.is_initialized():               # the one-rank world of the rank-shape blocks
+            dist.destroy_process_group()
         return
 
     # ---------------------------------------------------------------- N > 1: one process per GPU, halos over RCCL
@@ -378,9 +444,10 @@ PARITY_NUDGE_CELLS, PARITY_SPONGE_CELLS = 20, 24    # zones thinner than a rank'
 
 
 def parity_tile(world, D):
-    """global lattice of the small urban tile of the N > 1 self-check: 64 cells per rank in y and z, in x 256 per rank where x is split
-    (two 64-cell shell slabs and an interior between them, rows wide enough for the FP16C pair kernel) and 512 where it is whole"""
-    return ((256 * D[0]) if D[0] > 1 else 512, 64 * D[1], 64 * D[2])
+    """global lattice of the small urban tile of the N > 1 self-check: 64 cells per rank in y and z, in x 384 per rank where x is split
+    (two shell slabs -- 64 cells wide for FP32, 128 for FP16C -- and an interior of at least 128 cells between them: rows wide enough for the
+    FP16C pair kernel everywhere) and 512 where it is whole"""
+    return ((384 * D[0]) if D[0] > 1 else 512, 64 * D[1], 64 * D[2])
 
 
 def parity_forcing():

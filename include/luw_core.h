@@ -67,7 +67,7 @@ extern "C" {
 
 /* kernel selection.  The product library knows AUTO, SCALAR and PAIR (luw_create rejects the others); the remaining ids name A/B and
  * measurement-only variants that exist in the tools build only (make -C csrc ab, -DLUW_AB_KERNELS) */
-#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 256 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
+#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 128 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
 #define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */
@@ -239,6 +239,11 @@ int luw_stats_download_T(luw_solver* s, float* avg_T);   /* running mean of T (L
 /* device self-check: number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C
  * codec differs from the literal formulas of FX/kernel.cpp:864-875; must be 0 */
 int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches);
+/* Device self-check of the FP16C kernels' division and square root (the library's correctly rounded instruction sequences without their
+ * range handling, csrc/luw_device.hpp) against `a/b` and sqrtf(): mismatches[0] square roots over every float of the range, [1] quotients for
+ * every denominator in [1/4, 4] x 64 numerators, [2] the same with numerators on the 2^-25 grid of FP16C moment sums.  All three must be 0.
+ * (The reference divides with the OpenCL compiler's native operators, FX/kernel.cpp:1088-1100,1735: not bit-defined; the oracle uses IEEE.) */
+int luw_selfcheck_arith(int device, uint64_t* mismatches);
 
 /* measurement helper for bench.py: runs `steps` steps like luw_run and returns the mean duration of the
  * stream_collide kernel in milliseconds, taken with HIP events on the launch stream. */

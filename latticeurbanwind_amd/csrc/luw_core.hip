@@ -392,7 +392,10 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
 	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256).  LUW_PAIR_PARK=<bit mask of force
 	// modes> overrides (bit 0 force-free, 1 uniform, 2 general; A/B and test aid).
-	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (1u<<PAIR_FORCE_ANY);
+#ifndef LUW_PAIR_PARK_DEFAULT
+#define LUW_PAIR_PARK_DEFAULT (1u<<PAIR_FORCE_ANY)
+#endif
+	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (unsigned)(LUW_PAIR_PARK_DEFAULT);
 	if(park_modes&(1u<<mode)) {
 		const uint32_t lds = (bx/64u)*PAIR_PARK_BYTES_PER_WAVE;
 		#define LUW_LAUNCH_PP(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE, true>), grid, block, lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
@@ -424,9 +427,10 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
 	const bool fp16 = s->ddf_bytes==2u;
 	uint32_t k = s->kernel;
-	// AUTO: the scalar kernel, except FP16C rows of at least two waves of pairs, which take the pair kernel (dword accesses, packed
+	// AUTO: the scalar kernel, except FP16C rows of at least one wave of pairs, which take the pair kernel (dword accesses, packed
 	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
-	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=256u) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
+	static const uint32_t pair_min = getenv("LUW_PAIR_MIN_ROW") ? (uint32_t)strtoul(getenv("LUW_PAIR_MIN_ROW"), nullptr, 10) : 128u; // A/B aid (round 2: 256)
+	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=pair_min) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
 	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
 #ifdef LUW_AB_KERNELS
 	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the vector kernels assume rows that start on a 16-byte boundary at x = 0
@@ -1047,6 +1051,21 @@ int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches) {
 	HIP_TRY(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
 	(void)hipFree(d);
 	*mismatches = h;
+	return LUW_OK;
+}
+
+int luw_selfcheck_arith(int device, uint64_t* mismatches) {
+	if(!mismatches) return fail(LUW_ERR_INVALID, "luw_selfcheck_arith: null argument");
+	HIP_TRY(hipSetDevice(device));
+	unsigned long long* d = nullptr;
+	HIP_TRY(hipMalloc((void**)&d, 24));
+	HIP_TRY(hipMemset(d, 0, 24));
+	hipLaunchKernelGGL(k_arith_check, dim3(4096), dim3(256), 0, 0, d);
+	HIP_TRY(hipGetLastError());
+	unsigned long long h[3] = { 0ull, 0ull, 0ull };
+	HIP_TRY(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost));
+	(void)hipFree(d);
+	for(int k=0; k<3; k++) mismatches[k] = h[k];
 	return LUW_OK;
 }
 

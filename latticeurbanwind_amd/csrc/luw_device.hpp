@@ -157,15 +157,19 @@ __device__ __forceinline__ float clampf(const float x, const float a, const floa
 // scaled out of the denormal / overflow ranges), v_rcp_f32, two Newton fmas, the quotient, two residual corrections, v_div_fmas
 // (undoes the scaling) and v_div_fixup (zeros, infinities, NaNs): 11 instructions; for the square root a 2^32 pre-scaling of inputs
 // below 2^-96, v_sqrt_f32, the two neighbours of its result, their residuals, two selects, the un-scaling and a class test: 15.
-// Where the VALU is the limit (FP16C kernels) and the operands are known to sit in the plain range, the SAME instruction sequences
-// run without the scaling and the special-case tails -- bit-identical results by construction, since those parts are identities there:
-//   division n/d, d in [1/4, 4] (a density; the callers test it per wave and take the library path otherwise), n = 0 or 2^-103 <= |n| <
-//     2^64: v_div_scale leaves both operands alone (ISA: it scales for a denormal d or 1/d or n/d, |n| < 2^-103, exponents >= 96 apart)
-//     and VCC = 0, so v_div_fmas is a plain fma; v_div_fixup only re-applies the sign, which matters for n = -0 alone (this sequence
-//     gives +0: the sign of a zero, never a value).  The reciprocal refinement depends on d only: several numerators share it.
-//   square root, x = 0 or x >= 2^-96: no pre-scaling, the class test (zero / infinity pass through) is covered by v_sqrt_f32 itself:
+// Where the VALU is the limit (FP16C kernels) and the operands sit in the plain range, the SAME instruction sequences run without the
+// scaling and the special-case tails -- bit-identical results by construction, since those parts are identities there:
+//   division n/d, 2^-60 <= d < 2^60 (an "ordinary" density: density_is_ordinary, tested per lane; other lanes redo the quotient with `/`),
+//     n = 0 or 2^-25 <= |n| < 64 (moment sums of FP16C populations: multiples of 2^-25 below 38; the constants 0.5 and 2): v_div_scale leaves
+//     both operands alone (ISA: it scales for a denormal d, 1/d or n/d, for |n| < 2^-103, for exponents 96 or more apart) and VCC = 0, so
+//     v_div_fmas is a plain fma; v_div_fixup only re-applies the sign, which matters for n = -0 alone (this sequence gives +0: the sign of a
+//     zero, never a value).  The reciprocal refinement depends on d only: several numerators share it.
+//   square root, x = 0 or x >= 2^-96: no pre-scaling, and the class test (zero / infinity pass through) is covered by v_sqrt_f32 itself:
 //     for x = 0 both neighbour tests fail (NaN and +0 residuals) and 0 stays.
-// Checked on the device against the library forms: luw_selfcheck_arith (every float of the square root's range; 2^31 quotients).
+// Checked on the device against the library forms: luw_selfcheck_arith (every float of the square root's range; > 2^32 quotients).
+#ifndef LUW_PLAIN_ARITH
+#define LUW_PLAIN_ARITH 1   /* 0: the library's division / square root everywhere (A/B builds) */
+#endif
 struct Recip { float d, r; };
 __device__ __forceinline__ Recip recip_prepare(const float d) {
 	const float r0 = __builtin_amdgcn_rcpf(d);
@@ -184,8 +188,8 @@ __device__ __forceinline__ float sqrt_in_range(const float x) {
 	const float t = r_down<=0.0f ? down : s;
 	return r_up>0.0f ? up : t;
 }
-// the densities for which div_by is the library's division (tested per lane, voted per wave by the callers)
-__device__ __forceinline__ bool density_in_plain_range(const float rho) { return rho>=0.25f&&rho<=4.0f; }
+// the densities for which div_by is the library's division: finite, positive, exponent in [-60, 60)
+__device__ __forceinline__ bool density_is_ordinary(const float rho) { return __float_as_uint(rho)-0x21800000u<0x3C000000u; }
 
 // ---------------------------------------------------------------- f_eq, FX/kernel.cpp:1016-1055
 __device__ __forceinline__ void calculate_f_eq(const float rho, float ux, float uy, float uz, float* feq) {
@@ -323,8 +327,7 @@ template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const K
 // ---------------------------------------------------------------- collision of one cell, FX/kernel.cpp:1502-1515,1686-1748
 // Smagorinsky-Lilly relaxation rate, FX/kernel.cpp:1723-1737; sums run over i=1..18 in order, zero terms dropped (the
 // leading 0 + n of each sum too: it can only turn -0 into +0, and every sum is squared)
-// plain: the prepared reciprocal of rhon when the caller has established the plain operand range (FP16C kernels), else nullptr
-__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_, const Recip* plain = nullptr) {
+__device__ __forceinline__ float smagorinsky_Q(const float* n_) {
 	float Hxx = n_[ 1], Hyy = n_[ 3], Hzz = n_[ 5], Hxy = n_[ 7], Hxz = n_[ 9], Hyz = n_[11];
 	Hxx += n_[ 2]; Hxx += n_[ 7]; Hxx += n_[ 8]; Hxx += n_[ 9]; Hxx += n_[10]; Hxx += n_[13]; Hxx += n_[14]; Hxx += n_[15]; Hxx += n_[16];
 	Hyy += n_[ 4]; Hyy += n_[ 7]; Hyy += n_[ 8]; Hyy += n_[11]; Hyy += n_[12]; Hyy += n_[13]; Hyy += n_[14]; Hyy += n_[17]; Hyy += n_[18];
@@ -332,30 +335,50 @@ __device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float 
 	Hxy += n_[ 8]; Hxy += -n_[13]; Hxy += -n_[14];
 	Hxz += n_[10]; Hxz += -n_[15]; Hxz += -n_[16];
 	Hyz += n_[12]; Hyz += -n_[17]; Hyz += -n_[18];
-	const float Q = sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
-	if(plain) { // operands in the plain range (see recip_prepare): FP16C populations keep Q below ~1e4 and tau in [1, 20]; a Q under 2^-96, where
-		// sqrt_in_range may be an ulp off, adds less than 1e-14 to tau0sq >= 1/4 and changes nothing
-		const float s = 0.76421222f*sqrt_in_range(Q);
-		const float tau = p.tau0+sqrt_in_range(p.tau0sq+div_by(s, *plain));
-		return div_by(2.0f, recip_prepare(tau));
-	}
+	return sq(Hxx)+sq(Hyy)+sq(Hzz)+2.0f*(sq(Hxy)+sq(Hxz)+sq(Hyz));
+}
+__device__ __forceinline__ float smagorinsky_rate_of_Q(const KParams& p, const float rhon, const float Q) {
 	return 2.0f/(p.tau0+sqrtf(p.tau0sq+0.76421222f*sqrtf(Q)/rhon));
 }
-__device__ __forceinline__ float relaxation_rate(const KParams& p, const float rhon, const float* f, const float* feq) {
+// the same value for an ordinary density (R = recip_prepare(rhon)): FP16C populations keep Q below ~1e4 and tau in [1, 20], plain operands for
+// sqrt_in_range and div_by; a Q under 2^-96, where sqrt_in_range may be an ulp off, and a quotient s/rho so small that div_by's unscaled residuals
+// lose bits, both add less than a quarter ulp to tau0sq >= 1/4 and change nothing
+__device__ __forceinline__ float smagorinsky_rate_plain(const KParams& p, const float Q, const Recip R) {
+	const float s = 0.76421222f*sqrt_in_range(Q);
+	const float tau = p.tau0+sqrt_in_range(p.tau0sq+div_by(s, R));
+	return div_by(2.0f, recip_prepare(tau));
+}
+__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_) { return smagorinsky_rate_of_Q(p, rhon, smagorinsky_Q(n_)); }
+// PLAIN (FP16C storage, LUW_PLAIN_ARITH): divisions by the density and the square roots as plain-range sequences (recip_prepare); R is the prepared
+// reciprocal of rhon, odd_density marks the lanes that redo those results with the library forms
+struct DensityRecip { Recip R; bool odd; };
+template<bool PLAIN> __device__ __forceinline__ float relaxation_rate(const KParams& p, const float rhon, const float* f, const float* feq, const DensityRecip& dr) {
 	if(!p.subgrid) return p.w;
 	float n_[19];
 	#pragma unroll
 	for(int i=1; i<19; i++) n_[i] = f[i]-feq[i];
-	return smagorinsky_rate(p, rhon, n_);
+	const float Q = smagorinsky_Q(n_);
+	if constexpr(PLAIN) {
+		float w = smagorinsky_rate_plain(p, Q, dr.R);
+		if(dr.odd) w = smagorinsky_rate_of_Q(p, rhon, Q);
+		return w;
+	} else return smagorinsky_rate_of_Q(p, rhon, Q);
 }
 // rho, u of the cell (moments, or the stored values on TYPE_E cells) and the force acting on it
-template<bool NOFORCE=false> __device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const float* f,
-		const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float& fxn, float& fyn, float& fzn) {
+template<bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const float* f,
+		const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float& fxn, float& fyn, float& fzn, DensityRecip& dr) {
 	if(is_E) {
 		rhon = rho[n];
 		uxn = u[n];
 		uyn = u[(size_t)p.Np+n];
 		uzn = u[2ull*p.Np+n];
+		if constexpr(PLAIN) { dr.R = recip_prepare(rhon); dr.odd = !density_is_ordinary(rhon); }
+	} else if constexpr(PLAIN) {
+		float mx, my, mz;
+		moment_sums(f, rhon, mx, my, mz);
+		dr.R = recip_prepare(rhon); dr.odd = !density_is_ordinary(rhon);
+		uxn = div_by(mx, dr.R); uyn = div_by(my, dr.R); uzn = div_by(mz, dr.R);
+		if(dr.odd) { uxn = mx/rhon; uyn = my/rhon; uzn = mz/rhon; }
 	} else {
 		calculate_rho_u(f, rhon, uxn, uyn, uzn);
 	}
@@ -363,11 +386,15 @@ template<bool NOFORCE=false> __device__ __forceinline__ void collide_head(const 
 	else assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
 }
 // the general tail: Guo forcing, equilibrium override on TYPE_E cells
-__device__ __forceinline__ void collide_tail_general(const KParams& p, const bool is_E, const bool forced, const float fxn, const float fyn, const float fzn,
-		float* f, const float rhon, float& uxn, float& uyn, float& uzn) {
+template<bool PLAIN=false> __device__ __forceinline__ void collide_tail_general(const KParams& p, const bool is_E, const bool forced, const float fxn, const float fyn, const float fzn,
+		float* f, const float rhon, float& uxn, float& uyn, float& uzn, const DensityRecip& dr) {
 	float feq[19], Fin[19];
 	if(forced) {
-		const float rho2 = 0.5f/rhon;
+		float rho2;
+		if constexpr(PLAIN) {
+			rho2 = div_by(0.5f, dr.R);
+			if(dr.odd) { asm volatile(""); rho2 = 0.5f/rhon; } // (the empty asm keeps this a branch, see collide_cell_pk)
+		} else rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
 		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
 		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
@@ -380,7 +407,7 @@ __device__ __forceinline__ void collide_tail_general(const KParams& p, const boo
 		for(int i=0; i<19; i++) Fin[i] = 0.0f;
 	}
 	calculate_f_eq(rhon, uxn, uyn, uzn, feq);
-	const float w = relaxation_rate(p, rhon, f, feq);
+	const float w = relaxation_rate<PLAIN>(p, rhon, f, feq, dr);
 	const float c_tau = fmaf(w, -0.5f, 1.0f);
 	const float omw = 1.0f-w;
 	#pragma unroll
@@ -393,11 +420,13 @@ __device__ __forceinline__ void collide_tail_general(const KParams& p, const boo
 // shift and the +-c clamp) in rhon,uxn,uyn,uzn.
 // NOFORCE: no force can act on any cell of the launch (box_force_mode): without the force assembly the FP16C kernel needs 69 instead of 89
 // VGPRs (76 instead of 93 with the thermal lattice) and no scalar spills -- 7 resp. 6 waves per SIMD instead of 5
-template<bool FAST=true, bool NOFORCE=false> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+// PLAIN: the populations come out of FP16C storage (bounded operands): plain-range divisions and square roots (recip_prepare)
+template<bool FAST=true, bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
 		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	float fxn, fyn, fzn;
-	collide_head<NOFORCE>(p, n, x, y, z, is_E, f, rho, u, F, rhon, uxn, uyn, uzn, fxn, fyn, fzn);
+	DensityRecip dr{};
+	collide_head<NOFORCE, PLAIN>(p, n, x, y, z, is_E, f, rho, u, F, rhon, uxn, uyn, uzn, fxn, fyn, fzn, dr);
 	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
 	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
 	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
@@ -412,13 +441,13 @@ template<bool FAST=true, bool NOFORCE=false> __device__ __forceinline__ void col
 		uyn = clampf(uyn, -DEF_C, DEF_C);
 		uzn = clampf(uzn, -DEF_C, DEF_C);
 		calculate_f_eq(rhon, uxn, uyn, uzn, feq);
-		const float w = relaxation_rate(p, rhon, f, feq);
+		const float w = relaxation_rate<PLAIN>(p, rhon, f, feq, dr);
 		const float omw = 1.0f-w;
 		#pragma unroll
 		for(int i=0; i<19; i++) f[i] = fmaf(omw, f[i], w*feq[i]);
 		return;
 	}
-	collide_tail_general(p, is_E, forced, fxn, fyn, fzn, f, rhon, uxn, uyn, uzn);
+	collide_tail_general<PLAIN>(p, is_E, forced, fxn, fyn, fzn, f, rhon, uxn, uyn, uzn, dr);
 }
 
 // ---------------------------------------------------------------- the same collision on PACKED pairs
@@ -450,8 +479,10 @@ __device__ __forceinline__ void calculate_f_eq_pk(const float rho, float ux, flo
 template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, const float uF) {
 	constexpr int I = 2*K+1;
 	constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
+	// c_(2k+2) . v = -(c_(2k+1) . v) exactly (-a-b and -(a+b) round alike), so the second lane takes the first lane's sums through the packed
+	// instructions' negate modifiers instead of two more additions each
 	const float cF = cdot<I>(fx, fy, fz), cu = cdot<I>(ux, uy, uz);
-	const f32x2 a = { cF, cdot<I+1>(fx, fy, fz) }, b = { cu, cdot<I+1>(ux, uy, uz) };
+	const f32x2 a = { cF, -cF }, b = { cu, -cu };
 	return splat2(w9)*__builtin_elementwise_fma(a, b+splat2(0.33333334f), splat2(uF));
 }
 // All cases in one: wave-uniform switches for "some lane may feel a force" and "some lane is a TYPE_E cell" select the
@@ -471,21 +502,41 @@ template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, co
 //   PAIR_FORCE_ANY      everything, switched per wave.
 enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
 
-// PLAIN: the densities of the whole wave lie in [1/4, 4] (voted by collide_cell_pk): divisions and square roots as the library's instruction
-// sequences minus their range handling (recip_prepare), the five divisions by the density sharing one reciprocal
-template<int FORCE, bool PLAIN> __device__ __forceinline__ void collide_cell_pk_tail(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const bool wave_has_E, const bool may_force,
-		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, const float rho_m, const float mx, const float my, const float mz,
-		float& rhon, float& uxn, float& uyn, float& uzn) {
+// ORDINARY densities (density_is_ordinary: 2^-60 <= rho < 2^60 -- anything a lattice that has not blown up holds) take the divisions and square
+// roots as the library's instruction sequences minus their range handling (recip_prepare), the five divisions by the density sharing one
+// reciprocal: 808 instead of 876 VALU instructions per lane in the force-free kernel, 992 instead of 1074 with uniform forces.  Lanes with any
+// other density (zero, negative, NaN, absurd) redo exactly those results with the library forms inside rarely taken divergent blocks, so the
+// values are the IEEE ones for EVERY input.  (A per-wave vote between two complete collisions was measured first: the duplicated code cost
+// more than the arithmetic saved, 1024x1024x256 + Coriolis 4.05 -> 4.25 ms; this form 4.05 -> 3.89, profiles/r03_plain_arith_ab.txt.)
+template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
+	constexpr bool PLAIN = LUW_PLAIN_ARITH!=0;
+	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+	const bool wave_has_E = __ballot(is_E)!=0ull;
+	float rho_m, mx, my, mz;
+	{
+		float f[19];
+		f[0] = f0;
+		#pragma unroll
+		for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
+		moment_sums(f, rho_m, mx, my, mz);
+	}
+	rhon = rho_m;
 	[[maybe_unused]] Recip R{};   // of the density the divisions below use: the moment sum, or (TYPE_E lanes) the stored field
-	if constexpr(PLAIN) { R = recip_prepare(rho_m); uxn = div_by(mx, R); uyn = div_by(my, R); uzn = div_by(mz, R); }
-	else { uxn = mx/rho_m; uyn = my/rho_m; uzn = mz/rho_m; }
+	[[maybe_unused]] bool odd_density = false;
+	if constexpr(PLAIN) {
+		R = recip_prepare(rho_m); uxn = div_by(mx, R); uyn = div_by(my, R); uzn = div_by(mz, R);
+		odd_density = !density_is_ordinary(rho_m);
+		if(odd_density) { uxn = mx/rho_m; uyn = my/rho_m; uzn = mz/rho_m; }
+	} else { uxn = mx/rho_m; uyn = my/rho_m; uzn = mz/rho_m; }
 	if(wave_has_E) {
 		if(is_E) {
+			rhon = rho[n];
 			uxn = u[n];
 			uyn = u[(size_t)p.Np+n];
 			uzn = u[2ull*p.Np+n];
 		}
-		if constexpr(PLAIN) R = recip_prepare(rhon); // rhon: the field value on TYPE_E lanes, the moment sum elsewhere
+		if constexpr(PLAIN) { R = recip_prepare(rhon); odd_density = !density_is_ordinary(rhon); } // rhon: the field value on TYPE_E lanes, the moment sum elsewhere
 	}
 	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
 	f32x2 Finp[9]; float Fin0 = 0.0f;
@@ -493,7 +544,10 @@ template<int FORCE, bool PLAIN> __device__ __forceinline__ void collide_cell_pk_
 		float fxn, fyn, fzn;
 		assemble_force<(FORCE==PAIR_FORCE_ANY)>(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
 		float rho2;
-		if constexpr(PLAIN) rho2 = div_by(0.5f, R); else rho2 = 0.5f/rhon;
+		if constexpr(PLAIN) {
+			rho2 = div_by(0.5f, R);
+			if(odd_density) { asm volatile(""); rho2 = 0.5f/rhon; } // (the empty asm keeps this a branch: a lone division would be hoisted in front of a select and run for every lane)
+		} else rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
 		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
 		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
@@ -514,7 +568,9 @@ template<int FORCE, bool PLAIN> __device__ __forceinline__ void collide_cell_pk_
 		float n_[19];
 		#pragma unroll
 		for(int k=0; k<9; k++) { const f32x2 d = fp[k]-feqp[k]; n_[2*k+1] = d.x; n_[2*k+2] = d.y; }
-		w = smagorinsky_rate(p, rhon, n_, PLAIN ? &R : nullptr);
+		const float Q = smagorinsky_Q(n_);
+		if constexpr(PLAIN) { w = smagorinsky_rate_plain(p, Q, R); if(odd_density) w = smagorinsky_rate_of_Q(p, rhon, Q); }
+		else w = smagorinsky_rate_of_Q(p, rhon, Q);
 	}
 	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;   // TYPE_E lanes through the relaxation rate (f = 0, w = 1, no Guo term) instead of nineteen selects
 	if constexpr(E_BY_RATE) { if(wave_has_E) w = is_E ? 1.0f : w; }
@@ -541,32 +597,6 @@ template<int FORCE, bool PLAIN> __device__ __forceinline__ void collide_cell_pk_
 	f0 = r0;
 	#pragma unroll
 	for(int k=0; k<9; k++) fp[k] = rp[k];
-}
-#ifndef LUW_PLAIN_ARITH
-#define LUW_PLAIN_ARITH 1   /* 0: the library's division / square root everywhere (A/B builds) */
-#endif
-template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
-		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
-	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
-	const bool wave_has_E = __ballot(is_E)!=0ull;
-	float rho_m, mx, my, mz;
-	{
-		float f[19];
-		f[0] = f0;
-		#pragma unroll
-		for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
-		moment_sums(f, rho_m, mx, my, mz);
-	}
-	rhon = rho_m;
-	bool plain = density_in_plain_range(rho_m);
-	if(wave_has_E) {
-		if(is_E) rhon = rho[n];
-		plain = plain&&density_in_plain_range(rhon);
-	}
-	// one vote per wave: every density in [1/4, 4] (any lattice that has not blown up) -> the collision with the plain-range arithmetic;
-	// otherwise the same collision with the library's division and square root.  Same values either way inside the range.
-	if(LUW_PLAIN_ARITH&&__ballot(!plain)==0ull) collide_cell_pk_tail<FORCE, true>(p, n, x, y, z, is_E, wave_has_E, may_force, f0, fp, rho, u, F, rho_m, mx, my, mz, rhon, uxn, uyn, uzn);
-	else collide_cell_pk_tail<FORCE, false>(p, n, x, y, z, is_E, wave_has_E, may_force, f0, fp, rho, u, F, rho_m, mx, my, mz, rhon, uxn, uyn, uzn);
 }
 // position-only test: can buffer nudging or the top sponge act on this cell (the zones of assemble_force)?
 __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {

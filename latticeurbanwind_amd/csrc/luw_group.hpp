@@ -51,7 +51,12 @@ struct luw_group {
 	bool failed = false;                      // a run stopped half-way: streams and sequence numbers are not trustworthy any more
 };
 
-static const uint32_t GROUP_X_SHELL = 64u;   // thickness of the x boundary slabs: one memory line of cells (a one-cell x face would run one lane per wave)
+// thickness of the x boundary slabs: one 256-byte memory line of cells (a one-cell x face would run one lane per wave) -- 64 FP32 cells, 128 FP16C
+// cells (a full wave of the pair kernel, which narrower slabs would leave to the one-cell kernel); LUW_X_SHELL overrides (A/B aid)
+static uint32_t group_x_shell(const luw_group* g) {
+	static const uint32_t env = getenv("LUW_X_SHELL") ? (uint32_t)strtoul(getenv("LUW_X_SHELL"), nullptr, 10) : 0u;
+	return env ? env : (g->ddf_bytes==2u ? 128u : 64u);
+}
 
 static void group_axis_ranges(const luw_group* g, const GroupDomain& d, const int a, uint32_t nonhalo[2], uint32_t lo_slab[2], uint32_t hi_slab[2], uint32_t inner[2]) {
 	nonhalo[0] = g->H[a]; nonhalo[1] = d.lN[a]-g->H[a];
@@ -59,8 +64,9 @@ static void group_axis_ranges(const luw_group* g, const GroupDomain& d, const in
 	const uint32_t lo = nonhalo[0], hi = nonhalo[1];
 	if(a!=0) { lo_slab[0] = lo; lo_slab[1] = lo+1u; hi_slab[0] = hi-1u; hi_slab[1] = hi; }
 	else {
-		const uint32_t first_end = std::min(lo+GROUP_X_SHELL, hi);
-		const uint32_t last_start = std::max(lo+((hi-1u-lo)/GROUP_X_SHELL)*GROUP_X_SHELL, first_end);
+		const uint32_t X = group_x_shell(g);
+		const uint32_t first_end = std::min(lo+X, hi);
+		const uint32_t last_start = std::max(lo+((hi-1u-lo)/X)*X, first_end);
 		lo_slab[0] = lo; lo_slab[1] = first_end; hi_slab[0] = last_start; hi_slab[1] = hi;
 	}
 	inner[0] = lo_slab[1]; inner[1] = hi_slab[0];

@@ -233,3 +233,43 @@ __global__ __launch_bounds__(256) void k_codec_check(unsigned long long* __restr
 	if(bad) atomicAdd(mismatches, bad);
 }
 
+// the plain-range division and square root of luw_device.hpp (recip_prepare / div_by / sqrt_in_range) against the library forms they replace:
+// mismatches[0]: square roots -- every float x = 0 or 2^-96 <= x < Inf; mismatches[1]: quotients n/d -- every float d of [1/4, 4] (2^25 + 1
+// of them) and 2^26 hashed d of the whole ordinary range [2^-60, 2^60), 64 numerators each: 0, 0.5, 2, and hashed floats of either sign from
+// [2^-25, 64) (bit patterns compared; a zero quotient's sign is not, see recip_prepare); mismatches[2]: the same denominators with numerators
+// on the momentum grid of the FP16C kernels, n = k 2^-25, |k| < 2^24
+__device__ __forceinline__ void arith_check_denominator(const uint32_t db, unsigned long long& bad_div, unsigned long long& bad_grid) {
+	const float d = __uint_as_float(db);
+	const Recip R = recip_prepare(d);
+	uint32_t h = db*2654435761u+12345u;
+	for(int k=0; k<64; k++) {
+		h = h*1664525u+1013904223u;
+		uint32_t nb = (h&0x807FFFFFu)|((102u+(h>>23)%31u)<<23);   // exponent field 102 .. 132: 2^-25 <= |n| < 64
+		if(k==0) nb = 0u; else if(k==1) nb = 0x3F000000u; else if(k==2) nb = 0x40000000u;
+		const float n = __uint_as_float(nb);
+		const uint32_t want = __float_as_uint(n/d), got = __float_as_uint(div_by(n, R));
+		bad_div += (want!=got)&&(((want|got)&0x7FFFFFFFu)!=0u);
+		const float ng = (float)((int32_t)(h>>7)-(1<<24))*0x1p-25f;   // a multiple of 2^-25 below 1/2 in magnitude: what the moment sums of FP16C populations are
+		const uint32_t wg = __float_as_uint(ng/d), gg = __float_as_uint(div_by(ng, R));
+		bad_grid += (wg!=gg)&&(((wg|gg)&0x7FFFFFFFu)!=0u);
+	}
+}
+__global__ __launch_bounds__(256) void k_arith_check(unsigned long long* __restrict__ mismatches) {
+	const uint32_t tid = blockIdx.x*blockDim.x+threadIdx.x, nth = gridDim.x*blockDim.x;
+	unsigned long long bad_sqrt = 0ull, bad_div = 0ull, bad_grid = 0ull;
+	for(unsigned long long v=tid; v<0x7F800000ull; v+=nth) {
+		const uint32_t b = (uint32_t)v;
+		if(b!=0u&&b<(31u<<23)) continue;                           // below 2^-96: the library pre-scales, the callers do not care (smagorinsky_rate_plain)
+		const float x = __uint_as_float(b);
+		bad_sqrt += __float_as_uint(sqrt_in_range(x))!=__float_as_uint(sqrtf(x));
+	}
+	for(uint32_t db=0x3E800000u+tid; db<=0x40800000u; db+=nth) arith_check_denominator(db, bad_div, bad_grid);
+	for(uint32_t i=tid; i<(1u<<26); i+=nth) {                      // the whole ordinary range: bit patterns 0x21800000 .. 0x5D7FFFFF
+		const uint32_t h = i*2246822519u+374761393u;
+		const uint32_t db = 0x21800000u+(uint32_t)(((unsigned long long)h*0x3C000000ull)>>32);
+		if(density_is_ordinary(__uint_as_float(db))) arith_check_denominator(db, bad_div, bad_grid); else bad_div++;
+	}
+	if(bad_sqrt) atomicAdd(mismatches, bad_sqrt);
+	if(bad_div) atomicAdd(mismatches+1, bad_div);
+	if(bad_grid) atomicAdd(mismatches+2, bad_grid);
+}

@@ -148,10 +148,10 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STA
 		float rhon, uxn, uyn, uzn;
 		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
 			float u0[3];
-			collide_cell<true, NOFORCE>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
+			collide_cell<true, NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
 			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
 		} else
-		collide_cell<(MODE!=3), NOFORCE>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
+		collide_cell<(MODE!=3), NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
 			u[n] = uxn;

@@ -57,9 +57,10 @@ def tile_lattice(world):
 class DomainLayout:
     """Pure host logic: where a rank sits, what it owns, whom it talks to (FX/lbm.cpp:1066-1073,1912-1931)."""
 
-    X_SHELL = 64   # thickness of the x boundary slabs: one memory line of cells (see shell_boxes)
+    X_SHELL = 64   # thickness of the x boundary slabs: one memory line of FP32 cells (see shell_boxes); FP16C lattices take 128 (x_shell)
 
-    def __init__(self, global_N, D, rank):
+    def __init__(self, global_N, D, rank, x_shell=None):
+        if x_shell: self.X_SHELL = int(x_shell)
         self.gN = tuple(int(v) for v in global_N)
         self.D = tuple(int(v) for v in D)
         Dx, Dy, Dz = self.D
@@ -184,6 +185,18 @@ class TorchDistTransport:
                                   "to_ranks": [self.layout.neighbor(a, +1), self.layout.neighbor(a, -1)]}
         torch.cuda.synchronize(device)
         return wire
+
+
+class SelfExchangeTransport(TorchDistTransport):
+    """every neighbour is THIS rank: each face leaves and comes back through the real transport's self send / receive (RCCL on a GPU box).
+    Physically the rank's block made periodic.  What one rank of an N-GPU run does per step -- boundary shell, pack, exchange, unpack, interior,
+    pipelining -- on one GPU, without the wire to another device (bench.py's rank-shape blocks, tests/rank_shape_worker.py)."""
+
+    def __init__(self, layout, group=None):
+        super().__init__(layout, group)
+        import torch.distributed as dist
+        me = dist.get_rank() if dist.is_initialized() else 0
+        self.layout = type("SelfNeighbours", (), {"neighbor": staticmethod(lambda axis, sign: me), "lN": layout.lN, "split_axes": layout.split_axes})()
 
 
 def init_rccl_process_group(local_rank, timeout=None):
@@ -351,7 +364,10 @@ class DomainDecomposedLBM:
             import torch.distributed as dist
             rank = dist.get_rank()
         import os
-        self.layout = DomainLayout(global_N, D, rank)
+        # x slabs of the boundary shell: 64 cells = one 256-byte line of FP32 values; FP16C lattices take 128 cells -- the same bytes, and a full
+        # wave of the pair kernel (2 cells per lane), which narrower slabs would leave to the one-cell kernel (LUW_X_SHELL overrides: A/B aid)
+        x_shell = int(os.environ.get("LUW_X_SHELL", "0")) or (128 if backend_kw.get("fp16c") or getattr(getattr(backend, "o", None), "cfg", None) is not None and backend.o.cfg.fp16c else 64)
+        self.layout = DomainLayout(global_N, D, rank, x_shell=x_shell)
         self.wire = {}           # standalone face-exchange rates per split axis (TorchDistTransport.warm_up with LUW_MEASURE_WIRE=<repetitions>)
         self.lNx, self.lNy, self.lNz = self.layout.lN
         self.global_offset = self.layout.O

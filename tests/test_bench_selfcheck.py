@@ -45,4 +45,6 @@ def test_parity_tile_shapes():
             # zones thinner than every rank's block: a domain that does not own a face never lies inside that face's zone
             assert all(bench.PARITY_NUDGE_CELLS < g // d for g, d in zip(gN, D)) and bench.PARITY_SPONGE_CELLS < gN[2] // D[2]
             if D[0] > 1:
-                assert lay.interior_box()[1] - lay.interior_box()[0] >= 128        # an interior between the two 64-cell x slabs
+                for x_shell in (64, 128):                                          # FP32 / FP16C slabs
+                    l2 = DomainLayout(gN, D, world - 1, x_shell=x_shell)
+                    assert l2.interior_box()[1] - l2.interior_box()[0] >= 128      # an interior between the two x slabs, wide enough for the pair kernel

@@ -26,7 +26,7 @@ def bench(world, *extra):
 
 
 def test_two_ranks_self_check_and_blocks(luw):
-    out = bench(2, "--size", "256", "64", "64")
+    out = bench(2, "--size", "384", "64", "64")
     assert out["n_gpus"] == 2 and out["config"]["n_gpu"] == [2, 1, 1] and out["value"] > 0
     par = out["parity"]
     assert par["ok"] and len(par["cases"]) == 4                         # literal cut and x-whole cut, FP32 and FP16C + Coriolis
@@ -44,5 +44,5 @@ def test_two_ranks_self_check_and_blocks(luw):
 
 
 def test_four_ranks_fp16c_coriolis(luw):
-    out = bench(4, "--size", "256", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host")
+    out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host")
     assert out["config"]["n_gpu"] == [2, 2, 1] and out["parity"]["ok"] and out["value"] > 0

@@ -69,6 +69,31 @@ def test_fp16c_codec_exhaustive(luw):
     assert n.value == 0
 
 
+def test_plain_range_division_and_square_root_equal_the_library_forms(luw):
+    # recip_prepare / div_by / sqrt_in_range (csrc/luw_device.hpp) vs `a/b` and sqrtf() on the device: every float of the square root's range,
+    # 2^31 quotients over every denominator of [1/4, 4], and the same on the 2^-25 grid of FP16C moment sums
+    import ctypes as C
+    from latticeurbanwind_amd import capi
+    n = (C.c_uint64 * 3)(7, 7, 7)
+    capi.check(capi.load().luw_selfcheck_arith(0, n))
+    assert list(n) == [0, 0, 0]
+
+
+def test_density_outside_the_plain_range_takes_the_library_path(luw):
+    """densities outside [1/4, 4] (nothing a healthy lattice holds): the FP16C kernels vote per wave and fall back to the library's division and
+    square root -- the oracle's IEEE results, bit for bit, in both regimes and in waves that mix them"""
+    from oracle import oracle
+    Nx, Ny, Nz = 512, 6, 5
+    flags, u, rho = synthetic_state(Nx, Ny, Nz, seed=77, shell="luw")
+    rho = rho.copy().reshape(Nz, Ny, Nx)
+    rho[:, 2, :] = 0.2; rho[:, 3, 100:300] = 4.5; rho[2, 4, 7] = 0.01     # whole rows, part of a row, one cell
+    for kern in ("p", "s"):
+        g, o = make_pair(luw, oracle, Nx, Ny, Nz, 1e-4, True, kern, (flags, u, rho.ravel()), coriolis=(0.0, 3e-5, 4e-5))
+        g.run(3); o.run(3)
+        check(g, o, "densities outside the plain range, kernel " + kern)
+        g.close()
+
+
 SIZES = [(32, 32, 32), (48, 40, 24), (37, 19, 11), (6, 5, 7), (3, 4, 5), (130, 6, 5), (260, 3, 4), (2, 3, 3), (514, 4, 3)]
 
 
