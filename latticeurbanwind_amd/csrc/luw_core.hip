@@ -185,7 +185,8 @@ static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, con
 	size_t chunk = 0u;
 	if(total>=(64ull<<20)) {
 		const size_t cap = alloc_vmm_chunk(), mib2 = 2ull<<20;
-		if(cap==0u||cap==~(size_t)0u) chunk = cap;
+		static const bool whole_chunks = getenv("LUW_ALLOC_EQUAL")&&getenv("LUW_ALLOC_EQUAL")[0]=='0'; // 0: chunks of exactly the configured size, the array rounded up (round 2; A/B aid)
+		if(cap==0u||cap==~(size_t)0u||whole_chunks) chunk = cap==0u||cap==~(size_t)0u ? cap : std::min<size_t>(cap, ((total+mib2-1u)/mib2)*mib2);
 		else { const size_t pieces = (total+cap-1u)/cap; chunk = (((total+pieces-1u)/pieces+mib2-1u)/mib2)*mib2; }
 	}
 	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk);
@@ -307,6 +308,23 @@ static void force_free_core(const luw_solver* s, uint32_t lo[3], uint32_t hi[3])
 	if(k.sponge_active&&k.has_t) h[2] = std::min<int64_t>(h[2], (int64_t)k.Nzg-1-(int64_t)k.sponge_N-k.Oz);
 	for(int a=0; a<3; a++) { lo[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(l[a], 0), N[a]); hi[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(h[a], (int64_t)lo[a]), N[a]); }
 }
+// The nudging / sponge zones as cell ranges of this domain (KParams zw_lo ... zp_n): the conditions of FX/kernel.cpp:1537-1541,1598 -- the term is on,
+// the domain owns the face, it is not the downstream one, 0 <= distance <= Nbuf (sponge: 0 <= layer < Nsponge) -- solved for the local coordinate
+// and clipped to the domain.  n = 0: no cell.
+static void set_zone_ranges(KParams& k) {
+	auto range = [](const bool on, const int64_t lo, const int64_t hi, const int64_t N, uint32_t& zlo, uint32_t& zn) {
+		const int64_t a = std::max<int64_t>(lo, 0), b = std::min<int64_t>(hi, N-1);
+		if(on&&b>=a) { zlo = (uint32_t)a; zn = (uint32_t)(b-a+1); } else { zlo = 0u; zn = 0u; }
+	};
+	const int64_t nb = (int64_t)k.buffer_N;
+	const bool buf = k.buffer_active!=0u;
+	range(buf&&k.downstream_face!=1u&&k.has_w, k.west_x, k.west_x+nb, k.Nx, k.zw_lo, k.zw_n);
+	range(buf&&k.downstream_face!=2u&&k.has_e, k.east_x-nb, k.east_x, k.Nx, k.ze_lo, k.ze_n);
+	range(buf&&k.downstream_face!=3u&&k.has_s, k.south_y, k.south_y+nb, k.Ny, k.zs_lo, k.zs_n);
+	range(buf&&k.downstream_face!=4u&&k.has_n, k.north_y-nb, k.north_y, k.Ny, k.zn_lo, k.zn_n);
+	range(buf&&k.has_t, k.top_z-nb, k.top_z, k.Nz, k.zt_lo, k.zt_n);
+	range(k.sponge_active&&k.has_t, (int64_t)k.top_z-(int64_t)k.sponge_N, (int64_t)k.top_z-1, k.Nz, k.zp_lo, k.zp_n);
+}
 // what can push the cells of box b (collide_cell_pk): re-evaluated per launch, so luw_set_f / luw_set_coriolis take effect at once.
 // (Cutting a box that reaches into the zones along their boundaries -- specialised kernel on the zone-free core, general kernels on six slabs
 // around it -- was built and measured on the 512^3 urban tile with its 80-cell nudging zones and 100-layer sponge: 2.36-2.38 ms in one
@@ -387,6 +405,15 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 #endif
 	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where a specialisation would do (same values)
 	const int mode = general_only ? PAIR_FORCE_ANY : box_force_mode(s, b);
+	if(s->d_gi) { // thermal lattice on: both lattices two cells per lane (THERMAL), the second set of values parked in LDS
+		const uint32_t lds = (bx/64u)*pair_park_bytes_per_wave(true);
+		#define LUW_LAUNCH_PT(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE, true, true>), grid, block, lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{}, (uint16_t*)s->d_gi, s->d_T)
+		if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_PT(1, PAIR_FORCE_NONE); else LUW_LAUNCH_PT(0, PAIR_FORCE_NONE); }
+		else if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_PT(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_PT(0, PAIR_FORCE_UNIFORM); }
+		else { if(odd) LUW_LAUNCH_PT(1, PAIR_FORCE_ANY); else LUW_LAUNCH_PT(0, PAIR_FORCE_ANY); }
+		#undef LUW_LAUNCH_PT
+		return;
+	}
 	// PARK (luw_kernels_step.hpp): the lane's second set of 19 values waits in LDS instead of in registers.  Measured interleaved on MI355X
 	// (profiles/r03_pair_park_ab.txt): it pays where the registers cost a wave of occupancy that matters -- the general kernel, 109 -> 91 VGPRs,
 	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
@@ -397,7 +424,7 @@ static void launch_pair(luw_solver* s, const Box& b, const int write_fields, con
 #endif
 	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (unsigned)(LUW_PAIR_PARK_DEFAULT);
 	if(park_modes&(1u<<mode)) {
-		const uint32_t lds = (bx/64u)*PAIR_PARK_BYTES_PER_WAVE;
+		const uint32_t lds = (bx/64u)*pair_park_bytes_per_wave(false);
 		#define LUW_LAUNCH_PP(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE, true>), grid, block, lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
 		if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_NONE); else LUW_LAUNCH_PP(0, PAIR_FORCE_NONE); }
 		else if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_PP(0, PAIR_FORCE_UNIFORM); }
@@ -431,7 +458,8 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
 	static const uint32_t pair_min = getenv("LUW_PAIR_MIN_ROW") ? (uint32_t)strtoul(getenv("LUW_PAIR_MIN_ROW"), nullptr, 10) : 128u; // A/B aid (round 2: 256)
 	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=pair_min) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
-	if(s->d_gi) k = LUW_KERNEL_SCALAR; // the thermal cell update lives in the scalar kernel only
+	static const bool thermal_pair = !(getenv("LUW_THERMAL_PAIR")&&getenv("LUW_THERMAL_PAIR")[0]=='0'); // 0: the thermal lattice through the one-cell kernel only (round 2; A/B and test aid)
+	if(s->d_gi&&(!fp16||!thermal_pair||st)) k = LUW_KERNEL_SCALAR; // FP32 / sampled steps: the thermal cell update of the one-cell kernel
 #ifdef LUW_AB_KERNELS
 	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the vector kernels assume rows that start on a 16-byte boundary at x = 0
 #endif
@@ -652,6 +680,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	k.has_w = k.west_x>=0&&k.west_x<(int)cfg->Nx; k.has_e = k.east_x>=0&&k.east_x<(int)cfg->Nx;
 	k.has_s = k.south_y>=0&&k.south_y<(int)cfg->Ny; k.has_n = k.north_y>=0&&k.north_y<(int)cfg->Ny;
 	k.has_t = k.top_z>=0&&k.top_z<(int)cfg->Nz;
+	set_zone_ranges(k);
 	k.has_F = (cfg->options&LUW_OPT_FORCE_FIELD) ? 1u : 0u;
 	k.w_T = (cfg->options&LUW_OPT_TEMPERATURE) ? literal_roundtrip(1.0f/(2.0f*cfg->alpha+0.5f)) : 0.0f; // FX/lbm.cpp:750
 

@@ -45,6 +45,13 @@ struct KParams {
 	uint32_t has_w, has_e, has_s, has_n, has_t;
 	const float* wbuf;        // wbuf[d] = sin^2(pi/2 (1 - d/Nbuf)),           d = 0..Nbuf   (FX/kernel.cpp:1581-1583)
 	const float* sigma;       // sigma[d] = inv_tau sin^2(pi/2 (1 - d/(Ns-1))), d = 0..Ns-1  (FX/kernel.cpp:1604-1606)
+	// The same zones as cell ranges of THIS domain, filled by the host (luw_core.hip, set_zone_ranges): a coordinate c lies in a zone when
+	// (c - lo) < n as unsigned numbers; n = 0 where the zone does not exist here (term off, face not owned, downstream face).  One subtraction and
+	// one compare per face instead of the four conditions of FX/kernel.cpp:1537-1541 each; same cells.
+	uint32_t zw_lo, zw_n, ze_lo, ze_n;   // buffer nudging next to the west / east face (x)
+	uint32_t zs_lo, zs_n, zn_lo, zn_n;   // south / north face (y)
+	uint32_t zt_lo, zt_n;                // top (z)
+	uint32_t zp_lo, zp_n;                // top sponge layers (z)
 	uint32_t has_F;
 	float w_T;                // TEMPERATURE: def_w_T = 1/(2 alpha + 1/2), FX/lbm.cpp:750 (0 when the thermal lattice is off)
 };
@@ -275,26 +282,18 @@ template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const K
 	}
 	if constexpr(!ZONES) return;
 	if(p.buffer_active && !is_E) {
-		const int Nbuf_i = (int)p.buffer_N;
-		const int d_w_i = (int)x+p.Ox;
-		const int d_e_i = (int)(p.Nxg-1u)-((int)x+p.Ox);
-		const int d_s_i = (int)y+p.Oy;
-		const int d_n_i = (int)(p.Nyg-1u)-((int)y+p.Oy);
-		const int d_t_i = (int)(p.Nzg-1u)-((int)z+p.Oz);
-		const bool in_w = p.downstream_face!=1u&&p.has_w&&d_w_i>=0&&d_w_i<=Nbuf_i;
-		const bool in_e = p.downstream_face!=2u&&p.has_e&&d_e_i>=0&&d_e_i<=Nbuf_i;
-		const bool in_s = p.downstream_face!=3u&&p.has_s&&d_s_i>=0&&d_s_i<=Nbuf_i;
-		const bool in_n = p.downstream_face!=4u&&p.has_n&&d_n_i>=0&&d_n_i<=Nbuf_i;
-		const bool in_t = p.has_t&&d_t_i>=0&&d_t_i<=Nbuf_i;
+		// distance to each face (meaningful inside that face's zone, wrapped-around garbage outside, where it is not used)
+		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y, d_t = (uint32_t)p.top_z-z;
+		const bool in_w = x-p.zw_lo<p.zw_n, in_e = x-p.ze_lo<p.ze_n, in_s = y-p.zs_lo<p.zs_n, in_n = y-p.zn_lo<p.zn_n, in_t = z-p.zt_lo<p.zt_n;
 		if(in_w||in_e||in_s||in_n||in_t) {
 			uint32_t d_min = p.buffer_N+1u;
 			uint32_t n_ref = n;
 			const uint32_t rowyz = (y+z*p.Ny)*p.Px;
-			if(in_w) { const uint32_t d = (uint32_t)d_w_i; if(d<d_min) { d_min = d; n_ref = (uint32_t)p.west_x+rowyz; } }
-			if(in_e) { const uint32_t d = (uint32_t)d_e_i; if(d<d_min) { d_min = d; n_ref = (uint32_t)p.east_x+rowyz; } }
-			if(in_s) { const uint32_t d = (uint32_t)d_s_i; if(d<d_min) { d_min = d; n_ref = x+((uint32_t)p.south_y+z*p.Ny)*p.Px; } }
-			if(in_n) { const uint32_t d = (uint32_t)d_n_i; if(d<d_min) { d_min = d; n_ref = x+((uint32_t)p.north_y+z*p.Ny)*p.Px; } }
-			if(in_t) { const uint32_t d = (uint32_t)d_t_i; if(d<d_min) { d_min = d; n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px; } }
+			if(in_w) { if(d_w<d_min) { d_min = d_w; n_ref = (uint32_t)p.west_x+rowyz; } }
+			if(in_e) { if(d_e<d_min) { d_min = d_e; n_ref = (uint32_t)p.east_x+rowyz; } }
+			if(in_s) { if(d_s<d_min) { d_min = d_s; n_ref = x+((uint32_t)p.south_y+z*p.Ny)*p.Px; } }
+			if(in_n) { if(d_n<d_min) { d_min = d_n; n_ref = x+((uint32_t)p.north_y+z*p.Ny)*p.Px; } }
+			if(in_t) { if(d_t<d_min) { d_min = d_t; n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px; } }
 			const float w_buf = p.wbuf[d_min];
 			const float u_target_x = u[n_ref];
 			const float u_target_y = u[(size_t)p.Np+n_ref];
@@ -307,15 +306,12 @@ template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const K
 			fzn += rhon*a_z;
 		}
 	}
-	if(p.sponge_active && !is_E && p.has_t) {
-		const int d_t_i = (int)(p.Nzg-2u)-((int)z+p.Oz);
-		if(d_t_i>=0&&d_t_i<(int)p.sponge_N) {
-			const float sigma = p.sigma[d_t_i];
-			const uint32_t n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px;
-			fxn += rhon*sigma*(u[n_ref]-uxn);
-			fyn += rhon*sigma*(u[(size_t)p.Np+n_ref]-uyn);
-			fzn += rhon*sigma*(u[2ull*p.Np+n_ref]-uzn);
-		}
+	if(!is_E && z-p.zp_lo<p.zp_n) { // top sponge (zp_n = 0 unless the term is on and this domain owns the top)
+		const float sigma = p.sigma[(uint32_t)p.top_z-1u-z];   // layer index (Nzg-2) - (z+Oz), FX/kernel.cpp:1600
+		const uint32_t n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px;
+		fxn += rhon*sigma*(u[n_ref]-uxn);
+		fyn += rhon*sigma*(u[(size_t)p.Np+n_ref]-uyn);
+		fzn += rhon*sigma*(u[2ull*p.Np+n_ref]-uzn);
 	}
 	if(p.has_F) {
 		fxn += F[n];
@@ -509,7 +505,7 @@ enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
 // values are the IEEE ones for EVERY input.  (A per-wave vote between two complete collisions was measured first: the duplicated code cost
 // more than the arithmetic saved, 1024x1024x256 + Coriolis 4.05 -> 4.25 ms; this form 4.05 -> 3.89, profiles/r03_plain_arith_ab.txt.)
 template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
-		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn) {
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
 	constexpr bool PLAIN = LUW_PLAIN_ARITH!=0;
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
@@ -538,6 +534,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 		}
 		if constexpr(PLAIN) { R = recip_prepare(rhon); odd_density = !density_is_ordinary(rhon); } // rhon: the field value on TYPE_E lanes, the moment sum elsewhere
 	}
+	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
 	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
 	f32x2 Finp[9]; float Fin0 = 0.0f;
 	if(forced) {
@@ -600,15 +597,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 }
 // position-only test: can buffer nudging or the top sponge act on this cell (the zones of assemble_force)?
 __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {
-	bool zone = false;
-	if(p.buffer_active) { // the same face tests as assemble_force (the downstream face and faces this domain does not own have no zone)
-		const int Nbuf_i = (int)p.buffer_N;
-		const int d_w = (int)x+p.Ox, d_e = (int)(p.Nxg-1u)-((int)x+p.Ox), d_s = (int)y+p.Oy, d_n = (int)(p.Nyg-1u)-((int)y+p.Oy), d_t = (int)(p.Nzg-1u)-((int)z+p.Oz);
-		zone = (p.downstream_face!=1u&&p.has_w&&d_w>=0&&d_w<=Nbuf_i) || (p.downstream_face!=2u&&p.has_e&&d_e>=0&&d_e<=Nbuf_i)
-		    || (p.downstream_face!=3u&&p.has_s&&d_s>=0&&d_s<=Nbuf_i) || (p.downstream_face!=4u&&p.has_n&&d_n>=0&&d_n<=Nbuf_i) || (p.has_t&&d_t>=0&&d_t<=Nbuf_i);
-	}
-	if(p.sponge_active&&p.has_t) { const int d = (int)(p.Nzg-2u)-((int)z+p.Oz); zone = zone || (d>=0&&d<(int)p.sponge_N); }
-	return zone;
+	return x-p.zw_lo<p.zw_n || x-p.ze_lo<p.ze_n || y-p.zs_lo<p.zs_n || y-p.zn_lo<p.zn_n || z-p.zt_lo<p.zt_n || z-p.zp_lo<p.zp_n;
 }
 
 // ---------------------------------------------------------------- thermal D3Q7 lattice (TEMPERATURE), FX/kernel.cpp:1306-1335,1639-1684
@@ -618,6 +607,24 @@ __device__ __forceinline__ void calculate_g_eq(const float T, const float ux, co
 	geq[1] = fmaf(wsT4, ux, wsTm1); geq[2] = fmaf(wsT4, -ux, wsTm1);
 	geq[3] = fmaf(wsT4, uy, wsTm1); geq[4] = fmaf(wsT4, -uy, wsTm1);
 	geq[5] = fmaf(wsT4, uz, wsTm1); geq[6] = fmaf(wsT4, -uz, wsTm1);
+}
+// the cell update on streamed-in populations g[7] (in place): T = sum g + 1 (or the preset on TYPE_T cells), top sponge on T, BGK with w_T
+// (TYPE_T: g = g_eq); writes T of a cell that is not preset.  FX/kernel.cpp:1652-1684
+__device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+		const float ux, const float uy, const float uz, float* __restrict__ Tf, float* g) {
+	const bool preset = (flagsn&TYPE_T)!=0u;
+	float Tn;
+	if(preset) Tn = Tf[n];
+	else { Tn = 0.0f; for(int i=0; i<7; i++) Tn += g[i]; Tn += 1.0f; }
+	if(!preset && (flagsn&TYPE_BO)!=TYPE_E && z-p.zp_lo<p.zp_n) Tn = fmaf(p.sigma[(uint32_t)p.top_z-1u-z], Tf[x+(y+(uint32_t)p.top_z*p.Ny)*p.Px]-Tn, Tn);
+	float geq[7];
+	calculate_g_eq(Tn, ux, uy, uz, geq);
+	if(preset) { for(int i=0; i<7; i++) g[i] = geq[i]; }
+	else {
+		Tf[n] = Tn;
+		const float omw = 1.0f-p.w_T;
+		for(int i=0; i<7; i++) g[i] = fmaf(omw, g[i], p.w_T*geq[i]);
+	}
 }
 // One cell of the temperature lattice: Esoteric-Pull stream-in, T = sum g + 1 (or the preset on TYPE_T cells), top sponge
 // on T, BGK with w_T (TYPE_T: g = g_eq), stream-out.  n, jx, jy, jz are ELEMENT indices of the cell and its +x, +y, +z
@@ -634,22 +641,7 @@ template<typename T, int PARITY> __device__ __forceinline__ void thermal_collide
 		g[i  ] = ddf_decode<T>(gi[(size_t)(PARITY ? i : i+1)*Np+n]);
 		g[i+1] = ddf_decode<T>(gi[(size_t)(PARITY ? i+1 : i)*Np+jn[k]]);
 	}
-	const bool preset = (flagsn&TYPE_T)!=0u;
-	float Tn;
-	if(preset) Tn = Tf[n];
-	else { Tn = 0.0f; for(int i=0; i<7; i++) Tn += g[i]; Tn += 1.0f; }
-	if(p.sponge_active && !preset && (flagsn&TYPE_BO)!=TYPE_E && p.has_t) {
-		const int d_t_i = (int)(p.Nzg-2u)-((int)z+p.Oz);
-		if(d_t_i>=0&&d_t_i<(int)p.sponge_N) Tn = fmaf(p.sigma[d_t_i], Tf[x+(y+(uint32_t)p.top_z*p.Ny)*p.Px]-Tn, Tn);
-	}
-	float geq[7];
-	calculate_g_eq(Tn, ux, uy, uz, geq);
-	if(preset) { for(int i=0; i<7; i++) g[i] = geq[i]; }
-	else {
-		Tf[n] = Tn;
-		const float omw = 1.0f-p.w_T;
-		for(int i=0; i<7; i++) g[i] = fmaf(omw, g[i], p.w_T*geq[i]);
-	}
+	thermal_cell(p, n, x, y, z, flagsn, ux, uy, uz, Tf, g);
 }
 // stream-out of the 7 encoded populations (Esoteric-Pull slots); code_of(i) yields the storage value of population i
 template<typename T, int PARITY, typename F> __device__ __forceinline__ void thermal_store(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz, T* __restrict__ gi, F code_of) {

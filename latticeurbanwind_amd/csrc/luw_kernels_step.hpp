@@ -247,12 +247,27 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 #ifndef LUW_PARK_WAVES_ANY
 #define LUW_PARK_WAVES_ANY 5
 #endif
-constexpr int pair_waves(const int force, const bool park) {
+#ifndef LUW_THERMAL_WAVES_NONE
+#define LUW_THERMAL_WAVES_NONE 5
+#endif
+#ifndef LUW_THERMAL_WAVES_UNIFORM
+#define LUW_THERMAL_WAVES_UNIFORM 5
+#endif
+#ifndef LUW_THERMAL_WAVES_ANY
+#define LUW_THERMAL_WAVES_ANY 4
+#endif
+constexpr int pair_waves(const int force, const bool park, const bool thermal = false) {
+	if(thermal) return force==PAIR_FORCE_NONE ? LUW_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_THERMAL_WAVES_UNIFORM : LUW_THERMAL_WAVES_ANY; // (a wave more each spills to scratch)
 	return park ? (force==PAIR_FORCE_NONE ? LUW_PARK_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_PARK_WAVES_UNIFORM : LUW_PARK_WAVES_ANY) : (force==PAIR_FORCE_ANY ? 4 : 5);
 }
-constexpr uint32_t PAIR_PARK_BYTES_PER_WAVE = 19u*64u*4u;
-template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK), pair_waves(FORCE, PARK)))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
-		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}) {
+constexpr uint32_t pair_park_bytes_per_wave(const bool thermal) { return (thermal ? 26u : 19u)*64u*4u; }
+// THERMAL (LUW_OPT_TEMPERATURE): the D3Q7 lattice of both cells the same way -- seven more dwords per lane (plane 0 and the three (A, B) pairs of
+// +x, +y, +z: the +x plane on a 2-byte boundary like the five x+1 planes of the D3Q19 lattice), the cell update of luw_device.hpp (thermal_cell)
+// behind each collision with the velocity before the force shift, the seven codes of both cells merged per plane at the tail.
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL), pair_waves(FORCE, PARK, THERMAL)))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}, uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
+	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
+	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	const RowOff rb = row_offsets(p, y, z);
@@ -299,6 +314,15 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 			}
 		});
 	}
+	[[maybe_unused]] uint32_t rawg[7];                               // THERMAL: the same for the seven planes of the temperature lattice
+	if constexpr(THERMAL) {
+		gi += rb.r00;
+		rawg[0] = ld_pair<true>(gi, o.x);
+		rawg[1] = ld_pair<true>(gi+(size_t)slotA<PARITY>(1)*Np, o.x); rawg[2] = ld_pair<false>(gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb), nlane<1>(o));
+		rawg[3] = ld_pair<true>(gi+(size_t)slotA<PARITY>(3)*Np, o.x); rawg[4] = ld_pair<true>(gi+(size_t)slotB<PARITY>(3)*Np+nrow<3>(rb), nlane<3>(o));
+		rawg[5] = ld_pair<true>(gi+(size_t)slotA<PARITY>(5)*Np, o.x); rawg[6] = ld_pair<true>(gi+(size_t)slotB<PARITY>(5)*Np+nrow<5>(rb), nlane<5>(o));
+		if(wrap) { const uint32_t hi = *(gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb)); rawg[2] = (rawg[2]&0xFFFFu)|(hi<<16); }
+	}
 	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
 	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull);
 	// specialised modes: TYPE_E cells decode to f = 0 (collide_cell_pk relaxes them with w = 1)
@@ -307,7 +331,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&proc[0]&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (E_BY_RATE&&proc[1]&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
 	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
 	// (or pre-swap for the pass-through)
-	auto one_cell = [&](const int c, float& f0, f32x2* fp) {
+	auto one_cell = [&](const int c, float& f0, f32x2* fp, [[maybe_unused]] float* g) {
 		auto bits = [&](const int q) { // (sign-extended half) << 12 in one SDWA shift, then the mask of half_to_float_custom_sx
 			uint32_t t;
 			if(c) asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(raw[q]));
@@ -317,9 +341,20 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		f0 = __uint_as_float(bits(0))*0x1p+112f;
 		#pragma unroll
 		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
+		if constexpr(THERMAL) {
+			#pragma unroll
+			for(int q=0; q<7; q++) {
+				uint32_t t;
+				if(c) asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(rawg[q]));
+				else asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(rawg[q]));
+				g[q] = __uint_as_float(t&0x87FFF000u)*0x1p+112f;
+			}
+		}
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
-			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn);
+			[[maybe_unused]] float u0[3];
+			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr);
+			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				rho[n+c] = rhon;
 				u[n+c] = uxn;
@@ -333,19 +368,22 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		} else {
 			#pragma unroll
 			for(int k=0; k<9; k++) { const f32x2 t = { fp[k].y, fp[k].x }; fp[k] = t; }
+			if constexpr(THERMAL) { for(int k=0; k<3; k++) { const float t = g[2*k+1]; g[2*k+1] = g[2*k+2]; g[2*k+2] = t; } }
 			if constexpr(STATS) sample_idle_cell(c);
 		}
 	};
 	float fa0, fb0; f32x2 fa[9], fb[9];
+	[[maybe_unused]] float ga[7], gb[7];
 	[[maybe_unused]] uint32_t* slot = nullptr;                     // PARK: this lane's column in its wave's LDS region, slot[64*q]
 	if constexpr(PARK) {
 		extern __shared__ uint32_t pair_park[];
-		slot = pair_park+(threadIdx.x>>6)*(19u*64u)+(threadIdx.x&63u);
+		slot = pair_park+(threadIdx.x>>6)*((uint32_t)NSLOT*64u)+(threadIdx.x&63u);
 		#pragma unroll
 		for(int q=0; q<19; q++) slot[64*q] = raw[q];
+		if constexpr(THERMAL) { for(int q=0; q<7; q++) slot[64*(19+q)] = rawg[q]; }
 		asm volatile("" ::: "memory");
 	}
-	one_cell(0, fa0, fa);
+	one_cell(0, fa0, fa, ga);
 	if constexpr(PARK) {
 		asm_fence9(fa0, fa);                                       // cell x is finished ...
 		asm volatile("" ::: "memory");
@@ -357,15 +395,20 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 			slot[64*(2*k+1)] = __float_as_uint(fa[k].x); slot[64*(2*k+2)] = __float_as_uint(fa[k].y);
 			raw[2*k+1] = t0; raw[2*k+2] = t1;
 		}
+		if constexpr(THERMAL) { for(int q=0; q<7; q++) { const uint32_t t = slot[64*(19+q)]; slot[64*(19+q)] = __float_as_uint(ga[q]); rawg[q] = t; } }
 		asm volatile("" ::: "memory");
 		asm_fence_u(raw);
 	} else {
 		asm_fence9(fa0, fa); asm_fence_u(raw);                     // cell x is finished before cell x+1 starts
 	}
-	one_cell(1, fb0, fb);
+	one_cell(1, fb0, fb, gb);
 	if constexpr(STATS) stats_welford_pair(Np, S, n, smp);        // both cells' samples, one 8-byte access per array
 	if constexpr(!PARK) asm_fence9(fa0, fa);
 	asm_fence9(fb0, fb);                                           // all floating-point work is done ...
+	if constexpr(THERMAL) {
+		asm volatile("" : "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3]), "+v"(gb[4]), "+v"(gb[5]), "+v"(gb[6]));
+		if constexpr(!PARK) asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]));
+	}
 	// ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
 	if constexpr(PARK) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" ::: "memory"); else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");
 	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
@@ -382,8 +425,24 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		#pragma unroll
 		for(int k=0; k<9; k++) fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
 	}
+	[[maybe_unused]] uint32_t cg[7];                               // THERMAL: the merged dwords of the temperature lattice
+	if constexpr(THERMAL) {
+		#pragma unroll
+		for(int q=0; q<7; q++) {
+			float a;
+			if constexpr(PARK) a = __uint_as_float(slot[64*(19+q)]); else a = ga[q];
+			cg[q] = __builtin_amdgcn_perm(fp16c_code_hi_in_rtz_mode(gb[q]), fp16c_code_hi_in_rtz_mode(a), 0x07060302u);
+		}
+	}
 	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };
 	uint32_t cs[5];   // the five x+1 planes, stored last (dword or, on the row-end lane, two halves)
+	// General kernel: the plane bases of the stores are formed again from a plane stride the compiler cannot connect with the one the loads used, so
+	// that the 19 64-bit bases of the loads die with the loads instead of living through both collisions -- with the zone parameters on top they
+	// do not fit the scalar registers and went into lanes of a spill VGPR (40 v_writelane + 88 v_readlane per lane, static; now 12 + 24, and 92
+	// VALU instructions fewer).  The other instantiations have room (no spills) and keep the bases (the rebuilt ones cost 150 scalar instructions).
+	size_t Np_tail = p.Np;
+	if constexpr(FORCE==PAIR_FORCE_ANY) asm volatile("" : "+s"(Np_tail));
+	#define Np Np_tail
 	#define LUW_REDEFINE_OFFSETS asm volatile("" : "+v"(o.x), "+v"(o.xp)) /* saddr stores, see k_stream_collide_s */
 	LUW_REDEFINE_OFFSETS;
 	st_pair<true>(fi, o.x, pack(0));
@@ -395,6 +454,12 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		else cs[k] = pack(i);
 		st_pair<true>(fi+(size_t)slotA<PARITY>(i)*Np, o.x, pack(i+1));
 	});
+	if constexpr(THERMAL) { // the aligned planes of the temperature lattice; its +x plane goes with the five x+1 planes below
+		st_pair<true>(gi, o.x, cg[0]);
+		st_pair<true>(gi+(size_t)slotA<PARITY>(1)*Np, o.x, cg[2]);
+		st_pair<true>(gi+(size_t)slotB<PARITY>(3)*Np+nrow<3>(rb), nlane<3>(o), cg[3]); st_pair<true>(gi+(size_t)slotA<PARITY>(3)*Np, o.x, cg[4]);
+		st_pair<true>(gi+(size_t)slotB<PARITY>(5)*Np+nrow<5>(rb), nlane<5>(o), cg[5]); st_pair<true>(gi+(size_t)slotA<PARITY>(5)*Np, o.x, cg[6]);
+	}
 	if(!wrap&&!tail) {
 		LUW_REDEFINE_OFFSETS;
 		static_for_pairs([&](auto ic) {
@@ -402,6 +467,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 			constexpr int k = i==1 ? 0 : i==7 ? 1 : i==9 ? 2 : i==13 ? 3 : 4;
 			if constexpr(i==1||i==7||i==9||i==13||i==15) st_pair<false>(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb), nlane<i>(o), cs[k]);
 		});
+		if constexpr(THERMAL) st_pair<false>(gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb), nlane<1>(o), cg[1]);
 	} else if(tail) { // the only real cell is x = Nx-1: its x+1 neighbour is the row's x = 0 (the dword load above already started there);
 		// x = 1 belongs to another lane's stores, so only the low half goes out
 		static_for_pairs([&](auto ic) {
@@ -411,6 +477,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 				*(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)) = (uint16_t)(cs[k]&0xFFFFu);
 			}
 		});
+		if constexpr(THERMAL) *(gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb)) = (uint16_t)(cg[1]&0xFFFFu);
 	} else {
 		LUW_REDEFINE_OFFSETS;
 		static_for_pairs([&](auto ic) {
@@ -422,7 +489,9 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 				B[0] = (uint16_t)(cs[k]>>16);
 			}
 		});
+		if constexpr(THERMAL) { uint16_t* B = gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb); B[p.Nx-1u] = (uint16_t)(cg[1]&0xFFFFu); B[0] = (uint16_t)(cg[1]>>16); }
 	}
 	#undef LUW_REDEFINE_OFFSETS
+	#undef Np
 }
 

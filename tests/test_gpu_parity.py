@@ -436,6 +436,44 @@ def test_thermal_lattice_matches_oracle(luw, fp16c, sponge):
     g.close()
 
 
+@pytest.mark.parametrize("size", [(514, 5, 6), (257, 4, 5), (640, 6, 4), (130, 7, 5)])
+@pytest.mark.parametrize("forces", ["none", "coriolis", "zones"])
+def test_thermal_lattice_in_the_pair_kernel(luw, size, forces):
+    """FP16C + thermal lattice on rows wide enough for the pair kernel (both lattices two cells per lane, the second set of values parked in
+    LDS): even and odd widths (the row-end lane's wrap fix-up and the single-cell tail lane of the +x plane), TYPE_T presets on the TYPE_E shell
+    and inside, top sponge on T, all three force instantiations -- T, the thermal DDFs, u, rho and the DDFs against the oracle"""
+    from oracle import oracle
+    Nx, Ny, Nz = size
+    st = synthetic_state(Nx, Ny, Nz, seed=13, shell="luw")
+    spg = dict(n_cells=2, inv_tau=0.02)
+    nud = dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1) if forces == "zones" else None
+    g = luw.LBM(Nx, Ny, Nz, 1e-3, fp16c=True, alpha=4e-3, top_sponge=spg, buffer_nudging=nud)
+    o = oracle.OracleLBM(Nx, Ny, Nz, 1e-3, fp16c=True, alpha=4e-3)
+    o.set_top_sponge(2, 0.02)
+    if nud: o.set_buffer_nudging(3, 0.0133333, 2, 1)
+    if forces != "none":
+        g.set_coriolis(0.0, 3e-5, 4e-5); o.set_coriolis(0.0, 3e-5, 4e-5)
+    flags = st[0].copy()
+    flags[(flags & 3) == 2] |= TYPE_T
+    rng = np.random.default_rng(5)
+    flags[(rng.random(flags.size) < 0.02) & ((flags & 3) == 0)] |= TYPE_T
+    Tinit = np.ones(flags.size, np.float32)
+    hot = (flags & TYPE_T) != 0
+    Tinit[hot] = (1.0 + 0.05 * rng.standard_normal(flags.size).astype(np.float32))[hot]
+    for l in (g, o):
+        (l.flags.data if hasattr(l.flags, "data") else l.flags)[:] = flags
+        (l.u.data if hasattr(l.u, "data") else l.u)[:] = st[1]
+        (l.rho.data if hasattr(l.rho, "data") else l.rho)[:] = st[2]
+        (l.T.data if hasattr(l.T, "data") else l.T)[:] = Tinit
+    for steps in (1, 2, 6):
+        g.run(steps); o.run(steps)
+        g.T.read_from_device()
+        assert np.array_equal(g.T.data, o.T), "%s %s: T after %d more steps: %d cells differ" % (size, forces, steps, int((g.T.data != o.T).sum()))
+        assert ddf_equal(g.download_gi(), o.gi), "%s %s: thermal DDFs" % (size, forces)
+        check(g, o, "flow fields with the thermal lattice in the pair kernel")
+    g.close()
+
+
 def test_fp32_row_form_addressing_matches_oracle():
     """FP32 lattices whose planes exceed 32-bit byte offsets (beyond 2^30 cells per GPU, e.g. 1024^3) take the row-form addressing of
     the scalar kernel; the oracle cannot run at that size, so the same code path is forced on the small parity cases

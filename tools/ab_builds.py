@@ -23,8 +23,11 @@ src = os.path.join(ROOT, "latticeurbanwind_amd", "csrc", "luw_core.hip")
 libs = []
 for tag, extra in builds:
     so = os.path.join(out_dir, "libluw_%s.so" % tag)
+    if extra.startswith("@"):                     # a library built elsewhere (e.g. an older commit, shipped under tools/): "<tag>=@<path>"
+        so = os.path.join(ROOT, extra[1:])
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-Wno-unused-function", *extra.split(), "-shared", "-o", so, src]
-    subprocess.check_call(cmd)
+    if not extra.startswith("@"):
+        subprocess.check_call(cmd)
     L = C.CDLL(so)
     L.luw_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]; L.luw_host_ptr.argtypes = [C.c_void_p, C.c_int]; L.luw_host_ptr.restype = C.c_void_p
     L.luw_run_timed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]; L.luw_initialize.argtypes = [C.c_void_p]; L.luw_run.argtypes = [C.c_void_p, C.c_uint64]
