@@ -144,6 +144,10 @@ int luw_run(luw_solver* s, uint64_t steps);
 uint64_t luw_get_t(const luw_solver* s);     /* LBM::get_t */
 
 /* run-time setters the reference allows between steps at no cost (kernel arguments, FX/lbm.cpp:345) */
+/* 1 when every step of this solver writes rho,u like the reference's UPDATE_FIELDS build: LUW_OPT_UPDATE_FIELDS_EVERY_STEP, or -- decided by
+ * luw_initialize -- a buffer-nudging / sponge reference cell (outer face the domain owns, FX/kernel.cpp:1543-1611) is a fluid cell, whose u those
+ * terms read one step later; with TYPE_E / solid faces (every LUW deck) the fields are written by the last step of a run() call only. */
+int luw_fields_every_step(const luw_solver* s);
 int luw_set_f(luw_solver* s, float fx, float fy, float fz);               /* LBM::set_f */
 int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz);        /* LBM::set_coriolis */
 
@@ -300,6 +304,32 @@ int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_
 int luw_group_gather_attach(luw_group* g, uint32_t count, const uint64_t* cells);
 int luw_group_gather_u(luw_group* g, float* out);
 int luw_group_stats_reset(luw_group* g);
+/* VTK payloads straight from the devices: Memory_Container::write_vtk (FX/lbm.hpp:307-356) and the sections of write_avg_vtk (FX/setup.cpp:2513-2683)
+ * without the full-field download.  Every domain converts its own cells on its device -- SoA -> AoS, SI scaling, big-endian -- in z slabs that a
+ * writer thread puts into the open file `fd` with pwrite() from `file_offset` on (the caller has written the text header before it); planes
+ * z < Nz_write are written (0: all).  Same bytes as the host conversion.  source:
+ *   U, RHO       factor * value                         (raw_u / raw_rho files; rho,u must be current: the last step of a run writes them)
+ *   T            value * factor + offset if affine      (units.si_T), else factor * value
+ *   AVG_U, AVG_RHO, AVG_T     mean * factor + offset    (u_avg, rho_avg, T_avg of the averaged file)
+ *   FLUID, TKE, TI, TLS       the derived fields of write_avg_vtk from the means and second moments on the devices, times factor; u_factor = SI
+ *                velocity per lattice velocity, grid_dx = SI cell size, tls_cap = cap of the length scale; want_* = the deck's output switches */
+#define LUW_EXPORT_U 0
+#define LUW_EXPORT_RHO 1
+#define LUW_EXPORT_T 2
+#define LUW_EXPORT_AVG_U 3
+#define LUW_EXPORT_AVG_RHO 4
+#define LUW_EXPORT_AVG_T 5
+#define LUW_EXPORT_FLUID 6
+#define LUW_EXPORT_TKE 7
+#define LUW_EXPORT_TI 8
+#define LUW_EXPORT_TLS 9
+typedef struct luw_export_params {
+	uint32_t struct_size;
+	float factor, offset; int32_t affine;
+	float u_factor, grid_dx, tls_cap; int32_t want_tke, want_ti, want_tls;
+} luw_export_params;
+int luw_group_export_vtk(luw_group* g, int source, const luw_export_params* prm, uint32_t Nz_write, int fd, uint64_t file_offset);
+uint64_t luw_group_stats_count(const luw_group* g);            /* samples accumulated since luw_group_stats_reset (avg_count of FX/setup.cpp:4441) */
 int luw_group_stats_download(luw_group* g, float* avg_u, float* avg_rho, float* m2_u, float* m2_v, float* m2_w, float* avg_T, uint64_t* count);
 
 #ifdef __cplusplus

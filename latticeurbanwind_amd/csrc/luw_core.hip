@@ -102,7 +102,7 @@ static void dev_free(DevBlock& b) {
 	}
 	b = DevBlock{};
 }
-static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, const size_t vmm_chunk) {
+static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, const size_t vmm_chunk, const bool short_last = false) {
 	b = DevBlock{};
 	if(vmm_chunk==0u) { const hipError_t e = hipMalloc(&b.base, bytes); if(e==hipSuccess) b.bytes = bytes; else b.base = nullptr; return e; }
 	hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
@@ -110,18 +110,23 @@ static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, c
 	hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
 	if(e!=hipSuccess) return e;
 	const size_t want = vmm_chunk==~(size_t)0u ? bytes : vmm_chunk;   // ~0: the whole block as one physical allocation
-	const size_t chunk = ((std::max(want, gran)+gran-1u)/gran)*gran, total = ((bytes+chunk-1u)/chunk)*chunk;
+	const size_t chunk = ((std::max(want, gran)+gran-1u)/gran)*gran;
+	// short_last: the last chunk holds only the remainder (at the allocation granularity) instead of a whole chunk
+	const size_t whole = (bytes/chunk)*chunk, rest = ((bytes-whole+gran-1u)/gran)*gran;
+	const size_t total = short_last ? whole+rest : ((bytes+chunk-1u)/chunk)*chunk;
 	if((e = hipMemAddressReserve(&b.base, total, chunk, nullptr, 0ull))!=hipSuccess) { b.base = nullptr; return e; }
 	b.bytes = total; b.chunk_bytes = chunk;
+	size_t mapped = 0u;
 	for(size_t off=0u; off<total; off+=chunk) {
+		const size_t len = std::min(chunk, total-off);
 		hipMemGenericAllocationHandle_t h;
-		if((e = hipMemCreate(&h, chunk, &prop, 0ull))!=hipSuccess) break;
-		if((e = hipMemMap((char*)b.base+off, chunk, 0u, h, 0ull))!=hipSuccess) { (void)hipMemRelease(h); break; }
-		b.chunks.push_back(h);
+		if((e = hipMemCreate(&h, len, &prop, 0ull))!=hipSuccess) break;
+		if((e = hipMemMap((char*)b.base+off, len, 0u, h, 0ull))!=hipSuccess) { (void)hipMemRelease(h); break; }
+		b.chunks.push_back(h); mapped += len;
 	}
 	if(e==hipSuccess) { hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite; e = hipMemSetAccess(b.base, total, &acc, 1u); }
 	if(e!=hipSuccess) { // undo what was mapped
-		if(!b.chunks.empty()) (void)hipMemUnmap(b.base, b.chunks.size()*chunk);
+		if(!b.chunks.empty()) (void)hipMemUnmap(b.base, mapped);
 		for(auto& h : b.chunks) (void)hipMemRelease(h);
 		(void)hipMemAddressFree(b.base, total);
 		b = DevBlock{};
@@ -154,6 +159,7 @@ struct luw_solver {
 	bool initialized = false;
 	bool counted = false;    // registered in g_live_solvers
 	bool fields_current = true; // device rho,u reflect the state after the last executed step
+	bool every_step_auto = false; // a nudging / sponge reference cell is a fluid cell: rho,u are written by every step (see reference_cells_are_inputs)
 	size_t ddf_bytes = 4;
 	void* d_fi = nullptr;
 	float* d_rho = nullptr; float* d_u = nullptr; uint8_t* d_flags = nullptr; float* d_F = nullptr;
@@ -180,16 +186,17 @@ struct luw_solver {
 static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, const size_t elem_bytes) {
 	DevBlock blk;
 	const size_t lead = (size_t)(64u-s->kp.halo_x)*elem_bytes, total = elems*elem_bytes+64u*elem_bytes;
-	// arrays under 64 MiB: hipMalloc.  Larger ones: equal chunks of at most the configured size (1 GiB), sized so that the last one is full too --
-	// rounding the array up to whole 1 GiB chunks would cost up to a chunk per array (u, m2, avg_u of a 512^3 domain: 1.5 -> 2 GiB each)
+	// arrays under 64 MiB: hipMalloc.  Larger ones: chunks of EXACTLY the configured size (1 GiB) -- measured: the same lattice on chunks of 0.93 GiB
+	// ("equal pieces, no waste") runs the step 8-15 % slower (1024x1024x256 FP32 7.30 vs 6.72 ms, FP16C 3.97 vs 3.45; profiles/r03_alloc_chunks_ab.txt) --
+	// and only the LAST chunk cut to the remainder, so that an array costs at most one allocation granule more than its size instead of up to a
+	// whole chunk (u, m2, avg_u of a 512^3 domain: 1.5 -> 2 GiB each before).  LUW_ALLOC_LAST=whole keeps a whole last chunk (A/B aid).
+	static const bool whole_last = getenv("LUW_ALLOC_LAST")&&strncmp(getenv("LUW_ALLOC_LAST"), "whole", 5)==0;
 	size_t chunk = 0u;
 	if(total>=(64ull<<20)) {
 		const size_t cap = alloc_vmm_chunk(), mib2 = 2ull<<20;
-		static const bool whole_chunks = getenv("LUW_ALLOC_EQUAL")&&getenv("LUW_ALLOC_EQUAL")[0]=='0'; // 0: chunks of exactly the configured size, the array rounded up (round 2; A/B aid)
-		if(cap==0u||cap==~(size_t)0u||whole_chunks) chunk = cap==0u||cap==~(size_t)0u ? cap : std::min<size_t>(cap, ((total+mib2-1u)/mib2)*mib2);
-		else { const size_t pieces = (total+cap-1u)/cap; chunk = (((total+pieces-1u)/pieces+mib2-1u)/mib2)*mib2; }
+		chunk = (cap==0u||cap==~(size_t)0u) ? cap : std::min<size_t>(cap, ((total+mib2-1u)/mib2)*mib2);
 	}
-	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk);
+	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk, !whole_last);
 	if(e!=hipSuccess&&chunk) { (void)hipGetLastError(); e = dev_alloc(blk, total, s->cfg.device, 0u); } // no VMM on this system: hipMalloc
 	if(e!=hipSuccess) return e;
 	e = hipMemsetAsync(blk.base, 0, total, s->stream); // padding / not-yet-uploaded memory must hold defined values
@@ -1110,8 +1117,31 @@ int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz) {
 	return LUW_OK;
 }
 
+// Buffer nudging and the top sponge pull cells towards u of a REFERENCE cell on an outer face (FX/kernel.cpp:1543-1611).  In LUW's decks those
+// faces are TYPE_E (or solid ground): their u is an input that no step rewrites, so it does not matter that this library writes rho,u only in the
+// last step of a run() call while the reference (UPDATE_FIELDS) writes them in every step.  A caller who leaves FLUID cells on such a face would see
+// the target velocity of the last written step instead of the previous step's: for such a lattice the solver writes the fields every step, like
+// the reference, and the results stay the reference's whatever the length of the run() calls.  Checked on the host mirror at initialisation.
+static bool reference_cells_are_inputs(const luw_solver* s) {
+	const KParams& k = s->kp;
+	const uint32_t Nx = s->cfg.Nx, Ny = s->cfg.Ny, Nz = s->cfg.Nz;
+	auto input_cell = [&](const uint32_t x, const uint32_t y, const uint32_t z) { return (s->h_flags[(size_t)x+((size_t)y+(size_t)z*Ny)*Nx]&TYPE_BO)!=0u; };
+	bool ok = true;
+	auto x_face = [&](const uint32_t x) { for(uint32_t z=0u; z<Nz&&ok; z++) for(uint32_t y=0u; y<Ny; y++) if(!input_cell(x, y, z)) { ok = false; break; } };
+	auto y_face = [&](const uint32_t y) { for(uint32_t z=0u; z<Nz&&ok; z++) for(uint32_t x=0u; x<Nx; x++) if(!input_cell(x, y, z)) { ok = false; break; } };
+	auto z_face = [&](const uint32_t z) { for(uint32_t y=0u; y<Ny&&ok; y++) for(uint32_t x=0u; x<Nx; x++) if(!input_cell(x, y, z)) { ok = false; break; } };
+	if(k.zw_n) x_face((uint32_t)k.west_x);
+	if(k.ze_n&&ok) x_face((uint32_t)k.east_x);
+	if(k.zs_n&&ok) y_face((uint32_t)k.south_y);
+	if(k.zn_n&&ok) y_face((uint32_t)k.north_y);
+	if((k.zt_n||k.zp_n)&&ok) z_face((uint32_t)k.top_z);
+	return ok;
+}
+int luw_fields_every_step(const luw_solver* s) { return (s&&((s->cfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u||s->every_step_auto)) ? 1 : 0; }
+
 int luw_initialize(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_initialize: null solver");
+	s->every_step_auto = !reference_cells_are_inputs(s);
 	if(int e = luw_upload(s, LUW_MASK_RHO|LUW_MASK_U|LUW_MASK_FLAGS|LUW_MASK_F|LUW_MASK_T)) return e;
 	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
 	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
@@ -1206,7 +1236,7 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms, cons
 	if(int e = set_device(s)) return e;
 	if(!s->initialized) { if(int e = luw_initialize(s)) return e; } // LBM::run initialises on first use, FX/lbm.cpp:1294-1296
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
-	const bool every = (s->cfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
+	const bool every = luw_fields_every_step(s)!=0;
 	std::vector<hipEvent_t> ev;
 	struct EventsFree { std::vector<hipEvent_t>& v; ~EventsFree() { for(hipEvent_t e : v) if(e) (void)hipEventDestroy(e); } } events_free{ ev }; // on every path out
 	if(mean_kernel_ms) {
@@ -1283,3 +1313,4 @@ int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, 
 } // extern "C"
 
 #include "luw_group.hpp"
+#include "luw_export.hpp"

@@ -291,7 +291,7 @@ static int group_join(luw_group* g) {
 // what one step means for one domain, besides the exchange: kernels of step i of a luw_group_run call
 struct GroupStepPlan { bool sampled, fused, separate; int wf; };
 static int domain_plan_step(luw_group* g, const size_t k, const uint64_t i, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, GroupStepPlan& pl) {
-	const bool every = (g->gcfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u;
+	const bool every = luw_fields_every_step(g->dom[k].s)!=0; // the option, or a fluid reference cell on one of this domain's faces (luw_initialize)
 	pl.sampled = stride>0ull && i+1ull>=first_sample && (i+1ull-first_sample)%stride==0ull;
 	pl.fused = false;
 	if(pl.sampled) { int f = 0; GROUP_TRY(luw_stats_begin_sample(g->dom[k].s, &f)); pl.fused = f!=0; } // every domain answers alike (same kernels everywhere)
@@ -774,6 +774,7 @@ int luw_group_gather_u(luw_group* g, float* out) {
 	return LUW_OK;
 }
 
+uint64_t luw_group_stats_count(const luw_group* g) { return (g&&!g->dom.empty()) ? g->dom[0].s->avg_count : 0ull; }
 int luw_group_stats_reset(luw_group* g) {
 	if(!g) return fail(LUW_ERR_INVALID, "luw_group_stats_reset: null group");
 	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_stats_reset(d.s)); }

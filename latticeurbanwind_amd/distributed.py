@@ -443,6 +443,11 @@ class DomainDecomposedLBM:
         b.reset_time_step()               # FX/lbm.cpp:1258
         self.initialized = True
 
+    def _every_step(self):
+        """rho,u written by every step: a nudging / sponge reference cell of this rank's faces is a fluid cell (luw_fields_every_step)"""
+        lbm = getattr(self.backend, "lbm", None)
+        return bool(lbm is not None and lbm.fields_every_step())
+
     def _join(self):
         b = self.backend
         if hasattr(b, "comm"):
@@ -473,7 +478,7 @@ class DomainDecomposedLBM:
             fused = sampled and hasattr(b, "stats_begin_sample") and b.stats_begin_sample()
             kw = {"sample": True} if fused else {}
             if fused: sampled = False
-            wf = (i + 1 == steps) or sampled
+            wf = (i + 1 == steps) or sampled or self._every_step()
             if self.overlap:
                 comm, comp = b.comm, b.compute
                 if wf and stats_done is not None:

@@ -171,6 +171,12 @@ public:
 		if(s0) { luw_check(luw_stats_download(s0, avg_u, avg_rho, m2_u, m2_v, m2_w, count)); if(avg_T) luw_check(luw_stats_download_T(s0, avg_T)); }
 		else luw_check(luw_group_stats_download(g, avg_u, avg_rho, m2_u, m2_v, m2_w, avg_T, count));
 	}
+	uint64_t stats_count() const { return luw_group_stats_count(g); }
+	// Memory_Container::write_vtk's payload (FX/lbm.hpp:330-356) and the sections of write_avg_vtk without the full-field download: every domain
+	// converts its own cells on its device (SoA -> AoS, SI units, big-endian), a writer thread puts the slabs into the open file (luw_group_export_vtk)
+	void export_vtk(const int source, const luw_export_params& prm, const uint Nz_write, const int fd, const uint64_t file_offset) {
+		luw_check(luw_group_export_vtk(g, source, &prm, Nz_write, fd, file_offset));
+	}
 	void gather_attach(const uint32_t count, const uint64_t* cells) { luw_check(luw_group_gather_attach(g, count, cells)); }
 	void gather_u(float* out) { luw_check(luw_group_gather_u(g, out)); }
 	luw_group* group() { return g; }

@@ -26,6 +26,8 @@
 #include <cstring>
 #include <ctime>
 #include <filesystem>
+#include <fcntl.h>
+#include <unistd.h>
 #include <fstream>
 #include <functional>
 #include <iomanip>
@@ -359,6 +361,32 @@ static void write_field_vtk(const string& filename, const VtkGeom& g, const floa
 	// the field named T goes through units.si_T (value*unit_K + offset), every other one through its unit factor (FX/lbm.hpp:343)
 	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(affine ? data[(ulong)d*N+i]*factor+offset : factor*data[(ulong)d*N+i]); });
 	file.write((const char*)buf, (std::streamsize)(points*comps*4ull));
+}
+
+// The same files without the host in the data path (default; LUW_HOST_VTK=1 keeps the host conversion above, the cross-check of the tests): header by
+// this process, payload by the devices through LBM::export_vtk -- no field download, no global conversion buffer.
+static bool host_vtk_path() { static const bool on = std::getenv("LUW_HOST_VTK")&&std::getenv("LUW_HOST_VTK")[0]=='1'; return on; }
+struct VtkFile { // an open output file and the offset of its next byte
+	int fd = -1; uint64_t pos = 0ull;
+	explicit VtkFile(const string& filename) {
+		std::filesystem::create_directories(std::filesystem::path(filename).parent_path());
+		fd = ::open(filename.c_str(), O_WRONLY|O_CREAT|O_TRUNC, 0644);
+		if(fd<0) fatal("ERROR: cannot open "+filename+" for writing.");
+	}
+	~VtkFile() { if(fd>=0) ::close(fd); }
+	void text(const string& t) { size_t put = 0u; while(put<t.size()) { const ssize_t w = ::pwrite(fd, t.data()+put, t.size()-put, (off_t)(pos+put)); if(w<=0) fatal("ERROR: writing a VTK header failed."); put += (size_t)w; } pos += t.size(); }
+	void payload(LBM& lbm, const int source, const luw_export_params& prm, const VtkGeom& g, const uint comps) {
+		lbm.export_vtk(source, prm, g.Nz_out, fd, pos);
+		pos += (uint64_t)g.Nx*g.Ny*g.Nz_out*comps*4ull;
+	}
+};
+static luw_export_params export_params(const float factor, const float offset = 0.0f, const bool affine = false) {
+	luw_export_params p{}; p.struct_size = sizeof(p); p.factor = factor; p.offset = offset; p.affine = affine ? 1 : 0; return p;
+}
+static void write_device_field_vtk(LBM& lbm, const string& filename, const VtkGeom& g, const int source, const uint comps, const float factor, const float offset = 0.0f, const bool affine = false) {
+	VtkFile f(filename);
+	f.text(vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n");
+	f.payload(lbm, source, export_params(factor, offset, affine), g, comps);
 }
 
 // ------------------------------------------------------------------------------------------------ main
@@ -1171,7 +1199,12 @@ int main(int argc, char** argv) {
 			if(!speed_reported) { speed_reported = true; g_progress.emit("speed_estimate", "Estimating solve speed", "Benchmarking normal LBM solver step "+to_string_u(nsteps)+"/"+to_string_u(nsteps), (long long)nsteps, (long long)nsteps, false); }
 			batch_cap = std::max<ulong>((ulong)16u, std::min<ulong>((ulong)1u<<20, (ulong)(0.25*meter.steps_per_second(t))));
 			show_progress(false); // about 0.25 s of work per batch
-			if(unsteady>0ull&&t%unsteady==0ull) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); note_saved({fn}); last_u_vtk_t = t; }
+			if(unsteady>0ull&&t%unsteady==0ull) {
+				const string fn = default_filename(vtk_dir, "u", t);
+				if(host_vtk_path()) { lbm.u.read_from_device(); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); }
+				else write_device_field_vtk(lbm, fn, geom, LUW_EXPORT_U, 3u, units.si_u(1.0f));
+				note_saved({fn}); last_u_vtk_t = t;
+			}
 			if(!probes.empty()&&t>=probe_start_t) { // FX/setup.cpp:4498-4509
 				lbm.gather_u(probe_buf.data());
 				size_t k = 0u;
@@ -1186,9 +1219,19 @@ int main(int argc, char** argv) {
 		{ // write_final_transient, FX/setup.cpp:4762-4776
 			const ulong t = lbm.get_t();
 			std::vector<string> saved;
-			if(last_u_vtk_t!=t) { lbm.u.read_from_device(); const string fn = default_filename(vtk_dir, "u", t); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); saved.push_back(fn); }
-			lbm.rho.read_from_device(); const string fr = default_filename(vtk_dir, "rho", t); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f)); saved.push_back(fr);
-			if(use_temperature_bc) { lbm.T.read_from_device(); const string ft = default_filename(vtk_dir, "T", t); write_field_vtk(ft, geom, lbm.T.data<float>(), 1u, units.unit_K, units.unit_K_offset, true); saved.push_back(ft); }
+			const string fn = default_filename(vtk_dir, "u", t), fr = default_filename(vtk_dir, "rho", t), ft = default_filename(vtk_dir, "T", t);
+			if(host_vtk_path()) {
+				if(last_u_vtk_t!=t) { lbm.u.read_from_device(); write_field_vtk(fn, geom, lbm.u.data<float>(), 3u, units.si_u(1.0f)); }
+				lbm.rho.read_from_device(); write_field_vtk(fr, geom, lbm.rho.data<float>(), 1u, units.si_rho(1.0f));
+				if(use_temperature_bc) { lbm.T.read_from_device(); write_field_vtk(ft, geom, lbm.T.data<float>(), 1u, units.unit_K, units.unit_K_offset, true); }
+			} else {
+				if(last_u_vtk_t!=t) write_device_field_vtk(lbm, fn, geom, LUW_EXPORT_U, 3u, units.si_u(1.0f));
+				write_device_field_vtk(lbm, fr, geom, LUW_EXPORT_RHO, 1u, units.si_rho(1.0f));
+				if(use_temperature_bc) write_device_field_vtk(lbm, ft, geom, LUW_EXPORT_T, 1u, units.unit_K, units.unit_K_offset, true);
+			}
+			if(last_u_vtk_t!=t) saved.push_back(fn);
+			saved.push_back(fr);
+			if(use_temperature_bc) saved.push_back(ft);
 			bool first = true; for(const string& f : saved) { print_kv_row((first&&last_u_vtk_t!=t) ? "VTK file" : "", f+" saved"); first = false; }
 			g_progress.emit("save", "Saving results", saved.size()==1u ? saved.back() : to_string_u(saved.size())+" files saved; last: "+saved.back(), (long long)saved.size(), (long long)saved.size(), false);
 		}
@@ -1200,7 +1243,33 @@ int main(int argc, char** argv) {
 			if(info.is_open()) { const float dt_si = c.cell_m*(lbm_ref_u/si_ref_u); info << "dt = " << std::fixed << std::setprecision(10) << dt_si << "s\n"; info.close(); println("| Successfully wrote "+info_path+" |"); }
 			else println("ERROR: Could not open "+info_path+" for writing.");
 		}
-		if(avg_window>0ull) { // finalize_avg + write_avg_vtk, FX/setup.cpp:4693-4717,2513-2683
+		if(avg_window>0ull&&!host_vtk_path()) { // finalize_avg + write_avg_vtk (FX/setup.cpp:4693-4717,2513-2683) with the devices producing every section
+			const uint64_t avg_count = lbm.stats_count();
+			if(avg_count>0ull) {
+				const string fn = default_filename(results_vtk_dir, vtk_prefix+c.datetime+"_avg", lbm.get_t());
+				VtkFile f(fn);
+				f.text(vtk_header(fn, geom));
+				const float u_factor = units.si_u(1.0f), rho_factor = units.si_rho(1.0f);
+				auto section = [&](const string& name, const int source, const uint comps, luw_export_params prm) {
+					f.text("SCALARS "+name+" float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n");
+					prm.u_factor = u_factor; prm.grid_dx = fmaxf(geom.spacing, 1.0e-12f); prm.tls_cap = (float)std::max(std::max(Nx, Ny), Nz_out)*prm.grid_dx;
+					prm.want_tke = c.out_tke ? 1 : 0; prm.want_ti = c.out_ti ? 1 : 0; prm.want_tls = c.out_tls ? 1 : 0;
+					f.payload(lbm, source, prm, geom, comps);
+				};
+				section("u_avg", LUW_EXPORT_AVG_U, 3u, export_params(u_factor));
+				section("rho_avg", LUW_EXPORT_AVG_RHO, 1u, export_params(rho_factor));
+				if(use_temperature_bc) section("T_avg", LUW_EXPORT_AVG_T, 1u, export_params(units.si_dT(1.0f), units.si_T(0.0f))); // Kelvin: FX/setup.cpp:2526-2528,2580-2582
+				phase_mark("  u_avg, rho_avg written");
+				section("fluid", LUW_EXPORT_FLUID, 1u, export_params(1.0f));
+				if(c.out_tke) section("tke", LUW_EXPORT_TKE, 1u, export_params(u_factor*u_factor));
+				if(c.out_ti) section("TI", LUW_EXPORT_TI, 1u, export_params(1.0f));
+				if(c.out_tls) section("TLS", LUW_EXPORT_TLS, 1u, export_params(1.0f));
+				print_kv_row("VTK file", fn+" saved");
+				g_progress.emit("save", "Saving results", fn, 1ll, 1ll, false);
+				print_kv_row("Avg samples", to_string_u(avg_count));
+			}
+		}
+		if(avg_window>0ull&&host_vtk_path()) { // the same file through the host (cross-check path)
 			// 7 floats per cell, every one of them overwritten by the download: no value-initialisation (a 1.4 GB memset at 50 M cells)
 			std::unique_ptr<float[]> stats_mem(new float[7ull*N]); uint64_t avg_count = 0ull;
 			float* const avg_u = stats_mem.get(); float* const avg_rho = avg_u+3ull*N; float* const m2u = avg_rho+N; float* const m2v = m2u+N; float* const m2w = m2v+N;

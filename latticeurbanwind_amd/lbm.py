@@ -200,6 +200,7 @@ class LBM:
     def enqueue_insert_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def increment_time_step(self, steps=1): capi.check(self._L.luw_increment_time_step(self._h, steps))
     def reset_time_step(self): capi.check(self._L.luw_reset_time_step(self._h))
+    def fields_every_step(self): return bool(self._L.luw_fields_every_step(self._h))   # option, or a fluid nudging / sponge reference cell (luw_initialize)
     def finish(self): capi.check(self._L.luw_finish(self._h))
     def device_ptr(self, field): return self._L.luw_device_ptr(self._h, field)
     def pitch(self): return int(self._L.luw_get_pitch(self._h))

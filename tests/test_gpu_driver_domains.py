@@ -59,6 +59,33 @@ def test_driver_with_n_gpu_writes_the_single_domain_files(luw, tmp_path, case, n
         assert False, name + " differs"
 
 
+@pytest.mark.parametrize("case,n_gpu,ddf", [("CaseA", (1, 1, 1), "fp32"), ("CaseA", (2, 2, 1), "fp32"), ("CaseT1", (2, 1, 1), "fp32"), ("CaseG", (2, 2, 2), "fp16c"), ("CaseP", (1, 2, 1), "fp32")])
+def test_device_vtk_export_equals_the_host_conversion(luw, tmp_path, case, n_gpu, ddf):
+    """the output path: every VTK the driver writes with the devices producing the payload (per-domain kernel: SoA -> AoS, SI units, big-endian;
+    tke / TI / TLS from the statistics on the devices, the TLS stencil across domain cuts; slabs through pinned memory, pwrite from a writer
+    thread) against the files of the host path (full download, gather, host conversion: LUW_HOST_VTK=1) -- byte for byte"""
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
+    D = n_gpu[0] * n_gpu[1] * n_gpu[2]
+    dev = ["--devices", ",".join(["0"] * D)] if D > 1 else []
+    out = {}
+    for tag, env in (("_host", dict(os.environ, LUW_HOST_VTK="1")), ("_dev", dict(os.environ, LUW_HOST_VTK="0"))):
+        proj, deck = _case(tmp_path, case, n_gpu, tag)
+        r = subprocess.run([DRIVER, deck, "--ddf", ddf] + dev, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        out[tag] = _files(proj)
+    want, got = out["_host"], out["_dev"]
+    assert sorted(want) == sorted(got) and len(want) >= 3
+    for name in sorted(want):
+        if filecmp.cmp(want[name], got[name], shallow=False):
+            continue
+        if name.endswith(".vtk"):
+            hw, fw = read_vtk(want[name]); hg, fg = read_vtk(got[name])
+            assert hw == hg, name
+            for key in fw:
+                assert np.array_equal(fg[key].view(np.uint32), fw[key].view(np.uint32)), (name, key, int((fg[key].view(np.uint32) != fw[key].view(np.uint32)).sum()))
+        assert False, name + " differs"
+
+
 def test_z_split_voxelisation_follows_the_reference_ray_origin(luw, tmp_path):
     """A domain voxelises its box with rays that start at ITS lowest layer -- for the lower domain of a z split that is the halo
     layer below z = 0 -- exactly like the reference kernel (r_origin = position(xyz) + offset with xyz.z = clamp((int)z0 - Oz, ..),

@@ -186,6 +186,23 @@ def test_fp16c_zone_free_core_as_its_own_launch_box(luw, coriolis, grow):
 
 
 @pytest.mark.parametrize("kernel", ["s", "p"])
+def test_fluid_reference_cells_switch_to_fields_every_step(luw, kernel):
+    """buffer nudging / top sponge read u of reference cells on the outer faces one step after it was written (UPDATE_FIELDS, FX/kernel.cpp:1709-1716).
+    With TYPE_E / solid faces that u is an input and the library writes rho,u in the last step of a run() call only; on a lattice whose faces are
+    FLUID (fully periodic here) luw_initialize switches to writing them every step, so that a multi-step run() equals the reference for any call length"""
+    from oracle import oracle
+    Nx, Ny, Nz = (512, 10, 12) if kernel == "p" else (40, 28, 24)
+    nud = dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1); spg = dict(n_cells=3, inv_tau=0.02)
+    for shell, expect in (("luw", False), (None, True)):
+        g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, kernel == "p", kernel, synthetic_state(Nx, Ny, Nz, seed=31, shell=shell), nudging=nud, sponge=spg, every_step=False)
+        g.run(0)
+        assert g.fields_every_step() == expect
+        g.run(7); o.run(7)
+        check(g, o, "nudging / sponge with %s faces, one 7-step call" % ("input" if shell else "fluid"))
+        g.close()
+
+
+@pytest.mark.parametrize("kernel", ["s", "p"])
 def test_deferred_field_update_equals_every_step(luw, kernel):
     # default mode writes rho,u only in the last step of a run() call; observed values must equal UPDATE_FIELDS
     from oracle import oracle
