@@ -516,7 +516,11 @@ static std::atomic<int> g_live_solvers[64];
 static int tune_ddf_placement(luw_solver* s) {
 	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
 	const char* env = getenv("LUW_TUNE_PLACEMENT");
-	const int candidates = env ? atoi(env) : (s->raw.front().chunks.empty() ? 6 : 0); // chunk-mapped arrays need no search
+	// hipMalloc'ed arrays: up to 6 candidates (round 1).  Chunk-mapped arrays land in the fast class on most boxes by themselves (round 2) -- but not on all:
+	// round 3 met boxes on which the same binary ran the 1024x1024x256 FP32 step in 7.3 or 8.2 instead of 6.7 ms, process after process, and two solver
+	// instances of one process in different classes (profiles/r03_ab_builds_*.txt).  So they get a short search as a safety net: when the probe says "not the
+	// fast class", up to two more mappings are tried and the best is kept; on a good box the first probe passes and nothing else happens.
+	const int candidates = env ? atoi(env) : (s->raw.front().chunks.empty() ? 6 : 3);
 	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
 	if(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1) return LUW_OK; // this device is shared with other solvers of this process
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
@@ -1121,7 +1125,8 @@ int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz) {
 // faces are TYPE_E (or solid ground): their u is an input that no step rewrites, so it does not matter that this library writes rho,u only in the
 // last step of a run() call while the reference (UPDATE_FIELDS) writes them in every step.  A caller who leaves FLUID cells on such a face would see
 // the target velocity of the last written step instead of the previous step's: for such a lattice the solver writes the fields every step, like
-// the reference, and the results stay the reference's whatever the length of the run() calls.  Checked on the host mirror at initialisation.
+// the reference, whatever the length of the run() calls.  (Bit-level expectations end there: the reference kernel then reads a neighbour's u while that
+// neighbour's thread rewrites it in the same launch.)  Checked on the host mirror at initialisation.
 static bool reference_cells_are_inputs(const luw_solver* s) {
 	const KParams& k = s->kp;
 	const uint32_t Nx = s->cfg.Nx, Ny = s->cfg.Ny, Nz = s->cfg.Nz;
