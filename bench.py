@@ -40,6 +40,7 @@ WORKLOADS = {   # name -> (lattice, building array, BASELINE.json reference)
     "c3": ((1024, 1024, 256), True, "BASELINE configs[2]"),
     "c2": ((512, 512, 512), False, "BASELINE configs[1]"),
     "cube1024": ((1024, 1024, 1024), False, "north-star 1024^3-class grid"),
+    "tile512": ((512, 512, 512), True, "one GPU's share of the BASELINE configs[3] / [4] urban tile (the N = 1 point of the N > 1 lines; --urban adds its nudging + sponge)"),
 }
 
 
@@ -221,8 +222,8 @@ def device_context(torch, device):
     return ctx
 
 
-def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False):
-    return "%s_%dx%dx%d%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_cor" if coriolis else "", "_th" if thermal else "", "_uf" if every_step else "")
+def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False, urban=False):
+    return "%s_%dx%dx%d%s%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_urban" if urban else "", "_cor" if coriolis else "", "_th" if thermal else "", "_uf" if every_step else "")
 
 
 def attach_traffic(roof, key, kernel):
@@ -236,13 +237,14 @@ def attach_traffic(roof, key, kernel):
         roof["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
 
 
-def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, coriolis=False, thermal=False, every_step=False, kernel_name="auto", keep=None):
+def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, coriolis=False, thermal=False, every_step=False, kernel_name="auto", keep=None, urban=False):
     """one single-GPU workload: create, fill the host mirrors in place, upload + initialise, W warm-up steps, K timed steps.
     Returns the measurement block (MLUPS, ms/step, roofline of the stream_collide kernel)."""
     import torch
     Nx, Ny, Nz = size
     fp16c = dtype == "fp16c"
-    lbm = luw.LBM(Nx, Ny, Nz, NU, fp16c=fp16c, kernel=kern, device=device, update_fields_every_step=every_step, alpha=(2.1e-7 if thermal else None))
+    nud, spg = tile_forcing() if urban else (None, None)          # urban: buffer nudging + top sponge of the 8-GPU tile (general kernel on two thirds of the cells)
+    lbm = luw.LBM(Nx, Ny, Nz, NU, fp16c=fp16c, kernel=kern, device=device, update_fields_every_step=every_step, alpha=(2.1e-7 if thermal else None), buffer_nudging=nud, top_sponge=spg)
     try:
         fill_channel(lbm.flags.data, lbm.u.data, lbm.rho.data, Nx, Ny, Nz, buildings=buildings)
         solid = int(np.count_nonzero((lbm.flags.data & 3) == 1))
@@ -265,11 +267,11 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(launch_bytes),
             "note": "achieved = (%g B x %d non-solid cells + 1 flag byte x %d solid cells) / mean stream_collide duration (HIP events on the launch stream)" % (bpl, cells - solid, solid)}
-    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step), kernel_name)
+    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step, urban), kernel_name)
     mlups = cells * steps / dt / 1e6
     return {"value": round(mlups, 1), "unit": "MLUPS", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
             "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5), "bytes_per_lup": bpl,
-            "options": ("building array" if buildings else "no solids above the ground plane") + (" + Coriolis force" if coriolis else "") + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
+            "options": ("building array" if buildings else "no solids above the ground plane") + (" + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "") + (" + Coriolis force" if coriolis else "") + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
             "roofline": roof}
 
 
@@ -346,6 +348,7 @@ def main():
     ap.add_argument("--no-buildings", action="store_true", help="N > 1: plain channel tile without the building array / nudging / sponge")
     ap.add_argument("--coriolis", action="store_true", help="Coriolis body force at 31.25 deg N (BASELINE configs[4]): every cell takes the forced path")
     ap.add_argument("--thermal", action="store_true", help="also run the thermal D3Q7 lattice (the shipped reference build always does): +7 DDF planes and T")
+    ap.add_argument("--urban", action="store_true", help="N = 1: add the urban tile's buffer nudging + top sponge (deck defaults) to the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
@@ -381,11 +384,11 @@ def main():
         size, buildings, _ = WORKLOADS[args.workload]
         if args.size: size = tuple(args.size)
         buildings = buildings or args.buildings
-        head = run_single(luw, kern, local_rank, size, args.dtype, buildings, args.steps, args.warmup, args.coriolis, args.thermal, args.every_step_fields, args.kernel)
+        head = run_single(luw, kern, local_rank, size, args.dtype, buildings, args.steps, args.warmup, args.coriolis, args.thermal, args.every_step_fields, args.kernel, urban=args.urban)
         out = {
             "metric": METRIC, "value": head["value"], "unit": "MLUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-            "config": {"workload": describe(args.workload, size, buildings, args.dtype, args.coriolis, args.thermal, args.every_step_fields),
+            "config": {"workload": describe(args.workload, size, buildings, args.dtype, args.coriolis, args.thermal, args.every_step_fields) + (", buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if args.urban else ""),
                        "global_lattice": list(size), "n_gpu": [1, 1, 1], "halo_exchange": None, "kernel": args.kernel, "bytes_per_lup": head["bytes_per_lup"], "solid_fraction": head["solid_fraction"]},
             "roofline": dict(head["roofline"], whole_job_frac=round(head["roofline"]["algorithmic_bytes_per_launch"] / (head["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)),
         }
@@ -410,9 +413,14 @@ def main():
                     sec[key] = {"error": str(e)[:300]}
             # the 8-GPU tile of BASELINE configs[3] / configs[4] seen from ONE GPU: its N = 1 point (512^3 urban tile, undivided) and single ranks of
             # both cuts in their real local shapes, every face through the real transport's self send / receive (no wire to another device)
-            for key, kw in (("tile512_urban_f32", dict(fp16c=False, coriolis=False, D=(1, 1, 1), rank=0)),
-                            ("tile512_urban_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(1, 1, 1), rank=0)),
-                            ("c4_rank_4x2x1_f32", dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0)),
+            for key, dt_, cor in (("tile512_urban_f32", "f32", False), ("tile512_urban_fp16c_coriolis", "fp16c", True)):
+                try:
+                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, (512, 512, 512), dt_, True, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, urban=True)
+                    r["workload"] = "512^3 urban tile, undivided: the N = 1 point of the N > 1 lines (BASELINE configs[3]%s per GPU)" % (" / configs[4]" if cor else "")
+                    sec[key] = r
+                except Exception as e:
+                    sec[key] = {"error": str(e)[:300]}
+            for key, kw in (("c4_rank_4x2x1_f32", dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0)),
                             ("c5_rank_4x2x1_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0)),
                             ("c5_rank_1x4x2_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7))):
                 try:

@@ -344,107 +344,135 @@ static int box_force_mode(const luw_solver* s, const Box& b) {
 	if(b.x0<lo[0]||b.x1>hi[0]||b.y0<lo[1]||b.y1>hi[1]||b.z0<lo[2]||b.z1>hi[2]) return PAIR_FORCE_ANY;
 	return (k.coriolis||k.fx!=0.0f||k.fy!=0.0f||k.fz!=0.0f) ? PAIR_FORCE_UNIFORM : PAIR_FORCE_NONE;
 }
-template<typename T> static void launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
-	T* fi = (T*)s->d_fi;
-	const bool odd = (s->t&1ull)!=0ull;
-	const int xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
-	const uint32_t nx = (uint32_t)((int)b.x1-xa);
-	const uint32_t bx = row_block(nx);
-	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-#ifdef LUW_AB_KERNELS
-	const int mode = s->kernel==LUW_KERNEL_EXP_COPY ? 1 : s->kernel==LUW_KERNEL_EXP_NOSHIFT ? 2 : s->kernel==LUW_KERNEL_SCALAR_CACHED ? 3 : s->kernel==LUW_KERNEL_SCALAR_NT_ALL ? 4 : s->kernel==LUW_KERNEL_SCALAR_GENERAL ? 5 : 0;
+// ---------------------------------------------------------------- the kernel instantiations, as tables
+// Every stream_collide variant the library carries is one row: what it is for (the key the launchers look up) and the function that launches its two
+// time-parity instances.  Nothing else instantiates the step kernels.
+struct LaunchGeom { dim3 grid, block; int xa; uint32_t lds; };
+
+// ---- k_stream_collide_s: one cell per lane
+struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce; };   // mode 0: step, 4: step + thermal lattice; 1, 2, 3: A/B variants (tools build)
+typedef void (*ScalarLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
+template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+	T* const fi = (T*)s->d_fi; T* const gi = MODE==4 ? (T*)s->d_gi : nullptr; float* const Tf = MODE==4 ? s->d_T : nullptr;
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
+	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
+}
+struct ScalarRow { ScalarKey key; ScalarLaunch launch; const char* what; };
+static const ScalarRow scalar_table[] = {
+	//  bytes mode nt flat   stats  noforce
+	{ { 4u, 0, 2, true,  false, false }, scalar_instance<float, 0, 2, true, false, false>,       "FP32 product kernel, flat addressing (planes within 32-bit byte offsets)" },
+	{ { 4u, 0, 2, false, false, false }, scalar_instance<float, 0, 2, false, false, false>,      "FP32 product kernel, row addressing (any plane size)" },
+	{ { 4u, 0, 2, true,  true,  false }, scalar_instance<float, 0, 2, true, true, false>,        "FP32, sampled step (fused Welford update)" },
+	{ { 4u, 0, 2, false, true,  false }, scalar_instance<float, 0, 2, false, true, false>,       "FP32, sampled step, row addressing" },
+	{ { 4u, 4, 2, true,  false, false }, scalar_instance<float, 4, 2, true, false, false>,       "FP32 + thermal lattice" },
+	{ { 4u, 4, 2, false, false, false }, scalar_instance<float, 4, 2, false, false, false>,      "FP32 + thermal lattice, row addressing" },
+	{ { 2u, 0, 2, false, false, false }, scalar_instance<uint16_t, 0, 2, false, false, false>,   "FP16C one-cell kernel (rows too narrow / unaligned for the pair kernel)" },
+	{ { 2u, 0, 2, false, false, true  }, scalar_instance<uint16_t, 0, 2, false, false, true>,    "FP16C one-cell kernel, force-free box: 7 waves per SIMD" },
+	{ { 2u, 0, 2, false, true,  false }, scalar_instance<uint16_t, 0, 2, false, true, false>,    "FP16C one-cell kernel, sampled step" },
+	{ { 2u, 4, 2, false, false, false }, scalar_instance<uint16_t, 4, 2, false, false, false>,   "FP16C one-cell kernel + thermal lattice" },
+	{ { 2u, 4, 2, false, false, true  }, scalar_instance<uint16_t, 4, 2, false, false, true>,    "FP16C one-cell kernel + thermal lattice, force-free box" },
+#ifdef LUW_AB_KERNELS   // tools build: measurement-only and A/B variants
+	{ { 4u, 1, 1, true,  false, false }, scalar_instance<float, 1, 1, true, false, false>,       "A/B: no collision" },
+	{ { 4u, 1, 1, false, false, false }, scalar_instance<float, 1, 1, false, false, false>,      "A/B: no collision, row addressing" },
+	{ { 4u, 2, 1, true,  false, false }, scalar_instance<float, 2, 1, true, false, false>,       "A/B: x+1 neighbours replaced by x" },
+	{ { 4u, 2, 1, false, false, false }, scalar_instance<float, 2, 1, false, false, false>,      "A/B: no shift, row addressing" },
+	{ { 4u, 0, 0, true,  false, false }, scalar_instance<float, 0, 0, true, false, false>,       "A/B: default cache policy" },
+	{ { 4u, 0, 0, false, false, false }, scalar_instance<float, 0, 0, false, false, false>,      "A/B: default cache policy, row addressing" },
+	{ { 4u, 0, 1, true,  false, false }, scalar_instance<float, 0, 1, true, false, false>,       "A/B: non-temporal on all planes" },
+	{ { 4u, 0, 1, false, false, false }, scalar_instance<float, 0, 1, false, false, false>,      "A/B: non-temporal on all planes, row addressing" },
+	{ { 4u, 3, 2, true,  false, false }, scalar_instance<float, 3, 2, true, false, false>,       "A/B: general path only" },
+	{ { 4u, 3, 2, false, false, false }, scalar_instance<float, 3, 2, false, false, false>,      "A/B: general path only, row addressing" },
+	{ { 2u, 1, 1, false, false, false }, scalar_instance<uint16_t, 1, 1, false, false, false>,   "A/B: FP16C no collision" },
+	{ { 2u, 2, 1, false, false, false }, scalar_instance<uint16_t, 2, 1, false, false, false>,   "A/B: FP16C no shift" },
+	{ { 2u, 0, 0, false, false, false }, scalar_instance<uint16_t, 0, 0, false, false, false>,   "A/B: FP16C default cache policy" },
+	{ { 2u, 0, 1, false, false, false }, scalar_instance<uint16_t, 0, 1, false, false, false>,   "A/B: FP16C non-temporal on all planes" },
+	{ { 2u, 3, 2, false, false, false }, scalar_instance<uint16_t, 3, 2, false, false, false>,   "A/B: FP16C general path only" },
 #endif
-	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernels also where a specialisation would do (same values)
-	[[maybe_unused]] const bool force_free = sizeof(T)==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
-	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise
-	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;   // test aid: the row form also where the flat form would be valid (both are product code, same values)
-	// (in-plane offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with
-	// its 2^32-byte planes still qualifies: its largest offset is 2^32 - 4)
-	const bool flat = sizeof(T)==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*sizeof(T)<=(1ull<<32) && !force_row;
-	#define LUW_LAUNCH_SF(PAR, MODE, NT, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, MODE, NT, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields)
-	#define LUW_LAUNCH_S(PAR, MODE, NT) do { if constexpr(sizeof(T)==4u) { if(flat) LUW_LAUNCH_SF(PAR, MODE, NT, true); else LUW_LAUNCH_SF(PAR, MODE, NT, false); } else LUW_LAUNCH_SF(PAR, MODE, NT, false); } while(0)
-	if(st) { // a sampled step of the product kernel (can_fuse_stats): the Welford update rides on the cell update
-		#define LUW_LAUNCH_ST(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 0, 2, FL, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, *st)
-		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_ST(1, true); else LUW_LAUNCH_ST(0, true); } else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); } }
-		else { if(odd) LUW_LAUNCH_ST(1, false); else LUW_LAUNCH_ST(0, false); }
-		#undef LUW_LAUNCH_ST
-	}
-	else if(s->d_gi) { // thermal lattice on: the product kernel plus the D3Q7 cell update
-		#define LUW_LAUNCH_T(PAR, FL) hipLaunchKernelGGL((k_stream_collide_s<T, PAR, 4, 2, FL>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T)
-		if constexpr(sizeof(T)==2u) { if(force_free) { // FP16C, nothing can push the cells of this box: 76 VGPRs, 6 waves per SIMD
-			if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1, 4, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T, StatsArgs{});
-			else hipLaunchKernelGGL((k_stream_collide_s<T, 0, 4, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)s->d_gi, s->d_T, StatsArgs{});
-			return; } }
-		if constexpr(sizeof(T)==4u) { if(flat) { if(odd) LUW_LAUNCH_T(1, true); else LUW_LAUNCH_T(0, true); } else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); } }
-		else { if(odd) LUW_LAUNCH_T(1, false); else LUW_LAUNCH_T(0, false); }
-		#undef LUW_LAUNCH_T
-	}
+};
+static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
+	LaunchGeom g{};
+	g.xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
+	const uint32_t nx = (uint32_t)((int)b.x1-g.xa), bx = row_block(nx);
+	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
+	ScalarKey k{ (uint8_t)s->ddf_bytes, 0, 2, false, st!=nullptr, false };
+	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise.  In-plane
+	// offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with its 2^32-byte planes
+	// still qualifies (largest offset 2^32 - 4).  LUW_ADDR_ROW: the row form also where the flat form would do (both are product code, same values)
+	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;
+	k.flat = s->ddf_bytes==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*4ull<=(1ull<<32) && !force_row;
+	// FP16C, nothing can push the cells of this box: the instantiation without the force assembly (69 / 76 VGPRs).  LUW_PAIR_GENERAL: never (test aid)
+	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;
+	k.noforce = s->ddf_bytes==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
+	if(s->d_gi&&!st) k.mode = 4; // thermal lattice on: the product kernel plus the D3Q7 cell update
 #ifdef LUW_AB_KERNELS
-	else if(mode==1) { if(odd) LUW_LAUNCH_S(1, 1, 1); else LUW_LAUNCH_S(0, 1, 1); }
-	else if(mode==2) { if(odd) LUW_LAUNCH_S(1, 2, 1); else LUW_LAUNCH_S(0, 2, 1); }
-	else if(mode==3) { if(odd) LUW_LAUNCH_S(1, 0, 0); else LUW_LAUNCH_S(0, 0, 0); }
-	else if(mode==5) { if(odd) LUW_LAUNCH_S(1, 3, 2); else LUW_LAUNCH_S(0, 3, 2); }
-	else if(mode==4) { if(odd) LUW_LAUNCH_S(1, 0, 1); else LUW_LAUNCH_S(0, 0, 1); }
-#endif
-	else if(sizeof(T)==2u&&force_free) { // FP16C, nothing can push the cells of this box: 69 VGPRs, 7 waves per SIMD
-		if constexpr(sizeof(T)==2u) {
-			if(odd) hipLaunchKernelGGL((k_stream_collide_s<T, 1, 0, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, StatsArgs{});
-			else hipLaunchKernelGGL((k_stream_collide_s<T, 0, 0, 2, false, false, true>), grid, block, 0, s->stream, s->kp, b, xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, (T*)nullptr, (float*)nullptr, StatsArgs{});
-		}
+	if(!st&&!s->d_gi) switch(s->kernel) {
+		case LUW_KERNEL_EXP_COPY: k.mode = 1; k.nt = 1; k.noforce = false; break;
+		case LUW_KERNEL_EXP_NOSHIFT: k.mode = 2; k.nt = 1; k.noforce = false; break;
+		case LUW_KERNEL_SCALAR_CACHED: k.nt = 0; k.noforce = false; break;
+		case LUW_KERNEL_SCALAR_NT_ALL: k.nt = 1; k.noforce = false; break;
+		case LUW_KERNEL_SCALAR_GENERAL: k.mode = 3; k.noforce = false; break;
+		default: break;
 	}
-	else { if(odd) LUW_LAUNCH_S(1, 0, 2); else LUW_LAUNCH_S(0, 0, 2); }   // the product kernel
-	#undef LUW_LAUNCH_SF
-	#undef LUW_LAUNCH_S
+#endif
+	for(const ScalarRow& r : scalar_table) {
+		const ScalarKey& q = r.key;
+		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce) { r.launch(s, b, g, write_fields, st ? *st : StatsArgs{}); return LUW_OK; }
+	}
+	return fail(LUW_ERR_STATE, "stream_collide: this library carries no one-cell kernel for the requested combination");
 }
 
-static void launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
-	uint16_t* fi = (uint16_t*)s->d_fi;
-	const bool odd = (s->t&1ull)!=0ull;
+// ---- k_stream_collide_p: FP16C, two cells per lane
+struct PairKey { int mode; bool stats; int force; bool park, thermal; };   // mode 1: memory path only (tools build)
+typedef void (*PairLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
+template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+	uint16_t* const fi = (uint16_t*)s->d_fi; uint16_t* const gi = THERMAL ? (uint16_t*)s->d_gi : nullptr; float* const Tf = THERMAL ? s->d_T : nullptr;
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
+	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
+}
+struct PairRow { PairKey key; PairLaunch launch; const char* what; };
+static const PairRow pair_table[] = {
+	//  mode stats  force               park   thermal
+	{ { 0, false, PAIR_FORCE_NONE,    false, false }, pair_instance<0, false, PAIR_FORCE_NONE, false, false>,    "nothing can push the cells of the box: no force path, 5 waves per SIMD" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, false, false }, pair_instance<0, false, PAIR_FORCE_UNIFORM, false, false>, "volume force / Coriolis only, 5 waves" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  false }, pair_instance<0, false, PAIR_FORCE_ANY, true, false>,      "general (zones, force field): second cell's values parked in LDS, 5 waves" },
+	{ { 0, false, PAIR_FORCE_ANY,     false, false }, pair_instance<0, false, PAIR_FORCE_ANY, false, false>,     "general, everything in registers, 4 waves (LUW_PAIR_PARK=0: A/B and test aid)" },
+	{ { 0, true,  PAIR_FORCE_ANY,     false, false }, pair_instance<0, true, PAIR_FORCE_ANY, false, false>,      "sampled step (fused Welford update)" },
+	{ { 0, false, PAIR_FORCE_NONE,    true,  true  }, pair_instance<0, false, PAIR_FORCE_NONE, true, true>,      "+ thermal lattice, force-free box" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true  }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true>,   "+ thermal lattice, uniform forces" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  true  }, pair_instance<0, false, PAIR_FORCE_ANY, true, true>,       "+ thermal lattice, general" },
+#ifdef LUW_AB_KERNELS
+	{ { 1, false, PAIR_FORCE_ANY,     false, false }, pair_instance<1, false, PAIR_FORCE_ANY, false, false>,     "A/B: the kernel's memory path alone (LUW_PAIR_COPY)" },
+	{ { 0, false, PAIR_FORCE_NONE,    true,  false }, pair_instance<0, false, PAIR_FORCE_NONE, true, false>,     "A/B: force-free with PARK (7 waves: no gain, profiles/r03_pair_park_ab.txt)" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, true,  false }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, false>,  "A/B: uniform forces with PARK (6 waves: slower)" },
+#endif
+};
+static int launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
+	LaunchGeom g{};
 	const uint32_t nx = (b.x1-b.x0+1u)/2u;                         // an odd count only when the box ends at an odd Nx: the last lane owns one cell
 	const uint32_t bx = row_block(nx);
-	const dim3 grid((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0), block(bx);
-	if(st) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 0, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, *st);
-		else hipLaunchKernelGGL((k_stream_collide_p<0, 0, true>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, *st); return; }
-#ifdef LUW_AB_KERNELS
-	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // tools build, measurement aid: the kernel's memory path alone (no physics)
-	if(copy_only) { if(odd) hipLaunchKernelGGL((k_stream_collide_p<1, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
-		else hipLaunchKernelGGL((k_stream_collide_p<0, 1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields); return; }
-#endif
+	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
 	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where a specialisation would do (same values)
-	const int mode = general_only ? PAIR_FORCE_ANY : box_force_mode(s, b);
-	if(s->d_gi) { // thermal lattice on: both lattices two cells per lane (THERMAL), the second set of values parked in LDS
-		const uint32_t lds = (bx/64u)*pair_park_bytes_per_wave(true);
-		#define LUW_LAUNCH_PT(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE, true, true>), grid, block, lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{}, (uint16_t*)s->d_gi, s->d_T)
-		if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_PT(1, PAIR_FORCE_NONE); else LUW_LAUNCH_PT(0, PAIR_FORCE_NONE); }
-		else if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_PT(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_PT(0, PAIR_FORCE_UNIFORM); }
-		else { if(odd) LUW_LAUNCH_PT(1, PAIR_FORCE_ANY); else LUW_LAUNCH_PT(0, PAIR_FORCE_ANY); }
-		#undef LUW_LAUNCH_PT
-		return;
-	}
-	// PARK (luw_kernels_step.hpp): the lane's second set of 19 values waits in LDS instead of in registers.  Measured interleaved on MI355X
+	PairKey k{ 0, st!=nullptr, (st||general_only) ? PAIR_FORCE_ANY : box_force_mode(s, b), false, s->d_gi!=nullptr };
+	// PARK (luw_kernels_step.hpp): the lane's second set of values waits in LDS instead of in registers.  Measured interleaved on MI355X
 	// (profiles/r03_pair_park_ab.txt): it pays where the registers cost a wave of occupancy that matters -- the general kernel, 109 -> 91 VGPRs,
 	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
-	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256).  LUW_PAIR_PARK=<bit mask of force
-	// modes> overrides (bit 0 force-free, 1 uniform, 2 general; A/B and test aid).
+	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256); the thermal variants always park.
+	// LUW_PAIR_PARK=<bit mask of force modes> overrides (bit 0 force-free, 1 uniform, 2 general; the first two exist in the tools build only).
 #ifndef LUW_PAIR_PARK_DEFAULT
 #define LUW_PAIR_PARK_DEFAULT (1u<<PAIR_FORCE_ANY)
 #endif
 	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (unsigned)(LUW_PAIR_PARK_DEFAULT);
-	if(park_modes&(1u<<mode)) {
-		const uint32_t lds = (bx/64u)*pair_park_bytes_per_wave(false);
-		#define LUW_LAUNCH_PP(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE, true>), grid, block, lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
-		if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_NONE); else LUW_LAUNCH_PP(0, PAIR_FORCE_NONE); }
-		else if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_PP(0, PAIR_FORCE_UNIFORM); }
-		else { if(odd) LUW_LAUNCH_PP(1, PAIR_FORCE_ANY); else LUW_LAUNCH_PP(0, PAIR_FORCE_ANY); }
-		#undef LUW_LAUNCH_PP
-		return;
+	k.park = k.thermal || (!st && (park_modes&(1u<<k.force))!=0u);
+#ifdef LUW_AB_KERNELS
+	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // tools build, measurement aid: the kernel's memory path alone (no physics)
+	if(copy_only&&!st&&!k.thermal) k = PairKey{ 1, false, PAIR_FORCE_ANY, false, false };
+#endif
+	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal) : 0u;
+	for(const PairRow& r : pair_table) {
+		const PairKey& q = r.key;
+		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal) { r.launch(s, b, g, write_fields, st ? *st : StatsArgs{}); return LUW_OK; }
 	}
-	#define LUW_LAUNCH_P(PAR, FORCE) hipLaunchKernelGGL((k_stream_collide_p<PAR, 0, false, FORCE>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields, StatsArgs{})
-	if(mode==PAIR_FORCE_NONE) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_NONE); else LUW_LAUNCH_P(0, PAIR_FORCE_NONE); return; }       // nothing can push these cells: no force path, 5 waves per SIMD
-	if(mode==PAIR_FORCE_UNIFORM) { if(odd) LUW_LAUNCH_P(1, PAIR_FORCE_UNIFORM); else LUW_LAUNCH_P(0, PAIR_FORCE_UNIFORM); return; } // volume force / Coriolis only
-	#undef LUW_LAUNCH_P
-	if(odd) hipLaunchKernelGGL((k_stream_collide_p<1>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
-	else hipLaunchKernelGGL((k_stream_collide_p<0>), grid, block, 0, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+	return fail(LUW_ERR_STATE, "stream_collide: this library carries no pair kernel for the requested combination");
 }
 
 // Kernel choice.  LUW_KERNEL_AUTO = the scalar kernel (FP32: 39.5k MLUPS at 512^3; vector kernels 20-29k) and, for FP16C rows
@@ -479,14 +507,14 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 		if(!fp16||!starts_aligned||!whole_pairs) k = LUW_KERNEL_SCALAR;
 	}
 	if(st&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) return fail(LUW_ERR_STATE, "stream_collide: this kernel has no fused statistics");
-	if(k==LUW_KERNEL_PAIR) launch_pair(s, b, write_fields, st);
-	else if(st) { if(fp16) launch_scalar<uint16_t>(s, b, write_fields, st); else launch_scalar<float>(s, b, write_fields, st); }
+	if(k==LUW_KERNEL_PAIR) { if(int e = launch_pair(s, b, write_fields, st)) return e; }
+	else if(st) { if(int e = launch_scalar(s, b, write_fields, st)) return e; }
 #ifdef LUW_AB_KERNELS
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
 #endif
-	else { if(fp16) launch_scalar<uint16_t>(s, b, write_fields); else launch_scalar<float>(s, b, write_fields); }
+	else { if(int e = launch_scalar(s, b, write_fields)) return e; }
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }

@@ -47,347 +47,10 @@
 
 using namespace luw_host;
 using std::string;
-
-// ------------------------------------------------------------------------------------------------ console / text
-static std::ofstream g_log;
-static void println(const string& s = "") { std::cout << s << "\n"; std::cout.flush(); if(g_log.is_open()) { g_log << s << "\n"; g_log.flush(); } }
-static const uint CONSOLE_WIDTH = 94u; // FX/utilities.hpp:9
-// GUI protocol lines go to stdout only, never into the log (FX/utilities.hpp:3161-3178)
-static const ProgressChannel g_progress([](const string& line) { std::cout << line << "\n"; std::cout.flush(); });
-// the running row overwrites itself on the console (reprint, FX/info.cpp:273) and is not logged until it is final
-static void reprint_row(const string& s) { std::cout << "\r" << s; std::cout.flush(); }
-// LUW_DRIVER_TIMING=1: wall time of each phase of the run on stderr (profiling aid; console and log stay as the reference's)
-static void phase_mark(const char* name) {
-	static const bool on = [] { const char* e = std::getenv("LUW_DRIVER_TIMING"); return e&&e[0]=='1'; }();
-	static auto last = std::chrono::steady_clock::now();
-	if(!on) return;
-	const auto now = std::chrono::steady_clock::now();
-	std::fprintf(stderr, "[timing] %-28s %8.3f s\n", name, std::chrono::duration<double>(now-last).count());
-	last = now;
-}
-static string alignr(const uint n, const string& x) { string s(n, ' '); s += x; return s.substr((uint)std::min((int)s.length()-(int)n, (int)n)); }
-static string alignl(const uint n, const string& x) { string s = x+string(n, ' '); return s.substr(0, std::max(n, (uint)x.length())); }
-static string alignc(const uint n, const string& x) { if((uint)x.length()>=n) return x.substr(0u, n); const uint l = (n-(uint)x.length())/2u; return string(l, ' ')+x+string(n-(uint)x.length()-l, ' '); }
-static string hr_plain() { return "|"+string(CONSOLE_WIDTH-2u, '-')+"|"; }
-static void print_section_title(const string& t) { println(hr_plain()); println("|"+alignc(CONSOLE_WIDTH-2u, t)+"|"); println(hr_plain()); }
-static void print_kv_row(const string& k, const string& v) { println("| "+k+" | "+v+" |"); }
-static string to_string_u(ulong x) { string r; do { r = (char)(x%10ull+48ull)+r; x /= 10ull; } while(x); return r; }
-static string decimal_to_string(uint x, int digits) { string r; while((digits--)>0) { r = (char)(x%10u+48u)+r; x /= 10u; } return r; }
-// The reference prints floats with 9 significant digits -- "d.dddddddd[E<exp>]" -- and kernel constants and VTK headers travel
-// through that text (FX/utilities.hpp:2603-2634,2741-2750), so the digits must be the reference's, float operation for float
-// operation.  The decimal exponent comes from a binary ladder of powers of ten (each rung at most once, largest first); the nine
-// digits from one truncation and one round-half-up.  One implementation for the whole project: luw_format_float9 in the library.
-static string to_string_f(const float x) {
-	char text[48];
-	luw_format_float9(x, text, sizeof(text));
-	return text;
-}
-static string to_string_fd(float x, const uint decimals) { // FX/utilities.hpp:2762-2772
-	string s;
-	if(x<0.0f) { s += "-"; x = -x; }
-	if(std::isnan(x)) return s+"NaN";
-	if(std::isinf(x)) return s+"Inf";
-	const float power = std::pow(10.0f, (float)std::min(decimals, 8u));
-	x += 0.5f/power;
-	const ulong integral = (ulong)x;
-	const uint decimal = (uint)((x-(float)integral)*power);
-	return s+to_string_u(integral)+(decimals==0u ? "" : "."+decimal_to_string(decimal, (int)std::min(decimals, 8u)));
-}
-static string to_string_dd(double x, const uint decimals) { // FX/utilities.hpp:2773-2783
-	string s;
-	if(x<0.0) { s += "-"; x = -x; }
-	if(std::isnan(x)) return s+"NaN";
-	if(std::isinf(x)) return s+"Inf";
-	const double power = std::pow(10.0, (double)std::min(decimals, 16u));
-	x += 0.5/power;
-	const ulong integral = (ulong)x;
-	ulong decimal = (ulong)((x-(double)integral)*power);
-	string r; for(int d=(int)std::min(decimals, 16u); d>0; d--) { r = (char)(decimal%10ull+48ull)+r; decimal /= 10ull; }
-	return s+to_string_u(integral)+(decimals==0u ? "" : "."+r);
-}
-static string fmtf(float v, int prec = 4) { std::ostringstream os; os << std::fixed; os.precision(prec); os << v; return os.str(); }
-static string format_tag(float v) { string s = to_string_fd(v, 3u); if(s.find('.')!=string::npos) { while(!s.empty()&&s.back()=='0') s.pop_back(); if(!s.empty()&&s.back()=='.') s.pop_back(); } return s.empty() ? "0" : s; }
-static string now_str(const char* fmt = "%Y%m%d %H:%M:%S") { std::time_t tt = std::time(nullptr); std::tm tm{}; localtime_r(&tt, &tm); char b[64]; std::strftime(b, sizeof(b), fmt, &tm); return b; }
-[[noreturn]] static void fatal(const string& msg, const int code = -1) { println(msg); println(hr_plain()); std::exit(code); }
-
-template<typename Fn> static void parallel_for(const ulong N, Fn fn) { // FX/utilities.hpp:64-97
-	const uint threads = std::max(1u, std::min((uint)std::thread::hardware_concurrency(), 64u));
-	std::vector<std::thread> pool;
-	for(uint t=0u; t<threads; t++) pool.emplace_back([=]() { for(ulong n=N*(ulong)t/threads; n<N*(ulong)(t+1u)/threads; n++) fn(n); });
-	for(auto& th : pool) th.join();
-}
-static inline float reverse_bytes(const float v) { uint32_t u; std::memcpy(&u, &v, 4); u = __builtin_bswap32(u); float r; std::memcpy(&r, &u, 4); return r; }
-
-// ------------------------------------------------------------------------------------------------ units (FX/units.hpp)
-struct Units {
-	float unit_m = 1.0f, unit_kg = 1.0f, unit_s = 1.0f, unit_K = 1.0f, unit_K_offset = 0.0f; // T_SI = T*unit_K + unit_K_offset
-	void set_m_kg_s_K(const float x, const float u, const float rho, const float T, const float si_x, const float si_u, const float si_rho, const float si_T) {
-		unit_m = si_x/x; unit_kg = si_rho/rho*(unit_m*unit_m*unit_m); unit_s = u/si_u*unit_m; unit_K = si_T/T; unit_K_offset = 0.0f;
-	}
-	void set_temperature_reference(const float T_ref, const float si_T_ref) { unit_K_offset = si_T_ref-T_ref*unit_K; } // FX/units.hpp:37-39
-	float T(const float si_T) const { return (si_T-unit_K_offset)/unit_K; }
-	float si_T(const float T) const { return T*unit_K+unit_K_offset; }
-	float si_dT(const float dT) const { return dT*unit_K; }
-	float alpha(const float si_alpha) const { return si_alpha*unit_s/(unit_m*unit_m); }
-	float beta(const float si_beta) const { return si_beta*unit_K; }
-	float x(const float si_x) const { return si_x/unit_m; }
-	float si_x(const float x) const { return x*unit_m; }
-	float nu(const float si_nu) const { return si_nu*unit_s/(unit_m*unit_m); }
-	float si_u(const float u) const { return u*unit_m/unit_s; }
-	float si_rho(const float rho) const { return rho*unit_kg/(unit_m*unit_m*unit_m); }
-	ulong t(const float si_t) const { return (ulong)std::fmax(si_t/unit_s+0.5f, 0.5f); }
-};
-
-// ------------------------------------------------------------------------------------------------ configuration (defaults FX/setup.cpp:183-220)
-struct Config {
-	string caseName = "example", datetime = "20990101120000", parent, deck_path;
-	bool profile_mode = false, dataset_mode = false;
-	float z_si_offset = 50.0f;
-	bool downstream_open_face = false;
-	uint memory = 20000u; float cell_m = 20.0f;
-	float si_x = 0.0f, si_y = 0.0f, si_z = 0.0f;
-	uint Dx = 1u, Dy = 1u, Dz = 1u;
-	uint research_output_steps = 0u, unsteady_output_interval = 0u, purge_avg_steps = 0u, purge_avg_stride = 1u;
-	ulong run_nstep_override = 0ull;
-	bool out_tke = true, out_ti = true, out_tls = true;
-	bool enable_coriolis = false; float cut_lon[2] = {0, 0}, cut_lat[2] = {0, 0}; bool has_cut_lon = false, has_cut_lat = false;
-	bool enable_buffer_nudging = true; float buffer_thickness_m = 160.0f, buffer_tau_s = 300.0f; int buffer_nudge_vertical = 0;
-	bool enable_top_sponge = true; float sponge_thickness_m = 200.0f, sponge_tau_s = 120.0f; int sponge_ref_mode = 0;
-	bool vk_enable = true; int vk_nmodes = 256; float vk_ti = 0.05f, vk_sigma_si = 0.0f, vk_L_si = 100.0f; uint64_t vk_seed = 100ull; int vk_stride = 1;
-	VkUcMode vk_uc = VkUcMode::NORM_MEAN; bool vk_same = true, vk_interp = false, vk_inflow_only = false; VkFaceMode vk_face_mode = VkFaceMode::AUTO_SIDES; float vk_aniso[3] = {1.0f, 1.0f, 1.0f};
-	std::vector<float> inflow_list, angle_list;
-	// command line
-	string probes_raw, utm_crs; bool probes_output_defined = false; uint probes_output_steps = 0u; bool has_rotate_deg = false; double rotate_deg = 0.0;
-	bool buoyancy = true, buoyancy_explicit = false; // default-on unless explicitly false (FX/setup.cpp:2743)
-	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
-	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
-	std::vector<int> devices; uint32_t kernel = LUW_KERNEL_AUTO;
-};
-
-// memory model of the SHIPPED reference build (D3Q19 FP16C + FORCE_FIELD + TEMPERATURE + GRAPHICS), FX/lbm.cpp:188-228:
-// gpu_memory decks were sized against it, so the same deck must give the same grid here
-static uint vram_required_mb_per_device(const uint Nx, const uint Ny, const uint Nz, const uint Dx, const uint Dy, const uint Dz) {
-	const uint Hx = Dx>1u, Hy = Dy>1u, Hz = Dz>1u;
-	const ulong lx = (ulong)(Nx/Dx+2u*Hx), ly = (ulong)(Ny/Dy+2u*Hy), lz = (ulong)(Nz/Dz+2u*Hz), N = lx*ly*lz;
-	auto mb = [](const ulong bytes) { return (uint)(bytes/1048576ull); };
-	uint m = 0u;
-	m += mb(N*19ull*2ull); m += mb(N*4ull); m += mb(N*12ull); m += mb(N);           // fi, rho, u, flags
-	m += mb(N*12ull); m += mb(16ull);                                              // F, object_sum
-	m += mb(N*7ull*2ull); m += mb(N*4ull);                                          // gi, T
-	const ulong pixels = 1920ull*1080ull; m += mb(pixels*4ull); m += mb(pixels*4ull); m += mb(60ull); // bitmap, zbuffer, camera
-	if(Dx*Dy*Dz>1u) {
-		ulong Amax = 0ull;
-		if(Dx>1u) Amax = std::max(Amax, ly*lz); if(Dy>1u) Amax = std::max(Amax, lz*lx); if(Dz>1u) Amax = std::max(Amax, lx*ly);
-		m += 2u*mb(Amax*(ulong)std::max(5u*2u, 17u));
-	}
-	return m;
-}
-static uint vk_extra_mb(const Config& c, const uint Nx, const uint Ny, const uint Nz) { // FX/setup.cpp:312-333
-	if(!c.vk_enable||Nx<2u||Ny<2u||Nz<2u) return 0u;
-	const ulong nz_side = Nz>2u ? (ulong)(Nz-2u) : 0ull, nx_inner = Nx>2u ? (ulong)(Nx-2u) : 0ull;
-	const ulong pts = 2ull*(ulong)Ny*nz_side+2ull*nx_inner*nz_side+(ulong)Nx*(ulong)Ny;
-	const ulong mode_stride = 5ull*(ulong)std::max(1, c.vk_nmodes);
-	auto mb = [](const ulong bytes) { return (uint)(bytes/1048576ull); };
-	return mb(pts*8ull)+mb(pts)+mb(pts*28ull)+mb(mode_stride*40ull);
-}
-struct GridEstimate { uint Nx, Ny, Nz, core_mb, extra_mb, total_mb; };
-static GridEstimate estimate_from_cell_size(const Config& c, const float cell) { // FX/setup.cpp:345-369
-	const float safe = std::fmax(cell, 1.0e-6f);
-	GridEstimate e{};
-	e.Nx = (uint)std::max(1, (int)(c.si_x/safe+0.5f)); e.Ny = (uint)std::max(1, (int)(c.si_y/safe+0.5f));
-	const uint core = (uint)std::max(1, (int)(c.si_z/safe+0.5f));
-	const bool ext = c.enable_top_sponge&&c.sponge_tau_s>0.0f&&c.sponge_ref_mode==0&&core>2u;
-	e.Nz = core+(ext ? (uint)std::max(1, (int)std::lround(c.sponge_thickness_m/safe)) : 0u);
-	e.core_mb = vram_required_mb_per_device(e.Nx, e.Ny, e.Nz, c.Dx, c.Dy, c.Dz);
-	e.extra_mb = vk_extra_mb(c, e.Nx, e.Ny, e.Nz);
-	e.total_mb = e.core_mb+e.extra_mb;
-	return e;
-}
-// mesh_control = "gpu_memory": the finest cell size whose grid still fits the requested MB per device (FX/setup.cpp:371-407).
-// Memory falls monotonically with the cell size, so this is a bracket-and-bisect search in FP32: the coarse end starts at one
-// cell per domain edge and doubles until it fits, the fine end halves until it no longer does, then 48 halvings of the bracket.
-// The grid that comes out (751x742x174 for the reference's example deck) depends on every float of this sequence.
-static float fit_cell_size_to_gpu_memory_request(const Config& c, const uint target_mb) {
-	if(target_mb==0u) return 20.0f;
-	auto fits = [&](const float cell) { return estimate_from_cell_size(c, cell).total_mb<=target_mb; };
-	float coarse = std::fmax(std::fmax(std::fmax(c.si_x, c.si_y), c.si_z+std::fmax(c.sponge_thickness_m, 0.0f)), 1.0f); // feasible end of the bracket
-	for(int tries=32; tries>0&&!fits(coarse); tries--) coarse *= 2.0f;
-	float fine = coarse*0.5f;                                                                                          // infeasible end
-	for(int tries=64; tries>0&&fine>1.0e-6f&&fits(fine); tries--) { coarse = fine; fine *= 0.5f; }
-	for(int halvings=48; halvings>0; halvings--) {
-		const float mid = 0.5f*(fine+coarse);
-		(fits(mid) ? coarse : fine) = mid;
-	}
-	return coarse;
-}
-
-// ------------------------------------------------------------------------------------------------ profile (FX/setup.cpp:2122-2150,2243-2280)
-static std::vector<std::pair<float, float>> read_profile_dat(const string& path) {
-	std::vector<std::pair<float, float>> out;
-	std::ifstream fin(path);
-	if(!fin.is_open()) { println("ERROR: could not open profile file "+path); return out; }
-	string line;
-	while(std::getline(fin, line)) {
-		size_t c = line.find("//"); if(c!=string::npos) line.erase(c);
-		c = line.find('#'); if(c!=string::npos) line.erase(c);
-		line = Deck::strip(line);
-		if(line.empty()) continue;
-		for(char& ch : line) if(ch==','||ch==';') ch = ' ';
-		std::stringstream ss(line);
-		float z = 0.0f, u = 0.0f;
-		if(!(ss >> z >> u)) continue;
-		if(!std::isfinite(z)||!std::isfinite(u)) continue;
-		out.push_back({z, u});
-	}
-	return out;
-}
-// U(z) between the samples of profile.dat: a cubic Hermite segment through the two neighbouring samples with secant slopes
-// (one-sided at the ends of the table, centred inside), constant outside the table (FX/setup.cpp:2243-2280 with the basis of
-// FX/utilities.hpp:2374-2377; FP32, the order of the operations below is the reference's).
-static float profile_secant(const std::vector<float>& z, const std::vector<float>& u, const size_t i) {
-	const size_t n = z.size(), lo = i==0u ? 0u : (i+1u>=n ? n-2u : i-1u), hi = i==0u ? 1u : (i+1u>=n ? n-1u : i+1u);
-	const float dz = z[hi]-z[lo];
-	return dz!=0.0f ? (u[hi]-u[lo])/dz : 0.0f;
-}
-static float cubic_hermite(const float y0, const float y1, const float d0, const float d1, const float t) {
-	const float t2 = t*t, t3 = t*t*t;
-	return (2.0f*t3-3.0f*t2+1.0f)*y0+(-2.0f*t3+3.0f*t2)*y1+(t3-2.0f*t2+t)*d0+(t3-t2)*d1;
-}
-static float interpolate_profile_cubic(const std::vector<float>& z, const std::vector<float>& u, const float zq) {
-	if(z.empty()) return 0.0f;
-	if(z.size()==1u||zq<=z.front()) return u.front();
-	if(zq>=z.back()) return u.back();
-	size_t seg = 0u; // last sample at or below zq (z ascending)
-	for(size_t lo = 0u, hi = z.size()-1u; lo<hi; ) { const size_t mid = (lo+hi+1u)/2u; if(z[mid]<=zq) { lo = mid; seg = mid; } else hi = mid-1u; }
-	const size_t nxt = std::min(seg+1u, z.size()-1u);
-	const float h = z[nxt]-z[seg];
-	if(h<=0.0f) return u[seg];
-	return cubic_hermite(u[seg], u[nxt], profile_secant(z, u, seg)*h, profile_secant(z, u, nxt)*h, (zq-z[seg])/h);
-}
-
-// ------------------------------------------------------------------------------------------------ mesh + host voxeliser
-struct Mesh { std::vector<float> p0, p1, p2; uint n = 0u; float pmin[3], pmax[3]; };
-static void mesh_find_bounds(Mesh& m) { // FX/utilities.hpp:4774-4785: seeded with p0[0] only
-	for(int c=0; c<3; c++) m.pmin[c] = m.pmax[c] = m.p0[c];
-	for(uint i=1u; i<m.n; i++) for(int c=0; c<3; c++) {
-		m.pmin[c] = std::fmin(std::fmin(std::fmin(m.p0[3u*i+c], m.p1[3u*i+c]), m.p2[3u*i+c]), m.pmin[c]);
-		m.pmax[c] = std::fmax(std::fmax(std::fmax(m.p0[3u*i+c], m.p1[3u*i+c]), m.p2[3u*i+c]), m.pmax[c]);
-	}
-}
-static bool read_stl(const string& path, Mesh& m) { // binary STL only, FX/utilities.hpp:4835-4866
-	std::ifstream f(path, std::ios::in|std::ios::binary);
-	if(f.fail()) return false;
-	std::vector<char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-	if(data.size()<84u) return false;
-	uint tn; std::memcpy(&tn, data.data()+80, 4);
-	if(tn==0u||data.size()!=84u+50ull*tn) fatal("| Error: File \""+path+"\" is corrupt or unsupported! Only binary .stl files are supported.", 1);
-	m.n = tn; m.p0.resize(3u*tn); m.p1.resize(3u*tn); m.p2.resize(3u*tn);
-	for(uint i=0u; i<tn; i++) { const char* t = data.data()+84u+50ull*i; std::memcpy(&m.p0[3u*i], t+12, 12); std::memcpy(&m.p1[3u*i], t+24, 12); std::memcpy(&m.p2[3u*i], t+36, 12); }
-	mesh_find_bounds(m);
-	return true;
-}
-static void mesh_scale_translate(Mesh& m, const float scale) { // scale about center 0, then pmin -> (1,1,1): FX/setup.cpp:4086-4087
-	for(auto* v : {&m.p0, &m.p1, &m.p2}) for(float& f : *v) f = scale*f;
-	for(int c=0; c<3; c++) { m.pmin[c] = scale*m.pmin[c]; m.pmax[c] = scale*m.pmax[c]; }
-	float tr[3]; for(int c=0; c<3; c++) tr[c] = 1.0f-m.pmin[c];
-	for(auto* v : {&m.p0, &m.p1, &m.p2}) for(size_t i=0u; i<v->size(); i++) (*v)[i] += tr[i%3u];
-	for(int c=0; c<3; c++) { m.pmin[c] += tr[c]; m.pmax[c] += tr[c]; }
-}
-// voxelize_mesh with direction 2 and flag TYPE_S on one domain (FX/kernel.cpp:2381-2471, FX/lbm.cpp:498), on the host.
-// IEEE 1/g here vs the device reciprocal of the OpenCL build: faces exactly on lattice planes may land one cell off
-// (DESIGN.md section 3).
-static ulong voxelize_z(const Mesh& m, const uint Nx, const uint Ny, const uint Nz, std::vector<uchar>& flags) {
-	const float x0 = m.pmin[0]-2.0f, y0 = m.pmin[1]-2.0f, z0 = m.pmin[2]-2.0f, x1 = m.pmax[0]+2.0f, y1 = m.pmax[1]+2.0f, z1 = m.pmax[2]+2.0f;
-	auto clampi = [](const int v, const int lo, const int hi) { return std::max(lo, std::min(hi, v)); };
-	const uint zstart = (uint)clampi((int)z0, 0, (int)Nz-1), hmax = (uint)clampi((int)z1, 0, (int)Nz);
-	std::atomic<ulong> solid{0ull};
-	parallel_for((ulong)Nx*(ulong)Ny, [&](const ulong a) {
-		const uint x = (uint)(a%Nx), y = (uint)(a/Nx);
-		const float rx = (float)x, ry = (float)y, rz = (float)zstart;
-		if(rx<x0||ry<y0||rx>=x1||ry>=y1) return;
-		uint intersections = 0u, check = 0u;
-		unsigned short dist[64];
-		for(uint i=0u; i<m.n; i++) {
-			const float* a0 = &m.p0[3u*i]; const float* a1 = &m.p1[3u*i]; const float* a2 = &m.p2[3u*i];
-			const float u[3] = {a1[0]-a0[0], a1[1]-a0[1], a1[2]-a0[2]}, v[3] = {a2[0]-a0[0], a2[1]-a0[1], a2[2]-a0[2]}, w[3] = {rx-a0[0], ry-a0[1], rz-a0[2]};
-			const float h[3] = {0.0f*v[2]-1.0f*v[1], 1.0f*v[0]-0.0f*v[2], 0.0f*v[1]-0.0f*v[0]};             // cross(r_direction, v)
-			const float q[3] = {w[1]*u[2]-w[2]*u[1], w[2]*u[0]-w[0]*u[2], w[0]*u[1]-w[1]*u[0]};               // cross(w, u)
-			const float g = u[0]*h[0]+u[1]*h[1]+u[2]*h[2], f = 1.0f/g, s = f*(w[0]*h[0]+w[1]*h[1]+w[2]*h[2]), t = f*(0.0f*q[0]+0.0f*q[1]+1.0f*q[2]), d = f*(v[0]*q[0]+v[1]*q[1]+v[2]*q[2]);
-			if(g!=0.0f&&s>=0.0f&&s<1.0f&&t>=0.0f&&s+t<1.0f) {
-				if(d>0.0f) { if(intersections<64u&&d<65536.0f) dist[intersections] = (unsigned short)d; intersections++; } else check++;
-			}
-		}
-		const uint ns = std::min(intersections, 64u);
-		std::sort(dist, dist+ns);
-		bool inside = (intersections%2u)&&(check%2u);
-		uint k = (intersections%2u)!=(check%2u);
-		const uint h0 = zstart;
-		const uint hmesh = h0+(ns>0u ? (uint)dist[std::min(intersections-1u, 63u)] : 0u);
-		ulong cnt = 0ull;
-		for(uint h=h0; h<hmax; h++) {
-			while(k<intersections&&h>h0+(uint)dist[std::min(k, 63u)]) { inside = !inside; k++; }
-			inside = inside&&(k<intersections&&h<hmesh);
-			if(inside) { const ulong n = (ulong)x+((ulong)y+(ulong)h*Ny)*Nx; flags[n] = (uchar)((flags[n]&~0x03)|TYPE_S); cnt++; }
-		}
-		solid += cnt;
-	});
-	return solid.load();
-}
-
-// ------------------------------------------------------------------------------------------------ VTK writers
-static string default_filename(const string& path, const string& name, const ulong t) { // FX/lbm.cpp:235-239
-	string time = "00000000"+to_string_u(t);
-	time = time.substr(time.length()-9u, 9u);
-	return path+name+"-"+time+".vtk";
-}
-struct VtkGeom { uint Nx, Ny, Nz, Nz_out; float spacing; float origin[3]; };
-static string vtk_header(const string& filename, const VtkGeom& g) {
-	const string base = filename.substr(filename.find_last_of("/\\")+1u);
-	const ulong points = (ulong)g.Nx*(ulong)g.Ny*(ulong)g.Nz_out;
-	return "# vtk DataFile Version 3.0\nFluidX3D "+base+"\nBINARY\nDATASET STRUCTURED_POINTS\n"
-		"DIMENSIONS "+to_string_u(g.Nx)+" "+to_string_u(g.Ny)+" "+to_string_u(g.Nz_out)+"\n"
-		"ORIGIN "+to_string_f(g.origin[0])+" "+to_string_f(g.origin[1])+" "+to_string_f(g.origin[2])+"\n"
-		"SPACING "+to_string_f(g.spacing)+" "+to_string_f(g.spacing)+" "+to_string_f(g.spacing)+"\n"
-		"POINT_DATA "+to_string_u(points)+"\n";
-}
-// Memory_Container::write_vtk (FX/lbm.hpp:307-356): SoA host field -> AoS big-endian floats in SI units
-static void write_field_vtk(const string& filename, const VtkGeom& g, const float* data, const uint comps, const float factor, const float offset = 0.0f, const bool affine = false) {
-	std::filesystem::create_directories(std::filesystem::path(filename).parent_path());
-	std::ofstream file(filename, std::ios::out|std::ios::binary);
-	const string header = vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n";
-	file.write(header.c_str(), (std::streamsize)header.length());
-	const ulong N = (ulong)g.Nx*g.Ny*g.Nz, points = (ulong)g.Nx*g.Ny*g.Nz_out;
-	std::unique_ptr<float[]> conv(new float[points*comps]); float* const buf = conv.get(); // every element is written below: no value-initialisation
-	// the field named T goes through units.si_T (value*unit_K + offset), every other one through its unit factor (FX/lbm.hpp:343)
-	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(affine ? data[(ulong)d*N+i]*factor+offset : factor*data[(ulong)d*N+i]); });
-	file.write((const char*)buf, (std::streamsize)(points*comps*4ull));
-}
-
-// The same files without the host in the data path (default; LUW_HOST_VTK=1 keeps the host conversion above, the cross-check of the tests): header by
-// this process, payload by the devices through LBM::export_vtk -- no field download, no global conversion buffer.
-static bool host_vtk_path() { static const bool on = std::getenv("LUW_HOST_VTK")&&std::getenv("LUW_HOST_VTK")[0]=='1'; return on; }
-struct VtkFile { // an open output file and the offset of its next byte
-	int fd = -1; uint64_t pos = 0ull;
-	explicit VtkFile(const string& filename) {
-		std::filesystem::create_directories(std::filesystem::path(filename).parent_path());
-		fd = ::open(filename.c_str(), O_WRONLY|O_CREAT|O_TRUNC, 0644);
-		if(fd<0) fatal("ERROR: cannot open "+filename+" for writing.");
-	}
-	~VtkFile() { if(fd>=0) ::close(fd); }
-	void text(const string& t) { size_t put = 0u; while(put<t.size()) { const ssize_t w = ::pwrite(fd, t.data()+put, t.size()-put, (off_t)(pos+put)); if(w<=0) fatal("ERROR: writing a VTK header failed."); put += (size_t)w; } pos += t.size(); }
-	void payload(LBM& lbm, const int source, const luw_export_params& prm, const VtkGeom& g, const uint comps) {
-		lbm.export_vtk(source, prm, g.Nz_out, fd, pos);
-		pos += (uint64_t)g.Nx*g.Ny*g.Nz_out*comps*4ull;
-	}
-};
-static luw_export_params export_params(const float factor, const float offset = 0.0f, const bool affine = false) {
-	luw_export_params p{}; p.struct_size = sizeof(p); p.factor = factor; p.offset = offset; p.affine = affine ? 1 : 0; return p;
-}
-static void write_device_field_vtk(LBM& lbm, const string& filename, const VtkGeom& g, const int source, const uint comps, const float factor, const float offset = 0.0f, const bool affine = false) {
-	VtkFile f(filename);
-	f.text(vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n");
-	f.payload(lbm, source, export_params(factor, offset, affine), g, comps);
-}
+#include "console.hpp"
+#include "setup_math.hpp"
+#include "mesh.hpp"
+#include "vtk_writer.hpp"
 
 // ------------------------------------------------------------------------------------------------ main
 int main(int argc, char** argv) {
