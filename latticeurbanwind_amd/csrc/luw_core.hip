@@ -544,11 +544,11 @@ static std::atomic<int> g_live_solvers[64];
 static int tune_ddf_placement(luw_solver* s) {
 	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
 	const char* env = getenv("LUW_TUNE_PLACEMENT");
-	// hipMalloc'ed arrays: up to 6 candidates (round 1).  Chunk-mapped arrays land in the fast class on most boxes by themselves (round 2) -- but not on all:
-	// round 3 met boxes on which the same binary ran the 1024x1024x256 FP32 step in 7.3 or 8.2 instead of 6.7 ms, process after process, and two solver
-	// instances of one process in different classes (profiles/r03_ab_builds_*.txt).  So they get a short search as a safety net: when the probe says "not the
-	// fast class", up to two more mappings are tried and the best is kept; on a good box the first probe passes and nothing else happens.
-	const int candidates = env ? atoi(env) : (s->raw.front().chunks.empty() ? 6 : 3);
+	// hipMalloc'ed arrays: up to 6 candidates (round 1); chunk-mapped arrays: none.  (Round 3 tried a short search for them as a safety net against the
+	// boxes on which the same binary runs 10-20 % slower: the probe of the FIRST mapping of a process is biased -- 4.5 against 4.0 ms for later ones of the
+	// same size, the GPU is still ramping up -- and releasing a loser's address range and chunks (hipMemUnmap / hipMemRelease / hipMemAddressFree) leaves
+	// this ROCm's runtime in a state in which the solver's final dev_free segfaults, reproducibly.  LUW_TUNE_PLACEMENT=<n> still forces a search.)
+	const int candidates = env ? atoi(env) : (s->raw.front().chunks.empty() ? 6 : 0);
 	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
 	if(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1) return LUW_OK; // this device is shared with other solvers of this process
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
