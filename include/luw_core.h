@@ -304,6 +304,21 @@ int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_
 int luw_group_gather_attach(luw_group* g, uint32_t count, const uint64_t* cells);
 int luw_group_gather_u(luw_group* g, float* out);
 int luw_group_stats_reset(luw_group* g);
+/* ---- One domain's share of a decomposed step: the schedule BOTH hosts run -- luw_group_* for all domains of this process, and a host that owns one domain
+ * per process (latticeurbanwind_amd/distributed.py over RCCL), which does the exchange itself between luw_domain_step_launch calls.  Replaces, per domain,
+ * the body of LBM::do_time_step (FX/lbm.cpp:1262-1290) up to communicate_fi: here the boundary shell runs first on the communication stream, the interior on the
+ * compute stream, and consecutive steps are pipelined (interior(t) behind shell(t-1) only).
+ * luw_step_boxes: the boxes alone, pure host arithmetic (local extents incl. halo layers, halo flags per axis, thickness of the x slabs): whole6 / interior6 =
+ * x0,x1,y0,y1,z0,z1; shell_boxes = up to six such boxes. */
+typedef struct luw_domain_step luw_domain_step;
+int luw_step_boxes(const uint32_t* local_N, const uint32_t* halo, uint32_t x_shell, uint32_t* whole6, uint32_t* interior6, uint32_t* shell_boxes, uint32_t* shell_count, int* can_overlap);
+int luw_domain_step_create(luw_solver* s, void* compute_stream, void* comm_stream, uint32_t x_shell /* 0: 64 cells, FP16C 128 */, int overlap, luw_domain_step** out);
+void luw_domain_step_destroy(luw_domain_step* d);
+int luw_domain_step_overlaps(const luw_domain_step* d);       /* 1: shell on the communication stream + interior on the compute stream, pipelined */
+int luw_domain_step_launch(luw_domain_step* d, int write_fields /* bit 0 | LUW_WF_SAMPLE */, int timed);   /* the kernels of one step (the von-Karman inlet update first); no exchange, no t++ */
+int luw_domain_step_separate_stats(luw_domain_step* d);       /* a sampled step without fused statistics: luw_stats_accumulate behind the step, ordered against the next shell */
+int luw_domain_step_timing(luw_domain_step* d, double* kernel_ms, double* shell_ms);   /* means over the timed launches since the last call; waits for both streams */
+
 /* VTK payloads straight from the devices: Memory_Container::write_vtk (FX/lbm.hpp:307-356) and the sections of write_avg_vtk (FX/setup.cpp:2513-2683)
  * without the full-field download.  Every domain converts its own cells on its device -- SoA -> AoS, SI scaling, big-endian -- in z slabs that a
  * writer thread puts into the open file `fd` with pwrite() from `file_offset` on (the caller has written the text header before it); planes

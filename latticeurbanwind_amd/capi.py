@@ -30,7 +30,7 @@ SYMBOLS = [
     "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info", "luw_group_overlaps", "luw_group_direct_peer_stores",
     "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download", "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_run_timed",
     "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis", "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach", "luw_group_gather_u",
-    "luw_group_stats_reset", "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_selfcheck_arith", "luw_fields_every_step", "luw_group_export_vtk", "luw_group_stats_count",
+    "luw_group_stats_reset", "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_selfcheck_arith", "luw_fields_every_step", "luw_step_boxes", "luw_domain_step_create", "luw_domain_step_destroy", "luw_domain_step_overlaps", "luw_domain_step_launch", "luw_domain_step_separate_stats", "luw_domain_step_timing", "luw_group_export_vtk", "luw_group_stats_count",
     "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
@@ -153,6 +153,13 @@ def load(path=None):
     L.luw_group_stats_reset.argtypes = [vp]
     L.luw_group_stats_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.luw_group_transport.argtypes = [vp]
+    L.luw_step_boxes.argtypes = [u32p, u32p, u32, u32p, u32p, u32p, u32p, i32p]
+    L.luw_domain_step_create.argtypes = [vp, vp, vp, u32, i32, C.POINTER(vp)]
+    L.luw_domain_step_destroy.argtypes = [vp]; L.luw_domain_step_destroy.restype = None
+    L.luw_domain_step_overlaps.argtypes = [vp]
+    L.luw_domain_step_launch.argtypes = [vp, i32, i32]
+    L.luw_domain_step_separate_stats.argtypes = [vp]
+    L.luw_domain_step_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.luw_fields_every_step.argtypes = [vp]
     L.luw_group_stats_count.argtypes = [vp]; L.luw_group_stats_count.restype = u64
     L.luw_group_export_vtk.argtypes = [vp, i32, vp, u32, i32, u64]

@@ -86,50 +86,25 @@ class DomainLayout:
     def split_axes(self):
         return [a for a in range(3) if self.D[a] > 1]
 
-    # ---- boxes (x0,x1,y0,y1,z0,z1) in local coordinates
-    def nonhalo_range(self, a):
-        return (1, self.lN[a] - 1) if self.H[a] else (0, self.lN[a])
+    # ---- boxes (x0,x1,y0,y1,z0,z1) in local coordinates: ONE implementation, the library's (luw_step_boxes, csrc/luw_group.hpp: pure host arithmetic, also
+    # what the one-process host luw_group_* cuts its domains with).  whole = the non-halo cells; interior + the disjoint shell slabs cover it exactly once;
+    # y, z slabs are the one cell layer next to a halo (whole rows), x slabs whole blocks of X_SHELL cells from the first owned cell on.
+    def _boxes(self):
+        key = (self.lN, self.H, self.X_SHELL)
+        if getattr(self, "_box_key", None) != key:
+            import ctypes as C
+            from . import capi
+            u3 = C.c_uint32 * 3
+            whole, inner, shell, n, ok = (C.c_uint32 * 6)(), (C.c_uint32 * 6)(), (C.c_uint32 * 36)(), C.c_uint32(0), C.c_int(0)
+            capi.check(capi.load().luw_step_boxes(u3(*self.lN), u3(*self.H), int(self.X_SHELL), whole, inner, shell, C.byref(n), C.byref(ok)))
+            self._box_key = key
+            self._box_val = (tuple(whole), tuple(inner), [tuple(shell[6 * k:6 * k + 6]) for k in range(n.value)], bool(ok.value))
+        return self._box_val
 
-    def shell_ranges(self, a):
-        """(low slab, high slab) of the boundary shell along a split axis.  y, z: the one cell layer next to the halo.
-        x: whole 64-cell blocks starting at the first owned cell -- a one-cell-wide x face would run one lane per wave and
-        touch a full memory line per value; a line-wide slab costs the same traffic per cell as the interior."""
-        lo, hi = self.nonhalo_range(a)
-        if a != 0:
-            return (lo, lo + 1), (hi - 1, hi)
-        first_end = min(lo + self.X_SHELL, hi)
-        last_start = max(lo + ((hi - 1 - lo) // self.X_SHELL) * self.X_SHELL, first_end)
-        return (lo, first_end), (last_start, hi)
-
-    def interior_range(self, a):
-        if not self.H[a]:
-            return (0, self.lN[a])
-        low, high = self.shell_ranges(a)
-        return (low[1], high[0])
-
-    def whole_box(self):
-        r = [self.nonhalo_range(a) for a in range(3)]
-        return (r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1])
-
-    def interior_box(self):
-        r = [self.interior_range(a) for a in range(3)]
-        return (r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1])
-
-    def shell_boxes(self):
-        """disjoint slabs covering (non-halo cells) minus (interior box): the cells whose DDFs are packed"""
-        boxes = []
-        rng = [self.nonhalo_range(a) for a in range(3)]
-        for a in self.split_axes():
-            for s0, s1 in self.shell_ranges(a):
-                r = list(rng)
-                r[a] = (s0, s1)
-                if all(e > s for s, e in r):
-                    boxes.append((r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1]))
-            rng[a] = self.interior_range(a)       # later axes exclude what this axis already covered
-        return boxes
-
-    def can_overlap(self):
-        return all(self.lN[a] >= 6 for a in self.split_axes())
+    def whole_box(self): return self._boxes()[0]
+    def interior_box(self): return self._boxes()[1]
+    def shell_boxes(self): return list(self._boxes()[2])
+    def can_overlap(self): return self._boxes()[3]       # every split axis has at least four owned layers
 
     def local_slices(self):
         """slices of the GLOBAL (z,y,x) array that fill the local box incl. halos (periodic wrap), as index arrays"""
@@ -250,6 +225,8 @@ class HipDomain:
         # stuck behind the interior kernel's workgroups (LUW_COMM_PRIORITY=0 turns that off for A/B runs)
         import os
         self.comm = torch.cuda.Stream(device=self.device, priority=(-1 if os.environ.get("LUW_COMM_PRIORITY", "1") != "0" else 0))
+        # the schedule of a step -- which box on which stream, behind which event -- is the library's (luw_domain_step_*, shared with luw_group_*)
+        self.step = self.lbm.domain_step_create(self.compute.cuda_stream, self.comm.cuda_stream, layout.X_SHELL)
         self.thermal = kw.get("alpha") is not None       # thermal D3Q7 lattice: one more population per face cell travels
         self.buf, self.gbuf = {}, {}
         for a in layout.split_axes():
@@ -276,6 +253,14 @@ class HipDomain:
         self.lbm.enqueue_stream_collide(box, write_fields, sample)
 
     def stats_begin_sample(self): return self.lbm.stats_begin_sample()
+    def configure_step(self, overlap):
+        if self.lbm.domain_step_overlaps(self.step) != bool(overlap):
+            self.lbm.domain_step_destroy(self.step)
+            self.step = self.lbm.domain_step_create(self.compute.cuda_stream, self.comm.cuda_stream, self.layout.X_SHELL, overlap=overlap)
+    def step_overlaps(self): return self.lbm.domain_step_overlaps(self.step)
+    def step_launch(self, write_fields, timed=False): self.lbm.domain_step_launch(self.step, write_fields, timed)
+    def step_separate_stats(self): self.lbm.domain_step_separate_stats(self.step)
+    def step_timing(self): return self.lbm.domain_step_timing(self.step)
 
     def extract(self, axis, stream):
         self.lbm.set_stream(stream.cuda_stream)
@@ -353,6 +338,8 @@ class HipDomain:
 
     def close(self):
         self.torch.cuda.synchronize(self.device)
+        if getattr(self, "step", None):
+            self.lbm.domain_step_destroy(self.step); self.step = None
         self.lbm.close()
 
 
@@ -389,6 +376,8 @@ class DomainDecomposedLBM:
             import os
             overlap = self.layout.D[0] == 1 or os.environ.get("LUW_X_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and self.layout.can_overlap() and hasattr(self.backend, "comm")
+        if hasattr(self.backend, "configure_step"):
+            self.backend.configure_step(self.overlap)            # the library's step context follows the choice (LUW_X_OVERLAP=0, tests)
         import os
         self.pipeline = os.environ.get("LUW_PIPELINE", "1") != "0"     # A/B switch: 0 = join both streams after every step
         self.initialized = False
@@ -463,6 +452,8 @@ class DomainDecomposedLBM:
             self.initialize()
         b = self.backend
         lay = self.layout
+        if getattr(b, "step", None) is not None and self.overlap == b.step_overlaps() and self.pipeline and self.pre_step is None:
+            return self._run_library_schedule(steps, timed, sample)
         ev, ev_comm = [], []
         stats_done = None
         pipelined = self.overlap and self.pipeline
@@ -560,6 +551,35 @@ class DomainDecomposedLBM:
                 if ev_comm[0][0] is not None:
                     out["shell_ms"] = mean([(s0, s1) for s0, s1, _ in ev_comm])
             return out
+        return None
+
+    def _run_library_schedule(self, steps, timed, sample):
+        """the production path on a GPU: per step ONE call launches this domain's kernels in the library's schedule (luw_domain_step_launch: boundary shell on
+        the communication stream, interior on the compute stream, pipelined; the same code luw_group_* runs), then the exchange follows on the
+        communication stream.  What stays here is what differs between the hosts: who the neighbours are and how the faces travel."""
+        b = self.backend
+        import torch
+        comm = b.comm if self.overlap else b.compute
+        ev_comm = []
+        for i in range(steps):
+            sampled = sample is not None and i + 1 >= sample[0] and (i + 1 - sample[0]) % sample[1] == 0
+            fused = sampled and b.stats_begin_sample()
+            separate = sampled and not fused
+            wf = int((i + 1 == steps) or separate or self._every_step()) | (2 if fused else 0)
+            b.step_launch(wf, timed)
+            if timed:
+                x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                x0.record(comm)
+            self.communicate_fi(comm)
+            if timed:
+                x1.record(comm); ev_comm.append((x0, x1))
+            if separate:
+                b.step_separate_stats()
+            b.increment_time_step(1)
+        self._join()
+        if timed and steps:
+            kernel_ms, shell_ms = b.step_timing()
+            return {"kernel_ms": kernel_ms, "shell_ms": None if shell_ms < 0 else shell_ms, "exchange_ms": sum(a.elapsed_time(c) for a, c in ev_comm) / len(ev_comm)}
         return None
 
     def fields(self):

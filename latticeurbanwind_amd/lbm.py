@@ -200,6 +200,19 @@ class LBM:
     def enqueue_insert_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def increment_time_step(self, steps=1): capi.check(self._L.luw_increment_time_step(self._h, steps))
     def reset_time_step(self): capi.check(self._L.luw_reset_time_step(self._h))
+    # ---- the library's schedule of one domain's share of a decomposed step (luw_domain_step_*, csrc/luw_group.hpp)
+    def domain_step_create(self, compute_stream, comm_stream, x_shell=0, overlap=True):
+        d = C.c_void_p()
+        capi.check(self._L.luw_domain_step_create(self._h, compute_stream, comm_stream, int(x_shell), int(bool(overlap)), C.byref(d)))
+        return d
+    def domain_step_destroy(self, d): self._L.luw_domain_step_destroy(d)
+    def domain_step_overlaps(self, d): return bool(self._L.luw_domain_step_overlaps(d))
+    def domain_step_launch(self, d, write_fields, timed=False): capi.check(self._L.luw_domain_step_launch(d, int(write_fields), int(bool(timed))))
+    def domain_step_separate_stats(self, d): capi.check(self._L.luw_domain_step_separate_stats(d))
+    def domain_step_timing(self, d):
+        k, sh = C.c_double(0.0), C.c_double(0.0)
+        capi.check(self._L.luw_domain_step_timing(d, C.byref(k), C.byref(sh)))
+        return k.value, sh.value
     def fields_every_step(self): return bool(self._L.luw_fields_every_step(self._h))   # option, or a fluid nudging / sponge reference cell (luw_initialize)
     def finish(self): capi.check(self._L.luw_finish(self._h))
     def device_ptr(self, field): return self._L.luw_device_ptr(self._h, field)
