@@ -276,6 +276,9 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
 
 
 SECONDARY_STEPS, SECONDARY_WARMUP = 200, 20
+RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0),
+                     "c5_rank_4x2x1_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0),
+                     "c5_rank_1x4x2_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7)}
 
 
 def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, warmup):
@@ -354,6 +357,7 @@ def main():
     ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
     ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
+    ap.add_argument("--rank-shape-block", choices=sorted(RANK_SHAPE_BLOCKS), default=None, help="(used by the N = 1 line itself) measure ONE rank-shape secondary block in this fresh process and print it")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check against the CPU oracle (profiling runs)")
     ap.add_argument("--no-group-host", action="store_true", help="N > 1: skip the one-process multi-domain host block")
     args = ap.parse_args()
@@ -380,6 +384,14 @@ def main():
     fp16c = args.dtype == "fp16c"
     METRIC = "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref"
 
+    if args.rank_shape_block:
+        blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, **RANK_SHAPE_BLOCKS[args.rank_shape_block])
+        import torch.distributed as dist
+        if dist.is_initialized(): dist.destroy_process_group()
+        sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(blk)); sys.stdout.flush()
+        os.dup2(2, 1)
+        return
     if world == 1 and not args.force_distributed:
         size, buildings, _ = WORKLOADS[args.workload]
         if args.size: size = tuple(args.size)
@@ -420,11 +432,16 @@ def main():
                     sec[key] = r
                 except Exception as e:
                     sec[key] = {"error": str(e)[:300]}
-            for key, kw in (("c4_rank_4x2x1_f32", dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0)),
-                            ("c5_rank_4x2x1_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0)),
-                            ("c5_rank_1x4x2_fp16c_coriolis", dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7))):
+            # single ranks of both cuts, each in a FRESH process like a rank of a real run: RCCL's connections have to exist before the lattice is allocated
+            # (set up in a process that has already allocated and freed lattice-sized arrays they leave the kernels 24-40 % slower,
+            # profiles/r01g_halo_chain.md; this process has done that a dozen times by now)
+            import subprocess
+            for key in RANK_SHAPE_BLOCKS:
                 try:
-                    sec[key] = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=SECONDARY_STEPS, warmup=SECONDARY_WARMUP, **kw)
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rank-shape-block", key, "--steps", str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)],
+                                       capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+                    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    sec[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
                 except Exception as e:
                     sec[key] = {"error": str(e)[:300]}
             out["secondary"] = sec
