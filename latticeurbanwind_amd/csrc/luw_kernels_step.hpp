@@ -356,10 +356,14 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr);
 			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
-				rho[n+c] = rhon;
-				u[n+c] = uxn;
-				u[Np+n+c] = uyn;
-				u[2ull*Np+n+c] = uzn;
+				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of being
+				// hoisted in front of both collisions, where the pair of registers it occupied made the uniform-force kernel spill to scratch at 96 VGPRs)
+				uint32_t nw = n+(uint32_t)c;
+				asm volatile("" : "+v"(nw));
+				rho[nw] = rhon;
+				u[nw] = uxn;
+				u[Np+nw] = uyn;
+				u[2ull*Np+nw] = uzn;
 			}
 			if constexpr(STATS) {
 				if((fl[c]&TYPE_BO)==TYPE_E) sample_from_fields(c);
