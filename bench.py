@@ -360,6 +360,9 @@ def main():
     ap.add_argument("--rank-shape-block", choices=sorted(RANK_SHAPE_BLOCKS), default=None, help="(used by the N = 1 line itself) measure ONE rank-shape secondary block in this fresh process and print it")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check against the CPU oracle (profiling runs)")
     ap.add_argument("--no-group-host", action="store_true", help="N > 1: skip the one-process multi-domain host block")
+    ap.add_argument("--group-host-child", choices=sorted(GROUP_HOST_VARIANTS), default=None, help="(used by the N > 1 line itself) measure ONE variant of the one-process host in this fresh process and print it")
+    ap.add_argument("--devices", default=None, help="--group-host-child: the devices of the domains, comma separated")
+    ap.add_argument("--global-lattice", type=int, nargs=3, default=None, help="--group-host-child: the whole lattice")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything libraries print on file descriptor 1 while the run is set up
@@ -384,6 +387,15 @@ def main():
     fp16c = args.dtype == "fp16c"
     METRIC = "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref"
 
+    if args.group_host_child:
+        try:
+            blk = group_host_child(args, luw, capi, kern, fp16c)
+        except Exception as e:
+            blk = {"error": str(e)[:300]}
+        sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(blk)); sys.stdout.flush()
+        os.dup2(2, 1)
+        return
     if args.rank_shape_block:
         blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, **RANK_SHAPE_BLOCKS[args.rank_shape_block])
         import torch.distributed as dist
@@ -591,14 +603,11 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
     Dalt = choose_decomposition(world)                              # x kept whole (8 GPUs: [1,4,2]): the same tile, the cut with whole rows
     cuts = [D] + ([Dalt] if (not args.n_gpu and not args.no_secondary and world > 1 and Dalt != D) else [])
     parity = {"transport": transport, "cases": []}
-    oracle_f32 = None
     if not args.no_parity:
         for Dc in cuts:
             for p_fp16c, p_cor in ((False, False), (True, True)):
-                case, ora = parity_case(Dc, p_fp16c, p_cor)
+                case, _ = parity_case(Dc, p_fp16c, p_cor)
                 parity["cases"].append(case)
-                if Dc == D and not p_fp16c:
-                    oracle_f32 = ora                                 # kept for the one-process host's check below (rank 0)
         verdict = [all(c.get("equal") for c in parity["cases"])] if rank == 0 else [None]
         dist.broadcast_object_list(verdict, src=0)
         parity["ok"] = bool(verdict[0])
@@ -654,11 +663,11 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
     alt = run_tile(cuts[1]) if len(cuts) > 1 else None
 
     # ---- the product's OTHER multi-GPU host: one process, all GPUs (luw_group_*, what luw_driver runs for decks with n_gpu > 1).  Every rank
-    # has destroyed its solver; rank 0 alone drives all devices while the others wait in the barrier below.
+    # has destroyed its solver; child processes of rank 0 drive all devices, one variant each, while the ranks wait in the barrier below.
     group_host = None
     if rank == 0 and not args.no_group_host and world > 1:
         try:
-            group_host = run_group_host(args, luw, capi, D, res["gN"], [dev_of(r) for r in range(world)], fp16c, kern, urban, nud, spg, oracle_f32)
+            group_host = run_group_host(args, D, res["gN"], [dev_of(r) for r in range(world)])
         except Exception as e:      # never takes the RCCL line down; its absence is visible
             group_host = {"error": str(e)[:300]}
     if not shared:
@@ -716,66 +725,86 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
     dist.destroy_process_group()
 
 
-def run_group_host(args, luw, capi, D, gN, devices, fp16c, kern, urban, nud, spg, oracle_f32):
+GROUP_HOST_VARIANTS = {"peer": {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "0"}, "peer_threads": {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "1"},
+                       "rccl": {"LUW_GROUP_TRANSPORT": "rccl", "LUW_GROUP_THREADS": "0"}}
+GROUP_HOST_TIMEOUT_S = int(os.environ.get("LUW_BENCH_GROUP_HOST_TIMEOUT", "420"))     # per variant
+
+
+def run_group_host(args, D, gN, devices):
     """The one-process multi-domain host (csrc/luw_group.hpp behind luw_group_*: the reference's `LBM lbm(N, Dx, Dy, Dz, ...)`, what luw_driver runs
-    for decks with n_gpu > 1) on the SAME tile and cut, driven by this one process over all devices, once per transport: peer stores over xGMI
-    (default) and grouped ncclSend / ncclRecv.  Each with its own self-check first: the small urban tile against the CPU oracle's undivided run."""
-    from concurrent.futures import ThreadPoolExecutor
-    n = len(devices)
-    out = {"what": "one process drives all %d devices (luw_group_*, the deck driver's multi-GPU host); same tile and cut as the headline" % n, "devices": devices, "n_gpu": list(D), "global_lattice": list(gN)}
-    steps, warm = min(args.steps, 60), min(args.warmup, 5)
-    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_TRANSPORT", "LUW_GROUP_THREADS")}
-    try:
-        for label, env in (("peer", {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "0"}), ("peer_threads", {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "1"}),
-                           ("rccl", {"LUW_GROUP_TRANSPORT": "rccl", "LUW_GROUP_THREADS": "0"})):
-            os.environ.update(env)
-            blk = {}
-            try:
-                # self-check on the small tile (global arrays: it is small)
-                if oracle_f32 is not None:
-                    pg = parity_tile(n, D); pn, ps = parity_forcing()
-                    g = luw.LBMGroup(*pg, *D, NU, devices=devices, kernel=kern, buffer_nudging=pn, top_sponge=ps)
-                    try:
-                        fill_channel(g.flags, g.u, g.rho, *pg, buildings=True)
-                        g.run(0); g.run(PARITY_STEPS); g.read_from_device()
-                        blk["parity"] = {"equal": bool(np.array_equal(g.rho, oracle_f32.rho) and np.array_equal(g.u, oracle_f32.u)), "lattice": list(pg), "steps": PARITY_STEPS, "dtype": "f32",
-                                         "compared": "rho, u of every cell against the CPU oracle on the undivided lattice"}
-                        blk["transport"] = capi.TRANSPORT_NAMES.get(g.transport()); blk["overlap"] = g.overlaps()
-                    finally:
-                        g.close()
-                    if not blk["parity"]["equal"]:
-                        out[label] = blk
-                        continue                                     # a host that computes something else is not timed
-                kw = dict(buffer_nudging=nud, top_sponge=spg) if urban else {}
-                g = luw.LBMGroup(*gN, *D, NU, fp16c=fp16c, devices=devices, kernel=kern, global_arrays=False, **kw)
-                try:
-                    def fill(d):
-                        lN, off, _ = g.domain_info(d)
-                        fl, u, rho = g.domain_host(d)
-                        fill_channel(fl, u, rho, *lN, *off, *gN, buildings=urban)
-                    with ThreadPoolExecutor(max_workers=min(n, 8)) as ex:
-                        list(ex.map(fill, range(n)))
-                    if args.coriolis:
-                        g.set_coriolis(*coriolis_omega())
-                    g.initialize_from_domains()
-                    g.run(warm)
-                    t0 = time.perf_counter()
-                    kms = g.run_timed(steps)
-                    dt = time.perf_counter() - t0
-                    cells = gN[0] * gN[1] * gN[2]
-                    blk.update(value=round(cells * steps / dt / 1e6, 1), unit="MLUPS", ms_per_step=round(dt / steps * 1e3, 4), steps=steps, warmup=warm, domain0_kernel_ms=round(kms, 4),
-                               transport=capi.TRANSPORT_NAMES.get(g.transport()), direct_peer_stores=g.direct_peer_stores(), overlap=g.overlaps(),
-                               host_threads="one per domain" if env["LUW_GROUP_THREADS"] == "1" else "one")
-                finally:
-                    g.close()
-            except Exception as e:
-                blk["error"] = str(e)[:300]
-            out[label] = blk
-    finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+    for decks with n_gpu > 1) on the SAME tile and cut, one process over all devices, once per transport: peer stores over xGMI (one host thread, then one
+    per domain) and grouped ncclSend / ncclRecv.  Each variant runs in its OWN child process under a time limit (`--group-host-child`, below): a
+    host that hangs on hardware it has not met costs its own block, not the RCCL line this process still has to print."""
+    import subprocess
+    out = {"what": "one process drives all %d devices (luw_group_*, the deck driver's multi-GPU host); same tile and cut as the headline; each variant in a fresh child process" % len(devices),
+           "devices": devices, "n_gpu": list(D), "global_lattice": list(gN)}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC")}
+    for label in GROUP_HOST_VARIANTS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--group-host-child", label, "--devices", ",".join(str(d) for d in devices), "--n-gpu", *(str(d) for d in D),
+               "--global-lattice", *(str(g) for g in gN), "--dtype", args.dtype, "--kernel", args.kernel, "--steps", str(min(args.steps, 60)), "--warmup", str(min(args.warmup, 5))]
+        cmd += (["--coriolis"] if args.coriolis else []) + (["--no-buildings"] if args.no_buildings else []) + (["--no-parity"] if args.no_parity else [])
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=GROUP_HOST_TIMEOUT_S, env=env)     # a child past its limit is killed by its PID
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            blk = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
+        except subprocess.TimeoutExpired:
+            blk = {"error": "no result within %d s: child process killed" % GROUP_HOST_TIMEOUT_S}
+        except Exception as e:
+            blk = {"error": str(e)[:300]}
+        blk["process_wall_s"] = round(time.perf_counter() - t0, 1)
+        out[label] = blk
     return out
+
+
+def group_host_child(args, luw, capi, kern, fp16c):
+    """ONE variant of the one-process host, in this fresh process: its own self-check first (the small urban tile against the CPU oracle's undivided
+    run, FP32, rho and u of every cell), then the timed tile."""
+    from concurrent.futures import ThreadPoolExecutor
+    label = args.group_host_child
+    os.environ.update(GROUP_HOST_VARIANTS[label])
+    devices = [int(d) for d in args.devices.split(",")]
+    D, gN, n = tuple(args.n_gpu), tuple(args.global_lattice), len(devices)
+    urban = not args.no_buildings
+    nud, spg = tile_forcing() if urban else (None, None)
+    blk = {}
+    if not args.no_parity:
+        pg = parity_tile(n, D); pn, ps = parity_forcing()
+        ora = oracle_tile(pg, False, False, PARITY_STEPS)
+        g = luw.LBMGroup(*pg, *D, NU, devices=devices, kernel=kern, buffer_nudging=pn, top_sponge=ps)
+        try:
+            fill_channel(g.flags, g.u, g.rho, *pg, buildings=True)
+            g.run(0); g.run(PARITY_STEPS); g.read_from_device()
+            blk["parity"] = {"equal": bool(np.array_equal(g.rho, ora.rho) and np.array_equal(g.u, ora.u)), "lattice": list(pg), "steps": PARITY_STEPS, "dtype": "f32",
+                             "compared": "rho, u of every cell against the CPU oracle on the undivided lattice"}
+            blk["transport"] = capi.TRANSPORT_NAMES.get(g.transport()); blk["overlap"] = g.overlaps()
+        finally:
+            g.close()
+        if not blk["parity"]["equal"]:
+            return blk                                           # a host that computes something else is not timed
+    kw = dict(buffer_nudging=nud, top_sponge=spg) if urban else {}
+    g = luw.LBMGroup(*gN, *D, NU, fp16c=fp16c, devices=devices, kernel=kern, global_arrays=False, **kw)
+    try:
+        def fill(d):
+            lN, off, _ = g.domain_info(d)
+            fl, u, rho = g.domain_host(d)
+            fill_channel(fl, u, rho, *lN, *off, *gN, buildings=urban)
+        with ThreadPoolExecutor(max_workers=min(n, 8)) as ex:
+            list(ex.map(fill, range(n)))
+        if args.coriolis:
+            g.set_coriolis(*coriolis_omega())
+        g.initialize_from_domains()
+        g.run(args.warmup)
+        t0 = time.perf_counter()
+        kms = g.run_timed(args.steps)
+        dt = time.perf_counter() - t0
+        cells = gN[0] * gN[1] * gN[2]
+        blk.update(value=round(cells * args.steps / dt / 1e6, 1), unit="MLUPS", ms_per_step=round(dt / args.steps * 1e3, 4), steps=args.steps, warmup=args.warmup, domain0_kernel_ms=round(kms, 4),
+                   transport=capi.TRANSPORT_NAMES.get(g.transport()), direct_peer_stores=g.direct_peer_stores(), overlap=g.overlaps(),
+                   host_threads="one per domain" if GROUP_HOST_VARIANTS[label]["LUW_GROUP_THREADS"] == "1" else "one")
+    finally:
+        g.close()
+    return blk
 
 
 if __name__ == "__main__":

@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def bench(world, *extra):
+def bench(world, *extra, env=None):
     port = 29500 + ((os.getpid() + 97 + world) % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--share-device", "0", *extra]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -44,5 +44,8 @@ def test_two_ranks_self_check_and_blocks(luw):
 
 
 def test_four_ranks_fp16c_coriolis(luw):
-    out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host")
+    # the one-process host's variants run in child processes under a time limit: with a limit no child can meet, the line is still printed
+    out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", env={"LUW_BENCH_GROUP_HOST_TIMEOUT": "1"})
     assert out["config"]["n_gpu"] == [2, 2, 1] and out["parity"]["ok"] and out["value"] > 0
+    for label in ("peer", "peer_threads", "rccl"):
+        assert "no result within 1 s" in out["secondary"]["group_host"][label]["error"]
