@@ -64,8 +64,19 @@ template<typename F, uint MAXD> static string fixed_decimals(F x, const uint dec
 static string to_string_fd(const float x, const uint decimals) { return fixed_decimals<float, 8u>(x, decimals); }
 static string to_string_dd(const double x, const uint decimals) { return fixed_decimals<double, 16u>(x, decimals); }
 static string fmtf(float v, int prec = 4) { std::ostringstream os; os << std::fixed; os.precision(prec); os << v; return os.str(); }
-static string format_tag(float v) { string s = to_string_fd(v, 3u); if(s.find('.')!=string::npos) { while(!s.empty()&&s.back()=='0') s.pop_back(); if(!s.empty()&&s.back()=='.') s.pop_back(); } return s.empty() ? "0" : s; }
-static string now_str(const char* fmt = "%Y%m%d %H:%M:%S") { std::time_t tt = std::time(nullptr); std::tm tm{}; localtime_r(&tt, &tm); char b[64]; std::strftime(b, sizeof(b), fmt, &tm); return b; }
+static string format_tag(float v) {
+	string s = to_string_fd(v, 3u);
+	if(s.find('.')!=string::npos) { while(!s.empty()&&s.back()=='0') s.pop_back(); if(!s.empty()&&s.back()=='.') s.pop_back(); }
+	return s.empty() ? "0" : s;
+}
+static string now_str(const char* fmt = "%Y%m%d %H:%M:%S") {
+	std::time_t tt = std::time(nullptr);
+	std::tm tm{};
+	localtime_r(&tt, &tm);
+	char b[64];
+	std::strftime(b, sizeof(b), fmt, &tm);
+	return b;
+}
 [[noreturn]] static void fatal(const string& msg, const int code = -1) { println(msg); println(hr_plain()); std::exit(code); }
 
 template<typename Fn> static void parallel_for(const ulong N, Fn fn) { // FX/utilities.hpp:64-97

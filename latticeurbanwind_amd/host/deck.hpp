@@ -102,7 +102,8 @@ private:
 		while(a<b&&k[a]=='_') a++;
 		while(b>a&&k[b-1u]=='_') b--;
 		k = k.substr(a, b-a);
-		static const char* const renamed[][2] = { {"vk_inlet_aniso_scale", "vk_inlet_anisotropy"}, {"vk_inlet_anisotropy_scale", "vk_inlet_anisotropy"}, {"vk_inlet_enable", "turb_inflow_enable"} };
+		static const char* const renamed[][2] = { {"vk_inlet_aniso_scale", "vk_inlet_anisotropy"}, {"vk_inlet_anisotropy_scale", "vk_inlet_anisotropy"},
+			{"vk_inlet_enable", "turb_inflow_enable"} };
 		for(const auto& r : renamed) if(k==r[0]) return r[1];
 		return k;
 	}

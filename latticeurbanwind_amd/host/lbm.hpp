@@ -22,7 +22,8 @@ namespace luw_host {
 typedef unsigned int uint;
 typedef unsigned char uchar;
 typedef uint64_t ulong;
-struct uint3 { uint x, y, z; uint3(const uint x_ = 0u, const uint y_ = 0u, const uint z_ = 0u) : x(x_), y(y_), z(z_) {} }; // FX/utilities.hpp uint3, as far as LBM's constructors need it
+// FX/utilities.hpp uint3, as far as LBM's constructors need it
+struct uint3 { uint x, y, z; uint3(const uint x_ = 0u, const uint y_ = 0u, const uint z_ = 0u) : x(x_), y(y_), z(z_) {} };
 
 #define TYPE_S LUW_TYPE_S
 #define TYPE_E LUW_TYPE_E
@@ -35,7 +36,11 @@ inline void luw_check(const int rc) { // reference: print_error + exit(1), FX/ut
 // process-global solver configuration: what the reference keeps in globals of setup.cpp / lbm.cpp (FX/setup.cpp:205-220) and in
 // compile-time defines of its build (FX/defines.hpp: FP16C, TEMPERATURE), as run-time switches
 struct SolverGlobals {
-	bool buffer_nudging_active = false; int buffer_n_cells = 1; int buffer_downstream_face_id = 0; float buffer_inv_tau_lbmu = 0.0f; int buffer_nudge_vertical = 0;
+	bool buffer_nudging_active = false;
+	int buffer_n_cells = 1;
+	int buffer_downstream_face_id = 0;
+	float buffer_inv_tau_lbmu = 0.0f;
+	int buffer_nudge_vertical = 0;
 	bool top_sponge_active = false; int sponge_n_cells = 1; float sponge_inv_tau_lbmu = 0.0f;
 	bool fp16c = false;          // #define FP16C
 	bool temperature = false;    // #define TEMPERATURE: the alpha passed to the constructor takes effect (thermal D3Q7 lattice, lbm.T)
@@ -52,13 +57,19 @@ class LBM {
 	uint Nx = 1u, Ny = 1u, Nz = 1u, Dx = 1u, Dy = 1u, Dz = 1u;
 	bool initialized = false;
 	std::unique_ptr<char[]> global_store[6]; // D > 1: global host arrays by LUW_FIELD_* id
-	void construct(const uint Nx_, const uint Ny_, const uint Nz_, const uint Dx_, const uint Dy_, const uint Dz_, const float nu, const float fx, const float fy, const float fz, const float sigma, const float alpha, const float beta) {
+	void construct(const uint Nx_, const uint Ny_, const uint Nz_, const uint Dx_, const uint Dy_, const uint Dz_, const float nu, const float fx,
+		const float fy, const float fz, const float sigma, const float alpha, const float beta) {
 		const uint NDx = (Nx_/Dx_)*Dx_, NDy = (Ny_/Dy_)*Dy_, NDz = (Nz_/Dz_)*Dz_; // make resolution equally divisible by domains, FX/lbm.cpp:1058-1060
-		if(NDx!=Nx_||NDy!=Ny_||NDz!=Nz_) std::printf("| Warning: LBM grid (%ux%ux%u) is not equally divisible in domains (%ux%ux%u). Changing resolution to (%ux%ux%u).\n", Nx_, Ny_, Nz_, Dx_, Dy_, Dz_, NDx, NDy, NDz);
+		if(NDx!=Nx_||NDy!=Ny_||NDz!=Nz_)
+			std::printf("| Warning: LBM grid (%ux%ux%u) is not equally divisible in domains (%ux%ux%u). Changing resolution to (%ux%ux%u).\n", Nx_, Ny_, Nz_,
+			Dx_, Dy_, Dz_, NDx, NDy, NDz);
 		Nx = NDx; Ny = NDy; Nz = NDz; Dx = Dx_; Dy = Dy_; Dz = Dz_;
 		const SolverGlobals& G = solver_globals();
 		if(sigma!=0.0f) { std::fprintf(stderr, "| Error: surface tension (SURFACE extension) is not part of this solver.\n"); std::exit(1); }
-		if(beta!=0.0f&&(fx!=0.0f||fy!=0.0f||fz!=0.0f)&&G.temperature) { std::fprintf(stderr, "| Error: buoyancy (beta with a non-zero volume force) is not part of this solver; LUW runs with (fx,fy,fz) = 0.\n"); std::exit(1); }
+		if(beta!=0.0f&&(fx!=0.0f||fy!=0.0f||fz!=0.0f)&&G.temperature) {
+			std::fprintf(stderr, "| Error: buoyancy (beta with a non-zero volume force) is not part of this solver; LUW runs with (fx,fy,fz) = 0.\n");
+			std::exit(1);
+		}
 		luw_config c = {};
 		c.struct_size = sizeof(luw_config);
 		c.Nx = Nx; c.Ny = Ny; c.Nz = Nz; c.Dx = Dx; c.Dy = Dy; c.Dz = Dz;
@@ -71,7 +82,10 @@ class LBM {
 		c.top_sponge_active = G.top_sponge_active; c.sponge_n_cells = (uint32_t)G.sponge_n_cells; c.sponge_inv_tau_lbmu = G.sponge_inv_tau_lbmu;
 		c.device = G.device; c.kernel = G.kernel;
 		const uint D = Dx*Dy*Dz;
-		if(!G.devices.empty()&&G.devices.size()!=D) { std::fprintf(stderr, "| Error: the device list names %zu devices for %u domains.\n", G.devices.size(), D); std::exit(1); }
+		if(!G.devices.empty()&&G.devices.size()!=D) {
+			std::fprintf(stderr, "| Error: the device list names %zu devices for %u domains.\n", G.devices.size(), D);
+			std::exit(1);
+		}
 		luw_check(luw_group_create(&c, G.devices.empty() ? nullptr : G.devices.data(), &g));
 		const ulong N = get_N();
 		auto bind = [&](ScalarField& f, const int field, const uint32_t mask, const uint comps, const size_t elem, const float fill) {
@@ -80,7 +94,10 @@ class LBM {
 			if(!luw_host_ptr(luw_group_domain(g, 0u), field)) { f.host = nullptr; return; }
 			global_store[field].reset(new char[(size_t)N*comps*elem]);
 			f.host = global_store[field].get();
-			if(elem==4u) { float* p = static_cast<float*>(f.host); for(ulong n=0ull; n<N*comps; n++) p[n] = fill; } else std::memset(f.host, 0, (size_t)N*comps);
+			if(elem==4u) {
+				float* p = static_cast<float*>(f.host);
+				for(ulong n=0ull; n<N*comps; n++) p[n] = fill;
+			} else std::memset(f.host, 0, (size_t)N*comps);
 		};
 		if(D==1u) s0 = luw_group_domain(g, 0u);
 		bind(rho, LUW_FIELD_RHO, LUW_MASK_RHO, 1u, 4u, 1.0f); // Memory<float>(device, N, 1u, true, true, 1.0f), FX/lbm.cpp:286
@@ -114,16 +131,20 @@ public:
 	// the reference's constructors, FX/lbm.hpp:444-450 (the particle overloads belong to an extension outside this path).
 	// sigma must be 0 (SURFACE is not compiled in the shipped build either); alpha takes effect when the thermal lattice is on
 	// (SolverGlobals::temperature, the build's TEMPERATURE define); beta acts through (fx,fy,fz), which LUW keeps at zero.
-	LBM(const uint Nx_, const uint Ny_, const uint Nz_, const uint Dx_, const uint Dy_, const uint Dz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
+	LBM(const uint Nx_, const uint Ny_, const uint Nz_, const uint Dx_, const uint Dy_, const uint Dz_, const float nu, const float fx = 0.0f,
+		const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
 		construct(Nx_, Ny_, Nz_, Dx_, Dy_, Dz_, nu, fx, fy, fz, sigma, alpha, beta);
 	}
-	LBM(const uint Nx_, const uint Ny_, const uint Nz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
+	LBM(const uint Nx_, const uint Ny_, const uint Nz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f,
+		const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
 		construct(Nx_, Ny_, Nz_, 1u, 1u, 1u, nu, fx, fy, fz, sigma, alpha, beta);
 	}
-	LBM(const uint3 N, const uint Dx_, const uint Dy_, const uint Dz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
+	LBM(const uint3 N, const uint Dx_, const uint Dy_, const uint Dz_, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f,
+		const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
 		construct(N.x, N.y, N.z, Dx_, Dy_, Dz_, nu, fx, fy, fz, sigma, alpha, beta);
 	}
-	LBM(const uint3 N, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f) {
+	LBM(const uint3 N, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f,
+		const float beta = 0.0f) {
 		construct(N.x, N.y, N.z, 1u, 1u, 1u, nu, fx, fy, fz, sigma, alpha, beta);
 	}
 	~LBM() { luw_group_destroy(g); }
@@ -132,7 +153,8 @@ public:
 	void run(const ulong steps = 0ull, const ulong total_steps = 0ull) { // FX/lbm.cpp:1292-1312; run(0) = upload + initialize
 		(void)total_steps;
 		if(!initialized) {
-			if(!s0) for(ScalarField* f : { (ScalarField*)&rho, (ScalarField*)&u, (ScalarField*)&flags, (ScalarField*)&F, (ScalarField*)&T }) if(f->host) luw_check(luw_group_scatter(g, f->field, f->host));
+			if(!s0) for(ScalarField* f : { (ScalarField*)&rho, (ScalarField*)&u, (ScalarField*)&flags, (ScalarField*)&F, (ScalarField*)&T }) if(f->host)
+				luw_check(luw_group_scatter(g, f->field, f->host));
 			luw_check(luw_group_initialize(g)); initialized = true;
 		}
 		if(steps>0ull) luw_check(luw_group_run(g, steps));
@@ -143,7 +165,12 @@ public:
 	ulong get_t() const { return luw_group_get_t(g); }
 	void set_f(const float fx, const float fy, const float fz) { luw_check(luw_group_set_f(g, fx, fy, fz)); }
 	void set_coriolis(const float ox, const float oy, const float oz) { luw_check(luw_group_set_coriolis(g, ox, oy, oz)); }
-	void coordinates(const ulong n, uint& x, uint& y, uint& z) const { const ulong t = n%((ulong)Nx*(ulong)Ny); x = (uint)(t%(ulong)Nx); y = (uint)(t/(ulong)Nx); z = (uint)(n/((ulong)Nx*(ulong)Ny)); }
+	void coordinates(const ulong n, uint& x, uint& y, uint& z) const {
+		const ulong t = n%((ulong)Nx*(ulong)Ny);
+		x = (uint)(t%(ulong)Nx);
+		y = (uint)(t/(ulong)Nx);
+		z = (uint)(n/((ulong)Nx*(ulong)Ny));
+	}
 	ulong index(const uint x, const uint y, const uint z) const { return (ulong)x+((ulong)y+(ulong)z*(ulong)Ny)*(ulong)Nx; }
 	void position(const uint x, const uint y, const uint z, float& px, float& py, float& pz) const { // FX/lbm.hpp:523-525
 		px = (float)x-0.5f*(float)Nx+0.5f; py = (float)y-0.5f*(float)Ny+0.5f; pz = (float)z-0.5f*(float)Nz+0.5f;
@@ -151,7 +178,8 @@ public:
 	// lbm.voxelize_mesh_on_device(mesh, TYPE_S) for a static mesh, FX/lbm.hpp:560 / FX/lbm.cpp:1411: corners are float3
 	// arrays (xyz triples) in lattice index coordinates, pmin/pmax the Mesh's bounds; every domain voxelises its own box
 	// (FX/lbm.cpp:1455-1587); the result lands in flags[]
-	void voxelize_mesh_on_device(const uint triangle_number, const float* p0, const float* p1, const float* p2, const float* pmin, const float* pmax, const uchar flag = 0x01) {
+	void voxelize_mesh_on_device(const uint triangle_number, const float* p0, const float* p1, const float* p2, const float* pmin, const float* pmax,
+		const uchar flag = 0x01) {
 		const float bounds[6] = { pmin[0], pmin[1], pmin[2], pmax[0], pmax[1], pmax[2] };
 		if(s0) { luw_check(luw_voxelize_mesh(s0, triangle_number, p0, p1, p2, bounds, flag)); return; }
 		luw_check(luw_group_scatter(g, LUW_FIELD_FLAGS, flags.host)); luw_check(luw_group_scatter(g, LUW_FIELD_U, u.host));
@@ -160,9 +188,11 @@ public:
 	}
 	// ---- what LUW's run loop does around the solver (FX/setup.cpp:4117-4911), on the device(s) here
 	// von-Karman inlet tables with GLOBAL cell indices: every domain takes the points it owns (FX/setup.cpp:1012-1057)
-	void vk_inlet_attach(const uint64_t point_count, const uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, const int update_stride, const int stride_interpolation) {
+	void vk_inlet_attach(const uint64_t point_count, const uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face, const float* point_data,
+		const float* mode_data, const int update_stride, const int stride_interpolation) {
 		if(s0) luw_check(luw_vk_inlet_attach(s0, point_count, mode_count, point_cell, point_face, point_data, mode_data, update_stride, stride_interpolation));
-		else luw_check(luw_group_vk_inlet_attach(g, point_count, mode_count, point_cell, point_face, point_data, mode_data, update_stride, stride_interpolation));
+		else luw_check(luw_group_vk_inlet_attach(g, point_count, mode_count, point_cell, point_face, point_data, mode_data, update_stride,
+			stride_interpolation));
 	}
 	void stats_reset() { luw_check(luw_group_stats_reset(g)); }
 	void run_sampled(const ulong steps, const ulong first_sample, const ulong stride) { luw_check(luw_group_run_sampled(g, steps, first_sample, stride)); }

@@ -19,7 +19,12 @@ static bool read_stl(const string& path, Mesh& m) { // binary STL only, FX/utili
 	uint tn; std::memcpy(&tn, data.data()+80, 4);
 	if(tn==0u||data.size()!=84u+50ull*tn) fatal("| Error: File \""+path+"\" is corrupt or unsupported! Only binary .stl files are supported.", 1);
 	m.n = tn; m.p0.resize(3u*tn); m.p1.resize(3u*tn); m.p2.resize(3u*tn);
-	for(uint i=0u; i<tn; i++) { const char* t = data.data()+84u+50ull*i; std::memcpy(&m.p0[3u*i], t+12, 12); std::memcpy(&m.p1[3u*i], t+24, 12); std::memcpy(&m.p2[3u*i], t+36, 12); }
+	for(uint i=0u; i<tn; i++) {
+		const char* t = data.data()+84u+50ull*i;
+		std::memcpy(&m.p0[3u*i], t+12, 12);
+		std::memcpy(&m.p1[3u*i], t+24, 12);
+		std::memcpy(&m.p2[3u*i], t+36, 12);
+	}
 	mesh_find_bounds(m);
 	return true;
 }
@@ -49,7 +54,8 @@ static ulong voxelize_z(const Mesh& m, const uint Nx, const uint Ny, const uint 
 			const float u[3] = {a1[0]-a0[0], a1[1]-a0[1], a1[2]-a0[2]}, v[3] = {a2[0]-a0[0], a2[1]-a0[1], a2[2]-a0[2]}, w[3] = {rx-a0[0], ry-a0[1], rz-a0[2]};
 			const float h[3] = {0.0f*v[2]-1.0f*v[1], 1.0f*v[0]-0.0f*v[2], 0.0f*v[1]-0.0f*v[0]};             // cross(r_direction, v)
 			const float q[3] = {w[1]*u[2]-w[2]*u[1], w[2]*u[0]-w[0]*u[2], w[0]*u[1]-w[1]*u[0]};               // cross(w, u)
-			const float g = u[0]*h[0]+u[1]*h[1]+u[2]*h[2], f = 1.0f/g, s = f*(w[0]*h[0]+w[1]*h[1]+w[2]*h[2]), t = f*(0.0f*q[0]+0.0f*q[1]+1.0f*q[2]), d = f*(v[0]*q[0]+v[1]*q[1]+v[2]*q[2]);
+			const float g = u[0]*h[0]+u[1]*h[1]+u[2]*h[2], f = 1.0f/g, s = f*(w[0]*h[0]+w[1]*h[1]+w[2]*h[2]), t = f*(0.0f*q[0]+0.0f*q[1]+1.0f*q[2]),
+				d = f*(v[0]*q[0]+v[1]*q[1]+v[2]*q[2]);
 			if(g!=0.0f&&s>=0.0f&&s<1.0f&&t>=0.0f&&s+t<1.0f) {
 				if(d>0.0f) { if(intersections<64u&&d<65536.0f) dist[intersections] = (unsigned short)d; intersections++; } else check++;
 			}

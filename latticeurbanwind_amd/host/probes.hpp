@@ -17,12 +17,36 @@
 
 namespace luw_host {
 
-struct ProbeOffset { enum Mode { NONE, CELLS, METERS } mode = NONE; int north_cells = 0, east_cells = 0; double north_m = 0.0, east_m = 0.0; std::string label; };
+struct ProbeOffset {
+	enum Mode { NONE, CELLS, METERS }
+	mode = NONE;
+	int north_cells = 0, east_cells = 0;
+	double north_m = 0.0, east_m = 0.0;
+	std::string label;
+};
 struct ProbeRequest { std::string raw; double lon = 0.0, lat = 0.0; bool centre = false; ProbeOffset off; };
-struct GeoFrame { bool valid = false; int zone = 0; bool north = true; double rot_deg = 0.0, px = 0.0, py = 0.0, xmin = 0.0, ymin = 0.0, clon = 0.0, clat = 0.0, ex = 1.0, ey = 0.0, nx = 0.0, ny = 1.0; };
-struct ProbeColumn { ProbeRequest req; std::string stem; uint32_t x = 0u, y = 0u; std::vector<uint32_t> z; std::vector<float> height_si; std::vector<double> time_si; std::vector<float> uvw_si; /* [time][level][3] */ };
+struct GeoFrame {
+	bool valid = false;
+	int zone = 0;
+	bool north = true;
+	double rot_deg = 0.0, px = 0.0, py = 0.0, xmin = 0.0, ymin = 0.0, clon = 0.0, clat = 0.0, ex = 1.0, ey = 0.0, nx = 0.0, ny = 1.0;
+};
+struct ProbeColumn {
+	ProbeRequest req;
+	std::string stem;
+	uint32_t x = 0u, y = 0u;
+	std::vector<uint32_t> z;
+	std::vector<float> height_si;
+	std::vector<double> time_si;
+	std::vector<float> uvw_si;
+	/* [time][level][3] */
+};
 
-inline std::string pr_trim(const std::string& s) { const char* ws = " \t\r\n"; const size_t b = s.find_first_not_of(ws), e = s.find_last_not_of(ws); return b==std::string::npos ? std::string() : s.substr(b, e-b+1u); }
+inline std::string pr_trim(const std::string& s) {
+	const char* ws = " \t\r\n";
+	const size_t b = s.find_first_not_of(ws), e = s.find_last_not_of(ws);
+	return b==std::string::npos ? std::string() : s.substr(b, e-b+1u);
+}
 inline std::string fixed_trimmed(const double v, const int prec = 6) { // "%.6f" without trailing zeros
 	std::ostringstream o; o << std::fixed << std::setprecision(prec) << v;
 	std::string s = o.str();
@@ -59,7 +83,13 @@ inline bool parse_offset(const std::string& raw, ProbeOffset& o, std::string& er
 	o.label = s;
 	if(std::none_of(s.begin(), s.end(), [](const char c) { return c>='0'&&c<='9'; })) { // letters only: one cell per letter
 		o.mode = ProbeOffset::CELLS;
-		for(const char c : s) { if(c=='N') o.north_cells++; else if(c=='S') o.north_cells--; else if(c=='E') o.east_cells++; else if(c=='W') o.east_cells--; else { err = "grid offset can only contain N/S/E/W"; return false; } }
+		for(const char c : s) {
+			if(c=='N') o.north_cells++;
+			else if(c=='S') o.north_cells--;
+			else if(c=='E') o.east_cells++;
+			else if(c=='W') o.east_cells--;
+			else { err = "grid offset can only contain N/S/E/W"; return false; }
+		}
 		return true;
 	}
 	o.mode = ProbeOffset::METERS;
@@ -80,11 +110,19 @@ inline bool parse_probe(const std::string& token_in, ProbeRequest& r, std::strin
 	const std::string& t = r.raw;
 	if(t.empty()) { err = "empty probe token"; return false; }
 	auto lower = [](std::string s) { for(char& c : s) c = (char)std::tolower((unsigned char)c); return s; };
-	auto centre_word = [&](const std::string& word, const std::string& rest) { const std::string k = lower(pr_trim(word)); if(k!="center"&&k!="centre") return false; r.centre = true; return parse_offset(rest, r.off, err); };
+	auto centre_word = [&](const std::string& word, const std::string& rest) {
+		const std::string k = lower(pr_trim(word));
+		if(k!="center"&&k!="centre") return false;
+		r.centre = true;
+		return parse_offset(rest, r.off, err);
+	};
 	if(t.front()=='"'||t.front()=='\'') {
 		const size_t close = t.find(t.front(), 1u);
 		if(close==std::string::npos) { err = "quoted probe token is missing the closing quote"; return false; }
-		if(!centre_word(t.substr(1u, close-1u), pr_trim(t.substr(close+1u)))) { if(err.empty()) err = "quoted probe token only supports center/centre"; return false; }
+		if(!centre_word(t.substr(1u, close-1u), pr_trim(t.substr(close+1u)))) {
+			if(err.empty()) err = "quoted probe token only supports center/centre";
+			return false;
+		}
 		return true;
 	}
 	const std::string tl = lower(t);
@@ -123,17 +161,27 @@ inline void rotate_about(const double x, const double y, const double deg, const
 	const double th = deg*(3.1415926535897932384626433832795/180.0), c = std::cos(th), s = std::sin(th), dx = x-cx, dy = y-cy;
 	xr = c*dx-s*dy+cx; yr = s*dx+c*dy+cy;
 }
-inline GeoFrame make_geo_frame(const float lon0, const float lon1, const float lat0, const float lat1, const std::string& utm_crs, const bool has_rot, const double rot_override) {
+inline GeoFrame make_geo_frame(const float lon0, const float lon1, const float lat0, const float lat1, const std::string& utm_crs, const bool has_rot,
+	const double rot_override) {
 	GeoFrame g;
 	if(!std::isfinite(lon0)||!std::isfinite(lon1)||!std::isfinite(lat0)||!std::isfinite(lat1)) return g;
-	const double lo = std::min((double)lon0, (double)lon1), hi = std::max((double)lon0, (double)lon1), la = std::min((double)lat0, (double)lat1), lb = std::max((double)lat0, (double)lat1);
+	const double lo = std::min((double)lon0, (double)lon1), hi = std::max((double)lon0, (double)lon1), la = std::min((double)lat0, (double)lat1),
+		lb = std::max((double)lat0, (double)lat1);
 	if(!(hi>lo)||!(lb>la)) return g;
 	int zone = 0; bool north = true; bool from_crs = false;
 	{ std::string d; for(const char c : pr_trim(utm_crs)) if(c>='0'&&c<='9') d.push_back(c); // EPSG 326zz / 327zz
-	  if(!d.empty()) { const int code = atoi(d.c_str()); if(code>=32601&&code<=32660) { zone = code-32600; north = true; from_crs = true; } else if(code>=32701&&code<=32760) { zone = code-32700; north = false; from_crs = true; } } }
+	  if(!d.empty()) {
+		const int code = atoi(d.c_str());
+		if(code>=32601&&code<=32660) {
+			zone = code-32600;
+			north = true;
+			from_crs = true;
+		} else if(code>=32701&&code<=32760) { zone = code-32700; north = false; from_crs = true; }
+	} }
 	if(!from_crs) { zone = (int)std::floor((0.5*(lo+hi)+180.0)/6.0)+1; zone = std::min(60, std::max(1, zone)); north = 0.5*(la+lb)>=0.0; }
 	double x[4], y[4]; // corners: SW, SE, NE, NW
-	if(!utm_forward(lo, la, zone, north, x[0], y[0])||!utm_forward(hi, la, zone, north, x[1], y[1])||!utm_forward(hi, lb, zone, north, x[2], y[2])||!utm_forward(lo, lb, zone, north, x[3], y[3])) return g;
+	if(!utm_forward(lo, la, zone, north, x[0], y[0])||!utm_forward(hi, la, zone, north, x[1], y[1])||!utm_forward(hi, lb, zone, north, x[2], y[2])
+		||!utm_forward(lo, lb, zone, north, x[3], y[3])) return g;
 	const double cx = 0.25*(x[0]+x[1]+x[2]+x[3]), cy = 0.25*(y[0]+y[1]+y[2]+y[3]);
 	const double rot = has_rot ? rot_override : (-std::atan2(y[1]-y[0], x[1]-x[0])*180.0/3.1415926535897932384626433832795);
 	double xr[4], yr[4]; for(int k=0; k<4; k++) rotate_about(x[k], y[k], rot, cx, cy, xr[k], yr[k]);
@@ -157,7 +205,8 @@ inline uint32_t snap_index(const double coord_si, const uint32_t n, const float 
 	return i<=0l ? 0u : ((uint64_t)i>=(uint64_t)n ? n-1u : (uint32_t)i);
 }
 // lon/lat (+offset) -> lattice column; false with a reason when the point leaves the domain
-inline bool resolve_probe_xy(const ProbeRequest& r, const GeoFrame& g, const uint32_t Nx, const uint32_t Ny, const float cell_m, const float six, const float siy, uint32_t& x, uint32_t& y, std::string& why) {
+inline bool resolve_probe_xy(const ProbeRequest& r, const GeoFrame& g, const uint32_t Nx, const uint32_t Ny, const float cell_m, const float six,
+	const float siy, uint32_t& x, uint32_t& y, std::string& why) {
 	double bx, by;
 	if(!geo_to_local(g, r.centre ? g.clon : r.lon, r.centre ? g.clat : r.lat, bx, by)) { why = "projection failed"; return false; }
 	auto inside = [&](const double a, const double b) { return std::isfinite(a)&&std::isfinite(b)&&a>=0.0&&a<=(double)six&&b>=0.0&&b<=(double)siy; };
@@ -189,7 +238,11 @@ inline bool write_probe_csv(const std::string& path, const ProbeColumn& p) {
 	const size_t L = p.z.size(), T = p.time_si.size();
 	for(size_t l=0u; l<L; l++) {
 		f << fixed_trimmed((double)p.height_si[l], 6);
-		for(size_t t=0u; t<T; t++) { const size_t b = (t*L+l)*3u; f << "," << fixed_trimmed((double)p.uvw_si[b], 6) << ":" << fixed_trimmed((double)p.uvw_si[b+1u], 6) << ":" << fixed_trimmed((double)p.uvw_si[b+2u], 6); }
+		for(size_t t=0u; t<T; t++) {
+			const size_t b = (t*L+l)*3u;
+			f << "," << fixed_trimmed((double)p.uvw_si[b], 6) << ":" << fixed_trimmed((double)p.uvw_si[b+1u], 6) << ":" << fixed_trimmed((double)p.uvw_si[b+2u],
+				6);
+		}
 		f << "\n";
 	}
 	return true;

@@ -23,7 +23,12 @@ class ProgressChannel { // (1)
 	static std::string json_text(const std::string& s) {
 		std::string o; o.reserve(s.size()+8u);
 		for(const char ch : s) {
-			if(ch=='\\') o += "\\\\"; else if(ch=='"') o += "\\\""; else if(ch=='\n') o += "\\n"; else if(ch=='\r') o += "\\r"; else if(ch=='\t') o += "\\t"; else o.push_back(ch);
+			if(ch=='\\') o += "\\\\";
+			else if(ch=='"') o += "\\\"";
+			else if(ch=='\n') o += "\\n";
+			else if(ch=='\r') o += "\\r";
+			else if(ch=='\t') o += "\\t";
+			else o.push_back(ch);
 		}
 		return o;
 	}
@@ -34,9 +39,11 @@ public:
 		on = m=="gui"||m=="1"||m=="true";
 	}
 	bool gui() const { return on; }
-	void emit(const std::string& stage, const std::string& label, const std::string& detail = "", const long long current = -1ll, const long long total = -1ll, const bool indeterminate = true) const {
+	void emit(const std::string& stage, const std::string& label, const std::string& detail = "", const long long current = -1ll, const long long total = -1ll,
+		const bool indeterminate = true) const {
 		if(!on) return;
-		sink("[[LUW_PROGRESS]]{\"stage\":\""+json_text(stage)+"\",\"label\":\""+json_text(label)+"\",\"detail\":\""+json_text(detail)+"\",\"current\":"+std::to_string(current)+",\"total\":"+std::to_string(total)+",\"indeterminate\":"+(indeterminate ? "true" : "false")+"}");
+		sink("[[LUW_PROGRESS]]{\"stage\":\""+json_text(stage)+"\",\"label\":\""+json_text(label)+"\",\"detail\":\""+json_text(detail)+"\",\"current\":"
+			+std::to_string(current)+",\"total\":"+std::to_string(total)+",\"indeterminate\":"+(indeterminate ? "true" : "false")+"}");
 	}
 };
 
@@ -44,7 +51,8 @@ inline std::string clock_text(const double seconds) { // "1d 02h 03m 04s"-style 
 	const uint64_t s = (uint64_t)(seconds<0.0 ? 0.0 : seconds+0.5);
 	const uint64_t d = s/86400ull, h = (s%86400ull)/3600ull, m = (s%3600ull)/60ull, r = s%60ull;
 	char b[64];
-	if(d) std::snprintf(b, sizeof(b), "%llud %02lluh %02llum %02llus", (unsigned long long)d, (unsigned long long)h, (unsigned long long)m, (unsigned long long)r);
+	if(d) std::snprintf(b, sizeof(b), "%llud %02lluh %02llum %02llus", (unsigned long long)d, (unsigned long long)h, (unsigned long long)m,
+		(unsigned long long)r);
 	else if(h) std::snprintf(b, sizeof(b), "%lluh %02llum %02llus", (unsigned long long)h, (unsigned long long)m, (unsigned long long)r);
 	else if(m) std::snprintf(b, sizeof(b), "%llum %02llus", (unsigned long long)m, (unsigned long long)r);
 	else std::snprintf(b, sizeof(b), "%llus", (unsigned long long)r);
@@ -57,12 +65,21 @@ inline std::string clock_text(const double seconds) { // "1d 02h 03m 04s"-style 
 class StepRateMeter {
 	struct Estimate {
 		double seconds = 0.0; uint64_t samples = 0ull;
-		void add(const double v) { if(!(v>0.0)) return; seconds = samples==0ull ? v : seconds+(samples<8ull ? 1.0/(double)(samples+1ull) : 0.2)*(v-seconds); samples++; }
+		void add(const double v) {
+			if(!(v>0.0)) return;
+			seconds = samples==0ull ? v : seconds+(samples<8ull ? 1.0/(double)(samples+1ull) : 0.2)*(v-seconds);
+			samples++;
+		}
 	};
 	Estimate normal, window;
 	uint64_t total = 0ull, window_start = ~0ull; // window_start: first step (counted from 1) inside the statistics window
 public:
-	void configure(const uint64_t total_steps, const uint64_t window_first_step) { total = total_steps; window_start = window_first_step; normal = Estimate{}; window = Estimate{}; }
+	void configure(const uint64_t total_steps, const uint64_t window_first_step) {
+		total = total_steps;
+		window_start = window_first_step;
+		normal = Estimate{};
+		window = Estimate{};
+	}
 	void add_batch(const uint64_t t_after, const uint64_t steps, const double seconds) {
 		if(steps==0ull) return;
 		const bool in_window = window_start!=~0ull&&t_after>=window_start;
@@ -86,17 +103,25 @@ public:
 
 // (2) the table under "LBM SOLVER INFORMATION": column widths of FX/info.cpp:5-9
 class ProgressTable {
-	static std::string centre(const unsigned n, const std::string& x) { if(x.size()>=n) return x.substr(0u, n); const unsigned l = (n-(unsigned)x.size())/2u; return std::string(l, ' ')+x+std::string(n-(unsigned)x.size()-l, ' '); }
+	static std::string centre(const unsigned n, const std::string& x) {
+		if(x.size()>=n) return x.substr(0u, n);
+		const unsigned l = (n-(unsigned)x.size())/2u;
+		return std::string(l, ' ')+x+std::string(n-(unsigned)x.size()-l, ' ');
+	}
 	static constexpr unsigned W[5] = { 9u, 13u, 11u, 19u, 36u };
 public:
 	static std::string top() { return "|---------.-------'-----.-----------.-------------------.------------------------------------|"; }
 	static std::string bottom() { return "|---------'-------------'-----------'-------------------'------------------------------------|"; }
-	static std::string header() { return "|"+centre(W[0], "MLUPs")+"|"+centre(W[1], "Bandwidth")+"|"+centre(W[2], "Steps/s")+"|"+centre(W[3], "Current Step")+"|"+centre(W[4], "Time Remaining")+"|"; }
+	static std::string header() {
+		return "|"+centre(W[0], "MLUPs")+"|"+centre(W[1], "Bandwidth")+"|"+centre(W[2], "Steps/s")+"|"+centre(W[3], "Current Step")+"|"
+			+centre(W[4], "Time Remaining")+"|";
+	}
 	static std::string row(const uint64_t cells, const double bytes_per_cell, const StepRateMeter& m, const uint64_t t, const uint64_t total) {
 		const double dt = m.step_seconds(t>0ull ? t-1ull : 0ull);
 		const unsigned pct = total ? (unsigned)((double)(t>total ? total : t)*100.0/(double)total) : 100u;
 		char cur[48]; std::snprintf(cur, sizeof(cur), "%llu %3u%%", (unsigned long long)t, pct);
-		return "|"+centre(W[0], std::to_string((uint64_t)((double)cells*1.0e-6/dt)))+"|"+centre(W[1], std::to_string((uint64_t)((double)cells*bytes_per_cell*1.0e-9/dt))+" GB/s")+"|"
+		return "|"+centre(W[0], std::to_string((uint64_t)((double)cells*1.0e-6/dt)))+"|"
+			+centre(W[1], std::to_string((uint64_t)((double)cells*bytes_per_cell*1.0e-9/dt))+" GB/s")+"|"
 			+centre(W[2], std::to_string((uint64_t)(1.0/dt)))+"|"+centre(W[3], cur)+"|"+centre(W[4], clock_text(m.remaining_seconds(t)))+"|";
 	}
 };

@@ -38,12 +38,16 @@ struct Config {
 	bool enable_buffer_nudging = true; float buffer_thickness_m = 160.0f, buffer_tau_s = 300.0f; int buffer_nudge_vertical = 0;
 	bool enable_top_sponge = true; float sponge_thickness_m = 200.0f, sponge_tau_s = 120.0f; int sponge_ref_mode = 0;
 	bool vk_enable = true; int vk_nmodes = 256; float vk_ti = 0.05f, vk_sigma_si = 0.0f, vk_L_si = 100.0f; uint64_t vk_seed = 100ull; int vk_stride = 1;
-	VkUcMode vk_uc = VkUcMode::NORM_MEAN; bool vk_same = true, vk_interp = false, vk_inflow_only = false; VkFaceMode vk_face_mode = VkFaceMode::AUTO_SIDES; float vk_aniso[3] = {1.0f, 1.0f, 1.0f};
+	VkUcMode vk_uc = VkUcMode::NORM_MEAN;
+	bool vk_same = true, vk_interp = false, vk_inflow_only = false;
+	VkFaceMode vk_face_mode = VkFaceMode::AUTO_SIDES;
+	float vk_aniso[3] = {1.0f, 1.0f, 1.0f};
 	std::vector<float> inflow_list, angle_list;
 	// command line
 	string probes_raw, utm_crs; bool probes_output_defined = false; uint probes_output_steps = 0u; bool has_rotate_deg = false; double rotate_deg = 0.0;
 	bool buoyancy = true, buoyancy_explicit = false; // default-on unless explicitly false (FX/setup.cpp:2743)
-	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false; // *.luw
+	// *.luw
+	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false;
 	bool fp16c = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
 	std::vector<int> devices; uint32_t kernel = LUW_KERNEL_AUTO;
 };

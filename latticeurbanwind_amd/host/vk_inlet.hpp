@@ -113,7 +113,8 @@ inline uint64_t vk_mix_seed(const uint64_t seed, const uint32_t face_id) { retur
 // initialize(): collect_face_points_ + build_face_modes_ + the table packing of build_gpu_runtime_ for a single domain.
 // flags/u are the host fields in the reference layout AFTER the boundary fill (u = base inflow on TYPE_E cells).
 // log receives the reference's console lines.  Returns false when the inlet stays inactive.
-template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_in, const uint32_t Nx, const uint32_t Ny, const uint32_t Nz, const uint8_t* flags, const float* u, VkTables& T, LogFn log) {
+template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_in, const uint32_t Nx, const uint32_t Ny, const uint32_t Nz,
+	const uint8_t* flags, const float* u, VkTables& T, LogFn log) {
 	VkRuntimeConfig cfg = cfg_in;
 	T = VkTables();
 	if(!cfg.enable) return false;
@@ -130,9 +131,15 @@ template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_
 		if(z==0u) return false;
 		if((flags[n]&0x01u)!=0u) return false;
 		if((flags[n]&0x02u)==0u) return false;
-		if(cfg.face_mode==VkFaceMode::TARGET_INFLOW) { if(target_face>=0&&fid!=target_face) return false; if(target_face<0&&fid==TOP&&cfg.inflow_only) return false; }
+		if(cfg.face_mode==VkFaceMode::TARGET_INFLOW) {
+			if(target_face>=0&&fid!=target_face) return false;
+			if(target_face<0&&fid==TOP&&cfg.inflow_only) return false;
+		}
 		else if(cfg.face_mode==VkFaceMode::EXCLUDE_DOWNSTREAM) { if(cfg.downstream_face_id>=0&&fid==cfg.downstream_face_id) return false; }
-		else if(cfg.face_mode==VkFaceMode::EXCLUDE_DOWNSTREAM_SIDES) { if(fid==TOP) return false; if(cfg.downstream_face_id>=0&&fid==cfg.downstream_face_id) return false; }
+		else if(cfg.face_mode==VkFaceMode::EXCLUDE_DOWNSTREAM_SIDES) {
+			if(fid==TOP) return false;
+			if(cfg.downstream_face_id>=0&&fid==cfg.downstream_face_id) return false;
+		}
 		else if(cfg.face_mode==VkFaceMode::ALL_SIDES) { if(fid==TOP) return false; }
 		else if(fid==TOP&&cfg.inflow_only) return false;
 		return true;
@@ -154,7 +161,8 @@ template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_
 		for(const P& p : pts[(size_t)f]) { mu[0] += p.bu[0]; mu[1] += p.bu[1]; mu[2] += p.bu[2]; }
 		const float cnt = (float)pts[(size_t)f].size();
 		mu[0] /= cnt; mu[1] /= cnt; mu[2] /= cnt;
-		uc[(size_t)f] = cfg.uc_mode==VkUcMode::NORM_MEAN ? sqrtf(mu[0]*mu[0]+mu[1]*mu[1]+mu[2]*mu[2]) : fabsf(mu[0]*face_n[f][0]+mu[1]*face_n[f][1]+mu[2]*face_n[f][2]);
+		uc[(size_t)f] = cfg.uc_mode==VkUcMode::NORM_MEAN ? sqrtf(mu[0]*mu[0]+mu[1]*mu[1]+mu[2]*mu[2])
+			: fabsf(mu[0]*face_n[f][0]+mu[1]*face_n[f][1]+mu[2]*face_n[f][2]);
 		if(!(uc[(size_t)f]>1.0e-7f)) { log(std::string("| VK inlet face   | ")+names[f]+": disabled (Uc is too small)               |"); continue; }
 		enabled[(size_t)f] = true;
 	}
@@ -162,7 +170,13 @@ template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_
 	for(int f=0; f<5; f++) { // FX/setup.cpp:461-477
 		if(!enabled[(size_t)f]||pts[(size_t)f].empty()) continue;
 		face_enabled++;
-		for(const P& p : pts[(size_t)f]) { mean_all[0] += p.bu[0]; mean_all[1] += p.bu[1]; mean_all[2] += p.bu[2]; sum_mag += (double)sqrtf(p.bu[0]*p.bu[0]+p.bu[1]*p.bu[1]+p.bu[2]*p.bu[2]); count_u++; }
+		for(const P& p : pts[(size_t)f]) {
+			mean_all[0] += p.bu[0];
+			mean_all[1] += p.bu[1];
+			mean_all[2] += p.bu[2];
+			sum_mag += (double)sqrtf(p.bu[0]*p.bu[0]+p.bu[1]*p.bu[1]+p.bu[2]*p.bu[2]);
+			count_u++;
+		}
 		log(std::string("| VK inlet face   | ")+names[f]+": points="+std::to_string(pts[(size_t)f].size())+", Uc="+std::to_string(uc[(size_t)f])+" |");
 	}
 	if(face_enabled==0u) { log("| VK inlet        | enabled in config, but no valid inflow faces found         |"); return false; }
@@ -174,10 +188,16 @@ template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_
 	std::array<std::vector<VkMode>, 5> face_modes; // build_face_modes_, FX/setup.cpp:852-884
 	if(cfg.same_realization_all_faces) {
 		std::vector<VkMode> shared;
-		if(!vk_build_modes_for_seed(cfg, u_ref, conv, cfg.seed, shared)) { log("| VK inlet        | failed to build VK spectrum modes                           |"); return false; }
+		if(!vk_build_modes_for_seed(cfg, u_ref, conv, cfg.seed, shared)) {
+			log("| VK inlet        | failed to build VK spectrum modes                           |");
+			return false;
+		}
 		for(int f=0; f<5; f++) if(enabled[(size_t)f]&&!pts[(size_t)f].empty()) face_modes[(size_t)f] = shared;
 	} else {
-		for(int f=0; f<5; f++) { if(!enabled[(size_t)f]||pts[(size_t)f].empty()) continue; if(!vk_build_modes_for_seed(cfg, u_ref, conv, vk_mix_seed(cfg.seed, (uint32_t)f), face_modes[(size_t)f])) return false; }
+		for(int f=0; f<5; f++) {
+			if(!enabled[(size_t)f]||pts[(size_t)f].empty()) continue;
+			if(!vk_build_modes_for_seed(cfg, u_ref, conv, vk_mix_seed(cfg.seed, (uint32_t)f), face_modes[(size_t)f])) return false;
+		}
 	}
 	const uint64_t M = (uint64_t)cfg.nmodes, V = 5ull*M; // build_gpu_runtime_, FX/setup.cpp:886-1057
 	T.mode_count = M;
@@ -192,7 +212,8 @@ template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_
 	for(int f=0; f<5; f++) {
 		if(!enabled[(size_t)f]||pts[(size_t)f].empty()) continue;
 		for(const P& p : pts[(size_t)f]) {
-			const float u_char = cfg.uc_mode==VkUcMode::NORM_MEAN ? sqrtf(p.bu[0]*p.bu[0]+p.bu[1]*p.bu[1]+p.bu[2]*p.bu[2]) : fabsf(p.bu[0]*face_n[f][0]+p.bu[1]*face_n[f][1]+p.bu[2]*face_n[f][2]);
+			const float u_char = cfg.uc_mode==VkUcMode::NORM_MEAN ? sqrtf(p.bu[0]*p.bu[0]+p.bu[1]*p.bu[1]+p.bu[2]*p.bu[2])
+				: fabsf(p.bu[0]*face_n[f][0]+p.bu[1]*face_n[f][1]+p.bu[2]*face_n[f][2]);
 			const float sigma_local = cfg.ti>0.0f ? cfg.ti*u_char : cfg.sigma_lbm;
 			if(!(sigma_local>0.0f)) continue;
 			dps.push_back(DP{p.n, (uint8_t)f, (float)p.x, (float)p.y, (float)p.z, {p.bu[0], p.bu[1], p.bu[2]}, sigma_local});
@@ -211,15 +232,23 @@ template<typename LogFn> inline bool vk_build_tables(const VkRuntimeConfig& cfg_
 		const float vals[7] = {d.px, d.py, d.pz, d.bu[0], d.bu[1], d.bu[2], d.sigma};
 		for(int q=0; q<7; q++) T.point_data[(size_t)((uint64_t)q*Pn+i)] = vals[q];
 	}
-	log("| VK inlet        | active: points="+std::to_string(Pn)+", per-face modes="+std::to_string(M)+", L_lbm="+std::to_string(cfg.L_lbm)+", TI="+std::to_string(cfg.ti)+", stride="+std::to_string(cfg.update_stride)+" |");
+	log("| VK inlet        | active: points="+std::to_string(Pn)+", per-face modes="+std::to_string(M)+", L_lbm="+std::to_string(cfg.L_lbm)+", TI="
+		+std::to_string(cfg.ti)+", stride="+std::to_string(cfg.update_stride)+" |");
 	return true;
 }
 
 // compute_time_params_, FX/setup.cpp:1118-1140
-inline void vk_time_params(const uint64_t t, const int update_stride, const bool stride_interpolation, uint32_t& use_interp, float& t0, float& t1, float& alpha) {
+inline void vk_time_params(const uint64_t t, const int update_stride, const bool stride_interpolation, uint32_t& use_interp, float& t0, float& t1,
+	float& alpha) {
 	const uint64_t stride = update_stride>1 ? (uint64_t)update_stride : 1ull;
 	if(stride<=1ull) { use_interp = 0u; t0 = (float)t; t1 = t0; alpha = 0.0f; return; }
-	if(stride_interpolation) { const uint64_t anchor = (t/stride)*stride; use_interp = 1u; t0 = (float)anchor; t1 = (float)(anchor+stride); alpha = (float)(t-anchor)/(float)stride; }
+	if(stride_interpolation) {
+		const uint64_t anchor = (t/stride)*stride;
+		use_interp = 1u;
+		t0 = (float)anchor;
+		t1 = (float)(anchor+stride);
+		alpha = (float)(t-anchor)/(float)stride;
+	}
 	else { const uint64_t hold_t = (t/stride)*stride; use_interp = 0u; t0 = (float)hold_t; t1 = t0; alpha = 0.0f; }
 }
 

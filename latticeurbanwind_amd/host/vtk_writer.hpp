@@ -19,7 +19,8 @@ static string vtk_header(const string& filename, const VtkGeom& g) {
 		"POINT_DATA "+to_string_u(points)+"\n";
 }
 // Memory_Container::write_vtk (FX/lbm.hpp:307-356): SoA host field -> AoS big-endian floats in SI units
-static void write_field_vtk(const string& filename, const VtkGeom& g, const float* data, const uint comps, const float factor, const float offset = 0.0f, const bool affine = false) {
+static void write_field_vtk(const string& filename, const VtkGeom& g, const float* data, const uint comps, const float factor, const float offset = 0.0f,
+	const bool affine = false) {
 	std::filesystem::create_directories(std::filesystem::path(filename).parent_path());
 	std::ofstream file(filename, std::ios::out|std::ios::binary);
 	const string header = vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n";
@@ -27,7 +28,9 @@ static void write_field_vtk(const string& filename, const VtkGeom& g, const floa
 	const ulong N = (ulong)g.Nx*g.Ny*g.Nz, points = (ulong)g.Nx*g.Ny*g.Nz_out;
 	std::unique_ptr<float[]> conv(new float[points*comps]); float* const buf = conv.get(); // every element is written below: no value-initialisation
 	// the field named T goes through units.si_T (value*unit_K + offset), every other one through its unit factor (FX/lbm.hpp:343)
-	parallel_for(points, [&](const ulong i) { for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(affine ? data[(ulong)d*N+i]*factor+offset : factor*data[(ulong)d*N+i]); });
+	parallel_for(points, [&](const ulong i) {
+		for(uint d=0u; d<comps; d++) buf[i*comps+d] = reverse_bytes(affine ? data[(ulong)d*N+i]*factor+offset : factor*data[(ulong)d*N+i]);
+	});
 	file.write((const char*)buf, (std::streamsize)(points*comps*4ull));
 }
 
@@ -42,7 +45,15 @@ struct VtkFile { // an open output file and the offset of its next byte
 		if(fd<0) fatal("ERROR: cannot open "+filename+" for writing.");
 	}
 	~VtkFile() { if(fd>=0) ::close(fd); }
-	void text(const string& t) { size_t put = 0u; while(put<t.size()) { const ssize_t w = ::pwrite(fd, t.data()+put, t.size()-put, (off_t)(pos+put)); if(w<=0) fatal("ERROR: writing a VTK header failed."); put += (size_t)w; } pos += t.size(); }
+	void text(const string& t) {
+		size_t put = 0u;
+		while(put<t.size()) {
+			const ssize_t w = ::pwrite(fd, t.data()+put, t.size()-put, (off_t)(pos+put));
+			if(w<=0) fatal("ERROR: writing a VTK header failed.");
+			put += (size_t)w;
+		}
+		pos += t.size();
+	}
 	void payload(LBM& lbm, const int source, const luw_export_params& prm, const VtkGeom& g, const uint comps) {
 		lbm.export_vtk(source, prm, g.Nz_out, fd, pos);
 		pos += (uint64_t)g.Nx*g.Ny*g.Nz_out*comps*4ull;
@@ -51,7 +62,8 @@ struct VtkFile { // an open output file and the offset of its next byte
 static luw_export_params export_params(const float factor, const float offset = 0.0f, const bool affine = false) {
 	luw_export_params p{}; p.struct_size = sizeof(p); p.factor = factor; p.offset = offset; p.affine = affine ? 1 : 0; return p;
 }
-static void write_device_field_vtk(LBM& lbm, const string& filename, const VtkGeom& g, const int source, const uint comps, const float factor, const float offset = 0.0f, const bool affine = false) {
+static void write_device_field_vtk(LBM& lbm, const string& filename, const VtkGeom& g, const int source, const uint comps, const float factor,
+	const float offset = 0.0f, const bool affine = false) {
 	VtkFile f(filename);
 	f.text(vtk_header(filename, g)+"SCALARS data float "+to_string_u(comps)+"\nLOOKUP_TABLE default\n");
 	f.payload(lbm, source, export_params(factor, offset, affine), g, comps);

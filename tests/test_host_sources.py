@@ -1,0 +1,46 @@
+"""The deck driver's sources stay reviewable: no file of latticeurbanwind_amd/host/ over 400 lines, no line over 160 characters
+(tools/reflow_cpp.py is the white-space-only formatter that brings a new long line back under the limit), and main() stays the short
+list of the sections of the reference's main_setup that driver_state.hpp names."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "latticeurbanwind_amd", "host")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(HOST, "*.cpp")))
+
+
+def test_line_and_file_limits():
+    assert len(sources()) >= 19
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reflow_cpp.py"), "--check", "--limit", "160"] + sources(), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    long_files = {os.path.basename(p): sum(1 for _ in open(p)) for p in sources()}
+    assert {k: v for k, v in long_files.items() if v > 400} == {}
+
+
+def test_main_is_the_list_of_sections():
+    text = open(os.path.join(HOST, "luw_driver.cpp")).read()
+    body = text[text.index("int main("):]
+    assert body.count("\n") < 40
+    state = open(os.path.join(HOST, "driver_state.hpp")).read()
+    declared = set(re.findall(r"^\tvoid (\w+)\(", state, flags=re.M))
+    defined = set()
+    for p in glob.glob(os.path.join(HOST, "driver_*.hpp")):
+        defined |= set(re.findall(r"^inline (?:void|float) Driver::(\w+)\(", open(p).read(), flags=re.M))
+    assert declared <= defined, declared - defined            # every section the state header announces exists
+
+
+def test_reflow_changes_white_space_only(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import reflow_cpp
+    line = '\t\tif(a>b) { const float x = f(a, "one; two // not a comment", b)+g(a)*h(b); total += x; for(int i=0; i<3; i++) v[i] = x; } // why this is here'
+    out = reflow_cpp.reflow(line, 60)
+    assert all(reflow_cpp.width(l) <= 60 for l in out), out
+    squeeze = lambda s: re.sub(r"\s+", "", s)
+    assert squeeze("".join(l for l in out if not l.strip().startswith("//"))) == squeeze(line.split(" // why")[0])
+    assert any("why this is here" in l for l in out)
