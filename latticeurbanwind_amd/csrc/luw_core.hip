@@ -467,7 +467,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // tools build, measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only&&!st&&!k.thermal) k = PairKey{ 1, false, PAIR_FORCE_ANY, false, false };
 #endif
-	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal) : 0u;
+	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal, (k.mode==0&&!k.stats) ? k.force : PAIR_FORCE_NONE) : 0u;
 	for(const PairRow& r : pair_table) {
 		const PairKey& q = r.key;
 		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal) { r.launch(s, b, g, write_fields, st ? *st : StatsArgs{}); return LUW_OK; }

@@ -269,8 +269,47 @@ __device__ __forceinline__ void calculate_forcing_terms(const float ux, const fl
 // the cell, (x,y,z) its local coordinates.  u is the device velocity field (3 planes of stride Np).
 // ZONES = false: the caller knows that the cell lies outside the nudging / sponge zones and that there is no force field -- what is
 // left is the volume force and Coriolis (the uniform part)
+// The nudging / sponge references of one cell, fetched AHEAD of its collision (pair kernel, general instantiation): what assemble_force would read
+// through n_ref once the moments are known -- the target velocity of the nearest owned face with its weight, the top layer's velocity with the
+// sponge's sigma.  They depend on the position alone, so the loads go out with the DDF loads and their latency (four dependent trips to memory per
+// lane pair otherwise, ~3400 of a wave's 21000 cycles on the urban tile: profiles/r03_stall_counters.md) is hidden behind decode and moments.
+// A TYPE_E cell takes neither term; its four registers carry what it reads instead, its own rho and u (FX/kernel.cpp:1516-1523), fetched just as early.
+struct ForceRefs { float tu[3], wb, su[3], sg; bool zn, zs; };
+__device__ __forceinline__ void fetch_force_refs(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool live, const bool is_E,
+		const float* __restrict__ rho, const float* __restrict__ u, ForceRefs& r) {
+	// (values of lanes outside the zones are never read: defined as "whatever the register holds", at no instruction)
+	asm volatile("" : "=v"(r.tu[0]), "=v"(r.tu[1]), "=v"(r.tu[2]), "=v"(r.wb), "=v"(r.su[0]), "=v"(r.su[1]), "=v"(r.su[2]), "=v"(r.sg));
+	r.zn = false; r.zs = false;
+	if(!live) return;                                              // a cell that is not collided
+	if(is_E) { r.wb = rho[n]; r.tu[0] = u[n]; r.tu[1] = u[(size_t)p.Np+n]; r.tu[2] = u[2ull*p.Np+n]; return; }
+	if(p.buffer_active) { // the selection of assemble_force, statement for statement
+		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y, d_t = (uint32_t)p.top_z-z;
+		const bool in_w = x-p.zw_lo<p.zw_n, in_e = x-p.ze_lo<p.ze_n, in_s = y-p.zs_lo<p.zs_n, in_n = y-p.zn_lo<p.zn_n, in_t = z-p.zt_lo<p.zt_n;
+		if(in_w||in_e||in_s||in_n||in_t) {
+			uint32_t d_min = p.buffer_N+1u;
+			uint32_t n_ref = n;
+			const uint32_t rowyz = (y+z*p.Ny)*p.Px;
+			if(in_w) { if(d_w<d_min) { d_min = d_w; n_ref = (uint32_t)p.west_x+rowyz; } }
+			if(in_e) { if(d_e<d_min) { d_min = d_e; n_ref = (uint32_t)p.east_x+rowyz; } }
+			if(in_s) { if(d_s<d_min) { d_min = d_s; n_ref = x+((uint32_t)p.south_y+z*p.Ny)*p.Px; } }
+			if(in_n) { if(d_n<d_min) { d_min = d_n; n_ref = x+((uint32_t)p.north_y+z*p.Ny)*p.Px; } }
+			if(in_t) { if(d_t<d_min) { d_min = d_t; n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px; } }
+			r.zn = true;
+			r.wb = p.wbuf[d_min];
+			r.tu[0] = u[n_ref]; r.tu[1] = u[(size_t)p.Np+n_ref]; r.tu[2] = u[2ull*p.Np+n_ref];
+		}
+	}
+	if(z-p.zp_lo<p.zp_n) {
+		r.zs = true;
+		r.sg = p.sigma[(uint32_t)p.top_z-1u-z];
+		const uint32_t n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px;
+		r.su[0] = u[n_ref]; r.su[1] = u[(size_t)p.Np+n_ref]; r.su[2] = u[2ull*p.Np+n_ref];
+	}
+}
+// refs (pair kernel, general instantiation only): the references above, already fetched -- same arithmetic on them
 template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E,
-		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn, float& fzn) {
+		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn, float& fzn,
+		const ForceRefs* refs = nullptr) {
 	fxn = p.fx; fyn = p.fy; fzn = p.fz;
 	if(p.coriolis) { // with omega = 0 the three terms are +-0: adding them changes no value
 		const float cor_x = -2.0f*rhon*(p.omy*uzn-p.omz*uyn);
@@ -281,6 +320,27 @@ template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const K
 		fzn += cor_z;
 	}
 	if constexpr(!ZONES) return;
+	if(refs) {
+		if(refs->zn) {
+			const float a_x = refs->wb*p.buffer_inv_tau*(refs->tu[0]-uxn);
+			const float a_y = refs->wb*p.buffer_inv_tau*(refs->tu[1]-uyn);
+			const float a_z = p.nudge_vertical==1u ? refs->wb*p.buffer_inv_tau*(refs->tu[2]-uzn) : 0.0f;
+			fxn += rhon*a_x;
+			fyn += rhon*a_y;
+			fzn += rhon*a_z;
+		}
+		if(refs->zs) {
+			fxn += rhon*refs->sg*(refs->su[0]-uxn);
+			fyn += rhon*refs->sg*(refs->su[1]-uyn);
+			fzn += rhon*refs->sg*(refs->su[2]-uzn);
+		}
+		if(p.has_F) {
+			fxn += F[n];
+			fyn += F[(size_t)p.Np+n];
+			fzn += F[2ull*p.Np+n];
+		}
+		return;
+	}
 	if(p.buffer_active && !is_E) {
 		// distance to each face (meaningful inside that face's zone, wrapped-around garbage outside, where it is not used)
 		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y, d_t = (uint32_t)p.top_z-z;
@@ -505,7 +565,8 @@ enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
 // values are the IEEE ones for EVERY input.  (A per-wave vote between two complete collisions was measured first: the duplicated code cost
 // more than the arithmetic saved, 1024x1024x256 + Coriolis 4.05 -> 4.25 ms; this form 4.05 -> 3.89, profiles/r03_plain_arith_ab.txt.)
 template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
-		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr,
+		const ForceRefs* refs = nullptr) {
 	constexpr bool PLAIN = LUW_PLAIN_ARITH!=0;
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
@@ -527,10 +588,13 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	} else { uxn = mx/rho_m; uyn = my/rho_m; uzn = mz/rho_m; }
 	if(wave_has_E) {
 		if(is_E) {
-			rhon = rho[n];
-			uxn = u[n];
-			uyn = u[(size_t)p.Np+n];
-			uzn = u[2ull*p.Np+n];
+			if(refs) { rhon = refs->wb; uxn = refs->tu[0]; uyn = refs->tu[1]; uzn = refs->tu[2]; } // fetched with the DDF loads (fetch_force_refs)
+			else {
+				rhon = rho[n];
+				uxn = u[n];
+				uyn = u[(size_t)p.Np+n];
+				uzn = u[2ull*p.Np+n];
+			}
 		}
 		if constexpr(PLAIN) { R = recip_prepare(rhon); odd_density = !density_is_ordinary(rhon); } // rhon: the field value on TYPE_E lanes, the moment sum elsewhere
 	}
@@ -539,7 +603,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	f32x2 Finp[9]; float Fin0 = 0.0f;
 	if(forced) {
 		float fxn, fyn, fzn;
-		assemble_force<(FORCE==PAIR_FORCE_ANY)>(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
+		assemble_force<(FORCE==PAIR_FORCE_ANY)>(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn, refs);
 		float rho2;
 		if constexpr(PLAIN) {
 			rho2 = div_by(0.5f, R);

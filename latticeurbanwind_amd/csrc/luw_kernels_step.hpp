@@ -260,14 +260,19 @@ constexpr int pair_waves(const int force, const bool park, const bool thermal = 
 	if(thermal) return force==PAIR_FORCE_NONE ? LUW_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_THERMAL_WAVES_UNIFORM : LUW_THERMAL_WAVES_ANY; // (a wave more each spills to scratch)
 	return park ? (force==PAIR_FORCE_NONE ? LUW_PARK_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_PARK_WAVES_UNIFORM : LUW_PARK_WAVES_ANY) : (force==PAIR_FORCE_ANY ? 4 : 5);
 }
-constexpr uint32_t pair_park_bytes_per_wave(const bool thermal) { return (thermal ? 26u : 19u)*64u*4u; }
+#ifndef LUW_PAIR_PREFETCH
+#define LUW_PAIR_PREFETCH 1 /* general parked instantiation: nudging / sponge references fetched with the DDF loads (fetch_force_refs) */
+#endif
+constexpr bool pair_prefetch(const int force, const bool park) { return LUW_PAIR_PREFETCH!=0 && park && force==PAIR_FORCE_ANY; }
+constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force = PAIR_FORCE_NONE) { return ((thermal ? 26u : 19u)+(pair_prefetch(force, true) ? 8u : 0u))*64u*4u; }
 // THERMAL (LUW_OPT_TEMPERATURE): the D3Q7 lattice of both cells the same way -- seven more dwords per lane (plane 0 and the three (A, B) pairs of
 // +x, +y, +z: the +x plane on a 2-byte boundary like the five x+1 planes of the D3Q19 lattice), the cell update of luw_device.hpp (thermal_cell)
 // behind each collision with the velocity before the force shift, the seven codes of both cells merged per plane at the tail.
 template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL), pair_waves(FORCE, PARK, THERMAL)))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}, uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
-	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS
+	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
+	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	const RowOff rb = row_offsets(p, y, z);
@@ -323,8 +328,17 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		rawg[5] = ld_pair<true>(gi+(size_t)slotA<PARITY>(5)*Np, o.x); rawg[6] = ld_pair<true>(gi+(size_t)slotB<PARITY>(5)*Np+nrow<5>(rb), nlane<5>(o));
 		if(wrap) { const uint32_t hi = *(gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb)); rawg[2] = (rawg[2]&0xFFFFu)|(hi<<16); }
 	}
+	// PRE: the nudging / sponge references of both cells go out behind the DDF loads; those of cell x+1 wait in LDS like its raw dwords
+	[[maybe_unused]] ForceRefs refs[2];
+	if constexpr(PRE) {
+		#pragma unroll
+		for(int c=0; c<2; c++) fetch_force_refs(p, n+c, x+c, y, z, proc[c], (fl[c]&TYPE_BO)==TYPE_E, rho, u, refs[c]);
+	}
 	// wave-uniform: can any cell of this wave feel a force (then the Guo terms are computed for the whole wave)?
-	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z))!=0ull);
+	// (PRE: the fetch above has already decided, cell by cell, whether a zone term acts)
+	bool zone_lane;
+	if constexpr(PRE) zone_lane = refs[0].zn||refs[0].zs||refs[1].zn||refs[1].zs; else zone_lane = in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z);
+	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(zone_lane)!=0ull);
 	// specialised modes: TYPE_E cells decode to f = 0 (collide_cell_pk relaxes them with w = 1)
 	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;
 	// (only cells that are collided: a halo or padding cell passes what it decodes through unchanged, whatever its flag)
@@ -353,7 +367,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
 			[[maybe_unused]] float u0[3];
-			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr);
+			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c] : nullptr);
 			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of being
@@ -381,10 +395,15 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 	[[maybe_unused]] uint32_t* slot = nullptr;                     // PARK: this lane's column in its wave's LDS region, slot[64*q]
 	if constexpr(PARK) {
 		extern __shared__ uint32_t pair_park[];
-		slot = pair_park+(threadIdx.x>>6)*((uint32_t)NSLOT*64u)+(threadIdx.x&63u);
+		slot = pair_park+(threadIdx.x>>6)*((uint32_t)(NSLOT+(PRE ? 8 : 0))*64u)+(threadIdx.x&63u);
 		#pragma unroll
 		for(int q=0; q<19; q++) slot[64*q] = raw[q];
 		if constexpr(THERMAL) { for(int q=0; q<7; q++) slot[64*(19+q)] = rawg[q]; }
+		if constexpr(PRE) {
+			float* const fs = reinterpret_cast<float*>(slot)+64*NSLOT;
+			fs[0] = refs[1].tu[0]; fs[64] = refs[1].tu[1]; fs[128] = refs[1].tu[2]; fs[192] = refs[1].wb;
+			fs[256] = refs[1].su[0]; fs[320] = refs[1].su[1]; fs[384] = refs[1].su[2]; fs[448] = refs[1].sg;
+		}
 		asm volatile("" ::: "memory");
 	}
 	one_cell(0, fa0, fa, ga);
@@ -400,6 +419,11 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 			raw[2*k+1] = t0; raw[2*k+2] = t1;
 		}
 		if constexpr(THERMAL) { for(int q=0; q<7; q++) { const uint32_t t = slot[64*(19+q)]; slot[64*(19+q)] = __float_as_uint(ga[q]); rawg[q] = t; } }
+		if constexpr(PRE) {
+			const float* const fs = reinterpret_cast<const float*>(slot)+64*NSLOT;
+			refs[1].tu[0] = fs[0]; refs[1].tu[1] = fs[64]; refs[1].tu[2] = fs[128]; refs[1].wb = fs[192];
+			refs[1].su[0] = fs[256]; refs[1].su[1] = fs[320]; refs[1].su[2] = fs[384]; refs[1].sg = fs[448];
+		}
 		asm volatile("" ::: "memory");
 		asm_fence_u(raw);
 	} else {
