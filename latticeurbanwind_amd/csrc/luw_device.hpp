@@ -279,31 +279,42 @@ __device__ __forceinline__ void fetch_force_refs(const KParams& p, const uint32_
 		const float* __restrict__ rho, const float* __restrict__ u, ForceRefs& r) {
 	// (values of lanes outside the zones are never read: defined as "whatever the register holds", at no instruction)
 	asm volatile("" : "=v"(r.tu[0]), "=v"(r.tu[1]), "=v"(r.tu[2]), "=v"(r.wb), "=v"(r.su[0]), "=v"(r.su[1]), "=v"(r.su[2]), "=v"(r.sg));
-	r.zn = false; r.zs = false;
-	if(!live) return;                                              // a cell that is not collided
-	if(is_E) { r.wb = rho[n]; r.tu[0] = u[n]; r.tu[1] = u[(size_t)p.Np+n]; r.tu[2] = u[2ull*p.Np+n]; return; }
-	if(p.buffer_active) { // the selection of assemble_force, statement for statement
+	const bool own = live && is_E;                                  // reads its own fields
+	const bool act = live && !is_E;                                 // the zone terms can act (a cell that is not collided: nothing)
+	bool zn = false;
+	uint32_t d_min = 0u, n_ref = n;
+	if(p.buffer_active) { // the selection of assemble_force
 		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y, d_t = (uint32_t)p.top_z-z;
 		const bool in_w = x-p.zw_lo<p.zw_n, in_e = x-p.ze_lo<p.ze_n, in_s = y-p.zs_lo<p.zs_n, in_n = y-p.zn_lo<p.zn_n, in_t = z-p.zt_lo<p.zt_n;
-		if(in_w||in_e||in_s||in_n||in_t) {
-			uint32_t d_min = p.buffer_N+1u;
-			uint32_t n_ref = n;
+		zn = act && (in_w||in_e||in_s||in_n||in_t);
+		if(zn) {
+			// assemble_force walks w, e, s, n, t and keeps the first nearest face.  The three that depend on (y, z) alone -- the same for every lane
+			// of a row, scalar work in the pair kernel -- are settled among themselves first (same order, same strict <); w and e, which come before
+			// them, then only lose to a strictly nearer one: the same winner.
+			uint32_t d_row = p.buffer_N+1u, base_row = 0u;
+			if(in_s) { if(d_s<d_row) { d_row = d_s; base_row = ((uint32_t)p.south_y+z*p.Ny)*p.Px; } }
+			if(in_n) { if(d_n<d_row) { d_row = d_n; base_row = ((uint32_t)p.north_y+z*p.Ny)*p.Px; } }
+			if(in_t) { if(d_t<d_row) { d_row = d_t; base_row = (y+(uint32_t)p.top_z*p.Ny)*p.Px; } }
+			d_min = p.buffer_N+1u;
 			const uint32_t rowyz = (y+z*p.Ny)*p.Px;
 			if(in_w) { if(d_w<d_min) { d_min = d_w; n_ref = (uint32_t)p.west_x+rowyz; } }
 			if(in_e) { if(d_e<d_min) { d_min = d_e; n_ref = (uint32_t)p.east_x+rowyz; } }
-			if(in_s) { if(d_s<d_min) { d_min = d_s; n_ref = x+((uint32_t)p.south_y+z*p.Ny)*p.Px; } }
-			if(in_n) { if(d_n<d_min) { d_min = d_n; n_ref = x+((uint32_t)p.north_y+z*p.Ny)*p.Px; } }
-			if(in_t) { if(d_t<d_min) { d_min = d_t; n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px; } }
-			r.zn = true;
-			r.wb = p.wbuf[d_min];
-			r.tu[0] = u[n_ref]; r.tu[1] = u[(size_t)p.Np+n_ref]; r.tu[2] = u[2ull*p.Np+n_ref];
+			if(d_row<d_min) { d_min = d_row; n_ref = x+base_row; }
 		}
 	}
-	if(z-p.zp_lo<p.zp_n) {
-		r.zs = true;
+	r.zn = zn;
+	// ONE run of four loads for both kinds of lane (two runs in two branches made the second wait for every load in flight before it could reuse
+	// the first one's address registers): weight and target velocity of a zone lane, own density and velocity of a TYPE_E lane (n_ref = n there)
+	if(zn||own) {
+		const float* const first = own ? rho+n : p.wbuf+d_min;
+		r.wb = *first;
+		r.tu[0] = u[n_ref]; r.tu[1] = u[(size_t)p.Np+n_ref]; r.tu[2] = u[2ull*p.Np+n_ref];
+	}
+	r.zs = act && z-p.zp_lo<p.zp_n;
+	if(r.zs) {
 		r.sg = p.sigma[(uint32_t)p.top_z-1u-z];
-		const uint32_t n_ref = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px;
-		r.su[0] = u[n_ref]; r.su[1] = u[(size_t)p.Np+n_ref]; r.su[2] = u[2ull*p.Np+n_ref];
+		const uint32_t n_top = x+(y+(uint32_t)p.top_z*p.Ny)*p.Px;
+		r.su[0] = u[n_top]; r.su[1] = u[(size_t)p.Np+n_top]; r.su[2] = u[2ull*p.Np+n_top];
 	}
 }
 // refs (pair kernel, general instantiation only): the references above, already fetched -- same arithmetic on them

@@ -328,7 +328,8 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		rawg[5] = ld_pair<true>(gi+(size_t)slotA<PARITY>(5)*Np, o.x); rawg[6] = ld_pair<true>(gi+(size_t)slotB<PARITY>(5)*Np+nrow<5>(rb), nlane<5>(o));
 		if(wrap) { const uint32_t hi = *(gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb)); rawg[2] = (rawg[2]&0xFFFFu)|(hi<<16); }
 	}
-	// PRE: the nudging / sponge references of both cells go out behind the DDF loads; those of cell x+1 wait in LDS like its raw dwords
+	// PRE: the nudging / sponge references of both cells go out behind the DDF loads; those of cell x+1 wait in LDS like its raw dwords.  (In front of
+	// the row-end lane's fix-up, which waits for the DDF loads, they were no faster: profiles/r03_stall_counters.md.)
 	[[maybe_unused]] ForceRefs refs[2];
 	if constexpr(PRE) {
 		#pragma unroll
