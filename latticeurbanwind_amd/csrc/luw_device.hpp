@@ -577,7 +577,7 @@ enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
 // more than the arithmetic saved, 1024x1024x256 + Coriolis 4.05 -> 4.25 ms; this form 4.05 -> 3.89, profiles/r03_plain_arith_ab.txt.)
 template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
 		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr,
-		const ForceRefs* refs = nullptr) {
+		const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) { // refs: zone references fetched early (fetch_force_refs); own: a TYPE_E cell's rho / u fetched early (wb, tu)
 	constexpr bool PLAIN = LUW_PLAIN_ARITH!=0;
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
@@ -599,7 +599,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	} else { uxn = mx/rho_m; uyn = my/rho_m; uzn = mz/rho_m; }
 	if(wave_has_E) {
 		if(is_E) {
-			if(refs) { rhon = refs->wb; uxn = refs->tu[0]; uyn = refs->tu[1]; uzn = refs->tu[2]; } // fetched with the DDF loads (fetch_force_refs)
+			if(own) { rhon = own->wb; uxn = own->tu[0]; uyn = own->tu[1]; uzn = own->tu[2]; } // fetched ahead of the decode
 			else {
 				rhon = rho[n];
 				uxn = u[n];

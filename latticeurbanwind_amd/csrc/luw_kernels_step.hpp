@@ -263,6 +263,9 @@ constexpr int pair_waves(const int force, const bool park, const bool thermal = 
 #ifndef LUW_PAIR_PREFETCH
 #define LUW_PAIR_PREFETCH 1 /* general parked instantiation: nudging / sponge references fetched with the DDF loads (fetch_force_refs) */
 #endif
+#ifndef LUW_PAIR_OWN_EARLY
+#define LUW_PAIR_OWN_EARLY 1
+#endif
 constexpr bool pair_prefetch(const int force, const bool park) { return LUW_PAIR_PREFETCH!=0 && park && force==PAIR_FORCE_ANY; }
 constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force = PAIR_FORCE_NONE) { return ((thermal ? 26u : 19u)+(pair_prefetch(force, true) ? 8u : 0u))*64u*4u; }
 // THERMAL (LUW_OPT_TEMPERATURE): the D3Q7 lattice of both cells the same way -- seven more dwords per lane (plane 0 and the three (A, B) pairs of
@@ -273,6 +276,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
 	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
+	constexpr bool OWN = LUW_PAIR_OWN_EARLY!=0 && !PRE;
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	const RowOff rb = row_offsets(p, y, z);
@@ -353,6 +357,12 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 			else asm("v_lshlrev_b32_sdwa %0, 12, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(raw[q]));
 			if constexpr(E_BY_RATE) return t&dmask[c]; else return t&0x87FFF000u;
 		};
+		// OWN (the instantiations without the fetch above): a TYPE_E cell's own rho and u go out HERE, in front of its decode, instead of behind its moments
+		[[maybe_unused]] ForceRefs own;
+		if constexpr(OWN) {
+			asm volatile("" : "=v"(own.tu[0]), "=v"(own.tu[1]), "=v"(own.tu[2]), "=v"(own.wb));
+			if(MODE!=1&&proc[c]&&(fl[c]&TYPE_BO)==TYPE_E) { own.wb = rho[n+c]; own.tu[0] = u[n+c]; own.tu[1] = u[Np+n+c]; own.tu[2] = u[2ull*Np+n+c]; }
+		}
 		f0 = __uint_as_float(bits(0))*0x1p+112f;
 		#pragma unroll
 		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
@@ -368,7 +378,7 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
 			[[maybe_unused]] float u0[3];
-			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c] : nullptr);
+			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c] : nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
 			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of being
