@@ -48,3 +48,17 @@ def test_parity_tile_shapes():
                 for x_shell in (64, 128):                                          # FP32 / FP16C slabs
                     l2 = DomainLayout(gN, D, world - 1, x_shell=x_shell)
                     assert l2.interior_box()[1] - l2.interior_box()[0] >= 128      # an interior between the two x slabs, wide enough for the pair kernel
+
+
+def test_group_host_variant_past_its_time_limit_costs_only_its_own_block(monkeypatch):
+    """bench.py --gpus N measures the one-process host in child processes, one variant each, under a time limit: a child that does not answer
+    (here: a limit of one second, which the interpreter start alone exceeds) is killed by its PID and leaves an error in its block -- the line
+    of the RCCL measurement is still printed."""
+    import argparse
+    import bench
+    monkeypatch.setattr(bench, "GROUP_HOST_TIMEOUT_S", 1)
+    args = argparse.Namespace(dtype="f32", kernel="auto", steps=4, warmup=2, coriolis=False, no_buildings=False, no_parity=True)
+    out = bench.run_group_host(args, (2, 1, 1), (128, 64, 64), [0, 0])
+    assert set(bench.GROUP_HOST_VARIANTS) <= set(out)
+    for label in bench.GROUP_HOST_VARIANTS:
+        assert "no result within 1 s" in out[label]["error"] and out[label]["process_wall_s"] < 10

