@@ -542,7 +542,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
     shared = args.share_device is not None
     if shared: dist.init_process_group("gloo")
     else: init_rccl_process_group(local_rank)
-    # a CPU-side group for waiting: while rank 0 alone measures the one-process host on every device, the other ranks must not sit in an RCCL barrier (a
+    # a CPU-side group for waiting: while child processes of rank 0 measure the one-process host on every device, the ranks must not sit in an RCCL barrier (a
     # kernel spinning on their GPUs, where rank 0's domains are running)
     side = None if shared else dist.new_group(backend="gloo")
     os.environ.setdefault("LUW_MEASURE_WIRE", "10")                # TorchDistTransport.warm_up times the bare face exchange of every split axis
@@ -672,7 +672,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             group_host = {"error": str(e)[:300]}
     if not shared:
         torch.cuda.synchronize()
-    dist.barrier(group=side)                                        # on the CPU: ranks > 0 wait here while rank 0 drives all devices
+    dist.barrier(group=side)                                        # on the CPU: the ranks wait here while rank 0's child processes drive all devices
 
     if rank == 0:
         def block(r):
