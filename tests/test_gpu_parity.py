@@ -524,3 +524,13 @@ def test_1024_cubed_on_one_gpu_properties():
     assert r2.returncode == 0 and "exact fixed point = True" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-1500:]
     d1, d2 = re.search(r"digest (xor=\w+ sum=\w+)", r.stdout), re.search(r"digest (xor=\w+ sum=\w+)", r2.stdout)
     assert d1 and d2 and d1.group(1) == d2.group(1), (d1 and d1.group(1), d2 and d2.group(1))
+
+
+def test_random_force_zones_match_oracle(luw):
+    """tests/fuzz/fuzz_zones.py, a fixed draw: nudging / sponge zones of random thickness (thin, thicker than a wave's 128 cells, W / E zones that overlap on
+    narrow lattices), random downstream face, odd and even rows, Coriolis / volume force at random -- the general pair kernel with its early reference
+    fetch and both one-cell kernels against the oracle, every value."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_zones", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_zones.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.run(30, 11, say=lambda t: None) == 30
