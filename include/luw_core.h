@@ -312,7 +312,7 @@ int luw_group_stats_reset(luw_group* g);
  * x0,x1,y0,y1,z0,z1; shell_boxes = up to six such boxes. */
 typedef struct luw_domain_step luw_domain_step;
 int luw_step_boxes(const uint32_t* local_N, const uint32_t* halo, uint32_t x_shell, uint32_t* whole6, uint32_t* interior6, uint32_t* shell_boxes, uint32_t* shell_count, int* can_overlap);
-int luw_domain_step_create(luw_solver* s, void* compute_stream, void* comm_stream, uint32_t x_shell /* 0: 64 cells, FP16C 128 */, int overlap, luw_domain_step** out);
+int luw_domain_step_create(luw_solver* s, void* compute_stream, void* comm_stream, uint32_t x_shell /* 0: 128 cells */, int overlap, luw_domain_step** out);
 void luw_domain_step_destroy(luw_domain_step* d);
 int luw_domain_step_overlaps(const luw_domain_step* d);       /* 1: shell on the communication stream + interior on the compute stream, pipelined */
 int luw_domain_step_launch(luw_domain_step* d, int write_fields /* bit 0 | LUW_WF_SAMPLE */, int timed);   /* the kernels of one step (the von-Karman inlet update first); no exchange, no t++ */

@@ -51,11 +51,13 @@ struct luw_group {
 	bool failed = false;                      // a run stopped half-way: streams and sequence numbers are not trustworthy any more
 };
 
-// thickness of the x boundary slabs: one 256-byte memory line of cells (a one-cell x face would run one lane per wave) -- 64 FP32 cells, 128 FP16C
-// cells (a full wave of the pair kernel, which narrower slabs would leave to the one-cell kernel); LUW_X_SHELL overrides (A/B aid)
+// thickness of the x boundary slabs: 128 cells (a one-cell x face would run one lane per wave; 128 FP16C cells are a full wave of the pair kernel,
+// which narrower slabs would leave to the one-cell kernel; FP32: 16 / 32 / 64 / 128 / 256-cell slabs on the 514x514x512 rank of n_gpu = [4,2,1]
+// 4.13 / 3.91 / 3.85 / 3.77 / 3.84 ms per step, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL overrides (A/B aid)
 static uint32_t group_x_shell(const luw_group* g) {
 	static const uint32_t env = getenv("LUW_X_SHELL") ? (uint32_t)strtoul(getenv("LUW_X_SHELL"), nullptr, 10) : 0u;
-	return env ? env : (g->ddf_bytes==2u ? 128u : 64u);
+	(void)g;
+	return env ? env : 128u;
 }
 
 // ---- the schedule of ONE domain's share of a decomposed step, shared by both hosts: luw_group_* (all domains in this process) and the one-process-per-GPU
@@ -543,7 +545,7 @@ int luw_domain_step_create(luw_solver* s, void* compute_stream, void* comm_strea
 	std::unique_ptr<luw_domain_step, void(*)(luw_domain_step*)> d(new luw_domain_step(), luw_domain_step_destroy);
 	d->s = s; d->compute = (hipStream_t)compute_stream; d->comm = (hipStream_t)comm_stream;
 	const uint32_t lN[3] = { s->cfg.Nx, s->cfg.Ny, s->cfg.Nz }, H[3] = { s->kp.halo_x, s->kp.halo_y, s->kp.halo_z };
-	const uint32_t X = x_shell ? x_shell : (s->ddf_bytes==2u ? 128u : 64u);
+	const uint32_t X = x_shell ? x_shell : 128u;
 	step_boxes(lN, H, X, d->whole, d->interior, d->shell);
 	d->overlap = overlap!=0 && comm_stream!=nullptr && step_can_overlap(lN, H);
 	for(hipEvent_t* e : { &d->shell_done, &d->interior_done, &d->pre_done, &d->stats_done }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));

@@ -57,7 +57,7 @@ def tile_lattice(world):
 class DomainLayout:
     """Pure host logic: where a rank sits, what it owns, whom it talks to (FX/lbm.cpp:1066-1073,1912-1931)."""
 
-    X_SHELL = 64   # thickness of the x boundary slabs: one memory line of FP32 cells (see shell_boxes); FP16C lattices take 128 (x_shell)
+    X_SHELL = 128  # thickness of the x boundary slabs (see shell_boxes; csrc/luw_group.hpp group_x_shell)
 
     def __init__(self, global_N, D, rank, x_shell=None):
         if x_shell: self.X_SHELL = int(x_shell)
@@ -351,9 +351,9 @@ class DomainDecomposedLBM:
             import torch.distributed as dist
             rank = dist.get_rank()
         import os
-        # x slabs of the boundary shell: 64 cells = one 256-byte line of FP32 values; FP16C lattices take 128 cells -- the same bytes, and a full
-        # wave of the pair kernel (2 cells per lane), which narrower slabs would leave to the one-cell kernel (LUW_X_SHELL overrides: A/B aid)
-        x_shell = int(os.environ.get("LUW_X_SHELL", "0")) or (128 if backend_kw.get("fp16c") or getattr(getattr(backend, "o", None), "cfg", None) is not None and backend.o.cfg.fp16c else 64)
+        # x slabs of the boundary shell: 128 cells for both DDF formats (FP16C: a full wave of the pair kernel, 2 cells per lane, which narrower slabs
+        # would leave to the one-cell kernel; FP32: measured, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL overrides: A/B aid
+        x_shell = int(os.environ.get("LUW_X_SHELL", "0")) or DomainLayout.X_SHELL
         self.layout = DomainLayout(global_N, D, rank, x_shell=x_shell)
         self.wire = {}           # standalone face-exchange rates per split axis (TorchDistTransport.warm_up with LUW_MEASURE_WIRE=<repetitions>)
         self.lNx, self.lNy, self.lNz = self.layout.lN
