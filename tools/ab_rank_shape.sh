@@ -4,7 +4,7 @@
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 BLOCK="$1"; ROUNDS="$2"; shift 2
-LIB="$R/latticeurbanwind_amd/csrc/libluw_core.so"; cp "$LIB" /tmp/luw_product.so
+LIB="$R/latticeurbanwind_amd/csrc/libluw_core.so"; cp "$LIB" /tmp/luw_product.so; trap 'cp /tmp/luw_product.so "$LIB"' EXIT   # the product library is swapped in place per alternative and always put back
 for r in $(seq 1 "$ROUNDS"); do
   for alt in "$@"; do
     cp /tmp/luw_product.so "$LIB"; envs=()
