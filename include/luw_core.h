@@ -67,13 +67,16 @@ extern "C" {
 
 /* kernel selection.  The product library knows AUTO, SCALAR and PAIR (luw_create rejects the others); the remaining ids name A/B and
  * measurement-only variants that exist in the tools build only (make -C csrc ab, -DLUW_AB_KERNELS) */
-#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes at least 128 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
+/* FP32: SCALAR. FP16C: PAIR for boxes at least 128 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
+#define LUW_KERNEL_AUTO 0
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
 #define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
 #define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */
 #define LUW_KERNEL_SCALAR_CACHED 4      /* scalar kernel with the default cache policy instead of non-temporal DDF accesses (A/B) */
 #define LUW_KERNEL_SCALAR_NT_ALL 5      /* scalar kernel with non-temporal accesses on all 19 planes (A/B; the product uses nt on the 14 aligned planes) */
-#define LUW_KERNEL_PAIR 7               /* FP16C only: 2 cells / lane collided one after the other on packed FP32 pairs, one dword per lane and plane; falls back to SCALAR where it does not apply */
+/* FP16C only: 2 cells / lane collided one after the other on packed FP32 pairs, one dword per lane and plane; falls back to SCALAR where it does not
+ * apply */
+#define LUW_KERNEL_PAIR 7
 #define LUW_KERNEL_VEC1 6               /* 1 cell / lane with aligned accesses + wave64 lane shifts for the x+1 populations (A/B) */
 #define LUW_KERNEL_SCALAR_GENERAL 8     /* scalar kernel without the wave-uniform "no TYPE_E, no force in this wave" fast path (A/B) */
 #define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
@@ -206,7 +209,8 @@ int luw_gather_u(luw_solver* s, float* out);
 /* The same voxelisation on a bare lattice, without a solver object: flags is a host array u8[Nx*Ny*Nz] (reference layout,
  * in/out); bounds = pmin xyz, pmax xyz.  Used by the set-up export of decomposed runs, where the GLOBAL lattice is voxelised
  * once (the reference voxelises per domain with the triangles that overlap it, FX/lbm.cpp:1455-1587: same cells). */
-int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag, uint8_t* flags);
+int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1,
+	const float* p2, const float* bounds, uint8_t flag, uint8_t* flags);
 
 /* von-Karman synthetic-turbulence inlet: the device half of the reference's VonKarmanInletUpdater (FX/setup.cpp:413-1149,
  * kernel vk_inlet_apply FX/kernel.cpp:2495-2571).  The caller builds the tables like build_gpu_runtime_ does
@@ -268,7 +272,8 @@ typedef struct luw_group luw_group;
 int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out);       /* LBM::LBM */
 void luw_group_destroy(luw_group* g);                                                    /* LBM::~LBM */
 uint32_t luw_group_size(const luw_group* g);                                             /* LBM::get_D */
-luw_solver* luw_group_domain(luw_group* g, uint32_t d);                                  /* lbm.lbm_domain[d] (FX/setup.cpp:1085): host mirrors, device buffers, per-domain calls */
+/* lbm.lbm_domain[d] (FX/setup.cpp:1085): host mirrors, device buffers, per-domain calls */
+luw_solver* luw_group_domain(luw_group* g, uint32_t d);
 int luw_group_domain_info(const luw_group* g, uint32_t d, uint32_t* local_N, int32_t* offset, int* device); /* LBM_Domain::get_Nx.., Ox.. (FX/lbm.cpp:1072) */
 int luw_group_overlaps(const luw_group* g);                 /* 1: shell / interior overlap in use (every split axis has >= 4 owned layers) */
 int luw_group_direct_peer_stores(const luw_group* g);       /* 1: every face travels as peer stores of the pack kernel, none through a copy */
@@ -289,14 +294,17 @@ int luw_group_scatter(luw_group* g, int field, const void* global_src);
 int luw_group_gather(luw_group* g, int field, void* global_dst);
 int luw_group_upload(luw_group* g, uint32_t field_mask);
 int luw_group_download(luw_group* g, uint32_t field_mask);
-int luw_group_initialize(luw_group* g);                                                  /* LBM::initialize incl. the odd-t halo exchange, FX/lbm.cpp:1221-1260 */
+/* LBM::initialize incl. the odd-t halo exchange, FX/lbm.cpp:1221-1260 */
+int luw_group_initialize(luw_group* g);
 int luw_group_run(luw_group* g, uint64_t steps);                                         /* LBM::run(steps): returns after all devices finished */
-int luw_group_run_sampled(luw_group* g, uint64_t steps, uint64_t first_sample, uint64_t stride); /* luw_run_sampled for every domain, no host sync inside the window */
+/* luw_run_sampled for every domain, no host sync inside the window */
+int luw_group_run_sampled(luw_group* g, uint64_t steps, uint64_t first_sample, uint64_t stride);
 int luw_group_run_timed(luw_group* g, uint64_t steps, double* mean_kernel_ms);           /* mean duration of domain 0's interior (or whole-box) kernel */
 uint64_t luw_group_get_t(const luw_group* g);
 int luw_group_set_f(luw_group* g, float fx, float fy, float fz);
 int luw_group_set_coriolis(luw_group* g, float ox, float oy, float oz);
-int luw_group_voxelize_mesh(luw_group* g, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag); /* per domain, FX/lbm.cpp:1455-1587 */
+/* per domain, FX/lbm.cpp:1455-1587 */
+int luw_group_voxelize_mesh(luw_group* g, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag);
 /* global cell indices in, every domain gets the inlet points / probe cells it owns (VonKarmanInletUpdater::build_gpu_runtime_ does
  * the same per domain, FX/setup.cpp:1012-1057) */
 int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face,
@@ -306,18 +314,22 @@ int luw_group_gather_u(luw_group* g, float* out);
 int luw_group_stats_reset(luw_group* g);
 /* ---- One domain's share of a decomposed step: the schedule BOTH hosts run -- luw_group_* for all domains of this process, and a host that owns one domain
  * per process (latticeurbanwind_amd/distributed.py over RCCL), which does the exchange itself between luw_domain_step_launch calls.  Replaces, per domain,
- * the body of LBM::do_time_step (FX/lbm.cpp:1262-1290) up to communicate_fi: here the boundary shell runs first on the communication stream, the interior on the
- * compute stream, and consecutive steps are pipelined (interior(t) behind shell(t-1) only).
+ * the body of LBM::do_time_step (FX/lbm.cpp:1262-1290) up to communicate_fi: here the boundary shell runs first on the communication stream, the
+ * interior on the compute stream, and consecutive steps are pipelined (interior(t) behind shell(t-1) only).
  * luw_step_boxes: the boxes alone, pure host arithmetic (local extents incl. halo layers, halo flags per axis, thickness of the x slabs): whole6 / interior6 =
  * x0,x1,y0,y1,z0,z1; shell_boxes = up to six such boxes. */
 typedef struct luw_domain_step luw_domain_step;
-int luw_step_boxes(const uint32_t* local_N, const uint32_t* halo, uint32_t x_shell, uint32_t* whole6, uint32_t* interior6, uint32_t* shell_boxes, uint32_t* shell_count, int* can_overlap);
+int luw_step_boxes(const uint32_t* local_N, const uint32_t* halo, uint32_t x_shell, uint32_t* whole6, uint32_t* interior6, uint32_t* shell_boxes,
+	uint32_t* shell_count, int* can_overlap);
 int luw_domain_step_create(luw_solver* s, void* compute_stream, void* comm_stream, uint32_t x_shell /* 0: 128 cells */, int overlap, luw_domain_step** out);
 void luw_domain_step_destroy(luw_domain_step* d);
 int luw_domain_step_overlaps(const luw_domain_step* d);       /* 1: shell on the communication stream + interior on the compute stream, pipelined */
-int luw_domain_step_launch(luw_domain_step* d, int write_fields /* bit 0 | LUW_WF_SAMPLE */, int timed);   /* the kernels of one step (the von-Karman inlet update first); no exchange, no t++ */
-int luw_domain_step_separate_stats(luw_domain_step* d);       /* a sampled step without fused statistics: luw_stats_accumulate behind the step, ordered against the next shell */
-int luw_domain_step_timing(luw_domain_step* d, double* kernel_ms, double* shell_ms);   /* means over the timed launches since the last call; waits for both streams */
+/* the kernels of one step (the von-Karman inlet update first); no exchange, no t++ */
+int luw_domain_step_launch(luw_domain_step* d, int write_fields /* bit 0 | LUW_WF_SAMPLE */, int timed);
+/* a sampled step without fused statistics: luw_stats_accumulate behind the step, ordered against the next shell */
+int luw_domain_step_separate_stats(luw_domain_step* d);
+/* means over the timed launches since the last call; waits for both streams */
+int luw_domain_step_timing(luw_domain_step* d, double* kernel_ms, double* shell_ms);
 
 /* VTK payloads straight from the devices: Memory_Container::write_vtk (FX/lbm.hpp:307-356) and the sections of write_avg_vtk (FX/setup.cpp:2513-2683)
  * without the full-field download.  Every domain converts its own cells on its device -- SoA -> AoS, SI scaling, big-endian -- in z slabs that a

@@ -43,7 +43,10 @@ using namespace luw;
 // =====================================================================================================
 static thread_local std::string g_last_error;
 static int fail(const int code, const std::string& msg) { g_last_error = msg; return code; }
-#define HIP_TRY(expr) do { const hipError_t e_ = (expr); if(e_!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string(#expr)+": "+hipGetErrorString(e_)); } while(0)
+#define HIP_TRY(expr) do { \
+	const hipError_t e_ = (expr); \
+	if(e_!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string(#expr)+": "+hipGetErrorString(e_)); \
+} while(0)
 
 // ---- floats as 9-significant-digit text.  The reference bakes its kernel constants into OpenCL source as decimal text and writes
 // VTK headers the same way (to_string(float), FX/utilities.hpp:2603-2634,2741-2750; used at FX/lbm.cpp:664,774,780): what the
@@ -57,8 +60,14 @@ static Decimal9 split_decimal9(float x) {
 	Decimal9 d = { x<0.0f, false, 0u, 0u, 0 };
 	if(d.negative) x = -x;
 	if(std::isnan(x)||std::isinf(x)) { d.special = true; return d; }
-	static const struct { float at_least, times; int decades; } down[6] = { { 1E32f, 1E-32f, 32 }, { 1E16f, 1E-16f, 16 }, { 1E8f, 1E-8f, 8 }, { 1E4f, 1E-4f, 4 }, { 1E2f, 1E-2f, 2 }, { 1E1f, 1E-1f, 1 } };
-	static const struct { float below, times; int decades; } up[6] = { { 1E-31f, 1E32f, 32 }, { 1E-15f, 1E16f, 16 }, { 1E-7f, 1E8f, 8 }, { 1E-3f, 1E4f, 4 }, { 1E-1f, 1E2f, 2 }, { 1E0f, 1E1f, 1 } };
+	static const struct {
+		float at_least, times;
+		int decades;
+	} down[6] = { { 1E32f, 1E-32f, 32 }, { 1E16f, 1E-16f, 16 }, { 1E8f, 1E-8f, 8 }, { 1E4f, 1E-4f, 4 }, { 1E2f, 1E-2f, 2 }, { 1E1f, 1E-1f, 1 } };
+	static const struct {
+		float below, times;
+		int decades;
+	} up[6] = { { 1E-31f, 1E32f, 32 }, { 1E-15f, 1E16f, 16 }, { 1E-7f, 1E8f, 8 }, { 1E-3f, 1E4f, 4 }, { 1E-1f, 1E2f, 2 }, { 1E0f, 1E1f, 1 } };
 	if(x>=10.0f) for(const auto& r : down) if(x>=r.at_least) { x *= r.times; d.exponent += r.decades; }
 	if(x>0.0f&&x<=1.0f) for(const auto& r : up) if(x<r.below) { x *= r.times; d.exponent -= r.decades; }
 	d.integral = (uint32_t)x;
@@ -124,7 +133,12 @@ static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, c
 		if((e = hipMemMap((char*)b.base+off, len, 0u, h, 0ull))!=hipSuccess) { (void)hipMemRelease(h); break; }
 		b.chunks.push_back(h); mapped += len;
 	}
-	if(e==hipSuccess) { hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite; e = hipMemSetAccess(b.base, total, &acc, 1u); }
+	if(e==hipSuccess) {
+		hipMemAccessDesc acc{};
+		acc.location = prop.location;
+		acc.flags = hipMemAccessFlagsProtReadWrite;
+		e = hipMemSetAccess(b.base, total, &acc, 1u);
+	}
 	if(e!=hipSuccess) { // undo what was mapped
 		if(!b.chunks.empty()) (void)hipMemUnmap(b.base, mapped);
 		for(auto& h : b.chunks) (void)hipMemRelease(h);
@@ -168,7 +182,10 @@ struct luw_solver {
 	uint32_t vk_P = 0u, vk_M = 0u; int vk_stride = 1; bool vk_interp = false, vk_active = false; uint64_t vk_last_t = ~0ull;
 	uint32_t* d_vk_cell = nullptr; uint8_t* d_vk_face = nullptr; float* d_vk_point = nullptr; float* d_vk_mode = nullptr;
 	// the inlet values of step t+1 are evaluated on a side stream while step t runs (vk_apply): two packed buffers, the step each holds
-	float* d_vk_val[2] = { nullptr, nullptr }; uint64_t vk_val_t[2] = { ~0ull, ~0ull }; hipStream_t vk_stream = nullptr; hipEvent_t vk_ready[2] = { nullptr, nullptr }, vk_taken[2] = { nullptr, nullptr };
+	float* d_vk_val[2] = { nullptr, nullptr };
+	uint64_t vk_val_t[2] = { ~0ull, ~0ull };
+	hipStream_t vk_stream = nullptr;
+	hipEvent_t vk_ready[2] = { nullptr, nullptr }, vk_taken[2] = { nullptr, nullptr };
 	float* h_rho = nullptr; float* h_u = nullptr; uint8_t* h_flags = nullptr; float* h_F = nullptr;
 	void* d_gi = nullptr; float* d_T = nullptr; float* h_T = nullptr; float* d_avg_T = nullptr; // TEMPERATURE
 	hipStream_t own_stream = nullptr;
@@ -210,7 +227,8 @@ static int set_device(const luw_solver* s) { HIP_TRY(hipSetDevice(s->cfg.device)
 // Host mirror (reference layout, pitch Nx) <-> device array (pitch Px), `planes` components: 1-D copies between the host and a
 // contiguous device staging buffer of bounded size, and a kernel that moves the rows between staging and lattice (55 GB/s either
 // way on the test box: PCIe-bound).  The runtime's 2-D copy serves the cases it handles well (see below).
-template<typename E> __global__ __launch_bounds__(256) void k_rows_copy(E* __restrict__ lattice, const size_t lattice_pitch, E* __restrict__ staging, const uint32_t nx, const bool to_lattice) {
+template<typename E> __global__ __launch_bounds__(256) void k_rows_copy(E* __restrict__ lattice, const size_t lattice_pitch, E* __restrict__ staging,
+	const uint32_t nx, const bool to_lattice) {
 	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x;
 	if(x>=nx) return;
 	const size_t row = (size_t)blockIdx.y+(size_t)blockIdx.z*gridDim.y;
@@ -230,8 +248,10 @@ static int copy_pitched(void* dst, const void* src, const size_t elem, luw_solve
 	static const bool force_staged = getenv("LUW_COPY_STAGED")!=nullptr; // test aid: the staged path for every array
 	if(!force_staged&&(!blk||blk->chunks.size()<=1u)&&((size_t)s->cfg.Nx*elem)%4u==0u) {
 		for(uint32_t c=0u; c<planes; c++) {
-			if(to_device) HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (const char*)src+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyHostToDevice, st));
-			else HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (const char*)src+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyDeviceToHost, st));
+			if(to_device) HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (const char*)src+(size_t)c*s->N*elem,
+				(size_t)s->cfg.Nx*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyHostToDevice, st));
+			else HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->N*elem, (size_t)s->cfg.Nx*elem, (const char*)src+(size_t)c*s->kp.Np*elem,
+				(size_t)s->kp.Px*elem, (size_t)s->cfg.Nx*elem, rows, hipMemcpyDeviceToHost, st));
 		}
 		return LUW_OK;
 	}
@@ -284,7 +304,8 @@ template<typename T, int V> static void launch_vec(luw_solver* s, const Box& b, 
 	const uint32_t nchunk = (nvec+vx-1u)/vx;
 	const uint32_t rows = (b.y1-b.y0)*(b.z1-b.z0);
 	const dim3 grid(((rows+ry-1u)/ry)*nchunk), block(vx, ry);
-	if(odd) hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
+	if(odd)
+		hipLaunchKernelGGL((k_stream_collide_v<T, V, 1>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 	else hipLaunchKernelGGL((k_stream_collide_v<T, V, 0>), grid, block, 0, s->stream, s->kp, b, nchunk, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, write_fields);
 }
 #endif
@@ -313,7 +334,10 @@ static void force_free_core(const luw_solver* s, uint32_t lo[3], uint32_t hi[3])
 		if(k.has_t) h[2] = std::min<int64_t>(h[2], (int64_t)k.Nzg-1-nb-k.Oz);
 	}
 	if(k.sponge_active&&k.has_t) h[2] = std::min<int64_t>(h[2], (int64_t)k.Nzg-1-(int64_t)k.sponge_N-k.Oz);
-	for(int a=0; a<3; a++) { lo[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(l[a], 0), N[a]); hi[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(h[a], (int64_t)lo[a]), N[a]); }
+	for(int a=0; a<3; a++) {
+		lo[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(l[a], 0), N[a]);
+		hi[a] = (uint32_t)std::min<int64_t>(std::max<int64_t>(h[a], (int64_t)lo[a]), N[a]);
+	}
 }
 // The nudging / sponge zones as cell ranges of this domain (KParams zw_lo ... zp_n): the conditions of FX/kernel.cpp:1537-1541,1598 -- the term is on,
 // the domain owns the face, it is not the downstream one, 0 <= distance <= Nbuf (sponge: 0 <= layer < Nsponge) -- solved for the local coordinate
@@ -350,23 +374,29 @@ static int box_force_mode(const luw_solver* s, const Box& b) {
 struct LaunchGeom { dim3 grid, block; int xa; uint32_t lds; };
 
 // ---- k_stream_collide_s: one cell per lane
-struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce; };   // mode 0: step, 4: step + thermal lattice; 1, 2, 3: A/B variants (tools build)
+// mode 0: step, 4: step + thermal lattice; 1, 2, 3: A/B variants (tools build)
+struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce; };
 typedef void (*ScalarLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
-template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+template<typename T, int MODE, int NT, bool FLAT, bool STATS,
+	bool NOFORCE> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	T* const fi = (T*)s->d_fi; T* const gi = MODE==4 ? (T*)s->d_gi : nullptr; float* const Tf = MODE==4 ? s->d_T : nullptr;
-	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
-	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho,
+		s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
+	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho, s->d_u,
+		s->d_flags, s->d_F, wf, gi, Tf, S);
 }
 struct ScalarRow { ScalarKey key; ScalarLaunch launch; const char* what; };
 static const ScalarRow scalar_table[] = {
 	//  bytes mode nt flat   stats  noforce
-	{ { 4u, 0, 2, true,  false, false }, scalar_instance<float, 0, 2, true, false, false>,       "FP32 product kernel, flat addressing (planes within 32-bit byte offsets)" },
+	{ { 4u, 0, 2, true,  false, false }, scalar_instance<float, 0, 2, true, false, false>,
+		"FP32 product kernel, flat addressing (planes within 32-bit byte offsets)" },
 	{ { 4u, 0, 2, false, false, false }, scalar_instance<float, 0, 2, false, false, false>,      "FP32 product kernel, row addressing (any plane size)" },
 	{ { 4u, 0, 2, true,  true,  false }, scalar_instance<float, 0, 2, true, true, false>,        "FP32, sampled step (fused Welford update)" },
 	{ { 4u, 0, 2, false, true,  false }, scalar_instance<float, 0, 2, false, true, false>,       "FP32, sampled step, row addressing" },
 	{ { 4u, 4, 2, true,  false, false }, scalar_instance<float, 4, 2, true, false, false>,       "FP32 + thermal lattice" },
 	{ { 4u, 4, 2, false, false, false }, scalar_instance<float, 4, 2, false, false, false>,      "FP32 + thermal lattice, row addressing" },
-	{ { 2u, 0, 2, false, false, false }, scalar_instance<uint16_t, 0, 2, false, false, false>,   "FP16C one-cell kernel (rows too narrow / unaligned for the pair kernel)" },
+	{ { 2u, 0, 2, false, false, false }, scalar_instance<uint16_t, 0, 2, false, false, false>,
+		"FP16C one-cell kernel (rows too narrow / unaligned for the pair kernel)" },
 	{ { 2u, 0, 2, false, false, true  }, scalar_instance<uint16_t, 0, 2, false, false, true>,    "FP16C one-cell kernel, force-free box: 7 waves per SIMD" },
 	{ { 2u, 0, 2, false, true,  false }, scalar_instance<uint16_t, 0, 2, false, true, false>,    "FP16C one-cell kernel, sampled step" },
 	{ { 2u, 4, 2, false, false, false }, scalar_instance<uint16_t, 4, 2, false, false, false>,   "FP16C one-cell kernel + thermal lattice" },
@@ -416,7 +446,10 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 #endif
 	for(const ScalarRow& r : scalar_table) {
 		const ScalarKey& q = r.key;
-		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce) { r.launch(s, b, g, write_fields, st ? *st : StatsArgs{}); return LUW_OK; }
+		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce) {
+			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
+			return LUW_OK;
+		}
 	}
 	return fail(LUW_ERR_STATE, "stream_collide: this library carries no one-cell kernel for the requested combination");
 }
@@ -424,26 +457,35 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 // ---- k_stream_collide_p: FP16C, two cells per lane
 struct PairKey { int mode; bool stats; int force; bool park, thermal; };   // mode 1: memory path only (tools build)
 typedef void (*PairLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
-template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+template<int MODE, bool STATS, int FORCE, bool PARK,
+	bool THERMAL> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	uint16_t* const fi = (uint16_t*)s->d_fi; uint16_t* const gi = THERMAL ? (uint16_t*)s->d_gi : nullptr; float* const Tf = THERMAL ? s->d_T : nullptr;
-	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
-	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho,
+		s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
+	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u,
+		s->d_flags, s->d_F, wf, S, gi, Tf);
 }
 struct PairRow { PairKey key; PairLaunch launch; const char* what; };
 static const PairRow pair_table[] = {
 	//  mode stats  force               park   thermal
-	{ { 0, false, PAIR_FORCE_NONE,    false, false }, pair_instance<0, false, PAIR_FORCE_NONE, false, false>,    "nothing can push the cells of the box: no force path, 5 waves per SIMD" },
+	{ { 0, false, PAIR_FORCE_NONE,    false, false }, pair_instance<0, false, PAIR_FORCE_NONE, false, false>,
+		"nothing can push the cells of the box: no force path, 5 waves per SIMD" },
 	{ { 0, false, PAIR_FORCE_UNIFORM, false, false }, pair_instance<0, false, PAIR_FORCE_UNIFORM, false, false>, "volume force / Coriolis only, 5 waves" },
-	{ { 0, false, PAIR_FORCE_ANY,     true,  false }, pair_instance<0, false, PAIR_FORCE_ANY, true, false>,      "general (zones, force field): second cell's values parked in LDS, 5 waves" },
-	{ { 0, false, PAIR_FORCE_ANY,     false, false }, pair_instance<0, false, PAIR_FORCE_ANY, false, false>,     "general, everything in registers, 4 waves (LUW_PAIR_PARK=0: A/B and test aid)" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  false }, pair_instance<0, false, PAIR_FORCE_ANY, true, false>,
+		"general (zones, force field): second cell's values parked in LDS, 5 waves" },
+	{ { 0, false, PAIR_FORCE_ANY,     false, false }, pair_instance<0, false, PAIR_FORCE_ANY, false, false>,
+		"general, everything in registers, 4 waves (LUW_PAIR_PARK=0: A/B and test aid)" },
 	{ { 0, true,  PAIR_FORCE_ANY,     false, false }, pair_instance<0, true, PAIR_FORCE_ANY, false, false>,      "sampled step (fused Welford update)" },
 	{ { 0, false, PAIR_FORCE_NONE,    true,  true  }, pair_instance<0, false, PAIR_FORCE_NONE, true, true>,      "+ thermal lattice, force-free box" },
 	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true  }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true>,   "+ thermal lattice, uniform forces" },
 	{ { 0, false, PAIR_FORCE_ANY,     true,  true  }, pair_instance<0, false, PAIR_FORCE_ANY, true, true>,       "+ thermal lattice, general" },
 #ifdef LUW_AB_KERNELS
-	{ { 1, false, PAIR_FORCE_ANY,     false, false }, pair_instance<1, false, PAIR_FORCE_ANY, false, false>,     "A/B: the kernel's memory path alone (LUW_PAIR_COPY)" },
-	{ { 0, false, PAIR_FORCE_NONE,    true,  false }, pair_instance<0, false, PAIR_FORCE_NONE, true, false>,     "A/B: force-free with PARK (7 waves: no gain, profiles/r03_pair_park_ab.txt)" },
-	{ { 0, false, PAIR_FORCE_UNIFORM, true,  false }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, false>,  "A/B: uniform forces with PARK (6 waves: slower)" },
+	{ { 1, false, PAIR_FORCE_ANY,     false, false }, pair_instance<1, false, PAIR_FORCE_ANY, false, false>,
+		"A/B: the kernel's memory path alone (LUW_PAIR_COPY)" },
+	{ { 0, false, PAIR_FORCE_NONE,    true,  false }, pair_instance<0, false, PAIR_FORCE_NONE, true, false>,
+		"A/B: force-free with PARK (7 waves: no gain, profiles/r03_pair_park_ab.txt)" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, true,  false }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, false>,
+		"A/B: uniform forces with PARK (6 waves: slower)" },
 #endif
 };
 static int launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
@@ -470,7 +512,10 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal, (k.mode==0&&!k.stats) ? k.force : PAIR_FORCE_NONE) : 0u;
 	for(const PairRow& r : pair_table) {
 		const PairKey& q = r.key;
-		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal) { r.launch(s, b, g, write_fields, st ? *st : StatsArgs{}); return LUW_OK; }
+		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal) {
+			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
+			return LUW_OK;
+		}
 	}
 	return fail(LUW_ERR_STATE, "stream_collide: this library carries no pair kernel for the requested combination");
 }
@@ -493,10 +538,12 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
 	static const uint32_t pair_min = getenv("LUW_PAIR_MIN_ROW") ? (uint32_t)strtoul(getenv("LUW_PAIR_MIN_ROW"), nullptr, 10) : 128u; // A/B aid (round 2: 256)
 	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=pair_min) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
-	static const bool thermal_pair = !(getenv("LUW_THERMAL_PAIR")&&getenv("LUW_THERMAL_PAIR")[0]=='0'); // 0: the thermal lattice through the one-cell kernel only (round 2; A/B and test aid)
+	// 0: the thermal lattice through the one-cell kernel only (round 2; A/B and test aid)
+	static const bool thermal_pair = !(getenv("LUW_THERMAL_PAIR")&&getenv("LUW_THERMAL_PAIR")[0]=='0');
 	if(s->d_gi&&(!fp16||!thermal_pair||st)) k = LUW_KERNEL_SCALAR; // FP32 / sampled steps: the thermal cell update of the one-cell kernel
 #ifdef LUW_AB_KERNELS
-	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR; // the vector kernels assume rows that start on a 16-byte boundary at x = 0
+	// the vector kernels assume rows that start on a 16-byte boundary at x = 0
+	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR;
 #endif
 	// pair kernel: FP16C; pairs start on a 4-byte boundary -- at even x, or at odd x when x is split (the row's lead pad then puts
 	// x = 1 on a line start, lead_alloc); the range holds whole pairs, except that it may end at an odd Nx of an unsplit row (the
@@ -525,8 +572,10 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 	const dim3 grid((A+255u)/256u), block(256);
 	const uint32_t odd = (uint32_t)(s->t&1ull);
 	void* lat = G ? s->d_gi : s->d_fi;
-	#define LUW_TR(TT, DD) do { if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat); \
-		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat); } while(0)
+	#define LUW_TR(TT, DD) do { \
+		if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat); \
+		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat); \
+	} while(0)
 	if(s->ddf_bytes==2u) { if(direction==0u) LUW_TR(uint16_t, 0); else if(direction==1u) LUW_TR(uint16_t, 1); else LUW_TR(uint16_t, 2); }
 	else { if(direction==0u) LUW_TR(float, 0); else if(direction==1u) LUW_TR(float, 1); else LUW_TR(float, 2); }
 	#undef LUW_TR
@@ -635,8 +684,16 @@ int luw_p2p_info(int device, int peer, int* can_access, int* performance_rank, i
 	if(device<0||device>=ndev||peer<0||peer>=ndev) return fail(LUW_ERR_INVALID, "luw_p2p_info: no such HIP device");
 	int v = device==peer ? 1 : 0;
 	if(can_access) { if(device!=peer) HIP_TRY(hipDeviceCanAccessPeer(&v, device, peer)); *can_access = v; }
-	if(performance_rank) { v = 0; if(device!=peer&&hipDeviceGetP2PAttribute(&v, hipDevP2PAttrPerformanceRank, device, peer)!=hipSuccess) { (void)hipGetLastError(); v = -1; } *performance_rank = v; }
-	if(native_atomics) { v = 1; if(device!=peer&&hipDeviceGetP2PAttribute(&v, hipDevP2PAttrNativeAtomicSupported, device, peer)!=hipSuccess) { (void)hipGetLastError(); v = -1; } *native_atomics = v; }
+	if(performance_rank) {
+		v = 0;
+		if(device!=peer&&hipDeviceGetP2PAttribute(&v, hipDevP2PAttrPerformanceRank, device, peer)!=hipSuccess) { (void)hipGetLastError(); v = -1; }
+		*performance_rank = v;
+	}
+	if(native_atomics) {
+		v = 1;
+		if(device!=peer&&hipDeviceGetP2PAttribute(&v, hipDevP2PAttrNativeAtomicSupported, device, peer)!=hipSuccess) { (void)hipGetLastError(); v = -1; }
+		*native_atomics = v;
+	}
 	uint32_t lt = 0u, hc = 0u;
 	if(device!=peer&&hipExtGetLinkTypeAndHopCount(device, peer, &lt, &hc)!=hipSuccess) { (void)hipGetLastError(); lt = ~0u; hc = ~0u; }
 	if(link_type) *link_type = lt;
@@ -668,8 +725,10 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(cfg->nu==0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be 0."); // FX/lbm.cpp:1141
 	if(cfg->nu<0.0f) return fail(LUW_ERR_INVALID, "Viscosity cannot be negative."); // FX/lbm.cpp:1142
 	if(cfg->ddf_format!=LUW_DDF_FP32&&cfg->ddf_format!=LUW_DDF_FP16C) return fail(LUW_ERR_INVALID, "luw_create: unknown ddf_format");
-	if(!kernel_selectable(cfg->kernel)) return fail(LUW_ERR_INVALID, "luw_create: this library has no such kernel (A/B and measurement-only variants exist in the tools build only)");
-	if((cfg->Dx>1u&&cfg->Nx<3u)||(cfg->Dy>1u&&cfg->Ny<3u)||(cfg->Dz>1u&&cfg->Nz<3u)) return fail(LUW_ERR_INVALID, "luw_create: split axes need at least one interior cell between the halo layers");
+	if(!kernel_selectable(cfg->kernel))
+		return fail(LUW_ERR_INVALID, "luw_create: this library has no such kernel (A/B and measurement-only variants exist in the tools build only)");
+	if((cfg->Dx>1u&&cfg->Nx<3u)||(cfg->Dy>1u&&cfg->Ny<3u)||(cfg->Dz>1u&&cfg->Nz<3u))
+		return fail(LUW_ERR_INVALID, "luw_create: split axes need at least one interior cell between the halo layers");
 	if((cfg->options&LUW_OPT_TEMPERATURE)&&!(cfg->alpha>=0.0f)) return fail(LUW_ERR_INVALID, "luw_create: thermal diffusivity must not be negative");
 	if(cfg->buffer_nudging_active&&cfg->buffer_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: buffer_n_cells must be > 0");
 	if(cfg->top_sponge_active&&cfg->sponge_n_cells==0u) return fail(LUW_ERR_INVALID, "luw_create: sponge_n_cells must be > 0");
@@ -696,7 +755,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	s->ddf_bytes = cfg->ddf_format==LUW_DDF_FP16C ? 2u : 4u;
 	s->kernel = cfg->kernel;
 #ifdef LUW_AB_KERNELS
-	if(const char* ke = getenv("LUW_KERNEL")) s->kernel = (uint32_t)atoi(ke); // tools build: overrides the kernel choice of callers that expose none (the deck driver)
+	// tools build: overrides the kernel choice of callers that expose none (the deck driver)
+	if(const char* ke = getenv("LUW_KERNEL")) s->kernel = (uint32_t)atoi(ke);
 #endif
 	KParams& k = s->kp;
 	memset(&k, 0, sizeof(k));
@@ -756,7 +816,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 			w_buf *= w_buf;
 			wb[d] = w_buf;
 		}
-		if(hipMalloc((void**)&s->d_wbuf, wb.size()*4u)!=hipSuccess||hipMemcpy(s->d_wbuf, wb.data(), wb.size()*4u, hipMemcpyHostToDevice)!=hipSuccess) return oom("wbuf");
+		if(hipMalloc((void**)&s->d_wbuf, wb.size()*4u)!=hipSuccess||hipMemcpy(s->d_wbuf, wb.data(), wb.size()*4u, hipMemcpyHostToDevice)!=hipSuccess)
+			return oom("wbuf");
 		k.wbuf = s->d_wbuf;
 	}
 	if(k.sponge_active) {
@@ -769,7 +830,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 			sigma = inv_tau*sigma*sigma;
 			sg[d] = sigma;
 		}
-		if(hipMalloc((void**)&s->d_sigma, sg.size()*4u)!=hipSuccess||hipMemcpy(s->d_sigma, sg.data(), sg.size()*4u, hipMemcpyHostToDevice)!=hipSuccess) return oom("sigma");
+		if(hipMalloc((void**)&s->d_sigma, sg.size()*4u)!=hipSuccess||hipMemcpy(s->d_sigma, sg.data(), sg.size()*4u, hipMemcpyHostToDevice)!=hipSuccess)
+			return oom("sigma");
 		k.sigma = s->d_sigma;
 	}
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -877,7 +939,8 @@ int luw_run(luw_solver* s, uint64_t steps);
 int luw_upload(luw_solver* s, uint32_t mask);
 int luw_download(luw_solver* s, uint32_t mask);
 static int vk_apply(luw_solver* s);
-static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1, const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st);
+static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1,
+	const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st);
 int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag) {
 	if(!s||!p0||!p1||!p2||triangle_number==0u) return fail(LUW_ERR_INVALID, "luw_voxelize_mesh: bad argument");
 	if(int e = set_device(s)) return e;
@@ -904,7 +967,8 @@ int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, 
 }
 
 // bins + launch shared by luw_voxelize_mesh (a solver's domain) and luw_voxelize_lattice (bare lattice)
-static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1, const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st) {
+static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1,
+	const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st) {
 	const uint32_t tx = (vg.Nx+VOX_TILE-1u)/VOX_TILE, ty = (vg.Ny+VOX_TILE-1u)/VOX_TILE;
 	const bool brute = getenv("LUW_VOXELIZE_ALL_TRIANGLES")!=nullptr; // test aid: every tile sees every triangle
 	std::vector<uint32_t> start((size_t)tx*ty+1u, 0u), tri;
@@ -917,13 +981,28 @@ static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u
 		b0 = (int)floorf((ylo-pad-(float)vg.Oy)/(float)VOX_TILE); b1 = (int)floorf((yhi+pad-(float)vg.Oy)/(float)VOX_TILE);
 		a0 = std::max(a0, 0); b0 = std::max(b0, 0); a1 = std::min(a1, (int)tx-1); b1 = std::min(b1, (int)ty-1);
 	};
-	for(uint32_t i=0u; i<ntri; i++) { int a0, a1, b0, b1; range(i, a0, a1, b0, b1); for(int b=b0; b<=b1; b++) for(int a=a0; a<=a1; a++) start[(size_t)a+(size_t)b*tx+1u]++; }
-	for(size_t t=0u; t<(size_t)tx*ty; t++) { if((uint64_t)start[t]+start[t+1u]>0xFFFFFFFFull) return fail(LUW_ERR_INVALID, "voxelize: triangle bins exceed 2^32 entries"); start[t+1u] += start[t]; }
+	for(uint32_t i=0u; i<ntri; i++) {
+		int a0, a1, b0, b1;
+		range(i, a0, a1, b0, b1);
+		for(int b=b0; b<=b1; b++) for(int a=a0; a<=a1; a++) start[(size_t)a+(size_t)b*tx+1u]++;
+	}
+	for(size_t t=0u; t<(size_t)tx*ty; t++) {
+		if((uint64_t)start[t]+start[t+1u]>0xFFFFFFFFull) return fail(LUW_ERR_INVALID, "voxelize: triangle bins exceed 2^32 entries");
+		start[t+1u] += start[t];
+	}
 	tri.resize(std::max<size_t>(start.back(), 1u));
 	{ std::vector<uint32_t> fill(start.begin(), start.end()-1);
-	  for(uint32_t i=0u; i<ntri; i++) { int a0, a1, b0, b1; range(i, a0, a1, b0, b1); for(int b=b0; b<=b1; b++) for(int a=a0; a<=a1; a++) tri[fill[(size_t)a+(size_t)b*tx]++] = i; } }
+	  for(uint32_t i=0u; i<ntri; i++) {
+		int a0, a1, b0, b1;
+		range(i, a0, a1, b0, b1);
+		for(int b=b0; b<=b1; b++) for(int a=a0; a<=a1; a++) tri[fill[(size_t)a+(size_t)b*tx]++] = i;
+	} }
 	uint32_t* d_start = nullptr; uint32_t* d_tri = nullptr;
-	if(hipMalloc((void**)&d_start, 4ull*start.size())!=hipSuccess||hipMalloc((void**)&d_tri, 4ull*tri.size())!=hipSuccess) { (void)hipFree(d_start); (void)hipFree(d_tri); return fail(LUW_ERR_NOMEM, "voxelize: allocation failed"); }
+	if(hipMalloc((void**)&d_start, 4ull*start.size())!=hipSuccess||hipMalloc((void**)&d_tri, 4ull*tri.size())!=hipSuccess) {
+		(void)hipFree(d_start);
+		(void)hipFree(d_tri);
+		return fail(LUW_ERR_NOMEM, "voxelize: allocation failed");
+	}
 	hipError_t e = hipMemcpy(d_start, start.data(), 4ull*start.size(), hipMemcpyHostToDevice);
 	if(e==hipSuccess) e = hipMemcpy(d_tri, tri.data(), 4ull*tri.size(), hipMemcpyHostToDevice);
 	if(e==hipSuccess) {
@@ -950,9 +1029,19 @@ int luw_gather_attach(luw_solver* s, uint32_t count, const uint64_t* cells) {
 		c[i] = x+(y+z*s->cfg.Ny)*s->kp.Px;
 	}
 	auto drop = [&]() { (void)hipFree(s->d_gather_cell); (void)hipFree(s->d_gather_out); s->d_gather_cell = nullptr; s->d_gather_out = nullptr; };
-	if(hipMalloc((void**)&s->d_gather_cell, 4ull*count)!=hipSuccess) { s->d_gather_cell = nullptr; return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed"); }
-	if(hipMalloc((void**)&s->d_gather_out, 12ull*count)!=hipSuccess) { s->d_gather_out = nullptr; drop(); return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed"); }
-	if(hipMemcpy(s->d_gather_cell, c.data(), 4ull*count, hipMemcpyHostToDevice)!=hipSuccess) { drop(); return fail(LUW_ERR_DEVICE, "luw_gather_attach: upload failed"); }
+	if(hipMalloc((void**)&s->d_gather_cell, 4ull*count)!=hipSuccess) {
+		s->d_gather_cell = nullptr;
+		return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed");
+	}
+	if(hipMalloc((void**)&s->d_gather_out, 12ull*count)!=hipSuccess) {
+		s->d_gather_out = nullptr;
+		drop();
+		return fail(LUW_ERR_NOMEM, "luw_gather_attach: allocation failed");
+	}
+	if(hipMemcpy(s->d_gather_cell, c.data(), 4ull*count, hipMemcpyHostToDevice)!=hipSuccess) {
+		drop();
+		return fail(LUW_ERR_DEVICE, "luw_gather_attach: upload failed");
+	}
 	s->gather_count = count;
 	return LUW_OK;
 }
@@ -961,22 +1050,29 @@ int luw_gather_u(luw_solver* s, float* out) {
 	if(s->gather_count==0u) return LUW_OK;
 	if(!s->fields_current) return fail(LUW_ERR_STATE, "luw_gather_u: rho,u on the device are stale (the last step did not write fields)");
 	if(int e = set_device(s)) return e;
-	hipLaunchKernelGGL(k_gather_u, dim3((s->gather_count+255u)/256u), dim3(256), 0, s->stream, s->gather_count, s->d_gather_cell, s->d_u, (size_t)s->kp.Np, s->d_gather_out);
+	hipLaunchKernelGGL(k_gather_u, dim3((s->gather_count+255u)/256u), dim3(256), 0, s->stream, s->gather_count, s->d_gather_cell, s->d_u, (size_t)s->kp.Np,
+		s->d_gather_out);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(out, s->d_gather_out, 12ull*s->gather_count, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
 
-int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1, const float* p2, const float* bounds, uint8_t flag, uint8_t* flags) {
-	if(!p0||!p1||!p2||!bounds||!flags||triangle_number==0u||(uint64_t)Nx*Ny*Nz==0ull||(uint64_t)Nx*Ny>0xFFFFFF00ull) return fail(LUW_ERR_INVALID, "luw_voxelize_lattice: bad argument");
+int luw_voxelize_lattice(int device, uint32_t Nx, uint32_t Ny, uint32_t Nz, uint32_t triangle_number, const float* p0, const float* p1, const float* p2,
+	const float* bounds, uint8_t flag, uint8_t* flags) {
+	if(!p0||!p1||!p2||!bounds||!flags||triangle_number==0u||(uint64_t)Nx*Ny*Nz==0ull||(uint64_t)Nx*Ny>0xFFFFFF00ull)
+		return fail(LUW_ERR_INVALID, "luw_voxelize_lattice: bad argument");
 	HIP_TRY(hipSetDevice(device));
 	const uint64_t N = (uint64_t)Nx*Ny*Nz;
 	uint8_t* d_flags = nullptr; float* d[3] = { nullptr, nullptr, nullptr };
 	auto cleanup = [&]() { (void)hipFree(d_flags); for(int k=0; k<3; k++) (void)hipFree(d[k]); };
 	if(hipMalloc((void**)&d_flags, N)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_voxelize_lattice: allocation failed");
 	const float* h[3] = { p0, p1, p2 };
-	for(int k=0; k<3; k++) if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess||hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)!=hipSuccess) { cleanup(); return fail(LUW_ERR_NOMEM, "luw_voxelize_lattice: allocation failed"); }
+	for(int k=0; k<3; k++)
+		if(hipMalloc((void**)&d[k], 12ull*triangle_number)!=hipSuccess||hipMemcpy(d[k], h[k], 12ull*triangle_number, hipMemcpyHostToDevice)!=hipSuccess) {
+		cleanup();
+		return fail(LUW_ERR_NOMEM, "luw_voxelize_lattice: allocation failed");
+	}
 	if(hipMemcpy(d_flags, flags, N, hipMemcpyHostToDevice)!=hipSuccess) { cleanup(); return fail(LUW_ERR_DEVICE, "luw_voxelize_lattice: upload failed"); }
 	const VoxGrid vg = { Nx, Ny, Nz, Nx, 0, 0, 0, N };
 	const int rc = voxelize_launch(vg, d_flags, nullptr, flag, triangle_number, p0, p1, p2, d, bounds, bounds+3, (hipStream_t)0);
@@ -1001,7 +1097,8 @@ int luw_vk_inlet_detach(luw_solver* s) {
 	s->vk_active = false; s->vk_P = s->vk_M = 0u;
 	return LUW_OK;
 }
-int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, int update_stride, int stride_interpolation) {
+int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face,
+	const float* point_data, const float* mode_data, int update_stride, int stride_interpolation) {
 	if(!s||!point_cell||!point_face||!point_data||!mode_data) return fail(LUW_ERR_INVALID, "luw_vk_inlet_attach: null argument");
 	if(point_count==0ull||mode_count==0ull||point_count>=(1ull<<31)||mode_count>65536ull) return fail(LUW_ERR_INVALID, "luw_vk_inlet_attach: bad table sizes");
 	if(int e = set_device(s)) return e;
@@ -1020,7 +1117,8 @@ int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count
 		if(hipMalloc(dst, bytes)!=hipSuccess) { *dst = nullptr; return false; }
 		return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice)==hipSuccess;
 	};
-	if(!table((void**)&s->d_vk_cell, cell.data(), P*4u)||!table((void**)&s->d_vk_face, point_face, P)||!table((void**)&s->d_vk_point, point_data, 7ull*P*4u)||!table((void**)&s->d_vk_mode, mode_data, 10ull*V*4u)) {
+	if(!table((void**)&s->d_vk_cell, cell.data(), P*4u)||!table((void**)&s->d_vk_face, point_face, P)||!table((void**)&s->d_vk_point, point_data, 7ull*P*4u)
+		||!table((void**)&s->d_vk_mode, mode_data, 10ull*V*4u)) {
 		(void)hipGetLastError(); (void)luw_vk_inlet_detach(s);
 		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocating / uploading the inlet tables failed");
 	}
@@ -1030,7 +1128,8 @@ int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count
 		bool ok = hipMalloc((void**)&s->d_vk_val[0], 3ull*P*4u)==hipSuccess&&hipMalloc((void**)&s->d_vk_val[1], 3ull*P*4u)==hipSuccess;
 		if(ok&&!s->vk_stream) {
 			ok = hipStreamCreateWithFlags(&s->vk_stream, hipStreamNonBlocking)==hipSuccess;
-			for(int b=0; b<2&&ok; b++) ok = hipEventCreateWithFlags(&s->vk_ready[b], hipEventDisableTiming)==hipSuccess&&hipEventCreateWithFlags(&s->vk_taken[b], hipEventDisableTiming)==hipSuccess;
+			for(int b=0; b<2&&ok; b++) ok = hipEventCreateWithFlags(&s->vk_ready[b], hipEventDisableTiming)==hipSuccess
+				&&hipEventCreateWithFlags(&s->vk_taken[b], hipEventDisableTiming)==hipSuccess;
 		}
 		if(!ok) { (void)hipGetLastError(); (void)luw_vk_inlet_detach(s); return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: side stream / value buffers"); }
 	}
@@ -1049,7 +1148,8 @@ int luw_stats_reset(luw_solver* s) {
 	if(int e = set_device(s)) return e;
 	const size_t Np = s->kp.Np;
 	if(!s->d_avg_u) {
-		if(lead_alloc(s, (void**)&s->d_avg_u, 3ull*Np, 4u)!=hipSuccess||lead_alloc(s, (void**)&s->d_avg_rho, Np, 4u)!=hipSuccess||lead_alloc(s, (void**)&s->d_m2, 3ull*Np, 4u)!=hipSuccess)
+		if(lead_alloc(s, (void**)&s->d_avg_u, 3ull*Np, 4u)!=hipSuccess||lead_alloc(s, (void**)&s->d_avg_rho, Np, 4u)!=hipSuccess
+			||lead_alloc(s, (void**)&s->d_m2, 3ull*Np, 4u)!=hipSuccess)
 			return fail(LUW_ERR_NOMEM, "luw_stats_reset: allocation failed");
 	}
 	if(s->d_T&&!s->d_avg_T) { if(lead_alloc(s, (void**)&s->d_avg_T, Np, 4u)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_stats_reset: allocation failed"); }
@@ -1178,7 +1278,8 @@ int luw_initialize(luw_solver* s) {
 	if(int e = luw_upload(s, LUW_MASK_RHO|LUW_MASK_U|LUW_MASK_FLAGS|LUW_MASK_F|LUW_MASK_T)) return e;
 	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
 	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
-	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_initialize<uint16_t>), grid, block, 0, s->stream, s->kp, (uint16_t*)s->d_fi, s->d_rho, s->d_u, s->d_flags, (uint16_t*)s->d_gi, s->d_T);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_initialize<uint16_t>), grid, block, 0, s->stream, s->kp, (uint16_t*)s->d_fi, s->d_rho, s->d_u, s->d_flags,
+		(uint16_t*)s->d_gi, s->d_T);
 	else hipLaunchKernelGGL((k_initialize<float>), grid, block, 0, s->stream, s->kp, (float*)s->d_fi, s->d_rho, s->d_u, s->d_flags, (float*)s->d_gi, s->d_T);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1197,7 +1298,8 @@ int luw_enqueue_stream_collide(luw_solver* s, uint32_t x0, uint32_t x1, uint32_t
 	const int wf = write_fields&1;
 	s->fields_current = wf!=0; // callers cover the lattice with boxes of one step using the same flag
 	if(write_fields&LUW_WF_SAMPLE) { // a box of a sampled step (luw_stats_begin_sample counted it)
-		if(!s->d_avg_u||!can_fuse_stats(s)||s->avg_count==0ull) return fail(LUW_ERR_STATE, "luw_enqueue_stream_collide: LUW_WF_SAMPLE needs luw_stats_begin_sample to have returned fused = 1");
+		if(!s->d_avg_u||!can_fuse_stats(s)||s->avg_count==0ull)
+			return fail(LUW_ERR_STATE, "luw_enqueue_stream_collide: LUW_WF_SAMPLE needs luw_stats_begin_sample to have returned fused = 1");
 		const StatsArgs st = { s->d_avg_u, s->d_avg_rho, s->d_m2, 1.0f/(float)s->avg_count };
 		return launch_stream_collide(s, b, wf, &st);
 	}
@@ -1240,7 +1342,8 @@ static int vk_launch_eval(luw_solver* s, const uint64_t t, float* dst, const siz
 		if(s->vk_interp) { use_interp = 1u; t0 = (float)anchor; t1 = (float)(anchor+stride); alpha = (float)(t-anchor)/(float)stride; }
 		else { t0 = (float)anchor; t1 = t0; }
 	}
-	hipLaunchKernelGGL(k_vk_inlet_apply, dim3((s->vk_P+255u)/256u), dim3(256), 0, st, use_interp, t0, t1, alpha, s->vk_P, s->vk_M, 5u*s->vk_M, cell, s->d_vk_face, s->d_vk_point, s->d_vk_mode, dst, dstride);
+	hipLaunchKernelGGL(k_vk_inlet_apply, dim3((s->vk_P+255u)/256u), dim3(256), 0, st, use_interp, t0, t1, alpha, s->vk_P, s->vk_M, 5u*s->vk_M, cell,
+		s->d_vk_face, s->d_vk_point, s->d_vk_mode, dst, dstride);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
@@ -1271,7 +1374,8 @@ static int run_steps(luw_solver* s, uint64_t steps, double* mean_kernel_ms, cons
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
 	const bool every = luw_fields_every_step(s)!=0;
 	std::vector<hipEvent_t> ev;
-	struct EventsFree { std::vector<hipEvent_t>& v; ~EventsFree() { for(hipEvent_t e : v) if(e) (void)hipEventDestroy(e); } } events_free{ ev }; // on every path out
+	// on every path out
+	struct EventsFree { std::vector<hipEvent_t>& v; ~EventsFree() { for(hipEvent_t e : v) if(e) (void)hipEventDestroy(e); } } events_free{ ev };
 	if(mean_kernel_ms) {
 		ev.assign(2u*steps, nullptr);
 		for(auto& e : ev) HIP_TRY(hipEventCreate(&e));

@@ -70,7 +70,8 @@ __device__ __forceinline__ uint32_t float_to_half_custom_ref(const float x) { //
 	const uint32_t b = __float_as_uint(x)+0x00000800u;
 	const uint32_t e = (b&0x7F800000u)>>23;
 	const uint32_t m = b&0x007FFFFFu;
-	return (b&0x80000000u)>>16 | (uint32_t)(e>112u)*((((e-112u)<<11)&0x7800u)|m>>12) | (uint32_t)((e<113u)&(e>100u))*((((0x007FF800u+m)>>((124u-e)&31u))+1u)>>1);
+	return (b&0x80000000u)>>16 | (uint32_t)(e>112u)*((((e-112u)<<11)&0x7800u)|m>>12) | (uint32_t)((e<113u)&(e>100u))*((((0x007FF800u+m)>>((124u-e)&31u))
+		+1u)>>1);
 }
 // Decode: the 15 exponent+mantissa bits placed at float bits 12..26 form a tiny float 2^(e-127)(1+m/2048) (or, for
 // e = 0, the float DENORMAL m 2^-137); one exact multiplication by 2^112 turns both into the FP16C value
@@ -141,7 +142,8 @@ __device__ __forceinline__ void fp16c_code2_hi_in_rtz_mode(const f32x2_codec x, 
 __device__ __forceinline__ void fp16c_encode19_hi_rtz_final(float* f, uint32_t* code, float* g = nullptr, uint32_t* cg = nullptr) {
 	asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
 	if(g) asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]));
-	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]), "+v"(f[16]), "+v"(f[17]), "+v"(f[18]));
+	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]), "+v"(f[16]),
+		"+v"(f[17]), "+v"(f[18]));
 	#pragma unroll
 	for(int i=0; i<19; i++) code[i] = fp16c_code_hi_in_rtz_mode(f[i]);
 	if(g) {
@@ -252,13 +254,15 @@ template<int I> __device__ __forceinline__ float cdot(const float a, const float
 	else if constexpr(I==15) return  a-c; else if constexpr(I==16) return -a+c;
 	else if constexpr(I==17) return  b-c; else return -b+c; // 18
 }
-template<int I> __device__ __forceinline__ void forcing_term(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, const float uF, float* Fin) {
+template<int I> __device__ __forceinline__ void forcing_term(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz,
+	const float uF, float* Fin) {
 	constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
 	Fin[I] = w9*fmaf(cdot<I>(fx, fy, fz), cdot<I>(ux, uy, uz)+0.33333334f, uF);
 	if constexpr(I<18) forcing_term<I+1>(ux, uy, uz, fx, fy, fz, uF, Fin);
 }
 // Guo forcing, FX/kernel.cpp:1103-1113
-__device__ __forceinline__ void calculate_forcing_terms(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, float* Fin) {
+__device__ __forceinline__ void calculate_forcing_terms(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz,
+	float* Fin) {
 	const float uF = -0.33333334f*fmaf(ux, fx, fmaf(uy, fy, uz*fz));
 	Fin[0] = 9.0f*DEF_W0*uF;
 	forcing_term<1>(ux, uy, uz, fx, fy, fz, uF, Fin);
@@ -275,7 +279,8 @@ __device__ __forceinline__ void calculate_forcing_terms(const float ux, const fl
 // lane pair otherwise, ~3400 of a wave's 21000 cycles on the urban tile: profiles/r03_stall_counters.md) is hidden behind decode and moments.
 // A TYPE_E cell takes neither term; its four registers carry what it reads instead, its own rho and u (FX/kernel.cpp:1516-1523), fetched just as early.
 struct ForceRefs { float tu[3], wb, su[3], sg; bool zn, zs; };
-__device__ __forceinline__ void fetch_force_refs(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool live, const bool is_E,
+__device__ __forceinline__ void fetch_force_refs(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool live,
+	const bool is_E,
 		const float* __restrict__ rho, const float* __restrict__ u, ForceRefs& r) {
 	// (values of lanes outside the zones are never read: defined as "whatever the register holds", at no instruction)
 	asm volatile("" : "=v"(r.tu[0]), "=v"(r.tu[1]), "=v"(r.tu[2]), "=v"(r.wb), "=v"(r.su[0]), "=v"(r.su[1]), "=v"(r.su[2]), "=v"(r.sg));
@@ -284,7 +289,8 @@ __device__ __forceinline__ void fetch_force_refs(const KParams& p, const uint32_
 	bool zn = false;
 	uint32_t d_min = 0u, n_ref = n;
 	if(p.buffer_active) { // the selection of assemble_force
-		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y, d_t = (uint32_t)p.top_z-z;
+		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y,
+			d_t = (uint32_t)p.top_z-z;
 		const bool in_w = x-p.zw_lo<p.zw_n, in_e = x-p.ze_lo<p.ze_n, in_s = y-p.zs_lo<p.zs_n, in_n = y-p.zn_lo<p.zn_n, in_t = z-p.zt_lo<p.zt_n;
 		zn = act && (in_w||in_e||in_s||in_n||in_t);
 		if(zn) {
@@ -318,8 +324,10 @@ __device__ __forceinline__ void fetch_force_refs(const KParams& p, const uint32_
 	}
 }
 // refs (pair kernel, general instantiation only): the references above, already fetched -- same arithmetic on them
-template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E,
-		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn, float& fzn,
+template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y,
+	const uint32_t z, const bool is_E,
+		const float rhon, const float uxn, const float uyn, const float uzn, const float* __restrict__ u, const float* __restrict__ F, float& fxn, float& fyn,
+			float& fzn,
 		const ForceRefs* refs = nullptr) {
 	fxn = p.fx; fyn = p.fy; fzn = p.fz;
 	if(p.coriolis) { // with omega = 0 the three terms are +-0: adding them changes no value
@@ -354,7 +362,8 @@ template<bool ZONES=true> __device__ __forceinline__ void assemble_force(const K
 	}
 	if(p.buffer_active && !is_E) {
 		// distance to each face (meaningful inside that face's zone, wrapped-around garbage outside, where it is not used)
-		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y, d_t = (uint32_t)p.top_z-z;
+		const uint32_t d_w = x-(uint32_t)p.west_x, d_e = (uint32_t)p.east_x-x, d_s = y-(uint32_t)p.south_y, d_n = (uint32_t)p.north_y-y,
+			d_t = (uint32_t)p.top_z-z;
 		const bool in_w = x-p.zw_lo<p.zw_n, in_e = x-p.ze_lo<p.ze_n, in_s = y-p.zs_lo<p.zs_n, in_n = y-p.zn_lo<p.zn_n, in_t = z-p.zt_lo<p.zt_n;
 		if(in_w||in_e||in_s||in_n||in_t) {
 			uint32_t d_min = p.buffer_N+1u;
@@ -415,11 +424,14 @@ __device__ __forceinline__ float smagorinsky_rate_plain(const KParams& p, const 
 	const float tau = p.tau0+sqrt_in_range(p.tau0sq+div_by(s, R));
 	return div_by(2.0f, recip_prepare(tau));
 }
-__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_) { return smagorinsky_rate_of_Q(p, rhon, smagorinsky_Q(n_)); }
+__device__ __forceinline__ float smagorinsky_rate(const KParams& p, const float rhon, const float* n_) {
+	return smagorinsky_rate_of_Q(p, rhon, smagorinsky_Q(n_));
+}
 // PLAIN (FP16C storage, LUW_PLAIN_ARITH): divisions by the density and the square roots as plain-range sequences (recip_prepare); R is the prepared
 // reciprocal of rhon, odd_density marks the lanes that redo those results with the library forms
 struct DensityRecip { Recip R; bool odd; };
-template<bool PLAIN> __device__ __forceinline__ float relaxation_rate(const KParams& p, const float rhon, const float* f, const float* feq, const DensityRecip& dr) {
+template<bool PLAIN> __device__ __forceinline__ float relaxation_rate(const KParams& p, const float rhon, const float* f, const float* feq,
+	const DensityRecip& dr) {
 	if(!p.subgrid) return p.w;
 	float n_[19];
 	#pragma unroll
@@ -432,8 +444,10 @@ template<bool PLAIN> __device__ __forceinline__ float relaxation_rate(const KPar
 	} else return smagorinsky_rate_of_Q(p, rhon, Q);
 }
 // rho, u of the cell (moments, or the stored values on TYPE_E cells) and the force acting on it
-template<bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const bool is_E, const float* f,
-		const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float& fxn, float& fyn, float& fzn, DensityRecip& dr) {
+template<bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void collide_head(const KParams& p, const uint32_t n, const uint32_t x,
+	const uint32_t y, const uint32_t z, const bool is_E, const float* f,
+		const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float& fxn,
+			float& fyn, float& fzn, DensityRecip& dr) {
 	if(is_E) {
 		rhon = rho[n];
 		uxn = u[n];
@@ -453,7 +467,8 @@ template<bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void c
 	else assemble_force(p, n, x, y, z, is_E, rhon, uxn, uyn, uzn, u, F, fxn, fyn, fzn);
 }
 // the general tail: Guo forcing, equilibrium override on TYPE_E cells
-template<bool PLAIN=false> __device__ __forceinline__ void collide_tail_general(const KParams& p, const bool is_E, const bool forced, const float fxn, const float fyn, const float fzn,
+template<bool PLAIN=false> __device__ __forceinline__ void collide_tail_general(const KParams& p, const bool is_E, const bool forced, const float fxn,
+	const float fyn, const float fzn,
 		float* f, const float rhon, float& uxn, float& uyn, float& uzn, const DensityRecip& dr) {
 	float feq[19], Fin[19];
 	if(forced) {
@@ -488,13 +503,16 @@ template<bool PLAIN=false> __device__ __forceinline__ void collide_tail_general(
 // NOFORCE: no force can act on any cell of the launch (box_force_mode): without the force assembly the FP16C kernel needs 69 instead of 89
 // VGPRs (76 instead of 93 with the thermal lattice) and no scalar spills -- 7 resp. 6 waves per SIMD instead of 5
 // PLAIN: the populations come out of FP16C storage (bounded operands): plain-range divisions and square roots (recip_prepare)
-template<bool FAST=true, bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
-		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr) {
+template<bool FAST=true, bool NOFORCE=false, bool PLAIN=false> __device__ __forceinline__ void collide_cell(const KParams& p, const uint32_t n,
+	const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
+		float* f, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn,
+			float* u_before_force = nullptr) {
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	float fxn, fyn, fzn;
 	DensityRecip dr{};
 	collide_head<NOFORCE, PLAIN>(p, n, x, y, z, is_E, f, rho, u, F, rhon, uxn, uyn, uzn, fxn, fyn, fzn, dr);
-	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
+	// what the thermal lattice advects with (FX/kernel.cpp:1669)
+	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; }
 	// A cell without any force (the bulk of an urban case: no volume force, outside the nudging / sponge zones, no
 	// Coriolis) has Fin_i = +-0 exactly and u += 0/(2 rho); skipping that arithmetic is value-identical
 	// (fma(w, feq, +-0) == w*feq) as long as rho != 0.
@@ -543,7 +561,8 @@ __device__ __forceinline__ void calculate_f_eq_pk(const float rho, float ux, flo
 	}
 }
 // Guo terms of the pair (2k+1, 2k+2): c_(2k+2) = -c_(2k+1), so both are w9 fma(+-cF, +-cu + 1/3, uF) (FX/kernel.cpp:1103-1113)
-template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz, const float uF) {
+template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz,
+	const float uF) {
 	constexpr int I = 2*K+1;
 	constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
 	// c_(2k+2) . v = -(c_(2k+1) . v) exactly (-a-b and -(a+b) round alike), so the second lane takes the first lane's sums through the packed
@@ -575,9 +594,12 @@ enum { PAIR_FORCE_NONE = 0, PAIR_FORCE_UNIFORM = 1, PAIR_FORCE_ANY = 2 };
 // other density (zero, negative, NaN, absurd) redo exactly those results with the library forms inside rarely taken divergent blocks, so the
 // values are the IEEE ones for EVERY input.  (A per-wave vote between two complete collisions was measured first: the duplicated code cost
 // more than the arithmetic saved, 1024x1024x256 + Coriolis 4.05 -> 4.25 ms; this form 4.05 -> 3.89, profiles/r03_plain_arith_ab.txt.)
-template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const bool may_force,
-		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr,
-		const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) { // refs: zone references fetched early (fetch_force_refs); own: a TYPE_E cell's rho / u fetched early (wb, tu)
+template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y,
+	const uint32_t z, const uint8_t flagsn, const bool may_force,
+		float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon, float& uxn, float& uyn,
+			float& uzn, float* u_before_force = nullptr,
+		// refs: zone references fetched early (fetch_force_refs); own: a TYPE_E cell's rho / u fetched early (wb, tu)
+		const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) {
 	constexpr bool PLAIN = LUW_PLAIN_ARITH!=0;
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
@@ -607,9 +629,11 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 				uzn = u[2ull*p.Np+n];
 			}
 		}
-		if constexpr(PLAIN) { R = recip_prepare(rhon); odd_density = !density_is_ordinary(rhon); } // rhon: the field value on TYPE_E lanes, the moment sum elsewhere
+		// rhon: the field value on TYPE_E lanes, the moment sum elsewhere
+		if constexpr(PLAIN) { R = recip_prepare(rhon); odd_density = !density_is_ordinary(rhon); }
 	}
-	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; } // what the thermal lattice advects with (FX/kernel.cpp:1669)
+	// what the thermal lattice advects with (FX/kernel.cpp:1669)
+	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; }
 	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
 	f32x2 Finp[9]; float Fin0 = 0.0f;
 	if(forced) {
@@ -618,16 +642,23 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 		float rho2;
 		if constexpr(PLAIN) {
 			rho2 = div_by(0.5f, R);
-			if(odd_density) { asm volatile(""); rho2 = 0.5f/rhon; } // (the empty asm keeps this a branch: a lone division would be hoisted in front of a select and run for every lane)
+			// (the empty asm keeps this a branch: a lone division would be hoisted in front of a select and run for every lane)
+			if(odd_density) { asm volatile(""); rho2 = 0.5f/rhon; }
 		} else rho2 = 0.5f/rhon;
 		uxn = clampf(fmaf(fxn, rho2, uxn), -DEF_C, DEF_C);
 		uyn = clampf(fmaf(fyn, rho2, uyn), -DEF_C, DEF_C);
 		uzn = clampf(fmaf(fzn, rho2, uzn), -DEF_C, DEF_C);
 		const float uF = -0.33333334f*fmaf(uxn, fxn, fmaf(uyn, fyn, uzn*fzn));
 		Fin0 = 9.0f*DEF_W0*uF;
-		Finp[0] = forcing_pair<0>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[1] = forcing_pair<1>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[2] = forcing_pair<2>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
-		Finp[3] = forcing_pair<3>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[4] = forcing_pair<4>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[5] = forcing_pair<5>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
-		Finp[6] = forcing_pair<6>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[7] = forcing_pair<7>(uxn, uyn, uzn, fxn, fyn, fzn, uF); Finp[8] = forcing_pair<8>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[0] = forcing_pair<0>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[1] = forcing_pair<1>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[2] = forcing_pair<2>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[3] = forcing_pair<3>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[4] = forcing_pair<4>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[5] = forcing_pair<5>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[6] = forcing_pair<6>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[7] = forcing_pair<7>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+		Finp[8] = forcing_pair<8>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
 	} else {
 		uxn = clampf(uxn, -DEF_C, DEF_C);
 		uyn = clampf(uyn, -DEF_C, DEF_C);
@@ -705,8 +736,10 @@ __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n,
 // on T, BGK with w_T (TYPE_T: g = g_eq), stream-out.  n, jx, jy, jz are ELEMENT indices of the cell and its +x, +y, +z
 // neighbours; (ux,uy,uz) is the velocity before the force shift.  The buoyancy term it would add to the force carries the
 // factor (fx,fy,fz), which LUW sets to zero (FX/setup.cpp:4935): T is a passive scalar here.
-template<typename T, int PARITY> __device__ __forceinline__ void thermal_collide(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
-		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, const T* __restrict__ gi, float* __restrict__ Tf, float* g) {
+template<typename T,
+	int PARITY> __device__ __forceinline__ void thermal_collide(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
+		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, const T* __restrict__ gi,
+			float* __restrict__ Tf, float* g) {
 	const size_t Np = p.Np;
 	const uint32_t jn[3] = { jx, jy, jz };
 	g[0] = ddf_decode<T>(gi[n]);
@@ -719,7 +752,8 @@ template<typename T, int PARITY> __device__ __forceinline__ void thermal_collide
 	thermal_cell(p, n, x, y, z, flagsn, ux, uy, uz, Tf, g);
 }
 // stream-out of the 7 encoded populations (Esoteric-Pull slots); code_of(i) yields the storage value of population i
-template<typename T, int PARITY, typename F> __device__ __forceinline__ void thermal_store(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz, T* __restrict__ gi, F code_of) {
+template<typename T, int PARITY, typename F> __device__ __forceinline__ void thermal_store(const KParams& p, const uint32_t n, const uint32_t jx,
+	const uint32_t jy, const uint32_t jz, T* __restrict__ gi, F code_of) {
 	const size_t Np = p.Np;
 	const uint32_t jn[3] = { jx, jy, jz };
 	gi[n] = code_of(0);

@@ -40,7 +40,8 @@ template<int SRC> __global__ __launch_bounds__(256) void k_export_slab(const KPa
 		float v = 0.0f;
 		if constexpr(SRC==LUW_EXPORT_FLUID) v = solid ? 0.0f : 1.0f;
 		else if(e.has_m2&&!solid&&(e.want_tke||e.want_ti||e.want_tls)) {
-			const float var_u = fmaxf(e.m2[n]*e.inv_n, 0.0f), var_v = fmaxf(e.m2[Np+n]*e.inv_n, 0.0f), var_w = fmaxf(e.m2[2u*Np+n]*e.inv_n, 0.0f), var_sum = var_u+var_v+var_w;
+			const float var_u = fmaxf(e.m2[n]*e.inv_n, 0.0f), var_v = fmaxf(e.m2[Np+n]*e.inv_n, 0.0f), var_w = fmaxf(e.m2[2u*Np+n]*e.inv_n, 0.0f),
+				var_sum = var_u+var_v+var_w;
 			if constexpr(SRC==LUW_EXPORT_TKE) { if(e.want_tke) v = 0.5f*var_sum; }
 			else if constexpr(SRC==LUW_EXPORT_TI) {
 				if(e.want_ti) {
@@ -50,9 +51,12 @@ template<int SRC> __global__ __launch_bounds__(256) void k_export_slab(const KPa
 				}
 			} else if(e.want_tls) { // TLS: central differences of the SI mean velocity, one-sided at the edges of the WRITTEN lattice
 				const uint32_t gx = (uint32_t)((int32_t)x+p.Ox), gy = (uint32_t)((int32_t)y+p.Oy), gz = (uint32_t)((int32_t)z+p.Oz);
-				const uint32_t xm = gx>0u ? x-1u : x, xp = gx+1u<e.gNx ? x+1u : x, ym = gy>0u ? y-1u : y, yp = gy+1u<e.gNy ? y+1u : y, zm = gz>0u ? z-1u : z, zp = gz+1u<e.gNz_out ? z+1u : z;
-				const uint32_t ixm = xm+(y+z*p.Ny)*p.Px, ixp = xp+(y+z*p.Ny)*p.Px, iym = x+(ym+z*p.Ny)*p.Px, iyp = x+(yp+z*p.Ny)*p.Px, izm = x+(y+zm*p.Ny)*p.Px, izp = x+(y+zp*p.Ny)*p.Px;
-				const float idx_ = xp>xm ? 1.0f/((float)(xp-xm)*e.grid_dx) : 0.0f, idy = yp>ym ? 1.0f/((float)(yp-ym)*e.grid_dx) : 0.0f, idz = zp>zm ? 1.0f/((float)(zp-zm)*e.grid_dx) : 0.0f;
+				const uint32_t xm = gx>0u ? x-1u : x, xp = gx+1u<e.gNx ? x+1u : x, ym = gy>0u ? y-1u : y, yp = gy+1u<e.gNy ? y+1u : y, zm = gz>0u ? z-1u : z,
+					zp = gz+1u<e.gNz_out ? z+1u : z;
+				const uint32_t ixm = xm+(y+z*p.Ny)*p.Px, ixp = xp+(y+z*p.Ny)*p.Px, iym = x+(ym+z*p.Ny)*p.Px, iyp = x+(yp+z*p.Ny)*p.Px, izm = x+(y+zm*p.Ny)*p.Px,
+					izp = x+(y+zp*p.Ny)*p.Px;
+				const float idx_ = xp>xm ? 1.0f/((float)(xp-xm)*e.grid_dx) : 0.0f, idy = yp>ym ? 1.0f/((float)(yp-ym)*e.grid_dx) : 0.0f, idz = zp>zm
+					? 1.0f/((float)(zp-zm)*e.grid_dx) : 0.0f;
 				auto su = [&](const uint32_t i, const uint32_t c) { return e.a[c*Np+i]*e.u_factor; };
 				const float duxdx = (su(ixp, 0u)-su(ixm, 0u))*idx_, duydx = (su(ixp, 1u)-su(ixm, 1u))*idx_, duzdx = (su(ixp, 2u)-su(ixm, 2u))*idx_;
 				const float duxdy = (su(iyp, 0u)-su(iym, 0u))*idy, duydy = (su(iyp, 1u)-su(iym, 1u))*idy, duzdy = (su(iyp, 2u)-su(iym, 2u))*idy;
@@ -68,7 +72,8 @@ template<int SRC> __global__ __launch_bounds__(256) void k_export_slab(const KPa
 	}
 }
 // one cell layer of a float field (comps planes of stride Np) <-> a packed buffer [comps][A]; layer = coordinate `c` along `axis`
-template<bool SCATTER> __global__ __launch_bounds__(256) void k_field_layer(const KParams p, const uint32_t axis, const uint32_t c, const uint32_t comps, float* __restrict__ field, float* __restrict__ buf) {
+template<bool SCATTER> __global__ __launch_bounds__(256) void k_field_layer(const KParams p, const uint32_t axis, const uint32_t c, const uint32_t comps,
+	float* __restrict__ field, float* __restrict__ buf) {
 	const uint32_t N[3] = { p.Nx, p.Ny, p.Nz };
 	const uint32_t a1 = (axis+1u)%3u, a2 = (axis+2u)%3u, A = N[a1]*N[a2];
 	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
@@ -128,9 +133,19 @@ struct SlabWriter {
 		th = std::thread([this]() {
 			for(;;) {
 				Job j;
-				{ std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done||!queue.empty(); }); if(queue.empty()) return; j = queue.front(); queue.erase(queue.begin()); }
+				{
+					std::unique_lock<std::mutex> l(m);
+					cv.wait(l, [&] { return done||!queue.empty(); });
+					if(queue.empty()) return;
+					j = queue.front();
+					queue.erase(queue.begin());
+				}
 				size_t put = 0u;
-				while(put<j.bytes) { const ssize_t w = pwrite(fd, j.data+put, j.bytes-put, (off_t)(j.offset+put)); if(w<=0) { std::lock_guard<std::mutex> l(m); error = 1; break; } put += (size_t)w; }
+				while(put<j.bytes) {
+					const ssize_t w = pwrite(fd, j.data+put, j.bytes-put, (off_t)(j.offset+put));
+					if(w<=0) { std::lock_guard<std::mutex> l(m); error = 1; break; }
+					put += (size_t)w;
+				}
 				{ std::lock_guard<std::mutex> l(m); busy[j.slot] = 0; }
 				cv.notify_all();
 			}
@@ -150,8 +165,10 @@ extern "C" int luw_group_export_vtk(luw_group* g, int source, const luw_export_p
 	const bool from_stats = source>=LUW_EXPORT_AVG_U&&source!=LUW_EXPORT_FLUID;
 	for(GroupDomain& d : g->dom) {
 		if(from_stats&&!d.s->d_avg_u) return fail(LUW_ERR_STATE, "luw_group_export_vtk: no statistics have been accumulated");
-		if((source==LUW_EXPORT_T&&!d.s->d_T)||(source==LUW_EXPORT_AVG_T&&!d.s->d_avg_T)) return fail(LUW_ERR_STATE, "luw_group_export_vtk: the solver has no temperature field");
-		if((source==LUW_EXPORT_U||source==LUW_EXPORT_RHO)&&!d.s->fields_current) return fail(LUW_ERR_STATE, "luw_group_export_vtk: rho,u on the device are stale (the last step did not write fields)");
+		if((source==LUW_EXPORT_T&&!d.s->d_T)||(source==LUW_EXPORT_AVG_T&&!d.s->d_avg_T))
+			return fail(LUW_ERR_STATE, "luw_group_export_vtk: the solver has no temperature field");
+		if((source==LUW_EXPORT_U||source==LUW_EXPORT_RHO)&&!d.s->fields_current)
+			return fail(LUW_ERR_STATE, "luw_group_export_vtk: rho,u on the device are stale (the last step did not write fields)");
 	}
 	if(source==LUW_EXPORT_TLS&&prm->want_tls&&g->dom.size()>1u) // the stencil reads the mean velocity of cells next door
 		GROUP_TRY(group_fill_field_halos(g, [](luw_solver* s) { return s->d_avg_u; }, 3u));
@@ -160,14 +177,24 @@ extern "C" int luw_group_export_vtk(luw_group* g, int source, const luw_export_p
 	const uint32_t S = (uint32_t)std::max<size_t>(1u, std::min<size_t>(nzw, (192ull<<20)/plane_bytes));
 	char* slab[2] = { nullptr, nullptr };
 	struct Pinned { char** p; ~Pinned() { (void)hipHostFree(p[0]); (void)hipHostFree(p[1]); } } pinned{ slab };
-	for(int k=0; k<2; k++) if(hipHostMalloc((void**)&slab[k], (size_t)S*plane_bytes)!=hipSuccess) { slab[k] = nullptr; return fail(LUW_ERR_NOMEM, "luw_group_export_vtk: pinned slab"); }
+	for(int k=0; k<2; k++) if(hipHostMalloc((void**)&slab[k], (size_t)S*plane_bytes)!=hipSuccess) {
+		slab[k] = nullptr;
+		return fail(LUW_ERR_NOMEM, "luw_group_export_vtk: pinned slab");
+	}
 	std::vector<uint32_t*> stage(g->dom.size(), nullptr);
-	struct Stage { std::vector<uint32_t*>& v; luw_group* g; ~Stage() { for(size_t i=0; i<v.size(); i++) { (void)hipSetDevice(g->dom[i].device); (void)hipFree(v[i]); } } } stage_free{ stage, g };
+	struct Stage {
+		std::vector<uint32_t*>& v;
+		luw_group* g;
+		~Stage() { for(size_t i=0; i<v.size(); i++) { (void)hipSetDevice(g->dom[i].device); (void)hipFree(v[i]); } }
+	} stage_free{ stage, g };
 	for(size_t i=0; i<g->dom.size(); i++) {
 		GroupDomain& d = g->dom[i];
 		GROUP_TRY(group_set_device(d));
 		const size_t ox = d.lN[0]-2u*g->H[0], oy = d.lN[1]-2u*g->H[1];
-		if(hipMalloc((void**)&stage[i], (size_t)S*oy*ox*comps*4u)!=hipSuccess) { stage[i] = nullptr; return fail(LUW_ERR_NOMEM, "luw_group_export_vtk: device staging"); }
+		if(hipMalloc((void**)&stage[i], (size_t)S*oy*ox*comps*4u)!=hipSuccess) {
+			stage[i] = nullptr;
+			return fail(LUW_ERR_NOMEM, "luw_group_export_vtk: device staging");
+		}
 	}
 	SlabWriter writer(fd);
 	int slot = 0;
@@ -185,7 +212,12 @@ extern "C" int luw_group_export_vtk(luw_group* g, int source, const luw_export_p
 			luw_solver* s = d.s;
 			ExportSrc e{};
 			e.factor = prm->factor; e.offset = prm->offset; e.affine = prm->affine;
-			e.u_factor = prm->u_factor; e.grid_dx = prm->grid_dx; e.tls_cap = prm->tls_cap; e.want_tke = prm->want_tke; e.want_ti = prm->want_ti; e.want_tls = prm->want_tls;
+			e.u_factor = prm->u_factor;
+			e.grid_dx = prm->grid_dx;
+			e.tls_cap = prm->tls_cap;
+			e.want_tke = prm->want_tke;
+			e.want_ti = prm->want_ti;
+			e.want_tls = prm->want_tls;
 			e.has_m2 = s->avg_count>1ull ? 1 : 0; e.inv_n = e.has_m2 ? 1.0f/(float)s->avg_count : 0.0f;
 			e.gNx = gNx; e.gNy = gNy; e.gNz_out = nzw; e.flags = s->d_flags; e.m2 = s->d_m2;
 			switch(source) {
@@ -197,8 +229,16 @@ extern "C" int luw_group_export_vtk(luw_group* g, int source, const luw_export_p
 			const uint32_t z_local = a-gz0+H2;
 			#define LUW_EXPORT_CASE(SRC) case SRC: hipLaunchKernelGGL((k_export_slab<SRC>), grid, block, 0, d.compute, s->kp, e, z_local, stage[i]); break
 			switch(source) {
-				LUW_EXPORT_CASE(LUW_EXPORT_U); LUW_EXPORT_CASE(LUW_EXPORT_RHO); LUW_EXPORT_CASE(LUW_EXPORT_T); LUW_EXPORT_CASE(LUW_EXPORT_AVG_U); LUW_EXPORT_CASE(LUW_EXPORT_AVG_RHO);
-				LUW_EXPORT_CASE(LUW_EXPORT_AVG_T); LUW_EXPORT_CASE(LUW_EXPORT_FLUID); LUW_EXPORT_CASE(LUW_EXPORT_TKE); LUW_EXPORT_CASE(LUW_EXPORT_TI); LUW_EXPORT_CASE(LUW_EXPORT_TLS);
+				LUW_EXPORT_CASE(LUW_EXPORT_U);
+				LUW_EXPORT_CASE(LUW_EXPORT_RHO);
+				LUW_EXPORT_CASE(LUW_EXPORT_T);
+				LUW_EXPORT_CASE(LUW_EXPORT_AVG_U);
+				LUW_EXPORT_CASE(LUW_EXPORT_AVG_RHO);
+				LUW_EXPORT_CASE(LUW_EXPORT_AVG_T);
+				LUW_EXPORT_CASE(LUW_EXPORT_FLUID);
+				LUW_EXPORT_CASE(LUW_EXPORT_TKE);
+				LUW_EXPORT_CASE(LUW_EXPORT_TI);
+				LUW_EXPORT_CASE(LUW_EXPORT_TLS);
 			}
 			#undef LUW_EXPORT_CASE
 			HIP_TRY(hipGetLastError());

@@ -32,7 +32,8 @@ struct GroupDomain {
 	Box whole{}, interior{};
 	std::vector<Box> shell;
 	std::vector<uint32_t> gather_src;         // probe gather: positions of this domain's cells in the caller's list
-	uint64_t packed_seq[2][3] = {}, unpacked_seq[2][3] = {}; // [DDFs / thermal][axis]: number of the last exchange whose pack / unpack this domain has enqueued (threaded runs)
+	// [DDFs / thermal][axis]: number of the last exchange whose pack / unpack this domain has enqueued (threaded runs)
+	uint64_t packed_seq[2][3] = {}, unpacked_seq[2][3] = {};
 };
 
 struct luw_group {
@@ -63,12 +64,14 @@ static uint32_t group_x_shell(const luw_group* g) {
 // ---- the schedule of ONE domain's share of a decomposed step, shared by both hosts: luw_group_* (all domains in this process) and the one-process-per-GPU
 // driver latticeurbanwind_amd/distributed.py (through luw_domain_step_*; the exchange between its calls is RCCL's).
 // Boxes: whole (non-halo cells), interior, and the disjoint shell slabs covering their difference (cells whose DDFs the pack kernels read).
-static void step_axis_ranges(const uint32_t lN[3], const uint32_t H[3], const uint32_t x_shell, const int a, uint32_t nonhalo[2], uint32_t lo_slab[2], uint32_t hi_slab[2], uint32_t inner[2]) {
+static void step_axis_ranges(const uint32_t lN[3], const uint32_t H[3], const uint32_t x_shell, const int a, uint32_t nonhalo[2], uint32_t lo_slab[2],
+	uint32_t hi_slab[2], uint32_t inner[2]) {
 	nonhalo[0] = H[a]; nonhalo[1] = lN[a]-H[a];
 	if(!H[a]) { lo_slab[0] = lo_slab[1] = hi_slab[0] = hi_slab[1] = 0u; inner[0] = 0u; inner[1] = lN[a]; return; }
 	const uint32_t lo = nonhalo[0], hi = nonhalo[1];
 	if(a!=0) { lo_slab[0] = lo; lo_slab[1] = lo+1u; hi_slab[0] = hi-1u; hi_slab[1] = hi; }   // y, z: the one cell layer next to the halo (whole rows)
-	else { // x: whole blocks of x_shell cells from the first owned cell on (a one-cell x face would run one lane per wave and touch a full memory line per value)
+	// x: whole blocks of x_shell cells from the first owned cell on (a one-cell x face would run one lane per wave and touch a full memory line per value)
+	else {
 		const uint32_t first_end = std::min(lo+x_shell, hi);
 		const uint32_t last_start = std::max(lo+((hi-1u-lo)/x_shell)*x_shell, first_end);
 		lo_slab[0] = lo; lo_slab[1] = first_end; hi_slab[0] = last_start; hi_slab[1] = hi;
@@ -109,7 +112,12 @@ static void group_free(luw_group* g) {
 	for(GroupDomain& d : g->dom) {
 		(void)hipSetDevice(d.device);
 		if(d.s) { (void)luw_set_stream(d.s, nullptr); luw_destroy(d.s); }
-		for(int a=0; a<3; a++) for(int k=0; k<2; k++) { (void)hipFree(d.recv[a][k]); (void)hipFree(d.send[a][k]); (void)hipFree(d.grecv[a][k]); (void)hipFree(d.gsend[a][k]); }
+		for(int a=0; a<3; a++) for(int k=0; k<2; k++) {
+			(void)hipFree(d.recv[a][k]);
+			(void)hipFree(d.send[a][k]);
+			(void)hipFree(d.grecv[a][k]);
+			(void)hipFree(d.gsend[a][k]);
+		}
 		for(hipEvent_t e : { d.shell_done, d.interior_done, d.pre_done, d.stats_done }) if(e) (void)hipEventDestroy(e);
 		for(int a=0; a<3; a++) for(hipEvent_t e : { d.packed[a], d.unpacked[a], d.gpacked[a], d.gunpacked[a] }) if(e) (void)hipEventDestroy(e);
 		if(d.compute) (void)hipStreamDestroy(d.compute);
@@ -151,7 +159,8 @@ static int domain_unpack(luw_group* g, const size_t i, const int a, const bool t
 	HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? P.gpacked : P.packed)[a], 0));
 	HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? M.gpacked : M.packed)[a], 0));
 	GROUP_TRY(luw_set_stream(d.s, st));
-	GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]) : luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
+	GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1])
+		: luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
 	HIP_TRY(hipEventRecord((thermal_pass ? d.gunpacked : d.unpacked)[a], st));
 	return LUW_OK;
 }
@@ -244,7 +253,8 @@ static int group_exchange_rccl_axis(luw_group* g, const int a, const bool therma
 		GroupDomain& d = g->dom[i];
 		const uint32_t to = d.nbr[a][k];
 		const size_t bytes = (size_t)luw_get_area(d.s, (uint32_t)a)*(thermal_pass ? 1u : 5u)*g->ddf_bytes;
-		RCCL_TRY(R->Send((thermal_pass ? d.gsend : d.send)[a][k], bytes, RCCL_UINT8, g->rccl_rank[to], g->rccl_comm[g->rccl_rank[i]], stream_of(g->dom[leader(i)])));
+		RCCL_TRY(R->Send((thermal_pass ? d.gsend : d.send)[a][k], bytes, RCCL_UINT8, g->rccl_rank[to], g->rccl_comm[g->rccl_rank[i]],
+			stream_of(g->dom[leader(i)])));
 	}
 	for(size_t i=0; i<n; i++) for(int k=0; k<2; k++) {
 		GroupDomain& d = g->dom[i];
@@ -266,7 +276,8 @@ static int group_exchange_rccl_axis(luw_group* g, const int a, const bool therma
 		GROUP_TRY(group_set_device(d));
 		if(leader(i)!=i) HIP_TRY(hipStreamWaitEvent(stream_of(d), (thermal_pass ? g->dom[leader(i)].gunpacked : g->dom[leader(i)].unpacked)[a], 0));
 		GROUP_TRY(luw_set_stream(d.s, stream_of(d)));
-		GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]) : luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
+		GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1])
+			: luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
 	}
 	return LUW_OK;
 }
@@ -296,7 +307,8 @@ static int group_join(luw_group* g) {
 
 // what one step means for one domain, besides the exchange: kernels of step i of a luw_group_run call
 struct GroupStepPlan { bool sampled, fused, separate; int wf; };
-static int domain_plan_step(luw_group* g, const size_t k, const uint64_t i, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, GroupStepPlan& pl) {
+static int domain_plan_step(luw_group* g, const size_t k, const uint64_t i, const uint64_t steps, const uint64_t first_sample, const uint64_t stride,
+	GroupStepPlan& pl) {
 	const bool every = luw_fields_every_step(g->dom[k].s)!=0; // the option, or a fluid reference cell on one of this domain's faces (luw_initialize)
 	pl.sampled = stride>0ull && i+1ull>=first_sample && (i+1ull-first_sample)%stride==0ull;
 	pl.fused = false;
@@ -318,7 +330,8 @@ struct StepCtx {
 static int step_launch(const StepCtx& c, const int wf, hipEvent_t t0, hipEvent_t t1, hipEvent_t s0 = nullptr, hipEvent_t s1 = nullptr) {
 	luw_solver* s = c.s;
 	if(c.overlap) {
-		if((wf&1)&&*c.stats_pending) { HIP_TRY(hipStreamWaitEvent(c.comm, c.stats_done, 0)); *c.stats_pending = false; } // this step's shell rewrites the rho,u the last sample reads
+		// this step's shell rewrites the rho,u the last sample reads
+		if((wf&1)&&*c.stats_pending) { HIP_TRY(hipStreamWaitEvent(c.comm, c.stats_done, 0)); *c.stats_pending = false; }
 		HIP_TRY(hipStreamWaitEvent(c.compute, c.shell_done, 0));   // interior(t) needs shell(t-1) ...
 		HIP_TRY(hipStreamWaitEvent(c.comm, c.interior_done, 0));   // ... shell(t) needs interior(t-1); both no-ops before the first record
 		if(s->vk_active) { // pre_step_update (FX/setup.cpp:4872): rewrites u on TYPE_E inlet cells, read by shell and interior
@@ -346,7 +359,8 @@ static int step_launch(const StepCtx& c, const int wf, hipEvent_t t0, hipEvent_t
 	}
 	return LUW_OK;
 }
-static int step_separate_stats(const StepCtx& c) { // thermal lattice / no fused statistics: the step wrote rho,u; the statistics kernel follows on the compute stream
+// thermal lattice / no fused statistics: the step wrote rho,u; the statistics kernel follows on the compute stream
+static int step_separate_stats(const StepCtx& c) {
 	if(c.overlap) HIP_TRY(hipStreamWaitEvent(c.compute, c.shell_done, 0));
 	GROUP_TRY(luw_set_stream(c.s, c.compute));
 	c.s->fields_current = true;
@@ -356,9 +370,12 @@ static int step_separate_stats(const StepCtx& c) { // thermal lattice / no fused
 }
 static StepCtx group_step_ctx(luw_group* g, const size_t k) {
 	GroupDomain& d = g->dom[k];
-	return StepCtx{ d.s, d.compute, d.comm, d.shell_done, d.interior_done, d.pre_done, d.stats_done, &d.stats_pending, g->overlap, &d.whole, &d.interior, &d.shell };
+	return StepCtx{ d.s, d.compute, d.comm, d.shell_done, d.interior_done, d.pre_done, d.stats_done, &d.stats_pending, g->overlap, &d.whole, &d.interior,
+		&d.shell };
 }
-static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1) { return step_launch(group_step_ctx(g, k), pl.wf, t0, t1); }
+static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1) {
+	return step_launch(group_step_ctx(g, k), pl.wf, t0, t1);
+}
 static int domain_separate_stats(luw_group* g, const size_t k) { return step_separate_stats(group_step_ctx(g, k)); }
 
 // ---- one host thread PER DOMAIN (opt-in, LUW_GROUP_THREADS=1; for hosts where one enqueueing thread -- ~25 runtime calls per domain and
@@ -394,7 +411,8 @@ static int domain_exchange_threaded(luw_group* g, const size_t k, const bool the
 	}
 	return LUW_OK;
 }
-static int domain_run_threaded(luw_group* g, const size_t k, const uint64_t steps, const uint64_t first_sample, const uint64_t stride, std::vector<hipEvent_t>* tev, const uint64_t X0, GroupThreads& T) {
+static int domain_run_threaded(luw_group* g, const size_t k, const uint64_t steps, const uint64_t first_sample, const uint64_t stride,
+	std::vector<hipEvent_t>* tev, const uint64_t X0, GroupThreads& T) {
 	GroupDomain& d = g->dom[k];
 	GROUP_TRY(group_set_device(d)); // per host thread
 	for(uint64_t i=0ull; i<steps; i++) {
@@ -444,7 +462,8 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 	// Default: ONE enqueueing thread (measured with eight domains on one device: 44 us per domain and step, i.e. 0.36 ms per step for eight --
 	// well inside a 1.9 ms FP16C step; profiles/r02_group_one_gpu.txt).  LUW_GROUP_THREADS=1 gives every domain its own host thread.
 	const bool threaded = getenv("LUW_GROUP_THREADS")&&getenv("LUW_GROUP_THREADS")[0]=='1'; // read per call: one process can A/B both
-	if(threaded&&steps>=4ull&&g->transport!=LUW_TRANSPORT_RCCL) { // a call of a step or two (probe windows) is not worth starting threads for; RCCL's group calls are issued by ONE thread
+	// a call of a step or two (probe windows) is not worth starting threads for; RCCL's group calls are issued by ONE thread
+	if(threaded&&steps>=4ull&&g->transport!=LUW_TRANSPORT_RCCL) {
 		GroupThreads T; T.error.assign(g->dom.size(), std::string());
 		std::vector<int> rc(g->dom.size(), LUW_OK);
 		const uint64_t X0 = g->exchanges;
@@ -459,7 +478,8 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 		for(size_t k=0; k<g->dom.size(); k++) if(rc[k]!=LUW_OK&&!T.error[k].empty()) return fail(rc[k], T.error[k]);
 		for(size_t k=0; k<g->dom.size(); k++) if(rc[k]!=LUW_OK) return fail(rc[k], "luw_group_run: stopped because another domain failed");
 		g->exchanges = X0+steps; g->t += steps;
-		for(GroupDomain& d : g->dom) for(int f=0; f<2; f++) for(int a=0; a<3; a++) { d.packed_seq[f][a] = g->exchanges; d.unpacked_seq[f][a] = g->exchanges; } // axes / passes that never ran keep in step
+		// axes / passes that never ran keep in step
+		for(GroupDomain& d : g->dom) for(int f=0; f<2; f++) for(int a=0; a<3; a++) { d.packed_seq[f][a] = g->exchanges; d.unpacked_seq[f][a] = g->exchanges; }
 	} else {
 		for(uint64_t i=0ull; i<steps; i++) {
 			GroupStepPlan pl{};
@@ -516,10 +536,12 @@ struct luw_domain_step {
 	std::vector<hipEvent_t> timing; // per timed step: interior (or whole-box) start / end, shell start / end
 };
 static StepCtx domain_step_ctx(luw_domain_step* d) {
-	return StepCtx{ d->s, d->compute, d->comm, d->shell_done, d->interior_done, d->pre_done, d->stats_done, &d->stats_pending, d->overlap, &d->whole, &d->interior, &d->shell };
+	return StepCtx{ d->s, d->compute, d->comm, d->shell_done, d->interior_done, d->pre_done, d->stats_done, &d->stats_pending, d->overlap, &d->whole,
+		&d->interior, &d->shell };
 }
 static void domain_step_drop_timing(luw_domain_step* d) { for(hipEvent_t e : d->timing) if(e) (void)hipEventDestroy(e); d->timing.clear(); }
-int luw_step_boxes(const uint32_t* local_N, const uint32_t* halo, uint32_t x_shell, uint32_t* whole6, uint32_t* interior6, uint32_t* shell_boxes, uint32_t* shell_count, int* can_overlap) {
+int luw_step_boxes(const uint32_t* local_N, const uint32_t* halo, uint32_t x_shell, uint32_t* whole6, uint32_t* interior6, uint32_t* shell_boxes,
+	uint32_t* shell_count, int* can_overlap) {
 	if(!local_N||!halo||x_shell==0u) return fail(LUW_ERR_INVALID, "luw_step_boxes: bad argument");
 	Box w, in; std::vector<Box> sh;
 	step_boxes(local_N, halo, x_shell, w, in, sh);
@@ -589,11 +611,14 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 	const uint32_t D[3] = { cfg->Dx, cfg->Dy, cfg->Dz }, gN[3] = { cfg->Nx, cfg->Ny, cfg->Nz };
 	if(D[0]*D[1]*D[2]==0u) return fail(LUW_ERR_INVALID, "You specified 0 LBM grid domains."); // FX/lbm.cpp:1124
 	if((uint64_t)gN[0]*gN[1]*gN[2]==0ull) return fail(LUW_ERR_INVALID, "Grid point number is 0."); // FX/lbm.cpp:1123
-	for(int a=0; a<3; a++) if(gN[a]%D[a]!=0u) return fail(LUW_ERR_INVALID, "LBM grid is not equally divisible in domains (the caller shrinks it to a multiple first, FX/lbm.cpp:1058-1060)");
+	for(int a=0; a<3; a++) if(gN[a]%D[a]!=0u)
+		return fail(LUW_ERR_INVALID, "LBM grid is not equally divisible in domains (the caller shrinks it to a multiple first, FX/lbm.cpp:1058-1060)");
 	const uint32_t n = D[0]*D[1]*D[2];
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
-	if(!devices&&(int)n+cfg->device>ndev&&n>1u) return fail(LUW_ERR_INVALID, "luw_group_create: fewer HIP devices than domains (pass an explicit device list to share devices)"); // FX/lbm.cpp:961-979
+	// FX/lbm.cpp:961-979
+	if(!devices&&(int)n+cfg->device>ndev&&n>1u)
+		return fail(LUW_ERR_INVALID, "luw_group_create: fewer HIP devices than domains (pass an explicit device list to share devices)");
 	std::unique_ptr<luw_group, void(*)(luw_group*)> g(new luw_group(), group_free);
 	g->gcfg = *cfg;
 	for(int a=0; a<3; a++) { g->D[a] = D[a]; g->gN[a] = gN[a]; g->H[a] = D[a]>1u ? 1u : 0u; }
@@ -646,7 +671,10 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 		(void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
 		HIP_TRY(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking));
 		// shell, pack / unpack and copies on a high-priority queue: they are not to be stuck behind the interior kernel's workgroups
-		if(hipStreamCreateWithPriority(&d.comm, hipStreamNonBlocking, hi)!=hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipStreamCreateWithFlags(&d.comm, hipStreamNonBlocking)); }
+		if(hipStreamCreateWithPriority(&d.comm, hipStreamNonBlocking, hi)!=hipSuccess) {
+			(void)hipGetLastError();
+			HIP_TRY(hipStreamCreateWithFlags(&d.comm, hipStreamNonBlocking));
+		}
 		for(hipEvent_t* e : { &d.shell_done, &d.interior_done, &d.pre_done, &d.stats_done }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
 		for(int a=0; a<3; a++) {
 			for(hipEvent_t* e : { &d.packed[a], &d.unpacked[a], &d.gpacked[a], &d.gunpacked[a] }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -785,7 +813,8 @@ int luw_group_initialize(luw_group* g) { // LBM::initialize, FX/lbm.cpp:1221-126
 	if(!g) return fail(LUW_ERR_INVALID, "luw_group_initialize: null group");
 	for(GroupDomain& d : g->dom) { GROUP_TRY(luw_set_stream(d.s, nullptr)); GROUP_TRY(luw_initialize(d.s)); }
 	if(g->dom.size()>1u) {
-		for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull)); // "the communicate calls at initialization need an odd time step", FX/lbm.cpp:1242
+		// "the communicate calls at initialization need an odd time step", FX/lbm.cpp:1242
+		for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull));
 		GROUP_TRY(group_communicate(g, false));
 		GROUP_TRY(group_join(g));
 		for(GroupDomain& d : g->dom) GROUP_TRY(luw_reset_time_step(d.s)); // FX/lbm.cpp:1258
@@ -821,7 +850,8 @@ static void group_locate(const luw_group* g, const uint64_t n, uint32_t& dom, ui
 	const uint32_t lx = (uint32_t)((int32_t)x-d.O[0]), ly = (uint32_t)((int32_t)y-d.O[1]), lz = (uint32_t)((int32_t)z-d.O[2]);
 	local = (uint64_t)lx+((uint64_t)ly+(uint64_t)lz*d.lN[1])*d.lN[0];
 }
-int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face, const float* point_data, const float* mode_data, int update_stride, int stride_interpolation) {
+int luw_group_vk_inlet_attach(luw_group* g, uint64_t point_count, uint64_t mode_count, const uint64_t* point_cell, const uint8_t* point_face,
+	const float* point_data, const float* mode_data, int update_stride, int stride_interpolation) {
 	if(!g||!point_cell||!point_face||!point_data||!mode_data) return fail(LUW_ERR_INVALID, "luw_group_vk_inlet_attach: null argument");
 	const uint64_t GN = (uint64_t)g->gN[0]*g->gN[1]*g->gN[2];
 	const size_t n = g->dom.size();
@@ -891,7 +921,8 @@ int luw_group_stats_download(luw_group* g, float* avg_u, float* avg_rho, float* 
 		const uint64_t LN = (uint64_t)d.lN[0]*d.lN[1]*d.lN[2];
 		float* lu = buf.get(); float* lr = lu+3ull*LN; float* l2[3] = { lr+LN, lr+2ull*LN, lr+3ull*LN }; float* lT = lr+4ull*LN;
 		uint64_t cnt = 0ull;
-		GROUP_TRY(luw_stats_download(d.s, avg_u ? lu : nullptr, avg_rho ? lr : nullptr, m2_u ? l2[0] : nullptr, m2_v ? l2[1] : nullptr, m2_w ? l2[2] : nullptr, &cnt));
+		GROUP_TRY(luw_stats_download(d.s, avg_u ? lu : nullptr, avg_rho ? lr : nullptr, m2_u ? l2[0] : nullptr, m2_v ? l2[1] : nullptr, m2_w ? l2[2] : nullptr,
+			&cnt));
 		if(avg_T) GROUP_TRY(luw_stats_download_T(d.s, lT));
 		if(count) *count = cnt;
 		const uint32_t H0 = g->H[0], H1 = g->H[1], H2 = g->H[2];

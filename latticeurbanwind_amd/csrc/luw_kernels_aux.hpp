@@ -6,7 +6,8 @@
 // Face cell of thread t and its index a in the transfer buffers.  The buffers keep the reference's order (direction 0:
 // a = y + z Ny; 1: a = z + x Nz; 2: a = x + y Nx, FX/kernel.cpp:2188-2221), but the THREADS walk along x wherever x lies in the
 // face, so that the lattice side of the copy is coalesced (for direction 1 the small buffer side is strided instead).
-template<int DIR> __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t t, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& a) {
+template<int DIR> __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t t, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z,
+	uint32_t& a) {
 	if constexpr(DIR==0) { x = fixed; y = t%p.Ny; z = t/p.Ny; a = t; }
 	else if constexpr(DIR==1) { x = t%p.Nx; y = fixed; z = t/p.Nx; a = x*p.Nz+z; }
 	else { x = t%p.Nx; y = t/p.Nx; z = fixed; a = t; }
@@ -29,41 +30,65 @@ template<int DIR, int PM, int BB> struct TransferIndex {
 // G = false: the 5 D3Q19 populations of a face (fi); G = true: the single D3Q7 population of the thermal lattice (gi, i = side+1,
 // FX/kernel.cpp:2338-2351) -- same slot algebra, the D3Q7 neighbours are the first six of the D3Q19 list.
 // Everything about a population is compile-time (direction is a template parameter), so no per-thread index table exists.
-template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void extract_one(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf, const T* __restrict__ fi) {
+template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void extract_one(const KParams& p, const uint32_t x, const uint32_t y,
+	const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf, const T* __restrict__ fi) {
 	constexpr int i = G ? 2*DIR+PM+1 : TransferIndex<DIR, PM, BB>::value;
 	const uint32_t plane = t_odd ? ((i&1) ? i+1 : i-1) : i;
 	const uint32_t n = (i&1) ? neighbor_index<i>(p, x, y, z) : x+(y+z*p.Ny)*p.Px;
 	buf[(size_t)BB*A+a] = fi[(size_t)plane*p.Np+n];
 }
-template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void insert_one(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf, T* __restrict__ fi) {
+template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__ void insert_one(const KParams& p, const uint32_t x, const uint32_t y,
+	const uint32_t z, const uint32_t a, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf, T* __restrict__ fi) {
 	constexpr int i = G ? 2*DIR+PM+1 : TransferIndex<DIR, PM, BB>::value;
 	const uint32_t plane = t_odd ? i : ((i&1) ? i+1 : i-1);
 	const uint32_t n = (i&1) ? x+(y+z*p.Ny)*p.Px : neighbor_index<i-1>(p, x, y, z);
 	fi[(size_t)plane*p.Np+n] = buf[(size_t)BB*A+a];
 }
-template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t A, const uint32_t t_odd, T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
+template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t A, const uint32_t t_odd,
+	T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
 	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
 	if(t>=A) return;
 	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
 	uint32_t x, y, z, a;
 	face_cell<DIR>(p, t, Nd-2u, x, y, z, a);
 	extract_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
-	if constexpr(!G) { extract_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi); extract_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi); }
+	if constexpr(!G) {
+		extract_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		extract_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		extract_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		extract_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	}
 	face_cell<DIR>(p, t, 1u, x, y, z, a);
 	extract_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
-	if constexpr(!G) { extract_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi); extract_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi); }
+	if constexpr(!G) {
+		extract_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		extract_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		extract_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		extract_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	}
 }
-template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t A, const uint32_t t_odd, const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
+template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t A, const uint32_t t_odd,
+	const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
 	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
 	if(t>=A) return;
 	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
 	uint32_t x, y, z, a;
 	face_cell<DIR>(p, t, Nd-1u, x, y, z, a);
 	insert_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
-	if constexpr(!G) { insert_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi); insert_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi); }
+	if constexpr(!G) {
+		insert_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		insert_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		insert_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		insert_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	}
 	face_cell<DIR>(p, t, 0u, x, y, z, a);
 	insert_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
-	if constexpr(!G) { insert_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi); insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi); }
+	if constexpr(!G) {
+		insert_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		insert_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		insert_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	}
 }
 // ---------------------------------------------------------------- mesh voxeliser
 // voxelize_mesh with direction 2 (z rays; LUW always voxelises TYPE_S along z, FX/lbm.cpp:1427-1430) for a static mesh:
@@ -76,14 +101,17 @@ template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_i
 __device__ __forceinline__ float vdot(const float ax, const float ay, const float az, const float bx, const float by, const float bz) {
 	return fmaf(az, bz, fmaf(ay, by, ax*bx)); // dot(float3) of the OpenCL device library: mad(z, z', mad(y, y', x*x'))
 }
-struct VoxGrid { uint32_t Nx, Ny, Nz, Px; int Ox, Oy, Oz; uint64_t Np; }; // lattice of the pass: a solver domain, or a bare global lattice (luw_voxelize_lattice)
+// lattice of the pass: a solver domain, or a bare global lattice (luw_voxelize_lattice)
+struct VoxGrid { uint32_t Nx, Ny, Nz, Px; int Ox, Oy, Oz; uint64_t Np; };
 // One block = one 16x16 tile of columns; it visits only the triangles binned to the tile (tile_start / tile_tri: CSR, triangle
 // ids ascending, so hits are met in the reference's order and the 64-entry cut-off falls on the same hits).  The bins hold
 // every triangle whose xy bounding box, grown by one cell, touches the tile -- the margin the reference itself uses when it
 // hands a domain its triangle subset (FX/lbm.cpp:1455-1487).
 constexpr uint32_t VOX_TILE = 16u;
-__global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_tri,
-		const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2, const float x0, const float y0, const float z0, const float x1, const float y1, const float z1) {
+__global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __restrict__ flags, const float* __restrict__ u, const uint8_t flag,
+	const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_tri,
+		const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2, const float x0, const float y0, const float z0,
+			const float x1, const float y1, const float z1) {
 	const uint32_t x = blockIdx.x*VOX_TILE+threadIdx.x%VOX_TILE, y = blockIdx.y*VOX_TILE+threadIdx.x/VOX_TILE;
 	if(x>=p.Nx||y>=p.Ny) return;
 	const uint32_t tile = blockIdx.x+blockIdx.y*gridDim.x, k0 = tile_start[tile], k1 = tile_start[tile+1u];
@@ -127,7 +155,8 @@ __global__ __launch_bounds__(256) void k_voxelize_z(const VoxGrid p, uint8_t* __
 		const uint64_t n = (uint64_t)x+((uint64_t)y+(uint64_t)h*p.Ny)*p.Px;
 		uint8_t fl = flags[n];
 		if(inside) fl = (uint8_t)((fl&~TYPE_BO)|flag);
-		else if((fl&TYPE_BO)==TYPE_S&&(!u||(u[n]==0.0f&&u[p.Np+n]==0.0f&&u[2ull*p.Np+n]==0.0f))) fl = (uint8_t)(fl&~flag); // was solid with the mesh's velocity (static: 0), FX/kernel.cpp:2451-2462
+		// was solid with the mesh's velocity (static: 0), FX/kernel.cpp:2451-2462
+		else if((fl&TYPE_BO)==TYPE_S&&(!u||(u[n]==0.0f&&u[p.Np+n]==0.0f&&u[2ull*p.Np+n]==0.0f))) fl = (uint8_t)(fl&~flag);
 		flags[n] = fl;
 	}
 }
@@ -147,8 +176,10 @@ __global__ void k_gather_u(const uint32_t count, const uint32_t* __restrict__ ce
 // point_cell = nullptr: the values go to a PACKED buffer (u[c*Np + i], Np = P) instead of the lattice -- the evaluation of the NEXT
 // step's inlet values then runs beside the current step on another stream (VALU-bound here, HBM-bound there) and k_vk_scatter puts
 // them into place in a few microseconds.
-__global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint32_t P, const uint32_t M, const uint32_t V,
-		const uint32_t* __restrict__ point_cell, const uint8_t* __restrict__ point_face, const float* __restrict__ point_data, const float* __restrict__ mode_data, float* __restrict__ u, const size_t Np) {
+__global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_interp, const float t0, const float t1, const float alpha, const uint32_t P,
+	const uint32_t M, const uint32_t V,
+		const uint32_t* __restrict__ point_cell, const uint8_t* __restrict__ point_face, const float* __restrict__ point_data,
+			const float* __restrict__ mode_data, float* __restrict__ u, const size_t Np) {
 	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
 	if(i>=P) return;
 	const uint32_t n = point_cell ? point_cell[i] : i;
@@ -178,7 +209,8 @@ __global__ __launch_bounds__(256) void k_vk_inlet_apply(const uint32_t use_inter
 	u[2ull*Np+n] = fmaf(sigma, qz, ubz);
 }
 
-__global__ __launch_bounds__(256) void k_vk_scatter(const uint32_t P, const uint32_t* __restrict__ point_cell, const float* __restrict__ val, float* __restrict__ u, const size_t Np) {
+__global__ __launch_bounds__(256) void k_vk_scatter(const uint32_t P, const uint32_t* __restrict__ point_cell, const float* __restrict__ val,
+	float* __restrict__ u, const size_t Np) {
 	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
 	if(i>=P) return;
 	const uint32_t n = point_cell[i];
@@ -220,7 +252,11 @@ __global__ __launch_bounds__(256) void k_codec_check(unsigned long long* __restr
 	const uint32_t tid = blockIdx.x*blockDim.x+threadIdx.x, nth = gridDim.x*blockDim.x;
 	unsigned long long bad = 0ull;
 	for(uint32_t c=tid; c<65536u; c+=nth) bad += __float_as_uint(half_to_float_custom(c))!=__float_as_uint(half_to_float_custom_ref(c));
-	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) { if(((uint32_t)v&0x7F800000u)>=(230u<<23)) continue; const float x = __uint_as_float((uint32_t)v); bad += float_to_half_custom(x)!=float_to_half_custom_ref(x); }
+	for(unsigned long long v=tid; v<(1ull<<32); v+=nth) {
+		if(((uint32_t)v&0x7F800000u)>=(230u<<23)) continue;
+		const float x = __uint_as_float((uint32_t)v);
+		bad += float_to_half_custom(x)!=float_to_half_custom_ref(x);
+	}
 	// the product kernel's 3-instruction encode (fp16c_encode19_hi_rtz_final): every bit pattern except NaNs, under RTZ; the
 	// reference formula it is compared with is integer-only, so the mode does not touch it
 	asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(bad));
@@ -249,7 +285,8 @@ __device__ __forceinline__ void arith_check_denominator(const uint32_t db, unsig
 		const float n = __uint_as_float(nb);
 		const uint32_t want = __float_as_uint(n/d), got = __float_as_uint(div_by(n, R));
 		bad_div += (want!=got)&&(((want|got)&0x7FFFFFFFu)!=0u);
-		const float ng = (float)((int32_t)(h>>7)-(1<<24))*0x1p-25f;   // a multiple of 2^-25 below 1/2 in magnitude: what the moment sums of FP16C populations are
+		// a multiple of 2^-25 below 1/2 in magnitude: what the moment sums of FP16C populations are
+		const float ng = (float)((int32_t)(h>>7)-(1<<24))*0x1p-25f;
 		const uint32_t wg = __float_as_uint(ng/d), gg = __float_as_uint(div_by(ng, R));
 		bad_grid += (wg!=gg)&&(((wg|gg)&0x7FFFFFFFu)!=0u);
 	}

@@ -36,7 +36,8 @@ __device__ __forceinline__ void neighbors(const KParams& p, const uint32_t x, co
 	j[17] = x +yp+zm; j[18] = x +ym+zp;
 }
 
-template<typename T> __global__ __launch_bounds__(256) void k_initialize(const KParams p, T* __restrict__ fi, const float* __restrict__ rho, float* __restrict__ u, const uint8_t* __restrict__ flags, T* __restrict__ gi, const float* __restrict__ Tf) {
+template<typename T> __global__ __launch_bounds__(256) void k_initialize(const KParams p, T* __restrict__ fi, const float* __restrict__ rho,
+	float* __restrict__ u, const uint8_t* __restrict__ flags, T* __restrict__ gi, const float* __restrict__ Tf) {
 	const uint32_t x = blockIdx.x*blockDim.x+threadIdx.x, y = blockIdx.y, z = blockIdx.z;
 	if(x>=p.Nx) return;
 	if(cell_is_halo(p, x, y, z)) return;
@@ -87,7 +88,8 @@ struct StatsArgs { float* avg_u; float* avg_rho; float* m2; float inv_n; };
 #ifndef LUW_STATS_NT
 #define LUW_STATS_NT true   /* cache policy of the scalar kernels' statistics accesses (A/B: -DLUW_STATS_NT=false) */
 #endif
-__device__ __forceinline__ void stats_welford(const size_t Np, const StatsArgs& S, const uint32_t n, const float r, const float ux, const float uy, const float uz) {
+__device__ __forceinline__ void stats_welford(const size_t Np, const StatsArgs& S, const uint32_t n, const float r, const float ux, const float uy,
+	const float uz) {
 	const float v[3] = { ux, uy, uz };
 	float mean[3], m2n[3];
 	#pragma unroll
@@ -139,13 +141,15 @@ __device__ __forceinline__ void stats_welford_pair(const size_t Np, const StatsA
 // Stored as such, without arithmetic: a wave runs this branch AFTER its fluid lanes have gone through the kernel's tail, i.e.
 // with the FP16C kernels' round-toward-zero mode already set (the mode is per wave, not per lane) -- no floating-point
 // instruction may sit here (tests/test_isa_contract.py follows the control flow behind the switch).
-__device__ __forceinline__ void stats_hold_constant_cell(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho, const float* __restrict__ u) {
+__device__ __forceinline__ void stats_hold_constant_cell(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho,
+	const float* __restrict__ u) {
 	#pragma unroll
 	for(int c=0; c<3; c++) { stg<true>(S.avg_u+c*Np+n, u[c*Np+n]); stg<true>(S.m2+c*Np+n, 0.0f); }
 	stg<true>(S.avg_rho+n, rho[n]);
 }
 // a cell whose fields are inputs (TYPE_E): the sample is what rho,u hold
-__device__ __forceinline__ void stats_welford_from_fields(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho, const float* __restrict__ u) {
+__device__ __forceinline__ void stats_welford_from_fields(const size_t Np, const StatsArgs& S, const uint32_t n, const float* __restrict__ rho,
+	const float* __restrict__ u) {
 	stats_welford(Np, S, n, rho[n], u[n], u[Np+n], u[2ull*Np+n]);
 }
 

@@ -1,4 +1,5 @@
-// luw_kernels_step.hpp -- the product collide-stream kernels: k_stream_collide_s (1 cell per lane) and k_stream_collide_p (FP16C, 2 cells per lane), with their addressing
+// luw_kernels_step.hpp -- the product collide-stream kernels: k_stream_collide_s (1 cell per lane) and k_stream_collide_p (FP16C, 2 cells per lane), with their
+// addressing
 // Device code of libluw_core.so; included by luw_core.hip only (after luw_device.hpp, inside `using namespace luw`).
 #pragma once
 
@@ -91,7 +92,13 @@ template<typename T> struct CellAddr<T, true> {
 	NbrOff o; uint32_t n;
 	__device__ __forceinline__ size_t init(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z, const bool noshift) {
 		o = neighbor_offsets<T>(p, x, y, z);
-		if(noshift) { o.j1 = o.n; o.j7 = o.j3; o.j9 = o.j5; o.j13 = (x+(y==0u ? p.Ny-1u : y-1u)*p.Px+z*p.Px*p.Ny)*(uint32_t)sizeof(T); o.j15 = (x+y*p.Px+(z==0u ? p.Nz-1u : z-1u)*p.Px*p.Ny)*(uint32_t)sizeof(T); }
+		if(noshift) {
+			o.j1 = o.n;
+			o.j7 = o.j3;
+			o.j9 = o.j5;
+			o.j13 = (x+(y==0u ? p.Ny-1u : y-1u)*p.Px+z*p.Px*p.Ny)*(uint32_t)sizeof(T);
+			o.j15 = (x+y*p.Px+(z==0u ? p.Nz-1u : z-1u)*p.Px*p.Ny)*(uint32_t)sizeof(T);
+		}
 		n = o.n/(uint32_t)sizeof(T);
 		return 0u;
 	}
@@ -101,7 +108,9 @@ template<typename T> struct CellAddr<T, true> {
 	__device__ __forceinline__ uint32_t jx() const { return o.j1/(uint32_t)sizeof(T); }
 	__device__ __forceinline__ uint32_t jy() const { return o.j3/(uint32_t)sizeof(T); }
 	__device__ __forceinline__ uint32_t jz() const { return o.j5/(uint32_t)sizeof(T); }
-	__device__ __forceinline__ void redefine() { asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17)); }
+	__device__ __forceinline__ void redefine() {
+		asm volatile("" : "+v"(o.n), "+v"(o.j1), "+v"(o.j3), "+v"(o.j5), "+v"(o.j7), "+v"(o.j9), "+v"(o.j11), "+v"(o.j13), "+v"(o.j15), "+v"(o.j17));
+	}
 };
 
 // MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
@@ -115,8 +124,11 @@ template<typename T> struct CellAddr<T, true> {
 #define LUW_MAXW_F32 4
 #endif
 // STATS: this step is a statistics sample (stats_welford, luw_kernels_common.hpp); product MODE 0 only.
-template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8))) void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
-		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, const StatsArgs S = StatsArgs{}) {
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8)))
+void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr,
+		const StatsArgs S = StatsArgs{}) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
 	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
@@ -151,7 +163,8 @@ template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STA
 			collide_cell<true, NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
 			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
 		} else
-		collide_cell<(MODE!=3), NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn); // MODE 3: general path only (A/B)
+		// MODE 3: general path only (A/B)
+		collide_cell<(MODE!=3), NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
 			u[n] = uxn;
@@ -257,8 +270,10 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 #define LUW_THERMAL_WAVES_ANY 4
 #endif
 constexpr int pair_waves(const int force, const bool park, const bool thermal = false) {
-	if(thermal) return force==PAIR_FORCE_NONE ? LUW_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_THERMAL_WAVES_UNIFORM : LUW_THERMAL_WAVES_ANY; // (a wave more each spills to scratch)
-	return park ? (force==PAIR_FORCE_NONE ? LUW_PARK_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_PARK_WAVES_UNIFORM : LUW_PARK_WAVES_ANY) : (force==PAIR_FORCE_ANY ? 4 : 5);
+	// (a wave more each spills to scratch)
+	if(thermal) return force==PAIR_FORCE_NONE ? LUW_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_THERMAL_WAVES_UNIFORM : LUW_THERMAL_WAVES_ANY;
+	return park ? (force==PAIR_FORCE_NONE ? LUW_PARK_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_PARK_WAVES_UNIFORM : LUW_PARK_WAVES_ANY)
+		: (force==PAIR_FORCE_ANY ? 4 : 5);
 }
 #ifndef LUW_PAIR_PREFETCH
 #define LUW_PAIR_PREFETCH 1 /* general parked instantiation: nudging / sponge references fetched with the DDF loads (fetch_force_refs) */
@@ -267,12 +282,17 @@ constexpr int pair_waves(const int force, const bool park, const bool thermal = 
 #define LUW_PAIR_OWN_EARLY 1
 #endif
 constexpr bool pair_prefetch(const int force, const bool park) { return LUW_PAIR_PREFETCH!=0 && park && force==PAIR_FORCE_ANY; }
-constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force = PAIR_FORCE_NONE) { return ((thermal ? 26u : 19u)+(pair_prefetch(force, true) ? 8u : 0u))*64u*4u; }
+constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force = PAIR_FORCE_NONE) {
+	return ((thermal ? 26u : 19u)+(pair_prefetch(force, true) ? 8u : 0u))*64u*4u;
+}
 // THERMAL (LUW_OPT_TEMPERATURE): the D3Q7 lattice of both cells the same way -- seven more dwords per lane (plane 0 and the three (A, B) pairs of
 // +x, +y, +z: the +x plane on a 2-byte boundary like the five x+1 planes of the D3Q19 lattice), the cell update of luw_device.hpp (thermal_cell)
 // behind each collision with the velocity before the force shift, the seven codes of both cells merged per plane at the tail.
-template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL), pair_waves(FORCE, PARK, THERMAL)))) void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
-		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{}, uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL), pair_waves(FORCE, PARK, THERMAL))))
+void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{},
+		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
 	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
@@ -294,8 +314,18 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 	if(tail) proc[1] = false;                                      // passes through: reads and rewrites padding, except on the x+1 planes (below)
 	// STATS: a cell that is not updated but belongs to the lattice (solid) samples the fields it holds
 	[[maybe_unused]] PairSample smp;
-	[[maybe_unused]] auto sample_from_fields = [&](const int c) { smp.r[c] = rho[n+c]; smp.ux[c] = u[n+c]; smp.uy[c] = u[Np+n+c]; smp.uz[c] = u[2ull*Np+n+c]; smp.has[c] = true; };
-	[[maybe_unused]] auto sample_idle_cell = [&](const int c) { smp.r[c] = smp.ux[c] = smp.uy[c] = smp.uz[c] = 0.0f; smp.has[c] = false; if(!(c==1&&tail) && !cell_is_halo(p, x+c, y, z)) sample_from_fields(c); };
+	[[maybe_unused]] auto sample_from_fields = [&](const int c) {
+		smp.r[c] = rho[n+c];
+		smp.ux[c] = u[n+c];
+		smp.uy[c] = u[Np+n+c];
+		smp.uz[c] = u[2ull*Np+n+c];
+		smp.has[c] = true;
+	};
+	[[maybe_unused]] auto sample_idle_cell = [&](const int c) {
+		smp.r[c] = smp.ux[c] = smp.uy[c] = smp.uz[c] = 0.0f;
+		smp.has[c] = false;
+		if(!(c==1&&tail) && !cell_is_halo(p, x+c, y, z)) sample_from_fields(c);
+	};
 	if(!proc[0]&&!proc[1]) {
 		if constexpr(STATS) { // two idle cells (solid / halo / padding): constants, stored without arithmetic (stats_hold_constant_cell)
 			if(!cell_is_halo(p, x, y, z)) stats_hold_constant_cell(Np, S, n, rho, u);
@@ -347,7 +377,8 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 	// specialised modes: TYPE_E cells decode to f = 0 (collide_cell_pk relaxes them with w = 1)
 	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;
 	// (only cells that are collided: a halo or padding cell passes what it decodes through unchanged, whatever its flag)
-	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&proc[0]&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u, (E_BY_RATE&&proc[1]&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
+	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&proc[0]&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u,
+		(E_BY_RATE&&proc[1]&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
 	// one cell: decode its half of the 19 dwords into f0 and the nine (f[2k+1], f[2k+2]) pairs, collide on the packed pairs
 	// (or pre-swap for the pass-through)
 	auto one_cell = [&](const int c, float& f0, f32x2* fp, [[maybe_unused]] float* g) {
@@ -378,10 +409,12 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
 			[[maybe_unused]] float u0[3];
-			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c] : nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
+			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c]
+				: nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
 			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
-				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of being
+				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of
+				// being
 				// hoisted in front of both collisions, where the pair of registers it occupied made the uniform-force kernel spill to scratch at 96 VGPRs)
 				uint32_t nw = n+(uint32_t)c;
 				asm volatile("" : "+v"(nw));
@@ -449,7 +482,8 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 		if constexpr(!PARK) asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]));
 	}
 	// ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
-	if constexpr(PARK) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" ::: "memory"); else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");
+	if constexpr(PARK) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" ::: "memory");
+	else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");
 	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
 	uint32_t ca[19], cb[19];
 	cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
@@ -458,7 +492,10 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 	if constexpr(PARK) {
 		ca[0] = fp16c_code_hi_in_rtz_mode(__uint_as_float(slot[0]));
 		#pragma unroll
-		for(int k=0; k<9; k++) { const f32x2 v = { __uint_as_float(slot[64*(2*k+1)]), __uint_as_float(slot[64*(2*k+2)]) }; fp16c_code2_hi_in_rtz_mode(v, ca[2*k+1], ca[2*k+2]); }
+		for(int k=0; k<9; k++) {
+			const f32x2 v = { __uint_as_float(slot[64*(2*k+1)]), __uint_as_float(slot[64*(2*k+2)]) };
+			fp16c_code2_hi_in_rtz_mode(v, ca[2*k+1], ca[2*k+2]);
+		}
 	} else {
 		ca[0] = fp16c_code_hi_in_rtz_mode(fa0);
 		#pragma unroll
@@ -528,7 +565,11 @@ template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, boo
 				B[0] = (uint16_t)(cs[k]>>16);
 			}
 		});
-		if constexpr(THERMAL) { uint16_t* B = gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb); B[p.Nx-1u] = (uint16_t)(cg[1]&0xFFFFu); B[0] = (uint16_t)(cg[1]>>16); }
+		if constexpr(THERMAL) {
+			uint16_t* B = gi+(size_t)slotB<PARITY>(1)*Np+nrow<1>(rb);
+			B[p.Nx-1u] = (uint16_t)(cg[1]&0xFFFFu);
+			B[0] = (uint16_t)(cg[1]>>16);
+		}
 	}
 	#undef LUW_REDEFINE_OFFSETS
 	#undef Np

@@ -1,4 +1,5 @@
-// luw_kernels_vec.hpp -- A/B only: k_stream_collide_v, V cells per lane with aligned accesses and wave64 lane shifts (parity-tested, slower than the product kernels)
+// luw_kernels_vec.hpp -- A/B only: k_stream_collide_v, V cells per lane with aligned accesses and wave64 lane shifts (parity-tested, slower than the product
+// kernels)
 // Device code of libluw_core.so; included by luw_core.hip only (after luw_device.hpp, inside `using namespace luw`).
 #pragma once
 
@@ -39,7 +40,8 @@ template<> __device__ __forceinline__ float lane_up<float>(const float v) { retu
 // vectors; lanes on the box edge (or holding row padding) store element-wise and only what in-box cells own, so a
 // launch never writes a DDF slot owned by a cell outside its box (required when halo unpack / shell passes of the
 // multi-GPU driver run concurrently on another stream).
-template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k_stream_collide_v(const KParams p, const Box b, const uint32_t nchunk, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
+template<typename T, int V, int PARITY> __global__ __launch_bounds__(256) void k_stream_collide_v(const KParams p, const Box b, const uint32_t nchunk,
+	T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields) {
 	const uint32_t kfirst = b.x0/V, klast = (b.x1-1u)/V;
 	const uint32_t chunk = blockIdx.x%nchunk, rowblock = blockIdx.x/nchunk;

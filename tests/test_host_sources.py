@@ -23,6 +23,14 @@ def test_line_and_file_limits():
     assert {k: v for k, v in long_files.items() if v > 400} == {}
 
 
+def test_kernel_sources_and_header_keep_the_line_limit():
+    csrc = os.path.join(ROOT, "latticeurbanwind_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(ROOT, "include", "luw_core.h")]
+    assert len(files) >= 9
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reflow_cpp.py"), "--check", "--limit", "160"] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+
+
 def test_main_is_the_list_of_sections():
     text = open(os.path.join(HOST, "luw_driver.cpp")).read()
     body = text[text.index("int main("):]
