@@ -40,7 +40,8 @@ WORKLOADS = {   # name -> (lattice, building array, BASELINE.json reference)
     "c3": ((1024, 1024, 256), True, "BASELINE configs[2]"),
     "c2": ((512, 512, 512), False, "BASELINE configs[1]"),
     "cube1024": ((1024, 1024, 1024), False, "north-star 1024^3-class grid"),
-    "tile512": ((512, 512, 512), True, "one GPU's share of the BASELINE configs[3] / [4] urban tile (the N = 1 point of the N > 1 lines; --urban adds its nudging + sponge)"),
+    "tile512": ((512, 512, 512), True,
+        "one GPU's share of the BASELINE configs[3] / [4] urban tile (the N = 1 point of the N > 1 lines; --urban adds its nudging + sponge)"),
 }
 
 
@@ -118,11 +119,15 @@ def reference_parity():
         h, f = read_vtk(glob.glob(os.path.join(tmp, "CaseB", "RESULTS", "vtk", "*_raw_u-000000064.vtk"))[0])
         fac = np.float32(5.0) / np.float32(0.1)                      # si_ref_u = max profile U = 5 m/s, u_lbm = 0.1
         d = ((f["data"] - gold["u64"]) / fac)[~gold["solid"]].astype(np.float64)
-        return {"u_rmse_vs_reference": float(np.sqrt((d ** 2).sum(-1).mean())), "unit": "lattice units", "steps": 64, "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)",
+        return {"u_rmse_vs_reference": float(np.sqrt((d ** 2).sum(-1).mean())), "unit": "lattice units", "steps": 64,
+            "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)",
                 "lattice": [48, 40, 24], "cells": 48 * 40 * 24, "tolerance": 1e-5,
-                "horizon": "K = 64 steps on 46 k cells is the ONLY horizon pinned by outputs of the real reference (17 committed cases, FP32 and shipped FP16C builds, "
-                           "tests/golden/ref_*.npz); beyond it the chain is HIP path == CPU oracle bit for bit (literal 128^3 configs[0] at K = 100 turbulent and K = 1000 laminar, "
-                           "tests/test_gpu_c1.py; the bench workloads at full size, tests/test_gpu_bench_workloads.py) and oracle vs reference 0.5-1.3e-7 (FP32) at K = 64"}
+                "horizon": "K = 64 steps on 46 k cells is the ONLY horizon pinned by outputs of the real reference (17 committed cases, FP32 and shipped FP16C "
+                    "builds, "
+                           "tests/golden/ref_*.npz); beyond it the chain is HIP path == CPU oracle bit for bit (literal 128^3 configs[0] at K = 100 turbulent "
+                               "and K = 1000 laminar, "
+                           "tests/test_gpu_c1.py; the bench workloads at full size, tests/test_gpu_bench_workloads.py) and oracle vs reference 0.5-1.3e-7 "
+                               "(FP32) at K = 64"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -185,8 +190,10 @@ def cpu_baseline(max_seconds=20.0):
     mlups = N ** 3 * steps / dt / 1e6
     copy_gbps = oracle.copy_bandwidth_gbps(1 << 30)          # read 1 GiB + write 1 GiB with the same OpenMP threads
     return {"value": round(mlups, 1), "unit": "MLUPS", "cores": best_t, "kind": "port", "cpu_model": cpu_model(),
-            "dram_GBps": round(mlups * 169.0 / 1e3, 1), "copy_bandwidth_GBps": round(copy_gbps, 1), "dram_frac_of_copy": round(mlups * 169.0 / 1e3 / copy_gbps, 3) if copy_gbps else None,
-            "sample": "%d steps of a 256^3 FP32 channel (same recipe as the GPU workloads, 169 B per update incl. rho,u every step) in %.1f s, OpenMP threads swept over %s of %d usable cores" % (steps, dt, cands, cores)}
+            "dram_GBps": round(mlups * 169.0 / 1e3, 1), "copy_bandwidth_GBps": round(copy_gbps, 1),
+                "dram_frac_of_copy": round(mlups * 169.0 / 1e3 / copy_gbps, 3) if copy_gbps else None,
+            "sample": "%d steps of a 256^3 FP32 channel (same recipe as the GPU workloads, 169 B per update incl. rho,u every step) in %.1f s, OpenMP threads "
+                "swept over %s of %d usable cores" % (steps, dt, cands, cores)}
 
 
 def device_context(torch, device):
@@ -223,28 +230,33 @@ def device_context(torch, device):
 
 
 def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False, urban=False):
-    return "%s_%dx%dx%d%s%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_urban" if urban else "", "_cor" if coriolis else "", "_th" if thermal else "", "_uf" if every_step else "")
+    return "%s_%dx%dx%d%s%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_urban" if urban else "", "_cor" if coriolis else "",
+        "_th" if thermal else "", "_uf" if every_step else "")
 
 
 def attach_traffic(roof, key, kernel):
     """HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same workload
     (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
     and keyed on the full configuration; null when no profile of exactly this workload exists"""
-    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (3, 2)) if os.path.exists(q)), None)   # newest round first
+    # newest round first
+    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (3, 2)) if os.path.exists(q)), None)
     if kernel == "auto" and prof:
         pr = json.load(open(prof))
         roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
         roof["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"
 
 
-def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, coriolis=False, thermal=False, every_step=False, kernel_name="auto", keep=None, urban=False):
+def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, coriolis=False, thermal=False, every_step=False, kernel_name="auto", keep=None,
+        urban=False):
     """one single-GPU workload: create, fill the host mirrors in place, upload + initialise, W warm-up steps, K timed steps.
     Returns the measurement block (MLUPS, ms/step, roofline of the stream_collide kernel)."""
     import torch
     Nx, Ny, Nz = size
     fp16c = dtype == "fp16c"
-    nud, spg = tile_forcing() if urban else (None, None)          # urban: buffer nudging + top sponge of the 8-GPU tile (general kernel on two thirds of the cells)
-    lbm = luw.LBM(Nx, Ny, Nz, NU, fp16c=fp16c, kernel=kern, device=device, update_fields_every_step=every_step, alpha=(2.1e-7 if thermal else None), buffer_nudging=nud, top_sponge=spg)
+    # urban: buffer nudging + top sponge of the 8-GPU tile (general kernel on two thirds of the cells)
+    nud, spg = tile_forcing() if urban else (None, None)
+    lbm = luw.LBM(Nx, Ny, Nz, NU, fp16c=fp16c, kernel=kern, device=device, update_fields_every_step=every_step, alpha=(2.1e-7 if thermal else None),
+        buffer_nudging=nud, top_sponge=spg)
     try:
         fill_channel(lbm.flags.data, lbm.u.data, lbm.rho.data, Nx, Ny, Nz, buildings=buildings)
         solid = int(np.count_nonzero((lbm.flags.data & 3) == 1))
@@ -266,12 +278,16 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(launch_bytes),
-            "note": "achieved = (%g B x %d non-solid cells + 1 flag byte x %d solid cells) / mean stream_collide duration (HIP events on the launch stream)" % (bpl, cells - solid, solid)}
+            "note": "achieved = (%g B x %d non-solid cells + 1 flag byte x %d solid cells) / mean stream_collide duration (HIP events on the launch stream)" % (
+                bpl, cells - solid, solid)}
     attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step, urban), kernel_name)
     mlups = cells * steps / dt / 1e6
     return {"value": round(mlups, 1), "unit": "MLUPS", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
-            "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5), "bytes_per_lup": bpl,
-            "options": ("building array" if buildings else "no solids above the ground plane") + (" + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "") + (" + Coriolis force" if coriolis else "") + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
+            "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5),
+                "bytes_per_lup": bpl,
+            "options": ("building array" if buildings else "no solids above the ground plane")
+                + (" + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "") + (" + Coriolis force" if coriolis else "")
+                + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
             "roofline": roof}
 
 
@@ -316,16 +332,22 @@ def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, wa
     owned = (gN[0] // D[0]) * (gN[1] // D[1]) * (gN[2] // D[2])
     bpl = BYTES_PER_LUP["fp16c" if fp16c else "f32"]
     ms = dt / steps * 1e3
-    return {"value": round(owned / (ms * 1e-3) / 1e6, 1), "unit": "MLUPS (this rank's owned cells per wall second)", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
-            "n_gpu": list(D), "rank": rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "dtype": "fp16c-storage/f32-arithmetic" if fp16c else "f32",
-            "workload": "rank %d of the 2048x1024x512 urban tile as n_gpu=%s" % (rank, list(D)) if world > 1 else "512^3 urban tile, undivided (the N = 1 point of the N > 1 lines)",
+    return {"value": round(owned / (ms * 1e-3) / 1e6, 1), "unit": "MLUPS (this rank's owned cells per wall second)", "ms_per_step": round(ms, 4),
+        "steps": steps, "warmup": warmup,
+            "n_gpu": list(D), "rank": rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "dtype": "fp16c-storage/f32-arithmetic"
+                if fp16c else "f32",
+            "workload": "rank %d of the 2048x1024x512 urban tile as n_gpu=%s" % (rank, list(D)) if world > 1
+                else "512^3 urban tile, undivided (the N = 1 point of the N > 1 lines)",
             "options": "building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" + (" + Coriolis force" if coriolis else ""),
             "halo_exchange": "RCCL self send / receive of every face (no wire to another device)" if world > 1 else None, "overlap": bool(sim.overlap),
             "kernel_ms": round(tm["kernel_ms"], 4) if tm else None, "shell_ms": None if not tm or tm.get("shell_ms") is None else round(tm["shell_ms"], 4),
             "exchange_ms": None if not tm or tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
-            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": round(bpl * owned / (ms * 1e-3) / 1e9, 1), "frac": round(bpl * owned / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "kernel_frac": round(bpl * kcells / (tm["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tm and tm.get("kernel_ms") else None, "traffic": None,
-                         "note": "frac = %g B/LUP x %d owned cells / wall time of a whole step (shell + exchange + interior); kernel_frac = the %s kernel alone over its %d cells" % (bpl, owned, "interior-box" if sim.overlap else "whole-box", kcells)}}
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": round(bpl * owned / (ms * 1e-3) / 1e9, 1),
+                "frac": round(bpl * owned / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "kernel_frac": round(bpl * kcells / (tm["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tm and tm.get("kernel_ms") else None,
+                             "traffic": None,
+                         "note": "frac = %g B/LUP x %d owned cells / wall time of a whole step (shell + exchange + interior); kernel_frac = the %s kernel "
+                             "alone over its %d cells" % (bpl, owned, "interior-box" if sim.overlap else "whole-box", kcells)}}
 
 
 def describe(name, size, buildings, dtype, coriolis, thermal, every_step):
@@ -342,25 +364,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="N = 1 headline workload (default c3 = BASELINE configs[2], the largest single-GPU configuration)")
-    ap.add_argument("--size", type=int, nargs=3, default=None, help="N = 1: lattice instead of the workload's; N > 1: per-GPU block (default 512 512 512, 8 GPUs = the 2048x1024x512 tile)")
-    ap.add_argument("--n-gpu", type=int, nargs=3, default=None, help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 4 2 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
+        help="N = 1 headline workload (default c3 = BASELINE configs[2], the largest single-GPU configuration)")
+    ap.add_argument("--size", type=int, nargs=3, default=None,
+        help="N = 1: lattice instead of the workload's; N > 1: per-GPU block (default 512 512 512, 8 GPUs = the 2048x1024x512 tile)")
+    ap.add_argument("--n-gpu", type=int, nargs=3, default=None,
+        help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 4 2 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "pair"], default="auto")
-    ap.add_argument("--buildings", action="store_true", help="add the configs[2] solid mask to a workload that has none (c3 and the N > 1 tile always carry it)")
+    ap.add_argument("--buildings", action="store_true",
+        help="add the configs[2] solid mask to a workload that has none (c3 and the N > 1 tile always carry it)")
     ap.add_argument("--no-buildings", action="store_true", help="N > 1: plain channel tile without the building array / nudging / sponge")
     ap.add_argument("--coriolis", action="store_true", help="Coriolis body force at 31.25 deg N (BASELINE configs[4]): every cell takes the forced path")
     ap.add_argument("--thermal", action="store_true", help="also run the thermal D3Q7 lattice (the shipped reference build always does): +7 DDF planes and T")
     ap.add_argument("--urban", action="store_true", help="N = 1: add the urban tile's buffer nudging + top sponge (deck defaults) to the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline measurement (profiling runs)")
-    ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
-    ap.add_argument("--force-distributed", action="store_true", help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
+    ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of "
+        "the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
+    ap.add_argument("--force-distributed", action="store_true",
+        help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
-    ap.add_argument("--rank-shape-block", choices=sorted(RANK_SHAPE_BLOCKS), default=None, help="(used by the N = 1 line itself) measure ONE rank-shape secondary block in this fresh process and print it")
+    ap.add_argument("--rank-shape-block", choices=sorted(RANK_SHAPE_BLOCKS), default=None,
+        help="(used by the N = 1 line itself) measure ONE rank-shape secondary block in this fresh process and print it")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check against the CPU oracle (profiling runs)")
     ap.add_argument("--no-group-host", action="store_true", help="N > 1: skip the one-process multi-domain host block")
-    ap.add_argument("--group-host-child", choices=sorted(GROUP_HOST_VARIANTS), default=None, help="(used by the N > 1 line itself) measure ONE variant of the one-process host in this fresh process and print it")
+    ap.add_argument("--group-host-child", choices=sorted(GROUP_HOST_VARIANTS), default=None,
+        help="(used by the N > 1 line itself) measure ONE variant of the one-process host in this fresh process and print it")
     ap.add_argument("--devices", default=None, help="--group-host-child: the devices of the domains, comma separated")
     ap.add_argument("--global-lattice", type=int, nargs=3, default=None, help="--group-host-child: the whole lattice")
     args = ap.parse_args()
@@ -408,13 +438,17 @@ def main():
         size, buildings, _ = WORKLOADS[args.workload]
         if args.size: size = tuple(args.size)
         buildings = buildings or args.buildings
-        head = run_single(luw, kern, local_rank, size, args.dtype, buildings, args.steps, args.warmup, args.coriolis, args.thermal, args.every_step_fields, args.kernel, urban=args.urban)
+        head = run_single(luw, kern, local_rank, size, args.dtype, buildings, args.steps, args.warmup, args.coriolis, args.thermal, args.every_step_fields,
+            args.kernel, urban=args.urban)
         out = {
             "metric": METRIC, "value": head["value"], "unit": "MLUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-            "config": {"workload": describe(args.workload, size, buildings, args.dtype, args.coriolis, args.thermal, args.every_step_fields) + (", buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if args.urban else ""),
-                       "global_lattice": list(size), "n_gpu": [1, 1, 1], "halo_exchange": None, "kernel": args.kernel, "bytes_per_lup": head["bytes_per_lup"], "solid_fraction": head["solid_fraction"]},
-            "roofline": dict(head["roofline"], whole_job_frac=round(head["roofline"]["algorithmic_bytes_per_launch"] / (head["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)),
+            "config": {"workload": describe(args.workload, size, buildings, args.dtype, args.coriolis, args.thermal, args.every_step_fields)
+                + (", buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if args.urban else ""),
+                       "global_lattice": list(size), "n_gpu": [1, 1, 1], "halo_exchange": None, "kernel": args.kernel, "bytes_per_lup": head["bytes_per_lup"],
+                           "solid_fraction": head["solid_fraction"]},
+            "roofline": dict(head["roofline"],
+                whole_job_frac=round(head["roofline"]["algorithmic_bytes_per_launch"] / (head["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)),
         }
         out["device"] = device_context(torch, local_rank)
         if out["device"].get("copy_GBps"):
@@ -422,7 +456,8 @@ def main():
         if not args.no_secondary:
             # the other single-GPU configurations, same process, same code path, fewer steps (each is its own create / fill / run)
             sec = {}
-            plan = [("c2_f32", "c2", "f32", False, False), ("c2_fp16c", "c2", "fp16c", False, False), ("c3_fp16c", "c3", "fp16c", False, False), ("c3_fp16c_coriolis", "c3", "fp16c", True, False),
+            plan = [("c2_f32", "c2", "f32", False, False), ("c2_fp16c", "c2", "fp16c", False, False), ("c3_fp16c", "c3", "fp16c", False, False),
+                ("c3_fp16c_coriolis", "c3", "fp16c", True, False),
                     ("c3_fp16c_thermal", "c3", "fp16c", False, True),      # FP16C DDFs + the thermal D3Q7 lattice: what the shipped reference build runs
                     ("cube1024_f32", "cube1024", "f32", False, False), ("cube1024_fp16c", "cube1024", "fp16c", False, False)]
             for key, wl, dt_, cor, th in plan:
@@ -430,7 +465,8 @@ def main():
                 if (wl, dt_, cor, th) == (args.workload, args.dtype, args.coriolis, args.thermal) and not args.size:
                     continue
                 try:
-                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, thermal=th)     # >= 200 timed after >= 20 warm-up steps
+                    # >= 200 timed after >= 20 warm-up steps
+                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, thermal=th)
                     r["workload"] = describe(wl, sz, bld, dt_, cor, th, False)
                     sec[key] = r
                 except Exception as e:      # a secondary block never takes the headline down; its absence is visible
@@ -440,7 +476,8 @@ def main():
             for key, dt_, cor in (("tile512_urban_f32", "f32", False), ("tile512_urban_fp16c_coriolis", "fp16c", True)):
                 try:
                     r = run_single(luw, capi.KERNEL_AUTO, local_rank, (512, 512, 512), dt_, True, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, urban=True)
-                    r["workload"] = "512^3 urban tile, undivided: the N = 1 point of the N > 1 lines (BASELINE configs[3]%s per GPU)" % (" / configs[4]" if cor else "")
+                    r["workload"] = "512^3 urban tile, undivided: the N = 1 point of the N > 1 lines (BASELINE configs[3]%s per GPU)" % (" / configs[4]" if cor
+                        else "")
                     sec[key] = r
                 except Exception as e:
                     sec[key] = {"error": str(e)[:300]}
@@ -450,7 +487,8 @@ def main():
             import subprocess
             for key in RANK_SHAPE_BLOCKS:
                 try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rank-shape-block", key, "--steps", str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)],
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rank-shape-block", key, "--steps", str(SECONDARY_STEPS), "--warmup",
+                        str(SECONDARY_WARMUP)],
                                        capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
                     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                     sec[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
@@ -477,7 +515,8 @@ def main():
 
 # ======================================================================== N > 1
 PARITY_STEPS = 8                 # both time parities, eight exchanges per split axis
-PARITY_NUDGE_CELLS, PARITY_SPONGE_CELLS = 20, 24    # zones thinner than a rank's 64-cell block: only face-owning domains feel them (FX/kernel.cpp:1537-1541,1598)
+# zones thinner than a rank's 64-cell block: only face-owning domains feel them (FX/kernel.cpp:1537-1541,1598)
+PARITY_NUDGE_CELLS, PARITY_SPONGE_CELLS = 20, 24
 
 
 def parity_tile(world, D):
@@ -548,7 +587,8 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
     os.environ.setdefault("LUW_MEASURE_WIRE", "10")                # TorchDistTransport.warm_up times the bare face exchange of every split axis
     urban = not args.no_buildings
     nud, spg = tile_forcing() if urban else (None, None)
-    box = device_context(torch, local_rank)                        # this rank's GPU by itself (before the lattice exists): the slowest box sets the pace of a step
+    # this rank's GPU by itself (before the lattice exists): the slowest box sets the pace of a step
+    box = device_context(torch, local_rank)
     dev_of = (lambda r: args.share_device) if shared else (lambda r: r)   # one node: rank r drives device r
     transport = "gloo + host staging (--share-device test aid: NOT a multi-GPU result)" if shared else "RCCL p2p (batch_isend_irecv)"
 
@@ -593,7 +633,8 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             bad = [{"rank": r, "fields": [f for f in ("rho", "u", "fi") if got[r][f] != want[r][f]]} for r in range(world)]
             bad = [b for b in bad if b["fields"]]
             case.update(equal=not bad, mismatches=bad, cells_compared=gN[0] * gN[1] * gN[2], max_abs_uy=max(g["max_abs_uy"] for g in got),
-                        compared="rho, u and the 19 stored DDF planes of every rank's owned cells (128-bit digests, all-gathered) against the CPU oracle on the undivided lattice")
+                        compared="rho, u and the 19 stored DDF planes of every rank's owned cells (128-bit digests, all-gathered) against the CPU oracle on "
+                            "the undivided lattice")
             case["equal"] = case["equal"] and case["max_abs_uy"] > 0.0           # a flow that never left the inflow profile proves nothing
         return case, ora
 
@@ -614,7 +655,8 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
         if not parity["ok"]:
             if rank == 0:
                 sys.stdout.flush(); os.dup2(saved_stdout, 1)
-                print(json.dumps({"metric": METRIC, "value": None, "unit": "MLUPS", "n_gpus": world, "error": "decomposed run differs from the oracle: nothing was timed", "parity": parity}))
+                print(json.dumps({"metric": METRIC, "value": None, "unit": "MLUPS", "n_gpus": world,
+                    "error": "decomposed run differs from the oracle: nothing was timed", "parity": parity}))
                 sys.stdout.flush(); os.dup2(2, 1)
             dist.barrier(); dist.destroy_process_group()
             raise SystemExit(3)
@@ -645,17 +687,22 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             b = sim.layout.interior_box() if sim.overlap else sim.layout.whole_box()
             elem = 2 if fp16c else 4
             halo_out = sum(2 * 5 * lb.area(a) * elem for a in sim.layout.split_axes())      # bytes this rank sends per step (as many arrive)
-            mine = {"rank": rank, "device": local_rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "wall_ms_per_step": round(dt / args.steps * 1e3, 4),
+            mine = {"rank": rank, "device": local_rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN),
+                "wall_ms_per_step": round(dt / args.steps * 1e3, 4),
                     "kernel_ms": round(tm["kernel_ms"], 4), "kernel_cells": (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]),
-                    "shell_ms": None if tm.get("shell_ms") is None else round(tm["shell_ms"], 4), "exchange_ms": None if tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
+                    "shell_ms": None if tm.get("shell_ms") is None else round(tm["shell_ms"], 4), "exchange_ms": None if tm.get("exchange_ms") is None
+                        else round(tm["exchange_ms"], 4),
                     "halo_bytes_out_per_step": halo_out,
-                    "exchange_GBps_out": round(halo_out / (tm["exchange_ms"] * 1e-3) / 1e9, 2) if tm.get("exchange_ms") else None,    # pack + wire + unpack + waiting for the neighbours
-                    "wire": sim.wire,                                                       # the bare face exchange per split axis, measured before the lattice existed
+                    # pack + wire + unpack + waiting for the neighbours
+                    "exchange_GBps_out": round(halo_out / (tm["exchange_ms"] * 1e-3) / 1e9, 2) if tm.get("exchange_ms") else None,
+                    # the bare face exchange per split axis, measured before the lattice existed
+                    "wire": sim.wire,
                     "device_copy_GBps": box.get("copy_GBps"), "mclk": box.get("mclk"), "fclk": box.get("fclk")}
             mine.update(topology(sim.layout))
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
+            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap,
+                "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
         finally:
             sim.backend.close()
 
@@ -692,25 +739,33 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             "metric": METRIC, "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d D3Q19 %s (8 GPUs: BASELINE configs[3]) cut as n_gpu=%s, %dx%dx%d = %.0f M cells per GPU (the N = 1 line runs configs[2], 1024x1024x256 = 268 M cells on its GPU; its secondary block tile512_urban is this tile's N = 1 point), log-law profile inflow on TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s, rho/u written by the last step only"
-                       % (*res["gN"], "urban tile: building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "channel tile", list(res["D"]), *res["block"], per_gpu / 1e6,
+            "config": {"workload": "%dx%dx%d D3Q19 %s (8 GPUs: BASELINE configs[3]) cut as n_gpu=%s, %dx%dx%d = %.0f M cells per GPU (the N = 1 line runs "
+                "configs[2], 1024x1024x256 = 268 M cells on its GPU; its secondary block tile512_urban is this tile's N = 1 point), log-law profile inflow on "
+                "TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s, rho/u written by the last step only"
+                       % (*res["gN"], "urban tile: building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "channel tile",
+                           list(res["D"]), *res["block"], per_gpu / 1e6,
                           "FP16C" if fp16c else "FP32", " + Coriolis force" if args.coriolis else ""),
                        "global_lattice": list(res["gN"]), "n_gpu": list(res["D"]), "cells_per_gpu": per_gpu,
-                       "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel"), "kernel": args.kernel, "bytes_per_lup": bpl,
+                       "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel"),
+                           "kernel": args.kernel, "bytes_per_lup": bpl,
                        "rccl_version": rccl, "ranks_in_communicator": dist.get_world_size()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
                          "kernel_ms": res["per_rank"][0]["kernel_ms"],
                          "whole_job_frac": round(mlups * 1e6 * bpl / 1e9 / (HBM_PEAK_GBPS * world), 4),   # wall-clock MLUPS of all GPUs x B/LUP over N x peak
-                         "note": "achieved = %g B/LUP x %d cells / mean duration of rank 0's %s kernel (HIP events on its launch stream); solid cells are charged like fluid ones here (< 1 %% of the tile)"
-                                 % (bpl, res["per_rank"][0]["kernel_cells"], "interior-box (its boundary shell and the halo exchange run concurrently on the communication stream)" if res["overlap"] else "whole-box")},
+                         "note": "achieved = %g B/LUP x %d cells / mean duration of rank 0's %s kernel (HIP events on its launch stream); solid cells are "
+                             "charged like fluid ones here (< 1 %% of the tile)"
+                                 % (bpl, res["per_rank"][0]["kernel_cells"],
+                                     "interior-box (its boundary shell and the halo exchange run concurrently on the communication stream)" if res["overlap"]
+                                     else "whole-box")},
             "parity": parity if not args.no_parity else {"skipped": "--no-parity"},
             "per_rank": res["per_rank"],
         }
         sec = {}
         if alt is not None:
             m2, _, a2 = block(alt)
-            sec["x_whole_n_gpu"] = {"value": round(m2, 1), "unit": "MLUPS", "ms_per_step": round(alt["dt"] / args.steps * 1e3, 4), "n_gpu": list(alt["D"]), "global_lattice": list(alt["gN"]),
+            sec["x_whole_n_gpu"] = {"value": round(m2, 1), "unit": "MLUPS", "ms_per_step": round(alt["dt"] / args.steps * 1e3, 4), "n_gpu": list(alt["D"]),
+                "global_lattice": list(alt["gN"]),
                                     "what": "the same tile cut with x kept whole (rows stay complete memory lines; whole-row y/z shells)",
                                     "halo_exchange": transport + (", overlapped with the interior" if alt["overlap"] else " after the whole-box kernel"),
                                     "roofline_frac_rank0_kernel": round(a2 / HBM_PEAK_GBPS, 4) if a2 else None, "per_rank": alt["per_rank"]}
@@ -725,7 +780,8 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
     dist.destroy_process_group()
 
 
-GROUP_HOST_VARIANTS = {"peer": {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "0"}, "peer_threads": {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "1"},
+GROUP_HOST_VARIANTS = {"peer": {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "0"},
+    "peer_threads": {"LUW_GROUP_TRANSPORT": "peer", "LUW_GROUP_THREADS": "1"},
                        "rccl": {"LUW_GROUP_TRANSPORT": "rccl", "LUW_GROUP_THREADS": "0"}}
 GROUP_HOST_TIMEOUT_S = int(os.environ.get("LUW_BENCH_GROUP_HOST_TIMEOUT", "420"))     # per variant
 
@@ -736,12 +792,17 @@ def run_group_host(args, D, gN, devices):
     per domain) and grouped ncclSend / ncclRecv.  Each variant runs in its OWN child process under a time limit (`--group-host-child`, below): a
     host that hangs on hardware it has not met costs its own block, not the RCCL line this process still has to print."""
     import subprocess
-    out = {"what": "one process drives all %d devices (luw_group_*, the deck driver's multi-GPU host); same tile and cut as the headline; each variant in a fresh child process" % len(devices),
+    out = {"what": "one process drives all %d devices (luw_group_*, the deck driver's multi-GPU host); same tile and cut as the headline; each variant in a "
+        "fresh child process" % len(devices),
            "devices": devices, "n_gpu": list(D), "global_lattice": list(gN)}
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC")}
+    env = {k: v for k, v in os.environ.items()
+        if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+        and not k.startswith("TORCHELASTIC")}
     for label in GROUP_HOST_VARIANTS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--group-host-child", label, "--devices", ",".join(str(d) for d in devices), "--n-gpu", *(str(d) for d in D),
-               "--global-lattice", *(str(g) for g in gN), "--dtype", args.dtype, "--kernel", args.kernel, "--steps", str(min(args.steps, 60)), "--warmup", str(min(args.warmup, 5))]
+        cmd = [sys.executable, os.path.abspath(__file__), "--group-host-child", label, "--devices", ",".join(str(d) for d in devices), "--n-gpu",
+            *(str(d) for d in D),
+               "--global-lattice", *(str(g) for g in gN), "--dtype", args.dtype, "--kernel", args.kernel, "--steps", str(min(args.steps, 60)), "--warmup",
+                   str(min(args.warmup, 5))]
         cmd += (["--coriolis"] if args.coriolis else []) + (["--no-buildings"] if args.no_buildings else []) + (["--no-parity"] if args.no_parity else [])
         t0 = time.perf_counter()
         try:
@@ -775,7 +836,8 @@ def group_host_child(args, luw, capi, kern, fp16c):
         try:
             fill_channel(g.flags, g.u, g.rho, *pg, buildings=True)
             g.run(0); g.run(PARITY_STEPS); g.read_from_device()
-            blk["parity"] = {"equal": bool(np.array_equal(g.rho, ora.rho) and np.array_equal(g.u, ora.u)), "lattice": list(pg), "steps": PARITY_STEPS, "dtype": "f32",
+            blk["parity"] = {"equal": bool(np.array_equal(g.rho, ora.rho) and np.array_equal(g.u, ora.u)), "lattice": list(pg), "steps": PARITY_STEPS,
+                "dtype": "f32",
                              "compared": "rho, u of every cell against the CPU oracle on the undivided lattice"}
             blk["transport"] = capi.TRANSPORT_NAMES.get(g.transport()); blk["overlap"] = g.overlaps()
         finally:
@@ -799,7 +861,8 @@ def group_host_child(args, luw, capi, kern, fp16c):
         kms = g.run_timed(args.steps)
         dt = time.perf_counter() - t0
         cells = gN[0] * gN[1] * gN[2]
-        blk.update(value=round(cells * args.steps / dt / 1e6, 1), unit="MLUPS", ms_per_step=round(dt / args.steps * 1e3, 4), steps=args.steps, warmup=args.warmup, domain0_kernel_ms=round(kms, 4),
+        blk.update(value=round(cells * args.steps / dt / 1e6, 1), unit="MLUPS", ms_per_step=round(dt / args.steps * 1e3, 4), steps=args.steps,
+            warmup=args.warmup, domain0_kernel_ms=round(kms, 4),
                    transport=capi.TRANSPORT_NAMES.get(g.transport()), direct_peer_stores=g.direct_peer_stores(), overlap=g.overlaps(),
                    host_threads="one per domain" if GROUP_HOST_VARIANTS[label]["LUW_GROUP_THREADS"] == "1" else "one")
     finally:

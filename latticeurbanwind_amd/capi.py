@@ -27,11 +27,19 @@ SYMBOLS = [
     "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
     "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
     "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
-    "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info", "luw_group_overlaps", "luw_group_direct_peer_stores",
-    "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download", "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_run_timed",
-    "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis", "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach", "luw_group_gather_u",
-    "luw_group_stats_reset", "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_selfcheck_arith", "luw_fields_every_step", "luw_step_boxes", "luw_domain_step_create", "luw_domain_step_destroy", "luw_domain_step_overlaps", "luw_domain_step_launch", "luw_domain_step_separate_stats", "luw_domain_step_timing", "luw_group_export_vtk", "luw_group_stats_count",
-    "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample", "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
+    "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info", "luw_group_overlaps",
+        "luw_group_direct_peer_stores",
+    "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download", "luw_group_initialize", "luw_group_run", "luw_group_run_sampled",
+        "luw_group_run_timed",
+    "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis", "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach",
+        "luw_group_gather_u",
+    "luw_group_stats_reset", "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_selfcheck_arith",
+        "luw_fields_every_step", "luw_step_boxes", "luw_domain_step_create", "luw_domain_step_destroy", "luw_domain_step_overlaps", "luw_domain_step_launch",
+        "luw_domain_step_separate_stats", "luw_domain_step_timing", "luw_group_export_vtk", "luw_group_stats_count",
+    "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi",
+        "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample",
+        "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u",
+        "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
 ]
 
 
@@ -187,7 +195,8 @@ def p2p_info(device, peer):
     acc, rank, atom, lt, hops = C.c_int(0), C.c_int(0), C.c_int(0), C.c_uint32(0), C.c_uint32(0)
     check(load().luw_p2p_info(int(device), int(peer), C.byref(acc), C.byref(rank), C.byref(atom), C.byref(lt), C.byref(hops)))
     return {"peer": int(peer), "can_access": bool(acc.value), "performance_rank": rank.value, "native_atomics": atom.value,
-            "link": LINK_TYPES.get(lt.value, "type %d" % lt.value) if lt.value != 0xFFFFFFFF else None, "hops": None if hops.value == 0xFFFFFFFF else hops.value}
+            "link": LINK_TYPES.get(lt.value, "type %d" % lt.value) if lt.value != 0xFFFFFFFF else None, "hops": None if hops.value == 0xFFFFFFFF
+                else hops.value}
 
 
 def check(rc):

@@ -579,7 +579,8 @@ class DomainDecomposedLBM:
         self._join()
         if timed and steps:
             kernel_ms, shell_ms = b.step_timing()
-            return {"kernel_ms": kernel_ms, "shell_ms": None if shell_ms < 0 else shell_ms, "exchange_ms": sum(a.elapsed_time(c) for a, c in ev_comm) / len(ev_comm)}
+            return {"kernel_ms": kernel_ms, "shell_ms": None if shell_ms < 0 else shell_ms,
+                "exchange_ms": sum(a.elapsed_time(c) for a, c in ev_comm) / len(ev_comm)}
         return None
 
     def fields(self):

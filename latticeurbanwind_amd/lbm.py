@@ -54,7 +54,8 @@ class LBM:
         cfg.nu = float(nu)
         cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
         cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
-        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
+        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid
+            else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
         cfg.alpha = float(alpha) if alpha is not None else 0.0      # thermal D3Q7 lattice: LBM(..., alpha, beta), FX/lbm.hpp:444
         if buffer_nudging is not None:  # dict(n_cells, inv_tau, downstream_face, nudge_vertical): FX/setup.cpp:3844-3866
             cfg.buffer_nudging_active = 1
@@ -144,7 +145,8 @@ class LBM:
         pd = np.ascontiguousarray(point_data, np.float32); md = np.ascontiguousarray(mode_data, np.float32)
         assert pd.size == 7 * pc.size and md.size == 50 * int(mode_count)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        capi.check(self._L.luw_vk_inlet_attach(self._h, pc.size, int(mode_count), p(pc), p(pf), p(pd), p(md), int(update_stride), int(bool(stride_interpolation))))
+        capi.check(
+            self._L.luw_vk_inlet_attach(self._h, pc.size, int(mode_count), p(pc), p(pf), p(pd), p(md), int(update_stride), int(bool(stride_interpolation))))
 
     def vk_inlet_apply(self): capi.check(self._L.luw_vk_inlet_apply(self._h))
     def vk_inlet_detach(self): capi.check(self._L.luw_vk_inlet_detach(self._h))
@@ -254,12 +256,14 @@ class LBMGroup:
         cfg.nu = float(nu)
         cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
         cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
-        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
+        cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid
+            else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
         cfg.alpha = float(alpha) if alpha is not None else 0.0
         if buffer_nudging is not None:
             cfg.buffer_nudging_active = 1
             cfg.buffer_n_cells = int(buffer_nudging["n_cells"]); cfg.buffer_inv_tau_lbmu = float(buffer_nudging["inv_tau"])
-            cfg.buffer_downstream_face_id = int(buffer_nudging.get("downstream_face", 0)); cfg.buffer_nudge_vertical = int(buffer_nudging.get("nudge_vertical", 0))
+            cfg.buffer_downstream_face_id = int(buffer_nudging.get("downstream_face", 0)); cfg.buffer_nudge_vertical = int(
+                buffer_nudging.get("nudge_vertical", 0))
         if top_sponge is not None:
             cfg.top_sponge_active = 1
             cfg.sponge_n_cells = int(top_sponge["n_cells"]); cfg.sponge_inv_tau_lbmu = float(top_sponge["inv_tau"])
@@ -369,7 +373,8 @@ class LBMGroup:
     def vk_inlet_attach(self, point_cell, point_face, point_data, mode_data, mode_count, update_stride=1, stride_interpolation=False):
         pc = np.ascontiguousarray(point_cell, np.uint64); pf = np.ascontiguousarray(point_face, np.uint8)
         pd = np.ascontiguousarray(point_data, np.float32); md = np.ascontiguousarray(mode_data, np.float32)
-        capi.check(self._L.luw_group_vk_inlet_attach(self._h, pc.size, int(mode_count), self._p(pc), self._p(pf), self._p(pd), self._p(md), int(update_stride), int(bool(stride_interpolation))))
+        capi.check(self._L.luw_group_vk_inlet_attach(self._h, pc.size, int(mode_count), self._p(pc), self._p(pf), self._p(pd), self._p(md), int(update_stride),
+            int(bool(stride_interpolation))))
 
     def gather_attach(self, cells):
         c = np.ascontiguousarray(cells, np.uint64)
@@ -385,11 +390,13 @@ class LBMGroup:
 
     def stats_download(self):
         N = self.get_N()
-        out = dict(avg_u=np.zeros(3 * N, np.float32), avg_rho=np.zeros(N, np.float32), m2_u=np.zeros(N, np.float32), m2_v=np.zeros(N, np.float32), m2_w=np.zeros(N, np.float32))
+        out = dict(avg_u=np.zeros(3 * N, np.float32), avg_rho=np.zeros(N, np.float32), m2_u=np.zeros(N, np.float32), m2_v=np.zeros(N, np.float32),
+            m2_w=np.zeros(N, np.float32))
         if self.T is not None:
             out["avg_T"] = np.zeros(N, np.float32)
         cnt = C.c_uint64(0)
-        capi.check(self._L.luw_group_stats_download(self._h, self._p(out["avg_u"]), self._p(out["avg_rho"]), self._p(out["m2_u"]), self._p(out["m2_v"]), self._p(out["m2_w"]),
+        capi.check(self._L.luw_group_stats_download(self._h, self._p(out["avg_u"]), self._p(out["avg_rho"]), self._p(out["m2_u"]), self._p(out["m2_v"]),
+            self._p(out["m2_w"]),
                                                     self._p(out["avg_T"]) if self.T is not None else None, C.byref(cnt)))
         out["count"] = cnt.value
         return out

@@ -12,7 +12,8 @@ import torch.distributed as dist
 
 
 def main():
-    gN = tuple(int(v) for v in sys.argv[1:4]); D = tuple(int(v) for v in sys.argv[4:7]); fp16c = bool(int(sys.argv[7])); corrupt = int(sys.argv[8]); out = sys.argv[9]
+    gN = tuple(int(v) for v in sys.argv[1:4]); D = tuple(int(v) for v in sys.argv[4:7]); fp16c = bool(int(sys.argv[7])); corrupt = int(
+        sys.argv[8]); out = sys.argv[9]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import bench
@@ -30,7 +31,8 @@ def main():
     sim.run(4)
     u, rho = sim.fields()
     if corrupt and rank == world - 1:
-        u = u.copy(); u[((lay.lN[2] // 2) * lay.lN[1] + lay.lN[1] // 2) * lay.lN[0] + lay.lN[0] // 2] += np.float32(1e-6)   # one owned value of one rank: the check must see it
+        # one owned value of one rank: the check must see it
+        u = u.copy(); u[((lay.lN[2] // 2) * lay.lN[1] + lay.lN[1] // 2) * lay.lN[0] + lay.lN[0] // 2] += np.float32(1e-6)
     mine = bench.owned_digests(lay, u, rho, od.o.fi, fp16c)
     got = [None] * world
     dist.all_gather_object(got, mine)

@@ -46,7 +46,8 @@ for k in range(cases):
             tb, off = s.interior_to_global(s.backend.download_T(), 1)
             gT[:, off[2]:off[2] + tb.shape[1], off[1]:off[1] + tb.shape[2], off[0]:off[0] + tb.shape[3]] = tb
         ok = ok and np.array_equal(gT.ravel(), o.T)
-    print("%3d  lattice %-14s n_gpu %-9s %s kernel %d overlap %d thermal %d steps %d : %s" % (k, gN, D, "fp16c" if fp16c else "f32  ", kern, overlap, thermal, steps, "ok" if ok else "MISMATCH"), flush=True)
+    print("%3d  lattice %-14s n_gpu %-9s %s kernel %d overlap %d thermal %d steps %d : %s" % (k, gN, D, "fp16c" if fp16c else "f32  ", kern, overlap, thermal,
+        steps, "ok" if ok else "MISMATCH"), flush=True)
     for s in grp.sims: s.backend.lbm.close()
     assert ok
 print("all %d decomposed cases identical to the single-domain oracle" % cases)

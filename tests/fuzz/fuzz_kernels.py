@@ -39,7 +39,8 @@ for k in range(cases):
     if fi.dtype == np.uint16:            # value equality: the FP16C codes 0x0000 and 0x8000 are both zero
         fi = fi.copy(); ref = ref.copy(); fi[fi == 0x8000] = 0; ref[ref == 0x8000] = 0
     ok = np.array_equal(g.u.data, o.u) and np.array_equal(g.rho.data, o.rho) and np.array_equal(fi.ravel(), ref.ravel())
-    print("%3d  %4dx%2dx%2d %s kernel %d shell %-4s force %d coriolis %d steps %d : %s" % (k, Nx, Ny, Nz, "fp16c" if fp16c else "f32  ", kern, shell, any(force), bool(cor), steps, "ok" if ok else "MISMATCH"), flush=True)
+    print("%3d  %4dx%2dx%2d %s kernel %d shell %-4s force %d coriolis %d steps %d : %s" % (k, Nx, Ny, Nz, "fp16c" if fp16c else "f32  ", kern, shell,
+        any(force), bool(cor), steps, "ok" if ok else "MISMATCH"), flush=True)
     g.close()
     assert ok
 print("all %d cases identical" % cases)

@@ -25,12 +25,14 @@ def run(cases, seed, say=print):
         if fp16c and rng.integers(0, 5) == 0: kernel = "s"
         nb = int(rng.integers(1, max(2, min(Nx, Ny, Nz) // 2)))
         if rng.integers(0, 4) == 0: nb = int(rng.integers(1, 4))
-        nud = dict(n_cells=nb, inv_tau=float(rng.uniform(0.002, 0.05)), downstream_face=int(rng.integers(0, 5)), nudge_vertical=int(rng.integers(0, 2))) if rng.integers(0, 6) else None
+        nud = dict(n_cells=nb, inv_tau=float(rng.uniform(0.002, 0.05)), downstream_face=int(rng.integers(0, 5)),
+            nudge_vertical=int(rng.integers(0, 2))) if rng.integers(0, 6) else None
         spg = dict(n_cells=int(rng.integers(1, max(2, Nz - 3))), inv_tau=float(rng.uniform(0.002, 0.05))) if rng.integers(0, 5) else None
         cor = (0.0, 3e-5, 4e-5) if rng.integers(0, 2) else None
         force = tuple(float(v) for v in (rng.standard_normal(3) * 1e-5)) if rng.integers(0, 3) == 0 else (0.0, 0.0, 0.0)
         st = synthetic_state(Nx, Ny, Nz, seed=int(rng.integers(0, 1 << 30)), shell="luw", solids=bool(rng.integers(0, 2)))
-        g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, fp16c, kernel, st, force=force, coriolis=cor, nudging=nud, sponge=spg, every_step=bool(rng.integers(0, 2)))
+        g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, fp16c, kernel, st, force=force, coriolis=cor, nudging=nud, sponge=spg,
+            every_step=bool(rng.integers(0, 2)))
         steps = int(rng.integers(1, 7))
         g.run(steps); o.run(steps)
         what = "case %d: %dx%dx%d %s kernel %s nudging %s sponge %s coriolis %s force %s steps %d" % (

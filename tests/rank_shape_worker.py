@@ -80,7 +80,8 @@ def main():
     else:
         ok_f = all(np.array_equal(a[i], b[i]) for i in range(19))
     moved = float(np.abs(cut(gu, 3)[1]).max())       # the flow must have developed a cross-wind component somewhere: not a trivial state
-    print("rank-shape %s local %s of n_gpu %s rank %d, %d steps, opts %s: u equal %s, rho equal %s, DDFs equal %s, max|uy| %.3e" % (dt, lay.lN, D, rank, steps, sorted(opts), ok_u, ok_r, ok_f, moved))
+    print("rank-shape %s local %s of n_gpu %s rank %d, %d steps, opts %s: u equal %s, rho equal %s, DDFs equal %s, max|uy| %.3e" % (dt, lay.lN, D, rank, steps,
+        sorted(opts), ok_u, ok_r, ok_f, moved))
     sim.backend.close()
     dist.destroy_process_group()
     assert ok_u and ok_r and ok_f

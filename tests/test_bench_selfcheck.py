@@ -15,7 +15,8 @@ def run(tmp_path, gN, D, fp16c, corrupt):
     world = D[0] * D[1] * D[2]
     out = str(tmp_path / "digests.json")
     port = 29500 + ((os.getpid() + 31 + corrupt) % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+        str(port),
            os.path.join(ROOT, "tests", "bench_parity_worker.py"), *map(str, gN), *map(str, D), str(int(fp16c)), str(corrupt), out]
     r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -68,8 +68,10 @@ def test_float_text_equals_the_restatement(luw):
     from oracle import oracle
     L = capi.load()
     rng = np.random.default_rng(5)
-    vals = np.concatenate([np.float32([0.0, 1.0, 9.9999999, 0.99999999, 1e-7, 1.9999990, 0.57735027, 123456.789, 1e32, 3.4e38, 1.2e-38, 1e-45, 0.1, 0.0001, 99999999.0, 0.5000004]),
-                           rng.standard_normal(50000).astype(np.float32), (10.0 ** rng.uniform(-38, 38, 100000)).astype(np.float32), rng.integers(0, 2 ** 32, 50000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    vals = np.concatenate([np.float32(
+        [0.0, 1.0, 9.9999999, 0.99999999, 1e-7, 1.9999990, 0.57735027, 123456.789, 1e32, 3.4e38, 1.2e-38, 1e-45, 0.1, 0.0001, 99999999.0, 0.5000004]),
+                           rng.standard_normal(50000).astype(np.float32), (10.0 ** rng.uniform(-38, 38, 100000)).astype(np.float32),
+                               rng.integers(0, 2 ** 32, 50000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
     buf = C.create_string_buffer(48)
     for v in vals:
         if not np.isfinite(v):

@@ -61,10 +61,13 @@ def test_gloo_multi_domain_thermal_lattice(tmp_path):
 def test_layout_matches_reference_rules():
     from latticeurbanwind_amd.distributed import DomainLayout, choose_decomposition, tile_lattice
     assert choose_decomposition(8, split_x=True) == (4, 2, 1) and choose_decomposition(2, split_x=True) == (2, 1, 1) and choose_decomposition(1) == (1, 1, 1)
-    assert choose_decomposition(8) == (1, 4, 2) and choose_decomposition(4) == (1, 2, 2) and choose_decomposition(2) == (1, 2, 1) and choose_decomposition(6)[0] == 1
-    assert tile_lattice(1) == (512, 512, 512) and tile_lattice(2) == (1024, 512, 512) and tile_lattice(4) == (1024, 1024, 512) and tile_lattice(8) == (2048, 1024, 512)
+    assert choose_decomposition(8) == (1, 4, 2) and choose_decomposition(4) == (1, 2, 2) and choose_decomposition(2) == (1, 2, 1) and choose_decomposition(6)[
+        0] == 1
+    assert tile_lattice(1) == (512, 512, 512) and tile_lattice(2) == (1024, 512, 512) and tile_lattice(4) == (1024, 1024, 512) and tile_lattice(8) == (2048,
+        1024, 512)
     for w in (1, 2, 4, 8):
-        assert all(g % d == 0 for g, d in zip(tile_lattice(w), choose_decomposition(w))) and all(g % d == 0 for g, d in zip(tile_lattice(w), choose_decomposition(w, True)))
+        assert all(g % d == 0 for g, d in zip(tile_lattice(w), choose_decomposition(w))) and all(g % d == 0 for g,
+            d in zip(tile_lattice(w), choose_decomposition(w, True)))
     lay = DomainLayout((2048, 1024, 512), (4, 2, 1), 6)          # d = x + (y + z*Dy)*Dx -> x=2, y=1, z=0 (FX/lbm.cpp:1071)
     assert lay.coord == (2, 1, 0)
     assert lay.lN == (514, 514, 512) and lay.O == (1023, 511, 0)  # N/D + 2 on split axes, O = coord*N/D - 1 (FX/lbm.cpp:1072)

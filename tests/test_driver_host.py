@@ -37,9 +37,11 @@ def read_dump(path):
     extra = {}
     off = 80 + N + 12 * N
     if raw[off:off + 4] == b"TEMP":      # temperature cases: unit_K, unit_K_offset, T[N] in lattice units
-        extra = dict(unit_K=np.frombuffer(raw, np.float32, 1, off + 4)[0], unit_K_offset=np.frombuffer(raw, np.float32, 1, off + 8)[0], T=np.frombuffer(raw, np.float32, N, off + 12))
+        extra = dict(unit_K=np.frombuffer(raw, np.float32, 1, off + 4)[0], unit_K_offset=np.frombuffer(raw, np.float32, 1, off + 8)[0],
+            T=np.frombuffer(raw, np.float32, N, off + 12))
     return dict(extra, Nx=Nx, Ny=Ny, Nz=Nz, Nz_core=Nzc, nu=fh[0], si_u=fh[1], si_rho=fh[2], buffer_inv_tau=fh[3], sponge_inv_tau=fh[4], scale=fh[5],
-                buffer_active=ih[0], buffer_N=ih[1], buffer_face=ih[2], nudge_vertical=ih[3], sponge_active=ih[4], sponge_N=ih[5], nvox=ih[6], mapped=ih[7], flags=flags, u=u)
+                buffer_active=ih[0], buffer_N=ih[1], buffer_face=ih[2], nudge_vertical=ih[3], sponge_active=ih[4], sponge_N=ih[5], nvox=ih[6], mapped=ih[7],
+                    flags=flags, u=u)
 
 
 @pytest.mark.parametrize("case", ["CaseA", "CaseB", "CaseL"])
@@ -50,7 +52,8 @@ def test_initial_state_equals_python_restatement(driver, tmp_path, case):
     d = read_dump(dump)
     s = setup_profile.setup_profile_case(deck)
     assert (d["Nx"], d["Ny"], d["Nz"], d["Nz_core"]) == (s["Nx"], s["Ny"], s["Nz"], s["Nz_core"])
-    assert np.float32(d["nu"]) == np.float32(s["nu"]) and np.float32(d["si_u"]) == np.float32(s["si_u_factor"]) and np.float32(d["si_rho"]) == np.float32(s["si_rho_factor"])
+    assert np.float32(d["nu"]) == np.float32(s["nu"]) and np.float32(d["si_u"]) == np.float32(s["si_u_factor"]) and np.float32(d["si_rho"]) == np.float32(
+        s["si_rho_factor"])
     assert bool(d["buffer_active"]) == bool(s["buffer_active"]) and d["buffer_N"] == s["buffer_N"] and d["buffer_face"] == s["buffer_face"]
     assert np.float32(d["buffer_inv_tau"]) == np.float32(s["buffer_inv_tau"]) and np.float32(d["sponge_inv_tau"]) == np.float32(s["sponge_inv_tau"])
     assert bool(d["sponge_active"]) == bool(s["sponge_active"]) and d["sponge_N"] == s["sponge_N"]
@@ -74,7 +77,8 @@ def write_case_e_like(dirpath, deck_lines):
     sys.path.insert(0, GOLD)
     from make_refcases import box_tris, write_stl
     os.makedirs(os.path.join(dirpath, "proj_temp")); os.makedirs(os.path.join(dirpath, "wind_bc"))
-    write_stl(os.path.join(dirpath, "proj_temp", "CaseE_PF.stl"), box_tris(0, 2022.500153, 0, 1996.500092, -20.0, 0.0) + box_tris(900.0, 950.0, 900.0, 960.0, 0.0, 59.9))
+    write_stl(os.path.join(dirpath, "proj_temp", "CaseE_PF.stl"), box_tris(0, 2022.500153, 0, 1996.500092, -20.0, 0.0)
+        + box_tris(900.0, 950.0, 900.0, 960.0, 0.0, 59.9))
     with open(os.path.join(dirpath, "wind_bc", "profile.dat"), "w") as f:
         f.write("z,U\n" + "\n".join("%g\t%g" % zu for zu in [(1.25, 2.847), (5, 3.26), (25, 4.36), (100, 6.16), (250, 7.8)]) + "\n")
     base = ["casename = CaseE", "datetime = 20251222120000", "si_x_cfd = [0.000000, 2022.500153]", "si_y_cfd = [0.000000, 1996.500092]",
@@ -87,16 +91,19 @@ def write_case_e_like(dirpath, deck_lines):
 # host-stage goldens captured from the real reference binary: deck edits -> grid; unit line; Nbuf/inv_tau; Nsponge/inv_tau
 SIZING = [
     (['n_gpu = [2, 1, 1]', 'mesh_control = "gpu_memory"', 'gpu_memory = 4000'], "751,  742,  174 (nCell = 96960108)", "2x 3997 MB (core 3960 + extra 37)",
-     "1 cell = 2690.701 mm, 1 s = 29 time steps", "Nbuf=43 cells", "inv_tau_lbmu=0.00011501", "Nsponge=74 cells", "inv_tau_lbmu=0.00028753", "side_ref_cap_z=99"),
+     "1 cell = 2690.701 mm, 1 s = 29 time steps", "Nbuf=43 cells", "inv_tau_lbmu=0.00011501", "Nsponge=74 cells", "inv_tau_lbmu=0.00028753",
+         "side_ref_cap_z=99"),
     (['n_gpu = [1, 1, 1]', 'mesh_control = "cell_size"', 'cell_size = 16'], "126,  125,   30", None,
      "1 cell = 15972.001 mm, 1 s = 5 time steps", "Nbuf=7 cells", "inv_tau_lbmu=0.00068376", "Nsponge=13 cells", "inv_tau_lbmu=0.00170940", None),
     (['n_gpu = [1, 1, 1]', 'mesh_control = "cell_size"', 'cell_size = 8', 'enable_top_sponge = false'], "253,  250,   34", None,
      "1 cell = 7986.000 mm, 1 s = 10 time steps", "Nbuf=8 cells", "inv_tau_lbmu=0.00034188", None, "inv_tau_lbmu=0.00085470", None),
     (['n_gpu = [1, 1, 1]', 'mesh_control = "gpu_memory"', 'gpu_memory = 20000'], "1023, 1009,  238", "1x 19994 MB (core 19925 + extra 69)",
      "1 cell = 1978.692 mm, 1 s = 39 time steps", "Nbuf=59 cells", "inv_tau_lbmu=0.00008452", "Nsponge=101 cells", "inv_tau_lbmu=0.00021129", None),
-    (['n_gpu = [4, 2, 1]', 'mesh_control = "gpu_memory"', 'gpu_memory = 40000', 'turb_inflow_enable = false'], "2579, 2545,  599 (nCell = 3931569445)", "8x 39996 MB",
+    (['n_gpu = [4, 2, 1]', 'mesh_control = "gpu_memory"', 'gpu_memory = 40000', 'turb_inflow_enable = false'], "2579, 2545,  599 (nCell = 3931569445)",
+        "8x 39996 MB",
      "1 cell = 784.479 mm, 1 s = 99 time steps", "Nbuf=149 cells", "inv_tau_lbmu=0.00003352", "Nsponge=255 cells", "inv_tau_lbmu=0.00008380", None),
-    (['n_gpu = [2, 2, 1]', 'mesh_control = "cell_size"', 'cell_size = 5', 'enable_top_sponge = false', 'enable_buffer_nudging = false', 'turb_inflow_enable = false'],
+    (['n_gpu = [2, 2, 1]', 'mesh_control = "cell_size"', 'cell_size = 5', 'enable_top_sponge = false', 'enable_buffer_nudging = false',
+        'turb_inflow_enable = false'],
      "405,  399,   54", "4x 191 MB", "1 cell = 5003.760 mm, 1 s = 16 time steps", "Nbuf=13 cells", "inv_tau_lbmu=0.00021368", None, None, None),
 ]
 
@@ -120,7 +127,8 @@ def test_deck_grammar(driver, tmp_path):
 
 
 def test_luw_deck_without_surfdata_fails_loudly(driver, tmp_path):
-    deck = str(tmp_path / "x.luw"); open(deck, "w").write("casename = x\ndatetime = 20260101120000\nsi_x_cfd = [0, 96]\nsi_y_cfd = [0, 80]\nsi_z_cfd = [0, 48]\n")
+    deck = str(tmp_path / "x.luw"); open(deck, "w").write(
+        "casename = x\ndatetime = 20260101120000\nsi_x_cfd = [0, 96]\nsi_y_cfd = [0, 80]\nsi_z_cfd = [0, 48]\n")
     r = subprocess.run([driver, deck, "--dry-run"], capture_output=True, text=True)
     assert r.returncode != 0 and "could not open CSV" in r.stdout and "no inlet samples" in r.stdout
 
@@ -149,7 +157,8 @@ def test_nwp_boundary_builders_against_real_reference_fields(driver, tmp_path, c
     ref = open(os.path.join(GOLD, "ref_fp32_%s.console.txt" % case)).read()
     norm = lambda txt: [" ".join(l.strip().strip("|").split()) for l in txt.splitlines()]
     mine_all, theirs_all = norm(out), norm(ref)
-    for frag in ("Unit Conversion: 1 cell =", "CDF data loaded", "S_in=", "corrected=", "per-face dU", "patch-driven 2D mapping", "bottom =", "top =", "south =", "north =", "west =", "east ="):
+    for frag in ("Unit Conversion: 1 cell =", "CDF data loaded", "S_in=", "corrected=", "per-face dU", "patch-driven 2D mapping", "bottom =", "top =",
+            "south =", "north =", "west =", "east ="):
         mine = sorted(l for l in mine_all if frag in l)
         theirs = sorted(l for l in theirs_all if frag in l)
         assert mine == theirs, (frag, mine, theirs)

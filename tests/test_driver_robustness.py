@@ -111,7 +111,8 @@ INPUT_VARIANTS = {
     "stl_empty_file": ("CaseA", _stl(lambda b: b"")),
     "stl_header_only": ("CaseA", _stl(lambda b: b"\0" * 84)),
     "stl_nan_vertices": ("CaseA", _stl(_nan_vertices)),
-    "stl_ascii": ("CaseA", _stl(lambda b: b"solid x\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid x\n")),
+    "stl_ascii": ("CaseA",
+        _stl(lambda b: b"solid x\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid x\n")),
     "stl_truncated_dataset_mode": ("CaseDG", _stl(lambda b: b[:len(b) // 2 + 7])),
     "csv_empty": ("CaseN1", _csv(lambda t: "")),
     "csv_header_only": ("CaseN1", _csv(lambda t: "X,Y,Z,u,v,w\n")),

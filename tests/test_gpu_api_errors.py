@@ -21,8 +21,10 @@ def _create(L, cfg):
 
 
 @pytest.mark.parametrize("kw,msg", [
-    (dict(Nx=0), "Grid point number is 0"), (dict(Dx=0), "0 LBM grid domains"), (dict(nu=0.0), "Viscosity cannot be 0"), (dict(nu=-1.0), "Viscosity cannot be negative"),
-    (dict(ddf_format=7), "unknown ddf_format"), (dict(struct_size=12), "size mismatch"), (dict(Dx=2, Nx=2), "split axes need"), (dict(device=99), "no such HIP device"),
+    (dict(Nx=0), "Grid point number is 0"), (dict(Dx=0), "0 LBM grid domains"), (dict(nu=0.0), "Viscosity cannot be 0"),
+        (dict(nu=-1.0), "Viscosity cannot be negative"),
+    (dict(ddf_format=7), "unknown ddf_format"), (dict(struct_size=12), "size mismatch"), (dict(Dx=2, Nx=2), "split axes need"),
+        (dict(device=99), "no such HIP device"),
     (dict(buffer_nudging_active=1, buffer_n_cells=0), "buffer_n_cells"), (dict(options=8, alpha=-0.5), "thermal diffusivity"),
     (dict(Nx=2048, Ny=2048, Nz=1024), "2^32")])      # 4.3 G cells: beyond the 32-bit cell index (refused before anything is allocated)
 def test_create_rejects_bad_configurations(luw, kw, msg):
@@ -45,7 +47,8 @@ def test_call_order_and_argument_checks(luw):
     fused = C.c_int32(7)
     assert L.luw_stats_begin_sample(h, C.byref(fused)) == capi.ERR_STATE and "luw_stats_reset first" in L.luw_last_error().decode()
     assert L.luw_run(h, 3) == 0 and L.luw_get_t(h) == 3                                   # run() initialises on first use, FX/lbm.cpp:1294-1296
-    assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 2) == capi.ERR_STATE and "luw_stats_begin_sample" in L.luw_last_error().decode()   # LUW_WF_SAMPLE without statistics
+    # LUW_WF_SAMPLE without statistics
+    assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 2) == capi.ERR_STATE and "luw_stats_begin_sample" in L.luw_last_error().decode()
     assert L.luw_stats_reset(h) == 0
     assert L.luw_run_sampled(h, 4, 0, 1) == capi.ERR_INVALID and "count from 1" in L.luw_last_error().decode()
     assert L.luw_enqueue_stream_collide(h, 0, 8, 0, 8, 0, 8, 2) == capi.ERR_STATE          # no sample counted yet

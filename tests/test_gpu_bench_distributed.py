@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def bench(world, *extra, env=None):
     port = 29500 + ((os.getpid() + 97 + world) % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+        str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--share-device", "0", *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
@@ -31,7 +32,8 @@ def test_two_ranks_self_check_and_blocks(luw):
     par = out["parity"]
     assert par["ok"] and len(par["cases"]) == 4                         # literal cut and x-whole cut, FP32 and FP16C + Coriolis
     for c in par["cases"]:
-        assert c["equal"] and c["mismatches"] == [] and c["steps"] == 8 and c["max_abs_uy"] > 0 and c["cells_compared"] == c["lattice"][0] * c["lattice"][1] * c["lattice"][2]
+        assert c["equal"] and c["mismatches"] == [] and c["steps"] == 8 and c["max_abs_uy"] > 0 and c["cells_compared"] == c["lattice"][0] * c["lattice"][
+            1] * c["lattice"][2]
     assert {tuple(c["n_gpu"]) for c in par["cases"]} == {(2, 1, 1), (1, 2, 1)}
     for r in out["per_rank"]:
         assert r["pci_bus_id"] and r["halo_bytes_out_per_step"] == 2 * 5 * 64 * 64 * 4 and set(r["links"]) == {"x+", "x-"}

@@ -103,7 +103,8 @@ def test_c3_shipped_configuration_thermal_fp16c_vs_oracle(luw):
 RANK_CASES = [
     # dtype, per-GPU block, n_gpu, rank, options
     ("f32", (2048, 256, 256), (1, 4, 2), 0, ("bld", "forcing")),            # configs[3], bench default cut; rank 0: ground, west/east/south faces
-    ("f32", (512, 512, 512), (4, 2, 1), 7, ("bld", "forcing")),             # configs[3], the deck's literal n_gpu; last rank: east (downstream) + north faces, whole height
+    # configs[3], the deck's literal n_gpu; last rank: east (downstream) + north faces, whole height
+    ("f32", (512, 512, 512), (4, 2, 1), 7, ("bld", "forcing")),
     ("fp16c", (2048, 256, 256), (1, 4, 2), 7, ("bld", "forcing", "cor")),   # configs[4]; last rank: top sponge + north face
     ("fp16c", (512, 512, 512), (4, 2, 1), 0, ("bld", "forcing", "cor")),    # configs[4], literal n_gpu
 ]
@@ -111,7 +112,8 @@ RANK_CASES = [
 
 @pytest.mark.parametrize("dt,block,D,rank,opts", RANK_CASES)
 def test_rank_of_the_8gpu_tile_vs_oracle(dt, block, D, rank, opts):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + (os.getpid() + 7 * rank + len(opts)) % 150), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + (os.getpid() + 7 * rank + len(opts)) % 150), RANK="0", WORLD_SIZE="1",
+        LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_shape_worker.py"), dt, *map(str, block), *map(str, D), str(rank), "3", *opts]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "DDFs equal True" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]

@@ -16,7 +16,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 # examples/example_ProfileResearch_noDEM/wind_bc/profile.dat of the reference: data (height above ground in m, speed in m/s)
-PROFILE = [(1.25, 2.847), (2.5, 3.042), (5, 3.2604), (7.5, 3.4086), (12.5, 3.7674), (25, 4.3602), (50, 5.109), (75, 5.694), (100, 6.162), (150, 6.9654), (200, 7.3944), (250, 7.838)]
+PROFILE = [(1.25, 2.847), (2.5, 3.042), (5, 3.2604), (7.5, 3.4086), (12.5, 3.7674), (25, 4.3602), (50, 5.109), (75, 5.694), (100, 6.162), (150, 6.9654),
+    (200, 7.3944), (250, 7.838)]
 N = 128
 CELL_M = 2.0
 

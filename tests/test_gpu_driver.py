@@ -90,7 +90,8 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
 def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture):
     """deck in, VTK out, nothing injected: the driver's files against the files the REAL reference wrote for the same deck on
     an MI355X (geometry voxelised on the device, BC fill, VK inlet, run loop, averaging, writers).  Gates as in
-    test_gpu_parity.test_hip_path_vs_real_reference_fields (lattice units): first output 2e-7 (FP32) / 5e-6 (FP16C: 2^-12 storage rounding, amplified where terrain adds shear) u RMSE,
+    test_gpu_parity.test_hip_path_vs_real_reference_fields (lattice units): first output 2e-7 (FP32) / 5e-6 (FP16C: 2^-12 storage rounding, amplified
+    where terrain adds shear) u RMSE,
     final step 1e-6 / 1e-4; masks and headers exact."""
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
     proj = str(tmp_path / case)
@@ -103,7 +104,8 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     times = sorted(int(k[1:]) for k in gold.files if k[0] == "u" and k[1:].isdigit())
     fp16c = ddf == "fp16c"
     h, f = read_vtk(glob.glob(os.path.join(vt, "*_avg-%09d.vtk" % times[-1]))[0])
-    assert tuple(gold["dims"]) == h["dims"] and np.array_equal(gold["origin"], np.array(h["origin"])) and np.array_equal(gold["spacing"], np.array(h["spacing"]))
+    assert tuple(gold["dims"]) == h["dims"] and np.array_equal(gold["origin"], np.array(h["origin"])) and np.array_equal(gold["spacing"],
+        np.array(h["spacing"]))
     solid = f["fluid"][..., 0] == 0
     assert np.array_equal(solid, gold["solid"]), "TYPE_S mask differs from the reference in %d cells" % int((solid != gold["solid"]).sum())
     fluid = ~solid
@@ -155,7 +157,8 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
             hw, zw, vw = rd(os.path.join(probes, name)); hg, zg, vg = rd(os.path.join(proj, "RESULTS", name))
             assert hw == hg and zw == zg and vw.shape == vg.shape, name
             assert np.abs(vw - vg).max() / float(fac) < (1e-4 if fp16c else 1e-6), name
-        ref_rows = [" ".join(l.strip().strip("|").split()) for l in open(os.path.join(GOLD, fixture + ".console.txt")).read().splitlines() if "levels=" in l or "ignored:" in l]
+        ref_rows = [" ".join(l.strip().strip("|").split()) for l in open(os.path.join(GOLD, fixture + ".console.txt")).read().splitlines() if "levels=" in l
+            or "ignored:" in l]
         my_rows = [" ".join(l.strip().strip("|").split()) for l in r.stdout.splitlines() if "levels=" in l or "ignored:" in l]
         assert ref_rows == my_rows and len(ref_rows) == 6
     # voxel count line of the console, as the reference prints it
@@ -208,7 +211,8 @@ def test_pair_and_scalar_kernels_write_identical_files(luw, tmp_path):
     out = {}
     for tag, extra in (("pair", []), ("scalar", ["--kernel", "scalar"])):
         d = str(tmp_path / tag)
-        mr.write_case(d, "W", 20.0, ["enable_buffer_nudging = true", "enable_top_sponge = true", "sponge_thickness_m = 64", "vk_inlet_l = 60", "vk_inlet_nmodes = 32"],
+        mr.write_case(d, "W", 20.0,
+            ["enable_buffer_nudging = true", "enable_top_sponge = true", "sponge_thickness_m = 64", "vk_inlet_l = 60", "vk_inlet_nmodes = 32"],
                       dims=(51.2, 25.6, 6.4), building="city", nstep=24, unsteady=12, purge=6, vk=True, cell=0.1)
         r = subprocess.run([DRIVER, os.path.join(d, "W", "conf.luwpf"), "--ddf", "fp16c"] + extra, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -34,8 +34,10 @@ def _files(proj):
 
 
 # z splits: only cases whose geometry does not put a face exactly on a lattice plane below the cut (see the next test)
-@pytest.mark.parametrize("case,n_gpu,ddf", [("CaseA", (2, 1, 1), "fp32"), ("CaseV", (1, 2, 1), "fp32"), ("CaseV", (2, 2, 1), "fp32"), ("CaseN1", (1, 2, 1), "fp32"), ("CaseP", (2, 2, 1), "fp32"),
-                                            ("CaseT1", (2, 2, 1), "fp32"), ("CaseT3", (2, 1, 1), "fp16c"), ("CaseG", (2, 2, 2), "fp16c"), ("CaseL", (1, 1, 2), "fp32")])
+@pytest.mark.parametrize("case,n_gpu,ddf",
+    [("CaseA", (2, 1, 1), "fp32"), ("CaseV", (1, 2, 1), "fp32"), ("CaseV", (2, 2, 1), "fp32"), ("CaseN1", (1, 2, 1), "fp32"), ("CaseP", (2, 2, 1), "fp32"),
+                                            ("CaseT1", (2, 2, 1), "fp32"), ("CaseT3", (2, 1, 1), "fp16c"), ("CaseG", (2, 2, 2), "fp16c"),
+                                                ("CaseL", (1, 1, 2), "fp32")])
 def test_driver_with_n_gpu_writes_the_single_domain_files(luw, tmp_path, case, n_gpu, ddf):
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
     ref_proj, ref_deck = _case(tmp_path, case, (1, 1, 1), "_one")
@@ -59,7 +61,8 @@ def test_driver_with_n_gpu_writes_the_single_domain_files(luw, tmp_path, case, n
         assert False, name + " differs"
 
 
-@pytest.mark.parametrize("case,n_gpu,ddf", [("CaseA", (1, 1, 1), "fp32"), ("CaseA", (2, 2, 1), "fp32"), ("CaseT1", (2, 1, 1), "fp32"), ("CaseG", (2, 2, 2), "fp16c"), ("CaseP", (1, 2, 1), "fp32")])
+@pytest.mark.parametrize("case,n_gpu,ddf",
+    [("CaseA", (1, 1, 1), "fp32"), ("CaseA", (2, 2, 1), "fp32"), ("CaseT1", (2, 1, 1), "fp32"), ("CaseG", (2, 2, 2), "fp16c"), ("CaseP", (1, 2, 1), "fp32")])
 def test_device_vtk_export_equals_the_host_conversion(luw, tmp_path, case, n_gpu, ddf):
     """the output path: every VTK the driver writes with the devices producing the payload (per-domain kernel: SoA -> AoS, SI units, big-endian;
     tke / TI / TLS from the statistics on the devices, the TLS stencil across domain cuts; slabs through pinned memory, pwrite from a writer
@@ -82,7 +85,8 @@ def test_device_vtk_export_equals_the_host_conversion(luw, tmp_path, case, n_gpu
             hw, fw = read_vtk(want[name]); hg, fg = read_vtk(got[name])
             assert hw == hg, name
             for key in fw:
-                assert np.array_equal(fg[key].view(np.uint32), fw[key].view(np.uint32)), (name, key, int((fg[key].view(np.uint32) != fw[key].view(np.uint32)).sum()))
+                assert np.array_equal(fg[key].view(np.uint32), fw[key].view(np.uint32)), (name, key,
+                    int((fg[key].view(np.uint32) != fw[key].view(np.uint32)).sum()))
         assert False, name + " differs"
 
 

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [
     # global lattice, n_gpu, FP16C, expect shell / interior overlap
-    ((24, 20, 16), (2, 1, 1), False, True), ((24, 20, 16), (2, 2, 2), False, True), ((32, 24, 12), (4, 2, 1), False, True), ((26, 18, 16), (1, 3, 2), True, True),
+    ((24, 20, 16), (2, 1, 1), False, True), ((24, 20, 16), (2, 2, 2), False, True), ((32, 24, 12), (4, 2, 1), False, True),
+        ((26, 18, 16), (1, 3, 2), True, True),
     ((16, 12, 6), (2, 2, 2), False, False),             # 3 owned layers in z: too thin for a shell, whole box + exchange
     ((640, 24, 16), (2, 1, 2), True, True),             # rows wide enough for the FP16C pair kernel and 64-cell x slabs
     ((260, 12, 12), (1, 2, 2), False, True),
@@ -102,7 +103,8 @@ def test_group_voxelise_gather_and_inlet_match_the_single_domain(luw):
     from make_refcases import box_tris
     gN, D = (48, 40, 24), (2, 2, 1)
     st = synthetic_state(*gN, seed=47, solids=False, shell="luw")
-    tri = np.array(box_tris(10.0, 22.0, 8.0, 19.0, 1.0, 9.0) + box_tris(21.0, 30.0, 18.0, 27.0, 1.0, 14.0), np.float32)   # (T, 3, 3); the second box straddles the domain cut
+    # (T, 3, 3); the second box straddles the domain cut
+    tri = np.array(box_tris(10.0, 22.0, 8.0, 19.0, 1.0, 9.0) + box_tris(21.0, 30.0, 18.0, 27.0, 1.0, 14.0), np.float32)
     bounds = np.concatenate([tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0)])
     rng = np.random.default_rng(3)
     Nx, Ny, Nz = gN

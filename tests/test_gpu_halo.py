@@ -90,7 +90,8 @@ def test_box_launches_tile_the_domain(luw):
     st = synthetic_state(Nx, Ny, Nz, seed=8, shell="luw")
     res = {}
     for name, kern, boxes in (("whole_s", capi.KERNEL_SCALAR, [(0, Nx, 0, Ny, 0, Nz)]),
-                              ("split_a", capi.KERNEL_SCALAR, [(0, 1, 0, Ny, 0, Nz), (1, 7, 0, Ny, 0, Nz), (7, 30, 0, 5, 0, Nz), (7, 30, 5, Ny, 0, 4), (7, 30, 5, Ny, 4, Nz), (30, 44, 0, Ny, 0, Nz), (44, 45, 0, Ny, 0, Nz)]),
+                              ("split_a", capi.KERNEL_SCALAR, [(0, 1, 0, Ny, 0, Nz), (1, 7, 0, Ny, 0, Nz), (7, 30, 0, 5, 0, Nz), (7, 30, 5, Ny, 0, 4),
+                                  (7, 30, 5, Ny, 4, Nz), (30, 44, 0, Ny, 0, Nz), (44, 45, 0, Ny, 0, Nz)]),
                               ("split_s", capi.KERNEL_SCALAR, [(0, 20, 0, Ny, 0, Nz), (20, Nx, 0, 6, 0, Nz), (20, Nx, 6, Ny, 0, Nz)])):
         g = luw.LBM(Nx, Ny, Nz, 1e-3, kernel=kern)
         g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
@@ -114,6 +115,7 @@ def test_rccl_transport_through_self_send_recv(dt):
     those of the in-process loopback run bit for bit"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200 + (1 if dt == "f32" else 0)), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200 + (1 if dt == "f32" else 0)), RANK="0", WORLD_SIZE="1",
+        LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_nccl_self.py"), dt], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "fields identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

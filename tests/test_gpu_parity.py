@@ -148,7 +148,8 @@ def test_fp16c_pair_kernel_force_modes_match_oracle(luw, forces):
     nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1) if "zones" in forces else None
     spg = dict(n_cells=4, inv_tau=0.02) if "zones" in forces else None
     cor = (0.0, 3e-5, 4e-5) if "coriolis" in forces else None
-    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, True, "auto", synthetic_state(Nx, Ny, Nz, seed=21, shell="luw"), coriolis=cor, nudging=nud, sponge=spg, every_step=False)
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, True, "auto", synthetic_state(Nx, Ny, Nz, seed=21, shell="luw"), coriolis=cor, nudging=nud, sponge=spg,
+        every_step=False)
     for _ in range(2):
         g.run(5); o.run(5)
         check(g, o, "force mode %s t=%d" % (forces, o.t))
@@ -164,11 +165,14 @@ def test_fp16c_zone_free_core_as_its_own_launch_box(luw, coriolis, grow):
     would show as missing forces in those layers."""
     from oracle import oracle
     Nx, Ny, Nz = 648, 30, 28
-    nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1)       # zones: west 0..5, south 0..5, north Ny-6.., top Nz-6..; east is downstream
+    # zones: west 0..5, south 0..5, north Ny-6.., top Nz-6..; east is downstream
+    nud = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1)
     spg = dict(n_cells=4, inv_tau=0.02)                                                 # sponge: the 4 layers under the top one
     cor = (0.0, 3e-5, 4e-5) if coriolis else None
-    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, True, "auto", synthetic_state(Nx, Ny, Nz, seed=22, shell="luw"), coriolis=cor, nudging=nud, sponge=spg, every_step=True)
-    x0, y0, y1, z1 = 6, 6, Ny - 6, Nz - 6                                                # first cells behind / before the zones (x stays even, pairs stay whole)
+    g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, True, "auto", synthetic_state(Nx, Ny, Nz, seed=22, shell="luw"), coriolis=cor, nudging=nud, sponge=spg,
+        every_step=True)
+    # first cells behind / before the zones (x stays even, pairs stay whole)
+    x0, y0, y1, z1 = 6, 6, Ny - 6, Nz - 6
     if grow == "west": x0 -= 2
     if grow == "south": y0 -= 2
     if grow == "north": y1 += 2
@@ -195,7 +199,8 @@ def test_fluid_reference_cells_switch_to_fields_every_step(luw, kernel):
     Nx, Ny, Nz = (512, 10, 12) if kernel == "p" else (40, 28, 24)
     nud = dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1); spg = dict(n_cells=3, inv_tau=0.02)
     for shell, expect in (("luw", False), (None, True)):
-        g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, kernel == "p", kernel, synthetic_state(Nx, Ny, Nz, seed=31, shell=shell), nudging=nud, sponge=spg, every_step=False)
+        g, o = make_pair(luw, oracle, Nx, Ny, Nz, 2e-5, kernel == "p", kernel, synthetic_state(Nx, Ny, Nz, seed=31, shell=shell), nudging=nud, sponge=spg,
+            every_step=False)
         g.run(0)
         assert g.fields_every_step() == expect
         g.run(7); o.run(7)
@@ -379,7 +384,8 @@ def test_hip_path_vs_real_reference_fields(luw, case, fp16c, npz):
     from test_oracle_vs_reference import compare
     gold = np.load(os.path.join(GOLD, npz))
     s = setup_profile.setup_profile_case(os.path.join(GOLD, "refcases", case, "conf.luwpf"), solid_mask=gold["solid"])
-    nud = dict(n_cells=s["buffer_N"], inv_tau=float(s["buffer_inv_tau"]), downstream_face=s["buffer_face"], nudge_vertical=s["buffer_nudge_vertical"]) if s["buffer_active"] else None
+    nud = dict(n_cells=s["buffer_N"], inv_tau=float(s["buffer_inv_tau"]), downstream_face=s["buffer_face"], nudge_vertical=s["buffer_nudge_vertical"]) if s[
+        "buffer_active"] else None
     spg = dict(n_cells=s["sponge_N"], inv_tau=float(s["sponge_inv_tau"])) if s["sponge_active"] else None
     g = luw.LBM(s["Nx"], s["Ny"], s["Nz"], float(s["nu"]), fp16c=fp16c, buffer_nudging=nud, top_sponge=spg)
     g.flags.data[:] = s["flags"]; g.u.data[:] = s["u"]; g.rho.data[:] = s["rho"]
@@ -504,7 +510,8 @@ def test_fp32_row_form_addressing_matches_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_halo.py"),
-                        "-k", "(stream_collide_matches_oracle and False-s) or (all_force_terms and False-s) or thermal_lattice or (local_group_equals and False)"],
+                        "-k", "(stream_collide_matches_oracle and False-s) or (all_force_terms and False-s) or thermal_lattice or (local_group_equals and "
+                            "False)"],
                        env=dict(os.environ, LUW_ADDR_ROW="1"), capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
@@ -520,7 +527,8 @@ def test_1024_cubed_on_one_gpu_properties():
     assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     # (its 2^32-byte planes are the largest the flat addressing form takes: byte offsets up to 2^32 - 4.)  The row form at the same size
     # must leave the same 4.3 G values, bit for bit (digest over rho and u):
-    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, LUW_ADDR_ROW="1"))
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
+        env=dict(os.environ, LUW_ADDR_ROW="1"))
     assert r2.returncode == 0 and "exact fixed point = True" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-1500:]
     d1, d2 = re.search(r"digest (xor=\w+ sum=\w+)", r.stdout), re.search(r"digest (xor=\w+ sum=\w+)", r2.stdout)
     assert d1 and d2 and d1.group(1) == d2.group(1), (d1 and d1.group(1), d2 and d2.group(1))

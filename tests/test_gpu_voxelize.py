@@ -79,7 +79,8 @@ def test_triangle_bins_do_not_change_the_mask(luw):
             tris += mr.rot_box_tris(cx, cy, rng.uniform(4, 30), rng.uniform(4, 30), 3.0, 3.0 + rng.uniform(2, 50), rng.uniform(0, 90))
         elif kind == 1:
             w = rng.uniform(5, 20)
-            tris += mr.hull_tris([(cx - w, cy - w, 3.0), (cx + w, cy - w * 0.8, 3.0), (cx + w * 0.9, cy + w, 3.0), (cx - w, cy + w * 0.7, 3.0)], [(cx, cy, 3.0 + rng.uniform(5, 40))])
+            tris += mr.hull_tris([(cx - w, cy - w, 3.0), (cx + w, cy - w * 0.8, 3.0), (cx + w * 0.9, cy + w, 3.0), (cx - w, cy + w * 0.7, 3.0)],
+                [(cx, cy, 3.0 + rng.uniform(5, 40))])
         else:
             z = rng.uniform(10, 40)
             tris += mr.hull_tris([(cx - 6, cy - 5, z), (cx + 7, cy - 4, z + 1.5), (cx, cy + 8, z + 0.7)], [(cx + 0.5, cy, z + rng.uniform(4, 15))])

@@ -40,7 +40,8 @@ def device_asm(tmp_path_factory):
     return kernels
 
 
-FP_ARITH = re.compile(r"^v_(add|sub|subrev|fma|fmac|mad|mac|div|rcp|rsq|sqrt|min|max|med3|cvt|exp|log|sin|cos|ldexp|frexp|trunc|ceil|floor|rndne|fract|pk_fma|pk_add)_?\w*f(16|32|64)")
+FP_ARITH = re.compile(r"^v_(add|sub|subrev|fma|fmac|mad|mac|div|rcp|rsq|sqrt|min|max|med3|cvt|exp|log|sin|cos|ldexp|frexp|trunc|ceil|floor|rndne|fract"
+                      r"|pk_fma|pk_add)_?\w*f(16|32|64)")
 
 
 def reachable_from(body, start):
@@ -86,10 +87,12 @@ def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
     # scalar kernel: FP32 in both addressing forms (FLAT for planes within 32-bit byte offsets, row form beyond), FP16C in the row form,
     # general and force-free; pair kernel: force modes none / uniform / any in registers, any with the second cell parked in LDS (the product's general kernel),
     # and the three thermal variants (always parked); both time parities each: 8 + 8 + 6
-    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb0ELb[01]E", n) or re.search(r"k_stream_collide_pILi[01]ELi0ELb0ELi[012]E", n)]
+    product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb0ELb[01]E", n)
+        or re.search(r"k_stream_collide_pILi[01]ELi0ELb0ELi[012]E", n)]
     assert len(product) == 22, product
     # the same kernels with the statistics epilogue (sampled steps): no spills either
-    sampled = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb1ELb0E", n) or re.search(r"k_stream_collide_pILi[01]ELi0ELb1ELi2E", n)]
+    sampled = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb1ELb0E", n)
+        or re.search(r"k_stream_collide_pILi[01]ELi0ELb1ELi2E", n)]
     assert len(sampled) == 8, sampled
     for name in sampled:
         assert not any(t.startswith(("scratch_", "buffer_store", "buffer_load")) for t in device_asm[name]), name + ": spills"

@@ -25,12 +25,14 @@ for tag, extra in builds:
     so = os.path.join(out_dir, "libluw_%s.so" % tag)
     if extra.startswith("@"):                     # a library built elsewhere (e.g. an older commit, shipped under tools/): "<tag>=@<path>"
         so = os.path.join(ROOT, extra[1:])
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-Wno-unused-function", *extra.split(), "-shared", "-o", so, src]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-Wno-unused-function", *extra.split(),
+        "-shared", "-o", so, src]
     if not extra.startswith("@"):
         subprocess.check_call(cmd)
     L = C.CDLL(so)
     L.luw_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]; L.luw_host_ptr.argtypes = [C.c_void_p, C.c_int]; L.luw_host_ptr.restype = C.c_void_p
-    L.luw_run_timed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]; L.luw_initialize.argtypes = [C.c_void_p]; L.luw_run.argtypes = [C.c_void_p, C.c_uint64]
+    L.luw_run_timed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]; L.luw_initialize.argtypes = [C.c_void_p]; L.luw_run.argtypes = [C.c_void_p,
+        C.c_uint64]
     L.luw_set_coriolis.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]; L.luw_destroy.argtypes = [C.c_void_p]; L.luw_last_error.restype = C.c_char_p
     libs.append((tag, L))
 
@@ -41,7 +43,8 @@ def make(L, fp16c, N, opts):
     if "th" in opts: cfg.options = 8; cfg.alpha = 2.1e-7
     if "urban" in opts:
         nud, spg = tile_forcing()
-        cfg.buffer_nudging_active = 1; cfg.buffer_n_cells = nud["n_cells"]; cfg.buffer_inv_tau_lbmu = nud["inv_tau"]; cfg.buffer_downstream_face_id = nud["downstream_face"]
+        cfg.buffer_nudging_active = 1; cfg.buffer_n_cells = nud["n_cells"]; cfg.buffer_inv_tau_lbmu = nud["inv_tau"]; cfg.buffer_downstream_face_id = nud[
+            "downstream_face"]
         cfg.top_sponge_active = 1; cfg.sponge_n_cells = spg["n_cells"]; cfg.sponge_inv_tau_lbmu = spg["inv_tau"]
     h = C.c_void_p()
     assert L.luw_create(C.byref(cfg), C.byref(h)) == 0, L.luw_last_error()
@@ -63,5 +66,6 @@ for w in workloads:
     base = sorted(res[0])[len(res[0]) // 2]
     for (tag, L), r, h in zip(libs, res, hs):
         med = sorted(r)[len(r) // 2]
-        print("%-44s %-14s kernel ms median %.4f min %.4f  (%+.1f %% vs %s)   rounds %s" % (w, tag, med, min(r), (med / base - 1) * 100, libs[0][0], " ".join("%.3f" % v for v in r)), flush=True)
+        print("%-44s %-14s kernel ms median %.4f min %.4f  (%+.1f %% vs %s)   rounds %s" % (w, tag, med, min(r), (med / base - 1) * 100, libs[0][0],
+            " ".join("%.3f" % v for v in r)), flush=True)
         L.luw_destroy(h)

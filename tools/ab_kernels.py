@@ -23,4 +23,5 @@ for rnd in range(6):
         capi.check(g._L.luw_set_kernel(g._h, NAMES[k]))
         res[k].append(g.run_timed(40))
 for k in kernels:
-    r = sorted(res[k]); print("%s %s %-8s kernel ms min %.3f median %.3f -> %.0f MLUPS" % (N, dt, k, r[0], r[len(r) // 2], N[0] * N[1] * N[2] / r[len(r) // 2] / 1e3))
+    r = sorted(res[k]); print(
+        "%s %s %-8s kernel ms min %.3f median %.3f -> %.0f MLUPS" % (N, dt, k, r[0], r[len(r) // 2], N[0] * N[1] * N[2] / r[len(r) // 2] / 1e3))

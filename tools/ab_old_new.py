@@ -11,7 +11,8 @@ from bench import channel_state
 def make(libpath, N):
     L = C.CDLL(libpath)
     L.luw_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]; L.luw_host_ptr.argtypes = [C.c_void_p, C.c_int]; L.luw_host_ptr.restype = C.c_void_p
-    L.luw_run_timed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]; L.luw_initialize.argtypes = [C.c_void_p]; L.luw_run.argtypes = [C.c_void_p, C.c_uint64]
+    L.luw_run_timed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]; L.luw_initialize.argtypes = [C.c_void_p]; L.luw_run.argtypes = [C.c_void_p,
+        C.c_uint64]
     L.luw_last_error.restype = C.c_char_p
     cfg = Config(); cfg.struct_size = C.sizeof(Config); cfg.Nx, cfg.Ny, cfg.Nz = N; cfg.Dx = cfg.Dy = cfg.Dz = 1; cfg.nu = 1.48e-7
     cfg.ddf_format = 1 if FP16C else 0
@@ -35,6 +36,7 @@ for FP16C, N in shapes:
         for k, (L, h) in enumerate(objs):
             ms = C.c_double(); assert L.luw_run_timed(h, 40, C.byref(ms)) == 0; res[k].append(ms.value)
     for p, r in zip(libs, res):
-        r = sorted(r); print("%s %s %-28s kernel ms min %.3f median %.3f -> %.0f MLUPS" % (N, "fp16c" if FP16C else "f32", os.path.basename(p), r[0], r[2], N[0] * N[1] * N[2] / r[2] / 1e3))
+        r = sorted(r); print("%s %s %-28s kernel ms min %.3f median %.3f -> %.0f MLUPS" % (N, "fp16c" if FP16C else "f32", os.path.basename(p), r[0], r[2],
+            N[0] * N[1] * N[2] / r[2] / 1e3))
     for L, h in objs:
         L.luw_destroy.argtypes = [C.c_void_p]; L.luw_destroy(h)

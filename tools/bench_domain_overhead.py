@@ -16,7 +16,8 @@ class Loopback:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--D", type=int, nargs=3, default=[4, 2, 1]); ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
-    ap.add_argument("--steps", type=int, default=100); ap.add_argument("--dtype", default="f32"); ap.add_argument("--no-overlap", action="store_true"); ap.add_argument("--phases", action="store_true"); ap.add_argument("--x-shell", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=100); ap.add_argument("--dtype", default="f32"); ap.add_argument("--no-overlap",
+        action="store_true"); ap.add_argument("--phases", action="store_true"); ap.add_argument("--x-shell", type=int, default=0)
     a = ap.parse_args()
     import torch
     import latticeurbanwind_amd as luw
@@ -35,7 +36,8 @@ def main():
     sim.initialize(); sim.run(10); torch.cuda.synchronize()
     t0 = time.perf_counter(); k_ms = (sim.run(a.steps, timed=True) or {}).get("kernel_ms"); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     cells = a.size[0] * a.size[1] * a.size[2]
-    print("D=%s local=%s overlap=%s: %.3f ms/step -> %.0f MLUPS per GPU (interior kernel %.3f ms)" % (D, (sim.lNx, sim.lNy, sim.lNz), sim.overlap, dt / a.steps * 1e3, cells * a.steps / dt / 1e6, k_ms or 0))
+    print("D=%s local=%s overlap=%s: %.3f ms/step -> %.0f MLUPS per GPU (interior kernel %.3f ms)" % (D, (sim.lNx, sim.lNy, sim.lNz), sim.overlap,
+        dt / a.steps * 1e3, cells * a.steps / dt / 1e6, k_ms or 0))
     if a.phases:   # serialised phases, one stream: what each piece costs on its own
         b, lay = sim.backend, sim.layout
         st = b.compute

@@ -18,7 +18,8 @@ def run(gN, D, steps, label):
     fill_channel(g.flags, g.u, g.rho, *gN)
     g.run(0); g.run(5)
     t0 = time.perf_counter(); g.run(steps); dt = (time.perf_counter() - t0) / steps
-    print("%-64s %8.3f ms/step  = %7.3f ms per domain   (%.0f MLUPS on this one GPU; overlap %s, peer stores %s)" % (label, dt * 1e3, dt * 1e3 / n, gN[0] * gN[1] * gN[2] / dt / 1e6, g.overlaps(), g.direct_peer_stores()))
+    print("%-64s %8.3f ms/step  = %7.3f ms per domain   (%.0f MLUPS on this one GPU; overlap %s, peer stores %s)" % (label, dt * 1e3, dt * 1e3 / n,
+        gN[0] * gN[1] * gN[2] / dt / 1e6, g.overlaps(), g.direct_peer_stores()))
     g.close()
 
 

@@ -13,10 +13,12 @@ mr.write_case(tmp, "Big", s, ["enable_buffer_nudging = true", "enable_top_sponge
               dims=(102.4, 102.4, 22.4), building="city", nstep=40, unsteady=20, purge=8, vk=True, cell=0.1)
 deck = os.path.join(tmp, "Big", "conf.luwpf")
 t0 = time.time()
-r = subprocess.run([os.path.join(ROOT, "latticeurbanwind_amd/host/luw_driver"), deck, "--ddf", sys.argv[1] if len(sys.argv) > 1 else "fp16c"], capture_output=True, text=True)
+r = subprocess.run([os.path.join(ROOT, "latticeurbanwind_amd/host/luw_driver"), deck, "--ddf", sys.argv[1] if len(sys.argv) > 1 else "fp16c"],
+    capture_output=True, text=True)
 print("rc", r.returncode, "wall %.1f s" % (time.time() - t0))
 for l in r.stdout.splitlines():
-    if any(k in l for k in ("Grid Resolution", "Voxelized cells (whole", "profile boundaries mapped", "VK inlet", "Solver ", "Avg samples", "ERROR", "WARNING")):
+    if any(k in l
+            for k in ("Grid Resolution", "Voxelized cells (whole", "profile boundaries mapped", "VK inlet", "Solver ", "Avg samples", "ERROR", "WARNING")):
         print(l)
 for f in sorted(glob.glob(os.path.join(tmp, "Big", "RESULTS", "vtk", "*.vtk"))):
     h, d = read_vtk(f)

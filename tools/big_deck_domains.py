@@ -15,7 +15,9 @@ D = tuple(int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (4, 2, 1)
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 24
 tmp = tempfile.mkdtemp(dir=os.environ.get("LUW_BIG_TMP", "/tmp"))
 s = 20.0          # geometry units -> metres
-mr.write_case(tmp, "Tile", s, ["enable_buffer_nudging = true", "enable_top_sponge = true", "sponge_thickness_m = 64", "vk_inlet_l = 60", "vk_inlet_nmodes = 64", "n_gpu = [%d, %d, %d]" % D, "output_tke_ti_tls = []"],   # 37 GB of output instead of 62: the box's disk holds 79
+# 37 GB of output instead of 62: the box's disk holds 79
+mr.write_case(tmp, "Tile", s, ["enable_buffer_nudging = true", "enable_top_sponge = true", "sponge_thickness_m = 64", "vk_inlet_l = 60", "vk_inlet_nmodes = 64",
+    "n_gpu = [%d, %d, %d]" % D, "output_tke_ti_tls = []"],
               dims=(204.8, 102.4, 48.0), building="city", nstep=steps, unsteady=0, purge=8, vk=True, cell=0.1)
 deck = os.path.join(tmp, "Tile", "conf.luwpf")
 n = D[0] * D[1] * D[2]
@@ -25,7 +27,8 @@ r = subprocess.run([os.path.join(ROOT, "latticeurbanwind_amd/host/luw_driver"), 
 wall = time.time() - t0
 print("rc", r.returncode, "wall %.1f s, peak RSS of the driver %.1f GB" % (wall, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0))
 for l in r.stdout.splitlines():
-    if any(k in l for k in ("Grid Resolution", "Domains", "halo faces", "Voxelized cells (whole", "profile boundaries mapped", "VK inlet", "Solver ", "Avg samples", "ERROR", "WARNING", "Error")):
+    if any(k in l for k in ("Grid Resolution", "Domains", "halo faces", "Voxelized cells (whole", "profile boundaries mapped", "VK inlet", "Solver ",
+            "Avg samples", "ERROR", "WARNING", "Error")):
         print(l[:200])
 print(r.stderr[-3000:])
 for f in sorted(glob.glob(os.path.join(tmp, "Tile", "RESULTS", "vtk", "*.vtk"))):

@@ -31,6 +31,7 @@ mean = float(g.rho.data.astype(np.float64).mean()); fin = bool(np.isfinite(g.u.d
 dig_x = int(np.bitwise_xor.reduce(g.rho.data.view(np.uint32))) ^ int(np.bitwise_xor.reduce(g.u.data.view(np.uint32)))
 dig_s = (int(g.rho.data.view(np.uint32).sum(dtype=np.uint64)) + int(g.u.data.view(np.uint32).sum(dtype=np.uint64))) & 0xFFFFFFFFFFFFFFFF
 print("%s 1024^3 digest xor=%08x sum=%016x" % (dt, dig_x, dig_s), flush=True)
-print("%s 1024^3 shear wave, 12 steps: mean rho - 1 = %.2e, finite = %s, max |ux| = %.5f (decaying from 0.02)  (%.0f s)" % (dt, mean - 1.0, fin, umax, time.time() - t0))
+print("%s 1024^3 shear wave, 12 steps: mean rho - 1 = %.2e, finite = %s, max |ux| = %.5f (decaying from 0.02)  (%.0f s)" % (dt, mean - 1.0, fin, umax,
+    time.time() - t0))
 g.close()
 assert rest and fin and abs(mean - 1.0) < (1e-4 if dt == "fp16c" else 1e-6) and 0.015 < umax <= 0.02

@@ -38,12 +38,14 @@ class SelfNeighbour(TorchDistTransport):
 
 
 def run(transport_of):
-    sim = DomainDecomposedLBM(N, D, 1.48e-7, rank=0, transport=None if transport_of is None else Loopback(), overlap=(os.environ.get("LUW_SELF_OVERLAP", "1") != "0"), fp16c=(dt == "fp16c"), device=0)
+    sim = DomainDecomposedLBM(N, D, 1.48e-7, rank=0, transport=None if transport_of is None else Loopback(),
+        overlap=(os.environ.get("LUW_SELF_OVERLAP", "1") != "0"), fp16c=(dt == "fp16c"), device=0)
     if transport_of is not None:
         sim.transport = transport_of(sim.layout)
     fl, u, rho = channel_state(sim.lNx, sim.lNy, sim.lNz, *sim.global_offset, *N)
     sim.set_fields(fl, u, rho); sim.initialize(); sim.run(5)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); k_ms = (sim.run(steps, timed=True) or {}).get("kernel_ms"); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize(); t0 = time.perf_counter(); k_ms = (sim.run(steps, timed=True) or {}).get("kernel_ms"); torch.cuda.synchronize(); ms = (
+        time.perf_counter() - t0) / steps * 1e3
     sys.stderr.write("  %s: %.3f ms/step, interior kernel %.3f ms\n" % (type(sim.transport).__name__, ms, k_ms or 0.0))
     uu, rr = sim.fields()
     out = (uu.copy(), rr.copy(), ms)
@@ -76,6 +78,7 @@ else:
 c = run_undivided()
 same = np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 undiv = np.array_equal(c[2](b[0], 3).view(np.uint32), c[0].view(np.uint32)) and np.array_equal(c[2](b[1], 1).view(np.uint32), c[1].view(np.uint32))
-print("%s D=%s local %s: loopback %.3f ms/step, RCCL self send/recv %.3f ms/step, fields identical: %s, equal to the undivided periodic run: %s" % (dt, D, size, a[2], b[2], same, undiv))
+print("%s D=%s local %s: loopback %.3f ms/step, RCCL self send/recv %.3f ms/step, fields identical: %s, equal to the undivided periodic run: %s" % (dt, D, size,
+    a[2], b[2], same, undiv))
 dist.destroy_process_group()
 assert same and undiv

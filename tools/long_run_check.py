@@ -19,6 +19,7 @@ t0 = time.time(); g.run(steps); g.u.read_from_device(); g.rho.read_from_device()
 U = g.u.data.reshape(3, -1)
 ok = bool(np.isfinite(g.rho.data).all() and np.isfinite(g.u.data).all())
 m1 = float(g.rho.data[fluid].astype(np.float64).mean())
-print("%s %s %d steps in %.1f s: finite %s, mean rho of fluid cells %.8f -> %.8f, max |u| %.4f (inflow 0.1)" % (wl, dt, steps, dtw, ok, m0, m1, float(np.abs(U).max())))
+print("%s %s %d steps in %.1f s: finite %s, mean rho of fluid cells %.8f -> %.8f, max |u| %.4f (inflow 0.1)" % (wl, dt, steps, dtw, ok, m0, m1,
+    float(np.abs(U).max())))
 assert ok and abs(m1 - m0) < 5e-3 and float(np.abs(U).max()) < 0.45
 g.close()

@@ -16,7 +16,8 @@ for k in range(int(os.environ.get("NOBJ", "8"))):
     g.run(0); g.run(10)
     t = sorted(g.run_timed(40) for _ in range(3))[1]
     p = g.device_ptr(capi.FIELD_FI)
-    print("solver %d fi=0x%x (mod 2MiB=0x%x, mod 1GiB=0x%x) rho=0x%x  %.3f ms -> %.0f MLUPS" % (k, p, p % (2 << 20), p % (1 << 30), g.device_ptr(capi.FIELD_RHO), t, N[0] * N[1] * N[2] / t / 1e3))
+    print("solver %d fi=0x%x (mod 2MiB=0x%x, mod 1GiB=0x%x) rho=0x%x  %.3f ms -> %.0f MLUPS" % (k, p, p % (2 << 20), p % (1 << 30),
+        g.device_ptr(capi.FIELD_RHO), t, N[0] * N[1] * N[2] / t / 1e3))
     if KEEP_ALL or k % 2 == 0: keep.append(g)
     else: g.close()
 for g in ([] if KEEP_ALL else keep):   # re-time the kept ones at the end

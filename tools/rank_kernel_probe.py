@@ -34,5 +34,6 @@ print("interior kernel alone      %.3f ms" % alone(sim.layout.interior_box()))
 print("whole-box kernel alone     %.3f ms" % alone(sim.layout.whole_box()))
 for bx in sim.layout.shell_boxes(): print("shell box %s alone %.3f ms" % (bx, alone(bx)))
 t0 = time.perf_counter(); tm = sim.run(60, timed=True); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 60 * 1e3
-print("production step            %.3f ms wall; interior kernel inside it %.3f ms, shell %.3f ms, pack+exchange+unpack %.3f ms" % (ms, tm["kernel_ms"], tm["shell_ms"] or 0.0, tm["exchange_ms"]))
+print("production step            %.3f ms wall; interior kernel inside it %.3f ms, shell %.3f ms, pack+exchange+unpack %.3f ms" % (ms, tm["kernel_ms"],
+    tm["shell_ms"] or 0.0, tm["exchange_ms"]))
 sim.backend.close(); torch.distributed.destroy_process_group()

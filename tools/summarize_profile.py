@@ -36,12 +36,14 @@ def optional(dirpat, name):
 valu_busy, mem_stalled = optional("pmc_VALUBusy_MemUnitStalled", "VALUBusy"), optional("pmc_VALUBusy_MemUnitStalled", "MemUnitStalled")
 waves, insts_valu, insts_salu = (optional("pmc_SQ_WAVES_SQ_INSTS_VALU_SQ_INSTS_SALU", n) for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"))
 traffic = rd * 128.0 + write_kb * 1024.0
-s = {"tag": tag, "workload": bench["config"]["workload"], "kernel": kname, "launches": calls, "rocprof_avg_ms": round(tot / calls / 1e6, 4), "hip_event_avg_ms_same_run": bench["roofline"]["kernel_ms"],
+s = {"tag": tag, "workload": bench["config"]["workload"], "kernel": kname, "launches": calls, "rocprof_avg_ms": round(tot / calls / 1e6, 4),
+    "hip_event_avg_ms_same_run": bench["roofline"]["kernel_ms"],
      "algorithmic_bytes_per_launch": algo, "FETCH_SIZE_KB": fetch_kb, "FETCH_bytes_corrected_x2": fetch_kb * 1024.0 * 2.0, "TCC_EA0_RDREQ": rd,
      "read_bytes_128B_requests": rd * 128.0, "WRITE_SIZE_KB": write_kb, "write_bytes": write_kb * 1024.0, "TCC_EA0_WRREQ": wr,
      "hbm_traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": round(traffic / algo, 3), "L2_hit_rate": round(hit / max(hit + miss, 1.0), 4),
      "achieved_GBps_algorithmic": round(algo / (tot / calls) , 1),
      "VALUBusy_percent": None if valu_busy is None else round(valu_busy, 1), "MemUnitStalled_percent": None if mem_stalled is None else round(mem_stalled, 2),
-     "waves_per_launch": waves, "valu_insts_per_wave": None if not waves else round(insts_valu / waves, 1), "salu_insts_per_wave": None if not waves else round(insts_salu / waves, 1)}
+     "waves_per_launch": waves, "valu_insts_per_wave": None if not waves else round(insts_valu / waves, 1), "salu_insts_per_wave": None if not waves
+         else round(insts_salu / waves, 1)}
 json.dump(s, open(os.path.join(out, tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(s))

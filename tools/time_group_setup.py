@@ -22,5 +22,6 @@ t0 = time.perf_counter(); capi.check(L.luw_group_initialize(g._h)); tick("luw_gr
 g._initialized = True
 t0 = time.perf_counter(); g.run(4); tick("4 steps", t0)
 t0 = time.perf_counter(); capi.check(L.luw_group_download(g._h, capi.MASK_U | capi.MASK_RHO)); tick("download u, rho", t0)
-t0 = time.perf_counter(); capi.check(L.luw_group_gather(g._h, capi.FIELD_U, p(g.u))); capi.check(L.luw_group_gather(g._h, capi.FIELD_RHO, p(g.rho))); tick("gather u, rho", t0)
+t0 = time.perf_counter(); capi.check(L.luw_group_gather(g._h, capi.FIELD_U, p(g.u))); capi.check(L.luw_group_gather(g._h, capi.FIELD_RHO, p(g.rho))); tick(
+    "gather u, rho", t0)
 t0 = time.perf_counter(); g.close(); tick("destroy", t0)
