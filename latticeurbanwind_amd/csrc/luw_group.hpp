@@ -53,8 +53,8 @@ struct luw_group {
 };
 
 // thickness of the x boundary slabs: 128 cells (a one-cell x face would run one lane per wave; 128 FP16C cells are a full wave of the pair kernel,
-// which narrower slabs would leave to the one-cell kernel; FP32: 16 / 32 / 64 / 128 / 256-cell slabs on the 514x514x512 rank of n_gpu = [4,2,1]
-// 4.13 / 3.91 / 3.85 / 3.77 / 3.84 ms per step, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL overrides (A/B aid)
+// which narrower slabs would leave to the one-cell kernel; FP32: 16 / 32-cell slabs are slower, 64 / 128 / 256 equal within the spread between
+// fresh processes, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL overrides (A/B aid)
 static uint32_t group_x_shell(const luw_group* g) {
 	static const uint32_t env = getenv("LUW_X_SHELL") ? (uint32_t)strtoul(getenv("LUW_X_SHELL"), nullptr, 10) : 0u;
 	(void)g;
