@@ -292,6 +292,27 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
 
 
 SECONDARY_STEPS, SECONDARY_WARMUP = 200, 20
+# the single-GPU secondary blocks: (workload, dtype, Coriolis, thermal lattice, urban forcing)
+SINGLE_BLOCKS = {"c2_f32": ("c2", "f32", False, False, False), "c2_fp16c": ("c2", "fp16c", False, False, False),
+    "c3_fp16c": ("c3", "fp16c", False, False, False),
+                 "c3_fp16c_coriolis": ("c3", "fp16c", True, False, False),
+                 "c3_fp16c_thermal": ("c3", "fp16c", False, True, False),      # FP16C DDFs + the thermal D3Q7 lattice: what the shipped reference build runs
+                 "cube1024_f32": ("cube1024", "f32", False, False, False), "cube1024_fp16c": ("cube1024", "fp16c", False, False, False),
+                 # the 8-GPU tile of BASELINE configs[3] / configs[4] seen from ONE GPU: its N = 1 point (512^3 urban tile, undivided)
+                 "tile512_urban_f32": ("tile512", "f32", False, False, True), "tile512_urban_fp16c_coriolis": ("tile512", "fp16c", True, False, True)}
+
+
+def run_single_block(luw, capi, device, key):
+    wl, dt_, cor, th, urban = SINGLE_BLOCKS[key]
+    sz, bld, _ = WORKLOADS[wl]
+    # >= 200 timed after >= 20 warm-up steps
+    r = run_single(luw, capi.KERNEL_AUTO, device, sz, dt_, bld, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, thermal=th, urban=urban)
+    r["workload"] = (
+        "512^3 urban tile, undivided: the N = 1 point of the N > 1 lines (BASELINE configs[3]%s per GPU)" % (" / configs[4]" if cor else "")) if urban \
+        else describe(wl, sz, bld, dt_, cor, th, False)
+    return r
+
+
 RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0),
                      "c5_rank_4x2x1_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0),
                      "c5_rank_1x4x2_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7)}
@@ -385,6 +406,8 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
         help="take the N > 1 code path (process group, DomainDecomposedLBM) even with one rank: plumbing check")
     ap.add_argument("--every-step-fields", action="store_true", help="write rho,u every step like the reference's UPDATE_FIELDS (169 B/LUP)")
+    ap.add_argument("--secondary-block", choices=sorted(SINGLE_BLOCKS), default=None,
+        help="(used by the N = 1 line itself) measure ONE single-GPU secondary block in this fresh process and print it")
     ap.add_argument("--rank-shape-block", choices=sorted(RANK_SHAPE_BLOCKS), default=None,
         help="(used by the N = 1 line itself) measure ONE rank-shape secondary block in this fresh process and print it")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check against the CPU oracle (profiling runs)")
@@ -426,6 +449,15 @@ def main():
         print(json.dumps(blk)); sys.stdout.flush()
         os.dup2(2, 1)
         return
+    if args.secondary_block:
+        try:
+            blk = run_single_block(luw, capi, local_rank, args.secondary_block)
+        except Exception as e:
+            blk = {"error": str(e)[:300]}
+        sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(blk)); sys.stdout.flush()
+        os.dup2(2, 1)
+        return
     if args.rank_shape_block:
         blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, **RANK_SHAPE_BLOCKS[args.rank_shape_block])
         import torch.distributed as dist
@@ -454,45 +486,23 @@ def main():
         if out["device"].get("copy_GBps"):
             out["roofline"]["frac_of_device_copy"] = round(head["roofline"]["achieved"] / out["device"]["copy_GBps"], 4)
         if not args.no_secondary:
-            # the other single-GPU configurations, same process, same code path, fewer steps (each is its own create / fill / run)
+            # the other single-GPU configurations and single ranks of both cuts of the 8-GPU tile (real local shapes, every face through the real
+            # transport's self send / receive), EACH IN A FRESH PROCESS: a process that has allocated and freed lattice-sized arrays a few times draws worse
+            # physical placements for the next one (the same block 1.74 ms fresh, 1.94-1.98 ms as the third lattice of a process, profiles/r03d/e), and a
+            # rank's RCCL connections have to exist before its lattice is allocated (24-40 % otherwise, profiles/r01g_halo_chain.md)
+            import subprocess
             sec = {}
-            plan = [("c2_f32", "c2", "f32", False, False), ("c2_fp16c", "c2", "fp16c", False, False), ("c3_fp16c", "c3", "fp16c", False, False),
-                ("c3_fp16c_coriolis", "c3", "fp16c", True, False),
-                    ("c3_fp16c_thermal", "c3", "fp16c", False, True),      # FP16C DDFs + the thermal D3Q7 lattice: what the shipped reference build runs
-                    ("cube1024_f32", "cube1024", "f32", False, False), ("cube1024_fp16c", "cube1024", "fp16c", False, False)]
-            for key, wl, dt_, cor, th in plan:
-                sz, bld, _ = WORKLOADS[wl]
-                if (wl, dt_, cor, th) == (args.workload, args.dtype, args.coriolis, args.thermal) and not args.size:
+            headline_key = next((k for k, v in SINGLE_BLOCKS.items() if v == (args.workload, args.dtype, args.coriolis, args.thermal, args.urban)), None)
+            for key, flag in [(k, "--secondary-block") for k in SINGLE_BLOCKS] + [(k, "--rank-shape-block") for k in RANK_SHAPE_BLOCKS]:
+                if key == headline_key and not args.size:
                     continue
                 try:
-                    # >= 200 timed after >= 20 warm-up steps
-                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, sz, dt_, bld, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, thermal=th)
-                    r["workload"] = describe(wl, sz, bld, dt_, cor, th, False)
-                    sec[key] = r
-                except Exception as e:      # a secondary block never takes the headline down; its absence is visible
-                    sec[key] = {"error": str(e)[:300]}
-            # the 8-GPU tile of BASELINE configs[3] / configs[4] seen from ONE GPU: its N = 1 point (512^3 urban tile, undivided) and single ranks of
-            # both cuts in their real local shapes, every face through the real transport's self send / receive (no wire to another device)
-            for key, dt_, cor in (("tile512_urban_f32", "f32", False), ("tile512_urban_fp16c_coriolis", "fp16c", True)):
-                try:
-                    r = run_single(luw, capi.KERNEL_AUTO, local_rank, (512, 512, 512), dt_, True, SECONDARY_STEPS, SECONDARY_WARMUP, coriolis=cor, urban=True)
-                    r["workload"] = "512^3 urban tile, undivided: the N = 1 point of the N > 1 lines (BASELINE configs[3]%s per GPU)" % (" / configs[4]" if cor
-                        else "")
-                    sec[key] = r
-                except Exception as e:
-                    sec[key] = {"error": str(e)[:300]}
-            # single ranks of both cuts, each in a FRESH process like a rank of a real run: RCCL's connections have to exist before the lattice is allocated
-            # (set up in a process that has already allocated and freed lattice-sized arrays they leave the kernels 24-40 % slower,
-            # profiles/r01g_halo_chain.md; this process has done that a dozen times by now)
-            import subprocess
-            for key in RANK_SHAPE_BLOCKS:
-                try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rank-shape-block", key, "--steps", str(SECONDARY_STEPS), "--warmup",
-                        str(SECONDARY_WARMUP)],
+                    r = subprocess.run(
+                        [sys.executable, os.path.abspath(__file__), flag, key, "--steps", str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)],
                                        capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
                     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                     sec[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
-                except Exception as e:
+                except Exception as e:      # a secondary block never takes the headline down; its absence is visible
                     sec[key] = {"error": str(e)[:300]}
             out["secondary"] = sec
         if not args.no_cpu_baseline:
