@@ -352,7 +352,8 @@ class DomainDecomposedLBM:
             rank = dist.get_rank()
         import os
         # x slabs of the boundary shell: 128 cells for both DDF formats (FP16C: a full wave of the pair kernel, 2 cells per lane, which narrower slabs
-        # would leave to the one-cell kernel; FP32: no different from 64 within the run-to-run spread, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL overrides: A/B aid
+        # would leave to the one-cell kernel; FP32: no different from 64 within the run-to-run spread, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL
+        # overrides: A/B aid
         x_shell = int(os.environ.get("LUW_X_SHELL", "0")) or DomainLayout.X_SHELL
         self.layout = DomainLayout(global_N, D, rank, x_shell=x_shell)
         self.wire = {}           # standalone face-exchange rates per split axis (TorchDistTransport.warm_up with LUW_MEASURE_WIRE=<repetitions>)
