@@ -49,3 +49,17 @@ def test_four_ranks_fp16c_coriolis(luw):
     # (no one-process host here: four ranks, this process and a child of rank 0 would be the six processes a test box allows on its GPU)
     out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host")
     assert out["config"]["n_gpu"] == [2, 2, 1] and out["parity"]["ok"] and out["value"] > 0
+
+
+def test_one_rank_over_the_real_rccl_process_group(luw):
+    """the N > 1 code path with ONE rank and no --share-device: the RCCL process group itself (high-priority stream option, device id), the CPU-side gloo
+    group beside it, object collectives over RCCL, the self-check and the timing blocks -- everything of `bench.py --gpus N` that does not need a second GPU"""
+    port = 29500 + ((os.getpid() + 311) % 2000)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-distributed", "--size", "256", "64", "64", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["n_gpu"] == [1, 1, 1] and out["value"] > 0 and out["parity"]["ok"]
+    assert "RCCL" in out["config"]["halo_exchange"] and out["config"]["rccl_version"]
