@@ -272,7 +272,8 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
     finally:
         lbm.close()
     cells = Nx * Ny * Nz
-    bpl = BYTES_PER_LUP[dtype] + (16.0 if every_step else 0.0) + ((7 * 2 * (2 if fp16c else 4) + 4) if thermal else 0.0)   # + gi read/write + T write
+    # + gi read / write; T, like rho and u, is stored by the last step of a run only unless every step is asked for (+ 4 B then)
+    bpl = BYTES_PER_LUP[dtype] + (16.0 if every_step else 0.0) + ((7 * 2 * (2 if fp16c else 4) + (4 if every_step else 0)) if thermal else 0.0)
     # algorithmic bytes of one launch: every cell's flag byte is read; only non-solid cells (fluid and TYPE_E) move their DDFs
     launch_bytes = (bpl - 1.0) * (cells - solid) + 1.0 * cells
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
@@ -287,7 +288,7 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
                 "bytes_per_lup": bpl,
             "options": ("building array" if buildings else "no solids above the ground plane")
                 + (" + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" if urban else "") + (" + Coriolis force" if coriolis else "")
-                + (" + thermal D3Q7 lattice" if thermal else "") + (", rho/u written every step" if every_step else ""),
+                + (" + thermal D3Q7 lattice (T stored with rho/u)" if thermal else "") + (", rho/u written every step" if every_step else ""),
             "roofline": roof}
 
 

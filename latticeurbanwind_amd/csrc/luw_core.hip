@@ -1268,6 +1268,11 @@ static bool reference_cells_are_inputs(const luw_solver* s) {
 	if(k.zs_n&&ok) y_face((uint32_t)k.south_y);
 	if(k.zn_n&&ok) y_face((uint32_t)k.north_y);
 	if((k.zt_n||k.zp_n)&&ok) z_face((uint32_t)k.top_z);
+	// thermal lattice: the sponge on T reads the top layer's temperature, which only a preset (TYPE_T) keeps between the steps that store T (thermal_cell)
+	if(s->d_gi&&k.zp_n&&ok) {
+		const uint32_t z = (uint32_t)k.top_z;
+		for(uint32_t y=0u; y<Ny&&ok; y++) for(uint32_t x=0u; x<Nx; x++) if((s->h_flags[(size_t)x+((size_t)y+(size_t)z*Ny)*Nx]&TYPE_T)==0u) { ok = false; break; }
+	}
 	return ok;
 }
 int luw_fields_every_step(const luw_solver* s) { return (s&&((s->cfg.options&LUW_OPT_UPDATE_FIELDS_EVERY_STEP)!=0u||s->every_step_auto)) ? 1 : 0; }

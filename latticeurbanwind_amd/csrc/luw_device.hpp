@@ -716,8 +716,11 @@ __device__ __forceinline__ void calculate_g_eq(const float T, const float ux, co
 }
 // the cell update on streamed-in populations g[7] (in place): T = sum g + 1 (or the preset on TYPE_T cells), top sponge on T, BGK with w_T
 // (TYPE_T: g = g_eq); writes T of a cell that is not preset.  FX/kernel.cpp:1652-1684
+// write_T: like rho and u (write_fields), T is a by-product -- every step recomputes it from g; the only T the kernel READS are presets and, under the
+// sponge, the top layer's -- so it is stored by the steps whose fields are looked at (the last of a run, sampled steps, every step on request or when
+// a top-layer cell under the sponge is not a preset: reference_cells_are_inputs)
 __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n, const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn,
-		const float ux, const float uy, const float uz, float* __restrict__ Tf, float* g) {
+		const float ux, const float uy, const float uz, float* __restrict__ Tf, float* g, const bool write_T = true) {
 	const bool preset = (flagsn&TYPE_T)!=0u;
 	float Tn;
 	if(preset) Tn = Tf[n];
@@ -727,7 +730,7 @@ __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n,
 	calculate_g_eq(Tn, ux, uy, uz, geq);
 	if(preset) { for(int i=0; i<7; i++) g[i] = geq[i]; }
 	else {
-		Tf[n] = Tn;
+		if(write_T) Tf[n] = Tn;
 		const float omw = 1.0f-p.w_T;
 		for(int i=0; i<7; i++) g[i] = fmaf(omw, g[i], p.w_T*geq[i]);
 	}
@@ -739,7 +742,7 @@ __device__ __forceinline__ void thermal_cell(const KParams& p, const uint32_t n,
 template<typename T,
 	int PARITY> __device__ __forceinline__ void thermal_collide(const KParams& p, const uint32_t n, const uint32_t jx, const uint32_t jy, const uint32_t jz,
 		const uint32_t x, const uint32_t y, const uint32_t z, const uint8_t flagsn, const float ux, const float uy, const float uz, const T* __restrict__ gi,
-			float* __restrict__ Tf, float* g) {
+			float* __restrict__ Tf, float* g, const bool write_T = true) {
 	const size_t Np = p.Np;
 	const uint32_t jn[3] = { jx, jy, jz };
 	g[0] = ddf_decode<T>(gi[n]);
@@ -749,7 +752,7 @@ template<typename T,
 		g[i  ] = ddf_decode<T>(gi[(size_t)(PARITY ? i : i+1)*Np+n]);
 		g[i+1] = ddf_decode<T>(gi[(size_t)(PARITY ? i+1 : i)*Np+jn[k]]);
 	}
-	thermal_cell(p, n, x, y, z, flagsn, ux, uy, uz, Tf, g);
+	thermal_cell(p, n, x, y, z, flagsn, ux, uy, uz, Tf, g, write_T);
 }
 // stream-out of the 7 encoded populations (Esoteric-Pull slots); code_of(i) yields the storage value of population i
 template<typename T, int PARITY, typename F> __device__ __forceinline__ void thermal_store(const KParams& p, const uint32_t n, const uint32_t jx,

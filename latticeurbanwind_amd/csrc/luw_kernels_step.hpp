@@ -161,7 +161,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
 			float u0[3];
 			collide_cell<true, NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
-			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g);
+			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g, write_fields!=0);
 		} else
 		// MODE 3: general path only (A/B)
 		collide_cell<(MODE!=3), NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
@@ -411,7 +411,7 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 			[[maybe_unused]] float u0[3];
 			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c]
 				: nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
-			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g);
+			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g, write_fields!=0);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of
 				// being

@@ -24,8 +24,8 @@ inline void Driver::run_solver() {
 	// ---- the time loop.  The device runs batches of steps without any host round trip inside; between batches the host looks at the
 	// clock, refreshes the running row / the GUI's progress line and handles whatever must be observed at that step (unsteady output,
 	// probe samples).  A batch ends at the next such step, and otherwise after about a quarter of a second of work.
-	// DDFs + flags (+ thermal lattice), DESIGN.md section 5
-	const double bytes_per_cell = (c.fp16c ? 77.0 : 153.0)+(use_temperature_bc ? (c.fp16c ? 32.0 : 60.0) : 0.0);
+	// DDFs + flags (+ the 7 planes of the thermal lattice; rho, u and T are stored by the last step of a batch only), DESIGN.md section 5
+	const double bytes_per_cell = (c.fp16c ? 77.0 : 153.0)+(use_temperature_bc ? (c.fp16c ? 28.0 : 56.0) : 0.0);
 	StepRateMeter meter; meter.configure(total_steps, avg_window>0ull ? avg_start_t : ~0ull);
 	const bool console_row = !g_progress.gui(); // FX/info.cpp:225: the GUI gets protocol lines instead of the table
 	if(console_row) { println(ProgressTable::top()); println(ProgressTable::header()); }

@@ -454,6 +454,8 @@ def test_thermal_lattice_matches_oracle(luw, fp16c, sponge):
         (l.u.data if hasattr(l.u, "data") else l.u)[:] = st[1]
         (l.rho.data if hasattr(l.rho, "data") else l.rho)[:] = st[2]
         (l.T.data if hasattr(l.T, "data") else l.T)[:] = Tinit
+    g.run(0)
+    assert not g.fields_every_step()       # every temperature the kernel reads is a preset: T, like rho and u, is stored by the last step of a call only
     for steps in (1, 2, 14):
         g.run(steps); o.run(steps)
         g.T.read_from_device()
@@ -462,6 +464,25 @@ def test_thermal_lattice_matches_oracle(luw, fp16c, sponge):
         check(g, o, "flow fields with the thermal lattice on")
     assert np.isfinite(o.T).all() and o.T[(flags & 1) == 0].std() > 1e-4
     g.close()
+
+
+def test_sponge_on_a_computed_top_temperature_stores_T_every_step(luw):
+    """the top sponge pulls T towards the top layer's value (FX/kernel.cpp:1660-1666).  Where that layer is preset (TYPE_T, every LUW deck with
+    temperatures) T is an input and is stored by the last step of a call only; a top layer whose temperature is computed has to be stored by
+    every step, like the reference does"""
+    Nx, Ny, Nz = 40, 28, 24
+    st = synthetic_state(Nx, Ny, Nz, seed=12, shell="luw")
+    for preset_top, expect in ((True, False), (False, True)):
+        g = luw.LBM(Nx, Ny, Nz, 1e-3, alpha=4e-3, top_sponge=dict(n_cells=5, inv_tau=0.02))
+        flags = st[0].copy()
+        if preset_top:
+            flags.reshape(Nz, Ny, Nx)[Nz - 1] |= TYPE_T
+        g.flags.data[:] = flags; g.u.data[:] = st[1]; g.rho.data[:] = st[2]; g.T.data[:] = 1.0
+        g.run(0)
+        assert g.fields_every_step() == expect
+        g.run(5); g.T.read_from_device()
+        assert np.isfinite(g.T.data).all()
+        g.close()
 
 
 @pytest.mark.parametrize("size", [(514, 5, 6), (257, 4, 5), (640, 6, 4), (130, 7, 5)])
