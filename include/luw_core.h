@@ -59,8 +59,8 @@ extern "C" {
 
 /* option bits */
 #define LUW_OPT_FORCE_FIELD 0x1u        /* allocate + read the per-cell force F (FORCE_FIELD, FX/kernel.cpp:1617-1623) */
-#define LUW_OPT_UPDATE_FIELDS_EVERY_STEP 0x2u /* write rho,u in every step exactly like UPDATE_FIELDS (FX/kernel.cpp:1709-1716);
-                                           without it rho,u are written by the last step of each luw_run() call and on
+#define LUW_OPT_UPDATE_FIELDS_EVERY_STEP 0x2u /* write rho,u (and T) in every step exactly like UPDATE_FIELDS (FX/kernel.cpp:1709-1716);
+                                           without it rho,u,T are written by the last step of each luw_run() call and on
                                            luw_download(), which yields identical values whenever they are observed */
 #define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha */
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
@@ -149,7 +149,8 @@ uint64_t luw_get_t(const luw_solver* s);     /* LBM::get_t */
 /* run-time setters the reference allows between steps at no cost (kernel arguments, FX/lbm.cpp:345) */
 /* 1 when every step of this solver writes rho,u like the reference's UPDATE_FIELDS build: LUW_OPT_UPDATE_FIELDS_EVERY_STEP, or -- decided by
  * luw_initialize -- a buffer-nudging / sponge reference cell (outer face the domain owns, FX/kernel.cpp:1543-1611) is a fluid cell, whose u those
- * terms read one step later; with TYPE_E / solid faces (every LUW deck) the fields are written by the last step of a run() call only. */
+ * terms read one step later, or (thermal lattice) a top-layer cell under the sponge is not a TYPE_T preset; with TYPE_E / solid faces and preset
+ * boundary temperatures (every LUW deck) the fields are written by the last step of a run() call only. */
 int luw_fields_every_step(const luw_solver* s);
 int luw_set_f(luw_solver* s, float fx, float fy, float fz);               /* LBM::set_f */
 int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz);        /* LBM::set_coriolis */
