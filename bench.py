@@ -506,6 +506,17 @@ def main():
                 except Exception as e:      # a secondary block never takes the headline down; its absence is visible
                     sec[key] = {"error": str(e)[:300]}
             out["secondary"] = sec
+            # how this box compares: the 512^3 FP32 empty channel is the best-characterised workload of the repo (3.27-3.31 ms in ten fresh processes
+            # on the boxes of profiles/r02_placement_study*.txt, 3.29-3.32 ms in every default line of round 3 but one); whole boxes run everything 10-20 %
+            # slower at times (profiles/r02_skew_study.md, r03g_bench_default.json) without any clock or copy-rate reading showing it
+            ref_ms = 3.30
+            probe = sec.get("c2_f32", {}).get("ms_per_step") if args.workload != "c2" or args.dtype != "f32" else head["ms_per_step"]
+            if probe:
+                out["device"]["step_probe"] = {
+                    "workload": "512x512x512 FP32 empty channel (secondary c2_f32)", "ms_per_step": probe, "typical_ms_per_step": ref_ms,
+                    "box_factor": round(probe / ref_ms, 3),
+                    "note": "box_factor > 1.05: this box (or this session on it) runs the step kernels that much slower than the boxes the repo's "
+                            "numbers were taken on; it scales every block of this line alike"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             try:
