@@ -200,7 +200,7 @@ struct luw_solver {
 // 64 elements, the first OWNED cell of every row (x = halo_x) then begins a 256-byte (FP32) / 128-byte (FP16C) block, so
 // that a wave's 64 consecutive cells are exactly the lines it touches -- in a halo'ed domain (Nx = 512 + 2) just as in a
 // single one.  Measured on MI355X before this: interior kernel of a 514x514x512 domain 7.3 ms vs 3.5 ms for 512^3.
-static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, const size_t elem_bytes) {
+static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, const size_t elem_bytes, const size_t* chunk_override = nullptr) {
 	DevBlock blk;
 	const size_t lead = (size_t)(64u-s->kp.halo_x)*elem_bytes, total = elems*elem_bytes+64u*elem_bytes;
 	// arrays under 64 MiB: hipMalloc.  Larger ones: chunks of EXACTLY the configured size (1 GiB) -- measured: the same lattice on chunks of 0.93 GiB
@@ -210,7 +210,7 @@ static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, con
 	static const bool whole_last = getenv("LUW_ALLOC_LAST")&&strncmp(getenv("LUW_ALLOC_LAST"), "whole", 5)==0;
 	size_t chunk = 0u;
 	if(total>=(64ull<<20)) {
-		const size_t cap = alloc_vmm_chunk(), mib2 = 2ull<<20;
+		const size_t cap = chunk_override ? *chunk_override : alloc_vmm_chunk(), mib2 = 2ull<<20;   // (override: tune_ddf_placement's candidates)
 		chunk = (cap==0u||cap==~(size_t)0u) ? cap : std::min<size_t>(cap, ((total+mib2-1u)/mib2)*mib2);
 	}
 	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk, !whole_last);
@@ -593,13 +593,28 @@ static std::atomic<int> g_live_solvers[64];
 static int tune_ddf_placement(luw_solver* s) {
 	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
 	const char* env = getenv("LUW_TUNE_PLACEMENT");
-	// hipMalloc'ed arrays: up to 6 candidates (round 1); chunk-mapped arrays: none.  (Round 3 tried a short search for them as a safety net against the
-	// boxes on which the same binary runs 10-20 % slower: the probe of the FIRST mapping of a process is biased -- 4.5 against 4.0 ms for later ones of the
-	// same size, the GPU is still ramping up -- and releasing a loser's address range and chunks (hipMemUnmap / hipMemRelease / hipMemAddressFree) leaves
-	// this ROCm's runtime in a state in which the solver's final dev_free segfaults, reproducibly.  LUW_TUNE_PLACEMENT=<n> still forces a search.)
-	const int candidates = env ? atoi(env) : (s->raw.front().chunks.empty() ? 6 : 0);
+	// hipMalloc'ed arrays (LUW_ALLOC=malloc): up to 6 candidates of the same kind (round 1).  Chunk-mapped arrays (the default): on most boxes 1 GiB
+	// chunks are the fast class every time, but there are boxes on which the same binary runs the 512 MiB / 1 GiB-plane lattices 12-14 % slower on them
+	// while 2 GiB chunks or a plain hipMalloc are fast (profiles/r03_chunk_study_slow_box.txt: 512^3 FP32 3.76 / 3.39 ms on 1 GiB chunks / hipMalloc,
+	// 1024x1024x256 7.79 / 6.82 ms on 1 GiB / 2 GiB chunks) -- so a first mapping that is not of the fast class is followed by those alternatives.
+	// A chunk-mapped loser is NOT released before the solver goes (unmapping and releasing a mapping here left this ROCm's runtime in a state in which
+	// the solver's final dev_free crashed); it costs its memory until then, and the search stops when the device has no room for that.
+	const bool mapped = !s->raw.front().chunks.empty();
+	static size_t alternatives[3] = { 2048ull<<20, 512ull<<20, 0u };   // chunk sizes tried behind the default (0: hipMalloc)
+	if(const char* a = getenv("LUW_TUNE_ALTS")) { // study aid: "2048,512,0" (MiB)
+		unsigned long long v[3] = { 2048ull, 512ull, 0ull };
+		sscanf(a, "%llu,%llu,%llu", &v[0], &v[1], &v[2]);
+		for(int k=0; k<3; k++) alternatives[k] = (size_t)v[k]<<20;
+	}
+	const int candidates = env ? atoi(env) : (mapped ? 4 : 6);
 	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
+	// (planes of 2 GiB and more -- 1024^3 -- run alike on every kind of piece, profiles/r02_placement_study.txt: no search, no 80 GB candidates)
+	if(mapped&&!env&&s->kp.Np*s->ddf_bytes>(3ull<<29)) return LUW_OK;
 	if(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1) return LUW_OK; // this device is shared with other solvers of this process
+	// chunk-mapped arrays: ONE search per process and device (the first large solver: a bench run, a rank, a deck's first case).  A second search in
+	// a process that had released the candidates of a first one aborted inside the runtime (tests/test_gpu_tile_full.py under LUW_TUNE_FAST=99)
+	static std::atomic<bool> searched[64];
+	if(mapped&&s->cfg.device<64&&searched[s->cfg.device].exchange(true)) return LUW_OK;
 	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
 	struct Events { hipEvent_t e0 = nullptr, e1 = nullptr; ~Events() { if(e0) (void)hipEventDestroy(e0); if(e1) (void)hipEventDestroy(e1); } } ev;
 	HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
@@ -617,29 +632,39 @@ static int tune_ddf_placement(luw_solver* s) {
 		HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
 		return LUW_OK;
 	};
-	// a placement of the fast class moves this many algorithmic bytes per second through the probe (FP32 153, FP16C 77 B per update)
-	const double probe_bytes = 2.0*(s->ddf_bytes==4u ? 153.0 : 77.0)*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
-	auto fast_class = [&](const float ms) { return probe_bytes/((double)ms*1e-3)>=(s->ddf_bytes==4u ? 6.0e12 : 5.4e12); };
+	// a placement of the fast class moves this many algorithmic bytes per second through the probe (FP32 153, FP16C 77 B per update; the probe's lattice
+	// is all fluid at rest).  LUW_TUNE_FAST=<TB/s> overrides the bar (LUW_TUNE_FAST=99: every candidate is tried, test aid)
+	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)
+		+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
+	const double bar = getenv("LUW_TUNE_FAST") ? atof(getenv("LUW_TUNE_FAST"))*1e12 : (s->ddf_bytes==4u ? 6.15e12 : 5.9e12);
+	auto fast_class = [&](const float ms) { return probe_bytes/((double)ms*1e-3)>=bar; };
 	float best_ms = 0.0f;
+	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
 	if(int e = step_ms(best_ms)) return e;
 	const bool verbose = getenv("LUW_TUNE_VERBOSE")!=nullptr;
-	if(verbose) fprintf(stderr, "luw: placement candidate 0: %.3f ms per 2 steps\n", best_ms);
+	if(verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", mapped ? "1 GiB chunks" : "hipMalloc", best_ms,
+		probe_bytes/best_ms*1e-9);
 	for(int k=1; k<candidates&&!fast_class(best_ms); k++) {
+		if(mapped&&k>3) break;
 		size_t free_b = 0u, total_b = 0u;
-		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+bytes/4u+(2ull<<30)) break; // room for ONE more array plus what the run still allocates
+		// room for ONE more array plus what the run may still allocate (statistics: 32 B per cell, staging, halo buffers)
+		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+40ull*s->kp.Np+(2ull<<30)) break;
 		void* fi = nullptr;
-		if(lead_alloc(s, &fi, elems, s->ddf_bytes)!=hipSuccess) { (void)hipGetLastError(); break; }
+		if(lead_alloc(s, &fi, elems, s->ddf_bytes, mapped ? &alternatives[k-1] : nullptr)!=hipSuccess) { (void)hipGetLastError(); break; }
 		DevBlock cand = std::move(s->raw.back()); s->raw.pop_back();
 		void* const old_fi = s->d_fi;
 		s->d_fi = fi;
 		float ms = 0.0f;
-		if(int e = step_ms(ms)) { s->d_fi = old_fi; dev_free(cand); return e; }
-		if(verbose) fprintf(stderr, "luw: placement candidate %d: %.3f ms per 2 steps (best so far %.3f)\n", k, ms, best_ms);
+		if(int e = step_ms(ms)) { s->d_fi = old_fi; s->raw.push_back(std::move(cand)); return e; }
+		if(verbose) fprintf(stderr, "luw: placement candidate %d (%s): %.3f ms per 2 steps = %.2f TB/s (best so far %.3f)\n", k,
+			cand.chunks.empty() ? "hipMalloc" : cand.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : "512 MiB chunks", ms, probe_bytes/ms*1e-9, best_ms);
 		if(ms<best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
 		else s->d_fi = old_fi;
-		dev_free(cand);
+		if(cand.chunks.empty()) dev_free(cand);                       // a hipMalloc'ed loser goes at once ...
+		else s->raw.push_back(std::move(cand));                       // ... a mapped one with the solver (see above)
 	}
-	HIP_TRY(hipMemsetAsync(s->raw.front().base, 0, bytes+64u*s->ddf_bytes, s->stream)); // the probe steps left zeros, but be explicit
+	// the probe steps left zeros, but be explicit
+	HIP_TRY(hipMemsetAsync(s->raw.front().base, 0, std::min(s->raw.front().bytes, bytes+64u*s->ddf_bytes), s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
 }
@@ -1271,7 +1296,10 @@ static bool reference_cells_are_inputs(const luw_solver* s) {
 	// thermal lattice: the sponge on T reads the top layer's temperature, which only a preset (TYPE_T) keeps between the steps that store T (thermal_cell)
 	if(s->d_gi&&k.zp_n&&ok) {
 		const uint32_t z = (uint32_t)k.top_z;
-		for(uint32_t y=0u; y<Ny&&ok; y++) for(uint32_t x=0u; x<Nx; x++) if((s->h_flags[(size_t)x+((size_t)y+(size_t)z*Ny)*Nx]&TYPE_T)==0u) { ok = false; break; }
+		for(uint32_t y=0u; y<Ny&&ok; y++) for(uint32_t x=0u; x<Nx; x++) if((s->h_flags[(size_t)x+((size_t)y+(size_t)z*Ny)*Nx]&TYPE_T)==0u) {
+			ok = false;
+			break;
+		}
 	}
 	return ok;
 }
