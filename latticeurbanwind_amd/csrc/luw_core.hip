@@ -581,14 +581,12 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 	#undef LUW_TR
 }
 
-// Where the driver places the DDF array physically changes the step time of this 19-stream kernel by up to 10 % on MI355X:
-// allocations of the same size at the same virtual address come out in two classes (512^3 FP32: 3.40-3.50 ms vs 3.70-3.85 ms
-// per step, persistent for the life of the allocation; tools/placement_probe.py).  Large solvers therefore time the real kernel
-// on their DDF array (zero DDFs = rest state, flags 0 = all fluid: a valid, full-cost step) and, while it is not of the fast
-// class, try another allocation -- ONE extra array at a time: the loser of each comparison is freed before the next candidate
-// is allocated, so the search never holds more than two DDF arrays and needs no more memory than that.  LUW_TUNE_PLACEMENT=
-// <candidates> (default 6, 0/1 = off); skipped when the device is short of memory or other solvers already live on it (several
-// ranks / domains sharing one GPU: the test set-ups).
+// Where the driver places the DDF array physically changes the step time of this 19-stream kernel by 10-14 % on MI355X: allocations of the same
+// size come out in classes that last for the life of the allocation (512^3 FP32: 3.3 or 3.75 ms per step; tools/placement_probe.py,
+// tools/chunk_study.sh), and WHICH kind of allocation is of the fast class depends on the box.  Large solvers therefore time the real kernel on
+// their DDF array (zero DDFs = rest state, flags 0 = all fluid: a valid, full-cost step) and, while it is not of the fast class, try another
+// allocation.  LUW_TUNE_PLACEMENT=<candidates> (0/1 = off), LUW_TUNE_FAST=<TB/s> (the bar), LUW_TUNE_VERBOSE=1; skipped when the device is short of
+// memory or other solvers already live on it (several ranks / domains sharing one GPU: the test set-ups).
 static std::atomic<int> g_live_solvers[64];
 static int tune_ddf_placement(luw_solver* s) {
 	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
