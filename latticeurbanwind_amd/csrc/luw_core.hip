@@ -634,7 +634,9 @@ static int tune_ddf_placement(luw_solver* s) {
 	// is all fluid at rest).  LUW_TUNE_FAST=<TB/s> overrides the bar (LUW_TUNE_FAST=99: every candidate is tried, test aid)
 	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)
 		+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
-	const double bar = getenv("LUW_TUNE_FAST") ? atof(getenv("LUW_TUNE_FAST"))*1e12 : (s->ddf_bytes==4u ? 6.15e12 : 5.9e12);
+	// (FP16C with zones: the general kernel is VALU-bound)
+	const double bar = getenv("LUW_TUNE_FAST") ? atof(getenv("LUW_TUNE_FAST"))*1e12
+		: (s->ddf_bytes==4u ? 6.15e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 4.9e12 : 5.9e12);
 	auto fast_class = [&](const float ms) { return probe_bytes/((double)ms*1e-3)>=bar; };
 	float best_ms = 0.0f;
 	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
