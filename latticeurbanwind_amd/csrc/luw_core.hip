@@ -598,13 +598,16 @@ static int tune_ddf_placement(luw_solver* s) {
 	// A chunk-mapped loser is NOT released before the solver goes (unmapping and releasing a mapping here left this ROCm's runtime in a state in which
 	// the solver's final dev_free crashed); it costs its memory until then, and the search stops when the device has no room for that.
 	const bool mapped = !s->raw.front().chunks.empty();
-	static size_t alternatives[3] = { 2048ull<<20, 512ull<<20, 0u };   // chunk sizes tried behind the default (0: hipMalloc)
-	if(const char* a = getenv("LUW_TUNE_ALTS")) { // study aid: "2048,512,0" (MiB)
+	// chunk sizes tried behind the default (0: hipMalloc).  Which KIND is fast differs from box to box, and on some boxes from draw to draw: every
+	// candidate is one more draw, and the fastest stays
+	constexpr int NALT = 6;
+	static size_t alternatives[NALT] = { 2048ull<<20, 512ull<<20, 0u, 256ull<<20, 0u, 2048ull<<20 };
+	if(const char* a = getenv("LUW_TUNE_ALTS")) { // study aid: "2048,512,0" (MiB; repeated cyclically)
 		unsigned long long v[3] = { 2048ull, 512ull, 0ull };
 		sscanf(a, "%llu,%llu,%llu", &v[0], &v[1], &v[2]);
-		for(int k=0; k<3; k++) alternatives[k] = (size_t)v[k]<<20;
+		for(int k=0; k<NALT; k++) alternatives[k] = (size_t)v[k%3]<<20;
 	}
-	const int candidates = env ? atoi(env) : (mapped ? 4 : 6);
+	const int candidates = env ? atoi(env) : (mapped ? 1+NALT : 6);
 	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
 	// (planes of 2 GiB and more -- 1024^3 -- run alike on every kind of piece, profiles/r02_placement_study.txt: no search, no 80 GB candidates)
 	if(mapped&&!env&&s->kp.Np*s->ddf_bytes>(3ull<<29)) return LUW_OK;
@@ -645,7 +648,7 @@ static int tune_ddf_placement(luw_solver* s) {
 	if(verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", mapped ? "1 GiB chunks" : "hipMalloc", best_ms,
 		probe_bytes/best_ms*1e-9);
 	for(int k=1; k<candidates&&!fast_class(best_ms); k++) {
-		if(mapped&&k>3) break;
+		if(mapped&&k>NALT) break;
 		size_t free_b = 0u, total_b = 0u;
 		// room for ONE more array plus what the run may still allocate (statistics: 32 B per cell, staging, halo buffers)
 		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+40ull*s->kp.Np+(2ull<<30)) break;
@@ -657,7 +660,8 @@ static int tune_ddf_placement(luw_solver* s) {
 		float ms = 0.0f;
 		if(int e = step_ms(ms)) { s->d_fi = old_fi; s->raw.push_back(std::move(cand)); return e; }
 		if(verbose) fprintf(stderr, "luw: placement candidate %d (%s): %.3f ms per 2 steps = %.2f TB/s (best so far %.3f)\n", k,
-			cand.chunks.empty() ? "hipMalloc" : cand.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : "512 MiB chunks", ms, probe_bytes/ms*1e-9, best_ms);
+			cand.chunks.empty() ? "hipMalloc" : cand.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : cand.chunk_bytes>=(512ull<<20) ? "512 MiB chunks"
+				: "256 MiB chunks", ms, probe_bytes/ms*1e-9, best_ms);
 		if(ms<best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
 		else s->d_fi = old_fi;
 		if(cand.chunks.empty()) dev_free(cand);                       // a hipMalloc'ed loser goes at once ...
