@@ -639,7 +639,7 @@ static int tune_ddf_placement(luw_solver* s) {
 		+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
 	// (FP16C with zones: the general kernel is VALU-bound)
 	const double bar = getenv("LUW_TUNE_FAST") ? atof(getenv("LUW_TUNE_FAST"))*1e12
-		: (s->ddf_bytes==4u ? 6.15e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 4.9e12 : 5.9e12);
+		: (s->ddf_bytes==4u ? 6.25e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
 	auto fast_class = [&](const float ms) { return probe_bytes/((double)ms*1e-3)>=bar; };
 	float best_ms = 0.0f;
 	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
