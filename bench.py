@@ -247,7 +247,7 @@ def attach_traffic(roof, key, kernel):
 
 
 def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, coriolis=False, thermal=False, every_step=False, kernel_name="auto", keep=None,
-        urban=False):
+        urban=False, native=False):
     """one single-GPU workload: create, fill the host mirrors in place, upload + initialise, W warm-up steps, K timed steps.
     Returns the measurement block (MLUPS, ms/step, roofline of the stream_collide kernel)."""
     import torch
@@ -256,7 +256,7 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
     # urban: buffer nudging + top sponge of the 8-GPU tile (general kernel on two thirds of the cells)
     nud, spg = tile_forcing() if urban else (None, None)
     lbm = luw.LBM(Nx, Ny, Nz, NU, fp16c=fp16c, kernel=kern, device=device, update_fields_every_step=every_step, alpha=(2.1e-7 if thermal else None),
-        buffer_nudging=nud, top_sponge=spg)
+        buffer_nudging=nud, top_sponge=spg, native_arith=native)
     try:
         fill_channel(lbm.flags.data, lbm.u.data, lbm.rho.data, Nx, Ny, Nz, buildings=buildings)
         solid = int(np.count_nonzero((lbm.flags.data & 3) == 1))

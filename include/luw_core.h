@@ -64,6 +64,11 @@ extern "C" {
                                            luw_download(), which yields identical values whenever they are observed */
 #define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha */
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
+/* FP16C pair kernel in the hardware's own arithmetic: one v_rcp_f32 for the divisions by the density, v_sqrt_f32 / v_rcp_f32 for the Smagorinsky rate,
+ * free fma contraction, moment / stress sums in trees -- what the reference's own build does (-cl-mad-enable, native division: FX/opencl.hpp:305,
+ * FX/kernel.cpp:1088-1100,1735).  Results then agree with the bit-exact default (and with the CPU oracle) to rounding, within the gates of
+ * tests/test_gpu_native_arith.py, instead of bit for bit.  Ignored for FP32 DDFs and where the one-cell kernel runs. */
+#define LUW_OPT_NATIVE_ARITH 0x10u
 
 /* kernel selection.  The product library knows AUTO, SCALAR and PAIR (luw_create rejects the others); the remaining ids name A/B and
  * measurement-only variants that exist in the tools build only (make -C csrc ab, -DLUW_AB_KERNELS) */

@@ -14,7 +14,7 @@ LUW_OK = 0
 FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F, FIELD_FI, FIELD_T, FIELD_GI = 0, 1, 2, 3, 4, 5, 6
 MASK_RHO, MASK_U, MASK_FLAGS, MASK_F, MASK_T = 1, 2, 4, 8, 32
 DDF_FP32, DDF_FP16C = 0, 1
-OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID, OPT_TEMPERATURE = 1, 2, 4, 8
+OPT_FORCE_FIELD, OPT_UPDATE_FIELDS_EVERY_STEP, OPT_NO_SUBGRID, OPT_TEMPERATURE, OPT_NATIVE_ARITH = 1, 2, 4, 8, 16
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_PAIR = 0, 1, 7         # what the product library knows
 # ids of the A/B and measurement-only variants: only the tools build (make -C csrc ab -> tools/libluw_core_ab.so) has them
 KERNEL_VEC4, KERNEL_VEC2, KERNEL_SCALAR_CACHED, KERNEL_SCALAR_NT_ALL, KERNEL_VEC1, KERNEL_SCALAR_GENERAL = 2, 3, 4, 5, 6, 8

@@ -375,15 +375,15 @@ struct LaunchGeom { dim3 grid, block; int xa; uint32_t lds; };
 
 // ---- k_stream_collide_s: one cell per lane
 // mode 0: step, 4: step + thermal lattice; 1, 2, 3: A/B variants (tools build)
-struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce; };
+struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce, native; };
 typedef void (*ScalarLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
-template<typename T, int MODE, int NT, bool FLAT, bool STATS,
-	bool NOFORCE> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE,
+	bool NATIVE=false> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	T* const fi = (T*)s->d_fi; T* const gi = MODE==4 ? (T*)s->d_gi : nullptr; float* const Tf = MODE==4 ? s->d_T : nullptr;
-	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho,
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE, NATIVE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi,
+		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
+	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE, NATIVE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho,
 		s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
-	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho, s->d_u,
-		s->d_flags, s->d_F, wf, gi, Tf, S);
 }
 struct ScalarRow { ScalarKey key; ScalarLaunch launch; const char* what; };
 static const ScalarRow scalar_table[] = {
@@ -401,6 +401,9 @@ static const ScalarRow scalar_table[] = {
 	{ { 2u, 0, 2, false, true,  false }, scalar_instance<uint16_t, 0, 2, false, true, false>,    "FP16C one-cell kernel, sampled step" },
 	{ { 2u, 4, 2, false, false, false }, scalar_instance<uint16_t, 4, 2, false, false, false>,   "FP16C one-cell kernel + thermal lattice" },
 	{ { 2u, 4, 2, false, false, true  }, scalar_instance<uint16_t, 4, 2, false, false, true>,    "FP16C one-cell kernel + thermal lattice, force-free box" },
+	{ { 2u, 0, 2, false, false, false, true }, scalar_instance<uint16_t, 0, 2, false, false, false, true>, "FP16C one-cell kernel, native arithmetic" },
+	{ { 2u, 4, 2, false, false, false, true }, scalar_instance<uint16_t, 4, 2, false, false, false, true>,
+		"FP16C one-cell kernel + thermal lattice, native arithmetic" },
 #ifdef LUW_AB_KERNELS   // tools build: measurement-only and A/B variants
 	{ { 4u, 1, 1, true,  false, false }, scalar_instance<float, 1, 1, true, false, false>,       "A/B: no collision" },
 	{ { 4u, 1, 1, false, false, false }, scalar_instance<float, 1, 1, false, false, false>,      "A/B: no collision, row addressing" },
@@ -424,7 +427,7 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	g.xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
 	const uint32_t nx = (uint32_t)((int)b.x1-g.xa), bx = row_block(nx);
 	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
-	ScalarKey k{ (uint8_t)s->ddf_bytes, 0, 2, false, st!=nullptr, false };
+	ScalarKey k{ (uint8_t)s->ddf_bytes, 0, 2, false, st!=nullptr, false, false };
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise.  In-plane
 	// offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with its 2^32-byte planes
 	// still qualifies (largest offset 2^32 - 4).  LUW_ADDR_ROW: the row form also where the flat form would do (both are product code, same values)
@@ -434,6 +437,8 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;
 	k.noforce = s->ddf_bytes==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
 	if(s->d_gi&&!st) k.mode = 4; // thermal lattice on: the product kernel plus the D3Q7 cell update
+	// native arithmetic (FP16C, plain steps): one instantiation for every box
+	if(s->ddf_bytes==2u&&!st&&(s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u) { k.native = true; k.noforce = false; }
 #ifdef LUW_AB_KERNELS
 	if(!st&&!s->d_gi) switch(s->kernel) {
 		case LUW_KERNEL_EXP_COPY: k.mode = 1; k.nt = 1; k.noforce = false; break;
@@ -446,7 +451,7 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 #endif
 	for(const ScalarRow& r : scalar_table) {
 		const ScalarKey& q = r.key;
-		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce) {
+		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce&&q.native==k.native) {
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			return LUW_OK;
 		}
@@ -455,15 +460,15 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 }
 
 // ---- k_stream_collide_p: FP16C, two cells per lane
-struct PairKey { int mode; bool stats; int force; bool park, thermal; };   // mode 1: memory path only (tools build)
+struct PairKey { int mode; bool stats; int force; bool park, thermal, native; };   // mode 1: memory path only (tools build)
 typedef void (*PairLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
-template<int MODE, bool STATS, int FORCE, bool PARK,
-	bool THERMAL> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL,
+	bool NATIVE=false> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	uint16_t* const fi = (uint16_t*)s->d_fi; uint16_t* const gi = THERMAL ? (uint16_t*)s->d_gi : nullptr; float* const Tf = THERMAL ? s->d_T : nullptr;
-	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho,
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL, NATIVE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi,
+		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
+	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL, NATIVE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho,
 		s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
-	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho, s->d_u,
-		s->d_flags, s->d_F, wf, S, gi, Tf);
 }
 struct PairRow { PairKey key; PairLaunch launch; const char* what; };
 static const PairRow pair_table[] = {
@@ -479,6 +484,13 @@ static const PairRow pair_table[] = {
 	{ { 0, false, PAIR_FORCE_NONE,    true,  true  }, pair_instance<0, false, PAIR_FORCE_NONE, true, true>,      "+ thermal lattice, force-free box" },
 	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true  }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true>,   "+ thermal lattice, uniform forces" },
 	{ { 0, false, PAIR_FORCE_ANY,     true,  true  }, pair_instance<0, false, PAIR_FORCE_ANY, true, true>,       "+ thermal lattice, general" },
+	// LUW_OPT_NATIVE_ARITH: the same six in the hardware's own arithmetic (collide_cell_pk_native); sampled steps keep the exact kernel
+	{ { 0, false, PAIR_FORCE_NONE,    false, false, true }, pair_instance<0, false, PAIR_FORCE_NONE, false, false, true>,      "native: force-free box" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, false, false, true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, false, false, true>,   "native: uniform forces" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  false, true }, pair_instance<0, false, PAIR_FORCE_ANY, true, false, true>,        "native: general" },
+	{ { 0, false, PAIR_FORCE_NONE,    true,  true,  true }, pair_instance<0, false, PAIR_FORCE_NONE, true, true, true>,        "native + thermal, force-free" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true,  true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true, true>,     "native + thermal, uniform" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  true,  true }, pair_instance<0, false, PAIR_FORCE_ANY, true, true, true>,         "native + thermal, general" },
 #ifdef LUW_AB_KERNELS
 	{ { 1, false, PAIR_FORCE_ANY,     false, false }, pair_instance<1, false, PAIR_FORCE_ANY, false, false>,
 		"A/B: the kernel's memory path alone (LUW_PAIR_COPY)" },
@@ -505,6 +517,9 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 #endif
 	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (unsigned)(LUW_PAIR_PARK_DEFAULT);
 	k.park = k.thermal || (!st && (park_modes&(1u<<k.force))!=0u);
+	// native arithmetic: plain steps of the product kernel (a sampled step runs the exact kernel: its values differ in rounding only)
+	k.native = (s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u && !st;
+	if(k.native&&!k.thermal) k.park = k.force==PAIR_FORCE_ANY;
 #ifdef LUW_AB_KERNELS
 	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // tools build, measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only&&!st&&!k.thermal) k = PairKey{ 1, false, PAIR_FORCE_ANY, false, false };
@@ -512,7 +527,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal, (k.mode==0&&!k.stats) ? k.force : PAIR_FORCE_NONE) : 0u;
 	for(const PairRow& r : pair_table) {
 		const PairKey& q = r.key;
-		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal) {
+		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native) {
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			return LUW_OK;
 		}
@@ -794,8 +809,9 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	k.Ox = cfg->Ox; k.Oy = cfg->Oy; k.Oz = cfg->Oz;
 	k.w = literal_roundtrip(1.0f/(3.0f*cfg->nu+0.5f)); // FX/lbm.hpp:140, FX/lbm.cpp:664
 	k.fx = cfg->fx; k.fy = cfg->fy; k.fz = cfg->fz;
-	k.tau0 = 1.0f/k.w; k.tau0sq = k.tau0*k.tau0;
+	k.tau0 = 1.0f/k.w; k.tau0sq = k.tau0*k.tau0; k.half_tau0 = 0.5f*k.tau0;
 	k.omx = cfg->omega_x; k.omy = cfg->omega_y; k.omz = cfg->omega_z; k.coriolis = k.omx!=0.0f||k.omy!=0.0f||k.omz!=0.0f;
+	k.m2omx = -2.0f*k.omx; k.m2omy = -2.0f*k.omy; k.m2omz = -2.0f*k.omz;
 	k.subgrid = (cfg->options&LUW_OPT_NO_SUBGRID) ? 0u : 1u;
 	k.buffer_active = cfg->buffer_nudging_active ? 1u : 0u;
 	k.buffer_N = cfg->buffer_n_cells; k.nudge_vertical = (uint32_t)cfg->buffer_nudge_vertical; k.downstream_face = (uint32_t)cfg->buffer_downstream_face_id;
@@ -1275,6 +1291,7 @@ int luw_set_coriolis(luw_solver* s, float ox, float oy, float oz) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_set_coriolis: null solver");
 	s->cfg.omega_x = s->kp.omx = ox; s->cfg.omega_y = s->kp.omy = oy; s->cfg.omega_z = s->kp.omz = oz;
 	s->kp.coriolis = ox!=0.0f||oy!=0.0f||oz!=0.0f;
+	s->kp.m2omx = -2.0f*ox; s->kp.m2omy = -2.0f*oy; s->kp.m2omz = -2.0f*oz;
 	return LUW_OK;
 }
 

@@ -54,6 +54,9 @@ struct KParams {
 	uint32_t zp_lo, zp_n;                // top sponge layers (z)
 	uint32_t has_F;
 	float w_T;                // TEMPERATURE: def_w_T = 1/(2 alpha + 1/2), FX/lbm.cpp:750 (0 when the thermal lattice is off)
+	// native-arithmetic kernels (LUW_OPT_NATIVE_ARITH, collide_cell_pk_native): host-folded constants
+	float half_tau0;          // tau0 / 2
+	float m2omx, m2omy, m2omz; // -2 omega
 };
 
 // ---------------------------------------------------------------- FP16C codec, FX/kernel.cpp:864-875
@@ -700,6 +703,135 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	f0 = r0;
 	#pragma unroll
 	for(int k=0; k<9; k++) fp[k] = rp[k];
+}
+// ---------------------------------------------------------------- the same collision in NATIVE arithmetic (LUW_OPT_NATIVE_ARITH)
+// The contract above (every operation rounded like the CPU restatement's) is this project's, not the reference's: the reference kernel is compiled by the
+// OpenCL driver with -cl-mad-enable and native division / square root (FX/opencl.hpp:305, FX/kernel.cpp:1088-1100,1735) and is not bit-defined.  Where the
+// VALU is the limit (FP16C pair kernel) the same formulas can run with the hardware's own operations and the sums in any order:
+//   * one v_rcp_f32 of the density serves u = m / rho, F / (2 rho) and sqrt(Q) / rho; v_sqrt_f32 and v_rcp_f32 for the Smagorinsky rate
+//     (w = 1 / (tau0 / 2 + sqrt(tau0^2 + 0.76421222 sqrt(Q) / rho) / 2));
+//   * moments from the nine pair sums s_k = f[2k+1] + f[2k+2] and differences d_k = f[2k+1] - f[2k+2] (c_(2k+2) = -c_(2k+1)): rho = f0 + sum s_k + 1,
+//     mx = d0 + d3 + d4 + d6 + d7, ...; 40 additions in short trees instead of 46 in chains;
+//   * the stress tensor from the NON-EQUILIBRIUM PAIR SUMS alone: c c is the same for both directions of a pair, so Pi = sum_k (c c)_k (n_(2k+1) + n_(2k+2))
+//     and n_(2k+1) + n_(2k+2) = s_k - (rho w_k A_k + 2 (rho - 1) w_k) with A_k = (3 c.u)^2 - 3 u^2 of the equilibrium (its +-3 c.u parts cancel):
+//     18 + 15 operations instead of 18 + 36, and the nineteen equilibria are formed only once the rate is known (no f_eq registers across Q);
+//   * Guo terms with the constants folded: c_tau w9_i [(c_i.F)(c_i.u + 1/3) - u.F / 3] = fma(c_i.H, 3 c_i.u + 1, uH) with H = c_tau w9_i F / 3, the
+//     3 c.u of the equilibrium reused, added inside the relaxation's own fma;
+//   * free contraction (a*b+c as one fma), v_med3 for the +-c clamp, -2 omega from the host.
+// TYPE_E lanes in every FORCE mode: decoded as f = 0 by the caller, relaxed with w = 1 and c_tau = 0 -> f_eq (collide_cell_pk, E_BY_RATE).
+// Values differ from the exact kernels' in the last bits of each operation; with FP16C storage (2^-12 relative per stored value) those differences
+// surface as different roundings of single populations, exactly like the reference's own arithmetic against the restatement's.
+// The exact kernels stay the default and the anchor of every bit-for-bit test; tests/test_gpu_native_arith.py holds the tolerance gates of this one.
+#ifndef LUW_NATIVE_RCP_NEWTON
+#define LUW_NATIVE_RCP_NEWTON 0   /* 1: one Newton step behind the density's v_rcp_f32 (A/B: the u-RMSE against the oracle does not change) */
+#endif
+template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk_native(const KParams& p, const uint32_t n, const uint8_t flagsn,
+	const bool may_force, float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon,
+	float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr, const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) {
+	#pragma clang fp contract(fast)
+	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+	const bool wave_has_E = __ballot(is_E)!=0ull;
+	float s[9], mx, my, mz;
+	{
+		float d[9];
+		#pragma unroll
+		for(int k=0; k<9; k++) { s[k] = fp[k].x+fp[k].y; d[k] = fp[k].x-fp[k].y; }
+		rhon = (((f0+s[0])+(s[1]+s[2]))+((s[3]+s[4])+(s[5]+s[6])))+(s[7]+s[8])+1.0f;
+		mx = (d[0]+(d[3]+d[6]))+(d[4]+d[7]);
+		my = (d[1]+(d[3]-d[6]))+(d[5]+d[8]);
+		mz = (d[2]+(d[4]-d[7]))+(d[5]-d[8]);
+	}
+	if(wave_has_E) { if(is_E) rhon = own ? own->wb : rho[n]; }
+	float r = __builtin_amdgcn_rcpf(rhon);
+	if constexpr(LUW_NATIVE_RCP_NEWTON!=0) r = fmaf(fmaf(-rhon, r, 1.0f), r, r);
+	uxn = mx*r; uyn = my*r; uzn = mz*r;
+	if(wave_has_E) {
+		if(is_E) {
+			if(own) { uxn = own->tu[0]; uyn = own->tu[1]; uzn = own->tu[2]; }
+			else { uxn = u[n]; uyn = u[(size_t)p.Np+n]; uzn = u[2ull*p.Np+n]; }
+		}
+	}
+	if(u_before_force) { u_before_force[0] = uxn; u_before_force[1] = uyn; u_before_force[2] = uzn; }
+	const bool forced = FORCE==PAIR_FORCE_UNIFORM || (FORCE==PAIR_FORCE_ANY && may_force);
+	float fxn = 0.0f, fyn = 0.0f, fzn = 0.0f;
+	if(forced) {
+		fxn = p.fx; fyn = p.fy; fzn = p.fz;
+		if(p.coriolis) { // -2 rho omega x u
+			fxn += rhon*(p.m2omy*uzn-p.m2omz*uyn);
+			fyn += rhon*(p.m2omz*uxn-p.m2omx*uzn);
+			fzn += rhon*(p.m2omx*uyn-p.m2omy*uxn);
+		}
+		if constexpr(FORCE==PAIR_FORCE_ANY) {
+			if(refs) { // zone references fetched ahead (fetch_force_refs): nudging towards the nearest owned face, top sponge
+				if(refs->zn) {
+					const float wr = refs->wb*p.buffer_inv_tau*rhon;
+					fxn += wr*(refs->tu[0]-uxn);
+					fyn += wr*(refs->tu[1]-uyn);
+					if(p.nudge_vertical==1u) fzn += wr*(refs->tu[2]-uzn);
+				}
+				if(refs->zs) {
+					const float sr = refs->sg*rhon;
+					fxn += sr*(refs->su[0]-uxn);
+					fyn += sr*(refs->su[1]-uyn);
+					fzn += sr*(refs->su[2]-uzn);
+				}
+			}
+			if(p.has_F) { fxn += F[n]; fyn += F[(size_t)p.Np+n]; fzn += F[2ull*p.Np+n]; }
+		}
+		const float rho2 = 0.5f*r;
+		uxn += fxn*rho2; uyn += fyn*rho2; uzn += fzn*rho2;
+	}
+	uxn = __builtin_amdgcn_fmed3f(uxn, -DEF_C, DEF_C);
+	uyn = __builtin_amdgcn_fmed3f(uyn, -DEF_C, DEF_C);
+	uzn = __builtin_amdgcn_fmed3f(uzn, -DEF_C, DEF_C);
+	// equilibrium ingredients (FX/kernel.cpp:1016-1055): f_eq(2k+1 / 2k+2) = rho w_k (A_k / 2 +- v_k) + (rho - 1) w_k, v_k = 3 c_k.u, A_k = v_k^2 - 3 u^2
+	const float c3 = -3.0f*(uxn*uxn+uyn*uyn+uzn*uzn);
+	const float ux3 = 3.0f*uxn, uy3 = 3.0f*uyn, uz3 = 3.0f*uzn;
+	const float v[9] = { ux3, uy3, uz3, ux3+uy3, ux3+uz3, uy3+uz3, ux3-uy3, ux3-uz3, uy3-uz3 };
+	const float rhom1 = rhon-1.0f;
+	const float rhos = DEF_WS*rhon, rhoe = DEF_WE*rhon, rhom1s = DEF_WS*rhom1, rhom1e = DEF_WE*rhom1;
+	float A[9];
+	#pragma unroll
+	for(int k=0; k<9; k++) A[k] = v[k]*v[k]+c3;
+	float w = p.w;
+	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737, from the non-equilibrium pair sums
+		const float rm2s = 2.0f*rhom1s, rm2e = 2.0f*rhom1e;
+		float sn[9];
+		#pragma unroll
+		for(int k=0; k<9; k++) sn[k] = s[k]-((k<3 ? rhos : rhoe)*A[k]+(k<3 ? rm2s : rm2e));
+		const float Hxx = (sn[0]+(sn[3]+sn[4]))+(sn[6]+sn[7]), Hyy = (sn[1]+(sn[3]+sn[5]))+(sn[6]+sn[8]), Hzz = (sn[2]+(sn[4]+sn[5]))+(sn[7]+sn[8]);
+		const float Hxy = sn[3]-sn[6], Hxz = sn[4]-sn[7], Hyz = sn[5]-sn[8];
+		const float Q = (Hxx*Hxx+Hyy*Hyy+Hzz*Hzz)+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
+		const float sq = 0.76421222f*__builtin_amdgcn_sqrtf(Q);
+		w = __builtin_amdgcn_rcpf(0.5f*__builtin_amdgcn_sqrtf(sq*r+p.tau0sq)+p.half_tau0);
+	}
+	float c_tau = 1.0f-0.5f*w;
+	if(wave_has_E) { w = is_E ? 1.0f : w; c_tau = is_E ? 0.0f : c_tau; }
+	const float omw = 1.0f-w;
+	if(forced) {
+		// c_tau Fin_i = fma(+-c.H, +-v + 1, uH): H = c_tau w9 F / 3 (w9 = 1/2 axis, 1/4 diagonal), uH = -c_tau w9 (u.F) / 3; Fin_0 = -c_tau (u.F)
+		const float cs = c_tau*0.16666667f;
+		const float hx = cs*fxn, hy = cs*fyn, hz = cs*fzn;
+		const float dots = cs*(uxn*fxn+uyn*fyn+uzn*fzn);           // = -uH of the axis pairs
+		const float ex = 0.5f*hx, ey = 0.5f*hy, ez = 0.5f*hz, dote = 0.5f*dots;
+		const float cH[9] = { hx, hy, hz, ex+ey, ex+ez, ey+ez, ex-ey, ex-ez, ey-ez };
+		f0 = omw*f0+(w*(DEF_W0*(rhon*(0.5f*c3)+rhom1))-6.0f*dots);
+		#pragma unroll
+		for(int k=0; k<9; k++) {
+			const f32x2 in = splat2(0.5f*A[k])+pm2(v[k]);
+			const f32x2 feq = splat2(k<3 ? rhos : rhoe)*in+splat2(k<3 ? rhom1s : rhom1e);
+			const f32x2 fin = pm2(cH[k])*(pm2(v[k])+splat2(1.0f))-splat2(k<3 ? dots : dote);
+			fp[k] = splat2(omw)*fp[k]+(splat2(w)*feq+fin);
+		}
+	} else {
+		f0 = omw*f0+w*(DEF_W0*(rhon*(0.5f*c3)+rhom1));
+		#pragma unroll
+		for(int k=0; k<9; k++) {
+			const f32x2 in = splat2(0.5f*A[k])+pm2(v[k]);
+			const f32x2 feq = splat2(k<3 ? rhos : rhoe)*in+splat2(k<3 ? rhom1s : rhom1e);
+			fp[k] = splat2(omw)*fp[k]+splat2(w)*feq;
+		}
+	}
 }
 // position-only test: can buffer nudging or the top sponge act on this cell (the zones of assemble_force)?
 __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x, const uint32_t y, const uint32_t z) {

@@ -124,7 +124,9 @@ template<typename T> struct CellAddr<T, true> {
 #define LUW_MAXW_F32 4
 #endif
 // STATS: this step is a statistics sample (stats_welford, luw_kernels_common.hpp); product MODE 0 only.
-template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false>
+// NATIVE (FP16C, LUW_OPT_NATIVE_ARITH): the pair kernel's native-arithmetic collision (collide_cell_pk_native) on this kernel's one cell per lane -- the rows
+// too narrow or unaligned for the pair kernel, so that a native run is native everywhere.
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false, bool NATIVE=false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8)))
 void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr,
@@ -158,7 +160,22 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
-		if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
+		if constexpr(NATIVE) {
+			static_assert(sizeof(T)==2&&(MODE==0||MODE==4)&&!STATS, "native arithmetic: plain FP16C steps");
+			const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
+			ForceRefs refs;
+			fetch_force_refs(p, n, x, y, z, true, is_E, rho, u, refs);
+			const bool may_force = p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(refs.zn||refs.zs)!=0ull;
+			f32x2 fp[9];
+			#pragma unroll
+			for(int k=0; k<9; k++) { const f32x2 t = { is_E ? 0.0f : f[2*k+1], is_E ? 0.0f : f[2*k+2] }; fp[k] = t; }
+			float f0 = is_E ? 0.0f : f[0], u0[3];
+			collide_cell_pk_native<PAIR_FORCE_ANY>(p, n, flagsn, may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, MODE==4 ? u0 : nullptr, &refs, &refs);
+			f[0] = f0;
+			#pragma unroll
+			for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
+			if constexpr(MODE==4) thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g, write_fields!=0);
+		} else if constexpr(MODE==4) { // MODE 4: with the thermal lattice (LUW_OPT_TEMPERATURE)
 			float u0[3];
 			collide_cell<true, NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn, u0);
 			thermal_collide<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), x, y, z, flagsn, u0[0], u0[1], u0[2], gi, Tf, g, write_fields!=0);
@@ -269,7 +286,30 @@ __device__ __forceinline__ void asm_fence_u(uint32_t* v) {
 #ifndef LUW_THERMAL_WAVES_ANY
 #define LUW_THERMAL_WAVES_ANY 4
 #endif
-constexpr int pair_waves(const int force, const bool park, const bool thermal = false) {
+#ifndef LUW_NATIVE_WAVES_NONE
+#define LUW_NATIVE_WAVES_NONE 5
+#endif
+#ifndef LUW_NATIVE_WAVES_UNIFORM
+#define LUW_NATIVE_WAVES_UNIFORM 5
+#endif
+#ifndef LUW_NATIVE_WAVES_ANY
+#define LUW_NATIVE_WAVES_ANY 5
+#endif
+#ifndef LUW_NATIVE_THERMAL_WAVES_NONE
+#define LUW_NATIVE_THERMAL_WAVES_NONE 5
+#endif
+#ifndef LUW_NATIVE_THERMAL_WAVES_UNIFORM
+#define LUW_NATIVE_THERMAL_WAVES_UNIFORM 5
+#endif
+#ifndef LUW_NATIVE_THERMAL_WAVES_ANY
+#define LUW_NATIVE_THERMAL_WAVES_ANY 4
+#endif
+constexpr int pair_waves(const int force, const bool park, const bool thermal = false, const bool native = false) {
+	if(native) {
+		if(thermal) return force==PAIR_FORCE_NONE ? LUW_NATIVE_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_NATIVE_THERMAL_WAVES_UNIFORM
+			: LUW_NATIVE_THERMAL_WAVES_ANY;
+		return force==PAIR_FORCE_NONE ? LUW_NATIVE_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_NATIVE_WAVES_UNIFORM : LUW_NATIVE_WAVES_ANY;
+	}
 	// (a wave more each spills to scratch)
 	if(thermal) return force==PAIR_FORCE_NONE ? LUW_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_THERMAL_WAVES_UNIFORM : LUW_THERMAL_WAVES_ANY;
 	return park ? (force==PAIR_FORCE_NONE ? LUW_PARK_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_PARK_WAVES_UNIFORM : LUW_PARK_WAVES_ANY)
@@ -288,8 +328,10 @@ constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force 
 // THERMAL (LUW_OPT_TEMPERATURE): the D3Q7 lattice of both cells the same way -- seven more dwords per lane (plane 0 and the three (A, B) pairs of
 // +x, +y, +z: the +x plane on a 2-byte boundary like the five x+1 planes of the D3Q19 lattice), the cell update of luw_device.hpp (thermal_cell)
 // behind each collision with the velocity before the force shift, the seven codes of both cells merged per plane at the tail.
-template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL), pair_waves(FORCE, PARK, THERMAL))))
+// NATIVE (LUW_OPT_NATIVE_ARITH): the collision in the hardware's own arithmetic (collide_cell_pk_native, luw_device.hpp); same memory path, same codec.
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false, bool NATIVE=false>
+__global__ __launch_bounds__(256)
+	__attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL, NATIVE), pair_waves(FORCE, PARK, THERMAL, NATIVE))))
 void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{},
 		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
@@ -375,7 +417,7 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 	if constexpr(PRE) zone_lane = refs[0].zn||refs[0].zs||refs[1].zn||refs[1].zs; else zone_lane = in_force_zone(p, x, y, z)||in_force_zone(p, x+1u, y, z);
 	const bool may_force = FORCE==PAIR_FORCE_ANY && (p.coriolis || p.has_F || p.fx!=0.0f || p.fy!=0.0f || p.fz!=0.0f || __ballot(zone_lane)!=0ull);
 	// specialised modes: TYPE_E cells decode to f = 0 (collide_cell_pk relaxes them with w = 1)
-	constexpr bool E_BY_RATE = FORCE!=PAIR_FORCE_ANY;
+	constexpr bool E_BY_RATE = NATIVE || FORCE!=PAIR_FORCE_ANY;
 	// (only cells that are collided: a halo or padding cell passes what it decodes through unchanged, whatever its flag)
 	[[maybe_unused]] const uint32_t dmask[2] = { (E_BY_RATE&&proc[0]&&(fl[0]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u,
 		(E_BY_RATE&&proc[1]&&(fl[1]&TYPE_BO)==TYPE_E) ? 0u : 0x87FFF000u };
@@ -409,7 +451,9 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
 			[[maybe_unused]] float u0[3];
-			collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c]
+			if constexpr(NATIVE) collide_cell_pk_native<FORCE>(p, n+c, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr,
+				PRE ? &refs[c] : nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
+			else collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c]
 				: nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
 			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g, write_fields!=0);
 			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {

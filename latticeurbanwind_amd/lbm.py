@@ -44,7 +44,7 @@ class LBM:
 
     def __init__(self, Nx, Ny, Nz, nu, fx=0.0, fy=0.0, fz=0.0, *, fp16c=False, D=(1, 1, 1), O=(0, 0, 0),
                  force_field=False, update_fields_every_step=False, subgrid=True, device=0, kernel=capi.KERNEL_AUTO,
-                 buffer_nudging=None, top_sponge=None, alpha=None):
+                 buffer_nudging=None, top_sponge=None, alpha=None, native_arith=False):
         self._L = capi.load()
         cfg = capi.Config()
         cfg.struct_size = C.sizeof(capi.Config)
@@ -55,7 +55,7 @@ class LBM:
         cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
         cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
         cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid
-            else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
+            else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0) | (capi.OPT_NATIVE_ARITH if native_arith else 0)
         cfg.alpha = float(alpha) if alpha is not None else 0.0      # thermal D3Q7 lattice: LBM(..., alpha, beta), FX/lbm.hpp:444
         if buffer_nudging is not None:  # dict(n_cells, inv_tau, downstream_face, nudge_vertical): FX/setup.cpp:3844-3866
             cfg.buffer_nudging_active = 1
@@ -247,7 +247,7 @@ class LBMGroup:
     scattered to / gathered from the domains' mirrors.  devices: HIP device per domain (None: one device each, cfg.device + d)."""
 
     def __init__(self, Nx, Ny, Nz, Dx, Dy, Dz, nu, fx=0.0, fy=0.0, fz=0.0, *, fp16c=False, devices=None, force_field=False, update_fields_every_step=False,
-                 subgrid=True, device=0, kernel=capi.KERNEL_AUTO, buffer_nudging=None, top_sponge=None, alpha=None, global_arrays=True):
+                 subgrid=True, device=0, kernel=capi.KERNEL_AUTO, buffer_nudging=None, top_sponge=None, alpha=None, global_arrays=True, native_arith=False):
         self._L = capi.load()
         cfg = capi.Config()
         cfg.struct_size = C.sizeof(capi.Config)
@@ -257,7 +257,7 @@ class LBMGroup:
         cfg.fx, cfg.fy, cfg.fz = float(fx), float(fy), float(fz)
         cfg.ddf_format = capi.DDF_FP16C if fp16c else capi.DDF_FP32
         cfg.options = (capi.OPT_FORCE_FIELD if force_field else 0) | (capi.OPT_UPDATE_FIELDS_EVERY_STEP if update_fields_every_step else 0) | (0 if subgrid
-            else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0)
+            else capi.OPT_NO_SUBGRID) | (capi.OPT_TEMPERATURE if alpha is not None else 0) | (capi.OPT_NATIVE_ARITH if native_arith else 0)
         cfg.alpha = float(alpha) if alpha is not None else 0.0
         if buffer_nudging is not None:
             cfg.buffer_nudging_active = 1

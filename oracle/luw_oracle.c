@@ -459,16 +459,350 @@ static void stream_collide_cell(const LuwOracleCfg* c, const uint64_t N, const u
 	store_f(c, N, n, fhn, fi, j, t);
 }
 
-void luwo_stream_collide(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t) {
-	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
-	#pragma omp parallel for schedule(static)
-	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t, NULL);
-}
-void luwo_stream_collide_thermal(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, void* gi, float* T, const uint64_t t) {
+/* the literal path: one call of stream_collide_cell per cell, exactly like the reference's one work-item per cell */
+void luwo_stream_collide_literal(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, void* gi, float* T, const uint64_t t) {
 	const uint64_t N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz;
 	const LuwOracleThermal th = { gi, T };
 	#pragma omp parallel for schedule(static)
-	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t, &th);
+	for(int64_t n=0; n<(int64_t)N; n++) stream_collide_cell(c, N, (uint64_t)n, fi, rho, u, flags, F, t, gi ? &th : NULL);
+}
+
+/* ================================================================== row-wise path (same operations, organised for the host CPU)
+ * stream_collide_cell spends most of its time outside the arithmetic it restates: three coordinates() per cell (64-bit div / mod), six % in neighbors(),
+ * the face constants of FX/lbm.cpp:613-625 re-derived per cell, sinf per zone cell, and every fma() a call into libm.  The path below executes THE SAME
+ * floating-point statements in THE SAME order for every cell -- each statement of stream_collide_cell appears once, applied to the eight cells of a row
+ * chunk at a time (an IEEE single-precision add / mul / fma / div / sqrt yields the same value in a vector lane as in a scalar register; nothing is
+ * reassociated or contracted: -ffp-contract=off, explicit fused operations only where the reference writes fma) -- and replaces only the index work:
+ * rows are walked with additions, the neighbour rows (periodic wrap, FX/kernel.cpp:920-958) are formed once per row, the face constants once per call,
+ * the sin^2 ramps (same sinf calls on the same arguments) once per call into tables.  Cells whose lane is switched off (halo, TYPE_S / TYPE_G: the early
+ * returns of FX/kernel.cpp:1486-1496) compute on zeros and store nothing.
+ * tests/test_oracle_fast_path.py: both paths give the same bits on every fixture state (FP32, FP16C, forces, zones, thermal lattice, halo'ed domains).
+ * luwo_set_fast(0) selects the literal path for every call. */
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#define LUWO_HAVE_FAST 1
+typedef float v8f __attribute__((vector_size(32)));
+typedef int32_t v8i __attribute__((vector_size(32)));
+typedef uint32_t v8u __attribute__((vector_size(32)));
+static inline v8f vfma(const v8f a, const v8f b, const v8f c) { return (v8f)_mm256_fmadd_ps((__m256)a, (__m256)b, (__m256)c); }
+static inline v8f vsqrt(const v8f a) { return (v8f)_mm256_sqrt_ps((__m256)a); }
+static inline v8f vsplat(const float a) { return (v8f){ a, a, a, a, a, a, a, a }; }
+static inline v8f vsel(const v8i m, const v8f a, const v8f b) { return (v8f)_mm256_blendv_ps((__m256)b, (__m256)a, (__m256)m); } /* m ? a : b */
+static inline v8f vclamp(const v8f x, const float a, const float b) { /* fminf(fmaxf(x, a), b): the second operand is returned for a NaN x, like fmaxf */
+	return (v8f)_mm256_min_ps(_mm256_max_ps((__m256)x, (__m256)vsplat(a)), (__m256)vsplat(b));
+}
+static inline v8f vsq(const v8f x) { return x*x; }
+static inline v8f v_half_to_float(const v8u x) { /* luwo_half_to_float_custom, lane by lane */
+	const v8u e = (x&0x7800u)>>11;
+	const v8u m = (x&0x07FFu)<<12;
+	const v8u v = ((v8u)(v8f)_mm256_cvtepi32_ps((__m256i)m))>>23;
+	const v8u normal = (v8u)(e!=0u)&(((e+112u)<<23)|m);
+	const v8u denorm = (v8u)((e==0u)&(m!=0u))&(((v-37u)<<23)|((m<<((150u-v)&31u))&0x007FF000u));
+	return (v8f)(((x&0x8000u)<<16)|normal|denorm);
+}
+static inline v8u v_float_to_half(const v8f x) { /* luwo_float_to_half_custom, lane by lane */
+	const v8u b = (v8u)x+0x00000800u;
+	const v8u e = (b&0x7F800000u)>>23;
+	const v8u m = b&0x007FFFFFu;
+	const v8u sh = (124u-e)&31u;
+	return ((b&0x80000000u)>>16)|((v8u)(e>112u)&((((e-112u)<<11)&0x7800u)|(m>>12)))|((v8u)((e<113u)&(e>100u))&((((0x007FF800u+m)>>sh)+1u)>>1));
+}
+typedef struct {
+	const LuwOracleCfg* c; uint64_t N, t;
+	void* fi; float* rho; float* u; const uint8_t* flags; const float* F; void* gi; float* T;
+	uint32_t Nxg, Nyg, Nzg; int west_x, east_x, south_y, north_y, top_z, has_w, has_e, has_s, has_n, has_t;
+	float* wbuf; float* sigma;   /* w_buf of FX/kernel.cpp:1581-1583 per distance 0..Nbuf, sigma of :1604-1606 per layer 0..Nsponge-1 */
+} FastCtx;
+/* eight values of plane `plane` at row base `row` (element index of the row's x = 0), positions xi[l]; contig: xi[l] = xi[0]+l */
+static inline v8f fast_load8(const FastCtx* k, const void* lat, const uint64_t plane, const uint64_t row, const uint32_t* xi, const int contig) {
+	const uint64_t base = plane*k->N+row;
+	if(k->c->fp16c) {
+		const uint16_t* p = (const uint16_t*)lat+base;
+		v8u raw;
+		if(contig) raw = (v8u)_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(p+xi[0])));
+		else raw = (v8u){ p[xi[0]], p[xi[1]], p[xi[2]], p[xi[3]], p[xi[4]], p[xi[5]], p[xi[6]], p[xi[7]] };
+		return v_half_to_float(raw);
+	} else {
+		const float* p = (const float*)lat+base;
+		if(contig) return (v8f)_mm256_loadu_ps(p+xi[0]);
+		return (v8f){ p[xi[0]], p[xi[1]], p[xi[2]], p[xi[3]], p[xi[4]], p[xi[5]], p[xi[6]], p[xi[7]] };
+	}
+}
+static inline void fast_store8(const FastCtx* k, void* lat, const uint64_t plane, const uint64_t row, const uint32_t* xi, const int contig_all, const uint8_t* on,
+		const v8f v) {
+	const uint64_t base = plane*k->N+row;
+	if(k->c->fp16c) {
+		uint16_t* p = (uint16_t*)lat+base;
+		const v8u code = v_float_to_half(v);
+		if(contig_all) { const __m256i w = (__m256i)code; _mm_storeu_si128((__m128i*)(p+xi[0]), _mm_packus_epi32(_mm256_castsi256_si128(w), _mm256_extracti128_si256(w, 1))); }
+		else for(int l=0; l<8; l++) if(on[l]) p[xi[l]] = (uint16_t)code[l];
+	} else {
+		float* p = (float*)lat+base;
+		if(contig_all) _mm256_storeu_ps(p+xi[0], (__m256)v);
+		else for(int l=0; l<8; l++) if(on[l]) p[xi[l]] = v[l];
+	}
+}
+static void fast_row(const FastCtx* k, const uint32_t y, const uint32_t z) {
+	const LuwOracleCfg* c = k->c;
+	const uint64_t N = k->N, Nx = c->Nx, NxNy = Nx*(uint64_t)c->Ny;
+	const int odd = (int)(k->t%2ull);
+	/* rows of the cell and of its +c_i neighbours, i = 1,3,...,17 (neighbors(): j[i] for odd i) */
+	const uint64_t y0 = (uint64_t)y*Nx, yp = (uint64_t)((y+1u)%c->Ny)*Nx, ym = (uint64_t)((y+c->Ny-1u)%c->Ny)*Nx;
+	const uint64_t z0 = (uint64_t)z*NxNy, zp = (uint64_t)((z+1u)%c->Nz)*NxNy, zm = (uint64_t)((z+c->Nz-1u)%c->Nz)*NxNy;
+	const uint64_t r00 = y0+z0;
+	const uint64_t rowj[9] = { y0+z0, yp+z0, y0+zp, yp+z0, y0+zp, yp+zp, ym+z0, y0+zm, yp+zm };
+	static const int shifted[9] = { 1, 0, 0, 1, 1, 0, 1, 1, 0 };
+	const int yg = (int)y+c->Oy, zg = (int)z+c->Oz;
+	/* the parts of the zone conditions (FX/kernel.cpp:1537-1541,1598) that depend on the row alone */
+	const int Nbuf_i = (int)c->buffer_N, Nsponge_i = (int)c->sponge_N;
+	const int d_s_i = yg, d_n_i = (int)(k->Nyg-1u)-yg, d_t_i = (int)(k->Nzg-1u)-zg;
+	const int in_s = c->buffer_active&&c->downstream_face!=3&&k->has_s==1&&d_s_i>=0&&d_s_i<=Nbuf_i;
+	const int in_n = c->buffer_active&&c->downstream_face!=4&&k->has_n==1&&d_n_i>=0&&d_n_i<=Nbuf_i;
+	const int in_t = c->buffer_active&&k->has_t==1&&d_t_i>=0&&d_t_i<=Nbuf_i;
+	const int d_sp_i = (int)(k->Nzg-2u)-zg;
+	const int in_sp = c->sponge_active&&k->has_t==1&&d_sp_i>=0&&d_sp_i<Nsponge_i;
+	const v8f zero = vsplat(0.0f);
+	for(uint32_t x0=0u; x0<c->Nx; x0+=8u) {
+		const uint32_t cnt = c->Nx-x0<8u ? c->Nx-x0 : 8u;
+		uint32_t xn[8], xp[8]; uint8_t on[8], fl[8];
+		int any = 0, all = cnt==8u;
+		for(uint32_t l=0u; l<8u; l++) {
+			const uint32_t x = l<cnt ? x0+l : x0;               /* lanes behind the row end repeat its chunk's first cell and are switched off */
+			xn[l] = x; xp[l] = (x+1u)%c->Nx;
+			fl[l] = k->flags[r00+x];
+			const int halo = (c->Dx>1u)&&(x==0u||x>=c->Nx-1u);
+			on[l] = l<cnt && !halo && (fl[l]&TYPE_BO)!=TYPE_S && (fl[l]&TYPE_SU)!=TYPE_G;
+			any |= on[l]; all &= on[l];
+		}
+		if(!any) continue;
+		const int contig_n = cnt==8u, contig_p = cnt==8u&&x0+8u<c->Nx;   /* x+1 positions are consecutive unless the chunk holds the row end */
+		v8i m_on, m_E, m_T;
+		for(int l=0; l<8; l++) { m_on[l] = on[l] ? -1 : 0; m_E[l] = (fl[l]&TYPE_BO)==TYPE_E ? -1 : 0; m_T[l] = (fl[l]&TYPE_T) ? -1 : 0; }
+		/* load_f, FX/kernel.cpp:1338-1344 */
+		v8f fhn[19];
+		fhn[0] = fast_load8(k, k->fi, 0ull, r00, xn, contig_n);
+		for(uint32_t i=1u, q=0u; i<19u; i+=2u, q++) {
+			fhn[i   ] = fast_load8(k, k->fi, (uint64_t)(odd ? i    : i+1u), r00, xn, contig_n);
+			fhn[i+1u] = fast_load8(k, k->fi, (uint64_t)(odd ? i+1u : i   ), rowj[q], shifted[q] ? xp : xn, shifted[q] ? contig_p : contig_n);
+		}
+		for(uint32_t i=0u; i<19u; i++) fhn[i] = vsel(m_on, fhn[i], zero);
+		/* calculate_rho_u (FX/kernel.cpp:1075-1100) or, on TYPE_E cells, the fields */
+		v8f rhon, uxn, uyn, uzn;
+		{
+			v8f rho_ = fhn[0];
+			for(uint32_t i=1u; i<19u; i++) rho_ += fhn[i];
+			rho_ += 1.0f;
+			const v8f ux = fhn[ 1]-fhn[ 2]+fhn[ 7]-fhn[ 8]+fhn[ 9]-fhn[10]+fhn[13]-fhn[14]+fhn[15]-fhn[16];
+			const v8f uy = fhn[ 3]-fhn[ 4]+fhn[ 7]-fhn[ 8]+fhn[11]-fhn[12]+fhn[14]-fhn[13]+fhn[17]-fhn[18];
+			const v8f uz = fhn[ 5]-fhn[ 6]+fhn[ 9]-fhn[10]+fhn[11]-fhn[12]+fhn[16]-fhn[15]+fhn[18]-fhn[17];
+			rhon = rho_; uxn = ux/rho_; uyn = uy/rho_; uzn = uz/rho_;
+		}
+		v8f rho_f, ux_f, uy_f, uz_f;   /* rho[n], u[n] of the chunk's cells */
+		for(int l=0; l<8; l++) { const uint64_t n = r00+xn[l]; rho_f[l] = k->rho[n]; ux_f[l] = k->u[n]; uy_f[l] = k->u[N+n]; uz_f[l] = k->u[2ull*N+n]; }
+		rhon = vsel(m_E, rho_f, rhon); uxn = vsel(m_E, ux_f, uxn); uyn = vsel(m_E, uy_f, uyn); uzn = vsel(m_E, uz_f, uzn);
+		v8f fxn = vsplat(c->fx), fyn = vsplat(c->fy), fzn = vsplat(c->fz);
+		{
+			const v8f cor_x = -2.0f*rhon*(c->omega_y*uzn-c->omega_z*uyn);
+			const v8f cor_y = -2.0f*rhon*(c->omega_z*uxn-c->omega_x*uzn);
+			const v8f cor_z = -2.0f*rhon*(c->omega_x*uyn-c->omega_y*uxn);
+			fxn += cor_x; fyn += cor_y; fzn += cor_z;
+		}
+		if(c->buffer_active) { /* FX/kernel.cpp:1523-1595: the selection per cell as written there, the arithmetic for the chunk */
+			v8i m_z; v8f w_buf = zero, tx = zero, ty = zero, tz = zero;
+			int any_z = 0;
+			for(int l=0; l<8; l++) {
+				m_z[l] = 0;
+				if((fl[l]&TYPE_BO)==TYPE_E||!on[l]) continue;
+				const uint32_t x = xn[l];
+				const int xg = (int)x+c->Ox;
+				const int d_w_i = xg, d_e_i = (int)(k->Nxg-1u)-xg;
+				const int in_w = c->downstream_face!=1&&k->has_w==1&&d_w_i>=0&&d_w_i<=Nbuf_i;
+				const int in_e = c->downstream_face!=2&&k->has_e==1&&d_e_i>=0&&d_e_i<=Nbuf_i;
+				if(in_w||in_e||in_s||in_n||in_t) {
+					uint32_t d_min = c->buffer_N+1u;
+					uint64_t n_ref = r00+x;
+					if(in_w) { const uint32_t d = (uint32_t)d_w_i; if(d<d_min) { d_min = d; n_ref = index3(c, (uint32_t)k->west_x, y, z); } }
+					if(in_e) { const uint32_t d = (uint32_t)d_e_i; if(d<d_min) { d_min = d; n_ref = index3(c, (uint32_t)k->east_x, y, z); } }
+					if(in_s) { const uint32_t d = (uint32_t)d_s_i; if(d<d_min) { d_min = d; n_ref = index3(c, x, (uint32_t)k->south_y, z); } }
+					if(in_n) { const uint32_t d = (uint32_t)d_n_i; if(d<d_min) { d_min = d; n_ref = index3(c, x, (uint32_t)k->north_y, z); } }
+					if(in_t) { const uint32_t d = (uint32_t)d_t_i; if(d<d_min) { d_min = d; n_ref = index3(c, x, y, (uint32_t)k->top_z); } }
+					m_z[l] = -1; any_z = 1;
+					w_buf[l] = k->wbuf[d_min];
+					tx[l] = k->u[n_ref]; ty[l] = k->u[N+n_ref]; tz[l] = k->u[2ull*N+n_ref];
+				}
+			}
+			if(any_z) {
+				const v8f a_x = w_buf*c->buffer_inv_tau*(tx-uxn);
+				const v8f a_y = w_buf*c->buffer_inv_tau*(ty-uyn);
+				const v8f a_z = c->buffer_nudge_vertical==1 ? w_buf*c->buffer_inv_tau*(tz-uzn) : zero;
+				fxn = vsel(m_z, fxn+rhon*a_x, fxn);
+				fyn = vsel(m_z, fyn+rhon*a_y, fyn);
+				fzn = vsel(m_z, fzn+rhon*a_z, fzn);
+			}
+		}
+		v8i m_sp;   /* the top sponge acts on this lane (FX/kernel.cpp:1596-1614) */
+		for(int l=0; l<8; l++) m_sp[l] = (in_sp&&on[l]&&(fl[l]&TYPE_BO)!=TYPE_E) ? -1 : 0;
+		const uint64_t row_top = in_sp ? index3(c, 0u, y, (uint32_t)k->top_z) : 0ull;
+		if(in_sp) {
+			const v8f sigma = vsplat(k->sigma[d_sp_i]);
+			v8f sx, sy, sz;
+			for(int l=0; l<8; l++) { const uint64_t n_ref = row_top+xn[l]; sx[l] = k->u[n_ref]; sy[l] = k->u[N+n_ref]; sz[l] = k->u[2ull*N+n_ref]; }
+			fxn = vsel(m_sp, fxn+rhon*sigma*(sx-uxn), fxn);
+			fyn = vsel(m_sp, fyn+rhon*sigma*(sy-uyn), fyn);
+			fzn = vsel(m_sp, fzn+rhon*sigma*(sz-uzn), fzn);
+		}
+		if(k->gi) { /* TEMPERATURE, FX/kernel.cpp:1639-1684 */
+			v8f ghn[7];
+			ghn[0] = fast_load8(k, k->gi, 0ull, r00, xn, contig_n);
+			for(uint32_t i=1u, q=0u; i<7u; i+=2u, q++) {
+				ghn[i   ] = fast_load8(k, k->gi, (uint64_t)(odd ? i    : i+1u), r00, xn, contig_n);
+				ghn[i+1u] = fast_load8(k, k->gi, (uint64_t)(odd ? i+1u : i   ), rowj[q], shifted[q] ? xp : xn, shifted[q] ? contig_p : contig_n);
+			}
+			v8f T_f;
+			for(int l=0; l<8; l++) T_f[l] = k->T[r00+xn[l]];
+			v8f Tn = zero;
+			for(uint32_t i=0u; i<7u; i++) Tn += ghn[i];
+			Tn += 1.0f;
+			Tn = vsel(m_T, T_f, Tn);
+			if(in_sp) {
+				const v8f sigma_T = vsplat(k->sigma[d_sp_i]);
+				v8f T_top;
+				for(int l=0; l<8; l++) T_top[l] = k->T[row_top+xn[l]];
+				Tn = vsel(m_sp&~m_T, vfma(sigma_T, T_top-Tn, Tn), Tn);
+			}
+			v8f geq[7];
+			{
+				const v8f wsT4 = 0.5f*Tn, wsTm1 = 0.125f*(Tn-1.0f);
+				geq[0] = vfma(vsplat(0.25f), Tn, vsplat(-0.25f));
+				geq[1] = vfma(wsT4, uxn, wsTm1); geq[2] = vfma(wsT4, -uxn, wsTm1);
+				geq[3] = vfma(wsT4, uyn, wsTm1); geq[4] = vfma(wsT4, -uyn, wsTm1);
+				geq[5] = vfma(wsT4, uzn, wsTm1); geq[6] = vfma(wsT4, -uzn, wsTm1);
+			}
+			for(int l=0; l<8; l++) if(on[l]&&!(fl[l]&TYPE_T)) k->T[r00+xn[l]] = Tn[l]; /* UPDATE_FIELDS */
+			for(uint32_t i=0u; i<7u; i++) ghn[i] = vsel(m_T, geq[i], vfma(vsplat(1.0f-c->w_T), ghn[i], c->w_T*geq[i]));
+			fast_store8(k, k->gi, 0ull, r00, xn, all&&contig_n, on, ghn[0]);
+			for(uint32_t i=1u, q=0u; i<7u; i+=2u, q++) {
+				fast_store8(k, k->gi, (uint64_t)(odd ? i+1u : i   ), rowj[q], shifted[q] ? xp : xn, all&&(shifted[q] ? contig_p : contig_n), on, ghn[i   ]);
+				fast_store8(k, k->gi, (uint64_t)(odd ? i    : i+1u), r00, xn, all&&contig_n, on, ghn[i+1u]);
+			}
+		}
+		if(k->F) { /* FORCE_FIELD */
+			v8f Fx, Fy, Fz;
+			for(int l=0; l<8; l++) { const uint64_t n = r00+xn[l]; Fx[l] = k->F[n]; Fy[l] = k->F[N+n]; Fz[l] = k->F[2ull*N+n]; }
+			fxn += Fx; fyn += Fy; fzn += Fz;
+		}
+		v8f Fin[19];
+		{ /* VOLUME_FORCE, FX/kernel.cpp:1686-1692 + calculate_forcing_terms :1103-1113 */
+			const v8f rho2 = 0.5f/rhon;
+			uxn = vclamp(vfma(fxn, rho2, uxn), -DEF_C, DEF_C);
+			uyn = vclamp(vfma(fyn, rho2, uyn), -DEF_C, DEF_C);
+			uzn = vclamp(vfma(fzn, rho2, uzn), -DEF_C, DEF_C);
+			const v8f uF = -0.33333334f*vfma(uxn, fxn, vfma(uyn, fyn, uzn*fzn));
+			Fin[0] = 9.0f*DEF_W0*uF;
+			for(uint32_t i=1u; i<19u; i++) Fin[i] = 9.0f*wi(i)*vfma(CX[i]*fxn+CY[i]*fyn+CZ[i]*fzn, CX[i]*uxn+CY[i]*uyn+CZ[i]*uzn+0.33333334f, uF);
+		}
+		for(int l=0; l<8; l++) if(on[l]&&(fl[l]&TYPE_BO)!=TYPE_E) { /* UPDATE_FIELDS, FX/kernel.cpp:1709-1716 */
+			const uint64_t n = r00+xn[l];
+			k->rho[n] = rhon[l]; k->u[n] = uxn[l]; k->u[N+n] = uyn[l]; k->u[2ull*N+n] = uzn[l];
+		}
+		v8f feq[19];
+		{ /* luwo_calculate_f_eq */
+			const v8f rhom1 = rhon-1.0f;
+			const v8f c3 = -3.0f*(vsq(uxn)+vsq(uyn)+vsq(uzn));
+			const v8f uz = uzn*3.0f, ux = uxn*3.0f, uy = uyn*3.0f;
+			const v8f h = vsplat(0.5f);
+			feq[ 0] = DEF_W0*vfma(rhon, 0.5f*c3, rhom1);
+			const v8f u0=ux+uy, u1=ux+uz, u2=uy+uz, u3=ux-uy, u4=ux-uz, u5=uy-uz;
+			const v8f rhos=DEF_WS*rhon, rhoe=DEF_WE*rhon, rhom1s=DEF_WS*rhom1, rhom1e=DEF_WE*rhom1;
+			feq[ 1] = vfma(rhos, vfma(h, vfma(ux, ux, c3), ux), rhom1s); feq[ 2] = vfma(rhos, vfma(h, vfma(ux, ux, c3), -ux), rhom1s);
+			feq[ 3] = vfma(rhos, vfma(h, vfma(uy, uy, c3), uy), rhom1s); feq[ 4] = vfma(rhos, vfma(h, vfma(uy, uy, c3), -uy), rhom1s);
+			feq[ 5] = vfma(rhos, vfma(h, vfma(uz, uz, c3), uz), rhom1s); feq[ 6] = vfma(rhos, vfma(h, vfma(uz, uz, c3), -uz), rhom1s);
+			feq[ 7] = vfma(rhoe, vfma(h, vfma(u0, u0, c3), u0), rhom1e); feq[ 8] = vfma(rhoe, vfma(h, vfma(u0, u0, c3), -u0), rhom1e);
+			feq[ 9] = vfma(rhoe, vfma(h, vfma(u1, u1, c3), u1), rhom1e); feq[10] = vfma(rhoe, vfma(h, vfma(u1, u1, c3), -u1), rhom1e);
+			feq[11] = vfma(rhoe, vfma(h, vfma(u2, u2, c3), u2), rhom1e); feq[12] = vfma(rhoe, vfma(h, vfma(u2, u2, c3), -u2), rhom1e);
+			feq[13] = vfma(rhoe, vfma(h, vfma(u3, u3, c3), u3), rhom1e); feq[14] = vfma(rhoe, vfma(h, vfma(u3, u3, c3), -u3), rhom1e);
+			feq[15] = vfma(rhoe, vfma(h, vfma(u4, u4, c3), u4), rhom1e); feq[16] = vfma(rhoe, vfma(h, vfma(u4, u4, c3), -u4), rhom1e);
+			feq[17] = vfma(rhoe, vfma(h, vfma(u5, u5, c3), u5), rhom1e); feq[18] = vfma(rhoe, vfma(h, vfma(u5, u5, c3), -u5), rhom1e);
+		}
+		v8f w = vsplat(c->w);
+		if(c->subgrid) { /* FX/kernel.cpp:1723-1737 */
+			const float tau0 = 1.0f/c->w;
+			v8f Hxx=zero, Hyy=zero, Hzz=zero, Hxy=zero, Hxz=zero, Hyz=zero;
+			for(uint32_t i=1u; i<19u; i++) {
+				const v8f fneqi = fhn[i]-feq[i];
+				const float cxi=CX[i], cyi=CY[i], czi=CZ[i];
+				Hxx += cxi*cxi*fneqi;
+				Hxy += cxi*cyi*fneqi; Hyy += cyi*cyi*fneqi;
+				Hxz += cxi*czi*fneqi; Hyz += cyi*czi*fneqi; Hzz += czi*czi*fneqi;
+			}
+			const v8f Q = vsq(Hxx)+vsq(Hyy)+vsq(Hzz)+2.0f*(vsq(Hxy)+vsq(Hxz)+vsq(Hyz));
+			w = 2.0f/(tau0+vsqrt(sq(tau0)+0.76421222f*vsqrt(Q)/rhon));
+		}
+		const v8f c_tau = vfma(w, vsplat(-0.5f), vsplat(1.0f)); /* FX/kernel.cpp:1741-1742 */
+		for(uint32_t i=0u; i<19u; i++) Fin[i] *= c_tau;
+		for(uint32_t i=0u; i<19u; i++) fhn[i] = vsel(m_E, feq[i], vfma(1.0f-w, fhn[i], vfma(w, feq[i], Fin[i]))); /* FX/kernel.cpp:1747 */
+		/* store_f, FX/kernel.cpp:1345-1351 */
+		fast_store8(k, k->fi, 0ull, r00, xn, all&&contig_n, on, fhn[0]);
+		for(uint32_t i=1u, q=0u; i<19u; i+=2u, q++) {
+			fast_store8(k, k->fi, (uint64_t)(odd ? i+1u : i   ), rowj[q], shifted[q] ? xp : xn, all&&(shifted[q] ? contig_p : contig_n), on, fhn[i   ]);
+			fast_store8(k, k->fi, (uint64_t)(odd ? i    : i+1u), r00, xn, all&&contig_n, on, fhn[i+1u]);
+		}
+	}
+}
+static void stream_collide_rows(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, void* gi, float* T, const uint64_t t) {
+	FastCtx k;
+	memset(&k, 0, sizeof(k));
+	k.c = c; k.N = (uint64_t)c->Nx*(uint64_t)c->Ny*(uint64_t)c->Nz; k.t = t;
+	k.fi = fi; k.rho = rho; k.u = u; k.flags = flags; k.F = F; k.gi = gi; k.T = T;
+	/* derived face constants, FX/lbm.cpp:613-625 (stream_collide_cell derives the same per cell) */
+	k.Nxg = (c->Nx-2u*(c->Dx>1u))*c->Dx; k.Nyg = (c->Ny-2u*(c->Dy>1u))*c->Dy; k.Nzg = (c->Nz-2u*(c->Dz>1u))*c->Dz;
+	k.west_x = -c->Ox; k.east_x = (int)k.Nxg-1-c->Ox; k.south_y = -c->Oy; k.north_y = (int)k.Nyg-1-c->Oy; k.top_z = (int)k.Nzg-1-c->Oz;
+	k.has_w = k.west_x>=0&&k.west_x<(int)c->Nx ? 1 : 0; k.has_e = k.east_x>=0&&k.east_x<(int)c->Nx ? 1 : 0;
+	k.has_s = k.south_y>=0&&k.south_y<(int)c->Ny ? 1 : 0; k.has_n = k.north_y>=0&&k.north_y<(int)c->Ny ? 1 : 0;
+	k.has_t = k.top_z>=0&&k.top_z<(int)c->Nz ? 1 : 0;
+	if(c->buffer_active) { /* w_buf per distance, FX/kernel.cpp:1581-1583 */
+		k.wbuf = (float*)malloc(((size_t)c->buffer_N+2u)*sizeof(float));
+		for(uint32_t d=0u; d<=c->buffer_N+1u; d++) {
+			const float xi = 1.0f-(float)d/(float)c->buffer_N;
+			float w_buf = sinf(1.5707963267948966f*xi);
+			w_buf *= w_buf;
+			k.wbuf[d] = w_buf;
+		}
+	}
+	if(c->sponge_active) { /* sigma per layer, FX/kernel.cpp:1604-1606 */
+		const int Nsponge_i = (int)c->sponge_N;
+		k.sigma = (float*)malloc(((size_t)c->sponge_N+1u)*sizeof(float));
+		for(int d=0; d<Nsponge_i; d++) {
+			const float xi = Nsponge_i>1 ? 1.0f-(float)d/(float)(Nsponge_i-1) : 1.0f;
+			float sigma = sinf(1.5707963267948966f*xi);
+			sigma = c->sponge_inv_tau*sigma*sigma;
+			k.sigma[d] = sigma;
+		}
+	}
+	const int64_t rows = (int64_t)c->Ny*(int64_t)c->Nz;
+	#pragma omp parallel for schedule(static)
+	for(int64_t r=0; r<rows; r++) {
+		const uint32_t y = (uint32_t)(r%(int64_t)c->Ny), z = (uint32_t)(r/(int64_t)c->Ny);
+		if(((c->Dy>1u)&&(y==0u||y>=c->Ny-1u))||((c->Dz>1u)&&(z==0u||z>=c->Nz-1u))) continue; /* halo rows, FX/kernel.cpp:856-859 */
+		fast_row(&k, y, z);
+	}
+	free(k.wbuf); free(k.sigma);
+}
+#else
+#define LUWO_HAVE_FAST 0
+#endif
+static int g_fast = 1;
+void luwo_set_fast(const int on) { g_fast = on; }
+int luwo_get_fast(void) { return g_fast&&LUWO_HAVE_FAST; }
+
+void luwo_stream_collide_thermal(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, void* gi, float* T, const uint64_t t) {
+#if LUWO_HAVE_FAST
+	if(g_fast) { stream_collide_rows(c, fi, rho, u, flags, F, gi, T, t); return; }
+#endif
+	luwo_stream_collide_literal(c, fi, rho, u, flags, F, gi, T, t);
+}
+void luwo_stream_collide(const LuwOracleCfg* c, void* fi, float* rho, float* u, const uint8_t* flags, const float* F, const uint64_t t) {
+	luwo_stream_collide_thermal(c, fi, rho, u, flags, F, NULL, NULL, t);
 }
 
 /* LBM::run for a single domain: FX/lbm.cpp:1262-1312 (t increments after each stream_collide) */

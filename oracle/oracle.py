@@ -63,6 +63,9 @@ def lib():
         L.luwo_moments.argtypes = [cfgp, vp, u64, vp, vp]; L.luwo_moments.restype = None
         L.luwo_vk_inlet_apply.argtypes = [u64, u32, C.c_float, C.c_float, C.c_float, u64, u64, vp, vp, vp, vp, vp]; L.luwo_vk_inlet_apply.restype = None
         L.luwo_accumulate_stats.argtypes = [u64, u64] + [vp] * 7; L.luwo_accumulate_stats.restype = None
+        L.luwo_stream_collide_literal.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, vp, u64]; L.luwo_stream_collide_literal.restype = None
+        L.luwo_set_fast.argtypes = [C.c_int]; L.luwo_set_fast.restype = None
+        L.luwo_get_fast.restype = C.c_int
         L.luwo_set_threads.argtypes = [C.c_int]; L.luwo_set_threads.restype = None
         L.luwo_get_max_threads.restype = C.c_int
         L.luwo_copy_bandwidth_gbps.argtypes = [u64]; L.luwo_copy_bandwidth_gbps.restype = C.c_double
@@ -230,3 +233,12 @@ def half_to_float(codes):
 def float_to_half(vals):
     L = lib()
     return np.array([L.luwo_float_to_half_custom(float(v)) for v in np.asarray(vals, np.float32).ravel()], np.uint16)
+
+
+def set_fast(on):
+    """row-wise path of luw_oracle.c on (default) / off (every call takes the literal one-cell-at-a-time path)"""
+    lib().luwo_set_fast(int(bool(on)))
+
+
+def fast_available():
+    return bool(lib().luwo_get_fast())

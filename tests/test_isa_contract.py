@@ -86,10 +86,13 @@ def test_nothing_but_the_encode_follows_the_rounding_mode_switch(device_asm):
 def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
     # scalar kernel: FP32 in both addressing forms (FLAT for planes within 32-bit byte offsets, row form beyond), FP16C in the row form,
     # general and force-free; pair kernel: force modes none / uniform / any in registers, any with the second cell parked in LDS (the product's general kernel),
-    # and the three thermal variants (always parked); both time parities each: 8 + 8 + 6
+    # and the three thermal variants (always parked); both time parities each: 8 + 8 + 6; the native-arithmetic instantiations (LUW_OPT_NATIVE_ARITH): the
+    # one-cell
+    # FP16C kernel, the pair kernel's three force modes and their three thermal variants: 2 + 6 + 6
     product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb0ELb[01]E", n)
         or re.search(r"k_stream_collide_pILi[01]ELi0ELb0ELi[012]E", n)]
-    assert len(product) == 22, product
+    assert len(product) == 36, product
+    assert len([n for n in product if n.split("EvN3luw")[0].endswith("Lb1E")]) == 14          # trailing template flag NATIVE
     # the same kernels with the statistics epilogue (sampled steps): no spills either
     sampled = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb1ELb0E", n)
         or re.search(r"k_stream_collide_pILi[01]ELi0ELb1ELi2E", n)]

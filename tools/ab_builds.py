@@ -2,7 +2,7 @@
 """Interleaved A/B of several BUILDS of libluw_core.so in ONE process on one GPU: every build is compiled here (hipcc, the product flags plus the
 build's extra flags) into gpurun_out/ab/, loaded side by side through the bare C-ABI, and the workloads are stepped round-robin -- build A, build B,
 build A ... -- so that the drift of a box (whole sessions run 10 % apart, profiles/r02_skew_study.md) hits all builds alike.
-usage: ab_builds.py "<tag>=<extra flags>" ... [-- workload ...]      workload = f32|fp16c : NxxNyxNz [: bld] [: cor] [: urban] [: th]
+usage: ab_builds.py "<tag>=<extra flags>" ... [-- workload ...]      workload = f32|fp16c : NxxNyxNz [: bld] [: cor] [: urban] [: th] [: nat]
        (urban = the 8-GPU tile's forcing: buffer nudging 80 cells + top sponge 100 layers; bld = building array; cor = Coriolis; th = thermal lattice)
 e.g.   ab_builds.py "lib=" "noplain=-DLUW_PLAIN_ARITH=0" -- fp16c:1024x1024x256:bld fp16c:1024x1024x256:bld:cor fp16c:512x512x512:bld:urban:cor"""
 import ctypes as C, os, subprocess, sys
@@ -41,6 +41,7 @@ def make(L, fp16c, N, opts):
     cfg = Config(); cfg.struct_size = C.sizeof(Config); cfg.Nx, cfg.Ny, cfg.Nz = N; cfg.Dx = cfg.Dy = cfg.Dz = 1; cfg.nu = NU
     cfg.ddf_format = 1 if fp16c else 0
     if "th" in opts: cfg.options = 8; cfg.alpha = 2.1e-7
+    if "nat" in opts: cfg.options |= 16          # LUW_OPT_NATIVE_ARITH
     if "urban" in opts:
         nud, spg = tile_forcing()
         cfg.buffer_nudging_active = 1; cfg.buffer_n_cells = nud["n_cells"]; cfg.buffer_inv_tau_lbmu = nud["inv_tau"]; cfg.buffer_downstream_face_id = nud[
