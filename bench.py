@@ -845,7 +845,7 @@ def group_host_child(args, luw, capi, kern, fp16c):
     run, FP32, rho and u of every cell), then the timed tile."""
     from concurrent.futures import ThreadPoolExecutor
     label = args.group_host_child
-    os.environ.update(GROUP_HOST_VARIANTS[label])
+    os.environ.update(GROUP_HOST_VARIANTS[label]); capi.reload_tuning()
     devices = [int(d) for d in args.devices.split(",")]
     D, gN, n = tuple(args.n_gpu), tuple(args.global_lattice), len(devices)
     urban = not args.no_buildings

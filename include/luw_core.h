@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LUW_ABI_VERSION 4
+#define LUW_ABI_VERSION 5
 
 /* error codes */
 #define LUW_OK 0
@@ -70,22 +70,11 @@ extern "C" {
  * tests/test_gpu_native_arith.py, instead of bit for bit.  Ignored for FP32 DDFs and where the one-cell kernel runs. */
 #define LUW_OPT_NATIVE_ARITH 0x10u
 
-/* kernel selection.  The product library knows AUTO, SCALAR and PAIR (luw_create rejects the others); the remaining ids name A/B and
- * measurement-only variants that exist in the tools build only (make -C csrc ab, -DLUW_AB_KERNELS) */
-/* FP32: SCALAR. FP16C: PAIR for boxes at least 128 cells wide in x (whole pairs from a 4-byte boundary, no thermal lattice), else SCALAR */
-#define LUW_KERNEL_AUTO 0
+/* kernel selection (cfg.kernel, luw_set_kernel): all three compute the same values.  (The A/B and measurement-only variants of the tools build have
+ * their ids in include/luw_core_dev.h; this library rejects them.) */
+#define LUW_KERNEL_AUTO 0               /* FP32: SCALAR.  FP16C: PAIR for boxes of 128 cells and more in x (whole pairs from a 4-byte boundary), else SCALAR */
 #define LUW_KERNEL_SCALAR 1             /* 1 cell / lane, one dword (FP32) per lane and plane; non-temporal on the 14 aligned planes */
-#define LUW_KERNEL_VEC4 2               /* 4 cells / lane, one aligned access per lane and plane, wave64 lane shifts for x+1 populations */
-#define LUW_KERNEL_VEC2 3               /* 2 cells / lane (FP16C: one dword per lane and plane) */
-#define LUW_KERNEL_SCALAR_CACHED 4      /* scalar kernel with the default cache policy instead of non-temporal DDF accesses (A/B) */
-#define LUW_KERNEL_SCALAR_NT_ALL 5      /* scalar kernel with non-temporal accesses on all 19 planes (A/B; the product uses nt on the 14 aligned planes) */
-/* FP16C only: 2 cells / lane collided one after the other on packed FP32 pairs, one dword per lane and plane; falls back to SCALAR where it does not
- * apply */
-#define LUW_KERNEL_PAIR 7
-#define LUW_KERNEL_VEC1 6               /* 1 cell / lane with aligned accesses + wave64 lane shifts for the x+1 populations (A/B) */
-#define LUW_KERNEL_SCALAR_GENERAL 8     /* scalar kernel without the wave-uniform "no TYPE_E, no force in this wave" fast path (A/B) */
-#define LUW_KERNEL_EXP_COPY 100         /* measurement only: scalar kernel's loads/stores without the collision (no physics) */
-#define LUW_KERNEL_EXP_NOSHIFT 101      /* measurement only: scalar kernel with the x+1 neighbours replaced by x (no physics) */
+#define LUW_KERNEL_PAIR 7               /* FP16C only: 2 cells / lane collided one after the other on packed FP32 pairs, one dword per lane and plane */
 
 typedef struct luw_config {
 	uint32_t struct_size;            /* = sizeof(luw_config), ABI check */
@@ -129,10 +118,11 @@ int luw_p2p_info(int device, int peer, int* can_access, int* performance_rank, i
 int luw_format_float9(float x, char* text, uint64_t size);
 
 /* life cycle: LBM::LBM (FX/lbm.cpp:1057-1112) / LBM::~LBM.
- * For DDF arrays of 1 GiB and more luw_create tries a few candidate allocations and keeps the one on which the step kernel
- * runs fastest (physical placement changes the step time by up to 10 % on MI355X); this needs free
- * device memory for the candidates and is skipped when there is none.  Environment: LUW_TUNE_PLACEMENT=<candidates>
- * (default 6, 0/1 = off), LUW_TUNE_VERBOSE=1 prints the candidates' times. */
+ * For DDF arrays of 1 GiB and more luw_create times two steps of the real kernel on the freshly mapped array and, while that is under the rate of the
+ * fast class of placements, tries up to three other kinds of allocation, one at a time, keeping the fastest (physical placement changes the step time
+ * by up to 10 % on MI355X and which kind is fast differs between machines).  Nothing of the search outlives luw_create; it needs
+ * room for one more DDF array while it runs and is skipped without it, and on devices that several solvers share.  Environment knobs: INTEGRATION.md
+ * section 5 (LUW_TUNE_PLACEMENT=0 switches the search off). */
 int luw_create(const luw_config* cfg, luw_solver** out);
 void luw_destroy(luw_solver* s);
 
@@ -189,12 +179,6 @@ int luw_enqueue_extract_gi(luw_solver* s, uint32_t direction, void* buf_p, void*
 int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m);
 int luw_finish(luw_solver* s);                                            /* LBM_Domain::finish_queue */
 
-/* debugging / test access to the DDFs: copies the 19 planes to / from host memory in the reference's layout
- * fi[i*N + n] (FX/kernel.cpp:877-879), raw storage type (float or uint16_t FP16C codes). */
-int luw_download_fi(luw_solver* s, void* host_dst);
-int luw_download_gi(luw_solver* s, void* host_dst);   /* thermal DDFs as stored, gi[i*N+n], i = 0..6 (tests) */
-int luw_upload_fi(luw_solver* s, const void* host_src);
-
 /* switch the kernel variant of an existing solver (A/B on the same memory; values are identical for all product variants) */
 int luw_set_kernel(luw_solver* s, uint32_t kernel);
 
@@ -250,19 +234,6 @@ int luw_stats_download(luw_solver* s, float* avg_u, float* avg_rho, float* m2_u,
 int luw_run_sampled(luw_solver* s, uint64_t steps, uint64_t first_sample, uint64_t stride);
 int luw_stats_download_T(luw_solver* s, float* avg_T);   /* running mean of T (LUW_OPT_TEMPERATURE), T_avg of FX/setup.cpp:4481-4484 */
 
-/* device self-check: number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C
- * codec differs from the literal formulas of FX/kernel.cpp:864-875; must be 0 */
-int luw_selfcheck_fp16c_codec(int device, uint64_t* mismatches);
-/* Device self-check of the FP16C kernels' division and square root (the library's correctly rounded instruction sequences without their
- * range handling, csrc/luw_device.hpp) against `a/b` and sqrtf(): mismatches[0] square roots over every float of the range, [1] quotients for
- * every denominator in [1/4, 4] x 64 numerators, [2] the same with numerators on the 2^-25 grid of FP16C moment sums.  All three must be 0.
- * (The reference divides with the OpenCL compiler's native operators, FX/kernel.cpp:1088-1100,1735: not bit-defined; the oracle uses IEEE.) */
-int luw_selfcheck_arith(int device, uint64_t* mismatches);
-
-/* measurement helper for bench.py: runs `steps` steps like luw_run and returns the mean duration of the
- * stream_collide kernel in milliseconds, taken with HIP events on the launch stream. */
-int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms);
-
 /* ================================================================================================================
  * Several domains in ONE process: the reference's `LBM lbm(N, Dx, Dy, Dz, nu, ...)` for Dx*Dy*Dz > 1 (FX/lbm.hpp:444-450,
  * FX/lbm.cpp:1057-1112): it builds every LBM_Domain itself (one device each), steps them together (do_time_step,
@@ -305,7 +276,6 @@ int luw_group_initialize(luw_group* g);
 int luw_group_run(luw_group* g, uint64_t steps);                                         /* LBM::run(steps): returns after all devices finished */
 /* luw_run_sampled for every domain, no host sync inside the window */
 int luw_group_run_sampled(luw_group* g, uint64_t steps, uint64_t first_sample, uint64_t stride);
-int luw_group_run_timed(luw_group* g, uint64_t steps, double* mean_kernel_ms);           /* mean duration of domain 0's interior (or whole-box) kernel */
 uint64_t luw_group_get_t(const luw_group* g);
 int luw_group_set_f(luw_group* g, float fx, float fy, float fz);
 int luw_group_set_coriolis(luw_group* g, float ox, float oy, float oz);
@@ -334,8 +304,6 @@ int luw_domain_step_overlaps(const luw_domain_step* d);       /* 1: shell on the
 int luw_domain_step_launch(luw_domain_step* d, int write_fields /* bit 0 | LUW_WF_SAMPLE */, int timed);
 /* a sampled step without fused statistics: luw_stats_accumulate behind the step, ordered against the next shell */
 int luw_domain_step_separate_stats(luw_domain_step* d);
-/* means over the timed launches since the last call; waits for both streams */
-int luw_domain_step_timing(luw_domain_step* d, double* kernel_ms, double* shell_ms);
 
 /* VTK payloads straight from the devices: Memory_Container::write_vtk (FX/lbm.hpp:307-356) and the sections of write_avg_vtk (FX/setup.cpp:2513-2683)
  * without the full-field download.  Every domain converts its own cells on its device -- SoA -> AoS, SI scaling, big-endian -- in z slabs that a

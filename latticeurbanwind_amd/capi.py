@@ -1,4 +1,5 @@
-"""ctypes binding of the C-ABI declared in include/luw_core.h (product library csrc/libluw_core.so).
+"""ctypes binding of the C-ABI declared in include/luw_core.h (the drop-in boundary) and include/luw_core_dev.h (measurement / test entry points) of
+the product library csrc/libluw_core.so.
 
 There is deliberately no CPU fallback: if the HIP library is missing or no GPU is present, calls fail loudly.
 """
@@ -23,23 +24,24 @@ TYPE_S, TYPE_E, TYPE_T = 0x01, 0x02, 0x04
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4
 
 SYMBOLS = [
-    "luw_abi_version", "luw_last_error", "luw_device_count", "luw_format_float9", "luw_create", "luw_destroy", "luw_host_ptr",
-    "luw_get_N", "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f",
-    "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch", "luw_get_plane_stride", "luw_set_stream",
-    "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area", "luw_enqueue_extract_fi",
-    "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info", "luw_group_overlaps",
-        "luw_group_direct_peer_stores",
-    "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download", "luw_group_initialize", "luw_group_run", "luw_group_run_sampled",
-        "luw_group_run_timed",
-    "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis", "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach",
-        "luw_group_gather_u",
-    "luw_group_stats_reset", "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_selfcheck_arith",
-        "luw_fields_every_step", "luw_step_boxes", "luw_domain_step_create", "luw_domain_step_destroy", "luw_domain_step_overlaps", "luw_domain_step_launch",
-        "luw_domain_step_separate_stats", "luw_domain_step_timing", "luw_group_export_vtk", "luw_group_stats_count",
-    "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish", "luw_run_timed", "luw_download_fi", "luw_download_gi",
-        "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample",
-        "luw_stats_download", "luw_stats_download_T", "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u",
-        "luw_vk_inlet_attach", "luw_vk_inlet_apply", "luw_vk_inlet_detach",
+    "luw_abi_version", "luw_last_error", "luw_device_count", "luw_format_float9", "luw_create", "luw_destroy", "luw_host_ptr", "luw_get_N",
+    "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f", "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch",
+    "luw_get_plane_stride", "luw_set_stream", "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area",
+    "luw_enqueue_extract_fi", "luw_group_create", "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info",
+    "luw_group_overlaps", "luw_group_direct_peer_stores", "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download",
+    "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis",
+    "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach", "luw_group_gather_u", "luw_group_stats_reset",
+    "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_fields_every_step", "luw_step_boxes",
+    "luw_domain_step_create", "luw_domain_step_destroy", "luw_domain_step_overlaps", "luw_domain_step_launch", "luw_domain_step_separate_stats",
+    "luw_group_export_vtk", "luw_group_stats_count", "luw_enqueue_insert_fi", "luw_enqueue_extract_gi", "luw_enqueue_insert_gi", "luw_finish",
+    "luw_stats_reset", "luw_stats_accumulate", "luw_run_sampled", "luw_stats_begin_sample", "luw_stats_download", "luw_stats_download_T",
+    "luw_voxelize_mesh", "luw_voxelize_lattice", "luw_set_kernel", "luw_gather_attach", "luw_gather_u", "luw_vk_inlet_attach", "luw_vk_inlet_apply",
+    "luw_vk_inlet_detach",
+]
+# include/luw_core_dev.h
+DEV_SYMBOLS = [
+    "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_reload_tuning", "luw_dev_tuning_text",
+    "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_selfcheck_arith",
 ]
 
 
@@ -173,7 +175,9 @@ def load(path=None):
     L.luw_group_export_vtk.argtypes = [vp, i32, vp, u32, i32, u64]
     L.luw_device_info.argtypes = [i32, C.c_char_p, u64, C.c_char_p, u64, C.POINTER(u64)]
     L.luw_p2p_info.argtypes = [i32, i32, i32p, i32p, i32p, u32p, u32p]
-    if L.luw_abi_version() != 4:
+    L.luw_dev_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, u64]
+    L.luw_dev_tuning_text.argtypes = [C.c_char_p, u64]
+    if L.luw_abi_version() != 5:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
     return L
@@ -202,3 +206,21 @@ def p2p_info(device, peer):
 def check(rc):
     if rc != LUW_OK:
         raise LuwError("luw_core error %d: %s" % (rc, load().luw_last_error().decode("utf-8", "replace")))
+
+
+def reload_tuning():
+    """the library reads its environment knobs once; tests and A/B tools that change os.environ between two solvers call this"""
+    check(load().luw_dev_reload_tuning())
+
+
+def tuning_text():
+    buf = C.create_string_buffer(1024)
+    check(load().luw_dev_tuning_text(buf, 1024))
+    return buf.value.decode()
+
+
+def placement_info(handle):
+    """what luw_create's placement search did for a solver (luw_dev_placement_info)"""
+    n, tb, sec, kept = C.c_int(0), C.c_double(0.0), C.c_double(0.0), C.create_string_buffer(64)
+    check(load().luw_dev_placement_info(handle, C.byref(n), C.byref(tb), C.byref(sec), kept, 64))
+    return {"candidates_tried": n.value, "kept": kept.value.decode(), "probe_TBps": round(tb.value, 3), "create_s": round(sec.value, 3)}

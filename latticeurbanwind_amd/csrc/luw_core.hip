@@ -5,7 +5,6 @@
 //   luw_kernels_common.hpp  slot algebra, k_initialize (f_eq(rho,u) -> Esoteric-Pull store with t=1, FX/kernel.cpp:1370-1452)
 //   luw_kernels_step.hpp    k_stream_collide_s (1 cell per lane: FP32 product kernel, FP16C fallback, thermal lattice) and
 //                           k_stream_collide_p (FP16C product kernel: 2 cells per lane, packed FP32 collision)
-//   luw_kernels_vec.hpp     k_stream_collide_v (A/B variants: V cells per lane, aligned accesses + wave64 lane shifts)
 //   luw_kernels_aux.hpp     k_extract_fi / k_insert_fi (halo pack/unpack, FX/kernel.cpp:2241-2270), voxeliser, probe gather,
 //                           von-Karman inlet, statistics, codec self-check
 // This file: the host runtime (allocation and placement, launches, kernel choice) and the C-ABI.
@@ -14,7 +13,7 @@
 // array shifted by a lead pad so that the first owned cell of a row starts a 256-byte block (lead_alloc);
 // rho[Np], u[3][Np], flags[Np], F[3][Np] share the pitch.  Host mirrors keep the reference layout (pitch Nx).
 #include "luw_device.hpp"
-#include "../../include/luw_core.h"
+#include "../../include/luw_core_dev.h"
 
 #include <cmath>
 #include <cstdio>
@@ -28,13 +27,14 @@
 #include <algorithm>
 #include <memory>
 #include <dlfcn.h>
+#include <chrono>
 
 using namespace luw;
 
 #include "luw_kernels_common.hpp"
 #include "luw_kernels_step.hpp"
-#ifdef LUW_AB_KERNELS   // tools build only (make ab): A/B and measurement-only kernel variants; the product library has none of them
-#include "luw_kernels_vec.hpp"
+#ifdef LUW_AB_KERNELS   // tools build only (make ab; the header lives under tools/ab_kernels/): A/B and measurement-only kernel variants
+#include LUW_AB_KERNELS
 #endif
 #include "luw_kernels_aux.hpp"
 
@@ -47,6 +47,65 @@ static int fail(const int code, const std::string& msg) { g_last_error = msg; re
 	const hipError_t e_ = (expr); \
 	if(e_!=hipSuccess) return fail(LUW_ERR_DEVICE, std::string(#expr)+": "+hipGetErrorString(e_)); \
 } while(0)
+
+// ---------------------------------------------------------------- tuning table
+// Every knob the library takes from the environment, read ONCE into this table at first use (luw_dev_reload_tuning() reads it again: tests and A/B tools
+// that change the environment between two solvers of one process).  Nothing else in the library calls getenv, and no run / step path reads the
+// environment.  INTEGRATION.md section 5 lists each knob with its default and purpose; tests/test_capi_library.py holds the two lists together.
+struct Tuning {
+	size_t alloc_chunk = 1024ull<<20; // LUW_ALLOC = vmm:<MiB> (physical chunk size of lattice-sized arrays) | vmm:one (~0: one piece) | malloc (0: hipMalloc)
+	bool copy_staged = false;         // LUW_COPY_STAGED: host <-> device copies of every array through the staging buffer (test aid)
+	bool addr_row = false;            // LUW_ADDR_ROW: FP32 kernel in the row addressing form also where the flat form would do (test aid, same values)
+	bool pair_general = false;        // LUW_PAIR_GENERAL: FP16C kernels never take the force-free / uniform-force specialisations (test aid, same values)
+	bool fuse_stats = true;           // LUW_FUSE_STATS=0: sampled steps use the separate statistics kernel (A/B and test aid, same values)
+	uint64_t plane_skew = 0ull;       // LUW_PLANE_SKEW=<64-element blocks> behind each DDF plane (0: 513 for FP32, 33 for FP16C; study aid)
+	int placement_candidates = -1;    // LUW_TUNE_PLACEMENT=<n>: allocations of the DDF array luw_create may try (0 / 1: no search; default 4)
+	double placement_bar = 0.0;       // LUW_TUNE_FAST=<TB/s>: probe rate from which a placement is kept without further candidates (99: try all; test aid)
+	bool placement_verbose = false;   // LUW_TUNE_VERBOSE: print every candidate's probe time to stderr
+	bool vk_ahead = true;             // LUW_VK_AHEAD=0: von-Karman inlet evaluated in line instead of one step ahead on a side stream (A/B aid, same values)
+	bool voxelize_all = false;        // LUW_VOXELIZE_ALL_TRIANGLES: every voxeliser tile tests every triangle (test aid for the bins)
+	uint32_t x_shell = 0u;            // LUW_X_SHELL=<cells>: thickness of the x boundary slabs of a decomposed step (0: 128; A/B aid)
+	int group_transport = LUW_TRANSPORT_PEER; bool group_transport_bad = false; // LUW_GROUP_TRANSPORT = peer | staged | rccl (luw_group_create)
+	bool group_threads = false;       // LUW_GROUP_THREADS=1: one host thread per domain in luw_group_run
+#ifdef LUW_AB_KERNELS                 // tools build only
+	int ab_kernel = -1;               // LUW_KERNEL=<id>: overrides the kernel choice of callers that expose none
+	bool ab_pair_copy = false;        // LUW_PAIR_COPY: the pair kernel's memory path alone (no physics)
+#endif
+};
+static Tuning g_tuning;
+static std::atomic<bool> g_tuning_loaded{false};
+static void tuning_load() {
+	Tuning t;
+	auto on = [](const char* n) { return getenv(n)!=nullptr; };
+	auto off0 = [](const char* n) { const char* e = getenv(n); return e&&e[0]=='0'; };
+	if(const char* e = getenv("LUW_ALLOC")) {
+		if(strncmp(e, "malloc", 6)==0) t.alloc_chunk = 0u;
+		else if(strncmp(e, "vmm:one", 7)==0) t.alloc_chunk = ~(size_t)0u;
+		else if(strncmp(e, "vmm:", 4)==0) { const size_t v = (size_t)strtoull(e+4, nullptr, 10); if(v) t.alloc_chunk = v<<20; }
+	}
+	t.copy_staged = on("LUW_COPY_STAGED"); t.addr_row = on("LUW_ADDR_ROW"); t.pair_general = on("LUW_PAIR_GENERAL");
+	t.fuse_stats = !off0("LUW_FUSE_STATS");
+	if(const char* e = getenv("LUW_PLANE_SKEW")) t.plane_skew = strtoull(e, nullptr, 10);
+	if(const char* e = getenv("LUW_TUNE_PLACEMENT")) t.placement_candidates = atoi(e);
+	if(const char* e = getenv("LUW_TUNE_FAST")) t.placement_bar = atof(e);
+	t.placement_verbose = on("LUW_TUNE_VERBOSE");
+	t.vk_ahead = !off0("LUW_VK_AHEAD");
+	t.voxelize_all = on("LUW_VOXELIZE_ALL_TRIANGLES");
+	if(const char* e = getenv("LUW_X_SHELL")) t.x_shell = (uint32_t)strtoul(e, nullptr, 10);
+	if(const char* e = getenv("LUW_GROUP_TRANSPORT")) {
+		if(strcmp(e, "rccl")==0) t.group_transport = LUW_TRANSPORT_RCCL;
+		else if(strcmp(e, "staged")==0) t.group_transport = LUW_TRANSPORT_STAGED;
+		else if(strcmp(e, "peer")!=0&&e[0]) t.group_transport_bad = true;
+	}
+	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
+#ifdef LUW_AB_KERNELS
+	if(const char* e = getenv("LUW_KERNEL")) t.ab_kernel = atoi(e);
+	t.ab_pair_copy = on("LUW_PAIR_COPY");
+#endif
+	g_tuning = t;
+	g_tuning_loaded.store(true);
+}
+static const Tuning& tuning() { if(!g_tuning_loaded.load()) tuning_load(); return g_tuning; }
 
 // ---- floats as 9-significant-digit text.  The reference bakes its kernel constants into OpenCL source as decimal text and writes
 // VTK headers the same way (to_string(float), FX/utilities.hpp:2603-2634,2741-2750; used at FX/lbm.cpp:664,774,780): what the
@@ -101,14 +160,27 @@ struct DevBlock {
 	void* base = nullptr; size_t bytes = 0u;
 	std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk_bytes = 0u; // VMM only
 };
+// the mapped pieces of a block, in address order: (offset, length) of every hipMemMap call of dev_alloc
+static void dev_block_pieces(const DevBlock& b, const size_t mapped, std::vector<std::pair<size_t, size_t>>& out) {
+	out.clear();
+	for(size_t off=0u; off<mapped&&out.size()<b.chunks.size(); off+=b.chunk_bytes) out.emplace_back(off, std::min(b.chunk_bytes, mapped-off));
+}
+// Tear-down of a mapped block: every piece is unmapped with ITS OWN (address, length) -- hipMemUnmap takes one mapping, not a range of them.  Round 3 unmapped
+// the whole reserved range in one call (and ignored the return code): the pieces behind the first stayed mapped while their handles were released and the
+// address range freed, which is what made a release in the middle of luw_create crash a later one (tools/vmm_unmap_repro.hip shows both sequences).
+// The device is idle first: nothing in flight may still address the block.
 static void dev_free(DevBlock& b) {
 	if(!b.base) return;
+	(void)hipDeviceSynchronize();
 	if(b.chunks.empty()) (void)hipFree(b.base);
 	else {
-		(void)hipMemUnmap(b.base, b.bytes);
+		std::vector<std::pair<size_t, size_t>> pieces;
+		dev_block_pieces(b, b.bytes, pieces);
+		for(const auto& pc : pieces) (void)hipMemUnmap((char*)b.base+pc.first, pc.second);
 		for(auto& h : b.chunks) (void)hipMemRelease(h);
 		(void)hipMemAddressFree(b.base, b.bytes);
 	}
+	(void)hipGetLastError();
 	b = DevBlock{};
 }
 static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, const size_t vmm_chunk, const bool short_last = false) {
@@ -140,7 +212,9 @@ static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, c
 		e = hipMemSetAccess(b.base, total, &acc, 1u);
 	}
 	if(e!=hipSuccess) { // undo what was mapped
-		if(!b.chunks.empty()) (void)hipMemUnmap(b.base, mapped);
+		std::vector<std::pair<size_t, size_t>> pieces;
+		dev_block_pieces(b, mapped, pieces);
+		for(const auto& pc : pieces) (void)hipMemUnmap((char*)b.base+pc.first, pc.second);
 		for(auto& h : b.chunks) (void)hipMemRelease(h);
 		(void)hipMemAddressFree(b.base, total);
 		b = DevBlock{};
@@ -153,17 +227,7 @@ static hipError_t dev_alloc(DevBlock& b, const size_t bytes, const int device, c
 // physically contiguous pieces let the GPU's page tables use large fragments, and the 19 + 19 streams of a step stop
 // missing in the TLBs.  So arrays of at least 64 MiB are mapped from chunks (LUW_ALLOC=vmm:<chunk MiB>, default 1024);
 // LUW_ALLOC=malloc restores plain hipMalloc (and with it the placement search of tune_ddf_placement).
-static size_t alloc_vmm_chunk() {
-	static const size_t chunk = [] {
-		const char* e = getenv("LUW_ALLOC");
-		if(e&&strncmp(e, "malloc", 6)==0) return (size_t)0u;
-		size_t mib = 1024u;
-		if(e&&strncmp(e, "vmm:one", 7)==0) return ~(size_t)0u;     // one physical allocation per array (study aid)
-		if(e&&strncmp(e, "vmm:", 4)==0) { const size_t v = (size_t)strtoull(e+4, nullptr, 10); if(v) mib = v; }
-		return mib<<20;
-	}();
-	return chunk;
-}
+static size_t alloc_vmm_chunk() { return tuning().alloc_chunk; }
 
 struct luw_solver {
 	luw_config cfg;
@@ -194,6 +258,8 @@ struct luw_solver {
 	std::vector<DevBlock> raw; // device blocks behind the lattice-sized arrays (lead_alloc)
 	uint32_t gather_count = 0u; uint32_t* d_gather_cell = nullptr; float* d_gather_out = nullptr; // probe columns
 	void* d_stage = nullptr; size_t stage_bytes = 0u; // copy_pitched's staging buffer (chunk-mapped arrays)
+	// what luw_create's placement search did (luw_dev_placement_info): candidates probed, the kind kept, its probe rate, seconds spent in luw_create
+	int placement_tried = 0; std::string placement_kept = "default (no search)"; double placement_tbps = 0.0, create_seconds = 0.0;
 };
 
 // Lattice-sized device arrays start LEAD elements into their allocation, LEAD = 64 - halo_x: with the x pitch a multiple of
@@ -206,14 +272,13 @@ static hipError_t lead_alloc(luw_solver* s, void** base, const size_t elems, con
 	// arrays under 64 MiB: hipMalloc.  Larger ones: chunks of EXACTLY the configured size (1 GiB) -- measured: the same lattice on chunks of 0.93 GiB
 	// ("equal pieces, no waste") runs the step 8-15 % slower (1024x1024x256 FP32 7.30 vs 6.72 ms, FP16C 3.97 vs 3.45; profiles/r03_alloc_chunks_ab.txt) --
 	// and only the LAST chunk cut to the remainder, so that an array costs at most one allocation granule more than its size instead of up to a
-	// whole chunk (u, m2, avg_u of a 512^3 domain: 1.5 -> 2 GiB each before).  LUW_ALLOC_LAST=whole keeps a whole last chunk (A/B aid).
-	static const bool whole_last = getenv("LUW_ALLOC_LAST")&&strncmp(getenv("LUW_ALLOC_LAST"), "whole", 5)==0;
+	// whole chunk (u, m2, avg_u of a 512^3 domain: 1.5 -> 2 GiB each before).
 	size_t chunk = 0u;
 	if(total>=(64ull<<20)) {
 		const size_t cap = chunk_override ? *chunk_override : alloc_vmm_chunk(), mib2 = 2ull<<20;   // (override: tune_ddf_placement's candidates)
 		chunk = (cap==0u||cap==~(size_t)0u) ? cap : std::min<size_t>(cap, ((total+mib2-1u)/mib2)*mib2);
 	}
-	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk, !whole_last);
+	hipError_t e = dev_alloc(blk, total, s->cfg.device, chunk, true);
 	if(e!=hipSuccess&&chunk) { (void)hipGetLastError(); e = dev_alloc(blk, total, s->cfg.device, 0u); } // no VMM on this system: hipMalloc
 	if(e!=hipSuccess) return e;
 	e = hipMemsetAsync(blk.base, 0, total, s->stream); // padding / not-yet-uploaded memory must hold defined values
@@ -245,7 +310,7 @@ static int copy_pitched(void* dst, const void* src, const size_t elem, luw_solve
 	// ranges that span the chunks of a mapped array ("invalid argument"), and rows that are not a multiple of four bytes take a path
 	// that moves 0.06 GB/s (flags of a 514-cell-wide domain: 2.1 s instead of 3 ms) -- both go through the staging buffer.
 	const DevBlock* blk = block_of(s, to_device ? dst : src);
-	static const bool force_staged = getenv("LUW_COPY_STAGED")!=nullptr; // test aid: the staged path for every array
+	const bool force_staged = tuning().copy_staged; // test aid: the staged path for every array
 	if(!force_staged&&(!blk||blk->chunks.size()<=1u)&&((size_t)s->cfg.Nx*elem)%4u==0u) {
 		for(uint32_t c=0u; c<planes; c++) {
 			if(to_device) HIP_TRY(hipMemcpy2DAsync((char*)dst+(size_t)c*s->kp.Np*elem, (size_t)s->kp.Px*elem, (const char*)src+(size_t)c*s->N*elem,
@@ -431,10 +496,10 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise.  In-plane
 	// offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with its 2^32-byte planes
 	// still qualifies (largest offset 2^32 - 4).  LUW_ADDR_ROW: the row form also where the flat form would do (both are product code, same values)
-	static const bool force_row = getenv("LUW_ADDR_ROW")!=nullptr;
+	const bool force_row = tuning().addr_row;
 	k.flat = s->ddf_bytes==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*4ull<=(1ull<<32) && !force_row;
 	// FP16C, nothing can push the cells of this box: the instantiation without the force assembly (69 / 76 VGPRs).  LUW_PAIR_GENERAL: never (test aid)
-	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;
+	const bool general_only = tuning().pair_general;
 	k.noforce = s->ddf_bytes==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
 	if(s->d_gi&&!st) k.mode = 4; // thermal lattice on: the product kernel plus the D3Q7 cell update
 	// native arithmetic (FP16C, plain steps): one instantiation for every box
@@ -505,23 +570,19 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	const uint32_t nx = (b.x1-b.x0+1u)/2u;                         // an odd count only when the box ends at an odd Nx: the last lane owns one cell
 	const uint32_t bx = row_block(nx);
 	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
-	static const bool general_only = getenv("LUW_PAIR_GENERAL")!=nullptr;   // test aid: the general kernel also where a specialisation would do (same values)
+	const bool general_only = tuning().pair_general;   // test aid: the general kernel also where a specialisation would do (same values)
 	PairKey k{ 0, st!=nullptr, (st||general_only) ? PAIR_FORCE_ANY : box_force_mode(s, b), false, s->d_gi!=nullptr };
 	// PARK (luw_kernels_step.hpp): the lane's second set of values waits in LDS instead of in registers.  Measured interleaved on MI355X
 	// (profiles/r03_pair_park_ab.txt): it pays where the registers cost a wave of occupancy that matters -- the general kernel, 109 -> 91 VGPRs,
 	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
 	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256); the thermal variants always park.
-	// LUW_PAIR_PARK=<bit mask of force modes> overrides (bit 0 force-free, 1 uniform, 2 general; the first two exist in the tools build only).
-#ifndef LUW_PAIR_PARK_DEFAULT
-#define LUW_PAIR_PARK_DEFAULT (1u<<PAIR_FORCE_ANY)
-#endif
-	static const unsigned park_modes = getenv("LUW_PAIR_PARK") ? (unsigned)strtoul(getenv("LUW_PAIR_PARK"), nullptr, 0) : (unsigned)(LUW_PAIR_PARK_DEFAULT);
+	constexpr unsigned park_modes = 1u<<PAIR_FORCE_ANY;
 	k.park = k.thermal || (!st && (park_modes&(1u<<k.force))!=0u);
 	// native arithmetic: plain steps of the product kernel (a sampled step runs the exact kernel: its values differ in rounding only)
 	k.native = (s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u && !st;
 	if(k.native&&!k.thermal) k.park = k.force==PAIR_FORCE_ANY;
 #ifdef LUW_AB_KERNELS
-	static const bool copy_only = getenv("LUW_PAIR_COPY")!=nullptr;   // tools build, measurement aid: the kernel's memory path alone (no physics)
+	const bool copy_only = tuning().ab_pair_copy;   // tools build, measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only&&!st&&!k.thermal) k = PairKey{ 1, false, PAIR_FORCE_ANY, false, false };
 #endif
 	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal, (k.mode==0&&!k.stats) ? k.force : PAIR_FORCE_NONE) : 0u;
@@ -540,8 +601,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 // can a sampled step carry the Welford update itself?  Product kernels only (scalar / pair, no thermal lattice: its T statistics
 // stay with k_stats_accumulate); LUW_FUSE_STATS=0 keeps the separate kernel (A/B and test aid)
 static bool can_fuse_stats(const luw_solver* s) {
-	static const bool off = getenv("LUW_FUSE_STATS")!=nullptr && getenv("LUW_FUSE_STATS")[0]=='0';
-	return !off && !s->d_gi && (s->kernel==LUW_KERNEL_AUTO||s->kernel==LUW_KERNEL_SCALAR||s->kernel==LUW_KERNEL_PAIR);
+	return tuning().fuse_stats && !s->d_gi && (s->kernel==LUW_KERNEL_AUTO||s->kernel==LUW_KERNEL_SCALAR||s->kernel==LUW_KERNEL_PAIR);
 }
 static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
@@ -551,11 +611,9 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	uint32_t k = s->kernel;
 	// AUTO: the scalar kernel, except FP16C rows of at least one wave of pairs, which take the pair kernel (dword accesses, packed
 	// FP32 collision: 69.0k vs 67.2k MLUPS at 512^3, 63.1k vs 61.1k with Coriolis)
-	static const uint32_t pair_min = getenv("LUW_PAIR_MIN_ROW") ? (uint32_t)strtoul(getenv("LUW_PAIR_MIN_ROW"), nullptr, 10) : 128u; // A/B aid (round 2: 256)
+	constexpr uint32_t pair_min = 128u;   // (round 2: 256)
 	if(k==LUW_KERNEL_AUTO) k = (fp16 && b.x1-b.x0>=pair_min) ? LUW_KERNEL_PAIR : LUW_KERNEL_SCALAR;
-	// 0: the thermal lattice through the one-cell kernel only (round 2; A/B and test aid)
-	static const bool thermal_pair = !(getenv("LUW_THERMAL_PAIR")&&getenv("LUW_THERMAL_PAIR")[0]=='0');
-	if(s->d_gi&&(!fp16||!thermal_pair||st)) k = LUW_KERNEL_SCALAR; // FP32 / sampled steps: the thermal cell update of the one-cell kernel
+	if(s->d_gi&&(!fp16||st)) k = LUW_KERNEL_SCALAR; // FP32 / sampled steps: the thermal cell update of the one-cell kernel
 #ifdef LUW_AB_KERNELS
 	// the vector kernels assume rows that start on a 16-byte boundary at x = 0
 	if(s->kp.halo_x&&(k==LUW_KERNEL_VEC4||k==LUW_KERNEL_VEC2||k==LUW_KERNEL_VEC1)) k = LUW_KERNEL_SCALAR;
@@ -596,92 +654,85 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 	#undef LUW_TR
 }
 
-// Where the driver places the DDF array physically changes the step time of this 19-stream kernel by 10-14 % on MI355X: allocations of the same
-// size come out in classes that last for the life of the allocation (512^3 FP32: 3.3 or 3.75 ms per step; tools/placement_probe.py,
-// tools/chunk_study.sh), and WHICH kind of allocation is of the fast class depends on the box.  Large solvers therefore time the real kernel on
-// their DDF array (zero DDFs = rest state, flags 0 = all fluid: a valid, full-cost step) and, while it is not of the fast class, try another
-// allocation.  LUW_TUNE_PLACEMENT=<candidates> (0/1 = off), LUW_TUNE_FAST=<TB/s> (the bar), LUW_TUNE_VERBOSE=1; skipped when the device is short of
-// memory or other solvers already live on it (several ranks / domains sharing one GPU: the test set-ups).
+// Where the driver places the DDF array physically changes the step time of this 19-stream kernel by 10-14 % on MI355X: allocations of the same size come
+// out in classes that last for the life of the allocation (512^3 FP32: 3.3 or 3.75 ms per step; tools/placement_probe.py, tools/chunk_study.sh), and WHICH
+// kind of allocation is of the fast class depends on the box: 1 GiB chunks on most, 2 GiB chunks or a plain hipMalloc on others
+// (profiles/r03_chunk_study_slow_box.txt).  Large solvers therefore time the real kernel on their DDF array -- the box the step launches (non-halo cells),
+// zero DDFs = rest state, flags 0 = all fluid: a valid, full-cost step -- and, while the rate is under the bar of the fast class, try the OTHER kinds, once
+// each: 2 GiB chunks, hipMalloc, 512 MiB chunks.  Bounded: at most three further candidates, ONE extra array alive at a time, every loser released before
+// the next candidate is mapped and nothing of the search left when luw_create returns (placement_kept / placement_tbps / placement_tried say what
+// happened; bench.py prints them). Skipped for small lattices, for planes of 2 GiB and more (1024^3 runs alike on every kind,
+// profiles/r02_placement_study.txt),
+// when the device has no room for a second DDF array, and when the device is shared: other solvers of this process live on it (g_live_solvers), or the
+// caller says so (luw_group_create for devices that host several domains: thread-local g_device_is_shared; rank processes sharing one GPU set
+// LUW_TUNE_PLACEMENT=0) -- concurrent probes would time each other.
 static std::atomic<int> g_live_solvers[64];
+static thread_local bool g_device_is_shared = false;
+static const char* dev_block_kind(const DevBlock& b) {
+	if(b.chunks.empty()) return "hipMalloc";
+	return b.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : b.chunk_bytes>=(1024ull<<20) ? "1 GiB chunks" : b.chunk_bytes>=(512ull<<20) ? "512 MiB chunks"
+		: "chunks under 512 MiB";
+}
 static int tune_ddf_placement(luw_solver* s) {
+	const Tuning& T = tuning();
 	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
-	const char* env = getenv("LUW_TUNE_PLACEMENT");
-	// hipMalloc'ed arrays (LUW_ALLOC=malloc): up to 6 candidates of the same kind (round 1).  Chunk-mapped arrays (the default): on most boxes 1 GiB
-	// chunks are the fast class every time, but there are boxes on which the same binary runs the 512 MiB / 1 GiB-plane lattices 12-14 % slower on them
-	// while 2 GiB chunks or a plain hipMalloc are fast (profiles/r03_chunk_study_slow_box.txt: 512^3 FP32 3.76 / 3.39 ms on 1 GiB chunks / hipMalloc,
-	// 1024x1024x256 7.79 / 6.82 ms on 1 GiB / 2 GiB chunks) -- so a first mapping that is not of the fast class is followed by those alternatives.
-	// A chunk-mapped loser is NOT released before the solver goes (unmapping and releasing a mapping here left this ROCm's runtime in a state in which
-	// the solver's final dev_free crashed); it costs its memory until then, and the search stops when the device has no room for that.
 	const bool mapped = !s->raw.front().chunks.empty();
-	// chunk sizes tried behind the default (0: hipMalloc).  Which KIND is fast differs from box to box, and on some boxes from draw to draw: every
-	// candidate is one more draw, and the fastest stays
-	constexpr int NALT = 6;
-	static size_t alternatives[NALT] = { 2048ull<<20, 512ull<<20, 0u, 256ull<<20, 0u, 2048ull<<20 };
-	if(const char* a = getenv("LUW_TUNE_ALTS")) { // study aid: "2048,512,0" (MiB; repeated cyclically)
-		unsigned long long v[3] = { 2048ull, 512ull, 0ull };
-		sscanf(a, "%llu,%llu,%llu", &v[0], &v[1], &v[2]);
-		for(int k=0; k<NALT; k++) alternatives[k] = (size_t)v[k%3]<<20;
-	}
-	const int candidates = env ? atoi(env) : (mapped ? 1+NALT : 6);
-	if(bytes<(1ull<<30)||candidates<2) return LUW_OK;
-	// (planes of 2 GiB and more -- 1024^3 -- run alike on every kind of piece, profiles/r02_placement_study.txt: no search, no 80 GB candidates)
-	if(mapped&&!env&&s->kp.Np*s->ddf_bytes>(3ull<<29)) return LUW_OK;
-	if(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1) return LUW_OK; // this device is shared with other solvers of this process
-	// chunk-mapped arrays: ONE search per process and device (the first large solver: a bench run, a rank, a deck's first case).  A second search in
-	// a process that had released the candidates of a first one aborted inside the runtime (tests/test_gpu_tile_full.py under LUW_TUNE_FAST=99)
-	static std::atomic<bool> searched[64];
-	if(mapped&&s->cfg.device<64&&searched[s->cfg.device].exchange(true)) return LUW_OK;
-	const Box whole = { 0u, s->cfg.Nx, 0u, s->cfg.Ny, 0u, s->cfg.Nz };
+	s->placement_kept = std::string(dev_block_kind(s->raw.front()))+" (no search)";
+	constexpr int NALT = 3;
+	const size_t alternatives[NALT] = { 2048ull<<20, 0u, 512ull<<20 };   // chunk sizes behind the default's 1 GiB (0: hipMalloc)
+	const int candidates = std::min(T.placement_candidates>=0 ? T.placement_candidates : 1+NALT, 1+NALT);
+	if(bytes<(1ull<<30)||candidates<2||!mapped) return LUW_OK;
+	if(T.placement_candidates<0&&s->kp.Np*s->ddf_bytes>(3ull<<29)) return LUW_OK;
+	if(g_device_is_shared||(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1)) return LUW_OK;
+	// the box a step launches: every non-halo cell (the FP16C pair kernel needs its pairs to start at the first owned cell of an x-split row)
+	const Box box = { s->kp.halo_x, s->cfg.Nx-s->kp.halo_x, s->kp.halo_y, s->cfg.Ny-s->kp.halo_y, s->kp.halo_z, s->cfg.Nz-s->kp.halo_z };
 	struct Events { hipEvent_t e0 = nullptr, e1 = nullptr; ~Events() { if(e0) (void)hipEventDestroy(e0); if(e1) (void)hipEventDestroy(e1); } } ev;
 	HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
 	auto step_ms = [&](float& ms) -> int { // two steps (both parities) after one untimed
 		struct Restore { luw_solver* s; ~Restore() { s->initialized = false; s->t = 0ull; } } restore{ s };
 		s->initialized = true; s->t = 0ull;
-		if(int e = launch_stream_collide(s, whole, 0)) return e;
+		if(int e = launch_stream_collide(s, box, 0)) return e;
 		s->t = 1ull;
 		HIP_TRY(hipEventRecord(ev.e0, s->stream));
-		if(int e = launch_stream_collide(s, whole, 0)) return e;
+		if(int e = launch_stream_collide(s, box, 0)) return e;
 		s->t = 2ull;
-		if(int e = launch_stream_collide(s, whole, 0)) return e;
+		if(int e = launch_stream_collide(s, box, 0)) return e;
 		HIP_TRY(hipEventRecord(ev.e1, s->stream));
 		HIP_TRY(hipEventSynchronize(ev.e1));
 		HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
 		return LUW_OK;
 	};
-	// a placement of the fast class moves this many algorithmic bytes per second through the probe (FP32 153, FP16C 77 B per update; the probe's lattice
-	// is all fluid at rest).  LUW_TUNE_FAST=<TB/s> overrides the bar (LUW_TUNE_FAST=99: every candidate is tried, test aid)
-	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)
-		+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*(double)s->cfg.Nx*(double)s->cfg.Ny*(double)s->cfg.Nz;
-	// (FP16C with zones: the general kernel is VALU-bound)
-	const double bar = getenv("LUW_TUNE_FAST") ? atof(getenv("LUW_TUNE_FAST"))*1e12
-		: (s->ddf_bytes==4u ? 6.25e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
-	auto fast_class = [&](const float ms) { return probe_bytes/((double)ms*1e-3)>=bar; };
+	// a placement of the fast class moves this many algorithmic bytes per second through the probe (FP32 153, FP16C 77 B per update, + the thermal planes;
+	// FP16C with zones: the general kernel is VALU-bound).  LUW_TUNE_FAST=<TB/s> overrides the bar (99: every candidate is tried)
+	const double cells = (double)(box.x1-box.x0)*(double)(box.y1-box.y0)*(double)(box.z1-box.z0);
+	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*cells;
+	const double bar = T.placement_bar>0.0 ? T.placement_bar*1e12 : (s->ddf_bytes==4u ? 6.25e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
+	auto rate = [&](const float ms) { return probe_bytes/((double)ms*1e-3); };
 	float best_ms = 0.0f;
 	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
 	if(int e = step_ms(best_ms)) return e;
-	const bool verbose = getenv("LUW_TUNE_VERBOSE")!=nullptr;
-	if(verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", mapped ? "1 GiB chunks" : "hipMalloc", best_ms,
-		probe_bytes/best_ms*1e-9);
-	for(int k=1; k<candidates&&!fast_class(best_ms); k++) {
-		if(mapped&&k>NALT) break;
+	s->placement_tried = 1;
+	if(T.placement_verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", dev_block_kind(s->raw.front()), best_ms,
+		rate(best_ms)*1e-12);
+	for(int k=1; k<candidates&&rate(best_ms)<bar; k++) {
 		size_t free_b = 0u, total_b = 0u;
 		// room for ONE more array plus what the run may still allocate (statistics: 32 B per cell, staging, halo buffers)
 		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+40ull*s->kp.Np+(2ull<<30)) break;
 		void* fi = nullptr;
-		if(lead_alloc(s, &fi, elems, s->ddf_bytes, mapped ? &alternatives[k-1] : nullptr)!=hipSuccess) { (void)hipGetLastError(); break; }
+		if(lead_alloc(s, &fi, elems, s->ddf_bytes, &alternatives[k-1])!=hipSuccess) { (void)hipGetLastError(); break; }
 		DevBlock cand = std::move(s->raw.back()); s->raw.pop_back();
 		void* const old_fi = s->d_fi;
 		s->d_fi = fi;
 		float ms = 0.0f;
-		if(int e = step_ms(ms)) { s->d_fi = old_fi; s->raw.push_back(std::move(cand)); return e; }
-		if(verbose) fprintf(stderr, "luw: placement candidate %d (%s): %.3f ms per 2 steps = %.2f TB/s (best so far %.3f)\n", k,
-			cand.chunks.empty() ? "hipMalloc" : cand.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : cand.chunk_bytes>=(512ull<<20) ? "512 MiB chunks"
-				: "256 MiB chunks", ms, probe_bytes/ms*1e-9, best_ms);
+		if(int e = step_ms(ms)) { s->d_fi = old_fi; dev_free(cand); return e; }
+		s->placement_tried++;
+		if(T.placement_verbose) fprintf(stderr, "luw: placement candidate %d (%s): %.3f ms per 2 steps = %.2f TB/s (best so far %.3f ms)\n", k,
+			dev_block_kind(cand), ms, rate(ms)*1e-12, best_ms);
 		if(ms<best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
 		else s->d_fi = old_fi;
-		if(cand.chunks.empty()) dev_free(cand);                       // a hipMalloc'ed loser goes at once ...
-		else s->raw.push_back(std::move(cand));                       // ... a mapped one with the solver (see above)
+		dev_free(cand);                                                   // the loser goes before the next candidate comes
 	}
+	s->placement_kept = dev_block_kind(s->raw.front()); s->placement_tbps = rate(best_ms)*1e-12;
 	// the probe steps left zeros, but be explicit
 	HIP_TRY(hipMemsetAsync(s->raw.front().base, 0, std::min(s->raw.front().bytes, bytes+64u*s->ddf_bytes), s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -763,6 +814,7 @@ void luw_destroy(luw_solver* s) {
 int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(!cfg||!out) return fail(LUW_ERR_INVALID, "luw_create: null argument");
 	*out = nullptr;
+	const auto t_create = std::chrono::steady_clock::now();
 	if(cfg->struct_size!=sizeof(luw_config)) return fail(LUW_ERR_INVALID, "luw_create: luw_config size mismatch (ABI)");
 	if((uint64_t)cfg->Nx*cfg->Ny*cfg->Nz==0ull) return fail(LUW_ERR_INVALID, "Grid point number is 0."); // FX/lbm.cpp:1123
 	if(cfg->Dx*cfg->Dy*cfg->Dz==0u) return fail(LUW_ERR_INVALID, "You specified 0 LBM grid domains."); // FX/lbm.cpp:1124
@@ -783,7 +835,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	// worse from 385 on some lattices; FP32 with 33 blocks (8 KiB, the round-1 value) depends on the GPU it lands on -- 512^3 3.30 / 3.45 /
 	// 3.64 ms and 1024x512x256 3.48 / 3.76 ms on three boxes -- while 513 blocks (128 KiB + 256 B) gave 3.28-3.30 and 3.31-3.37 ms on all of
 	// them (1024x1024x256: 6.61-6.75 ms either way).  LUW_PLANE_SKEW=<blocks> overrides (study aid).
-	static const uint64_t skew_env = getenv("LUW_PLANE_SKEW") ? strtoull(getenv("LUW_PLANE_SKEW"), nullptr, 10) : 0ull;
+	const uint64_t skew_env = tuning().plane_skew;
 	const uint64_t skew_blocks = skew_env ? skew_env : cfg->ddf_format==LUW_DDF_FP16C ? 33ull : 513ull;
 	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz+64ull*skew_blocks;
 	if(Np>=(1ull<<32)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^32 (padded) cells per domain are not supported (32-bit cell indices)");
@@ -800,7 +852,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	s->kernel = cfg->kernel;
 #ifdef LUW_AB_KERNELS
 	// tools build: overrides the kernel choice of callers that expose none (the deck driver)
-	if(const char* ke = getenv("LUW_KERNEL")) s->kernel = (uint32_t)atoi(ke);
+	if(tuning().ab_kernel>=0) s->kernel = (uint32_t)tuning().ab_kernel;
 #endif
 	KParams& k = s->kp;
 	memset(&k, 0, sizeof(k));
@@ -881,6 +933,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	}
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if(int e = tune_ddf_placement(s)) { luw_destroy(s); return e; } // last: the probe steps run the complete kernel (nudging / sponge tables included)
+	s->create_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_create).count();
 	*out = s;
 	return LUW_OK;
 }
@@ -1015,7 +1068,7 @@ int luw_voxelize_mesh(luw_solver* s, uint32_t triangle_number, const float* p0, 
 static int voxelize_launch(const VoxGrid& vg, uint8_t* d_flags, const float* d_u, const uint8_t flag, const uint32_t ntri, const float* p0, const float* p1,
 	const float* p2, const float* const d[3], const float* pmin, const float* pmax, hipStream_t st) {
 	const uint32_t tx = (vg.Nx+VOX_TILE-1u)/VOX_TILE, ty = (vg.Ny+VOX_TILE-1u)/VOX_TILE;
-	const bool brute = getenv("LUW_VOXELIZE_ALL_TRIANGLES")!=nullptr; // test aid: every tile sees every triangle
+	const bool brute = tuning().voxelize_all; // test aid: every tile sees every triangle
 	std::vector<uint32_t> start((size_t)tx*ty+1u, 0u), tri;
 	auto range = [&](const uint32_t i, int& a0, int& a1, int& b0, int& b1) {
 		if(brute) { a0 = 0; a1 = (int)tx-1; b0 = 0; b1 = (int)ty-1; return; }
@@ -1168,7 +1221,7 @@ int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count
 		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocating / uploading the inlet tables failed");
 	}
 	s->vk_P = (uint32_t)P; s->vk_M = (uint32_t)mode_count; s->vk_stride = update_stride>1 ? update_stride : 1; s->vk_interp = stride_interpolation!=0;
-	static const bool ahead = !(getenv("LUW_VK_AHEAD")&&getenv("LUW_VK_AHEAD")[0]=='0'); // 0: evaluate in line before every step (A/B and test aid)
+	const bool ahead = tuning().vk_ahead; // LUW_VK_AHEAD=0: evaluate in line before every step (A/B and test aid)
 	if(ahead) {
 		bool ok = hipMalloc((void**)&s->d_vk_val[0], 3ull*P*4u)==hipSuccess&&hipMalloc((void**)&s->d_vk_val[1], 3ull*P*4u)==hipSuccess;
 		if(ok&&!s->vk_stream) {
@@ -1498,6 +1551,29 @@ int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, 
 	if(int e = set_device(s)) return e;
 	launch_transfer<true, true>(s, direction, const_cast<void*>(buf_p), const_cast<void*>(buf_m));
 	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+
+// ---- include/luw_core_dev.h: measurement and test entry points
+int luw_dev_reload_tuning(void) { tuning_load(); return LUW_OK; }
+int luw_dev_tuning_text(char* text, uint64_t size) {
+	if(!text||size<64u) return fail(LUW_ERR_INVALID, "luw_dev_tuning_text: needs a buffer");
+	const Tuning& t = tuning();
+	const std::string alloc = t.alloc_chunk==0u ? "malloc" : t.alloc_chunk==~(size_t)0u ? "vmm:one" : "vmm:"+std::to_string(t.alloc_chunk>>20);
+	snprintf(text, (size_t)size,
+		"LUW_ALLOC=%s LUW_COPY_STAGED=%d LUW_ADDR_ROW=%d LUW_PAIR_GENERAL=%d LUW_FUSE_STATS=%d LUW_PLANE_SKEW=%llu LUW_TUNE_PLACEMENT=%d "
+		"LUW_TUNE_FAST=%g LUW_TUNE_VERBOSE=%d LUW_VK_AHEAD=%d LUW_VOXELIZE_ALL_TRIANGLES=%d LUW_X_SHELL=%u LUW_GROUP_TRANSPORT=%s LUW_GROUP_THREADS=%d",
+		alloc.c_str(), (int)t.copy_staged, (int)t.addr_row, (int)t.pair_general, (int)t.fuse_stats, (unsigned long long)t.plane_skew, t.placement_candidates,
+		t.placement_bar, (int)t.placement_verbose, (int)t.vk_ahead, (int)t.voxelize_all, t.x_shell,
+		t.group_transport==LUW_TRANSPORT_RCCL ? "rccl" : t.group_transport==LUW_TRANSPORT_STAGED ? "staged" : "peer", (int)t.group_threads);
+	return LUW_OK;
+}
+int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* probe_TBps, double* create_seconds, char* kept, uint64_t kept_size) {
+	if(!s) return fail(LUW_ERR_INVALID, "luw_dev_placement_info: null solver");
+	if(candidates_tried) *candidates_tried = s->placement_tried;
+	if(probe_TBps) *probe_TBps = s->placement_tbps;
+	if(create_seconds) *create_seconds = s->create_seconds;
+	if(kept&&kept_size) snprintf(kept, (size_t)kept_size, "%s", s->placement_kept.c_str());
 	return LUW_OK;
 }
 

@@ -56,9 +56,8 @@ struct luw_group {
 // which narrower slabs would leave to the one-cell kernel; FP32: 16 / 32-cell slabs are slower, 64 / 128 / 256 equal within the spread between
 // fresh processes, profiles/r03_ab_rank_shape_xshell.txt); LUW_X_SHELL overrides (A/B aid)
 static uint32_t group_x_shell(const luw_group* g) {
-	static const uint32_t env = getenv("LUW_X_SHELL") ? (uint32_t)strtoul(getenv("LUW_X_SHELL"), nullptr, 10) : 0u;
 	(void)g;
-	return env ? env : 128u;
+	return tuning().x_shell ? tuning().x_shell : 128u;
 }
 
 // ---- the schedule of ONE domain's share of a decomposed step, shared by both hosts: luw_group_* (all domains in this process) and the one-process-per-GPU
@@ -461,7 +460,7 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.assign(2u*steps, nullptr); for(auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
 	// Default: ONE enqueueing thread (measured with eight domains on one device: 44 us per domain and step, i.e. 0.36 ms per step for eight --
 	// well inside a 1.9 ms FP16C step; profiles/r02_group_one_gpu.txt).  LUW_GROUP_THREADS=1 gives every domain its own host thread.
-	const bool threaded = getenv("LUW_GROUP_THREADS")&&getenv("LUW_GROUP_THREADS")[0]=='1'; // read per call: one process can A/B both
+	const bool threaded = tuning().group_threads;
 	// a call of a step or two (probe windows) is not worth starting threads for; RCCL's group calls are issued by ONE thread
 	if(threaded&&steps>=4ull&&g->transport!=LUW_TRANSPORT_RCCL) {
 		GroupThreads T; T.error.assign(g->dom.size(), std::string());
@@ -652,14 +651,10 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 			(void)hipGetLastError();
 		}
 	}
-	// transport: peer stores where the devices allow them (default), LUW_GROUP_TRANSPORT=staged the copy path everywhere (LUW_GROUP_STAGED:
-	// the same, older spelling), LUW_GROUP_TRANSPORT=rccl grouped ncclSend / ncclRecv.  Read at every create, so one process can A/B them.
-	{
-		const char* tr = getenv("LUW_GROUP_TRANSPORT");
-		if(tr&&strcmp(tr, "rccl")==0) g->transport = LUW_TRANSPORT_RCCL;
-		else if((tr&&strcmp(tr, "staged")==0)||getenv("LUW_GROUP_STAGED")) g->transport = LUW_TRANSPORT_STAGED;
-		else if(tr&&strcmp(tr, "peer")!=0&&tr[0]) return fail(LUW_ERR_INVALID, "luw_group_create: LUW_GROUP_TRANSPORT must be peer, staged or rccl");
-	}
+	// transport: peer stores where the devices allow them (default), LUW_GROUP_TRANSPORT=staged the copy path everywhere, LUW_GROUP_TRANSPORT=rccl grouped
+	// ncclSend / ncclRecv (tuning table)
+	if(tuning().group_transport_bad) return fail(LUW_ERR_INVALID, "luw_group_create: LUW_GROUP_TRANSPORT must be peer, staged or rccl");
+	g->transport = tuning().group_transport;
 	if(g->transport!=LUW_TRANSPORT_PEER) for(auto& row : g->peer) std::fill(row.begin(), row.end(), 0); // faces through send buffers
 	if(g->transport==LUW_TRANSPORT_RCCL&&n>1u) GROUP_TRY(group_rccl_setup(g.get())); // connections before the lattices (cf. TorchDistTransport.warm_up)
 	// Streams and halo buffers BEFORE the lattices: every long-lived small allocation is in place before the large arrays and the
@@ -699,7 +694,14 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 		c.Nx = d.lN[0]; c.Ny = d.lN[1]; c.Nz = d.lN[2];
 		c.Ox = d.O[0]; c.Oy = d.O[1]; c.Oz = d.O[2];
 		c.device = d.device;
-		GROUP_TRY(luw_create(&c, &d.s));
+		// a device that hosts several domains of this group (test set-ups: eight domains on one GPU) is shared: no placement search there -- the first domain
+		// would search alone, keep the memory the later ones need and be timed against nothing they run beside
+		size_t on_device = 0u;
+		for(const GroupDomain& o : g->dom) if(o.device==d.device) on_device++;
+		g_device_is_shared = on_device>1u;
+		const int rc = luw_create(&c, &d.s);
+		g_device_is_shared = false;
+		GROUP_TRY(rc);
 		group_boxes(g.get(), d);
 	}
 	*out = g.release();

@@ -6,13 +6,15 @@
 // options after the deck path (the reference ignores extra arguments with a warning, FX/setup.cpp:2768-2773); false: usage error
 static bool parse_command_line(const int argc, char** argv, Config& c) {
 	if(argc<2) {
-		std::fprintf(stderr, "usage: %s <deck.luwpf|.luwdg> [--ddf fp32|fp16c] [--device N] [--dry-run] [--dump-setup FILE]\n", argv[0]);
+		std::fprintf(stderr, "usage: %s <deck.luwpf|.luwdg> [--ddf fp32|fp16c] [--arith exact|native] [--device N] [--dry-run] [--dump-setup FILE]\n", argv[0]);
 		return false;
 	}
 	c.deck_path = argv[1];
 	for(int i=2; i<argc; i++) {
 		const string a = argv[i];
 		if(a=="--ddf"&&i+1<argc) { const string v = argv[++i]; c.fp16c = v!="fp32"; }
+		// FP16C collision in the hardware's own arithmetic (LUW_OPT_NATIVE_ARITH); default: the bit-exact kernels
+		else if(a=="--arith"&&i+1<argc) { const string v = argv[++i]; c.native_arith = v=="native"; }
 		else if(a=="--device"&&i+1<argc) c.device = std::atoi(argv[++i]);
 		else if(a=="--dry-run") c.dry_run = true;
 		else if(a=="--sizing-only") { c.dry_run = true; c.sizing_only = true; } // stop after the derived numbers (no lattice-sized host arrays)

@@ -58,6 +58,7 @@ inline void Driver::print_parameters() const {
 		println("| Probes Window  | "+alignr(57u, w)+" |");
 	}
 	println("| DDF storage     | "+alignr(57u, c.fp16c ? string("FP16C (as the shipped reference build)") : string("FP32"))+" |");
+	if(c.fp16c&&c.native_arith) println("| Arithmetic      | "+alignr(57u, string("native (v_rcp / v_sqrt, free contraction; --arith exact)"))+" |");
 }
 
 inline void Driver::size_lattice() { // FX/setup.cpp:3552-3568
@@ -167,7 +168,7 @@ inline void Driver::set_units_and_forcing() {
 	println("| Info: Unit Conversion: 1 cell = "+to_string_fd(1000.0f*units.si_x(1.0f), 3u)+" mm, 1 s = "+to_string_u(units.t(1.0f))+" time steps");
 	u_scale = lbm_ref_u/si_ref_u;
 	lbm_nu = units.nu(si_nu);
-	G.fp16c = c.fp16c; G.device = c.device; G.devices = c.devices; G.kernel = c.kernel;
+	G.fp16c = c.fp16c; G.native_arith = c.native_arith; G.device = c.device; G.devices = c.devices; G.kernel = c.kernel;
 	if(c.nwp_mode) {
 		println("| SI Reference U  | "+alignl(7u, fmtf(si_ref_u))+alignl(50u, "m/s")+" |");
 		println("| LBM Reference U | "+alignl(7u, fmtf(lbm_ref_u))+alignl(50u, "(Nondimensionalized)")+" |");

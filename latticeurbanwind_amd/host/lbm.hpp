@@ -43,6 +43,7 @@ struct SolverGlobals {
 	int buffer_nudge_vertical = 0;
 	bool top_sponge_active = false; int sponge_n_cells = 1; float sponge_inv_tau_lbmu = 0.0f;
 	bool fp16c = false;          // #define FP16C
+	bool native_arith = false;   // LUW_OPT_NATIVE_ARITH (FP16C collision in the hardware's own arithmetic, like the reference's -cl-mad-enable build)
 	bool temperature = false;    // #define TEMPERATURE: the alpha passed to the constructor takes effect (thermal D3Q7 lattice, lbm.T)
 	bool force_field = false;    // #define FORCE_FIELD: allocate lbm.F (LUW never writes it)
 	int device = 0;              // first HIP device; domain d runs on device + d unless `devices` says otherwise
@@ -75,7 +76,7 @@ class LBM {
 		c.Nx = Nx; c.Ny = Ny; c.Nz = Nz; c.Dx = Dx; c.Dy = Dy; c.Dz = Dz;
 		c.nu = nu; c.fx = fx; c.fy = fy; c.fz = fz;
 		c.ddf_format = G.fp16c ? LUW_DDF_FP16C : LUW_DDF_FP32;
-		c.options = (G.force_field ? LUW_OPT_FORCE_FIELD : 0u)|(G.temperature ? LUW_OPT_TEMPERATURE : 0u);
+		c.options = (G.force_field ? LUW_OPT_FORCE_FIELD : 0u)|(G.temperature ? LUW_OPT_TEMPERATURE : 0u)|(G.native_arith ? LUW_OPT_NATIVE_ARITH : 0u);
 		c.alpha = G.temperature ? alpha : 0.0f;
 		c.buffer_nudging_active = G.buffer_nudging_active; c.buffer_n_cells = (uint32_t)G.buffer_n_cells; c.buffer_inv_tau_lbmu = G.buffer_inv_tau_lbmu;
 		c.buffer_nudge_vertical = G.buffer_nudge_vertical; c.buffer_downstream_face_id = G.buffer_downstream_face_id;

@@ -65,3 +65,35 @@ def thermal_state(flags, gN, seed=5):
     T = np.ones(f.size, np.float32)
     T[pick] = (1.0 + 0.05 * rng.standard_normal(int(pick.sum()))).astype(np.float32)
     return f, T
+
+
+# ---- tolerance gates tied to what was observed
+# The distance of this path from the REAL reference's fields is whatever the reference's own (not bit-defined) arithmetic leaves: 0.5-1.3e-7 with FP32 DDFs,
+# 0.3-3e-5 after 64 LES steps with FP16C storage.  Class-level ceilings alone (1e-6 / 1e-4) would let a regression of an order of
+# magnitude pass, so every comparison against a reference fixture is ALSO held to twice the value recorded in tests/golden/observed_rmse.json (the product
+# equals the CPU oracle bit for bit, so the recorded values reproduce exactly).  LUW_RECORD_RMSE=<file>: append what is observed instead (new fixtures).
+import json as _json
+import os as _os
+
+_OBSERVED = None
+
+
+def observed_table():
+    global _OBSERVED
+    if _OBSERVED is None:
+        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "observed_rmse.json")
+        _OBSERVED = _json.load(open(path)) if _os.path.exists(path) else {}
+    return _OBSERVED
+
+
+def check_gate(key, value, ceiling, what="u RMSE"):
+    """value < ceiling (the class-level gate) and value <= 2 x the recorded observation of `key`"""
+    rec = _os.environ.get("LUW_RECORD_RMSE")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(_json.dumps({key: value}) + "\n")
+    assert value < ceiling, "%s %.3e (%s) above the ceiling %.1e" % (what, value, key, ceiling)
+    seen = observed_table().get(key)
+    if seen is not None and not rec:
+        assert value <= 2.0 * seen + 1e-12, "%s %.3e (%s) is more than twice the recorded %.3e" % (what, value, key, seen)
+    return value

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    hdr = open(os.path.join(ROOT, "include", "luw_core.h")).read()
+def declared_functions(header="luw_core.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(luw_[a-z_A-Z0-9]+)\s*\(", hdr)))
 
@@ -20,10 +20,45 @@ def test_library_exports_every_declared_symbol(luw):
     L = capi.load()
     names = declared_functions()
     assert len(names) >= 25
-    for n in names:
+    for n in names + declared_functions("luw_core_dev.h"):
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.SYMBOLS) == names
-    assert L.luw_abi_version() == 4
+    assert sorted(capi.DEV_SYMBOLS) == declared_functions("luw_core_dev.h")
+    assert L.luw_abi_version() == 5
+
+
+def test_product_header_is_the_boundary_only():
+    """include/luw_core.h names the three product kernels and nothing of the lab: A/B kernel ids, timed runs, self-checks and raw DDF access live in
+    include/luw_core_dev.h; the product sources carry no A/B kernel file"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "luw_core.h")).read(), flags=re.S)
+    assert sorted(re.findall(r"#define (LUW_KERNEL_\w+)", hdr)) == ["LUW_KERNEL_AUTO", "LUW_KERNEL_PAIR", "LUW_KERNEL_SCALAR"]
+    for lab in ("luw_run_timed", "luw_selfcheck", "luw_download_fi", "luw_dev_"):
+        assert lab not in hdr, lab
+    assert not os.path.exists(os.path.join(ROOT, "latticeurbanwind_amd", "csrc", "luw_kernels_vec.hpp"))
+
+
+def test_environment_knobs_are_the_documented_ones(luw):
+    """the library reads its environment in ONE place (the tuning table of luw_core.hip); the names in the binary, the names the table prints and the
+    names INTEGRATION.md documents are the same list"""
+    import subprocess
+    from latticeurbanwind_amd import capi
+    so = os.path.join(ROOT, "latticeurbanwind_amd", "csrc", "libluw_core.so")
+    strings = subprocess.run(["strings", so], capture_output=True, text=True).stdout
+    in_binary = sorted(set(re.findall(r"^(LUW_[A-Z_0-9]+)$", strings, flags=re.M)))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## 6. Environment knobs"):doc.index("### Other hosts")]
+    documented = sorted(set(re.findall(r"^\| `(LUW_[A-Z_0-9]+)", table, flags=re.M)))
+    assert in_binary == documented, (in_binary, documented)
+    src = "".join(open(os.path.join(ROOT, "latticeurbanwind_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "latticeurbanwind_amd", "csrc"))
+        if f.endswith((".hip", ".hpp")))
+    calls = re.findall(r"getenv\(", src)
+    loader = src[src.index("static void tuning_load()"):src.index("static const Tuning& tuning()")]
+    assert len(calls) == len(re.findall(r"getenv\(", loader)), "getenv outside the tuning table"
+    try:
+        printed = sorted(kv.split("=")[0] for kv in capi.tuning_text().split())
+    except capi.LuwError:
+        printed = None
+    assert printed is None or printed == documented
 
 
 def test_config_struct_layout_matches_header(luw):

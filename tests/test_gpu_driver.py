@@ -124,16 +124,15 @@ def test_driver_files_vs_real_reference_files(luw, tmp_path, case, ddf, fixture)
     def rmse(a, b):
         d = ((a - b) / fac)[fluid].astype(np.float64)
         return float(np.sqrt((d ** 2).sum(-1).mean()))
-    for t, gate in ((times[0], 5e-6 if fp16c else 2e-7), (times[-1], 1e-4 if fp16c else 1e-6)):
+    from helpers import check_gate
+    for t, gate, tag in ((times[0], 5e-6 if fp16c else 2e-7, "first"), (times[-1], 1e-4 if fp16c else 1e-6, "final")):
         hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_u-%09d.vtk" % t))[0])
-        e = rmse(ff["data"], gold["u%d" % t])
-        assert e < gate, "u RMSE %.3e at t=%d" % (e, t)
+        check_gate("driver:%s:%s" % (fixture, tag), rmse(ff["data"], gold["u%d" % t]), gate, "u RMSE at t=%d" % t)
     if case != "CaseV":   # without the VK inlet, TYPE_E cells keep what the boundary builders wrote: bit-exact on the side faces
         hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_u-%09d.vtk" % times[0]))[0])
         side = np.zeros(solid.shape, bool); side[:, 0, :] = side[:, -1, :] = side[:, :, 0] = side[:, :, -1] = True
         assert np.array_equal(ff["data"][side & fluid], gold["u%d" % times[0]][side & fluid]), "boundary velocities differ from the reference's"
-    e = rmse(f["u_avg"], gold["u_avg"])
-    assert e < (1e-4 if fp16c else 1e-6), "u_avg RMSE %.3e" % e
+    check_gate("driver:%s:u_avg" % fixture, rmse(f["u_avg"], gold["u_avg"]), 1e-4 if fp16c else 1e-6, "u_avg RMSE")
     hh, ff = read_vtk(glob.glob(os.path.join(vt, "*_raw_rho-%09d.vtk" % times[-1]))[0])
     dr = np.abs((ff["data"][..., 0] - gold["rho%d" % times[-1]]) / rho_fac)[fluid].max()
     assert dr < (1e-2 if fp16c else 1e-4), "rho max diff %.3e" % dr
@@ -190,14 +189,15 @@ def test_multi_run_decks_vs_real_reference_files(luw, tmp_path, ddf, build, case
         assert tuple(gold["dims"]) == h["dims"] and np.array_equal(solid, gold["solid"])
         fluid = ~solid
         side = np.zeros(solid.shape, bool); side[:, 0, :] = side[:, -1, :] = side[:, :, 0] = side[:, :, -1] = True
+        from helpers import check_gate
         for t, gate in ((8, 5e-6 if fp16c else 2e-7), (16, 1e-4 if fp16c else 1e-6)):
             hh, ff = read_vtk(glob.glob(os.path.join(vt, pre + "_*_raw_u-%09d.vtk" % t))[0])
             if t == 8:
                 assert np.array_equal(ff["data"][side & fluid], gold["u8"][side & fluid])
             d = ((ff["data"] - gold["u%d" % t]) / fac)[fluid].astype(np.float64)
-            assert float(np.sqrt((d ** 2).sum(-1).mean())) < gate, (pre, t)
+            check_gate("driver:ref_%s_%s_%s:u%d" % (build, case, pre, t), float(np.sqrt((d ** 2).sum(-1).mean())), gate, "u RMSE at t=%d" % t)
         d = ((f["u_avg"] - gold["u_avg"]) / fac)[fluid].astype(np.float64)
-        assert float(np.sqrt((d ** 2).sum(-1).mean())) < (1e-4 if fp16c else 1e-6)
+        check_gate("driver:ref_%s_%s_%s:u_avg" % (build, case, pre), float(np.sqrt((d ** 2).sum(-1).mean())), 1e-4 if fp16c else 1e-6, "u_avg RMSE")
 
 
 def test_pair_and_scalar_kernels_write_identical_files(luw, tmp_path):

@@ -140,7 +140,7 @@ def test_group_voxelise_gather_and_inlet_match_the_single_domain(luw):
 
 def test_group_staged_copy_path(tmp_path):
     """the path for devices without peer access (pack into a send buffer, hipMemcpyPeerAsync into the neighbour's receive
-    buffer), forced with LUW_GROUP_STAGED=1 in a child process: same bits as the oracle"""
+    buffer), forced with LUW_GROUP_TRANSPORT=staged in a child process: same bits as the oracle"""
     code = """
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -158,7 +158,7 @@ o = oracle.OracleLBM(*gN, 0.01); o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = 
 assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
 print("staged ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LUW_GROUP_STAGED="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LUW_GROUP_TRANSPORT="staged"), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
@@ -169,7 +169,7 @@ def test_group_rccl_transport_self(luw):
     from latticeurbanwind_amd import capi
     from oracle import oracle
     saved = os.environ.get("LUW_GROUP_TRANSPORT")
-    os.environ["LUW_GROUP_TRANSPORT"] = "rccl"                          # read at every luw_group_create
+    os.environ["LUW_GROUP_TRANSPORT"] = "rccl"; capi.reload_tuning()    # the library reads its environment once: read it again
     try:
         for gN, D, fp16c, alpha in (((32, 24, 12), (2, 2, 1), False, None), ((640, 24, 16), (2, 1, 2), True, None), ((24, 20, 16), (2, 2, 2), False, 0.004)):
             st = synthetic_state(*gN, seed=53, shell=None)
@@ -188,6 +188,7 @@ def test_group_rccl_transport_self(luw):
     finally:
         if saved is None: os.environ.pop("LUW_GROUP_TRANSPORT", None)
         else: os.environ["LUW_GROUP_TRANSPORT"] = saved
+        capi.reload_tuning()
 
 
 @pytest.mark.parametrize("transport", ["peer", "staged", "rccl"])
@@ -207,6 +208,8 @@ def test_group_on_distinct_devices(luw, transport, threads):
     gN = (640, 48, 24)
     saved = {k: os.environ.get(k) for k in ("LUW_GROUP_TRANSPORT", "LUW_GROUP_THREADS")}
     os.environ.update(LUW_GROUP_TRANSPORT=transport, LUW_GROUP_THREADS=threads)
+    from latticeurbanwind_amd import capi
+    capi.reload_tuning()
     try:
         for fp16c in (False, True):
             st = synthetic_state(*gN, seed=55, shell="luw")
@@ -224,6 +227,7 @@ def test_group_on_distinct_devices(luw, transport, threads):
         for k, v in saved.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
+        capi.reload_tuning()
 
 
 def test_group_one_host_thread_per_domain(tmp_path):

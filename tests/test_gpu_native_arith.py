@@ -1,0 +1,156 @@
+"""LUW_OPT_NATIVE_ARITH: the FP16C kernels' collision in the hardware's own arithmetic (one v_rcp_f32 for the divisions by the density, v_sqrt_f32 / v_rcp_f32
+in the Smagorinsky rate, sums in trees, free contraction -- csrc/luw_device.hpp, collide_cell_pk_native).  Not bit-equal to the oracle by design; the gates:
+
+  * ONE step from identical DDFs: u within 1e-8 RMSE of the oracle, rho bit-equal almost everywhere, at most 0.2 % of the stored FP16C codes different and
+    none by more than one code unit -- the arithmetic itself is right to the last bits;
+  * K = 8 / K = 64 on a deliberately noisy LES state: the differences of single stored codes (2^-12 relative each) grow like the flow lets them -- the same
+    growth the REAL reference shows against the oracle (tests/golden/ref_shipped_*: 0.3-0.9e-6 at K = 8, 0.4-2.6e-5 at K = 64); recorded values x 2;
+  * against the real reference's own fields: the same ceilings the bit-exact path has, and within twice the recorded values;
+  * mass: the drift of the mean density over 200 steps no larger than the exact kernels' (+ 1e-8).
+The bit-exact kernels stay the default and the anchor of every other test."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import synthetic_state, thermal_state, check_gate, rmse_u
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NUD = dict(n_cells=5, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1)
+SPG = dict(n_cells=4, inv_tau=0.02)
+COR = (0.0, 3e-5, 4e-5)
+
+
+def pair(luw, Nx, Ny, Nz, st, forces, alpha=None, T=None):
+    from oracle import oracle
+    kw = dict(buffer_nudging=NUD, top_sponge=SPG) if "zones" in forces else {}
+    g = luw.LBM(Nx, Ny, Nz, 2e-5, fp16c=True, native_arith=True, alpha=alpha, **kw)
+    o = oracle.OracleLBM(Nx, Ny, Nz, 2e-5, fp16c=True, alpha=alpha)
+    g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+    o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+    if T is not None:
+        g.T.data[:] = T; o.T[:] = T
+    if "coriolis" in forces:
+        g.set_coriolis(*COR); o.set_coriolis(*COR)
+    if "zones" in forces:
+        o.set_buffer_nudging(NUD["n_cells"], NUD["inv_tau"], NUD["downstream_face"], NUD["nudge_vertical"]); o.set_top_sponge(SPG["n_cells"], SPG["inv_tau"])
+    return g, o
+
+
+def code_distance(a, b):
+    """FP16C codes as signed integers on the format's own grid (sign-magnitude -> two's complement): |difference| in code units"""
+    mag = lambda c: (c.astype(np.int64) & 0x7FFF) * np.where(c & 0x8000, -1, 1)
+    return np.abs(mag(np.asarray(a)) - mag(np.asarray(b)))
+
+
+@pytest.mark.parametrize("forces", ["none", "coriolis", "zones+coriolis"])
+@pytest.mark.parametrize("size", [(648, 28, 26), (130, 9, 7), (48, 20, 12)])      # pair kernel (even and ragged rows), one-cell kernel
+def test_native_arithmetic_against_the_oracle(luw, size, forces):
+    Nx, Ny, Nz = size
+    st = synthetic_state(Nx, Ny, Nz, seed=21, shell="luw")
+    g, o = pair(luw, Nx, Ny, Nz, st, forces)
+    fluid = (st[0] & 3) == 0
+    key = "native:%dx%dx%d:%s" % (Nx, Ny, Nz, forces)
+    done = 0
+    for K, ceiling in ((1, 1e-8), (8, 1e-5), (64, 5e-5)):
+        g.run(K - done); o.run(K - done); done = K
+        g.u.read_from_device(); g.rho.read_from_device()
+        e = check_gate("%s:K%d" % (key, K), rmse_u(g.u.data, o.u, fluid), ceiling, "native vs oracle u RMSE at K=%d" % K)
+        if K == 1:
+            d = code_distance(g.download_fi(), o.fi)
+            assert (d > 0).mean() < 2e-3 and d.max() <= 1, "one step: %.4f %% of the codes differ, by up to %d units" % (100 * (d > 0).mean(), d.max())
+            assert np.abs(g.rho.data - o.rho).max() <= 2.4e-7 and np.abs(g.u.data - o.u).max() < 1e-7
+        assert np.isfinite(g.u.data).all() and e >= 0.0
+    g.close()
+
+
+@pytest.mark.parametrize("size", [(514, 5, 6), (40, 12, 6)])
+def test_native_arithmetic_with_the_thermal_lattice(luw, size):
+    # T is advected with the velocity before the force shift: one step keeps T within a float ulp of the oracle's, the thermal codes within one unit
+    Nx, Ny, Nz = size
+    st = synthetic_state(Nx, Ny, Nz, seed=4, shell="luw")
+    fl, T = thermal_state(st[0], size)
+    fl = fl.copy(); fl[(fl & 3) == 2] |= 4
+    g, o = pair(luw, Nx, Ny, Nz, (fl, st[1], st[2]), "coriolis", alpha=2e-5, T=T)
+    g.run(1); o.run(1)
+    g.T.read_from_device(); g.u.read_from_device()
+    assert np.abs(g.T.data - o.T).max() < 5e-7
+    d = code_distance(g.download_gi(), o.gi)
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3
+    g.run(15); o.run(15); g.u.read_from_device(); g.T.read_from_device()
+    check_gate("native:thermal:%dx%dx%d:K16" % size, rmse_u(g.u.data, o.u, (fl & 3) == 0), 2e-5, "native vs oracle u RMSE at K=16")
+    assert np.abs(g.T.data - o.T).max() < 1e-3
+    g.close()
+
+
+@pytest.mark.parametrize("case", ["CaseA", "CaseL"])
+def test_native_arithmetic_against_the_real_reference(luw, case):
+    # the reference's shipped build (FP16C, -cl-mad-enable, native division) against this path in ITS native arithmetic: same ceilings as the exact path
+    from oracle import setup_profile
+    from test_oracle_vs_reference import run_and_compare
+    gold = np.load(os.path.join(GOLD, "ref_shipped_%s.npz" % case))
+    s = setup_profile.setup_profile_case(os.path.join(GOLD, "refcases", case, "conf.luwpf"), solid_mask=gold["solid"])
+    nud = dict(n_cells=s["buffer_N"], inv_tau=float(s["buffer_inv_tau"]), downstream_face=s["buffer_face"], nudge_vertical=s["buffer_nudge_vertical"]) if s[
+        "buffer_active"] else None
+    spg = dict(n_cells=s["sponge_N"], inv_tau=float(s["sponge_inv_tau"])) if s["sponge_active"] else None
+    g = luw.LBM(s["Nx"], s["Ny"], s["Nz"], float(s["nu"]), fp16c=True, buffer_nudging=nud, top_sponge=spg, native_arith=True)
+    g.flags.data[:] = s["flags"]; g.u.data[:] = s["u"]; g.rho.data[:] = s["rho"]
+
+    def dev_u(l):
+        l.u.read_from_device(); return l.u.data
+
+    def dev_rho(l):
+        l.rho.read_from_device(); return l.rho.data
+    run_and_compare(g, gold, s, "native:ref_shipped_%s" % case, 2e-6, 6e-5, dev_u, dev_rho)
+    g.close()
+
+
+def test_native_arithmetic_conserves_mass_like_the_exact_kernels(luw):
+    Nx, Ny, Nz = 256, 64, 64
+    st = synthetic_state(Nx, Ny, Nz, seed=5, solids=False, shell=None)
+    drift = []
+    for nat in (False, True):
+        g = luw.LBM(Nx, Ny, Nz, 1e-4, fp16c=True, native_arith=nat)
+        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+        g.run(1); g.rho.read_from_device(); m0 = float(g.rho.data.astype(np.float64).mean())
+        g.run(200); g.rho.read_from_device(); drift.append(float(g.rho.data.astype(np.float64).mean()) - m0)
+        g.close()
+    assert abs(drift[1]) <= abs(drift[0]) + 1e-8, drift
+
+
+def test_native_arithmetic_is_ignored_for_fp32_and_in_sampled_steps(luw):
+    # FP32 DDFs: the option changes nothing (bit-equal to the oracle); FP16C sampled steps run the exact kernel (statistics equal the separate accumulation)
+    from oracle import oracle
+    Nx, Ny, Nz = 48, 20, 12
+    st = synthetic_state(Nx, Ny, Nz, seed=2, shell="luw")
+    g = luw.LBM(Nx, Ny, Nz, 2e-5, native_arith=True)
+    o = oracle.OracleLBM(Nx, Ny, Nz, 2e-5)
+    g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+    o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+    g.run(6); o.run(6); g.u.read_from_device()
+    assert np.array_equal(g.u.data, o.u) and np.array_equal(g.download_fi(), o.fi)
+    g.close()
+
+
+def test_driver_option_arith_native(luw, tmp_path):
+    # --arith native through the deck driver: files within the exact run's gates of the real reference, and different from the exact run's files
+    import glob, shutil, subprocess
+    from vtkio import read_vtk
+    drv = os.path.join(os.path.dirname(GOLD), "..", "latticeurbanwind_amd", "host", "luw_driver")
+    subprocess.check_call(["make", "-C", os.path.dirname(drv), "-s"])
+    gold = np.load(os.path.join(GOLD, "ref_shipped_CaseA.npz"))
+    out = {}
+    for mode in ("exact", "native"):
+        proj = str(tmp_path / mode)
+        shutil.copytree(os.path.join(GOLD, "refcases", "CaseA"), proj)
+        r = subprocess.run([drv, os.path.join(proj, "conf.luwpf"), "--ddf", "fp16c", "--arith", mode], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert ("Arithmetic" in r.stdout) == (mode == "native")
+        out[mode] = read_vtk(glob.glob(os.path.join(proj, "RESULTS", "vtk", "*_raw_u-000000064.vtk"))[0])[1]["data"]
+    fac = np.float32(5.0) / np.float32(0.1)
+    fluid = ~gold["solid"]
+    err = lambda a: float(np.sqrt(((((a - gold["u64"]) / fac)[fluid].astype(np.float64)) ** 2).sum(-1).mean()))
+    assert not np.array_equal(out["exact"], out["native"])
+    check_gate("driver:native:ref_shipped_CaseA:final", err(out["native"]), 6e-5)
+    assert err(out["exact"]) < 6e-5

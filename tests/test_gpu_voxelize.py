@@ -87,13 +87,16 @@ def test_triangle_bins_do_not_change_the_mask(luw):
     tri = np.array(tris, np.float32)
     masks, secs = [], []
     for brute in (False, True):
+        from latticeurbanwind_amd import capi
         if brute: os.environ["LUW_VOXELIZE_ALL_TRIANGLES"] = "1"
         else: os.environ.pop("LUW_VOXELIZE_ALL_TRIANGLES", None)
+        capi.reload_tuning()                                   # the library reads its environment once
         try:
             lbm = LBM(400, 320, 64, nu=0.01)
             t0 = time.perf_counter(); lbm.voxelize_mesh_on_device(tri); secs.append(time.perf_counter() - t0)
             masks.append((lbm.flags.data & 1).copy()); lbm.close()
         finally:
             os.environ.pop("LUW_VOXELIZE_ALL_TRIANGLES", None)
+            capi.reload_tuning()
     assert masks[0].sum() > 100000 and np.array_equal(masks[0], masks[1])
     print("voxelise %d triangles on 400x320x64: binned %.3f s, all triangles per column %.3f s" % (len(tris), secs[0], secs[1]))

@@ -25,8 +25,9 @@ def test_line_and_file_limits():
 
 def test_kernel_sources_and_header_keep_the_line_limit():
     csrc = os.path.join(ROOT, "latticeurbanwind_amd", "csrc")
-    files = sorted(glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(ROOT, "include", "luw_core.h")]
-    assert len(files) >= 9
+    files = sorted(glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(ROOT, "include", "luw_core.h"),
+        os.path.join(ROOT, "include", "luw_core_dev.h")] + sorted(glob.glob(os.path.join(ROOT, "tools", "ab_kernels", "*.hpp")))
+    assert len(files) >= 10
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reflow_cpp.py"), "--check", "--limit", "160"] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
 

@@ -33,14 +33,18 @@ def make_oracle(s, fp16c):
     return o
 
 
-def compare(g, s, u_now, rho_now, t, gate_rmse):
+def compare(g, s, u_now, rho_now, t, gate_rmse, key=None, field=None):
+    """u RMSE (lattice units, non-solid cells) against the reference's field `field` (default u<t>); key: the entry of tests/golden/observed_rmse.json that
+    also bounds it at twice the recorded value (helpers.check_gate)"""
+    from helpers import check_gate
     Nx, Ny, Nz, Nzc = s["Nx"], s["Ny"], s["Nz"], s["Nz_core"]
     fac = s["si_u_factor"]
     mine = (u_now.reshape(3, Nz, Ny, Nx)[:, :Nzc] * fac).astype(np.float32).transpose(1, 2, 3, 0)  # SI, like write_vtk
-    ref = g["u%d" % t]
+    ref = g[field or "u%d" % t]
     fluid = ~g["solid"]
     d = ((mine - ref) / fac)[fluid].astype(np.float64)
     rmse = float(np.sqrt((d ** 2).sum(-1).mean()))
+    if key: check_gate(key, rmse, gate_rmse, "u RMSE at t=%d" % t)
     assert rmse < gate_rmse, "u RMSE %.3e at t=%d" % (rmse, t)
     if rho_now is not None:
         mr = (rho_now.reshape(Nz, Ny, Nx)[:Nzc] * s["si_rho_factor"]).astype(np.float32)
@@ -82,20 +86,34 @@ def test_voxeliser_restatement_counts():
     assert "solid = 2616" in txt and "mapped: 5360 cells" in txt and "-> solid: 259" in txt
 
 
+def run_and_compare(lbm, g, s, fixture, ceil8, ceil64, get_u=lambda l: l.u, get_rho=lambda l: l.rho):
+    """8 steps, 52 more, then the last four one by one (u_avg of the fixtures = the reference's mean over its last 4 steps, FX/setup.cpp:4441-4488)"""
+    lbm.run(8)
+    r8 = compare(g, s, get_u(lbm), None, 8, ceil8, key=fixture + ":u8")
+    lbm.run(52)
+    mean = None
+    for k in range(4):
+        lbm.run(1)
+        u = get_u(lbm).copy()
+        mean = u if mean is None else mean + (u - mean) * np.float32(1.0 / (k + 1))     # Welford's running mean in FP32, like accumulate_from_buffers
+    r64 = compare(g, s, get_u(lbm), get_rho(lbm), 64, ceil64, key=fixture + ":u64")
+    ravg = compare(g, s, mean, None, 64, ceil64, key=fixture + ":u_avg", field="u_avg")
+    return r8, r64, ravg
+
+
 @pytest.mark.parametrize("case", ["CaseA", "CaseB", "CaseL"])
 def test_oracle_fp32_vs_real_reference(case):
     g, s, o = run_case(case, "ref_fp32_%s.npz" % case, False, make_oracle)
-    o.run(8)
-    compare(g, s, o.u, None, 8, 2e-7)
-    o.run(56)
-    rmse = compare(g, s, o.u, o.rho, 64, 1e-6)
-    print(case, "fp32 rmse@64 = %.3e" % rmse)
+    r8, r64, ravg = run_and_compare(o, g, s, "oracle:ref_fp32_%s" % case, 2e-7, 1e-6)
+    assert r64 < 1e-5 and ravg < 1e-5                       # the north star's gate, with two orders of margin
+    print(case, "fp32 rmse@8 %.3e @64 %.3e u_avg %.3e" % (r8, r64, ravg))
 
 
 @pytest.mark.parametrize("case", ["CaseA", "CaseL"])
 def test_oracle_fp16c_vs_real_reference_shipped_config(case):
+    # FP16C storage: 2^-12 relative per stored value.  K = 8 sits inside the north star's 1e-5; at K = 64 the LES case A does NOT (2.6e-5, u_avg 1.5e-5), the
+    # laminar case L does (4e-6): stated in bench.py's parity block, gated here at twice the observed values
     g, s, o = run_case(case, "ref_shipped_%s.npz" % case, True, make_oracle)
-    o.run(8)
-    compare(g, s, o.u, None, 8, 2e-6)
-    o.run(56)
-    compare(g, s, o.u, o.rho, 64, 1e-4)
+    r8, r64, ravg = run_and_compare(o, g, s, "oracle:ref_shipped_%s" % case, 2e-6, 6e-5)
+    assert r8 < 1e-5
+    print(case, "fp16c rmse@8 %.3e @64 %.3e u_avg %.3e" % (r8, r64, ravg))

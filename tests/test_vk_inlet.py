@@ -52,8 +52,8 @@ def test_oracle_with_vk_inlet_vs_real_reference(npz, fp16c, g8, g64):
     for t in range(64):
         oracle.vk_inlet_apply(o, T, *vk_inlet.time_params(o.t))
         o.run(1)
-        if o.t == 8: compare(g, s, o.u, None, 8, g8)
-    compare(g, s, o.u, o.rho, 64, g64)
+        if o.t == 8: compare(g, s, o.u, None, 8, g8, key="oracle:%s:u8" % npz[:-4])
+    compare(g, s, o.u, o.rho, 64, g64, key="oracle:%s:u64" % npz[:-4])
 
 
 def test_driver_vk_tables_equal_restatement(luw, tmp_path):
@@ -116,9 +116,10 @@ def test_hip_vk_inlet_vs_real_reference(luw):
     lbm.run(0)
     lbm.vk_inlet_attach(T["point_cell"], T["point_face"], T["point_data"], T["mode_data"], T["mode_count"])
     lbm.run(8); lbm.u.read_from_device()
-    compare(g, s, lbm.u.data, None, 8, 2e-7)
+    # (the device library's cosf against the host's: the inlet values may differ in the last bit, so this run has its own record)
+    compare(g, s, lbm.u.data, None, 8, 2e-7, key="hip:ref_fp32_CaseV:u8")
     lbm.run(56); lbm.u.read_from_device(); lbm.rho.read_from_device()
-    compare(g, s, lbm.u.data, lbm.rho.data, 64, 1e-6)
+    compare(g, s, lbm.u.data, lbm.rho.data, 64, 1e-6, key="hip:ref_fp32_CaseV:u64")
 
 
 @pytest.mark.gpu
