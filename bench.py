@@ -594,6 +594,56 @@ def oracle_digests(o, gN, D, world, fp16c):
     return out
 
 
+BLOCK_TIMEOUT_S = int(os.environ.get("LUW_BENCH_BLOCK_TIMEOUT", "900"))     # a secondary block of the N > 1 line that does not return
+
+
+def inject_failure(where):
+    """test hook (tests/test_gpu_bench_distributed.py): LUW_BENCH_INJECT=<block>:raise | <block>:hang makes that block of the N > 1 line fail the way a
+    first contact with real multi-GPU hardware might"""
+    spec = os.environ.get("LUW_BENCH_INJECT", "")
+    if spec.startswith(where + ":"):
+        if spec.endswith(":hang"):
+            time.sleep(10 ** 6)
+        raise RuntimeError("injected failure in block %s" % where)
+
+
+class LineKeeper:
+    """rank 0's guarantee of ONE parseable line: holds the most complete line so far; emit() prints it once; a block that does not return within its limit
+    makes the timer print the held line -- with an error in the pending block -- and end the process with a non-zero code (the launcher takes the other
+    ranks down), never a re-exec."""
+
+    def __init__(self, stdout_fd):
+        import threading
+        self.fd, self.lock, self.line, self.pending, self.timer, self.done = stdout_fd, threading.Lock(), None, None, None, False
+
+    def hold(self, line, pending=None):
+        with self.lock:
+            self.line, self.pending = line, pending
+
+    def emit(self, line=None):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            os.write(self.fd, (json.dumps(line if line is not None else self.line) + "\n").encode())
+
+    def arm(self, seconds):
+        import threading
+
+        def fire():
+            line = dict(self.line or {})
+            sec = dict(line.get("secondary", {}))
+            sec[self.pending or "block"] = {"error": "no result within %d s: the line is printed without this block" % seconds}
+            line["secondary"] = sec
+            self.emit(line)
+            os._exit(4)
+        self.timer = threading.Timer(seconds, fire); self.timer.daemon = True; self.timer.start()
+
+    def disarm(self):
+        if self.timer:
+            self.timer.cancel(); self.timer = None
+
+
 def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c, METRIC, saved_stdout):
     import torch.distributed as dist
     from latticeurbanwind_amd.distributed import DomainDecomposedLBM, choose_decomposition, tile_lattice, init_rccl_process_group
@@ -728,22 +778,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
         finally:
             sim.backend.close()
 
-    res = run_tile(D)
-    alt = run_tile(cuts[1]) if len(cuts) > 1 else None
-
-    # ---- the product's OTHER multi-GPU host: one process, all GPUs (luw_group_*, what luw_driver runs for decks with n_gpu > 1).  Every rank
-    # has destroyed its solver; child processes of rank 0 drive all devices, one variant each, while the ranks wait in the barrier below.
-    group_host = None
-    if rank == 0 and not args.no_group_host and world > 1:
-        try:
-            group_host = run_group_host(args, D, res["gN"], [dev_of(r) for r in range(world)])
-        except Exception as e:      # never takes the RCCL line down; its absence is visible
-            group_host = {"error": str(e)[:300]}
-    if not shared:
-        torch.cuda.synchronize()
-    dist.barrier(group=side)                                        # on the CPU: the ranks wait here while rank 0's child processes drive all devices
-
-    if rank == 0:
+    def build_line(res, alt, alt_error, group_host):
         def block(r):
             cells = r["gN"][0] * r["gN"][1] * r["gN"][2]
             mlups = cells * args.steps / r["dt"] / 1e6
@@ -791,13 +826,50 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
                                     "what": "the same tile cut with x kept whole (rows stay complete memory lines; whole-row y/z shells)",
                                     "halo_exchange": transport + (", overlapped with the interior" if alt["overlap"] else " after the whole-box kernel"),
                                     "roofline_frac_rank0_kernel": round(a2 / HBM_PEAK_GBPS, 4) if a2 else None, "per_rank": alt["per_rank"]}
+        elif alt_error is not None:
+            sec["x_whole_n_gpu"] = {"error": alt_error}
         if group_host is not None:
             sec["group_host"] = group_host
         if sec:
             out["secondary"] = sec
-        sys.stdout.flush(); os.dup2(saved_stdout, 1)
-        print(json.dumps(out)); sys.stdout.flush()
-        os.dup2(2, 1)
+        return out
+    res = run_tile(D)
+    # From here on rank 0 HOLDS a complete line (the headline measurement): whatever happens to a later block -- an exception on some rank, a collective that
+    # never returns on hardware nobody has met -- the line is printed, once, with what did run and an `error` in the block that did not.
+    keeper = LineKeeper(saved_stdout) if rank == 0 else None
+    alt = alt_error = None
+    if len(cuts) > 1:
+        if keeper:
+            keeper.hold(build_line(res, None, None, None), pending="x_whole_n_gpu")
+            keeper.arm(BLOCK_TIMEOUT_S)
+        try:
+            inject_failure("alt")
+            alt = run_tile(cuts[1])
+        except Exception as e:
+            alt_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+        finally:
+            if keeper: keeper.disarm()
+
+    # ---- the product's OTHER multi-GPU host: one process, all GPUs (luw_group_*, what luw_driver runs for decks with n_gpu > 1).  Every rank
+    # has destroyed its solver; child processes of rank 0 drive all devices, one variant each, while the ranks wait in the barrier below.
+    group_host = None
+    if rank == 0 and not args.no_group_host and world > 1:
+        keeper.hold(build_line(res, alt, alt_error, None), pending="group_host")
+        try:
+            inject_failure("group_host")
+            group_host = run_group_host(args, D, res["gN"], [dev_of(r) for r in range(world)])
+        except Exception as e:      # never takes the RCCL line down; its absence is visible
+            group_host = {"error": str(e)[:300]}
+    if not shared:
+        torch.cuda.synchronize()
+    if keeper:                                                      # a rank that never arrives (stuck in a collective of a failed block) must not cost the line
+        keeper.hold(build_line(res, alt, alt_error, group_host), pending="final_barrier"); keeper.arm(BLOCK_TIMEOUT_S)
+    dist.barrier(group=side)                                        # on the CPU: the ranks wait here while rank 0's child processes drive all devices
+    if keeper:
+        keeper.disarm()
+        keeper.emit(build_line(res, alt, alt_error, group_host))
+    if alt_error is not None:                 # some rank failed inside a collective sequence: the ranks are not in step any more
+        os._exit(3)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -42,6 +42,14 @@ int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_download_gi(luw_solver* s, void* host_dst);   /* thermal DDFs as stored, gi[i*N+n], i = 0..6 */
 int luw_upload_fi(luw_solver* s, const void* host_src);
 
+/* ---- fault injection for the multi-domain host (first-contact insurance: the paths a node with real peer links takes when something is missing, exercised
+ * on one GPU).  mask bit 0: luw_group_create treats every pair of domains (i, j) with i + j odd as devices WITHOUT peer access -- those pairs fall back
+ * to staged copies while the others keep their peer stores; bit 1: ncclCommInitAll "fails" (LUW_GROUP_TRANSPORT=rccl then ends in a clean error, nothing
+ * allocated, nothing hanging).  0 clears.  Takes effect for groups created afterwards. */
+#define LUW_FAULT_NO_PEER_ODD_PAIRS 1u
+#define LUW_FAULT_RCCL_INIT 2u
+int luw_dev_inject_fault(uint32_t mask);
+
 /* ---- device self-checks */
 /* number of inputs (all 2^16 FP16C codes + all 2^32 floats) for which the kernels' fast FP16C codec differs from the literal formulas of
  * FX/kernel.cpp:864-875; must be 0 */

@@ -41,6 +41,7 @@ SYMBOLS = [
 # include/luw_core_dev.h
 DEV_SYMBOLS = [
     "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_reload_tuning", "luw_dev_tuning_text",
+        "luw_dev_inject_fault",
     "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_selfcheck_arith",
 ]
 
@@ -177,6 +178,7 @@ def load(path=None):
     L.luw_p2p_info.argtypes = [i32, i32, i32p, i32p, i32p, u32p, u32p]
     L.luw_dev_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, u64]
     L.luw_dev_tuning_text.argtypes = [C.c_char_p, u64]
+    L.luw_dev_inject_fault.argtypes = [u32]
     if L.luw_abi_version() != 5:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
@@ -224,3 +226,11 @@ def placement_info(handle):
     n, tb, sec, kept = C.c_int(0), C.c_double(0.0), C.c_double(0.0), C.create_string_buffer(64)
     check(load().luw_dev_placement_info(handle, C.byref(n), C.byref(tb), C.byref(sec), kept, 64))
     return {"candidates_tried": n.value, "kept": kept.value.decode(), "probe_TBps": round(tb.value, 3), "create_s": round(sec.value, 3)}
+
+
+FAULT_NO_PEER_ODD_PAIRS, FAULT_RCCL_INIT = 1, 2
+
+
+def inject_fault(mask):
+    """luw_dev_inject_fault: test hook of the multi-domain host (0 clears)"""
+    check(load().luw_dev_inject_fault(int(mask)))

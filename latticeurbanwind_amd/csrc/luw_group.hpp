@@ -212,6 +212,7 @@ static int group_rccl_setup(luw_group* g) {
 		if(it==devs.end()) devs.push_back(g->dom[i].device);
 	}
 	std::vector<void*> comms(devs.size(), nullptr);
+	if(g_injected_faults.load()&LUW_FAULT_RCCL_INIT) return fail(LUW_ERR_DEVICE, "ncclCommInitAll: injected failure (luw_dev_inject_fault)");
 	RCCL_TRY(R->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
 	g->rccl_comm = comms;
 	return LUW_OK;
@@ -642,6 +643,7 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 	g->peer.assign(n, std::vector<char>(n, 0));
 	for(uint32_t i=0u; i<n; i++) for(uint32_t j=0u; j<n; j++) {
 		const int di = g->dom[i].device, dj = g->dom[j].device;
+		if((g_injected_faults.load()&LUW_FAULT_NO_PEER_ODD_PAIRS)&&((i+j)&1u)) continue; // test hook: this pair has "no peer access" (staged copies)
 		if(di==dj) { g->peer[i][j] = 1; continue; }
 		int can = 0;
 		if(hipDeviceCanAccessPeer(&can, di, dj)==hipSuccess&&can) {

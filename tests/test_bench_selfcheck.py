@@ -23,10 +23,11 @@ def run(tmp_path, gN, D, fp16c, corrupt):
     return json.load(open(out))
 
 
-@pytest.mark.parametrize("gN,D,fp16c", [((24, 16, 12), (2, 1, 1), False), ((16, 24, 12), (1, 2, 1), True)])
+@pytest.mark.parametrize("gN,D,fp16c", [((24, 16, 12), (2, 1, 1), False), ((16, 24, 12), (1, 2, 1), True), ((32, 16, 8), (4, 2, 1), False)])
 def test_selfcheck_passes_on_a_correct_decomposed_run(tmp_path, gN, D, fp16c):
+    # (the third case: eight ranks, BASELINE's literal cut)
     res = run(tmp_path, gN, D, fp16c, 0)
-    assert res["bad"] == [[], []] and res["max_abs_uy"] > 0.0
+    assert res["bad"] == [[] for _ in range(D[0] * D[1] * D[2])] and res["max_abs_uy"] > 0.0
 
 
 def test_selfcheck_sees_one_wrong_value(tmp_path):

@@ -22,7 +22,10 @@ def single_domain(gN, steps, fp16c):
     return o.u.copy(), o.rho.copy()
 
 
-@pytest.mark.parametrize("gN,D,fp16c", [((16, 10, 6), (2, 1, 1), False), ((12, 12, 8), (2, 2, 1), False), ((12, 8, 8), (1, 2, 2), True)])
+# world 8: the two cuts of BASELINE's 8-GPU tile -- the deck's literal n_gpu = [4,2,1] and the x-whole [1,4,2] -- with every rank's neighbours distinct ranks
+# (the one-GPU box can only rehearse them with all domains on one device)
+@pytest.mark.parametrize("gN,D,fp16c", [((16, 10, 6), (2, 1, 1), False), ((12, 12, 8), (2, 2, 1), False), ((12, 8, 8), (1, 2, 2), True),
+                                         ((16, 8, 6), (4, 2, 1), False), ((10, 16, 8), (1, 4, 2), True)])
 def test_gloo_multi_domain_equals_single_domain(tmp_path, gN, D, fp16c):
     world = D[0] * D[1] * D[2]
     steps = 5

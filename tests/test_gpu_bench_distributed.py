@@ -63,3 +63,21 @@ def test_one_rank_over_the_real_rccl_process_group(luw):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["config"]["n_gpu"] == [1, 1, 1] and out["value"] > 0 and out["parity"]["ok"]
     assert "RCCL" in out["config"]["halo_exchange"] and out["config"]["rccl_version"]
+
+
+@pytest.mark.parametrize("how,code", [("alt:raise", 3), ("alt:hang", 4)])
+def test_a_failing_secondary_block_still_yields_the_line(luw, how, code):
+    """first-contact insurance: the x-whole cut (a secondary block of the N > 1 line) raises on every rank, or never returns -- rank 0 still prints ONE
+    parseable line with n_gpus, the headline of the literal cut and its per-rank blocks, an `error` where the block would be, and the job ends non-zero
+    (no re-exec; the launcher takes the other ranks down)"""
+    port = 29500 + ((os.getpid() + 411 + code) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--share-device", "0", "--size", "384", "64", "64", "--no-parity",
+           "--no-group-host"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, LUW_BENCH_INJECT=how, LUW_BENCH_BLOCK_TIMEOUT="20"))
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and len(out["per_rank"]) == 2 and out["config"]["n_gpu"] == [2, 1, 1]
+    assert "error" in out["secondary"]["x_whole_n_gpu"]

@@ -260,3 +260,51 @@ def test_group_refuses_what_the_reference_refuses(luw):
         luw.LBMGroup(25, 20, 16, 2, 1, 1, 0.01, devices=[0, 0])          # not divisible: the caller shrinks the grid first
     with pytest.raises(capi.LuwError):
         luw.LBMGroup(24, 20, 16, 2, 1, 1, 0.01)                          # one device per domain unless a device list says otherwise (FX/lbm.cpp:961-979)
+
+
+def test_pairs_without_peer_access_fall_back_to_copies_pair_by_pair(luw):
+    """first-contact insurance (luw_dev_inject_fault): half of the domain pairs have "no peer access" -- their faces go through send buffers and
+    hipMemcpyPeerAsync while the other pairs keep the pack kernels' peer stores, in the same exchange; same bits as the oracle, overlap and pipelining on"""
+    from latticeurbanwind_amd import capi
+    from oracle import oracle
+    capi.inject_fault(capi.FAULT_NO_PEER_ODD_PAIRS)
+    try:
+        for gN, D, fp16c in (((32, 24, 12), (4, 2, 1), False), ((640, 24, 16), (2, 1, 2), True)):
+            st = synthetic_state(*gN, seed=47, shell=None)
+            g = run_group(luw, gN, D, fp16c, st, 0)
+            assert g.overlaps() and not g.direct_peer_stores() and g.transport() == 1     # reported as staged: some pair has no peer access
+            g.run(0); g.run(5); g.run(4); g.read_from_device()
+            o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
+            o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+            o.run(9)
+            assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
+            g.close()
+    finally:
+        capi.inject_fault(0)
+
+
+def test_failing_rccl_initialisation_is_a_clean_error(luw):
+    """LUW_GROUP_TRANSPORT=rccl with ncclCommInitAll failing (injected): luw_group_create returns an error with a message, nothing hangs, nothing leaks
+    into the next group, which runs on peer stores as if nothing had happened"""
+    from latticeurbanwind_amd import capi
+    from oracle import oracle
+    saved = os.environ.get("LUW_GROUP_TRANSPORT")
+    os.environ["LUW_GROUP_TRANSPORT"] = "rccl"; capi.reload_tuning(); capi.inject_fault(capi.FAULT_RCCL_INIT)
+    gN, D = (24, 20, 16), (2, 2, 1)
+    st = synthetic_state(*gN, seed=49, shell=None)
+    try:
+        with pytest.raises(capi.LuwError, match="ncclCommInitAll"):
+            run_group(luw, gN, D, False, st, 0)
+    finally:
+        capi.inject_fault(0)
+        if saved is None: os.environ.pop("LUW_GROUP_TRANSPORT", None)
+        else: os.environ["LUW_GROUP_TRANSPORT"] = saved
+        capi.reload_tuning()
+    g = run_group(luw, gN, D, False, st, 0)
+    assert g.direct_peer_stores()
+    g.run(0); g.run(5); g.read_from_device()
+    o = oracle.OracleLBM(*gN, 0.01)
+    o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
+    o.run(5)
+    assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
+    g.close()
