@@ -258,6 +258,8 @@ struct luw_solver {
 	std::vector<DevBlock> raw; // device blocks behind the lattice-sized arrays (lead_alloc)
 	uint32_t gather_count = 0u; uint32_t* d_gather_cell = nullptr; float* d_gather_out = nullptr; // probe columns
 	void* d_stage = nullptr; size_t stage_bytes = 0u; // copy_pitched's staging buffer (chunk-mapped arrays)
+	// x-face output of the step kernels (luw_set_x_face_buffers): buffers, and which of the two border columns the launches of step xf_t have covered
+	void* xf_p = nullptr; void* xf_m = nullptr; uint32_t xf_cover = 0u; uint64_t xf_t = ~0ull;
 	// what luw_create's placement search did (luw_dev_placement_info): candidates probed, the kind kept, its probe rate, seconds spent in luw_create
 	int placement_tried = 0; std::string placement_kept = "default (no search)"; double placement_tbps = 0.0, create_seconds = 0.0;
 };
@@ -433,6 +435,20 @@ static int box_force_mode(const luw_solver* s, const Box& b) {
 	if(b.x0<lo[0]||b.x1>hi[0]||b.y0<lo[1]||b.y1>hi[1]||b.z0<lo[2]||b.z1>hi[2]) return PAIR_FORCE_ANY;
 	return (k.coriolis||k.fx!=0.0f||k.fy!=0.0f||k.fz!=0.0f) ? PAIR_FORCE_UNIFORM : PAIR_FORCE_NONE;
 }
+// ---- x-face output of the step kernels (luw_set_x_face_buffers).  A launch takes the instantiation with the output when the buffers are set, x is split
+// and its box holds the first or the last owned x column; it "covers" a column when the box also spans every non-halo (y, z) of it.  When the launches of
+// a step have covered both columns, luw_enqueue_extract_fi(direction 0) on the same buffers has nothing left to do.
+static bool xface_wanted(const luw_solver* s, const Box& b) {
+	if(!s->xf_p||!s->xf_m||!s->kp.halo_x||s->cfg.Nx<4u) return false;
+	return (b.x0<=1u&&b.x1>1u)||(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u);
+}
+static void xface_covered(luw_solver* s, const Box& b) {
+	if(s->xf_t!=s->t) { s->xf_t = s->t; s->xf_cover = 0u; }
+	const bool spans = b.y0<=s->kp.halo_y&&b.y1>=s->cfg.Ny-s->kp.halo_y&&b.z0<=s->kp.halo_z&&b.z1>=s->cfg.Nz-s->kp.halo_z;
+	if(!spans) return;
+	if(b.x0<=1u&&b.x1>1u) s->xf_cover |= 2u;                            // first owned column: the face towards -x
+	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) s->xf_cover |= 1u;        // last owned column: the face towards +x
+}
 // ---------------------------------------------------------------- the kernel instantiations, as tables
 // Every stream_collide variant the library carries is one row: what it is for (the key the launchers look up) and the function that launches its two
 // time-parity instances.  Nothing else instantiates the step kernels.
@@ -440,15 +456,16 @@ struct LaunchGeom { dim3 grid, block; int xa; uint32_t lds; };
 
 // ---- k_stream_collide_s: one cell per lane
 // mode 0: step, 4: step + thermal lattice; 1, 2, 3: A/B variants (tools build)
-struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce, native; };
+struct ScalarKey { uint8_t ddf_bytes; int mode; int nt; bool flat, stats, noforce, native, xface; };
 typedef void (*ScalarLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
-template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE,
-	bool NATIVE=false> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE, bool NATIVE=false,
+	bool XFACE=false> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	T* const fi = (T*)s->d_fi; T* const gi = MODE==4 ? (T*)s->d_gi : nullptr; float* const Tf = MODE==4 ? s->d_T : nullptr;
-	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE, NATIVE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi,
-		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
-	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE, NATIVE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi, s->d_rho,
-		s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S);
+	T* const xp = XFACE ? (T*)s->xf_p : nullptr; T* const xm = XFACE ? (T*)s->xf_m : nullptr;
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE, NATIVE, XFACE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa,
+		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm);
+	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE, NATIVE, XFACE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi,
+		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm);
 }
 struct ScalarRow { ScalarKey key; ScalarLaunch launch; const char* what; };
 static const ScalarRow scalar_table[] = {
@@ -466,6 +483,9 @@ static const ScalarRow scalar_table[] = {
 	{ { 2u, 0, 2, false, true,  false }, scalar_instance<uint16_t, 0, 2, false, true, false>,    "FP16C one-cell kernel, sampled step" },
 	{ { 2u, 4, 2, false, false, false }, scalar_instance<uint16_t, 4, 2, false, false, false>,   "FP16C one-cell kernel + thermal lattice" },
 	{ { 2u, 4, 2, false, false, true  }, scalar_instance<uint16_t, 4, 2, false, false, true>,    "FP16C one-cell kernel + thermal lattice, force-free box" },
+	// x-split domains, boxes that hold the first / last owned x column: the same kernels with the x-face output (luw_set_x_face_buffers)
+	{ { 4u, 0, 2, true,  false, false, false, true }, scalar_instance<float, 0, 2, true, false, false, false, true>,  "FP32 + x-face output" },
+	{ { 4u, 0, 2, false, false, false, false, true }, scalar_instance<float, 0, 2, false, false, false, false, true>, "FP32, row addressing + x-face output" },
 	{ { 2u, 0, 2, false, false, false, true }, scalar_instance<uint16_t, 0, 2, false, false, false, true>, "FP16C one-cell kernel, native arithmetic" },
 	{ { 2u, 4, 2, false, false, false, true }, scalar_instance<uint16_t, 4, 2, false, false, false, true>,
 		"FP16C one-cell kernel + thermal lattice, native arithmetic" },
@@ -492,7 +512,7 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	g.xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
 	const uint32_t nx = (uint32_t)((int)b.x1-g.xa), bx = row_block(nx);
 	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
-	ScalarKey k{ (uint8_t)s->ddf_bytes, 0, 2, false, st!=nullptr, false, false };
+	ScalarKey k{ (uint8_t)s->ddf_bytes, 0, 2, false, st!=nullptr, false, false, false };
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise.  In-plane
 	// offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with its 2^32-byte planes
 	// still qualifies (largest offset 2^32 - 4).  LUW_ADDR_ROW: the row form also where the flat form would do (both are product code, same values)
@@ -504,6 +524,8 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	if(s->d_gi&&!st) k.mode = 4; // thermal lattice on: the product kernel plus the D3Q7 cell update
 	// native arithmetic (FP16C, plain steps): one instantiation for every box
 	if(s->ddf_bytes==2u&&!st&&(s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u) { k.native = true; k.noforce = false; }
+	// x-face output: FP32 plain steps on a box that holds a border column
+	k.xface = s->ddf_bytes==4u && k.mode==0 && !st && xface_wanted(s, b);
 #ifdef LUW_AB_KERNELS
 	if(!st&&!s->d_gi) switch(s->kernel) {
 		case LUW_KERNEL_EXP_COPY: k.mode = 1; k.nt = 1; k.noforce = false; break;
@@ -516,8 +538,9 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 #endif
 	for(const ScalarRow& r : scalar_table) {
 		const ScalarKey& q = r.key;
-		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce&&q.native==k.native) {
+		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce&&q.native==k.native&&q.xface==k.xface) {
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
+			if(k.xface) xface_covered(s, b);
 			return LUW_OK;
 		}
 	}
@@ -525,15 +548,16 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 }
 
 // ---- k_stream_collide_p: FP16C, two cells per lane
-struct PairKey { int mode; bool stats; int force; bool park, thermal, native; };   // mode 1: memory path only (tools build)
+struct PairKey { int mode; bool stats; int force; bool park, thermal, native, xface; };   // mode 1: memory path only (tools build)
 typedef void (*PairLaunch)(luw_solver*, const Box&, const LaunchGeom&, int write_fields, const StatsArgs&);
-template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL,
-	bool NATIVE=false> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
+template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL, bool NATIVE=false,
+	bool XFACE=false> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	uint16_t* const fi = (uint16_t*)s->d_fi; uint16_t* const gi = THERMAL ? (uint16_t*)s->d_gi : nullptr; float* const Tf = THERMAL ? s->d_T : nullptr;
-	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL, NATIVE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi,
-		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
-	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL, NATIVE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi, s->d_rho,
-		s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf);
+	uint16_t* const xp = XFACE ? (uint16_t*)s->xf_p : nullptr; uint16_t* const xm = XFACE ? (uint16_t*)s->xf_m : nullptr;
+	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL, NATIVE, XFACE>), g.grid, g.block, g.lds, s->stream, s->kp, b,
+		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm);
+	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL, NATIVE, XFACE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi,
+		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm);
 }
 struct PairRow { PairKey key; PairLaunch launch; const char* what; };
 static const PairRow pair_table[] = {
@@ -556,6 +580,14 @@ static const PairRow pair_table[] = {
 	{ { 0, false, PAIR_FORCE_NONE,    true,  true,  true }, pair_instance<0, false, PAIR_FORCE_NONE, true, true, true>,        "native + thermal, force-free" },
 	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true,  true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true, true>,     "native + thermal, uniform" },
 	{ { 0, false, PAIR_FORCE_ANY,     true,  true,  true }, pair_instance<0, false, PAIR_FORCE_ANY, true, true, true>,         "native + thermal, general" },
+	// x-split domains, boxes that hold the first / last owned x column: x-face output (luw_set_x_face_buffers), exact and native
+	{ { 0, false, PAIR_FORCE_NONE,    false, false, false, true }, pair_instance<0, false, PAIR_FORCE_NONE, false, false, false, true>,
+		"force-free + x-face" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, false, false, false, true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, false, false, false, true>, "uniform + x-face" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  false, false, true }, pair_instance<0, false, PAIR_FORCE_ANY, true, false, false, true>,      "general + x-face" },
+	{ { 0, false, PAIR_FORCE_NONE,    false, false, true,  true }, pair_instance<0, false, PAIR_FORCE_NONE, false, false, true, true>,     "native + x-face" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, false, false, true,  true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, false, false, true, true>,  "native + x-face" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  false, true,  true }, pair_instance<0, false, PAIR_FORCE_ANY, true, false, true, true>,       "native + x-face" },
 #ifdef LUW_AB_KERNELS
 	{ { 1, false, PAIR_FORCE_ANY,     false, false }, pair_instance<1, false, PAIR_FORCE_ANY, false, false>,
 		"A/B: the kernel's memory path alone (LUW_PAIR_COPY)" },
@@ -581,6 +613,8 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	// native arithmetic: plain steps of the product kernel (a sampled step runs the exact kernel: its values differ in rounding only)
 	k.native = (s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u && !st;
 	if(k.native&&!k.thermal) k.park = k.force==PAIR_FORCE_ANY;
+	// x-face output: plain steps of the D3Q19 lattice with the product's park choice, on a box that holds a border column
+	k.xface = !st && !k.thermal && k.mode==0 && k.park==(k.force==PAIR_FORCE_ANY) && xface_wanted(s, b);
 #ifdef LUW_AB_KERNELS
 	const bool copy_only = tuning().ab_pair_copy;   // tools build, measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only&&!st&&!k.thermal) k = PairKey{ 1, false, PAIR_FORCE_ANY, false, false };
@@ -588,8 +622,9 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	g.lds = k.park ? (bx/64u)*pair_park_bytes_per_wave(k.thermal, (k.mode==0&&!k.stats) ? k.force : PAIR_FORCE_NONE) : 0u;
 	for(const PairRow& r : pair_table) {
 		const PairKey& q = r.key;
-		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native) {
+		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native&&q.xface==k.xface) {
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
+			if(k.xface) xface_covered(s, b);
 			return LUW_OK;
 		}
 	}
@@ -1523,9 +1558,19 @@ int luw_run_timed(luw_solver* s, uint64_t steps, double* mean_kernel_ms) {
 	return run_steps(s, steps, mean_kernel_ms);
 }
 
+int luw_set_x_face_buffers(luw_solver* s, void* dev_buffer_p, void* dev_buffer_m) {
+	if(!s||((dev_buffer_p==nullptr)!=(dev_buffer_m==nullptr))) return fail(LUW_ERR_INVALID, "luw_set_x_face_buffers: bad argument");
+	s->xf_p = dev_buffer_p; s->xf_m = dev_buffer_m; s->xf_cover = 0u; s->xf_t = ~0ull;
+	return LUW_OK;
+}
 int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_fi: bad argument");
 	if(int e = set_device(s)) return e;
+	if(direction==0u) { // the step kernels of this step have written both x faces into these very buffers already
+		const bool done = buf_p==s->xf_p&&buf_m==s->xf_m&&s->xf_t==s->t&&s->xf_cover==3u;
+		s->xf_cover = 0u; s->xf_t = ~0ull;
+		if(done) return LUW_OK;
+	}
 	launch_transfer<false, false>(s, direction, buf_p, buf_m);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;

@@ -100,6 +100,18 @@ static bool step_can_overlap(const uint32_t lN[3], const uint32_t H[3]) { for(in
 static void group_boxes(const luw_group* g, GroupDomain& d) { step_boxes(d.lN, g->H, group_x_shell(g), d.whole, d.interior, d.shell); }
 
 static void group_rccl_teardown(luw_group* g);
+// the x faces of domain i go straight into its neighbours' receive buffers (peer stores)
+static bool group_x_direct(const luw_group* g, const size_t i) { return g->H[0]&&g->peer[i][g->dom[i].nbr[0][0]]&&g->peer[i][g->dom[i].nbr[0][1]]; }
+// ... and then the step kernels of domain i write there (luw_set_x_face_buffers): the launch that holds them waits, like the pack kernel would, until both
+// neighbours have consumed what the previous step put into those buffers
+static int group_x_face_ready(luw_group* g, const size_t i) {
+	if(!group_x_direct(g, i)) return LUW_OK;
+	GroupDomain& d = g->dom[i];
+	hipStream_t st = g->overlap ? d.comm : d.compute;
+	HIP_TRY(hipStreamWaitEvent(st, g->dom[d.nbr[0][0]].unpacked[0], 0));
+	HIP_TRY(hipStreamWaitEvent(st, g->dom[d.nbr[0][1]].unpacked[0], 0));
+	return LUW_OK;
+}
 static void group_free(luw_group* g) {
 	if(!g) return;
 	for(GroupDomain& d : g->dom) {
@@ -374,6 +386,7 @@ static StepCtx group_step_ctx(luw_group* g, const size_t k) {
 		&d.shell };
 }
 static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1) {
+	GROUP_TRY(group_x_face_ready(g, k));
 	return step_launch(group_step_ctx(g, k), pl.wf, t0, t1);
 }
 static int domain_separate_stats(luw_group* g, const size_t k) { return step_separate_stats(group_step_ctx(g, k)); }
@@ -418,6 +431,10 @@ static int domain_run_threaded(luw_group* g, const size_t k, const uint64_t step
 	for(uint64_t i=0ull; i<steps; i++) {
 		GroupStepPlan pl;
 		GROUP_TRY(domain_plan_step(g, k, i, steps, first_sample, stride, pl));
+		if(group_x_direct(g, k)) { // the neighbours have enqueued (and recorded) the x unpack of the previous exchange: domain_launch_step may wait for it
+			if(!group_wait_seq(&g->dom[d.nbr[0][0]].unpacked_seq[0][0], X0+i, T.abort)||!group_wait_seq(&g->dom[d.nbr[0][1]].unpacked_seq[0][0], X0+i, T.abort))
+				return LUW_ERR_STATE;
+		}
 		GROUP_TRY(domain_launch_step(g, k, pl, tev ? (*tev)[2u*i] : nullptr, tev ? (*tev)[2u*i+1u] : nullptr));
 		GROUP_TRY(domain_exchange_threaded(g, k, false, !g->overlap, X0+i+1ull, T));
 		if(g->thermal) GROUP_TRY(domain_exchange_threaded(g, k, true, !g->overlap, X0+i+1ull, T));
@@ -705,6 +722,11 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 		g_device_is_shared = false;
 		GROUP_TRY(rc);
 		group_boxes(g.get(), d);
+		if(g->H[0]) { // the step kernels write the x faces themselves (luw_set_x_face_buffers): into the neighbours' receive buffers, or into the send buffers
+			void* fp = group_x_direct(g.get(), i) ? g->dom[d.nbr[0][0]].recv[0][1] : d.send[0][0];
+			void* fm = group_x_direct(g.get(), i) ? g->dom[d.nbr[0][1]].recv[0][0] : d.send[0][1];
+			GROUP_TRY(luw_set_x_face_buffers(d.s, fp, fm));
+		}
 	}
 	*out = g.release();
 	return LUW_OK;

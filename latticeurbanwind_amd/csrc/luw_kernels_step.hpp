@@ -126,11 +126,15 @@ template<typename T> struct CellAddr<T, true> {
 // STATS: this step is a statistics sample (stats_welford, luw_kernels_common.hpp); product MODE 0 only.
 // NATIVE (FP16C, LUW_OPT_NATIVE_ARITH): the pair kernel's native-arithmetic collision (collide_cell_pk_native) on this kernel's one cell per lane -- the rows
 // too narrow or unaligned for the pair kernel, so that a native run is native everywhere.
-template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false, bool NATIVE=false>
+// XFACE (x-split domains, luw_set_x_face_buffers): the cells of the first / last owned x column also put their five outgoing populations into the face
+// buffers -- element (b A + a), a = y + z Ny, b as in FX/kernel.cpp:2223-2229: exactly what transfer_extract_fi (k_extract_fi, direction 0) would copy out
+// of the lattice behind this kernel, one element per 128-byte line.  A cell of those columns that is not collided (TYPE_S / TYPE_G) forwards what its
+// slots hold, like the extract kernel: the populations a fluid cell beyond the cut pushed into it come back that way (bounce-back across a cut).
+template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false, bool NATIVE=false, bool XFACE=false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8)))
 void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr,
-		const StatsArgs S = StatsArgs{}) {
+		const StatsArgs S = StatsArgs{}, T* __restrict__ xf_p = nullptr, T* __restrict__ xf_m = nullptr) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
 	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
@@ -145,8 +149,28 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 	const uint32_t n = a.n;
 	const uint8_t flagsn = flags[n];
 	const size_t Np = p.Np;
+	// XFACE: the face buffers' element of this cell, and the five values (b = 0..4: populations 1, 7, 13, 9, 15 towards +x, their partners 2, 8, 14, 10, 16
+	// towards -x) as value_of(i) hands them over
+	[[maybe_unused]] auto xface_out = [&](auto value_of) {
+		const size_t A = (size_t)p.Ny*p.Nz, e = (size_t)y+(size_t)z*p.Ny;
+		if(x==p.Nx-2u) { xf_p[e] = value_of(1); xf_p[A+e] = value_of(7); xf_p[2u*A+e] = value_of(13); xf_p[3u*A+e] = value_of(9); xf_p[4u*A+e] = value_of(15); }
+		if(x==1u) { xf_m[e] = value_of(2); xf_m[A+e] = value_of(8); xf_m[2u*A+e] = value_of(14); xf_m[3u*A+e] = value_of(10); xf_m[4u*A+e] = value_of(16); }
+	};
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) {
 		if constexpr(STATS) stats_hold_constant_cell(Np, S, n, rho, u);
+		if constexpr(XFACE) { // forward what the slots hold: population i sits in slot B(i) of the +c_i neighbour, its partner i + 1 in slot A(i) of the cell
+			if(x==p.Nx-2u||x==1u) {
+				T held[19];
+				static_for_pairs([&](auto ic) {
+					constexpr int i = decltype(ic)::value;
+					if constexpr(i==1||i==7||i==9||i==13||i==15) {
+						held[i] = ldo<false>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>());
+						held[i+1] = ldo<false>(fi+(size_t)slotA<PARITY>(i)*Np, a.own());
+					}
+				});
+				xface_out([&](const int i) { return held[i]; });
+			}
+		}
 		return;
 	}
 	float f[19];
@@ -211,6 +235,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 			sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), (T)(c[i]>>16));
 			sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), (T)(c[i+1]>>16));
 		});
+		if constexpr(XFACE) xface_out([&](const int i) { return (T)(c[i]>>16); });
 		return;
 	}
 	if constexpr(MODE==4) {
@@ -223,6 +248,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		sto<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), ddf_encode<T>(f[i]));
 		sto<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), ddf_encode<T>(f[i+1]));
 	});
+	if constexpr(XFACE) xface_out([&](const int i) { return ddf_encode<T>(f[i]); });
 }
 
 // ---------------------------------------------------------------- pair kernel: 2 cells per lane (FP16C DDFs)
@@ -329,13 +355,15 @@ constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force 
 // +x, +y, +z: the +x plane on a 2-byte boundary like the five x+1 planes of the D3Q19 lattice), the cell update of luw_device.hpp (thermal_cell)
 // behind each collision with the velocity before the force shift, the seven codes of both cells merged per plane at the tail.
 // NATIVE (LUW_OPT_NATIVE_ARITH): the collision in the hardware's own arithmetic (collide_cell_pk_native, luw_device.hpp); same memory path, same codec.
-template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false, bool NATIVE=false>
+// XFACE: see k_stream_collide_s.  Here the first owned column (x = 1) is cell x of its lane, the last (x = Nx - 2) cell x + 1 of its lane.
+template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false, bool NATIVE=false, bool XFACE=false>
 __global__ __launch_bounds__(256)
 	__attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL, NATIVE), pair_waves(FORCE, PARK, THERMAL, NATIVE))))
 void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{},
-		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr) {
+		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, uint16_t* __restrict__ xf_p = nullptr, uint16_t* __restrict__ xf_m = nullptr) {
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
+	static_assert(!XFACE||(!THERMAL&&!STATS&&MODE==0), "x-face output: plain steps of the D3Q19 lattice");
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
 	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
 	constexpr bool OWN = LUW_PAIR_OWN_EARLY!=0 && !PRE;
@@ -368,10 +396,23 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		smp.has[c] = false;
 		if(!(c==1&&tail) && !cell_is_halo(p, x+c, y, z)) sample_from_fields(c);
 	};
+	[[maybe_unused]] const size_t xfA = (size_t)p.Ny*p.Nz, xfe = (size_t)y+(size_t)z*p.Ny;   // XFACE: face area and this row's element of the face buffers
 	if(!proc[0]&&!proc[1]) {
 		if constexpr(STATS) { // two idle cells (solid / halo / padding): constants, stored without arithmetic (stats_hold_constant_cell)
 			if(!cell_is_halo(p, x, y, z)) stats_hold_constant_cell(Np, S, n, rho, u);
 			if(!tail&&!cell_is_halo(p, x+1u, y, z)) stats_hold_constant_cell(Np, S, n+1u, rho, u);
+		}
+		if constexpr(XFACE) { // two cells that are not collided forward what their slots hold (a lane with one live cell does so by its pass-through)
+			static_for_pairs([&](auto ic) {
+				constexpr int i = decltype(ic)::value;
+				if constexpr(i==1||i==7||i==9||i==13||i==15) {
+					constexpr int k = i==1 ? 0 : i==7 ? 1 : i==13 ? 2 : i==9 ? 3 : 4;
+					// first column (cell x): its own slot A(i) holds population i + 1; last column (cell x + 1): slot B(i) of its +c_i neighbour, at x + 2,
+					// holds i
+					if(x==1u) xf_m[(size_t)k*xfA+xfe] = fi[(size_t)slotA<PARITY>(i)*Np+x];
+					if(x+3u==p.Nx) xf_p[(size_t)k*xfA+xfe] = *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)+(x+2u));
+				}
+			});
 		}
 		return;
 	}
@@ -552,6 +593,16 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 			float a;
 			if constexpr(PARK) a = __uint_as_float(slot[64*(19+q)]); else a = ga[q];
 			cg[q] = __builtin_amdgcn_perm(fp16c_code_hi_in_rtz_mode(gb[q]), fp16c_code_hi_in_rtz_mode(a), 0x07060302u);
+		}
+	}
+	if constexpr(XFACE) { // codes sit in the high halves: ca = cell x, cb = cell x + 1
+		if(x==1u) {
+			xf_m[xfe] = (uint16_t)(ca[2]>>16); xf_m[xfA+xfe] = (uint16_t)(ca[8]>>16); xf_m[2u*xfA+xfe] = (uint16_t)(ca[14]>>16);
+			xf_m[3u*xfA+xfe] = (uint16_t)(ca[10]>>16); xf_m[4u*xfA+xfe] = (uint16_t)(ca[16]>>16);
+		}
+		if(x+3u==p.Nx) {
+			xf_p[xfe] = (uint16_t)(cb[1]>>16); xf_p[xfA+xfe] = (uint16_t)(cb[7]>>16); xf_p[2u*xfA+xfe] = (uint16_t)(cb[13]>>16);
+			xf_p[3u*xfA+xfe] = (uint16_t)(cb[9]>>16); xf_p[4u*xfA+xfe] = (uint16_t)(cb[15]>>16);
 		}
 	}
 	auto pack = [&](const int q) { return __builtin_amdgcn_perm(cb[q], ca[q], 0x07060302u); };

@@ -232,6 +232,10 @@ class HipDomain:
         for a in layout.split_axes():
             A = self.lbm.area(a)
             self.buf[a] = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(4)]  # send_p, send_m, recv_p, recv_m
+            if a == 0 and os.environ.get("LUW_X_FACE_FUSED", "1") != "0":
+                # the step kernels that hold the first / last owned x column write the x faces into the send buffers themselves; extract(0) then has
+                # nothing to launch (LUW_X_FACE_FUSED=0: the pack kernel as before, A/B switch)
+                self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
             if self.thermal:
                 self.gbuf[a] = [torch.zeros(A, dtype=self.dtype, device=self.device) for _ in range(4)]
 

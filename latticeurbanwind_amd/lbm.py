@@ -197,6 +197,7 @@ class LBM:
         capi.check(self._L.luw_stats_begin_sample(self._h, C.byref(fused)))
         return bool(fused.value)
     def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
+    def set_x_face_buffers(self, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_set_x_face_buffers(self._h, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_extract_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_gi(self._h, direction, buf_p_ptr, buf_m_ptr))

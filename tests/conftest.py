@@ -9,6 +9,25 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
         sys.path.insert(0, p)
 
 
+def usable_cores():
+    """cores this process may really use: the affinity mask capped by the cgroup's CPU quota (os.cpu_count() reports the whole host inside a container)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# The CPU oracle is OpenMP code, and libgomp sizes its team from the HOST's core count: on a GPU box whose container owns 16 of 200 cores every parallel
+# region of the oracle would start ~200 threads that spin on 16 cores (a 48x20x12 lattice then takes 125 ms per step; GPU suite of round 3: 13.5 minutes,
+# most of it this).  Set before the library is loaded: as many threads as cores we may use, and waiting threads that sleep instead of spinning.
+os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

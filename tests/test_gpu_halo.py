@@ -119,3 +119,51 @@ def test_rccl_transport_through_self_send_recv(dt):
         LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_nccl_self.py"), dt], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "fields identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("fp16c,native,Nx", [(False, False, 40), (True, False, 322), (True, True, 322)])
+@pytest.mark.parametrize("forces", ["none", "zones+coriolis"])
+def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c, native, Nx, forces):
+    """luw_set_x_face_buffers: the step kernels that hold the first / last owned x column put that column's five outgoing populations into the face buffers
+    themselves.  Against the pack kernel reading the lattice behind the same step: every element whose source cell is an owned cell -- collided or not
+    (solids on the border columns forward what their slots hold: bounce-back across a cut) -- must be the same value; with the buffers set, the extract
+    call on them launches nothing; sampled steps (no such instantiation) fall back to the pack kernel by themselves."""
+    import torch
+    from helpers import TYPE_S
+    Ny, Nz = 12, 10
+    st = synthetic_state(Nx, Ny, Nz, seed=17, shell=None)
+    flags = st[0].reshape(Nz, Ny, Nx).copy()
+    # solids on both border columns
+    flags[2:5, 3:7, 1] = TYPE_S; flags[4:8, 2:5, Nx - 2] = TYPE_S; flags[6, 6, 1:3] = TYPE_S; flags[3, 8, Nx - 3:Nx - 1] = TYPE_S
+    kw = dict(buffer_nudging=dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1),
+        top_sponge=dict(n_cells=3, inv_tau=0.02)) if "zones" in forces \
+        else {}
+    g = luw.LBM(Nx, Ny, Nz, 0.01, fp16c=fp16c, D=(2, 2, 1), O=(-1, -1, 0), native_arith=native, **kw)
+    if "coriolis" in forces: g.set_coriolis(0.0, 3e-5, 4e-5)
+    g.flags.data[:] = flags.ravel(); g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+    g.run(0)
+    tdt = torch.int16 if fp16c else torch.float32
+    A = g.area(0)
+    fused = [torch.full((5 * A,), 77, dtype=tdt, device="cuda") for _ in range(2)]
+    plain = [torch.zeros(5 * A, dtype=tdt, device="cuda") for _ in range(2)]
+    g.set_x_face_buffers(fused[0].data_ptr(), fused[1].data_ptr())
+    owned = np.zeros((Nz, Ny), bool); owned[:, 1:Ny - 1] = True                     # source rows that a launch covers (y is split: rows 0 and Ny-1 are halo)
+    sel = np.tile(owned.ravel(), 5)
+    x_slab = 128 if fp16c else 16
+    boxes = [(1, 1 + x_slab, 1, Ny - 1, 0, Nz), (1 + x_slab, Nx - 1 - x_slab, 1, Ny - 1, 0, Nz), (Nx - 1 - x_slab, Nx - 1, 1, Ny - 1, 0, Nz)]
+    for step in range(4):
+        for b in boxes:
+            g.enqueue_stream_collide(b, False)
+        g.enqueue_extract_fi(0, plain[0].data_ptr(), plain[1].data_ptr()); g.finish()          # other buffers: the pack kernel runs
+        for f, p_ in zip(fused, plain):
+            assert np.array_equal(f.cpu().numpy()[sel], p_.cpu().numpy()[sel]), "step %d" % step
+            assert (f.cpu().numpy()[~sel] == 77).all()                                        # rim rows are nobody's: untouched
+        before = [f.clone() for f in fused]
+        g.enqueue_extract_fi(0, fused[0].data_ptr(), fused[1].data_ptr()); g.finish()          # covered by the launches: nothing to do
+        assert all(torch.equal(a, b) for a, b in zip(before, fused))
+        g.increment_time_step(1)
+    # a box that cuts the columns does not cover them: the extract call does the work itself (rim rows included)
+    g.enqueue_stream_collide((1, Nx - 1, 1, Ny // 2, 0, Nz), False); g.enqueue_stream_collide((1, Nx - 1, Ny // 2, Ny - 1, 0, Nz), False)
+    g.enqueue_extract_fi(0, fused[0].data_ptr(), fused[1].data_ptr()); g.enqueue_extract_fi(0, plain[0].data_ptr(), plain[1].data_ptr()); g.finish()
+    assert all(torch.equal(a, b) for a, b in zip(plain, fused))
+    g.close()

@@ -91,8 +91,10 @@ def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
     # FP16C kernel, the pair kernel's three force modes and their three thermal variants: 2 + 6 + 6
     product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb0ELb[01]E", n)
         or re.search(r"k_stream_collide_pILi[01]ELi0ELb0ELi[012]E", n)]
-    assert len(product) == 36, product
-    assert len([n for n in product if n.split("EvN3luw")[0].endswith("Lb1E")]) == 14          # trailing template flag NATIVE
+    # ... and the instantiations with the x-face output (luw_set_x_face_buffers): FP32 flat / row, the pair kernel's three force modes exact and native: 4 + 12
+    assert len(product) == 52, product
+    flags_of = lambda n: re.findall(r"Lb([01])E", n.split("EvN3luw")[0])
+    assert sum(1 for n in product if flags_of(n)[-2] == "1") == 14 + 6 and sum(1 for n in product if flags_of(n)[-1] == "1") == 16      # NATIVE, XFACE
     # the same kernels with the statistics epilogue (sampled steps): no spills either
     sampled = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb1ELb0E", n)
         or re.search(r"k_stream_collide_pILi[01]ELi0ELb1ELi2E", n)]
@@ -102,6 +104,8 @@ def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
     for name in product:
         body = device_asm[name]
         assert not any(t.startswith(("scratch_", "buffer_store", "buffer_load")) for t in body), name + ": spills"
-        ddf_stores = [t for t in body if re.match(r"global_store_(dword|short)", t) and ("nt" in t.split()[-1] or "d16_hi" in t)]
+        # (the x-face output's five stores per border column go to a buffer through plain 64-bit addresses and carry no nt hint)
+        ddf_stores = [t for t in body if re.match(r"global_store_(dword|short)", t) and ("nt" in t.split()[-1] or ("d16_hi" in t and not re.match(
+            r"global_store_\w+ v\[", t)) or flags_of(name)[-1] == "0" and "d16_hi" in t)]
         vaddr = [t for t in ddf_stores if re.match(r"global_store_\w+ v\[", t)]
         assert len(ddf_stores) >= 14 and not vaddr, "%s: DDF stores with 64-bit VGPR addresses: %s" % (name, vaddr[:3])
