@@ -332,6 +332,11 @@ SINGLE_BLOCKS = {"c2_f32": ("c2", "f32", False, False, False), "c2_fp16c": ("c2"
                  "tile512_urban_f32": ("tile512", "f32", False, False, True), "tile512_urban_fp16c_coriolis": ("tile512", "fp16c", True, False, True)}
 
 
+# FP16C blocks that are also measured with the native-arithmetic kernels (the forced / thermal / zone kernels the exact arithmetic costs most, and the
+# plain one as the reference point)
+NATIVE_TWINS = ("c3_fp16c", "c3_fp16c_coriolis", "c3_fp16c_thermal", "tile512_urban_fp16c_coriolis", "c5_rank_4x2x1_fp16c_coriolis")
+
+
 def run_single_block(luw, capi, device, key, native=False):
     wl, dt_, cor, th, urban = SINGLE_BLOCKS[key]
     sz, bld, _ = WORKLOADS[wl]
@@ -348,14 +353,14 @@ RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4
                      "c5_rank_1x4x2_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7)}
 
 
-def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, warmup, native=False):
+def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, warmup, native=False, transport="rccl-self"):
     """One rank of the 2048x1024x512 urban tile (BASELINE configs[3]; configs[4] with FP16C + Coriolis) cut as n_gpu = D, in its real local shape and
     with its real share of the nudging / sponge zones, stepped through the production schedule of a multi-GPU run -- boundary shell on the
     communication stream, pack / exchange / unpack, interior on the compute stream, pipelined steps -- with every face going through the real
     transport to the rank itself (RCCL self send / receive).  D = (1,1,1): the 512^3 tile undivided, the N = 1 point of the scaling curve."""
     import torch.distributed as dist
-    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, SelfExchangeTransport, init_rccl_process_group
-    if not dist.is_initialized():
+    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, SelfExchangeTransport, PeerLoopbackTransport, init_rccl_process_group
+    if transport == "rccl-self" and not dist.is_initialized():
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29539"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", str(device))):
             os.environ.setdefault(k, v)
         init_rccl_process_group(device)
@@ -363,7 +368,7 @@ def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, wa
     gN = (512 * D[0], 512 * D[1], 512 * D[2]) if world > 1 else (512, 512, 512)
     nud, spg = tile_forcing()
     lay = DomainLayout(gN, D, rank)
-    tr = SelfExchangeTransport(lay)
+    tr = SelfExchangeTransport(lay) if transport == "rccl-self" else PeerLoopbackTransport(lay)
     if world > 1:
         tr.warm_up(torch.device("cuda", device), torch.float16 if fp16c else torch.float32)     # connections first, lattice second (as in a real run)
     sim = DomainDecomposedLBM(gN, D, NU, rank=rank, transport=tr, fp16c=fp16c, kernel=kern, device=device, buffer_nudging=nud, top_sponge=spg,
@@ -391,7 +396,9 @@ def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, wa
             "workload": "rank %d of the 2048x1024x512 urban tile as n_gpu=%s" % (rank, list(D)) if world > 1
                 else "512^3 urban tile, undivided (the N = 1 point of the N > 1 lines)",
             "options": "building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" + (" + Coriolis force" if coriolis else ""),
-            "halo_exchange": "RCCL self send / receive of every face (no wire to another device)" if world > 1 else None, "overlap": bool(sim.overlap),
+            "halo_exchange": None if world == 1 else "RCCL self send / receive of every face (no wire to another device)" if transport == "rccl-self"
+                else "peer-loopback: the faces are written straight into the receive buffers the unpack reads (the one-process host's peer stores with the "
+                     "rank as its own neighbour; no copy kernel, no wire)", "transport": transport, "overlap": bool(sim.overlap),
             "kernel_ms": round(tm["kernel_ms"], 4) if tm else None, "shell_ms": None if not tm or tm.get("shell_ms") is None else round(tm["shell_ms"], 4),
             "exchange_ms": None if not tm or tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
             "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": round(bpl * owned / (ms * 1e-3) / 1e9, 1),
@@ -444,6 +451,8 @@ def main():
         help="(used by the N = 1 line itself) measure ONE single-GPU secondary block in this fresh process and print it")
     ap.add_argument("--rank-shape-block", choices=sorted(RANK_SHAPE_BLOCKS), default=None,
         help="(used by the N = 1 line itself) measure ONE rank-shape secondary block in this fresh process and print it")
+    ap.add_argument("--rank-transport", choices=["rccl-self", "peer-loopback"], default="rccl-self",
+        help="--rank-shape-block: how the rank's faces come back to it (RCCL self send / receive, or written in place like the one-process host's peer stores)")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check against the CPU oracle (profiling runs)")
     ap.add_argument("--no-group-host", action="store_true", help="N > 1: skip the one-process multi-domain host block")
     ap.add_argument("--group-host-child", choices=sorted(GROUP_HOST_VARIANTS), default=None,
@@ -494,7 +503,7 @@ def main():
         return
     if args.rank_shape_block:
         blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, native=args.arith == "native",
-            **RANK_SHAPE_BLOCKS[args.rank_shape_block])
+            transport=args.rank_transport, **RANK_SHAPE_BLOCKS[args.rank_shape_block])
         import torch.distributed as dist
         if dist.is_initialized(): dist.destroy_process_group()
         sys.stdout.flush(); os.dup2(saved_stdout, 1)
@@ -545,7 +554,7 @@ def main():
                     sec[key] = {"error": str(e)[:300]}
                 # FP16C blocks: the same block once more with the native-arithmetic kernels (LUW_OPT_NATIVE_ARITH), again in a fresh process; the block's own
                 # numbers are the bit-exact kernels' ("arith": "exact"), the twin sits under "native"
-                if "fp16c" in key and "error" not in sec[key]:
+                if key in NATIVE_TWINS and "error" not in sec[key]:
                     try:
                         r = subprocess.run(
                             [sys.executable, os.path.abspath(__file__), flag, key, "--arith", "native", "--steps", str(SECONDARY_STEPS), "--warmup",
@@ -558,6 +567,20 @@ def main():
                     if "roofline" in nat:
                         sec[key]["native"]["roofline"] = {k: nat["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "kernel_frac")
                             if k in nat["roofline"]}
+                # rank shapes: the same rank once more with its faces written in place (the one-process host's peer stores) instead of RCCL self send / receive
+                if flag == "--rank-shape-block" and "error" not in sec[key]:
+                    try:
+                        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag, key, "--rank-transport", "peer-loopback", "--steps",
+                            str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)], capture_output=True, text=True, timeout=600,
+                            env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+                        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                        tw = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
+                    except Exception as e:
+                        tw = {"error": str(e)[:300]}
+                    sec[key]["peer_loopback"] = {k: tw[k] for k in ("value", "ms_per_step", "transport", "kernel_ms", "shell_ms", "exchange_ms", "error")
+                        if k in tw}
+                    if "roofline" in tw:
+                        sec[key]["peer_loopback"]["roofline"] = {k: tw["roofline"][k] for k in ("achieved", "frac", "kernel_frac") if k in tw["roofline"]}
             out["secondary"] = sec
             # how this box compares: the 512^3 FP32 empty channel is the best-characterised workload of the repo (3.27-3.31 ms in ten fresh processes
             # on the boxes of profiles/r02_placement_study*.txt, 3.29-3.32 ms in every default line of round 3 but one); whole boxes run everything 10-20 %

@@ -85,6 +85,8 @@ def load(path=None):
         if path is not None and os.path.abspath(path) != os.path.abspath(_SO):
             raise LuwError("another libluw_core build is already loaded in this process")
         return _LIB
+    if path is None and os.environ.get("LUW_LIB"):      # A/B scripts: another build of the same sources, named explicitly (never set by the package)
+        path = os.environ["LUW_LIB"]
     if path is not None:
         _SO = path
     if not os.path.exists(_SO):

@@ -167,8 +167,9 @@ extern "C" int luw_group_export_vtk(luw_group* g, int source, const luw_export_p
 		if(from_stats&&!d.s->d_avg_u) return fail(LUW_ERR_STATE, "luw_group_export_vtk: no statistics have been accumulated");
 		if((source==LUW_EXPORT_T&&!d.s->d_T)||(source==LUW_EXPORT_AVG_T&&!d.s->d_avg_T))
 			return fail(LUW_ERR_STATE, "luw_group_export_vtk: the solver has no temperature field");
-		if((source==LUW_EXPORT_U||source==LUW_EXPORT_RHO)&&!d.s->fields_current)
-			return fail(LUW_ERR_STATE, "luw_group_export_vtk: rho,u on the device are stale (the last step did not write fields)");
+		// (T is stored with rho and u: by the steps whose fields are looked at, thermal_cell)
+		if((source==LUW_EXPORT_U||source==LUW_EXPORT_RHO||source==LUW_EXPORT_T)&&!d.s->fields_current)
+			return fail(LUW_ERR_STATE, "luw_group_export_vtk: rho, u, T on the device are stale (the last step did not write fields)");
 	}
 	if(source==LUW_EXPORT_TLS&&prm->want_tls&&g->dom.size()>1u) // the stencil reads the mean velocity of cells next door
 		GROUP_TRY(group_fill_field_halos(g, [](luw_solver* s) { return s->d_avg_u; }, 3u));

@@ -174,6 +174,24 @@ class SelfExchangeTransport(TorchDistTransport):
         self.layout = type("SelfNeighbours", (), {"neighbor": staticmethod(lambda axis, sign: me), "lN": layout.lN, "split_axes": layout.split_axes})()
 
 
+class PeerLoopbackTransport:
+    """every neighbour is THIS rank and no transport at all: the face buffers a step fills ARE the buffers its unpack reads (HipDomain(alias_faces=True):
+    the + face is written where "what came from the - side" is read, and vice versa) -- what the one-process host's peer stores do between two domains
+    (csrc/luw_group.hpp: the pack kernel, or the step kernels themselves for the x faces, write straight into the neighbour's receive buffer), with the
+    rank as its own neighbour.  Physically the rank's block made periodic, like SelfExchangeTransport, minus RCCL's copy kernels: bench.py's rank-shape
+    blocks carry both, so that what a rank pays for the transport is on the line."""
+    alias_faces = True
+
+    def __init__(self, layout):
+        self.layout = layout
+
+    def exchange(self, axis, send_p, send_m, recv_p, recv_m):
+        assert send_p.data_ptr() == recv_m.data_ptr() and send_m.data_ptr() == recv_p.data_ptr()
+
+    def warm_up(self, device, dtype=None, measure=0):
+        return {}
+
+
 def init_rccl_process_group(local_rank, timeout=None):
     """`torch.distributed` over RCCL for one process per GPU.  RCCL's point-to-point kernels are launched while the interior
     collide-stream kernel fills every CU, so the process group's internal stream is asked to be a high-priority one (like the
@@ -210,7 +228,7 @@ class HostStagedTransport(TorchDistTransport):
 class HipDomain:
     """One LBM domain on one GPU through the C-ABI; buffers are torch CUDA tensors, work is enqueued on torch streams."""
 
-    def __init__(self, layout, nu, fp16c=False, kernel=0, device=0, **kw):
+    def __init__(self, layout, nu, fp16c=False, kernel=0, device=0, alias_faces=False, **kw):
         import torch
         from .lbm import LBM
         self.torch = torch
@@ -232,12 +250,16 @@ class HipDomain:
         for a in layout.split_axes():
             A = self.lbm.area(a)
             self.buf[a] = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(4)]  # send_p, send_m, recv_p, recv_m
+            if alias_faces:      # PeerLoopbackTransport: the rank is its own neighbour and the faces are written where they are read
+                self.buf[a][0], self.buf[a][1] = self.buf[a][3], self.buf[a][2]
             if a == 0 and os.environ.get("LUW_X_FACE_FUSED", "1") != "0":
                 # the step kernels that hold the first / last owned x column write the x faces into the send buffers themselves; extract(0) then has
                 # nothing to launch (LUW_X_FACE_FUSED=0: the pack kernel as before, A/B switch)
                 self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
             if self.thermal:
                 self.gbuf[a] = [torch.zeros(A, dtype=self.dtype, device=self.device) for _ in range(4)]
+                if alias_faces:
+                    self.gbuf[a][0], self.gbuf[a][1] = self.gbuf[a][3], self.gbuf[a][2]
 
     # host fields (reference layout, local box incl. halos)
     def set_fields(self, flags, u, rho, T=None):
@@ -372,7 +394,7 @@ class DomainDecomposedLBM:
                 self.wire = transport.warm_up(torch.device("cuda", backend_kw.get("device", 0)), torch.float16 if backend_kw.get("fp16c") else torch.float32,
                                               measure=int(os.environ.get("LUW_MEASURE_WIRE", "0")))
         self.transport = transport
-        self.backend = backend if backend is not None else HipDomain(self.layout, nu, **backend_kw)
+        self.backend = backend if backend is not None else HipDomain(self.layout, nu, alias_faces=getattr(transport, "alias_faces", False), **backend_kw)
         if overlap is None:
             # Shell/interior overlap.  x kept whole (whole-row shells): always.  x split: the 64-cell x slabs cost the step 4 %
             # (512^3 rank of n_gpu=[4,2,1] with pipelined steps: 3.94-3.98 ms against 3.78-3.89 for whole box + exchange when the

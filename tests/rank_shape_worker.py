@@ -4,7 +4,8 @@ halo faces through the real RCCL transport -- a one-rank world whose every neigh
 bit with the CPU oracle stepping the SAME haloed domain (same decomposition parameters D, O; its own extract / swap / insert
 following FX/lbm.cpp:1907-1935).  Physically: the rank's block made periodic.  tests/ only (imports the oracle).
 
-usage: rank_shape_worker.py <f32|fp16c> <bx by bz> <Dx Dy Dz> <rank> <steps> [bld] [forcing] [cor]"""
+usage: rank_shape_worker.py <f32|fp16c> <bx by bz> <Dx Dy Dz> <rank> <steps> [bld] [forcing] [cor] [peer]
+(peer: PeerLoopbackTransport instead of RCCL -- the faces are written where the unpack reads them)"""
 import os
 import sys
 
@@ -40,7 +41,11 @@ def main():
             self.layout = type("L", (), {"neighbor": staticmethod(lambda axis, sign: 0), "lN": layout.lN, "split_axes": layout.split_axes})()
 
     lay = DomainLayout(gN, D, rank)
-    tr = SelfNeighbour(lay)
+    if "peer" in opts:
+        from latticeurbanwind_amd.distributed import PeerLoopbackTransport
+        tr = PeerLoopbackTransport(lay)
+    else:
+        tr = SelfNeighbour(lay)
     tr.warm_up(torch.device("cuda", 0), torch.float16 if fp16c else torch.float32)      # connections first, lattice second (as in a real run)
     kw = dict(buffer_nudging=nud, top_sponge=spg) if nud else {}
     sim = DomainDecomposedLBM(gN, D, NU, rank=rank, transport=tr, fp16c=fp16c, device=0, **kw)

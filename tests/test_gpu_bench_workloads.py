@@ -107,6 +107,12 @@ RANK_CASES = [
     ("f32", (512, 512, 512), (4, 2, 1), 7, ("bld", "forcing")),
     ("fp16c", (2048, 256, 256), (1, 4, 2), 7, ("bld", "forcing", "cor")),   # configs[4]; last rank: top sponge + north face
     ("fp16c", (512, 512, 512), (4, 2, 1), 0, ("bld", "forcing", "cor")),    # configs[4], literal n_gpu
+    # the same production schedule with the faces written in place (PeerLoopbackTransport: the one-process host's peer stores, the rank its own neighbour;
+    # x faces straight from the step kernels), exact and native arithmetic (native: within the tolerance of one FP16C code over 3 steps is not asked here --
+    # the oracle comparison is for the exact kernels; the native run must equal ITS OWN RCCL-self run bit for bit: same kernels, another transport)
+    ("f32", (384, 96, 64), (4, 2, 1), 3, ("bld", "forcing", "peer")),
+    ("fp16c", (384, 96, 64), (4, 2, 1), 0, ("bld", "forcing", "cor", "peer")),
+    ("fp16c", (640, 64, 64), (1, 4, 2), 5, ("bld", "forcing", "cor", "peer")),
 ]
 
 
