@@ -189,7 +189,8 @@ def cpu_model():
 
 
 def cpu_baseline(max_seconds=20.0):
-    """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port") timed on this box's host cores on a bounded
+    """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port"; its row-wise path: the same operations per cell as the literal
+    path, eight cells per AVX2 statement, indices by addition -- oracle/luw_oracle.c, bit-identical to the literal path) timed on this box's host cores on a bounded
     sample of the benchmark recipe: 256^3 channel, FP32 DDFs, as many steps as fit into max_seconds.  The thread
     count is the fastest of a short sweep (over-subscription inside a CPU-limited container is disastrous).  Reported with the
     CPU model and the DRAM bandwidth it amounts to: the restatement moves 169 B per lattice update like the reference's
@@ -219,6 +220,7 @@ def cpu_baseline(max_seconds=20.0):
     return {"value": round(mlups, 1), "unit": "MLUPS", "cores": best_t, "kind": "port", "cpu_model": cpu_model(),
             "dram_GBps": round(mlups * 169.0 / 1e3, 1), "copy_bandwidth_GBps": round(copy_gbps, 1),
                 "dram_frac_of_copy": round(mlups * 169.0 / 1e3 / copy_gbps, 3) if copy_gbps else None,
+            "path": "row-wise (AVX2, 8 cells per statement; bit-identical to the literal one-cell-at-a-time path)" if oracle.fast_available() else "literal",
             "sample": "%d steps of a 256^3 FP32 channel (same recipe as the GPU workloads, 169 B per update incl. rho,u every step) in %.1f s, OpenMP threads "
                 "swept over %s of %d usable cores" % (steps, dt, cands, cores)}
 
@@ -503,7 +505,7 @@ def main():
         return
     if args.rank_shape_block:
         blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, native=args.arith == "native",
-            transport=args.rank_transport, **RANK_SHAPE_BLOCKS[args.rank_shape_block])
+            transport=os.environ.get("BENCH_RANK_TRANSPORT", args.rank_transport), **RANK_SHAPE_BLOCKS[args.rank_shape_block])
         import torch.distributed as dist
         if dist.is_initialized(): dist.destroy_process_group()
         sys.stdout.flush(); os.dup2(saved_stdout, 1)

@@ -169,15 +169,19 @@ static void dev_block_pieces(const DevBlock& b, const size_t mapped, std::vector
 // the whole reserved range in one call (and ignored the return code): the pieces behind the first stayed mapped while their handles were released and the
 // address range freed, which is what made a release in the middle of luw_create crash a later one (tools/vmm_unmap_repro.hip shows both sequences).
 // The device is idle first: nothing in flight may still address the block.
-static void dev_free(DevBlock& b) {
+// keep_range: the physical memory goes back now, the (empty) address range stays reserved until a later dev_free of the same block -- a candidate of the
+// placement search is released this way, so that the next candidate never lands on addresses whose page-table entries were torn down a moment ago.
+static void dev_free(DevBlock& b, const bool keep_range = false) {
 	if(!b.base) return;
 	(void)hipDeviceSynchronize();
-	if(b.chunks.empty()) (void)hipFree(b.base);
+	if(b.chunks.empty()&&b.chunk_bytes==0u) (void)hipFree(b.base);
 	else {
 		std::vector<std::pair<size_t, size_t>> pieces;
 		dev_block_pieces(b, b.bytes, pieces);
 		for(const auto& pc : pieces) (void)hipMemUnmap((char*)b.base+pc.first, pc.second);
 		for(auto& h : b.chunks) (void)hipMemRelease(h);
+		b.chunks.clear();
+		if(keep_range) { (void)hipGetLastError(); return; }           // chunk_bytes != 0 marks the block as "a reserved range, nothing mapped"
 		(void)hipMemAddressFree(b.base, b.bytes);
 	}
 	(void)hipGetLastError();
@@ -303,7 +307,7 @@ template<typename E> __global__ __launch_bounds__(256) void k_rows_copy(E* __res
 	if(to_lattice) *l = *t; else *t = *l;
 }
 static const DevBlock* block_of(const luw_solver* s, const void* p) {
-	for(const DevBlock& b : s->raw) if((const char*)p>=(const char*)b.base&&(const char*)p<(const char*)b.base+b.bytes) return &b;
+	for(const DevBlock& b : s->raw) if((const char*)p>=(const char*)b.base&&(const char*)p<(const char*)b.base+b.bytes&&!(b.chunks.empty()&&b.chunk_bytes)) return &b;
 	return nullptr;
 }
 static int copy_pitched(void* dst, const void* src, const size_t elem, luw_solver* s, const uint32_t planes, const bool to_device, hipStream_t st) {
@@ -703,6 +707,9 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 // LUW_TUNE_PLACEMENT=0) -- concurrent probes would time each other.
 static std::atomic<int> g_live_solvers[64];
 static thread_local bool g_device_is_shared = false;
+constexpr size_t PLACEMENT_UNSET = ~(size_t)0u-1u;     // g_placement_kind: chunk size the process's search kept for this device (0: hipMalloc)
+static std::atomic<size_t> g_placement_kind[64];
+static struct PlacementKindInit { PlacementKindInit() { for(auto& k : g_placement_kind) k.store(PLACEMENT_UNSET); } } g_placement_kind_init;
 static const char* dev_block_kind(const DevBlock& b) {
 	if(b.chunks.empty()) return "hipMalloc";
 	return b.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : b.chunk_bytes>=(1024ull<<20) ? "1 GiB chunks" : b.chunk_bytes>=(512ull<<20) ? "512 MiB chunks"
@@ -712,13 +719,16 @@ static int tune_ddf_placement(luw_solver* s) {
 	const Tuning& T = tuning();
 	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
 	const bool mapped = !s->raw.front().chunks.empty();
-	s->placement_kept = std::string(dev_block_kind(s->raw.front()))+" (no search)";
+	if(s->placement_kept=="default (no search)") s->placement_kept = std::string(dev_block_kind(s->raw.front()))+" (no search)";
 	constexpr int NALT = 3;
 	const size_t alternatives[NALT] = { 2048ull<<20, 0u, 512ull<<20 };   // chunk sizes behind the default's 1 GiB (0: hipMalloc)
 	const int candidates = std::min(T.placement_candidates>=0 ? T.placement_candidates : 1+NALT, 1+NALT);
 	if(bytes<(1ull<<30)||candidates<2||!mapped) return LUW_OK;
 	if(T.placement_candidates<0&&s->kp.Np*s->ddf_bytes>(3ull<<29)) return LUW_OK;
 	if(g_device_is_shared||(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1)) return LUW_OK;
+	// ONE search per process and device: which kind of allocation is the fast one is a property of the machine (and of the process's allocation history),
+	// not of the solver -- later large solvers of the process are allocated as the first one's winner straight away (luw_create, g_placement_kind)
+	if(s->cfg.device<64&&g_placement_kind[s->cfg.device].load()!=PLACEMENT_UNSET) return LUW_OK;
 	// the box a step launches: every non-halo cell (the FP16C pair kernel needs its pairs to start at the first owned cell of an x-split row)
 	const Box box = { s->kp.halo_x, s->cfg.Nx-s->kp.halo_x, s->kp.halo_y, s->cfg.Ny-s->kp.halo_y, s->kp.halo_z, s->cfg.Nz-s->kp.halo_z };
 	struct Events { hipEvent_t e0 = nullptr, e1 = nullptr; ~Events() { if(e0) (void)hipEventDestroy(e0); if(e1) (void)hipEventDestroy(e1); } } ev;
@@ -765,9 +775,13 @@ static int tune_ddf_placement(luw_solver* s) {
 			dev_block_kind(cand), ms, rate(ms)*1e-12, best_ms);
 		if(ms<best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
 		else s->d_fi = old_fi;
-		dev_free(cand);                                                   // the loser goes before the next candidate comes
+		// the loser's memory goes before the next candidate comes; a mapped loser's (now empty) address range goes with the solver
+		const bool was_mapped = !cand.chunks.empty();
+		dev_free(cand, was_mapped);
+		if(was_mapped) s->raw.push_back(std::move(cand));
 	}
 	s->placement_kept = dev_block_kind(s->raw.front()); s->placement_tbps = rate(best_ms)*1e-12;
+	if(s->cfg.device<64) g_placement_kind[s->cfg.device].store(s->raw.front().chunks.empty() ? (size_t)0u : s->raw.front().chunk_bytes);
 	// the probe steps left zeros, but be explicit
 	HIP_TRY(hipMemsetAsync(s->raw.front().base, 0, std::min(s->raw.front().bytes, bytes+64u*s->ddf_bytes), s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -919,7 +933,12 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	if(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking)!=hipSuccess) return oom("stream");
 	s->stream = s->own_stream;
 	// (memset inside lead_alloc runs on the solver's own non-blocking stream: the legacy NULL stream does not order against it)
-	if(lead_alloc(s, &s->d_fi, 19ull*Np, s->ddf_bytes)!=hipSuccess) return oom("fi");
+	{	// a DDF array of the size the placement search looks at, in a process whose search has already settled on a kind for this device: that kind
+		const size_t kind = cfg->device<64 ? g_placement_kind[cfg->device].load() : PLACEMENT_UNSET;
+		const bool reuse = kind!=PLACEMENT_UNSET && alloc_vmm_chunk()!=0u && 19ull*Np*s->ddf_bytes>=(1ull<<30) && Np*s->ddf_bytes<=(3ull<<29);
+		if(lead_alloc(s, &s->d_fi, 19ull*Np, s->ddf_bytes, reuse ? &kind : nullptr)!=hipSuccess) return oom("fi");
+		if(reuse) s->placement_kept = std::string(dev_block_kind(s->raw.front()))+" (the kind this process's first search kept)";
+	}
 	if(lead_alloc(s, (void**)&s->d_rho, Np, 4u)!=hipSuccess) return oom("rho");
 	if(lead_alloc(s, (void**)&s->d_u, 3ull*Np, 4u)!=hipSuccess) return oom("u");
 	if(lead_alloc(s, (void**)&s->d_flags, Np, 1u)!=hipSuccess) return oom("flags");

@@ -15,8 +15,13 @@ from helpers import synthetic_state
 fp16c = len(sys.argv) > 1 and sys.argv[1] == "fp16c"
 Nx, Ny, Nz = (512, 256, 512) if fp16c else (512, 256, 256)         # 19 planes of 64 / 32 M cells: 2.5 GB either way
 st = synthetic_state(Nx, Ny, Nz, seed=5, shell="luw")
+import torch
+from latticeurbanwind_amd import capi
 for cycle in range(2):
+    free0 = torch.cuda.mem_get_info(0)[0]
     g = luw.LBM(Nx, Ny, Nz, 1e-4, fp16c=fp16c)
+    print("placement", capi.placement_info(g._h), flush=True)
+    print("device memory used by the solver %.2f GB" % ((free0 - torch.cuda.mem_get_info(0)[0]) / 1e9), flush=True)
     o = oracle.OracleLBM(Nx, Ny, Nz, 1e-4, fp16c=fp16c)
     g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
     o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]
