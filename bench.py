@@ -190,8 +190,8 @@ def cpu_model():
 
 def cpu_baseline(max_seconds=20.0):
     """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port"; its row-wise path: the same operations per cell as the literal
-    path, eight cells per AVX2 statement, indices by addition -- oracle/luw_oracle.c, bit-identical to the literal path) timed on this box's host cores on a bounded
-    sample of the benchmark recipe: 256^3 channel, FP32 DDFs, as many steps as fit into max_seconds.  The thread
+    path, eight cells per AVX2 statement, indices by addition -- oracle/luw_oracle.c, bit-identical to the literal path) timed on this box's host
+    cores on a bounded sample of the benchmark recipe: 256^3 channel, FP32 DDFs, as many steps as fit into max_seconds.  The thread
     count is the fastest of a short sweep (over-subscription inside a CPU-limited container is disastrous).  Reported with the
     CPU model and the DRAM bandwidth it amounts to: the restatement moves 169 B per lattice update like the reference's
     UPDATE_FIELDS kernel (153 + 16 for rho,u every step), set against a copy-kernel bandwidth measured with the same threads."""

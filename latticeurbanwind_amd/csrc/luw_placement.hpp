@@ -1,0 +1,97 @@
+// luw_placement.hpp -- luw_create's placement search for the DDF array.  Included by luw_core.hip only, after luw_launch.hpp.
+#pragma once
+
+// Where the driver places the DDF array physically changes the step time of this 19-stream kernel by 10-14 % on MI355X: allocations of the same size come
+// out in classes that last for the life of the allocation (512^3 FP32: 3.3 or 3.75 ms per step; tools/placement_probe.py, tools/chunk_study.sh), and WHICH
+// kind of allocation is of the fast class depends on the box: 1 GiB chunks on most, 2 GiB chunks or a plain hipMalloc on others
+// (profiles/r03_chunk_study_slow_box.txt).  Large solvers therefore time the real kernel on their DDF array -- the box the step launches (non-halo cells),
+// zero DDFs = rest state, flags 0 = all fluid: a valid, full-cost step -- and, while the rate is under the bar of the fast class, try the OTHER kinds, once
+// each: 2 GiB chunks, hipMalloc, 512 MiB chunks.  Bounded: at most three further candidates, ONE extra array alive at a time, every loser released before
+// the next candidate is mapped and nothing of the search left when luw_create returns (placement_kept / placement_tbps / placement_tried say what
+// happened; bench.py prints them). Skipped for small lattices, for planes of 2 GiB and more (1024^3 runs alike on every kind,
+// profiles/r02_placement_study.txt),
+// when the device has no room for a second DDF array, and when the device is shared: other solvers of this process live on it (g_live_solvers), or the
+// caller says so (luw_group_create for devices that host several domains: thread-local g_device_is_shared; rank processes sharing one GPU set
+// LUW_TUNE_PLACEMENT=0) -- concurrent probes would time each other.
+static std::atomic<int> g_live_solvers[64];
+static thread_local bool g_device_is_shared = false;
+constexpr size_t PLACEMENT_UNSET = ~(size_t)0u-1u;     // g_placement_kind: chunk size the process's search kept for this device (0: hipMalloc)
+static std::atomic<size_t> g_placement_kind[64];
+static struct PlacementKindInit { PlacementKindInit() { for(auto& k : g_placement_kind) k.store(PLACEMENT_UNSET); } } g_placement_kind_init;
+static const char* dev_block_kind(const DevBlock& b) {
+	if(b.chunks.empty()) return "hipMalloc";
+	return b.chunk_bytes>=(2048ull<<20) ? "2 GiB chunks" : b.chunk_bytes>=(1024ull<<20) ? "1 GiB chunks" : b.chunk_bytes>=(512ull<<20) ? "512 MiB chunks"
+		: "chunks under 512 MiB";
+}
+static int tune_ddf_placement(luw_solver* s) {
+	const Tuning& T = tuning();
+	const size_t elems = 19ull*s->kp.Np, bytes = elems*s->ddf_bytes;
+	const bool mapped = !s->raw.front().chunks.empty();
+	if(s->placement_kept=="default (no search)") s->placement_kept = std::string(dev_block_kind(s->raw.front()))+" (no search)";
+	constexpr int NALT = 3;
+	const size_t alternatives[NALT] = { 2048ull<<20, 0u, 512ull<<20 };   // chunk sizes behind the default's 1 GiB (0: hipMalloc)
+	const int candidates = std::min(T.placement_candidates>=0 ? T.placement_candidates : 1+NALT, 1+NALT);
+	if(bytes<(1ull<<30)||candidates<2||!mapped) return LUW_OK;
+	if(T.placement_candidates<0&&s->kp.Np*s->ddf_bytes>(3ull<<29)) return LUW_OK;
+	if(g_device_is_shared||(s->cfg.device<64&&g_live_solvers[s->cfg.device].load()>1)) return LUW_OK;
+	// ONE search per process and device: which kind of allocation is the fast one is a property of the machine (and of the process's allocation history),
+	// not of the solver -- later large solvers of the process are allocated as the first one's winner straight away (luw_create, g_placement_kind)
+	if(s->cfg.device<64&&g_placement_kind[s->cfg.device].load()!=PLACEMENT_UNSET) return LUW_OK;
+	// the box a step launches: every non-halo cell (the FP16C pair kernel needs its pairs to start at the first owned cell of an x-split row)
+	const Box box = { s->kp.halo_x, s->cfg.Nx-s->kp.halo_x, s->kp.halo_y, s->cfg.Ny-s->kp.halo_y, s->kp.halo_z, s->cfg.Nz-s->kp.halo_z };
+	struct Events { hipEvent_t e0 = nullptr, e1 = nullptr; ~Events() { if(e0) (void)hipEventDestroy(e0); if(e1) (void)hipEventDestroy(e1); } } ev;
+	HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
+	auto step_ms = [&](float& ms) -> int { // two steps (both parities) after one untimed
+		struct Restore { luw_solver* s; ~Restore() { s->initialized = false; s->t = 0ull; } } restore{ s };
+		s->initialized = true; s->t = 0ull;
+		if(int e = launch_stream_collide(s, box, 0)) return e;
+		s->t = 1ull;
+		HIP_TRY(hipEventRecord(ev.e0, s->stream));
+		if(int e = launch_stream_collide(s, box, 0)) return e;
+		s->t = 2ull;
+		if(int e = launch_stream_collide(s, box, 0)) return e;
+		HIP_TRY(hipEventRecord(ev.e1, s->stream));
+		HIP_TRY(hipEventSynchronize(ev.e1));
+		HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+		return LUW_OK;
+	};
+	// a placement of the fast class moves this many algorithmic bytes per second through the probe (FP32 153, FP16C 77 B per update, + the thermal planes;
+	// FP16C with zones: the general kernel is VALU-bound).  LUW_TUNE_FAST=<TB/s> overrides the bar (99: every candidate is tried)
+	const double cells = (double)(box.x1-box.x0)*(double)(box.y1-box.y0)*(double)(box.z1-box.z0);
+	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*cells;
+	const double bar = T.placement_bar>0.0 ? T.placement_bar*1e12 : (s->ddf_bytes==4u ? 6.25e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
+	auto rate = [&](const float ms) { return probe_bytes/((double)ms*1e-3); };
+	float best_ms = 0.0f;
+	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
+	if(int e = step_ms(best_ms)) return e;
+	s->placement_tried = 1;
+	if(T.placement_verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", dev_block_kind(s->raw.front()), best_ms,
+		rate(best_ms)*1e-12);
+	for(int k=1; k<candidates&&rate(best_ms)<bar; k++) {
+		size_t free_b = 0u, total_b = 0u;
+		// room for ONE more array plus what the run may still allocate (statistics: 32 B per cell, staging, halo buffers)
+		if(hipMemGetInfo(&free_b, &total_b)!=hipSuccess||free_b<bytes+40ull*s->kp.Np+(2ull<<30)) break;
+		void* fi = nullptr;
+		if(lead_alloc(s, &fi, elems, s->ddf_bytes, &alternatives[k-1])!=hipSuccess) { (void)hipGetLastError(); break; }
+		DevBlock cand = std::move(s->raw.back()); s->raw.pop_back();
+		void* const old_fi = s->d_fi;
+		s->d_fi = fi;
+		float ms = 0.0f;
+		if(int e = step_ms(ms)) { s->d_fi = old_fi; dev_free(cand); return e; }
+		s->placement_tried++;
+		if(T.placement_verbose) fprintf(stderr, "luw: placement candidate %d (%s): %.3f ms per 2 steps = %.2f TB/s (best so far %.3f ms)\n", k,
+			dev_block_kind(cand), ms, rate(ms)*1e-12, best_ms);
+		if(ms<best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
+		else s->d_fi = old_fi;
+		// the loser's memory goes before the next candidate comes; a mapped loser's (now empty) address range goes with the solver
+		const bool was_mapped = !cand.chunks.empty();
+		dev_free(cand, was_mapped);
+		if(was_mapped) s->raw.push_back(std::move(cand));
+	}
+	s->placement_kept = dev_block_kind(s->raw.front()); s->placement_tbps = rate(best_ms)*1e-12;
+	if(s->cfg.device<64) g_placement_kind[s->cfg.device].store(s->raw.front().chunks.empty() ? (size_t)0u : s->raw.front().chunk_bytes);
+	// the probe steps left zeros, but be explicit
+	HIP_TRY(hipMemsetAsync(s->raw.front().base, 0, std::min(s->raw.front().bytes, bytes+64u*s->ddf_bytes), s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return LUW_OK;
+}

@@ -21,8 +21,10 @@ def usable_cores():
     return max(1, n)
 
 
-# The CPU oracle is OpenMP code, and libgomp sizes its team from the HOST's core count: on a GPU box whose container is allowed 16 of the 256 cores it sees (cgroup cpu.max) every parallel
-# region of the oracle would start 256 threads that spin on 16 cores' worth of time (a 48x20x12 lattice then takes 125 ms per step; GPU suite of round 3: 13.5 minutes,
+# The CPU oracle is OpenMP code, and libgomp sizes its team from the HOST's core count: on a GPU box whose container is allowed 16 of the 256 cores it sees
+# (cgroup cpu.max) every parallel
+# region of the oracle would start 256 threads that spin on 16 cores' worth of time (a 48x20x12 lattice then takes 125 ms per step; GPU suite of round 3: 13.5
+# minutes,
 # most of it this).  Set before the library is loaded: as many threads as cores we may use, and waiting threads that sleep instead of spinning.
 os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
