@@ -200,11 +200,8 @@ int luw_set_x_face_buffers(luw_solver* s, void* dev_buffer_p, void* dev_buffer_m
 int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_fi: bad argument");
 	if(int e = set_device(s)) return e;
-	if(direction==0u) { // the step kernels of this step have written both x faces into these very buffers already
-		const bool done = buf_p==s->xf_p&&buf_m==s->xf_m&&s->xf_t==s->t&&s->xf_cover==3u;
-		s->xf_cover = 0u; s->xf_t = ~0ull;
-		if(done) return LUW_OK;
-	}
+	// the step kernels of this step have written both x faces into these very buffers already (the record is of step xf_t: it lapses with the step)
+	if(direction==0u&&buf_p==s->xf_p&&buf_m==s->xf_m&&s->xf_t==s->t&&s->xf_cover==3u) return LUW_OK;
 	launch_transfer<false, false>(s, direction, buf_p, buf_m);
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
