@@ -258,9 +258,9 @@ def device_context(torch, device):
     return ctx
 
 
-def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False, urban=False):
-    return "%s_%dx%dx%d%s%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_urban" if urban else "", "_cor" if coriolis else "",
-        "_th" if thermal else "", "_uf" if every_step else "")
+def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False, urban=False, native=False):
+    return "%s_%dx%dx%d%s%s%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_urban" if urban else "", "_cor" if coriolis else "",
+        "_th" if thermal else "", "_uf" if every_step else "", "_nat" if native else "")
 
 
 def attach_traffic(roof, key, kernel):
@@ -268,7 +268,7 @@ def attach_traffic(roof, key, kernel):
     (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
     and keyed on the full configuration; null when no profile of exactly this workload exists"""
     # newest round first
-    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (3, 2)) if os.path.exists(q)), None)
+    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (4, 3, 2)) if os.path.exists(q)), None)
     if kernel == "auto" and prof:
         pr = json.load(open(prof))
         roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
@@ -312,7 +312,7 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(launch_bytes),
             "note": "achieved = (%g B x %d non-solid cells + 1 flag byte x %d solid cells) / mean stream_collide duration (HIP events on the launch stream)" % (
                 bpl, cells - solid, solid)}
-    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step, urban), kernel_name)
+    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step, urban, native and fp16c), kernel_name)
     mlups = cells * steps / dt / 1e6
     return {"value": round(mlups, 1), "unit": "MLUPS", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
             "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5),

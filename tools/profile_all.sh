@@ -17,6 +17,11 @@ for blk in ${@:-$ALL}; do
     cube_f32) key=f32_1024x1024x1024; args="--workload cube1024"; kern=k_stream_collide_s; algo="";;
     cube_fp16c) key=fp16c_1024x1024x1024; args="--workload cube1024 --dtype fp16c"; kern=k_stream_collide_p; algo="";;
     urban_fp16c_cor) key=fp16c_512x512x512_bld_urban_cor; args="--workload tile512 --urban --dtype fp16c --coriolis"; kern=k_stream_collide_p; algo="";;
+    # the same FP16C blocks with the native-arithmetic kernels (LUW_OPT_NATIVE_ARITH)
+    c3_fp16c_nat) key=fp16c_1024x1024x256_bld_nat; args="--workload c3 --dtype fp16c --arith native"; kern=k_stream_collide_p; algo="";;
+    c3_fp16c_cor_nat) key=fp16c_1024x1024x256_bld_cor_nat; args="--workload c3 --dtype fp16c --coriolis --arith native"; kern=k_stream_collide_p; algo="";;
+    c3_fp16c_th_nat) key=fp16c_1024x1024x256_bld_th_nat; args="--workload c3 --dtype fp16c --thermal --arith native"; kern=k_stream_collide_p; algo="";;
+    urban_fp16c_cor_nat) key=fp16c_512x512x512_bld_urban_cor_nat; args="--workload tile512 --urban --dtype fp16c --coriolis --arith native"; kern=k_stream_collide_p; algo="";;
   esac
   "$R/tools/profile_bench.sh" "${RT}_$key" --steps 40 --warmup 8 $args > /dev/null 2>&1
   python3 "$R/tools/summarize_profile.py" "${RT}_$key" $kern $algo | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['tag'], 'rocprof', d['rocprof_avg_ms'], 'events', d['hip_event_avg_ms_same_run'], 'traffic/algo', d['traffic_over_algorithmic'], 'VALUBusy', d['VALUBusy_percent'], 'valu/wave', d['valu_insts_per_wave'])"
