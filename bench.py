@@ -554,6 +554,7 @@ def main():
                     sec[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
                 except Exception as e:      # a secondary block never takes the headline down; its absence is visible
                     sec[key] = {"error": str(e)[:300]}
+                sys.stderr.write("bench.py: secondary block %s: %s\n" % (key, sec[key].get("ms_per_step", sec[key].get("error")))); sys.stderr.flush()
                 # FP16C blocks: the same block once more with the native-arithmetic kernels (LUW_OPT_NATIVE_ARITH), again in a fresh process; the block's own
                 # numbers are the bit-exact kernels' ("arith": "exact"), the twin sits under "native"
                 if key in NATIVE_TWINS and "error" not in sec[key]:
