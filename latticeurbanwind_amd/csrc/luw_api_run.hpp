@@ -213,6 +213,40 @@ int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, 
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
+// edge e (population 7 + e) exists on this domain when both axes of its pair are split; its buffer holds one element per cell of the third axis
+uint64_t luw_get_edge_length(const luw_solver* s, uint32_t edge) {
+	if(!s||edge>=12u) return 0ull;
+	const uint32_t pair = edge/4u, H[3] = { s->kp.halo_x, s->kp.halo_y, s->kp.halo_z }, N[3] = { s->cfg.Nx, s->cfg.Ny, s->cfg.Nz };
+	const uint32_t a = pair==2u ? 1u : 0u, b = pair==0u ? 1u : 2u;
+	return (H[a]&&H[b]) ? (uint64_t)N[3u-a-b] : 0ull;
+}
+static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, const char* who) {
+	if(!s||!bufs) return fail(LUW_ERR_INVALID, std::string(who)+": bad argument");
+	if(int e = set_device(s)) return e;
+	EdgeBufs B{}; uint32_t Lmax = 0u;
+	for(uint32_t e=0u; e<12u; e++) {
+		const uint64_t L = luw_get_edge_length(s, e);
+		B.p[e] = L ? bufs[e] : nullptr;
+		if(L&&!bufs[e]) return fail(LUW_ERR_INVALID, std::string(who)+": no buffer for an edge this domain has");
+		Lmax = std::max(Lmax, (uint32_t)L);
+	}
+	if(!Lmax) return LUW_OK;
+	const dim3 grid((Lmax+255u)/256u, 12u), block(256);
+	const uint32_t odd = (uint32_t)(s->t&1ull);
+	if(s->ddf_bytes==2u) {
+		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi);
+		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi);
+	} else {
+		if(insert) hipLaunchKernelGGL((k_edges<float, true>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi);
+		else hipLaunchKernelGGL((k_edges<float, false>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi);
+	}
+	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+int luw_enqueue_extract_edges(luw_solver* s, void* const* dev_buffers) { return launch_edges(s, dev_buffers, false, "luw_enqueue_extract_edges"); }
+int luw_enqueue_insert_edges(luw_solver* s, const void* const* dev_buffers) {
+	return launch_edges(s, const_cast<void* const*>(reinterpret_cast<const void* const*>(dev_buffers)), true, "luw_enqueue_insert_edges");
+}
 int luw_enqueue_extract_gi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_gi: bad argument");
 	if(!s->d_gi) return fail(LUW_ERR_STATE, "luw_enqueue_extract_gi: the solver was created without LUW_OPT_TEMPERATURE");

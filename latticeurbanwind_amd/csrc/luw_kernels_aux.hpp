@@ -90,6 +90,40 @@ template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_i
 		insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi);
 	}
 }
+// ---------------------------------------------------------------- edge populations: the halo exchange in ONE phase
+// The reference swaps faces axis by axis, x then y then z, each face including the halo rims of the axes before it, so that a population that crosses two
+// cuts at once reaches the diagonal neighbour in two hops (FX/lbm.cpp:1908-1934).  In D3Q19 exactly ONE population crosses a given pair of cuts in a given
+// diagonal direction (7, 8, 13, 14 for x-y; 9, 10, 15, 16 for x-z; 11, 12, 17, 18 for y-z; none crosses three), along the line of cells where the two faces
+// meet.  Sent straight to the diagonal neighbour -- edge e = i - 7 carries population i to the domain in direction c_i -- the faces of all axes can travel in
+// the same batch: what the rims of the faces carried (the first hop of exactly these populations; everything else in a rim is never read) is overwritten by the
+// edge insert, which therefore comes last.  Slots (Esoteric-Pull, FX/kernel.cpp:1338-1351; io = the odd partner of i):
+//   odd i   leaves in slot B(i) of the halo-halo line beyond the sender's corner cells, arrives in slot B(i) of the receiver's OWNED corner line opposite;
+//   even i  leaves in slot A(io) of the sender's owned corner line (where the cell stored it), arrives in slot A(io) of the receiver's halo-halo line opposite.
+// The same cells and values the two-hop route delivers (tests/test_gpu_halo.py, tests/test_distributed_gloo.py hold both routes to the oracle).
+struct EdgeBufs { void* p[12]; };
+// coordinate along a cut axis: SENDER side / RECEIVER side of population i (sign s = c_i on that axis)
+__device__ __forceinline__ uint32_t edge_coord(const bool odd_pop, const bool sender, const int s, const uint32_t N) {
+	if(odd_pop) return sender ? (s>0 ? N-1u : 0u) : (s>0 ? 1u : N-2u);        // halo-halo line beyond the corner -> owned corner line opposite
+	return sender ? (s>0 ? N-2u : 1u) : (s>0 ? 0u : N-1u);                    // owned corner line -> halo-halo line opposite
+}
+template<typename T, bool INSERT> __global__ __launch_bounds__(256) void k_edges(const KParams p, const uint32_t t_odd, const EdgeBufs bufs, T* __restrict__ fi) {
+	const uint32_t e = blockIdx.y, l = blockIdx.x*blockDim.x+threadIdx.x;
+	T* const buf = (T*)bufs.p[e];
+	if(!buf) return;
+	const int i = 7+(int)e, io = (i&1) ? i : i-1;
+	// c_i: pair 0 = (x, y), 1 = (x, z), 2 = (y, z); within a pair (+,+), (-,-), (+,-), (-,+)  (FX/kernel.cpp:890-893)
+	const int pair = (int)e/4, k = (int)e%4;
+	const int sa = (k==0||k==2) ? 1 : -1, sb = (k==0||k==3) ? 1 : -1;
+	const int ax_a = pair==2 ? 1 : 0, ax_b = pair==0 ? 1 : 2, ax_c = 3-ax_a-ax_b;
+	const uint32_t N[3] = { p.Nx, p.Ny, p.Nz };
+	if(l>=N[ax_c]) return;
+	uint32_t c[3];
+	c[ax_a] = edge_coord((i&1)!=0, !INSERT, sa, N[ax_a]); c[ax_b] = edge_coord((i&1)!=0, !INSERT, sb, N[ax_b]); c[ax_c] = l;
+	// slot A(io, t) = t odd ? io : io + 1 holds population io + 1 at the cell; slot B(io, t) = t odd ? io + 1 : io holds population io at the +c_io neighbour
+	const uint32_t plane = (i&1) ? (t_odd ? (uint32_t)io+1u : (uint32_t)io) : (t_odd ? (uint32_t)io : (uint32_t)io+1u);
+	const size_t n = (size_t)plane*p.Np+c[0]+((size_t)c[1]+(size_t)c[2]*p.Ny)*p.Px;
+	if constexpr(INSERT) fi[n] = buf[l]; else buf[l] = fi[n];
+}
 // ---------------------------------------------------------------- mesh voxeliser
 // voxelize_mesh with direction 2 (z rays; LUW always voxelises TYPE_S along z, FX/lbm.cpp:1427-1430) for a static mesh:
 // one lane per (x,y) column casts a ray from the bottom of the padded bounding box through ALL triangles

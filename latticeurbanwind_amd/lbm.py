@@ -198,6 +198,12 @@ class LBM:
         return bool(fused.value)
     def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def set_x_face_buffers(self, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_set_x_face_buffers(self._h, buf_p_ptr, buf_m_ptr))
+    def edge_length(self, e): return int(self._L.luw_get_edge_length(self._h, e))
+
+    def enqueue_edges(self, ptrs, insert):
+        """the 12 edge buffers (device pointers, 0 where the domain has no such edge): pack (insert False) or unpack"""
+        arr = (C.c_void_p * 12)(*[C.c_void_p(p) if p else None for p in ptrs])
+        capi.check((self._L.luw_enqueue_insert_edges if insert else self._L.luw_enqueue_extract_edges)(self._h, arr))
     def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_extract_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
