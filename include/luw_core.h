@@ -179,12 +179,12 @@ int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p
  * buffers must stay valid, and must not be overwritten between a step's launches and the use of its faces.  NULL, NULL switches the output off. */
 int luw_set_x_face_buffers(luw_solver* s, void* dev_buffer_p, void* dev_buffer_m);
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* dev_buffer_p, const void* dev_buffer_m);
-/* The halo exchange in ONE phase instead of the reference's x -> y -> z sequence (FX/lbm.cpp:1908-1934, where a population that crosses two cuts at once reaches
- * the diagonal neighbour in two hops through the rims of the faces): in D3Q19 exactly one population crosses a given pair of cuts in a given diagonal
- * direction, along the line where the two faces meet.  Edge e = 0..11 carries population i = 7 + e (c_i: FX/kernel.cpp:890-893) to the domain in direction
- * c_i; its buffer holds luw_get_edge_length(e) elements (the local extent of the third axis; 0 when that pair of axes is not split on this domain).  A host
- * packs all faces and edges, moves everything in one batch, inserts the faces of all axes (any order) and the edges LAST: same populations in the same slots
- * as the three-phase route.  dev_buffers: 12 device pointers (NULL where the length is 0). */
+/* The halo exchange in ONE phase instead of the reference's x -> y -> z sequence (FX/lbm.cpp:1908-1934, where a population that crosses two cuts at
+ * once reaches the diagonal neighbour in two hops through the rims of the faces): in D3Q19 exactly one population crosses a given pair of cuts in a
+ * given diagonal direction, along the line where the two faces meet.  Edge e = 0..11 carries population i = 7 + e (c_i: FX/kernel.cpp:890-893) to the
+ * domain in direction c_i; its buffer holds luw_get_edge_length(e) elements (the local extent of the third axis; 0 when that pair of axes is not split
+ * on this domain).  A host packs all faces and edges, moves everything in one batch, inserts the faces of all axes (any order) and the edges LAST: same
+ * populations in the same slots as the three-phase route.  dev_buffers: 12 device pointers (NULL where the length is 0). */
 uint64_t luw_get_edge_length(const luw_solver* s, uint32_t edge);
 int luw_enqueue_extract_edges(luw_solver* s, void* const* dev_buffers);
 int luw_enqueue_insert_edges(luw_solver* s, const void* const* dev_buffers);

@@ -216,7 +216,7 @@ int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, 
 // edge e (population 7 + e) exists on this domain when both axes of its pair are split; its buffer holds one element per cell of the third axis
 uint64_t luw_get_edge_length(const luw_solver* s, uint32_t edge) {
 	if(!s||edge>=12u) return 0ull;
-	const uint32_t pair = edge/4u, H[3] = { s->kp.halo_x, s->kp.halo_y, s->kp.halo_z }, N[3] = { s->cfg.Nx, s->cfg.Ny, s->cfg.Nz };
+	const uint32_t pair = (edge%6u)/2u, H[3] = { s->kp.halo_x, s->kp.halo_y, s->kp.halo_z }, N[3] = { s->cfg.Nx, s->cfg.Ny, s->cfg.Nz };
 	const uint32_t a = pair==2u ? 1u : 0u, b = pair==0u ? 1u : 2u;
 	return (H[a]&&H[b]) ? (uint64_t)N[3u-a-b] : 0ull;
 }

@@ -106,14 +106,14 @@ __device__ __forceinline__ uint32_t edge_coord(const bool odd_pop, const bool se
 	if(odd_pop) return sender ? (s>0 ? N-1u : 0u) : (s>0 ? 1u : N-2u);        // halo-halo line beyond the corner -> owned corner line opposite
 	return sender ? (s>0 ? N-2u : 1u) : (s>0 ? 0u : N-1u);                    // owned corner line -> halo-halo line opposite
 }
-template<typename T, bool INSERT> __global__ __launch_bounds__(256) void k_edges(const KParams p, const uint32_t t_odd, const EdgeBufs bufs, T* __restrict__ fi) {
+template<typename T,
+	bool INSERT> __global__ __launch_bounds__(256) void k_edges(const KParams p, const uint32_t t_odd, const EdgeBufs bufs, T* __restrict__ fi) {
 	const uint32_t e = blockIdx.y, l = blockIdx.x*blockDim.x+threadIdx.x;
 	T* const buf = (T*)bufs.p[e];
 	if(!buf) return;
 	const int i = 7+(int)e, io = (i&1) ? i : i-1;
-	// c_i: pair 0 = (x, y), 1 = (x, z), 2 = (y, z); within a pair (+,+), (-,-), (+,-), (-,+)  (FX/kernel.cpp:890-893)
-	const int pair = (int)e/4, k = (int)e%4;
-	const int sa = (k==0||k==2) ? 1 : -1, sb = (k==0||k==3) ? 1 : -1;
+	// c_i (FX/kernel.cpp:890-893): 7..12 = (+,+) and (-,-) for the axis pairs (x, y), (x, z), (y, z); 13..18 = (+,-) and (-,+) for the same pairs
+	const int pair = ((int)e%6)/2, sa = (i&1) ? 1 : -1, sb = e<6u ? sa : -sa;
 	const int ax_a = pair==2 ? 1 : 0, ax_b = pair==0 ? 1 : 2, ax_c = 3-ax_a-ax_b;
 	const uint32_t N[3] = { p.Nx, p.Ny, p.Nz };
 	if(l>=N[ax_c]) return;

@@ -7,14 +7,20 @@ What is reproduced from the reference (FX/lbm.cpp:1057-1073,1242-1290,1907-1935;
   * per step: stream_collide on every non-halo cell, then for axis x, y, z in this order: extract the 5 outgoing DDFs
     of both faces (face areas include the halo rims, so edge/corner data travel in up to 3 hops), swap with the two
     neighbours, insert; then t++.  LBM::initialize does the same exchange once with an odd t.
-What is ours: the exchange never touches the host (the reference stages every face through PCIe and swaps host
-pointers); the boundary shell (cells next to a halo) is computed first on a communication stream, its faces are
-packed and sent while the interior is computed on the compute stream, and the next step starts when both are done.
+What is ours: all faces travel in ONE batch -- the populations that cross two cuts at once (one per diagonal direction in D3Q19, along the line where two
+faces meet) go straight to the diagonal neighbour as 12 short edge messages instead of riding the rims of a second and third hop (csrc/luw_kernels_aux.hpp
+k_edges; LUW_EXCHANGE=sequential restores the reference's three phases); the exchange never touches the host (the reference stages every face through
+PCIe and swaps host pointers); the boundary shell (cells next to a halo) is computed first on a communication stream, its faces are packed and sent while
+the interior is computed on the compute stream, and the next step starts when both are done.
 
 Results are identical to a single-domain run of the global lattice (tests/test_distributed_gloo.py,
 tests/test_gpu_halo.py).
 """
 import numpy as np
+
+# D3Q19 directions c_i (FX/kernel.cpp:890-893); edge message e = 0..11 carries population 7 + e to the domain in direction c_(7+e)
+C19 = ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0), (-1, -1, 0), (1, 0, 1), (-1, 0, -1), (0, 1, 1), (0, -1, -1),
+       (1, -1, 0), (-1, 1, 0), (1, 0, -1), (-1, 0, 1), (0, 1, -1), (0, -1, 1))
 
 
 def choose_decomposition(world, split_x=False):
@@ -83,8 +89,20 @@ class DomainLayout:
         c[axis] = (c[axis] + sign) % self.D[axis]
         return self.rank_of(c)
 
+    def neighbor_dir(self, c):
+        """rank of the domain in direction c = (cx, cy, cz), periodic"""
+        return self.rank_of(tuple((k + d) % n for k, d, n in zip(self.coord, c, self.D)))
+
     def split_axes(self):
         return [a for a in range(3) if self.D[a] > 1]
+
+    def edges(self):
+        """edge messages this domain takes part in: population 7 + e crosses two cuts, both of them split"""
+        return [e for e in range(12) if all(self.D[a] > 1 for a in range(3) if C19[7 + e][a])]
+
+    def edge_length(self, e):
+        """cells of edge e's line: the local extent of the axis its population does not move along"""
+        return self.lN[[a for a in range(3) if C19[7 + e][a] == 0][0]]
 
     # ---- boxes (x0,x1,y0,y1,z0,z1) in local coordinates: ONE implementation, the library's (luw_step_boxes, csrc/luw_group.hpp: pure host arithmetic, also
     # what the one-process host luw_group_* cuts its domains with).  whole = the non-halo cells; interior + the disjoint shell slabs cover it exactly once;
@@ -131,6 +149,16 @@ class TorchDistTransport:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
+    def exchange_all(self, messages):
+        """ONE batch for everything a step moves.  messages: (send, recv, c) in a fixed order of message types -- `send` leaves for the domain in direction c,
+        `recv` takes the same type of message from the domain in direction -c.  Every rank lists the types in the same order, so the k-th send of A to B is
+        the k-th receive of B from A also where several directions lead to the same rank (two domains along an axis; a rank that is its own neighbour)."""
+        dist, lay = self.dist, self.layout
+        ops = [dist.P2POp(dist.isend, s, lay.neighbor_dir(c), self.group) for s, _, c in messages]
+        ops += [dist.P2POp(dist.irecv, r, lay.neighbor_dir(tuple(-v for v in c)), self.group) for _, r, c in messages]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
     def warm_up(self, device, dtype=None, measure=0):
         """One full-size exchange per split axis on scratch buffers, BEFORE the lattice is allocated: RCCL builds its
         point-to-point connections (channels, staging buffers) at the first send/recv to a peer.  Measured on MI355X
@@ -171,7 +199,8 @@ class SelfExchangeTransport(TorchDistTransport):
         super().__init__(layout, group)
         import torch.distributed as dist
         me = dist.get_rank() if dist.is_initialized() else 0
-        self.layout = type("SelfNeighbours", (), {"neighbor": staticmethod(lambda axis, sign: me), "lN": layout.lN, "split_axes": layout.split_axes})()
+        self.layout = type("SelfNeighbours", (), {"neighbor": staticmethod(lambda axis, sign: me), "neighbor_dir": staticmethod(lambda c: me),
+            "lN": layout.lN, "split_axes": layout.split_axes})()
 
 
 class PeerLoopbackTransport:
@@ -187,6 +216,9 @@ class PeerLoopbackTransport:
 
     def exchange(self, axis, send_p, send_m, recv_p, recv_m):
         assert send_p.data_ptr() == recv_m.data_ptr() and send_m.data_ptr() == recv_p.data_ptr()
+
+    def exchange_all(self, messages):
+        assert all(s.data_ptr() == r.data_ptr() for s, r, _ in messages)
 
     def warm_up(self, device, dtype=None, measure=0):
         return {}
@@ -224,6 +256,13 @@ class HostStagedTransport(TorchDistTransport):
         super().exchange(axis, sp, sm, rp, rm)
         recv_p.copy_(rp); recv_m.copy_(rm)
 
+    def exchange_all(self, messages):
+        import torch
+        staged = [(s.cpu(), torch.empty(r.shape, dtype=r.dtype), c) for s, r, c in messages]
+        super().exchange_all(staged)
+        for (_, r, _), (_, h, _) in zip(messages, staged):
+            r.copy_(h)
+
 
 class HipDomain:
     """One LBM domain on one GPU through the C-ABI; buffers are torch CUDA tensors, work is enqueued on torch streams."""
@@ -260,6 +299,10 @@ class HipDomain:
                 self.gbuf[a] = [torch.zeros(A, dtype=self.dtype, device=self.device) for _ in range(4)]
                 if alias_faces:
                     self.gbuf[a][0], self.gbuf[a][1] = self.gbuf[a][3], self.gbuf[a][2]
+        # edge messages of the one-phase exchange: [send, receive] per edge, one element per cell of the third axis
+        self.ebuf = {e: [torch.zeros(self.lbm.edge_length(e), dtype=self.dtype, device=self.device) for _ in range(2)] for e in layout.edges()}
+        if alias_faces:
+            for e in self.ebuf: self.ebuf[e][0] = self.ebuf[e][1]
 
     # host fields (reference layout, local box incl. halos)
     def set_fields(self, flags, u, rho, T=None):
@@ -301,6 +344,18 @@ class HipDomain:
         self.lbm.set_stream(stream.cuda_stream)
         b = self.buf[axis]
         self.lbm.enqueue_insert_fi(axis, b[2].data_ptr(), b[3].data_ptr())
+
+    def extract_edges(self, stream):
+        """packs every edge; returns [(e, send, receive)]"""
+        if self.ebuf:
+            self.lbm.set_stream(stream.cuda_stream)
+            self.lbm.enqueue_edges([self.ebuf[e][0].data_ptr() if e in self.ebuf else 0 for e in range(12)], insert=False)
+        return [(e, b[0], b[1]) for e, b in sorted(self.ebuf.items())]
+
+    def insert_edges(self, stream):
+        if self.ebuf:
+            self.lbm.set_stream(stream.cuda_stream)
+            self.lbm.enqueue_edges([self.ebuf[e][1].data_ptr() if e in self.ebuf else 0 for e in range(12)], insert=True)
 
     def extract_g(self, axis, stream):
         self.lbm.set_stream(stream.cuda_stream)
@@ -406,9 +461,16 @@ class DomainDecomposedLBM:
         if hasattr(self.backend, "configure_step"):
             self.backend.configure_step(self.overlap)            # the library's step context follows the choice (LUW_X_OVERLAP=0, tests)
         import os
+        # all faces + the 12 edge populations in one batch (default), or the reference's three phases with rims (LUW_EXCHANGE=sequential; also what a
+        # backend or transport without the edge calls gets)
+        self.batch_wanted = os.environ.get("LUW_EXCHANGE", "batch") != "sequential"
         self.pipeline = os.environ.get("LUW_PIPELINE", "1") != "0"     # A/B switch: 0 = join both streams after every step
         self.initialized = False
         self.pre_step = None     # callable(stream) enqueued before every step's kernels (von-Karman inlet update)
+
+    @property
+    def one_phase(self):
+        return self.batch_wanted and hasattr(self.backend, "extract_edges") and hasattr(self.transport, "exchange_all")
 
     def set_fields(self, flags, u, rho, T=None):
         if T is not None: self.backend.set_fields(flags, u, rho, T)
@@ -430,6 +492,8 @@ class DomainDecomposedLBM:
     # ---- FX/lbm.cpp:1907-1935 for the DDF field, device to device
     def communicate_fi(self, stream=None):
         b = self.backend
+        if self.one_phase:
+            return self._communicate_one_phase(stream)
         for axis in self.layout.split_axes():
             sp, sm = b.extract(axis, stream)
             rp, rm = b.recv_buffers(axis)
@@ -441,6 +505,39 @@ class DomainDecomposedLBM:
                 rp, rm = b.recv_buffers_g(axis)
                 self._exchange(axis, sp, sm, rp, rm, stream)
                 b.insert_g(axis, stream)
+
+    def _communicate_one_phase(self, stream):
+        """every face of every split axis, the edge populations and the thermal faces in ONE batch.  Message types in a fixed order (see
+        TorchDistTransport.exchange_all): per axis the + face, the - face; the edges by number; per axis the thermal + face, - face.  The rims of the faces
+        (halo rows of the other axes) travel along unused: what the reference's second and third hop carried in them is what the edge messages deliver,
+        inserted after the faces (csrc/luw_kernels_aux.hpp k_edges)."""
+        b = self.backend
+        axes = self.layout.split_axes()
+        unit = lambda a, s: tuple(s if k == a else 0 for k in range(3))
+        msgs = []
+        for a in axes:
+            sp, sm = b.extract(a, stream)
+            rp, rm = b.recv_buffers(a)
+            msgs += [(sp, rm, unit(a, +1)), (sm, rp, unit(a, -1))]     # my + face is the - halo of the domain above
+        msgs += [(s, r, C19[7 + e]) for e, s, r in b.extract_edges(stream)]
+        thermal = getattr(b, "thermal", False)
+        if thermal:
+            for a in axes:
+                sp, sm = b.extract_g(a, stream)
+                rp, rm = b.recv_buffers_g(a)
+                msgs += [(sp, rm, unit(a, +1)), (sm, rp, unit(a, -1))]
+        if stream is not None:
+            import torch
+            with torch.cuda.stream(stream):
+                self.transport.exchange_all(msgs)
+        else:
+            self.transport.exchange_all(msgs)
+        for a in axes:
+            b.insert(a, stream)
+        b.insert_edges(stream)
+        if thermal:
+            for a in axes:
+                b.insert_g(a, stream)
 
     def _exchange(self, axis, sp, sm, rp, rm, stream):
         if stream is not None:

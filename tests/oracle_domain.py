@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from oracle import oracle
+from latticeurbanwind_amd.distributed import C19
 
 
 class OracleDomain:
@@ -54,6 +55,36 @@ class OracleDomain:
     def insert_g(self, axis, stream):
         rp = self.gbuf[axis][2].numpy().view(self.np_dtype); rm = self.gbuf[axis][3].numpy().view(self.np_dtype)
         self.o.insert_gi(axis, np.ascontiguousarray(rp), np.ascontiguousarray(rm))
+
+    # ---- edge messages of the one-phase exchange, restated from the slot algebra of the reference's transfer kernels (FX/kernel.cpp:2241-2270: an odd
+    # population i is read at the +c_i neighbour of the face cell in plane (t odd ? i+1 : i), an even one at the cell itself in plane (t odd ? i-1 : i);
+    # inserts mirror that) for the ONE population that crosses both cuts of an edge, on the line of cells where the two faces meet
+    def _edge_line(self, e, sender):
+        i = 7 + e
+        c, N, odd = C19[i], self.layout.lN, bool(i & 1)
+        t_odd = self.o.t & 1
+        io = i if odd else i - 1
+        plane = (io + 1 if t_odd else io) if odd else (io if t_odd else io + 1)
+        idx = []
+        for a in range(3):
+            if c[a] == 0: idx.append(np.arange(N[a]))
+            elif odd: idx.append((N[a] - 1 if c[a] > 0 else 0) if sender else (1 if c[a] > 0 else N[a] - 2))
+            else: idx.append((N[a] - 2 if c[a] > 0 else 1) if sender else (0 if c[a] > 0 else N[a] - 1))
+        n = idx[0] + (idx[1] + idx[2] * N[1]) * N[0]
+        return plane * self.o.N + n
+
+    def extract_edges(self, stream):
+        if not hasattr(self, "ebuf"):
+            self.ebuf = {e: [torch.zeros(self.layout.edge_length(e), dtype=self.t_dtype) for _ in range(2)] for e in self.layout.edges()}
+        for e, b in self.ebuf.items():
+            b[0].copy_(torch.from_numpy(self._view(self.o.fi[self._edge_line(e, True)].copy())))
+        return [(e, b[0], b[1]) for e, b in sorted(self.ebuf.items())]
+
+    def insert_edges(self, stream):
+        import os
+        if os.environ.get("LUW_TEST_DROP_EDGES") == "1": return            # tests/test_distributed_gloo.py: the negative control
+        for e, b in getattr(self, "ebuf", {}).items():
+            self.o.fi[self._edge_line(e, False)] = b[1].numpy().view(self.np_dtype)
 
     def download_T(self): return self.o.T
 

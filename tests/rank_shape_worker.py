@@ -25,7 +25,7 @@ def main():
     opts = set(sys.argv[10:])
     fp16c = dt == "fp16c"
     import latticeurbanwind_amd as luw
-    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, TorchDistTransport, init_rccl_process_group
+    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, SelfExchangeTransport as SelfNeighbour, init_rccl_process_group
     from bench import fill_channel, tile_forcing, coriolis_omega, NU
     from oracle import oracle
     from oracle_domain import OracleDomain
@@ -34,11 +34,6 @@ def main():
     luw.load()
     gN = tuple(b * d for b, d in zip(block, D))
     nud, spg = tile_forcing() if "forcing" in opts else (None, None)
-
-    class SelfNeighbour(TorchDistTransport):         # every face goes to, and comes from, this process through RCCL's self send/recv
-        def __init__(self, layout):
-            super().__init__(layout)
-            self.layout = type("L", (), {"neighbor": staticmethod(lambda axis, sign: 0), "lN": layout.lN, "split_axes": layout.split_axes})()
 
     lay = DomainLayout(gN, D, rank)
     if "peer" in opts:

@@ -24,21 +24,25 @@ def single_domain(gN, steps, fp16c):
 
 # world 8: the two cuts of BASELINE's 8-GPU tile -- the deck's literal n_gpu = [4,2,1] and the x-whole [1,4,2] -- with every rank's neighbours distinct ranks
 # (the one-GPU box can only rehearse them with all domains on one device)
-@pytest.mark.parametrize("gN,D,fp16c", [((16, 10, 6), (2, 1, 1), False), ((12, 12, 8), (2, 2, 1), False), ((12, 8, 8), (1, 2, 2), True),
-                                         ((16, 8, 6), (4, 2, 1), False), ((10, 16, 8), (1, 4, 2), True)])
-def test_gloo_multi_domain_equals_single_domain(tmp_path, gN, D, fp16c):
+# exchange: "batch" = all faces + the 12 edge populations in one batch (the default), "sequential" = the reference's three phases with rims
+@pytest.mark.parametrize("gN,D,fp16c,exchange", [((16, 10, 6), (2, 1, 1), False, "batch"), ((12, 12, 8), (2, 2, 1), False, "batch"),
+    ((12, 12, 8), (2, 2, 1), False, "sequential"), ((12, 8, 8), (1, 2, 2), True, "batch"), ((16, 8, 6), (4, 2, 1), False, "batch"),
+    ((10, 16, 8), (1, 4, 2), True, "batch"), ((8, 8, 8), (2, 2, 2), True, "batch"), ((8, 8, 8), (2, 2, 2), False, "sequential"),
+    ((12, 12, 8), (2, 2, 1), False, "batch-without-edges")])
+def test_gloo_multi_domain_equals_single_domain(tmp_path, gN, D, fp16c, exchange):
     world = D[0] * D[1] * D[2]
     steps = 5
     out = str(tmp_path / "result.npz")
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), *map(str, gN), *map(str, D), str(steps), str(int(fp16c)), out]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", LUW_EXCHANGE=exchange.split("-")[0], LUW_TEST_DROP_EDGES=str(int(exchange.endswith("without-edges"))))
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = np.load(out)
     u_ref, rho_ref = single_domain(gN, steps, fp16c)
-    assert np.array_equal(got["u"], u_ref) and np.array_equal(got["rho"], rho_ref)
+    equal = np.array_equal(got["u"], u_ref) and np.array_equal(got["rho"], rho_ref)
+    assert equal != exchange.endswith("without-edges")        # the test notices a batch exchange that leaves the edge populations out
 
 
 def test_gloo_multi_domain_thermal_lattice(tmp_path):

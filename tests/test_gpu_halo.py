@@ -167,3 +167,42 @@ def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c
     g.enqueue_extract_fi(0, fused[0].data_ptr(), fused[1].data_ptr()); g.enqueue_extract_fi(0, plain[0].data_ptr(), plain[1].data_ptr()); g.finish()
     assert all(torch.equal(a, b) for a, b in zip(plain, fused))
     g.close()
+
+
+@pytest.mark.parametrize("fp16c", [False, True])
+@pytest.mark.parametrize("D", [(2, 2, 2), (4, 2, 1), (1, 2, 2)])
+def test_edge_kernels_move_the_lines_the_two_hop_route_moves(luw, fp16c, D):
+    """luw_enqueue_extract_edges / luw_enqueue_insert_edges (csrc/luw_kernels_aux.hpp k_edges) against the slot algebra restated in numpy
+    (tests/oracle_domain.py _edge_line, which tests/test_distributed_gloo.py holds to the undivided run): for both parities of t, every edge this domain
+    has reads exactly that line of the lattice, and writes exactly that line and nothing else."""
+    import torch
+    from latticeurbanwind_amd.distributed import DomainLayout
+    from oracle_domain import OracleDomain
+    gN = tuple(d * n for d, n in zip(D, (300, 7, 5)))        # a line longer than one block of the kernel
+    lay = DomainLayout(gN, D, 0)
+    od = OracleDomain(lay, 0.01, fp16c=fp16c)
+    g = luw.LBM(*lay.lN, 0.01, fp16c=fp16c, D=D, O=lay.O)
+    rng = np.random.default_rng(4)
+    n = 19 * od.o.N
+    fi = rng.integers(1, 60000, n).astype(np.uint16) if fp16c else rng.random(n, dtype=np.float32)
+    tdt = torch.int16 if fp16c else torch.float32
+    edges = lay.edges()
+    assert len(edges) == {3: 12, 2: 4}[len(lay.split_axes())] and all(g.edge_length(e) == (lay.edge_length(e) if e in edges else 0) for e in range(12))
+    for t in (0, 1):
+        od.o.t = t
+        g.upload_fi(fi)
+        out = {e: torch.full((g.edge_length(e),), 7, dtype=tdt, device="cuda") for e in edges}
+        g.enqueue_edges([out[e].data_ptr() if e in out else 0 for e in range(12)], insert=False); g.finish()
+        for e in edges:
+            assert np.array_equal(out[e].cpu().numpy().view(fi.dtype), fi[od._edge_line(e, True)]), (t, e)
+        msg = {e: (rng.integers(1, 60000, g.edge_length(e)).astype(np.uint16) if fp16c else rng.random(g.edge_length(e), dtype=np.float32)) for e in edges}
+        dev = {e: torch.from_numpy(m.view(np.int16) if fp16c else m).cuda() for e, m in msg.items()}
+        g.enqueue_edges([dev[e].data_ptr() if e in dev else 0 for e in range(12)], insert=True); g.finish()
+        want = fi.copy()
+        for e in edges:
+            want[od._edge_line(e, False)] = msg[e]
+        assert np.array_equal(np.asarray(g.download_fi()), want), t
+        g.increment_time_step(1)
+    with pytest.raises(luw.LuwError):
+        g.enqueue_edges([0] * 12, insert=False)              # an edge the domain has, without a buffer
+    g.close()

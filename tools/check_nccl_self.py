@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import latticeurbanwind_amd as luw
-from latticeurbanwind_amd.distributed import DomainDecomposedLBM, TorchDistTransport, init_rccl_process_group
+from latticeurbanwind_amd.distributed import DomainDecomposedLBM, SelfExchangeTransport as SelfNeighbour, init_rccl_process_group
 from bench import channel_state
 from tools.bench_domain_overhead import Loopback
 
@@ -29,12 +29,6 @@ D, size, steps = (1, 2, 2), (512, 256, 256), 60
 if len(sys.argv) >= 8:      # check_nccl_self.py f32 2048 256 256 1 4 2: one rank of the 8-GPU benchmark tile
     size, D = tuple(int(v) for v in sys.argv[2:5]), tuple(int(v) for v in sys.argv[5:8])
 N = tuple(s * d for s, d in zip(size, D))
-
-
-class SelfNeighbour(TorchDistTransport):
-    def __init__(self, layout):
-        super().__init__(layout)
-        self.layout = type("L", (), {"neighbor": staticmethod(lambda axis, sign: 0)})()
 
 
 def run(transport_of):
