@@ -186,6 +186,18 @@ class TorchDistTransport:
                 out_bytes = 2 * bufs[0].numel() * bufs[0].element_size()       # the + face and the - face leave, as many bytes arrive
                 wire["xyz"[a]] = {"bytes_out": out_bytes, "ms": round(ms, 4), "GBps_out": round(out_bytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
                                   "to_ranks": [self.layout.neighbor(a, +1), self.layout.neighbor(a, -1)]}
+        # the one-phase exchange also talks to the diagonal neighbours (edge messages): one batch of everything, so that those connections exist now as well
+        edges = self.layout.edges() if hasattr(self.layout, "edges") else []
+        if edges:
+            unit = lambda a, sgn: tuple(sgn if k == a else 0 for k in range(3))
+            msgs = []
+            for a in self.layout.split_axes():
+                A = lN[(a + 1) % 3] * lN[(a + 2) % 3]
+                msgs += [(torch.zeros(5 * A, dtype=dtype or torch.float32, device=device), torch.zeros(5 * A, dtype=dtype or torch.float32, device=device),
+                          unit(a, sgn)) for sgn in (+1, -1)]
+            msgs += [(torch.zeros(self.layout.edge_length(e), dtype=dtype or torch.float32, device=device),
+                      torch.zeros(self.layout.edge_length(e), dtype=dtype or torch.float32, device=device), C19[7 + e]) for e in edges]
+            self.exchange_all(msgs)
         torch.cuda.synchronize(device)
         return wire
 
@@ -200,7 +212,7 @@ class SelfExchangeTransport(TorchDistTransport):
         import torch.distributed as dist
         me = dist.get_rank() if dist.is_initialized() else 0
         self.layout = type("SelfNeighbours", (), {"neighbor": staticmethod(lambda axis, sign: me), "neighbor_dir": staticmethod(lambda c: me),
-            "lN": layout.lN, "split_axes": layout.split_axes})()
+            "lN": layout.lN, "split_axes": layout.split_axes, "edges": layout.edges, "edge_length": layout.edge_length})()
 
 
 class PeerLoopbackTransport:
