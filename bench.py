@@ -479,7 +479,7 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
     if args.share_device is not None:
         local_rank = args.share_device
-        os.environ.setdefault("LUW_TUNE_PLACEMENT", "0")    # rank processes on one device: their placement probes would time each other (csrc/luw_placement.hpp)
+        os.environ.setdefault("LUW_TUNE_PLACEMENT", "0")    # rank processes on one device: their placement probes would time each other (luw_placement.hpp)
     torch.cuda.set_device(local_rank)
     luw.load()
     kern = {"auto": capi.KERNEL_AUTO, "scalar": capi.KERNEL_SCALAR, "pair": capi.KERNEL_PAIR}[args.kernel]
