@@ -57,6 +57,45 @@ def transfer_slots(axis, t, lN, thermal):
     return reads, writes
 
 
+def edge_slots(e, t, lN):
+    """(slots the edge pack reads, slots the edge unpack writes) of edge message e = population 7 + e (csrc/luw_kernels_aux.hpp k_edges): an odd population
+    leaves in slot B of the halo-halo line beyond the sender's corner and lands in slot B of the receiver's owned corner line; an even one leaves in slot A of the
+    owned corner line and lands in the halo-halo line"""
+    i = 7 + e
+    odd_pop, io = i % 2 == 1, i if i % 2 else i - 1
+    plane = (io + 1 if t % 2 else io) if odd_pop else (io if t % 2 else io + 1)
+    def line(sender):
+        rng = []
+        for a in range(3):
+            c, n = C[i][a], lN[a]
+            if c == 0: rng.append(range(n))
+            elif odd_pop: rng.append([(n - 1 if c > 0 else 0) if sender else (1 if c > 0 else n - 2)])
+            else: rng.append([(n - 2 if c > 0 else 1) if sender else (0 if c > 0 else n - 1)])
+        return {(plane, cell) for cell in itertools.product(*rng)}
+    return line(True), line(False)
+
+
+@pytest.mark.parametrize("D,gN", [((1, 2, 2), (6, 12, 10)), ((2, 2, 1), (20, 12, 4)), ((2, 2, 2), (16, 12, 12))])
+def test_edge_messages_of_the_one_phase_exchange_keep_clear_of_the_interior(monkeypatch, D, gN):
+    """the edge pack / unpack of step t against the interior of step t+1 (disjoint: pipelining holds for the one-phase exchange too); and every slot an edge
+    message delivers is one the rims of the three-phase route's face inserts write as well -- the edge insert, coming last, replaces what those left there"""
+    monkeypatch.setattr(DomainLayout, "X_SHELL", 2)
+    lay = DomainLayout(gN, D, 0)
+    lN = tuple(lay.lN)
+    assert len(lay.edges()) == {2: 4, 3: 12}[len(lay.split_axes())]
+    for t in (0, 1):
+        interior = set()
+        for cell in box_cells(lay.interior_box()):
+            interior |= step_slots(cell, t + 1, lN, 19)
+        face_writes = set()
+        for axis in lay.split_axes():
+            face_writes |= transfer_slots(axis, t, lN, False)[1]
+        for e in lay.edges():
+            reads, writes = edge_slots(e, t, lN)
+            assert not (interior & reads) and not (interior & writes)
+            assert writes <= face_writes
+
+
 @pytest.mark.parametrize("thermal", [False, True])
 @pytest.mark.parametrize("D,gN", [((1, 2, 2), (6, 12, 10)), ((1, 2, 1), (5, 14, 6)), ((1, 1, 2), (6, 6, 12)), ((1, 3, 2), (4, 18, 12))])
 def test_interior_of_next_step_is_disjoint_from_the_exchange(D, gN, thermal):
