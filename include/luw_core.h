@@ -169,7 +169,9 @@ int luw_increment_time_step(luw_solver* s, uint64_t steps);               /* LBM
 int luw_reset_time_step(luw_solver* s);                                   /* LBM_Domain::reset_time_step */
 /* halo transfer of the 5 outgoing DDFs per face cell: transfer_extract_fi / transfer__insert_fi
  * (FX/kernel.cpp:2241-2270).  direction 0/1/2 = x/y/z.  Buffers are DEVICE pointers holding 5*A elements of
- * the DDF storage type, A = luw_get_area(direction), element (b*A + a) as in the reference. */
+ * the DDF storage type, A = luw_get_area(direction), element (b*A + a): population b of the face (reference order), face cell a with x running fastest
+ * wherever the face contains x (a = y + z*Ny, x + z*Nx, x + y*Nx for direction 0, 1, 2; the reference's y faces run a = z + x*Nz -- the order inside a
+ * buffer is private to extract and insert, the host only moves the bytes). */
 uint64_t luw_get_area(const luw_solver* s, uint32_t direction);           /* LBM_Domain::get_area */
 int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p, void* dev_buffer_m);
 /* x-split domains: while a pair of face buffers is set here, every stream_collide launch whose box holds the first / last owned x column ALSO writes that
@@ -179,6 +181,14 @@ int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p
  * buffers must stay valid, and must not be overwritten between a step's launches and the use of its faces.  NULL, NULL switches the output off. */
 int luw_set_x_face_buffers(luw_solver* s, void* dev_buffer_p, void* dev_buffer_m);
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* dev_buffer_p, const void* dev_buffer_m);
+/* The x-face insert without its kernel: luw_set_x_face_inputs(p, m) stands for luw_enqueue_insert_fi(s, 0, p, m) at the current t, but leaves the values in the
+ * buffers.  The launches of the NEXT step whose box holds the first / last owned x column read them there (the kernels with the x-face output: the loads
+ * they replace are the very slots the insert kernel would have filled, one element per 128-byte line); whatever else needs the values in the lattice first
+ * -- a launch of another kernel, a pack kernel, luw_download_fi, a change of t other than the step to t + 1 -- makes the library run the insert kernel then,
+ * on the stream set at that moment.  The caller keeps the buffers unchanged until the next step's launches have run (stream order on one stream is enough;
+ * a host whose neighbour writes them directly alternates two pairs), calls luw_enqueue_insert_edges AFTER this (the edges across the x cut then land in the
+ * rims of these buffers), and does not mix, within one step, launches on the border columns that can read the buffers with launches that cannot (error). */
+int luw_set_x_face_inputs(luw_solver* s, const void* dev_buffer_p, const void* dev_buffer_m);
 /* The halo exchange in ONE phase instead of the reference's x -> y -> z sequence (FX/lbm.cpp:1908-1934, where a population that crosses two cuts at
  * once reaches the diagonal neighbour in two hops through the rims of the faces): in D3Q19 exactly one population crosses a given pair of cuts in a
  * given diagonal direction, along the line where the two faces meet.  Edge e = 0..11 carries population i = 7 + e (c_i: FX/kernel.cpp:890-893) to the

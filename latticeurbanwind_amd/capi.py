@@ -27,7 +27,8 @@ SYMBOLS = [
     "luw_abi_version", "luw_last_error", "luw_device_count", "luw_format_float9", "luw_create", "luw_destroy", "luw_host_ptr", "luw_get_N",
     "luw_upload", "luw_download", "luw_initialize", "luw_run", "luw_get_t", "luw_set_f", "luw_set_coriolis", "luw_device_ptr", "luw_get_pitch",
     "luw_get_plane_stride", "luw_set_stream", "luw_enqueue_stream_collide", "luw_increment_time_step", "luw_reset_time_step", "luw_get_area",
-    "luw_enqueue_extract_fi", "luw_set_x_face_buffers", "luw_get_edge_length", "luw_enqueue_extract_edges", "luw_enqueue_insert_edges", "luw_group_create",
+    "luw_enqueue_extract_fi", "luw_set_x_face_buffers", "luw_set_x_face_inputs", "luw_get_edge_length", "luw_enqueue_extract_edges", "luw_enqueue_insert_edges",
+        "luw_group_create",
         "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info",
     "luw_group_overlaps", "luw_group_direct_peer_stores", "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download",
     "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis",
@@ -128,6 +129,7 @@ def load(path=None):
     L.luw_enqueue_extract_fi.argtypes = [vp, u32, vp, vp]
     L.luw_enqueue_insert_fi.argtypes = [vp, u32, vp, vp]
     L.luw_set_x_face_buffers.argtypes = [vp, vp, vp]
+    L.luw_set_x_face_inputs.argtypes = [vp, vp, vp]
     L.luw_get_edge_length.argtypes = [vp, u32]; L.luw_get_edge_length.restype = u64
     L.luw_enqueue_extract_edges.argtypes = [vp, C.POINTER(vp)]; L.luw_enqueue_insert_edges.argtypes = [vp, C.POINTER(vp)]
     L.luw_finish.argtypes = [vp]

@@ -281,6 +281,7 @@ int luw_download(luw_solver* s, uint32_t mask) {
 int luw_download_fi(luw_solver* s, void* host_dst) {
 	if(!s||!host_dst) return fail(LUW_ERR_INVALID, "luw_download_fi: bad argument");
 	if(int e = set_device(s)) return e;
+	if(int e = xin_settle(s)) return e;
 	if(int e = copy_pitched(host_dst, s->d_fi, s->ddf_bytes, s, 19u, false, s->stream)) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;
@@ -296,6 +297,7 @@ int luw_download_gi(luw_solver* s, void* host_dst) {
 int luw_upload_fi(luw_solver* s, const void* host_src) {
 	if(!s||!host_src) return fail(LUW_ERR_INVALID, "luw_upload_fi: bad argument");
 	if(int e = set_device(s)) return e;
+	xin_drop(s);   // a new lattice: nothing of an earlier exchange belongs to it
 	if(int e = copy_pitched(s->d_fi, host_src, s->ddf_bytes, s, 19u, true, s->stream)) return e;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return LUW_OK;

@@ -51,6 +51,7 @@ int luw_fields_every_step(const luw_solver* s) { return (s&&((s->cfg.options&LUW
 int luw_initialize(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_initialize: null solver");
 	s->every_step_auto = !reference_cells_are_inputs(s);
+	xin_drop(s);
 	if(int e = luw_upload(s, LUW_MASK_RHO|LUW_MASK_U|LUW_MASK_FLAGS|LUW_MASK_F|LUW_MASK_T)) return e;
 	const uint32_t bx = s->cfg.Nx>=256u ? 256u : ((s->cfg.Nx+63u)/64u)*64u;
 	const dim3 grid((s->cfg.Nx+bx-1u)/bx, s->cfg.Ny, s->cfg.Nz), block(bx);
@@ -96,12 +97,22 @@ int luw_set_kernel(luw_solver* s, uint32_t kernel) {
 }
 int luw_increment_time_step(luw_solver* s, uint64_t steps) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_increment_time_step: null solver");
+	if(s->xin_buf&&s->t+steps!=s->xin_for_t) { // pending x faces: only the step to the time they are for keeps them pending
+		if(int e = set_device(s)) return e;
+		if(int e = xin_settle(s)) return e;
+		xin_drop(s);
+	}
 	s->t += steps;
 	return LUW_OK;
 }
 
 int luw_reset_time_step(luw_solver* s) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_reset_time_step: null solver");
+	if(s->xin_buf) {
+		if(int e = set_device(s)) return e;
+		if(int e = xin_settle(s)) return e;
+		xin_drop(s);
+	}
 	s->t = 0ull;
 	return LUW_OK;
 }
@@ -202,13 +213,23 @@ int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* buf_p, void*
 	if(int e = set_device(s)) return e;
 	// the step kernels of this step have written both x faces into these very buffers already (the record is of step xf_t: it lapses with the step)
 	if(direction==0u&&buf_p==s->xf_p&&buf_m==s->xf_m&&s->xf_t==s->t&&s->xf_cover==3u) return LUW_OK;
+	if(int e = xin_settle(s)) return e;   // a pack kernel reads the lattice (the rims of the y / z faces: the x halo columns)
 	launch_transfer<false, false>(s, direction, buf_p, buf_m);
 	HIP_TRY(hipGetLastError());
+	return LUW_OK;
+}
+int luw_set_x_face_inputs(luw_solver* s, const void* buf_p, const void* buf_m) {
+	if(!s||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_set_x_face_inputs: bad argument");
+	if(!s->kp.halo_x) return fail(LUW_ERR_STATE, "luw_set_x_face_inputs: x is not split on this domain");
+	if(int e = set_device(s)) return e;
+	if(int e = xin_settle(s)) return e;      // an earlier pair that nothing has taken yet
+	s->xin_p = buf_p; s->xin_m = buf_m; s->xin_buf = 3u; s->xin_inplace = 0u; s->xin_odd = (uint32_t)(s->t&1ull); s->xin_for_t = s->t+1ull;
 	return LUW_OK;
 }
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_insert_fi: bad argument");
 	if(int e = set_device(s)) return e;
+	if(direction==0u) xin_drop(s);                                      // these values replace whatever was pending
 	launch_transfer<false, true>(s, direction, const_cast<void*>(buf_p), const_cast<void*>(buf_m));
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
@@ -233,12 +254,16 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 	if(!Lmax) return LUW_OK;
 	const dim3 grid((Lmax+255u)/256u, 12u), block(256);
 	const uint32_t odd = (uint32_t)(s->t&1ull);
+	// x faces pending in their receive buffers: the edges across the x cut join them there (whoever takes the faces -- a launch in place, or the insert
+	// kernel -- takes the edges with them)
+	const uint32_t to_faces = insert ? (s->xin_buf&~s->xin_inplace) : 0u;
+	void* const ip = (to_faces&1u) ? const_cast<void*>(s->xin_p) : nullptr; void* const im = (to_faces&2u) ? const_cast<void*>(s->xin_m) : nullptr;
 	if(s->ddf_bytes==2u) {
-		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi);
-		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi);
+		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)ip, (uint16_t*)im);
+		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)nullptr, (uint16_t*)nullptr);
 	} else {
-		if(insert) hipLaunchKernelGGL((k_edges<float, true>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi);
-		else hipLaunchKernelGGL((k_edges<float, false>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi);
+		if(insert) hipLaunchKernelGGL((k_edges<float, true>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)ip, (float*)im);
+		else hipLaunchKernelGGL((k_edges<float, false>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)nullptr, (float*)nullptr);
 	}
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;

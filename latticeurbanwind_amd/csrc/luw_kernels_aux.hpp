@@ -3,13 +3,14 @@
 #pragma once
 
 // ---------------------------------------------------------------- halo pack / unpack, FX/kernel.cpp:2188-2270
-// Face cell of thread t and its index a in the transfer buffers.  The buffers keep the reference's order (direction 0:
-// a = y + z Ny; 1: a = z + x Nz; 2: a = x + y Nx, FX/kernel.cpp:2188-2221), but the THREADS walk along x wherever x lies in the
-// face, so that the lattice side of the copy is coalesced (for direction 1 the small buffer side is strided instead).
+// Face cell of thread t and its index a in the transfer buffers: x runs fastest wherever x lies in the face (direction 0: a = y + z Ny; 1: a = x + z Nx;
+// 2: a = x + y Nx), so that threads, lattice rows AND buffer are walked together.  The reference orders its y faces a = z + x Nz (FX/kernel.cpp:2188-2221);
+// the order inside a buffer is private to the two kernels that fill and drain it -- the host only moves the bytes (FX/lbm.cpp:1908-1934) -- and with the
+// reference's order every element of a y face costs its own 128-byte line on the buffer side (0.046 -> 0.0xx ms per step on a 514x514x512 FP32 rank).
 template<int DIR> __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t t, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z,
 	uint32_t& a) {
 	if constexpr(DIR==0) { x = fixed; y = t%p.Ny; z = t/p.Ny; a = t; }
-	else if constexpr(DIR==1) { x = t%p.Nx; y = fixed; z = t/p.Nx; a = x*p.Nz+z; }
+	else if constexpr(DIR==1) { x = t%p.Nx; y = fixed; z = t/p.Nx; a = t; }
 	else { x = t%p.Nx; y = t/p.Nx; z = fixed; a = t; }
 }
 // device index of the neighbour of (x,y,z) in direction c_I (periodic wrap), I compile-time: three selects, no table
@@ -73,21 +74,25 @@ template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_i
 	if(t>=A) return;
 	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
 	uint32_t x, y, z, a;
-	face_cell<DIR>(p, t, Nd-1u, x, y, z, a);
-	insert_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
-	if constexpr(!G) {
-		insert_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi);
-		insert_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi);
-		insert_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi);
-		insert_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi);
+	if(buf_p) { // (a null buffer: that side is left alone -- xin_settle, luw_launch.hpp)
+		face_cell<DIR>(p, t, Nd-1u, x, y, z, a);
+		insert_one<T, G, DIR, 0, 0>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		if constexpr(!G) {
+			insert_one<T, G, DIR, 0, 1>(p, x, y, z, a, A, t_odd, buf_p, fi);
+			insert_one<T, G, DIR, 0, 2>(p, x, y, z, a, A, t_odd, buf_p, fi);
+			insert_one<T, G, DIR, 0, 3>(p, x, y, z, a, A, t_odd, buf_p, fi);
+			insert_one<T, G, DIR, 0, 4>(p, x, y, z, a, A, t_odd, buf_p, fi);
+		}
 	}
-	face_cell<DIR>(p, t, 0u, x, y, z, a);
-	insert_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
-	if constexpr(!G) {
-		insert_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi);
-		insert_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi);
-		insert_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi);
-		insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi);
+	if(buf_m) {
+		face_cell<DIR>(p, t, 0u, x, y, z, a);
+		insert_one<T, G, DIR, 1, 0>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		if constexpr(!G) {
+			insert_one<T, G, DIR, 1, 1>(p, x, y, z, a, A, t_odd, buf_m, fi);
+			insert_one<T, G, DIR, 1, 2>(p, x, y, z, a, A, t_odd, buf_m, fi);
+			insert_one<T, G, DIR, 1, 3>(p, x, y, z, a, A, t_odd, buf_m, fi);
+			insert_one<T, G, DIR, 1, 4>(p, x, y, z, a, A, t_odd, buf_m, fi);
+		}
 	}
 }
 // ---------------------------------------------------------------- edge populations: the halo exchange in ONE phase
@@ -106,8 +111,11 @@ __device__ __forceinline__ uint32_t edge_coord(const bool odd_pop, const bool se
 	if(odd_pop) return sender ? (s>0 ? N-1u : 0u) : (s>0 ? 1u : N-2u);        // halo-halo line beyond the corner -> owned corner line opposite
 	return sender ? (s>0 ? N-2u : 1u) : (s>0 ? 0u : N-1u);                    // owned corner line -> halo-halo line opposite
 }
-template<typename T,
-	bool INSERT> __global__ __launch_bounds__(256) void k_edges(const KParams p, const uint32_t t_odd, const EdgeBufs bufs, T* __restrict__ fi) {
+// INSERT with xin_p / xin_m set (the x faces wait in their receive buffers, luw_set_x_face_inputs): an edge across the x cut lands where the readers of those
+// buffers look for it -- the rim element of the halo cell that owns the slot (an odd population: the cell one step back along c from the owned corner cell, in
+// the buffer that came from -x; an even one: the halo-halo cell itself, in the buffer that came from +x) -- instead of in the lattice.
+template<typename T, bool INSERT> __global__ __launch_bounds__(256) void k_edges(const KParams p, const uint32_t t_odd, const EdgeBufs bufs,
+	T* __restrict__ fi, T* __restrict__ xin_p = nullptr, T* __restrict__ xin_m = nullptr) {
 	const uint32_t e = blockIdx.y, l = blockIdx.x*blockDim.x+threadIdx.x;
 	T* const buf = (T*)bufs.p[e];
 	if(!buf) return;
@@ -122,7 +130,14 @@ template<typename T,
 	// slot A(io, t) = t odd ? io : io + 1 holds population io + 1 at the cell; slot B(io, t) = t odd ? io + 1 : io holds population io at the +c_io neighbour
 	const uint32_t plane = (i&1) ? (t_odd ? (uint32_t)io+1u : (uint32_t)io) : (t_odd ? (uint32_t)io : (uint32_t)io+1u);
 	const size_t n = (size_t)plane*p.Np+c[0]+((size_t)c[1]+(size_t)c[2]*p.Ny)*p.Px;
-	if constexpr(INSERT) fi[n] = buf[l]; else buf[l] = fi[n];
+	if constexpr(INSERT) {
+		T* const face = pair==2 ? nullptr : (i&1) ? xin_m : xin_p;
+		if(face) {
+			const int k = io==7 ? 1 : io==13 ? 2 : io==9 ? 3 : 4;                                  // place of the pair in the face buffers (1, 7, 13, 9, 15)
+			if(i&1) c[ax_b] = (uint32_t)((int)c[ax_b]-sb);                                         // the halo cell that owns the slot
+			face[(size_t)k*p.Ny*p.Nz+c[1]+(size_t)c[2]*p.Ny] = buf[l];
+		} else fi[n] = buf[l];
+	} else buf[l] = fi[n];
 }
 // ---------------------------------------------------------------- mesh voxeliser
 // voxelize_mesh with direction 2 (z rays; LUW always voxelises TYPE_S along z, FX/lbm.cpp:1427-1430) for a static mesh:

@@ -115,6 +115,14 @@ template<typename T> struct CellAddr<T, true> {
 
 // MODE 0 is the product kernel.  MODE 1 ("copy": no collision) and MODE 2 ("noshift": x+1 neighbours replaced by x) are
 // measurement-only variants that isolate the memory system's share of the step; they do not compute physics.
+// XFACE input (luw_set_x_face_inputs): element of the x-face receive buffers that holds what the halo cell (x halo, y + dy, z + dz) of this row's border cell
+// received -- a = y + z Ny as in k_insert_fi<0>, periodic where y / z are not split (a split axis keeps y + dy inside its halo layers by itself)
+__device__ __forceinline__ size_t xface_in_elem(const KParams& p, const uint32_t y, const uint32_t z, const int dy, const int dz) {
+	uint32_t yy = y+(uint32_t)dy, zz = z+(uint32_t)dz;                   // unsigned wrap-around is undone by the two selects
+	if(dy<0&&y==0u) yy = p.Ny-1u; else if(dy>0&&yy==p.Ny) yy = 0u;
+	if(dz<0&&z==0u) zz = p.Nz-1u; else if(dz>0&&zz==p.Nz) zz = 0u;
+	return (size_t)yy+(size_t)zz*p.Ny;
+}
 // NT: 0 default cache policy, 1 non-temporal everywhere, 2 non-temporal on the 14 aligned planes and default policy on
 // the five x+1 planes, whose wave-edge lines are shared between neighbouring waves (product setting, measured best).
 // Waves per SIMD: the FP32 kernel is HBM-bound and measurably better with at most 4 resident waves (3.40 vs 3.43 ms at 512^3,
@@ -130,11 +138,16 @@ template<typename T> struct CellAddr<T, true> {
 // buffers -- element (b A + a), a = y + z Ny, b as in FX/kernel.cpp:2223-2229: exactly what transfer_extract_fi (k_extract_fi, direction 0) would copy out
 // of the lattice behind this kernel, one element per 128-byte line.  A cell of those columns that is not collided (TYPE_S / TYPE_G) forwards what its
 // slots hold, like the extract kernel: the populations a fluid cell beyond the cut pushed into it come back that way (bounce-back across a cut).
+// With xin_p / xin_m set (luw_set_x_face_inputs) the same cells take the five populations that ARRIVE through their face from the receive buffers of the last
+// exchange instead of from the lattice -- what k_insert_fi<0> would have put, one element per 128-byte line, into the slots these very loads read: the first
+// column's own slots A(1, 7, 13, 9, 15) (buffer "from -x", element of the halo cell the population left: y - c_y, z - c_z) and the last column's
+// neighbour slots B of the same pairs in the halo column (buffer "from +x", element y + c_y, z + c_z).
 template<typename T, int PARITY, int MODE=0, int NT=2, bool FLAT=false, bool STATS=false, bool NOFORCE=false, bool NATIVE=false, bool XFACE=false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T)==4 && LUW_MAXW_F32<4) ? LUW_MAXW_F32 : 4, sizeof(T)==4 ? LUW_MAXW_F32 : 8)))
 void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, T* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr,
-		const StatsArgs S = StatsArgs{}, T* __restrict__ xf_p = nullptr, T* __restrict__ xf_m = nullptr) {
+		const StatsArgs S = StatsArgs{}, T* __restrict__ xf_p = nullptr, T* __restrict__ xf_m = nullptr, const T* __restrict__ xin_p = nullptr,
+			const T* __restrict__ xin_m = nullptr) {
 	// lanes are laid over the row in 64-cell blocks aligned with the memory lines (xa = b.x0 rounded down to such a block
 	// start), whatever the box: lanes left of b.x0 idle
 	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
@@ -156,6 +169,19 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		if(x==p.Nx-2u) { xf_p[e] = value_of(1); xf_p[A+e] = value_of(7); xf_p[2u*A+e] = value_of(13); xf_p[3u*A+e] = value_of(9); xf_p[4u*A+e] = value_of(15); }
 		if(x==1u) { xf_m[e] = value_of(2); xf_m[A+e] = value_of(8); xf_m[2u*A+e] = value_of(14); xf_m[3u*A+e] = value_of(10); xf_m[4u*A+e] = value_of(16); }
 	};
+	// XFACE input: put(k, value) for the five loads of this cell that the receive buffers replace, k = the index the fluid path loads them into (k odd: own
+	// slot A(k); k even: slot B(k - 1) of the +c neighbour)
+	[[maybe_unused]] auto xface_in = [&](auto put) {
+		const size_t A = (size_t)p.Ny*p.Nz;
+		if(x==1u) {
+			put(1, xin_m[xface_in_elem(p, y, z, 0, 0)]); put(7, xin_m[A+xface_in_elem(p, y, z, -1, 0)]); put(13, xin_m[2u*A+xface_in_elem(p, y, z, 1, 0)]);
+			put(9, xin_m[3u*A+xface_in_elem(p, y, z, 0, -1)]); put(15, xin_m[4u*A+xface_in_elem(p, y, z, 0, 1)]);
+		}
+		if(x==p.Nx-2u) {
+			put(2, xin_p[xface_in_elem(p, y, z, 0, 0)]); put(8, xin_p[A+xface_in_elem(p, y, z, 1, 0)]); put(14, xin_p[2u*A+xface_in_elem(p, y, z, -1, 0)]);
+			put(10, xin_p[3u*A+xface_in_elem(p, y, z, 0, 1)]); put(16, xin_p[4u*A+xface_in_elem(p, y, z, 0, -1)]);
+		}
+	};
 	if((flagsn&TYPE_BO)==TYPE_S||(flagsn&TYPE_SU)==TYPE_G) {
 		if constexpr(STATS) stats_hold_constant_cell(Np, S, n, rho, u);
 		if constexpr(XFACE) { // forward what the slots hold: population i sits in slot B(i) of the +c_i neighbour, its partner i + 1 in slot A(i) of the cell
@@ -168,6 +194,16 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 						held[i+1] = ldo<false>(fi+(size_t)slotA<PARITY>(i)*Np, a.own());
 					}
 				});
+				if(xin_p) { // slot A(k) is held[k + 1], slot B(k - 1) is held[k - 1]; the lattice takes the values too (a pack kernel may read these slots later)
+					xface_in([&](const int k, const T v) { held[(k&1) ? k+1 : k-1] = v; });
+					static_for_pairs([&](auto ic) {
+						constexpr int i = decltype(ic)::value;
+						if constexpr(i==1||i==7||i==9||i==13||i==15) {
+							if(x==1u) sto<false>(fi+(size_t)slotA<PARITY>(i)*Np, a.own(), held[i+1]);
+							else sto<false>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>(), held[i]);
+						}
+					});
+				}
 				xface_out([&](const int i) { return held[i]; });
 			}
 		}
@@ -181,6 +217,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
 		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
 	});
+	if constexpr(XFACE) { if(xin_p&&(x==1u||x==p.Nx-2u)) xface_in([&](const int k, const T v) { f[k] = ddf_decode<T>(v); }); }
 	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
@@ -356,12 +393,17 @@ constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force 
 // behind each collision with the velocity before the force shift, the seven codes of both cells merged per plane at the tail.
 // NATIVE (LUW_OPT_NATIVE_ARITH): the collision in the hardware's own arithmetic (collide_cell_pk_native, luw_device.hpp); same memory path, same codec.
 // XFACE: see k_stream_collide_s.  Here the first owned column (x = 1) is cell x of its lane, the last (x = Nx - 2) cell x + 1 of its lane.
+// x-face INPUT (luw_set_x_face_inputs): every x-face instantiation but the uniform-force ones, which fill their 96 VGPRs (5 waves) without it -- five more
+// live registers behind the loads spill a pair into scratch, and parked in LDS the kernel loses what the saved unpack kernel gains (2.355 against 2.30 ms on
+// the FP16C + Coriolis rank of [4,2,1]).  Their launches have the library run the unpack kernel for their side.
+constexpr bool pair_reads_x_face_inputs(const int force) { return force!=PAIR_FORCE_UNIFORM; }
 template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false, bool NATIVE=false, bool XFACE=false>
 __global__ __launch_bounds__(256)
 	__attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL, NATIVE), pair_waves(FORCE, PARK, THERMAL, NATIVE))))
 void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi, float* __restrict__ rho, float* __restrict__ u,
 		const uint8_t* __restrict__ flags, const float* __restrict__ F, const int write_fields, const StatsArgs S = StatsArgs{},
-		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, uint16_t* __restrict__ xf_p = nullptr, uint16_t* __restrict__ xf_m = nullptr) {
+		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, uint16_t* __restrict__ xf_p = nullptr, uint16_t* __restrict__ xf_m = nullptr,
+			const uint16_t* __restrict__ xin_p = nullptr, const uint16_t* __restrict__ xin_m = nullptr) {
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
 	static_assert(!XFACE||(!THERMAL&&!STATS&&MODE==0), "x-face output: plain steps of the D3Q19 lattice");
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
@@ -397,6 +439,21 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		if(!(c==1&&tail) && !cell_is_halo(p, x+c, y, z)) sample_from_fields(c);
 	};
 	[[maybe_unused]] const size_t xfA = (size_t)p.Ny*p.Nz, xfe = (size_t)y+(size_t)z*p.Ny;   // XFACE: face area and this row's element of the face buffers
+	// x-face inputs: the five values of a border lane's cell, fetched from the receive buffers ahead of the DDF loads and merged into the loaded dwords behind
+	// them (first column: own slots, low halves; last column: the slots in the halo column, high halves)
+	[[maybe_unused]] uint32_t xv[5];
+	[[maybe_unused]] bool xin_first = false, xin_last = false;
+	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE)) {
+		if(xin_p) {
+			xin_first = x==1u; xin_last = x+3u==p.Nx;
+			if(xin_first||xin_last) {
+				const uint16_t* const src = xin_first ? xin_m : xin_p;
+				const int sg = xin_first ? -1 : 1;
+				xv[0] = src[xface_in_elem(p, y, z, 0, 0)]; xv[1] = src[xfA+xface_in_elem(p, y, z, sg, 0)]; xv[2] = src[2u*xfA+xface_in_elem(p, y, z, -sg, 0)];
+				xv[3] = src[3u*xfA+xface_in_elem(p, y, z, 0, sg)]; xv[4] = src[4u*xfA+xface_in_elem(p, y, z, 0, -sg)];
+			}
+		}
+	}
 	if(!proc[0]&&!proc[1]) {
 		if constexpr(STATS) { // two idle cells (solid / halo / padding): constants, stored without arithmetic (stats_hold_constant_cell)
 			if(!cell_is_halo(p, x, y, z)) stats_hold_constant_cell(Np, S, n, rho, u);
@@ -409,8 +466,11 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 					constexpr int k = i==1 ? 0 : i==7 ? 1 : i==13 ? 2 : i==9 ? 3 : 4;
 					// first column (cell x): its own slot A(i) holds population i + 1; last column (cell x + 1): slot B(i) of its +c_i neighbour, at x + 2,
 					// holds i
-					if(x==1u) xf_m[(size_t)k*xfA+xfe] = fi[(size_t)slotA<PARITY>(i)*Np+x];
-					if(x+3u==p.Nx) xf_p[(size_t)k*xfA+xfe] = *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)+(x+2u));
+					// (x-face inputs: what those slots would hold sits in xv; the lattice takes it too -- a pack kernel may read these slots later)
+					if(xin_first) fi[(size_t)slotA<PARITY>(i)*Np+x] = (uint16_t)xv[k];
+					if(xin_last) *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)+(x+2u)) = (uint16_t)xv[k];
+					if(x==1u) xf_m[(size_t)k*xfA+xfe] = xin_first ? (uint16_t)xv[k] : fi[(size_t)slotA<PARITY>(i)*Np+x];
+					if(x+3u==p.Nx) xf_p[(size_t)k*xfA+xfe] = xin_last ? (uint16_t)xv[k] : *(fi+(size_t)slotB<PARITY>(i)*Np+nrow<i>(rb)+(x+2u));
 				}
 			});
 		}
@@ -435,6 +495,18 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 				raw[i+1] = (raw[i+1]&0xFFFFu)|(hi<<16);
 			}
 		});
+	}
+	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE)) {
+		if(xin_first||xin_last) {
+			static_for_pairs([&](auto ic) {
+				constexpr int i = decltype(ic)::value;
+				if constexpr(i==1||i==7||i==9||i==13||i==15) {
+					constexpr int k = i==1 ? 0 : i==7 ? 1 : i==13 ? 2 : i==9 ? 3 : 4;
+					if(xin_first) raw[i] = (raw[i]&0xFFFF0000u)|xv[k];
+					if(xin_last) raw[i+1] = (raw[i+1]&0xFFFFu)|(xv[k]<<16);
+				}
+			});
+		}
 	}
 	[[maybe_unused]] uint32_t rawg[7];                               // THERMAL: the same for the seven planes of the temperature lattice
 	if constexpr(THERMAL) {

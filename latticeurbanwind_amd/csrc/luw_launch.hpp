@@ -90,6 +90,33 @@ static void xface_covered(luw_solver* s, const Box& b) {
 	if(b.x0<=1u&&b.x1>1u) s->xf_cover |= 2u;                            // first owned column: the face towards -x
 	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) s->xf_cover |= 1u;        // last owned column: the face towards +x
 }
+// ---- x-face input (luw_set_x_face_inputs): the insert of the x faces is pending, the values wait in the receive buffers.  A launch of the step they are for
+// that holds a border column reads that column's side there when its instantiation can (the ones with the x-face output); everything else that wants a side
+// in the lattice -- another instantiation, a pack kernel, a download, a change of t other than the step to xin_for_t -- has xin_settle run the insert kernel
+// for it first, with the time parity of the moment the buffers were handed over.  Once a launch has read a side in place the lattice cannot take it any more
+// (the cells' slots hold their new values): the launches of one step on one border column must agree on whether they can read the buffers.
+static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m, uint32_t odd);
+static int xin_settle(luw_solver* s, const uint32_t sides = 3u) {
+	const uint32_t todo = sides & s->xin_buf & ~s->xin_inplace;
+	if(!todo) return LUW_OK;
+	launch_insert_x(s, (todo&1u) ? s->xin_p : nullptr, (todo&2u) ? s->xin_m : nullptr, s->xin_odd);
+	HIP_TRY(hipGetLastError());
+	s->xin_buf &= ~todo;
+	return LUW_OK;
+}
+static void xin_drop(luw_solver* s) { s->xin_buf = 0u; s->xin_inplace = 0u; }
+// before a stream_collide launch: may it read the pending sides of its border columns in place (sets s->xin_use for the instance launcher), or must they go
+// into the lattice first?
+static int xin_before_launch(luw_solver* s, const Box& b, const bool instantiation_reads_them) {
+	s->xin_use = false;
+	if(!s->xin_buf||!s->kp.halo_x||s->cfg.Nx<4u) return LUW_OK;
+	const uint32_t need = (((b.x0<=1u&&b.x1>1u) ? 2u : 0u)|((b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) ? 1u : 0u)) & s->xin_buf;
+	if(!need) return LUW_OK;
+	if(instantiation_reads_them&&s->t==s->xin_for_t) { s->xin_use = true; s->xin_inplace |= need; return LUW_OK; }
+	if(need&s->xin_inplace) return fail(LUW_ERR_STATE, "stream_collide: an earlier launch of this step read this border column's x face in its receive buffer; "
+		"this launch cannot");
+	return xin_settle(s, need);
+}
 // ---------------------------------------------------------------- the kernel instantiations, as tables
 // Every stream_collide variant the library carries is one row: what it is for (the key the launchers look up) and the function that launches its two
 // time-parity instances.  Nothing else instantiates the step kernels.
@@ -103,10 +130,11 @@ template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE, bool
 	bool XFACE=false> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	T* const fi = (T*)s->d_fi; T* const gi = MODE==4 ? (T*)s->d_gi : nullptr; float* const Tf = MODE==4 ? s->d_T : nullptr;
 	T* const xp = XFACE ? (T*)s->xf_p : nullptr; T* const xm = XFACE ? (T*)s->xf_m : nullptr;
+	const T* const ip = (XFACE&&s->xin_use) ? (const T*)s->xin_p : nullptr; const T* const im = (XFACE&&s->xin_use) ? (const T*)s->xin_m : nullptr;
 	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE, NATIVE, XFACE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa,
-		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm);
+		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm, ip, im);
 	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE, NATIVE, XFACE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi,
-		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm);
+		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm, ip, im);
 }
 struct ScalarRow { ScalarKey key; ScalarLaunch launch; const char* what; };
 static const ScalarRow scalar_table[] = {
@@ -180,6 +208,7 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	for(const ScalarRow& r : scalar_table) {
 		const ScalarKey& q = r.key;
 		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce&&q.native==k.native&&q.xface==k.xface) {
+			if(int e = xin_before_launch(s, b, k.xface)) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
 			return LUW_OK;
@@ -195,10 +224,12 @@ template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL, bool NATIVE=f
 	bool XFACE=false> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	uint16_t* const fi = (uint16_t*)s->d_fi; uint16_t* const gi = THERMAL ? (uint16_t*)s->d_gi : nullptr; float* const Tf = THERMAL ? s->d_T : nullptr;
 	uint16_t* const xp = XFACE ? (uint16_t*)s->xf_p : nullptr; uint16_t* const xm = XFACE ? (uint16_t*)s->xf_m : nullptr;
+	const uint16_t* const ip = (XFACE&&s->xin_use) ? (const uint16_t*)s->xin_p : nullptr;
+	const uint16_t* const im = (XFACE&&s->xin_use) ? (const uint16_t*)s->xin_m : nullptr;
 	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL, NATIVE, XFACE>), g.grid, g.block, g.lds, s->stream, s->kp, b,
-		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm);
+		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm, ip, im);
 	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL, NATIVE, XFACE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi,
-		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm);
+		s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm, ip, im);
 }
 struct PairRow { PairKey key; PairLaunch launch; const char* what; };
 static const PairRow pair_table[] = {
@@ -264,6 +295,9 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	for(const PairRow& r : pair_table) {
 		const PairKey& q = r.key;
 		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native&&q.xface==k.xface) {
+			// (the uniform-force instantiation sits at its 96 VGPRs without a register for the x-face INPUT: it writes its faces, and has the unpack kernel
+			// run for what it receives -- pair_reads_x_face_inputs, luw_kernels_step.hpp)
+			if(int e = xin_before_launch(s, b, k.xface&&pair_reads_x_face_inputs(k.force))) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
 			return LUW_OK;
@@ -328,4 +362,12 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 	if(s->ddf_bytes==2u) { if(direction==0u) LUW_TR(uint16_t, 0); else if(direction==1u) LUW_TR(uint16_t, 1); else LUW_TR(uint16_t, 2); }
 	else { if(direction==0u) LUW_TR(float, 0); else if(direction==1u) LUW_TR(float, 1); else LUW_TR(float, 2); }
 	#undef LUW_TR
+}
+// the x-face insert with an explicit time parity (xin_settle: the parity of the moment the buffers were handed over)
+static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m, const uint32_t odd) {
+	const uint32_t A = (uint32_t)luw_get_area(s, 0u);
+	const dim3 grid((A+255u)/256u), block(256);
+	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const uint16_t*)buf_p,
+		(const uint16_t*)buf_m, (uint16_t*)s->d_fi);
+	else hipLaunchKernelGGL((k_insert_fi<float, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_fi);
 }

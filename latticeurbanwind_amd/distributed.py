@@ -298,6 +298,7 @@ class HipDomain:
         self.step = self.lbm.domain_step_create(self.compute.cuda_stream, self.comm.cuda_stream, layout.X_SHELL)
         self.thermal = kw.get("alpha") is not None       # thermal D3Q7 lattice: one more population per face cell travels
         self.buf, self.gbuf = {}, {}
+        self.x_insert_fused, self.x_pairs = False, None
         for a in layout.split_axes():
             A = self.lbm.area(a)
             self.buf[a] = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(4)]  # send_p, send_m, recv_p, recv_m
@@ -305,8 +306,14 @@ class HipDomain:
                 self.buf[a][0], self.buf[a][1] = self.buf[a][3], self.buf[a][2]
             if a == 0 and os.environ.get("LUW_X_FACE_FUSED", "1") != "0":
                 # the step kernels that hold the first / last owned x column write the x faces into the send buffers themselves; extract(0) then has
-                # nothing to launch (LUW_X_FACE_FUSED=0: the pack kernel as before, A/B switch)
+                # nothing to launch (LUW_X_FACE_FUSED=0: the pack kernel as before, A/B switch) ...
                 self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
+                # ... and read the x faces they receive from the receive buffers (insert_deferred; LUW_X_INSERT_FUSED=0: the unpack kernel, A/B switch)
+                self.x_insert_fused = os.environ.get("LUW_X_INSERT_FUSED", "1") != "0"
+                if alias_faces and self.x_insert_fused:
+                    # written where they are read: the step that reads one pair of buffers writes the other (a neighbour's stores would race with the loads)
+                    other = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(2)]
+                    self.x_pairs = [self.buf[0], [other[1], other[0], other[0], other[1]]]        # send_p is recv_m, send_m is recv_p
             if self.thermal:
                 self.gbuf[a] = [torch.zeros(A, dtype=self.dtype, device=self.device) for _ in range(4)]
                 if alias_faces:
@@ -356,6 +363,18 @@ class HipDomain:
         self.lbm.set_stream(stream.cuda_stream)
         b = self.buf[axis]
         self.lbm.enqueue_insert_fi(axis, b[2].data_ptr(), b[3].data_ptr())
+
+    def insert_deferred(self, axis, stream):
+        """insert(0) without its kernel where the library can do that (one-phase exchange: nothing packs from the lattice before the next step): the next
+        step's kernels read the x faces from the receive buffers.  Other axes: the unpack kernel."""
+        if axis != 0 or not self.x_insert_fused:
+            return self.insert(axis, stream)
+        self.lbm.set_stream(stream.cuda_stream)
+        b = self.buf[0]
+        self.lbm.set_x_face_inputs(b[2].data_ptr(), b[3].data_ptr())
+        if self.x_pairs:              # faces written where they are read: the next step writes the other pair
+            self.buf[0] = self.x_pairs[1] if b is self.x_pairs[0] else self.x_pairs[0]
+            self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
 
     def extract_edges(self, stream):
         """packs every edge; returns [(e, send, receive)]"""
@@ -545,7 +564,7 @@ class DomainDecomposedLBM:
         else:
             self.transport.exchange_all(msgs)
         for a in axes:
-            b.insert(a, stream)
+            (b.insert_deferred if hasattr(b, "insert_deferred") else b.insert)(a, stream)
         b.insert_edges(stream)
         if thermal:
             for a in axes:

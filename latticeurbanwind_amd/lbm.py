@@ -198,6 +198,7 @@ class LBM:
         return bool(fused.value)
     def enqueue_extract_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def set_x_face_buffers(self, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_set_x_face_buffers(self._h, buf_p_ptr, buf_m_ptr))
+    def set_x_face_inputs(self, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_set_x_face_inputs(self._h, buf_p_ptr, buf_m_ptr))
     def edge_length(self, e): return int(self._L.luw_get_edge_length(self._h, e))
 
     def enqueue_edges(self, ptrs, insert):

@@ -206,3 +206,49 @@ def test_edge_kernels_move_the_lines_the_two_hop_route_moves(luw, fp16c, D):
     with pytest.raises(luw.LuwError):
         g.enqueue_edges([0] * 12, insert=False)              # an edge the domain has, without a buffer
     g.close()
+
+
+@pytest.mark.parametrize("fp16c,native,Nx", [(False, False, 42), (True, False, 322), (True, True, 322)])
+@pytest.mark.parametrize("forces", ["none", "coriolis", "zones+coriolis"])
+def test_x_faces_read_from_the_receive_buffers_equal_the_insert_kernel(luw, monkeypatch, fp16c, native, Nx, forces):
+    """luw_set_x_face_inputs: the step kernels of an x-split rank take the x faces of the last exchange from the receive buffers (edges across the x cut in
+    their rims) instead of from the lattice behind the unpack kernel.  The production host on one rank that is its own neighbour, a few plain steps, then
+    sampled ones (kernels that cannot read the buffers: the library runs the unpack kernel by itself), solids on both border columns; the FP16C domain is
+    322 cells wide, so that its second x slab (64 cells) takes the one-cell kernel, which cannot read the buffers either: that side alone goes through the
+    unpack kernel.  Same DDFs, rho, u as with LUW_X_INSERT_FUSED=0, which the rank-shape tests hold to the oracle."""
+    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, PeerLoopbackTransport
+    from helpers import TYPE_S, TYPE_E
+    D, own = (2, 2, 1), (Nx - 2, 10, 9)
+    gN = tuple(o * d for o, d in zip(own, D))
+    monkeypatch.setenv("LUW_X_SHELL", "128" if fp16c else "16")
+    kw = dict(buffer_nudging=dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1), top_sponge=dict(n_cells=3, inv_tau=0.02)) \
+        if "zones" in forces else {}
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LUW_X_INSERT_FUSED", fused)
+        lay = DomainLayout(gN, D, 0)
+        sim = DomainDecomposedLBM(gN, D, 0.01, rank=0, transport=PeerLoopbackTransport(lay), fp16c=fp16c, device=0, native_arith=native, **kw)
+        assert sim.overlap and sim.one_phase and sim.backend.x_insert_fused == (fused == "1")
+        lx, ly, lz = lay.lN
+        st = synthetic_state(lx, ly, lz, seed=23, shell=None)
+        flags = st[0].reshape(lz, ly, lx).copy()
+        if "zones" in forces:      # the global faces this rank owns are inputs (reference cells of the zones: otherwise a step reads fields it is rewriting)
+            flags[:, :, 1] = TYPE_E; flags[:, 1, :] = TYPE_E; flags[lz - 1, :, :] = TYPE_E
+        flags[2:5, 3:7, 1] = TYPE_S; flags[4:8, 2:5, lx - 2] = TYPE_S; flags[6, 6, 1:3] = TYPE_S; flags[3, 8, lx - 3:lx - 1] = TYPE_S
+        sim.set_fields(flags.ravel(), st[1], st[2])
+        if "coriolis" in forces: sim.backend.set_coriolis(0.0, 3e-5, 4e-5)
+        sim.run(5)
+        assert not sim.backend.lbm.fields_every_step()      # (every reference cell is an input)
+        sim.backend.stats_reset()
+        sim.run(4, sample=(2, 2))
+        sim.run(3)
+        u, rho = sim.fields()
+        # DDF slots located at owned cells that are collided (a solid border cell's slots, and the halo column's, are storage nobody reads: the insert kernel
+        # fills them every step, the kernels that read the buffers forward from there)
+        live = np.zeros((lz, ly, lx), bool); live[:, 1:ly - 1, 1:lx - 1] = True
+        live &= flags != TYPE_S
+        fi = np.asarray(sim.backend.lbm.download_fi()).reshape(19, lz, ly, lx)[:, live]
+        res[fused] = (u.copy(), rho.copy(), fi.copy())
+        sim.backend.close()
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)

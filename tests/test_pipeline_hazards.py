@@ -59,8 +59,8 @@ def transfer_slots(axis, t, lN, thermal):
 
 def edge_slots(e, t, lN):
     """(slots the edge pack reads, slots the edge unpack writes) of edge message e = population 7 + e (csrc/luw_kernels_aux.hpp k_edges): an odd population
-    leaves in slot B of the halo-halo line beyond the sender's corner and lands in slot B of the receiver's owned corner line; an even one leaves in slot A of the
-    owned corner line and lands in the halo-halo line"""
+    leaves in slot B of the halo-halo line beyond the sender's corner and lands in slot B of the receiver's owned corner line; an even one leaves in slot A
+    of the owned corner line and lands in the halo-halo line"""
     i = 7 + e
     odd_pop, io = i % 2 == 1, i if i % 2 else i - 1
     plane = (io + 1 if t % 2 else io) if odd_pop else (io if t % 2 else io + 1)
