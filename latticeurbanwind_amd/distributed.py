@@ -154,6 +154,8 @@ class TorchDistTransport:
         `recv` takes the same type of message from the domain in direction -c.  Every rank lists the types in the same order, so the k-th send of A to B is
         the k-th receive of B from A also where several directions lead to the same rank (two domains along an axis; a rank that is its own neighbour)."""
         dist, lay = self.dist, self.layout
+        if not messages:         # a domain without a cut: nothing to move
+            return
         ops = [dist.P2POp(dist.isend, s, lay.neighbor_dir(c), self.group) for s, _, c in messages]
         ops += [dist.P2POp(dist.irecv, r, lay.neighbor_dir(tuple(-v for v in c)), self.group) for _, r, c in messages]
         for req in dist.batch_isend_irecv(ops):

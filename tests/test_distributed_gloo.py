@@ -24,8 +24,10 @@ def single_domain(gN, steps, fp16c):
 
 # world 8: the two cuts of BASELINE's 8-GPU tile -- the deck's literal n_gpu = [4,2,1] and the x-whole [1,4,2] -- with every rank's neighbours distinct ranks
 # (the one-GPU box can only rehearse them with all domains on one device)
+# (the first case: a world of one rank without any cut -- an exchange with nothing to move)
 # exchange: "batch" = all faces + the 12 edge populations in one batch (the default), "sequential" = the reference's three phases with rims
-@pytest.mark.parametrize("gN,D,fp16c,exchange", [((16, 10, 6), (2, 1, 1), False, "batch"), ((12, 12, 8), (2, 2, 1), False, "batch"),
+@pytest.mark.parametrize("gN,D,fp16c,exchange",
+    [((8, 6, 5), (1, 1, 1), False, "batch"), ((16, 10, 6), (2, 1, 1), False, "batch"), ((12, 12, 8), (2, 2, 1), False, "batch"),
     ((12, 12, 8), (2, 2, 1), False, "sequential"), ((12, 8, 8), (1, 2, 2), True, "batch"), ((16, 8, 6), (4, 2, 1), False, "batch"),
     ((10, 16, 8), (1, 4, 2), True, "batch"), ((8, 8, 8), (2, 2, 2), True, "batch"), ((8, 8, 8), (2, 2, 2), False, "sequential"),
     ((12, 12, 8), (2, 2, 1), False, "batch-without-edges")])
