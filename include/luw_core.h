@@ -187,14 +187,15 @@ int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* dev_buf
  * -- a launch of another kernel, a pack kernel, luw_download_fi, a change of t other than the step to t + 1 -- makes the library run the insert kernel then,
  * on the stream set at that moment.  The caller keeps the buffers unchanged until the next step's launches have run (stream order on one stream is enough;
  * a host whose neighbour writes them directly alternates two pairs), calls luw_enqueue_insert_edges AFTER this (the edges across the x cut then land in the
- * rims of these buffers), and does not mix, within one step, launches on the border columns that can read the buffers with launches that cannot (error). */
+ * rims of these buffers), and does not mix, within one step, launches on ONE border column that can read the buffers with launches that cannot (error;
+ * the two columns are tracked separately).  Either buffer may be NULL: that side is not handed over by the call. */
 int luw_set_x_face_inputs(luw_solver* s, const void* dev_buffer_p, const void* dev_buffer_m);
 /* The halo exchange in ONE phase instead of the reference's x -> y -> z sequence (FX/lbm.cpp:1908-1934, where a population that crosses two cuts at
  * once reaches the diagonal neighbour in two hops through the rims of the faces): in D3Q19 exactly one population crosses a given pair of cuts in a
  * given diagonal direction, along the line where the two faces meet.  Edge e = 0..11 carries population i = 7 + e (c_i: FX/kernel.cpp:890-893) to the
  * domain in direction c_i; its buffer holds luw_get_edge_length(e) elements (the local extent of the third axis; 0 when that pair of axes is not split
  * on this domain).  A host packs all faces and edges, moves everything in one batch, inserts the faces of all axes (any order) and the edges LAST: same
- * populations in the same slots as the three-phase route.  dev_buffers: 12 device pointers (NULL where the length is 0). */
+ * populations in the same slots as the three-phase route.  dev_buffers: 12 device pointers; a NULL entry: that edge is not moved by the call. */
 uint64_t luw_get_edge_length(const luw_solver* s, uint32_t edge);
 int luw_enqueue_extract_edges(luw_solver* s, void* const* dev_buffers);
 int luw_enqueue_insert_edges(luw_solver* s, const void* const* dev_buffers);

@@ -97,10 +97,11 @@ int luw_set_kernel(luw_solver* s, uint32_t kernel) {
 }
 int luw_increment_time_step(luw_solver* s, uint64_t steps) {
 	if(!s) return fail(LUW_ERR_INVALID, "luw_increment_time_step: null solver");
-	if(s->xin_buf&&s->t+steps!=s->xin_for_t) { // pending x faces: only the step to the time they are for keeps them pending
+	for(uint32_t side=0u; side<2u; side++) if((s->xin_buf&(1u<<side))&&s->t+steps!=s->xin_for_t[side]) {
+		// a pending x face: only the step to the time it is for keeps it pending
 		if(int e = set_device(s)) return e;
-		if(int e = xin_settle(s)) return e;
-		xin_drop(s);
+		if(int e = xin_settle(s, 1u<<side)) return e;
+		s->xin_buf &= ~(1u<<side); s->xin_inplace &= ~(1u<<side);
 	}
 	s->t += steps;
 	return LUW_OK;
@@ -219,11 +220,14 @@ int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* buf_p, void*
 	return LUW_OK;
 }
 int luw_set_x_face_inputs(luw_solver* s, const void* buf_p, const void* buf_m) {
-	if(!s||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_set_x_face_inputs: bad argument");
+	if(!s||(!buf_p&&!buf_m)) return fail(LUW_ERR_INVALID, "luw_set_x_face_inputs: bad argument");
 	if(!s->kp.halo_x) return fail(LUW_ERR_STATE, "luw_set_x_face_inputs: x is not split on this domain");
 	if(int e = set_device(s)) return e;
-	if(int e = xin_settle(s)) return e;      // an earlier pair that nothing has taken yet
-	s->xin_p = buf_p; s->xin_m = buf_m; s->xin_buf = 3u; s->xin_inplace = 0u; s->xin_odd = (uint32_t)(s->t&1ull); s->xin_for_t = s->t+1ull;
+	const uint32_t sides = (buf_p ? 1u : 0u)|(buf_m ? 2u : 0u);
+	if(int e = xin_settle(s, sides)) return e;      // an earlier buffer of that side that nothing has taken yet
+	if(buf_p) { s->xin_p = buf_p; s->xin_odd[0] = (uint32_t)(s->t&1ull); s->xin_for_t[0] = s->t+1ull; }
+	if(buf_m) { s->xin_m = buf_m; s->xin_odd[1] = (uint32_t)(s->t&1ull); s->xin_for_t[1] = s->t+1ull; }
+	s->xin_buf |= sides; s->xin_inplace &= ~sides;
 	return LUW_OK;
 }
 int luw_enqueue_insert_fi(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m) {
@@ -247,9 +251,8 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 	EdgeBufs B{}; uint32_t Lmax = 0u;
 	for(uint32_t e=0u; e<12u; e++) {
 		const uint64_t L = luw_get_edge_length(s, e);
-		B.p[e] = L ? bufs[e] : nullptr;
-		if(L&&!bufs[e]) return fail(LUW_ERR_INVALID, std::string(who)+": no buffer for an edge this domain has");
-		Lmax = std::max(Lmax, (uint32_t)L);
+		B.p[e] = L ? bufs[e] : nullptr;             // (a null entry: that edge is not moved by this call)
+		if(B.p[e]) Lmax = std::max(Lmax, (uint32_t)L);
 	}
 	if(!Lmax) return LUW_OK;
 	const dim3 grid((Lmax+255u)/256u, 12u), block(256);

@@ -173,11 +173,11 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 	// slot A(k); k even: slot B(k - 1) of the +c neighbour)
 	[[maybe_unused]] auto xface_in = [&](auto put) {
 		const size_t A = (size_t)p.Ny*p.Nz;
-		if(x==1u) {
+		if(x==1u&&xin_m) {
 			put(1, xin_m[xface_in_elem(p, y, z, 0, 0)]); put(7, xin_m[A+xface_in_elem(p, y, z, -1, 0)]); put(13, xin_m[2u*A+xface_in_elem(p, y, z, 1, 0)]);
 			put(9, xin_m[3u*A+xface_in_elem(p, y, z, 0, -1)]); put(15, xin_m[4u*A+xface_in_elem(p, y, z, 0, 1)]);
 		}
-		if(x==p.Nx-2u) {
+		if(x==p.Nx-2u&&xin_p) {
 			put(2, xin_p[xface_in_elem(p, y, z, 0, 0)]); put(8, xin_p[A+xface_in_elem(p, y, z, 1, 0)]); put(14, xin_p[2u*A+xface_in_elem(p, y, z, -1, 0)]);
 			put(10, xin_p[3u*A+xface_in_elem(p, y, z, 0, 1)]); put(16, xin_p[4u*A+xface_in_elem(p, y, z, 0, -1)]);
 		}
@@ -194,7 +194,8 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 						held[i+1] = ldo<false>(fi+(size_t)slotA<PARITY>(i)*Np, a.own());
 					}
 				});
-				if(xin_p) { // slot A(k) is held[k + 1], slot B(k - 1) is held[k - 1]; the lattice takes the values too (a pack kernel may read these slots later)
+				if((x==1u) ? xin_m!=nullptr : xin_p!=nullptr) {
+					// slot A(k) is held[k + 1], slot B(k - 1) is held[k - 1]; the lattice takes the values too (a pack kernel may read these slots later)
 					xface_in([&](const int k, const T v) { held[(k&1) ? k+1 : k-1] = v; });
 					static_for_pairs([&](auto ic) {
 						constexpr int i = decltype(ic)::value;
@@ -217,7 +218,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
 		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
 	});
-	if constexpr(XFACE) { if(xin_p&&(x==1u||x==p.Nx-2u)) xface_in([&](const int k, const T v) { f[k] = ddf_decode<T>(v); }); }
+	if constexpr(XFACE) { if((xin_p||xin_m)&&(x==1u||x==p.Nx-2u)) xface_in([&](const int k, const T v) { f[k] = ddf_decode<T>(v); }); }
 	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
@@ -444,8 +445,8 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 	[[maybe_unused]] uint32_t xv[5];
 	[[maybe_unused]] bool xin_first = false, xin_last = false;
 	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE)) {
-		if(xin_p) {
-			xin_first = x==1u; xin_last = x+3u==p.Nx;
+		if(xin_p||xin_m) {   // (each side on its own: a host may have handed over one of them only)
+			xin_first = x==1u&&xin_m; xin_last = x+3u==p.Nx&&xin_p;
 			if(xin_first||xin_last) {
 				const uint16_t* const src = xin_first ? xin_m : xin_p;
 				const int sg = xin_first ? -1 : 1;

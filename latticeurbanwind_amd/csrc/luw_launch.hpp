@@ -99,7 +99,11 @@ static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m,
 static int xin_settle(luw_solver* s, const uint32_t sides = 3u) {
 	const uint32_t todo = sides & s->xin_buf & ~s->xin_inplace;
 	if(!todo) return LUW_OK;
-	launch_insert_x(s, (todo&1u) ? s->xin_p : nullptr, (todo&2u) ? s->xin_m : nullptr, s->xin_odd);
+	if(todo==3u&&s->xin_odd[0]==s->xin_odd[1]) launch_insert_x(s, s->xin_p, s->xin_m, s->xin_odd[0]);
+	else {
+		if(todo&1u) launch_insert_x(s, s->xin_p, nullptr, s->xin_odd[0]);
+		if(todo&2u) launch_insert_x(s, nullptr, s->xin_m, s->xin_odd[1]);
+	}
 	HIP_TRY(hipGetLastError());
 	s->xin_buf &= ~todo;
 	return LUW_OK;
@@ -112,7 +116,9 @@ static int xin_before_launch(luw_solver* s, const Box& b, const bool instantiati
 	if(!s->xin_buf||!s->kp.halo_x||s->cfg.Nx<4u) return LUW_OK;
 	const uint32_t need = (((b.x0<=1u&&b.x1>1u) ? 2u : 0u)|((b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) ? 1u : 0u)) & s->xin_buf;
 	if(!need) return LUW_OK;
-	if(instantiation_reads_them&&s->t==s->xin_for_t) { s->xin_use = true; s->xin_inplace |= need; return LUW_OK; }
+	const bool for_this_step = (!(need&1u)||s->xin_for_t[0]==s->t) && (!(need&2u)||s->xin_for_t[1]==s->t);
+	// (a side the box does not hold, or that is in the lattice already, gets a null pointer: the kernel tests each side's lanes against its own buffer)
+	if(instantiation_reads_them&&for_this_step) { s->xin_use = true; s->xin_inplace |= need; return LUW_OK; }
 	if(need&s->xin_inplace) return fail(LUW_ERR_STATE, "stream_collide: an earlier launch of this step read this border column's x face in its receive buffer; "
 		"this launch cannot");
 	return xin_settle(s, need);
@@ -130,7 +136,8 @@ template<typename T, int MODE, int NT, bool FLAT, bool STATS, bool NOFORCE, bool
 	bool XFACE=false> static void scalar_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	T* const fi = (T*)s->d_fi; T* const gi = MODE==4 ? (T*)s->d_gi : nullptr; float* const Tf = MODE==4 ? s->d_T : nullptr;
 	T* const xp = XFACE ? (T*)s->xf_p : nullptr; T* const xm = XFACE ? (T*)s->xf_m : nullptr;
-	const T* const ip = (XFACE&&s->xin_use) ? (const T*)s->xin_p : nullptr; const T* const im = (XFACE&&s->xin_use) ? (const T*)s->xin_m : nullptr;
+	const T* const ip = (XFACE&&s->xin_use&&(s->xin_buf&1u)) ? (const T*)s->xin_p : nullptr;
+	const T* const im = (XFACE&&s->xin_use&&(s->xin_buf&2u)) ? (const T*)s->xin_m : nullptr;
 	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_s<T, 1, MODE, NT, FLAT, STATS, NOFORCE, NATIVE, XFACE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa,
 		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, gi, Tf, S, xp, xm, ip, im);
 	else hipLaunchKernelGGL((k_stream_collide_s<T, 0, MODE, NT, FLAT, STATS, NOFORCE, NATIVE, XFACE>), g.grid, g.block, 0, s->stream, s->kp, b, g.xa, fi,
@@ -224,8 +231,8 @@ template<int MODE, bool STATS, int FORCE, bool PARK, bool THERMAL, bool NATIVE=f
 	bool XFACE=false> static void pair_instance(luw_solver* s, const Box& b, const LaunchGeom& g, const int wf, const StatsArgs& S) {
 	uint16_t* const fi = (uint16_t*)s->d_fi; uint16_t* const gi = THERMAL ? (uint16_t*)s->d_gi : nullptr; float* const Tf = THERMAL ? s->d_T : nullptr;
 	uint16_t* const xp = XFACE ? (uint16_t*)s->xf_p : nullptr; uint16_t* const xm = XFACE ? (uint16_t*)s->xf_m : nullptr;
-	const uint16_t* const ip = (XFACE&&s->xin_use) ? (const uint16_t*)s->xin_p : nullptr;
-	const uint16_t* const im = (XFACE&&s->xin_use) ? (const uint16_t*)s->xin_m : nullptr;
+	const uint16_t* const ip = (XFACE&&s->xin_use&&(s->xin_buf&1u)) ? (const uint16_t*)s->xin_p : nullptr;
+	const uint16_t* const im = (XFACE&&s->xin_use&&(s->xin_buf&2u)) ? (const uint16_t*)s->xin_m : nullptr;
 	if(s->t&1ull) hipLaunchKernelGGL((k_stream_collide_p<1, MODE, STATS, FORCE, PARK, THERMAL, NATIVE, XFACE>), g.grid, g.block, g.lds, s->stream, s->kp, b,
 		fi, s->d_rho, s->d_u, s->d_flags, s->d_F, wf, S, gi, Tf, xp, xm, ip, im);
 	else hipLaunchKernelGGL((k_stream_collide_p<0, MODE, STATS, FORCE, PARK, THERMAL, NATIVE, XFACE>), g.grid, g.block, g.lds, s->stream, s->kp, b, fi,

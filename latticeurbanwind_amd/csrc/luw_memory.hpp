@@ -116,8 +116,9 @@ struct luw_solver {
 	// x-face input (luw_set_x_face_inputs): receive buffers whose insert is pending, side by side (bit 0: the face that came from +x, for the last owned
 	// column; bit 1: from -x, for the first) -- xin_buf: still only in the buffer; xin_inplace: read there by a launch of step xin_for_t.  Whatever else needs a
 	// side in the lattice has the insert kernel run for it first (xin_settle).
-	const void* xin_p = nullptr; const void* xin_m = nullptr; uint32_t xin_buf = 0u, xin_inplace = 0u, xin_odd = 0u; bool xin_use = false;
-	uint64_t xin_for_t = 0ull;
+	// Each side carries the step it is for and the time parity of its hand-over (a host may hand the two sides over at different moments of a step).
+	const void* xin_p = nullptr; const void* xin_m = nullptr; uint32_t xin_buf = 0u, xin_inplace = 0u, xin_odd[2] = { 0u, 0u }; bool xin_use = false;
+	uint64_t xin_for_t[2] = { 0ull, 0ull };
 	// what luw_create's placement search did (luw_dev_placement_info): candidates probed, the kind kept, its probe rate, seconds spent in luw_create
 	int placement_tried = 0; std::string placement_kept = "default (no search)"; double placement_tbps = 0.0, create_seconds = 0.0;
 };

@@ -374,21 +374,27 @@ class HipDomain:
         self.lbm.set_stream(stream.cuda_stream)
         b = self.buf[0]
         self.lbm.set_x_face_inputs(b[2].data_ptr(), b[3].data_ptr())
-        if self.x_pairs:              # faces written where they are read: the next step writes the other pair
-            self.buf[0] = self.x_pairs[1] if b is self.x_pairs[0] else self.x_pairs[0]
+        self.next_x_buffers()
+
+    def next_x_buffers(self):
+        """the x buffers of the next step: the other set (the set just filled is read while that step runs)"""
+        if self.x_pairs:
+            self.buf[0] = self.x_pairs[1] if self.buf[0] is self.x_pairs[0] else self.x_pairs[0]
             self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
 
-    def extract_edges(self, stream):
-        """packs every edge; returns [(e, send, receive)]"""
-        if self.ebuf:
+    def extract_edges(self, stream, only=None):
+        """packs every edge (only: those edges); returns [(e, send, receive)]"""
+        todo = sorted(e for e in self.ebuf if only is None or e in only)
+        if todo:
             self.lbm.set_stream(stream.cuda_stream)
-            self.lbm.enqueue_edges([self.ebuf[e][0].data_ptr() if e in self.ebuf else 0 for e in range(12)], insert=False)
-        return [(e, b[0], b[1]) for e, b in sorted(self.ebuf.items())]
+            self.lbm.enqueue_edges([self.ebuf[e][0].data_ptr() if e in todo else 0 for e in range(12)], insert=False)
+        return [(e, self.ebuf[e][0], self.ebuf[e][1]) for e in todo]
 
-    def insert_edges(self, stream):
-        if self.ebuf:
+    def insert_edges(self, stream, only=None):
+        todo = [e for e in self.ebuf if only is None or e in only]
+        if todo:
             self.lbm.set_stream(stream.cuda_stream)
-            self.lbm.enqueue_edges([self.ebuf[e][1].data_ptr() if e in self.ebuf else 0 for e in range(12)], insert=True)
+            self.lbm.enqueue_edges([self.ebuf[e][1].data_ptr() if e in todo else 0 for e in range(12)], insert=True)
 
     def extract_g(self, axis, stream):
         self.lbm.set_stream(stream.cuda_stream)

@@ -2,6 +2,8 @@
 on two streams, box launches of the vector kernel) driven in lock-step must equal the single-domain HIP run and the
 oracle bit for bit.  GPU only (what cannot run here -- RCCL between processes -- is covered by the gloo test of the
 same driver code)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -203,8 +205,7 @@ def test_edge_kernels_move_the_lines_the_two_hop_route_moves(luw, fp16c, D):
             want[od._edge_line(e, False)] = msg[e]
         assert np.array_equal(np.asarray(g.download_fi()), want), t
         g.increment_time_step(1)
-    with pytest.raises(luw.LuwError):
-        g.enqueue_edges([0] * 12, insert=False)              # an edge the domain has, without a buffer
+    g.enqueue_edges([0] * 12, insert=False); g.finish()     # null entries: those edges are not moved by the call
     g.close()
 
 

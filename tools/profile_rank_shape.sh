@@ -19,4 +19,17 @@ for r in csv.DictReader(open(stats)):
     if calls >= steps // 2:
         print("%-90s %6d %5.1f %9.1f %8.4f" % (r["Name"][:90], calls, calls / steps, tot / calls / 1e3, tot / steps / 1e6))
 PY
+python3 - "$OUT" <<'PY' >> "$OUT.txt"
+import csv, glob, os, re, sys
+out = sys.argv[1]
+tr = max(glob.glob(os.path.join(out, "trace/*/*_kernel_trace.csv")), key=os.path.getmtime)
+rows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[len(rows) // 2: len(rows) // 2 + 44]                 # a window in the middle of the run: two or three steps
+t0 = int(rows[0]["Start_Timestamp"])
+print("# timeline (us from the first row): start, duration, queue, kernel [grid]")
+for r in rows:
+    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:70]
+    print("%9.1f %8.1f  q%-3s %s [%s x %s x %s]" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+        r.get("Queue_Id", "?"), name, r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Grid_Size_Z", "?")))
+PY
 cat "$OUT.txt"
