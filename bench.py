@@ -401,6 +401,10 @@ def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, wa
             "halo_exchange": None if world == 1 else "RCCL self send / receive of every face (no wire to another device)" if transport == "rccl-self"
                 else "peer-loopback: the faces are written straight into the receive buffers the unpack reads (the one-process host's peer stores with the "
                      "rank as its own neighbour; no copy kernel, no wire)", "transport": transport, "overlap": bool(sim.overlap),
+            "exchange": ("one batch per step: faces of all axes + the 12 edge populations" if sim.one_phase
+                else "three phases x, y, z with rims (LUW_EXCHANGE)")
+                if world > 1 else None, "x_faces": None if sim.layout.D[0] == 1 else "written by the step kernels" + (", read from the receive buffers by the "
+                "next step's" if getattr(sim.backend, "x_insert_fused", False) else "; unpack kernel"),
             "kernel_ms": round(tm["kernel_ms"], 4) if tm else None, "shell_ms": None if not tm or tm.get("shell_ms") is None else round(tm["shell_ms"], 4),
             "exchange_ms": None if not tm or tm.get("exchange_ms") is None else round(tm["exchange_ms"], 4),
             "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": round(bpl * owned / (ms * 1e-3) / 1e9, 1),
@@ -853,7 +857,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             mine.update(topology(sim.layout))
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap,
+            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "one_phase": bool(sim.one_phase),
                 "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
         finally:
             sim.backend.close()
@@ -883,7 +887,8 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
                            list(res["D"]), *res["block"], per_gpu / 1e6,
                           "FP16C" if fp16c else "FP32", " + Coriolis force" if args.coriolis else ""),
                        "global_lattice": list(res["gN"]), "n_gpu": list(res["D"]), "cells_per_gpu": per_gpu,
-                       "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel"),
+                       "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel")
+                           + (", one batch per step (faces of all axes + the 12 edge populations)" if res.get("one_phase") else ", three phases x, y, z"),
                            "kernel": args.kernel, "bytes_per_lup": bpl,
                        "rccl_version": rccl, "ranks_in_communicator": dist.get_world_size()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
