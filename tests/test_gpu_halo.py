@@ -253,3 +253,39 @@ def test_x_faces_read_from_the_receive_buffers_equal_the_insert_kernel(luw, monk
         sim.backend.close()
     for a, b in zip(res["1"], res["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("fp16c,Nx", [(False, 42), (True, 322)])
+@pytest.mark.parametrize("thermal", [False, True])
+@pytest.mark.parametrize("D", [(2, 2, 1), (2, 1, 2)])
+def test_one_phase_exchange_equals_the_three_phase_route_on_the_device(luw, monkeypatch, fp16c, Nx, thermal, D):
+    """the production host on one rank that is its own neighbour: everything in one batch with edge messages and the x faces left in their buffers (default)
+    against the reference's three phases with rims and unpack kernels (LUW_EXCHANGE=sequential) -- with the thermal lattice too, whose kernels neither write
+    nor read x faces themselves (pack kernels; the pending x faces go through the unpack kernel in front of the next step): same rho, u, T, DDFs."""
+    from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, PeerLoopbackTransport
+    from helpers import thermal_state
+    own = (Nx - 2, 10, 9) if D[1] > 1 else (Nx - 2, 9, 10)
+    gN = tuple(o * d for o, d in zip(own, D))
+    monkeypatch.setenv("LUW_X_SHELL", "128" if fp16c else "16")
+    res = {}
+    for exchange in ("batch", "sequential"):
+        monkeypatch.setenv("LUW_EXCHANGE", exchange)
+        lay = DomainLayout(gN, D, 0)
+        sim = DomainDecomposedLBM(gN, D, 0.01, rank=0, transport=PeerLoopbackTransport(lay), fp16c=fp16c, device=0, **(dict(alpha=0.004) if thermal else {}))
+        assert sim.overlap and sim.one_phase == (exchange == "batch")
+        lx, ly, lz = lay.lN
+        st = synthetic_state(lx, ly, lz, seed=31, shell=None)
+        if thermal:
+            tflags, T = thermal_state(st[0], (lx, ly, lz))
+            sim.set_fields(tflags, st[1], st[2], T)
+        else:
+            sim.set_fields(st[0], st[1], st[2])
+        sim.run(7)
+        u, rho = sim.fields()
+        out = [u.copy(), rho.copy(), np.asarray(sim.backend.lbm.download_fi()).copy()]
+        if thermal: out += [sim.backend.download_T().copy(), np.asarray(sim.backend.lbm.download_gi()).copy()]
+        res[exchange] = out
+        sim.backend.close()
+    assert len(res["batch"]) == (5 if thermal else 3)
+    for a, b in zip(res["batch"], res["sequential"]):
+        assert np.array_equal(a, b)
