@@ -1,0 +1,257 @@
+"""bench.py, shared parts: constants of the metric, the synthetic workloads (channel with the building array, the urban tile's forcing), the CPU baseline, the
+parity block against the fields of the REAL reference, the device block and the link to the committed counter profiles."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); normally already exported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: gloo (side channel / test aid) over loopback, no hostname lookup
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_LUP = {"f32": 153.0, "fp16c": 77.0}   # 19 DDF reads + 19 DDF writes + 1 flag byte (FX/lbm.cpp:122)
+NU = 1.48e-7                    # units.nu(1.48e-5) for cell = 2 m, U_ref = 10 m/s at u_lbm = 0.1
+CELL_M, DT_S = 2.0, 2.0 * 0.1 / 10.0            # the unit system behind NU: 2 m cells, dt = cell * u_lbm / U_ref
+
+WORKLOADS = {   # name -> (lattice, building array, BASELINE.json reference)
+    "c3": ((1024, 1024, 256), True, "BASELINE configs[2]"),
+    "c2": ((512, 512, 512), False, "BASELINE configs[1]"),
+    "cube1024": ((1024, 1024, 1024), False, "north-star 1024^3-class grid"),
+    "tile512": ((512, 512, 512), True,
+        "one GPU's share of the BASELINE configs[3] / [4] urban tile (the N = 1 point of the N > 1 lines; --urban adds its nudging + sponge)"),
+}
+
+
+def loglaw_profile(nz, u_max=0.1):
+    """lattice-unit inflow speed per z level: log law over the cell centres above the solid z=0 plane"""
+    z = (np.arange(nz, dtype=np.float64) - 0.5) * 2.0          # metres above ground, cell = 2 m
+    z0 = 0.3
+    u = np.log(np.maximum(z, 0.0) / z0 + 1.0)
+    u[0] = 0.0
+    return (u_max * u / u.max()).astype(np.float32)
+
+
+BUILDING_TOP = 1 + 8 + 47      # no building cell at or above this z (heights 8 + (.. mod 48), standing on the z=0 plane)
+
+
+def fill_channel(flags, u, rho, Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None, buildings=False):
+    """Writes flags/u/rho of the (sub)box [gx0,gx0+Nx) x ... of the global channel GNx x GNy x GNz (wind along +x) into the
+    given arrays (reference layout, e.g. a solver's host mirrors), in place and without lattice-sized temporaries.
+    buildings=True adds BASELINE configs[2]'s solid mask: an array of axis-aligned boxes, footprint 24x24 cells on a 64-cell
+    pitch, heights 8+((7i+13j) mod 48) cells (closed form)"""
+    GNx, GNy, GNz = GNx or Nx, GNy or Ny, GNz or Nz
+    prof = loglaw_profile(GNz)
+    zs = (np.arange(Nz) + gz0) % GNz; ys = (np.arange(Ny) + gy0) % GNy; xs = (np.arange(Nx) + gx0) % GNx
+    fl3 = flags.reshape(Nz, Ny, Nx); u4 = u.reshape(3, Nz, Ny, Nx)
+    fl3[:] = 0
+    bz = (zs == GNz - 1); by = (ys == 0) | (ys == GNy - 1); bx = (xs == 0) | (xs == GNx - 1)
+    fl3[bz, :, :] = 2; fl3[:, by, :] = 2; fl3[:, :, bx] = 2
+    fl3[zs == 0, :, :] = 1
+    low = np.nonzero(zs < BUILDING_TOP)[0]                                     # the only z levels that can hold solids
+    if buildings and low.size:
+        i, j = xs // 64, ys // 64
+        inx = (xs % 64 >= 20) & (xs % 64 < 44) & (xs > 0) & (xs < GNx - 1); iny = (ys % 64 >= 20) & (ys % 64 < 44) & (ys > 0) & (ys < GNy - 1)
+        h = 8 + ((7 * i[None, :] + 13 * j[:, None]) % 48)                       # (Ny, Nx) building height in cells
+        zl = zs[low]
+        solid = (inx[None, :] & iny[:, None])[None, :, :] & (zl[:, None, None] >= 1) & (zl[:, None, None] < 1 + h[None, :, :])
+        sub = fl3[low]; sub[solid] = 1; fl3[low] = sub
+    u4[0] = prof[zs][:, None, None]; u4[1] = 0.0; u4[2] = 0.0
+    if low.size:
+        sub = u4[0][low]; sub[fl3[low] == 1] = 0.0; u4[0][low] = sub
+    rho[:] = 1.0
+
+
+def channel_state(Nx, Ny, Nz, gx0=0, gy0=0, gz0=0, GNx=None, GNy=None, GNz=None, buildings=False):
+    """fill_channel into fresh arrays: (flags, u, rho), flat, reference layout"""
+    n = Nx * Ny * Nz
+    flags, u, rho = np.empty(n, np.uint8), np.empty(3 * n, np.float32), np.empty(n, np.float32)
+    fill_channel(flags, u, rho, Nx, Ny, Nz, gx0, gy0, gz0, GNx, GNy, GNz, buildings)
+    return flags, u, rho
+
+
+def tile_forcing():
+    """buffer nudging + top sponge of the urban tile (BASELINE configs[3]/[4]) with the deck defaults of
+    project_template/conf.luw:49-56 in the benchmark's unit system: Nbuf = round(160 m / cell), inv_tau = dt / 300 s
+    (FX/setup.cpp:3844-3856), Nsponge = round(200 m / cell), inv_tau = dt / 120 s (:3867-3881); wind along +x, so the east face
+    is the downstream one (:3756-3761)"""
+    return (dict(n_cells=int(round(160.0 / CELL_M)), inv_tau=DT_S / 300.0, downstream_face=2, nudge_vertical=0),
+            dict(n_cells=int(round(200.0 / CELL_M)), inv_tau=DT_S / 120.0))
+
+
+def reference_case_rmse(case, ddf, fixture, arith="exact"):
+    """the deck driver on one committed synthetic case (48x40x24 + sponge layers, 64 steps) against the fields the REAL reference wrote for the same deck
+    on an MI355X (tests/golden/<fixture>.npz): u RMSE in lattice units over the non-solid cells at K = 8, K = 64 and of u_avg (mean of the last four steps)"""
+    import glob, shutil, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from vtkio import read_vtk
+    drv = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
+    gold = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copytree(os.path.join(ROOT, "tests", "golden", "refcases", case), os.path.join(tmp, case))
+        r = subprocess.run([drv, os.path.join(tmp, case, "conf.luwpf"), "--ddf", ddf, "--arith", arith], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "driver exit %d" % r.returncode}
+        fac = np.float32(5.0) / np.float32(0.1)                      # si_ref_u = max profile U = 5 m/s, u_lbm = 0.1
+        fluid = ~gold["solid"]
+
+        def err(mine, ref):
+            d = ((mine - ref) / fac)[fluid].astype(np.float64)
+            return float(np.sqrt((d ** 2).sum(-1).mean()))
+        vt = os.path.join(tmp, case, "RESULTS", "vtk")
+        out = {}
+        for t in (8, 64):
+            out["K%d" % t] = err(read_vtk(glob.glob(os.path.join(vt, "*_raw_u-%09d.vtk" % t))[0])[1]["data"], gold["u%d" % t])
+        out["u_avg"] = err(read_vtk(glob.glob(os.path.join(vt, "*_avg-000000064.vtk"))[0])[1]["u_avg"], gold["u_avg"])
+        return {k: float("%.3e" % v) for k, v in out.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def reference_parity():
+    """u-field RMSE against the REAL reference, measured now through the deck driver on this GPU: FP32 DDFs against the reference's FP32 build (case B: one
+    building, LES), and the SHIPPED precision -- FP16C DDFs -- against the reference's shipped build (case A: LES with nudging + sponge; case L: laminar),
+    with the bit-exact kernels and with the native-arithmetic ones (--arith native)."""
+    fp32 = reference_case_rmse("CaseB", "fp32", "ref_fp32_CaseB")
+    shipped = {}
+    for case in ("CaseA", "CaseL"):
+        shipped[case] = {"exact": reference_case_rmse(case, "fp16c", "ref_shipped_" + case), "native": reference_case_rmse(case, "fp16c", "ref_shipped_" + case,
+            "native")}
+    k64 = fp32.get("K64")
+    return {"u_rmse_vs_reference": k64, "unit": "lattice units", "steps": 64, "tolerance": 1e-5,
+            "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)", "lattice": [48, 40, 24], "cells": 48 * 40 * 24,
+            "fp32": dict(fp32, case="CaseB", within_tolerance=bool(k64 is not None and k64 < 1e-5)),
+            "shipped": dict(shipped, precision="FP16C DDFs (what the reference ships), reference build FP16C + TEMPERATURE",
+                within_tolerance_at_K8=all(v[a].get("K8", 1.0) < 1e-5 for v in shipped.values() for a in v),
+                within_tolerance_at_K64=all(v[a].get("K64", 1.0) < 1e-5 for v in shipped.values() for a in v),
+                note="FP16C storage rounds every stored population to 2^-12 relative; any arithmetic that is not bit-identical to the reference's own (built "
+                    "by "
+                     "the OpenCL driver with -cl-mad-enable and native division, i.e. not bit-defined) flips single roundings, which LES flow then amplifies: "
+                         "at "
+                     "K = 64 the LES case A sits at 2.6e-5 (u_avg 1.5e-5) -- OUTSIDE the north star's 1e-5 -- for the bit-exact kernels, the CPU oracle and "
+                     "the native-arithmetic kernels alike; the laminar case L (4e-6) and every case at K = 8 (< 1e-6) are inside.  FP32 DDFs: 1.2e-7."),
+            "horizon": "K = 64 steps on 46 k cells is the ONLY horizon pinned by outputs of the real reference (17 committed cases, FP32 and shipped FP16C "
+                "builds, tests/golden/ref_*.npz); beyond it the chain is HIP path == CPU oracle bit for bit (literal 128^3 configs[0] at K = 100 turbulent "
+                "and K = 1000 laminar, tests/test_gpu_c1.py; the bench workloads at full size, tests/test_gpu_bench_workloads.py) and oracle vs reference "
+                "0.5-1.3e-7 (FP32) at K = 64"}
+
+
+def coriolis_omega():
+    """Omega_earth (0, cos phi, sin phi) dt in lattice units at 31.25 deg N for cell = 2 m, U_ref = 10 m/s, u_lbm = 0.1 (FX/setup.cpp:3800-3823)"""
+    import math
+    return 0.0, 7.292115e-5 * math.cos(math.radians(31.25)) * DT_S, 7.292115e-5 * math.sin(math.radians(31.25)) * DT_S
+
+
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    whole host inside containers)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(max_seconds=20.0):
+    """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port"; its row-wise path: the same operations per cell as the literal
+    path, eight cells per AVX2 statement, indices by addition -- oracle/luw_oracle.c, bit-identical to the literal path) timed on this box's host
+    cores on a bounded sample of the benchmark recipe: 256^3 channel, FP32 DDFs, as many steps as fit into max_seconds.  The thread
+    count is the fastest of a short sweep (over-subscription inside a CPU-limited container is disastrous).  Reported with the
+    CPU model and the DRAM bandwidth it amounts to: the restatement moves 169 B per lattice update like the reference's
+    UPDATE_FIELDS kernel (153 + 16 for rho,u every step), set against a copy-kernel bandwidth measured with the same threads."""
+    from oracle import oracle
+    N = 256
+    o = oracle.OracleLBM(N, N, N, NU)
+    fill_channel(o.flags, o.u, o.rho, N, N, N)
+    o.run(1)
+    cores = usable_cores()
+    cands = sorted({max(1, c) for c in (cores, cores // 2, cores // 4, 64, 32, 16, 8) if c <= cores}, reverse=True)
+    best_t, best_rate = cands[-1], 0.0
+    for t in cands:
+        oracle.set_threads(t)
+        t0 = time.perf_counter(); o.run(2); dt = time.perf_counter() - t0
+        if 2 * N ** 3 / dt > best_rate:
+            best_rate, best_t = 2 * N ** 3 / dt, t
+    oracle.set_threads(best_t)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        o.run(2); steps += 2
+        dt = time.perf_counter() - t0
+        if dt > max_seconds or steps >= 2000:
+            break
+    mlups = N ** 3 * steps / dt / 1e6
+    copy_gbps = oracle.copy_bandwidth_gbps(1 << 30)          # read 1 GiB + write 1 GiB with the same OpenMP threads
+    return {"value": round(mlups, 1), "unit": "MLUPS", "cores": best_t, "kind": "port", "cpu_model": cpu_model(),
+            "dram_GBps": round(mlups * 169.0 / 1e3, 1), "copy_bandwidth_GBps": round(copy_gbps, 1),
+                "dram_frac_of_copy": round(mlups * 169.0 / 1e3 / copy_gbps, 3) if copy_gbps else None,
+            "path": "row-wise (AVX2, 8 cells per statement; bit-identical to the literal one-cell-at-a-time path)" if oracle.fast_available() else "literal",
+            "sample": "%d steps of a 256^3 FP32 channel (same recipe as the GPU workloads, 169 B per update incl. rho,u every step) in %.1f s, OpenMP threads "
+                "swept over %s of %d usable cores" % (steps, dt, cands, cores)}
+
+
+def device_context(torch, device):
+    """What this particular GPU streams by itself, next to the contract's 8 TB/s: the same binary ran the HBM-bound FP32 step 12 % apart on
+    different MI355X boxes of the pool (profiles/r02_skew_study.md), so the line carries the box's own device-to-device copy rate (2 GiB
+    tensor copy, bytes read + written, best of 5) and the memory / fabric clock levels the driver reports right after it."""
+    ctx = {"name": torch.cuda.get_device_name(device)}
+    try:
+        n = 1 << 29                                               # 2 GiB of float32
+        src = torch.empty(n, dtype=torch.float32, device="cuda:%d" % device).fill_(1.0)
+        dst = torch.empty_like(src)
+        best = None
+        for _ in range(5):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); dst.copy_(src); e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        ctx["copy_GBps"] = round(2.0 * n * 4 / (best * 1e-3) / 1e9, 1)
+        ctx["copy_frac_of_peak"] = round(ctx["copy_GBps"] / HBM_PEAK_GBPS, 4)
+        del src, dst
+        torch.cuda.empty_cache()
+    except Exception as e:
+        ctx["copy_error"] = str(e)[:120]
+    import glob
+    for name in ("mclk", "fclk", "sclk"):
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_%s" % name)):
+            try:
+                cur = [l.strip() for l in open(path) if l.strip().endswith("*")]
+                if cur:
+                    ctx.setdefault(name, cur[0].rstrip("*").strip())
+            except OSError:
+                pass
+    return ctx
+
+
+def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_step=False, urban=False, native=False):
+    return "%s_%dx%dx%d%s%s%s%s%s%s" % (dtype, size[0], size[1], size[2], "_bld" if buildings else "", "_urban" if urban else "", "_cor" if coriolis else "",
+        "_th" if thermal else "", "_uf" if every_step else "", "_nat" if native else "")
+
+
+def attach_traffic(roof, key, kernel):
+    """HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same workload
+    (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
+    and keyed on the full configuration; null when no profile of exactly this workload exists"""
+    # newest round first
+    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (4, 3, 2)) if os.path.exists(q)), None)
+    if kernel == "auto" and prof:
+        pr = json.load(open(prof))
+        roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])
+        roof["traffic_source"] = "profiles/" + os.path.basename(prof) + " (TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1024, per launch)"

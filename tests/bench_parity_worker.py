@@ -17,6 +17,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import bench
+    from benchmarks import multi
     from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout
     from oracle_domain import OracleDomain
     nud, spg = bench.tile_forcing()
@@ -33,12 +34,12 @@ def main():
     if corrupt and rank == world - 1:
         # one owned value of one rank: the check must see it
         u = u.copy(); u[((lay.lN[2] // 2) * lay.lN[1] + lay.lN[1] // 2) * lay.lN[0] + lay.lN[0] // 2] += np.float32(1e-6)
-    mine = bench.owned_digests(lay, u, rho, od.o.fi, fp16c)
+    mine = multi.owned_digests(lay, u, rho, od.o.fi, fp16c)
     got = [None] * world
     dist.all_gather_object(got, mine)
     if rank == 0:
-        o = bench.oracle_tile(gN, fp16c, True, 4, forcing)
-        want = bench.oracle_digests(o, gN, D, world, fp16c)
+        o = multi.oracle_tile(gN, fp16c, True, 4, forcing)
+        want = multi.oracle_digests(o, gN, D, world, fp16c)
         bad = [[f for f in ("rho", "u", "fi") if got[r][f] != want[r][f]] for r in range(world)]
         json.dump({"bad": bad, "max_abs_uy": max(g["max_abs_uy"] for g in got)}, open(out, "w"))
     dist.barrier()

@@ -37,15 +37,15 @@ def test_selfcheck_sees_one_wrong_value(tmp_path):
 
 def test_parity_tile_shapes():
     sys.path.insert(0, ROOT)
-    import bench
+    from benchmarks import multi
     from latticeurbanwind_amd.distributed import DomainLayout, choose_decomposition
     for world in (2, 4, 8):
         for D in (choose_decomposition(world, split_x=True), choose_decomposition(world)):
-            gN = bench.parity_tile(world, D)
+            gN = multi.parity_tile(world, D)
             lay = DomainLayout(gN, D, world - 1)
             assert lay.can_overlap()
             # zones thinner than every rank's block: a domain that does not own a face never lies inside that face's zone
-            assert all(bench.PARITY_NUDGE_CELLS < g // d for g, d in zip(gN, D)) and bench.PARITY_SPONGE_CELLS < gN[2] // D[2]
+            assert all(multi.PARITY_NUDGE_CELLS < g // d for g, d in zip(gN, D)) and multi.PARITY_SPONGE_CELLS < gN[2] // D[2]
             if D[0] > 1:
                 for x_shell in (64, 128):                                          # FP32 / FP16C slabs
                     l2 = DomainLayout(gN, D, world - 1, x_shell=x_shell)
@@ -57,10 +57,10 @@ def test_group_host_variant_past_its_time_limit_costs_only_its_own_block(monkeyp
     (here: a limit of one second, which the interpreter start alone exceeds) is killed by its PID and leaves an error in its block -- the line
     of the RCCL measurement is still printed."""
     import argparse
-    import bench
-    monkeypatch.setattr(bench, "GROUP_HOST_TIMEOUT_S", 1)
+    from benchmarks import multi
+    monkeypatch.setattr(multi, "GROUP_HOST_TIMEOUT_S", 1)
     args = argparse.Namespace(dtype="f32", kernel="auto", steps=4, warmup=2, coriolis=False, no_buildings=False, no_parity=True)
-    out = bench.run_group_host(args, (2, 1, 1), (128, 64, 64), [0, 0])
-    assert set(bench.GROUP_HOST_VARIANTS) <= set(out)
-    for label in bench.GROUP_HOST_VARIANTS:
+    out = multi.run_group_host(args, (2, 1, 1), (128, 64, 64), [0, 0])
+    assert set(multi.GROUP_HOST_VARIANTS) <= set(out)
+    for label in multi.GROUP_HOST_VARIANTS:
         assert "no result within 1 s" in out[label]["error"] and out[label]["process_wall_s"] < 10
