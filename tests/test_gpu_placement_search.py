@@ -1,7 +1,7 @@
-"""luw_create's placement search for the DDF array (csrc/luw_core.hip, tune_ddf_placement): with every candidate tried -- 1 GiB chunks, then 2 GiB chunks,
-hipMalloc and 512 MiB chunks, one extra array alive at a time, each loser's memory released before the next candidate is mapped -- the solver that keeps
-the fastest computes what the oracle computes, the device's free memory after luw_create is what ONE DDF array costs, and a second large solver of the same
-process is allocated as the winner's kind without a search."""
+"""luw_create's placement search for the DDF array (csrc/luw_placement.hpp, tune_ddf_placement): with every candidate tried -- 1 GiB chunks, 1 GiB chunks
+again, 4 GiB and 2 GiB chunks, hipMalloc and 512 MiB chunks, each a fresh draw of physical memory (the arrays tried before stay mapped until the search ends),
+all of them released before luw_create returns -- the solver that keeps the fastest computes what the oracle computes, the device's free memory after luw_create
+is what ONE DDF array costs, and a second large solver of the same process is allocated as the winner's kind without a search."""
 import os
 import subprocess
 import sys
@@ -20,9 +20,9 @@ def test_every_candidate_tried_and_results_equal_the_oracle(luw, dtype):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     assert "cycle 0 equal True" in r.stdout and "cycle 1 equal True" in r.stdout, r.stdout
     tried = [l for l in r.stderr.splitlines() if l.startswith("luw: placement candidate")]
-    assert len(tried) == 4, r.stderr[-2000:]                            # the default mapping + three further kinds, once per process
+    assert len(tried) == 6, r.stderr[-2000:]                            # the default mapping + five further draws, once per process
     info = [eval(l.split("placement ", 1)[1]) for l in r.stdout.splitlines() if l.startswith("placement ")]
-    assert info[0]["candidates_tried"] == 4 and info[0]["probe_TBps"] > 1.0 and info[0]["create_s"] > 0
+    assert info[0]["candidates_tried"] == 6 and info[0]["probe_TBps"] > 1.0 and info[0]["create_s"] > 0
     assert info[1]["candidates_tried"] == 0 and "first search kept" in info[1]["kept"] and info[1]["kept"].startswith(info[0]["kept"])
     used = [float(l.split()[-2]) for l in r.stdout.splitlines() if l.startswith("device memory used by the solver")]
     assert all(u < 1.35 * 2.6 + 1.0 for u in used), used               # GB: one DDF array (2.5 GB) + fields, nothing of the search left

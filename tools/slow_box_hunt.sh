@@ -14,10 +14,11 @@ echo "as shipped: $first" | tee "$OUT"
 ms=$(echo "$first" | sed -n 's/^kernel \([0-9.]*\) ms.*/\1/p')
 if python3 -c "import sys; sys.exit(0 if float('$ms') > 6.95 else 1)"; then
   echo "SLOW BOX: studying" | tee -a "$OUT"
-  for al in vmm:1024 vmm:2048 malloc vmm:512 vmm:4096 vmm:256 vmm:128 vmm:64 vmm:one vmm:3072 vmm:1536; do
+  "$R/tools/box_state_watch.sh" 14 | cut -c1-300 | sed 's/=\{5,\}[^;]*;//g' | tee -a "$OUT"        # the same kind again and again, with temperatures and clocks
+  for al in vmm:1024 vmm:4096; do
     echo "LUW_ALLOC=$al, no search: $(one LUW_ALLOC=$al LUW_TUNE_PLACEMENT=0)" | tee -a "$OUT"
   done
-  for sk in 33 129 257 1025 2049; do
+  for sk in; do
     echo "LUW_PLANE_SKEW=$sk (1 GiB chunks), no search: $(one LUW_PLANE_SKEW=$sk LUW_TUNE_PLACEMENT=0)" | tee -a "$OUT"
     echo "LUW_PLANE_SKEW=$sk (2 GiB chunks), no search: $(one LUW_PLANE_SKEW=$sk LUW_ALLOC=vmm:2048 LUW_TUNE_PLACEMENT=0)" | tee -a "$OUT"
   done
