@@ -48,6 +48,7 @@ int luw_upload_fi(luw_solver* s, const void* host_src);
  * allocated, nothing hanging).  0 clears.  Takes effect for groups created afterwards. */
 #define LUW_FAULT_NO_PEER_ODD_PAIRS 1u
 #define LUW_FAULT_RCCL_INIT 2u
+#define LUW_FAULT_SLOW_FIRST_PLACEMENT 4u   /* luw_create's placement search sees its first candidate 30 % slower than it is: another draw must replace it */
 int luw_dev_inject_fault(uint32_t mask);
 
 /* ---- device self-checks */

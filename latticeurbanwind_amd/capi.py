@@ -236,7 +236,7 @@ def placement_info(handle):
     return {"candidates_tried": n.value, "kept": kept.value.decode(), "probe_TBps": round(tb.value, 3), "create_s": round(sec.value, 3)}
 
 
-FAULT_NO_PEER_ODD_PAIRS, FAULT_RCCL_INIT = 1, 2
+FAULT_NO_PEER_ODD_PAIRS, FAULT_RCCL_INIT, FAULT_SLOW_FIRST_PLACEMENT = 1, 2, 4
 
 
 def inject_fault(mask):

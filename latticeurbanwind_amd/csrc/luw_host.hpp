@@ -36,6 +36,7 @@ struct Tuning {
 	bool ab_pair_copy = false;        // LUW_PAIR_COPY: the pair kernel's memory path alone (no physics)
 #endif
 };
+static std::atomic<uint32_t> g_injected_faults{0u};     // luw_dev_inject_fault (include/luw_core_dev.h): test hooks
 static Tuning g_tuning;
 static std::atomic<bool> g_tuning_loaded{false};
 static void tuning_load() {

@@ -59,11 +59,12 @@ static int tune_ddf_placement(luw_solver* s) {
 	// FP16C with zones: the general kernel is VALU-bound).  LUW_TUNE_FAST=<TB/s> overrides the bar (99: every candidate is tried)
 	const double cells = (double)(box.x1-box.x0)*(double)(box.y1-box.y0)*(double)(box.z1-box.z0);
 	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*cells;
-	const double bar = T.placement_bar>0.0 ? T.placement_bar*1e12 : (s->ddf_bytes==4u ? 6.18e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
+	const double bar = T.placement_bar>0.0 ? T.placement_bar*1e12 : (s->ddf_bytes==4u ? 6.27e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
 	auto rate = [&](const float ms) { return probe_bytes/((double)ms*1e-3); };
 	float best_ms = 0.0f;
 	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
 	if(int e = step_ms(best_ms)) return e;
+	if(g_injected_faults.load()&LUW_FAULT_SLOW_FIRST_PLACEMENT) best_ms *= 1.3f;   // test hook: the array in place has to be replaced by another draw
 	s->placement_tried = 1;
 	if(T.placement_verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", dev_block_kind(s->raw.front()), best_ms,
 		rate(best_ms)*1e-12);
@@ -89,7 +90,9 @@ static int tune_ddf_placement(luw_solver* s) {
 			dev_block_kind(cand), ms, rate(ms)*1e-12, best_ms);
 		// another draw has to be CLEARLY faster (3 %) to replace what is kept: a probe of a few steps resolves no less, and on a box where nothing reaches
 		// the bar (all within 1 % of each other: profiles/r04_placement_10x.txt) every process then keeps the same one -- the default
-		if(ms<0.97f*best_ms) { best_ms = ms; std::swap(s->raw.front(), cand); } // fi is the first lead_alloc of luw_create; cand now holds the loser
+		// (... or reach the bar where the kept one does not: on a box whose first draw probed 6.15 TB/s the second one's 6.30 was 2.4 % better -- and the
+		// workload ran 7.08 ms on the first, 6.75 on such a draw)
+		if(ms<0.97f*best_ms||(rate(ms)>=bar&&rate(best_ms)<bar)) { best_ms = ms; std::swap(s->raw.front(), cand); } // cand now holds the loser
 		else s->d_fi = old_fi;
 		held.push_back(std::move(cand));
 	}

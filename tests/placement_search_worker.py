@@ -17,6 +17,8 @@ Nx, Ny, Nz = (512, 256, 512) if fp16c else (512, 256, 256)         # 19 planes o
 st = synthetic_state(Nx, Ny, Nz, seed=5, shell="luw")
 import torch
 from latticeurbanwind_amd import capi
+if len(sys.argv) > 2 and sys.argv[2] == "replace":       # the search sees the array in place 30 % slower than it is: another draw has to take its place
+    capi.inject_fault(capi.FAULT_SLOW_FIRST_PLACEMENT)
 for cycle in range(2):
     free0 = torch.cuda.mem_get_info(0)[0]
     g = luw.LBM(Nx, Ny, Nz, 1e-4, fp16c=fp16c)
