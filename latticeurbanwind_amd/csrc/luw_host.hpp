@@ -23,7 +23,7 @@ struct Tuning {
 	bool pair_general = false;        // LUW_PAIR_GENERAL: FP16C kernels never take the force-free / uniform-force specialisations (test aid, same values)
 	bool fuse_stats = true;           // LUW_FUSE_STATS=0: sampled steps use the separate statistics kernel (A/B and test aid, same values)
 	uint64_t plane_skew = 0ull;       // LUW_PLANE_SKEW=<64-element blocks> behind each DDF plane (0: 513 for FP32, 33 for FP16C; study aid)
-	int placement_candidates = -1;    // LUW_TUNE_PLACEMENT=<n>: allocations of the DDF array luw_create may try (0 / 1: no search; default 4)
+	int placement_candidates = -1;    // LUW_TUNE_PLACEMENT=<n>: allocations of the DDF array luw_create may try (0 / 1: no search; default 6)
 	double placement_bar = 0.0;       // LUW_TUNE_FAST=<TB/s>: probe rate from which a placement is kept without further candidates (99: try all; test aid)
 	bool placement_verbose = false;   // LUW_TUNE_VERBOSE: print every candidate's probe time to stderr
 	bool vk_ahead = true;             // LUW_VK_AHEAD=0: von-Karman inlet evaluated in line instead of one step ahead on a side stream (A/B aid, same values)
