@@ -109,6 +109,7 @@ def run_single_block(luw, capi, device, key, native=False):
 
 
 RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0),
+                     "c4_rank_1x4x2_f32": dict(fp16c=False, coriolis=False, D=(1, 4, 2), rank=7),       # the cut `--gpus 8` takes by default
                      "c5_rank_4x2x1_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0),
                      "c5_rank_1x4x2_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7)}
 
