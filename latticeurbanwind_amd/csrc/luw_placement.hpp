@@ -59,7 +59,9 @@ static int tune_ddf_placement(luw_solver* s) {
 	// FP16C with zones: the general kernel is VALU-bound).  LUW_TUNE_FAST=<TB/s> overrides the bar (99: every candidate is tried)
 	const double cells = (double)(box.x1-box.x0)*(double)(box.y1-box.y0)*(double)(box.z1-box.z0);
 	const double probe_bytes = 2.0*((s->ddf_bytes==4u ? 153.0 : 77.0)+(s->d_gi ? 14.0*(double)s->ddf_bytes : 0.0))*cells;
-	const double bar = T.placement_bar>0.0 ? T.placement_bar*1e12 : (s->ddf_bytes==4u ? 6.27e12 : (s->kp.buffer_active||s->kp.sponge_active) ? 5.0e12 : 6.1e12);
+	// (zone cells cost the probe more: the FP32 urban tile probes 6.2 TB/s on a fast draw, 6.07-6.13 on a slow one)
+	const bool zones = s->kp.buffer_active||s->kp.sponge_active;
+	const double bar = T.placement_bar>0.0 ? T.placement_bar*1e12 : (s->ddf_bytes==4u ? (zones ? 6.2e12 : 6.27e12) : zones ? 5.0e12 : 6.1e12);
 	auto rate = [&](const float ms) { return probe_bytes/((double)ms*1e-3); };
 	float best_ms = 0.0f;
 	if(int e = step_ms(best_ms)) return e;   // (the first probe of a process also ramps the GPU up: measured again)
