@@ -1,0 +1,15 @@
+#!/usr/bin/env bash
+# CPU container: the oracle (oracle/luw_oracle.c, both paths) under AddressSanitizer through the tests that drive it hardest -- the row-wise path against the
+# literal one, the known answers, the fixtures of the real reference, the gloo worlds of 2-8 ranks with the halo maps and edge messages.  (GPU AddressSanitizer
+# is not available on the pool; this is the CPU build only.)  Restores the product build of the oracle afterwards.   usage: tools/oracle_asan.sh
+set -uo pipefail
+R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+cp "$R/oracle/libluw_oracle.so" /tmp/libluw_oracle_product.so 2>/dev/null
+gcc -O1 -g -march=x86-64-v3 -fPIC -std=gnu11 -D_GNU_SOURCE -ffp-contract=off -fno-fast-math -fno-math-errno -fopenmp -fsanitize=address -fno-omit-frame-pointer \
+  -shared -o "$R/oracle/libluw_oracle.so" "$R/oracle/luw_oracle.c" -lm && touch "$R/oracle/libluw_oracle.so"
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so)" python3 -m pytest "$R/tests/test_oracle_fast_path.py" "$R/tests/test_oracle_known_answers.py" \
+  "$R/tests/test_oracle_vs_reference.py" "$R/tests/test_vk_inlet.py" "$R/tests/test_distributed_gloo.py" "$R/tests/test_bench_selfcheck.py" -q -m "not gpu"
+rc=$?
+if [ -f /tmp/libluw_oracle_product.so ]; then cp /tmp/libluw_oracle_product.so "$R/oracle/libluw_oracle.so"; else make -C "$R/oracle" -s clean all; fi
+touch "$R/oracle/libluw_oracle.so"
+exit $rc
