@@ -25,7 +25,7 @@ if os.environ.get("LUW_SELF_EARLY", "1") == "1":        # as DomainDecomposedLBM
     x, y = torch.ones(1024, device="cuda"), torch.zeros(1024, device="cuda")
     for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, x, 0), dist.P2POp(dist.irecv, y, 0)]): r.wait()
     torch.cuda.synchronize()
-D, size, steps = (1, 2, 2), (512, 256, 256), 60
+D, size, steps = (1, 2, 2), (512, 256, 256), int(os.environ.get("LUW_SELF_STEPS", "60"))
 if len(sys.argv) >= 8:      # check_nccl_self.py f32 2048 256 256 1 4 2: one rank of the 8-GPU benchmark tile
     size, D = tuple(int(v) for v in sys.argv[2:5]), tuple(int(v) for v in sys.argv[5:8])
 N = tuple(s * d for s, d in zip(size, D))
