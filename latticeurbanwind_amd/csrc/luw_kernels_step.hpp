@@ -397,7 +397,8 @@ constexpr uint32_t pair_park_bytes_per_wave(const bool thermal, const int force 
 // x-face INPUT (luw_set_x_face_inputs): every x-face instantiation but the uniform-force ones, which fill their 96 VGPRs (5 waves) without it -- five more
 // live registers behind the loads spill a pair into scratch, and parked in LDS the kernel loses what the saved unpack kernel gains (2.355 against 2.30 ms on
 // the FP16C + Coriolis rank of [4,2,1]).  Their launches have the library run the unpack kernel for their side.
-constexpr bool pair_reads_x_face_inputs(const int force) { return force!=PAIR_FORCE_UNIFORM; }
+// (With the thermal lattice the second cell's values are parked in LDS anyway and every force mode has the registers.)
+constexpr bool pair_reads_x_face_inputs(const int force, const bool thermal = false) { return thermal || force!=PAIR_FORCE_UNIFORM; }
 template<int PARITY, int MODE=0, bool STATS=false, int FORCE=PAIR_FORCE_ANY, bool PARK=false, bool THERMAL=false, bool NATIVE=false, bool XFACE=false>
 __global__ __launch_bounds__(256)
 	__attribute__((amdgpu_waves_per_eu(pair_waves(FORCE, PARK, THERMAL, NATIVE), pair_waves(FORCE, PARK, THERMAL, NATIVE))))
@@ -406,7 +407,7 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, uint16_t* __restrict__ xf_p = nullptr, uint16_t* __restrict__ xf_m = nullptr,
 			const uint16_t* __restrict__ xin_p = nullptr, const uint16_t* __restrict__ xin_m = nullptr) {
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
-	static_assert(!XFACE||(!THERMAL&&!STATS&&MODE==0), "x-face output: plain steps of the D3Q19 lattice");
+	static_assert(!XFACE||(!STATS&&MODE==0), "x-face output: plain steps");       // (with the thermal lattice: the D3Q19 faces; the D3Q7 faces keep their kernels)
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
 	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
 	constexpr bool OWN = LUW_PAIR_OWN_EARLY!=0 && !PRE;
@@ -444,7 +445,7 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 	// them (first column: own slots, low halves; last column: the slots in the halo column, high halves)
 	[[maybe_unused]] uint32_t xv[5];
 	[[maybe_unused]] bool xin_first = false, xin_last = false;
-	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE)) {
+	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE, THERMAL)) {
 		if(xin_p||xin_m) {   // (each side on its own: a host may have handed over one of them only)
 			xin_first = x==1u&&xin_m; xin_last = x+3u==p.Nx&&xin_p;
 			if(xin_first||xin_last) {
@@ -497,7 +498,7 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 			}
 		});
 	}
-	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE)) {
+	if constexpr(XFACE&&pair_reads_x_face_inputs(FORCE, THERMAL)) {
 		if(xin_first||xin_last) {
 			static_for_pairs([&](auto ic) {
 				constexpr int i = decltype(ic)::value;

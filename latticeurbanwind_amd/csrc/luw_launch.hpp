@@ -267,6 +267,16 @@ static const PairRow pair_table[] = {
 	{ { 0, false, PAIR_FORCE_NONE,    false, false, true,  true }, pair_instance<0, false, PAIR_FORCE_NONE, false, false, true, true>,     "native + x-face" },
 	{ { 0, false, PAIR_FORCE_UNIFORM, false, false, true,  true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, false, false, true, true>,  "native + x-face" },
 	{ { 0, false, PAIR_FORCE_ANY,     true,  false, true,  true }, pair_instance<0, false, PAIR_FORCE_ANY, true, false, true, true>,       "native + x-face" },
+	// ... and with the thermal lattice (what the reference's shipped build runs): the D3Q19 x faces out of / into the kernels, the D3Q7 faces by their kernels
+	{ { 0, false, PAIR_FORCE_NONE,    true,  true,  false, true }, pair_instance<0, false, PAIR_FORCE_NONE, true, true, false, true>,      "thermal + x-face" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true,  false, true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true, false, true>,   "thermal + x-face" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  true,  false, true }, pair_instance<0, false, PAIR_FORCE_ANY, true, true, false, true>,       "thermal + x-face" },
+	{ { 0, false, PAIR_FORCE_NONE,    true,  true,  true,  true }, pair_instance<0, false, PAIR_FORCE_NONE, true, true, true, true>,
+		"thermal native + x-face" },
+	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true,  true,  true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true, true, true>,
+		"thermal native + x-face" },
+	{ { 0, false, PAIR_FORCE_ANY,     true,  true,  true,  true }, pair_instance<0, false, PAIR_FORCE_ANY, true, true, true, true>,
+		"thermal native + x-face" },
 #ifdef LUW_AB_KERNELS
 	{ { 1, false, PAIR_FORCE_ANY,     false, false }, pair_instance<1, false, PAIR_FORCE_ANY, false, false>,
 		"A/B: the kernel's memory path alone (LUW_PAIR_COPY)" },
@@ -293,7 +303,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	k.native = (s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u && !st;
 	if(k.native&&!k.thermal) k.park = k.force==PAIR_FORCE_ANY;
 	// x-face output: plain steps of the D3Q19 lattice with the product's park choice, on a box that holds a border column
-	k.xface = !st && !k.thermal && k.mode==0 && k.park==(k.force==PAIR_FORCE_ANY) && xface_wanted(s, b);
+	k.xface = !st && k.mode==0 && (k.thermal || k.park==(k.force==PAIR_FORCE_ANY)) && xface_wanted(s, b);
 #ifdef LUW_AB_KERNELS
 	const bool copy_only = tuning().ab_pair_copy;   // tools build, measurement aid: the kernel's memory path alone (no physics)
 	if(copy_only&&!st&&!k.thermal) k = PairKey{ 1, false, PAIR_FORCE_ANY, false, false };
@@ -304,7 +314,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native&&q.xface==k.xface) {
 			// (the uniform-force instantiation sits at its 96 VGPRs without a register for the x-face INPUT: it writes its faces, and has the unpack kernel
 			// run for what it receives -- pair_reads_x_face_inputs, luw_kernels_step.hpp)
-			if(int e = xin_before_launch(s, b, k.xface&&pair_reads_x_face_inputs(k.force))) return e;
+			if(int e = xin_before_launch(s, b, k.xface&&pair_reads_x_face_inputs(k.force, k.thermal))) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
 			return LUW_OK;
@@ -376,5 +386,6 @@ static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m,
 	const dim3 grid((A+255u)/256u), block(256);
 	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const uint16_t*)buf_p,
 		(const uint16_t*)buf_m, (uint16_t*)s->d_fi);
-	else hipLaunchKernelGGL((k_insert_fi<float, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const float*)buf_p, (const float*)buf_m, (float*)s->d_fi);
+	else hipLaunchKernelGGL((k_insert_fi<float, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const float*)buf_p, (const float*)buf_m,
+		(float*)s->d_fi);
 }

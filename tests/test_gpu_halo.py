@@ -123,9 +123,10 @@ def test_rccl_transport_through_self_send_recv(dt):
     assert r.returncode == 0 and "fields identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
-@pytest.mark.parametrize("fp16c,native,Nx", [(False, False, 40), (True, False, 322), (True, True, 322)])
+@pytest.mark.parametrize("fp16c,native,Nx,thermal", [(False, False, 40, False), (True, False, 322, False), (True, True, 322, False), (True, False, 322, True),
+    (True, True, 322, True)])
 @pytest.mark.parametrize("forces", ["none", "zones+coriolis"])
-def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c, native, Nx, forces):
+def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c, native, Nx, forces, thermal):
     """luw_set_x_face_buffers: the step kernels that hold the first / last owned x column put that column's five outgoing populations into the face buffers
     themselves.  Against the pack kernel reading the lattice behind the same step: every element whose source cell is an owned cell -- collided or not
     (solids on the border columns forward what their slots hold: bounce-back across a cut) -- must be the same value; with the buffers set, the extract
@@ -140,6 +141,7 @@ def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c
     kw = dict(buffer_nudging=dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1),
         top_sponge=dict(n_cells=3, inv_tau=0.02)) if "zones" in forces \
         else {}
+    if thermal: kw = dict(kw, alpha=0.004)        # the pair kernel with the thermal lattice (the shipped build's configuration) writes the D3Q19 faces too
     g = luw.LBM(Nx, Ny, Nz, 0.01, fp16c=fp16c, D=(2, 2, 1), O=(-1, -1, 0), native_arith=native, **kw)
     if "coriolis" in forces: g.set_coriolis(0.0, 3e-5, 4e-5)
     g.flags.data[:] = flags.ravel(); g.u.data[:] = st[1]; g.rho.data[:] = st[2]

@@ -91,10 +91,11 @@ def test_product_kernels_have_no_spills_and_store_through_saddr(device_asm):
     # FP16C kernel, the pair kernel's three force modes and their three thermal variants: 2 + 6 + 6
     product = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb0ELb[01]E", n)
         or re.search(r"k_stream_collide_pILi[01]ELi0ELb0ELi[012]E", n)]
-    # ... and the instantiations with the x-face output (luw_set_x_face_buffers): FP32 flat / row, the pair kernel's three force modes exact and native: 4 + 12
-    assert len(product) == 52, product
+    # ... and the instantiations with the x-face output (luw_set_x_face_buffers): FP32 flat / row, the pair kernel's three force modes exact and native, plain
+    # and with the thermal lattice: 4 + 12 + 12
+    assert len(product) == 64, product
     flags_of = lambda n: re.findall(r"Lb([01])E", n.split("EvN3luw")[0])
-    assert sum(1 for n in product if flags_of(n)[-2] == "1") == 14 + 6 and sum(1 for n in product if flags_of(n)[-1] == "1") == 16      # NATIVE, XFACE
+    assert sum(1 for n in product if flags_of(n)[-2] == "1") == 14 + 12 and sum(1 for n in product if flags_of(n)[-1] == "1") == 28      # NATIVE, XFACE
     # the same kernels with the statistics epilogue (sampled steps): no spills either
     sampled = [n for n in device_asm if re.search(r"k_stream_collide_sI[tf]Li[01]ELi0ELi2ELb[01]ELb1ELb0E", n)
         or re.search(r"k_stream_collide_pILi[01]ELi0ELb1ELi2E", n)]
