@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: one rank of n_gpu = [4,2,1] (local 514x514x512) in the reference's SHIPPED configuration -- FP16C DDFs and the thermal D3Q7 lattice -- stepped by the
-production host with the peer-loopback buffers; ms per step.  Run it under LUW_X_FACE_FUSED=0 / LUW_X_INSERT_FUSED=0 for the pack / unpack kernels instead of the
-x faces written and read by the step kernels.   usage: rank_thermal_probe.py [steps]"""
+"""GPU box: one rank of n_gpu = [4,2,1] (local 514x514x512) in the reference's SHIPPED configuration -- FP16C DDFs and the thermal D3Q7 lattice -- stepped by
+the production host with the peer-loopback buffers; ms per step.  Run it under LUW_X_FACE_FUSED=0 / LUW_X_INSERT_FUSED=0 for the pack / unpack kernels instead
+of the x faces written and read by the step kernels.   usage: rank_thermal_probe.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
