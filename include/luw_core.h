@@ -177,7 +177,7 @@ int luw_enqueue_extract_fi(luw_solver* s, uint32_t direction, void* dev_buffer_p
 /* x-split domains: while a pair of face buffers is set here, every stream_collide launch whose box holds the first / last owned x column ALSO writes that
  * column's five outgoing populations into them (same elements as luw_enqueue_extract_fi(s, 0, p, m): the values sit in registers there, the extract kernel
  * fetches them back one element per 128-byte line); luw_enqueue_extract_fi with direction 0 and the same buffers then returns without a launch when the
- * launches of the current step have covered both columns, and does its own work otherwise (FP32 with the thermal lattice, sampled steps, boxes that cut
+ * launches of the current step have covered both columns, and does its own work otherwise (sampled steps, the one-cell FP16C kernel, boxes that cut
  * a column).  The buffers must stay valid, and must not be overwritten between a step's launches and the use of its faces.  NULL, NULL switches the
  * output off. */
 int luw_set_x_face_buffers(luw_solver* s, void* dev_buffer_p, void* dev_buffer_m);

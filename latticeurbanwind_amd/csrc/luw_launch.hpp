@@ -162,6 +162,8 @@ static const ScalarRow scalar_table[] = {
 	// x-split domains, boxes that hold the first / last owned x column: the same kernels with the x-face output (luw_set_x_face_buffers)
 	{ { 4u, 0, 2, true,  false, false, false, true }, scalar_instance<float, 0, 2, true, false, false, false, true>,  "FP32 + x-face output" },
 	{ { 4u, 0, 2, false, false, false, false, true }, scalar_instance<float, 0, 2, false, false, false, false, true>, "FP32, row addressing + x-face output" },
+	{ { 4u, 4, 2, true,  false, false, false, true }, scalar_instance<float, 4, 2, true, false, false, false, true>,  "FP32 + thermal lattice + x-face output" },
+	{ { 4u, 4, 2, false, false, false, false, true }, scalar_instance<float, 4, 2, false, false, false, false, true>, "FP32 + thermal, row addressing + x-face" },
 	{ { 2u, 0, 2, false, false, false, true }, scalar_instance<uint16_t, 0, 2, false, false, false, true>, "FP16C one-cell kernel, native arithmetic" },
 	{ { 2u, 4, 2, false, false, false, true }, scalar_instance<uint16_t, 4, 2, false, false, false, true>,
 		"FP16C one-cell kernel + thermal lattice, native arithmetic" },
@@ -201,7 +203,7 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	// native arithmetic (FP16C, plain steps): one instantiation for every box
 	if(s->ddf_bytes==2u&&!st&&(s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u) { k.native = true; k.noforce = false; }
 	// x-face output: FP32 plain steps on a box that holds a border column
-	k.xface = s->ddf_bytes==4u && k.mode==0 && !st && xface_wanted(s, b);
+	k.xface = s->ddf_bytes==4u && (k.mode==0||k.mode==4) && !st && xface_wanted(s, b);
 #ifdef LUW_AB_KERNELS
 	if(!st&&!s->d_gi) switch(s->kernel) {
 		case LUW_KERNEL_EXP_COPY: k.mode = 1; k.nt = 1; k.noforce = false; break;

@@ -124,7 +124,7 @@ def test_rccl_transport_through_self_send_recv(dt):
 
 
 @pytest.mark.parametrize("fp16c,native,Nx,thermal", [(False, False, 40, False), (True, False, 322, False), (True, True, 322, False), (True, False, 322, True),
-    (True, True, 322, True)])
+    (True, True, 322, True), (False, False, 40, True)])
 @pytest.mark.parametrize("forces", ["none", "zones+coriolis"])
 def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c, native, Nx, forces, thermal):
     """luw_set_x_face_buffers: the step kernels that hold the first / last owned x column put that column's five outgoing populations into the face buffers
