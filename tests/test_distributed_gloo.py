@@ -90,3 +90,27 @@ def test_layout_matches_reference_rules():
     assert cover[w[4]:w[5], w[2]:w[3], w[0]:w[1]].min() == 1 and cover.max() == 1 and cover.sum() == 512 * 512 * 512
     with pytest.raises(ValueError):
         DomainLayout((10, 10, 10), (3, 1, 1), 0)
+
+
+@pytest.mark.parametrize("D", [(2, 1, 1), (2, 2, 1), (4, 2, 1), (1, 4, 2), (2, 2, 2), (3, 2, 2), (2, 3, 4)])
+def test_one_phase_messages_pair_up_on_every_rank(D):
+    """the one-phase exchange lists its message types in one order on every rank (faces per axis + then -, edges by number): for every pair of ranks the k-th
+    message A sends to B is the k-th B receives from A -- also where several directions lead to the same rank (two domains along an axis) -- and every edge a
+    rank sends is an edge its target expects (host logic only: DomainLayout.neighbor_dir / edges, TorchDistTransport.exchange_all's convention)"""
+    from latticeurbanwind_amd.distributed import DomainLayout, C19
+    gN = tuple(8 * d for d in D)
+    world = D[0] * D[1] * D[2]
+    lays = [DomainLayout(gN, D, r) for r in range(world)]
+    unit = lambda a, s: tuple(s if k == a else 0 for k in range(3))
+    def types(lay):
+        t = []
+        for a in lay.split_axes(): t += [("face", a, +1, unit(a, +1)), ("face", a, -1, unit(a, -1))]
+        t += [("edge", e, 0, C19[7 + e]) for e in lay.edges()]
+        return t
+    assert all(types(l) == types(lays[0]) for l in lays)                   # every rank has the same list (the decomposition is regular)
+    assert len(lays[0].edges()) == {1: 0, 2: 4, 3: 12}[len(lays[0].split_axes())]
+    for A in lays:
+        for B in lays:
+            sent = [(kind, n, s) for kind, n, s, c in types(A) if A.neighbor_dir(c) == B.rank]
+            received = [(kind, n, s) for kind, n, s, c in types(B) if B.neighbor_dir(tuple(-v for v in c)) == A.rank]
+            assert sent == received, (A.rank, B.rank, sent, received)
