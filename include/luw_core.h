@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LUW_ABI_VERSION 5
+#define LUW_ABI_VERSION 6
 
 /* error codes */
 #define LUW_OK 0

@@ -187,7 +187,7 @@ def load(path=None):
     L.luw_dev_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, u64]
     L.luw_dev_tuning_text.argtypes = [C.c_char_p, u64]
     L.luw_dev_inject_fault.argtypes = [u32]
-    if L.luw_abi_version() != 5:
+    if L.luw_abi_version() != 6:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
     return L

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(luw):
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.SYMBOLS) == names
     assert sorted(capi.DEV_SYMBOLS) == declared_functions("luw_core_dev.h")
-    assert L.luw_abi_version() == 5
+    assert L.luw_abi_version() == 6
 
 
 def test_product_header_is_the_boundary_only():
