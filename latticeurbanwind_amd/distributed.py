@@ -18,449 +18,9 @@ tests/test_gpu_halo.py).
 """
 import numpy as np
 
-# D3Q19 directions c_i (FX/kernel.cpp:890-893); edge message e = 0..11 carries population 7 + e to the domain in direction c_(7+e)
-C19 = ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0), (-1, -1, 0), (1, 0, 1), (-1, 0, -1), (0, 1, 1), (0, -1, -1),
-       (1, -1, 0), (-1, 1, 0), (1, 0, -1), (-1, 0, 1), (0, 1, -1), (0, -1, 1))
-
-
-def choose_decomposition(world, split_x=False):
-    """n_gpu and per-GPU lattice shape factors for a weak-scaled tile of 512^3 cells per GPU.
-
-    split_x=False (default): the memory-fastest axis is kept whole -- rows stay complete memory lines, the y/z boundary
-    shells are whole rows and the halo traffic hides behind the interior: 8 GPUs cover the 2048x1024x512 tile of
-    BASELINE configs[3] as n_gpu=[1,4,2] (local 2048x256x256: the least halo area among the x-whole grids, and the fastest
-    rank step measured, 3.42 ms vs 3.55 ms for [1,2,4]; tools/bench_layouts.py).  split_x=True reproduces the deck's literal
-    n_gpu=[4,2,1] (local 512^3); with x split the step runs the whole box first and exchanges afterwards (measured on
-    MI355X, one rank with loopback halos: 3.77 ms sequential vs 4.2-5.2 ms with an x shell, vs 3.37 ms undivided).
-    Returns (D, global_lattice)."""
-    if split_x:
-        table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1), 16: (4, 4, 1)}
-    else:
-        table = {1: (1, 1, 1), 2: (1, 2, 1), 4: (1, 2, 2), 8: (1, 4, 2), 16: (1, 4, 4)}
-    if world in table:
-        return table[world]
-    d = [1, 1, 1]
-    n, ax = world, 0
-    for p in (2, 3, 5, 7):
-        while n % p == 0:
-            d[(ax % 2) + 1 if not split_x else ax % 3] *= p; ax += 1; n //= p
-    if n != 1:
-        d[1 if not split_x else 0] *= n
-    return tuple(d)
-
-
-def tile_lattice(world):
-    """global lattice of the weak-scaled benchmark tile: 512^3 cells per GPU, growing x, then y, then x again
-    (1: 512^3 = BASELINE configs[1]; 2: 1024x512x512; 4: 1024x1024x512; 8: 2048x1024x512 = configs[3])"""
-    g = [512, 512, 512]
-    n, ax = world, 0
-    while n > 1 and n % 2 == 0:
-        g[(0, 1)[ax % 2]] *= 2; ax += 1; n //= 2
-    g[2] *= n
-    return tuple(g)
-
-
-class DomainLayout:
-    """Pure host logic: where a rank sits, what it owns, whom it talks to (FX/lbm.cpp:1066-1073,1912-1931)."""
-
-    X_SHELL = 128  # thickness of the x boundary slabs (see shell_boxes; csrc/luw_group.hpp group_x_shell)
-
-    def __init__(self, global_N, D, rank, x_shell=None):
-        if x_shell: self.X_SHELL = int(x_shell)
-        self.gN = tuple(int(v) for v in global_N)
-        self.D = tuple(int(v) for v in D)
-        Dx, Dy, Dz = self.D
-        if any(g % d for g, d in zip(self.gN, self.D)):
-            raise ValueError("LBM grid %s is not equally divisible in domains %s" % (self.gN, self.D))  # FX/lbm.cpp:1058-1059 shrinks; we refuse
-        if not 0 <= rank < Dx * Dy * Dz:
-            raise ValueError("rank outside the domain grid")
-        self.rank = rank
-        self.coord = ((rank % (Dx * Dy)) % Dx, (rank % (Dx * Dy)) // Dx, rank // (Dx * Dy))
-        self.H = tuple(int(d > 1) for d in self.D)                         # halo offsets
-        self.lN = tuple(g // d + 2 * h for g, d, h in zip(self.gN, self.D, self.H))
-        self.O = tuple(c * (g // d) - h for c, g, d, h in zip(self.coord, self.gN, self.D, self.H))
-
-    def rank_of(self, coord):
-        x, y, z = coord
-        return x + (y + z * self.D[1]) * self.D[0]
-
-    def neighbor(self, axis, sign):
-        c = list(self.coord)
-        c[axis] = (c[axis] + sign) % self.D[axis]
-        return self.rank_of(c)
-
-    def neighbor_dir(self, c):
-        """rank of the domain in direction c = (cx, cy, cz), periodic"""
-        return self.rank_of(tuple((k + d) % n for k, d, n in zip(self.coord, c, self.D)))
-
-    def split_axes(self):
-        return [a for a in range(3) if self.D[a] > 1]
-
-    def edges(self):
-        """edge messages this domain takes part in: population 7 + e crosses two cuts, both of them split"""
-        return [e for e in range(12) if all(self.D[a] > 1 for a in range(3) if C19[7 + e][a])]
-
-    def edge_length(self, e):
-        """cells of edge e's line: the local extent of the axis its population does not move along"""
-        return self.lN[[a for a in range(3) if C19[7 + e][a] == 0][0]]
-
-    # ---- boxes (x0,x1,y0,y1,z0,z1) in local coordinates: ONE implementation, the library's (luw_step_boxes, csrc/luw_group.hpp: pure host arithmetic, also
-    # what the one-process host luw_group_* cuts its domains with).  whole = the non-halo cells; interior + the disjoint shell slabs cover it exactly once;
-    # y, z slabs are the one cell layer next to a halo (whole rows), x slabs whole blocks of X_SHELL cells from the first owned cell on.
-    def _boxes(self):
-        key = (self.lN, self.H, self.X_SHELL)
-        if getattr(self, "_box_key", None) != key:
-            import ctypes as C
-            from . import capi
-            u3 = C.c_uint32 * 3
-            whole, inner, shell, n, ok = (C.c_uint32 * 6)(), (C.c_uint32 * 6)(), (C.c_uint32 * 36)(), C.c_uint32(0), C.c_int(0)
-            capi.check(capi.load().luw_step_boxes(u3(*self.lN), u3(*self.H), int(self.X_SHELL), whole, inner, shell, C.byref(n), C.byref(ok)))
-            self._box_key = key
-            self._box_val = (tuple(whole), tuple(inner), [tuple(shell[6 * k:6 * k + 6]) for k in range(n.value)], bool(ok.value))
-        return self._box_val
-
-    def whole_box(self): return self._boxes()[0]
-    def interior_box(self): return self._boxes()[1]
-    def shell_boxes(self): return list(self._boxes()[2])
-    def can_overlap(self): return self._boxes()[3]       # every split axis has at least four owned layers
-
-    def local_slices(self):
-        """slices of the GLOBAL (z,y,x) array that fill the local box incl. halos (periodic wrap), as index arrays"""
-        idx = []
-        for a in range(3):
-            idx.append((np.arange(self.lN[a]) + self.O[a]) % self.gN[a])
-        return idx  # x, y, z index arrays
-
-
-class TorchDistTransport:
-    """halo swap over torch.distributed point-to-point ops (RCCL on GPUs)"""
-
-    def __init__(self, layout, group=None):
-        import torch.distributed as dist
-        self.dist, self.layout, self.group = dist, layout, group
-
-    def exchange(self, axis, send_p, send_m, recv_p, recv_m):
-        """send_p -> +neighbour (arrives as its recv_m); send_m -> -neighbour (its recv_p)."""
-        dist = self.dist
-        plus, minus = self.layout.neighbor(axis, +1), self.layout.neighbor(axis, -1)
-        # fixed issue order on every rank keeps the pairing unambiguous when plus == minus (D = 2)
-        ops = [dist.P2POp(dist.isend, send_p, plus, self.group), dist.P2POp(dist.isend, send_m, minus, self.group),
-               dist.P2POp(dist.irecv, recv_m, minus, self.group), dist.P2POp(dist.irecv, recv_p, plus, self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
-    def exchange_all(self, messages):
-        """ONE batch for everything a step moves.  messages: (send, recv, c) in a fixed order of message types -- `send` leaves for the domain in direction c,
-        `recv` takes the same type of message from the domain in direction -c.  Every rank lists the types in the same order, so the k-th send of A to B is
-        the k-th receive of B from A also where several directions lead to the same rank (two domains along an axis; a rank that is its own neighbour)."""
-        dist, lay = self.dist, self.layout
-        if not messages:         # a domain without a cut: nothing to move
-            return
-        ops = [dist.P2POp(dist.isend, s, lay.neighbor_dir(c), self.group) for s, _, c in messages]
-        ops += [dist.P2POp(dist.irecv, r, lay.neighbor_dir(tuple(-v for v in c)), self.group) for _, r, c in messages]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
-    def warm_up(self, device, dtype=None, measure=0):
-        """One full-size exchange per split axis on scratch buffers, BEFORE the lattice is allocated: RCCL builds its
-        point-to-point connections (channels, staging buffers) at the first send/recv to a peer.  Measured on MI355X
-        (tools/check_nccl_self.py, LUW_SELF_EARLY): when that set-up happens in a process that has already allocated and freed
-        lattice-sized arrays, the interior kernel that follows runs 24 % slower for the life of the solver (2048x258x258 FP32:
-        4.44 instead of 3.55 ms); with the connections built first it does not.  Full-size messages, so that every channel the
-        real faces will use is connected now; the scratch buffers go back to torch's caching allocator, from which the domain's
-        halo buffers of the same sizes are then served."""
-        import torch
-        lN = self.layout.lN
-        wire = {}
-        for a in self.layout.split_axes():
-            A = lN[(a + 1) % 3] * lN[(a + 2) % 3]
-            bufs = [torch.zeros(5 * A, dtype=dtype or torch.float32, device=device) for _ in range(4)]
-            self.exchange(a, *bufs)
-            if measure:
-                # the wire alone: `measure` more exchanges of the same faces, HIP events on the stream the transport enqueues on
-                torch.cuda.synchronize(device)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(measure):
-                    self.exchange(a, *bufs)
-                e1.record(); e1.synchronize()
-                ms = e0.elapsed_time(e1) / measure
-                out_bytes = 2 * bufs[0].numel() * bufs[0].element_size()       # the + face and the - face leave, as many bytes arrive
-                wire["xyz"[a]] = {"bytes_out": out_bytes, "ms": round(ms, 4), "GBps_out": round(out_bytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
-                                  "to_ranks": [self.layout.neighbor(a, +1), self.layout.neighbor(a, -1)]}
-        # the one-phase exchange also talks to the diagonal neighbours (edge messages): one batch of everything, so that those connections exist now as well
-        edges = self.layout.edges() if hasattr(self.layout, "edges") else []
-        if edges:
-            unit = lambda a, sgn: tuple(sgn if k == a else 0 for k in range(3))
-            msgs = []
-            for a in self.layout.split_axes():
-                A = lN[(a + 1) % 3] * lN[(a + 2) % 3]
-                msgs += [(torch.zeros(5 * A, dtype=dtype or torch.float32, device=device), torch.zeros(5 * A, dtype=dtype or torch.float32, device=device),
-                          unit(a, sgn)) for sgn in (+1, -1)]
-            msgs += [(torch.zeros(self.layout.edge_length(e), dtype=dtype or torch.float32, device=device),
-                      torch.zeros(self.layout.edge_length(e), dtype=dtype or torch.float32, device=device), C19[7 + e]) for e in edges]
-            self.exchange_all(msgs)
-        torch.cuda.synchronize(device)
-        return wire
-
-
-class SelfExchangeTransport(TorchDistTransport):
-    """every neighbour is THIS rank: each face leaves and comes back through the real transport's self send / receive (RCCL on a GPU box).
-    Physically the rank's block made periodic.  What one rank of an N-GPU run does per step -- boundary shell, pack, exchange, unpack, interior,
-    pipelining -- on one GPU, without the wire to another device (bench.py's rank-shape blocks, tests/rank_shape_worker.py)."""
-
-    def __init__(self, layout, group=None):
-        super().__init__(layout, group)
-        import torch.distributed as dist
-        me = dist.get_rank() if dist.is_initialized() else 0
-        self.layout = type("SelfNeighbours", (), {"neighbor": staticmethod(lambda axis, sign: me), "neighbor_dir": staticmethod(lambda c: me),
-            "lN": layout.lN, "split_axes": layout.split_axes, "edges": layout.edges, "edge_length": layout.edge_length})()
-
-
-class PeerLoopbackTransport:
-    """every neighbour is THIS rank and no transport at all: the face buffers a step fills ARE the buffers its unpack reads (HipDomain(alias_faces=True):
-    the + face is written where "what came from the - side" is read, and vice versa) -- what the one-process host's peer stores do between two domains
-    (csrc/luw_group.hpp: the pack kernel, or the step kernels themselves for the x faces, write straight into the neighbour's receive buffer), with the
-    rank as its own neighbour.  Physically the rank's block made periodic, like SelfExchangeTransport, minus RCCL's copy kernels: bench.py's rank-shape
-    blocks carry both, so that what a rank pays for the transport is on the line."""
-    alias_faces = True
-
-    def __init__(self, layout):
-        self.layout = layout
-
-    def exchange(self, axis, send_p, send_m, recv_p, recv_m):
-        assert send_p.data_ptr() == recv_m.data_ptr() and send_m.data_ptr() == recv_p.data_ptr()
-
-    def exchange_all(self, messages):
-        assert all(s.data_ptr() == r.data_ptr() for s, r, _ in messages)
-
-    def warm_up(self, device, dtype=None, measure=0):
-        return {}
-
-
-def init_rccl_process_group(local_rank, timeout=None):
-    """`torch.distributed` over RCCL for one process per GPU.  RCCL's point-to-point kernels are launched while the interior
-    collide-stream kernel fills every CU, so the process group's internal stream is asked to be a high-priority one (like the
-    communication stream of `HipDomain`): the halo copies are dispatched ahead of the interior's remaining workgroups instead
-    of behind them (LUW_COMM_PRIORITY=0 turns both off for A/B runs, LUW_NCCL_PRIORITY=0 this one alone)."""
-    import os
-    import torch
-    import torch.distributed as dist
-    kw = {}
-    if os.environ.get("LUW_NCCL_PRIORITY", os.environ.get("LUW_COMM_PRIORITY", "1")) != "0":
-        try:
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-            kw["pg_options"] = opts
-        except Exception:           # a torch build without the option: default stream priority
-            pass
-    if timeout is not None:
-        kw["timeout"] = timeout
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
-
-
-class HostStagedTransport(TorchDistTransport):
-    """the same swap staged through host memory, for process groups that cannot move device memory (gloo): lets several
-    ranks share ONE GPU in tests; never the production path"""
-
-    def exchange(self, axis, send_p, send_m, recv_p, recv_m):
-        import torch
-        sp, sm = send_p.cpu(), send_m.cpu()                     # ordered after the pack kernel on the current stream
-        rp, rm = torch.empty_like(sp), torch.empty_like(sm)
-        super().exchange(axis, sp, sm, rp, rm)
-        recv_p.copy_(rp); recv_m.copy_(rm)
-
-    def exchange_all(self, messages):
-        import torch
-        staged = [(s.cpu(), torch.empty(r.shape, dtype=r.dtype), c) for s, r, c in messages]
-        super().exchange_all(staged)
-        for (_, r, _), (_, h, _) in zip(messages, staged):
-            r.copy_(h)
-
-
-class HipDomain:
-    """One LBM domain on one GPU through the C-ABI; buffers are torch CUDA tensors, work is enqueued on torch streams."""
-
-    def __init__(self, layout, nu, fp16c=False, kernel=0, device=0, alias_faces=False, **kw):
-        import torch
-        from .lbm import LBM
-        self.torch = torch
-        self.layout = layout
-        self.device = torch.device("cuda", device)
-        self.lbm = LBM(*layout.lN, nu, fp16c=fp16c, D=layout.D, O=layout.O, device=device, kernel=kernel, **kw)
-        # halo buffers travel as raw values: FP32 as float32, FP16C codes as float16 bit patterns (RCCL/NCCL has no int16 type;
-        # point-to-point ops copy bytes, nothing interprets the halves)
-        self.dtype = torch.float16 if fp16c else torch.float32
-        self.compute = torch.cuda.Stream(device=self.device)
-        # the boundary shell, the halo pack/unpack kernels and the exchange run on a high-priority queue so that they are not
-        # stuck behind the interior kernel's workgroups (LUW_COMM_PRIORITY=0 turns that off for A/B runs)
-        import os
-        self.comm = torch.cuda.Stream(device=self.device, priority=(-1 if os.environ.get("LUW_COMM_PRIORITY", "1") != "0" else 0))
-        # the schedule of a step -- which box on which stream, behind which event -- is the library's (luw_domain_step_*, shared with luw_group_*)
-        self.step = self.lbm.domain_step_create(self.compute.cuda_stream, self.comm.cuda_stream, layout.X_SHELL)
-        self.thermal = kw.get("alpha") is not None       # thermal D3Q7 lattice: one more population per face cell travels
-        self.buf, self.gbuf = {}, {}
-        self.x_insert_fused, self.x_pairs = False, None
-        for a in layout.split_axes():
-            A = self.lbm.area(a)
-            self.buf[a] = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(4)]  # send_p, send_m, recv_p, recv_m
-            if alias_faces:      # PeerLoopbackTransport: the rank is its own neighbour and the faces are written where they are read
-                self.buf[a][0], self.buf[a][1] = self.buf[a][3], self.buf[a][2]
-            if a == 0 and os.environ.get("LUW_X_FACE_FUSED", "1") != "0":
-                # the step kernels that hold the first / last owned x column write the x faces into the send buffers themselves; extract(0) then has
-                # nothing to launch (LUW_X_FACE_FUSED=0: the pack kernel as before, A/B switch) ...
-                self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
-                # ... and read the x faces they receive from the receive buffers (insert_deferred; LUW_X_INSERT_FUSED=0: the unpack kernel, A/B switch)
-                self.x_insert_fused = os.environ.get("LUW_X_INSERT_FUSED", "1") != "0"
-                if alias_faces and self.x_insert_fused:
-                    # written where they are read: the step that reads one pair of buffers writes the other (a neighbour's stores would race with the loads)
-                    other = [torch.zeros(5 * A, dtype=self.dtype, device=self.device) for _ in range(2)]
-                    self.x_pairs = [self.buf[0], [other[1], other[0], other[0], other[1]]]        # send_p is recv_m, send_m is recv_p
-            if self.thermal:
-                self.gbuf[a] = [torch.zeros(A, dtype=self.dtype, device=self.device) for _ in range(4)]
-                if alias_faces:
-                    self.gbuf[a][0], self.gbuf[a][1] = self.gbuf[a][3], self.gbuf[a][2]
-        # edge messages of the one-phase exchange: [send, receive] per edge, one element per cell of the third axis
-        self.ebuf = {e: [torch.zeros(self.lbm.edge_length(e), dtype=self.dtype, device=self.device) for _ in range(2)] for e in layout.edges()}
-        if alias_faces:
-            for e in self.ebuf: self.ebuf[e][0] = self.ebuf[e][1]
-
-    # host fields (reference layout, local box incl. halos)
-    def set_fields(self, flags, u, rho, T=None):
-        self.lbm.flags.data[:] = flags; self.lbm.u.data[:] = u; self.lbm.rho.data[:] = rho
-        if T is not None:
-            self.lbm.T.data[:] = T
-
-    def initialize(self):
-        self.lbm.run(0)
-
-    def get_t(self): return self.lbm.get_t()
-    def increment_time_step(self, n=1): self.lbm.increment_time_step(n)
-    def reset_time_step(self): self.lbm.reset_time_step()
-
-    def stream_collide(self, box, write_fields, stream, sample=False):
-        self.lbm.set_stream(stream.cuda_stream)
-        self.lbm.enqueue_stream_collide(box, write_fields, sample)
-
-    def stats_begin_sample(self): return self.lbm.stats_begin_sample()
-    def configure_step(self, overlap):
-        if self.lbm.domain_step_overlaps(self.step) != bool(overlap):
-            self.lbm.domain_step_destroy(self.step)
-            self.step = self.lbm.domain_step_create(self.compute.cuda_stream, self.comm.cuda_stream, self.layout.X_SHELL, overlap=overlap)
-    def step_overlaps(self): return self.lbm.domain_step_overlaps(self.step)
-    def step_launch(self, write_fields, timed=False): self.lbm.domain_step_launch(self.step, write_fields, timed)
-    def step_separate_stats(self): self.lbm.domain_step_separate_stats(self.step)
-    def step_timing(self): return self.lbm.domain_step_timing(self.step)
-
-    def extract(self, axis, stream):
-        self.lbm.set_stream(stream.cuda_stream)
-        b = self.buf[axis]
-        self.lbm.enqueue_extract_fi(axis, b[0].data_ptr(), b[1].data_ptr())
-        return b[0], b[1]
-
-    def recv_buffers(self, axis):
-        return self.buf[axis][2], self.buf[axis][3]
-
-    def insert(self, axis, stream):
-        self.lbm.set_stream(stream.cuda_stream)
-        b = self.buf[axis]
-        self.lbm.enqueue_insert_fi(axis, b[2].data_ptr(), b[3].data_ptr())
-
-    def insert_deferred(self, axis, stream):
-        """insert(0) without its kernel where the library can do that (one-phase exchange: nothing packs from the lattice before the next step): the next
-        step's kernels read the x faces from the receive buffers.  Other axes: the unpack kernel."""
-        if axis != 0 or not self.x_insert_fused:
-            return self.insert(axis, stream)
-        self.lbm.set_stream(stream.cuda_stream)
-        b = self.buf[0]
-        self.lbm.set_x_face_inputs(b[2].data_ptr(), b[3].data_ptr())
-        self.next_x_buffers()
-
-    def next_x_buffers(self):
-        """the x buffers of the next step: the other set (the set just filled is read while that step runs)"""
-        if self.x_pairs:
-            self.buf[0] = self.x_pairs[1] if self.buf[0] is self.x_pairs[0] else self.x_pairs[0]
-            self.lbm.set_x_face_buffers(self.buf[0][0].data_ptr(), self.buf[0][1].data_ptr())
-
-    def extract_edges(self, stream, only=None):
-        """packs every edge (only: those edges); returns [(e, send, receive)]"""
-        todo = sorted(e for e in self.ebuf if only is None or e in only)
-        if todo:
-            self.lbm.set_stream(stream.cuda_stream)
-            self.lbm.enqueue_edges([self.ebuf[e][0].data_ptr() if e in todo else 0 for e in range(12)], insert=False)
-        return [(e, self.ebuf[e][0], self.ebuf[e][1]) for e in todo]
-
-    def insert_edges(self, stream, only=None):
-        todo = [e for e in self.ebuf if only is None or e in only]
-        if todo:
-            self.lbm.set_stream(stream.cuda_stream)
-            self.lbm.enqueue_edges([self.ebuf[e][1].data_ptr() if e in todo else 0 for e in range(12)], insert=True)
-
-    def extract_g(self, axis, stream):
-        self.lbm.set_stream(stream.cuda_stream)
-        b = self.gbuf[axis]
-        self.lbm.enqueue_extract_gi(axis, b[0].data_ptr(), b[1].data_ptr())
-        return b[0], b[1]
-
-    def recv_buffers_g(self, axis):
-        return self.gbuf[axis][2], self.gbuf[axis][3]
-
-    def insert_g(self, axis, stream):
-        self.lbm.set_stream(stream.cuda_stream)
-        b = self.gbuf[axis]
-        self.lbm.enqueue_insert_gi(axis, b[2].data_ptr(), b[3].data_ptr())
-
-    def download_T(self):
-        self.torch.cuda.synchronize(self.device)
-        self.lbm.T.read_from_device()
-        return self.lbm.T.data
-
-    def download(self):
-        self.torch.cuda.synchronize(self.device)
-        self.lbm.u.read_from_device(); self.lbm.rho.read_from_device()
-        return self.lbm.u.data, self.lbm.rho.data
-
-    # ---- what a deck run loop needs besides the step (inlet, probes, statistics)
-    def set_coriolis(self, ox, oy, oz): self.lbm.set_coriolis(ox, oy, oz)
-
-    def vk_attach(self, cell, face, point_data, mode_data, mode_count, stride, interp):
-        self.lbm.vk_inlet_attach(cell, face, point_data, mode_data, mode_count, stride, interp)
-
-    def vk_apply(self, stream):
-        self.lbm.set_stream(stream.cuda_stream)
-        self.lbm.vk_inlet_apply()
-
-    def gather_attach(self, cells): self.lbm.gather_attach(cells)
-
-    def gather_u(self):
-        self.lbm.set_stream(self.compute.cuda_stream)
-        return self.lbm.gather_u()
-
-    def stats_reset(self): self.lbm.stats_reset()
-
-    def stats_accumulate(self):
-        self.lbm.set_stream(self.compute.cuda_stream)
-        self.lbm.stats_accumulate()
-        self.compute.synchronize()
-
-    def stats_enqueue(self, stream):
-        """the Welford update on `stream`, no host synchronisation (sampled steps inside DomainDecomposedLBM.run)"""
-        self.lbm.set_stream(stream.cuda_stream)
-        self.lbm.stats_accumulate()
-
-    def stats_download(self):
-        self.lbm.set_stream(self.compute.cuda_stream)
-        return self.lbm.stats_download()
-
-    def stats_download_T(self):
-        self.lbm.set_stream(self.compute.cuda_stream)
-        return self.lbm.stats_download_T()
-
-    def close(self):
-        self.torch.cuda.synchronize(self.device)
-        if getattr(self, "step", None):
-            self.lbm.domain_step_destroy(self.step); self.step = None
-        self.lbm.close()
+from .hip_domain import HipDomain   # noqa: F401
+from .layout import C19, DomainLayout, choose_decomposition, tile_lattice   # noqa: F401
+from .transports import HostStagedTransport, PeerLoopbackTransport, SelfExchangeTransport, TorchDistTransport, init_rccl_process_group   # noqa: F401
 
 
 class DomainDecomposedLBM:
