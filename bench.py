@@ -6,16 +6,20 @@
 
 N = 1 (the driver's BENCH line): BASELINE.json configs[2] ("C3", the largest single-GPU configuration): 1024x1024x256 D3Q19,
 voxelised building cluster (SURVEY 8d closed-form box array), bounce-back, Smagorinsky LES, FP32 DDFs, z=0 plane solid, the
-other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the same profile, rho=1.  The same JSON
-line carries `secondary` blocks measured in the same process after the headline: configs[1] ("C2", 512^3 empty channel) and the
-north star's 1024^3 grid, FP32 and FP16C each, and C3 with FP16C DDFs (--no-secondary skips them; --workload picks another
-headline).
+other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the same profile, rho=1.  After the
+headline a handful of `secondary` blocks are measured, each in a fresh child process (DEFAULT_BLOCKS: configs[1], the north
+star's 1024^3 grid, C3 with FP16C DDFs / Coriolis / the thermal lattice, the undivided urban tile and one rank of the literal
+n_gpu=[4,2,1] cut of configs[3] / configs[4]); --all-blocks adds the rest with their native-arithmetic and peer-loopback twins,
+--no-secondary skips them, --workload picks another headline.
 N > 1 (the driver's SCALE runs): the urban tile of BASELINE configs[3] weak-scaled at 512^3 cells per GPU (8 GPUs:
 2048x1024x512) -- building array, buffer nudging and top sponge with the deck defaults (160 m / 300 s, 200 m / 120 s), cut
-as n_gpu=[1,4,2] by default (--n-gpu 4 2 1 = the deck's literal grid, also measured as a secondary block), one-cell halos over
-RCCL.  There is no fallback transport: if RCCL point-to-point fails the run exits non-zero.
+as the deck's literal n_gpu (8 GPUs: [4,2,1], what BASELINE.json names; the x-whole cut [1,4,2] of the same tile is a secondary
+block; --n-gpu picks another grid), one-cell halos over RCCL.  There is no fallback transport: if RCCL point-to-point fails
+the run exits non-zero.
 A "step" is one stream_collide pass over the whole lattice; rho/u are written by the last step only (153 B/LUP mode, see
-DESIGN.md); data is synthetic and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+DESIGN.md); data is synthetic and resident in HBM before the timed region.
+Rank 0 prints ONE JSON line of at most 4 KB (benchmarks/line.py); the blocks in full go to gpurun_out/bench_secondary.json
+(LUW_BENCH_FULL_JSON names another path), which the line cites as `secondary_file`.
 """
 import argparse
 import json
@@ -29,6 +33,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from benchmarks.common import (BYTES_PER_LUP, BUILDING_TOP, CELL_M, DT_S, HBM_PEAK_GBPS, NU, ROOT, WORKLOADS, attach_traffic, channel_state, coriolis_omega,
     cpu_baseline,
     cpu_model, device_context, fill_channel, loglaw_profile, profile_key, reference_case_rmse, reference_parity, tile_forcing, usable_cores)   # noqa: F401
+from benchmarks.line import emit as emit_line
 from benchmarks.multi import GROUP_HOST_VARIANTS, group_host_child, run_distributed   # noqa: F401
 
 
@@ -108,10 +113,17 @@ def run_single_block(luw, capi, device, key, native=False):
     return r
 
 
-RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0),
-                     "c4_rank_1x4x2_f32": dict(fp16c=False, coriolis=False, D=(1, 4, 2), rank=7),       # the cut `--gpus 8` takes by default
+RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0),       # the cut `--gpus 8` times: BASELINE's literal n_gpu
+                     "c4_rank_1x4x2_f32": dict(fp16c=False, coriolis=False, D=(1, 4, 2), rank=7),       # the same tile with x kept whole (2048x258x258 per rank)
                      "c5_rank_4x2x1_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0),
                      "c5_rank_1x4x2_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7)}
+
+
+def rank_shape_lattice(D):
+    """the lattice a rank-shape block cuts: ONE tile whatever the cut (8 ranks: 2048x1024x512, so [1,4,2] ranks are 2048x258x258 and [4,2,1] ranks
+    514x514x512 with their halos) -- tests/test_bench_line.py holds the blocks to the shapes tests/test_gpu_bench_workloads.py checks against the oracle"""
+    from latticeurbanwind_amd.layout import tile_lattice
+    return tile_lattice(D[0] * D[1] * D[2])
 
 
 def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, warmup, native=False, transport="rccl-self"):
@@ -126,7 +138,7 @@ def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, wa
             os.environ.setdefault(k, v)
         init_rccl_process_group(device)
     world = D[0] * D[1] * D[2]
-    gN = (512 * D[0], 512 * D[1], 512 * D[2]) if world > 1 else (512, 512, 512)
+    gN = rank_shape_lattice(D)
     nud, spg = tile_forcing()
     lay = DomainLayout(gN, D, rank)
     tr = SelfExchangeTransport(lay) if transport == "rccl-self" else PeerLoopbackTransport(lay)
@@ -154,7 +166,7 @@ def run_rank_shape(luw, torch, kern, device, fp16c, coriolis, D, rank, steps, wa
         "steps": steps, "warmup": warmup,
             "n_gpu": list(D), "rank": rank, "coord": list(sim.layout.coord), "local_lattice": list(sim.layout.lN), "dtype": "fp16c-storage/f32-arithmetic"
                 if fp16c else "f32", "arith": "native" if (native and fp16c) else "exact",
-            "workload": "rank %d of the 2048x1024x512 urban tile as n_gpu=%s" % (rank, list(D)) if world > 1
+            "workload": "rank %d of the %dx%dx%d urban tile as n_gpu=%s" % (rank, *gN, list(D)) if world > 1
                 else "512^3 urban tile, undivided (the N = 1 point of the N > 1 lines)",
             "options": "building array + buffer nudging (160 m / 300 s) + top sponge (200 m / 120 s)" + (" + Coriolis force" if coriolis else ""),
             "halo_exchange": None if world == 1 else "RCCL self send / receive of every face (no wire to another device)" if transport == "rccl-self"
@@ -183,6 +195,29 @@ def describe(name, size, buildings, dtype, coriolis, thermal, every_step):
         "every step" if every_step else "by the last step only")
 
 
+# what the default N = 1 line measures after the headline (one fresh child process each); --all-blocks: every block, with its twins
+DEFAULT_BLOCKS = ("c2_f32", "c3_fp16c", "c3_fp16c_coriolis", "c3_fp16c_thermal", "cube1024_f32", "cube1024_fp16c", "tile512_urban_fp16c_coriolis",
+    "c4_rank_4x2x1_f32", "c5_rank_4x2x1_fp16c_coriolis")
+
+
+def child_block(flag, key, local_rank, *extra):
+    """ONE secondary block in a fresh child process (its JSON is the child's last stdout line); a failure is an `error` entry, never an exception"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag, key, *extra, "--steps", str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)],
+            capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
+    except Exception as e:
+        return {"error": str(e)[:300]}
+
+
+def block_note(b):
+    if "error" in b:
+        return "error: " + str(b["error"])[:200]
+    return "%.4f ms/step, %s of the HBM roofline" % (b["ms_per_step"], (b.get("roofline") or {}).get("frac"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +242,8 @@ def main():
     ap.add_argument("--urban", action="store_true", help="N = 1: add the urban tile's buffer nudging + top sponge (deck defaults) to the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--all-blocks", action="store_true", help="N = 1: every secondary block (not only DEFAULT_BLOCKS), FP16C blocks also with native arithmetic, "
+        "rank shapes also with the peer-loopback transport: 25 child processes, about two minutes")
     ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of "
         "the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
     ap.add_argument("--force-distributed", action="store_true",
@@ -304,46 +341,27 @@ def main():
             # transport's self send / receive), EACH IN A FRESH PROCESS: a process that has allocated and freed lattice-sized arrays a few times draws worse
             # physical placements for the next one (the same block 1.74 ms fresh, 1.94-1.98 ms as the third lattice of a process, profiles/r03d/e), and a
             # rank's RCCL connections have to exist before its lattice is allocated (24-40 % otherwise, profiles/r01g_halo_chain.md)
-            import subprocess
             sec = {}
             headline_key = next((k for k, v in SINGLE_BLOCKS.items() if v == (args.workload, args.dtype, args.coriolis, args.thermal, args.urban)), None)
-            for key, flag in [(k, "--secondary-block") for k in SINGLE_BLOCKS] + [(k, "--rank-shape-block") for k in RANK_SHAPE_BLOCKS]:
+            flag_of = lambda k: "--secondary-block" if k in SINGLE_BLOCKS else "--rank-shape-block"
+            for key in (list(SINGLE_BLOCKS) + list(RANK_SHAPE_BLOCKS)) if args.all_blocks else DEFAULT_BLOCKS:
                 if key == headline_key and not args.size:
                     continue
-                try:
-                    r = subprocess.run(
-                        [sys.executable, os.path.abspath(__file__), flag, key, "--steps", str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)],
-                                       capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-                    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                    sec[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
-                except Exception as e:      # a secondary block never takes the headline down; its absence is visible
-                    sec[key] = {"error": str(e)[:300]}
-                sys.stderr.write("bench.py: secondary block %s: %s\n" % (key, sec[key].get("ms_per_step", sec[key].get("error")))); sys.stderr.flush()
+                sec[key] = child_block(flag_of(key), key, local_rank)
+                sys.stderr.write("bench.py: secondary block %s: %s\n" % (key, block_note(sec[key]))); sys.stderr.flush()
+                if not args.all_blocks or "error" in sec[key]:
+                    continue
                 # FP16C blocks: the same block once more with the native-arithmetic kernels (LUW_OPT_NATIVE_ARITH), again in a fresh process; the block's own
                 # numbers are the bit-exact kernels' ("arith": "exact"), the twin sits under "native"
-                if key in NATIVE_TWINS and "error" not in sec[key]:
-                    try:
-                        r = subprocess.run(
-                            [sys.executable, os.path.abspath(__file__), flag, key, "--arith", "native", "--steps", str(SECONDARY_STEPS), "--warmup",
-                            str(SECONDARY_WARMUP)], capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-                        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                        nat = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
-                    except Exception as e:
-                        nat = {"error": str(e)[:300]}
+                if key in NATIVE_TWINS:
+                    nat = child_block(flag_of(key), key, local_rank, "--arith", "native")
                     sec[key]["native"] = {k: nat[k] for k in ("value", "ms_per_step", "arith", "kernel_ms", "shell_ms", "exchange_ms", "error") if k in nat}
                     if "roofline" in nat:
                         sec[key]["native"]["roofline"] = {k: nat["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "kernel_frac")
                             if k in nat["roofline"]}
                 # rank shapes: the same rank once more with its faces written in place (the one-process host's peer stores) instead of RCCL self send / receive
-                if flag == "--rank-shape-block" and "error" not in sec[key]:
-                    try:
-                        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag, key, "--rank-transport", "peer-loopback", "--steps",
-                            str(SECONDARY_STEPS), "--warmup", str(SECONDARY_WARMUP)], capture_output=True, text=True, timeout=600,
-                            env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-                        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                        tw = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": ("exit %d: " % r.returncode) + r.stderr[-300:]}
-                    except Exception as e:
-                        tw = {"error": str(e)[:300]}
+                if key in RANK_SHAPE_BLOCKS:
+                    tw = child_block(flag_of(key), key, local_rank, "--rank-transport", "peer-loopback")
                     sec[key]["peer_loopback"] = {k: tw[k] for k in ("value", "ms_per_step", "transport", "kernel_ms", "shell_ms", "exchange_ms", "error")
                         if k in tw}
                     if "roofline" in tw:
@@ -366,9 +384,8 @@ def main():
                 out["parity"] = reference_parity()
             except Exception as e:      # never let the side measurement break the benchmark line
                 out["parity"] = {"error": str(e)[:200]}
-        sys.stdout.flush(); os.dup2(saved_stdout, 1)
-        print(json.dumps(out)); sys.stdout.flush()
-        os.dup2(2, 1)
+        sys.stdout.flush()
+        emit_line(saved_stdout, out)            # the short line on stdout, everything above in gpurun_out/bench_secondary.json
         import torch.distributed as dist
         if dist.is_initialized():               # the one-rank world of the rank-shape blocks
             dist.destroy_process_group()

@@ -98,7 +98,8 @@ class LineKeeper:
             if self.done:
                 return
             self.done = True
-            os.write(self.fd, (json.dumps(line if line is not None else self.line) + "\n").encode())
+            from .line import emit as emit_line
+            emit_line(self.fd, line if line is not None else self.line)       # short line on stdout, the full record in its file
 
     def arm(self, seconds):
         import threading
@@ -199,10 +200,10 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
         parity["ok"] = bool(verdict[0])
         if not parity["ok"]:
             if rank == 0:
-                sys.stdout.flush(); os.dup2(saved_stdout, 1)
-                print(json.dumps({"metric": METRIC, "value": None, "unit": "MLUPS", "n_gpus": world,
-                    "error": "decomposed run differs from the oracle: nothing was timed", "parity": parity}))
-                sys.stdout.flush(); os.dup2(2, 1)
+                from .line import emit as emit_line
+                sys.stdout.flush()
+                emit_line(saved_stdout, {"metric": METRIC, "value": None, "unit": "MLUPS", "n_gpus": world, "per_rank": [],
+                    "error": "decomposed run differs from the oracle: nothing was timed", "parity": parity})
             dist.barrier(); dist.destroy_process_group()
             raise SystemExit(3)
 
