@@ -141,6 +141,14 @@ __device__ __forceinline__ void fp16c_code2_hi_in_rtz_mode(const f32x2_codec x, 
 	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c0) : "s"(0x7FFFFFFF), "v"(t0), "v"(x.x));
 	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c1) : "s"(0x7FFFFFFF), "v"(t1), "v"(x.y));
 }
+// the same code from a value that is ALREADY scaled by 2^-112 (native-arithmetic pair kernel, collide_cell_pk_native<.., RAW>): the float's own bits carry the
+// reference formula -- add 0x800, drop 12 bits; the sign bit leaves with the 4-bit shift and comes back through the bit-field insert.  Any rounding mode.
+__device__ __forceinline__ uint32_t fp16c_code_hi_of_scaled(const float x) {
+	uint32_t c, code;
+	asm("v_add_lshl_u32 %0, %1, %2, 4" : "=v"(c) : "v"(x), "s"(0x800));
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(code) : "s"(0x7FFFFFFF), "v"(c), "v"(x));
+	return code;
+}
 // g/cg: the 7 populations of the thermal lattice, encoded in the same region (nullptr without it)
 __device__ __forceinline__ void fp16c_encode19_hi_rtz_final(float* f, uint32_t* code, float* g = nullptr, uint32_t* cg = nullptr) {
 	asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
@@ -725,26 +733,43 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 #ifndef LUW_NATIVE_RCP_NEWTON
 #define LUW_NATIVE_RCP_NEWTON 0   /* 1: one Newton step behind the density's v_rcp_f32 (A/B: the u-RMSE against the oracle does not change) */
 #endif
-template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_pk_native(const KParams& p, const uint32_t n, const uint8_t flagsn,
-	const bool may_force, float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F, float& rhon,
-	float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr, const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) {
+// RAW (pair kernel without the thermal lattice): the populations arrive and leave SCALED by 2^-112 -- the bit pattern the codec's shift-and-mask produces
+// and consumes -- so that neither the decode nor the encode multiplies: every place the populations enter is linear in them, and the power of two moves
+// into a factor that exists anyway (rho = fma(sum, 2^112, 1); u = m (2^112 / rho); n_k = fma(s_k, 2^112, -eq_k); out = (1 - w) f + 2^-112 (w f_eq + F)).
+// A power of two commutes with every rounding as long as nothing underflows: the scaled populations are multiples of 2^-137 (the float denormal
+// quantum is 2^-149), their sums round like the unscaled ones; the outputs are rounded to 2^-149 = 2^-37 in lattice units where an FP16C code step is
+// 2^-25 at least.  The encode is then the reference's own formula on the float's bits (add 0x800, drop 12 bits: FX/kernel.cpp:870-875) under the default
+// rounding mode -- no switch to round-toward-zero, which the exact kernels need for their 2^-112 product alone.
+__device__ __forceinline__ f32x2 sum_and_negated_difference(const f32x2 a) { // { x + y, y - x } in one packed addition
+	f32x2 r;
+	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+	return r;
+}
+template<int FORCE=PAIR_FORCE_ANY, bool RAW=false> __device__ __forceinline__ void collide_cell_pk_native(const KParams& p, const uint32_t n,
+	const uint8_t flagsn, const bool may_force, float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F,
+	float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr, const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) {
 	#pragma clang fp contract(fast)
+	constexpr float UP = RAW ? 0x1p+112f : 1.0f, DOWN = RAW ? 0x1p-112f : 1.0f;
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
-	float s[9], mx, my, mz;
+	// pair sums s_k = f[2k+1] + f[2k+2] (.x) and NEGATED differences -d_k = f[2k+2] - f[2k+1] (.y), one packed addition per pair; the three pairs of
+	// pairs that share an axis (k = 3 / 6: +-x +-y, 4 / 7: +-x +-z, 5 / 8: +-y +-z) summed as pairs again: { s + s', -(d + d') }
+	f32x2 sd[9];
+	float nmx, nmy, nmz;                                           // -m = -sum c f
 	{
-		float d[9];
 		#pragma unroll
-		for(int k=0; k<9; k++) { s[k] = fp[k].x+fp[k].y; d[k] = fp[k].x-fp[k].y; }
-		rhon = (((f0+s[0])+(s[1]+s[2]))+((s[3]+s[4])+(s[5]+s[6])))+(s[7]+s[8])+1.0f;
-		mx = (d[0]+(d[3]+d[6]))+(d[4]+d[7]);
-		my = (d[1]+(d[3]-d[6]))+(d[5]+d[8]);
-		mz = (d[2]+(d[4]-d[7]))+(d[5]-d[8]);
+		for(int k=0; k<9; k++) sd[k] = sum_and_negated_difference(fp[k]);
+		const f32x2 p36 = sd[3]+sd[6], p47 = sd[4]+sd[7], p58 = sd[5]+sd[8];
+		const float sum = ((f0+sd[0].x)+(sd[1].x+sd[2].x))+((p36.x+p47.x)+p58.x);
+		rhon = sum*UP+1.0f;
+		nmx = (sd[0].y+p36.y)+p47.y;
+		nmy = (sd[1].y+(sd[3].y-sd[6].y))+p58.y;
+		nmz = (sd[2].y+(sd[4].y-sd[7].y))+(sd[5].y-sd[8].y);
 	}
 	if(wave_has_E) { if(is_E) rhon = own ? own->wb : rho[n]; }
 	float r = __builtin_amdgcn_rcpf(rhon);
 	if constexpr(LUW_NATIVE_RCP_NEWTON!=0) r = fmaf(fmaf(-rhon, r, 1.0f), r, r);
-	uxn = mx*r; uyn = my*r; uzn = mz*r;
+	{ const float nr = -UP*r; uxn = nmx*nr; uyn = nmy*nr; uzn = nmz*nr; }
 	if(wave_has_E) {
 		if(is_E) {
 			if(own) { uxn = own->tu[0]; uyn = own->tu[1]; uzn = own->tu[2]; }
@@ -794,11 +819,11 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	#pragma unroll
 	for(int k=0; k<9; k++) A[k] = v[k]*v[k]+c3;
 	float w = p.w;
-	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737, from the non-equilibrium pair sums
+	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737, from the non-equilibrium pair sums n_(2k+1) + n_(2k+2) = s_k - (rho w_k A_k + 2 (rho - 1) w_k)
 		const float rm2s = 2.0f*rhom1s, rm2e = 2.0f*rhom1e;
 		float sn[9];
 		#pragma unroll
-		for(int k=0; k<9; k++) sn[k] = s[k]-((k<3 ? rhos : rhoe)*A[k]+(k<3 ? rm2s : rm2e));
+		for(int k=0; k<9; k++) sn[k] = sd[k].x*UP-((k<3 ? rhos : rhoe)*A[k]+(k<3 ? rm2s : rm2e));
 		const float Hxx = (sn[0]+(sn[3]+sn[4]))+(sn[6]+sn[7]), Hyy = (sn[1]+(sn[3]+sn[5]))+(sn[6]+sn[8]), Hzz = (sn[2]+(sn[4]+sn[5]))+(sn[7]+sn[8]);
 		const float Hxy = sn[3]-sn[6], Hxz = sn[4]-sn[7], Hyz = sn[5]-sn[8];
 		const float Q = (Hxx*Hxx+Hyy*Hyy+Hzz*Hzz)+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
@@ -808,28 +833,38 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 	float c_tau = 1.0f-0.5f*w;
 	if(wave_has_E) { w = is_E ? 1.0f : w; c_tau = is_E ? 0.0f : c_tau; }
 	const float omw = 1.0f-w;
+	// relaxation with the rate folded into the equilibrium's coefficients: w f_eq(+-) = W (A / 2 +- v) + M, W = w rho w_k, M = w (rho - 1) w_k (RAW: times 2^-112)
+	const float wd = w*DOWN;
+	const float Ws = wd*rhos, We = wd*rhoe, Ms = wd*rhom1s, Me = wd*rhom1e;
 	if(forced) {
-		// c_tau Fin_i = fma(+-c.H, +-v + 1, uH): H = c_tau w9 F / 3 (w9 = 1/2 axis, 1/4 diagonal), uH = -c_tau w9 (u.F) / 3; Fin_0 = -c_tau (u.F)
-		const float cs = c_tau*0.16666667f;
+		// c_tau Fin_i = fma(+-c.H, +-v + 1, uH): H = c_tau w9 F / 3 (w9 = 1/2 axis, 1/4 diagonal), uH = -c_tau w9 (u.F) / 3; Fin_0 = -c_tau (u.F); the constant
+		// part uH joins M
+		const float cs = (c_tau*DOWN)*0.16666667f;
 		const float hx = cs*fxn, hy = cs*fyn, hz = cs*fzn;
 		const float dots = cs*(uxn*fxn+uyn*fyn+uzn*fzn);           // = -uH of the axis pairs
-		const float ex = 0.5f*hx, ey = 0.5f*hy, ez = 0.5f*hz, dote = 0.5f*dots;
-		const float cH[9] = { hx, hy, hz, ex+ey, ex+ez, ey+ez, ex-ey, ex-ez, ey-ez };
-		f0 = omw*f0+(w*(DEF_W0*(rhon*(0.5f*c3)+rhom1))-6.0f*dots);
+		const float ex = 0.5f*hx, ey = 0.5f*hy, ez = 0.5f*hz;
+		const float Mds = Ms-dots, Mde = Me-0.5f*dots;
+		f0 = omw*f0+(wd*(DEF_W0*(rhon*(0.5f*c3)+rhom1))-6.0f*dots);
+		// uniform-force instantiation (everything in registers, 96 of them for 5 waves): the six diagonal 3 c.u are formed AGAIN here instead of living from the
+		// equilibrium ingredients on -- six additions for six registers, without which the kernel spills (the empty asm keeps the compiler from reusing them)
+		float vx = ux3, vy = uy3, vz = uz3;
+		if constexpr(FORCE==PAIR_FORCE_UNIFORM) asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz));
 		#pragma unroll
 		for(int k=0; k<9; k++) {
-			const f32x2 in = splat2(0.5f*A[k])+pm2(v[k]);
-			const f32x2 feq = splat2(k<3 ? rhos : rhoe)*in+splat2(k<3 ? rhom1s : rhom1e);
-			const f32x2 fin = pm2(cH[k])*(pm2(v[k])+splat2(1.0f))-splat2(k<3 ? dots : dote);
-			fp[k] = splat2(omw)*fp[k]+(splat2(w)*feq+fin);
+			// c_k.H formed where it is used (six values live instead of nine)
+			const float cH = k==0 ? hx : k==1 ? hy : k==2 ? hz : k==3 ? ex+ey : k==4 ? ex+ez : k==5 ? ey+ez : k==6 ? ex-ey : k==7 ? ex-ez : ey-ez;
+			const float vk = FORCE!=PAIR_FORCE_UNIFORM ? v[k]
+				: k==0 ? vx : k==1 ? vy : k==2 ? vz : k==3 ? vx+vy : k==4 ? vx+vz : k==5 ? vy+vz : k==6 ? vx-vy : k==7 ? vx-vz : vy-vz;
+			const f32x2 in = __builtin_elementwise_fma(splat2(0.5f), splat2(A[k]), pm2(vk));
+			const f32x2 fin = __builtin_elementwise_fma(pm2(cH), pm2(vk)+splat2(1.0f), splat2(k<3 ? Mds : Mde));
+			fp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], __builtin_elementwise_fma(splat2(k<3 ? Ws : We), in, fin));
 		}
 	} else {
-		f0 = omw*f0+w*(DEF_W0*(rhon*(0.5f*c3)+rhom1));
+		f0 = omw*f0+wd*(DEF_W0*(rhon*(0.5f*c3)+rhom1));
 		#pragma unroll
 		for(int k=0; k<9; k++) {
-			const f32x2 in = splat2(0.5f*A[k])+pm2(v[k]);
-			const f32x2 feq = splat2(k<3 ? rhos : rhoe)*in+splat2(k<3 ? rhom1s : rhom1e);
-			fp[k] = splat2(omw)*fp[k]+splat2(w)*feq;
+			const f32x2 in = __builtin_elementwise_fma(splat2(0.5f), splat2(A[k]), pm2(v[k]));
+			fp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], __builtin_elementwise_fma(splat2(k<3 ? Ws : We), in, splat2(k<3 ? Ms : Me)));
 		}
 	}
 }

@@ -411,6 +411,9 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
 	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
 	constexpr bool OWN = LUW_PAIR_OWN_EARLY!=0 && !PRE;
+	// RAW: the populations stay scaled by 2^-112 from the decode's shift-and-mask to the encode's (collide_cell_pk_native<FORCE, RAW>, luw_device.hpp): no
+	// products in the codec, no switch of the rounding mode (the thermal lattice's exact cell update keeps the scaled-up form)
+	constexpr bool RAW = NATIVE && !THERMAL;
 	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	const RowOff rb = row_offsets(p, y, z);
@@ -551,9 +554,12 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 			asm volatile("" : "=v"(own.tu[0]), "=v"(own.tu[1]), "=v"(own.tu[2]), "=v"(own.wb));
 			if(MODE!=1&&proc[c]&&(fl[c]&TYPE_BO)==TYPE_E) { own.wb = rho[n+c]; own.tu[0] = u[n+c]; own.tu[1] = u[Np+n+c]; own.tu[2] = u[2ull*Np+n+c]; }
 		}
-		f0 = __uint_as_float(bits(0))*0x1p+112f;
+		f0 = RAW ? __uint_as_float(bits(0)) : __uint_as_float(bits(0))*0x1p+112f;
 		#pragma unroll
-		for(int k=0; k<9; k++) { const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) }; fp[k] = t*splat2(0x1p+112f); }
+		for(int k=0; k<9; k++) {
+			const f32x2 t = { __uint_as_float(bits(2*k+1)), __uint_as_float(bits(2*k+2)) };
+			if constexpr(RAW) fp[k] = t; else fp[k] = t*splat2(0x1p+112f);
+		}
 		if constexpr(THERMAL) {
 			#pragma unroll
 			for(int q=0; q<7; q++) {
@@ -566,7 +572,7 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
 			[[maybe_unused]] float u0[3];
-			if constexpr(NATIVE) collide_cell_pk_native<FORCE>(p, n+c, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr,
+			if constexpr(NATIVE) collide_cell_pk_native<FORCE, RAW>(p, n+c, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr,
 				PRE ? &refs[c] : nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
 			else collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c]
 				: nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
@@ -640,25 +646,30 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		asm volatile("" : "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3]), "+v"(gb[4]), "+v"(gb[5]), "+v"(gb[6]));
 		if constexpr(!PARK) asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]));
 	}
-	// ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp)
-	if constexpr(PARK) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" ::: "memory");
+	// ... before the wave's FP32 rounding mode becomes RTZ (see luw_device.hpp; RAW: the encode has no floating-point operation, the mode stays)
+	if constexpr(RAW) { if constexpr(PARK) asm volatile("" ::: "memory"); }
+	else if constexpr(PARK) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" ::: "memory");
 	else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");
 	// codes of both cells in the high halves, merged per plane: q = 0 or 2k+1+h
 	uint32_t ca[19], cb[19];
-	cb[0] = fp16c_code_hi_in_rtz_mode(fb0);
+	auto code1 = [&](const float v) { if constexpr(RAW) return fp16c_code_hi_of_scaled(v); else return fp16c_code_hi_in_rtz_mode(v); };
+	auto code2 = [&](const f32x2 v, uint32_t& c0, uint32_t& c1) {
+		if constexpr(RAW) { c0 = fp16c_code_hi_of_scaled(v.x); c1 = fp16c_code_hi_of_scaled(v.y); } else fp16c_code2_hi_in_rtz_mode(v, c0, c1);
+	};
+	cb[0] = code1(fb0);
 	#pragma unroll
-	for(int k=0; k<9; k++) fp16c_code2_hi_in_rtz_mode(fb[k], cb[2*k+1], cb[2*k+2]);
+	for(int k=0; k<9; k++) code2(fb[k], cb[2*k+1], cb[2*k+2]);
 	if constexpr(PARK) {
-		ca[0] = fp16c_code_hi_in_rtz_mode(__uint_as_float(slot[0]));
+		ca[0] = code1(__uint_as_float(slot[0]));
 		#pragma unroll
 		for(int k=0; k<9; k++) {
 			const f32x2 v = { __uint_as_float(slot[64*(2*k+1)]), __uint_as_float(slot[64*(2*k+2)]) };
-			fp16c_code2_hi_in_rtz_mode(v, ca[2*k+1], ca[2*k+2]);
+			code2(v, ca[2*k+1], ca[2*k+2]);
 		}
 	} else {
-		ca[0] = fp16c_code_hi_in_rtz_mode(fa0);
+		ca[0] = code1(fa0);
 		#pragma unroll
-		for(int k=0; k<9; k++) fp16c_code2_hi_in_rtz_mode(fa[k], ca[2*k+1], ca[2*k+2]);
+		for(int k=0; k<9; k++) code2(fa[k], ca[2*k+1], ca[2*k+2]);
 	}
 	[[maybe_unused]] uint32_t cg[7];                               // THERMAL: the merged dwords of the temperature lattice
 	if constexpr(THERMAL) {

@@ -6,7 +6,7 @@ in the Smagorinsky rate, sums in trees, free contraction -- csrc/luw_device.hpp,
   * K = 8 / K = 64 on a deliberately noisy LES state: the differences of single stored codes (2^-12 relative each) grow like the flow lets them -- the same
     growth the REAL reference shows against the oracle (tests/golden/ref_shipped_*: 0.3-0.9e-6 at K = 8, 0.4-2.6e-5 at K = 64); recorded values x 2;
   * against the real reference's own fields: the same ceilings the bit-exact path has, and within twice the recorded values;
-  * mass: the drift of the mean density over 200 steps no larger than the exact kernels' (+ 1e-8).
+  * mass: the drift of the mean density over 1000 steps in a periodic box, worst of three seeds, no larger than twice the exact kernels' (+ 2e-8).
 The bit-exact kernels stay the default and the anchor of every other test."""
 import os
 
@@ -107,16 +107,22 @@ def test_native_arithmetic_against_the_real_reference(luw, case):
 
 
 def test_native_arithmetic_conserves_mass_like_the_exact_kernels(luw):
+    # periodic box, no boundaries: the mean density moves by the rounding of the stored codes alone -- a random walk of either sign, 0.2-6e-8 after 1000 steps
+    # for both arithmetics (tools/native_mass_drift.py, profiles/r05_native_raw_codec.txt).  Three seeds, worst case each: a bias in the native formulas (a
+    # coefficient that does not cancel) would show as a drift of one sign growing with the step count.
     Nx, Ny, Nz = 256, 64, 64
-    st = synthetic_state(Nx, Ny, Nz, seed=5, solids=False, shell=None)
-    drift = []
+    worst = {}
     for nat in (False, True):
-        g = luw.LBM(Nx, Ny, Nz, 1e-4, fp16c=True, native_arith=nat)
-        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
-        g.run(1); g.rho.read_from_device(); m0 = float(g.rho.data.astype(np.float64).mean())
-        g.run(200); g.rho.read_from_device(); drift.append(float(g.rho.data.astype(np.float64).mean()) - m0)
-        g.close()
-    assert abs(drift[1]) <= abs(drift[0]) + 1e-8, drift
+        drift = []
+        for seed in (5, 6, 7):
+            st = synthetic_state(Nx, Ny, Nz, seed=seed, solids=False, shell=None)
+            g = luw.LBM(Nx, Ny, Nz, 1e-4, fp16c=True, native_arith=nat)
+            g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+            g.run(1); g.rho.read_from_device(); m0 = float(g.rho.data.astype(np.float64).mean())
+            g.run(1000); g.rho.read_from_device(); drift.append(float(g.rho.data.astype(np.float64).mean()) - m0)
+            g.close()
+        worst[nat] = max(abs(d) for d in drift)
+    assert worst[True] <= 2.0 * worst[False] + 2e-8 and worst[True] < 1.5e-7, worst
 
 
 def test_native_arithmetic_is_ignored_for_fp32_and_in_sampled_steps(luw):
