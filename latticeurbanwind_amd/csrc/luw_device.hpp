@@ -725,7 +725,7 @@ template<int FORCE=PAIR_FORCE_ANY> __device__ __forceinline__ void collide_cell_
 //     18 + 15 operations instead of 18 + 36, and the nineteen equilibria are formed only once the rate is known (no f_eq registers across Q);
 //   * Guo terms with the constants folded: c_tau w9_i [(c_i.F)(c_i.u + 1/3) - u.F / 3] = fma(c_i.H, 3 c_i.u + 1, uH) with H = c_tau w9_i F / 3, the
 //     3 c.u of the equilibrium reused, added inside the relaxation's own fma;
-//   * free contraction (a*b+c as one fma), v_med3 for the +-c clamp, -2 omega from the host.
+//   * fused multiply-adds wherever a product feeds a sum (written out: see below), v_med3 for the +-c clamp, -2 omega from the host.
 // TYPE_E lanes in every FORCE mode: decoded as f = 0 by the caller, relaxed with w = 1 and c_tau = 0 -> f_eq (collide_cell_pk, E_BY_RATE).
 // Values differ from the exact kernels' in the last bits of each operation; with FP16C storage (2^-12 relative per stored value) those differences
 // surface as different roundings of single populations, exactly like the reference's own arithmetic against the restatement's.
@@ -745,10 +745,16 @@ __device__ __forceinline__ f32x2 sum_and_negated_difference(const f32x2 a) { // 
 	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
 	return r;
 }
-template<int FORCE=PAIR_FORCE_ANY, bool RAW=false> __device__ __forceinline__ void collide_cell_pk_native(const KParams& p, const uint32_t n,
-	const uint8_t flagsn, const bool may_force, float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u, const float* __restrict__ F,
-	float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr, const ForceRefs* refs = nullptr, const ForceRefs* own = nullptr) {
-	#pragma clang fp contract(fast)
+// Every fused multiply-add is written out (the translation unit is compiled with -ffp-contract=off): the operation sequence is the same in every
+// instantiation and kernel that inlines this function, so a cell gets the same bits whether its row runs in the pair or in the one-cell kernel, in a whole
+// lattice or in a domain of a decomposed one (tests/test_gpu_native_arith.py::test_native_arithmetic_gives_a_cell_the_same_values_in_either_kernel).
+// on_fields(rho, ux, uy, uz): called once the cell's density and (force-shifted, clamped) velocity are final, i.e. BEFORE the relaxation -- the caller stores
+// the fields there (last step of a run) instead of keeping four registers alive through the relaxation loop.
+struct NoFieldSink { __device__ __forceinline__ void operator()(float, float, float, float) const {} };
+template<int FORCE=PAIR_FORCE_ANY, bool RAW=false, typename FieldSink=NoFieldSink> __device__ __forceinline__ void collide_cell_pk_native(const KParams& p,
+	const uint32_t n, const uint8_t flagsn, const bool may_force, float& f0, f32x2* fp, const float* __restrict__ rho, const float* __restrict__ u,
+	const float* __restrict__ F, float& rhon, float& uxn, float& uyn, float& uzn, float* u_before_force = nullptr, const ForceRefs* refs = nullptr,
+	const ForceRefs* own = nullptr, const FieldSink on_fields = FieldSink{}) {
 	constexpr float UP = RAW ? 0x1p+112f : 1.0f, DOWN = RAW ? 0x1p-112f : 1.0f;
 	const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 	const bool wave_has_E = __ballot(is_E)!=0ull;
@@ -761,7 +767,7 @@ template<int FORCE=PAIR_FORCE_ANY, bool RAW=false> __device__ __forceinline__ vo
 		for(int k=0; k<9; k++) sd[k] = sum_and_negated_difference(fp[k]);
 		const f32x2 p36 = sd[3]+sd[6], p47 = sd[4]+sd[7], p58 = sd[5]+sd[8];
 		const float sum = ((f0+sd[0].x)+(sd[1].x+sd[2].x))+((p36.x+p47.x)+p58.x);
-		rhon = sum*UP+1.0f;
+		rhon = fmaf(sum, UP, 1.0f);
 		nmx = (sd[0].y+p36.y)+p47.y;
 		nmy = (sd[1].y+(sd[3].y-sd[6].y))+p58.y;
 		nmz = (sd[2].y+(sd[4].y-sd[7].y))+(sd[5].y-sd[8].y);
@@ -782,69 +788,71 @@ template<int FORCE=PAIR_FORCE_ANY, bool RAW=false> __device__ __forceinline__ vo
 	if(forced) {
 		fxn = p.fx; fyn = p.fy; fzn = p.fz;
 		if(p.coriolis) { // -2 rho omega x u
-			fxn += rhon*(p.m2omy*uzn-p.m2omz*uyn);
-			fyn += rhon*(p.m2omz*uxn-p.m2omx*uzn);
-			fzn += rhon*(p.m2omx*uyn-p.m2omy*uxn);
+			fxn = fmaf(rhon, fmaf(p.m2omy, uzn, -(p.m2omz*uyn)), fxn);
+			fyn = fmaf(rhon, fmaf(p.m2omz, uxn, -(p.m2omx*uzn)), fyn);
+			fzn = fmaf(rhon, fmaf(p.m2omx, uyn, -(p.m2omy*uxn)), fzn);
 		}
 		if constexpr(FORCE==PAIR_FORCE_ANY) {
 			if(refs) { // zone references fetched ahead (fetch_force_refs): nudging towards the nearest owned face, top sponge
 				if(refs->zn) {
-					const float wr = refs->wb*p.buffer_inv_tau*rhon;
-					fxn += wr*(refs->tu[0]-uxn);
-					fyn += wr*(refs->tu[1]-uyn);
-					if(p.nudge_vertical==1u) fzn += wr*(refs->tu[2]-uzn);
+					const float wr = (refs->wb*p.buffer_inv_tau)*rhon;
+					fxn = fmaf(wr, refs->tu[0]-uxn, fxn);
+					fyn = fmaf(wr, refs->tu[1]-uyn, fyn);
+					if(p.nudge_vertical==1u) fzn = fmaf(wr, refs->tu[2]-uzn, fzn);
 				}
 				if(refs->zs) {
 					const float sr = refs->sg*rhon;
-					fxn += sr*(refs->su[0]-uxn);
-					fyn += sr*(refs->su[1]-uyn);
-					fzn += sr*(refs->su[2]-uzn);
+					fxn = fmaf(sr, refs->su[0]-uxn, fxn);
+					fyn = fmaf(sr, refs->su[1]-uyn, fyn);
+					fzn = fmaf(sr, refs->su[2]-uzn, fzn);
 				}
 			}
 			if(p.has_F) { fxn += F[n]; fyn += F[(size_t)p.Np+n]; fzn += F[2ull*p.Np+n]; }
 		}
 		const float rho2 = 0.5f*r;
-		uxn += fxn*rho2; uyn += fyn*rho2; uzn += fzn*rho2;
+		uxn = fmaf(fxn, rho2, uxn); uyn = fmaf(fyn, rho2, uyn); uzn = fmaf(fzn, rho2, uzn);
 	}
 	uxn = __builtin_amdgcn_fmed3f(uxn, -DEF_C, DEF_C);
 	uyn = __builtin_amdgcn_fmed3f(uyn, -DEF_C, DEF_C);
 	uzn = __builtin_amdgcn_fmed3f(uzn, -DEF_C, DEF_C);
+	on_fields(rhon, uxn, uyn, uzn);
 	// equilibrium ingredients (FX/kernel.cpp:1016-1055): f_eq(2k+1 / 2k+2) = rho w_k (A_k / 2 +- v_k) + (rho - 1) w_k, v_k = 3 c_k.u, A_k = v_k^2 - 3 u^2
-	const float c3 = -3.0f*(uxn*uxn+uyn*uyn+uzn*uzn);
+	const float c3 = -3.0f*fmaf(uzn, uzn, fmaf(uyn, uyn, uxn*uxn));
 	const float ux3 = 3.0f*uxn, uy3 = 3.0f*uyn, uz3 = 3.0f*uzn;
 	const float v[9] = { ux3, uy3, uz3, ux3+uy3, ux3+uz3, uy3+uz3, ux3-uy3, ux3-uz3, uy3-uz3 };
 	const float rhom1 = rhon-1.0f;
 	const float rhos = DEF_WS*rhon, rhoe = DEF_WE*rhon, rhom1s = DEF_WS*rhom1, rhom1e = DEF_WE*rhom1;
 	float A[9];
 	#pragma unroll
-	for(int k=0; k<9; k++) A[k] = v[k]*v[k]+c3;
+	for(int k=0; k<9; k++) A[k] = fmaf(v[k], v[k], c3);
 	float w = p.w;
 	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737, from the non-equilibrium pair sums n_(2k+1) + n_(2k+2) = s_k - (rho w_k A_k + 2 (rho - 1) w_k)
 		const float rm2s = 2.0f*rhom1s, rm2e = 2.0f*rhom1e;
 		float sn[9];
 		#pragma unroll
-		for(int k=0; k<9; k++) sn[k] = sd[k].x*UP-((k<3 ? rhos : rhoe)*A[k]+(k<3 ? rm2s : rm2e));
+		for(int k=0; k<9; k++) sn[k] = fmaf(sd[k].x, UP, -fmaf(k<3 ? rhos : rhoe, A[k], k<3 ? rm2s : rm2e));
 		const float Hxx = (sn[0]+(sn[3]+sn[4]))+(sn[6]+sn[7]), Hyy = (sn[1]+(sn[3]+sn[5]))+(sn[6]+sn[8]), Hzz = (sn[2]+(sn[4]+sn[5]))+(sn[7]+sn[8]);
 		const float Hxy = sn[3]-sn[6], Hxz = sn[4]-sn[7], Hyz = sn[5]-sn[8];
-		const float Q = (Hxx*Hxx+Hyy*Hyy+Hzz*Hzz)+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
+		const float Q = fmaf(2.0f, fmaf(Hyz, Hyz, fmaf(Hxz, Hxz, Hxy*Hxy)), fmaf(Hzz, Hzz, fmaf(Hyy, Hyy, Hxx*Hxx)));
 		const float sq = 0.76421222f*__builtin_amdgcn_sqrtf(Q);
-		w = __builtin_amdgcn_rcpf(0.5f*__builtin_amdgcn_sqrtf(sq*r+p.tau0sq)+p.half_tau0);
+		w = __builtin_amdgcn_rcpf(fmaf(0.5f, __builtin_amdgcn_sqrtf(fmaf(sq, r, p.tau0sq)), p.half_tau0));
 	}
-	float c_tau = 1.0f-0.5f*w;
+	float c_tau = fmaf(-0.5f, w, 1.0f);
 	if(wave_has_E) { w = is_E ? 1.0f : w; c_tau = is_E ? 0.0f : c_tau; }
 	const float omw = 1.0f-w;
 	// relaxation with the rate folded into the equilibrium's coefficients: w f_eq(+-) = W (A / 2 +- v) + M, W = w rho w_k, M = w (rho - 1) w_k (RAW: times 2^-112)
 	const float wd = w*DOWN;
 	const float Ws = wd*rhos, We = wd*rhoe, Ms = wd*rhom1s, Me = wd*rhom1e;
+	const float weq0 = wd*(DEF_W0*fmaf(rhon, 0.5f*c3, rhom1));      // w f_eq of the rest population
 	if(forced) {
 		// c_tau Fin_i = fma(+-c.H, +-v + 1, uH): H = c_tau w9 F / 3 (w9 = 1/2 axis, 1/4 diagonal), uH = -c_tau w9 (u.F) / 3; Fin_0 = -c_tau (u.F); the constant
 		// part uH joins M
 		const float cs = (c_tau*DOWN)*0.16666667f;
 		const float hx = cs*fxn, hy = cs*fyn, hz = cs*fzn;
-		const float dots = cs*(uxn*fxn+uyn*fyn+uzn*fzn);           // = -uH of the axis pairs
+		const float dots = cs*fmaf(uzn, fzn, fmaf(uyn, fyn, uxn*fxn));    // = -uH of the axis pairs
 		const float ex = 0.5f*hx, ey = 0.5f*hy, ez = 0.5f*hz;
-		const float Mds = Ms-dots, Mde = Me-0.5f*dots;
-		f0 = omw*f0+(wd*(DEF_W0*(rhon*(0.5f*c3)+rhom1))-6.0f*dots);
+		const float Mds = Ms-dots, Mde = fmaf(-0.5f, dots, Me);
+		f0 = fmaf(omw, f0, fmaf(-6.0f, dots, weq0));
 		// uniform-force instantiation (everything in registers, 96 of them for 5 waves): the six diagonal 3 c.u are formed AGAIN here instead of living from the
 		// equilibrium ingredients on -- six additions for six registers, without which the kernel spills (the empty asm keeps the compiler from reusing them)
 		float vx = ux3, vy = uy3, vz = uz3;
@@ -860,7 +868,7 @@ template<int FORCE=PAIR_FORCE_ANY, bool RAW=false> __device__ __forceinline__ vo
 			fp[k] = __builtin_elementwise_fma(splat2(omw), fp[k], __builtin_elementwise_fma(splat2(k<3 ? Ws : We), in, fin));
 		}
 	} else {
-		f0 = omw*f0+wd*(DEF_W0*(rhon*(0.5f*c3)+rhom1));
+		f0 = fmaf(omw, f0, weq0);
 		#pragma unroll
 		for(int k=0; k<9; k++) {
 			const f32x2 in = __builtin_elementwise_fma(splat2(0.5f), splat2(A[k]), pm2(v[k]));

@@ -210,15 +210,21 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		}
 		return;
 	}
+	// RAW (native arithmetic without the thermal lattice): the populations stay scaled by 2^-112 from decode to encode, exactly as in the pair kernel
+	// (collide_cell_pk_native<.., RAW>): a cell gets the same values whichever of the two kernels its row takes
+	constexpr bool RAW = NATIVE && MODE==0;
+	auto decode = [](const T v) {
+		if constexpr(RAW) return __uint_as_float(((uint32_t)(int32_t)(int16_t)v<<12)&0x87FFF000u); else return ddf_decode<T>(v);
+	};
 	float f[19];
-	f[0] = ddf_decode<T>(ldo<(NT!=0)>(fi, a.own()));
+	f[0] = decode(ldo<(NT!=0)>(fi, a.own()));
 	static_for_pairs([&](auto ic) {
 		constexpr int i = decltype(ic)::value;
 		constexpr bool shifted = i==1||i==7||i==9||i==13||i==15;
-		f[i  ] = ddf_decode<T>(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
-		f[i+1] = ddf_decode<T>(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
+		f[i  ] = decode(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
+		f[i+1] = decode(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
 	});
-	if constexpr(XFACE) { if((xin_p||xin_m)&&(x==1u||x==p.Nx-2u)) xface_in([&](const int k, const T v) { f[k] = ddf_decode<T>(v); }); }
+	if constexpr(XFACE) { if((xin_p||xin_m)&&(x==1u||x==p.Nx-2u)) xface_in([&](const int k, const T v) { f[k] = decode(v); }); }
 	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
@@ -232,7 +238,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 			#pragma unroll
 			for(int k=0; k<9; k++) { const f32x2 t = { is_E ? 0.0f : f[2*k+1], is_E ? 0.0f : f[2*k+2] }; fp[k] = t; }
 			float f0 = is_E ? 0.0f : f[0], u0[3];
-			collide_cell_pk_native<PAIR_FORCE_ANY>(p, n, flagsn, may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, MODE==4 ? u0 : nullptr, &refs, &refs);
+			collide_cell_pk_native<PAIR_FORCE_ANY, RAW>(p, n, flagsn, may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, MODE==4 ? u0 : nullptr, &refs, &refs);
 			f[0] = f0;
 			#pragma unroll
 			for(int k=0; k<9; k++) { f[2*k+1] = fp[k].x; f[2*k+2] = fp[k].y; }
@@ -265,6 +271,9 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 			uint32_t cg[7];
 			fp16c_encode19_hi_rtz_final(f, c, g, cg);
 			thermal_store<T, PARITY>(p, n, a.jx(), a.jy(), a.jz(), gi, [&](const int i) { return (T)(cg[i]>>16); });
+		} else if constexpr(RAW) {
+			#pragma unroll
+			for(int i=0; i<19; i++) c[i] = fp16c_code_hi_of_scaled(f[i]);
 		} else fp16c_encode19_hi_rtz_final(f, c);
 		sto<(NT!=0)>(fi, a.own(), (T)(c[0]>>16));
 		static_for_pairs([&](auto ic) {
@@ -572,12 +581,20 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		if(MODE!=1&&proc[c]) { // MODE 1: measurement-only, no collision (every cell passes through)
 			float rhon, uxn, uyn, uzn;
 			[[maybe_unused]] float u0[3];
+			// (native: rho / u of the last step of a run are stored from inside the collision, as soon as they are final)
+			auto store_fields = [&](const float r_, const float ux_, const float uy_, const float uz_) {
+				if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
+					uint32_t nw = n+(uint32_t)c;
+					asm volatile("" : "+v"(nw));
+					rho[nw] = r_; u[nw] = ux_; u[Np+nw] = uy_; u[2ull*Np+nw] = uz_;
+				}
+			};
 			if constexpr(NATIVE) collide_cell_pk_native<FORCE, RAW>(p, n+c, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr,
-				PRE ? &refs[c] : nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
+				PRE ? &refs[c] : nullptr, PRE ? &refs[c] : OWN ? &own : nullptr, store_fields);
 			else collide_cell_pk<FORCE>(p, n+c, x+c, y, z, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr, PRE ? &refs[c]
 				: nullptr, PRE ? &refs[c] : OWN ? &own : nullptr);
 			if constexpr(THERMAL) thermal_cell(p, n+c, x+c, y, z, fl[c], u0[0], u0[1], u0[2], Tf, g, write_fields!=0);
-			if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
+			if(!NATIVE && write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 				// (the index passes through an empty asm: its 64-bit address arithmetic is then done HERE, in the block of the last step of a run, instead of
 				// being
 				// hoisted in front of both collisions, where the pair of registers it occupied made the uniform-force kernel spill to scratch at 96 VGPRs)
