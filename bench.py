@@ -9,7 +9,7 @@ voxelised building cluster (SURVEY 8d closed-form box array), bounce-back, Smago
 other five outer faces TYPE_E with a log-law inflow profile, interior initialised with the same profile, rho=1.  After the
 headline a handful of `secondary` blocks are measured, each in a fresh child process (DEFAULT_BLOCKS: configs[1], the north
 star's 1024^3 grid, C3 with FP16C DDFs / Coriolis / the thermal lattice, the undivided urban tile and one rank of the literal
-n_gpu=[4,2,1] cut of configs[3] / configs[4]); --all-blocks adds the rest with their native-arithmetic and peer-loopback twins,
+n_gpu=[4,2,1] cut of configs[3] / configs[4]); --all-blocks adds the rest with their exact-arithmetic and peer-loopback twins,
 --no-secondary skips them, --workload picks another headline.
 N > 1 (the driver's SCALE runs): the urban tile of BASELINE configs[3] weak-scaled at 512^3 cells per GPU (8 GPUs:
 2048x1024x512) -- building array, buffer nudging and top sponge with the deck defaults (160 m / 300 s, 200 m / 120 s), cut
@@ -97,9 +97,9 @@ SINGLE_BLOCKS = {"c2_f32": ("c2", "f32", False, False, False), "c2_fp16c": ("c2"
                  "tile512_urban_f32": ("tile512", "f32", False, False, True), "tile512_urban_fp16c_coriolis": ("tile512", "fp16c", True, False, True)}
 
 
-# FP16C blocks that are also measured with the native-arithmetic kernels (the forced / thermal / zone kernels the exact arithmetic costs most, and the
-# plain one as the reference point)
-NATIVE_TWINS = ("c3_fp16c", "c3_fp16c_coriolis", "c3_fp16c_thermal", "tile512_urban_fp16c_coriolis", "c5_rank_4x2x1_fp16c_coriolis")
+# FP16C blocks that --all-blocks also measures with the bit-exact kernels (`--arith exact`: the forced / thermal / zone kernels the exact arithmetic costs
+# most, and the plain one as the reference point)
+EXACT_TWINS = ("c3_fp16c", "c3_fp16c_coriolis", "c3_fp16c_thermal", "tile512_urban_fp16c_coriolis", "c5_rank_4x2x1_fp16c_coriolis")
 
 
 def run_single_block(luw, capi, device, key, native=False):
@@ -114,7 +114,8 @@ def run_single_block(luw, capi, device, key, native=False):
 
 
 RANK_SHAPE_BLOCKS = {"c4_rank_4x2x1_f32": dict(fp16c=False, coriolis=False, D=(4, 2, 1), rank=0),       # the cut `--gpus 8` times: BASELINE's literal n_gpu
-                     "c4_rank_1x4x2_f32": dict(fp16c=False, coriolis=False, D=(1, 4, 2), rank=7),       # the same tile with x kept whole (2048x258x258 per rank)
+                     # the same tile with x kept whole (2048x258x258 per rank)
+                     "c4_rank_1x4x2_f32": dict(fp16c=False, coriolis=False, D=(1, 4, 2), rank=7),
                      "c5_rank_4x2x1_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(4, 2, 1), rank=0),
                      "c5_rank_1x4x2_fp16c_coriolis": dict(fp16c=True, coriolis=True, D=(1, 4, 2), rank=7)}
 
@@ -231,9 +232,10 @@ def main():
         help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 4 2 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "pair"], default="auto")
-    ap.add_argument("--arith", choices=["exact", "native"], default="exact",
-        help="FP16C collision arithmetic: exact = the bit-exact kernels (default, equal to the CPU oracle), native = LUW_OPT_NATIVE_ARITH (v_rcp / v_sqrt, "
-             "free contraction; within the tolerance gates of tests/test_gpu_native_arith.py)")
+    ap.add_argument("--arith", choices=["native", "exact"], default="native",
+        help="FP16C collision arithmetic: native = LUW_OPT_NATIVE_ARITH (default, as in the deck driver: v_rcp / v_sqrt, fused multiply-adds -- as close to "
+            "the "
+             "real reference's fields as the exact kernels are, tests/test_gpu_native_arith.py), exact = bit-equal to the CPU oracle.  FP32 DDFs: no effect")
     ap.add_argument("--buildings", action="store_true",
         help="add the configs[2] solid mask to a workload that has none (c3 and the N > 1 tile always carry it)")
     ap.add_argument("--no-buildings", action="store_true", help="N > 1: plain channel tile without the building array / nudging / sponge")
@@ -242,7 +244,8 @@ def main():
     ap.add_argument("--urban", action="store_true", help="N = 1: add the urban tile's buffer nudging + top sponge (deck defaults) to the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline measurement (profiling runs)")
-    ap.add_argument("--all-blocks", action="store_true", help="N = 1: every secondary block (not only DEFAULT_BLOCKS), FP16C blocks also with native arithmetic, "
+    ap.add_argument("--all-blocks", action="store_true",
+        help="N = 1: every secondary block (not only DEFAULT_BLOCKS), FP16C blocks also with exact arithmetic, "
         "rank shapes also with the peer-loopback transport: 25 child processes, about two minutes")
     ap.add_argument("--share-device", type=int, default=None, help="test aid: all ranks use this one GPU, halos through gloo + host staging (plumbing check of "
         "the N > 1 path on a 1-GPU box; the line is labelled, never a multi-GPU result)")
@@ -297,7 +300,7 @@ def main():
         return
     if args.secondary_block:
         try:
-            blk = run_single_block(luw, capi, local_rank, args.secondary_block, native=args.arith == "native")
+            blk = run_single_block(luw, capi, local_rank, args.secondary_block, native=args.arith != "exact")
         except Exception as e:
             blk = {"error": str(e)[:300]}
         sys.stdout.flush(); os.dup2(saved_stdout, 1)
@@ -305,7 +308,7 @@ def main():
         os.dup2(2, 1)
         return
     if args.rank_shape_block:
-        blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, native=args.arith == "native",
+        blk = run_rank_shape(luw, torch, capi.KERNEL_AUTO, local_rank, steps=args.steps, warmup=args.warmup, native=args.arith != "exact",
             transport=os.environ.get("BENCH_RANK_TRANSPORT", args.rank_transport), **RANK_SHAPE_BLOCKS[args.rank_shape_block])
         import torch.distributed as dist
         if dist.is_initialized(): dist.destroy_process_group()
@@ -318,7 +321,7 @@ def main():
         if args.size: size = tuple(args.size)
         buildings = buildings or args.buildings
         head = run_single(luw, kern, local_rank, size, args.dtype, buildings, args.steps, args.warmup, args.coriolis, args.thermal, args.every_step_fields,
-            args.kernel, urban=args.urban, native=args.arith == "native")
+            args.kernel, urban=args.urban, native=args.arith != "exact")
         out = {
             "metric": METRIC, "value": head["value"], "unit": "MLUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
@@ -351,13 +354,13 @@ def main():
                 sys.stderr.write("bench.py: secondary block %s: %s\n" % (key, block_note(sec[key]))); sys.stderr.flush()
                 if not args.all_blocks or "error" in sec[key]:
                     continue
-                # FP16C blocks: the same block once more with the native-arithmetic kernels (LUW_OPT_NATIVE_ARITH), again in a fresh process; the block's own
-                # numbers are the bit-exact kernels' ("arith": "exact"), the twin sits under "native"
-                if key in NATIVE_TWINS:
-                    nat = child_block(flag_of(key), key, local_rank, "--arith", "native")
-                    sec[key]["native"] = {k: nat[k] for k in ("value", "ms_per_step", "arith", "kernel_ms", "shell_ms", "exchange_ms", "error") if k in nat}
+                # FP16C blocks: the same block once more with the bit-exact kernels, again in a fresh process; the block's own numbers are the default
+                # arithmetic's ("arith": "native"), the twin sits under "exact"
+                if key in EXACT_TWINS:
+                    nat = child_block(flag_of(key), key, local_rank, "--arith", "exact")
+                    sec[key]["exact"] = {k: nat[k] for k in ("value", "ms_per_step", "arith", "kernel_ms", "shell_ms", "exchange_ms", "error") if k in nat}
                     if "roofline" in nat:
-                        sec[key]["native"]["roofline"] = {k: nat["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "kernel_frac")
+                        sec[key]["exact"]["roofline"] = {k: nat["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "kernel_frac")
                             if k in nat["roofline"]}
                 # rank shapes: the same rank once more with its faces written in place (the one-process host's peer stores) instead of RCCL self send / receive
                 if key in RANK_SHAPE_BLOCKS:

@@ -48,7 +48,9 @@ def block_summary(b):
     r = b.get("roofline") or {}
     if r.get("frac") is not None:
         s["frac"] = r["frac"]
-    for twin, name in (("native", "native_frac"), ("peer_loopback", "peer_frac")):
+    if "fp16c" in str(b.get("dtype", "")):
+        s["arith"] = b.get("arith")
+    for twin, name in (("exact", "exact_frac"), ("peer_loopback", "peer_frac")):
         if isinstance(b.get(twin), dict):
             s[name] = "error" if "error" in b[twin] else (b[twin].get("roofline") or {}).get("frac")
     return s
@@ -73,9 +75,10 @@ def parity_summary(p):
         out["fp32_within_tolerance"] = p["fp32"]["within_tolerance"]
     if "within_tolerance_at_K64" in sh:
         out["fp16c_within_tolerance_at_K64"] = sh["within_tolerance_at_K64"]
-    for k in ("reference_self_distance", "c1_planes"):
-        if k in p:
-            out[k] = p[k]
+    if isinstance(p.get("reference_self_distance"), dict):     # the reference's FP32 build against its own FP16C build, K = 64
+        out["reference_self_distance_K64"] = {c: v.get("K64") for c, v in p["reference_self_distance"].items() if isinstance(v, dict)}
+    if "c1_planes" in p:
+        out["c1_planes"] = p["c1_planes"]
     return out
 
 
@@ -83,7 +86,8 @@ def compact_single(full):
     out = {k: full.get(k) for k in CONTRACT_KEYS}
     out.update(pick(full, "dtype", "data"))
     cfg = full.get("config", {})
-    out["config"] = dict(pick(cfg, "global_lattice", "n_gpu", "bytes_per_lup", "arith", "kernel", "solid_fraction"), workload=clip(cfg.get("workload", ""), 260))
+    out["config"] = dict(pick(cfg, "global_lattice", "n_gpu", "bytes_per_lup", "arith", "kernel", "solid_fraction"),
+        workload=clip(cfg.get("workload", ""), 260))
     roof = full.get("roofline", {})
     out["roofline"] = dict(pick(roof, "bound", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_launch", "whole_job_frac"),
         traffic=roof.get("traffic"))
@@ -91,7 +95,8 @@ def compact_single(full):
         out["roofline"]["traffic_source"] = clip(roof["traffic_source"], 120)
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
-        out["cpu_baseline"] = dict(pick(cb, "value", "unit", "cores", "kind", "cpu_model", "dram_GBps", "copy_bandwidth_GBps"), sample=clip(cb.get("sample", ""), 160))
+        out["cpu_baseline"] = dict(pick(cb, "value", "unit", "cores", "kind", "cpu_model", "dram_GBps", "copy_bandwidth_GBps"),
+            sample=clip(cb.get("sample", ""), 160))
     if "parity" in full:
         out["parity"] = parity_summary(full["parity"])
     dev = full.get("device", {})

@@ -214,7 +214,8 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
         if any(g % d for g, d in zip(gN, D)):
             raise SystemExit("bench.py: lattice %s is not divisible by n_gpu %s" % (gN, D))
         kw = dict(buffer_nudging=nud, top_sponge=spg) if urban else {}
-        sim = DomainDecomposedLBM(gN, D, NU, fp16c=fp16c, kernel=kern, device=local_rank, **kw)   # RCCL connections to the neighbours first, then the lattice
+        # RCCL connections to the neighbours first, then the lattice (FP16C: --arith, native by default; the self-check above runs the bit-exact kernels)
+        sim = DomainDecomposedLBM(gN, D, NU, fp16c=fp16c, kernel=kern, device=local_rank, native_arith=fp16c and args.arith != "exact", **kw)
         try:
             ox, oy, oz = sim.global_offset
             lb = sim.backend.lbm
@@ -270,6 +271,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             "metric": METRIC, "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "data": "synthetic",
+            **({"arith": "exact" if args.arith == "exact" else "native"} if fp16c else {}),
             "config": {"workload": "%dx%dx%d D3Q19 %s (8 GPUs: BASELINE configs[3]) cut as n_gpu=%s, %dx%dx%d = %.0f M cells per GPU (the N = 1 line runs "
                 "configs[2], 1024x1024x256 = 268 M cells on its GPU; its secondary block tile512_urban is this tile's N = 1 point), log-law profile inflow on "
                 "TYPE_E faces, solid ground, SRT+Smagorinsky LES, %s DDFs%s, rho/u written by the last step only"
@@ -370,7 +372,8 @@ def run_group_host(args, D, gN, devices):
     for label in GROUP_HOST_VARIANTS:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--group-host-child", label, "--devices", ",".join(str(d) for d in devices), "--n-gpu",
             *(str(d) for d in D),
-               "--global-lattice", *(str(g) for g in gN), "--dtype", args.dtype, "--kernel", args.kernel, "--steps", str(min(args.steps, 60)), "--warmup",
+               "--global-lattice", *(str(g) for g in gN), "--dtype", args.dtype, "--arith", args.arith, "--kernel", args.kernel, "--steps",
+                   str(min(args.steps, 60)), "--warmup",
                    str(min(args.warmup, 5))]
         cmd += (["--coriolis"] if args.coriolis else []) + (["--no-buildings"] if args.no_buildings else []) + (["--no-parity"] if args.no_parity else [])
         t0 = time.perf_counter()
@@ -414,7 +417,7 @@ def group_host_child(args, luw, capi, kern, fp16c):
         if not blk["parity"]["equal"]:
             return blk                                           # a host that computes something else is not timed
     kw = dict(buffer_nudging=nud, top_sponge=spg) if urban else {}
-    g = luw.LBMGroup(*gN, *D, NU, fp16c=fp16c, devices=devices, kernel=kern, global_arrays=False, **kw)
+    g = luw.LBMGroup(*gN, *D, NU, fp16c=fp16c, devices=devices, kernel=kern, global_arrays=False, native_arith=fp16c and args.arith != "exact", **kw)
     try:
         def fill(d):
             lN, off, _ = g.domain_info(d)

@@ -263,7 +263,8 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 	void* const ip = (to_faces&1u) ? const_cast<void*>(s->xin_p) : nullptr; void* const im = (to_faces&2u) ? const_cast<void*>(s->xin_m) : nullptr;
 	if(s->ddf_bytes==2u) {
 		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)ip, (uint16_t*)im);
-		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)nullptr, (uint16_t*)nullptr);
+		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)nullptr,
+			(uint16_t*)nullptr);
 	} else {
 		if(insert) hipLaunchKernelGGL((k_edges<float, true>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)ip, (float*)im);
 		else hipLaunchKernelGGL((k_edges<float, false>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)nullptr, (float*)nullptr);

@@ -826,7 +826,8 @@ template<int FORCE=PAIR_FORCE_ANY, bool RAW=false, typename FieldSink=NoFieldSin
 	#pragma unroll
 	for(int k=0; k<9; k++) A[k] = fmaf(v[k], v[k], c3);
 	float w = p.w;
-	if(p.subgrid) { // Smagorinsky-Lilly, FX/kernel.cpp:1723-1737, from the non-equilibrium pair sums n_(2k+1) + n_(2k+2) = s_k - (rho w_k A_k + 2 (rho - 1) w_k)
+	// Smagorinsky-Lilly, FX/kernel.cpp:1723-1737, from the non-equilibrium pair sums n_(2k+1) + n_(2k+2) = s_k - (rho w_k A_k + 2 (rho - 1) w_k)
+	if(p.subgrid) {
 		const float rm2s = 2.0f*rhom1s, rm2e = 2.0f*rhom1e;
 		float sn[9];
 		#pragma unroll
@@ -840,7 +841,8 @@ template<int FORCE=PAIR_FORCE_ANY, bool RAW=false, typename FieldSink=NoFieldSin
 	float c_tau = fmaf(-0.5f, w, 1.0f);
 	if(wave_has_E) { w = is_E ? 1.0f : w; c_tau = is_E ? 0.0f : c_tau; }
 	const float omw = 1.0f-w;
-	// relaxation with the rate folded into the equilibrium's coefficients: w f_eq(+-) = W (A / 2 +- v) + M, W = w rho w_k, M = w (rho - 1) w_k (RAW: times 2^-112)
+	// relaxation with the rate folded into the equilibrium's coefficients: w f_eq(+-) = W (A / 2 +- v) + M, W = w rho w_k, M = w (rho - 1) w_k (RAW: times
+	// 2^-112)
 	const float wd = w*DOWN;
 	const float Ws = wd*rhos, We = wd*rhoe, Ms = wd*rhom1s, Me = wd*rhom1e;
 	const float weq0 = wd*(DEF_W0*fmaf(rhon, 0.5f*c3, rhom1));      // w f_eq of the rest population
@@ -853,7 +855,8 @@ template<int FORCE=PAIR_FORCE_ANY, bool RAW=false, typename FieldSink=NoFieldSin
 		const float ex = 0.5f*hx, ey = 0.5f*hy, ez = 0.5f*hz;
 		const float Mds = Ms-dots, Mde = fmaf(-0.5f, dots, Me);
 		f0 = fmaf(omw, f0, fmaf(-6.0f, dots, weq0));
-		// uniform-force instantiation (everything in registers, 96 of them for 5 waves): the six diagonal 3 c.u are formed AGAIN here instead of living from the
+		// uniform-force instantiation (everything in registers, 96 of them for 5 waves): the six diagonal 3 c.u are formed AGAIN here instead of living from
+		// the
 		// equilibrium ingredients on -- six additions for six registers, without which the kernel spills (the empty asm keeps the compiler from reusing them)
 		float vx = ux3, vy = uy3, vz = uz3;
 		if constexpr(FORCE==PAIR_FORCE_UNIFORM) asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz));

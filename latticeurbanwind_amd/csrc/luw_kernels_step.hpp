@@ -416,7 +416,8 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 		uint16_t* __restrict__ gi = nullptr, float* __restrict__ Tf = nullptr, uint16_t* __restrict__ xf_p = nullptr, uint16_t* __restrict__ xf_m = nullptr,
 			const uint16_t* __restrict__ xin_p = nullptr, const uint16_t* __restrict__ xin_m = nullptr) {
 	static_assert(!(THERMAL&&STATS), "the thermal lattice keeps the separate statistics kernel");
-	static_assert(!XFACE||(!STATS&&MODE==0), "x-face output: plain steps");       // (with the thermal lattice: the D3Q19 faces; the D3Q7 faces keep their kernels)
+	// (with the thermal lattice: the D3Q19 faces; the D3Q7 faces keep their kernels)
+	static_assert(!XFACE||(!STATS&&MODE==0), "x-face output: plain steps");
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
 	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
 	constexpr bool OWN = LUW_PAIR_OWN_EARLY!=0 && !PRE;

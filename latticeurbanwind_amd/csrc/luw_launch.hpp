@@ -162,8 +162,10 @@ static const ScalarRow scalar_table[] = {
 	// x-split domains, boxes that hold the first / last owned x column: the same kernels with the x-face output (luw_set_x_face_buffers)
 	{ { 4u, 0, 2, true,  false, false, false, true }, scalar_instance<float, 0, 2, true, false, false, false, true>,  "FP32 + x-face output" },
 	{ { 4u, 0, 2, false, false, false, false, true }, scalar_instance<float, 0, 2, false, false, false, false, true>, "FP32, row addressing + x-face output" },
-	{ { 4u, 4, 2, true,  false, false, false, true }, scalar_instance<float, 4, 2, true, false, false, false, true>,  "FP32 + thermal lattice + x-face output" },
-	{ { 4u, 4, 2, false, false, false, false, true }, scalar_instance<float, 4, 2, false, false, false, false, true>, "FP32 + thermal, row addressing + x-face" },
+	{ { 4u, 4, 2, true,  false, false, false, true }, scalar_instance<float, 4, 2, true, false, false, false, true>,
+		"FP32 + thermal lattice + x-face output" },
+	{ { 4u, 4, 2, false, false, false, false, true }, scalar_instance<float, 4, 2, false, false, false, false, true>,
+		"FP32 + thermal, row addressing + x-face" },
 	{ { 2u, 0, 2, false, false, false, true }, scalar_instance<uint16_t, 0, 2, false, false, false, true>, "FP16C one-cell kernel, native arithmetic" },
 	{ { 2u, 4, 2, false, false, false, true }, scalar_instance<uint16_t, 4, 2, false, false, false, true>,
 		"FP16C one-cell kernel + thermal lattice, native arithmetic" },

@@ -114,7 +114,7 @@ struct luw_solver {
 	// x-face output of the step kernels (luw_set_x_face_buffers): buffers, and which of the two border columns the launches of step xf_t have covered
 	void* xf_p = nullptr; void* xf_m = nullptr; uint32_t xf_cover = 0u; uint64_t xf_t = ~0ull;
 	// x-face input (luw_set_x_face_inputs): receive buffers whose insert is pending, side by side (bit 0: the face that came from +x, for the last owned
-	// column; bit 1: from -x, for the first) -- xin_buf: still only in the buffer; xin_inplace: read there by a launch of step xin_for_t.  Whatever else needs a
+	// column; bit 1: from -x, for the first) -- xin_buf: still only in the buffer; xin_inplace: read there by a launch of step xin_for_t. Whatever else needs a
 	// side in the lattice has the insert kernel run for it first (xin_settle).
 	// Each side carries the step it is for and the time parity of its hand-over (a host may hand the two sides over at different moments of a step).
 	const void* xin_p = nullptr; const void* xin_m = nullptr; uint32_t xin_buf = 0u, xin_inplace = 0u, xin_odd[2] = { 0u, 0u }; bool xin_use = false;

@@ -13,8 +13,9 @@ static bool parse_command_line(const int argc, char** argv, Config& c) {
 	for(int i=2; i<argc; i++) {
 		const string a = argv[i];
 		if(a=="--ddf"&&i+1<argc) { const string v = argv[++i]; c.fp16c = v!="fp32"; }
-		// FP16C collision in the hardware's own arithmetic (LUW_OPT_NATIVE_ARITH); default: the bit-exact kernels
-		else if(a=="--arith"&&i+1<argc) { const string v = argv[++i]; c.native_arith = v=="native"; }
+		// FP16C collision arithmetic: native (default: the hardware's own division / square root and fused multiply-adds, LUW_OPT_NATIVE_ARITH -- what the
+		// reference's OpenCL build does, and as close to its fields as the bit-exact kernels are: DESIGN.md section 3) or exact (bit-equal to the CPU oracle)
+		else if(a=="--arith"&&i+1<argc) { const string v = argv[++i]; c.native_arith = v!="exact"; }
 		else if(a=="--device"&&i+1<argc) c.device = std::atoi(argv[++i]);
 		else if(a=="--dry-run") c.dry_run = true;
 		else if(a=="--sizing-only") { c.dry_run = true; c.sizing_only = true; } // stop after the derived numbers (no lattice-sized host arrays)

@@ -58,7 +58,8 @@ inline void Driver::print_parameters() const {
 		println("| Probes Window  | "+alignr(57u, w)+" |");
 	}
 	println("| DDF storage     | "+alignr(57u, c.fp16c ? string("FP16C (as the shipped reference build)") : string("FP32"))+" |");
-	if(c.fp16c&&c.native_arith) println("| Arithmetic      | "+alignr(57u, string("native (v_rcp / v_sqrt, free contraction; --arith exact)"))+" |");
+	if(c.fp16c) println("| Arithmetic      | "+alignr(57u, c.native_arith ? string("native (v_rcp / v_sqrt, fused multiply-adds; --arith exact)")
+		: string("exact (bit-equal to the CPU restatement; --arith native)"))+" |");
 }
 
 inline void Driver::size_lattice() { // FX/setup.cpp:3552-3568

@@ -14,7 +14,8 @@
 // inlet tables are built here (vk_inlet.hpp) and evaluated on the device before every step.
 // Decks with n_gpu = [Dx, Dy, Dz] run all Dx*Dy*Dz domains in THIS process, one HIP device each (like the reference's LBM object;
 // halos between the devices inside the library, luw_group_*).
-// Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build), --arith exact|native (FP16C),
+// Options after the deck path (the reference ignores extra args): --ddf fp32|fp16c (default fp16c = shipped build), --arith native|exact (FP16C; default
+// native),
 //   --device N (first device; domain d runs on N + d), --devices a,b,.. (explicit device per domain), --kernel auto|scalar|pair,
 //   --dry-run (host stage only, no GPU), --sizing-only (stop after grid / unit / buffer / sponge numbers),
 //   --dump-setup FILE (raw initial state of the first case).

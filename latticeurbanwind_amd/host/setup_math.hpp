@@ -48,7 +48,7 @@ struct Config {
 	bool buoyancy = true, buoyancy_explicit = false; // default-on unless explicitly false (FX/setup.cpp:2743)
 	// *.luw
 	bool nwp_mode = false; string downstream_bc = "+y", downstream_bc_yaw, validation = "unknown"; bool use_high_order = false, flux_correction = false;
-	bool fp16c = true, native_arith = false; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
+	bool fp16c = true, native_arith = true; int device = 0; bool dry_run = false, sizing_only = false; string dump_setup, dump_vk;
 	std::vector<int> devices; uint32_t kernel = LUW_KERNEL_AUTO;
 };
 

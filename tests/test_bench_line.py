@@ -25,7 +25,8 @@ def block(err=False):
         return {"error": "exit 1: " + LONG}
     b = {"value": 68853.5, "unit": "MLUPS", "ms_per_step": 1.9493, "steps": 200, "warmup": 20, "lattice": [1024, 1024, 256], "workload": LONG, "options": LONG,
         "roofline": roof(0.6587), "placement": {"create_s": 1.2, "text": LONG}}
-    b["native"] = {"value": 1.0, "ms_per_step": 1.9, "roofline": {"frac": 0.66, "kernel_ms": 1.9}}
+    b["exact"] = {"value": 1.0, "ms_per_step": 1.9, "roofline": {"frac": 0.66, "kernel_ms": 1.9}}
+    b["dtype"], b["arith"] = "fp16c-storage/f32-arithmetic", "native"
     b["peer_loopback"] = {"value": 1.0, "ms_per_step": 1.9, "transport": "peer-loopback", "roofline": {"frac": 0.66}}
     return b
 
@@ -43,12 +44,14 @@ def single_full():
         "secondary": {k: block(err=(i == 3)) for i, k in enumerate(keys)},
         "cpu_baseline": {"value": 513.8, "unit": "MLUPS", "cores": 16, "kind": "port", "cpu_model": "AMD EPYC 9575F 64-Core Processor", "dram_GBps": 86.8,
             "copy_bandwidth_GBps": 150.2, "dram_frac_of_copy": 0.58, "path": LONG, "sample": LONG},
-        "parity": {"u_rmse_vs_reference": 1.2e-7, "unit": "lattice units", "steps": 64, "tolerance": 1e-5, "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)",
+        "parity": {"u_rmse_vs_reference": 1.2e-7, "unit": "lattice units", "steps": 64, "tolerance": 1e-5,
+            "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)",
             "fp32": {"K8": 1e-8, "K64": 1.2e-7, "u_avg": float("nan"), "within_tolerance": True},
             "shipped": {"CaseA": {"exact": {"K8": 1e-7, "K64": 2.65e-5, "u_avg": 1.5e-5}, "native": {"K8": 1e-7, "K64": 2.62e-5, "u_avg": 1.48e-5}},
                 "CaseL": {"exact": {"K8": 1e-7, "K64": 4.0e-6, "u_avg": 2.4e-6}, "native": {"K8": 1e-7, "K64": 4.0e-6, "u_avg": 2.4e-6}},
                 "precision": LONG, "within_tolerance_at_K8": True, "within_tolerance_at_K64": False, "note": LONG},
-            "reference_self_distance": {"CaseA": {"K8": 3e-6, "K64": 2.7e-5, "u_avg": 1.6e-5}, "what": "FP32 build vs shipped build of the reference, same deck"},
+            "reference_self_distance": {"CaseA": {"K8": 1e-5, "K64": 2.2e-5, "u_avg": 1.4e-5}, "CaseL": {"K8": 2e-6, "K64": 3.2e-6, "u_avg": 2.3e-6},
+                "what": "FP32 build vs shipped build of the reference, same deck"},
             "c1_planes": {"fp32": 2.9e-7, "fp16c": 9e-6, "steps": 100, "lattice": [128, 128, 128]}, "horizon": LONG}}
 
 
@@ -66,9 +69,11 @@ def multi_full(world=8):
         gh[lab] = {"parity": {"equal": True, "lattice": [1536, 128, 64], "compared": LONG}, "transport": "peer stores", "overlap": True, "value": 251234.5,
             "unit": "MLUPS", "ms_per_step": 4.2, "domain0_kernel_ms": 1.7, "direct_peer_stores": True, "host_threads": "one", "process_wall_s": 41.2}
     gh["rccl"] = {"error": LONG}
-    return {"metric": "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref", "value": 298123.4, "unit": "MLUPS", "n_gpus": world, "steps": 200,
+    return {"metric": "MLUPS (D3Q19) at 1/2/4/8 MI355X; % of HBM roofline; u-field RMSE vs ref", "value": 298123.4, "unit": "MLUPS", "n_gpus": world,
+        "steps": 200,
         "warmup": 20, "ms_per_step": 3.6012, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": LONG, "global_lattice": [2048, 1024, 512], "n_gpu": [4, 2, 1], "cells_per_gpu": 512 ** 3, "halo_exchange": LONG, "kernel": "auto",
+        "config": {"workload": LONG, "global_lattice": [2048, 1024, 512], "n_gpu": [4, 2, 1], "cells_per_gpu": 512 ** 3, "halo_exchange": LONG,
+            "kernel": "auto",
             "bytes_per_lup": 153.0, "rccl_version": "2.26.6", "ranks_in_communicator": world},
         "roofline": dict(roof(), note=LONG), "parity": {"transport": LONG, "ok": True, "cases": [case] * 4}, "per_rank": ranks,
         "secondary": {"x_whole_n_gpu": {"value": 300000.1, "unit": "MLUPS", "ms_per_step": 3.5, "n_gpu": [1, 4, 2], "global_lattice": [2048, 1024, 512],
@@ -91,11 +96,12 @@ def test_single_gpu_line_worst_case_fits_and_is_strict_json():
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "cpu_model", "dram_GBps"}
     assert d["config"]["workload"] and d["config"]["global_lattice"] == [1024, 1024, 256] and "model" not in d["config"]
-    assert d["parity"]["u_rmse_vs_reference"] == 1.2e-7 and d["parity"]["fp16c_K64"]["CaseA"] == 2.65e-5 and "reference_self_distance" in d["parity"]
+    assert d["parity"]["u_rmse_vs_reference"] == 1.2e-7 and d["parity"]["fp16c_K64"]["CaseA"] == 2.65e-5 and d["parity"]["reference_self_distance_K64"] == {
+        "CaseA": 2.2e-5, "CaseL": 3.2e-6}
     import bench
     assert set(d["secondary"]) == set(bench.SINGLE_BLOCKS) | set(bench.RANK_SHAPE_BLOCKS)          # nothing shed: two numbers per block fit
     ok = d["secondary"]["c2_f32"]
-    assert ok == {"ms": 1.9493, "frac": 0.6587, "native_frac": 0.66, "peer_frac": 0.66}
+    assert ok == {"ms": 1.9493, "frac": 0.6587, "arith": "native", "exact_frac": 0.66, "peer_frac": 0.66}
     assert sum("error" in v for v in d["secondary"].values()) == 1
 
 

@@ -59,7 +59,7 @@ def test_group_host_variant_past_its_time_limit_costs_only_its_own_block(monkeyp
     import argparse
     from benchmarks import multi
     monkeypatch.setattr(multi, "GROUP_HOST_TIMEOUT_S", 1)
-    args = argparse.Namespace(dtype="f32", kernel="auto", steps=4, warmup=2, coriolis=False, no_buildings=False, no_parity=True)
+    args = argparse.Namespace(dtype="f32", arith="native", kernel="auto", steps=4, warmup=2, coriolis=False, no_buildings=False, no_parity=True)
     out = multi.run_group_host(args, (2, 1, 1), (128, 64, 64), [0, 0])
     assert set(multi.GROUP_HOST_VARIANTS) <= set(out)
     for label in multi.GROUP_HOST_VARIANTS:

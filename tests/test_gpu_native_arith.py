@@ -162,7 +162,8 @@ def test_native_arithmetic_is_ignored_for_fp32_and_in_sampled_steps(luw):
 
 
 def test_driver_option_arith_native(luw, tmp_path):
-    # --arith native through the deck driver: files within the exact run's gates of the real reference, and different from the exact run's files
+    # --arith through the deck driver (native is its default for FP16C): files within the exact run's gates of the real reference, and different from the
+    # exact run's files
     import glob, shutil, subprocess
     from vtkio import read_vtk
     drv = os.path.join(os.path.dirname(GOLD), "..", "latticeurbanwind_amd", "host", "luw_driver")
@@ -174,7 +175,7 @@ def test_driver_option_arith_native(luw, tmp_path):
         shutil.copytree(os.path.join(GOLD, "refcases", "CaseA"), proj)
         r = subprocess.run([drv, os.path.join(proj, "conf.luwpf"), "--ddf", "fp16c", "--arith", mode], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        assert ("Arithmetic" in r.stdout) == (mode == "native")
+        assert ("native (v_rcp" in r.stdout) == (mode == "native") and ("exact (bit-equal" in r.stdout) == (mode == "exact")
         out[mode] = read_vtk(glob.glob(os.path.join(proj, "RESULTS", "vtk", "*_raw_u-000000064.vtk"))[0])[1]["data"]
     fac = np.float32(5.0) / np.float32(0.1)
     fluid = ~gold["solid"]

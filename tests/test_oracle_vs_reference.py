@@ -6,6 +6,7 @@ Tolerances (lattice units, stated per the north star): the reference is compiled
 DDFs the fields agree to ~1e-7 RMSE after 64 steps (gate 1e-6, an order below the 1e-5 acceptance gate); with
 FP16C DDFs every differing last bit can flip an 11-bit mantissa rounding (2^-12 relative), giving ~3e-7 RMSE
 after 8 steps and ~2.5e-5 after 64 steps of LES flow (gates 2e-6 / 1e-4)."""
+import json
 import os
 
 import numpy as np
@@ -117,3 +118,19 @@ def test_oracle_fp16c_vs_real_reference_shipped_config(case):
     r8, r64, ravg = run_and_compare(o, g, s, "oracle:ref_shipped_%s" % case, 2e-6, 6e-5)
     assert r8 < 1e-5
     print(case, "fp16c rmse@8 %.3e @64 %.3e u_avg %.3e" % (r8, r64, ravg))
+
+
+def test_the_reference_moves_from_itself_by_more_than_the_fp16c_distances_measured_here():
+    """The yardstick for every FP16C number (bench line `parity.reference_self_distance_K64`): the reference's FP32 build against its own shipped FP16C build,
+    same deck, from the committed fixtures alone.  On the LES case A the storage format alone moves it by 2.2e-5 at K = 64 (1.0e-5 already at K = 8, u_avg
+    1.4e-5) -- the 2.6e-5 between this repo's FP16C runs (exact or native arithmetic) and the shipped build are of that size, and no FP16C run, the
+    reference's own included, can meet 1e-5 against an FP32 field at that horizon.  Laminar case L: 3.2e-6."""
+    import sys
+    sys.path.insert(0, os.path.dirname(GOLD[:-len("/golden")]))
+    from benchmarks.common import reference_self_distance
+    d = reference_self_distance()
+    assert 1.5e-5 < d["CaseA"]["K64"] < 3e-5 and 0.5e-5 < d["CaseA"]["K8"] < 1.5e-5 and 1e-5 < d["CaseA"]["u_avg"] < 2e-5
+    assert 2e-6 < d["CaseL"]["K64"] < 5e-6
+    recorded = json.load(open(os.path.join(GOLD, "observed_rmse.json")))
+    ours = recorded["driver:native:ref_shipped_CaseA:final"]
+    assert ours < 1.5 * d["CaseA"]["K64"]                      # this repo's FP16C run against the shipped build: the same order as the reference against itself

@@ -2,7 +2,8 @@
 """GPU box: drift of the mean density over K steps in a periodic box, FP16C DDFs, exact and native arithmetic (LUW_LIB picks the build), several seeds."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0,
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import latticeurbanwind_amd as luw
 from helpers import synthetic_state
 luw.load()
