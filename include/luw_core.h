@@ -118,11 +118,13 @@ int luw_p2p_info(int device, int peer, int* can_access, int* performance_rank, i
 int luw_format_float9(float x, char* text, uint64_t size);
 
 /* life cycle: LBM::LBM (FX/lbm.cpp:1057-1112) / LBM::~LBM.
- * For DDF arrays of 1 GiB and more luw_create times two steps of the real kernel on the freshly mapped array and, while that is under the rate of the
- * fast class of placements, tries up to three other kinds of allocation, one at a time, keeping the fastest (physical placement changes the step time
- * by up to 10 % on MI355X and which kind is fast differs between machines).  Nothing of the search outlives luw_create; it needs
- * room for one more DDF array while it runs and is skipped without it, and on devices that several solvers share.  Environment knobs: INTEGRATION.md
- * section 5 (LUW_TUNE_PLACEMENT=0 switches the search off). */
+ * For DDF arrays of 1 GiB and more (planes under 1.5 GiB) luw_create times four steps of the real kernel on the freshly mapped array and, while that is
+ * under the rate of the fast class of placements, makes up to FIVE further draws of physical memory (1 GiB chunks again, 4 GiB, 2 GiB, hipMalloc, 512 MiB
+ * chunks), keeping the fastest (physical placement changes the step time by up to 10 % on MI355X).  Every array tried stays mapped
+ * until the search ends: the PEAK device memory of luw_create is up to six DDF arrays, each further draw only if free memory exceeds one array + 40 B per
+ * cell + 2 GiB -- a co-tenant process allocating on the same device in that window can run out of memory; LUW_TUNE_PLACEMENT=0 (or =<n> draws) bounds
+ * it.  Nothing of the search outlives luw_create (one search per process and device); it is skipped on devices that several solvers share.
+ * Environment knobs: INTEGRATION.md section 5; the library reads them once per process (luw_dev_reload_tuning reads them again). */
 int luw_create(const luw_config* cfg, luw_solver** out);
 void luw_destroy(luw_solver* s);
 
@@ -281,6 +283,10 @@ luw_solver* luw_group_domain(luw_group* g, uint32_t d);
 int luw_group_domain_info(const luw_group* g, uint32_t d, uint32_t* local_N, int32_t* offset, int* device); /* LBM_Domain::get_Nx.., Ox.. (FX/lbm.cpp:1072) */
 int luw_group_overlaps(const luw_group* g);                 /* 1: shell / interior overlap in use (every split axis has >= 4 owned layers) */
 int luw_group_direct_peer_stores(const luw_group* g);       /* 1: every face travels as peer stores of the pack kernel, none through a copy */
+/* 1: ONE pack / unpack round per step -- the faces of all axes together, the populations that cross two cuts as twelve edge messages straight to the
+ * diagonal neighbours, the x faces written by the step kernels and read by the next step's in place (the default where every pair of trading domains has
+ * peer access); 0: the reference's three phases x, y, z with rims, FX/lbm.cpp:1907-1935 (staged and RCCL transports; LUW_GROUP_EXCHANGE=sequential) */
+int luw_group_one_phase(const luw_group* g);
 /* How the faces of communicate_field (FX/lbm.cpp:1907-1935) travel between the domains of this process.  Chosen at luw_group_create from
  * the environment variable LUW_GROUP_TRANSPORT = peer (default) | staged | rccl:
  *   PEER    the pack kernel of a domain stores straight into the neighbour's receive buffer (xGMI remote stores); pairs of devices

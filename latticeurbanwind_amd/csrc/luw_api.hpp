@@ -199,7 +199,7 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 			return oom("sigma");
 		k.sigma = s->d_sigma;
 	}
-	HIP_TRY(hipStreamSynchronize(s->stream));
+	if(hipStreamSynchronize(s->stream)!=hipSuccess) { luw_destroy(s); return fail(LUW_ERR_DEVICE, "luw_create: the device did not finish the set-up copies"); }
 	if(int e = tune_ddf_placement(s)) { luw_destroy(s); return e; } // last: the probe steps run the complete kernel (nudging / sponge tables included)
 	s->create_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now()-t_create).count();
 	*out = s;

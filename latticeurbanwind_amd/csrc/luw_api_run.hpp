@@ -294,7 +294,7 @@ int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, 
 }
 
 // ---- include/luw_core_dev.h: measurement and test entry points
-int luw_dev_reload_tuning(void) { tuning_load(); return LUW_OK; }
+int luw_dev_reload_tuning(void) { (void)tuning(); tuning_load(); return LUW_OK; } // (not while another thread is inside the library)
 int luw_dev_inject_fault(uint32_t mask) { g_injected_faults.store(mask); return LUW_OK; }
 int luw_dev_tuning_text(char* text, uint64_t size) {
 	if(!text||size<64u) return fail(LUW_ERR_INVALID, "luw_dev_tuning_text: needs a buffer");

@@ -32,6 +32,7 @@
 #include <thread>
 #include <functional>
 #include <atomic>
+#include <mutex>
 #include <algorithm>
 #include <memory>
 #include <dlfcn.h>

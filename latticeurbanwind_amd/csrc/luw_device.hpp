@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace luw {
 
@@ -211,25 +212,49 @@ __device__ __forceinline__ float sqrt_in_range(const float x) {
 // the densities for which div_by is the library's division: finite, positive, exponent in [-60, 60)
 __device__ __forceinline__ bool density_is_ordinary(const float rho) { return __float_as_uint(rho)-0x21800000u<0x3C000000u; }
 
+// ---------------------------------------------------------------- direction algebra, FX/kernel.cpp:890-893
+// c_I . (a, b, c) with the zero terms dropped, evaluated left to right like c(i)*a+c(19+i)*b+c(38+i)*c (FX/kernel.cpp:1111).  D3Q19 order: rest, the six
+// axis directions (+x -x +y -y +z -z), then the diagonals (++0 --0, +0+ -0-, 0++ 0--, +-0 -+0, +0- -0+, 0+- 0-+): odd I and I + 1 are opposite.
+template<int I> __device__ __forceinline__ float cdot(const float a, const float b, const float c) {
+	if constexpr(I== 1) return  a; else if constexpr(I== 2) return -a;
+	else if constexpr(I== 3) return  b; else if constexpr(I== 4) return -b;
+	else if constexpr(I== 5) return  c; else if constexpr(I== 6) return -c;
+	else if constexpr(I== 7) return  a+b; else if constexpr(I== 8) return -a-b;
+	else if constexpr(I== 9) return  a+c; else if constexpr(I==10) return -a-c;
+	else if constexpr(I==11) return  b+c; else if constexpr(I==12) return -b-c;
+	else if constexpr(I==13) return  a-b; else if constexpr(I==14) return -a+b;
+	else if constexpr(I==15) return  a-c; else if constexpr(I==16) return -a+c;
+	else if constexpr(I==17) return  b-c; else return -b+c; // 18
+}
+template<int K, typename Fn> __device__ __forceinline__ void for_each_pair(Fn&& fn) { // fn(K), fn(K + 1), ..., fn(8) with K a compile-time constant
+	fn(std::integral_constant<int, K>{});
+	if constexpr(K<8) for_each_pair<K+1>(fn);
+}
+
 // ---------------------------------------------------------------- f_eq, FX/kernel.cpp:1016-1055
-__device__ __forceinline__ void calculate_f_eq(const float rho, float ux, float uy, float uz, float* feq) {
-	const float rhom1 = rho-1.0f;
-	const float c3 = -3.0f*(sq(ux)+sq(uy)+sq(uz));
-	uz *= 3.0f;
-	ux *= 3.0f;
-	uy *= 3.0f;
-	feq[ 0] = DEF_W0*fmaf(rho, 0.5f*c3, rhom1);
-	const float u0=ux+uy, u1=ux+uz, u2=uy+uz, u3=ux-uy, u4=ux-uz, u5=uy-uz;
-	const float rhos=DEF_WS*rho, rhoe=DEF_WE*rho, rhom1s=DEF_WS*rhom1, rhom1e=DEF_WE*rhom1;
-	feq[ 1] = fmaf(rhos, fmaf(0.5f, fmaf(ux, ux, c3), ux), rhom1s); feq[ 2] = fmaf(rhos, fmaf(0.5f, fmaf(ux, ux, c3), -ux), rhom1s);
-	feq[ 3] = fmaf(rhos, fmaf(0.5f, fmaf(uy, uy, c3), uy), rhom1s); feq[ 4] = fmaf(rhos, fmaf(0.5f, fmaf(uy, uy, c3), -uy), rhom1s);
-	feq[ 5] = fmaf(rhos, fmaf(0.5f, fmaf(uz, uz, c3), uz), rhom1s); feq[ 6] = fmaf(rhos, fmaf(0.5f, fmaf(uz, uz, c3), -uz), rhom1s);
-	feq[ 7] = fmaf(rhoe, fmaf(0.5f, fmaf(u0, u0, c3), u0), rhom1e); feq[ 8] = fmaf(rhoe, fmaf(0.5f, fmaf(u0, u0, c3), -u0), rhom1e);
-	feq[ 9] = fmaf(rhoe, fmaf(0.5f, fmaf(u1, u1, c3), u1), rhom1e); feq[10] = fmaf(rhoe, fmaf(0.5f, fmaf(u1, u1, c3), -u1), rhom1e);
-	feq[11] = fmaf(rhoe, fmaf(0.5f, fmaf(u2, u2, c3), u2), rhom1e); feq[12] = fmaf(rhoe, fmaf(0.5f, fmaf(u2, u2, c3), -u2), rhom1e);
-	feq[13] = fmaf(rhoe, fmaf(0.5f, fmaf(u3, u3, c3), u3), rhom1e); feq[14] = fmaf(rhoe, fmaf(0.5f, fmaf(u3, u3, c3), -u3), rhom1e);
-	feq[15] = fmaf(rhoe, fmaf(0.5f, fmaf(u4, u4, c3), u4), rhom1e); feq[16] = fmaf(rhoe, fmaf(0.5f, fmaf(u4, u4, c3), -u4), rhom1e);
-	feq[17] = fmaf(rhoe, fmaf(0.5f, fmaf(u5, u5, c3), u5), rhom1e); feq[18] = fmaf(rhoe, fmaf(0.5f, fmaf(u5, u5, c3), -u5), rhom1e);
+// Second-order equilibrium of the SHIFTED populations (stored value = f - w_i): per opposite pair k (directions 2k+1, 2k+2) with s = 3 c.u and
+// q = s^2 - 3 u^2, f_eq = w_k rho (q / 2 +- s) + w_k (rho - 1).  The nesting of the fused multiply-adds is the reference's (three deep per population:
+// fma(s, s, -3 u^2), fma(1/2, q, +-s), fma(w rho, ., w (rho - 1))), which is what makes the values bit-equal to its restatement; the pair loop and the
+// two weight classes (k < 3: axis directions, 1/18; else diagonals, 1/36) are this file's.
+struct EqCommon { float q0, lead[2], base[2], s3[3]; };            // -3 u^2; w rho and w (rho - 1) per weight class; 3 u
+__device__ __forceinline__ EqCommon eq_common(const float rho, const float ux, const float uy, const float uz, float& feq_rest) {
+	EqCommon e;
+	const float dev = rho-1.0f;
+	e.q0 = -3.0f*(sq(ux)+sq(uy)+sq(uz));
+	e.s3[0] = ux*3.0f; e.s3[1] = uy*3.0f; e.s3[2] = uz*3.0f;
+	feq_rest = DEF_W0*fmaf(rho, 0.5f*e.q0, dev);
+	e.lead[0] = DEF_WS*rho; e.lead[1] = DEF_WE*rho; e.base[0] = DEF_WS*dev; e.base[1] = DEF_WE*dev;
+	return e;
+}
+__device__ __forceinline__ void calculate_f_eq(const float rho, const float ux, const float uy, const float uz, float* feq) {
+	const EqCommon e = eq_common(rho, ux, uy, uz, feq[0]);
+	for_each_pair<0>([&](auto kc) {
+		constexpr int k = decltype(kc)::value, cls = k<3 ? 0 : 1;
+		const float s = cdot<2*k+1>(e.s3[0], e.s3[1], e.s3[2]);
+		const float q = fmaf(s, s, e.q0);
+		feq[2*k+1] = fmaf(e.lead[cls], fmaf(0.5f, q, s), e.base[cls]);
+		feq[2*k+2] = fmaf(e.lead[cls], fmaf(0.5f, q, -s), e.base[cls]);
+	});
 }
 
 // ---------------------------------------------------------------- moments, FX/kernel.cpp:1075-1100
@@ -252,19 +277,6 @@ __device__ __forceinline__ void calculate_rho_u(const float* f, float& rhon, flo
 	uzn = uz/rho;
 }
 
-// c_i . (a,b,c) with the zero terms dropped, evaluated left to right like c(i)*a+c(19+i)*b+c(38+i)*c
-// (FX/kernel.cpp:1111).  D3Q19 order: FX/kernel.cpp:890-893.
-template<int I> __device__ __forceinline__ float cdot(const float a, const float b, const float c) {
-	if constexpr(I== 1) return  a; else if constexpr(I== 2) return -a;
-	else if constexpr(I== 3) return  b; else if constexpr(I== 4) return -b;
-	else if constexpr(I== 5) return  c; else if constexpr(I== 6) return -c;
-	else if constexpr(I== 7) return  a+b; else if constexpr(I== 8) return -a-b;
-	else if constexpr(I== 9) return  a+c; else if constexpr(I==10) return -a-c;
-	else if constexpr(I==11) return  b+c; else if constexpr(I==12) return -b-c;
-	else if constexpr(I==13) return  a-b; else if constexpr(I==14) return -a+b;
-	else if constexpr(I==15) return  a-c; else if constexpr(I==16) return -a+c;
-	else if constexpr(I==17) return  b-c; else return -b+c; // 18
-}
 template<int I> __device__ __forceinline__ void forcing_term(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz,
 	const float uF, float* Fin) {
 	constexpr float w9 = 9.0f*(I<7 ? DEF_WS : DEF_WE);
@@ -554,22 +566,14 @@ template<bool FAST=true, bool NOFORCE=false, bool PLAIN=false> __device__ __forc
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(const float a) { f32x2 r = { a, a }; return r; }
 __device__ __forceinline__ f32x2 pm2(const float a) { f32x2 r = { a, -a }; return r; }
-__device__ __forceinline__ void calculate_f_eq_pk(const float rho, float ux, float uy, float uz, float& feq0, f32x2* feqp) {
-	const float rhom1 = rho-1.0f;
-	const float c3 = -3.0f*(sq(ux)+sq(uy)+sq(uz));
-	uz *= 3.0f;
-	ux *= 3.0f;
-	uy *= 3.0f;
-	feq0 = DEF_W0*fmaf(rho, 0.5f*c3, rhom1);
-	const float u0=ux+uy, u1=ux+uz, u2=uy+uz, u3=ux-uy, u4=ux-uz, u5=uy-uz;
-	const float rhos=DEF_WS*rho, rhoe=DEF_WE*rho, rhom1s=DEF_WS*rhom1, rhom1e=DEF_WE*rhom1;
-	const float v[9] = { ux, uy, uz, u0, u1, u2, u3, u4, u5 };
-	#pragma unroll
-	for(int k=0; k<9; k++) { // feq[2k+1] = fma(rw, fma(0.5, fma(v,v,c3), v), rm1w), feq[2k+2] the same with -v (FX/kernel.cpp:1045-1055)
-		const float A = fmaf(v[k], v[k], c3);
-		const f32x2 in = __builtin_elementwise_fma(splat2(0.5f), splat2(A), pm2(v[k]));
-		feqp[k] = __builtin_elementwise_fma(splat2(k<3 ? rhos : rhoe), in, splat2(k<3 ? rhom1s : rhom1e));
-	}
+__device__ __forceinline__ void calculate_f_eq_pk(const float rho, const float ux, const float uy, const float uz, float& feq0, f32x2* feqp) {
+	const EqCommon e = eq_common(rho, ux, uy, uz, feq0);
+	for_each_pair<0>([&](auto kc) { // both populations of pair k in the two halves of packed instructions: (q / 2 + s, q / 2 - s), then the weights
+		constexpr int k = decltype(kc)::value, cls = k<3 ? 0 : 1;
+		const float s = cdot<2*k+1>(e.s3[0], e.s3[1], e.s3[2]);
+		const f32x2 inner = __builtin_elementwise_fma(splat2(0.5f), splat2(fmaf(s, s, e.q0)), pm2(s));
+		feqp[k] = __builtin_elementwise_fma(splat2(e.lead[cls]), inner, splat2(e.base[cls]));
+	});
 }
 // Guo terms of the pair (2k+1, 2k+2): c_(2k+2) = -c_(2k+1), so both are w9 fma(+-cF, +-cu + 1/3, uF) (FX/kernel.cpp:1103-1113)
 template<int K> __device__ __forceinline__ f32x2 forcing_pair(const float ux, const float uy, const float uz, const float fx, const float fy, const float fz,
@@ -885,12 +889,13 @@ __device__ __forceinline__ bool in_force_zone(const KParams& p, const uint32_t x
 }
 
 // ---------------------------------------------------------------- thermal D3Q7 lattice (TEMPERATURE), FX/kernel.cpp:1306-1335,1639-1684
+// D3Q7 equilibrium of the shifted populations: rest T / 4 - 1 / 4, axis pair a: (T / 8)(1 +- 4 u_a) - 1 / 8 as one fma each on T / 2 and (T - 1) / 8
 __device__ __forceinline__ void calculate_g_eq(const float T, const float ux, const float uy, const float uz, float* geq) {
-	const float wsT4 = 0.5f*T, wsTm1 = 0.125f*(T-1.0f);
+	const float half_T = 0.5f*T, shift = 0.125f*(T-1.0f);
+	const float ua[3] = { ux, uy, uz };
 	geq[0] = fmaf(0.25f, T, -0.25f);
-	geq[1] = fmaf(wsT4, ux, wsTm1); geq[2] = fmaf(wsT4, -ux, wsTm1);
-	geq[3] = fmaf(wsT4, uy, wsTm1); geq[4] = fmaf(wsT4, -uy, wsTm1);
-	geq[5] = fmaf(wsT4, uz, wsTm1); geq[6] = fmaf(wsT4, -uz, wsTm1);
+	#pragma unroll
+	for(int a=0; a<3; a++) { geq[2*a+1] = fmaf(half_T, ua[a], shift); geq[2*a+2] = fmaf(half_T, -ua[a], shift); }
 }
 // the cell update on streamed-in populations g[7] (in place): T = sum g + 1 (or the preset on TYPE_T cells), top sponge on T, BGK with w_T
 // (TYPE_T: g = g_eq); writes T of a cell that is not preset.  FX/kernel.cpp:1652-1684

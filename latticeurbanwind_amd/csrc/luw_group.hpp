@@ -26,6 +26,14 @@ struct GroupDomain {
 	void* recv[3][2] = {};                    // [axis][0: face coming from the + neighbour (insert's buf_p), 1: from the - neighbour (buf_m)], 5*A DDF elements
 	void* send[3][2] = {};                    // staging, only for neighbours without peer access
 	void* grecv[3][2] = {}; void* gsend[3][2] = {}; // thermal lattice: one population per face cell
+	// one-phase exchange (group_exchange_one_phase): the x faces arrive in TWO sets of receive buffers used in turn (set 0 is recv[0]: a step's kernels
+	// read one set in place while the neighbours' kernels of the same step fill the other); the twelve edge messages land in erecv[e] (population 7 + e,
+	// sent by the domain in direction -c, enbr[e] being the domain in direction +c that takes OUR edge e); nbrs: every domain this one trades with
+	void* recvx[2][2] = {};
+	void* erecv[12] = {};
+	uint32_t enbr[12] = {};
+	std::vector<uint32_t> nbrs;
+	hipEvent_t packed_all = nullptr, unpacked_all = nullptr;
 	hipEvent_t shell_done = nullptr, interior_done = nullptr, pre_done = nullptr, stats_done = nullptr;
 	hipEvent_t packed[3] = {}, unpacked[3] = {}, gpacked[3] = {}, gunpacked[3] = {};
 	bool stats_pending = false;
@@ -50,6 +58,8 @@ struct luw_group {
 	std::vector<void*> rccl_comm;             // LUW_TRANSPORT_RCCL: one communicator per DISTINCT device ...
 	std::vector<int> rccl_rank;               // ... and every domain's rank in it (domains sharing a device share the rank)
 	bool failed = false;                      // a run stopped half-way: streams and sequence numbers are not trustworthy any more
+	bool one_phase = false;                   // every face, the edge messages and the thermal faces in one pack / unpack round per step (peer stores)
+	uint32_t xset = 0u;                       // one-phase: the set of x receive buffers the NEXT exchange fills
 };
 
 // thickness of the x boundary slabs: 128 cells (a one-cell x face would run one lane per wave; 128 FP16C cells are a full wave of the pair kernel,
@@ -67,10 +77,17 @@ static void group_rccl_teardown(luw_group* g);
 static bool group_x_direct(const luw_group* g, const size_t i) { return g->H[0]&&g->peer[i][g->dom[i].nbr[0][0]]&&g->peer[i][g->dom[i].nbr[0][1]]; }
 // ... and then the step kernels of domain i write there (luw_set_x_face_buffers): the launch that holds them waits, like the pack kernel would, until both
 // neighbours have consumed what the previous step put into those buffers
-static int group_x_face_ready(luw_group* g, const size_t i) {
+static int group_x_face_ready(luw_group* g, const size_t i, const uint32_t xs) { // xs: the set of x receive buffers this step fills (one-phase exchange)
 	if(!group_x_direct(g, i)) return LUW_OK;
 	GroupDomain& d = g->dom[i];
 	hipStream_t st = g->overlap ? d.comm : d.compute;
+	if(g->one_phase) {
+		// this step's kernels fill set xs of the x neighbours' receive buffers: the launches that READ that set -- the neighbours' previous step, which
+		// their `packed_all` record follows on the same stream -- have to be through; the set those launches are reading now is the other one
+		GroupDomain& P = g->dom[d.nbr[0][0]]; GroupDomain& M = g->dom[d.nbr[0][1]];
+		HIP_TRY(hipStreamWaitEvent(st, P.packed_all, 0)); HIP_TRY(hipStreamWaitEvent(st, M.packed_all, 0));
+		return luw_set_x_face_buffers(d.s, P.recvx[xs][1], M.recvx[xs][0]);
+	}
 	HIP_TRY(hipStreamWaitEvent(st, g->dom[d.nbr[0][0]].unpacked[0], 0));
 	HIP_TRY(hipStreamWaitEvent(st, g->dom[d.nbr[0][1]].unpacked[0], 0));
 	return LUW_OK;
@@ -86,6 +103,9 @@ static void group_free(luw_group* g) {
 	for(GroupDomain& d : g->dom) {
 		(void)hipSetDevice(d.device);
 		if(d.s) { (void)luw_set_stream(d.s, nullptr); luw_destroy(d.s); }
+		for(int k=0; k<2; k++) (void)hipFree(d.recvx[1][k]);         // (set 0 is recv[0])
+		for(void* e : d.erecv) (void)hipFree(e);
+		for(hipEvent_t e : { d.packed_all, d.unpacked_all }) if(e) (void)hipEventDestroy(e);
 		for(int a=0; a<3; a++) for(int k=0; k<2; k++) {
 			(void)hipFree(d.recv[a][k]);
 			(void)hipFree(d.send[a][k]);
@@ -256,6 +276,56 @@ static int group_exchange_rccl_axis(luw_group* g, const int a, const bool therma
 	return LUW_OK;
 }
 
+// ---- the exchange in ONE phase (default where every pair of trading domains has peer access): what latticeurbanwind_amd/distributed.py does per rank over
+// RCCL (_communicate_one_phase), with peer stores.  Per step and domain ONE pack round -- the y / z faces by their pack kernels and the twelve edge
+// populations (k_edges: the population that crosses two cuts at once goes straight to the diagonal neighbour instead of riding in the rims of two
+// consecutive face exchanges, FX/lbm.cpp:1908-1934), all written into the receivers' buffers; the x faces are there already, written by the step kernels --
+// and ONE unpack round: the x faces are handed to the next step's kernels where they lie (luw_set_x_face_inputs: no unpack kernel), y / z faces inserted,
+// the edges last (they overwrite what the rims of the faces carried).  Same populations in the same slots as the three-phase route
+// (tests/test_gpu_group.py, tests/fuzz/fuzz_exchange_gpu.py hold both to each other and to the oracle).
+static int domain_pack_all(luw_group* g, const size_t i, const bool on_compute, const uint32_t xs) {
+	GroupDomain& d = g->dom[i];
+	hipStream_t st = on_compute ? d.compute : d.comm;
+	for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].unpacked_all, 0)); // they have consumed what the previous step put there
+	GROUP_TRY(luw_set_stream(d.s, st));
+	for(int a=0; a<3; a++) {
+		if(!g->H[a]) continue;
+		GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
+		// (x: no launch where this step's kernels have written both faces -- into these very buffers, group_x_face_ready)
+		if(a==0) GROUP_TRY(luw_enqueue_extract_fi(d.s, 0u, P.recvx[xs][1], M.recvx[xs][0]));
+		else GROUP_TRY(luw_enqueue_extract_fi(d.s, (uint32_t)a, P.recv[a][1], M.recv[a][0]));
+	}
+	void* out[12];
+	for(uint32_t e=0u; e<12u; e++) out[e] = luw_get_edge_length(d.s, e) ? g->dom[d.enbr[e]].erecv[e] : nullptr;
+	GROUP_TRY(luw_enqueue_extract_edges(d.s, out));
+	if(g->thermal) for(int a=0; a<3; a++) if(g->H[a])
+		GROUP_TRY(luw_enqueue_extract_gi(d.s, (uint32_t)a, g->dom[d.nbr[a][0]].grecv[a][1], g->dom[d.nbr[a][1]].grecv[a][0]));
+	HIP_TRY(hipEventRecord(d.packed_all, st));
+	return LUW_OK;
+}
+// x_in_place: the x faces stay in their receive buffers for the next step's kernels (not at initialisation, whose exchange is followed by a reset of t)
+static int domain_unpack_all(luw_group* g, const size_t i, const bool on_compute, const bool x_in_place, const uint32_t xs) {
+	GroupDomain& d = g->dom[i];
+	hipStream_t st = on_compute ? d.compute : d.comm;
+	for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].packed_all, 0));
+	GROUP_TRY(luw_set_stream(d.s, st));
+	if(g->H[0]) {
+		if(x_in_place) GROUP_TRY(luw_set_x_face_inputs(d.s, d.recvx[xs][0], d.recvx[xs][1]));
+		else GROUP_TRY(luw_enqueue_insert_fi(d.s, 0u, d.recvx[xs][0], d.recvx[xs][1]));
+	}
+	for(int a=1; a<3; a++) if(g->H[a]) GROUP_TRY(luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
+	GROUP_TRY(luw_enqueue_insert_edges(d.s, d.erecv));
+	if(g->thermal) for(int a=0; a<3; a++) if(g->H[a]) GROUP_TRY(luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1]));
+	HIP_TRY(hipEventRecord(d.unpacked_all, st));
+	return LUW_OK;
+}
+static int group_exchange_one_phase(luw_group* g, const bool on_compute, const bool x_in_place) {
+	for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_pack_all(g, i, on_compute, g->xset)); }
+	for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_unpack_all(g, i, on_compute, x_in_place, g->xset)); }
+	g->xset ^= 1u;
+	return LUW_OK;
+}
+
 // one host thread for all domains: every domain packs, then every domain unpacks, axis by axis
 static int group_exchange(luw_group* g, const bool thermal_pass, const bool on_compute) {
 	for(int a=0; a<3; a++) {
@@ -266,7 +336,8 @@ static int group_exchange(luw_group* g, const bool thermal_pass, const bool on_c
 	}
 	return LUW_OK;
 }
-static int group_communicate(luw_group* g, const bool on_compute) { // communicate_fi, then communicate_gi (FX/lbm.cpp:1266-1284)
+static int group_communicate(luw_group* g, const bool on_compute, const bool x_in_place = true) { // communicate_fi, then communicate_gi (FX/lbm.cpp:1266-1284)
+	if(g->one_phase) return group_exchange_one_phase(g, on_compute, x_in_place);
 	GROUP_TRY(group_exchange(g, false, on_compute));
 	if(g->thermal) GROUP_TRY(group_exchange(g, true, on_compute));
 	return LUW_OK;
@@ -296,8 +367,8 @@ static StepCtx group_step_ctx(luw_group* g, const size_t k) {
 	return StepCtx{ d.s, d.compute, d.comm, d.shell_done, d.interior_done, d.pre_done, d.stats_done, &d.stats_pending, g->overlap, &d.whole, &d.interior,
 		&d.shell };
 }
-static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1) {
-	GROUP_TRY(group_x_face_ready(g, k));
+static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1, const uint32_t xs) {
+	GROUP_TRY(group_x_face_ready(g, k, xs));
 	return step_launch(group_step_ctx(g, k), pl.wf, t0, t1);
 }
 static int domain_separate_stats(luw_group* g, const size_t k) { return step_separate_stats(group_step_ctx(g, k)); }
@@ -335,18 +406,40 @@ static int domain_exchange_threaded(luw_group* g, const size_t k, const bool the
 	}
 	return LUW_OK;
 }
+// one-phase exchange number X of one domain's thread: the counters packed_seq[0][0] / unpacked_seq[0][0] stand for the whole round
+static int domain_exchange_one_phase_threaded(luw_group* g, const size_t k, const bool on_compute, const uint64_t X, GroupThreads& T, const uint32_t xs) {
+	GroupDomain& d = g->dom[k];
+	for(const uint32_t nb : d.nbrs) if(!group_wait_seq(&g->dom[nb].unpacked_seq[0][0], X-1ull, T.abort)) return LUW_ERR_STATE;
+	GROUP_TRY(domain_pack_all(g, k, on_compute, xs));
+	__atomic_store_n(&d.packed_seq[0][0], X, __ATOMIC_RELEASE);
+	for(const uint32_t nb : d.nbrs) if(!group_wait_seq(&g->dom[nb].packed_seq[0][0], X, T.abort)) return LUW_ERR_STATE;
+	GROUP_TRY(domain_unpack_all(g, k, on_compute, true, xs));
+	__atomic_store_n(&d.unpacked_seq[0][0], X, __ATOMIC_RELEASE);
+	return LUW_OK;
+}
 static int domain_run_threaded(luw_group* g, const size_t k, const uint64_t steps, const uint64_t first_sample, const uint64_t stride,
 	std::vector<hipEvent_t>* tev, const uint64_t X0, GroupThreads& T) {
 	GroupDomain& d = g->dom[k];
 	GROUP_TRY(group_set_device(d)); // per host thread
+	const uint32_t xset0 = g->xset;   // (the group's set counter moves with the steps; threads derive it from the step number)
 	for(uint64_t i=0ull; i<steps; i++) {
 		GroupStepPlan pl;
 		GROUP_TRY(domain_plan_step(g, k, i, steps, first_sample, stride, pl));
+		if(g->one_phase) {
+			// the x neighbours have enqueued (and recorded) the pack round of the previous exchange: group_x_face_ready waits for that record
+			if(group_x_direct(g, k)&&(!group_wait_seq(&g->dom[d.nbr[0][0]].packed_seq[0][0], X0+i, T.abort)
+				||!group_wait_seq(&g->dom[d.nbr[0][1]].packed_seq[0][0], X0+i, T.abort))) return LUW_ERR_STATE;
+			GROUP_TRY(domain_launch_step(g, k, pl, tev ? (*tev)[2u*i] : nullptr, tev ? (*tev)[2u*i+1u] : nullptr, (xset0+(uint32_t)i)&1u));
+			GROUP_TRY(domain_exchange_one_phase_threaded(g, k, !g->overlap, X0+i+1ull, T, (xset0+(uint32_t)i)&1u));
+			if(pl.separate) GROUP_TRY(domain_separate_stats(g, k));
+			GROUP_TRY(luw_increment_time_step(d.s, 1ull));
+			continue;
+		}
 		if(group_x_direct(g, k)) { // the neighbours have enqueued (and recorded) the x unpack of the previous exchange: domain_launch_step may wait for it
 			if(!group_wait_seq(&g->dom[d.nbr[0][0]].unpacked_seq[0][0], X0+i, T.abort)||!group_wait_seq(&g->dom[d.nbr[0][1]].unpacked_seq[0][0], X0+i, T.abort))
 				return LUW_ERR_STATE;
 		}
-		GROUP_TRY(domain_launch_step(g, k, pl, tev ? (*tev)[2u*i] : nullptr, tev ? (*tev)[2u*i+1u] : nullptr));
+		GROUP_TRY(domain_launch_step(g, k, pl, tev ? (*tev)[2u*i] : nullptr, tev ? (*tev)[2u*i+1u] : nullptr, 0u));
 		GROUP_TRY(domain_exchange_threaded(g, k, false, !g->overlap, X0+i+1ull, T));
 		if(g->thermal) GROUP_TRY(domain_exchange_threaded(g, k, true, !g->overlap, X0+i+1ull, T));
 		if(pl.separate) GROUP_TRY(domain_separate_stats(g, k));
@@ -406,6 +499,7 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 		for(size_t k=0; k<g->dom.size(); k++) if(rc[k]!=LUW_OK&&!T.error[k].empty()) return fail(rc[k], T.error[k]);
 		for(size_t k=0; k<g->dom.size(); k++) if(rc[k]!=LUW_OK) return fail(rc[k], "luw_group_run: stopped because another domain failed");
 		g->exchanges = X0+steps; g->t += steps;
+		if(g->one_phase) g->xset = (g->xset+(uint32_t)(steps&1ull))&1u;
 		// axes / passes that never ran keep in step
 		for(GroupDomain& d : g->dom) for(int f=0; f<2; f++) for(int a=0; a<3; a++) { d.packed_seq[f][a] = g->exchanges; d.unpacked_seq[f][a] = g->exchanges; }
 	} else {
@@ -414,7 +508,8 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 			for(size_t k=0; k<g->dom.size(); k++) {
 				GROUP_TRY(group_set_device(g->dom[k]));
 				GROUP_TRY(domain_plan_step(g, k, i, steps, first_sample, stride, pl));
-				GROUP_TRY(domain_launch_step(g, k, pl, (mean_kernel_ms&&k==0u) ? tev[2u*i] : nullptr, (mean_kernel_ms&&k==0u) ? tev[2u*i+1u] : nullptr));
+				GROUP_TRY(domain_launch_step(g, k, pl, (mean_kernel_ms&&k==0u) ? tev[2u*i] : nullptr, (mean_kernel_ms&&k==0u) ? tev[2u*i+1u] : nullptr,
+					g->xset));
 			}
 			GROUP_TRY(group_communicate(g, !g->overlap));
 			if(pl.separate) for(size_t k=0; k<g->dom.size(); k++) { GROUP_TRY(group_set_device(g->dom[k])); GROUP_TRY(domain_separate_stats(g, k)); }
@@ -509,6 +604,29 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 	g->transport = tuning().group_transport;
 	if(g->transport!=LUW_TRANSPORT_PEER) for(auto& row : g->peer) std::fill(row.begin(), row.end(), 0); // faces through send buffers
 	if(g->transport==LUW_TRANSPORT_RCCL&&n>1u) GROUP_TRY(group_rccl_setup(g.get())); // connections before the lattices (cf. TorchDistTransport.warm_up)
+	// the diagonal neighbours (edge e carries population 7 + e to the domain in direction c_(7+e), FX/kernel.cpp:890-893) and everybody a domain trades with
+	static const int EC[12][3] = { { 1, 1, 0 }, { -1, -1, 0 }, { 1, 0, 1 }, { -1, 0, -1 }, { 0, 1, 1 }, { 0, -1, -1 }, { 1, -1, 0 }, { -1, 1, 0 }, { 1, 0, -1 },
+		{ -1, 0, 1 }, { 0, 1, -1 }, { 0, -1, 1 } };
+	auto edge_exists = [&](const int e) { for(int a=0; a<3; a++) if(EC[e][a]!=0&&!g->H[a]) return false; return true; };
+	for(uint32_t i=0u; i<n; i++) {
+		GroupDomain& d = g->dom[i];
+		auto at = [&](const int sx, const int sy, const int sz) {
+			const uint32_t c[3] = { (d.coord[0]+D[0]+(uint32_t)sx)%D[0], (d.coord[1]+D[1]+(uint32_t)sy)%D[1], (d.coord[2]+D[2]+(uint32_t)sz)%D[2] };
+			return c[0]+(c[1]+c[2]*D[1])*D[0];
+		};
+		std::vector<uint32_t> all;
+		for(int a=0; a<3; a++) if(g->H[a]) { all.push_back(d.nbr[a][0]); all.push_back(d.nbr[a][1]); }
+		for(int e=0; e<12; e++) if(edge_exists(e)) {
+			d.enbr[e] = at(EC[e][0], EC[e][1], EC[e][2]);
+			all.push_back(d.enbr[e]); all.push_back(at(-EC[e][0], -EC[e][1], -EC[e][2]));
+		}
+		std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+		d.nbrs = all;
+	}
+	// ONE pack / unpack round per step where the faces travel as peer stores between every pair of trading domains (LUW_GROUP_EXCHANGE=sequential: the
+	// reference's three phases, which the staged and RCCL transports always take)
+	g->one_phase = n>1u && g->transport==LUW_TRANSPORT_PEER && !tuning().group_sequential;
+	for(uint32_t i=0u; i<n&&g->one_phase; i++) for(const uint32_t j : g->dom[i].nbrs) if(!g->peer[i][j]) { g->one_phase = false; break; }
 	// Streams and halo buffers BEFORE the lattices: every long-lived small allocation is in place before the large arrays and the
 	// placement search of luw_create run
 	for(uint32_t i=0u; i<n; i++) {
@@ -522,7 +640,13 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 			(void)hipGetLastError();
 			HIP_TRY(hipStreamCreateWithFlags(&d.comm, hipStreamNonBlocking));
 		}
-		for(hipEvent_t* e : { &d.shell_done, &d.interior_done, &d.pre_done, &d.stats_done }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+		for(hipEvent_t* e : { &d.shell_done, &d.interior_done, &d.pre_done, &d.stats_done, &d.packed_all, &d.unpacked_all })
+			HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+		if(g->one_phase) for(int e=0; e<12; e++) if(edge_exists(e)) { // one element per cell of the axis the edge runs along
+			const size_t L = (size_t)d.lN[EC[e][0]==0 ? 0 : EC[e][1]==0 ? 1 : 2];
+			if(hipMalloc(&d.erecv[e], L*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+			HIP_TRY(hipMemset(d.erecv[e], 0, L*g->ddf_bytes));
+		}
 		for(int a=0; a<3; a++) {
 			for(hipEvent_t* e : { &d.packed[a], &d.unpacked[a], &d.gpacked[a], &d.gunpacked[a] }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
 			if(!g->H[a]) continue;
@@ -532,6 +656,13 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 				if(hipMalloc(&d.recv[a][k], 5u*A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
 				HIP_TRY(hipMemset(d.recv[a][k], 0, 5u*A*g->ddf_bytes));
 				if(staged&&hipMalloc(&d.send[a][k], 5u*A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+				if(a==0) {
+					d.recvx[0][k] = d.recv[0][k];
+					if(g->one_phase) {
+						if(hipMalloc(&d.recvx[1][k], 5u*A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+						HIP_TRY(hipMemset(d.recvx[1][k], 0, 5u*A*g->ddf_bytes));
+					}
+				}
 				if(g->thermal) {
 					if(hipMalloc(&d.grecv[a][k], A*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
 					HIP_TRY(hipMemset(d.grecv[a][k], 0, A*g->ddf_bytes));
@@ -569,6 +700,7 @@ uint32_t luw_group_size(const luw_group* g) { return g ? (uint32_t)g->dom.size()
 luw_solver* luw_group_domain(luw_group* g, uint32_t d) { return (g&&d<g->dom.size()) ? g->dom[d].s : nullptr; }
 uint64_t luw_group_get_t(const luw_group* g) { return g ? g->t : 0ull; }
 int luw_group_overlaps(const luw_group* g) { return (g&&g->overlap) ? 1 : 0; }
+int luw_group_one_phase(const luw_group* g) { return (g&&g->one_phase) ? 1 : 0; }
 int luw_group_transport(const luw_group* g) {
 	if(!g) return -1;
 	if(g->transport==LUW_TRANSPORT_PEER&&!luw_group_direct_peer_stores(g)) return LUW_TRANSPORT_STAGED; // some pair of devices has no peer access
@@ -674,7 +806,7 @@ int luw_group_initialize(luw_group* g) { // LBM::initialize, FX/lbm.cpp:1221-126
 	if(g->dom.size()>1u) {
 		// "the communicate calls at initialization need an odd time step", FX/lbm.cpp:1242
 		for(GroupDomain& d : g->dom) GROUP_TRY(luw_increment_time_step(d.s, 1ull));
-		GROUP_TRY(group_communicate(g, false));
+		GROUP_TRY(group_communicate(g, false, false));                // (one-phase: the x faces go into the lattice here, t is reset behind this exchange)
 		GROUP_TRY(group_join(g));
 		for(GroupDomain& d : g->dom) GROUP_TRY(luw_reset_time_step(d.s)); // FX/lbm.cpp:1258
 	}

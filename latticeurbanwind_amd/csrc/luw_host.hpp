@@ -30,6 +30,7 @@ struct Tuning {
 	bool voxelize_all = false;        // LUW_VOXELIZE_ALL_TRIANGLES: every voxeliser tile tests every triangle (test aid for the bins)
 	uint32_t x_shell = 0u;            // LUW_X_SHELL=<cells>: thickness of the x boundary slabs of a decomposed step (0: 128; A/B aid)
 	int group_transport = LUW_TRANSPORT_PEER; bool group_transport_bad = false; // LUW_GROUP_TRANSPORT = peer | staged | rccl (luw_group_create)
+	bool group_sequential = false;    // LUW_GROUP_EXCHANGE=sequential: luw_group_* exchanges in the reference's three phases also where one round would do
 	bool group_threads = false;       // LUW_GROUP_THREADS=1: one host thread per domain in luw_group_run
 #ifdef LUW_AB_KERNELS                 // tools build only
 	int ab_kernel = -1;               // LUW_KERNEL=<id>: overrides the kernel choice of callers that expose none
@@ -37,8 +38,11 @@ struct Tuning {
 #endif
 };
 static std::atomic<uint32_t> g_injected_faults{0u};     // luw_dev_inject_fault (include/luw_core_dev.h): test hooks
+// Read ONCE per process, on first use (std::call_once: the first use may come from several threads at the same time -- the per-domain threads of
+// luw_group, callers' thread pools).  luw_dev_reload_tuning (tests and A/B tools that change the environment between two solvers) reads it again; it must
+// not run while another thread is inside the library.
 static Tuning g_tuning;
-static std::atomic<bool> g_tuning_loaded{false};
+static std::once_flag g_tuning_once;
 static void tuning_load() {
 	Tuning t;
 	auto on = [](const char* n) { return getenv(n)!=nullptr; };
@@ -63,14 +67,14 @@ static void tuning_load() {
 		else if(strcmp(e, "peer")!=0&&e[0]) t.group_transport_bad = true;
 	}
 	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
+	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; }
 #ifdef LUW_AB_KERNELS
 	if(const char* e = getenv("LUW_KERNEL")) t.ab_kernel = atoi(e);
 	t.ab_pair_copy = on("LUW_PAIR_COPY");
 #endif
 	g_tuning = t;
-	g_tuning_loaded.store(true);
 }
-static const Tuning& tuning() { if(!g_tuning_loaded.load()) tuning_load(); return g_tuning; }
+static const Tuning& tuning() { std::call_once(g_tuning_once, tuning_load); return g_tuning; }
 
 // ---- floats as 9-significant-digit text.  The reference bakes its kernel constants into OpenCL source as decimal text and writes
 // VTK headers the same way (to_string(float), FX/utilities.hpp:2603-2634,2741-2750; used at FX/lbm.cpp:664,774,780): what the

@@ -252,9 +252,8 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		collide_cell<(MODE!=3), NOFORCE, (sizeof(T)==2&&LUW_PLAIN_ARITH!=0)>(p, n, x, y, z, flagsn, f, rho, u, F, rhon, uxn, uyn, uzn);
 		if(write_fields && (flagsn&TYPE_BO)!=TYPE_E) {
 			rho[n] = rhon;
-			u[n] = uxn;
-			u[Np+n] = uyn;
-			u[2ull*Np+n] = uzn;
+			if constexpr(NATIVE) { u[n] = uxn+0.0f; u[Np+n] = uyn+0.0f; u[2ull*Np+n] = uzn+0.0f; } // (zero velocities as +0, like the pair kernel's native path)
+			else { u[n] = uxn; u[Np+n] = uyn; u[2ull*Np+n] = uzn; }
 		}
 		if constexpr(STATS) {
 			if((flagsn&TYPE_BO)==TYPE_E) stats_welford_from_fields(Np, S, n, rho, u); // TYPE_E keeps its input fields (UPDATE_FIELDS skips it)
@@ -587,7 +586,8 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 				if(write_fields && (fl[c]&TYPE_BO)!=TYPE_E) {
 					uint32_t nw = n+(uint32_t)c;
 					asm volatile("" : "+v"(nw));
-					rho[nw] = r_; u[nw] = ux_; u[Np+nw] = uy_; u[2ull*Np+nw] = uz_;
+					// (+ 0: a zero velocity is stored as +0 whatever the signs of the zero populations it came from -- those depend on the kernel that ran)
+					rho[nw] = r_; u[nw] = ux_+0.0f; u[Np+nw] = uy_+0.0f; u[2ull*Np+nw] = uz_+0.0f;
 				}
 			};
 			if constexpr(NATIVE) collide_cell_pk_native<FORCE, RAW>(p, n+c, fl[c], may_force, f0, fp, rho, u, F, rhon, uxn, uyn, uzn, THERMAL ? u0 : nullptr,

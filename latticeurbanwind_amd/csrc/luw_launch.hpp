@@ -118,7 +118,9 @@ static int xin_before_launch(luw_solver* s, const Box& b, const bool instantiati
 	if(!need) return LUW_OK;
 	const bool for_this_step = (!(need&1u)||s->xin_for_t[0]==s->t) && (!(need&2u)||s->xin_for_t[1]==s->t);
 	// (a side the box does not hold, or that is in the lattice already, gets a null pointer: the kernel tests each side's lanes against its own buffer)
-	if(instantiation_reads_them&&for_this_step) { s->xin_use = true; s->xin_inplace |= need; return LUW_OK; }
+	// (rows of fewer than six cells: a pair-kernel lane could hold the first AND the last owned column, and it fetches one side's values -- such a domain
+	// takes its faces through the insert kernel)
+	if(instantiation_reads_them&&for_this_step&&s->cfg.Nx>=6u) { s->xin_use = true; s->xin_inplace |= need; return LUW_OK; }
 	if(need&s->xin_inplace) return fail(LUW_ERR_STATE, "stream_collide: an earlier launch of this step read this border column's x face in its receive buffer; "
 		"this launch cannot");
 	return xin_settle(s, need);

@@ -312,6 +312,7 @@ class LBMGroup:
     def get_D(self): return self.D[0] * self.D[1] * self.D[2]
     def overlaps(self): return bool(self._L.luw_group_overlaps(self._h))
     def direct_peer_stores(self): return bool(self._L.luw_group_direct_peer_stores(self._h))
+    def one_phase(self): return bool(self._L.luw_group_one_phase(self._h))
     def transport(self): return int(self._L.luw_group_transport(self._h))   # capi.TRANSPORT_NAMES
     def set_f(self, fx, fy, fz): capi.check(self._L.luw_group_set_f(self._h, fx, fy, fz))
     def set_coriolis(self, ox, oy, oz): capi.check(self._L.luw_group_set_coriolis(self._h, ox, oy, oz))

@@ -25,7 +25,8 @@ def test_driver_outputs_equal_cpu_restatement(luw, tmp_path, case, ddf):
     proj = str(tmp_path / case)
     shutil.copytree(os.path.join(GOLD, "refcases", case), proj)
     deck = os.path.join(proj, "conf.luwpf")
-    r = subprocess.run([DRIVER, deck, "--ddf", ddf], capture_output=True, text=True, timeout=600)
+    # (--arith exact: the bit-exact kernels; the driver's default for FP16C is the native arithmetic, held to the real reference's files below)
+    r = subprocess.run([DRIVER, deck, "--ddf", ddf, "--arith", "exact"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # the driver voxelises on the device (bit-identical to the reference's masks, tests/test_gpu_voxelize.py); the python
     # set-up restatement takes the reference's mask instead of its IEEE-division host voxeliser

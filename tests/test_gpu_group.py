@@ -25,6 +25,21 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["one_phase", "sequential"])
+def exchange(request):
+    """both exchange routes of luw_group_*: ONE pack / unpack round per step (default with peer stores: faces of all axes, twelve edge messages, x faces read
+    in place by the next step's kernels) and the reference's three phases x, y, z (LUW_GROUP_EXCHANGE=sequential)"""
+    from latticeurbanwind_amd import capi
+    saved = os.environ.get("LUW_GROUP_EXCHANGE")
+    if request.param == "sequential": os.environ["LUW_GROUP_EXCHANGE"] = "sequential"
+    else: os.environ.pop("LUW_GROUP_EXCHANGE", None)
+    capi.reload_tuning()
+    yield request.param
+    if saved is None: os.environ.pop("LUW_GROUP_EXCHANGE", None)
+    else: os.environ["LUW_GROUP_EXCHANGE"] = saved
+    capi.reload_tuning()
+
+
 def run_group(luw, gN, D, fp16c, state, steps, **kw):
     n = D[0] * D[1] * D[2]
     g = luw.LBMGroup(*gN, *D, 0.01, fp16c=fp16c, devices=[0] * n, **kw)
@@ -33,11 +48,11 @@ def run_group(luw, gN, D, fp16c, state, steps, **kw):
 
 
 @pytest.mark.parametrize("gN,D,fp16c,overlap", CASES)
-def test_group_equals_oracle_on_the_undivided_lattice(luw, gN, D, fp16c, overlap):
+def test_group_equals_oracle_on_the_undivided_lattice(luw, gN, D, fp16c, overlap, exchange):
     from oracle import oracle
     st = synthetic_state(*gN, seed=41, shell=None)                      # fully periodic: the wrap runs through the halo ring
     g = run_group(luw, gN, D, fp16c, st, 7)
-    assert g.overlaps() == overlap and g.direct_peer_stores()
+    assert g.overlaps() == overlap and g.direct_peer_stores() and g.one_phase() == (exchange == "one_phase")
     g.run(0); g.run(4); g.run(3)                                        # two calls: events of the first are reused by the second
     g.read_from_device()
     o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
@@ -48,7 +63,7 @@ def test_group_equals_oracle_on_the_undivided_lattice(luw, gN, D, fp16c, overlap
     g.close()
 
 
-def test_group_with_luw_shell_forces_and_statistics(luw):
+def test_group_with_luw_shell_forces_and_statistics(luw, exchange):
     """solid ground + TYPE_E shell, nudging + sponge + Coriolis, a sampling window: fields and Welford statistics of a
     [2,2,1] group against the oracle (+ host Welford) on the undivided lattice"""
     from oracle import oracle
@@ -78,7 +93,7 @@ def test_group_with_luw_shell_forces_and_statistics(luw):
 
 
 @pytest.mark.parametrize("D,fp16c", [((2, 1, 1), False), ((2, 2, 2), True)])
-def test_group_thermal_lattice(luw, D, fp16c):
+def test_group_thermal_lattice(luw, D, fp16c, exchange):
     from oracle import oracle
     gN = (24, 20, 16)
     st = synthetic_state(*gN, seed=45, shell=None)
@@ -175,7 +190,7 @@ def test_group_rccl_transport_self(luw):
             st = synthetic_state(*gN, seed=53, shell=None)
             tflags, T = thermal_state(st[0], gN) if alpha else (st[0], None)
             g = run_group(luw, gN, D, fp16c, (tflags, st[1], st[2]), 0, **({"alpha": alpha} if alpha else {}))
-            assert g.transport() == 2 and not g.direct_peer_stores(), capi.TRANSPORT_NAMES[g.transport()]
+            assert g.transport() == 2 and not g.direct_peer_stores() and not g.one_phase(), capi.TRANSPORT_NAMES[g.transport()]
             if alpha: g.T[:] = T
             g.run(0); g.run(4); g.run(3)
             g.read_from_device(("u", "rho", "T") if alpha else ("u", "rho"))
@@ -273,6 +288,7 @@ def test_pairs_without_peer_access_fall_back_to_copies_pair_by_pair(luw):
             st = synthetic_state(*gN, seed=47, shell=None)
             g = run_group(luw, gN, D, fp16c, st, 0)
             assert g.overlaps() and not g.direct_peer_stores() and g.transport() == 1     # reported as staged: some pair has no peer access
+            assert not g.one_phase()                                                       # ... and the exchange falls back to the three phases
             g.run(0); g.run(5); g.run(4); g.read_from_device()
             o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
             o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]

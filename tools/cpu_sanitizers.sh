@@ -6,6 +6,14 @@
 # Restores the product builds afterwards.   usage: tools/cpu_sanitizers.sh
 set -uo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+H="$R/latticeurbanwind_amd/host"
+# whatever ends this script (a failing command under set -u, a signal, Ctrl-C): the product builds come back
+restore() {
+  if [ -f /tmp/libluw_oracle_product.so ]; then cp /tmp/libluw_oracle_product.so "$R/oracle/libluw_oracle.so"; touch "$R/oracle/libluw_oracle.so"; fi
+  if [ -f /tmp/luw_driver_product ]; then cp /tmp/luw_driver_product "$H/luw_driver"; touch "$H/luw_driver"; fi
+}
+trap restore EXIT
+rm -f /tmp/libluw_oracle_product.so /tmp/luw_driver_product
 cp "$R/oracle/libluw_oracle.so" /tmp/libluw_oracle_product.so 2>/dev/null
 gcc -O1 -g -march=x86-64-v3 -fPIC -std=gnu11 -D_GNU_SOURCE -ffp-contract=off -fno-fast-math -fno-math-errno -fopenmp -fsanitize=address -fno-omit-frame-pointer \
   -shared -o "$R/oracle/libluw_oracle.so" "$R/oracle/luw_oracle.c" -lm && touch "$R/oracle/libluw_oracle.so"
@@ -14,7 +22,6 @@ ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so)" pyth
 rc=$?
 if [ -f /tmp/libluw_oracle_product.so ]; then cp /tmp/libluw_oracle_product.so "$R/oracle/libluw_oracle.so"; else make -C "$R/oracle" -s clean all; fi
 touch "$R/oracle/libluw_oracle.so"
-H="$R/latticeurbanwind_amd/host"
 cp "$H/luw_driver" /tmp/luw_driver_product 2>/dev/null
 ( cd "$H" && g++ -std=c++17 -O1 -g -ffp-contract=off -pthread -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Wall \
   -Wno-misleading-indentation -o luw_driver luw_driver.cpp -L../csrc -lluw_core -Wl,-rpath,'$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib && touch luw_driver )
