@@ -30,7 +30,8 @@ SYMBOLS = [
     "luw_enqueue_extract_fi", "luw_set_x_face_buffers", "luw_set_x_face_inputs", "luw_get_edge_length", "luw_enqueue_extract_edges", "luw_enqueue_insert_edges",
         "luw_group_create",
         "luw_group_destroy", "luw_group_size", "luw_group_domain", "luw_group_domain_info",
-    "luw_group_overlaps", "luw_group_direct_peer_stores", "luw_group_one_phase", "luw_group_scatter", "luw_group_gather", "luw_group_upload", "luw_group_download",
+    "luw_group_overlaps", "luw_group_direct_peer_stores", "luw_group_one_phase", "luw_group_scatter", "luw_group_gather", "luw_group_upload",
+        "luw_group_download",
     "luw_group_initialize", "luw_group_run", "luw_group_run_sampled", "luw_group_get_t", "luw_group_set_f", "luw_group_set_coriolis",
     "luw_group_voxelize_mesh", "luw_group_vk_inlet_attach", "luw_group_gather_attach", "luw_group_gather_u", "luw_group_stats_reset",
     "luw_group_stats_download", "luw_group_transport", "luw_device_info", "luw_p2p_info", "luw_fields_every_step", "luw_step_boxes",

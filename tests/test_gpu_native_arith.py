@@ -149,7 +149,8 @@ def test_native_arithmetic_gives_a_cell_the_same_values_in_either_kernel(luw, fo
         fi = np.asarray(g.download_fi()).copy(); fi[fi == 0x8000] = 0
         out.append((fi, g.u.data.copy(), g.rho.data.copy()))
         g.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)) and np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)) and np.array_equal(out[0][2],
+        out[1][2])
 
 
 def test_native_arithmetic_is_ignored_for_fp32_and_in_sampled_steps(luw):
