@@ -201,6 +201,9 @@ DEFAULT_BLOCKS = ("c2_f32", "c3_fp16c", "c3_fp16c_coriolis", "c3_fp16c_thermal",
     "c4_rank_4x2x1_f32", "c5_rank_4x2x1_fp16c_coriolis")
 
 
+DEFAULT_EXACT_TWINS = ("tile512_urban_fp16c_coriolis", "c5_rank_4x2x1_fp16c_coriolis")
+
+
 def child_block(flag, key, local_rank, *extra):
     """ONE secondary block in a fresh child process (its JSON is the child's last stdout line); a failure is an `error` entry, never an exception"""
     import subprocess
@@ -352,7 +355,14 @@ def main():
                     continue
                 sec[key] = child_block(flag_of(key), key, local_rank)
                 sys.stderr.write("bench.py: secondary block %s: %s\n" % (key, block_note(sec[key]))); sys.stderr.flush()
-                if not args.all_blocks or "error" in sec[key]:
+                if "error" in sec[key]:
+                    continue
+                if not args.all_blocks:
+                    # (the default line still shows what the FP16C arithmetic choice is worth on configs[4]'s physics: the exact twin of its two blocks)
+                    if key in DEFAULT_EXACT_TWINS:
+                        ex = child_block(flag_of(key), key, local_rank, "--arith", "exact")
+                        sec[key]["exact"] = {k: ex[k] for k in ("ms_per_step", "arith", "error") if k in ex}
+                        if "roofline" in ex: sec[key]["exact"]["roofline"] = {"frac": ex["roofline"]["frac"]}
                     continue
                 # FP16C blocks: the same block once more with the bit-exact kernels, again in a fresh process; the block's own numbers are the default
                 # arithmetic's ("arith": "native"), the twin sits under "exact"

@@ -129,6 +129,40 @@ def reference_self_distance(cases=("CaseA", "CaseL")):
     return out
 
 
+def c1_planes_rmse(ddf=None, arith="native", fixture="ref_fp32", other="ref_shipped"):
+    """BASELINE configs[0] at full size against the REAL reference: the deck tests/golden/refcases/CaseC1 (128^3, K = 100) through the deck driver, u at
+    K = 100 on the three orthogonal mid-planes the reference's builds left as fixtures (tests/golden/ref_{fp32,shipped}_C1_planes.npz); RMSE in lattice units over the
+    non-solid cells of the planes.  ddf=None: no run -- the two fixtures against each other (the reference's FP32 build against its shipped FP16C build)."""
+    import glob, shutil, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from vtkio import read_vtk
+    gdir = os.path.join(ROOT, "tests", "golden")
+    gold = np.load(os.path.join(gdir, fixture + "_C1_planes.npz"))
+    fac = np.float32(7.838) / np.float32(0.1)
+    cut = lambda a: {"xy": a[a.shape[0] // 2], "xz": a[:, a.shape[1] // 2], "yz": a[:, :, a.shape[2] // 2]}
+    if ddf is None:
+        b = np.load(os.path.join(gdir, other + "_C1_planes.npz"))
+        mine = {pl: b["u100_" + pl] for pl in ("xy", "xz", "yz")}
+    else:
+        tmp = tempfile.mkdtemp()
+        try:
+            shutil.copytree(os.path.join(gdir, "refcases", "CaseC1"), os.path.join(tmp, "CaseC1"))
+            r = subprocess.run(
+                [os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver"), os.path.join(tmp, "CaseC1", "conf.luwpf"), "--ddf", ddf, "--arith",
+                arith], capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None
+            mine = cut(read_vtk(glob.glob(os.path.join(tmp, "CaseC1", "RESULTS", "vtk", "*_raw_u-000000100.vtk"))[0])[1]["data"])
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    sq, cells = 0.0, 0
+    for pl, a in mine.items():
+        fluid = ~gold["solid_" + pl]
+        d = ((a - gold["u100_" + pl]) / fac)[fluid].astype(np.float64)
+        sq += float((d ** 2).sum()); cells += int(fluid.sum())
+    return float("%.3e" % np.sqrt(sq / cells))
+
+
 def reference_parity():
     """u-field RMSE against the REAL reference, measured now through the deck driver on this GPU: FP32 DDFs against the reference's FP32 build (case B: one
     building, LES), and the SHIPPED precision -- FP16C DDFs -- against the reference's shipped build (case A: LES with nudging + sponge; case L: laminar),
@@ -143,7 +177,13 @@ def reference_parity():
         self_d = dict(reference_self_distance(), what="the reference's FP32 build against its own shipped FP16C build, same decks (committed fixtures)")
     except Exception as e:
         self_d = {"error": str(e)[:120]}
-    return {"reference_self_distance": self_d, "u_rmse_vs_reference": k64, "unit": "lattice units", "steps": 64, "tolerance": 1e-5,
+    try:
+        c1 = {"lattice": [128, 128, 128], "steps": 100, "what": "tests/golden/refcases/CaseC1 (BASELINE configs[0] as a deck), u on three mid-planes",
+            "fp32": c1_planes_rmse("fp32", "exact", "ref_fp32"), "fp16c_native_vs_shipped": c1_planes_rmse("fp16c", "native", "ref_shipped"),
+            "fp16c_exact_vs_shipped": c1_planes_rmse("fp16c", "exact", "ref_shipped"), "reference_fp32_vs_shipped": c1_planes_rmse()}
+    except Exception as e:
+        c1 = {"error": str(e)[:120]}
+    return {"c1_planes": c1, "reference_self_distance": self_d, "u_rmse_vs_reference": k64, "unit": "lattice units", "steps": 64, "tolerance": 1e-5,
             "case": "tests/golden/refcases/CaseB (48x40x24, FP32 DDFs)", "lattice": [48, 40, 24], "cells": 48 * 40 * 24,
             "fp32": dict(fp32, case="CaseB", within_tolerance=bool(k64 is not None and k64 < 1e-5)),
             "shipped": dict(shipped, precision="FP16C DDFs (what the reference ships), reference build FP16C + TEMPERATURE",

@@ -77,8 +77,8 @@ def parity_summary(p):
         out["fp16c_within_tolerance_at_K64"] = sh["within_tolerance_at_K64"]
     if isinstance(p.get("reference_self_distance"), dict):     # the reference's FP32 build against its own FP16C build, K = 64
         out["reference_self_distance_K64"] = {c: v.get("K64") for c, v in p["reference_self_distance"].items() if isinstance(v, dict)}
-    if "c1_planes" in p:
-        out["c1_planes"] = p["c1_planes"]
+    if isinstance(p.get("c1_planes"), dict):                   # configs[0] at full size (128^3, K = 100) against the real reference's planes
+        out["c1_K100"] = pick(p["c1_planes"], "fp32", "fp16c_native_vs_shipped", "fp16c_exact_vs_shipped", "reference_fp32_vs_shipped", "error")
     return out
 
 

@@ -20,6 +20,8 @@ Cases (all 48x40xNz grids, cell 2 m, wind from 270 deg = +x, VK inlet off, singl
   N1..N4  *.luw (NWP) decks on the case-B geometry with synthetic SurfData CSVs: N1 patch-driven 2-D mapping + flux
      correction + Coriolis; N2 KNN-HD (high_order) + flux correction; N3 nearest-sample + nudging + sponge + open
      downstream face; N4 patch mapping with an open downstream face
+  C1 BASELINE configs[0] as a deck: 128^3 cells of 2 m, the 12-point profile of the reference's example deck, no buildings (ground slab only), nudging,
+     sponge and VK inlet off, 100 steps (outputs at 50 and 100, last 4 averaged)
   G,H case B with a 'city' STL (aligned / off-grid / rotated boxes, roofs, pyramid, floating tetrahedron, overlapping
      boxes) at cell 2 m and 2.5 m: voxeliser goldens
 """
@@ -81,7 +83,12 @@ def city_tris(s):
     t += box_tris(74.1*s, 86.3*s, 64.8*s, 75.6*s, 0.0, 15.2*s)
     return t
 
-def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0, z0=0.0, dem=False, angles="[270]"):
+# BASELINE configs[0]: the 12-point profile of the reference's example_ProfileResearch_noDEM deck (height above ground in m, speed in m/s: data)
+C1_PROFILE = [(1.25, 2.847), (2.5, 3.042), (5, 3.2604), (7.5, 3.4086), (12.5, 3.7674), (25, 4.3602), (50, 5.109), (75, 5.694), (100, 6.162), (150, 6.9654),
+    (200, 7.3944), (250, 7.838)]
+
+def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64, unsteady=8, purge=4, vk=False, cell=2.0, z0=0.0, dem=False, angles="[270]",
+        profile=None):
     """s = length scale (metres per 'unit'); the box geometry is dims units (default 96 x 80 x 48), base slab 4 units."""
     d = os.path.join(root, name)
     os.makedirs(os.path.join(d, "proj_temp"), exist_ok=True)
@@ -103,8 +110,8 @@ def write_case(root, name, s, extra, dims=(96, 80, 48), building=True, nstep=64,
     write_stl(os.path.join(d, "proj_temp", name + "_PF.stl"), tris)
     with open(os.path.join(d, "wind_bc", "profile.dat"), "w") as f:
         f.write("z,U\n")
-        for z, u in [(1,1.9),(2,2.4),(4,2.9),(8,3.4),(12,3.8),(20,4.3),(30,4.7),(44,5.0),(60,5.0)]:
-            f.write("%g\t%g\n" % (z*s if s >= 1 else z, u))
+        for z, u in (profile or [(1,1.9),(2,2.4),(4,2.9),(8,3.4),(12,3.8),(20,4.3),(30,4.7),(44,5.0),(60,5.0)]):
+            f.write("%g\t%g\n" % ((z*s if s >= 1 else z) if profile is None else z, u))
     deck = [
         "// LUW deck (synthetic, generated by tests/golden/make_refcases.py)",
         "casename = %s" % name,
@@ -250,6 +257,8 @@ if __name__ == "__main__":
     write_luw_case(root, "CaseT2", "cloud", off + ["high_order = true", "flux_correction = false", "coriolis_term = false"], with_T=True)
     write_luw_case(root, "CaseT3", "cloud", ["enable_buffer_nudging = false", "enable_top_sponge = true", "sponge_thickness_m = 8", "sponge_tau_s = 2", "high_order = false",
                                              "flux_correction = false", "coriolis_term = false", "downstream_open_face = true"], with_T=True)
+    # C1: BASELINE configs[0] as a deck (128^3 cells of 2 m, the reference's example profile, no buildings): the size-class fixture of tests/test_gpu_c1.py
+    write_case(root, "CaseC1", 1.0, off, dims=(256, 256, 256), building=False, nstep=100, unsteady=50, purge=4, profile=C1_PROFILE)
     # performance decks for timing the reference itself on the GPU box (not fixtures: generated on demand)
     if "--perf" in sys.argv:
         write_case(root, "Perf512", 1.0, off, dims=(1024, 1024, 1024), building=False, nstep=300, unsteady=0, purge=0)

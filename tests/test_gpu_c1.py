@@ -7,8 +7,18 @@ same profile, rho = 1 -- stepped by the HIP path and by the CPU oracle from iden
   * laminar regime, nu = 0.1 / 6, K = 1000 steps, FP32.
 
 Bar: bit for bit (rho, u, all 19 DDF planes), which is far inside the north star's 1e-5 RMSE gate at these horizons; the oracle itself is
-pinned to the real reference at K = 64 on the committed cases (tests/test_oracle_vs_reference.py)."""
+pinned to the real reference at K = 64 on the committed cases (tests/test_oracle_vs_reference.py).
+
+And against the REAL reference at this size: the same configuration as a deck (tests/golden/refcases/CaseC1: 128^3 cells of 2 m, that profile, a ground
+slab, K = 100) went through both builds of the reference on an MI355X (tools/reference_session_c1.sh); three orthogonal mid-planes of u at K = 100 and of
+u_avg, with the fields' global minimum / maximum / mean, are committed as tests/golden/ref_{fp32,shipped}_C1_planes.npz.  test_c1_deck_against_the_real_
+reference runs the deck driver on the deck and holds its planes to them."""
+import glob
 import math
+import os
+import shutil
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -76,3 +86,50 @@ def test_c1_literal(luw, regime, fp16c, steps):
     if regime == "turbulent":
         assert uy > 0.0                                        # the flow left the pure profile (corner cells of the TYPE_E shell shed it)
     g.close()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+DRIVER = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
+SI_PER_LU = np.float32(7.838) / np.float32(0.1)           # si_ref_u = the profile's maximum at u_lbm = 0.1
+
+
+def planes_of(a):
+    nz, ny, nx = a.shape[:3]
+    return {"xy": a[nz // 2], "xz": a[:, ny // 2], "yz": a[:, :, nx // 2]}
+
+
+@pytest.mark.parametrize("ddf,arith,fixture,ceiling",
+    [("fp32", "exact", "ref_fp32", 1e-5), ("fp16c", "native", "ref_shipped", 1e-4), ("fp16c", "exact", "ref_shipped", 1e-4),
+    ("fp16c", "native", "ref_fp32", 1e-4)])
+def test_c1_deck_against_the_real_reference(luw, tmp_path, ddf, arith, fixture, ceiling):
+    """FP32 DDFs: inside the north star's 1e-5 with a factor of forty (2.5e-7 at K = 100).  FP16C DDFs: the shipped precision against the shipped build, native
+    (the driver's default) and exact arithmetic, and the native run against the reference's FP32 build -- every such pair sits at 3-4e-5, which is where the
+    reference's shipped build sits against its OWN FP32 build (3.2e-5, test_the_reference_at_c1_size_against_itself): recorded values x 2 (check_gate)."""
+    from helpers import check_gate
+    sys.path.insert(0, GOLD)
+    from vtkio import read_vtk
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "-s"])
+    proj = str(tmp_path / "CaseC1")
+    shutil.copytree(os.path.join(GOLD, "refcases", "CaseC1"), proj)
+    r = subprocess.run([DRIVER, os.path.join(proj, "conf.luwpf"), "--ddf", ddf, "--arith", arith], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    gold = np.load(os.path.join(GOLD, fixture + "_C1_planes.npz"))
+    vt = os.path.join(proj, "RESULTS", "vtk")
+    h, f = read_vtk(glob.glob(os.path.join(vt, "*_raw_u-000000100.vtk"))[0])
+    ha, fa = read_vtk(glob.glob(os.path.join(vt, "*_avg-000000100.vtk"))[0])
+    assert tuple(h["dims"]) == tuple(int(v) for v in gold["dims"]) == (128, 128, 128)
+    assert int((fa["fluid"][..., 0] == 0).sum()) == int(gold["solid_count"])                 # the same voxels are solid
+    for name, mine in (("u100", f["data"]), ("u_avg", fa["u_avg"])):
+        sq, cells = 0.0, 0
+        for pl, a in planes_of(mine).items():
+            fluid = ~gold["solid_" + pl]
+            d = ((a - gold["%s_%s" % (name, pl)]) / SI_PER_LU)[fluid].astype(np.float64)
+            sq += float((d ** 2).sum()); cells += int(fluid.sum())
+        rm = math.sqrt(sq / cells)
+        check_gate("c1deck:%s:%s:%s:%s" % (ddf, arith, fixture, name), rm, ceiling, "%s RMSE over the three mid-planes, lattice units" % name)
+        if ddf == "fp32":
+            assert rm < 1e-6
+        fl3 = fa["fluid"][..., 0] != 0
+        st = np.array([mine[fl3].min(0), mine[fl3].max(0), mine[fl3].astype(np.float64).mean(0)])
+        assert np.abs(st - gold[name + "_stats"]).max() / SI_PER_LU < (2e-6 if ddf == "fp32" else 2e-3), (name, st, gold[name + "_stats"])

@@ -134,3 +134,17 @@ def test_the_reference_moves_from_itself_by_more_than_the_fp16c_distances_measur
     recorded = json.load(open(os.path.join(GOLD, "observed_rmse.json")))
     ours = recorded["driver:native:ref_shipped_CaseA:final"]
     assert ours < 1.5 * d["CaseA"]["K64"]                      # this repo's FP16C run against the shipped build: the same order as the reference against itself
+
+
+def test_the_reference_at_c1_size_against_itself():
+    """from the fixtures alone (no GPU work): the reference's shipped FP16C build against its own FP32 build on the three mid-planes of the 128^3 deck at
+    K = 100 -- 3.2e-5 in lattice units (u_avg 2.2e-5), three times the north star's 1e-5: the yardstick for the FP16C gates above"""
+    a, b = np.load(os.path.join(GOLD, "ref_fp32_C1_planes.npz")), np.load(os.path.join(GOLD, "ref_shipped_C1_planes.npz"))
+    assert np.array_equal(a["solid_xy"], b["solid_xy"]) and int(a["solid_count"]) == int(b["solid_count"])
+    for name, lo, hi in (("u100", 2e-5, 5e-5), ("u_avg", 1e-5, 4e-5)):
+        sq, cells = 0.0, 0
+        for pl in ("xy", "xz", "yz"):
+            fluid = ~a["solid_" + pl]
+            d = ((a["%s_%s" % (name, pl)] - b["%s_%s" % (name, pl)]) / (np.float32(7.838) / np.float32(0.1)))[fluid].astype(np.float64)
+            sq += float((d ** 2).sum()); cells += int(fluid.sum())
+        assert lo < np.sqrt(sq / cells) < hi, (name, np.sqrt(sq / cells))

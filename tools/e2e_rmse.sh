@@ -2,7 +2,7 @@
 # u-field RMSE against the REAL reference at a bench-class size (GPU box, via gpurun): the same 512x512x128 profile deck (one
 # building, nudging + sponge on) runs K steps on the reference's FP32 build and on this repo's driver (--ddf fp32), and on the
 # shipped FP16C build vs --ddf fp16c; prints sqrt(mean |u_ours - u_ref|^2) over the non-solid cells in lattice units.
-# usage: tools/e2e_rmse.sh [K]
+# usage: tools/e2e_rmse.sh [K]      (LUW_E2E_ARITH=exact|native: the FP16C run's arithmetic, default native like the driver's)
 set -u
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"; cd "$R"
 K="${1:-100}"
@@ -18,7 +18,7 @@ for tag in ref_fp32 ref_shipped ours_fp32 ours_fp16c; do cp -r "$W/R" "$W/$tag";
 ( cd oracle/_ref && ./FluidX3D_fp32 "$W/ref_fp32/conf.luwpf" > "$W/ref_fp32/console.log" 2>&1 </dev/null )
 ( cd oracle/_ref && ./FluidX3D "$W/ref_shipped/conf.luwpf" > "$W/ref_shipped/console.log" 2>&1 </dev/null )
 latticeurbanwind_amd/host/luw_driver "$W/ours_fp32/conf.luwpf" --ddf fp32 > "$W/ours_fp32/console.log" 2>&1
-latticeurbanwind_amd/host/luw_driver "$W/ours_fp16c/conf.luwpf" --ddf fp16c > "$W/ours_fp16c/console.log" 2>&1
+latticeurbanwind_amd/host/luw_driver "$W/ours_fp16c/conf.luwpf" --ddf fp16c --arith "${LUW_E2E_ARITH:-native}" > "$W/ours_fp16c/console.log" 2>&1
 python3 - "$W" "$K" <<'PY'
 import sys, os, glob
 import numpy as np
