@@ -132,7 +132,8 @@ def reference_self_distance(cases=("CaseA", "CaseL")):
 def c1_planes_rmse(ddf=None, arith="native", fixture="ref_fp32", other="ref_shipped"):
     """BASELINE configs[0] at full size against the REAL reference: the deck tests/golden/refcases/CaseC1 (128^3, K = 100) through the deck driver, u at
     K = 100 on the three orthogonal mid-planes the reference's builds left as fixtures (tests/golden/ref_{fp32,shipped}_C1_planes.npz); RMSE in lattice
-    units over the non-solid cells of the planes.  ddf=None: no run -- the two fixtures against each other (the reference's FP32 build against its shipped FP16C build)."""
+    units over the non-solid cells of the planes.  ddf=None: no run -- the two fixtures against each other (the reference's FP32 build against its shipped
+    FP16C build)."""
     import glob, shutil, subprocess, tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from vtkio import read_vtk
