@@ -55,7 +55,7 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
         if coriolis:
             lbm.set_coriolis(*coriolis_omega())
         from latticeurbanwind_amd import capi as _capi
-        placement = _capi.placement_info(lbm._h)     # what luw_create's placement search did (DESIGN.md section 5)
+        placement = _capi.placement_info(lbm._h)     # what luw_create's placement search did (DESIGN.md section 4)
         lbm.run(0)
         lbm.run(warmup)
         torch.cuda.synchronize()

@@ -311,7 +311,7 @@ def attach_traffic(roof, key, kernel):
     (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
     and keyed on the full configuration; null when no profile of exactly this workload exists"""
     # newest round first
-    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (4, 3, 2)) if os.path.exists(q)), None)
+    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (5, 4, 3, 2)) if os.path.exists(q)), None)
     if kernel == "auto" and prof:
         pr = json.load(open(prof))
         roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])

@@ -120,7 +120,7 @@ int luw_format_float9(float x, char* text, uint64_t size);
 /* life cycle: LBM::LBM (FX/lbm.cpp:1057-1112) / LBM::~LBM.
  * For DDF arrays of 1 GiB and more (planes under 1.5 GiB) luw_create times four steps of the real kernel on the freshly mapped array and, while that is
  * under the rate of the fast class of placements, makes up to FIVE further draws of physical memory (1 GiB chunks again, 4 GiB, 2 GiB, hipMalloc, 512 MiB
- * chunks), keeping the fastest (physical placement changes the step time by up to 10 % on MI355X, DESIGN.md section 5).  Every array tried stays mapped
+ * chunks), keeping the fastest (physical placement changes the step time by up to 10 % on MI355X, DESIGN.md section 4).  Every array tried stays mapped
  * until the search ends: the PEAK device memory of luw_create is up to six DDF arrays, each further draw only if free memory exceeds one array + 40 B per
  * cell + 2 GiB -- a co-tenant process allocating on the same device in that window can run out of memory; LUW_TUNE_PLACEMENT=0 (or =<n> draws) bounds
  * it.  Nothing of the search outlives luw_create (one search per process and device); it is skipped on devices that several solvers share.

@@ -39,7 +39,7 @@ def main():
             flags, T = thermal_state(flags, gN)
             # boundary cells carry their temperature as a preset, as in every LUW deck (FX/setup.cpp:5945-5985): the top sponge then relaxes T towards an
             # INPUT.  (A top-layer cell that computes its T is read and rewritten by the same launch -- order-dependent in the reference kernel itself,
-            # and the one place where the GPU kernels and the sequential oracle may differ; DESIGN.md section 5.)
+            # and the one place where the GPU kernels and the sequential oracle may differ; DESIGN.md section 3.)
             flags = flags.copy(); flags[(flags & 3) == 2] |= 4
         kw = dict(alpha=0.004) if thermal else {}
         nud = dict(n_cells=3, inv_tau=0.0133333, downstream_face=2, nudge_vertical=1); spg = dict(n_cells=2, inv_tau=0.02)

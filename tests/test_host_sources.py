@@ -64,3 +64,12 @@ def test_reflow_changes_white_space_only(tmp_path):
     squeeze = lambda s: re.sub(r"\s+", "", s)
     assert squeeze("".join(l for l in out if not l.strip().startswith("//"))) == squeeze(line.split(" // why")[0])
     assert any("why this is here" in l for l in out)
+
+
+def test_design_document_stays_reviewable():
+    """DESIGN.md says what the code is today in at most 40 KB and lines of at most 160 characters; narratives of earlier rounds live in profiles/history.md"""
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert len(text.encode()) <= 40 * 1024
+    assert [i + 1 for i, l in enumerate(text.splitlines()) if len(l) > 160] == []
+    for section in ("## 1. The path and its boundary", "## 3. Oracle", "## 4. Data layout in HBM", "## 5. Kernels and their rooflines", "## 6. Multi-GPU"):
+        assert section in text

@@ -1,0 +1,72 @@
+#!/usr/bin/env bash
+# First contact with a multi-GPU node (nothing that crosses a device boundary has ever run: one-GPU boxes only).  Stage by stage, a FRESH process per
+# stage, the first failure ends the script with that stage's number as exit code; nothing is retried and no process that has touched a GPU execs another
+# program (each stage is a child of this shell).
+#   1  the node as the HIP runtime sees it: devices, PCI bus ids, the peer-access / link-type / hop matrix (luw_device_info, luw_p2p_info)
+#   2  the one-process host across devices: tests/test_gpu_group.py -k distinct_devices (peer stores into another GPU's buffers, cross-device stream waits,
+#      hipMemcpyPeerAsync, multi-rank RCCL communicators; one host thread and one per domain)
+#   3  two ranks over RCCL: bench.py --gpus 2 --steps 20 -- its self-check against the CPU oracle through the real transport must pass before anything is timed
+#   4  all GPUs: bench.py --gpus N (N = device count, at most 8) -- the line carries rccl.world_size, every rank's PCI bus id and the link type to each
+#      halo neighbour, and the one-process host's block
+# usage: tools/first_contact.sh [--share-device D] [--dry-run] [--out DIR]
+#   --share-device D  rehearsal on a ONE-GPU box: stages 3 and 4 with every rank on device D and the faces staged through gloo (stage 4 with 4 ranks: a test
+#                     box allows six processes on its GPU); stage 2 is skipped by its own test (needs two GPUs)
+#   --dry-run         rehearsal of the control flow WITHOUT a GPU: every stage prints its command instead of running it; FIRST_CONTACT_FAIL=<n> makes stage n fail
+set -u
+R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
+SHARE=""; DRY=0; OUT="gpurun_out/first_contact"
+while [ $# -gt 0 ]; do case "$1" in --share-device) SHARE="$2"; shift 2;; --dry-run) DRY=1; shift;; --out) OUT="$2"; shift 2;; *) echo "unknown option $1" >&2; exit 64;; esac; done
+mkdir -p "$OUT"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+stage() { # stage <number> <what> <command...>: runs it as a child process, logs to $OUT/stage<number>.log, ends the script on failure
+  local n="$1" what="$2"; shift 2
+  echo "== stage $n: $what"
+  if [ "$DRY" = 1 ]; then
+    echo "   [dry run] $*" | tee "$OUT/stage$n.log"
+    if [ "${FIRST_CONTACT_FAIL:-0}" = "$n" ]; then echo "== stage $n FAILED (injected)"; exit "$n"; fi
+    return 0
+  fi
+  "$@" > "$OUT/stage$n.log" 2>&1; local rc=$?
+  tail -n 12 "$OUT/stage$n.log" | sed 's/^/   /'
+  if [ $rc -ne 0 ]; then echo "== stage $n FAILED (exit $rc): $OUT/stage$n.log"; exit "$n"; fi
+}
+NDEV=2
+if [ "$DRY" != 1 ]; then NDEV=$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0); fi
+PORT=$((29500 + ($$ % 2000)))
+stage 1 "devices and links" python3 -c "
+import sys; sys.path.insert(0, '$R')
+import latticeurbanwind_amd as luw
+from latticeurbanwind_amd import capi
+import torch
+luw.load(); n = torch.cuda.device_count()
+for d in range(n): print(capi.device_info(d))
+print('from\\\\to ' + ' '.join('%9d' % j for j in range(n)))
+for i in range(n):
+    row = []
+    for j in range(n):
+        p = capi.p2p_info(i, j) if i != j else None
+        row.append('     self' if p is None else '%9s' % ('%s/%s%s' % (p['link'], p['hops'], '' if p['can_access'] else '!')))
+    print('%7d  ' % i + ' '.join(row))
+print('(link type / hops; ! = no peer access)')
+assert n >= 1
+"
+stage 2 "one-process host across devices" python3 -m pytest tests/test_gpu_group.py -k distinct_devices -x -q
+if [ -n "$SHARE" ]; then EXTRA=(--share-device "$SHARE" --size 384 64 64); N4=4; else EXTRA=(); N4=$(( NDEV < 8 ? NDEV : 8 )); fi
+check_line() { # the printed line of a bench.py --gpus N run: parity passed, the communicator has N ranks, every rank names its bus id and links
+  python3 -c "
+import json, sys
+lines = [l for l in open('$1') if l.startswith('{')]
+assert len(lines) == 1, 'expected ONE JSON line, found %d' % len(lines)
+d = json.loads(lines[0]); n = int('$2')
+assert d['n_gpus'] == n and d['value'] and d['parity'].get('ok') is True and d['rccl']['world_size'] == n, d
+assert len(d['ranks']) == n and all(r['bus'] and r['links'] for r in d['ranks']), d['ranks']
+print('   %d ranks: %.0f MLUPS, %.3f ms per step, parity ok (%d cases), links %s' % (n, d['value'], d['ms_per_step'], d['parity']['cases'], sorted({v for r in d['ranks'] for v in r['links'].values() if v})))
+"
+}
+bench_n() { python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$1" --master-addr 127.0.0.1 --master-port "$2" bench.py --gpus "$1" --steps 20 --warmup 5 "${EXTRA[@]}"; }
+stage 3 "two ranks over RCCL, self-check first" bench_n 2 "$PORT"
+[ "$DRY" = 1 ] || check_line "$OUT/stage3.log" 2 || { echo "== stage 3 FAILED (line check)"; exit 3; }
+[ -n "$SHARE" ] && EXTRA+=(--no-group-host)      # (four ranks + a child of rank 0 + the caller: more processes than a test box allows on its GPU)
+stage 4 "$N4 ranks" bench_n "$N4" $((PORT + 1))
+[ "$DRY" = 1 ] || check_line "$OUT/stage4.log" "$N4" || { echo "== stage 4 FAILED (line check)"; exit 4; }
+echo "== first contact complete: $OUT"

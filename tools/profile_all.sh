@@ -9,14 +9,17 @@ ALL="c3_f32 c3_fp16c c3_fp16c_cor c3_fp16c_th c2_f32 c2_fp16c cube_f32 cube_fp16
 for blk in ${@:-$ALL}; do
   case $blk in
     c3_f32) key=f32_1024x1024x256_bld; args="--workload c3"; kern=k_stream_collide_s; algo="";;
-    c3_fp16c) key=fp16c_1024x1024x256_bld; args="--workload c3 --dtype fp16c"; kern=k_stream_collide_p; algo="";;
-    c3_fp16c_cor) key=fp16c_1024x1024x256_bld_cor; args="--workload c3 --dtype fp16c --coriolis"; kern=k_stream_collide_p; algo="";;
-    c3_fp16c_th) key=fp16c_1024x1024x256_bld_th; args="--workload c3 --dtype fp16c --thermal"; kern=k_stream_collide_p; algo="";;
+    # FP16C: the bit-exact kernels (--arith exact) under the plain keys, the native-arithmetic ones (bench.py's and the driver's default) under _nat
+    c3_fp16c) key=fp16c_1024x1024x256_bld; args="--workload c3 --dtype fp16c --arith exact"; kern=k_stream_collide_p; algo="";;
+    c3_fp16c_cor) key=fp16c_1024x1024x256_bld_cor; args="--workload c3 --dtype fp16c --coriolis --arith exact"; kern=k_stream_collide_p; algo="";;
+    c3_fp16c_th) key=fp16c_1024x1024x256_bld_th; args="--workload c3 --dtype fp16c --thermal --arith exact"; kern=k_stream_collide_p; algo="";;
     c2_f32) key=f32_512x512x512; args="--workload c2"; kern=k_stream_collide_s; algo="";;
-    c2_fp16c) key=fp16c_512x512x512; args="--workload c2 --dtype fp16c"; kern=k_stream_collide_p; algo="";;
+    c2_fp16c) key=fp16c_512x512x512; args="--workload c2 --dtype fp16c --arith exact"; kern=k_stream_collide_p; algo="";;
+    c2_fp16c_nat) key=fp16c_512x512x512_nat; args="--workload c2 --dtype fp16c --arith native"; kern=k_stream_collide_p; algo="";;
     cube_f32) key=f32_1024x1024x1024; args="--workload cube1024"; kern=k_stream_collide_s; algo="";;
-    cube_fp16c) key=fp16c_1024x1024x1024; args="--workload cube1024 --dtype fp16c"; kern=k_stream_collide_p; algo="";;
-    urban_fp16c_cor) key=fp16c_512x512x512_bld_urban_cor; args="--workload tile512 --urban --dtype fp16c --coriolis"; kern=k_stream_collide_p; algo="";;
+    cube_fp16c) key=fp16c_1024x1024x1024; args="--workload cube1024 --dtype fp16c --arith exact"; kern=k_stream_collide_p; algo="";;
+    cube_fp16c_nat) key=fp16c_1024x1024x1024_nat; args="--workload cube1024 --dtype fp16c --arith native"; kern=k_stream_collide_p; algo="";;
+    urban_fp16c_cor) key=fp16c_512x512x512_bld_urban_cor; args="--workload tile512 --urban --dtype fp16c --coriolis --arith exact"; kern=k_stream_collide_p; algo="";;
     # the same FP16C blocks with the native-arithmetic kernels (LUW_OPT_NATIVE_ARITH)
     c3_fp16c_nat) key=fp16c_1024x1024x256_bld_nat; args="--workload c3 --dtype fp16c --arith native"; kern=k_stream_collide_p; algo="";;
     c3_fp16c_cor_nat) key=fp16c_1024x1024x256_bld_cor_nat; args="--workload c3 --dtype fp16c --coriolis --arith native"; kern=k_stream_collide_p; algo="";;
