@@ -4,7 +4,7 @@
 
 // One block of device memory.  Two ways to get it: hipMalloc, or the virtual memory management API: ONE address range backed by
 // physical chunks of a chosen size (hipMemCreate / hipMemMap), which fixes the size of the physically contiguous pieces a lattice
-// array is made of instead of leaving it to the state of the driver's heap (alloc_vmm_chunk below, DESIGN.md section 5).
+// array is made of instead of leaving it to the state of the driver's heap (alloc_vmm_chunk below, DESIGN.md section 4).
 struct DevBlock {
 	void* base = nullptr; size_t bytes = 0u;
 	std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk_bytes = 0u; // VMM only
