@@ -13,5 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("script,cases,seed", [("fuzz_exchange_gpu.py", 24, 3), ("fuzz_exchange_group_gpu.py", 60, 5)])
 def test_exchange_fuzz_slice(luw, script, cases, seed):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", script), str(cases), str(seed)], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", script), str(cases), str(seed)], capture_output=True, text=True, timeout=900,
+        cwd=ROOT)
     assert r.returncode == 0 and "fuzz: %d cases, 0 different" % cases in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
