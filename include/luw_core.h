@@ -64,10 +64,12 @@ extern "C" {
                                            luw_download(), which yields identical values whenever they are observed */
 #define LUW_OPT_TEMPERATURE 0x8u        /* thermal D3Q7 lattice (TEMPERATURE, FX/kernel.cpp:1306-1335,1639-1684): T field, TYPE_T cells, cfg.alpha */
 #define LUW_OPT_NO_SUBGRID 0x4u         /* disable the Smagorinsky-Lilly model (reference: always on, FX/defines.hpp:25) */
-/* FP16C pair kernel in the hardware's own arithmetic: one v_rcp_f32 for the divisions by the density, v_sqrt_f32 / v_rcp_f32 for the Smagorinsky rate,
- * free fma contraction, moment / stress sums in trees -- what the reference's own build does (-cl-mad-enable, native division: FX/opencl.hpp:305,
- * FX/kernel.cpp:1088-1100,1735).  Results then agree with the bit-exact default (and with the CPU oracle) to rounding, within the gates of
- * tests/test_gpu_native_arith.py, instead of bit for bit.  Ignored for FP32 DDFs and where the one-cell kernel runs. */
+/* FP16C kernels in the hardware's own arithmetic: one v_rcp_f32 for the divisions by the density, v_sqrt_f32 / v_rcp_f32 for the Smagorinsky rate,
+ * every fused multiply-add written out, moment / stress sums in trees, populations scaled by 2^-112 between decode and encode -- what the reference's own
+ * build does in spirit (-cl-mad-enable, native division: FX/opencl.hpp:305, FX/kernel.cpp:1088-1100,1735).  Results then agree with the bit-exact
+ * default of this interface (and with the CPU oracle) to rounding, within the gates of tests/test_gpu_native_arith.py, instead of bit for bit; they are
+ * deterministic and the same in the pair and the one-cell kernel, i.e. independent of how a lattice is cut.  The deck driver and bench.py set this bit
+ * for FP16C unless asked for `--arith exact`.  Ignored for FP32 DDFs and in sampled steps. */
 #define LUW_OPT_NATIVE_ARITH 0x10u
 
 /* kernel selection (cfg.kernel, luw_set_kernel): all three compute the same values.  (The A/B and measurement-only variants of the tools build have
