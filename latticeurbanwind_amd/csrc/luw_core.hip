@@ -14,7 +14,8 @@
 //   luw_placement.hpp       luw_create's placement search for the DDF array
 //   luw_api.hpp / luw_api_aux.hpp / luw_api_run.hpp   the C-ABI of one domain (include/luw_core.h, luw_core_dev.h)
 //   luw_step.hpp            one domain's share of a decomposed step: boxes, launches on two streams, pipelining events (luw_domain_step_*; both hosts)
-//   luw_group.hpp           the multi-domain host (luw_group_*), luw_export.hpp the VTK payloads produced on the devices
+//   luw_group.hpp           the multi-domain host: exchange routes and step loop (+ luw_group_rccl.hpp), luw_group_api.hpp its C-ABI (luw_group_*),
+//                           luw_export.hpp the VTK payloads produced on the devices
 // This file is the translation unit: nothing but the includes.
 //
 // Memory layout in HBM: SoA planes fi[q][z][y][x] with x-pitch Px (multiple of 64) and plane stride Np=Px*Ny*Nz, every
@@ -57,4 +58,5 @@ using namespace luw;
 
 #include "luw_step.hpp"
 #include "luw_group.hpp"
+#include "luw_group_api.hpp"
 #include "luw_export.hpp"

@@ -88,7 +88,7 @@ class DomainLayout:
         """cells of edge e's line: the local extent of the axis its population does not move along"""
         return self.lN[[a for a in range(3) if C19[7 + e][a] == 0][0]]
 
-    # ---- boxes (x0,x1,y0,y1,z0,z1) in local coordinates: ONE implementation, the library's (luw_step_boxes, csrc/luw_group.hpp: pure host arithmetic, also
+    # ---- boxes (x0,x1,y0,y1,z0,z1) in local coordinates: ONE implementation, the library's (luw_step_boxes, csrc/luw_step.hpp: pure host arithmetic, also
     # what the one-process host luw_group_* cuts its domains with).  whole = the non-halo cells; interior + the disjoint shell slabs cover it exactly once;
     # y, z slabs are the one cell layer next to a halo (whole rows), x slabs whole blocks of X_SHELL cells from the first owned cell on.
     def _boxes(self):
