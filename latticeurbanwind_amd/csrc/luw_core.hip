@@ -1,7 +1,8 @@
 // luw_core.hip -- HIP kernels (gfx950) + C-ABI of the MI355X-native D3Q19 core.  See include/luw_core.h.
 //
 // Device code (included below):
-//   luw_device.hpp          per-cell arithmetic: f_eq, moments, forces, collision (scalar and packed), FP16C codec, thermal cell
+//   luw_device.hpp          per-cell arithmetic: f_eq, moments, forces, the collision of one cell, thermal cell; with luw_codec.hpp (FP16C codec),
+//                           luw_device_pair.hpp (the collision on packed pairs, exact) and luw_device_native.hpp (native arithmetic)
 //   luw_kernels_common.hpp  slot algebra, k_initialize (f_eq(rho,u) -> Esoteric-Pull store with t=1, FX/kernel.cpp:1370-1452)
 //   luw_kernels_step.hpp    k_stream_collide_s (1 cell per lane: FP32 product kernel, FP16C fallback, thermal lattice) and
 //                           k_stream_collide_p (FP16C product kernel: 2 cells per lane, packed FP32 collision)
