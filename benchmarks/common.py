@@ -231,7 +231,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(max_seconds=12.0):
+def cpu_baseline(max_seconds=10.0):
     """The CPU oracle (our C/OpenMP restatement of the reference kernel, kind "port"; its row-wise path: the same operations per cell as the literal
     path, eight cells per AVX2 statement, indices by addition -- oracle/luw_oracle.c, bit-identical to the literal path) timed on this box's host
     cores on a bounded sample of the benchmark recipe: 256^3 channel, FP32 DDFs, as many steps as fit into max_seconds.  The thread
