@@ -358,7 +358,7 @@ def main():
                 if "error" in sec[key]:
                     continue
                 if not args.all_blocks:
-                    # (the default line still shows what the FP16C arithmetic choice is worth on configs[4]'s physics: the exact twin of the undivided urban tile)
+                    # (the default line still shows what the FP16C arithmetic choice is worth on configs[4]'s physics: the exact twin of the urban tile)
                     if key in DEFAULT_EXACT_TWINS:
                         ex = child_block(flag_of(key), key, local_rank, "--arith", "exact")
                         sec[key]["exact"] = {k: ex[k] for k in ("ms_per_step", "arith", "error") if k in ex}
