@@ -4,8 +4,8 @@
 //   luw_device.hpp          per-cell arithmetic: f_eq, moments, forces, the collision of one cell, thermal cell; with luw_codec.hpp (FP16C codec),
 //                           luw_device_pair.hpp (the collision on packed pairs, exact) and luw_device_native.hpp (native arithmetic)
 //   luw_kernels_common.hpp  slot algebra, k_initialize (f_eq(rho,u) -> Esoteric-Pull store with t=1, FX/kernel.cpp:1370-1452)
-//   luw_kernels_step.hpp    k_stream_collide_s (1 cell per lane: FP32 product kernel, FP16C fallback, thermal lattice) and
-//                           k_stream_collide_p (FP16C product kernel: 2 cells per lane, packed FP32 collision)
+//   luw_kernels_step.hpp    k_stream_collide_s (1 cell per lane: FP32 product kernel, FP16C fallback, thermal lattice) and the shared addressing
+//   luw_kernels_pair.hpp    k_stream_collide_p (FP16C product kernel: 2 cells per lane, packed FP32 collision)
 //   luw_kernels_aux.hpp     k_extract_fi / k_insert_fi (halo pack/unpack, FX/kernel.cpp:2241-2270), voxeliser, probe gather,
 //                           von-Karman inlet, statistics, codec self-check
 // Host code (included behind it, in this order):
@@ -44,6 +44,7 @@ using namespace luw;
 
 #include "luw_kernels_common.hpp"
 #include "luw_kernels_step.hpp"
+#include "luw_kernels_pair.hpp"
 #ifdef LUW_AB_KERNELS   // tools build only (make ab; the header lives under tools/ab_kernels/): A/B and measurement-only kernel variants
 #include LUW_AB_KERNELS
 #endif

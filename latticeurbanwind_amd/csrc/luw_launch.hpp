@@ -299,7 +299,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
 	const bool general_only = tuning().pair_general;   // test aid: the general kernel also where a specialisation would do (same values)
 	PairKey k{ 0, st!=nullptr, (st||general_only) ? PAIR_FORCE_ANY : box_force_mode(s, b), false, s->d_gi!=nullptr };
-	// PARK (luw_kernels_step.hpp): the lane's second set of values waits in LDS instead of in registers.  Measured interleaved on MI355X
+	// PARK (luw_kernels_pair.hpp): the lane's second set of values waits in LDS instead of in registers.  Measured interleaved on MI355X
 	// (profiles/r03_pair_park_ab.txt): it pays where the registers cost a wave of occupancy that matters -- the general kernel, 109 -> 91 VGPRs,
 	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
 	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256); the thermal variants always park.
@@ -319,7 +319,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 		const PairKey& q = r.key;
 		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native&&q.xface==k.xface) {
 			// (the uniform-force instantiation sits at its 96 VGPRs without a register for the x-face INPUT: it writes its faces, and has the unpack kernel
-			// run for what it receives -- pair_reads_x_face_inputs, luw_kernels_step.hpp)
+			// run for what it receives -- pair_reads_x_face_inputs, luw_kernels_pair.hpp)
 			if(int e = xin_before_launch(s, b, k.xface&&pair_reads_x_face_inputs(k.force, k.thermal))) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
