@@ -69,7 +69,7 @@ extern "C" {
  * build does in spirit (-cl-mad-enable, native division: FX/opencl.hpp:305, FX/kernel.cpp:1088-1100,1735).  Results then agree with the bit-exact
  * default of this interface (and with the CPU oracle) to rounding, within the gates of tests/test_gpu_native_arith.py, instead of bit for bit; they are
  * deterministic and the same in the pair and the one-cell kernel, i.e. independent of how a lattice is cut.  The deck driver and bench.py set this bit
- * for FP16C unless asked for `--arith exact`.  Ignored for FP32 DDFs and in sampled steps. */
+ * for FP16C unless asked for `--arith exact`.  Ignored for FP32 DDFs. */
 #define LUW_OPT_NATIVE_ARITH 0x10u
 
 /* kernel selection (cfg.kernel, luw_set_kernel): all three compute the same values.  (The A/B and measurement-only variants of the tools build have

@@ -85,6 +85,7 @@ constexpr int pair_waves(const int force, const bool park, const bool thermal = 
 	if(native) {
 		if(thermal) return force==PAIR_FORCE_NONE ? LUW_NATIVE_THERMAL_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_NATIVE_THERMAL_WAVES_UNIFORM
 			: LUW_NATIVE_THERMAL_WAVES_ANY;
+		if(force==PAIR_FORCE_ANY&&!park) return 4;   // (the sampled step's instantiation keeps both cells in registers, like the exact one)
 		return force==PAIR_FORCE_NONE ? LUW_NATIVE_WAVES_NONE : force==PAIR_FORCE_UNIFORM ? LUW_NATIVE_WAVES_UNIFORM : LUW_NATIVE_WAVES_ANY;
 	}
 	// (a wave more each spills to scratch)
@@ -123,7 +124,8 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 	// (with the thermal lattice: the D3Q19 faces; the D3Q7 faces keep their kernels)
 	static_assert(!XFACE||(!STATS&&MODE==0), "x-face output: plain steps");
 	constexpr int NSLOT = THERMAL ? 26 : 19;                         // PARK: dwords per lane in LDS (PRE: eight more behind them)
-	constexpr bool PRE = pair_prefetch(FORCE, PARK) && MODE==0 && !STATS;
+	// (the native collision takes the zone terms from the prefetched references ONLY: its general instantiations always fetch, sampled steps included)
+	constexpr bool PRE = ((pair_prefetch(FORCE, PARK) && !STATS) || (NATIVE && FORCE==PAIR_FORCE_ANY)) && MODE==0;
 	constexpr bool OWN = LUW_PAIR_OWN_EARLY!=0 && !PRE;
 	// RAW: the populations stay scaled by 2^-112 from the decode's shift-and-mask to the encode's (collide_cell_pk_native<FORCE, RAW>, luw_device.hpp): no
 	// products in the codec, no switch of the rounding mode (the thermal lattice's exact cell update keeps the scaled-up form)
@@ -313,6 +315,8 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 			}
 			if constexpr(STATS) {
 				if((fl[c]&TYPE_BO)==TYPE_E) sample_from_fields(c);
+				// (native: a zero velocity is sampled as +0, the value the field write stores)
+				else if constexpr(NATIVE) { smp.r[c] = rhon; smp.ux[c] = uxn+0.0f; smp.uy[c] = uyn+0.0f; smp.uz[c] = uzn+0.0f; smp.has[c] = true; }
 				else { smp.r[c] = rhon; smp.ux[c] = uxn; smp.uy[c] = uyn; smp.uz[c] = uzn; smp.has[c] = true; }
 			}
 		} else {

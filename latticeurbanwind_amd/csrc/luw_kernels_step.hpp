@@ -229,7 +229,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
 		if constexpr(NATIVE) {
-			static_assert(sizeof(T)==2&&(MODE==0||MODE==4)&&!STATS, "native arithmetic: plain FP16C steps");
+			static_assert(sizeof(T)==2&&(MODE==0||MODE==4)&&!(STATS&&MODE==4), "native arithmetic: FP16C steps (sampled ones without the thermal lattice)");
 			const bool is_E = (flagsn&TYPE_BO)==TYPE_E;
 			ForceRefs refs;
 			fetch_force_refs(p, n, x, y, z, true, is_E, rho, u, refs);
@@ -257,6 +257,7 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		}
 		if constexpr(STATS) {
 			if((flagsn&TYPE_BO)==TYPE_E) stats_welford_from_fields(Np, S, n, rho, u); // TYPE_E keeps its input fields (UPDATE_FIELDS skips it)
+			else if constexpr(NATIVE) stats_welford(Np, S, n, rhon, uxn+0.0f, uyn+0.0f, uzn+0.0f);   // (zero velocities as +0, like the field write)
 			else stats_welford(Np, S, n, rhon, uxn, uyn, uzn);
 		}
 	}

@@ -171,6 +171,8 @@ static const ScalarRow scalar_table[] = {
 	{ { 2u, 0, 2, false, false, false, true }, scalar_instance<uint16_t, 0, 2, false, false, false, true>, "FP16C one-cell kernel, native arithmetic" },
 	{ { 2u, 4, 2, false, false, false, true }, scalar_instance<uint16_t, 4, 2, false, false, false, true>,
 		"FP16C one-cell kernel + thermal lattice, native arithmetic" },
+	{ { 2u, 0, 2, false, true,  false, true }, scalar_instance<uint16_t, 0, 2, false, true, false, true>,
+		"FP16C one-cell kernel, sampled step, native arithmetic" },
 #ifdef LUW_AB_KERNELS   // tools build: measurement-only and A/B variants
 	{ { 4u, 1, 1, true,  false, false }, scalar_instance<float, 1, 1, true, false, false>,       "A/B: no collision" },
 	{ { 4u, 1, 1, false, false, false }, scalar_instance<float, 1, 1, false, false, false>,      "A/B: no collision, row addressing" },
@@ -204,8 +206,8 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	const bool general_only = tuning().pair_general;
 	k.noforce = s->ddf_bytes==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
 	if(s->d_gi&&!st) k.mode = 4; // thermal lattice on: the product kernel plus the D3Q7 cell update
-	// native arithmetic (FP16C, plain steps): one instantiation for every box
-	if(s->ddf_bytes==2u&&!st&&(s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u) { k.native = true; k.noforce = false; }
+	// native arithmetic (FP16C; plain and sampled steps -- a sampled step with the thermal lattice never comes here: can_fuse_stats): one instantiation per kind
+	if(s->ddf_bytes==2u&&(s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u) { k.native = true; k.noforce = false; }
 	// x-face output: FP32 plain steps on a box that holds a border column
 	k.xface = s->ddf_bytes==4u && (k.mode==0||k.mode==4) && !st && xface_wanted(s, b);
 #ifdef LUW_AB_KERNELS
@@ -265,6 +267,7 @@ static const PairRow pair_table[] = {
 	{ { 0, false, PAIR_FORCE_NONE,    true,  true,  true }, pair_instance<0, false, PAIR_FORCE_NONE, true, true, true>,        "native + thermal, force-free" },
 	{ { 0, false, PAIR_FORCE_UNIFORM, true,  true,  true }, pair_instance<0, false, PAIR_FORCE_UNIFORM, true, true, true>,     "native + thermal, uniform" },
 	{ { 0, false, PAIR_FORCE_ANY,     true,  true,  true }, pair_instance<0, false, PAIR_FORCE_ANY, true, true, true>,         "native + thermal, general" },
+	{ { 0, true,  PAIR_FORCE_ANY,     false, false, true }, pair_instance<0, true, PAIR_FORCE_ANY, false, false, true>,        "native: sampled step" },
 	// x-split domains, boxes that hold the first / last owned x column: x-face output (luw_set_x_face_buffers), exact and native
 	{ { 0, false, PAIR_FORCE_NONE,    false, false, false, true }, pair_instance<0, false, PAIR_FORCE_NONE, false, false, false, true>,
 		"force-free + x-face" },
@@ -305,9 +308,9 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 	// VGPRs, 7 waves: 3.50 -> 3.49 ms; uniform forces 96 -> 78, 6 waves: 3.78 -> 3.91 ms on 1024x1024x256); the thermal variants always park.
 	constexpr unsigned park_modes = 1u<<PAIR_FORCE_ANY;
 	k.park = k.thermal || (!st && (park_modes&(1u<<k.force))!=0u);
-	// native arithmetic: plain steps of the product kernel (a sampled step runs the exact kernel: its values differ in rounding only)
-	k.native = (s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u && !st;
-	if(k.native&&!k.thermal) k.park = k.force==PAIR_FORCE_ANY;
+	// native arithmetic: plain and sampled steps of the product kernel (a run is native from its first step to its last)
+	k.native = (s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u;
+	if(k.native&&!k.thermal&&!st) k.park = k.force==PAIR_FORCE_ANY;
 	// x-face output: plain steps of the D3Q19 lattice with the product's park choice, on a box that holds a border column
 	k.xface = !st && k.mode==0 && (k.thermal || k.park==(k.force==PAIR_FORCE_ANY)) && xface_wanted(s, b);
 #ifdef LUW_AB_KERNELS

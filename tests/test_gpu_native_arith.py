@@ -153,8 +153,40 @@ def test_native_arithmetic_gives_a_cell_the_same_values_in_either_kernel(luw, fo
         out[1][2])
 
 
-def test_native_arithmetic_is_ignored_for_fp32_and_in_sampled_steps(luw):
-    # FP32 DDFs: the option changes nothing (bit-equal to the oracle); FP16C sampled steps run the exact kernel (statistics equal the separate accumulation)
+@pytest.mark.parametrize("size,kernel", [((260, 14, 10), "pair"), ((48, 20, 12), "scalar")])
+def test_native_sampled_steps_are_native_too(luw, size, kernel):
+    # a native run is native from its first step to its last: the sampled steps carry the Welford update in the native kernels' epilogue, and that equals
+    # the separate path { run(1); stats_accumulate() } on the fields the native kernels wrote, bit for bit (signs of zero included); the fields after the
+    # window equal those of a plain native run of as many steps
+    from latticeurbanwind_amd import capi
+    Nx, Ny, Nz = size
+    st = synthetic_state(Nx, Ny, Nz, seed=31, shell="luw")
+    kern = capi.KERNEL_PAIR if kernel == "pair" else capi.KERNEL_SCALAR
+    def make():
+        g = luw.LBM(Nx, Ny, Nz, 2e-5, fp16c=True, native_arith=True, kernel=kern, buffer_nudging=NUD, top_sponge=SPG)
+        g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]; g.set_coriolis(*COR)
+        return g
+    a, b, c = make(), make(), make()
+    for g in (a, b, c): g.run(3)
+    a.stats_reset(); b.stats_reset()
+    a.run_sampled(7, 2, 2)                                             # samples at steps 2, 4, 6 of the window
+    for i in range(1, 8):
+        b.run(1)
+        if i >= 2 and (i - 2) % 2 == 0: b.stats_accumulate()
+    c.run(7)
+    da, db = a.stats_download(), b.stats_download()
+    assert da["count"] == db["count"] == 3
+    for k in ("avg_u", "avg_rho", "m2_u", "m2_v", "m2_w"):
+        assert np.array_equal(np.asarray(da[k]).view(np.uint32), np.asarray(db[k]).view(np.uint32)), k
+    for g in (a, c): g.u.read_from_device(); g.rho.read_from_device()
+    assert np.array_equal(a.u.data.view(np.uint32), c.u.data.view(np.uint32)) and np.array_equal(a.rho.data, c.rho.data)
+    fa = np.asarray(a.download_fi()).copy(); fc = np.asarray(c.download_fi()).copy(); fa[fa == 0x8000] = 0; fc[fc == 0x8000] = 0
+    assert np.array_equal(fa, fc)
+    for g in (a, b, c): g.close()
+
+
+def test_native_arithmetic_is_ignored_for_fp32(luw):
+    # FP32 DDFs: the option changes nothing (bit-equal to the oracle)
     from oracle import oracle
     Nx, Ny, Nz = 48, 20, 12
     st = synthetic_state(Nx, Ny, Nz, seed=2, shell="luw")
