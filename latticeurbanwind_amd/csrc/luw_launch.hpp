@@ -83,13 +83,20 @@ static bool xface_wanted(const luw_solver* s, const Box& b) {
 	if(!s->xf_p||!s->xf_m||!s->kp.halo_x||s->cfg.Nx<4u) return false;
 	return (b.x0<=1u&&b.x1>1u)||(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u);
 }
+// (a column is covered when the (y, z) areas of the step's launches that hold it add up to every non-halo (y, z): the boxes of one step are disjoint --
+// one whole box, or the shell boxes and the interior of luw_step.hpp)
 static void xface_covered(luw_solver* s, const Box& b) {
-	if(s->xf_t!=s->t) { s->xf_t = s->t; s->xf_cover = 0u; }
-	const bool spans = b.y0<=s->kp.halo_y&&b.y1>=s->cfg.Ny-s->kp.halo_y&&b.z0<=s->kp.halo_z&&b.z1>=s->cfg.Nz-s->kp.halo_z;
-	if(!spans) return;
-	if(b.x0<=1u&&b.x1>1u) s->xf_cover |= 2u;                            // first owned column: the face towards -x
-	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) s->xf_cover |= 1u;        // last owned column: the face towards +x
+	if(s->xf_t!=s->t) { s->xf_t = s->t; s->xf_cover = 0u; s->xf_area[0] = s->xf_area[1] = 0ull; }
+	const uint32_t y0 = std::max(b.y0, s->kp.halo_y), y1 = std::min(b.y1, s->cfg.Ny-s->kp.halo_y), z0 = std::max(b.z0, s->kp.halo_z),
+		z1 = std::min(b.z1, s->cfg.Nz-s->kp.halo_z);
+	if(y1<=y0||z1<=z0) return;
+	const uint64_t area = (uint64_t)(y1-y0)*(z1-z0), full = (uint64_t)(s->cfg.Ny-2u*s->kp.halo_y)*(s->cfg.Nz-2u*s->kp.halo_z);
+	if(b.x0<=1u&&b.x1>1u) { s->xf_area[1] += area; if(s->xf_area[1]>=full) s->xf_cover |= 2u; }                  // first owned column: the face towards -x
+	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) { s->xf_area[0] += area; if(s->xf_area[0]>=full) s->xf_cover |= 1u; }        // last owned column: towards +x
 }
+static bool xfaces_covered_now(const luw_solver* s) { return s->xf_t==s->t&&s->xf_cover==3u; }
+// what a launch WOULD do with the x faces (dry run of the kernel choice): does its instantiation write the border columns' faces / read the pending inputs?
+struct LaunchCaps { bool xface_out = false, xface_in = false; };
 // ---- x-face input (luw_set_x_face_inputs): the insert of the x faces is pending, the values wait in the receive buffers.  A launch of the step they are for
 // that holds a border column reads that column's side there when its instantiation can (the ones with the x-face output); everything else that wants a side
 // in the lattice -- another instantiation, a pack kernel, a download, a change of t other than the step to xin_for_t -- has xin_settle run the insert kernel
@@ -191,7 +198,7 @@ static const ScalarRow scalar_table[] = {
 	{ { 2u, 3, 2, false, false, false }, scalar_instance<uint16_t, 3, 2, false, false, false>,   "A/B: FP16C general path only" },
 #endif
 };
-static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
+static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr, LaunchCaps* caps = nullptr) {
 	LaunchGeom g{};
 	g.xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
 	const uint32_t nx = (uint32_t)((int)b.x1-g.xa), bx = row_block(nx);
@@ -223,6 +230,7 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	for(const ScalarRow& r : scalar_table) {
 		const ScalarKey& q = r.key;
 		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce&&q.native==k.native&&q.xface==k.xface) {
+			if(caps) { caps->xface_out = k.xface; caps->xface_in = k.xface; return LUW_OK; }
 			if(int e = xin_before_launch(s, b, k.xface)) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
@@ -295,7 +303,7 @@ static const PairRow pair_table[] = {
 		"A/B: uniform forces with PARK (6 waves: slower)" },
 #endif
 };
-static int launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
+static int launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr, LaunchCaps* caps = nullptr) {
 	LaunchGeom g{};
 	const uint32_t nx = (b.x1-b.x0+1u)/2u;                         // an odd count only when the box ends at an odd Nx: the last lane owns one cell
 	const uint32_t bx = row_block(nx);
@@ -323,6 +331,7 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native&&q.xface==k.xface) {
 			// (the uniform-force instantiation sits at its 96 VGPRs without a register for the x-face INPUT: it writes its faces, and has the unpack kernel
 			// run for what it receives -- pair_reads_x_face_inputs, luw_kernels_pair.hpp)
+			if(caps) { caps->xface_out = k.xface; caps->xface_in = k.xface&&pair_reads_x_face_inputs(k.force, k.thermal); return LUW_OK; }
 			if(int e = xin_before_launch(s, b, k.xface&&pair_reads_x_face_inputs(k.force, k.thermal))) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
@@ -339,8 +348,8 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 static bool can_fuse_stats(const luw_solver* s) {
 	return tuning().fuse_stats && !s->d_gi && (s->kernel==LUW_KERNEL_AUTO||s->kernel==LUW_KERNEL_SCALAR||s->kernel==LUW_KERNEL_PAIR);
 }
-static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
-	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
+static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr, LaunchCaps* caps = nullptr) {
+	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) { if(caps) caps->xface_out = caps->xface_in = true; return LUW_OK; } // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
 	const bool fp16 = s->ddf_bytes==2u;
@@ -363,14 +372,16 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 		if(!fp16||!starts_aligned||!whole_pairs) k = LUW_KERNEL_SCALAR;
 	}
 	if(st&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) return fail(LUW_ERR_STATE, "stream_collide: this kernel has no fused statistics");
-	if(k==LUW_KERNEL_PAIR) { if(int e = launch_pair(s, b, write_fields, st)) return e; }
-	else if(st) { if(int e = launch_scalar(s, b, write_fields, st)) return e; }
+	if(caps&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) { *caps = LaunchCaps{}; return LUW_OK; }   // (A/B kernels of the tools build: neither)
+	if(k==LUW_KERNEL_PAIR) { if(int e = launch_pair(s, b, write_fields, st, caps)) return e; }
+	else if(st) { if(int e = launch_scalar(s, b, write_fields, st, caps)) return e; }
 #ifdef LUW_AB_KERNELS
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
 #endif
-	else { if(int e = launch_scalar(s, b, write_fields)) return e; }
+	else { if(int e = launch_scalar(s, b, write_fields, nullptr, caps)) return e; }
+	if(caps) return LUW_OK;
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }

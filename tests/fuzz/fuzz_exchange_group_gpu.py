@@ -29,6 +29,7 @@ def main():
         steps = (int(rng.integers(1, 7)), int(rng.integers(0, 6)))
         os.environ["LUW_X_SHELL"] = str(int(rng.choice([16, 64, 128])))
         os.environ["LUW_GROUP_THREADS"] = "1" if threads else "0"
+        os.environ["LUW_GROUP_X_SLABS"] = "1" if rng.integers(2) == 0 else "0"        # (0: no x slabs where the one-round exchange runs on one thread)
         seed = int(rng.integers(1 << 30))
         st = synthetic_state(*gN, seed=seed, shell="luw" if forces else None)
         flags = st[0].copy()
@@ -73,8 +74,9 @@ def main():
             same = same and ok
             vs_oracle = ", oracle %s" % ("equal" if ok else "DIFFERENT")
         bad += not same
-        print("case %d: %s global %s n_gpu %s thermal %s forces %s threads %s x_shell %s steps %s: %s%s" % (case, "fp16c" if fp16c else "f32", gN, D, thermal,
-            forces, threads, os.environ["LUW_X_SHELL"], steps, "routes equal" if same else "DIFFERENT", vs_oracle), flush=True)
+        print("case %d: %s global %s n_gpu %s thermal %s forces %s threads %s x_shell %s x_slabs %s steps %s: %s%s" % (case, "fp16c" if fp16c else "f32", gN, D,
+            thermal, forces, threads, os.environ["LUW_X_SHELL"], os.environ["LUW_GROUP_X_SLABS"], steps, "routes equal" if same else "DIFFERENT", vs_oracle),
+                flush=True)
     print("fuzz: %d cases, %d different" % (cases, bad))
     sys.exit(1 if bad else 0)
 

@@ -25,18 +25,22 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["one_phase", "sequential"])
+@pytest.fixture(params=["one_phase", "one_phase_no_x_slabs", "sequential"])
 def exchange(request):
     """both exchange routes of luw_group_*: ONE pack / unpack round per step (default with peer stores: faces of all axes, twelve edge messages, x faces read
-    in place by the next step's kernels) and the reference's three phases x, y, z (LUW_GROUP_EXCHANGE=sequential)"""
+    in place by the next step's kernels; with x split: the 128-cell x boundary slabs, or LUW_GROUP_X_SLABS=0 without them) and the reference's three phases
+    x, y, z (LUW_GROUP_EXCHANGE=sequential)"""
     from latticeurbanwind_amd import capi
-    saved = os.environ.get("LUW_GROUP_EXCHANGE")
+    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_EXCHANGE", "LUW_GROUP_X_SLABS")}
+    for k in saved: os.environ.pop(k, None)
     if request.param == "sequential": os.environ["LUW_GROUP_EXCHANGE"] = "sequential"
-    else: os.environ.pop("LUW_GROUP_EXCHANGE", None)
+    # (no x slabs: the interior launch holds the border columns)
+    if request.param == "one_phase_no_x_slabs": os.environ["LUW_GROUP_X_SLABS"] = "0"
     capi.reload_tuning()
     yield request.param
-    if saved is None: os.environ.pop("LUW_GROUP_EXCHANGE", None)
-    else: os.environ["LUW_GROUP_EXCHANGE"] = saved
+    for k, v in saved.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
     capi.reload_tuning()
 
 
@@ -52,7 +56,7 @@ def test_group_equals_oracle_on_the_undivided_lattice(luw, gN, D, fp16c, overlap
     from oracle import oracle
     st = synthetic_state(*gN, seed=41, shell=None)                      # fully periodic: the wrap runs through the halo ring
     g = run_group(luw, gN, D, fp16c, st, 7)
-    assert g.overlaps() == overlap and g.direct_peer_stores() and g.one_phase() == (exchange == "one_phase")
+    assert g.overlaps() == overlap and g.direct_peer_stores() and g.one_phase() == (exchange != "sequential")
     g.run(0); g.run(4); g.run(3)                                        # two calls: events of the first are reused by the second
     g.read_from_device()
     o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c)
