@@ -396,7 +396,7 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.assign(2u*steps, nullptr); for(auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
 	// Default: ONE enqueueing thread (measured with eight domains on one device: 44 us per domain and step, i.e. 0.36 ms per step for eight --
 	// well inside a 1.9 ms FP16C step; profiles/r02_group_one_gpu.txt).  LUW_GROUP_THREADS=1 gives every domain its own host thread.
-	const bool threaded = tuning().group_threads;
+	const bool threaded = tuning().group_threads&&!g->x_free;   // (the slab-free schedule waits for neighbours' interior events: one enqueueing thread only)
 	// a call of a step or two (probe windows) is not worth starting threads for; RCCL's group calls are issued by ONE thread
 	if(threaded&&steps>=4ull&&g->transport!=LUW_TRANSPORT_RCCL) {
 		GroupThreads T; T.error.assign(g->dom.size(), std::string());

@@ -83,16 +83,31 @@ static bool xface_wanted(const luw_solver* s, const Box& b) {
 	if(!s->xf_p||!s->xf_m||!s->kp.halo_x||s->cfg.Nx<4u) return false;
 	return (b.x0<=1u&&b.x1>1u)||(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u);
 }
-// (a column is covered when the (y, z) areas of the step's launches that hold it add up to every non-halo (y, z): the boxes of one step are disjoint --
-// one whole box, or the shell boxes and the interior of luw_step.hpp)
+// (a column is covered when the (y, z) extents of the step's launches that hold it are disjoint and add up to every non-halo (y, z) -- one whole box, or
+// the shell boxes and the interior of luw_step.hpp.  Extents that overlap, e.g. a box launched twice, or more than eight of them: no claim for this step,
+// the pack kernel runs)
 static void xface_covered(luw_solver* s, const Box& b) {
-	if(s->xf_t!=s->t) { s->xf_t = s->t; s->xf_cover = 0u; s->xf_area[0] = s->xf_area[1] = 0ull; }
-	const uint32_t y0 = std::max(b.y0, s->kp.halo_y), y1 = std::min(b.y1, s->cfg.Ny-s->kp.halo_y), z0 = std::max(b.z0, s->kp.halo_z),
-		z1 = std::min(b.z1, s->cfg.Nz-s->kp.halo_z);
-	if(y1<=y0||z1<=z0) return;
-	const uint64_t area = (uint64_t)(y1-y0)*(z1-z0), full = (uint64_t)(s->cfg.Ny-2u*s->kp.halo_y)*(s->cfg.Nz-2u*s->kp.halo_z);
-	if(b.x0<=1u&&b.x1>1u) { s->xf_area[1] += area; if(s->xf_area[1]>=full) s->xf_cover |= 2u; }                  // first owned column: the face towards -x
-	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) { s->xf_area[0] += area; if(s->xf_area[0]>=full) s->xf_cover |= 1u; }        // last owned column: towards +x
+	if(s->xf_t!=s->t) {
+		s->xf_t = s->t; s->xf_cover = 0u;
+		for(int k=0; k<2; k++) { s->xf_area[k] = 0ull; s->xf_rects[k] = 0u; s->xf_lost[k] = false; }
+	}
+	const luw_solver::FaceRect r{ std::max(b.y0, s->kp.halo_y), std::min(b.y1, s->cfg.Ny-s->kp.halo_y), std::max(b.z0, s->kp.halo_z),
+		std::min(b.z1, s->cfg.Nz-s->kp.halo_z) };
+	if(r.y1<=r.y0||r.z1<=r.z0) return;
+	const uint64_t full = (uint64_t)(s->cfg.Ny-2u*s->kp.halo_y)*(s->cfg.Nz-2u*s->kp.halo_z);
+	auto add = [&](const int k, const uint32_t bit) { // k = 1: first owned column, the face towards -x; 0: last owned column, towards +x
+		if(s->xf_lost[k]) return;
+		for(uint32_t q=0u; q<s->xf_rects[k]; q++) {
+			const luw_solver::FaceRect& o = s->xf_rect[k][q];
+			if(r.y0<o.y1&&o.y0<r.y1&&r.z0<o.z1&&o.z0<r.z1) { s->xf_lost[k] = true; s->xf_cover &= ~bit; return; }
+		}
+		if(s->xf_rects[k]==8u) { s->xf_lost[k] = true; s->xf_cover &= ~bit; return; }
+		s->xf_rect[k][s->xf_rects[k]++] = r;
+		s->xf_area[k] += (uint64_t)(r.y1-r.y0)*(r.z1-r.z0);
+		if(s->xf_area[k]>=full) s->xf_cover |= bit;
+	};
+	if(b.x0<=1u&&b.x1>1u) add(1, 2u);
+	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) add(0, 1u);
 }
 static bool xfaces_covered_now(const luw_solver* s) { return s->xf_t==s->t&&s->xf_cover==3u; }
 // what a launch WOULD do with the x faces (dry run of the kernel choice): does its instantiation write the border columns' faces / read the pending inputs?

@@ -113,6 +113,8 @@ struct luw_solver {
 	void* d_stage = nullptr; size_t stage_bytes = 0u; // copy_pitched's staging buffer (chunk-mapped arrays)
 	// x-face output of the step kernels (luw_set_x_face_buffers): buffers, and which of the two border columns the launches of step xf_t have covered
 	void* xf_p = nullptr; void* xf_m = nullptr; uint32_t xf_cover = 0u; uint64_t xf_t = ~0ull, xf_area[2] = { 0ull, 0ull };
+	struct FaceRect { uint32_t y0, y1, z0, z1; };     // (y, z) extents of the launches of step xf_t that held a border column, per side (xface_covered)
+	FaceRect xf_rect[2][8] = {}; uint32_t xf_rects[2] = { 0u, 0u }; bool xf_lost[2] = { false, false };
 	// x-face input (luw_set_x_face_inputs): receive buffers whose insert is pending, side by side (bit 0: the face that came from +x, for the last owned
 	// column; bit 1: from -x, for the first) -- xin_buf: still only in the buffer; xin_inplace: read there by a launch of step xin_for_t. Whatever else needs a
 	// side in the lattice has the insert kernel run for it first (xin_settle).

@@ -166,10 +166,20 @@ def test_x_faces_written_by_the_step_kernels_equal_the_extract_kernel(luw, fp16c
         g.enqueue_extract_fi(0, fused[0].data_ptr(), fused[1].data_ptr()); g.finish()          # covered by the launches: nothing to do
         assert all(torch.equal(a, b) for a, b in zip(before, fused))
         g.increment_time_step(1)
-    # a box that cuts the columns does not cover them: the extract call does the work itself (rim rows included)
+    # disjoint boxes that cut the columns cover them together (the step without x slabs: y / z layers and interior); rim rows stay nobody's
     g.enqueue_stream_collide((1, Nx - 1, 1, Ny // 2, 0, Nz), False); g.enqueue_stream_collide((1, Nx - 1, Ny // 2, Ny - 1, 0, Nz), False)
+    g.finish(); before = [f.clone() for f in fused]
     g.enqueue_extract_fi(0, fused[0].data_ptr(), fused[1].data_ptr()); g.enqueue_extract_fi(0, plain[0].data_ptr(), plain[1].data_ptr()); g.finish()
-    assert all(torch.equal(a, b) for a, b in zip(plain, fused))
+    assert all(torch.equal(a, b) for a, b in zip(before, fused))
+    for f, p_ in zip(fused, plain): assert np.array_equal(f.cpu().numpy()[sel], p_.cpu().numpy()[sel])
+    g.increment_time_step(1)
+    # part of the columns, or a box launched twice, is no cover: the extract call does the work itself (rim rows included)
+    for twice in (False, True):
+        g.enqueue_stream_collide((1, Nx - 1, 1, Ny // 2, 0, Nz), False)
+        if twice: g.enqueue_stream_collide((1, Nx - 1, 1, Ny // 2, 0, Nz), False); g.enqueue_stream_collide((1, Nx - 1, Ny // 2, Ny - 1, 0, Nz), False)
+        g.enqueue_extract_fi(0, fused[0].data_ptr(), fused[1].data_ptr()); g.enqueue_extract_fi(0, plain[0].data_ptr(), plain[1].data_ptr()); g.finish()
+        assert all(torch.equal(a, b) for a, b in zip(plain, fused)), twice
+        g.increment_time_step(1)
     g.close()
 
 
