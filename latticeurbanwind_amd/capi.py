@@ -44,7 +44,7 @@ SYMBOLS = [
 # include/luw_core_dev.h
 DEV_SYMBOLS = [
     "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_reload_tuning", "luw_dev_tuning_text",
-        "luw_dev_inject_fault",
+        "luw_dev_inject_fault", "luw_dev_schedule_jitter",
     "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_selfcheck_arith",
 ]
 
@@ -188,6 +188,7 @@ def load(path=None):
     L.luw_dev_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, u64]
     L.luw_dev_tuning_text.argtypes = [C.c_char_p, u64]
     L.luw_dev_inject_fault.argtypes = [u32]
+    L.luw_dev_schedule_jitter.argtypes = [u64, u32]
     if L.luw_abi_version() != 6:
         raise LuwError("libluw_core.so ABI version mismatch")
     _LIB = L
@@ -238,6 +239,11 @@ def placement_info(handle):
 
 
 FAULT_NO_PEER_ODD_PAIRS, FAULT_RCCL_INIT, FAULT_SLOW_FIRST_PLACEMENT = 1, 2, 4
+
+
+def schedule_jitter(seed, max_us):
+    """luw_dev_schedule_jitter: random delays in front of every second kernel the library enqueues (max_us = 0 switches it off)"""
+    check(load().luw_dev_schedule_jitter(int(seed), int(max_us)))
 
 
 def inject_fault(mask):

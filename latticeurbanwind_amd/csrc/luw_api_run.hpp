@@ -261,6 +261,7 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 	// kernel -- takes the edges with them)
 	const uint32_t to_faces = insert ? (s->xin_buf&~s->xin_inplace) : 0u;
 	void* const ip = (to_faces&1u) ? const_cast<void*>(s->xin_p) : nullptr; void* const im = (to_faces&2u) ? const_cast<void*>(s->xin_m) : nullptr;
+	schedule_jitter(s->stream);
 	if(s->ddf_bytes==2u) {
 		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)ip, (uint16_t*)im);
 		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)nullptr,
@@ -296,6 +297,7 @@ int luw_enqueue_insert_gi(luw_solver* s, uint32_t direction, const void* buf_p, 
 // ---- include/luw_core_dev.h: measurement and test entry points
 int luw_dev_reload_tuning(void) { (void)tuning(); tuning_load(); return LUW_OK; } // (not while another thread is inside the library)
 int luw_dev_inject_fault(uint32_t mask) { g_injected_faults.store(mask); return LUW_OK; }
+int luw_dev_schedule_jitter(uint64_t seed, uint32_t max_us) { g_jitter_state.store(seed); g_jitter_max_us.store(std::min(max_us, 5000u)); return LUW_OK; }
 int luw_dev_tuning_text(char* text, uint64_t size) {
 	if(!text||size<64u) return fail(LUW_ERR_INVALID, "luw_dev_tuning_text: needs a buffer");
 	const Tuning& t = tuning();

@@ -35,6 +35,7 @@
 #include <functional>
 #include <atomic>
 #include <mutex>
+#include <deque>
 #include <algorithm>
 #include <memory>
 #include <dlfcn.h>

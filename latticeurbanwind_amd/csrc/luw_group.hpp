@@ -156,8 +156,10 @@ static int domain_unpack(luw_group* g, const size_t i, const int a, const bool t
 	GroupDomain& d = g->dom[i];
 	hipStream_t st = on_compute ? d.compute : d.comm;
 	GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
-	HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? P.gpacked : P.packed)[a], 0));
-	HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? M.gpacked : M.packed)[a], 0));
+	if(!(g_injected_faults.load()&LUW_FAULT_UNPACK_WITHOUT_WAIT)) {   // (test hook: the dependency the schedule fuzz must miss when it is gone)
+		HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? P.gpacked : P.packed)[a], 0));
+		HIP_TRY(hipStreamWaitEvent(st, (thermal_pass ? M.gpacked : M.packed)[a], 0));
+	}
 	GROUP_TRY(luw_set_stream(d.s, st));
 	GROUP_TRY(thermal_pass ? luw_enqueue_insert_gi(d.s, (uint32_t)a, d.grecv[a][0], d.grecv[a][1])
 		: luw_enqueue_insert_fi(d.s, (uint32_t)a, d.recv[a][0], d.recv[a][1]));
@@ -202,7 +204,7 @@ static int domain_pack_all(luw_group* g, const size_t i, const bool on_compute, 
 static int domain_unpack_all(luw_group* g, const size_t i, const bool on_compute, const bool x_in_place, const uint32_t xs) {
 	GroupDomain& d = g->dom[i];
 	hipStream_t st = on_compute ? d.compute : d.comm;
-	for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].packed_all, 0));
+	if(!(g_injected_faults.load()&LUW_FAULT_UNPACK_WITHOUT_WAIT)) for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].packed_all, 0));
 	GROUP_TRY(luw_set_stream(d.s, st));
 	if(g->H[0]) {
 		if(x_in_place) GROUP_TRY(luw_set_x_face_inputs(d.s, d.recvx[xs][0], d.recvx[xs][1]));

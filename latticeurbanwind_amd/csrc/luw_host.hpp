@@ -39,6 +39,18 @@ struct Tuning {
 #endif
 };
 static std::atomic<uint32_t> g_injected_faults{0u};     // luw_dev_inject_fault (include/luw_core_dev.h): test hooks
+// luw_dev_schedule_jitter: every second launch of a step / pack / unpack kernel is held back by a random delay on its stream.  A result that depends on one
+// kernel being faster than another -- a missing event between two streams -- then shows as a difference from the oracle.
+static std::atomic<uint64_t> g_jitter_state{0ull};
+static std::atomic<uint32_t> g_jitter_max_us{0u};
+static void schedule_jitter(hipStream_t st) {
+	const uint32_t max_us = g_jitter_max_us.load(std::memory_order_relaxed);
+	if(!max_us) return;
+	uint64_t z = g_jitter_state.fetch_add(0x9E3779B97F4A7C15ull)+0x9E3779B97F4A7C15ull;   // splitmix64
+	z = (z^(z>>30))*0xBF58476D1CE4E5B9ull; z = (z^(z>>27))*0x94D049BB133111EBull; z ^= z>>31;
+	if(z&1ull) return;
+	hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, 1u+(uint32_t)((z>>8)%max_us));
+}
 // Read ONCE per process, on first use (std::call_once: the first use may come from several threads at the same time -- the per-domain threads of
 // luw_group, callers' thread pools).  luw_dev_reload_tuning (tests and A/B tools that change the environment between two solvers) reads it again; it must
 // not run while another thread is inside the library.

@@ -359,3 +359,10 @@ __global__ __launch_bounds__(256) void k_arith_check(unsigned long long* __restr
 	if(bad_div) atomicAdd(mismatches+1, bad_div);
 	if(bad_grid) atomicAdd(mismatches+2, bad_grid);
 }
+
+// ---- test hook (luw_dev_schedule_jitter): one lane that keeps its stream busy for about `us` microseconds -- whatever is enqueued behind it runs late.
+// Bounded twice: by the 100 MHz wall clock and by the number of sleeps, so that it ends whatever the clock does.
+__global__ void k_delay(const uint32_t us) {
+	const uint64_t t0 = wall_clock64();
+	for(uint32_t i=0u; i<4u*us+4u && wall_clock64()-t0<100ull*us; i++) __builtin_amdgcn_s_sleep(32);
+}

@@ -388,6 +388,7 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 	}
 	if(st&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) return fail(LUW_ERR_STATE, "stream_collide: this kernel has no fused statistics");
 	if(caps&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) { *caps = LaunchCaps{}; return LUW_OK; }   // (A/B kernels of the tools build: neither)
+	if(!caps) schedule_jitter(s->stream);
 	if(k==LUW_KERNEL_PAIR) { if(int e = launch_pair(s, b, write_fields, st, caps)) return e; }
 	else if(st) { if(int e = launch_scalar(s, b, write_fields, st, caps)) return e; }
 #ifdef LUW_AB_KERNELS
@@ -407,6 +408,7 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 	const dim3 grid((A+255u)/256u), block(256);
 	const uint32_t odd = (uint32_t)(s->t&1ull);
 	void* lat = G ? s->d_gi : s->d_fi;
+	schedule_jitter(s->stream);
 	#define LUW_TR(TT, DD) do { \
 		if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat); \
 		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat); \
@@ -419,6 +421,7 @@ template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const u
 static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m, const uint32_t odd) {
 	const uint32_t A = (uint32_t)luw_get_area(s, 0u);
 	const dim3 grid((A+255u)/256u), block(256);
+	schedule_jitter(s->stream);
 	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const uint16_t*)buf_p,
 		(const uint16_t*)buf_m, (uint16_t*)s->d_fi);
 	else hipLaunchKernelGGL((k_insert_fi<float, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const float*)buf_p, (const float*)buf_m,

@@ -20,6 +20,22 @@ static void dev_block_pieces(const DevBlock& b, const size_t mapped, std::vector
 // The device is idle first: nothing in flight may still address the block.
 // keep_range: the physical memory goes back now, the (empty) address range stays reserved until a later dev_free of the same block -- a candidate of the
 // placement search is released this way, so that the next candidate never lands on addresses whose page-table entries were torn down a moment ago.
+// An address range whose mappings are gone is not handed back to the runtime at once: the next reservation of the process would land on the very addresses
+// whose page-table entries were torn down a moment ago, and on this ROCm a kernel that touches such a fresh mapping can die with a memory access fault
+// (round 5: the GPU suite, twice, in the runtime's own memset of a just-mapped array, right after an eight-domain group had released fifty ranges;
+// profiles/r05_vmm_range_reuse.txt).  Retired ranges wait here -- reserved, nothing mapped, no physical memory -- and only the oldest go back once more than
+// 4 TiB of address space or 512 ranges are waiting.
+static std::mutex g_retired_mutex;
+static std::deque<std::pair<void*, size_t>> g_retired_ranges;
+static size_t g_retired_bytes = 0u;
+static void retire_address_range(void* base, const size_t bytes) {
+	std::lock_guard<std::mutex> lock(g_retired_mutex);
+	g_retired_ranges.emplace_back(base, bytes); g_retired_bytes += bytes;
+	while(g_retired_ranges.size()>512u||g_retired_bytes>(4ull<<40)) {
+		(void)hipMemAddressFree(g_retired_ranges.front().first, g_retired_ranges.front().second);
+		g_retired_bytes -= g_retired_ranges.front().second; g_retired_ranges.pop_front();
+	}
+}
 static void dev_free(DevBlock& b, const bool keep_range = false) {
 	if(!b.base) return;
 	(void)hipDeviceSynchronize();
@@ -31,7 +47,7 @@ static void dev_free(DevBlock& b, const bool keep_range = false) {
 		for(auto& h : b.chunks) (void)hipMemRelease(h);
 		b.chunks.clear();
 		if(keep_range) { (void)hipGetLastError(); return; }           // chunk_bytes != 0 marks the block as "a reserved range, nothing mapped"
-		(void)hipMemAddressFree(b.base, b.bytes);
+		retire_address_range(b.base, b.bytes);
 	}
 	(void)hipGetLastError();
 	b = DevBlock{};

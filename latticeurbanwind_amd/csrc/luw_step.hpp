@@ -6,9 +6,7 @@
 
 #define GROUP_TRY(call) do { if(int e_ = (call)) return e_; } while(0)
 
-// ---- the schedule of ONE domain's share of a decomposed step, shared by both hosts: luw_group_* (all domains in this process) and the one-process-per-GPU
-// driver latticeurbanwind_amd/distributed.py (through luw_domain_step_*; the exchange between its calls is RCCL's).
-// Boxes: whole (non-halo cells), interior, and the disjoint shell slabs covering their difference (cells whose DDFs the pack kernels read).
+// ---- Boxes: whole (non-halo cells), interior, and the disjoint shell slabs covering their difference (cells whose DDFs the pack kernels read).
 static void step_axis_ranges(const uint32_t lN[3], const uint32_t H[3], const uint32_t x_shell, const int a, uint32_t nonhalo[2], uint32_t lo_slab[2],
 	uint32_t hi_slab[2], uint32_t inner[2]) {
 	nonhalo[0] = H[a]; nonhalo[1] = lN[a]-H[a];
@@ -172,7 +170,7 @@ int luw_domain_step_launch(luw_domain_step* d, int write_fields, int timed) {
 	if(!d) return fail(LUW_ERR_INVALID, "luw_domain_step_launch: null argument");
 	if(int e = set_device(d->s)) return e;
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-	if(timed) { for(hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e)); d->timing.insert(d->timing.end(), ev, ev+4); }
+	if(timed) for(hipEvent_t& e : ev) { HIP_TRY(hipEventCreate(&e)); d->timing.push_back(e); }   // (owned by d->timing at once: a failure leaks none)
 	return step_launch(domain_step_ctx(d), write_fields, ev[0], ev[1], d->overlap ? ev[2] : nullptr, d->overlap ? ev[3] : nullptr);
 }
 int luw_domain_step_separate_stats(luw_domain_step* d) {

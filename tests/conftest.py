@@ -41,3 +41,29 @@ def luw():
     pkg.build()
     pkg.load()
     return pkg
+
+
+def pytest_runtest_setup(item):
+    """LUW_TEST_MEMLOG=<file>: one line per test with the device's free memory, this process's resident set and the host's available memory -- the trail to read
+    when a long GPU session dies in an allocation (tools/gpu_suite_memlog.sh)"""
+    path = os.environ.get("LUW_TEST_MEMLOG")
+    if not path:
+        return
+    free = total = -1
+    try:
+        import torch
+        if torch.cuda.is_available():
+            free, total = torch.cuda.mem_get_info(0)
+    except Exception:                                        # noqa: BLE001 -- a diagnostic must never fail a test
+        pass
+    rss = avail = -1
+    try:
+        for line in open("/proc/self/status"):
+            if line.startswith("VmRSS:"): rss = int(line.split()[1]) // 1024
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"): avail = int(line.split()[1]) // 1024
+        threads = len(os.listdir("/proc/self/task"))
+    except OSError:
+        threads = -1
+    with open(path, "a") as f:
+        f.write("%s device_free_MiB %d of %d rss_MiB %d host_available_MiB %d threads %d\n" % (item.nodeid, free >> 20, total >> 20, rss, avail, threads))

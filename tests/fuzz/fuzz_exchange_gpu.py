@@ -14,6 +14,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
     import latticeurbanwind_amd as luw
+    from latticeurbanwind_amd import capi
     from latticeurbanwind_amd.distributed import DomainDecomposedLBM, DomainLayout, PeerLoopbackTransport
     from helpers import synthetic_state, thermal_state, TYPE_S
     luw.load()
@@ -27,9 +28,11 @@ def main():
         steps = int(rng.integers(1, 9))
         os.environ["LUW_X_SHELL"] = str(int(rng.choice([16, 64, 128])))
         seed = int(rng.integers(1 << 30))
+        jitter = int(rng.choice([0, 0, 100, 400]))            # schedule fuzzing (luw_dev_schedule_jitter): random delays in front of the library's kernels
         res = {}
         for exchange in ("batch", "sequential"):
             os.environ["LUW_EXCHANGE"] = exchange
+            capi.schedule_jitter(seed + (exchange == "sequential"), jitter)
             lay = DomainLayout(gN, D, 0)
             if not lay.can_overlap(): break
             sim = DomainDecomposedLBM(gN, D, 0.01, rank=0, transport=PeerLoopbackTransport(lay), fp16c=fp16c, device=0,
@@ -50,11 +53,12 @@ def main():
             if thermal: out += [sim.backend.download_T().copy(), np.asarray(sim.backend.lbm.download_gi()).copy()]
             res[exchange] = out
             sim.backend.close()
+            capi.schedule_jitter(0, 0)
         if len(res) < 2: continue
         same = all(np.array_equal(a, b) for a, b in zip(res["batch"], res["sequential"]))
         bad += not same
-        print("case %d: %s local %s n_gpu %s thermal %s x_shell %s steps %d: %s" % (case, "fp16c" if fp16c else "f32", own, D, thermal,
-            os.environ["LUW_X_SHELL"], steps,
+        print("case %d: %s local %s n_gpu %s thermal %s x_shell %s jitter %d steps %d: %s" % (case, "fp16c" if fp16c else "f32", own, D, thermal,
+            os.environ["LUW_X_SHELL"], jitter, steps,
             "equal" if same else "DIFFERENT"), flush=True)
     print("fuzz: %d cases, %d different" % (cases, bad))
     sys.exit(1 if bad else 0)

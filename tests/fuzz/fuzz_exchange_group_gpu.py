@@ -31,6 +31,7 @@ def main():
         os.environ["LUW_GROUP_THREADS"] = "1" if threads else "0"
         os.environ["LUW_GROUP_X_SLABS"] = "1" if rng.integers(2) == 0 else "0"        # (0: no x slabs where the one-round exchange runs on one thread)
         seed = int(rng.integers(1 << 30))
+        jitter = int(rng.choice([0, 0, 100, 400]))                                        # schedule fuzzing: random delays in front of the kernels (us at most)
         st = synthetic_state(*gN, seed=seed, shell="luw" if forces else None)
         flags = st[0].copy()
         r2 = np.random.default_rng(seed)
@@ -50,6 +51,7 @@ def main():
             if exchange == "sequential": os.environ["LUW_GROUP_EXCHANGE"] = "sequential"
             else: os.environ.pop("LUW_GROUP_EXCHANGE", None)
             capi.reload_tuning()
+            capi.schedule_jitter(seed + (exchange == "sequential"), jitter)
             g = luw.LBMGroup(*gN, *D, 0.01, fp16c=fp16c, devices=[0] * n, **kw)
             assert g.one_phase() == (exchange == "one_phase")
             g.flags[:] = flags; g.u[:] = st[1]; g.rho[:] = st[2]
@@ -59,6 +61,7 @@ def main():
             g.read_from_device(("u", "rho", "T") if thermal else ("u", "rho"))
             res[exchange] = [g.u.copy(), g.rho.copy()] + ([g.T.copy()] if thermal else [])
             g.close()
+            capi.schedule_jitter(0, 0)
         same = all(np.array_equal(a, b) for a, b in zip(res["one_phase"], res["sequential"]))
         vs_oracle = ""
         if gN[0] * gN[1] * gN[2] <= 200000:
@@ -74,9 +77,9 @@ def main():
             same = same and ok
             vs_oracle = ", oracle %s" % ("equal" if ok else "DIFFERENT")
         bad += not same
-        print("case %d: %s global %s n_gpu %s thermal %s forces %s threads %s x_shell %s x_slabs %s steps %s: %s%s" % (case, "fp16c" if fp16c else "f32", gN, D,
-            thermal, forces, threads, os.environ["LUW_X_SHELL"], os.environ["LUW_GROUP_X_SLABS"], steps, "routes equal" if same else "DIFFERENT", vs_oracle),
-                flush=True)
+        print("case %d: %s global %s n_gpu %s thermal %s forces %s threads %s x_shell %s x_slabs %s jitter %s steps %s: %s%s" % (case,
+            "fp16c" if fp16c else "f32", gN, D, thermal, forces, threads, os.environ["LUW_X_SHELL"], os.environ["LUW_GROUP_X_SLABS"], jitter, steps,
+            "routes equal" if same else "DIFFERENT", vs_oracle), flush=True)
     print("fuzz: %d cases, %d different" % (cases, bad))
     sys.exit(1 if bad else 0)
 
