@@ -49,7 +49,7 @@ int luw_upload_fi(luw_solver* s, const void* host_src);
 #define LUW_FAULT_NO_PEER_ODD_PAIRS 1u
 #define LUW_FAULT_RCCL_INIT 2u
 #define LUW_FAULT_SLOW_FIRST_PLACEMENT 4u   /* luw_create's placement search sees its first candidate 30 % slower than it is: another draw must replace it */
-#define LUW_FAULT_UNPACK_WITHOUT_WAIT 8u    /* luw_group_*: unpack kernels do not wait for the neighbours' pack kernels (negative control of the schedule fuzz) */
+#define LUW_FAULT_UNPACK_WITHOUT_WAIT 8u    /* luw_group_*: unpack kernels do not wait for the neighbours' pack kernels (schedule fuzz: negative control) */
 int luw_dev_inject_fault(uint32_t mask);
 /* schedule fuzzing: from now on every second step / pack / unpack / edge kernel the library enqueues is held back on its stream by a delay kernel of
  * 1 .. max_us microseconds (drawn from `seed`; at most 5000; 0 switches it off).  Results must not change: one that depends on a kernel being faster than
