@@ -31,6 +31,7 @@ struct Tuning {
 	uint32_t x_shell = 0u;            // LUW_X_SHELL=<cells>: thickness of the x boundary slabs of a decomposed step (0: 128; A/B aid)
 	int group_transport = LUW_TRANSPORT_PEER; bool group_transport_bad = false; // LUW_GROUP_TRANSPORT = peer | staged | rccl (luw_group_create)
 	bool group_sequential = false;    // LUW_GROUP_EXCHANGE=sequential: luw_group_* exchanges in the reference's three phases also where one round would do
+	uint64_t jitter_seed = 0ull; uint32_t jitter_us = 0u; // LUW_SCHEDULE_JITTER=<seed>:<max us>: schedule fuzzing from the first kernel on (schedule_jitter below)
 	bool group_x_slabs = true;        // LUW_GROUP_X_SLABS=0: luw_group_* drops the x boundary slabs where its one-round exchange needs none (slower on one GPU)
 	bool group_threads = false;       // LUW_GROUP_THREADS=1: one host thread per domain in luw_group_run
 #ifdef LUW_AB_KERNELS                 // tools build only
@@ -82,6 +83,12 @@ static void tuning_load() {
 	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
 	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; }
 	{ const char* e = getenv("LUW_GROUP_X_SLABS"); t.group_x_slabs = !(e&&e[0]=='0'); }
+	if(const char* e = getenv("LUW_SCHEDULE_JITTER")) {
+		char* end = nullptr;
+		t.jitter_seed = strtoull(e, &end, 10);
+		t.jitter_us = (end&&*end==':') ? (uint32_t)std::min<unsigned long>(strtoul(end+1, nullptr, 10), 5000ul) : 0u;
+		g_jitter_state.store(t.jitter_seed); g_jitter_max_us.store(t.jitter_us);
+	}
 #ifdef LUW_AB_KERNELS
 	if(const char* e = getenv("LUW_KERNEL")) t.ab_kernel = atoi(e);
 	t.ab_pair_copy = on("LUW_PAIR_COPY");

@@ -14,12 +14,12 @@ def test_dry_run_walks_all_stages_in_order(tmp_path):
     r = subprocess.run([SCRIPT, "--dry-run", "--out", str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     marks = [l for l in r.stdout.splitlines() if l.startswith("== stage")]
-    assert [m.split(":")[0] for m in marks] == ["== stage 1", "== stage 2", "== stage 3", "== stage 4"] and "first contact complete" in r.stdout
+    assert [m.split(":")[0] for m in marks] == ["== stage %d" % n for n in range(1, 7)] and "first contact complete" in r.stdout
     assert "distinct_devices" in r.stdout and "bench_n 2" in r.stdout
-    assert sorted(os.listdir(tmp_path)) == ["stage1.log", "stage2.log", "stage3.log", "stage4.log"]
+    assert sorted(os.listdir(tmp_path)) == ["stage%d.log" % n for n in range(1, 7)] and r.stdout.count("LUW_SCHEDULE_JITTER") == 2
 
 
-@pytest.mark.parametrize("fail", [1, 2, 3, 4])
+@pytest.mark.parametrize("fail", [1, 2, 3, 4, 5, 6])
 def test_first_failure_ends_the_script_with_the_stage_number(tmp_path, fail):
     r = subprocess.run([SCRIPT, "--dry-run", "--out", str(tmp_path)], capture_output=True, text=True, timeout=60,
         env=dict(os.environ, FIRST_CONTACT_FAIL=str(fail)))

@@ -8,6 +8,9 @@
 #   3  two ranks over RCCL: bench.py --gpus 2 --steps 20 -- its self-check against the CPU oracle through the real transport must pass before anything is timed
 #   4  all GPUs: bench.py --gpus N (N = device count, at most 8) -- the line carries rccl.world_size, every rank's PCI bus id and the link type to each
 #      halo neighbour, and the one-process host's block
+#   5  stage 2 once more under schedule fuzzing (LUW_SCHEDULE_JITTER: random delays of up to 400 us in front of the library's kernels -- an ordering that
+#      only held because of how long kernels take on ONE device shows as a difference from the oracle)
+#   6  stage 3 once more under schedule fuzzing: the self-check is what counts, the timed value means nothing
 # usage: tools/first_contact.sh [--share-device D] [--dry-run] [--out DIR]
 #   --share-device D  rehearsal on a ONE-GPU box: stages 3 and 4 with every rank on device D and the faces staged through gloo (stage 4 with 4 ranks: a test
 #                     box allows six processes on its GPU); stage 2 is skipped by its own test (needs two GPUs)
@@ -69,4 +72,9 @@ stage 3 "two ranks over RCCL, self-check first" bench_n 2 "$PORT"
 [ -n "$SHARE" ] && EXTRA+=(--no-group-host)      # (four ranks + a child of rank 0 + the caller: more processes than a test box allows on its GPU)
 stage 4 "$N4 ranks" bench_n "$N4" $((PORT + 1))
 [ "$DRY" = 1 ] || check_line "$OUT/stage4.log" "$N4" || { echo "== stage 4 FAILED (line check)"; exit 4; }
+stage 5 "one-process host across devices, schedule fuzzing" env LUW_SCHEDULE_JITTER=7:400 python3 -m pytest tests/test_gpu_group.py -k distinct_devices -x -q
+[ -n "$SHARE" ] && EXTRA=(--share-device "$SHARE" --size 384 64 64)
+stage 6 "two ranks over RCCL, schedule fuzzing" env LUW_SCHEDULE_JITTER=11:400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port $((PORT + 2)) bench.py --gpus 2 --steps 20 --warmup 5 --no-secondary "${EXTRA[@]}"
+[ "$DRY" = 1 ] || check_line "$OUT/stage6.log" 2 || { echo "== stage 6 FAILED (line check)"; exit 6; }
 echo "== first contact complete: $OUT"
