@@ -305,11 +305,11 @@ int luw_dev_tuning_text(char* text, uint64_t size) {
 	snprintf(text, (size_t)size,
 		"LUW_ALLOC=%s LUW_COPY_STAGED=%d LUW_ADDR_ROW=%d LUW_PAIR_GENERAL=%d LUW_FUSE_STATS=%d LUW_PLANE_SKEW=%llu LUW_TUNE_PLACEMENT=%d "
 		"LUW_TUNE_FAST=%g LUW_TUNE_VERBOSE=%d LUW_VK_AHEAD=%d LUW_VOXELIZE_ALL_TRIANGLES=%d LUW_X_SHELL=%u LUW_GROUP_TRANSPORT=%s LUW_GROUP_THREADS=%d "
-		"LUW_GROUP_EXCHANGE=%s LUW_GROUP_X_SLABS=%d LUW_SCHEDULE_JITTER=%llu:%u",
+		"LUW_GROUP_EXCHANGE=%s LUW_GROUP_X_SLABS=%d LUW_XCD_ROWS=%d LUW_SCHEDULE_JITTER=%llu:%u",
 		alloc.c_str(), (int)t.copy_staged, (int)t.addr_row, (int)t.pair_general, (int)t.fuse_stats, (unsigned long long)t.plane_skew, t.placement_candidates,
 		t.placement_bar, (int)t.placement_verbose, (int)t.vk_ahead, (int)t.voxelize_all, t.x_shell,
 		t.group_transport==LUW_TRANSPORT_RCCL ? "rccl" : t.group_transport==LUW_TRANSPORT_STAGED ? "staged" : "peer", (int)t.group_threads,
-		t.group_sequential ? "sequential" : "one-round", (int)t.group_x_slabs, (unsigned long long)t.jitter_seed, t.jitter_us);
+		t.group_sequential ? "sequential" : "one-round", (int)t.group_x_slabs, t.xcd_rows, (unsigned long long)t.jitter_seed, t.jitter_us);
 	return LUW_OK;
 }
 int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* probe_TBps, double* create_seconds, char* kept, uint64_t kept_size) {

@@ -32,6 +32,7 @@ struct Tuning {
 	int group_transport = LUW_TRANSPORT_PEER; bool group_transport_bad = false; // LUW_GROUP_TRANSPORT = peer | staged | rccl (luw_group_create)
 	bool group_sequential = false;    // LUW_GROUP_EXCHANGE=sequential: luw_group_* exchanges in the reference's three phases also where one round would do
 	uint64_t jitter_seed = 0ull; uint32_t jitter_us = 0u; // LUW_SCHEDULE_JITTER=<seed>:<max us>: schedule fuzzing from the first kernel on (schedule_jitter below)
+	int xcd_rows = -1;                // LUW_XCD_ROWS=0 / 1: workgroup order of the step kernels (KParams::xcd_rows) for every lattice; unset: luw_create's rule
 	bool group_x_slabs = true;        // LUW_GROUP_X_SLABS=0: luw_group_* drops the x boundary slabs where its one-round exchange needs none (slower on one GPU)
 	bool group_threads = false;       // LUW_GROUP_THREADS=1: one host thread per domain in luw_group_run
 #ifdef LUW_AB_KERNELS                 // tools build only
@@ -83,6 +84,7 @@ static void tuning_load() {
 	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
 	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; }
 	{ const char* e = getenv("LUW_GROUP_X_SLABS"); t.group_x_slabs = !(e&&e[0]=='0'); }
+	if(const char* e = getenv("LUW_XCD_ROWS")) t.xcd_rows = e[0]=='1' ? 1 : e[0]=='0' ? 0 : -1;
 	if(const char* e = getenv("LUW_SCHEDULE_JITTER")) {
 		char* end = nullptr;
 		t.jitter_seed = strtoull(e, &end, 10);

@@ -130,7 +130,9 @@ void k_stream_collide_p(const KParams p, const Box b, uint16_t* __restrict__ fi,
 	// RAW: the populations stay scaled by 2^-112 from the decode's shift-and-mask to the encode's (collide_cell_pk_native<FORCE, RAW>, luw_device.hpp): no
 	// products in the codec, no switch of the rounding mode (the thermal lattice's exact cell update keeps the scaled-up form)
 	constexpr bool RAW = NATIVE && !THERMAL;
-	const uint32_t x = b.x0+2u*(blockIdx.x*blockDim.x+threadIdx.x), y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
+	uint32_t bix, biy;
+	xcd_row_order(p, bix, biy);
+	const uint32_t x = b.x0+2u*(bix*blockDim.x+threadIdx.x), y = b.y0+biy, z = b.z0+blockIdx.z;
 	if(x>=b.x1) return;
 	const RowOff rb = row_offsets(p, y, z);
 	LaneOff o = lane_offsets<uint16_t>(p, x);                      // offsets of cell x; cell x+1 sits 2 bytes further

@@ -153,9 +153,11 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 	// (workgroups go round-robin to the 8 XCDs; remapping them so that each XCD owns one contiguous eighth of the box was
 	// measured 3.5 % slower, 3.50 vs 3.39 ms at 512^3 -- no population is shared between workgroups, so there is nothing
 	// for an XCD's L2 to reuse, and eight distant fronts cost DRAM page locality)
-	const int xi = xa+(int)(blockIdx.x*blockDim.x+threadIdx.x);
+	uint32_t bix, biy;
+	xcd_row_order(p, bix, biy);
+	const int xi = xa+(int)(bix*blockDim.x+threadIdx.x);
 	if(xi<(int)b.x0||xi>=(int)b.x1) return;
-	const uint32_t x = (uint32_t)xi, y = b.y0+blockIdx.y, z = b.z0+blockIdx.z;
+	const uint32_t x = (uint32_t)xi, y = b.y0+biy, z = b.z0+blockIdx.z;
 	if(cell_is_halo(p, x, y, z)) return;
 	CellAddr<T, FLAT> a;
 	fi += a.init(p, x, y, z, MODE==2);
