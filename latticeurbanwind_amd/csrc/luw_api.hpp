@@ -141,10 +141,12 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	k.has_t = k.top_z>=0&&k.top_z<(int)cfg->Nz;
 	set_zone_ranges(k);
 	k.has_F = (cfg->options&LUW_OPT_FORCE_FIELD) ? 1u : 0u;
-	// Workgroup order (xcd_row_order, luw_device.hpp).  Measured over eight lattice shapes, FP32 and FP16C, interleaved (profiles/r05_xcd_rows_sweep.txt):
-	// FP32 lattices whose DDF planes reach 2 GiB run faster with a row's blocks on one XCD -- 1024^3 +4.4 / +5.2 %, 2048x1024x512 +6.4 / +4.5 %,
-	// 2048x2048x256 +5.6 / +3.7 %, 1024x1024x512 +1.0 / +2.8 % -- smaller ones do not (512^3 -1.4 %, 1024x1024x256 -3.1 / +1.1 %), FP16C is even.
-	k.xcd_rows = tuning().xcd_rows>=0 ? (uint32_t)tuning().xcd_rows : (cfg->ddf_format!=LUW_DDF_FP16C&&Np*4ull>=(2ull<<30)) ? 1u : 0u;
+	// Workgroup order (xcd_row_order, luw_device.hpp): G = 4 consecutive lattice rows per XCD and turn for lattices with large DDF planes.  Measured
+	// interleaved over lattice shapes and G = 0 / 1 / 2 / 4 / 16 (profiles/r05_xcd_rows_sweep.txt): FP32 1024^3, 2048x1024x512, 2048x2048x256 +3-6 %,
+	// the 1024x1024x256 headline +1.0 % (four rounds of four), 512^3 and the 512^3 urban tile even -- so FP32 from 1 GiB planes on; FP16C gains only at
+	// 1024^3 (2 GiB planes, +1.5 %) and is mixed below.  G = 1 and 2 lose on the smaller lattices (a single row per turn: -2.5 % at 512^3), 4 never did.
+	const uint64_t plane_bytes = Np*(cfg->ddf_format==LUW_DDF_FP16C ? 2ull : 4ull);
+	k.xcd_rows = tuning().xcd_rows>=0 ? (uint32_t)tuning().xcd_rows : plane_bytes>=((cfg->ddf_format==LUW_DDF_FP16C ? 2ull : 1ull)<<30) ? 4u : 0u;
 	k.w_T = (cfg->options&LUW_OPT_TEMPERATURE) ? literal_roundtrip(1.0f/(2.0f*cfg->alpha+0.5f)) : 0.0f; // FX/lbm.cpp:750
 
 	auto oom = [&](const char* what) { luw_destroy(s); return fail(LUW_ERR_NOMEM, std::string("luw_create: allocation failed: ")+what); };

@@ -59,13 +59,16 @@ struct KParams {
 	float half_tau0;          // tau0 / 2
 	float m2omx, m2omy, m2omz; // -2 omega
 	// workgroup order of the step kernels: 0 = as dispatched (consecutive workgroups go round robin to the 8 XCDs: the blocks of a row sit on different XCDs),
-	// 1 = the blocks of one row on ONE XCD, eight consecutive rows in flight (xcd_row_order below; which lattices get it: luw_create)
+	// G > 0 = the blocks of one row on ONE XCD, G consecutive rows per XCD and turn (xcd_row_order below; which lattices get it: luw_create)
 	uint32_t xcd_rows;
 };
 // blockIdx.x / blockIdx.y of the block this workgroup works on (rows of the launch in multiples of eight; any other launch keeps the dispatch order)
 __device__ __forceinline__ void xcd_row_order(const KParams& p, uint32_t& bix, uint32_t& biy) {
 	bix = blockIdx.x; biy = blockIdx.y;
-	if(p.xcd_rows&&(gridDim.y&7u)==0u) { const uint32_t pp = blockIdx.x+gridDim.x*blockIdx.y, sq = pp>>3; biy = (sq/gridDim.x)*8u+(pp&7u); bix = sq%gridDim.x; }
+	if(p.xcd_rows&&gridDim.y%(8u*p.xcd_rows)==0u) {   // xcd_rows = G: G consecutive rows per XCD and turn
+		const uint32_t pp = blockIdx.x+gridDim.x*blockIdx.y, sq = pp>>3, G = p.xcd_rows, r = sq/gridDim.x;
+		biy = (r/G)*8u*G+(pp&7u)*G+r%G; bix = sq%gridDim.x;
+	}
 }
 
 #include "luw_codec.hpp"   // FP16C <-> FP32, inside namespace luw

@@ -84,7 +84,7 @@ static void tuning_load() {
 	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
 	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; }
 	{ const char* e = getenv("LUW_GROUP_X_SLABS"); t.group_x_slabs = !(e&&e[0]=='0'); }
-	if(const char* e = getenv("LUW_XCD_ROWS")) t.xcd_rows = e[0]=='1' ? 1 : e[0]=='0' ? 0 : -1;
+	if(const char* e = getenv("LUW_XCD_ROWS")) t.xcd_rows = (e[0]>='0'&&e[0]<='9') ? std::min(atoi(e), 64) : -1;
 	if(const char* e = getenv("LUW_SCHEDULE_JITTER")) {
 		char* end = nullptr;
 		t.jitter_seed = strtoull(e, &end, 10);

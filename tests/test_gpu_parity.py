@@ -126,16 +126,16 @@ def test_periodic_box_without_boundaries(luw, kernel, fp16c, Nx):
 @pytest.mark.parametrize("kernel,fp16c,N", [("s", False, (300, 16, 8)), ("s", False, (40, 24, 5)), ("p", True, (640, 16, 6)), ("s", True, (70, 8, 9)),
     ("s", False, (300, 12, 8))])
 def test_rows_of_a_block_row_on_one_xcd_same_values(luw, kernel, fp16c, N):
-    """LUW_XCD_ROWS=1 (luw_create switches it on by itself for FP32 lattices with DDF planes of 2 GiB and more): the step kernels remap their workgroups so
-    that the blocks of one lattice row run on one XCD (xcd_row_order, csrc/luw_device.hpp) -- a permutation of the launch's blocks when its row count is a
-    multiple of eight, the dispatch order otherwise (12 rows here).  Same bits as the oracle, several blocks per row included"""
+    """LUW_XCD_ROWS=G (luw_create sets 4 by itself for lattices with large DDF planes): the step kernels remap their workgroups so that the blocks of one
+    lattice row run on one XCD, G rows per XCD and turn (xcd_row_order, csrc/luw_device.hpp) -- a permutation of the launch's blocks when its row count is
+    a multiple of 8 G, the dispatch order otherwise.  Same bits as the oracle, several blocks per row included"""
     import os
     from latticeurbanwind_amd import capi
     from oracle import oracle
     saved = os.environ.get("LUW_XCD_ROWS")
-    os.environ["LUW_XCD_ROWS"] = "1"; capi.reload_tuning()
+    os.environ["LUW_XCD_ROWS"] = G = "1" if N[1] != 16 else "2"; capi.reload_tuning()           # (16 rows: one turn of two rows per XCD)
     try:
-        assert "LUW_XCD_ROWS=1" in capi.tuning_text()
+        assert "LUW_XCD_ROWS=" + G in capi.tuning_text()
         g, o = make_pair(luw, oracle, *N, 0.02, fp16c, kernel, synthetic_state(*N, seed=7, solids=True, shell=None), every_step=True)
         g.run(7); o.run(7)
         check(g, o, "xcd rows")
