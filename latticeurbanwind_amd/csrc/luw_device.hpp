@@ -62,11 +62,13 @@ struct KParams {
 	// G > 0 = the blocks of one row on ONE XCD, G consecutive rows per XCD and turn (xcd_row_order below; which lattices get it: luw_create)
 	uint32_t xcd_rows;
 };
-// blockIdx.x / blockIdx.y of the block this workgroup works on (rows of the launch in multiples of eight; any other launch keeps the dispatch order)
+// blockIdx.x / blockIdx.y of the block this workgroup works on: a permutation of the launch's blocks within each z layer -- of its first rows, as many as
+// make whole turns of 8 G rows; the rows behind them keep the dispatch order
 __device__ __forceinline__ void xcd_row_order(const KParams& p, uint32_t& bix, uint32_t& biy) {
 	bix = blockIdx.x; biy = blockIdx.y;
-	if(p.xcd_rows&&gridDim.y%(8u*p.xcd_rows)==0u) {   // xcd_rows = G: G consecutive rows per XCD and turn
-		const uint32_t pp = blockIdx.x+gridDim.x*blockIdx.y, sq = pp>>3, G = p.xcd_rows, r = sq/gridDim.x;
+	const uint32_t G = p.xcd_rows;                     // G consecutive rows per XCD and turn
+	if(G&&blockIdx.y<gridDim.y-gridDim.y%(8u*G)) {
+		const uint32_t pp = blockIdx.x+gridDim.x*blockIdx.y, sq = pp>>3, r = sq/gridDim.x;
 		biy = (r/G)*8u*G+(pp&7u)*G+r%G; bix = sq%gridDim.x;
 	}
 }

@@ -123,19 +123,21 @@ def test_periodic_box_without_boundaries(luw, kernel, fp16c, Nx):
     check(g, o, "periodic")
 
 
-@pytest.mark.parametrize("kernel,fp16c,N", [("s", False, (300, 16, 8)), ("s", False, (40, 24, 5)), ("p", True, (640, 16, 6)), ("s", True, (70, 8, 9)),
-    ("s", False, (300, 12, 8))])
-def test_rows_of_a_block_row_on_one_xcd_same_values(luw, kernel, fp16c, N):
+@pytest.mark.parametrize("kernel,fp16c,N,G", [("s", False, (300, 16, 8), 2), ("s", False, (40, 24, 5), 1), ("p", True, (640, 16, 6), 1),
+    ("s", True, (70, 8, 9), 1), ("s", False, (300, 12, 8), 1), ("s", False, (130, 70, 4), 2), ("p", True, (256, 44, 4), 4), ("s", False, (520, 33, 3), 4)])
+def test_rows_of_a_block_row_on_one_xcd_same_values(luw, kernel, fp16c, N, G):
     """LUW_XCD_ROWS=G (luw_create sets 4 by itself for lattices with large DDF planes): the step kernels remap their workgroups so that the blocks of one
-    lattice row run on one XCD, G rows per XCD and turn (xcd_row_order, csrc/luw_device.hpp) -- a permutation of the launch's blocks when its row count is
-    a multiple of 8 G, the dispatch order otherwise.  Same bits as the oracle, several blocks per row included"""
+    lattice row run on one XCD, G rows per XCD and turn (xcd_row_order, csrc/luw_device.hpp) -- a permutation of the blocks of the launch's first rows, as
+    many as
+    make whole turns of 8 G rows; the rows behind them keep the dispatch order (12, 70, 44, 33 rows here).  Same bits as the oracle, several blocks per
+    row included"""
     import os
     from latticeurbanwind_amd import capi
     from oracle import oracle
     saved = os.environ.get("LUW_XCD_ROWS")
-    os.environ["LUW_XCD_ROWS"] = G = "1" if N[1] != 16 else "2"; capi.reload_tuning()           # (16 rows: one turn of two rows per XCD)
+    os.environ["LUW_XCD_ROWS"] = str(G); capi.reload_tuning()
     try:
-        assert "LUW_XCD_ROWS=" + G in capi.tuning_text()
+        assert "LUW_XCD_ROWS=%d" % G in capi.tuning_text()
         g, o = make_pair(luw, oracle, *N, 0.02, fp16c, kernel, synthetic_state(*N, seed=7, solids=True, shell=None), every_step=True)
         g.run(7); o.run(7)
         check(g, o, "xcd rows")
