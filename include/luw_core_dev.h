@@ -31,6 +31,8 @@ int luw_domain_step_timing(luw_domain_step* d, double* kernel_ms, double* shell_
 /* what luw_create's placement search did for this solver: candidates probed (0: no search), algorithmic TB/s of the kept candidate's probe, seconds spent
  * in luw_create, and the kind of allocation kept ("1 GiB chunks", "2 GiB chunks", "hipMalloc", ...; "... (no search)" when none ran) */
 int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* probe_TBps, double* create_seconds, char* kept, uint64_t kept_size);
+/* workgroup order of this solver's step kernels: lattice rows per XCD and turn (0: as dispatched; luw_create's rule or LUW_XCD_ROWS), -1 for a null solver */
+int luw_dev_workgroup_order(const luw_solver* s);
 
 /* ---- the tuning table: the library reads its environment knobs once, at first use */
 int luw_dev_reload_tuning(void);                         /* read the environment again (tests and A/B tools that change it between two solvers) */

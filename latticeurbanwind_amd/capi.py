@@ -43,8 +43,8 @@ SYMBOLS = [
 ]
 # include/luw_core_dev.h
 DEV_SYMBOLS = [
-    "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_reload_tuning", "luw_dev_tuning_text",
-        "luw_dev_inject_fault", "luw_dev_schedule_jitter",
+    "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_workgroup_order", "luw_dev_reload_tuning",
+    "luw_dev_tuning_text", "luw_dev_inject_fault", "luw_dev_schedule_jitter",
     "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_selfcheck_arith",
 ]
 
@@ -186,6 +186,7 @@ def load(path=None):
     L.luw_device_info.argtypes = [i32, C.c_char_p, u64, C.c_char_p, u64, C.POINTER(u64)]
     L.luw_p2p_info.argtypes = [i32, i32, i32p, i32p, i32p, u32p, u32p]
     L.luw_dev_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, u64]
+    L.luw_dev_workgroup_order.argtypes = [vp]
     L.luw_dev_tuning_text.argtypes = [C.c_char_p, u64]
     L.luw_dev_inject_fault.argtypes = [u32]
     L.luw_dev_schedule_jitter.argtypes = [u64, u32]
@@ -235,7 +236,8 @@ def placement_info(handle):
     """what luw_create's placement search did for a solver (luw_dev_placement_info)"""
     n, tb, sec, kept = C.c_int(0), C.c_double(0.0), C.c_double(0.0), C.create_string_buffer(64)
     check(load().luw_dev_placement_info(handle, C.byref(n), C.byref(tb), C.byref(sec), kept, 64))
-    return {"candidates_tried": n.value, "kept": kept.value.decode(), "probe_TBps": round(tb.value, 3), "create_s": round(sec.value, 3)}
+    return {"candidates_tried": n.value, "kept": kept.value.decode(), "probe_TBps": round(tb.value, 3), "create_s": round(sec.value, 3),
+        "rows_per_xcd": int(load().luw_dev_workgroup_order(handle))}
 
 
 FAULT_NO_PEER_ODD_PAIRS, FAULT_RCCL_INIT, FAULT_SLOW_FIRST_PLACEMENT = 1, 2, 4

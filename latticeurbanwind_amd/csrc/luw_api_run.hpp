@@ -320,5 +320,6 @@ int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* p
 	if(kept&&kept_size) snprintf(kept, (size_t)kept_size, "%s", s->placement_kept.c_str());
 	return LUW_OK;
 }
+int luw_dev_workgroup_order(const luw_solver* s) { return s ? (int)s->kp.xcd_rows : -1; }
 
 } // extern "C"
