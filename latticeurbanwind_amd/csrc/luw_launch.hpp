@@ -403,15 +403,18 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 }
 
 // launch helper: picks the template instance for (storage type, lattice, direction)
-template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const uint32_t direction, void* buf_p, void* buf_m) {
-	const uint32_t A = (uint32_t)luw_get_area(s, direction);
-	const dim3 grid((A+255u)/256u), block(256);
+// (first, count: the face elements to move; count 0 = the whole face)
+template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const uint32_t direction, void* buf_p, void* buf_m, const uint32_t first = 0u,
+	const uint32_t count = 0u) {
+	const uint32_t A = (uint32_t)luw_get_area(s, direction), e0 = count ? first : 0u, e1 = count ? first+count : A;
+	const dim3 grid((e1-e0+255u)/256u), block(256);
 	const uint32_t odd = (uint32_t)(s->t&1ull);
 	void* lat = G ? s->d_gi : s->d_fi;
 	schedule_jitter(s->stream);
 	#define LUW_TR(TT, DD) do { \
-		if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat); \
-		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat); \
+		if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat, \
+			e0, e1); \
+		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat, e0, e1); \
 	} while(0)
 	if(s->ddf_bytes==2u) { if(direction==0u) LUW_TR(uint16_t, 0); else if(direction==1u) LUW_TR(uint16_t, 1); else LUW_TR(uint16_t, 2); }
 	else { if(direction==0u) LUW_TR(float, 0); else if(direction==1u) LUW_TR(float, 1); else LUW_TR(float, 2); }
@@ -423,7 +426,7 @@ static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m,
 	const dim3 grid((A+255u)/256u), block(256);
 	schedule_jitter(s->stream);
 	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const uint16_t*)buf_p,
-		(const uint16_t*)buf_m, (uint16_t*)s->d_fi);
+		(const uint16_t*)buf_m, (uint16_t*)s->d_fi, 0u, A);
 	else hipLaunchKernelGGL((k_insert_fi<float, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const float*)buf_p, (const float*)buf_m,
-		(float*)s->d_fi);
+		(float*)s->d_fi, 0u, A);
 }

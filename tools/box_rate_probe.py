@@ -31,16 +31,29 @@ boxes += [("z-quarter, whole rows", (x0, x1, y0, y1, z0, z0 + q)), ("x-half", (x
           ("x 128..384 all y", (x0 + 128, x1 - 128, y0, y1, z0, z1)), ("x-slab 128 all y", (x0, x0 + 128, y0, y1, z0, z1)),
           ("x-slab 256 all y", (x0, x0 + 256, y0, y1, z0, z1)), ("y-half", (x0, x1, y0, y0 + (y1 - y0) // 2, z0, z1))]
 reps = int(os.environ.get("PROBE_REPS", "10"))
+# PROBE_XFACE=out: the step kernels also write the x faces of boxes that hold a border column (luw_set_x_face_buffers); =inout: and read the incoming ones
+# from buffers instead of the lattice (luw_set_x_face_inputs before every launch): what the x-face instantiation costs a box
+xmode = os.environ.get("PROBE_XFACE", "")
+if xmode:
+    A = g.area(0)
+    xdt = torch.int16 if fp16c else torch.float32
+    xbuf = [torch.zeros(5 * A, dtype=xdt, device="cuda") for _ in range(4)]
+    g.set_x_face_buffers(xbuf[0].data_ptr(), xbuf[1].data_ptr())
+    print("x-face mode:", xmode, flush=True)
+def launch(b):
+    if xmode == "inout": g.set_x_face_inputs(xbuf[2].data_ptr(), xbuf[3].data_ptr()); g.increment_time_step(1)
+    g.enqueue_stream_collide(b, False)
+    if xmode != "inout": g.increment_time_step(1)
 base = None
 for name, b in boxes:
     cells = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4])
     if cells <= 0: continue
     for _ in range(2):
-        g.enqueue_stream_collide(b, False); g.increment_time_step(1)
+        launch(b)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(reps):
-        g.enqueue_stream_collide(b, False); g.increment_time_step(1)
+        launch(b)
     e1.record(st); e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     ns = ms * 1e6 / cells
