@@ -218,6 +218,22 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 	auto decode = [](const T v) {
 		if constexpr(RAW) return __uint_as_float(((uint32_t)(int32_t)(int16_t)v<<12)&0x87FFF000u); else return ddf_decode<T>(v);
 	};
+	// x-face inputs of a border lane's cell: fetched HERE, ahead of the DDF loads (like the pair kernel's), so that the wave waits for memory once.  Behind
+	// the loads, where the values are merged in, they were a second round trip for every wave that holds a border column: alone on the device a 128-cell x
+	// slab of a 514x514x512 domain lost 12 % to it and a whole-row box 3 %, now 3.6 % and 0.4 % (tools/box_rate_probe.py, PROBE_XFACE=inout;
+	// profiles/r05_zchunks.txt); beside the interior, as in the default schedule, the step is the same within 0.5 %
+	[[maybe_unused]] T xv[5];
+	[[maybe_unused]] bool xin_here = false;
+	if constexpr(XFACE) {
+		xin_here = (x==1u&&xin_m!=nullptr)||(x==p.Nx-2u&&xin_p!=nullptr);
+		if(xin_here) {
+			const T* const src = x==1u ? xin_m : xin_p;
+			const int sg = x==1u ? -1 : 1;
+			const size_t A = (size_t)p.Ny*p.Nz;
+			xv[0] = src[xface_in_elem(p, y, z, 0, 0)]; xv[1] = src[A+xface_in_elem(p, y, z, sg, 0)]; xv[2] = src[2u*A+xface_in_elem(p, y, z, -sg, 0)];
+			xv[3] = src[3u*A+xface_in_elem(p, y, z, 0, sg)]; xv[4] = src[4u*A+xface_in_elem(p, y, z, 0, -sg)];
+		}
+	}
 	float f[19];
 	f[0] = decode(ldo<(NT!=0)>(fi, a.own()));
 	static_for_pairs([&](auto ic) {
@@ -226,7 +242,12 @@ void k_stream_collide_s(const KParams p, const Box b, const int xa, T* __restric
 		f[i  ] = decode(ldo<(NT!=0)>(fi+(size_t)slotA<PARITY>(i)*Np, a.own()));
 		f[i+1] = decode(ldo<(NT==1||(NT==2&&!shifted))>(fi+(size_t)slotB<PARITY>(i)*Np+a.template row<i>(), a.template lane<i>()));
 	});
-	if constexpr(XFACE) { if((xin_p||xin_m)&&(x==1u||x==p.Nx-2u)) xface_in([&](const int k, const T v) { f[k] = decode(v); }); }
+	if constexpr(XFACE) {   // (first column: the own slots A(1, 7, 13, 9, 15); last column: the slots B in the halo column, loaded into f[2, 8, 14, 10, 16])
+		if(xin_here) {
+			if(x==1u) { f[1] = decode(xv[0]); f[7] = decode(xv[1]); f[13] = decode(xv[2]); f[9] = decode(xv[3]); f[15] = decode(xv[4]); }
+			else { f[2] = decode(xv[0]); f[8] = decode(xv[1]); f[14] = decode(xv[2]); f[10] = decode(xv[3]); f[16] = decode(xv[4]); }
+		}
+	}
 	[[maybe_unused]] float g[7];   // MODE 4: post-collision populations of the thermal lattice
 	if constexpr(MODE!=1) {
 		float rhon, uxn, uyn, uzn;
