@@ -43,6 +43,27 @@ def supported(sim, sample):
         for wf in (False, True))
 
 
+def neighbours(m, C):
+    """the chunks whose z layers chunk m's cells, faces and edge lines touch (z is periodic in the kernel)"""
+    return {(m - 1) % C, m, (m + 1) % C}
+
+
+def comm_plan(order, C):
+    """what the communication stream does in a step whose chunks are computed in `order`: [("wait", k) | ("insert", m) | ("send", k)].  After the wait for
+    chunk k: first the inserts that only waited for k to end (the next step starts on them -- they must not queue behind k's faces on the wire), then k's
+    pack + send, then k's own insert if its neighbours have ended already.  Pure logic, checked by tests/test_zchunks_plan.py."""
+    plan, computed, sent, inserted = [], set(), set(), set()
+    for k in order:
+        plan.append(("wait", k)); computed.add(k)
+        for m in order:
+            if m != k and m in sent and m not in inserted and neighbours(m, C) <= computed:
+                plan.append(("insert", m)); inserted.add(m)
+        plan.append(("send", k)); sent.add(k)
+        if neighbours(k, C) <= computed:
+            plan.append(("insert", k)); inserted.add(k)
+    return plan
+
+
 def run(sim, steps, timed=False):
     import torch
     b, lay = sim.backend, sim.layout
@@ -56,7 +77,7 @@ def run(sim, steps, timed=False):
     if 0 in axes: b.two_x_receive_sets()
     edges = sorted(b.ebuf)
     state = sim.__dict__.setdefault("_zchunk_state", {"start": 0, "inserted": {}})
-    nb = lambda m: {(m - 1) % C, m, (m + 1) % C}
+    from .layout import C19
     ev_k, ev_c = [], []
     # whatever the previous call or the initialisation left on either stream (the unpack of the first exchange runs on the communication stream) comes first
     comp.wait_stream(comm); comm.wait_stream(comp)
@@ -67,14 +88,14 @@ def run(sim, steps, timed=False):
         if timed:
             e0 = torch.cuda.Event(enable_timing=True); e0.record(comp)
         for k in order:                                          # 1. the chunks, whole rows, on the compute stream
-            for m in sorted(nb(k)):
+            for m in sorted(neighbours(k, C)):
                 if m in state["inserted"]: comp.wait_event(state["inserted"][m])
             b.stream_collide(boxes[k], wf, comp)
             done[k] = torch.cuda.Event(); done[k].record(comp)
         if timed:
             e1 = torch.cuda.Event(enable_timing=True); e1.record(comp); ev_k.append((e0, e1))
             x0 = torch.cuda.Event(enable_timing=True); x0.record(comm)
-        computed, sent, inserted = set(), set(), {}
+        inserted = {}
         inputs_pending = [False]
 
         def insert(m):
@@ -86,10 +107,7 @@ def run(sim, steps, timed=False):
             if edges: b.edges_range(comm, z0, z1 - z0, insert=True)
             inserted[m] = torch.cuda.Event(); inserted[m].record(comm)
 
-        for k in order:                                          # 2. their faces, on the communication stream
-            comm.wait_event(done[k]); computed.add(k)
-            for m in order:                                      # inserts that only waited for this chunk to end go first: the next step starts on them
-                if m != k and m in sent and m not in inserted and nb(m) <= computed: insert(m)
+        def send(k):
             z0, z1 = zr[k]
             msgs = []
             for a in axes:
@@ -102,12 +120,14 @@ def run(sim, steps, timed=False):
                     msgs += [(sp[sl], rm[sl], unit), (sm[sl], rp[sl], tuple(-v for v in unit))]
             if edges:
                 b.edges_range(comm, z0, z1 - z0, insert=False)
-                from .layout import C19
                 msgs += [(b.ebuf[e][0][z0:z1], b.ebuf[e][1][z0:z1], C19[7 + e]) for e in edges]
             with torch.cuda.stream(comm):
                 sim.transport.exchange_all(msgs)
-            sent.add(k)
-            if nb(k) <= computed: insert(k)
+
+        for what, k in comm_plan(order, C):                      # 2. their faces, on the communication stream
+            if what == "wait": comm.wait_event(done[k])
+            elif what == "insert": insert(k)
+            else: send(k)
         assert len(inserted) == C
         if 0 in axes: b.next_x_buffers()
         if timed:
