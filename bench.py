@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MLUPS of the D3Q19 collide-stream hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own ranks, benchmarks/launch.py)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N = 1 (the driver's BENCH line): BASELINE.json configs[2] ("C3", the largest single-GPU configuration): 1024x1024x256 D3Q19,
@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from benchmarks.common import (BYTES_PER_LUP, BUILDING_TOP, CELL_M, DT_S, HBM_PEAK_GBPS, NU, ROOT, WORKLOADS, attach_traffic, channel_state, coriolis_omega,
     cpu_baseline,
     cpu_model, device_context, fill_channel, loglaw_profile, profile_key, reference_case_rmse, reference_parity, tile_forcing, usable_cores)   # noqa: F401
+from benchmarks.launch import needs_launcher, self_launch
 from benchmarks.line import emit as emit_line
 from benchmarks.multi import GROUP_HOST_VARIANTS, group_host_child, run_distributed   # noqa: F401
 
@@ -232,7 +233,7 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=None,
         help="N = 1: lattice instead of the workload's; N > 1: per-GPU block (default 512 512 512, 8 GPUs = the 2048x1024x512 tile)")
     ap.add_argument("--n-gpu", type=int, nargs=3, default=None,
-        help="domain grid Dx Dy Dz (default: x kept whole, e.g. 1 4 2 on 8 GPUs; the deck's literal 4 2 1 is accepted)")
+        help="domain grid Dx Dy Dz (default: the deck's literal cut, 4 2 1 on 8 GPUs; the x-whole cut 1 4 2 of the same tile is a secondary block)")
     ap.add_argument("--dtype", choices=["f32", "fp16c"], default="f32")
     ap.add_argument("--kernel", choices=["auto", "scalar", "pair"], default="auto")
     ap.add_argument("--arith", choices=["native", "exact"], default="native",
@@ -268,6 +269,11 @@ def main():
     ap.add_argument("--devices", default=None, help="--group-host-child: the devices of the domains, comma separated")
     ap.add_argument("--global-lattice", type=int, nargs=3, default=None, help="--group-host-child: the whole lattice")
     args = ap.parse_args()
+
+    # the bare `python3 bench.py --gpus N` (the driver's SCALE form): no launcher has set WORLD_SIZE, so this process starts its N ranks as a child
+    # torch.distributed.run and exits with its code -- decided here, before torch or the HIP library are imported (benchmarks/launch.py)
+    if needs_launcher(args.gpus, os.environ):
+        raise SystemExit(self_launch(__file__, sys.argv[1:], args.gpus))
 
     # stdout carries exactly ONE line (the JSON, rank 0): everything libraries print on file descriptor 1 while the run is set up
     # (RCCL's "Librccl path", Gloo's connection notes) is sent to stderr until the result is printed

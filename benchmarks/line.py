@@ -113,7 +113,9 @@ def compact_single(full):
 
 def compact_multi(full):
     out = {k: full.get(k) for k in CONTRACT_KEYS}
-    out.update(pick(full, "dtype", "data", "error"))
+    out.update(pick(full, "dtype", "data"))
+    if full.get("error"):
+        out["error"] = clip(str(full["error"]), 200)
     cfg = full.get("config", {})
     out["config"] = dict(pick(cfg, "global_lattice", "n_gpu", "cells_per_gpu", "bytes_per_lup", "kernel"), workload=clip(cfg.get("workload", ""), 260),
         halo_exchange=clip(cfg.get("halo_exchange", ""), 120))
@@ -166,7 +168,10 @@ def render(full, full_path=None):
             line[k] = {"see": "secondary_file"}
             text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     if len(text) > LINE_LIMIT:
-        raise ValueError("bench line of %d bytes" % len(text))
+        # last resort, never an exception (a line must come out, also from the watchdog's timer thread): the contract's keys, where the rest is, and why
+        bare = {k: line.get(k) for k in CONTRACT_KEYS}
+        bare.update(secondary_file=full_path, error=clip("line of %d bytes cut to the contract keys; %s" % (len(text), line.get("error") or ""), 200))
+        text = json.dumps(bare, allow_nan=False, separators=(",", ":"))
     return text
 
 

@@ -160,3 +160,18 @@ def test_full_record_goes_to_a_file_and_the_line_cites_it(tmp_path):
     assert json.loads(text)["secondary_file"] == path
     rec = json.load(open(path))
     assert rec["secondary"]["c2_f32"]["workload"] == LONG and rec["parity"]["fp32"]["u_avg"] is None
+
+
+def test_render_never_raises_and_clips_the_error_text():
+    # a line that cannot be brought under the limit by shedding (a config text nobody clipped): the contract keys still come out, with a short reason
+    full = multi_full(8)
+    full["error"] = "E" * 9000
+    text = L.render(full, "gpurun_out/bench_secondary.json")
+    assert len(text) <= L.LINE_LIMIT and len(json.loads(text)["error"]) <= 200
+    full["metric"] = "m" * 200; full["unit"] = "MLUPS"
+    huge = dict(full, n_gpus=1); huge.pop("per_rank", None)
+    huge["config"] = {"workload": "w"}
+    huge["roofline"] = dict(roof(), bound="b" * 5000)                 # (nothing sheds the roofline)
+    text = L.render(huge, "gpurun_out/bench_secondary.json")
+    d = json.loads(text)
+    assert len(text) <= L.LINE_LIMIT and all(k in d for k in L.CONTRACT_KEYS) and d["secondary_file"] and "cut to the contract keys" in d["error"]

@@ -58,6 +58,21 @@ def test_two_ranks_self_check_and_blocks(luw, tmp_path):
     assert gh["peer"]["direct_peer_stores"] and not gh["rccl"]["direct_peer_stores"]
 
 
+def test_plain_command_starts_its_own_ranks(luw, tmp_path):
+    """`python3 bench.py --gpus 2 ...` with NO launcher around it -- the form the driver's SCALE runs use: the process starts its ranks as a child
+    torch.distributed.run (benchmarks/launch.py), their ONE line comes out of its stdout, its exit code is theirs"""
+    path = str(tmp_path / "full.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "0", "--size", "384", "64", "64", "--steps", "4", "--warmup", "2",
+        "--no-group-host"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, LUW_BENCH_FULL_JSON=path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    assert "without a launcher: starting -m torch.distributed.run" in r.stderr
+    line, out = full_record(r.stdout, path)
+    assert line["n_gpus"] == 2 and line["rccl"]["world_size"] == 2 and line["value"] > 0 and line["parity"]["ok"] is True
+    assert out["config"]["n_gpu"] == [2, 1, 1] and len(out["per_rank"]) == 2
+
+
 def test_four_ranks_fp16c_coriolis(luw, tmp_path):
     # (no one-process host here: four ranks, this process and a child of rank 0 would be the six processes a test box allows on its GPU)
     out = bench(4, "--size", "384", "64", "64", "--dtype", "fp16c", "--coriolis", "--no-group-host", tmp_path=tmp_path)

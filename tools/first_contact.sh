@@ -66,7 +66,8 @@ assert len(d['ranks']) == n and all(r['bus'] and r['links'] for r in d['ranks'])
 print('   %d ranks: %.0f MLUPS, %.3f ms per step, parity ok (%d cases), links %s' % (n, d['value'], d['ms_per_step'], d['parity']['cases'], sorted({v for r in d['ranks'] for v in r['links'].values() if v})))
 "
 }
-bench_n() { python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$1" --master-addr 127.0.0.1 --master-port "$2" bench.py --gpus "$1" --steps 20 --warmup 5 "${EXTRA[@]}"; }
+# the plain command, as the driver's SCALE runs give it: bench.py starts its own ranks (a child torch.distributed.run, benchmarks/launch.py)
+bench_n() { env LUW_BENCH_MASTER_PORT="$2" python3 bench.py --gpus "$1" --steps 20 --warmup 5 "${EXTRA[@]}"; }
 stage 3 "two ranks over RCCL, self-check first" bench_n 2 "$PORT"
 [ "$DRY" = 1 ] || check_line "$OUT/stage3.log" 2 || { echo "== stage 3 FAILED (line check)"; exit 3; }
 [ -n "$SHARE" ] && EXTRA+=(--no-group-host)      # (four ranks + a child of rank 0 + the caller: more processes than a test box allows on its GPU)
@@ -74,7 +75,7 @@ stage 4 "$N4 ranks" bench_n "$N4" $((PORT + 1))
 [ "$DRY" = 1 ] || check_line "$OUT/stage4.log" "$N4" || { echo "== stage 4 FAILED (line check)"; exit 4; }
 stage 5 "one-process host across devices, schedule fuzzing" env LUW_SCHEDULE_JITTER=7:400 python3 -m pytest tests/test_gpu_group.py -k distinct_devices -x -q
 [ -n "$SHARE" ] && EXTRA=(--share-device "$SHARE" --size 384 64 64)
-stage 6 "two ranks over RCCL, schedule fuzzing" env LUW_SCHEDULE_JITTER=11:400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-  --master-addr 127.0.0.1 --master-port $((PORT + 2)) bench.py --gpus 2 --steps 20 --warmup 5 --no-secondary "${EXTRA[@]}"
+stage 6 "two ranks over RCCL, schedule fuzzing" env LUW_SCHEDULE_JITTER=11:400 LUW_BENCH_MASTER_PORT=$((PORT + 2)) python3 bench.py --gpus 2 --steps 20 --warmup 5 \
+  --no-secondary "${EXTRA[@]}"
 [ "$DRY" = 1 ] || check_line "$OUT/stage6.log" 2 || { echo "== stage 6 FAILED (line check)"; exit 6; }
 echo "== first contact complete: $OUT"
