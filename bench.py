@@ -76,7 +76,7 @@ def run_single(luw, kern, device, size, dtype, buildings, steps, warmup, corioli
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(launch_bytes),
             "note": "achieved = (%g B x %d non-solid cells + 1 flag byte x %d solid cells) / mean stream_collide duration (HIP events on the launch stream)" % (
                 bpl, cells - solid, solid)}
-    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step, urban, native and fp16c), kernel_name)
+    attach_traffic(roof, profile_key(dtype, size, buildings, coriolis, thermal, every_step, urban, native and fp16c), kernel_name, placement["rows_per_xcd"])
     mlups = cells * steps / dt / 1e6
     return {"value": round(mlups, 1), "unit": "MLUPS", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
             "lattice": [Nx, Ny, Nz], "dtype": "f32" if not fp16c else "fp16c-storage/f32-arithmetic", "solid_fraction": round(solid / cells, 5),

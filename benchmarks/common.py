@@ -306,12 +306,17 @@ def profile_key(dtype, size, buildings, coriolis=False, thermal=False, every_ste
         "_th" if thermal else "", "_uf" if every_step else "", "_nat" if native else "")
 
 
-def attach_traffic(roof, key, kernel):
+def attach_traffic(roof, key, kernel, rows_per_xcd=None):
     """HBM traffic of the dominant kernel from rocprofv3 PMC counters: collected in separate --pmc passes of this same workload
     (tools/profile_bench.sh), corrected as MI355X_MICROARCH.md prescribes (read requests are 128 B), committed under profiles/
-    and keyed on the full configuration; null when no profile of exactly this workload exists"""
-    # newest round first
-    prof = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key)) for rnd in (5, 4, 3, 2)) if os.path.exists(q)), None)
+    and keyed on the full configuration (lattice, options, arithmetic); null when no profile of exactly this workload AND this
+    workgroup order exists (a summary records the `rows_per_xcd` of its run since round 6; older ones do not say and are not used)"""
+    prof = None
+    for rnd in range(9, 5, -1):           # newest round first
+        q = os.path.join(ROOT, "profiles", "r%02d_%s_summary.json" % (rnd, key))
+        if os.path.exists(q) and json.load(open(q)).get("rows_per_xcd", "unrecorded") == rows_per_xcd:
+            prof = q
+            break
     if kernel == "auto" and prof:
         pr = json.load(open(prof))
         roof["traffic"] = round(pr["hbm_traffic_bytes_per_launch"])

@@ -88,6 +88,8 @@ def compact_single(full):
     cfg = full.get("config", {})
     out["config"] = dict(pick(cfg, "global_lattice", "n_gpu", "bytes_per_lup", "arith", "kernel", "solid_fraction"),
         workload=clip(cfg.get("workload", ""), 260))
+    if isinstance(cfg.get("placement"), dict):      # workgroup order of the step kernels (the line says which order was timed)
+        out["config"]["rows_per_xcd"] = cfg["placement"].get("rows_per_xcd")
     roof = full.get("roofline", {})
     out["roofline"] = dict(pick(roof, "bound", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_launch", "whole_job_frac"),
         traffic=roof.get("traffic"))

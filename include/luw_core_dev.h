@@ -33,10 +33,6 @@ int luw_domain_step_timing(luw_domain_step* d, double* kernel_ms, double* shell_
 int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* probe_TBps, double* create_seconds, char* kept, uint64_t kept_size);
 /* workgroup order of this solver's step kernels: lattice rows per XCD and turn (0: as dispatched; luw_create's rule or LUW_XCD_ROWS), -1 for a null solver */
 int luw_dev_workgroup_order(const luw_solver* s);
-/* what a plain step launch on this box WOULD do with the x faces (dry run of the kernel choice, nothing is enqueued): does its instantiation write the
- * border columns' faces into the buffers of luw_set_x_face_buffers, does it read pending inputs (luw_set_x_face_inputs) in place?  A host that relies on
- * either for every launch of a step (latticeurbanwind_amd/zchunks.py) asks first. */
-int luw_dev_launch_x_face_caps(luw_solver* s, const uint32_t* box6, int write_fields, int* writes_faces, int* reads_inputs);
 
 /* ---- the tuning table: the library reads its environment knobs once, at first use */
 int luw_dev_reload_tuning(void);                         /* read the environment again (tests and A/B tools that change it between two solvers) */
@@ -47,17 +43,6 @@ int luw_dev_tuning_text(char* text, uint64_t size);      /* the table in effect 
 int luw_download_fi(luw_solver* s, void* host_dst);
 int luw_download_gi(luw_solver* s, void* host_dst);   /* thermal DDFs as stored, gi[i*N+n], i = 0..6 */
 int luw_upload_fi(luw_solver* s, const void* host_src);
-
-/* ---- experimental schedule (LUW_STEP_SCHEDULE=zchunks, built and measured in round 5, not adopted: profiles/r05_zchunks.txt).  Parts of the one-round
- * exchange, for a host that pipelines a step along z (whole-row launches of z ranges one after the other, each range's faces travelling while
- * the next ranges are stepped; latticeurbanwind_amd/distributed.py): the same pack / unpack kernels over the face elements [first, first + count) of a y or
- * z face (element = x + z Nx on a y face: a z range is one contiguous run in each of the five planes of the buffer, which keeps the whole-face layout) and
- * over the cells [first, first + count) of every edge line.  No reference counterpart (communicate_field moves whole faces, FX/lbm.cpp:1907-1935).  The x
- * faces need no such call: the step kernels write and read them (luw_set_x_face_buffers / luw_set_x_face_inputs), whatever box they are launched on. */
-int luw_enqueue_extract_fi_range(luw_solver* s, uint32_t direction, void* dev_buffer_p, void* dev_buffer_m, uint32_t first, uint32_t count);
-int luw_enqueue_insert_fi_range(luw_solver* s, uint32_t direction, const void* dev_buffer_p, const void* dev_buffer_m, uint32_t first, uint32_t count);
-int luw_enqueue_extract_edges_range(luw_solver* s, void* const* dev_buffers, uint32_t first, uint32_t count);
-int luw_enqueue_insert_edges_range(luw_solver* s, const void* const* dev_buffers, uint32_t first, uint32_t count);
 
 /* ---- fault injection for the multi-domain host (first-contact insurance: the paths a node with real peer links takes when something is missing, exercised
  * on one GPU).  mask bit 0: luw_group_create treats every pair of domains (i, j) with i + j odd as devices WITHOUT peer access -- those pairs fall back

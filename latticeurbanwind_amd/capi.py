@@ -43,10 +43,8 @@ SYMBOLS = [
 ]
 # include/luw_core_dev.h
 DEV_SYMBOLS = [
-    "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_workgroup_order", "luw_dev_launch_x_face_caps",
-    "luw_dev_reload_tuning",
+    "luw_run_timed", "luw_group_run_timed", "luw_domain_step_timing", "luw_dev_placement_info", "luw_dev_workgroup_order", "luw_dev_reload_tuning",
     "luw_dev_tuning_text", "luw_dev_inject_fault", "luw_dev_schedule_jitter",
-    "luw_enqueue_extract_fi_range", "luw_enqueue_insert_fi_range", "luw_enqueue_extract_edges_range", "luw_enqueue_insert_edges_range",
     "luw_download_fi", "luw_download_gi", "luw_upload_fi", "luw_selfcheck_fp16c_codec", "luw_selfcheck_arith",
 ]
 
@@ -135,8 +133,6 @@ def load(path=None):
     L.luw_set_x_face_inputs.argtypes = [vp, vp, vp]
     L.luw_get_edge_length.argtypes = [vp, u32]; L.luw_get_edge_length.restype = u64
     L.luw_enqueue_extract_edges.argtypes = [vp, C.POINTER(vp)]; L.luw_enqueue_insert_edges.argtypes = [vp, C.POINTER(vp)]
-    L.luw_enqueue_extract_fi_range.argtypes = [vp, u32, vp, vp, u32, u32]; L.luw_enqueue_insert_fi_range.argtypes = [vp, u32, vp, vp, u32, u32]
-    L.luw_enqueue_extract_edges_range.argtypes = [vp, C.POINTER(vp), u32, u32]; L.luw_enqueue_insert_edges_range.argtypes = [vp, C.POINTER(vp), u32, u32]
     L.luw_finish.argtypes = [vp]
     L.luw_download_fi.argtypes = [vp, vp]
     L.luw_upload_fi.argtypes = [vp, vp]
@@ -191,7 +187,6 @@ def load(path=None):
     L.luw_p2p_info.argtypes = [i32, i32, i32p, i32p, i32p, u32p, u32p]
     L.luw_dev_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, u64]
     L.luw_dev_workgroup_order.argtypes = [vp]
-    L.luw_dev_launch_x_face_caps.argtypes = [vp, C.POINTER(u32), i32, C.POINTER(i32), C.POINTER(i32)]
     L.luw_dev_tuning_text.argtypes = [C.c_char_p, u64]
     L.luw_dev_inject_fault.argtypes = [u32]
     L.luw_dev_schedule_jitter.argtypes = [u64, u32]

@@ -97,9 +97,8 @@ int luw_create(const luw_config* cfg, luw_solver** out) {
 	// DRAM address mapping and was measured (tools/skew_study.sh, profiles/r02_skew_study.md): FP16C is flat from 33 blocks (4 KiB) up and
 	// worse from 385 on some lattices; FP32 with 33 blocks (8 KiB, the round-1 value) depends on the GPU it lands on -- 512^3 3.30 / 3.45 /
 	// 3.64 ms and 1024x512x256 3.48 / 3.76 ms on three boxes -- while 513 blocks (128 KiB + 256 B) gave 3.28-3.30 and 3.31-3.37 ms on all of
-	// them (1024x1024x256: 6.61-6.75 ms either way).  LUW_PLANE_SKEW=<blocks> overrides (study aid).
-	const uint64_t skew_env = tuning().plane_skew;
-	const uint64_t skew_blocks = skew_env ? skew_env : cfg->ddf_format==LUW_DDF_FP16C ? 33ull : 513ull;
+	// them (1024x1024x256: 6.61-6.75 ms either way).
+	const uint64_t skew_blocks = cfg->ddf_format==LUW_DDF_FP16C ? 33ull : 513ull;
 	const uint64_t Np = (uint64_t)Px*cfg->Ny*cfg->Nz+64ull*skew_blocks;
 	if(Np>=(1ull<<32)) return fail(LUW_ERR_INVALID, "luw_create: more than 2^32 (padded) cells per domain are not supported (32-bit cell indices)");
 	int ndev = 0;

@@ -192,7 +192,7 @@ int luw_vk_inlet_attach(luw_solver* s, uint64_t point_count, uint64_t mode_count
 		return fail(LUW_ERR_NOMEM, "luw_vk_inlet_attach: allocating / uploading the inlet tables failed");
 	}
 	s->vk_P = (uint32_t)P; s->vk_M = (uint32_t)mode_count; s->vk_stride = update_stride>1 ? update_stride : 1; s->vk_interp = stride_interpolation!=0;
-	const bool ahead = tuning().vk_ahead; // LUW_VK_AHEAD=0: evaluate in line before every step (A/B and test aid)
+	const bool ahead = tuning().vk_ahead; // LUW_TEST_AIDS=vk_inline: evaluate in line before every step
 	if(ahead) {
 		bool ok = hipMalloc((void**)&s->d_vk_val[0], 3ull*P*4u)==hipSuccess&&hipMalloc((void**)&s->d_vk_val[1], 3ull*P*4u)==hipSuccess;
 		if(ok&&!s->vk_stream) {

@@ -245,7 +245,7 @@ uint64_t luw_get_edge_length(const luw_solver* s, uint32_t edge) {
 	const uint32_t a = pair==2u ? 1u : 0u, b = pair==0u ? 1u : 2u;
 	return (H[a]&&H[b]) ? (uint64_t)N[3u-a-b] : 0ull;
 }
-static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, const char* who, const uint32_t first = 0u, const uint32_t count = 0u) {
+static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, const char* who) {
 	if(!s||!bufs) return fail(LUW_ERR_INVALID, std::string(who)+": bad argument");
 	if(int e = set_device(s)) return e;
 	EdgeBufs B{}; uint32_t Lmax = 0u;
@@ -255,9 +255,7 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 		if(B.p[e]) Lmax = std::max(Lmax, (uint32_t)L);
 	}
 	if(!Lmax) return LUW_OK;
-	const uint32_t l0 = count ? first : 0u, l1 = count ? std::min(first+count, Lmax) : Lmax;   // (the part of every line to move; count 0 = all)
-	if(l1<=l0) return LUW_OK;
-	const dim3 grid((l1-l0+255u)/256u, 12u), block(256);
+	const dim3 grid((Lmax+255u)/256u, 12u), block(256);
 	const uint32_t odd = (uint32_t)(s->t&1ull);
 	// x faces pending in their receive buffers: the edges across the x cut join them there (whoever takes the faces -- a launch in place, or the insert
 	// kernel -- takes the edges with them)
@@ -265,14 +263,12 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 	void* const ip = (to_faces&1u) ? const_cast<void*>(s->xin_p) : nullptr; void* const im = (to_faces&2u) ? const_cast<void*>(s->xin_m) : nullptr;
 	schedule_jitter(s->stream);
 	if(s->ddf_bytes==2u) {
-		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)ip, (uint16_t*)im,
-			l0, l1);
+		if(insert) hipLaunchKernelGGL((k_edges<uint16_t, true>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)ip, (uint16_t*)im);
 		else hipLaunchKernelGGL((k_edges<uint16_t, false>), grid, block, 0, s->stream, s->kp, odd, B, (uint16_t*)s->d_fi, (uint16_t*)nullptr,
-			(uint16_t*)nullptr, l0, l1);
+			(uint16_t*)nullptr);
 	} else {
-		if(insert) hipLaunchKernelGGL((k_edges<float, true>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)ip, (float*)im, l0, l1);
-		else hipLaunchKernelGGL((k_edges<float, false>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)nullptr, (float*)nullptr,
-			l0, l1);
+		if(insert) hipLaunchKernelGGL((k_edges<float, true>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)ip, (float*)im);
+		else hipLaunchKernelGGL((k_edges<float, false>), grid, block, 0, s->stream, s->kp, odd, B, (float*)s->d_fi, (float*)nullptr, (float*)nullptr);
 	}
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
@@ -280,36 +276,6 @@ static int launch_edges(luw_solver* s, void* const* bufs, const bool insert, con
 int luw_enqueue_extract_edges(luw_solver* s, void* const* dev_buffers) { return launch_edges(s, dev_buffers, false, "luw_enqueue_extract_edges"); }
 int luw_enqueue_insert_edges(luw_solver* s, const void* const* dev_buffers) {
 	return launch_edges(s, const_cast<void* const*>(reinterpret_cast<const void* const*>(dev_buffers)), true, "luw_enqueue_insert_edges");
-}
-// ---- parts of the exchange, for a host that pipelines a step along z (latticeurbanwind_amd/distributed.py, _run_zchunks): the same kernels over the face
-// elements [first, first + count) of the y / z faces (element = x + z Nx on a y face: a z range is one contiguous run in each of the five planes) and over
-// the cells [first, first + count) of every edge line.  The x faces have no such call: the step kernels write and read them (luw_set_x_face_buffers / _inputs).
-int luw_enqueue_extract_fi_range(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m, uint32_t first, uint32_t count) {
-	if(!s||direction<1u||direction>2u||!buf_p||!buf_m||!count||(uint64_t)first+count>luw_get_area(s, direction))
-		return fail(LUW_ERR_INVALID, "luw_enqueue_extract_fi_range: bad argument");
-	if(int e = set_device(s)) return e;
-	// (no xin_settle here, unlike luw_enqueue_extract_fi: a host that moves ranges has handed the NEXT step's x faces over already while later ranges of this
-	// step are still being packed -- and parts of those faces have not arrived.  What the lattice holds in the x halo columns travels as the rims of this
-	// face; in the one-round exchange, the only one that moves ranges, the edge messages replace what the rims carry)
-	launch_transfer<false, false>(s, direction, buf_p, buf_m, first, count);
-	HIP_TRY(hipGetLastError());
-	return LUW_OK;
-}
-int luw_enqueue_insert_fi_range(luw_solver* s, uint32_t direction, const void* buf_p, const void* buf_m, uint32_t first, uint32_t count) {
-	if(!s||direction<1u||direction>2u||!buf_p||!buf_m||!count||(uint64_t)first+count>luw_get_area(s, direction))
-		return fail(LUW_ERR_INVALID, "luw_enqueue_insert_fi_range: bad argument");
-	if(int e = set_device(s)) return e;
-	launch_transfer<false, true>(s, direction, const_cast<void*>(buf_p), const_cast<void*>(buf_m), first, count);
-	HIP_TRY(hipGetLastError());
-	return LUW_OK;
-}
-int luw_enqueue_extract_edges_range(luw_solver* s, void* const* dev_buffers, uint32_t first, uint32_t count) {
-	if(!count) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_edges_range: bad argument");
-	return launch_edges(s, dev_buffers, false, "luw_enqueue_extract_edges_range", first, count);
-}
-int luw_enqueue_insert_edges_range(luw_solver* s, const void* const* dev_buffers, uint32_t first, uint32_t count) {
-	if(!count) return fail(LUW_ERR_INVALID, "luw_enqueue_insert_edges_range: bad argument");
-	return launch_edges(s, const_cast<void* const*>(reinterpret_cast<const void* const*>(dev_buffers)), true, "luw_enqueue_insert_edges_range", first, count);
 }
 int luw_enqueue_extract_gi(luw_solver* s, uint32_t direction, void* buf_p, void* buf_m) {
 	if(!s||direction>2u||!buf_p||!buf_m) return fail(LUW_ERR_INVALID, "luw_enqueue_extract_gi: bad argument");
@@ -337,13 +303,12 @@ int luw_dev_tuning_text(char* text, uint64_t size) {
 	const Tuning& t = tuning();
 	const std::string alloc = t.alloc_chunk==0u ? "malloc" : t.alloc_chunk==~(size_t)0u ? "vmm:one" : "vmm:"+std::to_string(t.alloc_chunk>>20);
 	snprintf(text, (size_t)size,
-		"LUW_ALLOC=%s LUW_COPY_STAGED=%d LUW_ADDR_ROW=%d LUW_PAIR_GENERAL=%d LUW_FUSE_STATS=%d LUW_PLANE_SKEW=%llu LUW_TUNE_PLACEMENT=%d "
-		"LUW_TUNE_FAST=%g LUW_TUNE_VERBOSE=%d LUW_VK_AHEAD=%d LUW_VOXELIZE_ALL_TRIANGLES=%d LUW_X_SHELL=%u LUW_GROUP_TRANSPORT=%s LUW_GROUP_THREADS=%d "
-		"LUW_GROUP_EXCHANGE=%s LUW_GROUP_X_SLABS=%d LUW_XCD_ROWS=%d LUW_SCHEDULE_JITTER=%llu:%u",
-		alloc.c_str(), (int)t.copy_staged, (int)t.addr_row, (int)t.pair_general, (int)t.fuse_stats, (unsigned long long)t.plane_skew, t.placement_candidates,
-		t.placement_bar, (int)t.placement_verbose, (int)t.vk_ahead, (int)t.voxelize_all, t.x_shell,
+		"LUW_ALLOC=%s LUW_TEST_AIDS=%s%s%s%s LUW_TUNE_PLACEMENT=%d LUW_TUNE_FAST=%g LUW_X_SHELL=%u LUW_GROUP_TRANSPORT=%s LUW_GROUP_THREADS=%d "
+		"LUW_GROUP_EXCHANGE=%s LUW_XCD_ROWS=%d LUW_SCHEDULE_JITTER=%llu:%u",
+		alloc.c_str(), t.addr_row ? "addr_row," : "", t.fuse_stats ? "" : "separate_stats,", t.vk_ahead ? "" : "vk_inline,", t.voxelize_all ? "voxelize_all," : "",
+		t.placement_candidates, t.placement_bar, t.x_shell,
 		t.group_transport==LUW_TRANSPORT_RCCL ? "rccl" : t.group_transport==LUW_TRANSPORT_STAGED ? "staged" : "peer", (int)t.group_threads,
-		t.group_sequential ? "sequential" : "one-round", (int)t.group_x_slabs, t.xcd_rows, (unsigned long long)t.jitter_seed, t.jitter_us);
+		t.group_sequential ? "sequential" : "one-round", t.xcd_rows, (unsigned long long)t.jitter_seed, t.jitter_us);
 	return LUW_OK;
 }
 int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* probe_TBps, double* create_seconds, char* kept, uint64_t kept_size) {
@@ -355,12 +320,5 @@ int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* p
 	return LUW_OK;
 }
 int luw_dev_workgroup_order(const luw_solver* s) { return s ? (int)s->kp.xcd_rows : -1; }
-int luw_dev_launch_x_face_caps(luw_solver* s, const uint32_t* box6, int write_fields, int* writes_faces, int* reads_inputs) {
-	if(!s||!box6||!writes_faces||!reads_inputs) return fail(LUW_ERR_INVALID, "luw_dev_launch_x_face_caps: null argument");
-	LaunchCaps caps;
-	if(int e = launch_stream_collide(s, Box{ box6[0], box6[1], box6[2], box6[3], box6[4], box6[5] }, write_fields, nullptr, &caps)) return e;
-	*writes_faces = caps.xface_out ? 1 : 0; *reads_inputs = caps.xface_in ? 1 : 0;
-	return LUW_OK;
-}
 
 } // extern "C"

@@ -33,7 +33,7 @@ struct GroupDomain {
 	void* erecv[12] = {};
 	uint32_t enbr[12] = {};
 	std::vector<uint32_t> nbrs;
-	hipEvent_t packed_all = nullptr, unpacked_all = nullptr, x_settled = nullptr;
+	hipEvent_t packed_all = nullptr, unpacked_all = nullptr;
 	hipEvent_t shell_done = nullptr, interior_done = nullptr, pre_done = nullptr, stats_done = nullptr;
 	hipEvent_t packed[3] = {}, unpacked[3] = {}, gpacked[3] = {}, gunpacked[3] = {};
 	bool stats_pending = false;
@@ -59,9 +59,6 @@ struct luw_group {
 	std::vector<int> rccl_rank;               // ... and every domain's rank in it (domains sharing a device share the rank)
 	bool failed = false;                      // a run stopped half-way: streams and sequence numbers are not trustworthy any more
 	bool one_phase = false;                   // every face, the edge messages and the thermal faces in one pack / unpack round per step (peer stores)
-	// one-phase, x split, one enqueueing thread: NO x slabs -- the x faces travel as peer stores of whichever launch holds the border columns, so nothing
-	// has to run first for them; the interior box spans the whole rows (group_boxes) and waits for the x neighbours' interior of the previous step
-	bool x_free = false;
 	uint32_t xset = 0u;                       // one-phase: the set of x receive buffers the NEXT exchange fills
 };
 
@@ -73,7 +70,7 @@ static uint32_t group_x_shell(const luw_group* g) {
 	return tuning().x_shell ? tuning().x_shell : 128u;
 }
 
-static void group_boxes(const luw_group* g, GroupDomain& d) { step_boxes(d.lN, g->H, g->x_free ? 0u : group_x_shell(g), d.whole, d.interior, d.shell); }
+static void group_boxes(const luw_group* g, GroupDomain& d) { step_boxes(d.lN, g->H, group_x_shell(g), d.whole, d.interior, d.shell); }
 
 static void group_rccl_teardown(luw_group* g);
 // the x faces of domain i go straight into its neighbours' receive buffers (peer stores)
@@ -89,10 +86,6 @@ static int group_x_face_ready(luw_group* g, const size_t i, const uint32_t xs) {
 		// their `packed_all` record follows on the same stream -- have to be through; the set those launches are reading now is the other one
 		GroupDomain& P = g->dom[d.nbr[0][0]]; GroupDomain& M = g->dom[d.nbr[0][1]];
 		HIP_TRY(hipStreamWaitEvent(st, P.packed_all, 0)); HIP_TRY(hipStreamWaitEvent(st, M.packed_all, 0));
-		// no x slabs: the neighbours' INTERIOR of the previous step holds border columns too -- it read elements of set xs next to the rows this step's
-		// shell is about to write (a diagonal population comes from the row above or below), and it wrote the elements this step's shell reads beside
-		// its own rows
-		if(g->x_free) { HIP_TRY(hipStreamWaitEvent(st, P.interior_done, 0)); HIP_TRY(hipStreamWaitEvent(st, M.interior_done, 0)); }
 		return luw_set_x_face_buffers(d.s, P.recvx[xs][1], M.recvx[xs][0]);
 	}
 	HIP_TRY(hipStreamWaitEvent(st, g->dom[d.nbr[0][0]].unpacked[0], 0));
@@ -112,7 +105,7 @@ static void group_free(luw_group* g) {
 		if(d.s) { (void)luw_set_stream(d.s, nullptr); luw_destroy(d.s); }
 		for(int k=0; k<2; k++) (void)hipFree(d.recvx[1][k]);         // (set 0 is recv[0])
 		for(void* e : d.erecv) (void)hipFree(e);
-		for(hipEvent_t e : { d.packed_all, d.unpacked_all, d.x_settled }) if(e) (void)hipEventDestroy(e);
+		for(hipEvent_t e : { d.packed_all, d.unpacked_all }) if(e) (void)hipEventDestroy(e);
 		for(int a=0; a<3; a++) for(int k=0; k<2; k++) {
 			(void)hipFree(d.recv[a][k]);
 			(void)hipFree(d.send[a][k]);
@@ -183,13 +176,8 @@ static int domain_pack_all(luw_group* g, const size_t i, const bool on_compute, 
 	for(int a=0; a<3; a++) {
 		if(!g->H[a]) continue;
 		GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
-		// (x: no launch where this step's kernels have written both faces -- into these very buffers, group_x_face_ready.  Without x slabs the border
-		// columns are also the interior's: if its launch could not write the faces -- a sampled step, rows for the one-cell FP16C kernel -- the pack
-		// kernel fetches them once the interior is through)
-		if(a==0) {
-			if(g->x_free&&!xfaces_covered_now(d.s)) HIP_TRY(hipStreamWaitEvent(st, d.interior_done, 0));
-			GROUP_TRY(luw_enqueue_extract_fi(d.s, 0u, P.recvx[xs][1], M.recvx[xs][0]));
-		}
+		// (x: no launch where this step's kernels have written both faces -- into these very buffers, group_x_face_ready)
+		if(a==0) GROUP_TRY(luw_enqueue_extract_fi(d.s, 0u, P.recvx[xs][1], M.recvx[xs][0]));
 		else GROUP_TRY(luw_enqueue_extract_fi(d.s, (uint32_t)a, P.recv[a][1], M.recv[a][0]));
 	}
 	void* out[12];
@@ -266,26 +254,7 @@ static StepCtx group_step_ctx(luw_group* g, const size_t k) {
 }
 static int domain_launch_step(luw_group* g, const size_t k, const GroupStepPlan& pl, hipEvent_t t0, hipEvent_t t1, const uint32_t xs) {
 	GROUP_TRY(group_x_face_ready(g, k, xs));
-	StepCtx c = group_step_ctx(g, k);
-	if(!g->x_free) return step_launch(c, pl.wf, t0, t1);
-	// No x slabs: shell (y / z layers) AND interior hold border columns.  The interior reads the x faces its neighbours' interior of the previous step wrote
-	// (and overwrites the set they read then), and the rims the last unpack round put there: it waits for that round and for the neighbours' interior.
-	// The launches of one step must agree on reading the pending x inputs in place (luw_set_x_face_inputs): where one of them cannot, the insert kernel
-	// puts the faces into the lattice first, on the communication stream, and the interior waits for it.
-	GroupDomain& d = g->dom[k];
-	hipEvent_t waits[4] = { d.unpacked_all, g->dom[d.nbr[0][0]].interior_done, g->dom[d.nbr[0][1]].interior_done, nullptr };
-	int n = 3;
-	bool all_in = true;
-	GROUP_TRY(step_caps(c, pl.wf, all_in));
-	if(!all_in&&d.s->xin_buf) {
-		HIP_TRY(hipStreamWaitEvent(d.comm, d.interior_done, 0));   // (the insert kernel writes slots the previous step's interior may still be working on)
-		GROUP_TRY(luw_set_stream(d.s, d.comm));
-		GROUP_TRY(xin_settle(d.s));
-		HIP_TRY(hipEventRecord(d.x_settled, d.comm));
-		waits[n++] = d.x_settled;
-	}
-	c.interior_waits = waits; c.n_interior_waits = n;
-	return step_launch(c, pl.wf, t0, t1);
+	return step_launch(group_step_ctx(g, k), pl.wf, t0, t1);
 }
 static int domain_separate_stats(luw_group* g, const size_t k) { return step_separate_stats(group_step_ctx(g, k)); }
 
@@ -398,7 +367,7 @@ static int group_run_steps(luw_group* g, const uint64_t steps, const uint64_t fi
 	if(mean_kernel_ms) { GROUP_TRY(group_set_device(g->dom[0])); tev.assign(2u*steps, nullptr); for(auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
 	// Default: ONE enqueueing thread (measured with eight domains on one device: 44 us per domain and step, i.e. 0.36 ms per step for eight --
 	// well inside a 1.9 ms FP16C step; profiles/r02_group_one_gpu.txt).  LUW_GROUP_THREADS=1 gives every domain its own host thread.
-	const bool threaded = tuning().group_threads&&!g->x_free;   // (the slab-free schedule waits for neighbours' interior events: one enqueueing thread only)
+	const bool threaded = tuning().group_threads;
 	// a call of a step or two (probe windows) is not worth starting threads for; RCCL's group calls are issued by ONE thread
 	if(threaded&&steps>=4ull&&g->transport!=LUW_TRANSPORT_RCCL) {
 		GroupThreads T; T.error.assign(g->dom.size(), std::string());

@@ -102,8 +102,6 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 	// reference's three phases, which the staged and RCCL transports always take)
 	g->one_phase = n>1u && g->transport==LUW_TRANSPORT_PEER && !tuning().group_sequential;
 	for(uint32_t i=0u; i<n&&g->one_phase; i++) for(const uint32_t j : g->dom[i].nbrs) if(!g->peer[i][j]) { g->one_phase = false; break; }
-	// (not with the thermal lattice: its x faces are packed by a kernel behind the SHELL, which must then hold the border columns)
-	g->x_free = g->one_phase && g->overlap && g->H[0] && !g->thermal && !tuning().group_threads && !tuning().group_x_slabs;
 	// Streams and halo buffers BEFORE the lattices: every long-lived small allocation is in place before the large arrays and the
 	// placement search of luw_create run
 	for(uint32_t i=0u; i<n; i++) {
@@ -117,7 +115,7 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 			(void)hipGetLastError();
 			HIP_TRY(hipStreamCreateWithFlags(&d.comm, hipStreamNonBlocking));
 		}
-		for(hipEvent_t* e : { &d.shell_done, &d.interior_done, &d.pre_done, &d.stats_done, &d.packed_all, &d.unpacked_all, &d.x_settled })
+		for(hipEvent_t* e : { &d.shell_done, &d.interior_done, &d.pre_done, &d.stats_done, &d.packed_all, &d.unpacked_all })
 			HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
 		if(g->one_phase) for(int e=0; e<12; e++) if(edge_exists(e)) { // one element per cell of the axis the edge runs along
 			const size_t L = (size_t)d.lN[EC[e][0]==0 ? 0 : EC[e][1]==0 ? 1 : 2];

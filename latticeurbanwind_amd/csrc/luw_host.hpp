@@ -18,22 +18,18 @@ static int fail(const int code, const std::string& msg) { g_last_error = msg; re
 // environment.  INTEGRATION.md section 5 lists each knob with its default and purpose; tests/test_capi_library.py holds the two lists together.
 struct Tuning {
 	size_t alloc_chunk = 1024ull<<20; // LUW_ALLOC = vmm:<MiB> (physical chunk size of lattice-sized arrays) | vmm:one (~0: one piece) | malloc (0: hipMalloc)
-	bool copy_staged = false;         // LUW_COPY_STAGED: host <-> device copies of every array through the staging buffer (test aid)
-	bool addr_row = false;            // LUW_ADDR_ROW: FP32 kernel in the row addressing form also where the flat form would do (test aid, same values)
-	bool pair_general = false;        // LUW_PAIR_GENERAL: FP16C kernels never take the force-free / uniform-force specialisations (test aid, same values)
-	bool fuse_stats = true;           // LUW_FUSE_STATS=0: sampled steps use the separate statistics kernel (A/B and test aid, same values)
-	uint64_t plane_skew = 0ull;       // LUW_PLANE_SKEW=<64-element blocks> behind each DDF plane (0: 513 for FP32, 33 for FP16C; study aid)
+	// LUW_TEST_AIDS=<comma list>: other product paths for the same values, taken on request by the tests that hold them to the default ones
+	bool addr_row = false;            //   addr_row: FP32 kernel in the row addressing form also where the flat form would do
+	bool fuse_stats = true;           //   separate_stats: sampled steps use the separate statistics kernel instead of the fused epilogue
+	bool vk_ahead = true;             //   vk_inline: von-Karman inlet evaluated in line instead of one step ahead on a side stream
+	bool voxelize_all = false;        //   voxelize_all: every voxeliser tile tests every triangle (no bins)
 	int placement_candidates = -1;    // LUW_TUNE_PLACEMENT=<n>: allocations of the DDF array luw_create may try (0 / 1: no search; default 6)
 	double placement_bar = 0.0;       // LUW_TUNE_FAST=<TB/s>: probe rate from which a placement is kept without further candidates (99: try all; test aid)
-	bool placement_verbose = false;   // LUW_TUNE_VERBOSE: print every candidate's probe time to stderr
-	bool vk_ahead = true;             // LUW_VK_AHEAD=0: von-Karman inlet evaluated in line instead of one step ahead on a side stream (A/B aid, same values)
-	bool voxelize_all = false;        // LUW_VOXELIZE_ALL_TRIANGLES: every voxeliser tile tests every triangle (test aid for the bins)
 	uint32_t x_shell = 0u;            // LUW_X_SHELL=<cells>: thickness of the x boundary slabs of a decomposed step (0: 128; A/B aid)
 	int group_transport = LUW_TRANSPORT_PEER; bool group_transport_bad = false; // LUW_GROUP_TRANSPORT = peer | staged | rccl (luw_group_create)
 	bool group_sequential = false;    // LUW_GROUP_EXCHANGE=sequential: luw_group_* exchanges in the reference's three phases also where one round would do
 	uint64_t jitter_seed = 0ull; uint32_t jitter_us = 0u; // LUW_SCHEDULE_JITTER=<seed>:<max us>: schedule fuzzing from the first kernel on (schedule_jitter below)
 	int xcd_rows = -1;                // LUW_XCD_ROWS=0 / 1: workgroup order of the step kernels (KParams::xcd_rows) for every lattice; unset: luw_create's rule
-	bool group_x_slabs = true;        // LUW_GROUP_X_SLABS=0: luw_group_* drops the x boundary slabs where its one-round exchange needs none (slower on one GPU)
 	bool group_threads = false;       // LUW_GROUP_THREADS=1: one host thread per domain in luw_group_run
 #ifdef LUW_AB_KERNELS                 // tools build only
 	int ab_kernel = -1;               // LUW_KERNEL=<id>: overrides the kernel choice of callers that expose none
@@ -60,21 +56,19 @@ static Tuning g_tuning;
 static std::once_flag g_tuning_once;
 static void tuning_load() {
 	Tuning t;
-	auto on = [](const char* n) { return getenv(n)!=nullptr; };
-	auto off0 = [](const char* n) { const char* e = getenv(n); return e&&e[0]=='0'; };
+	[[maybe_unused]] auto on = [](const char* n) { return getenv(n)!=nullptr; };
 	if(const char* e = getenv("LUW_ALLOC")) {
 		if(strncmp(e, "malloc", 6)==0) t.alloc_chunk = 0u;
 		else if(strncmp(e, "vmm:one", 7)==0) t.alloc_chunk = ~(size_t)0u;
 		else if(strncmp(e, "vmm:", 4)==0) { const size_t v = (size_t)strtoull(e+4, nullptr, 10); if(v) t.alloc_chunk = v<<20; }
 	}
-	t.copy_staged = on("LUW_COPY_STAGED"); t.addr_row = on("LUW_ADDR_ROW"); t.pair_general = on("LUW_PAIR_GENERAL");
-	t.fuse_stats = !off0("LUW_FUSE_STATS");
-	if(const char* e = getenv("LUW_PLANE_SKEW")) t.plane_skew = strtoull(e, nullptr, 10);
+	if(const char* e = getenv("LUW_TEST_AIDS")) {
+		const std::string list = std::string(",")+e+",";
+		auto has = [&](const char* name) { return list.find(std::string(",")+name+",")!=std::string::npos; };
+		t.addr_row = has("addr_row"); t.fuse_stats = !has("separate_stats"); t.vk_ahead = !has("vk_inline"); t.voxelize_all = has("voxelize_all");
+	}
 	if(const char* e = getenv("LUW_TUNE_PLACEMENT")) t.placement_candidates = atoi(e);
 	if(const char* e = getenv("LUW_TUNE_FAST")) t.placement_bar = atof(e);
-	t.placement_verbose = on("LUW_TUNE_VERBOSE");
-	t.vk_ahead = !off0("LUW_VK_AHEAD");
-	t.voxelize_all = on("LUW_VOXELIZE_ALL_TRIANGLES");
 	if(const char* e = getenv("LUW_X_SHELL")) t.x_shell = (uint32_t)strtoul(e, nullptr, 10);
 	if(const char* e = getenv("LUW_GROUP_TRANSPORT")) {
 		if(strcmp(e, "rccl")==0) t.group_transport = LUW_TRANSPORT_RCCL;
@@ -83,7 +77,6 @@ static void tuning_load() {
 	}
 	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
 	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; }
-	{ const char* e = getenv("LUW_GROUP_X_SLABS"); t.group_x_slabs = !(e&&e[0]=='0'); }
 	if(const char* e = getenv("LUW_XCD_ROWS")) t.xcd_rows = (e[0]>='0'&&e[0]<='9') ? std::min(atoi(e), 64) : -1;
 	if(const char* e = getenv("LUW_SCHEDULE_JITTER")) {
 		char* end = nullptr;

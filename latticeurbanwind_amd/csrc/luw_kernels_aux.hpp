@@ -45,11 +45,10 @@ template<typename T, bool G, int DIR, int PM, int BB> __device__ __forceinline__
 	const uint32_t n = (i&1) ? x+(y+z*p.Ny)*p.Px : neighbor_index<i-1>(p, x, y, z);
 	fi[(size_t)plane*p.Np+n] = buf[(size_t)BB*A+a];
 }
-// (e0, e1: the face elements this launch moves -- the whole face, or the z range of one chunk of a step pipelined along z, luw_enqueue_*_range)
 template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_extract_fi(const KParams p, const uint32_t A, const uint32_t t_odd,
-	T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi, const uint32_t e0, const uint32_t e1) {
-	const uint32_t t = e0+blockIdx.x*blockDim.x+threadIdx.x;
-	if(t>=e1) return;
+	T* __restrict__ buf_p, T* __restrict__ buf_m, const T* __restrict__ fi) {
+	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
+	if(t>=A) return;
 	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
 	uint32_t x, y, z, a;
 	face_cell<DIR>(p, t, Nd-2u, x, y, z, a);
@@ -70,9 +69,9 @@ template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_e
 	}
 }
 template<typename T, bool G, int DIR> __global__ __launch_bounds__(256) void k_insert_fi(const KParams p, const uint32_t A, const uint32_t t_odd,
-	const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi, const uint32_t e0, const uint32_t e1) {
-	const uint32_t t = e0+blockIdx.x*blockDim.x+threadIdx.x;
-	if(t>=e1) return;
+	const T* __restrict__ buf_p, const T* __restrict__ buf_m, T* __restrict__ fi) {
+	const uint32_t t = blockIdx.x*blockDim.x+threadIdx.x;
+	if(t>=A) return;
 	const uint32_t Nd = DIR==0 ? p.Nx : DIR==1 ? p.Ny : p.Nz;
 	uint32_t x, y, z, a;
 	if(buf_p) { // (a null buffer: that side is left alone -- xin_settle, luw_launch.hpp)
@@ -116,8 +115,8 @@ __device__ __forceinline__ uint32_t edge_coord(const bool odd_pop, const bool se
 // buffers look for it -- the rim element of the halo cell that owns the slot (an odd population: the cell one step back along c from the owned corner cell, in
 // the buffer that came from -x; an even one: the halo-halo cell itself, in the buffer that came from +x) -- instead of in the lattice.
 template<typename T, bool INSERT> __global__ __launch_bounds__(256) void k_edges(const KParams p, const uint32_t t_odd, const EdgeBufs bufs,
-	T* __restrict__ fi, T* __restrict__ xin_p, T* __restrict__ xin_m, const uint32_t l0, const uint32_t l1) {   // (l0, l1: the part of every line to move)
-	const uint32_t e = blockIdx.y, l = l0+blockIdx.x*blockDim.x+threadIdx.x;
+	T* __restrict__ fi, T* __restrict__ xin_p = nullptr, T* __restrict__ xin_m = nullptr) {
+	const uint32_t e = blockIdx.y, l = blockIdx.x*blockDim.x+threadIdx.x;
 	T* const buf = (T*)bufs.p[e];
 	if(!buf) return;
 	const int i = 7+(int)e, io = (i&1) ? i : i-1;
@@ -125,7 +124,7 @@ template<typename T, bool INSERT> __global__ __launch_bounds__(256) void k_edges
 	const int pair = ((int)e%6)/2, sa = (i&1) ? 1 : -1, sb = e<6u ? sa : -sa;
 	const int ax_a = pair==2 ? 1 : 0, ax_b = pair==0 ? 1 : 2, ax_c = 3-ax_a-ax_b;
 	const uint32_t N[3] = { p.Nx, p.Ny, p.Nz };
-	if(l>=N[ax_c]||l>=l1) return;
+	if(l>=N[ax_c]) return;
 	uint32_t c[3];
 	c[ax_a] = edge_coord((i&1)!=0, !INSERT, sa, N[ax_a]); c[ax_b] = edge_coord((i&1)!=0, !INSERT, sb, N[ax_b]); c[ax_c] = l;
 	// slot A(io, t) = t odd ? io : io + 1 holds population io + 1 at the cell; slot B(io, t) = t odd ? io + 1 : io holds population io at the +c_io neighbour

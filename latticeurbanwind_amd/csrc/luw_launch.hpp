@@ -109,9 +109,6 @@ static void xface_covered(luw_solver* s, const Box& b) {
 	if(b.x0<=1u&&b.x1>1u) add(1, 2u);
 	if(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u) add(0, 1u);
 }
-static bool xfaces_covered_now(const luw_solver* s) { return s->xf_t==s->t&&s->xf_cover==3u; }
-// what a launch WOULD do with the x faces (dry run of the kernel choice): does its instantiation write the border columns' faces / read the pending inputs?
-struct LaunchCaps { bool xface_out = false, xface_in = false; };
 // ---- x-face input (luw_set_x_face_inputs): the insert of the x faces is pending, the values wait in the receive buffers.  A launch of the step they are for
 // that holds a border column reads that column's side there when its instantiation can (the ones with the x-face output); everything else that wants a side
 // in the lattice -- another instantiation, a pack kernel, a download, a change of t other than the step to xin_for_t -- has xin_settle run the insert kernel
@@ -213,7 +210,7 @@ static const ScalarRow scalar_table[] = {
 	{ { 2u, 3, 2, false, false, false }, scalar_instance<uint16_t, 3, 2, false, false, false>,   "A/B: FP16C general path only" },
 #endif
 };
-static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr, LaunchCaps* caps = nullptr) {
+static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	LaunchGeom g{};
 	g.xa = (int)b.x0-(int)((b.x0+64u-s->kp.halo_x)&63u); // block start of the line that holds b.x0 (see lead_alloc)
 	const uint32_t nx = (uint32_t)((int)b.x1-g.xa), bx = row_block(nx);
@@ -221,12 +218,11 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	ScalarKey k{ (uint8_t)s->ddf_bytes, 0, 2, false, st!=nullptr, false, false, false };
 	// FLAT addressing (one 32-bit byte offset per neighbour within a plane) for FP32 lattices whose planes fit it; the row form otherwise.  In-plane
 	// offsets span the lattice part Px*Ny*Nz of a plane only -- the skew behind it is stride, never addressed -- so 1024^3 with its 2^32-byte planes
-	// still qualifies (largest offset 2^32 - 4).  LUW_ADDR_ROW: the row form also where the flat form would do (both are product code, same values)
+	// still qualifies (largest offset 2^32 - 4).  LUW_TEST_AIDS=addr_row: the row form also where the flat form would do (both are product code, same values)
 	const bool force_row = tuning().addr_row;
 	k.flat = s->ddf_bytes==4u && (uint64_t)s->kp.Px*s->cfg.Ny*s->cfg.Nz*4ull<=(1ull<<32) && !force_row;
-	// FP16C, nothing can push the cells of this box: the instantiation without the force assembly (69 / 76 VGPRs).  LUW_PAIR_GENERAL: never (test aid)
-	const bool general_only = tuning().pair_general;
-	k.noforce = s->ddf_bytes==2u && !st && !general_only && box_force_mode(s, b)==PAIR_FORCE_NONE;
+	// FP16C, nothing can push the cells of this box: the instantiation without the force assembly (69 / 76 VGPRs)
+	k.noforce = s->ddf_bytes==2u && !st && box_force_mode(s, b)==PAIR_FORCE_NONE;
 	if(s->d_gi&&!st) k.mode = 4; // thermal lattice on: the product kernel plus the D3Q7 cell update
 	// native arithmetic (FP16C; plain and sampled steps -- a sampled step with the thermal lattice never comes here: can_fuse_stats): one instantiation per kind
 	if(s->ddf_bytes==2u&&(s->cfg.options&LUW_OPT_NATIVE_ARITH)!=0u) { k.native = true; k.noforce = false; }
@@ -245,7 +241,6 @@ static int launch_scalar(luw_solver* s, const Box& b, const int write_fields, co
 	for(const ScalarRow& r : scalar_table) {
 		const ScalarKey& q = r.key;
 		if(q.ddf_bytes==k.ddf_bytes&&q.mode==k.mode&&q.nt==k.nt&&q.flat==k.flat&&q.stats==k.stats&&q.noforce==k.noforce&&q.native==k.native&&q.xface==k.xface) {
-			if(caps) { caps->xface_out = k.xface; caps->xface_in = k.xface; return LUW_OK; }
 			if(int e = xin_before_launch(s, b, k.xface)) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
@@ -318,13 +313,12 @@ static const PairRow pair_table[] = {
 		"A/B: uniform forces with PARK (6 waves: slower)" },
 #endif
 };
-static int launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr, LaunchCaps* caps = nullptr) {
+static int launch_pair(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
 	LaunchGeom g{};
 	const uint32_t nx = (b.x1-b.x0+1u)/2u;                         // an odd count only when the box ends at an odd Nx: the last lane owns one cell
 	const uint32_t bx = row_block(nx);
 	g.grid = dim3((nx+bx-1u)/bx, b.y1-b.y0, b.z1-b.z0); g.block = dim3(bx);
-	const bool general_only = tuning().pair_general;   // test aid: the general kernel also where a specialisation would do (same values)
-	PairKey k{ 0, st!=nullptr, (st||general_only) ? PAIR_FORCE_ANY : box_force_mode(s, b), false, s->d_gi!=nullptr };
+	PairKey k{ 0, st!=nullptr, st ? PAIR_FORCE_ANY : box_force_mode(s, b), false, s->d_gi!=nullptr };
 	// PARK (luw_kernels_pair.hpp): the lane's second set of values waits in LDS instead of in registers.  Measured interleaved on MI355X
 	// (profiles/r03_pair_park_ab.txt): it pays where the registers cost a wave of occupancy that matters -- the general kernel, 109 -> 91 VGPRs,
 	// 4 -> 5 waves per SIMD: urban 512^3 tile 2.344 -> 2.276 ms, + Coriolis 2.465 -> 2.375 -- and not above five waves (force-free 86 -> 68
@@ -346,7 +340,6 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 		if(q.mode==k.mode&&q.stats==k.stats&&q.force==k.force&&q.park==k.park&&q.thermal==k.thermal&&q.native==k.native&&q.xface==k.xface) {
 			// (the uniform-force instantiation sits at its 96 VGPRs without a register for the x-face INPUT: it writes its faces, and has the unpack kernel
 			// run for what it receives -- pair_reads_x_face_inputs, luw_kernels_pair.hpp)
-			if(caps) { caps->xface_out = k.xface; caps->xface_in = k.xface&&pair_reads_x_face_inputs(k.force, k.thermal); return LUW_OK; }
 			if(int e = xin_before_launch(s, b, k.xface&&pair_reads_x_face_inputs(k.force, k.thermal))) return e;
 			r.launch(s, b, g, write_fields, st ? *st : StatsArgs{});
 			if(k.xface) xface_covered(s, b);
@@ -359,12 +352,12 @@ static int launch_pair(luw_solver* s, const Box& b, const int write_fields, cons
 // Kernel choice.  LUW_KERNEL_AUTO = the scalar kernel (FP32: 39.5k MLUPS at 512^3; vector kernels 20-29k) and, for FP16C rows
 // wide enough, the pair kernel (profiles/r01_kernel_ab.md).  The other kernels stay selectable for A/B runs.
 // can a sampled step carry the Welford update itself?  Product kernels only (scalar / pair, no thermal lattice: its T statistics
-// stay with k_stats_accumulate); LUW_FUSE_STATS=0 keeps the separate kernel (A/B and test aid)
+// stay with k_stats_accumulate); LUW_TEST_AIDS=separate_stats keeps the separate kernel
 static bool can_fuse_stats(const luw_solver* s) {
 	return tuning().fuse_stats && !s->d_gi && (s->kernel==LUW_KERNEL_AUTO||s->kernel==LUW_KERNEL_SCALAR||s->kernel==LUW_KERNEL_PAIR);
 }
-static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr, LaunchCaps* caps = nullptr) {
-	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) { if(caps) caps->xface_out = caps->xface_in = true; return LUW_OK; } // empty box
+static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fields, const StatsArgs* st = nullptr) {
+	if(b.x0>=b.x1||b.y0>=b.y1||b.z0>=b.z1) return LUW_OK; // empty box
 	if(b.x1>s->cfg.Nx||b.y1>s->cfg.Ny||b.z1>s->cfg.Nz) return fail(LUW_ERR_INVALID, "stream_collide: box exceeds the local lattice");
 	if(b.y1-b.y0>65535u||b.z1-b.z0>65535u) return fail(LUW_ERR_INVALID, "stream_collide: box too large for the launch geometry");
 	const bool fp16 = s->ddf_bytes==2u;
@@ -387,34 +380,33 @@ static int launch_stream_collide(luw_solver* s, const Box& b, const int write_fi
 		if(!fp16||!starts_aligned||!whole_pairs) k = LUW_KERNEL_SCALAR;
 	}
 	if(st&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) return fail(LUW_ERR_STATE, "stream_collide: this kernel has no fused statistics");
-	if(caps&&k!=LUW_KERNEL_PAIR&&k!=LUW_KERNEL_SCALAR) { *caps = LaunchCaps{}; return LUW_OK; }   // (A/B kernels of the tools build: neither)
-	if(!caps) schedule_jitter(s->stream);
-	if(k==LUW_KERNEL_PAIR) { if(int e = launch_pair(s, b, write_fields, st, caps)) return e; }
-	else if(st) { if(int e = launch_scalar(s, b, write_fields, st, caps)) return e; }
+	schedule_jitter(s->stream);
+	// the workgroup order of large lattices (KParams::xcd_rows, luw_create's rule) is a property of launches over ALL non-halo rows -- what it was measured
+	// on; a shell or slab box of a decomposed step keeps the dispatch order
+	struct OrderGuard { luw_solver* s; uint32_t G; ~OrderGuard() { s->kp.xcd_rows = G; } } order{ s, s->kp.xcd_rows };
+	if(!(b.y0<=s->kp.halo_y&&b.y1>=s->cfg.Ny-s->kp.halo_y&&b.z0<=s->kp.halo_z&&b.z1>=s->cfg.Nz-s->kp.halo_z)) s->kp.xcd_rows = 0u;
+	if(k==LUW_KERNEL_PAIR) { if(int e = launch_pair(s, b, write_fields, st)) return e; }
+	else if(st) { if(int e = launch_scalar(s, b, write_fields, st)) return e; }
 #ifdef LUW_AB_KERNELS
 	else if(k==LUW_KERNEL_VEC4) { if(fp16) launch_vec<uint16_t, 4>(s, b, write_fields); else launch_vec<float, 4>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC2) { if(fp16) launch_vec<uint16_t, 2>(s, b, write_fields); else launch_vec<float, 2>(s, b, write_fields); }
 	else if(k==LUW_KERNEL_VEC1) { if(fp16) launch_vec<uint16_t, 1>(s, b, write_fields); else launch_vec<float, 1>(s, b, write_fields); }
 #endif
-	else { if(int e = launch_scalar(s, b, write_fields, nullptr, caps)) return e; }
-	if(caps) return LUW_OK;
+	else { if(int e = launch_scalar(s, b, write_fields)) return e; }
 	HIP_TRY(hipGetLastError());
 	return LUW_OK;
 }
 
 // launch helper: picks the template instance for (storage type, lattice, direction)
-// (first, count: the face elements to move; count 0 = the whole face)
-template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const uint32_t direction, void* buf_p, void* buf_m, const uint32_t first = 0u,
-	const uint32_t count = 0u) {
-	const uint32_t A = (uint32_t)luw_get_area(s, direction), e0 = count ? first : 0u, e1 = count ? first+count : A;
-	const dim3 grid((e1-e0+255u)/256u), block(256);
+template<bool G, bool INSERT> static void launch_transfer(luw_solver* s, const uint32_t direction, void* buf_p, void* buf_m) {
+	const uint32_t A = (uint32_t)luw_get_area(s, direction);
+	const dim3 grid((A+255u)/256u), block(256);
 	const uint32_t odd = (uint32_t)(s->t&1ull);
 	void* lat = G ? s->d_gi : s->d_fi;
 	schedule_jitter(s->stream);
 	#define LUW_TR(TT, DD) do { \
-		if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat, \
-			e0, e1); \
-		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat, e0, e1); \
+		if constexpr(INSERT) hipLaunchKernelGGL((k_insert_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (const TT*)buf_p, (const TT*)buf_m, (TT*)lat); \
+		else hipLaunchKernelGGL((k_extract_fi<TT, G, DD>), grid, block, 0, s->stream, s->kp, A, odd, (TT*)buf_p, (TT*)buf_m, (const TT*)lat); \
 	} while(0)
 	if(s->ddf_bytes==2u) { if(direction==0u) LUW_TR(uint16_t, 0); else if(direction==1u) LUW_TR(uint16_t, 1); else LUW_TR(uint16_t, 2); }
 	else { if(direction==0u) LUW_TR(float, 0); else if(direction==1u) LUW_TR(float, 1); else LUW_TR(float, 2); }
@@ -426,7 +418,7 @@ static void launch_insert_x(luw_solver* s, const void* buf_p, const void* buf_m,
 	const dim3 grid((A+255u)/256u), block(256);
 	schedule_jitter(s->stream);
 	if(s->ddf_bytes==2u) hipLaunchKernelGGL((k_insert_fi<uint16_t, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const uint16_t*)buf_p,
-		(const uint16_t*)buf_m, (uint16_t*)s->d_fi, 0u, A);
+		(const uint16_t*)buf_m, (uint16_t*)s->d_fi);
 	else hipLaunchKernelGGL((k_insert_fi<float, false, 0>), grid, block, 0, s->stream, s->kp, A, odd, (const float*)buf_p, (const float*)buf_m,
-		(float*)s->d_fi, 0u, A);
+		(float*)s->d_fi);
 }

@@ -68,8 +68,6 @@ static int tune_ddf_placement(luw_solver* s) {
 	if(int e = step_ms(best_ms)) return e;
 	if(g_injected_faults.load()&LUW_FAULT_SLOW_FIRST_PLACEMENT) best_ms *= 1.3f;   // test hook: the array in place has to be replaced by another draw
 	s->placement_tried = 1;
-	if(T.placement_verbose) fprintf(stderr, "luw: placement candidate 0 (%s): %.3f ms per 2 steps = %.2f TB/s\n", dev_block_kind(s->raw.front()), best_ms,
-		rate(best_ms)*1e-12);
 	// Every candidate is a fresh draw of physical memory: the arrays tried before stay mapped until the search ends, so that a new one cannot be handed the
 	// pages a slow one has just given back.  (What decides the class is WHERE the array lands, more than its kind: on a box in its slow state one kind, mapped
 	// by fresh processes back to back -- each getting the pages its predecessor returned -- ran the workload at 7.0-7.6 ms a dozen times in a row, and kinds
@@ -88,8 +86,6 @@ static int tune_ddf_placement(luw_solver* s) {
 		float ms = 0.0f;
 		if(int e = step_ms(ms)) { s->d_fi = old_fi; dev_free(cand); for(DevBlock& h : held) dev_free(h); return e; }
 		s->placement_tried++;
-		if(T.placement_verbose) fprintf(stderr, "luw: placement candidate %d (%s): %.3f ms per 2 steps = %.2f TB/s (best so far %.3f ms)\n", k,
-			dev_block_kind(cand), ms, rate(ms)*1e-12, best_ms);
 		// another draw has to be CLEARLY faster (3 %) to replace what is kept: a probe of a few steps resolves no less, and on a box where nothing reaches
 		// the bar (all within 1 % of each other: profiles/r04_placement_10x.txt) every process then keeps the same one -- the default
 		// (... or reach the bar where the kept one does not: on a box whose first draw probed 6.15 TB/s the second one's 6.30 was 2.4 % better -- and the

@@ -14,7 +14,6 @@ static void step_axis_ranges(const uint32_t lN[3], const uint32_t H[3], const ui
 	const uint32_t lo = nonhalo[0], hi = nonhalo[1];
 	if(a!=0) { lo_slab[0] = lo; lo_slab[1] = lo+1u; hi_slab[0] = hi-1u; hi_slab[1] = hi; }   // y, z: the one cell layer next to the halo (whole rows)
 	// x: whole blocks of x_shell cells from the first owned cell on (a one-cell x face would run one lane per wave and touch a full memory line per value)
-	else if(x_shell==0u) { lo_slab[0] = lo_slab[1] = lo; hi_slab[0] = hi_slab[1] = hi; }   // no x slabs: border columns go with the y / z layers and the interior
 	else {
 		const uint32_t first_end = std::min(lo+x_shell, hi);
 		const uint32_t last_start = std::max(lo+((hi-1u-lo)/x_shell)*x_shell, first_end);
@@ -48,26 +47,7 @@ struct StepCtx {
 	luw_solver* s; hipStream_t compute, comm;
 	hipEvent_t shell_done, interior_done, pre_done, stats_done; bool* stats_pending;
 	bool overlap; const Box* whole; const Box* interior; const std::vector<Box>* shell;
-	// further events the interior launch waits for (a host whose interior box holds the x border columns: luw_group.hpp, "no x slabs")
-	const hipEvent_t* interior_waits = nullptr; int n_interior_waits = 0;
 };
-// what the launches of one step would do with the x faces (dry run, luw_launch.hpp): do ALL boxes that hold a border column read the pending inputs in place?
-static int step_caps(const StepCtx& c, const int wf, bool& all_read_inputs) {
-	luw_solver* s = c.s;
-	all_read_inputs = true;
-	if(!s->kp.halo_x) return LUW_OK;
-	StatsArgs st{};
-	const bool sample = (wf&LUW_WF_SAMPLE)!=0;
-	auto one = [&](const Box& b) -> int {
-		if(!((b.x0<=1u&&b.x1>1u)||(b.x0<=s->cfg.Nx-2u&&b.x1>s->cfg.Nx-2u))) return LUW_OK;
-		LaunchCaps caps;
-		if(int e = launch_stream_collide(s, b, wf&1, sample ? &st : nullptr, &caps)) return e;
-		all_read_inputs = all_read_inputs&&caps.xface_in;
-		return LUW_OK;
-	};
-	if(c.overlap) { for(const Box& b : *c.shell) if(int e = one(b)) return e; return one(*c.interior); }
-	return one(*c.whole);
-}
 // The kernels of one step.  Overlap: boundary shell on the communication stream (the exchange follows it there), interior on the compute stream, steps
 // pipelined -- interior(t) waits for shell(t-1) only, shell(t) for interior(t-1) (and, by stream order, for the unpack of step t-1); the dependency
 // analysis is tests/test_pipeline_hazards.py.  Otherwise the whole box on the compute stream.  t0/t1 (s0/s1): optional timing events around the
@@ -89,7 +69,6 @@ static int step_launch(const StepCtx& c, const int wf, hipEvent_t t0, hipEvent_t
 		if(s1) HIP_TRY(hipEventRecord(s1, c.comm));
 		HIP_TRY(hipEventRecord(c.shell_done, c.comm));
 		GROUP_TRY(luw_set_stream(s, c.compute));
-		for(int k=0; k<c.n_interior_waits; k++) HIP_TRY(hipStreamWaitEvent(c.compute, c.interior_waits[k], 0));
 		if(t0) HIP_TRY(hipEventRecord(t0, c.compute));
 		const Box& in = *c.interior;
 		GROUP_TRY(luw_enqueue_stream_collide(s, in.x0, in.x1, in.y0, in.y1, in.z0, in.z1, wf)); // ... interior overlaps the halo traffic

@@ -175,9 +175,6 @@ class DomainDecomposedLBM:
             self.initialize()
         b = self.backend
         lay = self.layout
-        from . import zchunks
-        if zchunks.wanted() and zchunks.supported(self, sample):      # opt-in: the step pipelined along z (whole-row launches, no x slabs)
-            return zchunks.run(self, steps, timed)
         if getattr(b, "step", None) is not None and self.overlap == b.step_overlaps() and self.pipeline and self.pre_step is None:
             return self._run_library_schedule(steps, timed, sample)
         ev, ev_comm = [], []

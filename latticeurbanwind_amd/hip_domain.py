@@ -100,31 +100,6 @@ class HipDomain:
         self.lbm.set_x_face_inputs(b[2].data_ptr(), b[3].data_ptr())
         self.next_x_buffers()
 
-    # ---- what a step pipelined along z needs (latticeurbanwind_amd/zchunks.py)
-    def two_x_receive_sets(self):
-        """two sets of x receive buffers used in turn, also where the faces arrive through a transport (a step's kernels read one set while the neighbours'
-        faces of the same step arrive in the other); the send buffers stay"""
-        if self.x_pairs is None:
-            b = self.buf[0]
-            other = [self.torch.zeros_like(b[2]), self.torch.zeros_like(b[3])]
-            self.x_pairs = [b, [b[0], b[1], other[0], other[1]]]
-
-    def x_inputs_pending(self, stream):
-        """the x faces of this step wait in the receive set being filled: the next step's kernels read them there (no unpack kernel); the set changes with
-        next_x_buffers at the end of the step"""
-        self.lbm.set_stream(stream.cuda_stream)
-        self.lbm.set_x_face_inputs(self.buf[0][2].data_ptr(), self.buf[0][3].data_ptr())
-
-    def face_range(self, axis, stream, first, count, insert):
-        """pack (into the send buffers) or unpack (from the receive buffers) the face elements [first, first + count) of a y / z face"""
-        self.lbm.set_stream(stream.cuda_stream)
-        b = self.buf[axis]
-        self.lbm.enqueue_face_range(axis, b[2 if insert else 0].data_ptr(), b[3 if insert else 1].data_ptr(), first, count, insert)
-
-    def edges_range(self, stream, first, count, insert):
-        self.lbm.set_stream(stream.cuda_stream)
-        self.lbm.enqueue_edges_range([self.ebuf[e][1 if insert else 0].data_ptr() if e in self.ebuf else 0 for e in range(12)], first, count, insert)
-
     def next_x_buffers(self):
         """the x buffers of the next step: the other set (the set just filled is read while that step runs)"""
         if self.x_pairs:

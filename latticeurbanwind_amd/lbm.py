@@ -206,22 +206,6 @@ class LBM:
         arr = (C.c_void_p * 12)(*[C.c_void_p(p) if p else None for p in ptrs])
         capi.check((self._L.luw_enqueue_insert_edges if insert else self._L.luw_enqueue_extract_edges)(self._h, arr))
     def enqueue_insert_fi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_fi(self._h, direction, buf_p_ptr, buf_m_ptr))
-
-    def launch_x_face_caps(self, box, write_fields=False):
-        """(writes the x faces itself, reads pending x inputs in place) for a plain step launch on `box` -- a dry run of the kernel choice"""
-        w, r = C.c_int32(0), C.c_int32(0)
-        capi.check(self._L.luw_dev_launch_x_face_caps(self._h, (C.c_uint32 * 6)(*box), int(bool(write_fields)), C.byref(w), C.byref(r)))
-        return bool(w.value), bool(r.value)
-
-    def enqueue_face_range(self, direction, buf_p_ptr, buf_m_ptr, first, count, insert):
-        """pack / unpack of the face elements [first, first + count) of a y or z face (luw_enqueue_extract_fi_range / _insert_fi_range)"""
-        f = self._L.luw_enqueue_insert_fi_range if insert else self._L.luw_enqueue_extract_fi_range
-        capi.check(f(self._h, direction, buf_p_ptr, buf_m_ptr, first, count))
-
-    def enqueue_edges_range(self, ptrs, first, count, insert):
-        """enqueue_edges over the cells [first, first + count) of every edge line"""
-        arr = (C.c_void_p * 12)(*[C.c_void_p(p) if p else None for p in ptrs])
-        capi.check((self._L.luw_enqueue_insert_edges_range if insert else self._L.luw_enqueue_extract_edges_range)(self._h, arr, first, count))
     def enqueue_extract_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_extract_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def enqueue_insert_gi(self, direction, buf_p_ptr, buf_m_ptr): capi.check(self._L.luw_enqueue_insert_gi(self._h, direction, buf_p_ptr, buf_m_ptr))
     def increment_time_step(self, steps=1): capi.check(self._L.luw_increment_time_step(self._h, steps))

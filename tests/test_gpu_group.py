@@ -25,17 +25,14 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["one_phase", "one_phase_no_x_slabs", "sequential"])
+@pytest.fixture(params=["one_phase", "sequential"])
 def exchange(request):
     """both exchange routes of luw_group_*: ONE pack / unpack round per step (default with peer stores: faces of all axes, twelve edge messages, x faces read
-    in place by the next step's kernels; with x split: the 128-cell x boundary slabs, or LUW_GROUP_X_SLABS=0 without them) and the reference's three phases
-    x, y, z (LUW_GROUP_EXCHANGE=sequential)"""
+    in place by the next step's kernels) and the reference's three phases x, y, z (LUW_GROUP_EXCHANGE=sequential)"""
     from latticeurbanwind_amd import capi
-    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_EXCHANGE", "LUW_GROUP_X_SLABS")}
+    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_EXCHANGE",)}
     for k in saved: os.environ.pop(k, None)
     if request.param == "sequential": os.environ["LUW_GROUP_EXCHANGE"] = "sequential"
-    # (no x slabs: the interior launch holds the border columns)
-    if request.param == "one_phase_no_x_slabs": os.environ["LUW_GROUP_X_SLABS"] = "0"
     capi.reload_tuning()
     yield request.param
     for k, v in saved.items():

@@ -238,7 +238,7 @@ def test_x_faces_read_from_the_receive_buffers_equal_the_insert_kernel(luw, monk
         if "zones" in forces else {}
     from latticeurbanwind_amd import capi
     if not fp16c and forces == "coriolis":      # the FP32 kernel's row addressing form (what lattices with planes beyond 4 GiB take) in this one case
-        monkeypatch.setenv("LUW_ADDR_ROW", "1")
+        monkeypatch.setenv("LUW_TEST_AIDS", "addr_row")
     capi.reload_tuning()
     res = {}
     for fused in ("1", "0"):
@@ -267,7 +267,7 @@ def test_x_faces_read_from_the_receive_buffers_equal_the_insert_kernel(luw, monk
         fi = np.asarray(sim.backend.lbm.download_fi()).reshape(19, lz, ly, lx)[:, live]
         res[fused] = (u.copy(), rho.copy(), fi.copy())
         sim.backend.close()
-    monkeypatch.delenv("LUW_ADDR_ROW", raising=False)
+    monkeypatch.delenv("LUW_TEST_AIDS", raising=False)
     capi.reload_tuning()
     for a, b in zip(res["1"], res["0"]):
         assert np.array_equal(a, b)

@@ -278,7 +278,7 @@ def test_on_device_time_averaging_matches_host_welford(luw, size):
 def test_sampled_run_with_fused_statistics_matches_host_welford(luw, size, fp16c, kernel, first, stride):
     # luw_run_sampled: sampled steps carry the Welford update in the step kernel's epilogue (scalar and pair kernels, solids,
     # TYPE_E cells, odd row widths).  Must equal the reference's host loop (FX/setup.cpp:4441-4488) on the oracle's fields bit
-    # for bit, leave the same rho,u as a plain run, and equal the separate-kernel path (LUW_FUSE_STATS=0 is process-wide, so
+    # for bit, leave the same rho,u as a plain run, and equal the separate-kernel path (LUW_TEST_AIDS=separate_stats is process-wide, so
     # that path is compared through { run(1); stats_accumulate() }).
     from oracle import oracle
     Nx, Ny, Nz = size
@@ -558,14 +558,14 @@ def test_thermal_lattice_in_the_pair_kernel(luw, size, forces):
 def test_fp32_row_form_addressing_matches_oracle():
     """FP32 lattices whose planes exceed 32-bit byte offsets (beyond 2^30 cells per GPU, e.g. 1024^3) take the row-form addressing of
     the scalar kernel; the oracle cannot run at that size, so the same code path is forced on the small parity cases
-    (LUW_ADDR_ROW=1) in a child process: step, forces, thermal lattice and multi-domain halos, FP32."""
+    (LUW_TEST_AIDS=addr_row) in a child process: step, forces, thermal lattice and multi-domain halos, FP32."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_halo.py"),
                         "-k", "(stream_collide_matches_oracle and False-s) or (all_force_terms and False-s) or thermal_lattice or (local_group_equals and "
                             "False)"],
-                       env=dict(os.environ, LUW_ADDR_ROW="1"), capture_output=True, text=True, timeout=1200, cwd=root)
+                       env=dict(os.environ, LUW_TEST_AIDS="addr_row"), capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
 
@@ -581,7 +581,7 @@ def test_1024_cubed_on_one_gpu_properties():
     # (its 2^32-byte planes are the largest the flat addressing form takes: byte offsets up to 2^32 - 4.)  The row form at the same size
     # must leave the same 4.3 G values, bit for bit (digest over rho and u):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
-        env=dict(os.environ, LUW_ADDR_ROW="1"))
+        env=dict(os.environ, LUW_TEST_AIDS="addr_row"))
     assert r2.returncode == 0 and "exact fixed point = True" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-1500:]
     d1, d2 = re.search(r"digest (xor=\w+ sum=\w+)", r.stdout), re.search(r"digest (xor=\w+ sum=\w+)", r2.stdout)
     assert d1 and d2 and d1.group(1) == d2.group(1), (d1 and d1.group(1), d2 and d2.group(1))

@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 SEEDS = (1, 2, 3, 4)
 MAX_US = 300
-MODES = {"one_phase": {}, "one_phase_no_x_slabs": {"LUW_GROUP_X_SLABS": "0"}, "sequential": {"LUW_GROUP_EXCHANGE": "sequential"},
+MODES = {"one_phase": {}, "sequential": {"LUW_GROUP_EXCHANGE": "sequential"},
     "one_phase_threads": {"LUW_GROUP_THREADS": "1"}, "sequential_threads": {"LUW_GROUP_EXCHANGE": "sequential", "LUW_GROUP_THREADS": "1"}}
-KNOBS = ("LUW_GROUP_EXCHANGE", "LUW_GROUP_X_SLABS", "LUW_GROUP_THREADS")
+KNOBS = ("LUW_GROUP_EXCHANGE", "LUW_GROUP_THREADS")
 
 
 @pytest.fixture(params=list(MODES))

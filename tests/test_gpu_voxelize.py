@@ -64,7 +64,7 @@ def test_voxelize_preserves_other_flags_and_clears_stale_solids(luw):
 
 def test_triangle_bins_do_not_change_the_mask(luw):
     """the kernel visits only the triangles binned to a 16x16 column tile (bounding box grown by one cell, triangle order
-    kept); with LUW_VOXELIZE_ALL_TRIANGLES every tile sees every triangle, as the reference kernel does: same cells, on a
+    kept); with LUW_TEST_AIDS=voxelize_all every tile sees every triangle, as the reference kernel does: same cells, on a
     mesh of 300 rotated boxes / pyramids / tetrahedra spread over a 400x320x64 lattice"""
     import sys, time
     sys.path.insert(0, GOLD)
@@ -88,15 +88,15 @@ def test_triangle_bins_do_not_change_the_mask(luw):
     masks, secs = [], []
     for brute in (False, True):
         from latticeurbanwind_amd import capi
-        if brute: os.environ["LUW_VOXELIZE_ALL_TRIANGLES"] = "1"
-        else: os.environ.pop("LUW_VOXELIZE_ALL_TRIANGLES", None)
+        if brute: os.environ["LUW_TEST_AIDS"] = "voxelize_all"
+        else: os.environ.pop("LUW_TEST_AIDS", None)
         capi.reload_tuning()                                   # the library reads its environment once
         try:
             lbm = LBM(400, 320, 64, nu=0.01)
             t0 = time.perf_counter(); lbm.voxelize_mesh_on_device(tri); secs.append(time.perf_counter() - t0)
             masks.append((lbm.flags.data & 1).copy()); lbm.close()
         finally:
-            os.environ.pop("LUW_VOXELIZE_ALL_TRIANGLES", None)
+            os.environ.pop("LUW_TEST_AIDS", None)
             capi.reload_tuning()
     assert masks[0].sum() > 100000 and np.array_equal(masks[0], masks[1])
     print("voxelise %d triangles on 400x320x64: binned %.3f s, all triangles per column %.3f s" % (len(tris), secs[0], secs[1]))

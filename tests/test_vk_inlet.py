@@ -125,7 +125,7 @@ def test_hip_vk_inlet_vs_real_reference(luw):
 @pytest.mark.gpu
 def test_values_computed_ahead_equal_values_computed_in_line(luw, tmp_path):
     """the product evaluates the inlet values of step t+1 on a side stream while step t runs and scatters them into u before the
-    next step; LUW_VK_AHEAD=0 evaluates them in line in front of every step.  Same kernel arithmetic: the deck driver must write
+    next step; LUW_TEST_AIDS=vk_inline evaluates them in line in front of every step.  Same kernel arithmetic: the deck driver must write
     byte-identical files either way (case V: inlet on, unsteady outputs, averaging; and with update stride 3 + interpolation)."""
     import filecmp, glob, shutil, subprocess
     driver = os.path.join(ROOT, "latticeurbanwind_amd", "host", "luw_driver")
@@ -137,7 +137,7 @@ def test_values_computed_ahead_equal_values_computed_in_line(luw, tmp_path):
             shutil.copytree(os.path.join(GOLD, "refcases", "CaseV"), proj)
             deck = os.path.join(proj, "conf.luwpf")
             open(deck, "a").write("\n" + extra)
-            r = subprocess.run([driver, deck, "--ddf", "fp32"], capture_output=True, text=True, timeout=600, env=dict(os.environ, LUW_VK_AHEAD=mode))
+            r = subprocess.run([driver, deck, "--ddf", "fp32"], capture_output=True, text=True, timeout=600, env=dict(os.environ, LUW_TEST_AIDS=("" if mode == "1" else "vk_inline")))
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
             out[mode] = sorted(glob.glob(os.path.join(proj, "RESULTS", "vtk", "*.vtk")))
         assert len(out["1"]) >= 4 and [os.path.basename(p) for p in out["1"]] == [os.path.basename(p) for p in out["0"]]

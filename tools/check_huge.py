@@ -2,7 +2,7 @@
 """1024^3 on one MI355X (FP32: 82 GB of DDFs; FP16C: 41 GB, pair kernel): size-independent properties that need no oracle -- the rest
 state is an exact fixed point, and a periodic box with a three-dimensional wave field conserves mass and stays finite.  Prints a digest
 (xor and sum over the bit patterns of rho and u) so that two runs -- e.g. the flat and the row addressing form of the FP32 kernel
-(LUW_ADDR_ROW=1) -- can be held to identical results value for value.
+(LUW_TEST_AIDS=addr_row) -- can be held to identical results value for value.
 usage: check_huge.py [f32|fp16c]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the FP16C pair kernel with both cells of a lane at once (LUW_PAIR_CROSS=1) against the one-after-the-other kernels: bit-for-bit tests first,
-# then fresh-process bench blocks interleaved.   usage: tools/ab_cross.sh <out dir> [blocks...]
-R="$(cd "$(dirname "$0")/.." && pwd)"; O="$1"; shift; mkdir -p "$O"
+# then fresh-process bench blocks interleaved.   usage: tools/experiments/cross_pack/ab_cross.sh <out dir> [blocks...]   (after applying product_sources.patch)
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}"; O="$1"; shift; mkdir -p "$O"
 BLOCKS="${@:-c2_fp16c c3_fp16c c3_fp16c_coriolis tile512_urban_fp16c_coriolis}"
 if [ -z "$SKIP_TESTS" ]; then
   LUW_PAIR_CROSS=1 timeout -k 10 900 python3 -m pytest "$R/tests/test_gpu_parity.py" "$R/tests/test_gpu_halo.py" -x -q -k "fp16 or pair or force or zone or halo or coriolis" > "$O/pytest_cross.txt" 2>&1 \

@@ -2,7 +2,7 @@
 # GPU box: the step pipelined along z (LUW_STEP_SCHEDULE=zchunks) against the default shell / interior schedule on the rank-shape blocks of bench.py (one rank
 # of the 8-GPU tile in its real shape, whole step through RCCL's self send / receive or peer loopback), fresh process per measurement, interleaved.
 #   usage: tools/ab_zchunks.sh <out dir> [blocks...]
-R="$(cd "$(dirname "$0")/.." && pwd)"; O="$1"; shift; mkdir -p "$O"; : > "$O/ab_zchunks.txt"
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}"; O="$1"; shift; mkdir -p "$O"; : > "$O/ab_zchunks.txt"
 BLOCKS="${@:-c4_rank_4x2x1_f32 c5_rank_4x2x1_fp16c_coriolis}"
 for rep in 1 2 3; do for blk in $BLOCKS; do for tr in rccl-self peer-loopback; do for sch in default zchunks; do
   if [ $sch = zchunks ]; then export LUW_STEP_SCHEDULE=zchunks; else unset LUW_STEP_SCHEDULE; fi

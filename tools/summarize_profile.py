@@ -36,7 +36,8 @@ def optional(dirpat, name):
 valu_busy, mem_stalled = optional("pmc_VALUBusy_MemUnitStalled", "VALUBusy"), optional("pmc_VALUBusy_MemUnitStalled", "MemUnitStalled")
 waves, insts_valu, insts_salu = (optional("pmc_SQ_WAVES_SQ_INSTS_VALU_SQ_INSTS_SALU", n) for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"))
 traffic = rd * 128.0 + write_kb * 1024.0
-s = {"tag": tag, "workload": bench["config"]["workload"], "kernel": kname, "launches": calls, "rocprof_avg_ms": round(tot / calls / 1e6, 4),
+s = {"tag": tag, "workload": bench["config"]["workload"], "rows_per_xcd": bench["config"].get("rows_per_xcd"),
+    "arith": bench["config"].get("arith"), "kernel": kname, "launches": calls, "rocprof_avg_ms": round(tot / calls / 1e6, 4),
     "hip_event_avg_ms_same_run": bench["roofline"]["kernel_ms"],
      "algorithmic_bytes_per_launch": algo, "FETCH_SIZE_KB": fetch_kb, "FETCH_bytes_corrected_x2": fetch_kb * 1024.0 * 2.0, "TCC_EA0_RDREQ": rd,
      "read_bytes_128B_requests": rd * 128.0, "WRITE_SIZE_KB": write_kb, "write_bytes": write_kb * 1024.0, "TCC_EA0_WRREQ": wr,
