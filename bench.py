@@ -30,7 +30,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from benchmarks.common import (BYTES_PER_LUP, BUILDING_TOP, CELL_M, DT_S, HBM_PEAK_GBPS, NU, ROOT, WORKLOADS, attach_traffic, channel_state, coriolis_omega,
+from benchmarks.common import (REFERENCE_GPU_CONTEXT, BYTES_PER_LUP, BUILDING_TOP, CELL_M, DT_S, HBM_PEAK_GBPS, NU, ROOT, WORKLOADS, attach_traffic, channel_state, coriolis_omega,
     cpu_baseline,
     cpu_model, device_context, fill_channel, loglaw_profile, profile_key, reference_case_rmse, reference_parity, tile_forcing, usable_cores)   # noqa: F401
 from benchmarks.launch import needs_launcher, self_launch
@@ -399,6 +399,7 @@ def main():
                             "numbers were taken on; it scales every block of this line alike"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["reference_context"] = REFERENCE_GPU_CONTEXT      # (full record only: benchmarks/line.py cites it as two numbers under cpu_baseline)
             try:
                 out["parity"] = reference_parity()
             except Exception as e:      # never let the side measurement break the benchmark line

@@ -268,6 +268,14 @@ def cpu_baseline(max_seconds=10.0):
                 "swept over %s of %d usable cores" % (steps, dt, cands, cores)}
 
 
+# The REAL reference's own GPU kernels (both builds, AMD OpenCL runtime) on an MI355X of this pool: context beside cpu_baseline, not a target and not measured
+# by bench.py (the reference's binaries never travel with the repo: tools/reference_perf_session.sh, a fixture-regeneration session of round 5)
+REFERENCE_GPU_CONTEXT = {"reference_gpu_opencl_mlups": {"fp32_build": 15189, "shipped_fp16c_thermal_build": 15673},
+    "workload": "1024x1024x256 empty channel deck, 200 steps, MLUPS from the reference's own 'normal Steps/s' line",
+    "device": "one MI355X (same pool, another session)", "source": "profiles/r05_reference_perf_and_e2e_wall.txt",
+    "kind": "context: the reference's OpenCL kernels on the same GPU model; its CPU-OpenCL path cannot run here (no CPU OpenCL runtime, SURVEY 8d)"}
+
+
 def device_context(torch, device):
     """What this particular GPU streams by itself, next to the contract's 8 TB/s: the same binary ran the HBM-bound FP32 step 12 % apart on
     different MI355X boxes of the pool (profiles/r02_skew_study.md), so the line carries the box's own device-to-device copy rate (2 GiB

@@ -99,6 +99,9 @@ def compact_single(full):
         cb = full["cpu_baseline"]
         out["cpu_baseline"] = dict(pick(cb, "value", "unit", "cores", "kind", "cpu_model", "dram_GBps", "copy_bandwidth_GBps"),
             sample=clip(cb.get("sample", ""), 160))
+        ref = (full.get("reference_context") or {}).get("reference_gpu_opencl_mlups")
+        if ref:     # the reference's own OpenCL kernels on an MI355X (context, another session): one file holds both baselines
+            out["cpu_baseline"]["reference_gpu_opencl_mlups"] = ref
     if "parity" in full:
         out["parity"] = parity_summary(full["parity"])
     dev = full.get("device", {})

@@ -125,6 +125,36 @@ def test_native_arithmetic_conserves_mass_like_the_exact_kernels(luw):
     assert worst[True] <= 2.0 * worst[False] + 2e-8 and worst[True] < 1.5e-7, worst
 
 
+def test_native_mass_drift_is_a_random_walk_not_a_bias(luw):
+    """what justifies the bound above: a bias of the native formulas -- a folded coefficient that does not cancel, a reciprocal that is always low
+    -- moves the mean density by the SAME signed amount every step; rounding of the stored codes moves it by increments of either sign.  Per-step increments
+    of the mean density over 600 steps, three seeds, both arithmetics: the mean increment of the native kernels must lie within four standard errors of zero
+    or of the exact kernels' (whose encode is round-to-nearest-even: unbiased), and the walk must have ended where sqrt(K) growth puts it, not K growth."""
+    Nx, Ny, Nz, K = 256, 64, 64, 600
+    stats = {}
+    for nat in (False, True):
+        for seed in (5, 6, 7):
+            st = synthetic_state(Nx, Ny, Nz, seed=seed, solids=False, shell=None)
+            g = luw.LBM(Nx, Ny, Nz, 1e-4, fp16c=True, native_arith=nat)
+            g.flags.data[:] = st[0]; g.u.data[:] = st[1]; g.rho.data[:] = st[2]
+            g.run(1)
+            m = []
+            for _ in range(K + 1):
+                g.rho.read_from_device(); m.append(float(g.rho.data.astype(np.float64).mean())); g.run(1)
+            g.close()
+            d = np.diff(np.array(m))
+            stats[(nat, seed)] = (d.mean(), d.std(ddof=1) / np.sqrt(len(d)), m[-1] - m[0], d.std(ddof=1))
+    for seed in (5, 6, 7):
+        (me, se_e, tot_e, sd_e), (mn, se_n, tot_n, sd_n) = stats[(False, seed)], stats[(True, seed)]
+        print("seed %d: mean increment exact %+.2e +- %.1e, native %+.2e +- %.1e; total over %d steps %+.2e / %+.2e; sigma %.2e / %.2e" % (seed, me, se_e, mn,
+            se_n, K, tot_e, tot_n, sd_e, sd_n))
+        assert abs(mn) <= 4.0 * se_n or abs(mn - me) <= 4.0 * np.hypot(se_n, se_e), (seed, mn, se_n, me, se_e)
+        assert abs(tot_n) <= 6.0 * sd_n * np.sqrt(K), (seed, tot_n, sd_n)          # a walk of K independent increments; a bias b would add b K
+    # the three seeds do not all drift the same way by more than their own noise
+    means = [stats[(True, s_)][0] for s_ in (5, 6, 7)]; ses = [stats[(True, s_)][1] for s_ in (5, 6, 7)]
+    assert not (all(m_ > 3 * e_ for m_, e_ in zip(means, ses)) or all(m_ < -3 * e_ for m_, e_ in zip(means, ses))), (means, ses)
+
+
 @pytest.mark.parametrize("forces", ["none", "zones+coriolis"])
 def test_native_arithmetic_gives_a_cell_the_same_values_in_either_kernel(luw, forces):
     # a decomposed run takes the one-cell kernel where rows are narrow or unaligned and the pair kernel elsewhere: both run collide_cell_pk_native with the
