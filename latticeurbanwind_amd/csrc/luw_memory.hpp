@@ -21,17 +21,20 @@ static void dev_block_pieces(const DevBlock& b, const size_t mapped, std::vector
 // keep_range: the physical memory goes back now, the (empty) address range stays reserved until a later dev_free of the same block -- a candidate of the
 // placement search is released this way, so that the next candidate never lands on addresses whose page-table entries were torn down a moment ago.
 // An address range whose mappings are gone is not handed back to the runtime at once: the next reservation of the process would land on the very addresses
-// whose page-table entries were torn down a moment ago, and on this ROCm a kernel that touches such a fresh mapping can die with a memory access fault
-// (round 5: the GPU suite, twice, in the runtime's own memset of a just-mapped array, right after an eight-domain group had released fifty ranges;
-// profiles/r05_vmm_range_reuse.txt).  Retired ranges wait here -- reserved, nothing mapped, no physical memory -- and only the oldest go back once more than
-// 4 TiB of address space or 512 ranges are waiting.
+// whose translations were torn down a moment ago, and on this ROCm (7.2, gfx950) a NEW mapping at a recycled virtual address is not seen by all of the
+// device: tools/vmm_group_cycle.hip, a bare HIP program, maps fifty ranges from 1 GiB chunks, zeroes them, writes a mark into every 2 MiB page with one
+// kernel and reads it back with the next -- with hipMemAddressFree at once, from the second cycle on about 2 % of the pages do not read back what was
+// written (translations of the previous mapping survive somewhere); with the ranges kept reserved, none (profiles/r06_vmm.txt).  Round 5 met the same thing
+// as a memory access fault in the runtime's own memset of a just-mapped array, right after an eight-domain group had released fifty ranges
+// (profiles/r05_vmm_range_reuse.txt).  Retired ranges wait here -- reserved, nothing mapped, their physical memory given back (checked:
+// tools/vmm_product_cycle.py) -- and only the oldest go back once more than 32 TiB of address space or 2048 ranges are waiting: thousands of solvers later.
 static std::mutex g_retired_mutex;
 static std::deque<std::pair<void*, size_t>> g_retired_ranges;
 static size_t g_retired_bytes = 0u;
 static void retire_address_range(void* base, const size_t bytes) {
 	std::lock_guard<std::mutex> lock(g_retired_mutex);
 	g_retired_ranges.emplace_back(base, bytes); g_retired_bytes += bytes;
-	while(g_retired_ranges.size()>512u||g_retired_bytes>(4ull<<40)) {
+	while(g_retired_ranges.size()>2048u||g_retired_bytes>(32ull<<40)) {
 		(void)hipMemAddressFree(g_retired_ranges.front().first, g_retired_ranges.front().second);
 		g_retired_bytes -= g_retired_ranges.front().second; g_retired_ranges.pop_front();
 	}
