@@ -286,8 +286,9 @@ int luw_group_domain_info(const luw_group* g, uint32_t d, uint32_t* local_N, int
 int luw_group_overlaps(const luw_group* g);                 /* 1: shell / interior overlap in use (every split axis has >= 4 owned layers) */
 int luw_group_direct_peer_stores(const luw_group* g);       /* 1: every face travels as peer stores of the pack kernel, none through a copy */
 /* 1: ONE pack / unpack round per step -- the faces of all axes together, the populations that cross two cuts as twelve edge messages straight to the
- * diagonal neighbours, the x faces written by the step kernels and read by the next step's in place (the default where every pair of trading domains has
- * peer access); 0: the reference's three phases x, y, z with rims, FX/lbm.cpp:1907-1935 (staged and RCCL transports; LUW_GROUP_EXCHANGE=sequential) */
+ * diagonal neighbours, the x faces written by the step kernels and read by the next step's in place (the default: as peer stores where every pair of
+ * trading domains has peer access, through send buffers and ONE batch of copies / ncclSend / ncclRecv with the staged and RCCL transports); 0: the
+ * reference's three phases x, y, z with rims, FX/lbm.cpp:1907-1935 (LUW_GROUP_EXCHANGE=sequential; a peer transport where SOME pair lacks peer access) */
 int luw_group_one_phase(const luw_group* g);
 /* How the faces of communicate_field (FX/lbm.cpp:1907-1935) travel between the domains of this process.  Chosen at luw_group_create from
  * the environment variable LUW_GROUP_TRANSPORT = peer (default) | staged | rccl:

@@ -31,6 +31,7 @@ struct GroupDomain {
 	// sent by the domain in direction -c, enbr[e] being the domain in direction +c that takes OUR edge e); nbrs: every domain this one trades with
 	void* recvx[2][2] = {};
 	void* erecv[12] = {};
+	void* esend[12] = {};                     // staging of the edge messages where they do not travel as peer stores (staged copies, RCCL)
 	uint32_t enbr[12] = {};
 	std::vector<uint32_t> nbrs;
 	hipEvent_t packed_all = nullptr, unpacked_all = nullptr;
@@ -105,6 +106,7 @@ static void group_free(luw_group* g) {
 		if(d.s) { (void)luw_set_stream(d.s, nullptr); luw_destroy(d.s); }
 		for(int k=0; k<2; k++) (void)hipFree(d.recvx[1][k]);         // (set 0 is recv[0])
 		for(void* e : d.erecv) (void)hipFree(e);
+		for(void* e : d.esend) (void)hipFree(e);
 		for(hipEvent_t e : { d.packed_all, d.unpacked_all }) if(e) (void)hipEventDestroy(e);
 		for(int a=0; a<3; a++) for(int k=0; k<2; k++) {
 			(void)hipFree(d.recv[a][k]);
@@ -159,6 +161,11 @@ static int domain_unpack(luw_group* g, const size_t i, const int a, const bool t
 	HIP_TRY(hipEventRecord((thermal_pass ? d.gunpacked : d.unpacked)[a], st));
 	return LUW_OK;
 }
+// a communicator works on ONE stream per batch: the stream of the first domain on its device (on a node every domain is its own leader)
+static size_t group_leader(const luw_group* g, const size_t i) { for(size_t k=0; k<i; k++) if(g->dom[k].device==g->dom[i].device) return k; return i; }
+// one message of the one-round exchange where faces do not travel as peer stores: from a send buffer of domain src into a receive buffer of domain dst
+struct GroupMsg { uint32_t src, dst; const void* from; void* into; size_t bytes; };
+static void domain_messages(luw_group* g, const size_t i, const uint32_t xs, std::vector<GroupMsg>& out);
 #include "luw_group_rccl.hpp"   // LUW_GROUP_TRANSPORT=rccl: grouped ncclSend / ncclRecv (librccl looked up at run time)
 
 // ---- the exchange in ONE phase (default where every pair of trading domains has peer access): what latticeurbanwind_amd/distributed.py does per rank over
@@ -168,23 +175,48 @@ static int domain_unpack(luw_group* g, const size_t i, const int a, const bool t
 // and ONE unpack round: the x faces are handed to the next step's kernels where they lie (luw_set_x_face_inputs: no unpack kernel), y / z faces inserted,
 // the edges last (they overwrite what the rims of the faces carried).  Same populations in the same slots as the three-phase route
 // (tests/test_gpu_group.py, tests/fuzz/fuzz_exchange_gpu.py hold both to each other and to the oracle).
+// Where the faces do not travel as peer stores (LUW_GROUP_TRANSPORT=staged / rccl) the same round packs into the domain's own send buffers -- the x faces
+// are there already, written by the step kernels -- and every message (two faces per split axis, the edges, the thermal faces) is then moved into the
+// receiver's buffer: hipMemcpyPeerAsync behind the pack kernels (staged), or ONE grouped batch of ncclSend / ncclRecv for the whole group (rccl,
+// group_exchange_rccl_all below).
+static void domain_messages(luw_group* g, const size_t i, const uint32_t xs, std::vector<GroupMsg>& out) {
+	GroupDomain& d = g->dom[i];
+	for(int a=0; a<3; a++) if(g->H[a]) for(int k=0; k<2; k++) {
+		GroupDomain& to = g->dom[d.nbr[a][k]];
+		const size_t A = (size_t)luw_get_area(d.s, (uint32_t)a);
+		// my + face (k = 0) is what the + neighbour receives "from its - side" ([1]); my - face lands in the - neighbour's [0]
+		out.push_back(GroupMsg{ (uint32_t)i, d.nbr[a][k], d.send[a][k], a==0 ? to.recvx[xs][1-k] : to.recv[a][1-k], 5u*A*g->ddf_bytes });
+		if(g->thermal) out.push_back(GroupMsg{ (uint32_t)i, d.nbr[a][k], d.gsend[a][k], to.grecv[a][1-k], A*g->ddf_bytes });
+	}
+	for(uint32_t e=0u; e<12u; e++) if(const uint64_t L = luw_get_edge_length(d.s, e))
+		out.push_back(GroupMsg{ (uint32_t)i, d.enbr[e], d.esend[e], g->dom[d.enbr[e]].erecv[e], (size_t)L*g->ddf_bytes });
+}
 static int domain_pack_all(luw_group* g, const size_t i, const bool on_compute, const uint32_t xs) {
 	GroupDomain& d = g->dom[i];
 	hipStream_t st = on_compute ? d.compute : d.comm;
+	const bool direct = g->transport==LUW_TRANSPORT_PEER;   // (one round with peer stores: every pair of trading domains has peer access, luw_group_create)
 	for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].unpacked_all, 0)); // they have consumed what the previous step put there
 	GROUP_TRY(luw_set_stream(d.s, st));
 	for(int a=0; a<3; a++) {
 		if(!g->H[a]) continue;
 		GroupDomain& P = g->dom[d.nbr[a][0]]; GroupDomain& M = g->dom[d.nbr[a][1]];
-		// (x: no launch where this step's kernels have written both faces -- into these very buffers, group_x_face_ready)
-		if(a==0) GROUP_TRY(luw_enqueue_extract_fi(d.s, 0u, P.recvx[xs][1], M.recvx[xs][0]));
+		// (x: no launch where this step's kernels have written both faces -- into these very buffers, group_x_face_ready / luw_group_create)
+		if(!direct) GROUP_TRY(luw_enqueue_extract_fi(d.s, (uint32_t)a, d.send[a][0], d.send[a][1]));
+		else if(a==0) GROUP_TRY(luw_enqueue_extract_fi(d.s, 0u, P.recvx[xs][1], M.recvx[xs][0]));
 		else GROUP_TRY(luw_enqueue_extract_fi(d.s, (uint32_t)a, P.recv[a][1], M.recv[a][0]));
 	}
 	void* out[12];
-	for(uint32_t e=0u; e<12u; e++) out[e] = luw_get_edge_length(d.s, e) ? g->dom[d.enbr[e]].erecv[e] : nullptr;
+	for(uint32_t e=0u; e<12u; e++) out[e] = !luw_get_edge_length(d.s, e) ? nullptr : direct ? g->dom[d.enbr[e]].erecv[e] : d.esend[e];
 	GROUP_TRY(luw_enqueue_extract_edges(d.s, out));
-	if(g->thermal) for(int a=0; a<3; a++) if(g->H[a])
-		GROUP_TRY(luw_enqueue_extract_gi(d.s, (uint32_t)a, g->dom[d.nbr[a][0]].grecv[a][1], g->dom[d.nbr[a][1]].grecv[a][0]));
+	if(g->thermal) for(int a=0; a<3; a++) if(g->H[a]) {
+		if(direct) GROUP_TRY(luw_enqueue_extract_gi(d.s, (uint32_t)a, g->dom[d.nbr[a][0]].grecv[a][1], g->dom[d.nbr[a][1]].grecv[a][0]));
+		else GROUP_TRY(luw_enqueue_extract_gi(d.s, (uint32_t)a, d.gsend[a][0], d.gsend[a][1]));
+	}
+	if(g->transport==LUW_TRANSPORT_STAGED) {
+		std::vector<GroupMsg> msgs;
+		domain_messages(g, i, xs, msgs);
+		for(const GroupMsg& m : msgs) HIP_TRY(hipMemcpyPeerAsync(m.into, g->dom[m.dst].device, m.from, d.device, m.bytes, st));
+	}
 	HIP_TRY(hipEventRecord(d.packed_all, st));
 	return LUW_OK;
 }
@@ -192,7 +224,11 @@ static int domain_pack_all(luw_group* g, const size_t i, const bool on_compute, 
 static int domain_unpack_all(luw_group* g, const size_t i, const bool on_compute, const bool x_in_place, const uint32_t xs) {
 	GroupDomain& d = g->dom[i];
 	hipStream_t st = on_compute ? d.compute : d.comm;
-	if(!(g_injected_faults.load()&LUW_FAULT_UNPACK_WITHOUT_WAIT)) for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].packed_all, 0));
+	if(!(g_injected_faults.load()&LUW_FAULT_UNPACK_WITHOUT_WAIT)) {
+		for(const uint32_t nb : d.nbrs) HIP_TRY(hipStreamWaitEvent(st, g->dom[nb].packed_all, 0));
+		// rccl: what this domain receives arrives on its device's leader stream (group_exchange_rccl_all records packed[0] behind the batch there)
+		if(g->transport==LUW_TRANSPORT_RCCL) HIP_TRY(hipStreamWaitEvent(st, g->dom[group_leader(g, i)].packed[0], 0));
+	}
 	GROUP_TRY(luw_set_stream(d.s, st));
 	if(g->H[0]) {
 		if(x_in_place) GROUP_TRY(luw_set_x_face_inputs(d.s, d.recvx[xs][0], d.recvx[xs][1]));
@@ -206,6 +242,7 @@ static int domain_unpack_all(luw_group* g, const size_t i, const bool on_compute
 }
 static int group_exchange_one_phase(luw_group* g, const bool on_compute, const bool x_in_place) {
 	for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_pack_all(g, i, on_compute, g->xset)); }
+	if(g->transport==LUW_TRANSPORT_RCCL) GROUP_TRY(group_exchange_rccl_all(g, on_compute, g->xset));
 	for(size_t i=0; i<g->dom.size(); i++) { GROUP_TRY(group_set_device(g->dom[i])); GROUP_TRY(domain_unpack_all(g, i, on_compute, x_in_place, g->xset)); }
 	g->xset ^= 1u;
 	return LUW_OK;

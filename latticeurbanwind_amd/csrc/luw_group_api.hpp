@@ -98,10 +98,12 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 		std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
 		d.nbrs = all;
 	}
-	// ONE pack / unpack round per step where the faces travel as peer stores between every pair of trading domains (LUW_GROUP_EXCHANGE=sequential: the
-	// reference's three phases, which the staged and RCCL transports always take)
-	g->one_phase = n>1u && g->transport==LUW_TRANSPORT_PEER && !tuning().group_sequential;
-	for(uint32_t i=0u; i<n&&g->one_phase; i++) for(const uint32_t j : g->dom[i].nbrs) if(!g->peer[i][j]) { g->one_phase = false; break; }
+	// ONE pack / unpack round per step: as peer stores where every pair of trading domains has peer access, through the send buffers and ONE batch of copies /
+	// ncclSend / ncclRecv with the staged and RCCL transports (LUW_GROUP_EXCHANGE=sequential: the reference's three phases; also what a peer transport takes
+	// on a node where SOME pair of trading devices has no peer access)
+	g->one_phase = n>1u && !tuning().group_sequential;
+	if(g->transport==LUW_TRANSPORT_PEER) for(uint32_t i=0u; i<n&&g->one_phase; i++) for(const uint32_t j : g->dom[i].nbrs)
+		if(!g->peer[i][j]) { g->one_phase = false; break; }
 	// Streams and halo buffers BEFORE the lattices: every long-lived small allocation is in place before the large arrays and the
 	// placement search of luw_create run
 	for(uint32_t i=0u; i<n; i++) {
@@ -121,6 +123,10 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 			const size_t L = (size_t)d.lN[EC[e][0]==0 ? 0 : EC[e][1]==0 ? 1 : 2];
 			if(hipMalloc(&d.erecv[e], L*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
 			HIP_TRY(hipMemset(d.erecv[e], 0, L*g->ddf_bytes));
+			if(g->transport!=LUW_TRANSPORT_PEER) {
+				if(hipMalloc(&d.esend[e], L*g->ddf_bytes)!=hipSuccess) return fail(LUW_ERR_NOMEM, "luw_group_create: halo buffers");
+				HIP_TRY(hipMemset(d.esend[e], 0, L*g->ddf_bytes));
+			}
 		}
 		for(int a=0; a<3; a++) {
 			for(hipEvent_t* e : { &d.packed[a], &d.unpacked[a], &d.gpacked[a], &d.gunpacked[a] }) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));

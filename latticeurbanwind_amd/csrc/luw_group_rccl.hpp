@@ -69,7 +69,7 @@ static int group_exchange_rccl_axis(luw_group* g, const int a, const bool therma
 	RcclApi* R = rccl_api();
 	const size_t n = g->dom.size();
 	auto stream_of = [&](GroupDomain& d) { return on_compute ? d.compute : d.comm; };
-	auto leader = [&](const size_t i) { size_t l = i; for(size_t k=0; k<i; k++) if(g->dom[k].device==g->dom[i].device) { l = k; break; } return l; };
+	auto leader = [&](const size_t i) { return group_leader(g, i); };
 	for(size_t i=0; i<n; i++) {
 		GroupDomain& d = g->dom[i];
 		GROUP_TRY(group_set_device(d));
@@ -120,3 +120,38 @@ static int group_exchange_rccl_axis(luw_group* g, const int a, const bool therma
 	}
 	return LUW_OK;
 }
+// The one-round exchange (luw_group.hpp, group_exchange_one_phase) over RCCL: every domain has packed its faces, edges and thermal faces into its send
+// buffers (domain_pack_all; the x faces were written there by the step kernels); ONE ncclGroupStart / End per step carries all of it -- what
+// latticeurbanwind_amd/distributed.py does per rank with one batch_isend_irecv.  Same populations into the same slots as the three phases
+// (FX/lbm.cpp:1907-1935), the twelve edge messages in place of the rims.  Leaders as in group_exchange_rccl_axis: the batch of a device runs on the stream
+// of the first domain on it; behind the batch that stream records the leader's packed[0] ("this device's batch is done": the per-axis events are free in
+// this mode), which domain_unpack_all of every domain on the device waits for.
+static int group_exchange_rccl_all(luw_group* g, const bool on_compute, const uint32_t xs) {
+	RcclApi* R = rccl_api();
+	const size_t n = g->dom.size();
+	auto stream_of = [&](GroupDomain& d) { return on_compute ? d.compute : d.comm; };
+	for(size_t i=0; i<n; i++) {
+		const size_t l = group_leader(g, i);
+		GroupDomain& L = g->dom[l];
+		GROUP_TRY(group_set_device(L));
+		// the leader's batch reads this domain's send buffers (packed_all) and writes its receive buffers (consumed by its last unpack round)
+		if(l!=i) { HIP_TRY(hipStreamWaitEvent(stream_of(L), g->dom[i].packed_all, 0)); HIP_TRY(hipStreamWaitEvent(stream_of(L), g->dom[i].unpacked_all, 0)); }
+	}
+	// ONE global order of messages, walked once for the sends and once for the receives: RCCL pairs the k-th send of rank s to rank r with the k-th receive
+	// of r from s, and any two messages between the same pair of ranks keep their relative order in both walks
+	std::vector<GroupMsg> msgs;
+	for(size_t i=0; i<n; i++) domain_messages(g, i, xs, msgs);
+	RCCL_TRY(R->GroupStart());
+	for(const GroupMsg& m : msgs)
+		RCCL_TRY(R->Send(m.from, m.bytes, RCCL_UINT8, g->rccl_rank[m.dst], g->rccl_comm[g->rccl_rank[m.src]], stream_of(g->dom[group_leader(g, m.src)])));
+	for(const GroupMsg& m : msgs)
+		RCCL_TRY(R->Recv(m.into, m.bytes, RCCL_UINT8, g->rccl_rank[m.src], g->rccl_comm[g->rccl_rank[m.dst]], stream_of(g->dom[group_leader(g, m.dst)])));
+	RCCL_TRY(R->GroupEnd());
+	for(size_t i=0; i<n; i++) if(group_leader(g, i)==i) {
+		GroupDomain& L = g->dom[i];
+		GROUP_TRY(group_set_device(L));
+		HIP_TRY(hipEventRecord(L.packed[0], stream_of(L)));
+	}
+	return LUW_OK;
+}
+

@@ -29,7 +29,11 @@ def main():
         steps = (int(rng.integers(1, 7)), int(rng.integers(0, 6)))
         os.environ["LUW_X_SHELL"] = str(int(rng.choice([16, 64, 128])))
         os.environ["LUW_GROUP_THREADS"] = "1" if threads else "0"
-        rng.integers(2)                                                                # (a draw the cases of round 5 spent on a removed option: keeps their numbering)
+        # (the draw round 5's cases spent on a removed option now picks the transport of half of them: the one-round exchange through send buffers + copies /
+        # ONE grouped ncclSend / ncclRecv batch, round 6; RCCL's group calls are issued by one thread)
+        transport = "peer" if rng.integers(2) == 0 else ("staged" if case % 2 == 0 else "rccl")
+        if transport == "rccl": threads = False; os.environ["LUW_GROUP_THREADS"] = "0"
+        os.environ["LUW_GROUP_TRANSPORT"] = transport
         seed = int(rng.integers(1 << 30))
         jitter = int(rng.choice([0, 0, 100, 400]))                                        # schedule fuzzing: random delays in front of the kernels (us at most)
         st = synthetic_state(*gN, seed=seed, shell="luw" if forces else None)
@@ -77,8 +81,8 @@ def main():
             same = same and ok
             vs_oracle = ", oracle %s" % ("equal" if ok else "DIFFERENT")
         bad += not same
-        print("case %d: %s global %s n_gpu %s thermal %s forces %s threads %s x_shell %s jitter %s steps %s: %s%s" % (case,
-            "fp16c" if fp16c else "f32", gN, D, thermal, forces, threads, os.environ["LUW_X_SHELL"], jitter, steps,
+        print("case %d: %s global %s n_gpu %s thermal %s forces %s threads %s transport %s x_shell %s jitter %s steps %s: %s%s" % (case,
+            "fp16c" if fp16c else "f32", gN, D, thermal, forces, threads, transport, os.environ["LUW_X_SHELL"], jitter, steps,
             "routes equal" if same else "DIFFERENT", vs_oracle), flush=True)
     print("fuzz: %d cases, %d different" % (cases, bad))
     sys.exit(1 if bad else 0)

@@ -154,44 +154,55 @@ def test_group_voxelise_gather_and_inlet_match_the_single_domain(luw):
         assert np.array_equal(a, b)
 
 
-def test_group_staged_copy_path(tmp_path):
+@pytest.mark.parametrize("exchange_env", ["", "sequential"])
+def test_group_staged_copy_path(tmp_path, exchange_env):
     """the path for devices without peer access (pack into a send buffer, hipMemcpyPeerAsync into the neighbour's receive
-    buffer), forced with LUW_GROUP_TRANSPORT=staged in a child process: same bits as the oracle"""
+    buffer), forced with LUW_GROUP_TRANSPORT=staged in a child process -- in ONE round per step (faces of all axes, edge messages, x faces written by the
+    step kernels and read in place; round 6) and in the reference's three phases: same bits as the oracle, thermal lattice and an x-split FP16C case included"""
     code = """
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import latticeurbanwind_amd as luw
-from helpers import synthetic_state
+from helpers import synthetic_state, thermal_state
 from oracle import oracle
 luw.load()
-gN, D = (32, 24, 12), (2, 2, 1)
-st = synthetic_state(*gN, seed=49, shell=None)
-g = luw.LBMGroup(*gN, *D, 0.01, devices=[0] * 4)
-assert not g.direct_peer_stores()
-g.flags[:] = st[0]; g.u[:] = st[1]; g.rho[:] = st[2]
-g.run(6); g.read_from_device()
-o = oracle.OracleLBM(*gN, 0.01); o.flags[:] = st[0]; o.u[:] = st[1]; o.rho[:] = st[2]; o.run(6)
-assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho)
+for gN, D, fp16c, alpha in (((32, 24, 12), (2, 2, 1), False, None), ((640, 24, 16), (2, 1, 2), True, None), ((24, 20, 16), (2, 2, 2), False, 0.004)):
+    st = synthetic_state(*gN, seed=49, shell=None)
+    fl, T = thermal_state(st[0], gN) if alpha else (st[0], None)
+    g = luw.LBMGroup(*gN, *D, 0.01, fp16c=fp16c, devices=[0] * (D[0] * D[1] * D[2]), **({"alpha": alpha} if alpha else {}))
+    assert not g.direct_peer_stores() and g.one_phase() == (%r != "sequential")
+    g.flags[:] = fl; g.u[:] = st[1]; g.rho[:] = st[2]
+    if alpha: g.T[:] = T
+    g.run(0); g.run(4); g.run(3); g.read_from_device(("u", "rho", "T") if alpha else ("u", "rho"))
+    o = oracle.OracleLBM(*gN, 0.01, fp16c=fp16c, alpha=alpha); o.flags[:] = fl; o.u[:] = st[1]; o.rho[:] = st[2]
+    if alpha: o.T[:] = T
+    o.run(7)
+    assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho) and (not alpha or np.array_equal(g.T, o.T)), (gN, D)
+    g.close()
 print("staged ok")
-""" % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LUW_GROUP_TRANSPORT="staged"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+""" % (ROOT, os.path.join(ROOT, "tests"), exchange_env)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LUW_GROUP_TRANSPORT="staged", LUW_GROUP_EXCHANGE=exchange_env), capture_output=True,
+        text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
-def test_group_rccl_transport_self(luw):
+@pytest.mark.parametrize("exchange_env", ["", "sequential"])
+def test_group_rccl_transport_self(luw, exchange_env):
     """LUW_GROUP_TRANSPORT=rccl (grouped ncclSend / ncclRecv, librccl loaded on demand): with all domains on the box's one GPU the
-    communicator has one rank and every face is a self send / receive -- message pairing, buffer roles and stream ordering of the
-    transport are the ones a node uses; same bits as the oracle, thermal lattice (second message pass) included"""
+    communicator has one rank and every message is a self send / receive -- message pairing, buffer roles and stream ordering of the
+    transport are the ones a node uses.  ONE batch per step (faces of all axes, twelve edge messages, thermal faces; round 6) and the reference's three
+    phases: same bits as the oracle, thermal lattice included"""
     from latticeurbanwind_amd import capi
     from oracle import oracle
-    saved = os.environ.get("LUW_GROUP_TRANSPORT")
-    os.environ["LUW_GROUP_TRANSPORT"] = "rccl"; capi.reload_tuning()    # the library reads its environment once: read it again
+    saved = {k: os.environ.get(k) for k in ("LUW_GROUP_TRANSPORT", "LUW_GROUP_EXCHANGE")}
+    os.environ["LUW_GROUP_TRANSPORT"] = "rccl"; os.environ["LUW_GROUP_EXCHANGE"] = exchange_env
+    capi.reload_tuning()    # the library reads its environment once: read it again
     try:
         for gN, D, fp16c, alpha in (((32, 24, 12), (2, 2, 1), False, None), ((640, 24, 16), (2, 1, 2), True, None), ((24, 20, 16), (2, 2, 2), False, 0.004)):
             st = synthetic_state(*gN, seed=53, shell=None)
             tflags, T = thermal_state(st[0], gN) if alpha else (st[0], None)
             g = run_group(luw, gN, D, fp16c, (tflags, st[1], st[2]), 0, **({"alpha": alpha} if alpha else {}))
-            assert g.transport() == 2 and not g.direct_peer_stores() and not g.one_phase(), capi.TRANSPORT_NAMES[g.transport()]
+            assert g.transport() == 2 and not g.direct_peer_stores() and g.one_phase() == (exchange_env != "sequential"), capi.TRANSPORT_NAMES[g.transport()]
             if alpha: g.T[:] = T
             g.run(0); g.run(4); g.run(3)
             g.read_from_device(("u", "rho", "T") if alpha else ("u", "rho"))
@@ -202,8 +213,9 @@ def test_group_rccl_transport_self(luw):
             assert np.array_equal(g.u, o.u) and np.array_equal(g.rho, o.rho) and (not alpha or np.array_equal(g.T, o.T))
             g.close()
     finally:
-        if saved is None: os.environ.pop("LUW_GROUP_TRANSPORT", None)
-        else: os.environ["LUW_GROUP_TRANSPORT"] = saved
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
         capi.reload_tuning()
 
 

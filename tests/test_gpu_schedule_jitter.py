@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 SEEDS = (1, 2, 3, 4)
 MAX_US = 300
 MODES = {"one_phase": {}, "sequential": {"LUW_GROUP_EXCHANGE": "sequential"},
-    "one_phase_threads": {"LUW_GROUP_THREADS": "1"}, "sequential_threads": {"LUW_GROUP_EXCHANGE": "sequential", "LUW_GROUP_THREADS": "1"}}
-KNOBS = ("LUW_GROUP_EXCHANGE", "LUW_GROUP_THREADS")
+    "one_phase_threads": {"LUW_GROUP_THREADS": "1"}, "sequential_threads": {"LUW_GROUP_EXCHANGE": "sequential", "LUW_GROUP_THREADS": "1"},
+    # the one-round exchange through send buffers: copies behind the pack kernels / ONE grouped ncclSend / ncclRecv batch per step (round 6)
+    "one_phase_staged": {"LUW_GROUP_TRANSPORT": "staged"}, "one_phase_rccl": {"LUW_GROUP_TRANSPORT": "rccl"}}
+KNOBS = ("LUW_GROUP_EXCHANGE", "LUW_GROUP_THREADS", "LUW_GROUP_TRANSPORT")
 
 
 @pytest.fixture(params=list(MODES))
