@@ -79,7 +79,7 @@ static bool group_x_direct(const luw_group* g, const size_t i) { return g->H[0]&
 // ... and then the step kernels of domain i write there (luw_set_x_face_buffers): the launch that holds them waits, like the pack kernel would, until both
 // neighbours have consumed what the previous step put into those buffers
 static int group_x_face_ready(luw_group* g, const size_t i, const uint32_t xs) { // xs: the set of x receive buffers this step fills (one-phase exchange)
-	if(!group_x_direct(g, i)) return LUW_OK;
+	if(!group_x_direct(g, i)||tuning().group_x_packed) return LUW_OK;
 	GroupDomain& d = g->dom[i];
 	hipStream_t st = g->overlap ? d.comm : d.compute;
 	if(g->one_phase) {

@@ -58,7 +58,7 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 			c[a] = (d.coord[a]+D[a]-1u)%D[a]; d.nbr[a][1] = c[0]+(c[1]+c[2]*D[1])*D[0];
 		}
 	}
-	g->overlap = n>1u&&step_can_overlap(g->dom[0].lN, g->H);
+	g->overlap = n>1u&&step_can_overlap(g->dom[0].lN, g->H)&&tuning().group_overlap;
 	// peer access between the devices of neighbouring domains (xGMI): enables the direct remote stores of the pack kernels
 	g->peer.assign(n, std::vector<char>(n, 0));
 	for(uint32_t i=0u; i<n; i++) for(uint32_t j=0u; j<n; j++) {
@@ -167,7 +167,9 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 		g_device_is_shared = false;
 		GROUP_TRY(rc);
 		group_boxes(g.get(), d);
-		if(g->H[0]) { // the step kernels write the x faces themselves (luw_set_x_face_buffers): into the neighbours' receive buffers, or into the send buffers
+		// (LUW_GROUP_EXCHANGE=one_packed: not at all -- the pack kernel fetches the x faces and the insert kernel puts them: what first contact times the
+		// kernels' scattered 2-4-byte remote stores against, tools/first_contact_defaults.py)
+		if(g->H[0]&&!tuning().group_x_packed) { // the step kernels write the x faces themselves (luw_set_x_face_buffers): into the neighbours' receive buffers, or into the send buffers
 			void* fp = group_x_direct(g.get(), i) ? g->dom[d.nbr[0][0]].recv[0][1] : d.send[0][0];
 			void* fm = group_x_direct(g.get(), i) ? g->dom[d.nbr[0][1]].recv[0][0] : d.send[0][1];
 			GROUP_TRY(luw_set_x_face_buffers(d.s, fp, fm));

@@ -28,6 +28,8 @@ struct Tuning {
 	uint32_t x_shell = 0u;            // LUW_X_SHELL=<cells>: thickness of the x boundary slabs of a decomposed step (0: 128; A/B aid)
 	int group_transport = LUW_TRANSPORT_PEER; bool group_transport_bad = false; // LUW_GROUP_TRANSPORT = peer | staged | rccl (luw_group_create)
 	bool group_sequential = false;    // LUW_GROUP_EXCHANGE=sequential: luw_group_* exchanges in the reference's three phases also where one round would do
+	bool group_x_packed = false;      // LUW_GROUP_EXCHANGE=one_packed: one round, but the x faces through the pack / unpack kernels instead of the step kernels
+	bool group_overlap = true;        // LUW_GROUP_OVERLAP=0: whole box as ONE launch, then the exchange (no boundary shell, no second stream in the step)
 	uint64_t jitter_seed = 0ull; uint32_t jitter_us = 0u; // LUW_SCHEDULE_JITTER=<seed>:<max us>: schedule fuzzing from the first kernel on (schedule_jitter below)
 	int xcd_rows = -1;                // LUW_XCD_ROWS=0 / 1: workgroup order of the step kernels (KParams::xcd_rows) for every lattice; unset: luw_create's rule
 	bool group_threads = false;       // LUW_GROUP_THREADS=1: one host thread per domain in luw_group_run
@@ -76,7 +78,8 @@ static void tuning_load() {
 		else if(strcmp(e, "peer")!=0&&e[0]) t.group_transport_bad = true;
 	}
 	{ const char* e = getenv("LUW_GROUP_THREADS"); t.group_threads = e&&e[0]=='1'; }
-	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; }
+	{ const char* e = getenv("LUW_GROUP_EXCHANGE"); t.group_sequential = e&&strcmp(e, "sequential")==0; t.group_x_packed = e&&strcmp(e, "one_packed")==0; }
+	{ const char* e = getenv("LUW_GROUP_OVERLAP"); t.group_overlap = !(e&&e[0]=='0'); }
 	if(const char* e = getenv("LUW_XCD_ROWS")) t.xcd_rows = (e[0]>='0'&&e[0]<='9') ? std::min(atoi(e), 64) : -1;
 	if(const char* e = getenv("LUW_SCHEDULE_JITTER")) {
 		char* end = nullptr;

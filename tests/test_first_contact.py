@@ -8,24 +8,48 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = os.path.join(ROOT, "tools", "first_contact.sh")
+STAGES = ["1", "2", "2b", "3", "4", "5", "6"]
 
 
 def test_dry_run_walks_all_stages_in_order(tmp_path):
     r = subprocess.run([SCRIPT, "--dry-run", "--out", str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     marks = [l for l in r.stdout.splitlines() if l.startswith("== stage")]
-    assert [m.split(":")[0] for m in marks] == ["== stage %d" % n for n in range(1, 7)] and "first contact complete" in r.stdout
-    assert "distinct_devices" in r.stdout and "bench_n 2" in r.stdout
-    assert sorted(os.listdir(tmp_path)) == ["stage%d.log" % n for n in range(1, 7)] and r.stdout.count("LUW_SCHEDULE_JITTER") == 2
+    assert [m.split(":")[0] for m in marks] == ["== stage %s" % n for n in STAGES] and "first contact complete" in r.stdout
+    assert "distinct_devices" in r.stdout and "bench_n 2" in r.stdout and "stage2b" in r.stdout
+    assert sorted(os.listdir(tmp_path)) == sorted("stage%s.log" % n for n in STAGES) and r.stdout.count("LUW_SCHEDULE_JITTER") == 2
 
 
-@pytest.mark.parametrize("fail", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("fail", STAGES)
 def test_first_failure_ends_the_script_with_the_stage_number(tmp_path, fail):
     r = subprocess.run([SCRIPT, "--dry-run", "--out", str(tmp_path)], capture_output=True, text=True, timeout=60,
-        env=dict(os.environ, FIRST_CONTACT_FAIL=str(fail)))
-    assert r.returncode == fail
-    started = [int(l.split()[2].rstrip(":")) for l in r.stdout.splitlines() if l.startswith("== stage") and "FAILED" not in l]
-    assert started == list(range(1, fail + 1)) and "first contact complete" not in r.stdout
+        env=dict(os.environ, FIRST_CONTACT_FAIL=fail))
+    assert r.returncode == (20 if fail == "2b" else int(fail))           # (stage 2b: exit code 20)
+    started = [l.split()[2].rstrip(":") for l in r.stdout.splitlines() if l.startswith("== stage") and "FAILED" not in l]
+    assert started == STAGES[:STAGES.index(fail) + 1] and "first contact complete" not in r.stdout
+
+
+def test_the_defaults_matrix_as_a_dry_run():
+    """stage 2b's tool without a GPU: one all-defaults run and one run per alternative and round, for both workloads; RCCL never with host threads"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_contact_defaults.py"), "--dry-run", "--devices", "0,1,2,3,4,5,6,7"], capture_output=True,
+        text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    cmds = [l for l in r.stdout.splitlines() if l.startswith("[dry run] ") and "--child" in l]
+    assert len(cmds) == 2 * 2 * 7 and sum("(defaults)" in c for c in cmds) == 4 and all("--size 512 512 512" in c and "--steps 40" in c for c in cmds)
+    for knob in ("LUW_GROUP_EXCHANGE=one_packed", "LUW_GROUP_EXCHANGE=sequential", "LUW_GROUP_TRANSPORT=staged", "LUW_GROUP_TRANSPORT=rccl",
+            "LUW_GROUP_OVERLAP=0", "LUW_GROUP_THREADS=1"):
+        assert sum(knob in c for c in cmds) == 4, knob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import first_contact_defaults as F
+    # the rule: an alternative replaces the default only when it is more than 2 % faster in EVERY round
+    res = {(q, lab): [10.0, 10.0] for q, alts in F.QUESTIONS.items() for lab in alts}
+    res[("x_faces", "packed (pack / insert kernels)")] = [9.7, 9.9]                      # 3 % and 1 %: the default stays
+    res[("transport", "rccl batch")] = [9.5, 9.6]; res[("transport", "staged copies")] = [9.7, 9.7]
+    d = F.decide(res, rehearsal=False)
+    assert d["x_faces"]["recommended"].startswith("fused") and d["transport"]["recommended"] == "rccl batch"
+    assert d["transport"]["environment"] == {"LUW_GROUP_TRANSPORT": "rccl"} and d["schedule"]["environment"] == {}
+    assert all(v["recommended"] == v["default"] and v["environment"] == {} for v in F.decide(res, rehearsal=True).values())
 
 
 def test_no_stage_replaces_a_gpu_process_by_another_program():
@@ -40,3 +64,10 @@ def test_rehearsal_on_one_gpu(tmp_path):
     r = subprocess.run([SCRIPT, "--share-device", "0", "--out", str(tmp_path)], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "2 ranks:" in r.stdout and "4 ranks:" in r.stdout and "parity ok" in r.stdout and "first contact complete" in r.stdout
+    import json
+    d = json.load(open(tmp_path / "defaults.json"))      # stage 2b: every alternative ran on the one GPU and agreed bit for bit; no recommendation from it
+    assert d["rehearsal"] is True and len(d["workloads"]) == 2
+    for w in d["workloads"].values():
+        assert w["all_variants_bit_equal"] is True and len(w["runs"]) == 11 and not any("error" in r_ for r_ in w["runs"])
+        assert all(v["recommended"] == v["default"] for v in w["decision"].values())
+    assert "all values arrived" in open(tmp_path / "stage2b.log").read()

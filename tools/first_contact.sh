@@ -5,6 +5,10 @@
 #   1  the node as the HIP runtime sees it: devices, PCI bus ids, the peer-access / link-type / hop matrix (luw_device_info, luw_p2p_info)
 #   2  the one-process host across devices: tests/test_gpu_group.py -k distinct_devices (peer stores into another GPU's buffers, cross-device stream waits,
 #      hipMemcpyPeerAsync, multi-rank RCCL communicators; one host thread and one per domain)
+#   2b the cross-device DEFAULTS by data (tools/xgmi_store_probe.hip + tools/first_contact_defaults.py): what device A's kernels get when they store into
+#      device B's memory in the three shapes of the exchange (256-byte rows, one 4-byte / 2-byte element per workgroup); then the one-process host on
+#      the literal cut with x faces fused / packed, one round / three phases, peer / staged / rccl, shell-first / whole box, one / many host threads --
+#      fresh process each, interleaved, all bit-equal or the stage fails -> $OUT/defaults.json with the winners and the rule applied
 #   3  two ranks over RCCL: bench.py --gpus 2 --steps 20 -- its self-check against the CPU oracle through the real transport must pass before anything is timed
 #   4  all GPUs: bench.py --gpus N (N = device count, at most 8) -- the line carries rccl.world_size, every rank's PCI bus id and the link type to each
 #      halo neighbour, and the one-process host's block
@@ -23,15 +27,16 @@ mkdir -p "$OUT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 stage() { # stage <number> <what> <command...>: runs it as a child process, logs to $OUT/stage<number>.log, ends the script on failure
   local n="$1" what="$2"; shift 2
+  local code="$n"; [ "$n" = 2b ] && code=20
   echo "== stage $n: $what"
   if [ "$DRY" = 1 ]; then
     echo "   [dry run] $*" | tee "$OUT/stage$n.log"
-    if [ "${FIRST_CONTACT_FAIL:-0}" = "$n" ]; then echo "== stage $n FAILED (injected)"; exit "$n"; fi
+    if [ "${FIRST_CONTACT_FAIL:-0}" = "$n" ]; then echo "== stage $n FAILED (injected)"; exit "$code"; fi
     return 0
   fi
   "$@" > "$OUT/stage$n.log" 2>&1; local rc=$?
   tail -n 12 "$OUT/stage$n.log" | sed 's/^/   /'
-  if [ $rc -ne 0 ]; then echo "== stage $n FAILED (exit $rc): $OUT/stage$n.log"; exit "$n"; fi
+  if [ $rc -ne 0 ]; then echo "== stage $n FAILED (exit $rc): $OUT/stage$n.log"; exit "$code"; fi
 }
 NDEV=2
 if [ "$DRY" != 1 ]; then NDEV=$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0); fi
@@ -54,6 +59,19 @@ print('(link type / hops; ! = no peer access)')
 assert n >= 1
 "
 stage 2 "one-process host across devices" python3 -m pytest tests/test_gpu_group.py -k distinct_devices -x -q
+stage2b() ( # (a subshell) the store probe between device 0 and device 1 (a rehearsal on itself with one device), then the defaults matrix over all devices
+  set -e
+  [ -x tools/xgmi_store_probe ] || hipcc --offload-arch=gfx950 -O2 -o tools/xgmi_store_probe tools/xgmi_store_probe.hip
+  if [ -n "$SHARE" ] || [ "$NDEV" -lt 2 ]; then
+    tools/xgmi_store_probe "${SHARE:-0}" "${SHARE:-0}" 65536 5
+    python3 tools/first_contact_defaults.py --devices "$(printf "${SHARE:-0},%.0s" 1 2 3 4 5 6 7 8 | sed 's/,$//')" --reps 1 --size 128 32 32 --steps 4 --out "$OUT"
+  else
+    tools/xgmi_store_probe 0 1; tools/xgmi_store_probe 1 0
+    if [ "$NDEV" -ge 8 ]; then python3 tools/first_contact_defaults.py --devices 0,1,2,3,4,5,6,7 --n-gpu 4 2 1 --out "$OUT"
+    else python3 tools/first_contact_defaults.py --devices 0,1 --n-gpu 2 1 1 --out "$OUT"; fi
+  fi
+)
+stage 2b "cross-device defaults by data (store shapes; fused / packed, one round / three phases, peer / staged / rccl, shell-first / whole box)" stage2b
 if [ -n "$SHARE" ]; then EXTRA=(--share-device "$SHARE" --size 384 64 64); N4=4; else EXTRA=(); N4=$(( NDEV < 8 ? NDEV : 8 )); fi
 check_line() { # the printed line of a bench.py --gpus N run: parity passed, the communicator has N ranks, every rank names its bus id and links
   python3 -c "
