@@ -104,7 +104,7 @@ def test_a_failing_secondary_block_still_yields_the_line(luw, how, code, tmp_pat
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--share-device", "0", "--size", "384", "64", "64", "--no-parity",
            "--no-group-host"]
     path = str(tmp_path / "full.json")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, LUW_BENCH_INJECT=how, LUW_BENCH_BLOCK_TIMEOUT="20",
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, LUW_BENCH_INJECT=how, LUW_BENCH_BLOCK_TIMEOUT="8",
         LUW_BENCH_FULL_JSON=path))
     assert r.returncode != 0
     line, out = full_record(r.stdout, path)

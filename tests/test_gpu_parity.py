@@ -580,9 +580,9 @@ def test_1024_cubed_on_one_gpu_properties():
     assert r.returncode == 0 and "exact fixed point = True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     # (its 2^32-byte planes are the largest the flat addressing form takes: byte offsets up to 2^32 - 4.)  The row form at the same size
     # must leave the same 4.3 G values, bit for bit (digest over rho and u):
-    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_huge.py"), "f32", "wave"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
         env=dict(os.environ, LUW_TEST_AIDS="addr_row"))
-    assert r2.returncode == 0 and "exact fixed point = True" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-1500:]
+    assert r2.returncode == 0 and "shear wave, 12 steps" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-1500:]
     d1, d2 = re.search(r"digest (xor=\w+ sum=\w+)", r.stdout), re.search(r"digest (xor=\w+ sum=\w+)", r2.stdout)
     assert d1 and d2 and d1.group(1) == d2.group(1), (d1 and d1.group(1), d2 and d2.group(1))
 
