@@ -30,7 +30,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from benchmarks.common import (REFERENCE_GPU_CONTEXT, BYTES_PER_LUP, BUILDING_TOP, CELL_M, DT_S, HBM_PEAK_GBPS, NU, ROOT, WORKLOADS, attach_traffic, channel_state, coriolis_omega,
+from benchmarks.common import (REFERENCE_GPU_CONTEXT, BYTES_PER_LUP, BUILDING_TOP, CELL_M, DT_S, HBM_PEAK_GBPS, NU, ROOT, WORKLOADS, attach_traffic,
+    channel_state, coriolis_omega,
     cpu_baseline,
     cpu_model, device_context, fill_channel, loglaw_profile, profile_key, reference_case_rmse, reference_parity, tile_forcing, usable_cores)   # noqa: F401
 from benchmarks.launch import needs_launcher, self_launch

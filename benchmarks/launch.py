@@ -49,9 +49,9 @@ def launcher_env(environ, gpus=1):
     return env
 
 
-def self_launch(script, argv, gpus, environ=None, run=subprocess.run):
+def self_launch(script, argv, gpus, environ=None, run=subprocess.run, loaded=gpu_runtime_loaded):
     """start the ranks, wait, return the exit code for this process (non-zero when any rank failed)"""
-    if gpu_runtime_loaded():
+    if loaded():
         raise RuntimeError("bench.py: the launcher branch was reached after torch / the HIP library were imported")
     environ = os.environ if environ is None else environ
     cmd = launcher_argv(script, argv, gpus, int(environ.get("LUW_BENCH_MASTER_PORT", 0)) or free_port())

@@ -305,10 +305,12 @@ int luw_dev_tuning_text(char* text, uint64_t size) {
 	snprintf(text, (size_t)size,
 		"LUW_ALLOC=%s LUW_TEST_AIDS=%s%s%s%s LUW_TUNE_PLACEMENT=%d LUW_TUNE_FAST=%g LUW_X_SHELL=%u LUW_GROUP_TRANSPORT=%s LUW_GROUP_THREADS=%d "
 		"LUW_GROUP_EXCHANGE=%s LUW_GROUP_OVERLAP=%d LUW_XCD_ROWS=%d LUW_SCHEDULE_JITTER=%llu:%u",
-		alloc.c_str(), t.addr_row ? "addr_row," : "", t.fuse_stats ? "" : "separate_stats,", t.vk_ahead ? "" : "vk_inline,", t.voxelize_all ? "voxelize_all," : "",
+		alloc.c_str(), t.addr_row ? "addr_row," : "", t.fuse_stats ? "" : "separate_stats,", t.vk_ahead ? "" : "vk_inline,",
+		t.voxelize_all ? "voxelize_all," : "",
 		t.placement_candidates, t.placement_bar, t.x_shell,
 		t.group_transport==LUW_TRANSPORT_RCCL ? "rccl" : t.group_transport==LUW_TRANSPORT_STAGED ? "staged" : "peer", (int)t.group_threads,
-		t.group_sequential ? "sequential" : t.group_x_packed ? "one_packed" : "one-round", (int)t.group_overlap, t.xcd_rows, (unsigned long long)t.jitter_seed, t.jitter_us);
+		t.group_sequential ? "sequential" : t.group_x_packed ? "one_packed" : "one-round", (int)t.group_overlap, t.xcd_rows,
+		(unsigned long long)t.jitter_seed, t.jitter_us);
 	return LUW_OK;
 }
 int luw_dev_placement_info(const luw_solver* s, int* candidates_tried, double* probe_TBps, double* create_seconds, char* kept, uint64_t kept_size) {

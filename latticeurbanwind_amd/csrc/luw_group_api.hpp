@@ -169,7 +169,8 @@ int luw_group_create(const luw_config* cfg, const int* devices, luw_group** out)
 		group_boxes(g.get(), d);
 		// (LUW_GROUP_EXCHANGE=one_packed: not at all -- the pack kernel fetches the x faces and the insert kernel puts them: what first contact times the
 		// kernels' scattered 2-4-byte remote stores against, tools/first_contact_defaults.py)
-		if(g->H[0]&&!tuning().group_x_packed) { // the step kernels write the x faces themselves (luw_set_x_face_buffers): into the neighbours' receive buffers, or into the send buffers
+		// otherwise the step kernels write the x faces themselves (luw_set_x_face_buffers): into the neighbours' receive buffers, or into the send buffers
+		if(g->H[0]&&!tuning().group_x_packed) {
 			void* fp = group_x_direct(g.get(), i) ? g->dom[d.nbr[0][0]].recv[0][1] : d.send[0][0];
 			void* fm = group_x_direct(g.get(), i) ? g->dom[d.nbr[0][1]].recv[0][0] : d.send[0][1];
 			GROUP_TRY(luw_set_x_face_buffers(d.s, fp, fm));

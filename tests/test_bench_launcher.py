@@ -36,9 +36,16 @@ def test_self_launch_passes_the_exit_code_and_marks_the_ranks():
         return types.SimpleNamespace(returncode=seen["rc"])
     for rc, want in ((0, 0), (1, 1), (-9, 137)):
         seen["rc"] = rc
-        assert launch.self_launch("bench.py", ["--gpus", "4"], 4, environ={"LUW_BENCH_MASTER_PORT": "29777", "PATH": "x"}, run=run) == want
+        assert launch.self_launch("bench.py", ["--gpus", "4"], 4, environ={"LUW_BENCH_MASTER_PORT": "29777", "PATH": "x"}, run=run,
+            loaded=lambda: False) == want
     assert seen["cmd"][8:10] == ["--master-port", "29777"] and seen["cmd"][4:6] == ["--nproc-per-node", "4"]
     assert seen["env"][launch.LAUNCHED_MARK] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["PATH"] == "x"
+    # a process that has imported torch or the HIP binding must never take the branch (it may have initialised the GPU): refused, nothing started
+    import pytest
+    seen.clear()
+    with pytest.raises(RuntimeError):
+        launch.self_launch("bench.py", ["--gpus", "4"], 4, environ={}, run=run, loaded=lambda: True)
+    assert not seen
 
 
 def test_branch_is_reached_before_any_gpu_runtime_is_imported():
@@ -55,7 +62,8 @@ def test_branch_is_reached_before_any_gpu_runtime_is_imported():
 
 
 def test_plain_command_really_starts_ranks_here():
-    # no GPU in this container: the ranks come up under torch.distributed.run and say so (the launcher ends the second one when the first fails); the parent relays the failure as ITS exit code and
+    # no GPU in this container: the ranks come up under torch.distributed.run and say so (the launcher ends the second one when the first fails); the parent
+    # relays the failure as ITS exit code and
     # prints no line.  (Before: "--gpus 2 but WORLD_SIZE=1" from the parent itself, no rank ever started.)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", launch.LAUNCHED_MARK)}
     env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""

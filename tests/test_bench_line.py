@@ -178,9 +178,11 @@ def test_render_never_raises_and_clips_the_error_text():
 
 
 def test_reference_context_sits_beside_the_cpu_baseline():
-    # a reader of ONE record sees both baselines -- the CPU restatement timed by this run and the reference's own OpenCL kernels on an MI355X
+    # a reader of ONE record sees both baselines -- the CPU restatement timed by this run and the reference's own OpenCL kernels on an
+    # MI355X
     from benchmarks.common import REFERENCE_GPU_CONTEXT
     full = single_full(); full["reference_context"] = REFERENCE_GPU_CONTEXT
     d = json.loads(L.render(full, "gpurun_out/bench_secondary.json"))
-    assert d["cpu_baseline"]["reference_gpu_opencl_mlups"] == {"fp32_build": 15189, "shipped_fp16c_thermal_build": 15673} and d["cpu_baseline"]["kind"] == "port"
+    assert d["cpu_baseline"]["reference_gpu_opencl_mlups"] == {"fp32_build": 15189, "shipped_fp16c_thermal_build": 15673} and d["cpu_baseline"][
+        "kind"] == "port"
     assert "profiles/r05_reference_perf" in REFERENCE_GPU_CONTEXT["source"] and os.path.exists(os.path.join(ROOT, REFERENCE_GPU_CONTEXT["source"]))

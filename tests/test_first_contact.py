@@ -32,7 +32,8 @@ def test_first_failure_ends_the_script_with_the_stage_number(tmp_path, fail):
 def test_the_defaults_matrix_as_a_dry_run():
     """stage 2b's tool without a GPU: one all-defaults run and one run per alternative and round, for both workloads; RCCL never with host threads"""
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_contact_defaults.py"), "--dry-run", "--devices", "0,1,2,3,4,5,6,7"], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_contact_defaults.py"), "--dry-run", "--devices", "0,1,2,3,4,5,6,7"],
+        capture_output=True,
         text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     cmds = [l for l in r.stdout.splitlines() if l.startswith("[dry run] ") and "--child" in l]

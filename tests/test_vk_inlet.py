@@ -137,7 +137,8 @@ def test_values_computed_ahead_equal_values_computed_in_line(luw, tmp_path):
             shutil.copytree(os.path.join(GOLD, "refcases", "CaseV"), proj)
             deck = os.path.join(proj, "conf.luwpf")
             open(deck, "a").write("\n" + extra)
-            r = subprocess.run([driver, deck, "--ddf", "fp32"], capture_output=True, text=True, timeout=600, env=dict(os.environ, LUW_TEST_AIDS=("" if mode == "1" else "vk_inline")))
+            r = subprocess.run([driver, deck, "--ddf", "fp32"], capture_output=True, text=True, timeout=600,
+                env=dict(os.environ, LUW_TEST_AIDS=("" if mode == "1" else "vk_inline")))
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
             out[mode] = sorted(glob.glob(os.path.join(proj, "RESULTS", "vtk", "*.vtk")))
         assert len(out["1"]) >= 4 and [os.path.basename(p) for p in out["1"]] == [os.path.basename(p) for p in out["0"]]

@@ -107,11 +107,14 @@ def main():
         return child(args)
     os.makedirs(args.out, exist_ok=True)
     record = {"devices": args.devices[:n], "n_gpu": args.n_gpu, "owned_cells_per_domain": args.size, "steps": args.steps, "rounds": args.reps,
-        "rehearsal": rehearsal, "rule": "the default of a question is kept unless an alternative is more than %d %% faster in EVERY round; all alternatives must "
+        "rehearsal": rehearsal,
+            "rule": "the default of a question is kept unless an alternative is more than %d %% faster in EVERY round; all alternatives must "
             "give the same rho and u bit for bit" % int(KEEP_DEFAULT_UNLESS_FASTER_BY * 100), "workloads": {}}
     if rehearsal:
-        record["note"] = "REHEARSAL: all domains on one device -- every variant ran and agreed; the timings say nothing about a node and no recommendation is made"
-    base = [sys.executable, os.path.abspath(__file__), "--child", "--devices", ",".join(str(d) for d in args.devices), "--n-gpu", *map(str, args.n_gpu), "--size",
+        record[
+            "note"] = "REHEARSAL: all domains on one device -- every variant ran and agreed; the timings say nothing about a node and no recommendation is made"
+    base = [sys.executable, os.path.abspath(__file__), "--child", "--devices", ",".join(str(d) for d in args.devices), "--n-gpu", *map(str, args.n_gpu),
+        "--size",
         *map(str, args.size), "--steps", str(args.steps)]
     failed = False
     for wl, extra in (("configs[3] urban tile, FP32", []), ("configs[4] urban tile, FP16C + Coriolis", ["--fp16c"])):
@@ -128,7 +131,8 @@ def main():
                 if key not in seen:
                     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env), cwd=ROOT)
                     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                    seen[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+                    seen[key] = json.loads(lines[-1]) if r.returncode == 0 and lines else {
+                        "error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
                 if "error" in seen[key]:
                     runs.append({"question": q, "variant": label, "round": rnd, "error": seen[key]["error"]}); failed = True
                     print("%-13s %-44s FAILED: %s" % (q, label, seen[key]["error"][-200:]), flush=True)
@@ -147,7 +151,8 @@ def main():
         return 0
     with open(os.path.join(args.out, "defaults.json"), "w") as f:
         json.dump(record, f, indent=1); f.write("\n")
-    print("first_contact_defaults: %s -> %s" % ("FAILED" if failed else ("rehearsal complete" if rehearsal else "decided"), os.path.join(args.out, "defaults.json")))
+    print("first_contact_defaults: %s -> %s" % ("FAILED" if failed else ("rehearsal complete" if rehearsal else "decided"),
+        os.path.join(args.out, "defaults.json")))
     return 1 if failed else 0
 
 
