@@ -16,8 +16,10 @@ MAX_US = 300
 MODES = {"one_phase": {}, "sequential": {"LUW_GROUP_EXCHANGE": "sequential"},
     "one_phase_threads": {"LUW_GROUP_THREADS": "1"}, "sequential_threads": {"LUW_GROUP_EXCHANGE": "sequential", "LUW_GROUP_THREADS": "1"},
     # the one-round exchange through send buffers: copies behind the pack kernels / ONE grouped ncclSend / ncclRecv batch per step (round 6)
-    "one_phase_staged": {"LUW_GROUP_TRANSPORT": "staged"}, "one_phase_rccl": {"LUW_GROUP_TRANSPORT": "rccl"}}
-KNOBS = ("LUW_GROUP_EXCHANGE", "LUW_GROUP_THREADS", "LUW_GROUP_TRANSPORT")
+    "one_phase_staged": {"LUW_GROUP_TRANSPORT": "staged"}, "one_phase_rccl": {"LUW_GROUP_TRANSPORT": "rccl"},
+    # the alternatives first contact times against the defaults: x faces through the pack / insert kernels; the whole box as one launch, then the exchange
+    "one_phase_x_packed": {"LUW_GROUP_EXCHANGE": "one_packed"}, "whole_box_then_exchange": {"LUW_GROUP_OVERLAP": "0"}}
+KNOBS = ("LUW_GROUP_EXCHANGE", "LUW_GROUP_THREADS", "LUW_GROUP_TRANSPORT", "LUW_GROUP_OVERLAP")
 
 
 @pytest.fixture(params=list(MODES))
