@@ -124,6 +124,10 @@ def compact_multi(full):
     cfg = full.get("config", {})
     out["config"] = dict(pick(cfg, "global_lattice", "n_gpu", "cells_per_gpu", "bytes_per_lup", "kernel"), workload=clip(cfg.get("workload", ""), 260),
         halo_exchange=clip(cfg.get("halo_exchange", ""), 120))
+    if isinstance(cfg.get("schedule_probe"), dict):        # the start-up probe of the two step schedules: what was measured on the slowest rank, what was kept
+        sp = cfg["schedule_probe"]
+        out["config"]["schedule_probe"] = {"shell_first_ms": sp.get("shell_first_ms"), "whole_box_ms": sp.get("whole_box_ms"),
+            "kept": clip(sp.get("kept", ""), 48)}
     out["rccl"] = {"version": cfg.get("rccl_version"), "world_size": cfg.get("ranks_in_communicator")}
     roof = full.get("roofline", {})
     out["roofline"] = dict(pick(roof, "bound", "achieved", "peak", "unit", "frac", "kernel_ms", "whole_job_frac"), traffic=roof.get("traffic"))

@@ -10,6 +10,7 @@ import numpy as np
 from .common import BYTES_PER_LUP, HBM_PEAK_GBPS, NU, ROOT, coriolis_omega, device_context, fill_channel, tile_forcing
 # ======================================================================== N > 1
 PARITY_STEPS = 8                 # both time parities, eight exchanges per split axis
+PROBE_STEPS = 20                 # real steps per schedule of the start-up probe (DomainDecomposedLBM.choose_schedule)
 # zones thinner than a rank's 64-cell block: only face-owning domains feel them (FX/kernel.cpp:1537-1541,1598)
 PARITY_NUDGE_CELLS, PARITY_SPONGE_CELLS = 20, 24
 
@@ -223,6 +224,15 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             if args.coriolis:
                 sim.backend.set_coriolis(*coriolis_omega())
             sim.initialize()
+            # which of the two step schedules this node wants is a matter of its wire: a probe of real steps under each, decided by the
+            # slowest rank, before the warm-up (x-split cuts only: with x whole the shell is two thin layers and always goes first)
+            probe = None
+            if D[0] > 1 and os.environ.get("LUW_SCHEDULE_PROBE", "1") != "0":
+                def slowest(v):
+                    t = torch.tensor(v, dtype=torch.float64, device="cpu" if shared else "cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return t.tolist()
+                probe = sim.choose_schedule(steps=PROBE_STEPS, reduce_max=slowest)
             sim.run(args.warmup)
             dist.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -248,7 +258,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             mine.update(topology(sim.layout))
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "one_phase": bool(sim.one_phase),
+            return {"D": D, "gN": gN, "dt": float(tmax.item()), "per_rank": per_rank, "overlap": sim.overlap, "one_phase": bool(sim.one_phase), "probe": probe,
                 "block": (gN[0] // D[0], gN[1] // D[1], gN[2] // D[2])}
         finally:
             sim.backend.close()
@@ -282,7 +292,7 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
                        "halo_exchange": transport + (", overlapped with the interior" if res["overlap"] else " after the whole-box kernel")
                            + (", one batch per step (faces of all axes + the 12 edge populations)" if res.get("one_phase") else ", three phases x, y, z"),
                            "kernel": args.kernel, "bytes_per_lup": bpl,
-                       "rccl_version": rccl, "ranks_in_communicator": dist.get_world_size()},
+                       "rccl_version": rccl, "ranks_in_communicator": dist.get_world_size(), "schedule_probe": res.get("probe")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None, "traffic": None,
                          "kernel_ms": res["per_rank"][0]["kernel_ms"],

@@ -67,6 +67,46 @@ class DomainDecomposedLBM:
         self.initialized = False
         self.pre_step = None     # callable(stream) enqueued before every step's kernels (von-Karman inlet update)
 
+    def set_schedule(self, overlap):
+        """between two run() calls: boundary shell first + exchange beside the interior (True), or the whole box as ONE launch followed by the exchange
+        (False).  Same values either way; which is faster depends on what the exchange costs on the wire."""
+        ov = bool(overlap) and self.layout.can_overlap() and hasattr(self.backend, "comm")
+        if ov != self.overlap:
+            self._join()
+            self.overlap = ov
+            if hasattr(self.backend, "configure_step"):
+                self.backend.configure_step(ov)
+        return self.overlap
+
+    def choose_schedule(self, steps=20, reduce_max=None, margin=0.02):
+        """Start-up probe, like luw_create's placement probe: `steps` REAL steps of this run under each schedule (the state simply advances), wall time
+        of the slowest rank (reduce_max: a callable that takes [ms, ms] and returns the element-wise maximum over the ranks -- EVERY rank calls it exactly
+        once, whatever happened locally, so no rank waits for another's collective), and the default (shell first) is kept unless the whole-box schedule
+        is more than `margin` faster.  Returns what was measured and kept; None where there is nothing to choose."""
+        if not (self.layout.can_overlap() and hasattr(self.backend, "comm") and hasattr(self.backend, "configure_step")):
+            return None
+        import time
+        import torch
+        if not self.initialized:
+            self.initialize()
+        default, ms = self.overlap, {}
+        for ov in (True, False):
+            try:
+                self.set_schedule(ov); self.run(3); torch.cuda.synchronize()
+                t0 = time.perf_counter(); self.run(steps); torch.cuda.synchronize()
+                ms[ov] = (time.perf_counter() - t0) / steps * 1e3
+            except Exception:                                   # a schedule that cannot run here is never chosen
+                ms[ov] = float("inf")
+        vec = [ms[True], ms[False]]
+        if reduce_max is not None:
+            vec = [float(v) for v in reduce_max(vec)]
+        usable = all(v == v and v != float("inf") for v in vec)
+        pick = default if not usable else (False if vec[1] < vec[0] * (1.0 - margin) else True)
+        self.set_schedule(pick)
+        return {"shell_first_ms": vec[0], "whole_box_ms": vec[1], "kept": "shell first, exchange beside the interior" if self.overlap
+            else "whole box, then the exchange", "probe_steps": steps,
+                "rule": "the default (shell first) unless the whole box is more than %d %% faster on the slowest rank" % int(margin * 100)}
+
     @property
     def one_phase(self):
         return self.batch_wanted and hasattr(self.backend, "extract_edges") and hasattr(self.transport, "exchange_all")

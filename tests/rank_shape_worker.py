@@ -4,8 +4,9 @@ halo faces through the real RCCL transport -- a one-rank world whose every neigh
 bit with the CPU oracle stepping the SAME haloed domain (same decomposition parameters D, O; its own extract / swap / insert
 following FX/lbm.cpp:1907-1935).  Physically: the rank's block made periodic.  tests/ only (imports the oracle).
 
-usage: rank_shape_worker.py <f32|fp16c> <bx by bz> <Dx Dy Dz> <rank> <steps> [bld] [forcing] [cor] [peer]
-(peer: PeerLoopbackTransport instead of RCCL -- the faces are written where the unpack reads them)"""
+usage: rank_shape_worker.py <f32|fp16c> <bx by bz> <Dx Dy Dz> <rank> <steps> [bld] [forcing] [cor] [peer] [switch]
+(peer: PeerLoopbackTransport instead of RCCL -- the faces are written where the unpack reads them; switch: the run changes between the two step schedules,
+through DomainDecomposedLBM.choose_schedule and by hand)"""
 import os
 import sys
 
@@ -66,7 +67,18 @@ def main():
 
     sim.initialize()
     o.initialize(); o.t = 1; oracle_exchange(); o.t = 0      # FX/lbm.cpp:1242-1258
-    sim.run(steps)
+    if "switch" in opts:
+        # the start-up probe of bench.py --gpus N (choose_schedule: real steps under each schedule, the state simply advances), then both schedules once more
+        # by hand: every switch between "shell first" and "whole box" must leave the run on the oracle's values
+        pr = sim.choose_schedule(steps=2)
+        assert pr and pr["shell_first_ms"] > 0 and pr["whole_box_ms"] > 0 and pr["kept"], pr
+        assert sim.set_schedule(False) is False
+        sim.run(2)
+        assert sim.set_schedule(True) is True
+        sim.run(steps)
+        steps += 2 * (3 + 2) + 2
+    else:
+        sim.run(steps)
     for _ in range(steps):
         o.stream_collide(); oracle_exchange(); o.t += 1
     gu, grho = sim.fields()

@@ -42,6 +42,11 @@ def bench(world, *extra, env=None, tmp_path=None):
 def test_two_ranks_self_check_and_blocks(luw, tmp_path):
     out = bench(2, "--size", "384", "64", "64", tmp_path=tmp_path)
     assert out["n_gpus"] == 2 and out["config"]["n_gpu"] == [2, 1, 1] and out["value"] > 0
+    # the start-up probe of the two step schedules (x is split): both timed on the slowest rank, one kept, and the line says which
+    sp = out["config"]["schedule_probe"]
+    assert sp["shell_first_ms"] > 0 and sp["whole_box_ms"] > 0 and sp["probe_steps"] == 20 and sp["kept"] in ("shell first, exchange beside the interior",
+        "whole box, then the exchange")
+    assert ("overlapped with the interior" in out["config"]["halo_exchange"]) == sp["kept"].startswith("shell first")
     par = out["parity"]
     assert par["ok"] and len(par["cases"]) == 4                         # literal cut and x-whole cut, FP32 and FP16C + Coriolis
     for c in par["cases"]:

@@ -113,6 +113,10 @@ RANK_CASES = [
     ("f32", (384, 96, 64), (4, 2, 1), 3, ("bld", "forcing", "peer")),
     ("fp16c", (384, 96, 64), (4, 2, 1), 0, ("bld", "forcing", "cor", "peer")),
     ("fp16c", (640, 64, 64), (1, 4, 2), 5, ("bld", "forcing", "cor", "peer")),
+    # the start-up schedule probe of `bench.py --gpus N` and switches between the two step schedules in the middle of a run (round 6): RCCL self copies and
+    # faces written in place
+    ("f32", (384, 96, 64), (4, 2, 1), 0, ("bld", "forcing", "switch")),
+    ("fp16c", (384, 96, 64), (4, 2, 1), 5, ("bld", "forcing", "cor", "peer", "switch")),
 ]
 
 
