@@ -1,6 +1,7 @@
-"""A slice of the two exchange fuzzers in the GPU suite (the long runs are profiles/r04_fuzz_exchange.txt, profiles/r05_group_one_phase.txt and, over the three transports, profiles/r06_exchange_fuzz.txt): random
-lattices, cuts, formats, thermal lattice, solids on border columns and corner lines -- the one-round exchange against the three phases, bit for bit, for the
-one-process-per-GPU host (one rank, its own neighbour) and for the one-process host (up to eight domains on the one GPU, also against the CPU oracle)."""
+"""A slice of the two exchange fuzzers in the GPU suite (the long runs are profiles/r04_fuzz_exchange.txt, profiles/r05_group_one_phase.txt and, over the
+three transports, profiles/r06_exchange_fuzz.txt): random lattices, cuts, formats, thermal lattice, solids on border columns and corner lines -- the
+one-round exchange against the three phases, bit for bit, for the one-process-per-GPU host (one rank, its own neighbour) and for the one-process host (up
+to eight domains on the one GPU, peer / staged / rccl, also against the CPU oracle)."""
 import os
 import subprocess
 import sys
