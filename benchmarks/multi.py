@@ -224,13 +224,11 @@ def run_distributed(args, torch, luw, capi, kern, rank, world, local_rank, fp16c
             if args.coriolis:
                 sim.backend.set_coriolis(*coriolis_omega())
             sim.initialize()
-            # which of the two step schedules this node wants is a matter of its wire: a probe of real steps under each, decided by the
-            # slowest rank, before the warm-up (x-split cuts only: with x whole the shell is two thin layers and always goes first)
+            # which step schedule this node wants depends on its wire: real steps under each, the slowest rank decides (x-split cuts only)
             probe = None
             if D[0] > 1 and os.environ.get("LUW_SCHEDULE_PROBE", "1") != "0":
                 def slowest(v):
-                    t = torch.tensor(v, dtype=torch.float64, device="cpu" if shared else "cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    t = torch.tensor(v, dtype=torch.float64, device="cpu" if shared else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     return t.tolist()
                 probe = sim.choose_schedule(steps=PROBE_STEPS, reduce_max=slowest)
             sim.run(args.warmup)
