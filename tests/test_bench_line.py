@@ -76,7 +76,9 @@ def multi_full(world=8):
         "warmup": 20, "ms_per_step": 3.6012, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": LONG, "global_lattice": [2048, 1024, 512], "n_gpu": [4, 2, 1], "cells_per_gpu": 512 ** 3, "halo_exchange": LONG,
             "kernel": "auto",
-            "bytes_per_lup": 153.0, "rccl_version": "2.26.6", "ranks_in_communicator": world},
+            "bytes_per_lup": 153.0, "rccl_version": "2.26.6", "ranks_in_communicator": world,
+            "schedule_probe": {"shell_first_ms": 3.6123, "whole_box_ms": float("inf"), "kept": "shell first, exchange beside the interior", "probe_steps": 20,
+                "rule": LONG}},
         "roofline": dict(roof(), note=LONG), "parity": {"transport": LONG, "ok": True, "cases": [case] * 4}, "per_rank": ranks,
         "secondary": {"x_whole_n_gpu": {"value": 300000.1, "unit": "MLUPS", "ms_per_step": 3.5, "n_gpu": [1, 4, 2], "global_lattice": [2048, 1024, 512],
             "what": LONG, "halo_exchange": LONG, "roofline_frac_rank0_kernel": 0.74, "per_rank": ranks}, "group_host": gh}}
@@ -186,3 +188,10 @@ def test_reference_context_sits_beside_the_cpu_baseline():
     assert d["cpu_baseline"]["reference_gpu_opencl_mlups"] == {"fp32_build": 15189, "shipped_fp16c_thermal_build": 15673} and d["cpu_baseline"][
         "kind"] == "port"
     assert "profiles/r05_reference_perf" in REFERENCE_GPU_CONTEXT["source"] and os.path.exists(os.path.join(ROOT, REFERENCE_GPU_CONTEXT["source"]))
+
+
+def test_the_schedule_probe_is_on_the_multi_gpu_line():
+    # what the start-up probe measured and kept (an infinite time -- a schedule that could not run on some rank -- becomes null: strict JSON)
+    d = parse_strict(L.render(multi_full(8), "gpurun_out/bench_secondary.json"))
+    sp = d["config"]["schedule_probe"]
+    assert sp["shell_first_ms"] == 3.6123 and sp["whole_box_ms"] is None and sp["kept"].startswith("shell first") and "rule" not in sp
